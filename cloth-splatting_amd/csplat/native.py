@@ -1,0 +1,95 @@
+"""ctypes binding of libcsplat.so (C-ABI declared in include/csplat.h).  torch is used only for device
+memory and streams; no torch type crosses the ABI (data_ptr() integers and the raw hipStream_t do)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsplat.so")
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension has not been built.  Run `python __graft_entry__.py build` "
+        "(or cloth-splatting_amd/csrc/build.sh).  There is deliberately no fallback path.")
+
+lib = C.CDLL(LIB_PATH)
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+EXPORTS = {
+    "csplat_abi_version": (_i, []),
+    "csplat_last_error": (C.c_char_p, []),
+    "csplat_geom_bytes": (_sz, [_i]),
+    "csplat_image_bytes": (_sz, [_i, _i]),
+    "csplat_binning_bytes": (_sz, [_i64]),
+    "csplat_temp_bytes": (_sz, [_i, _i64]),
+    "csplat_geom_layout": (_i, [_i, C.POINTER(_sz)]),
+    "csplat_binning_layout": (_i, [_i64, C.POINTER(_sz)]),
+    "csplat_image_layout": (_i, [_i, _i, C.POINTER(_sz)]),
+    "csplat_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                            _i, ALLOC_FN, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp),
+                            C.POINTER(_vp)]),
+    "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
+    "csplat_gnn_csr_temp_bytes": (_sz, [_i, _i64]),
+    "csplat_gnn_build_csr": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp]),
+    "csplat_gnn_edge_combine_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "csplat_gnn_edge_combine_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_gnn_segment_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "csplat_gnn_gather_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+}
+for _name, (_res, _args) in EXPORTS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what include/csplat.h declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.csplat_abi_version() != ABI_VERSION:
+    raise ImportError(f"libcsplat.so ABI {lib.csplat_abi_version()} != expected {ABI_VERSION}; rebuild")
+
+
+class CsplatError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CsplatError(f"{what} failed (rc={rc}): {lib.csplat_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "csplat: non-contiguous tensor passed to the C-ABI"
+    return t.data_ptr()
+
+
+def stream_handle(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CsplatError("csplat: expected a GPU (HIP) tensor; this path has no CPU fallback")
+
+
+class ChunkAllocator:
+    """Answers csplat_alloc_fn with torch-owned byte buffers and keeps them alive."""
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks = {}
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, _ctx, chunk, nbytes):
+        try:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self.chunks[int(chunk)] = buf
+            return buf.data_ptr()
+        except Exception:  # never let an exception cross the C boundary
+            return None

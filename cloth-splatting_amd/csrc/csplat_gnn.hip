@@ -1,0 +1,184 @@
+// csplat_gnn.hip -- MeshNet message-passing data movement for gfx950.
+//
+// Replaces the torch_geometric MessagePassing machinery inside InteractionNetwork.propagate
+// (/root/reference/meshnet/graph_network.py:173-174 gather x_i/x_j, :197 concat, :136 aggr='add';
+// SURVEY.md 2.1 K10-K12).  The [E,3L] concat is never materialised: the first edge-MLP layer is split into
+// node-level products (xa = x W_i^T, xb = x W_j^T, done by rocBLAS on the Python side) and this file's
+// gather-add kernel; the scatter-add is a segmented sum over a CSR-by-destination ordering with a fixed
+// (ascending edge id) order, i.e. deterministic and without float atomics.  All kernels are HBM-bound row
+// movers: 16 B per lane, a row of L floats is read by L/4 consecutive lanes (full 128-B lines at L >= 32).
+#include "csplat_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_count(int64_t E, const int64_t *__restrict__ keys, uint32_t *__restrict__ cnt) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&cnt[keys[e]], 1u);
+}
+__global__ __launch_bounds__(256) void k_rowptr(int N, const uint32_t *__restrict__ incl, int32_t *__restrict__ rowptr) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) rowptr[0] = 0;
+    if (n < N) rowptr[n + 1] = (int32_t)incl[n];
+}
+__global__ __launch_bounds__(256) void k_fill(int64_t E, const int64_t *__restrict__ keys, const int32_t *__restrict__ rowptr,
+                                               uint32_t *__restrict__ cursor, int32_t *__restrict__ perm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const int64_t k = keys[e];
+        const uint32_t slot = atomicAdd(&cursor[k], 1u);
+        perm[rowptr[k] + slot] = (int32_t)e;
+    }
+}
+// each row is put into ascending edge-id order (rows are short: mesh degree), making the summation order fixed
+__global__ __launch_bounds__(256) void k_sort_rows(int N, const int32_t *__restrict__ rowptr, int32_t *__restrict__ perm) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int s = rowptr[n], e = rowptr[n + 1];
+    for (int i = s + 1; i < e; i++) {
+        const int32_t v = perm[i];
+        int j = i - 1;
+        while (j >= s && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+        perm[j + 1] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_edge_combine_fwd(int64_t E, int L4, const int64_t *__restrict__ ei,
+                                                           const float4 *__restrict__ xa, const float4 *__restrict__ xb,
+                                                           const float4 *__restrict__ ec, int relu, float4 *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * L4) return;
+    const int64_t e = t / L4;
+    const int c = (int)(t - e * L4);
+    const int64_t src = ei[e], dst = ei[E + e];
+    const float4 a = xa[dst * L4 + c], b = xb[src * L4 + c], v = ec[t];
+    float4 r = make_float4(a.x + b.x + v.x, a.y + b.y + v.y, a.z + b.z + v.z, a.w + b.w + v.w);
+    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    out[t] = r;
+}
+
+__global__ __launch_bounds__(256) void k_relu_mask(int64_t n4, const float4 *__restrict__ g, const float4 *__restrict__ out,
+                                                    float4 *__restrict__ gm) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const float4 a = g[t], o = out[t];
+    gm[t] = make_float4(o.x > 0.f ? a.x : 0.f, o.y > 0.f ? a.y : 0.f, o.z > 0.f ? a.z : 0.f, o.w > 0.f ? a.w : 0.f);
+}
+
+// agg[n][c] = sum over the row's edges, ascending edge id, plain sequential fp32 adds (== index_add_ on the CPU)
+__global__ __launch_bounds__(256) void k_segment_sum(int N, int L4, const float4 *__restrict__ msg,
+                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
+                                                      float4 *__restrict__ agg) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * L4) return;
+    const int n = (int)(t / L4), c = (int)(t - (int64_t)n * L4);
+    const int s = rowptr[n], e = rowptr[n + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = s;
+    for (; i + 4 <= e; i += 4) {  // 4 independent row loads in flight per lane
+        const int p0 = perm[i], p1 = perm[i + 1], p2 = perm[i + 2], p3 = perm[i + 3];
+        const float4 v0 = msg[(int64_t)p0 * L4 + c], v1 = msg[(int64_t)p1 * L4 + c], v2 = msg[(int64_t)p2 * L4 + c],
+                     v3 = msg[(int64_t)p3 * L4 + c];
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; i < e; i++) {
+        const float4 v = msg[(int64_t)perm[i] * L4 + c];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    agg[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(int64_t E, int L4, const float4 *__restrict__ rows,
+                                                      const int64_t *__restrict__ keys, float4 *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * L4) return;
+    const int64_t e = t / L4;
+    const int c = (int)(t - e * L4);
+    out[t] = rows[keys[e] * L4 + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t csplat_gnn_csr_temp_bytes(int N, int64_t E) {
+    (void)E;
+    return 2 * align256((size_t)(N + 1) * 4) + csplat_scan_temp_bytes(N);
+}
+
+int csplat_gnn_build_csr(void *stream, int N, int64_t E, const int64_t *keys, int32_t *rowptr, int32_t *perm, void *temp) {
+    hipStream_t s = (hipStream_t)stream;
+    CSPLAT_REQUIRE(N > 0 && E >= 0 && E < (int64_t)1 << 31, "csplat_gnn_build_csr: bad sizes");
+    uint32_t *cnt = (uint32_t *)temp;
+    uint32_t *incl = (uint32_t *)((char *)temp + align256((size_t)(N + 1) * 4));
+    void *scan_tmp = (char *)temp + 2 * align256((size_t)(N + 1) * 4);
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)N * 4, s));
+    if (E > 0) { k_count<<<cdiv(E, 256), 256, 0, s>>>(E, keys, cnt); LAUNCH_CHECK(); }
+    if (int rc = csplat_inclusive_scan_u32(s, cnt, incl, N, scan_tmp)) return rc;
+    k_rowptr<<<cdiv(N, 256), 256, 0, s>>>(N, incl, rowptr);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)N * 4, s));
+    if (E > 0) {
+        k_fill<<<cdiv(E, 256), 256, 0, s>>>(E, keys, rowptr, cnt, perm);
+        LAUNCH_CHECK();
+        k_sort_rows<<<cdiv(N, 256), 256, 0, s>>>(N, rowptr, perm);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int csplat_gnn_edge_combine_fwd(void *stream, int N, int64_t E, int L, const int64_t *edge_index, const float *xa,
+                                const float *xb, const float *ec, int relu, float *out) {
+    (void)N;
+    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    if (E == 0) return 0;
+    const int L4 = L / 4;
+    k_edge_combine_fwd<<<cdiv(E * L4, 256), 256, 0, (hipStream_t)stream>>>(E, L4, edge_index, (const float4 *)xa,
+                                                                           (const float4 *)xb, (const float4 *)ec, relu,
+                                                                           (float4 *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *msg, const int32_t *rowptr,
+                           const int32_t *perm, float *agg) {
+    (void)E;
+    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    if (N == 0) return 0;
+    const int L4 = L / 4;
+    k_segment_sum<<<cdiv((int64_t)N * L4, 256), 256, 0, (hipStream_t)stream>>>(N, L4, (const float4 *)msg, rowptr, perm,
+                                                                               (float4 *)agg);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_gnn_edge_combine_bwd(void *stream, int N, int64_t E, int L, const float *g, const float *out, int relu,
+                                const int32_t *rowptr_dst, const int32_t *perm_dst, const int32_t *rowptr_src,
+                                const int32_t *perm_src, float *g_masked, float *dxa, float *dxb) {
+    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    hipStream_t s = (hipStream_t)stream;
+    const float *gm = g;
+    if (relu) {
+        if (E > 0) {
+            k_relu_mask<<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E * (L / 4), (const float4 *)g, (const float4 *)out,
+                                                               (float4 *)g_masked);
+            LAUNCH_CHECK();
+        }
+        gm = g_masked;
+    }
+    if (int rc = csplat_gnn_segment_sum(stream, N, E, L, gm, rowptr_dst, perm_dst, dxa)) return rc;
+    return csplat_gnn_segment_sum(stream, N, E, L, gm, rowptr_src, perm_src, dxb);
+}
+
+int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out) {
+    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    if (E == 0) return 0;
+    const int L4 = L / 4;
+    k_gather_rows<<<cdiv(E * L4, 256), 256, 0, (hipStream_t)stream>>>(E, L4, (const float4 *)rows, keys, (float4 *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,855 @@
+// csplat_raster.hip -- the depth-aware differentiable Gaussian rasterizer for gfx950 (MI355X).
+//
+// Replaces the CUDA extension behind GaussianRasterizer.forward / backward
+// (/root/reference/gaussian_renderer/__init__.py:16,76,156-164; backward via
+// scene_reconstruction/train_utils.py:288).  Kernel inventory = SURVEY.md 2.1 K1..K8:
+//   K1 k_preprocess        per-Gaussian cull / projection / cov3D / cov2D / conic / radius / rect / SH->RGB
+//   K2 (csplat_sort.hip)   inclusive scan of tiles_touched
+//   K3 k_emit_keys         (tile<<32 | depth bits, id) per touched tile
+//   K4 (csplat_sort.hip)   stable radix sort
+//   K5 k_tile_ranges       [first,last) per tile
+//   K6 k_render_fwd        front-to-back compositing of RGB + depth, 16x16 tile per workgroup
+//   K7 k_render_bwd        back-to-front replay, wavefront (64-lane) DPP reduction, one atomic set per wave
+//   K8 k_preprocess_bwd    conic->cov2D->cov3D/mean, mean2D(NDC)->mean3D, colour->SH, cov3D->(scale,quat)
+//
+// Index-deciding arithmetic (radius, tile rectangle, sort key) is compiled with FP contraction OFF and is
+// written in the same association order as oracle/raster_ref.c, so tile/bin indices are bit-exact.
+#include "csplat_common.h"
+
+namespace {
+
+constexpr float NEAR_Z = 0.2f;
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Geom {
+    float *depth;           // [P]
+    float2 *xy;             // [P]
+    float4 *conic_opacity;  // [P]
+    float *rgb;             // [P][3]
+    float *cov3D;           // [P][6]
+    uint32_t *clamped;      // [P] bit c
+    uint32_t *tiles_touched;// [P]
+    uint32_t *offsets;      // [P] inclusive scan
+    void *scan_tmp;
+};
+
+struct Cam {
+    const float *view;    // device, 16 floats (transposed world->view)
+    const float *proj;    // device, 16 floats (transposed full projection)
+    const float *campos;  // device, 3 floats
+    float tanfovx, tanfovy, fx, fy;
+    int W, H, gx, gy;
+};
+
+struct ProjJac {
+    float t0[3], t1[3];
+    float tx, ty, tz;
+    bool x_in, y_in;
+};
+
+__device__ __forceinline__ void quat_to_rot(const float *q, float R[3][3]) {
+#pragma clang fp contract(off)
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y - r * z);
+    R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y);
+    R[2][1] = 2.f * (y * z + r * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float *scale, float mod, const float *q, float *c6) {
+#pragma clang fp contract(off)
+    float R[3][3], m[3][3];
+    quat_to_rot(q, R);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float s = mod * scale[k];
+#pragma unroll
+        for (int i = 0; i < 3; i++) m[k][i] = s * R[i][k];
+    }
+    c6[0] = m[0][0] * m[0][0] + m[1][0] * m[1][0] + m[2][0] * m[2][0];
+    c6[1] = m[0][0] * m[0][1] + m[1][0] * m[1][1] + m[2][0] * m[2][1];
+    c6[2] = m[0][0] * m[0][2] + m[1][0] * m[1][2] + m[2][0] * m[2][2];
+    c6[3] = m[0][1] * m[0][1] + m[1][1] * m[1][1] + m[2][1] * m[2][1];
+    c6[4] = m[0][1] * m[0][2] + m[1][1] * m[1][2] + m[2][1] * m[2][2];
+    c6[5] = m[0][2] * m[0][2] + m[1][2] * m[1][2] + m[2][2] * m[2][2];
+}
+
+__device__ __forceinline__ void view_point(const float *p, const float *V, float *o) {
+#pragma clang fp contract(off)
+    o[0] = V[0] * p[0] + V[4] * p[1] + V[8] * p[2] + V[12];
+    o[1] = V[1] * p[0] + V[5] * p[1] + V[9] * p[2] + V[13];
+    o[2] = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+}
+
+__device__ __forceinline__ void proj_jacobian(const float *pv, const Cam &c, ProjJac &o) {
+#pragma clang fp contract(off)
+    const float limx = 1.3f * c.tanfovx, limy = 1.3f * c.tanfovy;
+    const float tz = pv[2];
+    const float txtz = pv[0] / tz, tytz = pv[1] / tz;
+    o.x_in = !(txtz < -limx || txtz > limx);
+    o.y_in = !(tytz < -limy || tytz > limy);
+    const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const float J00 = c.fx / tz, J02 = -(c.fx * tx) / (tz * tz);
+    const float J11 = c.fy / tz, J12 = -(c.fy * ty) / (tz * tz);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o.t0[a] = c.view[4 * a + 0] * J00 + c.view[4 * a + 2] * J02;
+        o.t1[a] = c.view[4 * a + 1] * J11 + c.view[4 * a + 2] * J12;
+    }
+    o.tx = tx; o.ty = ty; o.tz = tz;
+}
+
+__device__ __forceinline__ void cov2d_from_cov3d(const float *c6, const ProjJac &pj, float &a, float &b, float &c) {
+#pragma clang fp contract(off)
+    const float *t0 = pj.t0, *t1 = pj.t1;
+    const float Vm[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float u0[3], u1[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        u0[j] = t0[0] * Vm[0][j] + t0[1] * Vm[1][j] + t0[2] * Vm[2][j];
+        u1[j] = t1[0] * Vm[0][j] + t1[1] * Vm[1][j] + t1[2] * Vm[2][j];
+    }
+    a = (u0[0] * t0[0] + u0[1] * t0[1] + u0[2] * t0[2]) + 0.3f;
+    b = u0[0] * t1[0] + u0[1] * t1[1] + u0[2] * t1[2];
+    c = (u1[0] * t1[0] + u1[1] * t1[1] + u1[2] * t1[2]) + 0.3f;
+}
+
+__device__ __forceinline__ void tile_rect(float px, float py, int rad, const Cam &c, int &minx, int &miny, int &maxx,
+                                          int &maxy) {
+#pragma clang fp contract(off)
+    minx = min(c.gx, max(0, (int)((px - (float)rad) / (float)CSPLAT_TILE)));
+    miny = min(c.gy, max(0, (int)((py - (float)rad) / (float)CSPLAT_TILE)));
+    maxx = min(c.gx, max(0, (int)((px + (float)rad + (float)(CSPLAT_TILE - 1)) / (float)CSPLAT_TILE)));
+    maxy = min(c.gy, max(0, (int)((py + (float)rad + (float)(CSPLAT_TILE - 1)) / (float)CSPLAT_TILE)));
+}
+
+// ------------------------------------------------------------------------------------------- K1
+__global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const float *__restrict__ means3D,
+                                                     const float *__restrict__ shs,
+                                                     const float *__restrict__ colors_precomp,
+                                                     const float *__restrict__ opacities,
+                                                     const float *__restrict__ scales, float scale_mod,
+                                                     const float *__restrict__ rotations,
+                                                     const float *__restrict__ cov3D_precomp, Cam cam, Geom g,
+                                                     int32_t *__restrict__ radii) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float depth = 0.f, px = 0.f, py = 0.f;
+    float4 co = {0.f, 0.f, 0.f, 0.f};
+    float rgb[3] = {0.f, 0.f, 0.f};
+    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t clampbits = 0, touched = 0;
+    int rad = 0;
+
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float pv[3];
+    view_point(p, cam.view, pv);
+    do {
+        if (pv[2] <= NEAR_Z) break;
+        const float *pr = cam.proj;
+        const float hx = pr[0] * p[0] + pr[4] * p[1] + pr[8] * p[2] + pr[12];
+        const float hy = pr[1] * p[0] + pr[5] * p[1] + pr[9] * p[2] + pr[13];
+        const float hw = pr[3] * p[0] + pr[7] * p[1] + pr[11] * p[2] + pr[15];
+        const float pw = 1.0f / (hw + 0.0000001f);
+        const float ndcx = hx * pw, ndcy = hy * pw;
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * i + k];
+        } else {
+            const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+            const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+            cov3d_from_scale_rot(s, scale_mod, q, c6);
+        }
+        ProjJac pj;
+        proj_jacobian(pv, cam, pj);
+        float a, b, c;
+        cov2d_from_cov3d(c6, pj, a, b, c);
+        const float det = a * c - b * b;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float mid = 0.5f * (a + c);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lam1 = mid + sq, lam2 = mid - sq;
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+        const float ix = ((ndcx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+        const float iy = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+        const int r = (int)my_radius;
+        int minx, miny, maxx, maxy;
+        tile_rect(ix, iy, r, cam, minx, miny, maxx, maxy);
+        if ((maxx - minx) * (maxy - miny) == 0) break;
+
+        if (colors_precomp) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) rgb[k] = colors_precomp[3 * i + k];
+        } else {
+            const float *sh = shs + (size_t)i * M * 3;
+            const float d0 = p[0] - cam.campos[0], d1 = p[1] - cam.campos[1], d2 = p[2] - cam.campos[2];
+            const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            const float x = d0 / len, y = d1 / len, z = d2 / len;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+#define S(k) sh[(k) * 3 + ch]
+                float res = SH_C0 * S(0);
+                if (D > 0) {
+                    res = res - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
+                    if (D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        res = res + SH_C2[0] * xy * S(4) + SH_C2[1] * yz * S(5) + SH_C2[2] * (2.f * zz - xx - yy) * S(6) +
+                              SH_C2[3] * xz * S(7) + SH_C2[4] * (xx - yy) * S(8);
+                        if (D > 2) {
+                            res = res + SH_C3[0] * y * (3.f * xx - yy) * S(9) + SH_C3[1] * xy * z * S(10) +
+                                  SH_C3[2] * y * (4.f * zz - xx - yy) * S(11) +
+                                  SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * S(12) +
+                                  SH_C3[4] * x * (4.f * zz - xx - yy) * S(13) + SH_C3[5] * z * (xx - yy) * S(14) +
+                                  SH_C3[6] * x * (xx - 3.f * yy) * S(15);
+                        }
+                    }
+                }
+#undef S
+                res += 0.5f;
+                if (res < 0.f) clampbits |= (1u << ch);
+                rgb[ch] = fmaxf(res, 0.f);
+            }
+        }
+        depth = pv[2];
+        rad = r;
+        px = ix; py = iy;
+        co = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
+        touched = (uint32_t)((maxy - miny) * (maxx - minx));
+    } while (0);
+
+    g.depth[i] = depth;
+    radii[i] = rad;
+    g.xy[i] = make_float2(px, py);
+    g.conic_opacity[i] = co;
+#pragma unroll
+    for (int k = 0; k < 3; k++) g.rgb[3 * i + k] = rgb[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) g.cov3D[6 * i + k] = c6[k];
+    g.clamped[i] = clampbits;
+    g.tiles_touched[i] = touched;
+}
+
+// ------------------------------------------------------------------------------------------- K3
+__global__ __launch_bounds__(256) void k_emit_keys(int P, const float2 *__restrict__ xy, const float *__restrict__ depth,
+                                                    const uint32_t *__restrict__ offsets,
+                                                    const int32_t *__restrict__ radii, Cam cam,
+                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int rad = radii[i];
+    if (rad <= 0) return;
+    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+    const float2 p = xy[i];
+    int minx, miny, maxx, maxy;
+    tile_rect(p.x, p.y, rad, cam, minx, miny, maxx, maxy);
+    const uint32_t dbits = __float_as_uint(depth[i]);
+    for (int y = miny; y < maxy; y++)
+        for (int x = minx; x < maxx; x++) {
+            keys[off] = ((uint64_t)(uint32_t)(y * cam.gx + x) << 32) | dbits;
+            ids[off] = (uint32_t)i;
+            off++;
+        }
+}
+
+// ------------------------------------------------------------------------------------------- K5
+__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint64_t *__restrict__ keys, int2 *__restrict__ ranges) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        if (tp != t) { ranges[tp].y = (int)i; ranges[t].x = (int)i; }
+    }
+    if (i == R - 1) ranges[t].y = (int)R;
+}
+
+// pixel owned by a thread: each 64-lane wavefront covers one 8x8 quadrant of the 16x16 tile, which keeps the
+// lanes of a wave spatially compact (coherent early termination, more all-lane skips in the backward).
+__device__ __forceinline__ void thread_pixel(int tile, int gx, int &px, int &py) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    px = (tile % gx) * CSPLAT_TILE + ((w & 1) << 3) + (l & 7);
+    py = (tile / gx) * CSPLAT_TILE + ((w >> 1) << 3) + (l >> 3);
+}
+
+// ------------------------------------------------------------------------------------------- K6
+__global__ __launch_bounds__(256) void k_render_fwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                                                     int W, int H, int gx, const float2 *__restrict__ xy,
+                                                     const float *__restrict__ rgb, const float *__restrict__ depth,
+                                                     const float4 *__restrict__ conic_opacity,
+                                                     const float *__restrict__ bg, float *__restrict__ final_T,
+                                                     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
+                                                     float *__restrict__ out_depth) {
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_cd[256];  // rgb + depth
+    const int tile = blockIdx.x;
+    int px, py;
+    thread_pixel(tile, gx, px, py);
+    const bool inside = px < W && py < H;
+    const int pix = py * W + px;
+    const float fx = (float)px, fy = (float)py;
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    const int rounds = (n + 255) / 256;
+    bool done = !inside;
+    int toDo = n;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t contributor = 0, last = 0;
+    for (int r = 0; r < rounds; r++, toDo -= 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const int prog = r * 256 + threadIdx.x;
+        if (prog < n) {
+            const uint32_t id = point_list[range.x + prog];
+            s_xy[threadIdx.x] = xy[id];
+            s_co[threadIdx.x] = conic_opacity[id];
+            s_cd[threadIdx.x] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], depth[id]);
+        }
+        __syncthreads();
+        const int m = toDo < 256 ? toDo : 256;
+        for (int j = 0; !done && j < m; j++) {
+            contributor++;
+            const float2 p = s_xy[j];
+            const float dx = p.x - fx, dy = p.y - fy;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.f) continue;
+            const float alpha = fminf(0.99f, co.w * __expf(power));
+            if (alpha < 1.f / 255.f) continue;
+            const float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float4 cd = s_cd[j];
+            const float wgt = alpha * T;
+            C0 += cd.x * wgt; C1 += cd.y * wgt; C2 += cd.z * wgt; Dp += cd.w * wgt;
+            T = test_T;
+            last = contributor;
+        }
+    }
+    if (inside) {
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        const size_t HW = (size_t)H * W;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = Dp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K7
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RMASK, 0xF, false));
+}
+// sum over the 64 lanes of the wavefront; the total is valid in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2,3
+    return v;
+}
+
+// per-Gaussian accumulation record written by K7 and consumed by K8 (one 48-byte line segment per Gaussian):
+//   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..11 pad
+constexpr int ACC_STRIDE = 12;
+
+__global__ __launch_bounds__(256) void k_render_bwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                                                     int W, int H, int gx, const float *__restrict__ bg,
+                                                     const float2 *__restrict__ xy,
+                                                     const float4 *__restrict__ conic_opacity,
+                                                     const float *__restrict__ rgb, const float *__restrict__ final_T,
+                                                     const uint32_t *__restrict__ n_contrib,
+                                                     const float *__restrict__ dL_dpix, float *__restrict__ acc) {
+    __shared__ uint32_t s_id[256];
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_c[256];
+    const int tile = blockIdx.x;
+    int px, py;
+    thread_pixel(tile, gx, px, py);
+    const bool inside = px < W && py < H;
+    const int pix = py * W + px;
+    const float fx = (float)px, fy = (float)py;
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    if (n <= 0) return;
+    const int rounds = (n + 255) / 256;
+    const int lane = threadIdx.x & 63;
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    // the workgroup only needs to replay from the deepest contributor of any of its pixels
+    float accr0 = 0.f, accr1 = 0.f, accr2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    const size_t HW = (size_t)H * W;
+    const float dp0 = inside ? dL_dpix[pix] : 0.f, dp1 = inside ? dL_dpix[HW + pix] : 0.f,
+                dp2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    int contributor = n;
+    int toDo = n;
+    for (int r = 0; r < rounds; r++, toDo -= 256) {
+        __syncthreads();
+        const int prog = r * 256 + threadIdx.x;
+        if (prog < n) {
+            const uint32_t id = point_list[range.y - prog - 1];
+            s_id[threadIdx.x] = id;
+            s_xy[threadIdx.x] = xy[id];
+            s_co[threadIdx.x] = conic_opacity[id];
+            s_c[threadIdx.x] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
+        }
+        __syncthreads();
+        const int m = toDo < 256 ? toDo : 256;
+        for (int j = 0; j < m; j++) {
+            contributor--;
+            bool act = contributor < last_contributor;
+            const float2 p = s_xy[j];
+            const float dx = p.x - fx, dy = p.y - fy;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            act = act && !(power > 0.f);
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, co.w * G);
+            act = act && !(alpha < 1.f / 255.f);
+            if (__ballot(act) == 0ull) continue;  // wave-uniform: nothing to do for these 64 pixels
+
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+            if (act) {
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                const float4 c = s_c[j];
+                accr0 = last_alpha * lc0 + (1.f - last_alpha) * accr0;
+                accr1 = last_alpha * lc1 + (1.f - last_alpha) * accr1;
+                accr2 = last_alpha * lc2 + (1.f - last_alpha) * accr2;
+                lc0 = c.x; lc1 = c.y; lc2 = c.z;
+                float dL_dalpha = (c.x - accr0) * dp0 + (c.y - accr1) * dp1 + (c.z - accr2) * dp2;
+                v6 = dchannel_dcolor * dp0; v7 = dchannel_dcolor * dp1; v8 = dchannel_dcolor * dp2;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                v0 = dL_dG * dG_ddelx * ddelx_dx;
+                v1 = dL_dG * dG_ddely * ddely_dy;
+                v2 = -0.5f * gdx * dx * dL_dG;
+                v3 = -0.5f * gdx * dy * dL_dG;
+                v4 = -0.5f * gdy * dy * dL_dG;
+                v5 = G * dL_dalpha;
+            }
+            v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
+            v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
+            v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
+            if (lane == 63) {
+                float *a = acc + (size_t)s_id[j] * ACC_STRIDE;
+                atomicAdd(a + 0, v0); atomicAdd(a + 1, v1); atomicAdd(a + 2, v2); atomicAdd(a + 3, v3);
+                atomicAdd(a + 4, v4); atomicAdd(a + 5, v5); atomicAdd(a + 6, v6); atomicAdd(a + 7, v7);
+                atomicAdd(a + 8, v8);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K8
+__global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, const float *__restrict__ means3D,
+                                                         const float *__restrict__ shs, const float *__restrict__ scales,
+                                                         float scale_mod, const float *__restrict__ rotations,
+                                                         int use_precomp_cov, Cam cam, Geom g,
+                                                         const int32_t *__restrict__ radii, const float *__restrict__ acc,
+                                                         float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic,
+                                                         float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolor,
+                                                         float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D,
+                                                         float *__restrict__ dL_dsh, float *__restrict__ dL_dscale,
+                                                         float *__restrict__ dL_drot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool vis = radii[i] > 0;
+    float a9[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
+    dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
+    dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
+    dL_dopacity[i] = a9[5];
+    dL_dcolor[3 * i] = a9[6]; dL_dcolor[3 * i + 1] = a9[7]; dL_dcolor[3 * i + 2] = a9[8];
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!vis) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
+        if (dL_dsh) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
+        if (dL_dscale) { dL_dscale[3 * i] = 0.f; dL_dscale[3 * i + 1] = 0.f; dL_dscale[3 * i + 2] = 0.f; }
+        if (dL_drot) { dL_drot[4 * i] = 0.f; dL_drot[4 * i + 1] = 0.f; dL_drot[4 * i + 2] = 0.f; dL_drot[4 * i + 3] = 0.f; }
+        return;
+    }
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    const float *view = cam.view, *proj = cam.proj;
+
+    // ---- conic -> cov2D -> cov3D and view-space mean
+    {
+        float pv[3];
+        view_point(p, view, pv);
+        ProjJac pj;
+        proj_jacobian(pv, cam, pj);
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = g.cov3D[6 * i + k];
+        float a, b, c;
+        cov2d_from_cov3d(c6, pj, a, b, c);
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        const float gcx = a9[2], gcy = a9[3], gcz = a9[4];
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float *t0 = pj.t0, *t1 = pj.t1;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * gcx + 2.f * b * c * gcy + (denom - a * c) * gcz);
+            dL_dc = denom2inv * (-a * a * gcz + 2.f * a * b * gcy + (denom - a * c) * gcx);
+            dL_db = denom2inv * 2.f * (b * c * gcx - (denom + 2.f * b * b) * gcy + a * b * gcz);
+            g6[0] = t0[0] * t0[0] * dL_da + t0[0] * t1[0] * dL_db + t1[0] * t1[0] * dL_dc;
+            g6[3] = t0[1] * t0[1] * dL_da + t0[1] * t1[1] * dL_db + t1[1] * t1[1] * dL_dc;
+            g6[5] = t0[2] * t0[2] * dL_da + t0[2] * t1[2] * dL_db + t1[2] * t1[2] * dL_dc;
+            g6[1] = 2.f * t0[0] * t0[1] * dL_da + (t0[0] * t1[1] + t0[1] * t1[0]) * dL_db + 2.f * t1[0] * t1[1] * dL_dc;
+            g6[2] = 2.f * t0[0] * t0[2] * dL_da + (t0[0] * t1[2] + t0[2] * t1[0]) * dL_db + 2.f * t1[0] * t1[2] * dL_dc;
+            g6[4] = 2.f * t0[2] * t0[1] * dL_da + (t0[1] * t1[2] + t0[2] * t1[1]) * dL_db + 2.f * t1[1] * t1[2] * dL_dc;
+        }
+        const float Vm[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float Vt0 = Vm[r][0] * t0[0] + Vm[r][1] * t0[1] + Vm[r][2] * t0[2];
+            const float Vt1 = Vm[r][0] * t1[0] + Vm[r][1] * t1[1] + Vm[r][2] * t1[2];
+            dT0[r] = 2.f * Vt0 * dL_da + Vt1 * dL_db;
+            dT1[r] = 2.f * Vt1 * dL_dc + Vt0 * dL_db;
+        }
+        const float dJ00 = view[0] * dT0[0] + view[4] * dT0[1] + view[8] * dT0[2];
+        const float dJ02 = view[2] * dT0[0] + view[6] * dT0[1] + view[10] * dT0[2];
+        const float dJ11 = view[1] * dT1[0] + view[5] * dT1[1] + view[9] * dT1[2];
+        const float dJ12 = view[2] * dT1[0] + view[6] * dT1[1] + view[10] * dT1[2];
+        const float tz = 1.f / pj.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float xg = pj.x_in ? 1.f : 0.f, yg = pj.y_in ? 1.f : 0.f;
+        const float dtx = xg * -cam.fx * tz2 * dJ02;
+        const float dty = yg * -cam.fy * tz2 * dJ12;
+        const float dtz = -cam.fx * tz2 * dJ00 - cam.fy * tz2 * dJ11 + (2.f * cam.fx * pj.tx) * tz3 * dJ02 +
+                          (2.f * cam.fy * pj.ty) * tz3 * dJ12;
+        dmean[0] += view[0] * dtx + view[1] * dty + view[2] * dtz;
+        dmean[1] += view[4] * dtx + view[5] * dty + view[6] * dtz;
+        dmean[2] += view[8] * dtx + view[9] * dty + view[10] * dtz;
+    }
+    // ---- mean2D (NDC) -> mean3D
+    {
+        const float hw = proj[3] * p[0] + proj[7] * p[1] + proj[11] * p[2] + proj[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (proj[0] * p[0] + proj[4] * p[1] + proj[8] * p[2] + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * p[0] + proj[5] * p[1] + proj[9] * p[2] + proj[13]) * m_w * m_w;
+        const float gx2 = a9[0], gy2 = a9[1];
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gx2 + (proj[1] * m_w - proj[3] * mul2) * gy2;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
+    }
+    // ---- colour -> SH (+ view direction -> mean3D)
+    if (shs && dL_dsh) {
+        const float *sh = shs + (size_t)i * M * 3;
+        float *gsh = dL_dsh + (size_t)i * M * 3;
+        const uint32_t cl = g.clamped[i];
+        const float vx = p[0] - cam.campos[0], vy = p[1] - cam.campos[1], vz = p[2] - cam.campos[2];
+        const float sum2 = vx * vx + vy * vy + vz * vz;
+        const float len = sqrtf(sum2);
+        const float x = vx / len, y = vy / len, z = vz / len;
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        for (int k = (D + 1) * (D + 1) * 3; k < M * 3; k++) gsh[k] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float dRGB = ((cl >> ch) & 1u) ? 0.f : a9[6 + ch];
+            float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;
+#define S(k) sh[(k) * 3 + ch]
+#define GS(k) gsh[(k) * 3 + ch]
+            GS(0) = SH_C0 * dRGB;
+            if (D > 0) {
+                GS(1) = -SH_C1 * y * dRGB;
+                GS(2) = SH_C1 * z * dRGB;
+                GS(3) = -SH_C1 * x * dRGB;
+                dx_ = -SH_C1 * S(3); dy_ = -SH_C1 * S(1); dz_ = SH_C1 * S(2);
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    GS(4) = SH_C2[0] * xy * dRGB;
+                    GS(5) = SH_C2[1] * yz * dRGB;
+                    GS(6) = SH_C2[2] * (2.f * zz - xx - yy) * dRGB;
+                    GS(7) = SH_C2[3] * xz * dRGB;
+                    GS(8) = SH_C2[4] * (xx - yy) * dRGB;
+                    dx_ += SH_C2[0] * y * S(4) + SH_C2[2] * 2.f * -x * S(6) + SH_C2[3] * z * S(7) + SH_C2[4] * 2.f * x * S(8);
+                    dy_ += SH_C2[0] * x * S(4) + SH_C2[1] * z * S(5) + SH_C2[2] * 2.f * -y * S(6) + SH_C2[4] * 2.f * -y * S(8);
+                    dz_ += SH_C2[1] * y * S(5) + SH_C2[2] * 4.f * z * S(6) + SH_C2[3] * x * S(7);
+                    if (D > 2) {
+                        GS(9) = SH_C3[0] * y * (3.f * xx - yy) * dRGB;
+                        GS(10) = SH_C3[1] * xy * z * dRGB;
+                        GS(11) = SH_C3[2] * y * (4.f * zz - xx - yy) * dRGB;
+                        GS(12) = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * dRGB;
+                        GS(13) = SH_C3[4] * x * (4.f * zz - xx - yy) * dRGB;
+                        GS(14) = SH_C3[5] * z * (xx - yy) * dRGB;
+                        GS(15) = SH_C3[6] * x * (xx - 3.f * yy) * dRGB;
+                        dx_ += SH_C3[0] * S(9) * 6.f * xy + SH_C3[1] * S(10) * yz + SH_C3[2] * S(11) * -2.f * xy +
+                               SH_C3[3] * S(12) * -6.f * xz + SH_C3[4] * S(13) * (-3.f * xx + 4.f * zz - yy) +
+                               SH_C3[5] * S(14) * 2.f * xz + SH_C3[6] * S(15) * 3.f * (xx - yy);
+                        dy_ += SH_C3[0] * S(9) * 3.f * (xx - yy) + SH_C3[1] * S(10) * xz +
+                               SH_C3[2] * S(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * S(12) * -6.f * yz +
+                               SH_C3[4] * S(13) * -2.f * xy + SH_C3[5] * S(14) * -2.f * yz + SH_C3[6] * S(15) * -6.f * xy;
+                        dz_ += SH_C3[1] * S(10) * xy + SH_C3[2] * S(11) * 8.f * yz +
+                               SH_C3[3] * S(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * S(13) * 8.f * xz +
+                               SH_C3[5] * S(14) * (xx - yy);
+                    }
+                }
+            }
+#undef S
+#undef GS
+            ddx += dx_ * dRGB; ddy += dy_ * dRGB; ddz += dz_ * dRGB;
+        }
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean[0] += ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * invsum32;
+        dmean[1] += (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * invsum32;
+        dmean[2] += (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * invsum32;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = dmean[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = g6[k];
+
+    // ---- cov3D -> scale, quaternion
+    if (!use_precomp_cov && dL_dscale && dL_drot) {
+        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        float R[3][3];
+        quat_to_rot(q, R);
+        const float s[3] = {scale_mod * scales[3 * i], scale_mod * scales[3 * i + 1], scale_mod * scales[3 * i + 2]};
+        const float dS[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
+                                {0.5f * g6[1], g6[3], 0.5f * g6[4]},
+                                {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
+        float dA[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dA[r][k] = 2.f * (dS[r][0] * R[0][k] * s[k] + dS[r][1] * R[1][k] * s[k] + dS[r][2] * R[2][k] * s[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dscale[3 * i + k] = dA[0][k] * R[0][k] + dA[1][k] * R[1][k] + dA[2][k] * R[2][k];
+        float dR[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) dR[r][k] = dA[r][k] * s[k];
+        const float qr = q[0], qx = q[1], qy = q[2], qz = q[3];
+        dL_drot[4 * i + 0] = 2.f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        dL_drot[4 * i + 1] = 2.f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.f * qx * dR[1][1] - qr * dR[1][2] +
+                                    qz * dR[2][0] + qr * dR[2][1] - 2.f * qx * dR[2][2]);
+        dL_drot[4 * i + 2] = 2.f * (-2.f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
+                                    qr * dR[2][0] + qz * dR[2][1] - 2.f * qy * dR[2][2]);
+        dL_drot[4 * i + 3] = 2.f * (-2.f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.f * qz * dR[1][1] +
+                                    qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- layouts
+enum { G_DEPTH, G_XY, G_CONIC, G_RGB, G_COV3D, G_CLAMPED, G_TOUCHED, G_OFFSETS, G_SCANTMP, G_ACC, G_NFIELDS };
+
+size_t geom_offsets(int P, size_t *off) {
+    size_t o = 0;
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t sz[G_NFIELDS] = {n * 4, n * 8, n * 16, n * 12, n * 24, n * 4, n * 4, n * 4,
+                                  csplat_scan_temp_bytes(P), n * ACC_STRIDE * 4};
+    for (int k = 0; k < G_NFIELDS; k++) { off[k] = o; o += align256(sz[k]); }
+    return o;
+}
+Geom geom_view(void *base, int P) {
+    size_t off[G_NFIELDS];
+    geom_offsets(P, off);
+    char *b = (char *)base;
+    Geom g;
+    g.depth = (float *)(b + off[G_DEPTH]); g.xy = (float2 *)(b + off[G_XY]);
+    g.conic_opacity = (float4 *)(b + off[G_CONIC]); g.rgb = (float *)(b + off[G_RGB]);
+    g.cov3D = (float *)(b + off[G_COV3D]); g.clamped = (uint32_t *)(b + off[G_CLAMPED]);
+    g.tiles_touched = (uint32_t *)(b + off[G_TOUCHED]); g.offsets = (uint32_t *)(b + off[G_OFFSETS]);
+    g.scan_tmp = (void *)(b + off[G_SCANTMP]);
+    return g;
+}
+size_t image_offsets(int W, int H, size_t *off) {
+    const size_t tiles = (size_t)cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), X = (size_t)W * H;
+    off[0] = 0;
+    off[1] = align256(tiles * 8);
+    off[2] = off[1] + align256(X * 4);
+    return off[2] + align256(X * 4);
+}
+size_t binning_offsets(int64_t R, size_t *off) {
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    off[0] = 0;
+    off[1] = align256(n * 8);
+    return off[1] + align256(n * 4);
+}
+// temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
+size_t temp_offsets(int64_t R, size_t *off) {
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    off[0] = 0;
+    off[1] = off[0] + align256(n * 8);
+    off[2] = off[1] + align256(n * 4);
+    off[3] = off[2] + align256(n * 8);
+    off[4] = off[3] + align256(n * 4);
+    return off[4] + csplat_sort_temp_bytes(R);
+}
+
+// camera constants stay in HBM (80 bytes, read through the scalar cache by every wave): no host round trip
+int make_cam(Cam &c, const float *view, const float *proj, const float *campos, float tanfovx, float tanfovy, int W, int H) {
+    c.view = view; c.proj = proj; c.campos = campos;
+    c.tanfovx = tanfovx; c.tanfovy = tanfovy;
+    c.fx = (float)W / (2.0f * tanfovx); c.fy = (float)H / (2.0f * tanfovy);
+    c.W = W; c.H = H; c.gx = cdiv(W, CSPLAT_TILE); c.gy = cdiv(H, CSPLAT_TILE);
+    return 0;
+}
+
+int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n (upstream getHigherMsb)
+    int b = 0;
+    while ((1u << b) < n && b < 31) b++;
+    return b == 0 ? 1 : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csplat_abi_version(void) { return CSPLAT_ABI_VERSION; }
+const char *csplat_last_error(void) { return g_csplat_err; }
+
+size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
+size_t csplat_image_bytes(int W, int H) { size_t off[3]; return image_offsets(W, H, off); }
+size_t csplat_binning_bytes(int64_t R) { size_t off[2]; return binning_offsets(R, off); }
+size_t csplat_temp_bytes(int P, int64_t R) { (void)P; size_t off[5]; return temp_offsets(R, off); }
+int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
+int csplat_binning_layout(int64_t R, size_t *o2) { binning_offsets(R, o2); return 0; }
+int csplat_image_layout(int W, int H, size_t *o3) { image_offsets(W, H, o3); return 0; }
+
+int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                   const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                   float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
+                   const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                   csplat_alloc_fn alloc, void *alloc_ctx, float *out_color, float *out_depth, int32_t *radii,
+                   int *num_rendered, void **geom_out, void **binning_out, void **image_out) {
+    hipStream_t s = (hipStream_t)stream;
+    (void)prefiltered;
+    CSPLAT_REQUIRE(P >= 0 && W > 0 && H > 0, "csplat_forward: bad sizes");
+    CSPLAT_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
+    CSPLAT_REQUIRE((cov3D_precomp != nullptr) != (scales != nullptr && rotations != nullptr),
+                   "provide exactly one of (scales, rotations) / cov3D_precomp");
+    CSPLAT_REQUIRE(shs == nullptr || (D >= 0 && D <= 3 && M >= (D + 1) * (D + 1)), "SH degree / coefficient count mismatch");
+    CSPLAT_REQUIRE(alloc != nullptr, "allocator callback missing");
+    Cam cam;
+    make_cam(cam, view, proj, campos, tanfovx, tanfovy, W, H);
+
+    void *gbase = alloc(alloc_ctx, CSPLAT_CHUNK_GEOM, csplat_geom_bytes(P));
+    void *ibase = alloc(alloc_ctx, CSPLAT_CHUNK_IMAGE, csplat_image_bytes(W, H));
+    CSPLAT_REQUIRE(gbase && ibase, "allocator returned NULL");
+    Geom g = geom_view(gbase, P);
+    size_t ioff[3];
+    image_offsets(W, H, ioff);
+    int2 *ranges = (int2 *)((char *)ibase + ioff[0]);
+    uint32_t *n_contrib = (uint32_t *)((char *)ibase + ioff[1]);
+    float *final_T = (float *)((char *)ibase + ioff[2]);
+    const int tiles = cam.gx * cam.gy;
+
+    uint32_t R = 0;
+    if (P > 0) {
+        k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                                   rotations, cov3D_precomp, cam, g, radii);
+        LAUNCH_CHECK();
+        if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
+        HIP_TRY(hipMemcpyAsync(&R, g.offsets + (P - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    *num_rendered = (int)R;
+    void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R));
+    CSPLAT_REQUIRE(bbase, "allocator returned NULL");
+    size_t boff[2];
+    binning_offsets(R, boff);
+    uint64_t *keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
+    uint32_t *ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
+    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
+    if (R > 0) {
+        void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R));
+        CSPLAT_REQUIRE(tbase, "allocator returned NULL");
+        size_t toff[5];
+        temp_offsets(R, toff);
+        uint64_t *keys_u = (uint64_t *)((char *)tbase + toff[0]);
+        uint32_t *ids_u = (uint32_t *)((char *)tbase + toff[1]);
+        uint64_t *keys_t = (uint64_t *)((char *)tbase + toff[2]);
+        uint32_t *ids_t = (uint32_t *)((char *)tbase + toff[3]);
+        void *stab = (char *)tbase + toff[4];
+        k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, ids_u);
+        LAUNCH_CHECK();
+        const int end_bit = 32 + higher_msb((uint32_t)tiles);
+        if (int rc = csplat_sort_pairs(s, keys_u, ids_u, keys_sorted, ids_sorted, keys_t, ids_t, R, end_bit, stab)) return rc;
+        k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+        LAUNCH_CHECK();
+    }
+    k_render_fwd<<<tiles, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, bg, final_T,
+                                       n_contrib, out_color, out_depth);
+    LAUNCH_CHECK();
+    *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
+    return 0;
+}
+
+int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
+                    const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                    const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
+                    const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
+                    const void *binning, const void *image, const float *dL_dpix, float *dL_dmean2D,
+                    float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
+                    float *dL_dsh, float *dL_dscale, float *dL_drot) {
+    hipStream_t s = (hipStream_t)stream;
+    (void)colors_precomp;
+    CSPLAT_REQUIRE(geom && binning && image, "csplat_backward: missing saved state");
+    CSPLAT_REQUIRE(dL_dmean2D && dL_dconic && dL_dopacity && dL_dcolor && dL_dmean3D && dL_dcov3D, "missing gradient outputs");
+    if (P <= 0) return 0;
+    Cam cam;
+    make_cam(cam, view, proj, campos, tanfovx, tanfovy, W, H);
+    Geom g = geom_view((void *)geom, P);
+    size_t goff[G_NFIELDS];
+    geom_offsets(P, goff);
+    float *acc = (float *)((char *)geom + goff[G_ACC]);
+    size_t ioff[3], boff[2];
+    image_offsets(W, H, ioff);
+    binning_offsets(R, boff);
+    const int2 *ranges = (const int2 *)((const char *)image + ioff[0]);
+    const uint32_t *n_contrib = (const uint32_t *)((const char *)image + ioff[1]);
+    const float *final_T = (const float *)((const char *)image + ioff[2]);
+    const uint32_t *ids_sorted = (const uint32_t *)((const char *)binning + boff[1]);
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
+    if (R > 0) {
+        k_render_bwd<<<cam.gx * cam.gy, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, bg, g.xy, g.conic_opacity, g.rgb,
+                                                     final_T, n_contrib, dL_dpix, acc);
+        LAUNCH_CHECK();
+    }
+    k_preprocess_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                   cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D, dL_dconic,
+                                                   dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

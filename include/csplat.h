@@ -1,0 +1,123 @@
+/*
+ * include/csplat.h -- C-ABI of libcsplat.so, the MI355X (gfx950) hot path of cloth-splatting.
+ *
+ * Plain pointers and sizes only; every pointer named "device" is HBM memory owned by the caller
+ * (torch tensors on the Python side), `stream` is a hipStream_t passed as void*.  All calls are
+ * stream-ordered; the only host synchronisation is the 4-byte read of `num_rendered` inside
+ * csplat_forward (as the upstream CUDA extension does).  Return value: 0 = ok, non-zero = error
+ * (text via csplat_last_error()); no C++ exception crosses this boundary.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *   csplat_forward / csplat_backward
+ *       the `diff_gaussian_rasterization._C.rasterize_gaussians{,_backward}` calls behind
+ *       GaussianRasterizer.forward, gaussian_renderer/__init__.py:16,76,156-164 (backward runs from
+ *       loss.backward(), scene_reconstruction/train_utils.py:288).  Sources of that extension are an empty
+ *       submodule (.gitmodules:7-9); the argument list mirrors its published rasterize_points.h.
+ *   csplat_dist2
+ *       `simple_knn._C.distCUDA2`, scene_reconstruction/gaussian_mesh.py:26,250; gaussian_model.py:20,134.
+ *   csplat_gnn_*
+ *       the torch_geometric MessagePassing gather / scatter-add inside InteractionNetwork.propagate,
+ *       meshnet/graph_network.py:173-174 (gather x_i, x_j: PyG __lift__), :197 (concat), :136 (aggr='add').
+ */
+#ifndef CSPLAT_H
+#define CSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSPLAT_ABI_VERSION 1
+
+/* scratch chunks requested through the allocator callback */
+#define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
+#define CSPLAT_CHUNK_BINNING 1 /* sorted tile instances, kept for backward */
+#define CSPLAT_CHUNK_IMAGE 2   /* per-tile ranges, per-pixel n_contrib / final_T, kept for backward */
+#define CSPLAT_CHUNK_TEMP 3    /* sort ping-pong + histograms; may be freed after forward */
+
+/* Must return a device pointer to at least `bytes` bytes, 256-byte aligned, valid until the matching
+ * backward has run (GEOM/BINNING/IMAGE) or until csplat_forward returns (TEMP).  NULL = failure. */
+typedef void *(*csplat_alloc_fn)(void *ctx, int chunk, size_t bytes);
+
+int csplat_abi_version(void);
+const char *csplat_last_error(void);
+
+/* Sizes of the chunks (bytes) so that a caller may pre-allocate instead of answering the callback lazily. */
+size_t csplat_geom_bytes(int P);
+size_t csplat_image_bytes(int W, int H);
+size_t csplat_binning_bytes(int64_t R);
+size_t csplat_temp_bytes(int P, int64_t R);
+
+/* Byte offsets of the named sub-buffers inside a chunk (for tests / debugging; see DESIGN.md "HBM layout").
+ * geom:    0 depth f32[P] | 1 xy f32[P][2] | 2 conic_opacity f32[P][4] | 3 rgb f32[P][3] | 4 cov3D f32[P][6]
+ *          | 5 clamped u32[P] (bit c = channel c clamped) | 6 tiles_touched u32[P] | 7 offsets u32[P] (inclusive scan)
+ * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)
+ * image:   0 ranges i32[tiles][2] | 1 n_contrib u32[H*W] | 2 final_T f32[H*W]                               */
+int csplat_geom_layout(int P, size_t *offsets8);
+int csplat_binning_layout(int64_t R, size_t *offsets2);
+int csplat_image_layout(int W, int H, size_t *offsets3);
+
+/* Forward: K1 preprocess, K2 scan, K3 key emission, K4 radix sort, K5 tile ranges, K6 compositing.
+ *   means3D[P][3], shs[P][M][3] or NULL, colors_precomp[P][3] or NULL (exactly one of the two),
+ *   opacities[P], scales[P][3]+rotations[P][4] or cov3D_precomp[P][6] (exactly one of the two),
+ *   view/proj: the reference's transposed 4x4 matrices (flat index 4*row+col of world_view_transform /
+ *   full_proj_transform, scene_reconstruction/cameras.py:63-67), campos[3], bg[3]  -- all device, fp32.
+ *   D = active SH degree (0..3), M = SH coefficients per channel stored (16 for max degree 3).
+ * Outputs (device): out_color[3][H][W], out_depth[1][H][W], radii[P] (int32).
+ * *num_rendered (host) receives R = number of (Gaussian, tile) instances.
+ * The three kept chunks are returned through geom/binning/image (device pointers from `alloc`). */
+int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                   const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                   float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
+                   const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                   csplat_alloc_fn alloc, void *alloc_ctx, float *out_color, float *out_depth, int32_t *radii,
+                   int *num_rendered, void **geom, void **binning, void **image);
+
+/* Backward: K7 compositing backward, K8 per-Gaussian backward.
+ * dL_dpix[3][H][W] is the gradient of the colour image (the depth image carries no gradient, as upstream).
+ * Gradient outputs (device, fully overwritten): dL_dmean2D[P][3] (NDC units, .z = 0), dL_dconic[P][4],
+ * dL_dopacity[P], dL_dcolor[P][3], dL_dmean3D[P][3], dL_dcov3D[P][6], dL_dsh[P][M][3] (may be NULL when
+ * colors_precomp was used), dL_dscale[P][3], dL_drot[P][4] (may be NULL when cov3D_precomp was used). */
+int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
+                    const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                    const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
+                    const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
+                    const void *binning, const void *image, const float *dL_dpix, float *dL_dmean2D,
+                    float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
+                    float *dL_dsh, float *dL_dscale, float *dL_drot);
+
+/* distCUDA2: out[i] = mean of squared distances from point i to its 3 nearest other points. */
+int csplat_dist2(void *stream, int P, const float *xyz, float *out);
+
+/* ---- MeshNet message passing (meshnet/graph_network.py:151-222) ------------------------------------
+ * Graph structure is passed as two CSR orderings of the E directed edges, built once per graph by
+ * csplat_gnn_build_csr: for key in {dst = edge_index[1], src = edge_index[0]}:
+ *   rowptr[N+1] (int32) and perm[E] (int32) listing edge ids grouped by key, ascending edge id inside a row
+ *   (=> a fixed, reproducible summation order; no float atomics on this path).
+ * L (latent width) must be a multiple of 4. */
+size_t csplat_gnn_csr_temp_bytes(int N, int64_t E);
+int csplat_gnn_build_csr(void *stream, int N, int64_t E, const int64_t *keys /* device, [E] */, int32_t *rowptr,
+                         int32_t *perm, void *temp);
+
+/* edge pre-activation of the first edge-MLP layer with the concat folded away:
+ *   out[e][:] = relu?( xa[dst[e]][:] + xb[src[e]][:] + ec[e][:] )          (ec already holds e@W_e^T + b)
+ * xa = x @ W_i^T, xb = x @ W_j^T are node-level products (N x L); may run in place (out == ec). */
+int csplat_gnn_edge_combine_fwd(void *stream, int N, int64_t E, int L, const int64_t *edge_index /* [2][E] */,
+                                const float *xa, const float *xb, const float *ec, int relu, float *out);
+/* backward of the above w.r.t. xa, xb (gradient w.r.t. ec is g itself, masked by relu):
+ *   g_masked = g * (out > 0) if relu;  dxa[n] = sum_{e: dst(e)=n} g_masked[e];  dxb[n] = sum_{e: src(e)=n} g_masked[e] */
+int csplat_gnn_edge_combine_bwd(void *stream, int N, int64_t E, int L, const float *g, const float *out, int relu,
+                                const int32_t *rowptr_dst, const int32_t *perm_dst, const int32_t *rowptr_src,
+                                const int32_t *perm_src, float *g_masked, float *dxa, float *dxb);
+/* aggr='add': agg[n][:] = sum_{e in row n} msg[perm[e]][:]   (deterministic segmented sum) */
+int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *msg, const int32_t *rowptr,
+                           const int32_t *perm, float *agg);
+/* its backward: dmsg[e][:] = dagg[key[e]][:]   (row gather) */
+int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSPLAT_H */

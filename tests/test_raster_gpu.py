@@ -1,0 +1,230 @@
+"""Parity of the HIP rasterizer (through the C-ABI, via the diff_gaussian_rasterization drop-in) against the
+oracle.  Bars (BASELINE.json north_star / BASELINE.md): tile & bin indices bit-exact; RGB, depth and gradients
+within 1e-4 relative in fp32 (tolerance written at each assert)."""
+import numpy as np
+import pytest
+
+import util
+from util import make_case, oracle_forward, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = 1e-4  # north_star: "rendered RGB/depth and gradients within 1e-4 rel fp32"
+
+
+def _run_gpu(case, dpix, scale_mod=1.0, **over):
+    import diff_gaussian_rasterization as dgr
+    inp = util.gpu_inputs(case)
+    rs = util.gpu_settings(case, scale_mod=scale_mod, sh_degree=over.pop("sh_degree", None))
+    kw = dict(shs=inp["shs"], colors_precomp=None, scales=inp["scales"], rotations=inp["rotations"], cov3D_precomp=None)
+    for k, v in over.items():
+        kw[k] = None if v is None else torch.tensor(np.asarray(v, np.float32), device="cuda", requires_grad=True)
+    color, radii, depth = dgr.GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=inp["means2D"],
+                                                     opacities=inp["opacities"], **kw)
+    (color * torch.tensor(dpix, device="cuda")).sum().backward()
+    torch.cuda.synchronize()
+    return inp, kw, color, radii, depth
+
+
+CASES = [
+    dict(P=2000, W=128, H=96, seed=7, grid=20, scale_mul=1.0),
+    dict(P=3000, W=200, H=136, seed=8, grid=16, scale_mul=2.5),     # ragged: W,H not multiples of 16
+    dict(P=800, W=64, H=64, seed=9, grid=10, scale_mul=4.0, radius=1.2),  # close camera: frustum clamp + culling
+]
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_indices_bit_exact(cfg):
+    case = make_case(**cfg)
+    o = oracle_forward(case)
+    color, radii, depth, st = util.gpu_forward_raw(case)
+    assert st["R"] == o.R
+    np.testing.assert_array_equal(radii.cpu().numpy(), o.radii)
+    np.testing.assert_array_equal(st["tiles_touched"], o.tiles_touched)
+    np.testing.assert_array_equal(st["offsets"], np.cumsum(o.tiles_touched, dtype=np.uint64).astype(np.uint32))
+    # per-Gaussian state that feeds the keys is bit-identical (same association order, contraction off)
+    np.testing.assert_array_equal(st["depth"].view(np.uint32), o.depth.view(np.uint32))
+    np.testing.assert_array_equal(st["xy"].view(np.uint32), o.xy.view(np.uint32))
+    np.testing.assert_array_equal(st["conic_opacity"].view(np.uint32), o.conic_opacity.view(np.uint32))
+    np.testing.assert_array_equal(st["cov3D"].view(np.uint32), o.cov3D.view(np.uint32))
+    # sorted (tile|depth) keys, sorted Gaussian ids and tile ranges: bit-exact
+    np.testing.assert_array_equal(st["keys"], o.keys)
+    np.testing.assert_array_equal(st["ids"], o.ids)
+    np.testing.assert_array_equal(st["ranges"], o.ranges)
+    clamped = np.stack([(st["clamped"] >> c) & 1 for c in range(3)], 1).astype(np.uint8)
+    vis = o.radii > 0
+    assert (clamped[vis] != o.clamped[vis]).sum() <= 2  # SH sum can round across 0 differently only at |rgb|~1e-7
+    assert rel_err(st["rgb"], o.rgb) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_forward_image(cfg):
+    case = make_case(**cfg)
+    o = oracle_forward(case)
+    o64 = oracle_forward(case, dtype=np.float64)
+    color, radii, depth, st = util.gpu_forward_raw(case)
+    c, d = color.cpu().numpy(), depth.cpu().numpy()
+    assert rel_err(c, o64.color) < TOL and rel_err(d, o64.out_depth) < TOL
+    assert rel_err(c, o.color) < TOL and rel_err(d, o.out_depth) < TOL
+    assert rel_err(st["final_T"], o.final_T) < TOL
+    # n_contrib is an index: exact, except where an alpha / transmittance test sits within an exp() ulp of its
+    # threshold (GPU v_exp_f32 vs glibc expf).  Such ties are counted and must be vanishingly rare.
+    mism = (st["n_contrib"] != o.n_contrib)
+    assert mism.mean() < 2e-4, f"{mism.sum()} n_contrib mismatches"
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_backward_grads(cfg):
+    case = make_case(**cfg)
+    rng = np.random.default_rng(3)
+    dpix = rng.normal(size=(3, case["H"], case["W"])).astype(np.float32)
+    o64 = oracle_forward(case, dtype=np.float64)
+    g64 = util.ro.backward(o64, dpix)
+    inp, kw, color, radii, depth = _run_gpu(case, dpix)
+    got = dict(mean3D=inp["means3D"].grad, mean2D=inp["means2D"].grad, opacity=inp["opacities"].grad.reshape(-1),
+               sh=inp["shs"].grad, scale=inp["scales"].grad, rot=inp["rotations"].grad)
+    for k, v in got.items():
+        e = rel_err(v.cpu().numpy(), getattr(g64, k))
+        assert e < TOL, (k, e)
+
+
+def test_colors_precomp_and_cov_precomp():
+    case = make_case(P=1500, W=96, H=80, seed=11, grid=12, scale_mul=2.0)
+    g = case["g"]
+    rng = np.random.default_rng(5)
+    colors = rng.uniform(0, 1, size=(case["P"], 3)).astype(np.float32)
+    o_pre = oracle_forward(case, dtype=np.float64)  # to get cov3D
+    cov = o_pre.cov3D.astype(np.float32)
+    # make cov3D defined for every Gaussian (culled ones were left 0 by the oracle)
+    o = oracle_forward(case, dtype=np.float64, shs=None, colors_precomp=colors, scales=None, rotations=None,
+                       cov3D_precomp=cov)
+    dpix = rng.normal(size=(3, case["H"], case["W"])).astype(np.float32)
+    g64 = util.ro.backward(o, dpix)
+    inp, kw, color, radii, depth = _run_gpu(case, dpix, shs=None, colors_precomp=colors, scales=None, rotations=None,
+                                            cov3D_precomp=cov)
+    assert rel_err(color.detach().cpu().numpy(), o.color) < TOL
+    np.testing.assert_array_equal(radii.cpu().numpy(), oracle_forward(case, shs=None, colors_precomp=colors, scales=None,
+                                                                      rotations=None, cov3D_precomp=cov).radii)
+    assert rel_err(kw["colors_precomp"].grad.cpu().numpy(), g64.color) < TOL
+    assert rel_err(kw["cov3D_precomp"].grad.cpu().numpy(), g64.cov3D) < TOL
+    assert rel_err(inp["means3D"].grad.cpu().numpy(), g64.mean3D) < TOL
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_lower_sh_degrees(deg):
+    case = make_case(P=1000, W=64, H=64, seed=12, grid=10, scale_mul=3.0)
+    case["sh_degree"] = deg
+    o = oracle_forward(case, dtype=np.float64)
+    dpix = np.random.default_rng(1).normal(size=(3, 64, 64)).astype(np.float32)
+    g64 = util.ro.backward(o, dpix)
+    inp, kw, color, radii, depth = _run_gpu(case, dpix)
+    assert rel_err(color.detach().cpu().numpy(), o.color) < TOL
+    assert rel_err(inp["shs"].grad.cpu().numpy(), g64.sh) < TOL
+    assert float(inp["shs"].grad[:, (deg + 1) ** 2:].abs().max()) == 0.0
+
+
+def test_scale_modifier_quirk():
+    """dL/dscale omits the modifier factor (upstream behaviour, raster_ref.c header)."""
+    case = make_case(P=1000, W=64, H=64, seed=13, grid=10, scale_mul=2.0)
+    o = oracle_forward(case, dtype=np.float64, scale_mod=1.7)
+    dpix = np.random.default_rng(2).normal(size=(3, 64, 64)).astype(np.float32)
+    g64 = util.ro.backward(o, dpix)
+    inp, kw, color, radii, depth = _run_gpu(case, dpix, scale_mod=1.7)
+    assert rel_err(color.detach().cpu().numpy(), o.color) < TOL
+    assert rel_err(inp["scales"].grad.cpu().numpy(), g64.scale) < TOL
+    assert rel_err(inp["rotations"].grad.cpu().numpy(), g64.rot) < TOL
+
+
+def test_empty_and_all_culled():
+    import diff_gaussian_rasterization as dgr
+    case = make_case(P=64, W=48, H=32, seed=14, grid=6)
+    rs = util.gpu_settings(case)
+    # all Gaussians behind the camera -> background image, zero radii, zero grads
+    inp = util.gpu_inputs(case)
+    with torch.no_grad():
+        inp["means3D"] += torch.tensor(case["cam"]["camera_center"], device="cuda") * 3.0
+    color, radii, depth = dgr.GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"],
+                                                     shs=inp["shs"], scales=inp["scales"], rotations=inp["rotations"])
+    color.sum().backward()
+    assert int(radii.max()) == 0
+    assert torch.allclose(color, torch.ones_like(color))
+    assert float(depth.abs().max()) == 0.0
+    assert float(inp["means3D"].grad.abs().max()) == 0.0 and float(inp["shs"].grad.abs().max()) == 0.0
+    # P == 0
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    color, radii, depth = dgr.GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), shs=z(0, 16, 3),
+                                                     scales=z(0, 3), rotations=z(0, 4))
+    assert torch.allclose(color, torch.ones_like(color)) and radii.numel() == 0
+
+
+def test_argument_errors():
+    import diff_gaussian_rasterization as dgr
+    case = make_case(P=16, W=32, H=32, seed=15, grid=4)
+    rs = util.gpu_settings(case)
+    inp = util.gpu_inputs(case)
+    with pytest.raises(Exception):
+        dgr.GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"],
+                                   scales=inp["scales"], rotations=inp["rotations"])  # neither shs nor colours
+    with pytest.raises(Exception):
+        dgr.GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"],
+                                   shs=inp["shs"])  # no covariance source
+
+
+def test_known_answer_single_gaussian():
+    """One isotropic Gaussian straight ahead: closed-form centre pixel, radius and alpha."""
+    import diff_gaussian_rasterization as dgr
+    from csplat import synthetic as syn
+    W = H = 64
+    cam = syn.make_camera(0.0, W, H, radius=4.0)
+    case = dict(cam=cam, W=W, H=H, P=1, bg=np.zeros(3, np.float32), sh_degree=0)
+    rs = util.gpu_settings(case)
+    s = 0.05
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device="cuda")  # noqa: E731
+    color, radii, depth = dgr.GaussianRasterizer(rs)(
+        means3D=t([[0, 0, 0]]), means2D=t([[0, 0, 0]]), opacities=t([[0.8]]), colors_precomp=t([[1.0, 0.5, 0.25]]),
+        scales=t([[s, s, s]]), rotations=t([[1, 0, 0, 0]]))
+    focal = W / (2 * cam["tanfovx"])
+    sigma2 = (s * focal / 4.0) ** 2 + 0.3
+    assert int(radii[0]) == int(np.ceil(3 * np.sqrt(sigma2)))
+    # projected centre is (W-1)/2: the 4 central pixels are at distance sqrt(0.5)
+    alpha = 0.8 * np.exp(-0.5 * 0.5 / sigma2)
+    c = color[:, H // 2, W // 2].cpu().numpy()
+    np.testing.assert_allclose(c, alpha * np.array([1.0, 0.5, 0.25]), rtol=2e-4)
+    np.testing.assert_allclose(float(depth[0, H // 2, W // 2]), alpha * 4.0, rtol=2e-4)
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (P=100k, 800x800): size-independent properties of the binning and the backward."""
+    import diff_gaussian_rasterization as dgr
+    from csplat import synthetic as syn
+    sc = syn.scene_1(P=100_000, W=800, H=800, n_cams=1)
+    case = dict(g=syn.gaussians_at(sc), cam=sc["cameras"][0], W=800, H=800, P=100_000, bg=sc["bg"], sh_degree=3)
+    color, radii, depth, st = util.gpu_forward_raw(case)
+    keys, ids, ranges = st["keys"], st["ids"], st["ranges"]
+    R = st["R"]
+    assert R == int(st["tiles_touched"].astype(np.int64).sum())
+    assert np.all(keys[1:] >= keys[:-1])                                    # sortedness
+    assert np.array_equal(np.bincount(ids, minlength=100_000), st["tiles_touched"])  # permutation of the emitted instances
+    assert int((ranges[:, 1] - ranges[:, 0]).sum()) == R                      # ranges tile the list
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    nz = np.nonzero(ranges[:, 1] > ranges[:, 0])[0]
+    assert np.array_equal(np.unique(tiles), nz)
+    # stability: equal keys keep ascending Gaussian id
+    eq = keys[1:] == keys[:-1]
+    assert np.all(ids[1:][eq] > ids[:-1][eq])
+    assert np.isfinite(color.cpu().numpy()).all()
+    # backward is linear in dL/dpix
+    rng = np.random.default_rng(0)
+    dp = torch.tensor(rng.normal(size=(3, 800, 800)).astype(np.float32), device="cuda")
+    grads = []
+    for scale in (1.0, 2.0):
+        inp = util.gpu_inputs(case)
+        rs = util.gpu_settings(case)
+        c, _, _ = dgr.GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=inp["means2D"], opacities=inp["opacities"],
+                                             shs=inp["shs"], scales=inp["scales"], rotations=inp["rotations"])
+        (c * dp * scale).sum().backward()
+        grads.append([inp[k].grad.clone() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")])
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all()
+        assert float((2 * a - b).abs().max()) <= 2e-3 * float(b.abs().max())  # fp32 atomics reorder sums

@@ -1,0 +1,110 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "cloth-splatting_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from csplat import synthetic as syn  # noqa: E402
+from oracle import raster_oracle as ro  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def make_case(P=2000, W=128, H=96, seed=7, grid=20, scale_mul=1.0, theta=0.0, radius=4.0, fovx=syn.CAMERA_ANGLE_X):
+    sc = syn.scene_1(P=P, W=W, H=H, n_cams=1, grid=grid, seed=seed)
+    g = syn.gaussians_at(sc)
+    g["scales"] = (g["scales"] * scale_mul).astype(np.float32)
+    cam = syn.make_camera(theta, W, H, radius=radius, fovx=fovx)
+    return dict(g=g, cam=cam, W=W, H=H, P=P, bg=sc["bg"], sh_degree=3)
+
+
+def oracle_forward(case, dtype=np.float32, **over):
+    g, cam = case["g"], case["cam"]
+    kw = dict(shs=g["shs"], sh_degree=case["sh_degree"], scales=g["scales"], rotations=g["rotations"])
+    kw.update(over)
+    return ro.forward(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
+                      cam["camera_center"], cam["tanfovx"], cam["tanfovy"], case["W"], case["H"], case["bg"],
+                      dtype=dtype, **kw)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ---------------------------------------------------------------- GPU side (imports torch lazily)
+def gpu_settings(case, scale_mod=1.0, sh_degree=None, device="cuda"):
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    cam = case["cam"]
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=device)  # noqa: E731
+    return GaussianRasterizationSettings(
+        image_height=case["H"], image_width=case["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+        bg=t(case["bg"]), scale_modifier=scale_mod, viewmatrix=t(cam["world_view_transform"]),
+        projmatrix=t(cam["full_proj_transform"]), sh_degree=case["sh_degree"] if sh_degree is None else sh_degree,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+
+
+def gpu_inputs(case, device="cuda", requires_grad=True):
+    import torch
+    g = case["g"]
+    mk = lambda a: torch.tensor(np.asarray(a, np.float32), device=device, requires_grad=requires_grad)  # noqa: E731
+    d = dict(means3D=mk(g["means3D"]), opacities=mk(g["opacities"]), shs=mk(g["shs"]), scales=mk(g["scales"]),
+             rotations=mk(g["rotations"]))
+    d["means2D"] = torch.zeros(case["P"], 3, device=device, requires_grad=requires_grad)
+    return d
+
+
+def gpu_chunks(ctx_chunks, P, W, H, R):
+    """Decode the GEOM / BINNING / IMAGE byte chunks (layout from the C-ABI) into numpy arrays."""
+    from csplat import native as n
+    geom, binning, image = (c.cpu().numpy() for c in ctx_chunks)
+    o8 = (C.c_size_t * 8)(); n.lib.csplat_geom_layout(P, o8)
+    o2 = (C.c_size_t * 2)(); n.lib.csplat_binning_layout(R, o2)
+    o3 = (C.c_size_t * 3)(); n.lib.csplat_image_layout(W, H, o3)
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def view(buf, off, dt, count):
+        return np.frombuffer(buf.tobytes()[off:off + count * np.dtype(dt).itemsize], dtype=dt).copy()
+    out = dict(
+        depth=view(geom, o8[0], np.float32, P), xy=view(geom, o8[1], np.float32, 2 * P).reshape(P, 2),
+        conic_opacity=view(geom, o8[2], np.float32, 4 * P).reshape(P, 4), rgb=view(geom, o8[3], np.float32, 3 * P).reshape(P, 3),
+        cov3D=view(geom, o8[4], np.float32, 6 * P).reshape(P, 6), clamped=view(geom, o8[5], np.uint32, P),
+        tiles_touched=view(geom, o8[6], np.uint32, P), offsets=view(geom, o8[7], np.uint32, P),
+        keys=view(binning, o2[0], np.uint64, R), ids=view(binning, o2[1], np.uint32, R),
+        ranges=view(image, o3[0], np.int32, 2 * tiles).reshape(tiles, 2),
+        n_contrib=view(image, o3[1], np.uint32, W * H).reshape(H, W), final_T=view(image, o3[2], np.float32, W * H).reshape(H, W))
+    return out
+
+
+def gpu_forward_raw(case, inputs=None, settings=None, **over):
+    """Run the autograd Function directly so the saved chunks can be inspected.  Returns (color, radii, depth, state)."""
+    import torch
+    import diff_gaussian_rasterization as dgr
+    inp = inputs or gpu_inputs(case)
+    rs = settings or gpu_settings(case)
+    args = dict(sh=inp["shs"], colors_precomp=None, scales=inp["scales"], rotations=inp["rotations"], cov3Ds_precomp=None)
+    args.update(over)
+
+    class Ctx:  # minimal stand-in for the autograd ctx so that forward() can be called un-differentiated
+        def save_for_backward(self, *a): self.saved_tensors = a
+        def mark_non_differentiable(self, *a): pass
+    ctx = Ctx()
+    with torch.no_grad():
+        color, radii, depth = dgr._RasterizeGaussians.forward(
+            ctx, inp["means3D"], inp["means2D"], args["sh"], args["colors_precomp"], inp["opacities"], args["scales"],
+            args["rotations"], args["cov3Ds_precomp"], rs)
+    torch.cuda.synchronize()
+    state = gpu_chunks(ctx.chunks, case["P"], case["W"], case["H"], ctx.num_rendered)
+    state["R"] = ctx.num_rendered
+    return color, radii, depth, state
