@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on synthetic scene_1: rendered Mpix/s of the rasterizer hot path, forward +
+backward, P = 100k Gaussians, 4 cameras 800x800 per GPU (BASELINE.json configs[1]).
+
+A "step" = one pass of the hot path over one batch: for each of the rank's 4 views, GaussianRasterizer forward
+(K1..K6), L1 loss against a fixed target image, backward (K7, K8); with N > 1 ranks (view-parallel, one process per
+GPU) the step ends with ONE RCCL all-reduce of the flat per-Gaussian gradient buffer.
+All inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+
+
+def cpu_baseline(scene, cams, P, W, H):
+    """Oracle (C restatement, OpenMP) timed on the host cores: ONE step (all views, fwd+bwd) of the same workload."""
+    from csplat import synthetic as syn
+    from oracle import raster_oracle as ro
+    ro.build()
+    g = syn.gaussians_at(scene)
+    rng = np.random.default_rng(0)
+    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    t0 = time.perf_counter()
+    for cam in cams:
+        o = ro.forward(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
+                       cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H, scene["bg"], shs=g["shs"],
+                       sh_degree=3, scales=g["scales"], rotations=g["rotations"])
+        ro.backward(o, dpix)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(cams) * W * H / 1e6 / dt, 4), "unit": "Mpix/s", "cores": int(ro.num_threads()),
+            "kind": "port",
+            "sample": f"one full step: {len(cams)} views {W}x{H}, P={P}, fwd+bwd through oracle/raster_ref.c "
+                      f"(OpenMP, fp32), {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--P", type=int, default=100_000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from csplat import native, synthetic as syn
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    P, W, H, V = args.P, args.res, args.res, args.views
+    scene = syn.scene_1(P=P, W=W, H=H, n_cams=V)
+    # view-parallel: rank r renders its own 4 cameras (azimuth offset), Gaussians replicated
+    cams = [syn.make_camera(-180.0 + 360.0 * (k + rank / max(world, 1)) / V, W, H) for k in range(V)]
+    g = syn.gaussians_at(scene)
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)  # noqa: E731
+    params = {k: T(g[k], True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    bg = T(scene["bg"])
+    settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+        viewmatrix=T(c["world_view_transform"]), projmatrix=T(c["full_proj_transform"]), sh_degree=3,
+        campos=T(c["camera_center"]), prefiltered=False, debug=False) for c in cams]
+
+    def render(i, means2D):
+        return GaussianRasterizer(settings[i])(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                                               shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+
+    # target images = render of a perturbed copy (so the loss and its gradient are non-trivial)
+    with torch.no_grad():
+        keep = {k: v.detach().clone() for k, v in params.items()}
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        params["shs"].add_(0.2 * torch.randn(params["shs"].shape, device=dev, generator=gen))
+        params["means3D"].add_(0.003 * torch.randn(params["means3D"].shape, device=dev, generator=gen))
+        targets = [render(i, torch.zeros(P, 3, device=dev))[0].clone() for i in range(V)]
+        for k, v in keep.items():
+            params[k].copy_(v)
+
+    flat_names = ("means3D", "opacities", "shs", "scales", "rotations")
+    R_per_view = [0] * V
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        m2d_grads = []
+        for i in range(V):
+            means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+            color, radii, depth = render(i, means2D)
+            loss = (color - targets[i]).abs().mean()
+            loss.backward()
+            m2d_grads.append(means2D.grad)
+        if world > 1:
+            flat = torch.cat([params[k].grad.reshape(P, -1) for k in flat_names] + [sum(m2d_grads)], dim=1)
+            dist.all_reduce(flat)
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # R (tile instances) per view for the algorithmic-byte count; constant across steps (same inputs)
+    import diff_gaussian_rasterization as dgr
+    sync()
+    native.prof_enable(["K7_render_bwd"])
+    native.prof_read("K7_render_bwd")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    k7_ms, k7_n = native.prof_read("K7_render_bwd")
+    native.prof_enable([])
+
+    # per-kernel breakdown (separate, untimed pass) and R per view
+    native.prof_enable(native.PROF_CLASSES[:8])
+    for c in native.PROF_CLASSES[:8]:
+        native.prof_read(c)
+    step(); torch.cuda.synchronize()
+    breakdown = {}
+    for c in native.PROF_CLASSES[:8]:
+        ms, n = native.prof_read(c)
+        breakdown[c] = round(ms / max(n, 1) * 1e3, 2)  # us per launch-bracket
+    native.prof_enable([])
+    with torch.no_grad():
+        for i in range(V):
+            ctx = type("C", (), {"save_for_backward": lambda s, *a: None, "mark_non_differentiable": lambda s, *a: None})()
+            dgr._RasterizeGaussians.forward(ctx, params["means3D"], None, params["shs"], None, params["opacities"],
+                                            params["scales"], params["rotations"], None, settings[i])
+            R_per_view[i] = ctx.num_rendered
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    mpix = world * V * W * H / 1e6
+    value = mpix / (dt / args.steps)
+
+    # roofline of the dominant kernel named by BASELINE.json north_star: compositing backward (K7).
+    # algorithmic bytes per launch = 84*R + 24*X (instance re-read 44 B + 40 B partials per instance;
+    # dL_dpix 16 B (incl. unused depth grad slot) + T 4 B + n_contrib 4 B per pixel), R = that view's tile instances.
+    X = W * H
+    alg_bytes = float(np.mean([84.0 * r + 24.0 * X for r in R_per_view]))
+    k7_avg_s = (k7_ms / max(k7_n, 1)) * 1e-3
+    achieved = alg_bytes / k7_avg_s / 1e9 if k7_avg_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_k7_pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "rasterizer fwd+bwd rendered Mpix/s (scene_1, 800x800)", "value": round(value, 3), "unit": "Mpix/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"scene_1 synthetic, P={P} Gaussians, {V} cams {W}x{H} per GPU, SH degree 3, "
+                               "fwd (K1-K6) + L1 + bwd (K7-K8)" + (", + RCCL all-reduce of flat grads" if world > 1 else ""),
+                   "tile_instances_per_view": R_per_view, "parallelism": f"view-parallel x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "k_render_bwd (K7 compositing backward)", "achieved": round(achieved, 3),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
+                     "launches_timed": int(k7_n)},
+        "kernel_us": breakdown,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene, cams, P, W, H)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

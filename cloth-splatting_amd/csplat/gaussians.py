@@ -1,0 +1,150 @@
+"""MeshGaussians: the hot-path subset of the reference's MultiGaussianMesh (scene_reconstruction/gaussian_mesh.py)
+that gaussian_renderer.render() and train_step touch -- parameters, activations (gaussian_model.py:27-48,96-121),
+get_xyz (barycentric gather, gaussian_mesh.py:151-169), get_rotation (per-Gaussian Kabsch of its face + quaternion
+composition, :171-188, incl. the wxyz/xyzw convention mix of SURVEY F8, reproduced not fixed) and the
+distCUDA2-based scale initialisation (:249-251).  Densification, PLY/HDF5 I/O and Adam-state surgery are "next" rows
+(SURVEY.md 8(f) N3/N4), not built here."""
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import rotations as rot
+from .native import require_cuda
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def build_rotation(r):
+    """utils/general_utils.py:81-102"""
+    q = r / r.norm(dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.reshape(-1, 3, 3)
+
+
+class MeshGaussians:
+    def __init__(self, sh_degree: int):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.mesh = SimpleNamespace(pos=None, face=None, edge_index=None)
+        self.face_ids = torch.empty(0)
+        self.face_bary = torch.empty(0)
+        self.face_offset = torch.empty(0)
+        self._features_dc = self._features_rest = self._scaling = self._rotation = self._opacity = torch.empty(0)
+        self.edge_norm = torch.empty(0)
+        self.optimizer = None
+
+    # ---- construction -------------------------------------------------------------------------------------------
+    def from_mesh(self, pos, face, edge_index, gaussian_init_factor=2, generator=None):
+        """gaussian_mesh.py:207-263: P = factor * F Gaussians, barycentric jitter, scales from distCUDA2."""
+        from simple_knn._C import distCUDA2
+        require_cuda(pos)
+        dev = pos.device
+        self.mesh = SimpleNamespace(pos=pos, face=face, edge_index=edge_index)
+        disp = pos[edge_index[1]] - pos[edge_index[0]]
+        self.edge_norm = disp.norm(dim=-1, keepdim=True)
+        F = face.shape[1]
+        P = gaussian_init_factor * F
+        bary = torch.full((P, 3), 1.0 / 3.0, device=dev)
+        if gaussian_init_factor > 1:
+            bary = torch.clip(torch.normal(bary, 0.05, generator=generator), 0.0, 1.0)
+            bary = bary / bary.sum(dim=1, keepdim=True)
+        self.face_bary = nn.Parameter(bary.requires_grad_(True))
+        self.face_offset = nn.Parameter(torch.zeros(P, 1, device=dev).requires_grad_(True))
+        self.face_ids = torch.arange(0, F, dtype=torch.long, device=dev).repeat(gaussian_init_factor).sort().values
+        rgb = torch.rand(P, 3, device=dev, generator=generator) / 255.0
+        feats = torch.zeros(P, 3, (self.max_sh_degree + 1) ** 2, device=dev)
+        feats[:, :3, 0] = (rgb - 0.5) / 0.28209479177387814
+        dist2 = torch.clamp_min(distCUDA2(self.get_xyz().detach()), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros(P, 4, device=dev)
+        rots[:, 0] = 1
+        opac = inverse_sigmoid(0.1 * torch.ones(P, 1, device=dev))
+        self._features_dc = nn.Parameter(feats[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(feats[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
+        self._scaling = nn.Parameter(scales.requires_grad_(True))
+        self._rotation = nn.Parameter(rots.requires_grad_(True))
+        self._opacity = nn.Parameter(opac.requires_grad_(True))
+        return self
+
+    def from_arrays(self, pos, face, edge_index, face_ids, bary, log_scales, quats, opacity_logits, sh):
+        """load explicit parameters (synthetic scene_1)."""
+        self.mesh = SimpleNamespace(pos=pos, face=face, edge_index=edge_index)
+        self.edge_norm = (pos[edge_index[1]] - pos[edge_index[0]]).norm(dim=-1, keepdim=True)
+        self.face_ids = face_ids
+        self.face_bary = nn.Parameter(bary.clone().requires_grad_(True))
+        self.face_offset = nn.Parameter(torch.zeros(bary.shape[0], 1, device=bary.device).requires_grad_(True))
+        self._features_dc = nn.Parameter(sh[:, 0:1].contiguous().clone().requires_grad_(True))
+        self._features_rest = nn.Parameter(sh[:, 1:].contiguous().clone().requires_grad_(True))
+        self._scaling = nn.Parameter(log_scales.clone().requires_grad_(True))
+        self._rotation = nn.Parameter(quats.clone().requires_grad_(True))
+        self._opacity = nn.Parameter(opacity_logits.clone().requires_grad_(True))
+        return self
+
+    def parameters(self):
+        return [self.face_bary, self.face_offset, self._features_dc, self._features_rest, self._opacity, self._scaling,
+                self._rotation]
+
+    def training_setup(self, position_lr=1.6e-4, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
+                       spatial_lr_scale=1.0):
+        """the 7 Adam parameter groups of gaussian_mesh.py:126-136"""
+        groups = [
+            {'params': [self.face_bary], 'lr': position_lr * spatial_lr_scale, "name": "face_bary"},
+            {'params': [self.face_offset], 'lr': position_lr * spatial_lr_scale, "name": "face_offset"},
+            {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
+            {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"},
+            {'params': [self._opacity], 'lr': opacity_lr, "name": "opacity"},
+            {'params': [self._scaling], 'lr': scaling_lr, "name": "scaling"},
+            {'params': [self._rotation], 'lr': rotation_lr, "name": "rotation"}]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        return self.optimizer
+
+    # ---- activations (gaussian_model.py:96-121) -----------------------------------------------------------------
+    @property
+    def num_gaussians(self):
+        return self.face_ids.shape[0]
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def get_covariance(self, scaling_modifier=1):
+        L = build_rotation(self._rotation) @ torch.diag_embed(scaling_modifier * self.get_scaling)
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1)
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- mesh -> Gaussian transform (gaussian_mesh.py:151-188) --------------------------------------------------
+    def _vertex_ids(self):
+        return self.mesh.face[:, self.face_ids].transpose(0, 1)  # [P, 3]
+
+    def get_xyz(self, deformed_vertices=None):
+        vid = self._vertex_ids()
+        verts = self.mesh.pos if deformed_vertices is None else deformed_vertices
+        face_pos = verts[vid, :]                                                      # [P, 3 (vertex), 3 (xyz)]
+        nb = self.face_bary / self.face_bary.sum(dim=1, keepdim=True)
+        return (nb.unsqueeze(1) @ face_pos).squeeze(1)
+
+    def get_rotation(self, deformed_vertices=None):
+        rotation = torch.nn.functional.normalize(self._rotation)
+        if deformed_vertices is None:
+            return rotation
+        vid = self._vertex_ids()
+        R, _ = rot.rigid_points_registration(self.mesh.pos[vid, :], deformed_vertices[vid, :])
+        return rot.quat_composition([rotation, rot.rotmat_to_unitquat(R)])

@@ -35,6 +35,8 @@ EXPORTS = {
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
+    "csplat_prof_enable": (_i, [C.c_uint]),
+    "csplat_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "csplat_gnn_csr_temp_bytes": (_sz, [_i, _i64]),
     "csplat_gnn_build_csr": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "csplat_gnn_edge_combine_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -93,3 +95,21 @@ class ChunkAllocator:
             return buf.data_ptr()
         except Exception:  # never let an exception cross the C boundary
             return None
+
+
+PROF_CLASSES = ["K1_preprocess", "K2_scan", "K3_emit_keys", "K4_radix_sort", "K5_tile_ranges", "K6_render_fwd",
+                "K7_render_bwd", "K8_preprocess_bwd", "K9_dist2", "GNN"]
+
+
+def prof_enable(classes=()):
+    mask = 0
+    for c in classes:
+        mask |= 1 << (PROF_CLASSES.index(c) if isinstance(c, str) else int(c))
+    check(lib.csplat_prof_enable(mask), "csplat_prof_enable")
+
+
+def prof_read(cls):
+    k = PROF_CLASSES.index(cls) if isinstance(cls, str) else int(cls)
+    ms, n = C.c_double(0), _i64(0)
+    check(lib.csplat_prof_read(k, C.byref(ms), C.byref(n)), "csplat_prof_read")
+    return ms.value, n.value

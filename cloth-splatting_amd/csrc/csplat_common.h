@@ -47,3 +47,13 @@ int csplat_inclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, 
 size_t csplat_sort_temp_bytes(int64_t n);
 int csplat_sort_pairs(hipStream_t s, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
                       uint32_t *vals_out, uint64_t *keys_tmp, uint32_t *vals_tmp, int64_t n, int end_bit, void *temp);
+
+// ---- optional event bracketing (csplat_prof_*), implemented in csplat_sort.hip --------------------
+enum { PROF_K1 = 0, PROF_K2, PROF_K3, PROF_K4, PROF_K5, PROF_K6, PROF_K7, PROF_K8, PROF_KNN, PROF_GNN, PROF_NCLASSES };
+extern unsigned g_csplat_prof_mask;
+void csplat_prof_mark(int cls, hipStream_t s, bool begin);
+struct ProfScope {
+    int cls; hipStream_t s; bool on;
+    ProfScope(int c, hipStream_t st) : cls(c), s(st), on((g_csplat_prof_mask >> c) & 1u) { if (on) csplat_prof_mark(cls, s, true); }
+    ~ProfScope() { if (on) csplat_prof_mark(cls, s, false); }
+};

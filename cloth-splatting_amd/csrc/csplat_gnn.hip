@@ -42,61 +42,69 @@ __global__ __launch_bounds__(256) void k_sort_rows(int N, const int32_t *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void k_edge_combine_fwd(int64_t E, int L4, const int64_t *__restrict__ ei,
-                                                           const float4 *__restrict__ xa, const float4 *__restrict__ xb,
-                                                           const float4 *__restrict__ ec, int relu, float4 *__restrict__ out) {
+// row movers are templated on the per-lane vector: float4 (16 B/lane) when L % 4 == 0, float otherwise
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vrelu(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float vrelu(float a) { return fmaxf(a, 0.f); }
+__device__ __forceinline__ float4 vmask(float4 g, float4 o) {
+    return make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+}
+__device__ __forceinline__ float vmask(float g, float o) { return o > 0.f ? g : 0.f; }
+__device__ __forceinline__ void vzero(float4 &a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(float &a) { a = 0.f; }
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_edge_combine_fwd(int64_t E, int LV, const int64_t *__restrict__ ei,
+                                                           const VT *__restrict__ xa, const VT *__restrict__ xb,
+                                                           const VT *__restrict__ ec, int relu, VT *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E * L4) return;
-    const int64_t e = t / L4;
-    const int c = (int)(t - e * L4);
+    if (t >= E * LV) return;
+    const int64_t e = t / LV;
+    const int c = (int)(t - e * LV);
     const int64_t src = ei[e], dst = ei[E + e];
-    const float4 a = xa[dst * L4 + c], b = xb[src * L4 + c], v = ec[t];
-    float4 r = make_float4(a.x + b.x + v.x, a.y + b.y + v.y, a.z + b.z + v.z, a.w + b.w + v.w);
-    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    VT r = vadd(vadd(xa[dst * LV + c], xb[src * LV + c]), ec[t]);
+    if (relu) r = vrelu(r);
     out[t] = r;
 }
 
-__global__ __launch_bounds__(256) void k_relu_mask(int64_t n4, const float4 *__restrict__ g, const float4 *__restrict__ out,
-                                                    float4 *__restrict__ gm) {
+template <typename VT>
+__global__ __launch_bounds__(256) void k_relu_mask(int64_t nv, const VT *__restrict__ g, const VT *__restrict__ out,
+                                                    VT *__restrict__ gm) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n4) return;
-    const float4 a = g[t], o = out[t];
-    gm[t] = make_float4(o.x > 0.f ? a.x : 0.f, o.y > 0.f ? a.y : 0.f, o.z > 0.f ? a.z : 0.f, o.w > 0.f ? a.w : 0.f);
+    if (t < nv) gm[t] = vmask(g[t], out[t]);
 }
 
 // agg[n][c] = sum over the row's edges, ascending edge id, plain sequential fp32 adds (== index_add_ on the CPU)
-__global__ __launch_bounds__(256) void k_segment_sum(int N, int L4, const float4 *__restrict__ msg,
+template <typename VT>
+__global__ __launch_bounds__(256) void k_segment_sum(int N, int LV, const VT *__restrict__ msg,
                                                       const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
-                                                      float4 *__restrict__ agg) {
+                                                      VT *__restrict__ agg) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)N * L4) return;
-    const int n = (int)(t / L4), c = (int)(t - (int64_t)n * L4);
+    if (t >= (int64_t)N * LV) return;
+    const int n = (int)(t / LV), c = (int)(t - (int64_t)n * LV);
     const int s = rowptr[n], e = rowptr[n + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    VT acc;
+    vzero(acc);
     int i = s;
-    for (; i + 4 <= e; i += 4) {  // 4 independent row loads in flight per lane
+    for (; i + 4 <= e; i += 4) {  // 4 independent row loads in flight per lane, summed in list order
         const int p0 = perm[i], p1 = perm[i + 1], p2 = perm[i + 2], p3 = perm[i + 3];
-        const float4 v0 = msg[(int64_t)p0 * L4 + c], v1 = msg[(int64_t)p1 * L4 + c], v2 = msg[(int64_t)p2 * L4 + c],
-                     v3 = msg[(int64_t)p3 * L4 + c];
-        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        const VT v0 = msg[(int64_t)p0 * LV + c], v1 = msg[(int64_t)p1 * LV + c], v2 = msg[(int64_t)p2 * LV + c],
+                 v3 = msg[(int64_t)p3 * LV + c];
+        acc = vadd(vadd(vadd(vadd(acc, v0), v1), v2), v3);
     }
-    for (; i < e; i++) {
-        const float4 v = msg[(int64_t)perm[i] * L4 + c];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
+    for (; i < e; i++) acc = vadd(acc, msg[(int64_t)perm[i] * LV + c]);
     agg[t] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_gather_rows(int64_t E, int L4, const float4 *__restrict__ rows,
-                                                      const int64_t *__restrict__ keys, float4 *__restrict__ out) {
+template <typename VT>
+__global__ __launch_bounds__(256) void k_gather_rows(int64_t E, int LV, const VT *__restrict__ rows,
+                                                      const int64_t *__restrict__ keys, VT *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E * L4) return;
-    const int64_t e = t / L4;
-    const int c = (int)(t - e * L4);
-    out[t] = rows[keys[e] * L4 + c];
+    if (t >= E * LV) return;
+    const int64_t e = t / LV;
+    const int c = (int)(t - e * LV);
+    out[t] = rows[keys[e] * LV + c];
 }
 
 }  // namespace
@@ -132,12 +140,16 @@ int csplat_gnn_build_csr(void *stream, int N, int64_t E, const int64_t *keys, in
 int csplat_gnn_edge_combine_fwd(void *stream, int N, int64_t E, int L, const int64_t *edge_index, const float *xa,
                                 const float *xb, const float *ec, int relu, float *out) {
     (void)N;
-    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
     if (E == 0) return 0;
-    const int L4 = L / 4;
-    k_edge_combine_fwd<<<cdiv(E * L4, 256), 256, 0, (hipStream_t)stream>>>(E, L4, edge_index, (const float4 *)xa,
-                                                                           (const float4 *)xb, (const float4 *)ec, relu,
-                                                                           (float4 *)out);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    if (L % 4 == 0)
+        k_edge_combine_fwd<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E, L / 4, edge_index, (const float4 *)xa,
+                                                                          (const float4 *)xb, (const float4 *)ec, relu,
+                                                                          (float4 *)out);
+    else
+        k_edge_combine_fwd<float><<<cdiv(E * L, 256), 256, 0, s>>>(E, L, edge_index, xa, xb, ec, relu, out);
     LAUNCH_CHECK();
     return 0;
 }
@@ -145,11 +157,15 @@ int csplat_gnn_edge_combine_fwd(void *stream, int N, int64_t E, int L, const int
 int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *msg, const int32_t *rowptr,
                            const int32_t *perm, float *agg) {
     (void)E;
-    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
     if (N == 0) return 0;
-    const int L4 = L / 4;
-    k_segment_sum<<<cdiv((int64_t)N * L4, 256), 256, 0, (hipStream_t)stream>>>(N, L4, (const float4 *)msg, rowptr, perm,
-                                                                               (float4 *)agg);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    if (L % 4 == 0)
+        k_segment_sum<float4><<<cdiv((int64_t)N * (L / 4), 256), 256, 0, s>>>(N, L / 4, (const float4 *)msg, rowptr, perm,
+                                                                              (float4 *)agg);
+    else
+        k_segment_sum<float><<<cdiv((int64_t)N * L, 256), 256, 0, s>>>(N, L, msg, rowptr, perm, agg);
     LAUNCH_CHECK();
     return 0;
 }
@@ -157,13 +173,17 @@ int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *m
 int csplat_gnn_edge_combine_bwd(void *stream, int N, int64_t E, int L, const float *g, const float *out, int relu,
                                 const int32_t *rowptr_dst, const int32_t *perm_dst, const int32_t *rowptr_src,
                                 const int32_t *perm_src, float *g_masked, float *dxa, float *dxb) {
-    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
     hipStream_t s = (hipStream_t)stream;
     const float *gm = g;
     if (relu) {
         if (E > 0) {
-            k_relu_mask<<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E * (L / 4), (const float4 *)g, (const float4 *)out,
-                                                               (float4 *)g_masked);
+            ProfScope ps(PROF_GNN, s);
+            if (L % 4 == 0)
+                k_relu_mask<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E * (L / 4), (const float4 *)g,
+                                                                           (const float4 *)out, (float4 *)g_masked);
+            else
+                k_relu_mask<float><<<cdiv(E * L, 256), 256, 0, s>>>(E * L, g, out, g_masked);
             LAUNCH_CHECK();
         }
         gm = g_masked;
@@ -173,10 +193,14 @@ int csplat_gnn_edge_combine_bwd(void *stream, int N, int64_t E, int L, const flo
 }
 
 int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out) {
-    CSPLAT_REQUIRE(L > 0 && L % 4 == 0, "latent width must be a multiple of 4");
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
     if (E == 0) return 0;
-    const int L4 = L / 4;
-    k_gather_rows<<<cdiv(E * L4, 256), 256, 0, (hipStream_t)stream>>>(E, L4, (const float4 *)rows, keys, (float4 *)out);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    if (L % 4 == 0)
+        k_gather_rows<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E, L / 4, (const float4 *)rows, keys, (float4 *)out);
+    else
+        k_gather_rows<float><<<cdiv(E * L, 256), 256, 0, s>>>(E, L, rows, keys, out);
     LAUNCH_CHECK();
     return 0;
 }

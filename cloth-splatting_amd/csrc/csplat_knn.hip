@@ -44,6 +44,7 @@ __global__ __launch_bounds__(KNN_THREADS) void k_dist2(int P, const float *__res
 extern "C" int csplat_dist2(void *stream, int P, const float *xyz, float *out) {
     CSPLAT_REQUIRE(P >= 0, "csplat_dist2: bad P");
     if (P == 0) return 0;
+    ProfScope ps(PROF_KNN, (hipStream_t)stream);
     k_dist2<<<cdiv(P, KNN_THREADS), KNN_THREADS, 0, (hipStream_t)stream>>>(P, xyz, out);
     LAUNCH_CHECK();
     return 0;

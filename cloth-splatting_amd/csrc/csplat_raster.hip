@@ -754,8 +754,9 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     hipStream_t s = (hipStream_t)stream;
     (void)prefiltered;
     CSPLAT_REQUIRE(P >= 0 && W > 0 && H > 0, "csplat_forward: bad sizes");
-    CSPLAT_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
-    CSPLAT_REQUIRE((cov3D_precomp != nullptr) != (scales != nullptr && rotations != nullptr),
+    // (an empty input, P == 0, legitimately arrives with NULL data pointers)
+    CSPLAT_REQUIRE(P == 0 || (shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
+    CSPLAT_REQUIRE(P == 0 || (cov3D_precomp != nullptr) != (scales != nullptr && rotations != nullptr),
                    "provide exactly one of (scales, rotations) / cov3D_precomp");
     CSPLAT_REQUIRE(shs == nullptr || (D >= 0 && D <= 3 && M >= (D + 1) * (D + 1)), "SH degree / coefficient count mismatch");
     CSPLAT_REQUIRE(alloc != nullptr, "allocator callback missing");
@@ -775,10 +776,16 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
 
     uint32_t R = 0;
     if (P > 0) {
-        k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                                                   rotations, cov3D_precomp, cam, g, radii);
-        LAUNCH_CHECK();
-        if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
+        {
+            ProfScope ps(PROF_K1, s);
+            k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+                                                       scale_modifier, rotations, cov3D_precomp, cam, g, radii);
+            LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(PROF_K2, s);
+            if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
+        }
         HIP_TRY(hipMemcpyAsync(&R, g.offsets + (P - 1), 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -800,16 +807,28 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         uint64_t *keys_t = (uint64_t *)((char *)tbase + toff[2]);
         uint32_t *ids_t = (uint32_t *)((char *)tbase + toff[3]);
         void *stab = (char *)tbase + toff[4];
-        k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, ids_u);
-        LAUNCH_CHECK();
+        {
+            ProfScope ps(PROF_K3, s);
+            k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, ids_u);
+            LAUNCH_CHECK();
+        }
         const int end_bit = 32 + higher_msb((uint32_t)tiles);
-        if (int rc = csplat_sort_pairs(s, keys_u, ids_u, keys_sorted, ids_sorted, keys_t, ids_t, R, end_bit, stab)) return rc;
-        k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+        {
+            ProfScope ps(PROF_K4, s);
+            if (int rc = csplat_sort_pairs(s, keys_u, ids_u, keys_sorted, ids_sorted, keys_t, ids_t, R, end_bit, stab)) return rc;
+        }
+        {
+            ProfScope ps(PROF_K5, s);
+            k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+            LAUNCH_CHECK();
+        }
+    }
+    {
+        ProfScope ps(PROF_K6, s);
+        k_render_fwd<<<tiles, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, bg,
+                                           final_T, n_contrib, out_color, out_depth);
         LAUNCH_CHECK();
     }
-    k_render_fwd<<<tiles, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, bg, final_T,
-                                       n_contrib, out_color, out_depth);
-    LAUNCH_CHECK();
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
     return 0;
 }
@@ -841,14 +860,19 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
     const uint32_t *ids_sorted = (const uint32_t *)((const char *)binning + boff[1]);
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
     if (R > 0) {
+        ProfScope ps(PROF_K7, s);
         k_render_bwd<<<cam.gx * cam.gy, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, bg, g.xy, g.conic_opacity, g.rgb,
                                                      final_T, n_contrib, dL_dpix, acc);
         LAUNCH_CHECK();
     }
-    k_preprocess_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
-                                                   cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D, dL_dconic,
-                                                   dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
-    LAUNCH_CHECK();
+    {
+        ProfScope ps(PROF_K8, s);
+        k_preprocess_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                       cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D, dL_dconic,
+                                                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                                                       dL_drot);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -9,7 +9,55 @@
 // Stability is what makes equal (tile, depth) keys keep their emission order (ascending Gaussian id).
 #include "csplat_common.h"
 
+#include <mutex>
+#include <vector>
+
 thread_local char g_csplat_err[512] = {0};
+unsigned g_csplat_prof_mask = 0;
+
+namespace {
+struct ProfClass {
+    std::vector<hipEvent_t> begin, end, pool;
+};
+ProfClass g_prof[PROF_NCLASSES];
+std::mutex g_prof_mu;
+hipEvent_t prof_event(ProfClass &c) {
+    hipEvent_t e = nullptr;
+    if (!c.pool.empty()) { e = c.pool.back(); c.pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void csplat_prof_mark(int cls, hipStream_t s, bool begin) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfClass &c = g_prof[cls];
+    hipEvent_t e = prof_event(c);
+    (void)hipEventRecord(e, s);
+    (begin ? c.begin : c.end).push_back(e);
+}
+
+extern "C" int csplat_prof_enable(unsigned mask) { g_csplat_prof_mask = mask; return 0; }
+
+extern "C" int csplat_prof_read(int cls, double *ms_total, int64_t *launches) {
+    CSPLAT_REQUIRE(cls >= 0 && cls < PROF_NCLASSES, "csplat_prof_read: bad kernel class");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfClass &c = g_prof[cls];
+    double tot = 0;
+    const size_t n = c.begin.size() < c.end.size() ? c.begin.size() : c.end.size();
+    for (size_t i = 0; i < n; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(c.end[i]));
+        HIP_TRY(hipEventElapsedTime(&ms, c.begin[i], c.end[i]));
+        tot += ms;
+    }
+    for (hipEvent_t e : c.begin) c.pool.push_back(e);
+    for (hipEvent_t e : c.end) c.pool.push_back(e);
+    c.begin.clear(); c.end.clear();
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = (int64_t)n;
+    return 0;
+}
 
 namespace {
 

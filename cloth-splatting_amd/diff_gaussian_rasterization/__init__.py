@@ -55,11 +55,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = int(means3D.shape[0])
         H, W = int(rs.image_height), int(rs.image_width)
         means3D = _f32c(means3D, dev); opacities = _f32c(opacities, dev)
-        sh = _f32c(sh, dev) if sh is not None and sh.numel() > 0 else None
-        colors_precomp = _f32c(colors_precomp, dev) if colors_precomp is not None and colors_precomp.numel() > 0 else None
-        scales = _f32c(scales, dev) if scales is not None and scales.numel() > 0 else None
-        rotations = _f32c(rotations, dev) if rotations is not None and rotations.numel() > 0 else None
-        cov3Ds_precomp = _f32c(cov3Ds_precomp, dev) if cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0 else None
+        sh = _f32c(sh, dev)
+        colors_precomp = _f32c(colors_precomp, dev)
+        scales = _f32c(scales, dev)
+        rotations = _f32c(rotations, dev)
+        cov3Ds_precomp = _f32c(cov3Ds_precomp, dev)
         bg = _f32c(rs.bg, dev); view = _f32c(rs.viewmatrix, dev); proj = _f32c(rs.projmatrix, dev)
         campos = _f32c(rs.campos, dev)
         M = int(sh.shape[1]) if sh is not None else 0

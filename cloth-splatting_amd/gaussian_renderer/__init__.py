@@ -1,0 +1,96 @@
+"""Drop-in for /root/reference/gaussian_renderer/__init__.py: render() with the reference's signature and
+RenderResults record (:22-36, :39-206), driving the MI355X rasterizer (libcsplat.so) through the
+diff_gaussian_rasterization drop-in.  `pc` may be the reference's own MultiGaussianMesh or csplat.gaussians.MeshGaussians;
+`simulator` any module with forward(time_vector=[V,1]) -> [V,3] (ResidualMeshSimulator).
+"""
+import math
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+
+class RenderResults(NamedTuple):
+    render: torch.Tensor
+    viewspace_points: torch.Tensor
+    visibility_filter: torch.Tensor
+    radii: torch.Tensor
+    depth: torch.Tensor
+    means3D_deform: torch.Tensor
+    vertice_deform: torch.Tensor
+    shadows_mean: Optional[torch.Tensor]
+    shadows_std: Optional[torch.Tensor]
+    projections: torch.Tensor
+    rotations: torch.Tensor
+    opacities: torch.Tensor
+    shadows: Optional[torch.Tensor]
+    vertice_projections: Optional[torch.Tensor]
+
+
+def _project(cam, points):
+    """pixel coordinates of world points (reference :166-179): p_h @ full_proj, /w, ndc -> ((v+1)*S-1)/2."""
+    full = cam.full_proj_transform.to(points.device)
+    hom = torch.cat([points, torch.ones_like(points[:, 0:1])], dim=1) @ full
+    ndc = hom[:, :2] / hom[:, 3:4]
+    H, W = int(cam.image_height), int(cam.image_width)
+    return torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], dim=1)
+
+
+def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           log_deform_path=None, no_shadow=False, render_static=False, project_vertices=False) -> RenderResults:
+    """Render the scene (background tensor must be on the GPU)."""
+    base_xyz = pc.get_xyz()
+    dev = base_xyz.device
+    # zero tensor whose gradient is the screen-space (NDC) gradient of the 2D means (used by densification)
+    screenspace_points = torch.zeros_like(base_xyz, dtype=base_xyz.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform.to(dev), projmatrix=viewpoint_camera.full_proj_transform.to(dev),
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center.to(dev), prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    if pipe.compute_cov3D_python:
+        cov3D_precomp, scales = pc.get_covariance(scaling_modifier), None
+    else:
+        cov3D_precomp, scales = None, pc.get_scaling
+    opacity = pc.get_opacity
+
+    time = torch.tensor(viewpoint_camera.time).to(pc.mesh.pos.device).repeat(pc.mesh.pos.shape[0], 1)
+    if render_static:
+        vertice_deform = pc.mesh.pos
+        means3D_deform = base_xyz
+        rotations_deform = pc.get_rotation()
+    else:
+        vertice_deform = simulator(time_vector=time)
+        means3D_deform = pc.get_xyz(vertice_deform)
+        rotations_deform = pc.get_rotation(vertice_deform)
+
+    if log_deform_path is not None:
+        np.savez(log_deform_path, means3D=base_xyz.detach().cpu().numpy(),
+                 means3D_deform=means3D_deform.detach().cpu().numpy(),
+                 vertice_deform=vertice_deform.detach().cpu().numpy(), rotations=rotations_deform.detach().cpu().numpy(),
+                 vertice_rotations=pc.get_vertice_rotation(vertice_deform).detach().cpu().numpy())
+
+    # shadow scalars are disabled in the reference (always None): colours come from SH inside the rasterizer
+    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+
+    rendered_image, radii, depth = rasterizer(
+        means3D=means3D_deform, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=None if cov3D_precomp is not None else rotations_deform, cov3D_precomp=cov3D_precomp)
+
+    gaussian_projections = _project(viewpoint_camera, means3D_deform)
+    vertice_projections = _project(viewpoint_camera, vertice_deform) if project_vertices else None
+
+    return RenderResults(render=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
+                         radii=radii, depth=depth, means3D_deform=means3D_deform, vertice_deform=vertice_deform,
+                         shadows_mean=None, shadows_std=None, projections=gaussian_projections,
+                         rotations=rotations_deform, opacities=opacity, shadows=None,
+                         vertice_projections=vertice_projections)

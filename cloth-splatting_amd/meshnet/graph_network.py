@@ -1,0 +1,153 @@
+"""Drop-in for /root/reference/meshnet/graph_network.py with the torch_geometric dependency replaced by the
+csplat HIP kernels.  Class names, constructor / forward signatures and state_dict keys are the reference's
+(`_encoder.node_fn.0.NN-0.weight`, `_processor.gnn_stacks.K.edge_fn.0.NN-0.weight`, ...), so `model-N.pt`
+checkpoints load unchanged (cloth_network.py:242-243).
+
+Semantics reproduced from PyG `MessagePassing(aggr='add')`:
+  x_j = x[edge_index[0]], x_i = x[edge_index[1]];  message = LN(MLP(cat[x_i, x_j, e]))   (graph_network.py:178-199)
+  aggregate = sum over edge_index[1], dim_size = N                                    (graph_network.py:136)
+  update gets the ORIGINAL edge features -> every layer returns edge_out = 2 * edge_in  (graph_network.py:173-176,222)
+
+MI355X design: the [E, 3L] concat is never built.  W1 of the edge MLP is applied as three column blocks:
+x @ W_i^T and x @ W_j^T at node level (N rows), e @ W_e^T at edge level; csplat_gnn_edge_combine_fwd gathers and
+adds them (+ReLU) in one HBM pass.  The scatter-add is csplat_gnn_segment_sum over a CSR-by-destination order
+(deterministic).  The node MLP's cat[agg, x] is likewise split.  GEMMs stay on rocBLAS (torch.addmm).
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .graph_ops import EdgeCombine, GraphCSR, SegmentSum
+
+
+def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
+              output_activation: nn.Module = nn.Identity, activation: nn.Module = nn.ReLU) -> nn.Module:
+    """graph_network.py:7-45 -- Sequential of Linear "NN-i" / activation "Act-i"."""
+    layer_sizes = [input_size] + hidden_layer_sizes
+    if output_size:
+        layer_sizes.append(output_size)
+    nlayers = len(layer_sizes) - 1
+    act = [activation for _ in range(nlayers)]
+    act[-1] = output_activation
+    mlp = nn.Sequential()
+    for i in range(nlayers):
+        mlp.add_module("NN-" + str(i), nn.Linear(layer_sizes[i], layer_sizes[i + 1]))
+        mlp.add_module("Act-" + str(i), act[i]())
+    return mlp
+
+
+class Encoder(nn.Module):
+    """graph_network.py:48-111"""
+
+    def __init__(self, nnode_in_features: int, nnode_out_features: int, nedge_in_features: int, nedge_out_features: int,
+                 nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.node_fn = nn.Sequential(*[build_mlp(nnode_in_features, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nnode_out_features), nn.LayerNorm(nnode_out_features)])
+        self.edge_fn = nn.Sequential(*[build_mlp(nedge_in_features, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nedge_out_features), nn.LayerNorm(nedge_out_features)])
+
+    def forward(self, x: torch.Tensor, edge_features: torch.Tensor):
+        return self.node_fn(x), self.edge_fn(edge_features)
+
+
+def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool) -> torch.Tensor:
+    """run build_mlp's layers after the first Linear (whose activation has already been applied iff first_has_act)."""
+    mods = list(seq_mlp.children())
+    start = 2 if first_has_act else 1  # skip NN-0 (+ Act-0 when it was fused)
+    for m in mods[start:]:
+        h = m(h)
+    return h
+
+
+class InteractionNetwork(nn.Module):
+    """graph_network.py:114-222 (PyG MessagePassing, aggr='add')."""
+
+    def __init__(self, nnode_in: int, nnode_out: int, nedge_in: int, nedge_out: int, nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.aggr = 'add'
+        self.node_fn = nn.Sequential(*[build_mlp(nnode_in + nedge_out, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nnode_out), nn.LayerNorm(nnode_out)])
+        self.edge_fn = nn.Sequential(*[build_mlp(nnode_in + nnode_in + nedge_in, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nedge_out), nn.LayerNorm(nedge_out)])
+        self._nnode_in, self._nedge_in = nnode_in, nedge_in
+
+    def forward(self, x, edge_index, edge_features):
+        x_residual, edge_features_residual = x, edge_features
+        csr = GraphCSR.get(edge_index, x.shape[0])
+        n = self._nnode_in
+        # ---- message: LN(MLP(cat[x_i, x_j, e])) with the first Linear split into three column blocks
+        mlp_e = self.edge_fn[0]
+        lin0 = mlp_e[0]
+        relu0 = isinstance(mlp_e[1], nn.ReLU)
+        W = lin0.weight
+        xa = x @ W[:, :n].t()                       # contribution of x_i = x[edge_index[1]]
+        xb = x @ W[:, n:2 * n].t()                  # contribution of x_j = x[edge_index[0]]
+        ec = torch.addmm(lin0.bias, edge_features, W[:, 2 * n:].t())
+        h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
+        h = _tail(mlp_e, h, relu0)
+        msg = self.edge_fn[1](h)
+        # ---- aggregate: sum over destination nodes
+        agg = SegmentSum.apply(msg, csr)
+        # ---- update: LN(MLP(cat[agg, x])), concat folded into two GEMMs
+        mlp_n = self.node_fn[0]
+        l0 = mlp_n[0]
+        a = agg.shape[1]
+        hn = torch.addmm(l0.bias, agg, l0.weight[:, :a].t()) + x @ l0.weight[:, a:].t()
+        hn = mlp_n[1](hn)
+        hn = _tail(mlp_n, hn, True)
+        x_updated = self.node_fn[1](hn)
+        # PyG hands update() the ORIGINAL edge features: edge output = input + input
+        return x_updated + x_residual, edge_features + edge_features_residual
+
+
+class Processor(nn.Module):
+    """graph_network.py:225-292 (declared aggr='max' upstream but never propagates itself)."""
+
+    def __init__(self, nnode_in: int, nnode_out: int, nedge_in: int, nedge_out: int, nmessage_passing_steps: int,
+                 nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.aggr = 'max'
+        self.gnn_stacks = nn.ModuleList([
+            InteractionNetwork(nnode_in=nnode_in, nnode_out=nnode_out, nedge_in=nedge_in, nedge_out=nedge_out,
+                               nmlp_layers=nmlp_layers, mlp_hidden_dim=mlp_hidden_dim)
+            for _ in range(nmessage_passing_steps)])
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+        for gnn in self.gnn_stacks:
+            x, edge_features = gnn(x, edge_index, edge_features)
+        return x, edge_features
+
+
+class Decoder(nn.Module):
+    """graph_network.py:295-332"""
+
+    def __init__(self, nnode_in: int, nnode_out: int, nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.node_fn = build_mlp(nnode_in, [mlp_hidden_dim for _ in range(nmlp_layers)], nnode_out)
+
+    def forward(self, x: torch.Tensor):
+        return self.node_fn(x)
+
+
+class EncodeProcessDecode(nn.Module):
+    """graph_network.py:335-408"""
+
+    def __init__(self, nnode_in_features: int, nnode_out_features: int, nedge_in_features: int, latent_dim: int,
+                 nmessage_passing_steps: int, nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self._encoder = Encoder(nnode_in_features=nnode_in_features, nnode_out_features=latent_dim,
+                                nedge_in_features=nedge_in_features, nedge_out_features=latent_dim,
+                                nmlp_layers=nmlp_layers, mlp_hidden_dim=mlp_hidden_dim)
+        self._processor = Processor(nnode_in=latent_dim, nnode_out=latent_dim, nedge_in=latent_dim, nedge_out=latent_dim,
+                                    nmessage_passing_steps=nmessage_passing_steps, nmlp_layers=nmlp_layers,
+                                    mlp_hidden_dim=mlp_hidden_dim)
+        self._decoder = Decoder(nnode_in=latent_dim, nnode_out=nnode_out_features, nmlp_layers=nmlp_layers,
+                                mlp_hidden_dim=mlp_hidden_dim)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+        x, edge_features = self._encoder(x, edge_features)
+        x, edge_features = self._processor(x, edge_index, edge_features)
+        x = self._decoder(x)
+        return x

@@ -1,0 +1,110 @@
+"""Autograd wrappers around the csplat_gnn_* C-ABI entry points (include/csplat.h): the gather / concat /
+scatter-add that torch_geometric's MessagePassing.propagate performs for InteractionNetwork
+(/root/reference/meshnet/graph_network.py:136,173-174,197).  GPU only; no fallback."""
+import weakref
+
+import torch
+
+from csplat import native as _n
+
+
+class GraphCSR:
+    """Two CSR orderings (by destination = edge_index[1], by source = edge_index[0]) of one edge list, built once
+    per graph on the GPU and reused by every message-passing layer and by the backward pass."""
+
+    _cache = {}
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        _n.require_cuda(edge_index)
+        assert edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.shape[0] == 2
+        self.ei = edge_index.contiguous()
+        self.N, self.E = int(num_nodes), int(edge_index.shape[1])
+        dev = edge_index.device
+        self.rowptr, self.perm = {}, {}
+        tmp = torch.empty(max(int(_n.lib.csplat_gnn_csr_temp_bytes(self.N, self.E)), 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            for name, row in (("src", 0), ("dst", 1)):
+                rp = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+                pm = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+                _n.check(_n.lib.csplat_gnn_build_csr(_n.stream_handle(dev), self.N, self.E, self.ei[row].data_ptr(),
+                                                     _n.ptr(rp), _n.ptr(pm), _n.ptr(tmp)), "csplat_gnn_build_csr")
+                self.rowptr[name], self.perm[name] = rp, pm
+
+    @classmethod
+    def get(cls, edge_index, num_nodes):
+        """CSR for this edge_index tensor OBJECT (weakly referenced) at its current in-place version."""
+        key = id(edge_index)
+        hit = cls._cache.get(key)
+        if hit is not None:
+            ref, version, n, csr = hit
+            if ref() is edge_index and version == edge_index._version and n == int(num_nodes):
+                return csr
+        for k in [k for k, v in cls._cache.items() if v[0]() is None]:
+            del cls._cache[k]
+        csr = cls(edge_index, num_nodes)
+        cls._cache[key] = (weakref.ref(edge_index), edge_index._version, int(num_nodes), csr)
+        return csr
+
+
+def _f32(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+class EdgeCombine(torch.autograd.Function):
+    """h[e] = relu?(xa[dst[e]] + xb[src[e]] + ec[e]) -- first edge-MLP layer with the [x_i, x_j, e] concat folded away."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, ec, csr, relu):
+        xa, xb, ec = _f32(xa), _f32(xb), _f32(ec)
+        E, L = ec.shape
+        out = torch.empty_like(ec)
+        with torch.cuda.device(ec.device):
+            _n.check(_n.lib.csplat_gnn_edge_combine_fwd(_n.stream_handle(ec.device), csr.N, E, L, _n.ptr(csr.ei), _n.ptr(xa),
+                                                        _n.ptr(xb), _n.ptr(ec), int(relu), _n.ptr(out)),
+                     "csplat_gnn_edge_combine_fwd")
+        ctx.csr, ctx.relu = csr, bool(relu)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        csr = ctx.csr
+        g = _f32(g)
+        E, L = out.shape
+        gm = torch.empty_like(g) if ctx.relu else g
+        dxa = torch.empty(csr.N, L, dtype=torch.float32, device=g.device)
+        dxb = torch.empty_like(dxa)
+        with torch.cuda.device(g.device):
+            _n.check(_n.lib.csplat_gnn_edge_combine_bwd(
+                _n.stream_handle(g.device), csr.N, E, L, _n.ptr(g), _n.ptr(out), int(ctx.relu), _n.ptr(csr.rowptr["dst"]),
+                _n.ptr(csr.perm["dst"]), _n.ptr(csr.rowptr["src"]), _n.ptr(csr.perm["src"]), _n.ptr(gm), _n.ptr(dxa),
+                _n.ptr(dxb)), "csplat_gnn_edge_combine_bwd")
+        return dxa, dxb, gm, None, None
+
+
+class SegmentSum(torch.autograd.Function):
+    """agg[n] = sum_{e: dst(e) = n} msg[e]  (aggr='add', dim_size = N), fixed ascending-edge-id order."""
+
+    @staticmethod
+    def forward(ctx, msg, csr):
+        msg = _f32(msg)
+        E, L = msg.shape
+        agg = torch.empty(csr.N, L, dtype=torch.float32, device=msg.device)
+        with torch.cuda.device(msg.device):
+            _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(msg.device), csr.N, E, L, _n.ptr(msg),
+                                                   _n.ptr(csr.rowptr["dst"]), _n.ptr(csr.perm["dst"]), _n.ptr(agg)),
+                     "csplat_gnn_segment_sum")
+        ctx.csr = csr
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        csr = ctx.csr
+        g = _f32(g)
+        L = g.shape[1]
+        out = torch.empty(csr.E, L, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _n.check(_n.lib.csplat_gnn_gather_rows(_n.stream_handle(g.device), csr.E, L, _n.ptr(g), csr.ei[1].data_ptr(),
+                                                   _n.ptr(out)), "csplat_gnn_gather_rows")
+        return out, None

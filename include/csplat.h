@@ -91,12 +91,21 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
 /* distCUDA2: out[i] = mean of squared distances from point i to its 3 nearest other points. */
 int csplat_dist2(void *stream, int P, const float *xyz, float *out);
 
+/* ---- in-library kernel timing (HIP events on the launch stream; used by bench.py's roofline leg) ------
+ * mask bit k enables bracketing of kernel class k with a start/stop event pair on the stream it is launched on:
+ *   0 K1 preprocess | 1 K2 scan | 2 K3 key emission | 3 K4 radix sort (all passes) | 4 K5 tile ranges
+ *   5 K6 compositing fwd | 6 K7 compositing bwd | 7 K8 preprocess bwd | 8 distCUDA2 | 9 GNN kernels
+ * csplat_prof_read synchronises the recorded events of class k, returns their summed duration (ms) and the
+ * number of brackets, and recycles the events. */
+int csplat_prof_enable(unsigned mask);
+int csplat_prof_read(int kernel_class, double *ms_total, int64_t *launches);
+
 /* ---- MeshNet message passing (meshnet/graph_network.py:151-222) ------------------------------------
  * Graph structure is passed as two CSR orderings of the E directed edges, built once per graph by
  * csplat_gnn_build_csr: for key in {dst = edge_index[1], src = edge_index[0]}:
  *   rowptr[N+1] (int32) and perm[E] (int32) listing edge ids grouped by key, ascending edge id inside a row
  *   (=> a fixed, reproducible summation order; no float atomics on this path).
- * L (latent width) must be a multiple of 4. */
+ * Rows of L floats move as float4 (16 B per lane) when L % 4 == 0, as scalars otherwise. */
 size_t csplat_gnn_csr_temp_bytes(int N, int64_t E);
 int csplat_gnn_build_csr(void *stream, int N, int64_t E, const int64_t *keys /* device, [E] */, int32_t *rowptr,
                          int32_t *perm, void *temp);

@@ -1,0 +1,155 @@
+"""GPU parity of distCUDA2 and of the MeshNet message-passing path (through the C-ABI) against the oracle and the
+shim-derived golden vectors of the reference modules."""
+import numpy as np
+import pytest
+
+import util
+from util import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+from oracle import gnn_ref, raster_oracle as ro  # noqa: E402
+
+
+def test_dist2_bit_exact_vs_oracle():
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(5)
+    for P in (4, 100, 1023, 5000):
+        pts = rng.normal(size=(P, 3)).astype(np.float32)
+        if P > 20:
+            pts[10] = pts[11]                      # coincident points
+        got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
+        np.testing.assert_array_equal(got, ro.dist2(pts))       # same fp32 association order: bit-exact
+    assert distCUDA2(torch.zeros(0, 3, device="cuda")).numel() == 0
+
+
+def test_dist2_full_size_vs_kdtree():
+    """config-2 size: 100k points of synthetic scene_1 against scipy's exact kd-tree (tolerance 1e-6 rel)."""
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    from csplat import synthetic as syn
+    sc = syn.scene_1(P=100_000, n_cams=1)
+    pts = syn.gaussians_at(sc)["means3D"]
+    got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy().astype(np.float64)
+    dd, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    ref = (dd[:, 1:] ** 2).mean(1)
+    assert np.abs(got - ref).max() <= 1e-6 * ref.max() + 1e-12
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-12)   # per-point: fp32 squared differences of ~1e-3 offsets
+
+
+def _load(net, g, prefix):
+    sd = {k[len(prefix):]: torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
+    net.load_state_dict(sd)
+    return net.cuda()
+
+
+def test_interaction_network_matches_reference_incl_f7():
+    g = golden("gnn.npz")
+    from meshnet.graph_network import InteractionNetwork
+    net = _load(InteractionNetwork(16, 16, 16, 16, 2, 16), g, "inet.")
+    ei = torch.tensor(g["edge_index"], device="cuda")
+    x1, e1 = net(torch.tensor(g["in_x"], device="cuda"), ei, torch.tensor(g["in_e"], device="cuda"))
+    assert rel_err(x1.detach().cpu().numpy(), g["in_x_out"]) < 1e-4
+    np.testing.assert_array_equal(e1.detach().cpu().numpy(), g["in_e_out"])     # edge output = 2 x edge input (F7)
+
+
+def test_encode_process_decode_forward_backward_vs_reference():
+    g = golden("gnn.npz")
+    from meshnet.graph_network import EncodeProcessDecode
+    net = _load(EncodeProcessDecode(8, 3, 4, 32, 3, 2, 32), g, "epd.")
+    ei = torch.tensor(g["edge_index"], device="cuda")
+    x = torch.tensor(g["epd_x"], device="cuda", requires_grad=True)
+    e = torch.tensor(g["epd_e"], device="cuda", requires_grad=True)
+    y = net(x, ei, e)
+    assert rel_err(y.detach().cpu().numpy(), g["epd_y"]) < 1e-4                  # GNN output <= 1e-4 rel
+    (y * torch.tensor(g["epd_w"], device="cuda")).sum().backward()
+    assert rel_err(x.grad.cpu().numpy(), g["epd_dx"]) < 1e-4
+    assert rel_err(e.grad.cpu().numpy(), g["epd_de"]) < 1e-4
+    dW = net._processor.gnn_stacks[0].edge_fn[0][0].weight.grad.cpu().numpy()
+    assert rel_err(dW, g["epd_dW_first"]) < 1e-4
+
+
+def test_cloth_simulator_vs_reference():
+    g = golden("gnn.npz")
+    from meshnet.cloth_network import ClothMeshSimulator
+    dev = "cuda"
+    sim = ClothMeshSimulator(3, 8, 4, 32, 2, 2, 32, 2, 2, normalize=True, device=dev)
+    sim.load_state_dict({k[4:]: torch.tensor(g[k]) for k in g.files if k.startswith("sim.") and not k.startswith("sim_")})
+    sim = sim.to(dev)
+    T = lambda k: torch.tensor(g[k], device=dev)  # noqa: E731
+    ei = T("edge_index")
+    sim.train()
+    pa, ta = sim.predict_acceleration(T("sim_vel"), T("sim_type"), ei, T("epd_e"), target_velocities=T("sim_tgt"),
+                                      velocity_noise=T("sim_noise"))
+    assert rel_err(pa.detach().cpu().numpy(), g["sim_pred_acc"]) < 1e-4
+    assert rel_err(ta.detach().cpu().numpy(), g["sim_tgt_acc"]) < 1e-4
+    np.testing.assert_allclose(sim._node_normalizer._acc_sum.cpu().numpy(), g["sim_node_normalizer._acc_sum"], rtol=1e-5)
+    sim.eval()
+    pv = sim.predict_velocity(T("sim_vel"), T("sim_type"), ei, T("epd_e"))
+    assert rel_err(pv.detach().cpu().numpy(), g["sim_pred_vel"]) < 1e-4
+    sim2 = ClothMeshSimulator(3, 8, 4, 32, 2, 2, 32, 2, 2, normalize=False, device=dev)
+    sim2.load_state_dict({k[5:]: torch.tensor(g[k]) for k in g.files if k.startswith("sim2.")})
+    sim2 = sim2.to(dev).eval()
+    assert rel_err(sim2.predict_velocity(T("sim_vel"), T("sim_type"), ei, T("epd_e")).detach().cpu().numpy(),
+                   g["sim2_pred_vel"]) < 1e-4
+
+
+@pytest.mark.parametrize("L,N,E", [(128, 500, 6000), (32, 64, 0), (20, 300, 2000), (6, 50, 400)])
+def test_gnn_kernels_vs_numpy(L, N, E):
+    """raw C-ABI kernels: CSR build, edge combine fwd/bwd, segment sum (== sequential index_add, bit-exact), row gather.
+    Ragged degrees incl. isolated nodes, empty edge list, widths that are / are not multiples of 4."""
+    from meshnet.graph_ops import EdgeCombine, GraphCSR, SegmentSum
+    rng = np.random.default_rng(L)
+    ei_np = rng.integers(0, max(N - 5, 1), size=(2, E)).astype(np.int64)      # last 5 nodes isolated
+    ei = torch.tensor(ei_np, device="cuda")
+    csr = GraphCSR(ei, N)
+    for name, row in (("src", 0), ("dst", 1)):
+        rp, pm = csr.rowptr[name].cpu().numpy(), csr.perm[name].cpu().numpy()[:E]
+        np.testing.assert_array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(ei_np[row], minlength=N))]))
+        np.testing.assert_array_equal(pm, np.argsort(ei_np[row], kind="stable"))   # ascending edge id inside a row
+    msg = rng.normal(size=(E, L)).astype(np.float32)
+    m = torch.tensor(msg, device="cuda", requires_grad=True)
+    agg = SegmentSum.apply(m, csr)
+    ref = np.zeros((N, L), np.float32)
+    np.add.at(ref, ei_np[1], msg)                                             # sequential fp32 adds in edge order
+    np.testing.assert_array_equal(agg.detach().cpu().numpy(), ref)
+    gout = rng.normal(size=(N, L)).astype(np.float32)
+    agg.backward(torch.tensor(gout, device="cuda"))
+    np.testing.assert_array_equal(m.grad.cpu().numpy(), gout[ei_np[1]])
+    xa, xb = rng.normal(size=(N, L)).astype(np.float32), rng.normal(size=(N, L)).astype(np.float32)
+    ec = rng.normal(size=(E, L)).astype(np.float32)
+    txa, txb, tec = (torch.tensor(a, device="cuda", requires_grad=True) for a in (xa, xb, ec))
+    h = EdgeCombine.apply(txa, txb, tec, csr, True)
+    href = np.maximum((xa[ei_np[1]] + xb[ei_np[0]]) + ec, 0)
+    np.testing.assert_array_equal(h.detach().cpu().numpy(), href)
+    gh = rng.normal(size=(E, L)).astype(np.float32)
+    h.backward(torch.tensor(gh, device="cuda"))
+    gm = gh * (href > 0)
+    dxa = np.zeros((N, L), np.float32); np.add.at(dxa, ei_np[1], gm)
+    dxb = np.zeros((N, L), np.float32); np.add.at(dxb, ei_np[0], gm)
+    np.testing.assert_array_equal(tec.grad.cpu().numpy(), gm)
+    np.testing.assert_array_equal(txa.grad.cpu().numpy(), dxa)
+    np.testing.assert_array_equal(txb.grad.cpu().numpy(), dxb)
+
+
+def test_config4_size_rollout_step_properties():
+    """BASELINE config 4 shape (N=10k, E=300k, L=128, 15 steps): finite output, determinism (no float atomics)
+    and agreement with the fp64 numpy oracle on the same weights."""
+    from meshnet.cloth_network import ClothMeshSimulator
+    torch.manual_seed(0)
+    sim = ClothMeshSimulator(3, 8, 4, 128, 15, 2, 128, 2, 2, normalize=False, device="cuda").eval()
+    N, E = 10_000, 300_000
+    gen = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, N, (2, E), generator=gen).cuda()
+    vel = (torch.randn(N, 6, generator=gen) * 0.1).cuda()
+    ntype = torch.randint(0, 2, (N, 1), generator=gen).cuda()
+    ef = torch.randn(E, 4, generator=gen).cuda()
+    with torch.no_grad():
+        a = sim.predict_velocity(vel, ntype, ei, ef)
+        b = sim.predict_velocity(vel, ntype, ei, ef)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)                                                   # reproducible bit for bit
+    feats = torch.cat([vel, torch.nn.functional.one_hot(ntype.squeeze().long(), 2)], 1).cpu().numpy()
+    p = {k: v.detach().cpu().numpy() for k, v in sim._encode_process_decode.state_dict().items()}
+    ref = vel[:, -3:].cpu().numpy() + gnn_ref.encode_process_decode(p, feats, ei.cpu().numpy(), ef.cpu().numpy())
+    assert rel_err(a.cpu().numpy(), ref) < 1e-4

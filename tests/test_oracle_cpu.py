@@ -1,0 +1,311 @@
+"""CPU suite (-m "not gpu"): the oracle against the golden vectors captured from the reference's importable modules
+(tests/golden/make_golden.py), the two independent restatements against each other, host-side logic, and the C-ABI
+export list.  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from util import golden, make_case, oracle_forward, rel_err
+
+torch = pytest.importorskip("torch")
+from csplat import synthetic as syn  # noqa: E402
+from oracle import gnn_ref, raster_oracle as ro, raster_torch as rt  # noqa: E402
+
+
+# ------------------------------------------------------------------ golden: camera math (cameras.py / graphics_utils.py)
+def test_camera_matrices_match_reference():
+    g = golden("camera.npz")
+    for k in range(g["R"].shape[0]):
+        R, T = syn.c2w_to_RT(g["c2w"][k])
+        np.testing.assert_allclose(R, g["R"][k], atol=1e-12)
+        np.testing.assert_allclose(T, g["T"][k], atol=1e-12)
+        wv, full, center = syn.camera_matrices(R, T, float(g["fovx"][k]), float(g["fovy"][k]))
+        np.testing.assert_allclose(wv, g["world_view_transform"][k], atol=1e-6)
+        np.testing.assert_allclose(full, g["full_proj_transform"][k], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(center, g["camera_center"][k], atol=2e-5)
+    np.testing.assert_allclose(syn.projection_matrix(0.01, 100.0, 0.6911, 0.5), g["proj_0p01_100"], atol=1e-7)
+    np.testing.assert_allclose(syn.world_to_view(g["R"][0], g["T"][0], np.array([0.1, -0.2, 0.3]), 1.5),
+                               g["w2v2_translate"], atol=1e-6)
+
+
+# ------------------------------------------------------------------ golden: SH -> RGB stage of K1 (utils/sh_utils.py)
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_oracle_sh_matches_reference_eval_sh(deg):
+    g = golden("sh.npz")
+    sh = np.ascontiguousarray(g["sh"].transpose(0, 2, 1))  # reference layout [N,3,16] -> rasterizer layout [N,16,3]
+    dirs = g["dirs"]
+    n = dirs.shape[0]
+    # a camera that sees every point at depth 1 and for which normalize(p - campos) == dirs
+    view = np.zeros((4, 4), np.float32); view[0, 0] = view[1, 1] = 1; view[3, 2] = 1.0; view[3, 3] = 1
+    proj = np.zeros((4, 4), np.float32); proj[0, 0] = proj[1, 1] = 0.3; proj[3, 3] = 1
+    for dt, tol in ((np.float32, 3e-6), (np.float64, 2e-6)):
+        o = ro.forward(dirs, np.full(n, 0.5), view, proj, np.zeros(3), 0.5, 0.5, 64, 64, np.zeros(3), shs=sh,
+                       sh_degree=deg, scales=np.full((n, 3), 0.05), rotations=np.tile([1.0, 0, 0, 0], (n, 1)), dtype=dt,
+                       stages="preprocess")
+        assert (o.radii > 0).all()
+        np.testing.assert_allclose(o.rgb, g[f"clamped_deg{deg}"], atol=tol)
+        np.testing.assert_array_equal(o.clamped.astype(bool), (g[f"rgb_deg{deg}"] + 0.5) < 0)
+    t = rt._eval_sh(deg, torch.tensor(sh, dtype=torch.float64), torch.tensor(dirs, dtype=torch.float64)).numpy()
+    np.testing.assert_allclose(t, g[f"rgb_deg{deg}"], atol=2e-6)
+
+
+def test_misc_golden():
+    g = golden("misc.npz")
+    a, b = g["psnr_a"], g["psnr_b"]
+    mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1, keepdims=True)
+    np.testing.assert_allclose(20 * np.log10(1.0 / np.sqrt(mse)), g["psnr"], rtol=1e-5)
+    x = g["inv_sigmoid_in"]
+    np.testing.assert_allclose(np.log(x / (1 - x)), g["inv_sigmoid"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the two restatements agree; analytic bwd == autograd
+def _small_case():
+    case = make_case(P=600, W=64, H=64, seed=21, grid=12, scale_mul=3.0)
+    return case
+
+
+def test_c_forward_equals_torch_forward():
+    case = _small_case()
+    o = oracle_forward(case, dtype=np.float64)
+    g = case["g"]
+    T = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
+    color, depth, ncon = rt.render(o, T(g["means3D"]), torch.zeros(case["P"], 3, dtype=torch.float64), T(g["opacities"]),
+                                   shs=T(g["shs"]), scales=T(g["scales"]), rotations=T(g["rotations"]))
+    assert np.abs(color.numpy() - o.color).max() < 1e-12
+    assert np.abs(depth.numpy() - o.out_depth).max() < 1e-11
+    assert (ncon.numpy() != o.n_contrib).sum() == 0
+    assert o.R > 500 and o.n_contrib.max() > 50  # the case exercises deep lists and early termination
+
+
+@pytest.mark.parametrize("mode", ["sh_scale_rot", "precomp", "deg1_mod"])
+def test_c_backward_equals_autograd(mode):
+    case = _small_case()
+    g = case["g"]
+    P = case["P"]
+    rng = np.random.default_rng(4)
+    dpix = rng.normal(size=(3, case["H"], case["W"]))
+    T = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)  # noqa: E731
+    m3, m2, op = T(g["means3D"]), T(np.zeros((P, 3))), T(g["opacities"])
+    mod = 1.0
+    if mode == "precomp":
+        o0 = oracle_forward(case, dtype=np.float64)
+        colors = rng.uniform(0, 1, size=(P, 3))
+        kw = dict(shs=None, colors_precomp=colors, scales=None, rotations=None, cov3D_precomp=o0.cov3D)
+        o = oracle_forward(case, dtype=np.float64, **kw)
+        col, cov = T(colors), T(o0.cov3D)
+        color, _, _ = rt.render(o, m3, m2, op, colors_precomp=col, cov3D_precomp=cov)
+    else:
+        if mode == "deg1_mod":
+            case["sh_degree"] = 1
+            mod = 1.6
+        o = oracle_forward(case, dtype=np.float64, scale_mod=mod)
+        sh, scl, rot = T(g["shs"]), T(g["scales"]), T(g["rotations"])
+        color, _, _ = rt.render(o, m3, m2, op, shs=sh, scales=scl, rotations=rot)
+    gr = ro.backward(o, dpix)
+    (color * torch.tensor(dpix)).sum().backward()
+    # 1/(det^2 + 1e-7) guard of the analytic path vs exact autograd: <= 1e-6 relative on this case
+    assert rel_err(gr.mean3D, m3.grad.numpy()) < 1e-6
+    assert rel_err(gr.mean2D, m2.grad.numpy()) < 1e-12
+    assert rel_err(gr.opacity, op.grad.numpy().reshape(-1)) < 1e-12
+    if mode == "precomp":
+        assert rel_err(gr.color, col.grad.numpy()) < 1e-12
+        assert rel_err(gr.cov3D, cov.grad.numpy()) < 1e-5
+    else:
+        assert rel_err(gr.sh, sh.grad.numpy()) < 1e-12
+        # upstream quirk: dL/dscale is the gradient w.r.t. (modifier * scale)
+        assert rel_err(gr.scale * mod, scl.grad.numpy()) < 1e-5
+        assert rel_err(gr.rot, rot.grad.numpy()) < 1e-5
+
+
+def test_f32_oracle_tracks_f64_oracle():
+    case = make_case(P=2000, W=128, H=96, seed=7, grid=20)
+    o32, o64 = oracle_forward(case), oracle_forward(case, dtype=np.float64)
+    assert rel_err(o32.color, o64.color) < 1e-5 and rel_err(o32.out_depth, o64.out_depth) < 1e-5
+    assert (o32.radii != o64.radii).mean() < 0.01
+    dpix = np.random.default_rng(0).normal(size=(3, 96, 128)).astype(np.float32)
+    g32, g64 = ro.backward(o32, dpix), ro.backward(o64, dpix)
+    for k in ("mean3D", "mean2D", "opacity", "sh", "scale", "rot"):
+        assert rel_err(getattr(g32, k), getattr(g64, k)) < 2e-4, k
+
+
+def test_binning_invariants_and_edge_cases():
+    case = make_case(P=3000, W=200, H=136, seed=8, grid=16, scale_mul=2.5)  # ragged image size
+    o = oracle_forward(case)
+    assert o.R == int(o.tiles_touched.sum()) and o.R == len(o.keys)
+    assert np.all(o.keys[1:] >= o.keys[:-1])
+    eq = o.keys[1:] == o.keys[:-1]
+    assert np.all(o.ids[1:][eq] > o.ids[:-1][eq])           # stable: equal (tile, depth) keeps ascending id
+    assert int((o.ranges[:, 1] - o.ranges[:, 0]).sum()) == o.R
+    area = (o.rect[:, 2] - o.rect[:, 0]) * (o.rect[:, 3] - o.rect[:, 1])
+    np.testing.assert_array_equal(area[o.radii > 0], o.tiles_touched[o.radii > 0])
+    # everything behind the camera: nothing rendered, image = background
+    far = dict(case); far["g"] = dict(case["g"]); far["g"]["means3D"] = case["g"]["means3D"] + case["cam"]["camera_center"] * 3
+    oz = oracle_forward(far)
+    assert oz.R == 0 and int(oz.radii.max()) == 0 and np.allclose(oz.color, 1.0)
+
+
+def test_known_answer_single_gaussian_cpu():
+    W = H = 64
+    cam = syn.make_camera(0.0, W, H, radius=4.0)
+    s = 0.05
+    o = ro.forward(np.zeros((1, 3)), np.array([0.8]), cam["world_view_transform"], cam["full_proj_transform"],
+                   cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H, np.zeros(3),
+                   colors_precomp=np.array([[1.0, 0.5, 0.25]]), scales=np.full((1, 3), s), rotations=np.array([[1.0, 0, 0, 0]]),
+                   dtype=np.float64)
+    focal = W / (2 * cam["tanfovx"])
+    sigma2 = (s * focal / 4.0) ** 2 + 0.3
+    assert int(o.radii[0]) == int(np.ceil(3 * np.sqrt(sigma2 + np.sqrt(0.1))))  # lambda = mid + sqrt(max(0.1, mid^2 - det))
+    np.testing.assert_allclose(o.xy[0], [(W - 1) / 2, (H - 1) / 2], atol=1e-4)
+    alpha = 0.8 * np.exp(-0.25 / sigma2)
+    np.testing.assert_allclose(o.color[:, H // 2, W // 2], alpha * np.array([1.0, 0.5, 0.25]), rtol=1e-5)
+    np.testing.assert_allclose(o.out_depth[0, H // 2, W // 2], alpha * 4.0, rtol=1e-5)
+    assert o.n_contrib[H // 2, W // 2] == 1 and o.n_contrib[0, 0] == 0
+
+
+# ------------------------------------------------------------------ distCUDA2 restatement
+def test_knn_oracle_vs_kdtree():
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(3000, 3)).astype(np.float32)
+    pts[10] = pts[11]  # coincident pair -> one zero distance
+    d64 = ro.dist2(pts, np.float64)
+    dd, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    np.testing.assert_allclose(d64, (dd[:, 1:] ** 2).mean(1), rtol=1e-10, atol=1e-14)
+    d32 = ro.dist2(pts, np.float32)
+    np.testing.assert_allclose(d32, d64, rtol=1e-5)
+    assert ro.dist2(pts[:4], np.float64).shape == (4,)
+
+
+# ------------------------------------------------------------------ GNN restatement vs shim-derived goldens
+def test_gnn_oracle_matches_reference_modules():
+    g = golden("gnn.npz")
+    p = {k[4:]: g[k] for k in g.files if k.startswith("epd.")}
+    y = gnn_ref.encode_process_decode(p, g["epd_x"], g["edge_index"], g["epd_e"])
+    assert rel_err(y, g["epd_y"]) < 1e-5
+    pi = {"L." + k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith("inet.")}
+    x1, e1 = gnn_ref.interaction(pi, "L", g["in_x"].astype(np.float64), g["edge_index"], g["in_e"].astype(np.float64))
+    assert rel_err(x1, g["in_x_out"]) < 1e-5
+    np.testing.assert_array_equal(g["in_e_out"], 2 * g["in_e"])      # SURVEY F7 in the reference's own output
+    np.testing.assert_allclose(e1, g["in_e_out"], rtol=1e-7)
+
+
+def test_normalizer_oracle_and_module_match_reference():
+    g = golden("normalizer.npz")
+    nz = gnn_ref.Normalizer(5)
+    o1 = nz(g["b1"].astype(np.float64), True); o2 = nz(g["b2"].astype(np.float64), True); o3 = nz(g["b1"].astype(np.float64), False)
+    for a, k in ((o1, "o1"), (o2, "o2"), (o3, "o3"), (nz.inverse(o3), "inv")):
+        np.testing.assert_allclose(a, g[k], rtol=2e-4, atol=2e-5)
+    from meshnet.model_utils import Normalizer
+    m = Normalizer(size=5, device="cpu")
+    t = lambda a: torch.tensor(a)  # noqa: E731
+    r1 = m(t(g["b1"]), True); r2 = m(t(g["b2"]), True); r3 = m(t(g["b1"]), False)
+    for a, k in ((r1, "o1"), (r2, "o2"), (r3, "o3"), (m.inverse(r3), "inv")):
+        np.testing.assert_allclose(a.numpy(), g[k], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m._acc_sum.numpy(), g["acc_sum"], rtol=1e-6)
+    assert float(m._acc_count) == float(g["acc_count"]) and float(m._num_accumulations) == float(g["num_acc"])
+
+
+# ------------------------------------------------------------------ host logic of the drop-in modules (CPU torch)
+def test_simulators_match_reference():
+    g = golden("simulator.npz")
+    from meshnet.meshnet_network import ResidualMeshSimulator, ResidualMeshSimulatorEmbedding, SinusoidalEncoder
+    enc = SinusoidalEncoder(input_dim=1, num_freqs=6)
+    assert enc.output_dim == int(g["enc_dim"]) == 13
+    out = torch.stack([enc(t) for t in torch.tensor(g["enc_in"])])
+    np.testing.assert_allclose(out.numpy(), g["enc_out"], atol=1e-6)
+    enc3 = SinusoidalEncoder(input_dim=3, num_freqs=4, min_freq_log2=-1, scale=0.5, use_identity=False)
+    np.testing.assert_allclose(enc3(torch.tensor(g["enc3_in"])).numpy(), g["enc3_out"], atol=1e-6)
+    mesh = torch.tensor(g["res_mesh"])
+    V = mesh.shape[1]
+    sim = ResidualMeshSimulator(mesh, device="cpu")
+    sd = {k[4:]: torch.tensor(g[k]) for k in g.files if k.startswith("res.")}
+    assert set(sd) == set(sim.state_dict())              # checkpoint keys identical to the reference's
+    sim.load_state_dict(sd)
+    assert sim.time_delta == float(g["res_time_delta"])
+    for tt, ref in zip(g["res_times"], g["res_out"]):
+        got = sim(torch.tensor(float(tt)).repeat(V, 1))
+        np.testing.assert_allclose(got.detach().numpy(), ref, atol=1e-5)
+    assert ResidualMeshSimulator(mesh[:1], device="cpu").time_delta == float(g["res1_time_delta"]) == 1.0
+    with pytest.raises(ValueError):
+        sim(torch.tensor(1.3).repeat(V, 1))
+    assert int(g["res_oob_raises"]) == 1
+    emb = ResidualMeshSimulatorEmbedding(mesh, device="cpu")
+    emb.load_state_dict({k[4:]: torch.tensor(g[k]) for k in g.files if k.startswith("emb.")})
+    for tt, ref in zip(g["res_times"], g["emb_out"]):
+        np.testing.assert_allclose(emb(torch.tensor(float(tt)).repeat(V, 1)).detach().numpy(), ref, atol=1e-6)
+
+
+def test_gnn_module_state_dict_keys_and_fail_loud_on_cpu():
+    g = golden("gnn.npz")
+    from meshnet.graph_network import EncodeProcessDecode
+    from meshnet.cloth_network import ClothMeshSimulator
+    from csplat.native import CsplatError
+    net = EncodeProcessDecode(8, 3, 4, 32, 3, 2, 32)
+    ref_keys = {k[4:] for k in g.files if k.startswith("epd.")}
+    assert set(net.state_dict()) == ref_keys
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == g["epd." + k].shape
+    sim = ClothMeshSimulator(3, 8, 4, 32, 2, 2, 32, 2, 2, normalize=True, device="cpu")
+    assert set(sim.state_dict()) == {k[4:] for k in g.files if k.startswith("sim.")}
+    # the message-passing kernels have no CPU path: CPU tensors must raise, never silently fall back
+    with pytest.raises(CsplatError):
+        net(torch.tensor(g["epd_x"]), torch.tensor(g["edge_index"]), torch.tensor(g["epd_e"]))
+
+
+def test_rasterizer_dropin_fails_loudly_without_gpu_tensors():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from simple_knn._C import distCUDA2
+    from csplat.native import CsplatError
+    z = torch.zeros
+    rs = GaussianRasterizationSettings(16, 16, 0.5, 0.5, z(3), 1.0, torch.eye(4), torch.eye(4), 0, z(3), False, False)
+    with pytest.raises(CsplatError):
+        GaussianRasterizer(rs)(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 1, 3), scales=z(4, 3),
+                               rotations=z(4, 4))
+    with pytest.raises(CsplatError):
+        distCUDA2(z(8, 3))
+    with pytest.raises(Exception):   # argument validation mirrors upstream ("provide exactly one of ...")
+        GaussianRasterizer(rs)(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 1, 3), colors_precomp=z(4, 3),
+                               scales=z(4, 3), rotations=z(4, 4))
+
+
+def test_rotation_helpers():
+    from csplat import rotations as r
+    gen = torch.Generator().manual_seed(0)
+    Q = torch.linalg.qr(torch.randn(50, 3, 3, generator=gen, dtype=torch.float64))[0]
+    Q = Q * torch.det(Q)[:, None, None]
+    x = torch.randn(50, 3, 3, generator=gen, dtype=torch.float64)  # a triangle per item
+    y = x @ Q.transpose(1, 2) + torch.randn(50, 1, 3, generator=gen, dtype=torch.float64)
+    R, t = r.rigid_points_registration(x, y)
+    assert float((R @ x.transpose(1, 2) + t[:, :, None] - y.transpose(1, 2)).abs().max()) < 1e-9
+    q = r.rotmat_to_unitquat(Q)
+    # xyzw quaternion -> matrix round trip
+    X, Y, Z, Wq = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rq = torch.stack([1 - 2 * (Y * Y + Z * Z), 2 * (X * Y - Z * Wq), 2 * (X * Z + Y * Wq),
+                      2 * (X * Y + Z * Wq), 1 - 2 * (X * X + Z * Z), 2 * (Y * Z - X * Wq),
+                      2 * (X * Z - Y * Wq), 2 * (Y * Z + X * Wq), 1 - 2 * (X * X + Y * Y)], 1).reshape(-1, 3, 3)
+    assert float((Rq - Q).abs().max()) < 1e-9
+    ident = torch.tensor([[0.0, 0, 0, 1]], dtype=torch.float64).expand(50, 4)
+    assert float((r.quat_composition([q, ident]) - q).abs().max()) < 1e-12
+
+
+# ------------------------------------------------------------------ the C-ABI library loads and exports the header
+def test_cabi_exports_every_declared_symbol():
+    from csplat import native
+    hdr = open(os.path.join(util.ROOT, "include", "csplat.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(csplat_[a-z0-9_]+)\s*\(", hdr)) - {"csplat_alloc_fn"}
+    assert len(declared) >= 18
+    lib = C.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libcsplat.so does not export {name}"
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    assert native.lib.csplat_abi_version() == native.ABI_VERSION
+    # size / layout helpers are pure host code
+    assert native.lib.csplat_geom_bytes(1000) > 1000 * (4 + 8 + 16 + 12 + 24)
+    o3 = (C.c_size_t * 3)()
+    native.lib.csplat_image_layout(800, 800, o3)
+    assert o3[0] == 0 and o3[1] >= 2500 * 8 and o3[2] - o3[1] >= 640000 * 4

@@ -186,7 +186,7 @@ def test_known_answer_single_gaussian():
         scales=t([[s, s, s]]), rotations=t([[1, 0, 0, 0]]))
     focal = W / (2 * cam["tanfovx"])
     sigma2 = (s * focal / 4.0) ** 2 + 0.3
-    assert int(radii[0]) == int(np.ceil(3 * np.sqrt(sigma2)))
+    assert int(radii[0]) == int(np.ceil(3 * np.sqrt(sigma2 + np.sqrt(0.1))))  # lambda = mid + sqrt(max(0.1, mid^2 - det))
     # projected centre is (W-1)/2: the 4 central pixels are at distance sqrt(0.5)
     alpha = 0.8 * np.exp(-0.5 * 0.5 / sigma2)
     c = color[:, H // 2, W // 2].cpu().numpy()

@@ -1,0 +1,117 @@
+"""gaussian_renderer.render() drop-in (boundary a1): signature, RenderResults record, gradients reaching the
+simulator and the Gaussian parameters, and agreement of the whole render with the oracle given the same
+rasterizer-level inputs."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import util
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+from csplat import synthetic as syn  # noqa: E402
+from oracle import raster_oracle as ro  # noqa: E402
+
+
+def _scene(P=3000, W=160, H=120, grid=14, n_times=5):
+    sc = syn.scene_1(P=P, W=W, H=H, n_cams=1, grid=grid, n_times=n_times, seed=31)
+    sc["log_scales"] = sc["log_scales"] + math.log(2.5)
+    return sc
+
+
+def _camera(c, time):
+    t = lambda a: torch.tensor(a)  # noqa: E731
+    return SimpleNamespace(image_height=c["image_height"], image_width=c["image_width"], FoVx=c["FoVx"], FoVy=c["FoVy"],
+                           world_view_transform=t(c["world_view_transform"]), full_proj_transform=t(c["full_proj_transform"]),
+                           camera_center=t(c["camera_center"]), time=time)
+
+
+def _build(sc, dev="cuda"):
+    from csplat.gaussians import MeshGaussians
+    from meshnet.meshnet_network import ResidualMeshSimulator
+    T = lambda a, dt=torch.float32: torch.tensor(a, device=dev, dtype=dt)  # noqa: E731
+    pc = MeshGaussians(3).from_arrays(T(sc["mesh_pos"][0]), T(sc["faces"].T.copy(), torch.long), T(sc["edge_index"], torch.long),
+                                      T(sc["face_ids"], torch.long), T(sc["bary"]), T(sc["log_scales"]), T(sc["quats"]),
+                                      T(sc["opacity_logits"]), T(sc["sh"]))
+    pc.active_sh_degree = 3
+    sim = ResidualMeshSimulator(T(sc["mesh_pos"]), device=dev)
+    return pc, sim
+
+
+def test_render_results_and_gradients():
+    from gaussian_renderer import render, RenderResults
+    sc = _scene()
+    pc, sim = _build(sc)
+    with torch.no_grad():
+        sim.output.weight.normal_(0, 1e-3)
+    cam = _camera(sc["cameras"][0], time=0.5)
+    pipe = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+    bg = torch.ones(3, device="cuda")
+    res = render(cam, pc, sim, pipe, bg, project_vertices=True)
+    assert isinstance(res, RenderResults) and len(res) == 14
+    P, V = sc["face_ids"].shape[0], sc["mesh_pos"].shape[1]
+    assert res.render.shape == (3, 120, 160) and res.depth.shape == (1, 120, 160)
+    assert res.radii.dtype == torch.int32 and res.radii.shape == (P,)
+    assert res.visibility_filter.dtype == torch.bool and torch.equal(res.visibility_filter, res.radii > 0)
+    assert res.viewspace_points.shape == (P, 3) and res.means3D_deform.shape == (P, 3) and res.rotations.shape == (P, 4)
+    assert res.vertice_deform.shape == (V, 3) and res.projections.shape == (P, 2) and res.vertice_projections.shape == (V, 2)
+    assert res.shadows is None and res.shadows_mean is None and res.shadows_std is None
+    loss = (res.render - 0.5).abs().mean()
+    loss.backward()
+    assert res.viewspace_points.grad is not None and float(res.viewspace_points.grad[:, :2].abs().max()) > 0
+    for p in (pc.face_bary, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
+    assert sim.output.weight.grad is not None and float(sim.output.weight.grad.abs().max()) > 0   # reaches the simulator
+    # projections agree with the rasterizer's own pixel centres for visible Gaussians
+    o = ro.forward(res.means3D_deform.detach().cpu().numpy(), pc.get_opacity.detach().cpu().numpy(),
+                   sc["cameras"][0]["world_view_transform"], sc["cameras"][0]["full_proj_transform"],
+                   sc["cameras"][0]["camera_center"], sc["cameras"][0]["tanfovx"], sc["cameras"][0]["tanfovy"], 160, 120,
+                   np.ones(3), shs=pc.get_features.detach().cpu().numpy(), sh_degree=3,
+                   scales=pc.get_scaling.detach().cpu().numpy(), rotations=res.rotations.detach().cpu().numpy(),
+                   dtype=np.float64)
+    assert rel_err(res.render.detach().cpu().numpy(), o.color) < 1e-4          # whole render == oracle on same inputs
+    assert rel_err(res.depth.detach().cpu().numpy(), o.out_depth) < 1e-4
+    np.testing.assert_array_equal(res.radii.cpu().numpy(), ro.forward(
+        res.means3D_deform.detach().cpu().numpy(), pc.get_opacity.detach().cpu().numpy(),
+        sc["cameras"][0]["world_view_transform"], sc["cameras"][0]["full_proj_transform"], sc["cameras"][0]["camera_center"],
+        sc["cameras"][0]["tanfovx"], sc["cameras"][0]["tanfovy"], 160, 120, np.ones(3), shs=pc.get_features.detach().cpu().numpy(),
+        sh_degree=3, scales=pc.get_scaling.detach().cpu().numpy(), rotations=res.rotations.detach().cpu().numpy(),
+        stages="preprocess").radii)
+    vis = o.radii > 0
+    np.testing.assert_allclose(res.projections.detach().cpu().numpy()[vis], o.xy[vis], atol=2e-3)
+
+
+def test_render_static_no_grad_and_override_color():
+    from gaussian_renderer import render
+    sc = _scene(P=1000, W=64, H=64, grid=8)
+    pc, sim = _build(sc)
+    cam = _camera(sc["cameras"][0], time=0.0)
+    pipe = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+    bg = torch.zeros(3, device="cuda")
+    with torch.no_grad():
+        a = render(cam, pc, sim, pipe, bg, render_static=True)
+        col = torch.rand(1000, 3, device="cuda")
+        b = render(cam, pc, sim, pipe, bg, render_static=True, override_color=col)
+        pipe2 = SimpleNamespace(compute_cov3D_python=True, convert_SHs_python=False, debug=False)
+        c = render(cam, pc, sim, pipe2, bg, render_static=True)
+    assert torch.isfinite(a.render).all() and a.vertice_projections is None
+    assert not torch.allclose(a.render, b.render)
+    assert rel_err(c.render.cpu().numpy(), a.render.cpu().numpy()) < 1e-4       # python covariance path == scale/rot path
+    with pytest.raises(ValueError):
+        render(_camera(sc["cameras"][0], time=1.4), pc, sim, pipe, bg)          # time beyond the mesh table
+
+
+def test_from_mesh_uses_dist2():
+    from csplat.gaussians import MeshGaussians
+    sc = _scene(P=10, grid=10)
+    T = lambda a, dt=torch.float32: torch.tensor(a, device="cuda", dtype=dt)  # noqa: E731
+    pc = MeshGaussians(3).from_mesh(T(sc["mesh_pos"][0]), T(sc["faces"].T.copy(), torch.long), T(sc["edge_index"], torch.long),
+                                    gaussian_init_factor=2, generator=torch.Generator(device="cuda").manual_seed(0))
+    P = 2 * sc["faces"].shape[0]
+    assert pc.num_gaussians == P and pc._scaling.shape == (P, 3)
+    xyz = pc.get_xyz().detach().cpu().numpy()
+    ref = np.log(np.sqrt(np.maximum(ro.dist2(xyz), 1e-7)))
+    np.testing.assert_allclose(pc._scaling.detach().cpu().numpy()[:, 0], ref, rtol=1e-5, atol=1e-6)
