@@ -119,22 +119,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint32_t
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-// single workgroup: in-place exclusive scan of m values (chunk per thread), m <= ~1M
+// single workgroup: in-place exclusive scan of m values; coalesced 16-byte accesses, 4096 values per sweep
 __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *__restrict__ data, int64_t m, uint32_t *__restrict__ total_out) {
     __shared__ uint32_t lds[1024 / 64 + 1];
-    const int64_t chunk = (m + 1023) / 1024;
-    const int64_t s = (int64_t)threadIdx.x * chunk;
-    const int64_t e = s + chunk < m ? s + chunk : m;
-    uint32_t sum = 0;
-    for (int64_t i = s; i < e; i++) sum += data[i];
-    uint32_t tot;
-    uint32_t run = block_exclusive_scan<1024>(sum, lds, &tot);
-    for (int64_t i = s; i < e; i++) {
-        uint32_t v = data[i];
-        data[i] = run;
-        run += v;
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < m; base += 4096) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+        uint32_t v[4];
+        const bool full = i0 + 4 <= m;
+        if (full) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(data + i0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (i0 + k < m) ? data[i0 + k] : 0u;
+        }
+        const uint32_t s4 = v[0] + v[1] + v[2] + v[3];
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<1024>(s4, lds, &tot) + carry;
+        uint32_t o[4];
+        o[0] = ex; o[1] = o[0] + v[0]; o[2] = o[1] + v[1]; o[3] = o[2] + v[2];
+        if (full) {
+            *reinterpret_cast<uint4 *>(data + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i0 + k < m) data[i0 + k] = o[k];
+        }
+        carry += tot;
     }
-    if (total_out && threadIdx.x == 0) *total_out = tot;
+    if (total_out && threadIdx.x == 0) *total_out = carry;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,

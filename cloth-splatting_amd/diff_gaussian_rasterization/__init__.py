@@ -103,12 +103,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_sh = new(P, M, 3) if sh is not None else None
         d_scale = new(P, 3) if scales is not None else None
         d_rot = new(P, 4) if rotations is not None else None
+        scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, ctx.num_rendered)), 256), dtype=torch.uint8,
+                              device=dev)
         with torch.cuda.device(dev):
             rc = _n.lib.csplat_backward(
                 _n.stream_handle(dev), P, int(rs.sh_degree), M, ctx.num_rendered, _n.ptr(bg), W, H, _n.ptr(means3D),
                 _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(scales), float(rs.scale_modifier), _n.ptr(rotations),
                 _n.ptr(cov3Ds_precomp), _n.ptr(view), _n.ptr(proj), _n.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image), _n.ptr(grad_color), _n.ptr(d_mean2D),
+                _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image), _n.ptr(grad_color), _n.ptr(scratch),
+                _n.ptr(d_mean2D),
                 _n.ptr(d_conic), _n.ptr(d_opac), _n.ptr(d_color), _n.ptr(d_mean3D), _n.ptr(d_cov3D), _n.ptr(d_sh),
                 _n.ptr(d_scale), _n.ptr(d_rot))
         _n.check(rc, "csplat_backward")
