@@ -253,14 +253,10 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
 }
 
 // ------------------------------------------------------------------------------------------- K3
-// Emits one (key, slot) pair per touched tile.  The sort payload is the UNSORTED SLOT u (position in emission
-// order); slots of Gaussian i are the contiguous run [offsets[i-1], offsets[i]).  K7 writes its per-instance
-// gradient partials to slab[u] with plain stores and K8 sums each Gaussian's contiguous run: no float atomics.
 __global__ __launch_bounds__(256) void k_emit_keys(int P, const float2 *__restrict__ xy, const float *__restrict__ depth,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ radii, Cam cam,
-                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ slots,
-                                                    uint32_t *__restrict__ slot_ids) {
+                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ ids) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const int rad = radii[i];
@@ -273,21 +269,15 @@ __global__ __launch_bounds__(256) void k_emit_keys(int P, const float2 *__restri
     for (int y = miny; y < maxy; y++)
         for (int x = minx; x < maxx; x++) {
             keys[off] = ((uint64_t)(uint32_t)(y * cam.gx + x) << 32) | dbits;
-            slots[off] = off;
-            slot_ids[off] = (uint32_t)i;
+            ids[off] = (uint32_t)i;
             off++;
         }
 }
 
 // ------------------------------------------------------------------------------------------- K5
-// tile ranges + sorted Gaussian ids (ids[i] = Gaussian that owns sorted instance i)
-__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint64_t *__restrict__ keys,
-                                                      const uint32_t *__restrict__ slots_sorted,
-                                                      const uint32_t *__restrict__ slot_ids, uint32_t *__restrict__ ids_sorted,
-                                                      int2 *__restrict__ ranges) {
+__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint64_t *__restrict__ keys, int2 *__restrict__ ranges) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
-    ids_sorted[i] = slot_ids[slots_sorted[i]];
     const uint32_t t = (uint32_t)(keys[i] >> 32);
     if (i == 0) ranges[t].x = 0;
     else {
@@ -295,14 +285,6 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint64_t *
         if (tp != t) { ranges[tp].y = (int)i; ranges[t].x = (int)i; }
     }
     if (i == R - 1) ranges[t].y = (int)R;
-}
-
-// pixel owned by a thread: each 64-lane wavefront covers one 8x8 quadrant of the 16x16 tile, which keeps the
-// lanes of a wave spatially compact (coherent early termination, tight wave bounding boxes for the culling below).
-__device__ __forceinline__ void thread_pixel(int tile, int gx, int &px, int &py) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    px = (tile % gx) * CSPLAT_TILE + ((w & 1) << 3) + (l & 7);
-    py = (tile / gx) * CSPLAT_TILE + ((w >> 1) << 3) + (l >> 3);
 }
 
 template <int CTRL, int RMASK>
@@ -332,74 +314,107 @@ __device__ __forceinline__ bool box_hit(float2 c, float cut2, float bx0, float b
 }
 
 // ------------------------------------------------------------------------------------------- K6
-__global__ __launch_bounds__(256) void k_render_fwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                     int W, int H, int gx, const float2 *__restrict__ xy,
-                                                     const float *__restrict__ rgb, const float *__restrict__ depth,
-                                                     const float4 *__restrict__ conic_opacity,
-                                                     const float *__restrict__ cut2, const float *__restrict__ bg,
-                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                     float *__restrict__ out_color, float *__restrict__ out_depth) {
-    __shared__ float2 s_xy[256];
-    __shared__ float s_cut[256];
-    __shared__ float4 s_co[256];
-    __shared__ float4 s_cd[256];  // rgb + depth
-    const int tile = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    int px, py;
-    thread_pixel(tile, gx, px, py);
+// One 64-lane wavefront per workgroup, one workgroup per 8x8 pixel quadrant of a 16x16 tile (4 independent
+// workgroups share a tile's list).  No workgroup barrier anywhere: the wave streams the tile list in 64-entry
+// chunks (lane l gathers entry l, two chunks of ids / one chunk of data prefetched ahead of use), culls the chunk
+// with one ballot against the box of its still-live pixels, and composites the surviving entries in groups of four
+// (four independent alpha evaluations in flight, then the short sequential transmittance chain).
+constexpr int FWD_GROUP = 4;
+
+__device__ __forceinline__ void quadrant_pixel(int quad, int gx, int lane, int &tile, int &px, int &py) {
+    tile = quad >> 2;
+    const int w = quad & 3;
+    px = (tile % gx) * CSPLAT_TILE + ((w & 1) << 3) + (lane & 7);
+    py = (tile / gx) * CSPLAT_TILE + ((w >> 1) << 3) + (lane >> 3);
+}
+
+__global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                                                    int W, int H, int gx, const float2 *__restrict__ xy,
+                                                    const float *__restrict__ rgb, const float *__restrict__ depth,
+                                                    const float4 *__restrict__ conic_opacity,
+                                                    const float *__restrict__ cut2, const float *__restrict__ bg,
+                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                    float *__restrict__ out_color, float *__restrict__ out_depth) {
+    __shared__ float2 s_xy[64];
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_cd[64];  // rgb + depth
+    const int lane = threadIdx.x;
+    int tile, px, py;
+    quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
     const bool inside = px < W && py < H;
     const int pix = py * W + px;
     const float fx = (float)px, fy = (float)py;
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
-    const int rounds = (n + 255) / 256;
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    for (int r = 0; r < rounds; r++) {
-        if (__syncthreads_count(done) == 256) break;
-        const int prog = r * 256 + threadIdx.x;
-        if (prog < n) {
-            const uint32_t id = point_list[range.x + prog];
-            s_xy[threadIdx.x] = xy[id];
-            s_cut[threadIdx.x] = cut2[id];
-            s_co[threadIdx.x] = conic_opacity[id];
-            s_cd[threadIdx.x] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], depth[id]);
-        }
-        __syncthreads();
-        if (__ballot(!done) == 0ull) continue;  // this wave's 64 pixels are finished; keep serving the barriers
-        // bounding box of the wave's live pixels (refreshed once per 256-entry batch)
-        const float bx0 = wave_min(done ? 3.0e38f : fx), bx1 = wave_max(done ? -3.0e38f : fx);
-        const float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
-        const int m = min(256, n - r * 256);
-        for (int sub = 0; sub < m; sub += 64) {
-            const int e = sub + lane;
-            const bool hit = (e < m) && box_hit(s_xy[e], s_cut[e], bx0, bx1, by0, by1);
+
+    if (n > 0 && __ballot(!done) != 0ull) {
+        float bx0 = wave_min(done ? 3.0e38f : fx), bx1 = wave_max(done ? -3.0e38f : fx);
+        float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
+        unsigned long long live = __ballot(!done);
+        const uint32_t *pl = point_list + range.x;
+        // software pipeline: ids two chunks ahead, per-entry data one chunk ahead
+        uint32_t id_cur = lane < n ? pl[lane] : 0u;
+        uint32_t id_nxt = 64 + lane < n ? pl[64 + lane] : 0u;
+        float2 c_cur = xy[id_cur];
+        float cut_cur = lane < n ? cut2[id_cur] : -1.f;
+        float4 co_cur = conic_opacity[id_cur];
+        float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
+        for (int base = 0; base < n; base += 64) {
+            // stage the current chunk for broadcast reads, start the loads of the next one
+            __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk before these writes
+            s_xy[lane] = c_cur; s_co[lane] = co_cur; s_cd[lane] = cd_cur;
+            const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+            const int nb = base + 64;
+            const uint32_t id_n2 = nb + 64 + lane < n ? pl[nb + 64 + lane] : 0u;
+            c_cur = xy[id_nxt];
+            cut_cur = nb + lane < n ? cut2[id_nxt] : -1.f;
+            co_cur = conic_opacity[id_nxt];
+            cd_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
+            id_nxt = id_n2;
             unsigned long long mask = __ballot(hit);
+            __syncthreads();
             while (mask) {
-                const int j = sub + (__ffsll((long long)mask) - 1);
-                mask &= mask - 1ull;
-                if (!done) {
-                    const float2 p = s_xy[j];
+                int j[FWD_GROUP];
+                float al[FWD_GROUP];
+                float4 cd[FWD_GROUP];
+#pragma unroll
+                for (int k = 0; k < FWD_GROUP; k++) {
+                    const bool ok = mask != 0ull;
+                    j[k] = ok ? (__ffsll((long long)mask) - 1) : 0;
+                    mask &= mask - 1ull;   // (0 stays 0)
+                    const float2 p = s_xy[j[k]];
+                    const float4 co = s_co[j[k]];
+                    cd[k] = s_cd[j[k]];
                     const float dx = p.x - fx, dy = p.y - fy;
-                    const float4 co = s_co[j];
                     const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    const float alpha = fminf(0.99f, co.w * __expf(power));
-                    if (power <= 0.f && alpha >= 1.f / 255.f) {
-                        const float test_T = T * (1.f - alpha);
+                    const float a = fminf(0.99f, co.w * __expf(power));
+                    al[k] = (ok && power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < FWD_GROUP; k++) {
+                    if (!done && al[k] > 0.f) {
+                        const float test_T = T * (1.f - al[k]);
                         if (test_T < 0.0001f) {
                             done = true;
                         } else {
-                            const float4 cd = s_cd[j];
-                            const float wgt = alpha * T;
-                            C0 += cd.x * wgt; C1 += cd.y * wgt; C2 += cd.z * wgt; Dp += cd.w * wgt;
+                            const float wgt = al[k] * T;
+                            C0 += cd[k].x * wgt; C1 += cd[k].y * wgt; C2 += cd[k].z * wgt; Dp += cd[k].w * wgt;
                             T = test_T;
-                            last = (uint32_t)(r * 256 + j + 1);
+                            last = (uint32_t)(base + j[k] + 1);
                         }
                     }
                 }
             }
-            if (__ballot(!done) == 0ull) break;
+            const unsigned long long now = __ballot(!done);
+            if (now == 0ull) break;
+            if (now != live) {  // some pixels finished: shrink the culling box to the survivors
+                live = now;
+                bx0 = wave_min(done ? 3.0e38f : fx); bx1 = wave_max(done ? -3.0e38f : fx);
+                by0 = wave_min(done ? 3.0e38f : fy); by1 = wave_max(done ? -3.0e38f : fy);
+            }
         }
     }
     if (inside) {
@@ -427,37 +442,43 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-// per-instance gradient partial written by K7 (plain 16-byte stores) and summed per Gaussian by K8:
-//   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..11 pad  (48 B)
-constexpr int SLAB_STRIDE = 12;
+// per-Gaussian gradient accumulator filled by K7 and consumed by K8 (one 48-byte record per Gaussian):
+//   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..11 pad
+constexpr int ACC_STRIDE = 12;
+constexpr int BWD_GROUP = 2;
 
-__global__ __launch_bounds__(256) void k_render_bwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                     const uint32_t *__restrict__ slot_list, int W, int H, int gx,
-                                                     const float *__restrict__ bg, const float2 *__restrict__ xy,
-                                                     const float4 *__restrict__ conic_opacity,
-                                                     const float *__restrict__ rgb, const float *__restrict__ cut2,
-                                                     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                                                     const float *__restrict__ dL_dpix, float *__restrict__ slab) {
-    __shared__ float2 s_xy[256];
-    __shared__ float s_cut[256];
-    __shared__ float4 s_co[256];
-    __shared__ float4 s_c[256];
-    __shared__ float s_acc[256 * SLAB_STRIDE];   // per-entry partials of this batch, summed over the 4 waves
-    __shared__ int s_red[4];
-    const int tile = blockIdx.x;
-    int px, py;
-    thread_pixel(tile, gx, px, py);
-    const bool inside = px < W && py < H;
-    const int pix = py * W + px;
-    const float fx = (float)px, fy = (float)py;
+// Same decomposition as K6: one wavefront per 8x8 quadrant, no barriers, the tile list walked back to front from the
+// quadrant's deepest contributor in 64-entry chunks (prefetched), one ballot of box-culled survivors per chunk.
+// Per surviving entry the 64 per-pixel partials are folded with DPP row sums; lane q of every row then takes value q,
+// two cross-row exchanges finish the sum, and lanes 0..8 issue ONE 36-byte atomic instruction into the Gaussian's
+// record (<= 4 quadrants x tiles-touched adds per address, instead of one atomic per pixel as upstream does).
+__global__ __launch_bounds__(64) void k_render_bwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                                                    int W, int H, int gx, const float *__restrict__ bg,
+                                                    const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
+                                                    const float *__restrict__ rgb, const float *__restrict__ cut2,
+                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                    const float *__restrict__ dL_dpix, float *__restrict__ acc) {
+    __shared__ float2 s_xy[64];
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_c[64];   // rgb + Gaussian id (bit pattern) in .w
+    const int lane = threadIdx.x;
+    int tile, px, py;
+    quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
     if (n <= 0) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool inside = px < W && py < H;
+    const int pix = py * W + px;
+    const float fx = (float)px, fy = (float)py;
+    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    const int wave_last = (int)wave_max((float)last_contributor);   // deepest contributor of the quadrant
+    if (wave_last <= 0) return;
+    const bool has = last_contributor > 0;
+    const float bx0 = wave_min(has ? fx : 3.0e38f), bx1 = wave_max(has ? fx : -3.0e38f);
+    const float by0 = wave_min(has ? fy : 3.0e38f), by1 = wave_max(has ? fy : -3.0e38f);
 
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
     float accr0 = 0.f, accr1 = 0.f, accr2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
     const size_t HW = (size_t)H * W;
     const float dp0 = inside ? dL_dpix[pix] : 0.f, dp1 = inside ? dL_dpix[HW + pix] : 0.f,
@@ -465,98 +486,99 @@ __global__ __launch_bounds__(256) void k_render_bwd(const int2 *__restrict__ ran
     const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-    // deepest contributor of the wave / of the workgroup: nothing behind it can receive a gradient
-    const int wave_last = (int)wave_max((float)last_contributor);
-    if (lane == 0) s_red[w] = wave_last;
-    // box of the wave's pixels that have any contributor at all
-    const bool has = last_contributor > 0;
-    const float bx0 = wave_min(has ? fx : 3.0e38f), bx1 = wave_max(has ? fx : -3.0e38f);
-    const float by0 = wave_min(has ? fy : 3.0e38f), by1 = wave_max(has ? fy : -3.0e38f);
-    __syncthreads();
-    const int n_eff = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));  // entries [0, n_eff) of the tile list matter
-    const int rounds = (n_eff + 255) / 256;
-
-    for (int r = 0; r < rounds; r++) {
-        __syncthreads();   // previous batch fully consumed (s_acc flushed) before it is overwritten
-        // batch r holds list positions pos = n_eff-1 - (r*256 + k), k = 0..255 : back to front
-        const int k = threadIdx.x;
-        const int pos = n_eff - 1 - (r * 256 + k);
-        uint32_t my_slot = 0;
-        if (pos >= 0) {
-            const uint32_t id = point_list[range.x + pos];
-            my_slot = slot_list[range.x + pos];
-            s_xy[k] = xy[id];
-            s_cut[k] = cut2[id];
-            s_co[k] = conic_opacity[id];
-            s_c[k] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < SLAB_STRIDE; q++) s_acc[q * 256 + k] = 0.f;
+    // chunk c, lane l  <->  list position pos = wave_last-1 - (64c + l)   (back to front)
+    const uint32_t *pl = point_list + range.x;
+    const int q16 = lane & 15;
+    auto idx_of = [&](int e) { return wave_last - 1 - e; };
+    uint32_t id_cur = lane < wave_last ? pl[idx_of(lane)] : 0u;
+    uint32_t id_nxt = 64 + lane < wave_last ? pl[idx_of(64 + lane)] : 0u;
+    float2 c_cur = xy[id_cur];
+    float cut_cur = lane < wave_last ? cut2[id_cur] : -1.f;
+    float4 co_cur = conic_opacity[id_cur];
+    float4 col_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], __uint_as_float(id_cur));
+    for (int base = 0; base < wave_last; base += 64) {
+        __syncthreads();   // single-wave workgroup: previous chunk's LDS reads precede these writes
+        s_xy[lane] = c_cur; s_co[lane] = co_cur; s_c[lane] = col_cur;
+        const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+        const int nb = base + 64;
+        const uint32_t id_n2 = nb + 64 + lane < wave_last ? pl[idx_of(nb + 64 + lane)] : 0u;
+        c_cur = xy[id_nxt];
+        cut_cur = nb + lane < wave_last ? cut2[id_nxt] : -1.f;
+        co_cur = conic_opacity[id_nxt];
+        col_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], __uint_as_float(id_nxt));
+        id_nxt = id_n2;
+        unsigned long long mask = __ballot(hit);
         __syncthreads();
-        const int m = min(256, n_eff - r * 256);
-        if (wave_last > 0) {
-            for (int sub = 0; sub < m; sub += 64) {
-                const int e = sub + lane;
-                const int epos = n_eff - 1 - (r * 256 + e);
-                const bool hit = (e < m) && (epos < wave_last) && box_hit(s_xy[e], s_cut[e], bx0, bx1, by0, by1);
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int j = sub + (__ffsll((long long)mask) - 1);
-                    mask &= mask - 1ull;
-                    const int jpos = n_eff - 1 - (r * 256 + j);
-                    const float2 p = s_xy[j];
-                    const float dx = p.x - fx, dy = p.y - fy;
-                    const float4 co = s_co[j];
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    const float G = __expf(power);
-                    const float alpha = fminf(0.99f, co.w * G);
-                    const bool act = (jpos < last_contributor) && !(power > 0.f) && !(alpha < 1.f / 255.f);
-                    if (__ballot(act) == 0ull) continue;
-                    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-                    if (act) {
-                        T = T / (1.f - alpha);
-                        const float dchannel_dcolor = alpha * T;
-                        const float4 c = s_c[j];
-                        accr0 = last_alpha * lc0 + (1.f - last_alpha) * accr0;
-                        accr1 = last_alpha * lc1 + (1.f - last_alpha) * accr1;
-                        accr2 = last_alpha * lc2 + (1.f - last_alpha) * accr2;
-                        lc0 = c.x; lc1 = c.y; lc2 = c.z;
-                        float dL_dalpha = (c.x - accr0) * dp0 + (c.y - accr1) * dp1 + (c.z - accr2) * dp2;
-                        v6 = dchannel_dcolor * dp0; v7 = dchannel_dcolor * dp1; v8 = dchannel_dcolor * dp2;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                        const float dL_dG = co.w * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                        const float dG_ddely = -gdy * co.z - gdx * co.y;
-                        v0 = dL_dG * dG_ddelx * ddelx_dx;
-                        v1 = dL_dG * dG_ddely * ddely_dy;
-                        v2 = -0.5f * gdx * dx * dL_dG;
-                        v3 = -0.5f * gdx * dy * dL_dG;
-                        v4 = -0.5f * gdy * dy * dL_dG;
-                        v5 = G * dL_dalpha;
-                    }
-                    // 64 -> 4 row sums per value (DPP), then lane q of every row takes value q and the four rows are
-                    // folded with two cross-row exchanges: lanes 0..8 hold the 9 wave totals -> ONE LDS atomic instruction
-                    v0 = row_sum(v0); v1 = row_sum(v1); v2 = row_sum(v2); v3 = row_sum(v3); v4 = row_sum(v4);
-                    v5 = row_sum(v5); v6 = row_sum(v6); v7 = row_sum(v7); v8 = row_sum(v8);
-                    const int q = lane & 15;
-                    float x = v0;
-                    x = q == 1 ? v1 : x; x = q == 2 ? v2 : x; x = q == 3 ? v3 : x; x = q == 4 ? v4 : x;
-                    x = q == 5 ? v5 : x; x = q == 6 ? v6 : x; x = q == 7 ? v7 : x; x = q == 8 ? v8 : x;
-                    x += __shfl_xor(x, 16, 64);
-                    x += __shfl_xor(x, 32, 64);
-                    if (lane < 9) atomicAdd(&s_acc[lane * 256 + j], x);
+        while (mask) {
+            int j[BWD_GROUP];
+            bool ok[BWD_GROUP];
+            float al[BWD_GROUP], Gv[BWD_GROUP], dxv[BWD_GROUP], dyv[BWD_GROUP];
+            float4 cov[BWD_GROUP], colv[BWD_GROUP];
+#pragma unroll
+            for (int k = 0; k < BWD_GROUP; k++) {
+                ok[k] = mask != 0ull;
+                j[k] = ok[k] ? (__ffsll((long long)mask) - 1) : 0;
+                mask &= mask - 1ull;
+                const float2 p = s_xy[j[k]];
+                cov[k] = s_co[j[k]];
+                colv[k] = s_c[j[k]];
+                dxv[k] = p.x - fx; dyv[k] = p.y - fy;
+                const float power = -0.5f * (cov[k].x * dxv[k] * dxv[k] + cov[k].z * dyv[k] * dyv[k]) - cov[k].y * dxv[k] * dyv[k];
+                Gv[k] = __expf(power);
+                const float a = fminf(0.99f, cov[k].w * Gv[k]);
+                const int jpos = wave_last - 1 - (base + j[k]);
+                al[k] = (ok[k] && jpos < last_contributor && power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
+            }
+            float v[BWD_GROUP][9];
+            unsigned long long any[BWD_GROUP];
+#pragma unroll
+            for (int k = 0; k < BWD_GROUP; k++) {   // short sequential chain (T, colour behind), then the partials
+                const bool act = al[k] > 0.f;
+                any[k] = __ballot(act);
+#pragma unroll
+                for (int t = 0; t < 9; t++) v[k][t] = 0.f;
+                if (act) {
+                    const float alpha = al[k];
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * inv;
+                    const float dchannel_dcolor = alpha * T;
+                    const float4 c = colv[k];
+                    accr0 = last_alpha * lc0 + (1.f - last_alpha) * accr0;
+                    accr1 = last_alpha * lc1 + (1.f - last_alpha) * accr1;
+                    accr2 = last_alpha * lc2 + (1.f - last_alpha) * accr2;
+                    lc0 = c.x; lc1 = c.y; lc2 = c.z;
+                    float dL_dalpha = (c.x - accr0) * dp0 + (c.y - accr1) * dp1 + (c.z - accr2) * dp2;
+                    v[k][6] = dchannel_dcolor * dp0; v[k][7] = dchannel_dcolor * dp1; v[k][8] = dchannel_dcolor * dp2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final * inv) * bg_dot;
+                    const float4 co = cov[k];
+                    const float dL_dG = co.w * dL_dalpha;
+                    const float gdx = Gv[k] * dxv[k], gdy = Gv[k] * dyv[k];
+                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                    const float dG_ddely = -gdy * co.z - gdx * co.y;
+                    v[k][0] = dL_dG * dG_ddelx * ddelx_dx;
+                    v[k][1] = dL_dG * dG_ddely * ddely_dy;
+                    v[k][2] = -0.5f * gdx * dxv[k] * dL_dG;
+                    v[k][3] = -0.5f * gdx * dyv[k] * dL_dG;
+                    v[k][4] = -0.5f * gdy * dyv[k] * dL_dG;
+                    v[k][5] = Gv[k] * dL_dalpha;
                 }
             }
-        }
-        __syncthreads();
-        if (pos >= 0) {   // flush this batch: one 48-byte record per instance, plain stores
-            float4 *dst = reinterpret_cast<float4 *>(slab + (size_t)my_slot * SLAB_STRIDE);
-            dst[0] = make_float4(s_acc[0 * 256 + k], s_acc[1 * 256 + k], s_acc[2 * 256 + k], s_acc[3 * 256 + k]);
-            dst[1] = make_float4(s_acc[4 * 256 + k], s_acc[5 * 256 + k], s_acc[6 * 256 + k], s_acc[7 * 256 + k]);
-            dst[2] = make_float4(s_acc[8 * 256 + k], 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < BWD_GROUP; k++) {
+                if (any[k] == 0ull) continue;   // wave-uniform
+                float x = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const float r = row_sum(v[k][t]);
+                    x = q16 == t ? r : x;
+                }
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                const uint32_t gid = __float_as_uint(colv[k].w);
+                if (lane < 9) atomicAdd(acc + (size_t)gid * ACC_STRIDE + lane, x);
+            }
         }
     }
 }
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, con
                                                          const float *__restrict__ shs, const float *__restrict__ scales,
                                                          float scale_mod, const float *__restrict__ rotations,
                                                          int use_precomp_cov, Cam cam, Geom g,
-                                                         const int32_t *__restrict__ radii, const float *__restrict__ slab,
+                                                         const int32_t *__restrict__ radii, const float *__restrict__ acc,
                                                          float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic,
                                                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolor,
                                                          float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D,
@@ -575,19 +597,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, con
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const bool vis = radii[i] > 0;
-    // sum the Gaussian's per-instance partials: its slots are the contiguous run [offsets[i-1], offsets[i]), read in
-    // ascending order -> a fixed summation order, bitwise reproducible
-    float a9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (vis) {
-        const uint32_t s0 = i == 0 ? 0u : g.offsets[i - 1], s1 = g.offsets[i];
-        for (uint32_t u = s0; u < s1; u++) {
-            const float4 *rec = reinterpret_cast<const float4 *>(slab + (size_t)u * SLAB_STRIDE);
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
-            a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w;
-            a9[8] += r2.x;
-        }
-    }
+    float a9[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
     dL_dopacity[i] = a9[5];
@@ -800,15 +812,14 @@ size_t image_offsets(int W, int H, size_t *off) {
     off[2] = off[1] + align256(X * 4);
     return off[2] + align256(X * 4);
 }
-// binning: 0 keys_sorted u64 | 1 ids_sorted u32 | 2 slots_sorted u32 (unsorted slot of each sorted instance)
+// binning: 0 keys_sorted u64 | 1 ids_sorted u32
 size_t binning_offsets(int64_t R, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
     off[0] = 0;
     off[1] = align256(n * 8);
-    off[2] = off[1] + align256(n * 4);
-    return off[2] + align256(n * 4);
+    return off[1] + align256(n * 4);
 }
-// temp: 0 keys_unsorted | 1 slots_unsorted | 2 keys_tmp | 3 slots_tmp | 4 sort table | 5 slot_ids
+// temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
 size_t temp_offsets(int64_t R, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
     off[0] = 0;
@@ -816,8 +827,7 @@ size_t temp_offsets(int64_t R, size_t *off) {
     off[2] = off[1] + align256(n * 4);
     off[3] = off[2] + align256(n * 8);
     off[4] = off[3] + align256(n * 4);
-    off[5] = off[4] + csplat_sort_temp_bytes(R);
-    return off[5] + align256(n * 4);
+    return off[4] + csplat_sort_temp_bytes(R);
 }
 
 // camera constants stay in HBM (80 bytes, read through the scalar cache by every wave): no host round trip
@@ -844,11 +854,11 @@ const char *csplat_last_error(void) { return g_csplat_err; }
 
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
 size_t csplat_image_bytes(int W, int H) { size_t off[3]; return image_offsets(W, H, off); }
-size_t csplat_binning_bytes(int64_t R) { size_t off[3]; return binning_offsets(R, off); }
-size_t csplat_temp_bytes(int P, int64_t R) { (void)P; size_t off[6]; return temp_offsets(R, off); }
-size_t csplat_backward_scratch_bytes(int P, int64_t R) { (void)P; return align256((size_t)(R > 0 ? R : 1) * SLAB_STRIDE * 4); }
+size_t csplat_binning_bytes(int64_t R) { size_t off[2]; return binning_offsets(R, off); }
+size_t csplat_temp_bytes(int P, int64_t R) { (void)P; size_t off[5]; return temp_offsets(R, off); }
+size_t csplat_backward_scratch_bytes(int P, int64_t R) { (void)R; return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4); }
 int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
-int csplat_binning_layout(int64_t R, size_t *o2) { size_t off[3]; binning_offsets(R, off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
+int csplat_binning_layout(int64_t R, size_t *o2) { binning_offsets(R, o2); return 0; }
 int csplat_image_layout(int W, int H, size_t *o3) { image_offsets(W, H, o3); return 0; }
 
 int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
@@ -898,43 +908,41 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     *num_rendered = (int)R;
     void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R));
     CSPLAT_REQUIRE(bbase, "allocator returned NULL");
-    size_t boff[3];
+    size_t boff[2];
     binning_offsets(R, boff);
     uint64_t *keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
     uint32_t *ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
-    uint32_t *slots_sorted = (uint32_t *)((char *)bbase + boff[2]);
     HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
     if (R > 0) {
         void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R));
         CSPLAT_REQUIRE(tbase, "allocator returned NULL");
-        size_t toff[6];
+        size_t toff[5];
         temp_offsets(R, toff);
         uint64_t *keys_u = (uint64_t *)((char *)tbase + toff[0]);
-        uint32_t *slots_u = (uint32_t *)((char *)tbase + toff[1]);
+        uint32_t *ids_u = (uint32_t *)((char *)tbase + toff[1]);
         uint64_t *keys_t = (uint64_t *)((char *)tbase + toff[2]);
-        uint32_t *slots_t = (uint32_t *)((char *)tbase + toff[3]);
+        uint32_t *ids_t = (uint32_t *)((char *)tbase + toff[3]);
         void *stab = (char *)tbase + toff[4];
-        uint32_t *slot_ids = (uint32_t *)((char *)tbase + toff[5]);
         {
             ProfScope ps(PROF_K3, s);
-            k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, slots_u, slot_ids);
+            k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, ids_u);
             LAUNCH_CHECK();
         }
         const int end_bit = 32 + higher_msb((uint32_t)tiles);
         {
             ProfScope ps(PROF_K4, s);
-            if (int rc = csplat_sort_pairs(s, keys_u, slots_u, keys_sorted, slots_sorted, keys_t, slots_t, R, end_bit, stab)) return rc;
+            if (int rc = csplat_sort_pairs(s, keys_u, ids_u, keys_sorted, ids_sorted, keys_t, ids_t, R, end_bit, stab)) return rc;
         }
         {
             ProfScope ps(PROF_K5, s);
-            k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, slots_sorted, slot_ids, ids_sorted, ranges);
+            k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
             LAUNCH_CHECK();
         }
     }
     {
         ProfScope ps(PROF_K6, s);
-        k_render_fwd<<<tiles, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, g.cut2, bg,
-                                           final_T, n_contrib, out_color, out_depth);
+        k_render_fwd<<<tiles * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, g.cut2,
+                                              bg, final_T, n_contrib, out_color, out_depth);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
@@ -952,32 +960,30 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
     (void)colors_precomp;
     CSPLAT_REQUIRE(geom && binning && image, "csplat_backward: missing saved state");
     CSPLAT_REQUIRE(dL_dmean2D && dL_dconic && dL_dopacity && dL_dcolor && dL_dmean3D && dL_dcov3D, "missing gradient outputs");
-    CSPLAT_REQUIRE(scratch != nullptr || R == 0, "csplat_backward: scratch (csplat_backward_scratch_bytes) missing");
+    CSPLAT_REQUIRE(scratch != nullptr, "csplat_backward: scratch (csplat_backward_scratch_bytes) missing");
     if (P <= 0) return 0;
     Cam cam;
     make_cam(cam, view, proj, campos, tanfovx, tanfovy, W, H);
     Geom g = geom_view((void *)geom, P);
-    size_t ioff[3], boff[3];
+    size_t ioff[3], boff[2];
     image_offsets(W, H, ioff);
     binning_offsets(R, boff);
     const int2 *ranges = (const int2 *)((const char *)image + ioff[0]);
     const uint32_t *n_contrib = (const uint32_t *)((const char *)image + ioff[1]);
     const float *final_T = (const float *)((const char *)image + ioff[2]);
     const uint32_t *ids_sorted = (const uint32_t *)((const char *)binning + boff[1]);
-    const uint32_t *slots_sorted = (const uint32_t *)((const char *)binning + boff[2]);
-    float *slab = (float *)scratch;
+    float *acc = (float *)scratch;
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
     if (R > 0) {
-        // instances behind every pixel's last contributor are never visited by K7: their partials must read as zero
-        HIP_TRY(hipMemsetAsync(slab, 0, (size_t)R * SLAB_STRIDE * 4, s));
         ProfScope ps(PROF_K7, s);
-        k_render_bwd<<<cam.gx * cam.gy, 256, 0, s>>>(ranges, ids_sorted, slots_sorted, W, H, cam.gx, bg, g.xy, g.conic_opacity,
-                                                     g.rgb, g.cut2, final_T, n_contrib, dL_dpix, slab);
+        k_render_bwd<<<cam.gx * cam.gy * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, bg, g.xy, g.conic_opacity, g.rgb,
+                                                        g.cut2, final_T, n_contrib, dL_dpix, acc);
         LAUNCH_CHECK();
     }
     {
         ProfScope ps(PROF_K8, s);
         k_preprocess_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
-                                                       cov3D_precomp != nullptr, cam, g, radii, slab, dL_dmean2D, dL_dconic,
+                                                       cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D, dL_dconic,
                                                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                                                        dL_drot);
         LAUNCH_CHECK();

@@ -49,12 +49,12 @@ size_t csplat_geom_bytes(int P);
 size_t csplat_image_bytes(int W, int H);
 size_t csplat_binning_bytes(int64_t R);
 size_t csplat_temp_bytes(int P, int64_t R);
-size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-instance gradient slab used by csplat_backward */
+size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-Gaussian accumulation records used by csplat_backward */
 
 /* Byte offsets of the named sub-buffers inside a chunk (for tests / debugging; see DESIGN.md "HBM layout").
  * geom:    0 depth f32[P] | 1 xy f32[P][2] | 2 conic_opacity f32[P][4] | 3 rgb f32[P][3] | 4 cov3D f32[P][6]
  *          | 5 clamped u32[P] (bit c = channel c clamped) | 6 tiles_touched u32[P] | 7 offsets u32[P] (inclusive scan)
- * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)  [| slots u32[R]: emission slot of each sorted instance]
+ * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)
  * image:   0 ranges i32[tiles][2] | 1 n_contrib u32[H*W] | 2 final_T f32[H*W]                               */
 int csplat_geom_layout(int P, size_t *offsets8);
 int csplat_binning_layout(int64_t R, size_t *offsets2);
@@ -78,8 +78,8 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
 
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
  * dL_dpix[3][H][W] is the gradient of the colour image (the depth image carries no gradient, as upstream).
- * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes (K7 writes one 48-byte partial per tile
- * instance with plain stores, K8 sums each Gaussian's contiguous run: no float atomics, bitwise reproducible).
+ * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes (one 48-byte accumulation record per Gaussian:
+ * K7 adds one wave-reduced 36-byte partial per (quadrant, surviving list entry), K8 consumes the records).
  * Gradient outputs (device, fully overwritten): dL_dmean2D[P][3] (NDC units, .z = 0), dL_dconic[P][4],
  * dL_dopacity[P], dL_dcolor[P][3], dL_dmean3D[P][3], dL_dcov3D[P][6], dL_dsh[P][M][3] (may be NULL when
  * colors_precomp was used), dL_dscale[P][3], dL_drot[P][4] (may be NULL when cov3D_precomp was used). */
