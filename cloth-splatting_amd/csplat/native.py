@@ -22,19 +22,20 @@ _vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 EXPORTS = {
     "csplat_abi_version": (_i, []),
     "csplat_last_error": (C.c_char_p, []),
+    "csplat_debug_flags": (_i, [C.c_uint]),
     "csplat_geom_bytes": (_sz, [_i]),
     "csplat_image_bytes": (_sz, [_i, _i]),
-    "csplat_binning_bytes": (_sz, [_i64]),
+    "csplat_binning_bytes": (_sz, [_i64, _i, _i]),
     "csplat_temp_bytes": (_sz, [_i, _i64]),
     "csplat_backward_scratch_bytes": (_sz, [_i, _i64]),
     "csplat_geom_layout": (_i, [_i, C.POINTER(_sz)]),
-    "csplat_binning_layout": (_i, [_i64, C.POINTER(_sz)]),
+    "csplat_binning_layout": (_i, [_i64, _i, _i, C.POINTER(_sz)]),
     "csplat_image_layout": (_i, [_i, _i, C.POINTER(_sz)]),
     "csplat_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                             _i, ALLOC_FN, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp),
                             C.POINTER(_vp)]),
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
-                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
     "csplat_prof_enable": (_i, [C.c_uint]),
     "csplat_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),

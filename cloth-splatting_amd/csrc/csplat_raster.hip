@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
                                                      const float *__restrict__ scales, float scale_mod,
                                                      const float *__restrict__ rotations,
                                                      const float *__restrict__ cov3D_precomp, Cam cam, Geom g,
-                                                     int32_t *__restrict__ radii) {
+                                                     int32_t *__restrict__ radii, int nocull) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
         // conic uniformly) and of the per-pixel power evaluation.
         const float cancel = 4e-7f * (a * c + b * b) / det;
         cut = cancel < 0.25f ? 2.f * lam1 * logf(255.f * op) * (1.0001f + 2.f * cancel) + 0.01f : 3.0e38f;
+        if (nocull) cut = 3.0e38f;
     } while (0);
 
     g.depth[i] = depth;
@@ -320,6 +321,42 @@ __device__ __forceinline__ bool box_hit(float2 c, float cut2, float bx0, float b
 // with one ballot against the box of its still-live pixels, and composites the surviving entries in groups of four
 // (four independent alpha evaluations in flight, then the short sequential transmittance chain).
 constexpr int FWD_GROUP = 4;
+constexpr int SEG = 256;   // tile-list entries per backward segment (multiple of 64)
+
+// per-tile segment plan: seg_offset[t] = first segment slot of tile t (exclusive scan of ceil(n_t / SEG)),
+// slot_tile[slot] = owning tile.  One workgroup; tiles are few (2500 at 800x800).
+__global__ __launch_bounds__(1024) void k_seg_plan(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
+                                                    int *__restrict__ slot_tile) {
+    __shared__ int s_w[17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < tiles; base += 1024) {
+        const int t = base + threadIdx.x;
+        int ns = 0;
+        if (t < tiles) { const int2 r = ranges[t]; ns = (r.y - r.x + SEG - 1) / SEG; }
+        int inc = ns;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        if (w == 0) {
+            int v = lane < 16 ? s_w[lane] : 0, vi = v;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(vi, d, 64); if (lane >= d) vi += o; }
+            if (lane < 16) s_w[lane] = vi - v;
+            if (lane == 15) s_w[16] = vi;
+        }
+        __syncthreads();
+        const int ex = carry + s_w[w] + inc - ns;
+        if (t < tiles) {
+            seg_offset[t] = ex;
+            for (int k = 0; k < ns; k++) slot_tile[ex + k] = t;
+        }
+        carry += s_w[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) seg_offset[tiles] = carry;
+}
 
 __device__ __forceinline__ void quadrant_pixel(int quad, int gx, int lane, int &tile, int &px, int &py) {
     tile = quad >> 2;
@@ -333,6 +370,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
                                                     const float *__restrict__ rgb, const float *__restrict__ depth,
                                                     const float4 *__restrict__ conic_opacity,
                                                     const float *__restrict__ cut2, const float *__restrict__ bg,
+                                                    const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth) {
     __shared__ float2 s_xy[64];
@@ -362,7 +400,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
         float cut_cur = lane < n ? cut2[id_cur] : -1.f;
         float4 co_cur = conic_opacity[id_cur];
         float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
+        const int seg0 = seg_offset[tile];
         for (int base = 0; base < n; base += 64) {
+            // segment boundary: checkpoint (T, colour so far) so that K7 can replay every SEG-entry segment of this
+            // quadrant independently (depth-split backward)
+            if ((base & (SEG - 1)) == 0)
+                ckpt[(size_t)(seg0 + base / SEG) * 256 + (blockIdx.x & 3) * 64 + lane] = make_float4(T, C0, C1, C2);
             // stage the current chunk for broadcast reads, start the loads of the next one
             __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk before these writes
             s_xy[lane] = c_cur; s_co[lane] = co_cur; s_cd[lane] = cd_cur;
@@ -447,63 +490,82 @@ __device__ __forceinline__ float row_sum(float v) {
 constexpr int ACC_STRIDE = 12;
 constexpr int BWD_GROUP = 2;
 
-// Same decomposition as K6: one wavefront per 8x8 quadrant, no barriers, the tile list walked back to front from the
-// quadrant's deepest contributor in 64-entry chunks (prefetched), one ballot of box-culled survivors per chunk.
-// Per surviving entry the 64 per-pixel partials are folded with DPP row sums; lane q of every row then takes value q,
-// two cross-row exchanges finish the sum, and lanes 0..8 issue ONE 36-byte atomic instruction into the Gaussian's
-// record (<= 4 quadrants x tiles-touched adds per address, instead of one atomic per pixel as upstream does).
-__global__ __launch_bounds__(64) void k_render_bwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                    int W, int H, int gx, const float *__restrict__ bg,
-                                                    const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                                    const float *__restrict__ rgb, const float *__restrict__ cut2,
-                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+// Same decomposition as K6 plus a DEPTH SPLIT: one wavefront per (8x8 quadrant, SEG-entry segment of the tile list).
+// Every segment restarts from the forward pass' checkpoint at the start of the NEXT segment: T there, and the colour
+// accumulated behind it, (C_final - C_prefix) / T.  The serial chain per wave is therefore at most SEG entries long
+// whatever the depth of the list, and a deep quadrant spreads over many SIMDs.  Inside a segment: back to front,
+// 64-entry chunks (prefetched), one ballot of box-culled survivors per chunk; per survivor the 64 per-pixel partials are
+// folded with DPP row sums, lane q of every row takes value q, two cross-row exchanges finish the sum and lanes 0..8
+// issue ONE 36-byte atomic instruction into the Gaussian's record (instead of one atomic per pixel as upstream does).
+__global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__restrict__ ranges,
+                                                    const uint32_t *__restrict__ point_list, const int *__restrict__ seg_offset,
+                                                    const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt, int W,
+                                                    int H, int gx, const float *__restrict__ bg, const float2 *__restrict__ xy,
+                                                    const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                                                    const float *__restrict__ cut2, const float *__restrict__ final_T,
+                                                    const uint32_t *__restrict__ n_contrib, const float *__restrict__ out_color,
                                                     const float *__restrict__ dL_dpix, float *__restrict__ acc) {
     __shared__ float2 s_xy[64];
     __shared__ float4 s_co[64];
     __shared__ float4 s_c[64];   // rgb + Gaussian id (bit pattern) in .w
+    const int slot = blockIdx.x >> 2, wq = blockIdx.x & 3;
+    if (slot >= seg_offset[tiles]) return;
+    const int tile = slot_tile[slot];
+    const int seg = slot - seg_offset[tile];
     const int lane = threadIdx.x;
-    int tile, px, py;
-    quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
+    int tile_, px, py;
+    quadrant_pixel(tile * 4 + wq, gx, lane, tile_, px, py);
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
-    if (n <= 0) return;
+    const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
     const bool inside = px < W && py < H;
     const int pix = py * W + px;
     const float fx = (float)px, fy = (float)py;
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    const int wave_last = (int)wave_max((float)last_contributor);   // deepest contributor of the quadrant
-    if (wave_last <= 0) return;
-    const bool has = last_contributor > 0;
+    const int lane_hi = min(last_contributor, seg_hi);      // this lane replays positions [seg_lo, lane_hi)
+    const int wave_hi = (int)wave_max((float)lane_hi);
+    if (wave_hi <= seg_lo) return;
+    const bool has = lane_hi > seg_lo;
     const float bx0 = wave_min(has ? fx : 3.0e38f), bx1 = wave_max(has ? fx : -3.0e38f);
     const float by0 = wave_min(has ? fy : 3.0e38f), by1 = wave_max(has ? fy : -3.0e38f);
 
+    const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
     float accr0 = 0.f, accr1 = 0.f, accr2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
-    const size_t HW = (size_t)H * W;
+    if (last_contributor > seg_hi) {
+        // contributors exist behind this segment: resume from the checkpoint at the start of the next segment
+        const float4 ck = ckpt[(size_t)(slot + 1) * 256 + wq * 64 + lane];
+        T = ck.x;
+        const float inv = 1.f / ck.x;
+        accr0 = (out_color[pix] - T_final * bg[0] - ck.y) * inv;
+        accr1 = (out_color[HW + pix] - T_final * bg[1] - ck.z) * inv;
+        accr2 = (out_color[2 * HW + pix] - T_final * bg[2] - ck.w) * inv;
+    }
     const float dp0 = inside ? dL_dpix[pix] : 0.f, dp1 = inside ? dL_dpix[HW + pix] : 0.f,
                 dp2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-    // chunk c, lane l  <->  list position pos = wave_last-1 - (64c + l)   (back to front)
+    // chunk c, lane l  <->  list position pos = wave_hi-1 - (64c + l), down to seg_lo   (back to front)
     const uint32_t *pl = point_list + range.x;
+    const int cnt = wave_hi - seg_lo;
     const int q16 = lane & 15;
-    auto idx_of = [&](int e) { return wave_last - 1 - e; };
-    uint32_t id_cur = lane < wave_last ? pl[idx_of(lane)] : 0u;
-    uint32_t id_nxt = 64 + lane < wave_last ? pl[idx_of(64 + lane)] : 0u;
+    auto idx_of = [&](int e) { return wave_hi - 1 - e; };
+    uint32_t id_cur = lane < cnt ? pl[idx_of(lane)] : 0u;
+    uint32_t id_nxt = 64 + lane < cnt ? pl[idx_of(64 + lane)] : 0u;
     float2 c_cur = xy[id_cur];
-    float cut_cur = lane < wave_last ? cut2[id_cur] : -1.f;
+    float cut_cur = lane < cnt ? cut2[id_cur] : -1.f;
     float4 co_cur = conic_opacity[id_cur];
     float4 col_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], __uint_as_float(id_cur));
-    for (int base = 0; base < wave_last; base += 64) {
+    for (int base = 0; base < cnt; base += 64) {
         __syncthreads();   // single-wave workgroup: previous chunk's LDS reads precede these writes
         s_xy[lane] = c_cur; s_co[lane] = co_cur; s_c[lane] = col_cur;
         const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
         const int nb = base + 64;
-        const uint32_t id_n2 = nb + 64 + lane < wave_last ? pl[idx_of(nb + 64 + lane)] : 0u;
+        const uint32_t id_n2 = nb + 64 + lane < cnt ? pl[idx_of(nb + 64 + lane)] : 0u;
         c_cur = xy[id_nxt];
-        cut_cur = nb + lane < wave_last ? cut2[id_nxt] : -1.f;
+        cut_cur = nb + lane < cnt ? cut2[id_nxt] : -1.f;
         co_cur = conic_opacity[id_nxt];
         col_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], __uint_as_float(id_nxt));
         id_nxt = id_n2;
@@ -526,8 +588,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(const int2 *__restrict__ rang
                 const float power = -0.5f * (cov[k].x * dxv[k] * dxv[k] + cov[k].z * dyv[k] * dyv[k]) - cov[k].y * dxv[k] * dyv[k];
                 Gv[k] = __expf(power);
                 const float a = fminf(0.99f, cov[k].w * Gv[k]);
-                const int jpos = wave_last - 1 - (base + j[k]);
-                al[k] = (ok[k] && jpos < last_contributor && power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
+                const int jpos = wave_hi - 1 - (base + j[k]);
+                al[k] = (ok[k] && jpos < lane_hi && power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
             }
             float v[BWD_GROUP][9];
             unsigned long long any[BWD_GROUP];
@@ -812,12 +874,18 @@ size_t image_offsets(int W, int H, size_t *off) {
     off[2] = off[1] + align256(X * 4);
     return off[2] + align256(X * 4);
 }
-// binning: 0 keys_sorted u64 | 1 ids_sorted u32
-size_t binning_offsets(int64_t R, size_t *off) {
+// binning: 0 keys_sorted u64[R] | 1 ids_sorted u32[R] | 2 seg_offset i32[tiles+1] | 3 slot_tile i32[slots]
+//          | 4 ckpt float4[slots][4 quadrants][64 lanes]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
+int64_t max_slots(int64_t R, int tiles) { return R / SEG + tiles + 1; }
+size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
+    const size_t slots = (size_t)max_slots(R, tiles);
     off[0] = 0;
     off[1] = align256(n * 8);
-    return off[1] + align256(n * 4);
+    off[2] = off[1] + align256(n * 4);
+    off[3] = off[2] + align256((size_t)(tiles + 1) * 4);
+    off[4] = off[3] + align256(slots * 4);
+    return off[4] + align256(slots * 256 * 16);
 }
 // temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
 size_t temp_offsets(int64_t R, size_t *off) {
@@ -839,6 +907,8 @@ int make_cam(Cam &c, const float *view, const float *proj, const float *campos, 
     return 0;
 }
 
+unsigned g_debug_flags = 0;   // bit 0: disable wave-level culling (test hook, csplat_debug_flags)
+
 int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n (upstream getHigherMsb)
     int b = 0;
     while ((1u << b) < n && b < 31) b++;
@@ -850,15 +920,16 @@ int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n
 extern "C" {
 
 int csplat_abi_version(void) { return CSPLAT_ABI_VERSION; }
+int csplat_debug_flags(unsigned flags) { g_debug_flags = flags; return 0; }
 const char *csplat_last_error(void) { return g_csplat_err; }
 
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
 size_t csplat_image_bytes(int W, int H) { size_t off[3]; return image_offsets(W, H, off); }
-size_t csplat_binning_bytes(int64_t R) { size_t off[2]; return binning_offsets(R, off); }
+size_t csplat_binning_bytes(int64_t R, int W, int H) { size_t off[5]; return binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); }
 size_t csplat_temp_bytes(int P, int64_t R) { (void)P; size_t off[5]; return temp_offsets(R, off); }
 size_t csplat_backward_scratch_bytes(int P, int64_t R) { (void)R; return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4); }
 int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
-int csplat_binning_layout(int64_t R, size_t *o2) { binning_offsets(R, o2); return 0; }
+int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[5]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
 int csplat_image_layout(int W, int H, size_t *o3) { image_offsets(W, H, o3); return 0; }
 
 int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
@@ -895,7 +966,7 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         {
             ProfScope ps(PROF_K1, s);
             k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
-                                                       scale_modifier, rotations, cov3D_precomp, cam, g, radii);
+                                                       scale_modifier, rotations, cov3D_precomp, cam, g, radii, (int)(g_debug_flags & 1u));
             LAUNCH_CHECK();
         }
         {
@@ -906,12 +977,15 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         HIP_TRY(hipStreamSynchronize(s));
     }
     *num_rendered = (int)R;
-    void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R));
+    void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
     CSPLAT_REQUIRE(bbase, "allocator returned NULL");
-    size_t boff[2];
-    binning_offsets(R, boff);
+    size_t boff[5];
+    binning_offsets(R, tiles, boff);
     uint64_t *keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
     uint32_t *ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
+    int *seg_offset = (int *)((char *)bbase + boff[2]);
+    int *slot_tile = (int *)((char *)bbase + boff[3]);
+    float4 *ckpt = (float4 *)((char *)bbase + boff[4]);
     HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
     if (R > 0) {
         void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R));
@@ -940,9 +1014,14 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         }
     }
     {
+        ProfScope ps(PROF_K5, s);
+        k_seg_plan<<<1, 1024, 0, s>>>(tiles, ranges, seg_offset, slot_tile);
+        LAUNCH_CHECK();
+    }
+    {
         ProfScope ps(PROF_K6, s);
         k_render_fwd<<<tiles * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, g.cut2,
-                                              bg, final_T, n_contrib, out_color, out_depth);
+                                              bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
@@ -953,31 +1032,37 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
                     const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
                     const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
                     const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
-                    const void *binning, const void *image, const float *dL_dpix, void *scratch, float *dL_dmean2D,
+                    const void *binning, const void *image, const float *out_color, const float *dL_dpix, void *scratch,
+                    float *dL_dmean2D,
                     float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
                     float *dL_dsh, float *dL_dscale, float *dL_drot) {
     hipStream_t s = (hipStream_t)stream;
     (void)colors_precomp;
-    CSPLAT_REQUIRE(geom && binning && image, "csplat_backward: missing saved state");
+    CSPLAT_REQUIRE(geom && binning && image && out_color, "csplat_backward: missing saved state");
     CSPLAT_REQUIRE(dL_dmean2D && dL_dconic && dL_dopacity && dL_dcolor && dL_dmean3D && dL_dcov3D, "missing gradient outputs");
     CSPLAT_REQUIRE(scratch != nullptr, "csplat_backward: scratch (csplat_backward_scratch_bytes) missing");
     if (P <= 0) return 0;
     Cam cam;
     make_cam(cam, view, proj, campos, tanfovx, tanfovy, W, H);
     Geom g = geom_view((void *)geom, P);
-    size_t ioff[3], boff[2];
+    const int tiles = cam.gx * cam.gy;
+    size_t ioff[3], boff[5];
     image_offsets(W, H, ioff);
-    binning_offsets(R, boff);
+    binning_offsets(R, tiles, boff);
     const int2 *ranges = (const int2 *)((const char *)image + ioff[0]);
     const uint32_t *n_contrib = (const uint32_t *)((const char *)image + ioff[1]);
     const float *final_T = (const float *)((const char *)image + ioff[2]);
     const uint32_t *ids_sorted = (const uint32_t *)((const char *)binning + boff[1]);
+    const int *seg_offset = (const int *)((const char *)binning + boff[2]);
+    const int *slot_tile = (const int *)((const char *)binning + boff[3]);
+    const float4 *ckpt = (const float4 *)((const char *)binning + boff[4]);
     float *acc = (float *)scratch;
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
     if (R > 0) {
         ProfScope ps(PROF_K7, s);
-        k_render_bwd<<<cam.gx * cam.gy * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, bg, g.xy, g.conic_opacity, g.rgb,
-                                                        g.cut2, final_T, n_contrib, dL_dpix, acc);
+        k_render_bwd<<<(unsigned)(max_slots(R, tiles) * 4), 64, 0, s>>>(tiles, ranges, ids_sorted, seg_offset, slot_tile, ckpt, W, H,
+                                                                        cam.gx, bg, g.xy, g.conic_opacity, g.rgb, g.cut2, final_T,
+                                                                        n_contrib, out_color, dL_dpix, acc);
         LAUNCH_CHECK();
     }
     {

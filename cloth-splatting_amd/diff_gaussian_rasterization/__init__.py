@@ -82,13 +82,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.M = M
         ctx.chunks = (alloc.chunks[_n_GEOM], alloc.chunks[_n_BINNING], alloc.chunks[_n_IMAGE])
         ctx.consts = (bg, view, proj, campos)
-        ctx.save_for_backward(means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii)
+        ctx.save_for_backward(means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color)
         ctx.mark_non_differentiable(radii, depth)
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, _grad_depth):
-        means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii = ctx.saved_tensors
+        means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color = ctx.saved_tensors
         rs = ctx.rs
         dev = means3D.device
         P = int(means3D.shape[0])
@@ -110,7 +110,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _n.stream_handle(dev), P, int(rs.sh_degree), M, ctx.num_rendered, _n.ptr(bg), W, H, _n.ptr(means3D),
                 _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(scales), float(rs.scale_modifier), _n.ptr(rotations),
                 _n.ptr(cov3Ds_precomp), _n.ptr(view), _n.ptr(proj), _n.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image), _n.ptr(grad_color), _n.ptr(scratch),
+                _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image), _n.ptr(color), _n.ptr(grad_color),
+                _n.ptr(scratch),
                 _n.ptr(d_mean2D),
                 _n.ptr(d_conic), _n.ptr(d_opac), _n.ptr(d_color), _n.ptr(d_mean3D), _n.ptr(d_cov3D), _n.ptr(d_sh),
                 _n.ptr(d_scale), _n.ptr(d_rot))

@@ -42,22 +42,24 @@ extern "C" {
 typedef void *(*csplat_alloc_fn)(void *ctx, int chunk, size_t bytes);
 
 int csplat_abi_version(void);
+int csplat_debug_flags(unsigned flags); /* test hook. bit 0: disable the wave-level culling of K6/K7 (results must not change) */
 const char *csplat_last_error(void);
 
 /* Sizes of the chunks (bytes) so that a caller may pre-allocate instead of answering the callback lazily. */
 size_t csplat_geom_bytes(int P);
 size_t csplat_image_bytes(int W, int H);
-size_t csplat_binning_bytes(int64_t R);
+size_t csplat_binning_bytes(int64_t R, int W, int H);
 size_t csplat_temp_bytes(int P, int64_t R);
 size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-Gaussian accumulation records used by csplat_backward */
 
 /* Byte offsets of the named sub-buffers inside a chunk (for tests / debugging; see DESIGN.md "HBM layout").
  * geom:    0 depth f32[P] | 1 xy f32[P][2] | 2 conic_opacity f32[P][4] | 3 rgb f32[P][3] | 4 cov3D f32[P][6]
  *          | 5 clamped u32[P] (bit c = channel c clamped) | 6 tiles_touched u32[P] | 7 offsets u32[P] (inclusive scan)
- * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)
+ * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)   [then the per-tile segment plan and the forward's
+ *          per-segment (T, colour) checkpoints that the depth-split backward restarts from]
  * image:   0 ranges i32[tiles][2] | 1 n_contrib u32[H*W] | 2 final_T f32[H*W]                               */
 int csplat_geom_layout(int P, size_t *offsets8);
-int csplat_binning_layout(int64_t R, size_t *offsets2);
+int csplat_binning_layout(int64_t R, int W, int H, size_t *offsets2);
 int csplat_image_layout(int W, int H, size_t *offsets3);
 
 /* Forward: K1 preprocess, K2 scan, K3 key emission, K4 radix sort, K5 tile ranges, K6 compositing.
@@ -77,7 +79,8 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
                    int *num_rendered, void **geom, void **binning, void **image);
 
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
- * dL_dpix[3][H][W] is the gradient of the colour image (the depth image carries no gradient, as upstream).
+ * out_color is the forward's colour image; dL_dpix[3][H][W] its gradient (the depth image carries no gradient,
+ * as upstream).
  * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes (one 48-byte accumulation record per Gaussian:
  * K7 adds one wave-reduced 36-byte partial per (quadrant, surviving list entry), K8 consumes the records).
  * Gradient outputs (device, fully overwritten): dL_dmean2D[P][3] (NDC units, .z = 0), dL_dconic[P][4],
@@ -87,7 +90,8 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
                     const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
                     const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
                     const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
-                    const void *binning, const void *image, const float *dL_dpix, void *scratch, float *dL_dmean2D,
+                    const void *binning, const void *image, const float *out_color, const float *dL_dpix, void *scratch,
+                    float *dL_dmean2D,
                     float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
                     float *dL_dsh, float *dL_dscale, float *dL_drot);
 

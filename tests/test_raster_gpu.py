@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import util
-from util import make_case, oracle_forward, rel_err
+from util import image_err, make_case, oracle_forward, rel_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -65,9 +65,9 @@ def test_forward_image(cfg):
     o64 = oracle_forward(case, dtype=np.float64)
     color, radii, depth, st = util.gpu_forward_raw(case)
     c, d = color.cpu().numpy(), depth.cpu().numpy()
-    assert rel_err(c, o64.color) < TOL and rel_err(d, o64.out_depth) < TOL
-    assert rel_err(c, o.color) < TOL and rel_err(d, o.out_depth) < TOL
-    assert rel_err(st["final_T"], o.final_T) < TOL
+    assert image_err(c, o64.color) < TOL and image_err(d, o64.out_depth) < TOL
+    assert image_err(c, o.color) < TOL and image_err(d, o.out_depth) < TOL
+    assert image_err(st["final_T"], o.final_T) < TOL
     # n_contrib is an index: exact, except where an alpha / transmittance test sits within an exp() ulp of its
     # threshold (GPU v_exp_f32 vs glibc expf).  Such ties are counted and must be vanishingly rare.
     mism = (st["n_contrib"] != o.n_contrib)
@@ -103,7 +103,7 @@ def test_colors_precomp_and_cov_precomp():
     g64 = util.ro.backward(o, dpix)
     inp, kw, color, radii, depth = _run_gpu(case, dpix, shs=None, colors_precomp=colors, scales=None, rotations=None,
                                             cov3D_precomp=cov)
-    assert rel_err(color.detach().cpu().numpy(), o.color) < TOL
+    assert image_err(color.detach().cpu().numpy(), o.color) < TOL
     np.testing.assert_array_equal(radii.cpu().numpy(), oracle_forward(case, shs=None, colors_precomp=colors, scales=None,
                                                                       rotations=None, cov3D_precomp=cov).radii)
     assert rel_err(kw["colors_precomp"].grad.cpu().numpy(), g64.color) < TOL
@@ -119,7 +119,7 @@ def test_lower_sh_degrees(deg):
     dpix = np.random.default_rng(1).normal(size=(3, 64, 64)).astype(np.float32)
     g64 = util.ro.backward(o, dpix)
     inp, kw, color, radii, depth = _run_gpu(case, dpix)
-    assert rel_err(color.detach().cpu().numpy(), o.color) < TOL
+    assert image_err(color.detach().cpu().numpy(), o.color) < TOL
     assert rel_err(inp["shs"].grad.cpu().numpy(), g64.sh) < TOL
     assert float(inp["shs"].grad[:, (deg + 1) ** 2:].abs().max()) == 0.0
 
@@ -131,9 +131,31 @@ def test_scale_modifier_quirk():
     dpix = np.random.default_rng(2).normal(size=(3, 64, 64)).astype(np.float32)
     g64 = util.ro.backward(o, dpix)
     inp, kw, color, radii, depth = _run_gpu(case, dpix, scale_mod=1.7)
-    assert rel_err(color.detach().cpu().numpy(), o.color) < TOL
+    assert image_err(color.detach().cpu().numpy(), o.color) < TOL
     assert rel_err(inp["scales"].grad.cpu().numpy(), g64.scale) < TOL
     assert rel_err(inp["rotations"].grad.cpu().numpy(), g64.rot) < TOL
+
+
+def test_wave_culling_is_exact():
+    """The ballot culling of K6/K7 may only skip entries that cannot change any pixel of the wave: image, n_contrib and
+    (up to atomic order) gradients must be identical with the culling switched off (csplat_debug_flags bit 0)."""
+    from csplat import native
+    case = make_case(P=3000, W=200, H=136, seed=8, grid=16, scale_mul=2.5)
+    dpix = np.random.default_rng(9).normal(size=(3, case["H"], case["W"])).astype(np.float32)
+    res = []
+    try:
+        for flag in (0, 1):
+            native.lib.csplat_debug_flags(flag)
+            color, radii, depth, st = util.gpu_forward_raw(case)
+            inp, kw, c2, _, _ = _run_gpu(case, dpix)
+            res.append((color.cpu().numpy(), depth.cpu().numpy(), st["n_contrib"], st["final_T"],
+                        {k: inp[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}))
+    finally:
+        native.lib.csplat_debug_flags(0)
+    for a, b in zip(res[0][:4], res[1][:4]):
+        np.testing.assert_array_equal(a, b)
+    for k in res[0][4]:
+        assert rel_err(res[0][4][k], res[1][4][k]) < 1e-5, k
 
 
 def test_empty_and_all_culled():
