@@ -288,6 +288,164 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint64_t *
     if (i == R - 1) ranges[t].y = (int)R;
 }
 
+// ---- tile-bucketed binning (default path) ------------------------------------------------------------------------
+// One MSD "radix" pass whose digit is the tile id, without any global atomic:
+//   k_tile_count   workgroup b (1024 Gaussians) histograms its instances per tile in LDS -> table[b][tile]
+//   k_tile_colscan per tile: exclusive scan over the workgroups, in place (each workgroup's offset inside the tile's list)
+//   k_tile_scan    exclusive scan of the per-tile totals: tile ranges, R and the longest list
+//   k_emit_bucket  workgroup b reloads its bases into LDS and drops every instance at base[tile]++ (LDS atomic)
+//   k_tile_sort    each tile's list ordered by (depth bits, Gaussian id) with an in-LDS bitonic network.  The composite
+//                  key is unique, so the result is exactly the stable (tile | depth) radix order of the upstream pipeline.
+constexpr int BUCKET_CAP = 8192;    // longest tile list the LDS sort takes (64 KB); longer lists -> global radix sort
+constexpr int BUCKET_TILES = 12288; // most tiles the per-workgroup LDS histogram takes (48 KB)
+constexpr int BUCKET_G = 1024;      // Gaussians per counting workgroup
+
+__global__ __launch_bounds__(BUCKET_G) void k_tile_count(int P, int tiles, const float2 *__restrict__ xy,
+                                                          const int32_t *__restrict__ radii, Cam cam,
+                                                          uint32_t *__restrict__ table) {
+    extern __shared__ uint32_t s_hist[];
+    for (int t = threadIdx.x; t < tiles; t += BUCKET_G) s_hist[t] = 0u;
+    __syncthreads();
+    const int i = blockIdx.x * BUCKET_G + threadIdx.x;
+    if (i < P) {
+        const int rad = radii[i];
+        if (rad > 0) {
+            const float2 p = xy[i];
+            int minx, miny, maxx, maxy;
+            tile_rect(p.x, p.y, rad, cam, minx, miny, maxx, maxy);
+            for (int y = miny; y < maxy; y++)
+                for (int x = minx; x < maxx; x++) atomicAdd(&s_hist[y * cam.gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *row = table + (size_t)blockIdx.x * tiles;
+    for (int t = threadIdx.x; t < tiles; t += BUCKET_G) row[t] = s_hist[t];
+}
+
+// per tile (one lane each, coalesced across tiles): exclusive prefix over the nb counting workgroups, in place;
+// the column total goes to cnt[tile]
+__global__ __launch_bounds__(256) void k_tile_colscan(int tiles, int nb, uint32_t *__restrict__ table, uint32_t *__restrict__ cnt) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles) return;
+    uint32_t run = 0;
+    int b = 0;
+    for (; b + 8 <= nb; b += 8) {   // 8 independent loads in flight
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = table[(size_t)(b + u) * tiles + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { table[(size_t)(b + u) * tiles + t] = run; run += v[u]; }
+    }
+    for (; b < nb; b++) { const uint32_t v = table[(size_t)b * tiles + t]; table[(size_t)b * tiles + t] = run; run += v; }
+    cnt[t] = run;
+}
+
+// single workgroup: exclusive scan of the per-tile totals -> tile ranges, R, longest list
+__global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
+                                                     uint32_t *__restrict__ info) {
+    __shared__ uint32_t s_w[17];
+    __shared__ uint32_t s_max[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t carry = 0, mx = 0;
+    for (int base = 0; base < tiles; base += 1024) {
+        const int t = base + threadIdx.x;
+        const uint32_t c = t < tiles ? cnt[t] : 0u;
+        mx = max(mx, c);
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        if (w == 0) {
+            uint32_t v = lane < 16 ? s_w[lane] : 0u, vi = v;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const uint32_t o = __shfl_up(vi, d, 64); if (lane >= d) vi += o; }
+            if (lane < 16) s_w[lane] = vi - v;
+            if (lane == 15) s_w[16] = vi;
+        }
+        __syncthreads();
+        const uint32_t ex = carry + s_w[w] + inc - c;
+        if (t < tiles) ranges[t] = c ? make_int2((int)ex, (int)(ex + c)) : make_int2(0, 0);
+        carry += s_w[16];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 0) s_max[w] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (int k = 0; k < 16; k++) m = max(m, s_max[k]);
+        info[0] = carry;
+        info[1] = m;
+    }
+}
+
+__global__ __launch_bounds__(BUCKET_G) void k_emit_bucket(int P, int tiles, const float2 *__restrict__ xy,
+                                                           const float *__restrict__ depth, const int32_t *__restrict__ radii,
+                                                           Cam cam, const uint32_t *__restrict__ table,
+                                                           const int2 *__restrict__ ranges, uint64_t *__restrict__ comp) {
+    extern __shared__ uint32_t s_base[];
+    const uint32_t *row = table + (size_t)blockIdx.x * tiles;
+    for (int t = threadIdx.x; t < tiles; t += BUCKET_G) s_base[t] = (uint32_t)ranges[t].x + row[t];
+    __syncthreads();
+    const int i = blockIdx.x * BUCKET_G + threadIdx.x;
+    if (i >= P) return;
+    const int rad = radii[i];
+    if (rad <= 0) return;
+    const float2 p = xy[i];
+    int minx, miny, maxx, maxy;
+    tile_rect(p.x, p.y, rad, cam, minx, miny, maxx, maxy);
+    const uint64_t v = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+    for (int y = miny; y < maxy; y++)
+        for (int x = minx; x < maxx; x++) comp[atomicAdd(&s_base[y * cam.gx + x], 1u)] = v;
+}
+
+constexpr int TSORT_THREADS = 1024;
+__global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
+                                                              uint64_t *__restrict__ keys_sorted,
+                                                              uint32_t *__restrict__ ids_sorted) {
+    extern __shared__ uint64_t s_key[];
+    const int tile = blockIdx.x;
+    const int2 r = ranges[tile];
+    const int n = r.y - r.x;
+    if (n <= 0) return;
+    int m = 64;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += TSORT_THREADS) s_key[i] = i < n ? comp[r.x + i] : ~0ull;
+    __syncthreads();
+    const int half = m >> 1;
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            // up to 4 independent compare-exchanges per thread, loads first (ILP), then the conditional stores
+            for (int i0 = threadIdx.x; i0 < half; i0 += 4 * TSORT_THREADS) {
+                int l[4];
+                uint64_t a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * TSORT_THREADS;
+                    l[u] = i < half ? 2 * i - (i & (j - 1)) : -1;
+                    if (l[u] >= 0) { a[u] = s_key[l[u]]; b[u] = s_key[l[u] + j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (l[u] >= 0) {
+                        const bool asc = (l[u] & k) == 0;
+                        if ((a[u] > b[u]) == asc) { s_key[l[u]] = b[u]; s_key[l[u] + j] = a[u]; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
+    for (int i = threadIdx.x; i < n; i += TSORT_THREADS) {
+        const uint64_t v = s_key[i];
+        keys_sorted[r.x + i] = hi | (v >> 32);
+        ids_sorted[r.x + i] = (uint32_t)v;
+    }
+}
+
 template <int CTRL, int RMASK>
 __device__ __forceinline__ float dpp_mov(float v, float old) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, RMASK, 0xF, false));
@@ -867,13 +1025,18 @@ Geom geom_view(void *base, int P) {
     g.scan_tmp = (void *)(b + off[G_SCANTMP]);
     return g;
 }
+// image: 0 ranges | 1 n_contrib | 2 final_T | 3 info u32[4] (R, longest tile list)
 size_t image_offsets(int W, int H, size_t *off) {
     const size_t tiles = (size_t)cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), X = (size_t)W * H;
     off[0] = 0;
     off[1] = align256(tiles * 8);
     off[2] = off[1] + align256(X * 4);
-    return off[2] + align256(X * 4);
+    off[3] = off[2] + align256(X * 4);
+    off[4] = off[3] + 256;
+    return off[4];
 }
+// per-(counting workgroup, tile) table of the bucketed binning path; requested as its own TEMP-class chunk
+size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 0 ? P : 1, BUCKET_G) + 1) * tiles * 4); }
 // binning: 0 keys_sorted u64[R] | 1 ids_sorted u32[R] | 2 seg_offset i32[tiles+1] | 3 slot_tile i32[slots]
 //          | 4 ckpt float4[slots][4 quadrants][64 lanes]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
 int64_t max_slots(int64_t R, int tiles) { return R / SEG + tiles + 1; }
@@ -924,13 +1087,13 @@ int csplat_debug_flags(unsigned flags) { g_debug_flags = flags; return 0; }
 const char *csplat_last_error(void) { return g_csplat_err; }
 
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
-size_t csplat_image_bytes(int W, int H) { size_t off[3]; return image_offsets(W, H, off); }
+size_t csplat_image_bytes(int W, int H) { size_t off[5]; return image_offsets(W, H, off); }
 size_t csplat_binning_bytes(int64_t R, int W, int H) { size_t off[5]; return binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); }
 size_t csplat_temp_bytes(int P, int64_t R) { (void)P; size_t off[5]; return temp_offsets(R, off); }
 size_t csplat_backward_scratch_bytes(int P, int64_t R) { (void)R; return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4); }
 int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
 int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[5]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
-int csplat_image_layout(int W, int H, size_t *o3) { image_offsets(W, H, o3); return 0; }
+int csplat_image_layout(int W, int H, size_t *o3) { size_t off[5]; image_offsets(W, H, off); o3[0] = off[0]; o3[1] = off[1]; o3[2] = off[2]; return 0; }
 
 int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
                    const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
@@ -954,28 +1117,52 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     void *ibase = alloc(alloc_ctx, CSPLAT_CHUNK_IMAGE, csplat_image_bytes(W, H));
     CSPLAT_REQUIRE(gbase && ibase, "allocator returned NULL");
     Geom g = geom_view(gbase, P);
-    size_t ioff[3];
+    size_t ioff[5];
     image_offsets(W, H, ioff);
     int2 *ranges = (int2 *)((char *)ibase + ioff[0]);
     uint32_t *n_contrib = (uint32_t *)((char *)ibase + ioff[1]);
     float *final_T = (float *)((char *)ibase + ioff[2]);
+    uint32_t *info = (uint32_t *)((char *)ibase + ioff[3]);
     const int tiles = cam.gx * cam.gy;
+    const int nb = cdiv(P > 0 ? P : 1, BUCKET_G);
+    const bool can_bucket = tiles <= BUCKET_TILES && !(g_debug_flags & 2u);
 
-    uint32_t R = 0;
+    uint32_t host_info[2] = {0, 0};   // R, longest tile list
+    if (!can_bucket) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
     if (P > 0) {
-        {
-            ProfScope ps(PROF_K1, s);
-            k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
-                                                       scale_modifier, rotations, cov3D_precomp, cam, g, radii, (int)(g_debug_flags & 1u));
-            LAUNCH_CHECK();
-        }
-        {
-            ProfScope ps(PROF_K2, s);
-            if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
-        }
-        HIP_TRY(hipMemcpyAsync(&R, g.offsets + (P - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        ProfScope ps(PROF_K1, s);
+        k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+                                                   scale_modifier, rotations, cov3D_precomp, cam, g, radii,
+                                                   (int)(g_debug_flags & 1u));
+        LAUNCH_CHECK();
     }
+    uint32_t *table = nullptr;
+    if (can_bucket) {
+        table = (uint32_t *)alloc(alloc_ctx, CSPLAT_CHUNK_TABLE, bucket_table_bytes(P, tiles));
+        CSPLAT_REQUIRE(table, "allocator returned NULL");
+        ProfScope ps(PROF_K2, s);
+        if (P > 0) {
+            k_tile_count<<<nb, BUCKET_G, (size_t)tiles * 4, s>>>(P, tiles, g.xy, radii, cam, table);
+            LAUNCH_CHECK();
+        } else {
+            HIP_TRY(hipMemsetAsync(table, 0, (size_t)nb * tiles * 4, s));
+        }
+        uint32_t *tile_cnt = table + (size_t)nb * tiles;   // last row of the chunk: per-tile totals
+        k_tile_colscan<<<cdiv(tiles, 256), 256, 0, s>>>(tiles, nb, table, tile_cnt);
+        LAUNCH_CHECK();
+        k_tile_scan<<<1, 1024, 0, s>>>(tiles, tile_cnt, ranges, info);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(host_info, info, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } else if (P > 0) {
+        ProfScope ps(PROF_K2, s);
+        if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
+        HIP_TRY(hipMemcpyAsync(host_info, g.offsets + (P - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        host_info[1] = 0xFFFFFFFFu;
+    }
+    const uint32_t R = host_info[0];
+    const bool bucketed = can_bucket && host_info[1] <= (uint32_t)BUCKET_CAP;
     *num_rendered = (int)R;
     void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
     CSPLAT_REQUIRE(bbase, "allocator returned NULL");
@@ -986,31 +1173,49 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     int *seg_offset = (int *)((char *)bbase + boff[2]);
     int *slot_tile = (int *)((char *)bbase + boff[3]);
     float4 *ckpt = (float4 *)((char *)bbase + boff[4]);
-    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
     if (R > 0) {
         void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R));
         CSPLAT_REQUIRE(tbase, "allocator returned NULL");
         size_t toff[5];
         temp_offsets(R, toff);
         uint64_t *keys_u = (uint64_t *)((char *)tbase + toff[0]);
-        uint32_t *ids_u = (uint32_t *)((char *)tbase + toff[1]);
-        uint64_t *keys_t = (uint64_t *)((char *)tbase + toff[2]);
-        uint32_t *ids_t = (uint32_t *)((char *)tbase + toff[3]);
-        void *stab = (char *)tbase + toff[4];
-        {
-            ProfScope ps(PROF_K3, s);
-            k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, ids_u);
-            LAUNCH_CHECK();
-        }
-        const int end_bit = 32 + higher_msb((uint32_t)tiles);
-        {
+        if (bucketed) {
+            {
+                ProfScope ps(PROF_K3, s);
+                k_emit_bucket<<<nb, BUCKET_G, (size_t)tiles * 4, s>>>(P, tiles, g.xy, g.depth, radii, cam, table, ranges, keys_u);
+                LAUNCH_CHECK();
+            }
+            int m = 64;
+            while (m < (int)host_info[1]) m <<= 1;
             ProfScope ps(PROF_K4, s);
-            if (int rc = csplat_sort_pairs(s, keys_u, ids_u, keys_sorted, ids_sorted, keys_t, ids_t, R, end_bit, stab)) return rc;
-        }
-        {
-            ProfScope ps(PROF_K5, s);
-            k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+            k_tile_sort<<<tiles, TSORT_THREADS, (size_t)m * 8, s>>>(ranges, keys_u, keys_sorted, ids_sorted);
             LAUNCH_CHECK();
+        } else {
+            // a tile list longer than the LDS sort takes: the global stable radix sort (upstream's pipeline shape)
+            uint32_t *ids_u = (uint32_t *)((char *)tbase + toff[1]);
+            uint64_t *keys_t = (uint64_t *)((char *)tbase + toff[2]);
+            uint32_t *ids_t = (uint32_t *)((char *)tbase + toff[3]);
+            void *stab = (char *)tbase + toff[4];
+            if (can_bucket) {   // (the bucket path was attempted: the P-scan has not run yet)
+                ProfScope ps(PROF_K2, s);
+                if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
+            }
+            {
+                ProfScope ps(PROF_K3, s);
+                k_emit_keys<<<cdiv(P, 256), 256, 0, s>>>(P, g.xy, g.depth, g.offsets, radii, cam, keys_u, ids_u);
+                LAUNCH_CHECK();
+            }
+            const int end_bit = 32 + higher_msb((uint32_t)tiles);
+            {
+                ProfScope ps(PROF_K4, s);
+                if (int rc = csplat_sort_pairs(s, keys_u, ids_u, keys_sorted, ids_sorted, keys_t, ids_t, R, end_bit, stab)) return rc;
+            }
+            {
+                ProfScope ps(PROF_K5, s);
+                HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
+                k_tile_ranges<<<cdiv(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+                LAUNCH_CHECK();
+            }
         }
     }
     {
@@ -1046,7 +1251,7 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
     make_cam(cam, view, proj, campos, tanfovx, tanfovy, W, H);
     Geom g = geom_view((void *)geom, P);
     const int tiles = cam.gx * cam.gy;
-    size_t ioff[3], boff[5];
+    size_t ioff[5], boff[5];
     image_offsets(W, H, ioff);
     binning_offsets(R, tiles, boff);
     const int2 *ranges = (const int2 *)((const char *)image + ioff[0]);

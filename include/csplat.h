@@ -35,14 +35,17 @@ extern "C" {
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
 #define CSPLAT_CHUNK_BINNING 1 /* sorted tile instances, kept for backward */
 #define CSPLAT_CHUNK_IMAGE 2   /* per-tile ranges, per-pixel n_contrib / final_T, kept for backward */
-#define CSPLAT_CHUNK_TEMP 3    /* sort ping-pong + histograms; may be freed after forward */
+#define CSPLAT_CHUNK_TEMP 3    /* unsorted instances, sort ping-pong + histograms; may be freed after forward */
+#define CSPLAT_CHUNK_TABLE 4   /* per-(workgroup, tile) counting table of the bucketed binning; may be freed after forward */
 
 /* Must return a device pointer to at least `bytes` bytes, 256-byte aligned, valid until the matching
  * backward has run (GEOM/BINNING/IMAGE) or until csplat_forward returns (TEMP).  NULL = failure. */
 typedef void *(*csplat_alloc_fn)(void *ctx, int chunk, size_t bytes);
 
 int csplat_abi_version(void);
-int csplat_debug_flags(unsigned flags); /* test hook. bit 0: disable the wave-level culling of K6/K7 (results must not change) */
+/* test hook (results must not change).  bit 0: disable the wave-level culling of K6/K7;
+ * bit 1: force the global radix-sort binning path instead of the tile-bucketed LDS sort */
+int csplat_debug_flags(unsigned flags);
 const char *csplat_last_error(void);
 
 /* Sizes of the chunks (bytes) so that a caller may pre-allocate instead of answering the callback lazily. */
@@ -54,7 +57,8 @@ size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-Gaussian accumula
 
 /* Byte offsets of the named sub-buffers inside a chunk (for tests / debugging; see DESIGN.md "HBM layout").
  * geom:    0 depth f32[P] | 1 xy f32[P][2] | 2 conic_opacity f32[P][4] | 3 rgb f32[P][3] | 4 cov3D f32[P][6]
- *          | 5 clamped u32[P] (bit c = channel c clamped) | 6 tiles_touched u32[P] | 7 offsets u32[P] (inclusive scan)
+ *          | 5 clamped u32[P] (bit c = channel c clamped) | 6 tiles_touched u32[P]
+ *          | 7 offsets u32[P] (inclusive scan; filled only on the global radix-sort path)
  * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)   [then the per-tile segment plan and the forward's
  *          per-segment (T, colour) checkpoints that the depth-split backward restarts from]
  * image:   0 ranges i32[tiles][2] | 1 n_contrib u32[H*W] | 2 final_T f32[H*W]                               */
@@ -62,7 +66,8 @@ int csplat_geom_layout(int P, size_t *offsets8);
 int csplat_binning_layout(int64_t R, int W, int H, size_t *offsets2);
 int csplat_image_layout(int W, int H, size_t *offsets3);
 
-/* Forward: K1 preprocess, K2 scan, K3 key emission, K4 radix sort, K5 tile ranges, K6 compositing.
+/* Forward: K1 preprocess (+ per-tile counts), K2 tile scan, K3 instance emission into tile buckets, K4 per-tile LDS sort
+ * (global stable radix sort when a tile list exceeds 8192 entries), K5 segment plan, K6 compositing.
  *   means3D[P][3], shs[P][M][3] or NULL, colors_precomp[P][3] or NULL (exactly one of the two),
  *   opacities[P], scales[P][3]+rotations[P][4] or cov3D_precomp[P][6] (exactly one of the two),
  *   view/proj: the reference's transposed 4x4 matrices (flat index 4*row+col of world_view_transform /
