@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""bench_gnn.py -- BASELINE.json configs[3]: ClothMeshSimulator rollout step, N = 10,000 nodes, E = 300,000 directed
+edges (30 per node), latent 128, 15 message-passing steps, history 2 (nnode_in = 8), eval mode; plus the training step
+(forward + backward).  Secondary bench (the driver's contract is bench.py); prints one JSON line.
+
+Beside the HIP path it times a plain-torch restatement of what torch_geometric does on the GPU (index_select gathers,
+[E,3L] concat, index_add_ scatter) with the same weights -- a same-device comparison of the data-movement design,
+NOT the product path."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def pyg_like_forward(net, x, ei, e):
+    """what MessagePassing.propagate executes (gather, cat, MLP, scatter-add), for timing only"""
+    x, e = net._encoder(x, e)
+    for g in net._processor.gnn_stacks:
+        xi, xj = x.index_select(0, ei[1]), x.index_select(0, ei[0])
+        m = g.edge_fn(torch.cat([xi, xj, e], dim=-1))
+        agg = torch.zeros_like(x).index_add_(0, ei[1], m)
+        x = g.node_fn(torch.cat([agg, x], dim=-1)) + x
+        e = e + e
+    return net._decoder(x)
+
+
+def timeit(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--N", type=int, default=10_000)
+    ap.add_argument("--deg", type=int, default=30)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    from csplat import native
+    from meshnet.cloth_network import ClothMeshSimulator
+    torch.manual_seed(0)
+    sim = ClothMeshSimulator(3, 8, 4, 128, 15, 2, 128, 2, 2, normalize=False, device=dev).eval()
+    N, E = args.N, args.N * args.deg
+    gen = torch.Generator().manual_seed(3)
+    # radius-graph-like connectivity: every node linked to `deg` nodes from a local window (mesh locality)
+    dst = torch.arange(N).repeat_interleave(args.deg)
+    src = (dst + torch.randint(-64, 65, (E,), generator=gen)).clamp_(0, N - 1)
+    ei = torch.stack([src, dst]).to(dev)
+    vel = (torch.randn(N, 6, generator=gen) * 0.1).to(dev)
+    ntype = torch.randint(0, 2, (N, 1), generator=gen).to(dev)
+    ef = torch.randn(E, 4, generator=gen).to(dev)
+    net = sim._encode_process_decode
+    feats = torch.cat([vel, torch.nn.functional.one_hot(ntype.squeeze().long(), 2)], 1).float()
+
+    with torch.no_grad():
+        ms_roll = timeit(lambda: sim.predict_velocity(vel, ntype, ei, ef), args.steps, args.warmup)
+        ms_pyg = timeit(lambda: pyg_like_forward(net, feats, ei, ef), args.steps, args.warmup)
+        a = net(feats, ei, ef); b = pyg_like_forward(net, feats, ei, ef)
+        rel = float((a - b).abs().max() / b.abs().max())
+        native.prof_enable(["GNN"]); native.prof_read("GNN")
+        sim.predict_velocity(vel, ntype, ei, ef); torch.cuda.synchronize()
+        gnn_ms, gnn_n = native.prof_read("GNN"); native.prof_enable([])
+
+    sim.train()
+    opt = torch.optim.Adam(sim.parameters(), lr=1e-4)
+    tgt = torch.randn(N, 3, device=dev) * 0.1
+
+    def train_step(fwd):
+        opt.zero_grad(set_to_none=True)
+        pred = fwd()
+        loss = ((pred - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+    ms_train = timeit(lambda: train_step(lambda: net(feats, ei, ef)), args.steps, args.warmup)
+    ms_train_pyg = timeit(lambda: train_step(lambda: pyg_like_forward(net, feats, ei, ef)), args.steps, args.warmup)
+
+    L, M = 128, 15
+    alg = (16 * E + 12 * N) * L * M          # bytes of gather/scatter traffic per rollout step
+    out = {"metric": "MeshNet rollout step ms (N=10k, E=300k, L=128, M=15)", "value": round(ms_roll, 3), "unit": "ms",
+           "higher_is_better": False, "dtype": "f32", "data": "synthetic",
+           "rollout_ms": round(ms_roll, 3), "pyg_like_torch_rollout_ms": round(ms_pyg, 3),
+           "train_step_ms": round(ms_train, 3), "pyg_like_torch_train_step_ms": round(ms_train_pyg, 3),
+           "hip_vs_pyg_like_rel_diff": rel,
+           "gnn_kernels": {"launches_per_step": int(gnn_n), "total_ms_per_step": round(gnn_ms, 3),
+                           "algorithmic_GBps": round(alg / (gnn_ms * 1e-3) / 1e9, 1) if gnn_ms > 0 else None,
+                           "algorithmic_bytes_per_step": alg},
+           "config": {"workload": f"ClothMeshSimulator N={N} E={E} L=128 M=15 hist=2 eval + train"}}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
