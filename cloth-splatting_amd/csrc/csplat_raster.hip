@@ -478,7 +478,7 @@ __device__ __forceinline__ bool box_hit(float2 c, float cut2, float bx0, float b
 // chunks (lane l gathers entry l, two chunks of ids / one chunk of data prefetched ahead of use), culls the chunk
 // with one ballot against the box of its still-live pixels, and composites the surviving entries in groups of four
 // (four independent alpha evaluations in flight, then the short sequential transmittance chain).
-constexpr int FWD_GROUP = 4;
+constexpr int FWD_GROUP = 8;
 constexpr int SEG = 256;   // tile-list entries per backward segment (multiple of 64)
 
 // per-tile segment plan: seg_offset[t] = first segment slot of tile t (exclusive scan of ceil(n_t / SEG)),
@@ -531,9 +531,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
                                                     const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth) {
-    __shared__ float2 s_xy[64];
-    __shared__ float4 s_co[64];
-    __shared__ float4 s_cd[64];  // rgb + depth
+    // survivors of a chunk are COMPACTED into these arrays (slot = rank of the lane among the ballot's set bits), so the
+    // compositing loop is a plain counted loop over contiguous LDS records with immediate offsets; slots past the
+    // survivor count hold a harmless record (opacity 0).  +FWD_GROUP slots of padding for the last group.
+    __shared__ float4 s_xyi[64 + FWD_GROUP];  // x, y, list index + 1 (as float bits), unused
+    __shared__ float4 s_co[64 + FWD_GROUP];
+    __shared__ float4 s_cd[64 + FWD_GROUP];   // rgb + depth
     const int lane = threadIdx.x;
     int tile, px, py;
     quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
         float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
         unsigned long long live = __ballot(!done);
         const uint32_t *pl = point_list + range.x;
+        const int seg0 = seg_offset[tile];
         // software pipeline: ids two chunks ahead, per-entry data one chunk ahead
         uint32_t id_cur = lane < n ? pl[lane] : 0u;
         uint32_t id_nxt = 64 + lane < n ? pl[64 + lane] : 0u;
@@ -558,16 +562,27 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
         float cut_cur = lane < n ? cut2[id_cur] : -1.f;
         float4 co_cur = conic_opacity[id_cur];
         float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
-        const int seg0 = seg_offset[tile];
         for (int base = 0; base < n; base += 64) {
             // segment boundary: checkpoint (T, colour so far) so that K7 can replay every SEG-entry segment of this
             // quadrant independently (depth-split backward)
             if ((base & (SEG - 1)) == 0)
                 ckpt[(size_t)(seg0 + base / SEG) * 256 + (blockIdx.x & 3) * 64 + lane] = make_float4(T, C0, C1, C2);
-            // stage the current chunk for broadcast reads, start the loads of the next one
-            __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk before these writes
-            s_xy[lane] = c_cur; s_co[lane] = co_cur; s_cd[lane] = cd_cur;
             const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+            const unsigned long long mask = __ballot(hit);
+            const int nh = __popcll(mask);
+            __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk before these writes
+            if (hit) {
+                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                s_xyi[slot] = make_float4(c_cur.x, c_cur.y, __uint_as_float((uint32_t)(base + lane + 1)), 0.f);
+                s_co[slot] = co_cur;
+                s_cd[slot] = cd_cur;
+            }
+            if (lane < FWD_GROUP) {   // padding records behind the survivors: opacity 0 -> alpha 0 -> no effect
+                s_xyi[nh + lane] = make_float4(fx, fy, 0.f, 0.f);
+                s_co[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_cd[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // start the loads of the next chunk
             const int nb = base + 64;
             const uint32_t id_n2 = nb + 64 + lane < n ? pl[nb + 64 + lane] : 0u;
             c_cur = xy[id_nxt];
@@ -575,38 +590,34 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
             co_cur = conic_opacity[id_nxt];
             cd_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
             id_nxt = id_n2;
-            unsigned long long mask = __ballot(hit);
             __syncthreads();
-            while (mask) {
-                int j[FWD_GROUP];
+            for (int h0 = 0; h0 < nh; h0 += FWD_GROUP) {
                 float al[FWD_GROUP];
                 float4 cd[FWD_GROUP];
+                uint32_t idx[FWD_GROUP];
 #pragma unroll
-                for (int k = 0; k < FWD_GROUP; k++) {
-                    const bool ok = mask != 0ull;
-                    j[k] = ok ? (__ffsll((long long)mask) - 1) : 0;
-                    mask &= mask - 1ull;   // (0 stays 0)
-                    const float2 p = s_xy[j[k]];
-                    const float4 co = s_co[j[k]];
-                    cd[k] = s_cd[j[k]];
+                for (int k = 0; k < FWD_GROUP; k++) {   // independent alpha evaluations: all loads / exps in flight together
+                    const float4 p = s_xyi[h0 + k];
+                    const float4 co = s_co[h0 + k];
+                    cd[k] = s_cd[h0 + k];
+                    idx[k] = __float_as_uint(p.z);
                     const float dx = p.x - fx, dy = p.y - fy;
                     const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                     const float a = fminf(0.99f, co.w * __expf(power));
-                    al[k] = (ok && power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
+                    al[k] = (power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < FWD_GROUP; k++) {
-                    if (!done && al[k] > 0.f) {
-                        const float test_T = T * (1.f - al[k]);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const float wgt = al[k] * T;
-                            C0 += cd[k].x * wgt; C1 += cd[k].y * wgt; C2 += cd[k].z * wgt; Dp += cd[k].w * wgt;
-                            T = test_T;
-                            last = (uint32_t)(base + j[k] + 1);
-                        }
-                    }
+                    // branch-free serial part: the only loop-carried chain is T -> test_T -> select (3 dependent ops);
+                    // the colour / depth accumulations hang off it
+                    const float test_T = T * (1.f - al[k]);
+                    const bool contributes = al[k] > 0.f;
+                    done = done || (contributes && test_T < 0.0001f);
+                    const bool blend = contributes && !done;
+                    const float wgt = blend ? al[k] * T : 0.f;
+                    C0 += cd[k].x * wgt; C1 += cd[k].y * wgt; C2 += cd[k].z * wgt; Dp += cd[k].w * wgt;
+                    T = blend ? test_T : T;
+                    last = blend ? idx[k] : last;
                 }
             }
             const unsigned long long now = __ballot(!done);
