@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""bench_train.py -- BASELINE.json configs[2]: scene_1 full train-step loop analogue on 1 x MI355X:
+3 cameras (t-1, t, t+1 of one view) 800x800, ResidualMeshSimulator + mesh->Gaussian transform + rasterizer +
+L1 + 0.05 (1-SSIM) + regularisers + 2 x Adam (no densification in the timed window).  Secondary bench; one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def build(P, W, H, grid, n_times, dev):
+    from csplat import synthetic as syn
+    from csplat.gaussians import MeshGaussians
+    from meshnet.meshnet_network import ResidualMeshSimulator
+    sc = syn.scene_1(P=P, W=W, H=H, n_cams=1, grid=grid, n_times=n_times)
+    T = lambda a, dt=torch.float32: torch.tensor(a, device=dev, dtype=dt)  # noqa: E731
+    pc = MeshGaussians(3).from_arrays(T(sc["mesh_pos"][0]), T(sc["faces"].T.copy(), torch.long), T(sc["edge_index"], torch.long),
+                                      T(sc["face_ids"], torch.long), T(sc["bary"]), T(sc["log_scales"]), T(sc["quats"]),
+                                      T(sc["opacity_logits"]), T(sc["sh"]))
+    pc.active_sh_degree = 3
+    sim = ResidualMeshSimulator(T(sc["mesh_pos"]), device=dev)
+    return sc, pc, sim
+
+
+def cameras(sc, times, dev, targets=None):
+    c = sc["cameras"][0]
+    t = lambda a: torch.tensor(a)  # noqa: E731
+    return [SimpleNamespace(image_height=c["image_height"], image_width=c["image_width"], FoVx=c["FoVx"], FoVy=c["FoVy"],
+                            world_view_transform=t(c["world_view_transform"]).to(dev),
+                            full_proj_transform=t(c["full_proj_transform"]).to(dev), camera_center=t(c["camera_center"]).to(dev),
+                            time=float(tm), original_image=None if targets is None else targets[i], mask=None)
+            for i, tm in enumerate(times)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--P", type=int, default=100_000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--grid", type=int, default=100)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    from csplat import train as tr
+    from gaussian_renderer import render
+    n_times = 30
+    sc, pc, sim = build(args.P, args.res, args.res, args.grid, n_times, dev)
+    bg = torch.ones(3, device=dev)
+    times = [k / (n_times - 1) for k in (9, 10, 11)]
+    with torch.no_grad():   # targets: render of a perturbed copy
+        keep = [p.detach().clone() for p in pc.parameters()]
+        gen = torch.Generator(device=dev).manual_seed(7)
+        pc._features_dc.add_(0.3 * torch.randn(pc._features_dc.shape, device=dev, generator=gen))
+        pc._opacity.add_(0.5 * torch.randn(pc._opacity.shape, device=dev, generator=gen))
+        targets = [render(c, pc, sim, tr.DEFAULT_PIPE, bg).render.clamp(0, 1).clone() for c in cameras(sc, times, dev)]
+        for p, k in zip(pc.parameters(), keep):
+            p.copy_(k)
+    cams = cameras(sc, times, dev, targets)
+    pc.training_setup(feature_lr=tr.DEFAULT_OPT.feature_lr)
+    mopt = torch.optim.Adam(sim.parameters(), lr=tr.DEFAULT_OPT.meshnet_lr)
+    hist = []
+    for it in range(1, args.warmup + 1):
+        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)
+        hist.append(float(ps))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.warmup + 1, args.warmup + args.steps + 1):
+        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)
+        hist.append(float(ps))   # (.item(): the reference logs PSNR / loss every step too, train.py:182-189)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    out = {"metric": "train-step ms (scene_1, 3 cams 800x800, P=100k)", "value": round(ms, 3), "unit": "ms",
+           "higher_is_better": False, "dtype": "f32", "data": "synthetic", "steps": args.steps, "warmup": args.warmup,
+           "rendered_Mpix_per_s": round(3 * args.res * args.res / 1e6 / (ms * 1e-3), 1),
+           "psnr_first": round(hist[0], 3), "psnr_last": round(hist[-1], 3),
+           "config": {"workload": f"train_step analogue: V={sc['mesh_pos'].shape[1]} mesh nodes, P={args.P}, 3 cams "
+                                  f"{args.res}x{args.res}, ResidualMeshSimulator + Kabsch transform + rasterizer + L1 + "
+                                  "0.05(1-SSIM) + rigid/momentum/deform regs + 2 Adam"}}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

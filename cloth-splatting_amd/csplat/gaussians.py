@@ -146,5 +146,6 @@ class MeshGaussians:
         if deformed_vertices is None:
             return rotation
         vid = self._vertex_ids()
-        R, _ = rot.rigid_points_registration(self.mesh.pos[vid, :], deformed_vertices[vid, :])
+        # closed-form 3-point Kabsch (== roma.rigid_points_registration's SVD solution, csplat/rotations.py)
+        R = rot.kabsch_triangles(self.mesh.pos[vid, :], deformed_vertices[vid, :])
         return rot.quat_composition([rotation, rot.rotmat_to_unitquat(R)])

@@ -22,6 +22,42 @@ def rigid_points_registration(x, y):
     return R, t
 
 
+def _plane_basis(p):
+    """orthonormal (u, v, n) spanning the plane of centred triangle points p [..., 3, 3] (rows = points)."""
+    u = torch.nn.functional.normalize(p[..., 0, :], dim=-1)
+    t = p[..., 1, :] - (p[..., 1, :] * u).sum(-1, keepdim=True) * u
+    v = torch.nn.functional.normalize(t, dim=-1)
+    return u, v, torch.cross(u, v, dim=-1)
+
+
+def kabsch_triangles(x, y):
+    """Closed form of rigid_points_registration for K = 3 points (the per-Gaussian face registration of
+    scene_reconstruction/gaussian_mesh.py:182-186): no SVD.  The 3x3 covariance of two centred triangles has rank 2:
+    M = By M2 Bx^T with M2 2x2 in the two triangle planes; R = By Q Bx^T + det(Q) ny nx^T where Q is the orthogonal polar
+    factor of M2 -- a rotation (M2 + cof M2, normalised) when det M2 > 0, a reflection (M2 - cof M2, normalised) when
+    det M2 < 0, in which case Kabsch's determinant fix flips the (zero) third singular direction.  Equals the SVD
+    solution up to rounding; differentiable w.r.t. y; ~25 elementwise kernels instead of two batched 3x3 SVDs."""
+    xh = x - x.mean(dim=-2, keepdim=True)
+    yh = y - y.mean(dim=-2, keepdim=True)
+    ux, vx, nx = _plane_basis(xh)
+    uy, vy, ny = _plane_basis(yh)
+    xu, xv = (xh * ux.unsqueeze(-2)).sum(-1), (xh * vx.unsqueeze(-2)).sum(-1)      # [..., 3] in-plane coordinates
+    yu, yv = (yh * uy.unsqueeze(-2)).sum(-1), (yh * vy.unsqueeze(-2)).sum(-1)
+    a, b = (yu * xu).sum(-1), (yu * xv).sum(-1)
+    c, d = (yv * xu).sum(-1), (yv * xv).sum(-1)
+    pos = (a * d - b * c) > 0
+    q00 = torch.where(pos, a + d, a - d)
+    q01 = torch.where(pos, b - c, b + c)
+    nrm = torch.rsqrt(q00 * q00 + q01 * q01)
+    q00, q01 = q00 * nrm, q01 * nrm
+    q10 = torch.where(pos, -q01, q01)
+    q11 = torch.where(pos, q00, -q00)
+    sgn = torch.where(pos, torch.ones_like(a), -torch.ones_like(a))
+    o = lambda p, q: p.unsqueeze(-1) * q.unsqueeze(-2)  # noqa: E731  outer product
+    e = lambda s_: s_[..., None, None]  # noqa: E731
+    return e(q00) * o(uy, ux) + e(q01) * o(uy, vx) + e(q10) * o(vy, ux) + e(q11) * o(vy, vx) + e(sgn) * o(ny, nx)
+
+
 def rotmat_to_unitquat(R):
     """[..., 3, 3] -> [..., 4] XYZW."""
     shape = R.shape[:-2]

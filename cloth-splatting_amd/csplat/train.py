@@ -1,0 +1,141 @@
+"""train_step analogue (BASELINE.json configs[2]): the call pattern of
+/root/reference/scene_reconstruction/train_utils.py:240-321 around the hot path -- for each camera of the mini-batch
+(3 consecutive timesteps of one view, scene_reconstruction/dataset.py:75-87) render() = simulator -> mesh->Gaussian
+transform -> HIP rasterizer; stack; L1 + lambda_dssim*(1-SSIM) (train_utils.py:50-74, utils/loss_utils.py:20-70);
+regularisation (train_utils.py:77-100: deformation magnitude, rigid edge length, momentum); ONE backward; the summed
+screen-space gradient / radii / visibility that densification consumes (:276-292); two Adam steps (:310-319).
+Densification / pruning itself (Adam-state surgery) is a "next" row and is not performed here.
+Host-side torch only; the compute is in the drop-in modules."""
+from math import exp
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from gaussian_renderer import render
+from . import dist as cd
+
+# arguments/__init__.py:109-150 overlaid by arguments/cloth_splatting/default.py:1-43
+DEFAULT_OPT = SimpleNamespace(lambda_dssim=0.05, lambda_rigid=0.3, lambda_deform_mag=0.01, lambda_momentum=0.1,
+                              position_lr_init=0.00016, feature_lr=0.00025, opacity_lr=0.05, scaling_lr=0.005,
+                              rotation_lr=0.001, meshnet_lr=3e-4)
+DEFAULT_PIPE = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+
+
+def l1_loss(network_output, gt, mask=None):
+    if mask is not None:
+        return torch.abs((network_output - gt) * mask).mean()
+    return torch.abs(network_output - gt).mean()
+
+
+_WINDOWS = {}
+
+
+def _window1d(window_size, channel, like):
+    key = (window_size, channel, like.device, like.dtype)
+    if key not in _WINDOWS:
+        g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+        g = (g / g.sum()).to(like)
+        _WINDOWS[key] = (g.view(1, 1, 1, -1).expand(channel, 1, 1, window_size).contiguous(),
+                         g.view(1, 1, -1, 1).expand(channel, 1, window_size, 1).contiguous())
+    return _WINDOWS[key]
+
+
+def _blur(x, wh, wv, pad, channel):
+    """the reference's 11x11 window is the outer product of a 1-D Gaussian with itself (loss_utils.py:30-38): the
+    zero-padded 2-D grouped convolution equals a horizontal then a vertical 11-tap pass (22 instead of 121 MACs)."""
+    return F.conv2d(F.conv2d(x, wh, padding=(0, pad), groups=channel), wv, padding=(pad, 0), groups=channel)
+
+
+def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
+    """utils/loss_utils.py:40-70: Gaussian-window SSIM (window 11, sigma 1.5), separable form."""
+    channel = img1.size(-3)
+    wh, wv = _window1d(window_size, channel, img1)
+    pad = window_size // 2
+    both = _blur(torch.cat([img1, img2, img1 * img1, img2 * img2, img1 * img2], dim=0), wh, wv, pad, channel)
+    n = img1.shape[0]
+    mu1, mu2 = both[:n], both[n:2 * n]
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = both[2 * n:3 * n] - mu1_sq
+    sigma2_sq = both[3 * n:4 * n] - mu2_sq
+    sigma12 = both[4 * n:] - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    if return_map:
+        return ssim_map
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+@torch.no_grad()
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def image_losses(image_tensor, gt_image_tensor, opt, mask_tensor=None):
+    loss = l1_loss(image_tensor, gt_image_tensor, mask_tensor)
+    if opt.lambda_dssim != 0:
+        if mask_tensor is None:
+            ssim_loss = 1.0 - ssim(image_tensor, gt_image_tensor)
+        else:
+            ssim_loss = ((1.0 - ssim(image_tensor, gt_image_tensor, return_map=True)) * mask_tensor).mean()
+        loss = loss + opt.lambda_dssim * ssim_loss
+    return loss
+
+
+def regularization(all_vertice_deform, gaussians, opt, static=False):
+    n_cams = all_vertice_deform.shape[0]
+    loss = torch.zeros([], device=all_vertice_deform.device)
+    if not static and opt.lambda_deform_mag > 0. and n_cams >= 3:
+        d0 = torch.linalg.norm(all_vertice_deform[1] - all_vertice_deform[0], dim=-1).mean()
+        d1 = torch.linalg.norm(all_vertice_deform[2] - all_vertice_deform[1], dim=-1).mean()
+        loss = loss + opt.lambda_deform_mag * 0.5 * (d0 + d1)
+    if not static and opt.lambda_rigid > 0:
+        ei = gaussians.mesh.edge_index
+        disp = all_vertice_deform[:, ei[1]] - all_vertice_deform[:, ei[0]]
+        deformed_norm = torch.linalg.norm(disp, dim=-1, keepdim=True)
+        static_norm = gaussians.edge_norm.unsqueeze(0).expand(n_cams, -1, -1)
+        loss = loss + opt.lambda_rigid * F.l1_loss(static_norm, deformed_norm)
+    if not static and opt.lambda_momentum > 0 and n_cams >= 3:
+        m = all_vertice_deform[2] - 2 * all_vertice_deform[1] + all_vertice_deform[0]
+        loss = loss + opt.lambda_momentum * torch.linalg.norm(m, dim=-1, ord=1).mean()
+    return loss
+
+
+def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT,
+               background=None, static=False, view_parallel=False):
+    """One optimisation step.  Returns (psnr, loss, stats) where stats holds what densification consumes.
+    view_parallel=True shards `viewpoint_cams` over the ranks of the default process group and all-reduces the
+    gradients / statistics (csplat/dist.py); with one rank it is the reference's single-GPU step."""
+    if iteration % 1000 == 0:
+        gaussians.oneupSHdegree()
+    cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
+    images, gts, radii_l, vis_l, vsp_l, verts = [], [], [], [], [], []
+    for cam in cams:
+        pkg = render(cam, gaussians, simulator, pipe, background, render_static=static)
+        images.append(pkg.render.unsqueeze(0))
+        gts.append(cam.original_image.to(pkg.render.device).unsqueeze(0))
+        radii_l.append(pkg.radii.unsqueeze(0))
+        vis_l.append(pkg.visibility_filter.unsqueeze(0))
+        vsp_l.append(pkg.viewspace_points)
+        verts.append(pkg.vertice_deform[None])
+    all_vertice_deform = torch.cat(verts, 0)
+    radii = torch.cat(radii_l, 0).max(dim=0).values
+    visibility_filter = torch.cat(vis_l).any(dim=0)
+    image_tensor, gt_image_tensor = torch.cat(images, 0), torch.cat(gts, 0)
+    psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
+    loss = image_losses(image_tensor, gt_image_tensor, opt) + regularization(all_vertice_deform, gaussians, opt, static)
+    loss.backward()
+    viewspace_grad = torch.zeros_like(vsp_l[0])
+    for v in vsp_l:
+        viewspace_grad = viewspace_grad + v.grad
+    with torch.no_grad():
+        if view_parallel and cd.is_dist():
+            cd.allreduce_gradients(list(gaussians.parameters()) + list(simulator.parameters()))
+            viewspace_grad, radii, visibility_filter = cd.reduce_densification_stats(viewspace_grad, radii, visibility_filter)
+        gaussians.optimizer.step()
+        if not static:
+            meshnet_optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+        meshnet_optimizer.zero_grad()
+    return psnr_, loss.detach(), dict(viewspace_grad=viewspace_grad, radii=radii, visibility_filter=visibility_filter)

@@ -104,7 +104,9 @@ class ResidualMeshSimulator(torch.nn.Module):
         time = time_vector[0, :]
         h = torch.relu(self.input(self.encoder(time)))
         h = torch.relu(self.hidden(h))
-        residual_deform = self.output(h).reshape(-1, 3)
+        # a single time value feeds the whole mesh: the 256 -> 3V output layer is a matrix-VECTOR product.  Issued as
+        # gemv (streams the 3V x 256 weights once at HBM rate) instead of an M = 1 GEMM; same result.
+        residual_deform = (torch.mv(self.output.weight, h) + self.output.bias).reshape(-1, 3)
         time_id = torch.round(time / self.time_delta).to(dtype=torch.long)
         if time_id >= self.n_times:
             raise ValueError(f"Time {time} is out of bounds for the mesh simulator.")

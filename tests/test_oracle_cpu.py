@@ -292,6 +292,47 @@ def test_rotation_helpers():
     assert float((r.quat_composition([q, ident]) - q).abs().max()) < 1e-12
 
 
+def test_separable_ssim_equals_2d_window_ssim():
+    """csplat.train.ssim (two 11-tap passes) == the reference's 11x11 grouped-conv formulation (utils/loss_utils.py:30-70,
+    restated inline: that module imports lpips and cannot be imported here)."""
+    from math import exp
+    import torch.nn.functional as F
+    from csplat import train as tr
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.rand(2, 3, 40, 52, generator=g), torch.rand(2, 3, 40, 52, generator=g)
+    w1 = torch.tensor([exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
+    w1 = (w1 / w1.sum()).unsqueeze(1)
+    w = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(3, 1, 11, 11).contiguous()
+    c = lambda x: F.conv2d(x, w, padding=5, groups=3)  # noqa: E731
+    mu1, mu2 = c(a), c(b)
+    s1, s2, s12 = c(a * a) - mu1 ** 2, c(b * b) - mu2 ** 2, c(a * b) - mu1 * mu2
+    ref = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))
+    assert abs(float(ref.mean()) - float(tr.ssim(a, b))) < 1e-6
+    assert float((ref - tr.ssim(a, b, return_map=True)).abs().max()) < 1e-5
+    assert abs(float(tr.ssim(a, a)) - 1.0) < 1e-5
+
+
+def test_closed_form_triangle_kabsch_equals_svd():
+    """csplat.rotations.kabsch_triangles (no SVD) == the SVD Kabsch solution, values and gradients, incl. non-rigid
+    deformations and mirrored triangles (determinant fix)."""
+    from csplat import rotations as r
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(500, 3, 3, generator=g, dtype=torch.float64)
+    Q = torch.linalg.qr(torch.randn(500, 3, 3, generator=g, dtype=torch.float64))[0]
+    Q = Q * torch.det(Q)[:, None, None]
+    y = x @ Q.transpose(1, 2) + torch.randn(500, 1, 3, generator=g, dtype=torch.float64) \
+        + 0.2 * torch.randn(500, 3, 3, generator=g, dtype=torch.float64)
+    y[:50] = -y[:50]
+    y.requires_grad_(True)
+    R1, _ = r.rigid_points_registration(x, y)
+    R2 = r.kabsch_triangles(x, y)
+    assert float((R1 - R2).abs().max()) < 1e-10 and float((torch.det(R2) - 1).abs().max()) < 1e-10
+    w = torch.randn(500, 3, 3, generator=g, dtype=torch.float64)
+    g1, = torch.autograd.grad((R1 * w).sum(), y, retain_graph=True)
+    g2, = torch.autograd.grad((R2 * w).sum(), y)
+    assert float((g1 - g2).abs().max() / g1.abs().max()) < 1e-9
+
+
 # ------------------------------------------------------------------ the C-ABI library loads and exports the header
 def test_cabi_exports_every_declared_symbol():
     from csplat import native
