@@ -28,6 +28,42 @@ def l1_loss(network_output, gt, mask=None):
     return torch.abs(network_output - gt).mean()
 
 
+import ctypes as _C
+from math import exp as _exp
+
+from . import native as _n
+
+_TAPS = {}
+
+
+def _taps(window_size=11, sigma=1.5):
+    """the reference's float32 window (loss_utils.py:30-32): torch.Tensor([exp(.)]) / sum, both in float32"""
+    if window_size not in _TAPS:
+        g = torch.tensor([_exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+        g = g / g.sum()
+        _TAPS[window_size] = (_C.c_float * window_size)(*[float(v) for v in g])
+    return _TAPS[window_size]
+
+
+class GaussianBlur11(torch.autograd.Function):
+    """zero-padded 11x11 Gaussian window (sigma 1.5) on every [H, W] plane, HIP kernel csplat_blur11; self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _n.require_cuda(x)
+        x = x.contiguous().float()
+        H, W = x.shape[-2:]
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_blur11(_n.stream_handle(x.device), x.numel() // (H * W), H, W, _taps(), _n.ptr(x), _n.ptr(out)),
+                     "csplat_blur11")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return GaussianBlur11.apply(g)
+
+
 _WINDOWS = {}
 
 
@@ -52,7 +88,11 @@ def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
     channel = img1.size(-3)
     wh, wv = _window1d(window_size, channel, img1)
     pad = window_size // 2
-    both = _blur(torch.cat([img1, img2, img1 * img1, img2 * img2, img1 * img2], dim=0), wh, wv, pad, channel)
+    stacked = torch.cat([img1, img2, img1 * img1, img2 * img2, img1 * img2], dim=0)
+    if window_size == 11 and stacked.is_cuda:
+        both = GaussianBlur11.apply(stacked)                     # one HIP launch for all five windows (and one in backward)
+    else:
+        both = _blur(stacked, wh, wv, pad, channel)              # CPU tensors (tests) / other window sizes
     n = img1.shape[0]
     mu1, mu2 = both[:n], both[n:2 * n]
     mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2

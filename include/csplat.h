@@ -103,6 +103,11 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
 /* distCUDA2: out[i] = mean of squared distances from point i to its 3 nearest other points. */
 int csplat_dist2(void *stream, int P, const float *xyz, float *out);
 
+/* Separable 11-tap window of the SSIM loss (utils/loss_utils.py:30-58), zero padded: out = G (x) G * in for every one of
+ * the n_images [H][W] planes.  taps11 is a HOST pointer to the 11 normalised window weights.  Self-adjoint: the backward
+ * of the operator is the operator.  (SURVEY.md 8(f) "next" row N2.) */
+int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *in, float *out);
+
 /* ---- in-library kernel timing (HIP events on the launch stream; used by bench.py's roofline leg) ------
  * mask bit k enables bracketing of kernel class k with a start/stop event pair on the stream it is launched on:
  *   0 K1 preprocess | 1 K2 scan | 2 K3 key emission | 3 K4 radix sort (all passes) | 4 K5 tile ranges

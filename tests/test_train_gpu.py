@@ -45,3 +45,26 @@ def test_ssim_identity_and_psnr():
     assert float(tr.ssim(a, torch.rand_like(a))) < 0.2
     b = (a + 0.1).clamp(0, 1)
     assert 15 < float(tr.psnr(a, b).mean()) < 25
+
+
+def test_blur_kernel_matches_grouped_conv_and_is_self_adjoint():
+    """csplat_blur11 == the reference's zero-padded 11x11 grouped conv2d window (utils/loss_utils.py:30-58), on ragged
+    sizes; gradient through it == blur of the gradient."""
+    import torch.nn.functional as F
+    from math import exp
+    from csplat import train as tr
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for (n, c, H, W) in [(2, 3, 37, 53), (1, 3, 128, 200), (3, 1, 16, 64)]:
+        x = torch.rand(n, c, H, W, device="cuda", generator=g, requires_grad=True)
+        w1 = torch.tensor([exp(-(k - 5) ** 2 / float(2 * 1.5 ** 2)) for k in range(11)])
+        w1 = (w1 / w1.sum()).unsqueeze(1)
+        w = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(c, 1, 11, 11).contiguous().cuda()
+        ref = F.conv2d(x, w, padding=5, groups=c)
+        got = tr.GaussianBlur11.apply(x)
+        assert float((ref - got).abs().max()) < 2e-6
+        wgt = torch.rand_like(ref)
+        g_ref, = torch.autograd.grad((ref * wgt).sum(), x)
+        g_got, = torch.autograd.grad((got * wgt).sum(), x)
+        assert float((g_ref - g_got).abs().max()) < 2e-6
+    a, b = torch.rand(2, 3, 96, 80, device="cuda", generator=g), torch.rand(2, 3, 96, 80, device="cuda", generator=g)
+    assert abs(float(tr.ssim(a, b)) - float(tr.ssim(a.cpu(), b.cpu()))) < 1e-6     # HIP window == torch conv formulation
