@@ -9,8 +9,40 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
+from . import native as _n
 from . import rotations as rot
 from .native import require_cuda
+
+
+class MeshTransform(torch.autograd.Function):
+    """(deformed vertices, face_bary, _rotation) -> (means3D, rotations): one HIP kernel each way
+    (csplat_mesh_transform_fwd / _bwd, include/csplat.h)."""
+
+    @staticmethod
+    def forward(ctx, vertices, bary, rotation, vid, rest):
+        vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
+        P = int(vid.shape[0])
+        xyz = torch.empty(P, 3, dtype=torch.float32, device=vertices.device)
+        quat = torch.empty(P, 4, dtype=torch.float32, device=vertices.device)
+        with torch.cuda.device(vertices.device):
+            _n.check(_n.lib.csplat_mesh_transform_fwd(_n.stream_handle(vertices.device), P, _n.ptr(vid), _n.ptr(vertices),
+                                                      _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest), _n.ptr(xyz), _n.ptr(quat)),
+                     "csplat_mesh_transform_fwd")
+        ctx.save_for_backward(vertices, bary, rotation, vid, rest)
+        return xyz, quat
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_quat):
+        vertices, bary, rotation, vid, rest = ctx.saved_tensors
+        P, V = int(vid.shape[0]), int(vertices.shape[0])
+        d_v, d_b, d_r = torch.empty_like(vertices), torch.empty_like(bary), torch.empty_like(rotation)
+        g_xyz = None if g_xyz is None else g_xyz.contiguous().float()
+        g_quat = None if g_quat is None else g_quat.contiguous().float()
+        with torch.cuda.device(vertices.device):
+            _n.check(_n.lib.csplat_mesh_transform_bwd(_n.stream_handle(vertices.device), P, V, _n.ptr(vid), _n.ptr(vertices),
+                                                      _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest), _n.ptr(g_xyz), _n.ptr(g_quat),
+                                                      _n.ptr(d_v), _n.ptr(d_b), _n.ptr(d_r)), "csplat_mesh_transform_bwd")
+        return d_v, d_b, d_r, None, None
 
 
 def inverse_sigmoid(x):
@@ -38,6 +70,7 @@ class MeshGaussians:
         self._features_dc = self._features_rest = self._scaling = self._rotation = self._opacity = torch.empty(0)
         self.edge_norm = torch.empty(0)
         self.optimizer = None
+        self.fused = True   # mesh -> Gaussian transform through csplat_mesh_transform_* (False: the torch formulation)
 
     # ---- construction -------------------------------------------------------------------------------------------
     def from_mesh(self, pos, face, edge_index, gaussian_init_factor=2, generator=None):
@@ -134,7 +167,29 @@ class MeshGaussians:
     def _vertex_ids(self):
         return self.mesh.face[:, self.face_ids].transpose(0, 1)  # [P, 3]
 
+    def _fused(self, deformed_vertices):
+        """(xyz, rotation) on the deformed mesh through the fused HIP kernel; render() asks for both, one after the other
+        with the same vertex tensor, so the pair is computed once and cached on that tensor object."""
+        c = self.__dict__.get("_fused_cache")
+        if c is not None and c[0] is deformed_vertices and c[1] == deformed_vertices._version:
+            return c[2]
+        key = (self.face_ids.data_ptr(), self.face_ids._version, self.mesh.pos.data_ptr(), self.mesh.pos._version)
+        r = self.__dict__.get("_rest_cache")
+        if r is None or r[0] != key:
+            vid = self._vertex_ids().contiguous()
+            rest = torch.empty(max(int(_n.lib.csplat_mesh_rest_bytes(vid.shape[0])), 256), dtype=torch.uint8, device=vid.device)
+            with torch.cuda.device(vid.device):
+                _n.check(_n.lib.csplat_mesh_rest(_n.stream_handle(vid.device), int(vid.shape[0]), _n.ptr(vid),
+                                                 _n.ptr(self.mesh.pos.contiguous().float()), _n.ptr(rest)), "csplat_mesh_rest")
+            r = (key, vid, rest)
+            self._rest_cache = r
+        out = MeshTransform.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2])
+        self._fused_cache = (deformed_vertices, deformed_vertices._version, out)
+        return out
+
     def get_xyz(self, deformed_vertices=None):
+        if deformed_vertices is not None and deformed_vertices.is_cuda and self.fused:
+            return self._fused(deformed_vertices)[0]
         vid = self._vertex_ids()
         verts = self.mesh.pos if deformed_vertices is None else deformed_vertices
         face_pos = verts[vid, :]                                                      # [P, 3 (vertex), 3 (xyz)]
@@ -144,6 +199,8 @@ class MeshGaussians:
         return (nb.unsqueeze(-1) * face_pos).sum(dim=1)
 
     def get_rotation(self, deformed_vertices=None):
+        if deformed_vertices is not None and deformed_vertices.is_cuda and self.fused:
+            return self._fused(deformed_vertices)[1]
         rotation = torch.nn.functional.normalize(self._rotation)
         if deformed_vertices is None:
             return rotation

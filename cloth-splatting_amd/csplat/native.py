@@ -37,6 +37,10 @@ EXPORTS = {
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
+    "csplat_mesh_rest_bytes": (_sz, [_i]),
+    "csplat_mesh_rest": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "csplat_mesh_transform_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_mesh_transform_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_blur11": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
     "csplat_prof_enable": (_i, [C.c_uint]),
     "csplat_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -108,6 +108,21 @@ int csplat_dist2(void *stream, int P, const float *xyz, float *out);
  * of the operator is the operator.  (SURVEY.md 8(f) "next" row N2.) */
 int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *in, float *out);
 
+/* Fused mesh -> Gaussian transform (SURVEY.md 8(f) "next" row N1): MultiGaussianMesh.get_xyz + get_rotation,
+ * scene_reconstruction/gaussian_mesh.py:151-188.  face_vertex_ids[P][3] (int64, device) = mesh.face[:, face_ids].T.
+ *   csplat_mesh_rest       per-Gaussian constants of the REST face (in-plane basis, normal, in-plane coordinates) into
+ *                          `rest` (csplat_mesh_rest_bytes(P) bytes); recompute when the mesh / face assignment changes
+ *   csplat_mesh_transform_fwd   out_xyz[P][3] = barycentric centre on the deformed vertices; out_quat[P][4] =
+ *                          normalize(rotation) (x) quaternion(Kabsch(rest face -> deformed face)), roma XYZW convention
+ *   csplat_mesh_transform_bwd   gradients w.r.t. vertices[V][3] (atomically scattered, zeroed here), bary[P][3], rotation[P][4] */
+size_t csplat_mesh_rest_bytes(int P);
+int csplat_mesh_rest(void *stream, int P, const int64_t *face_vertex_ids, const float *rest_vertices, void *rest);
+int csplat_mesh_transform_fwd(void *stream, int P, const int64_t *face_vertex_ids, const float *vertices, const float *bary,
+                              const float *rotation, const void *rest, float *out_xyz, float *out_quat);
+int csplat_mesh_transform_bwd(void *stream, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
+                              const float *bary, const float *rotation, const void *rest, const float *g_xyz,
+                              const float *g_quat, float *d_vertices, float *d_bary, float *d_rotation);
+
 /* ---- in-library kernel timing (HIP events on the launch stream; used by bench.py's roofline leg) ------
  * mask bit k enables bracketing of kernel class k with a start/stop event pair on the stream it is launched on:
  *   0 K1 preprocess | 1 K2 scan | 2 K3 key emission | 3 K4 radix sort (all passes) | 4 K5 tile ranges

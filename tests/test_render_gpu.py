@@ -116,3 +116,28 @@ def test_from_mesh_uses_dist2():
     xyz = pc.get_xyz().detach().cpu().numpy()
     ref = np.log(np.sqrt(np.maximum(ro.dist2(xyz), 1e-7)))
     np.testing.assert_allclose(pc._scaling.detach().cpu().numpy()[:, 0], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_mesh_transform_equals_torch_formulation():
+    """csplat_mesh_transform_fwd/_bwd (closed-form Kabsch, in-kernel forward-mode AD) == the torch formulation of
+    get_xyz / get_rotation (gaussian_mesh.py:151-188 with roma restated in csplat/rotations.py), values and gradients
+    w.r.t. the deformed vertices, the barycentric weights and the rotation parameter."""
+    sc = _scene(P=5000, W=64, H=64, grid=12)
+    outs = []
+    for fused in (True, False):
+        pc, sim = _build(sc)
+        pc.fused = fused
+        torch.manual_seed(3)
+        with torch.no_grad():
+            pc._rotation.copy_(torch.randn_like(pc._rotation))           # non-trivial, un-normalised own rotations
+        V = sc["mesh_pos"].shape[1]
+        verts = (pc.mesh.pos + 0.05 * torch.randn(V, 3, device="cuda")).requires_grad_(True)
+        xyz, rot = pc.get_xyz(verts), pc.get_rotation(verts)
+        w1, w2 = torch.randn_like(xyz), torch.randn_like(rot)
+        ((xyz * w1).sum() + (rot * w2).sum()).backward()
+        outs.append((xyz.detach(), rot.detach(), verts.grad.clone(), pc.face_bary.grad.clone(), pc._rotation.grad.clone()))
+    names = ("xyz", "rotation", "d_vertices", "d_bary", "d_rotation")
+    for n, a, b in zip(names, outs[0], outs[1]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err < 2e-4, (n, err)       # fp32 both sides; vertex grads: atomics vs sort-based index_put
+    assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
