@@ -137,7 +137,24 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, const Cam
     maxy = min(c.gy, max(0, (int)((py + (float)rad + (float)(CSPLAT_TILE - 1)) / (float)CSPLAT_TILE)));
 }
 
+// SH coefficients are 48 floats (192 B) per Gaussian: read lane-per-Gaussian that is a 192-byte stride.  With STAGE the
+// workgroup first copies its 256 x 48 contiguous floats into LDS with 16-byte coalesced loads (row stride 49 floats:
+// conflict-free column reads) and the per-Gaussian code reads LDS instead.
+constexpr int SH_ROW = 49;
+
+template <int NT>
+__device__ __forceinline__ void stage_sh_rows(const float *__restrict__ src, int rows, float *s_rows) {
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    for (int t = threadIdx.x; t < rows * 12; t += NT) {
+        const float4 v = src4[t];
+        const int row = t / 12, c = (t - row * 12) * 4;
+        float *d = s_rows + row * SH_ROW + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- K1
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const float *__restrict__ means3D,
                                                      const float *__restrict__ shs,
                                                      const float *__restrict__ colors_precomp,
@@ -147,7 +164,13 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
                                                      const float *__restrict__ cov3D_precomp, Cam cam, Geom g,
                                                      int32_t *__restrict__ radii, int nocull) {
 #pragma clang fp contract(off)
+    __shared__ float s_shrows[STAGE ? 256 * SH_ROW : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (STAGE) {
+        const int base = blockIdx.x * 256;
+        stage_sh_rows<256>(shs + (size_t)base * 48, min(256, P - base), s_shrows);
+        __syncthreads();
+    }
     if (i >= P) return;
     float depth = 0.f, px = 0.f, py = 0.f, cut = -1.f;
     float4 co = {0.f, 0.f, 0.f, 0.f};
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
 #pragma unroll
             for (int k = 0; k < 3; k++) rgb[k] = colors_precomp[3 * i + k];
         } else {
-            const float *sh = shs + (size_t)i * M * 3;
+            const float *sh = STAGE ? (const float *)(s_shrows + threadIdx.x * SH_ROW) : shs + (size_t)i * M * 3;
             const float d0 = p[0] - cam.campos[0], d1 = p[1] - cam.campos[1], d2 = p[2] - cam.campos[2];
             const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
             const float x = d0 / len, y = d1 / len, z = d2 / len;
@@ -873,7 +896,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__rest
 }
 
 // ------------------------------------------------------------------------------------------- K8
-__global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, const float *__restrict__ means3D,
+template <bool STAGE, int NT>
+__global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, const float *__restrict__ means3D,
                                                          const float *__restrict__ shs, const float *__restrict__ scales,
                                                          float scale_mod, const float *__restrict__ rotations,
                                                          int use_precomp_cov, Cam cam, Geom g,
@@ -883,8 +907,18 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, con
                                                          float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D,
                                                          float *__restrict__ dL_dsh, float *__restrict__ dL_dscale,
                                                          float *__restrict__ dL_drot) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    // STAGE: SH coefficients in / SH gradients out go through LDS so that HBM sees contiguous 16-byte accesses (the
+    // lane-per-Gaussian 4-byte stores at a 192-byte stride wrote 2.7x the algorithmic bytes)
+    __shared__ float s_in[STAGE ? NT * SH_ROW : 1];
+    __shared__ float s_out[STAGE ? NT * SH_ROW : 1];
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int rows = min(NT, P - blockIdx.x * NT);
+    if (STAGE) {
+        stage_sh_rows<NT>(shs + (size_t)blockIdx.x * NT * 48, rows, s_in);
+        for (int k = 0; k < 48; k++) s_out[threadIdx.x * SH_ROW + k] = 0.f;
+        __syncthreads();
+    }
+    if (i < P) {
     const bool vis = radii[i] > 0;
     float a9[9];
 #pragma unroll
@@ -901,11 +935,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, con
         for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
-        if (dL_dsh) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
+        if (dL_dsh && !STAGE) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
         if (dL_dscale) { dL_dscale[3 * i] = 0.f; dL_dscale[3 * i + 1] = 0.f; dL_dscale[3 * i + 2] = 0.f; }
         if (dL_drot) { dL_drot[4 * i] = 0.f; dL_drot[4 * i + 1] = 0.f; dL_drot[4 * i + 2] = 0.f; dL_drot[4 * i + 3] = 0.f; }
-        return;
-    }
+    } else {
     const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
     const float *view = cam.view, *proj = cam.proj;
 
@@ -972,8 +1005,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, con
     }
     // ---- colour -> SH (+ view direction -> mean3D)
     if (shs && dL_dsh) {
-        const float *sh = shs + (size_t)i * M * 3;
-        float *gsh = dL_dsh + (size_t)i * M * 3;
+        const float *sh = STAGE ? (const float *)(s_in + threadIdx.x * SH_ROW) : shs + (size_t)i * M * 3;
+        float *gsh = STAGE ? s_out + threadIdx.x * SH_ROW : dL_dsh + (size_t)i * M * 3;
         const uint32_t cl = g.clamped[i];
         const float vx = p[0] - cam.campos[0], vy = p[1] - cam.campos[1], vz = p[2] - cam.campos[2];
         const float sum2 = vx * vx + vy * vy + vz * vz;
@@ -1067,6 +1100,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(int P, int D, int M, con
                                     qr * dR[2][0] + qz * dR[2][1] - 2.f * qy * dR[2][2]);
         dL_drot[4 * i + 3] = 2.f * (-2.f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.f * qz * dR[1][1] +
                                     qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+    }
+    }   // visible
+    }   // i < P
+    if (STAGE) {   // coalesced 16-byte stores of the workgroup's SH gradients
+        __syncthreads();
+        float4 *dst4 = reinterpret_cast<float4 *>(dL_dsh + (size_t)blockIdx.x * NT * 48);
+        for (int t = threadIdx.x; t < rows * 12; t += NT) {
+            const int row = t / 12, c = (t - row * 12) * 4;
+            const float *sp = s_out + row * SH_ROW + c;
+            dst4[t] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
     }
 }
 
@@ -1200,9 +1244,15 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     if (!can_bucket) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
     if (P > 0) {
         ProfScope ps(PROF_K1, s);
-        k_preprocess<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
-                                                   scale_modifier, rotations, cov3D_precomp, cam, g, radii,
-                                                   (int)(g_debug_flags & 1u));
+        const bool stage = shs != nullptr && M == 16 && ((uintptr_t)shs & 15u) == 0;
+        if (stage)
+            k_preprocess<true><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+                                                             scale_modifier, rotations, cov3D_precomp, cam, g, radii,
+                                                             (int)(g_debug_flags & 1u));
+        else
+            k_preprocess<false><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+                                                              scale_modifier, rotations, cov3D_precomp, cam, g, radii,
+                                                              (int)(g_debug_flags & 1u));
         LAUNCH_CHECK();
     }
     uint32_t *table = nullptr;
@@ -1348,10 +1398,17 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
     }
     {
         ProfScope ps(PROF_K8, s);
-        k_preprocess_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
-                                                       cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D, dL_dconic,
-                                                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                                                       dL_drot);
+        const bool stage = shs != nullptr && dL_dsh != nullptr && M == 16 && (((uintptr_t)shs | (uintptr_t)dL_dsh) & 15u) == 0;
+        if (stage)
+            k_preprocess_bwd<true, 128><<<cdiv(P, 128), 128, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                                      cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D,
+                                                                      dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                                                                      dL_dsh, dL_dscale, dL_drot);
+        else
+            k_preprocess_bwd<false, 256><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                                       cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D,
+                                                                       dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                                                                       dL_dsh, dL_dscale, dL_drot);
         LAUNCH_CHECK();
     }
     return 0;
