@@ -16,6 +16,10 @@
 // written in the same association order as oracle/raster_ref.c, so tile/bin indices are bit-exact.
 #include "csplat_common.h"
 
+#include <atomic>
+#include <chrono>
+#include <mutex>
+
 namespace {
 
 constexpr float NEAR_Z = 0.2f;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void k_tile_colscan(int tiles, int nb, uint32_
 
 // single workgroup: exclusive scan of the per-tile totals -> tile ranges, R, longest list
 __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
-                                                     uint32_t *__restrict__ info) {
+                                                     uint32_t *__restrict__ info, volatile uint32_t *mailbox, uint32_t tag) {
     __shared__ uint32_t s_w[17];
     __shared__ uint32_t s_max[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -401,6 +405,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t *_
         for (int k = 0; k < 16; k++) m = max(m, s_max[k]);
         info[0] = carry;
         info[1] = m;
+        if (mailbox) {   // host-mapped pinned memory: the host polls the tag instead of blocking in a stream synchronise
+            mailbox[0] = carry;
+            mailbox[1] = m;
+            __threadfence_system();
+            mailbox[2] = tag;
+        }
     }
 }
 
@@ -1183,6 +1193,35 @@ int make_cam(Cam &c, const float *view, const float *proj, const float *campos, 
     return 0;
 }
 
+// Mailboxes for the one host read of the forward (R and the longest tile list): 64 slots of host-pinned, device-mapped
+// memory.  The scan kernel stores the two words, fences at system scope and stores a per-call tag; the host spins on the
+// tag.  A blocking hipStreamSynchronize costs tens of microseconds of wake-up latency during which the GPU idles.
+struct Mailboxes {
+    volatile uint32_t *host = nullptr;
+    uint32_t *dev = nullptr;
+    std::atomic<uint32_t> next{1};
+    bool tried = false;
+};
+Mailboxes g_mail;
+std::mutex g_mail_mu;
+constexpr int MAIL_SLOTS = 64, MAIL_WORDS = 16;
+
+bool mail_init() {
+    std::lock_guard<std::mutex> lk(g_mail_mu);
+    if (!g_mail.tried) {
+        g_mail.tried = true;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, MAIL_SLOTS * MAIL_WORDS * 4, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, MAIL_SLOTS * MAIL_WORDS * 4);
+            g_mail.host = (volatile uint32_t *)h;
+            g_mail.dev = (uint32_t *)d;
+        }
+        (void)hipGetLastError();
+    }
+    return g_mail.host != nullptr;
+}
+
 unsigned g_debug_flags = 0;   // bit 0: disable wave-level culling (test hook, csplat_debug_flags)
 
 int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n (upstream getHigherMsb)
@@ -1269,10 +1308,33 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         uint32_t *tile_cnt = table + (size_t)nb * tiles;   // last row of the chunk: per-tile totals
         k_tile_colscan<<<cdiv(tiles, 256), 256, 0, s>>>(tiles, nb, table, tile_cnt);
         LAUNCH_CHECK();
-        k_tile_scan<<<1, 1024, 0, s>>>(tiles, tile_cnt, ranges, info);
+        const bool use_mail = !(g_debug_flags & 4u) && mail_init();
+        uint32_t tag = 0;
+        volatile uint32_t *mb_host = nullptr;
+        uint32_t *mb_dev = nullptr;
+        if (use_mail) {
+            tag = g_mail.next.fetch_add(1);
+            if (tag == 0) tag = g_mail.next.fetch_add(1);
+            const int slot = (int)(tag % MAIL_SLOTS);
+            mb_host = g_mail.host + slot * MAIL_WORDS;
+            mb_dev = g_mail.dev + slot * MAIL_WORDS;
+        }
+        k_tile_scan<<<1, 1024, 0, s>>>(tiles, tile_cnt, ranges, info, mb_dev, tag);
         LAUNCH_CHECK();
-        HIP_TRY(hipMemcpyAsync(host_info, info, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        bool got = false;
+        if (use_mail) {   // spin on the tag (bounded: fall back to a stream synchronise after 2 s)
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (!(got = (mb_host[2] == tag))) {
+                if ((++spins & 0x3FFu) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+            }
+            if (got) { host_info[0] = mb_host[0]; host_info[1] = mb_host[1]; }
+        }
+        if (!got) {
+            HIP_TRY(hipMemcpyAsync(host_info, info, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
     } else if (P > 0) {
         ProfScope ps(PROF_K2, s);
         if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;

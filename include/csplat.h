@@ -3,8 +3,9 @@
  *
  * Plain pointers and sizes only; every pointer named "device" is HBM memory owned by the caller
  * (torch tensors on the Python side), `stream` is a hipStream_t passed as void*.  All calls are
- * stream-ordered; the only host synchronisation is the 4-byte read of `num_rendered` inside
- * csplat_forward (as the upstream CUDA extension does).  Return value: 0 = ok, non-zero = error
+ * stream-ordered; the only host synchronisation is the 8-byte read of `num_rendered` (and the longest
+ * tile list) inside csplat_forward (upstream reads num_rendered the same way): the scan kernel posts it
+ * to a host-pinned mailbox that the host polls.  Return value: 0 = ok, non-zero = error
  * (text via csplat_last_error()); no C++ exception crosses this boundary.
  *
  * What each entry point replaces in the reference (/root/reference):
@@ -44,7 +45,8 @@ typedef void *(*csplat_alloc_fn)(void *ctx, int chunk, size_t bytes);
 
 int csplat_abi_version(void);
 /* test hook (results must not change).  bit 0: disable the wave-level culling of K6/K7;
- * bit 1: force the global radix-sort binning path instead of the tile-bucketed LDS sort */
+ * bit 1: force the global radix-sort binning path instead of the tile-bucketed LDS sort;
+ * bit 2: read R with a blocking stream synchronise instead of polling the pinned mailbox */
 int csplat_debug_flags(unsigned flags);
 const char *csplat_last_error(void);
 
