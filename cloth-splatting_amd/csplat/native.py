@@ -26,7 +26,7 @@ EXPORTS = {
     "csplat_geom_bytes": (_sz, [_i]),
     "csplat_image_bytes": (_sz, [_i, _i]),
     "csplat_binning_bytes": (_sz, [_i64, _i, _i]),
-    "csplat_temp_bytes": (_sz, [_i, _i64]),
+    "csplat_temp_bytes": (_sz, [_i, _i64, _i, _i]),
     "csplat_backward_scratch_bytes": (_sz, [_i, _i64]),
     "csplat_geom_layout": (_i, [_i, C.POINTER(_sz)]),
     "csplat_binning_layout": (_i, [_i64, _i, _i, C.POINTER(_sz)]),

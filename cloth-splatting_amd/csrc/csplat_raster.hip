@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
         // conic uniformly) and of the per-pixel power evaluation.
         const float cancel = 4e-7f * (a * c + b * b) / det;
         cut = cancel < 0.25f ? 2.f * lam1 * logf(255.f * op) * (1.0001f + 2.f * cancel) + 0.01f : 3.0e38f;
-        if (nocull) cut = 3.0e38f;
+        if (nocull == 1) cut = 3.0e38f;
+        if (nocull == 2) cut = cut * 4.f + 4.f;
     } while (0);
 
     g.depth[i] = depth;
@@ -731,6 +732,214 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
     }
 }
 
+// ------------------------------------------------------------------------------------------- K6, depth-split form
+// The sequential kernel above is bounded by the serial chain of the deepest quadrant (one wave walks the whole tile list).
+// This alternative forward (csplat_debug_flags bit 3) gives every 8x8 quadrant a workgroup of FOUR wavefronts that all map their lanes to the SAME 64
+// pixels and advance through the list in ROUNDS of four 256-entry segments:
+//   1. wave w composites segment 4r+w speculatively: from T = 1, no termination test -> per pixel the segment's
+//      transmittance product P, colour / depth partial sums and last contributing index, exchanged through LDS;
+//   2. every wave walks the four results in order for its 64 lanes (redundantly -- it is ~40 operations): checkpoint
+//      (T, colour so far; the same checkpoint K7 restarts from), then C += T * C_s, T *= P_s.  T only decreases, so a pixel's
+//      termination (first entry with T(1-alpha) < 1e-4) lies in the first segment with T * P_s < 1e-4;
+//   3. if some pixel terminates in this round, wave w replays ITS segment exactly (the upstream sequential rule, from the
+//      checkpointed T) for the pixels that terminate there -- each pixel is replayed by exactly one wave -- and the
+//      finished pixels are merged through LDS.
+// Everything before a pixel's terminating segment is exact by associativity of the compositing operator (rounding differs
+// in the last bits); speculation is bounded by three segments per quadrant, no serial chain is longer than one segment
+// per round, and a deep quadrant occupies four SIMDs instead of one.
+// EXACT = false: speculative (no termination test); EXACT = true: the upstream sequential rule.  Composites list entries
+// [lo, hi) of the tile for this wave's lanes; s_* are this wave's private LDS staging arrays.
+template <bool EXACT, int G>
+__device__ __forceinline__ void composite_range(const uint32_t *__restrict__ pl, int lo, int hi, int lane, float fx, float fy,
+                                                const float2 *__restrict__ xy, const float *__restrict__ rgb,
+                                                const float *__restrict__ depth, const float4 *__restrict__ conic_opacity,
+                                                const float *__restrict__ cut2, float4 *s_xyi, float4 *s_co, float4 *s_cd,
+                                                bool &done, float &T, float &C0, float &C1, float &C2, float &Dp,
+                                                uint32_t &last) {
+    float bx0 = wave_min(done ? 3.0e38f : fx), bx1 = wave_max(done ? -3.0e38f : fx);
+    float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
+    unsigned long long live = __ballot(!done);
+    const int n = hi - lo;
+    const uint32_t *p0 = pl + lo;
+    uint32_t id_cur = lane < n ? p0[lane] : 0u;
+    uint32_t id_nxt = 64 + lane < n ? p0[64 + lane] : 0u;
+    float2 c_cur = xy[id_cur];
+    float cut_cur = lane < n ? cut2[id_cur] : -1.f;
+    float4 co_cur = conic_opacity[id_cur];
+    float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
+    for (int base = 0; base < n; base += 64) {
+        const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+        const unsigned long long mask = __ballot(hit);
+        const int nh = __popcll(mask);
+        // wave-private LDS: a wave's LDS operations execute in order, only the compiler has to be told not to move the
+        // next chunk's writes above this chunk's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (hit) {
+            const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            s_xyi[slot] = make_float4(c_cur.x, c_cur.y, __uint_as_float((uint32_t)(lo + base + lane + 1)), 0.f);
+            s_co[slot] = co_cur;
+            s_cd[slot] = cd_cur;
+        }
+        if (lane < G) {
+            s_xyi[nh + lane] = make_float4(fx, fy, 0.f, 0.f);
+            s_co[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_cd[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int nb = base + 64;
+        const uint32_t id_n2 = nb + 64 + lane < n ? p0[nb + 64 + lane] : 0u;
+        c_cur = xy[id_nxt];
+        cut_cur = nb + lane < n ? cut2[id_nxt] : -1.f;
+        co_cur = conic_opacity[id_nxt];
+        cd_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
+        id_nxt = id_n2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int h0 = 0; h0 < nh; h0 += G) {
+            float al[G];
+            float4 cd[G];
+            uint32_t idx[G];
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const float4 p = s_xyi[h0 + k];
+                const float4 co = s_co[h0 + k];
+                cd[k] = s_cd[h0 + k];
+                idx[k] = __float_as_uint(p.z);
+                const float dx = p.x - fx, dy = p.y - fy;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                const float a = fminf(0.99f, co.w * __expf(power));
+                al[k] = (power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const float test_T = T * (1.f - al[k]);
+                const bool contributes = al[k] > 0.f;
+                if (EXACT) done = done || (contributes && test_T < 0.0001f);
+                const bool blend = contributes && !done;
+                const float wgt = blend ? al[k] * T : 0.f;
+                C0 += cd[k].x * wgt; C1 += cd[k].y * wgt; C2 += cd[k].z * wgt; Dp += cd[k].w * wgt;
+                T = blend ? test_T : T;
+                last = blend ? idx[k] : last;
+            }
+        }
+        if (EXACT) {
+            const unsigned long long now = __ballot(!done);
+            if (now == 0ull) break;
+            if (now != live) {
+                live = now;
+                bx0 = wave_min(done ? 3.0e38f : fx); bx1 = wave_max(done ? -3.0e38f : fx);
+                by0 = wave_min(done ? 3.0e38f : fy); by1 = wave_max(done ? -3.0e38f : fy);
+            }
+        }
+    }
+}
+
+constexpr int FWD_WAVES = 4;
+constexpr int RND_GROUP = 4;   // survivors per group in the 4-wave kernel (keeps it under 128 VGPRs: 4 workgroups per CU)
+
+__global__ __launch_bounds__(256, 4) void k_render_fwd_rounds(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                                                           int W, int H, int gx, const float2 *__restrict__ xy,
+                                                           const float *__restrict__ rgb, const float *__restrict__ depth,
+                                                           const float4 *__restrict__ conic_opacity,
+                                                           const float *__restrict__ cut2, const float *__restrict__ bg,
+                                                           const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
+                                                           float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                           float *__restrict__ out_color, float *__restrict__ out_depth) {
+    __shared__ float4 s_xyi[FWD_WAVES][64 + FWD_GROUP];
+    __shared__ float4 s_co[FWD_WAVES][64 + FWD_GROUP];
+    __shared__ float4 s_cd[FWD_WAVES][64 + FWD_GROUP];
+    __shared__ float4 s_resA[FWD_WAVES][64];   // P, C0, C1, C2 of the wave's segment (speculative) / replay result
+    __shared__ float2 s_resB[FWD_WAVES][64];   // D, last index + 1
+    __shared__ float4 s_finA[64];              // T, C0, C1, C2 of pixels finished by a replay
+    __shared__ float2 s_finB[64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int tile, px, py;
+    quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
+    const bool inside = px < W && py < H;
+    const int pix = py * W + px;
+    const float fx = (float)px, fy = (float)py;
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    const int wq = blockIdx.x & 3;
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    if (n > 0 && __ballot(!done) != 0ull) {   // (workgroup-uniform: all four waves see the same 64 pixels)
+        const uint32_t *pl = point_list + range.x;
+        const int seg0 = seg_offset[tile];
+        const int nseg = (n + SEG - 1) / SEG;
+        for (int r0 = 0; r0 < nseg; r0 += FWD_WAVES) {
+            // ---- 1. speculative composite of this wave's segment
+            const int seg = r0 + w;
+            {
+                bool sd = done;   // lanes already finished stay out of the culling box
+                float sT = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, aD = 0.f;
+                uint32_t sl = 0;
+                if (seg < nseg && __ballot(!sd) != 0ull)
+                    composite_range<false, RND_GROUP>(pl, seg * SEG, min(n, seg * SEG + SEG), lane, fx, fy, xy, rgb, depth, conic_opacity, cut2,
+                                           s_xyi[w], s_co[w], s_cd[w], sd, sT, a0, a1, a2, aD, sl);
+                s_resA[w][lane] = make_float4(sT, a0, a1, a2);
+                s_resB[w][lane] = make_float2(aD, __uint_as_float(sl));
+            }
+            __syncthreads();
+            // ---- 2. ordered combine (every wave, redundantly, for its copy of the 64 pixels)
+            int term = -1;           // segment (0..3 within the round) holding this pixel's termination
+            float tT = T, t0 = C0, t1 = C1, t2 = C2, tD = Dp;   // state at the start of the terminating segment
+            uint32_t tl = last;
+#pragma unroll
+            for (int k = 0; k < FWD_WAVES; k++) {
+                if (r0 + k < nseg) {
+                    if (w == k) ckpt[(size_t)(seg0 + r0 + k) * 256 + wq * 64 + lane] = make_float4(T, C0, C1, C2);
+                    const float4 a = s_resA[k][lane];
+                    const float2 b = s_resB[k][lane];
+                    const float test_T = T * a.x;
+                    const bool live = !done && term < 0;
+                    if (live && test_T < 0.0001f) { term = k; tT = T; t0 = C0; t1 = C1; t2 = C2; tD = Dp; tl = last; }
+                    if (live && term < 0) {
+                        C0 += T * a.y; C1 += T * a.z; C2 += T * a.w; Dp += T * b.x;
+                        const uint32_t l = __float_as_uint(b.y);
+                        last = l ? l : last;
+                        T = test_T;
+                    }
+                }
+            }
+            const bool any_term = __syncthreads_or(term >= 0);
+            // ---- 3. exact replay of terminating segments (wave w replays segment r0 + w for the pixels that end there)
+            if (any_term) {
+                const bool mine = term == w;
+                bool rd = !mine;
+                float rT = tT, q0 = t0, q1 = t1, q2 = t2, qD = tD;
+                uint32_t rl = tl;
+                if (__ballot(mine) != 0ull) {
+                    composite_range<true, RND_GROUP>(pl, seg * SEG, min(n, seg * SEG + SEG), lane, fx, fy, xy, rgb, depth, conic_opacity, cut2,
+                                          s_xyi[w], s_co[w], s_cd[w], rd, rT, q0, q1, q2, qD, rl);
+                    if (mine) {
+                        s_finA[lane] = make_float4(rT, q0, q1, q2);
+                        s_finB[lane] = make_float2(qD, __uint_as_float(rl));
+                    }
+                }
+                __syncthreads();
+                if (term >= 0) {
+                    const float4 fa = s_finA[lane];
+                    const float2 fb = s_finB[lane];
+                    T = fa.x; C0 = fa.y; C1 = fa.z; C2 = fa.w; Dp = fb.x; last = __float_as_uint(fb.y);
+                    done = true;   // (a replay that does not hit the threshold -- a rounding tie -- still ends the pixel here)
+                }
+            }
+            if (__syncthreads_and(done)) break;
+        }
+    }
+    if (inside && w == 0) {
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        const size_t HW = (size_t)H * W;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = Dp;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- K7
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -1127,6 +1336,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
 // ------------------------------------------------------------------------------------------- layouts
 enum { G_DEPTH, G_XY, G_CONIC, G_RGB, G_COV3D, G_CLAMPED, G_TOUCHED, G_OFFSETS, G_CUT2, G_SCANTMP, G_NFIELDS };
 
+int64_t max_slots(int64_t R, int tiles) { return R / SEG + tiles + 1; }
 size_t geom_offsets(int P, size_t *off) {
     size_t o = 0;
     const size_t n = (size_t)(P > 0 ? P : 1);
@@ -1162,7 +1372,6 @@ size_t image_offsets(int W, int H, size_t *off) {
 size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 0 ? P : 1, BUCKET_G) + 1) * tiles * 4); }
 // binning: 0 keys_sorted u64[R] | 1 ids_sorted u32[R] | 2 seg_offset i32[tiles+1] | 3 slot_tile i32[slots]
 //          | 4 ckpt float4[slots][4 quadrants][64 lanes]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
-int64_t max_slots(int64_t R, int tiles) { return R / SEG + tiles + 1; }
 size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
     const size_t slots = (size_t)max_slots(R, tiles);
@@ -1241,7 +1450,7 @@ const char *csplat_last_error(void) { return g_csplat_err; }
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
 size_t csplat_image_bytes(int W, int H) { size_t off[5]; return image_offsets(W, H, off); }
 size_t csplat_binning_bytes(int64_t R, int W, int H) { size_t off[5]; return binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); }
-size_t csplat_temp_bytes(int P, int64_t R) { (void)P; size_t off[5]; return temp_offsets(R, off); }
+size_t csplat_temp_bytes(int P, int64_t R, int W, int H) { (void)P; (void)W; (void)H; size_t off[5]; return temp_offsets(R, off); }
 size_t csplat_backward_scratch_bytes(int P, int64_t R) { (void)R; return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4); }
 int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
 int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[5]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
@@ -1287,11 +1496,11 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         if (stage)
             k_preprocess<true><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
                                                              scale_modifier, rotations, cov3D_precomp, cam, g, radii,
-                                                             (int)(g_debug_flags & 1u));
+                                                             (int)((g_debug_flags & 1u) ? 1 : ((g_debug_flags & 16u) ? 2 : 0)));
         else
             k_preprocess<false><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
                                                               scale_modifier, rotations, cov3D_precomp, cam, g, radii,
-                                                              (int)(g_debug_flags & 1u));
+                                                              (int)((g_debug_flags & 1u) ? 1 : ((g_debug_flags & 16u) ? 2 : 0)));
         LAUNCH_CHECK();
     }
     uint32_t *table = nullptr;
@@ -1362,7 +1571,7 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     int *slot_tile = (int *)((char *)bbase + boff[3]);
     float4 *ckpt = (float4 *)((char *)bbase + boff[4]);
     if (R > 0) {
-        void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R));
+        void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
         CSPLAT_REQUIRE(tbase, "allocator returned NULL");
         size_t toff[5];
         temp_offsets(R, toff);
@@ -1411,10 +1620,15 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         k_seg_plan<<<1, 1024, 0, s>>>(tiles, ranges, seg_offset, slot_tile);
         LAUNCH_CHECK();
     }
-    {
+    if (!(g_debug_flags & 8u)) {   // default: sequential forward (one wave walks a quadrant's whole list)
         ProfScope ps(PROF_K6, s);
         k_render_fwd<<<tiles * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, g.cut2,
                                               bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth);
+        LAUNCH_CHECK();
+    } else {   // opt-in (measured 192 us vs 172 us on scene_1): four waves per quadrant, speculative rounds
+        ProfScope ps(PROF_K6, s);
+        k_render_fwd_rounds<<<tiles * 4, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity,
+                                                      g.cut2, bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;

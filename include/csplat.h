@@ -46,7 +46,10 @@ typedef void *(*csplat_alloc_fn)(void *ctx, int chunk, size_t bytes);
 int csplat_abi_version(void);
 /* test hook (results must not change).  bit 0: disable the wave-level culling of K6/K7;
  * bit 1: force the global radix-sort binning path instead of the tile-bucketed LDS sort;
- * bit 2: read R with a blocking stream synchronise instead of polling the pinned mailbox */
+ * bit 2: read R with a blocking stream synchronise instead of polling the pinned mailbox;
+ * bit 3: depth-split forward compositing (four wavefronts per quadrant, rounds of speculative 256-entry segments with
+ *        exact replay of terminating segments) instead of the sequential one-wavefront-per-quadrant kernel;
+ * bit 4: quadruple the culling radius (sensitivity check of the culling bound) */
 int csplat_debug_flags(unsigned flags);
 const char *csplat_last_error(void);
 
@@ -54,7 +57,7 @@ const char *csplat_last_error(void);
 size_t csplat_geom_bytes(int P);
 size_t csplat_image_bytes(int W, int H);
 size_t csplat_binning_bytes(int64_t R, int W, int H);
-size_t csplat_temp_bytes(int P, int64_t R);
+size_t csplat_temp_bytes(int P, int64_t R, int W, int H);
 size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-Gaussian accumulation records used by csplat_backward */
 
 /* Byte offsets of the named sub-buffers inside a chunk (for tests / debugging; see DESIGN.md "HBM layout").
