@@ -1,0 +1,113 @@
+"""Training-level parity (north_star "PSNR within 0.05 dB of reference"): the same train_step
+analogue run (a) on the MI355X through the HIP hot path in fp32 and (b) on the CPU through the oracle -- the C
+restatement for the tile lists plus the differentiable fp64 torch restatement for image and gradients -- from identical
+initial parameters, targets, optimisers and learning rates.  After a fixed number of steps the PSNR must agree to 0.05 dB.
+(The reference itself has no CPU rasterizer, SURVEY F2: the oracle stands in for it; small scene so the CPU side runs in
+seconds.)"""
+import numpy as np
+import pytest
+
+import util  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+STEPS = 40
+
+
+def _oracle_render(cam, pc, sim, bg_np):
+    """render() on CPU tensors through oracle/: simulator and mesh->Gaussian transform in torch (fp64), rasterizer =
+    raster_ref.c (lists) + raster_torch.py (autograd)."""
+    from oracle import raster_oracle as ro, raster_torch as rt
+    V = pc.mesh.pos.shape[0]
+    time = torch.tensor(cam.time, dtype=torch.float64).repeat(V, 1)
+    verts = sim(time_vector=time)
+    means3D = pc.get_xyz(verts)
+    rots = pc.get_rotation(verts)
+    n = lambda t: t.detach().numpy()  # noqa: E731
+    H, W = cam.image_height, cam.image_width
+    o = ro.forward(n(means3D), n(pc.get_opacity), n(cam.world_view_transform), n(cam.full_proj_transform), n(cam.camera_center),
+                   np.tan(cam.FoVx * 0.5), np.tan(cam.FoVy * 0.5), W, H, bg_np, shs=n(pc.get_features), sh_degree=pc.active_sh_degree,
+                   scales=n(pc.get_scaling), rotations=n(rots), dtype=np.float64)
+    m2d = torch.zeros(means3D.shape[0], 3, dtype=torch.float64)
+    color, _, _ = rt.render(o, means3D, m2d, pc.get_opacity, shs=pc.get_features, scales=pc.get_scaling, rotations=rots)
+    return color, verts
+
+
+def test_psnr_parity_hip_vs_oracle_training():
+    import bench_train as bt
+    from csplat import train as tr
+    from csplat.gaussians import MeshGaussians
+    from gaussian_renderer import render
+    from meshnet.meshnet_network import ResidualMeshSimulator
+    P, W, H, grid, n_times = 400, 48, 48, 8, 4
+    from csplat import synthetic as syn
+    sc = syn.scene_1(P=P, W=W, H=H, n_cams=1, grid=grid, n_times=n_times, seed=77)
+    sc["log_scales"] = sc["log_scales"] + np.log(6.0)       # splats large enough for a 48x48 image
+    times = [1 / 3, 2 / 3, 1.0]
+
+    def build(dev, dt):
+        T = lambda a, d=dt: torch.tensor(a, device=dev, dtype=d)  # noqa: E731
+        pc = MeshGaussians(3).from_arrays(T(sc["mesh_pos"][0]), T(sc["faces"].T.copy(), torch.long), T(sc["edge_index"], torch.long),
+                                          T(sc["face_ids"], torch.long), T(sc["bary"]), T(sc["log_scales"]), T(sc["quats"]),
+                                          T(sc["opacity_logits"]), T(sc["sh"]))
+        pc.active_sh_degree = 3
+        sim = ResidualMeshSimulator(T(sc["mesh_pos"]), device=dev)
+        torch.manual_seed(5)
+        w_in, w_h = torch.randn(256, 13) * 0.2, torch.randn(256, 256) * 0.05
+        w_out = torch.randn(sc["mesh_pos"].shape[1] * 3, 256) * 1e-3
+        with torch.no_grad():   # identical simulator weights on both sides
+            sim.input.weight.copy_(w_in.to(dev, dt)); sim.hidden.weight.copy_(w_h.to(dev, dt)); sim.output.weight.copy_(w_out.to(dev, dt))
+            sim.input.bias.zero_(); sim.hidden.bias.zero_(); sim.output.bias.zero_()
+        if dt == torch.float64:
+            sim = sim.double()
+        return pc, sim
+
+    # ---- targets from the GPU renderer on perturbed colours / opacities (shared by both runs)
+    dev = torch.device("cuda:0")
+    pc_g, sim_g = build(dev, torch.float32)
+    bg = torch.ones(3, device=dev)
+    cams_g = bt.cameras(sc, times, dev)
+    with torch.no_grad():
+        keep = [p.detach().clone() for p in pc_g.parameters()]
+        torch.manual_seed(9)
+        pc_g._features_dc.add_(0.6 * torch.randn(P, 1, 3, device=dev))
+        pc_g._opacity.add_(0.8 * torch.randn(P, 1, device=dev))
+        targets = [render(c, pc_g, sim_g, tr.DEFAULT_PIPE, bg).render.clamp(0, 1).clone() for c in cams_g]
+        for p, k in zip(pc_g.parameters(), keep):
+            p.copy_(k)
+    cams_g = bt.cameras(sc, times, dev, targets)
+
+    # ---- (a) HIP training
+    pc_g.training_setup(feature_lr=0.01)
+    mopt_g = torch.optim.Adam(sim_g.parameters(), lr=3e-4)
+    psnr_g = []
+    for it in range(1, STEPS + 1):
+        p, _, _ = tr.train_step(it, cams_g, pc_g, sim_g, mopt_g, background=bg)
+        psnr_g.append(float(p))
+
+    # ---- (b) oracle training on the CPU (fp64), same step structure as csplat.train.train_step
+    pc_c, sim_c = build("cpu", torch.float64)
+    pc_c.fused = False
+    pc_c.training_setup(feature_lr=0.01)
+    mopt_c = torch.optim.Adam(sim_c.parameters(), lr=3e-4)
+    cams_c = bt.cameras(sc, times, "cpu", [t.cpu().double() for t in targets])
+    bg_np = np.ones(3)
+    psnr_c = []
+    for it in range(1, STEPS + 1):
+        imgs, verts = [], []
+        for c in cams_c:
+            color, v = _oracle_render(c, pc_c, sim_c, bg_np)
+            imgs.append(color.unsqueeze(0)); verts.append(v[None])
+        image_tensor = torch.cat(imgs, 0)
+        gt = torch.stack([c.original_image for c in cams_c])
+        psnr_c.append(float(tr.psnr(image_tensor, gt).mean()))
+        loss = tr.image_losses(image_tensor, gt, tr.DEFAULT_OPT) + tr.regularization(torch.cat(verts, 0), pc_c, tr.DEFAULT_OPT)
+        loss.backward()
+        pc_c.optimizer.step(); mopt_c.step()
+        pc_c.optimizer.zero_grad(set_to_none=True); mopt_c.zero_grad()
+
+    psnr_g, psnr_c = np.array(psnr_g), np.array(psnr_c)
+    assert psnr_g[-1] > psnr_g[0] + 0.5                      # both actually train
+    assert abs(psnr_g[-1] - psnr_c[-1]) <= 0.05, (psnr_g[-1], psnr_c[-1])      # north_star: within 0.05 dB
+    assert np.abs(psnr_g - psnr_c).max() <= 0.05, np.abs(psnr_g - psnr_c).max()  # ... along the whole trajectory
