@@ -1,0 +1,223 @@
+// csplat_gemm.hip -- the 128-wide Linear layers of the MeshNet MLPs for INFERENCE (rollout,
+// BASELINE configs[3]): out[M][128] = act(A[M][128] @ W[128][128]^T + bias), fp32 in, fp32 accumulate, exact-fp32 MFMA.
+//
+// The reference runs these through cuBLAS sgemm (meshnet/graph_network.py:198,221 via nn.Linear); on this stack the same
+// call (rocBLAS / hipBLASLt, M = 300,000 rows, N = K = 128) reaches ~34 TFLOP/s, i.e. ~290 us per layer, and the 45 such
+// layers of a rollout step are 85 % of its time.  The shape is fixed and skinny, so a dedicated kernel can sit on both
+// roofs at once: 9.8 GFLOP at the 155 TFLOP/s fp32-MFMA rate is 63 us, 2 x 154 MB at ~5 TB/s is 62 us.
+//
+// Design (gfx950): persistent workgroups of 4 wavefronts; W^T is staged ONCE per workgroup in LDS (k-major, 64.5 KB);
+// a wave owns 32 output rows x 128 columns: 4 accumulator tiles of v_mfma_f32_32x32x2_f32 (64 VGPRs).  The contraction
+// index is permuted so that lane-half h of a wave takes k = 64h + s at step s: each lane then needs ONE contiguous
+// 256-byte run of its A row (16 x global_load_dwordx4, no redundancy between the halves, no LDS for A), and the B operand
+// of step s is one conflict-free ds_read_b32 per column tile (32 consecutive columns at row k of W^T).  Bias + ReLU are
+// applied to the accumulators; each (register, lane-half) stores 32 consecutive floats of one output row.
+#include "csplat_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GK = 128, GN = 128, WT_STRIDE = 129;   // W^T rows padded: conflict-free transposed staging
+
+// Epilogue options (all fused into the accumulator registers, no extra HBM pass):
+//   alpha     : out = alpha * (A @ W^T) + bias                (the 2^l edge-feature scale of graph_network.py:222)
+//   GATHER    : + ga[ia[row]][col] + gb[ib[row]][col]          (the x_i / x_j column blocks of the split first Linear)
+//   relu      : max(., 0)
+//   LN        : LayerNorm over the 128 columns of each row (biased variance, eps), then * gamma + beta
+template <bool GATHER, bool LN>
+__global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A, const float *__restrict__ W,
+                                                    const float *__restrict__ bias, float alpha, int relu,
+                                                    const float *__restrict__ ga, const int64_t *__restrict__ ia,
+                                                    const float *__restrict__ gb, const int64_t *__restrict__ ib,
+                                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                    float *out) {
+    extern __shared__ float s_wt[];   // [GK][WT_STRIDE]: s_wt[k * WT_STRIDE + j] = W[j][k]
+    {   // all 16 float4 loads of a thread in flight at once; W[j][4i..4i+3] -> rows 4i..4i+3 of W^T
+        float4 wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = reinterpret_cast<const float4 *>(W)[threadIdx.x + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int t = threadIdx.x + 256 * i, j = t >> 5, k = (t & 31) * 4;
+            s_wt[(k + 0) * WT_STRIDE + j] = wv[i].x;
+            s_wt[(k + 1) * WT_STRIDE + j] = wv[i].y;
+            s_wt[(k + 2) * WT_STRIDE + j] = wv[i].z;
+            s_wt[(k + 3) * WT_STRIDE + j] = wv[i].w;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int64_t ntile = (M + 31) / 32;
+    float bcol[4], gcol[4], becol[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        bcol[c] = bias ? bias[32 * c + r32] : 0.f;
+        gcol[c] = LN ? gamma[32 * c + r32] : 1.f;
+        becol[c] = LN ? beta[32 * c + r32] : 0.f;
+    }
+    // Memory-op choreography.  On gfx9-family ISAs loads and stores share vmcnt and may retire out of order with respect
+    // to each other, so a wait on ANY load while stores are in flight is a wait for those stores.  Each iteration
+    // therefore (1) runs this tile's 256 MFMAs, re-filling each 16-byte chunk of the A-row registers with the NEXT tile's
+    // data as soon as its last MFMA has consumed it (no second register set), (2) waits for those loads -- all but the
+    // last few long since landed -- and only then (3) issues this tile's stores, which drain under the next tile's MFMAs.
+    // Rows past M are clamped to M - 1 (loads stay unconditional; MFMA rows are independent, masked at the store).
+    auto row_of = [&](int64_t tile) {
+        const int64_t row = tile * 32 + r32;
+        return row < M ? row : M - 1;
+    };
+    const int64_t tstride = (int64_t)gridDim.x * 4;
+    float4 X[16];                                  // k = 64h .. 64h + 63 of this lane's row
+    int ja = 0, jb = 0, jan = 0, jbn = 0;          // gather rows of tile row r32 (node ids: < 2^31)
+    {
+        const int64_t row = row_of((int64_t)blockIdx.x * 4 + w);
+        const float4 *ap = reinterpret_cast<const float4 *>(A + row * GK + 64 * h);
+#pragma unroll
+        for (int q = 0; q < 16; q++) X[q] = ap[q];
+        if (GATHER) { ja = (int)ia[row]; jb = (int)ib[row]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing from the prologue is pending at loop entry
+    const float *wrow = s_wt + (64 * h) * WT_STRIDE + r32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntile; tile += tstride) {
+        const int64_t nrow = row_of(tile + tstride);
+        const float4 *apn = reinterpret_cast<const float4 *>(A + nrow * GK + 64 * h);
+        if (GATHER) { jan = (int)ia[nrow]; jbn = (int)ib[nrow]; }
+        f32x16 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
+        // B operand: step s (this lane contributes k = 64h + s) and column tile c read s_wt[(64h + s)][32c + r32].
+        // Explicitly double-buffered in groups of 2 steps: the 8 ds_reads of group g + 1 are issued before the 8 MFMAs
+        // (512 cycles) of group g, so the MFMA pipe never waits on LDS latency; sched_barrier pins the order.
+        float bc[8], bn[8];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) bc[4 * u + c] = wrow[u * WT_STRIDE + 32 * c];
+#pragma unroll
+        for (int g = 0; g < 32; g++) {
+            if (g < 31) {
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) bn[4 * u + c] = wrow[(2 * (g + 1) + u) * WT_STRIDE + 32 * c];
+            }
+            const float4 xq = X[g >> 1];
+            const float av[2] = {(g & 1) ? xq.z : xq.x, (g & 1) ? xq.w : xq.y};
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[4 * u + c], acc[c], 0, 0, 0);
+            if (g & 1) X[g >> 1] = apn[g >> 1];     // chunk consumed: fetch the next tile's into the same registers
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) bc[i] = bn[i];
+        }
+        // C/D layout of 32x32 tiles: column = lane & 31, tile row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        float o[16][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[r][c] = alpha * acc[c][r] + bcol[c];
+        if (GATHER) {
+            // The gather rows of the tile go through a 256-byte wave-private LDS strip (DS ops of one wave execute in
+            // order: no barrier), so each row's index is one broadcast ds_read instead of a cross-lane shuffle.
+            int *strip = reinterpret_cast<int *>(s_wt + GK * WT_STRIDE) + w * 64;
+            if (h == 0) { strip[r32] = ja; strip[32 + r32] = jb; }
+            // four batches of 4 rows: the 32 gather loads of a batch are in flight together (no stores pending here)
+#pragma unroll
+            for (int b4 = 0; b4 < 4; b4++) {
+                float g[4][4][2];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int r = 4 * b4 + rr, trow = (r & 3) + 8 * (r >> 2);
+                    const int64_t ra = strip[trow + 4 * h], rb = strip[32 + trow + 4 * h];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        g[rr][c][0] = ga[ra * GN + 32 * c + r32];
+                        g[rr][c][1] = gb[rb * GN + 32 * c + r32];
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        o[4 * b4 + rr][c] += g[rr][c][0] + g[rr][c][1];
+                        asm volatile("" : "+v"(o[4 * b4 + rr][c]));   // pin the add here: keeps the gathered values short-lived
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // The wait on this phase's loads, made explicit so that it precedes the stores.  The 6 youngest loads (chunks
+        // 10..15 of the next tile, issued in the last third of the MFMA phase) may stay in flight: they are not needed
+        // before step 40 of the next tile, by which time these stores have drained.
+        __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6)
+        ja = jan; jb = jbn;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = relu ? fmaxf(o[r][c], 0.f) : o[r][c];
+            if (LN) {
+                float sum = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                const float mean = sum * (1.f / GN);
+                float d[4], sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) { d[c] = v[c] - mean; sq += d[c] * d[c]; }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+                const float rstd = rsqrtf(sq * (1.f / GN) + eps);
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = d[c] * rstd * gcol[c] + becol[c];
+            }
+            if (orow < M) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) out[orow * GN + 32 * c + r32] = v[c];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, const float *bias, float alpha, int relu,
+                                const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
+                                const float *ln_gamma, const float *ln_beta, float ln_eps, float *out) {
+    CSPLAT_REQUIRE(M >= 0 && (M == 0 || (A && W && out)), "csplat_linear128: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)A | (uintptr_t)out | (uintptr_t)W) & 15u) == 0, "csplat_linear128: A / W / out must be 16-byte aligned");
+    if (M == 0) return 0;
+    const bool gather = gather_a != nullptr;
+    CSPLAT_REQUIRE(!gather || (index_a && gather_b && index_b), "csplat_linear128: gather needs both row sets and both index arrays");
+    const bool ln = ln_gamma != nullptr;
+    CSPLAT_REQUIRE(!ln || ln_beta, "csplat_linear128: LayerNorm needs gamma and beta");
+    static int s_ok = -1;
+    const size_t lds = (size_t)GK * WT_STRIDE * 4 + 4 * 64 * sizeof(int);   // W^T + the gather-index strips
+    if (s_ok < 0) {
+        s_ok = 1;
+        const void *fns[4] = {(const void *)k_linear128<false, false>, (const void *)k_linear128<false, true>,
+                              (const void *)k_linear128<true, false>, (const void *)k_linear128<true, true>};
+        for (const void *f : fns) s_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    CSPLAT_REQUIRE(s_ok, "csplat_linear128: 67 KB of dynamic LDS refused by the runtime");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    const int64_t ntile = (M + 31) / 32;
+    int grid = (int)((ntile + 3) / 4);
+    if (grid > 512) grid = 512;    // persistent: 2 workgroups per CU, W^T staged once each
+#define CSPLAT_L128(G, L)                                                                                                  \
+    k_linear128<G, L><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, ln_gamma, \
+                                             ln_beta, ln_eps, out)
+    if (gather && ln) CSPLAT_L128(true, true);
+    else if (gather) CSPLAT_L128(true, false);
+    else if (ln) CSPLAT_L128(false, true);
+    else CSPLAT_L128(false, false);
+#undef CSPLAT_L128
+    LAUNCH_CHECK();
+    return 0;
+}

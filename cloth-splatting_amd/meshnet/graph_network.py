@@ -18,7 +18,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import EdgeCombine, GraphCSR, SegmentSum
+from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, linear128
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -58,6 +58,30 @@ def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool) -> torch
     start = 2 if first_has_act else 1  # skip NN-0 (+ Act-0 when it was fused)
     for m in mods[start:]:
         h = m(h)
+    return h
+
+
+def _fusable(seq: nn.Sequential, width: int = 128) -> bool:
+    """[build_mlp(...), LayerNorm] whose layers after the first are 128 -> 128 Linear + ReLU (Identity last)."""
+    mlp, ln = seq[0], seq[1]
+    mods = list(mlp.children())
+    lins, acts = mods[0::2], mods[1::2]
+    if not (isinstance(ln, nn.LayerNorm) and tuple(ln.normalized_shape) == (width,) and ln.elementwise_affine):
+        return False
+    if len(lins) < 2 or not all(isinstance(m, nn.Linear) and m.out_features == width for m in lins):
+        return False
+    if not all(m.in_features == width for m in lins[1:]):
+        return False
+    return all(isinstance(a, nn.ReLU) for a in acts[:-1]) and isinstance(acts[-1], nn.Identity) and \
+        lins[0].weight.dtype == torch.float32 and lins[0].weight.is_cuda
+
+
+def _fused_tail(seq: nn.Sequential, h: torch.Tensor) -> torch.Tensor:
+    """layers 1.. of a _fusable MLP + its LayerNorm, in place on h (h = activated output of layer 0)."""
+    lins = list(seq[0].children())[0::2]
+    for i, lin in enumerate(lins[1:], start=1):
+        last = i == len(lins) - 1
+        h = linear128(h, lin.weight, lin.bias, relu=not last, layer_norm=seq[1] if last else None, out=h)
     return h
 
 
@@ -101,6 +125,30 @@ class InteractionNetwork(nn.Module):
         # PyG hands update() the ORIGINAL edge features: edge output = input + input
         return x_updated + x_residual, edge_features + edge_features_residual
 
+    def inference_ok(self, x, edge_features) -> bool:
+        n = self._nnode_in
+        return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and \
+            edge_features.dtype == torch.float32 and n == 128 and self._nedge_in == 128 and \
+            _fusable(self.edge_fn) and _fusable(self.node_fn)
+
+    def forward_inference(self, x, edge_index, e0, scale: float):
+        """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd, returns
+        the updated nodes only.  Per layer the [E,128] activations make three read+write passes (one per Linear, with
+        gather / bias / ReLU / LayerNorm in the epilogues) and one read by the segmented sum."""
+        csr = GraphCSR.get(edge_index, x.shape[0])
+        n = self._nnode_in
+        lin0 = self.edge_fn[0][0]
+        W = lin0.weight
+        xa = x @ W[:, :n].t()
+        xb = x @ W[:, n:2 * n].t()
+        h = linear128(e0, W[:, 2 * n:], lin0.bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
+        msg = _fused_tail(self.edge_fn, h)
+        agg = SegmentSum.apply(msg, csr)
+        l0 = self.node_fn[0][0]
+        a = agg.shape[1]
+        hn = torch.addmm(l0.bias, agg, l0.weight[:, :a].t()).addmm_(x, l0.weight[:, a:].t()).relu_()
+        return _fused_tail(self.node_fn, hn).add_(x)
+
 
 class Processor(nn.Module):
     """graph_network.py:225-292 (declared aggr='max' upstream but never propagates itself)."""
@@ -115,6 +163,13 @@ class Processor(nn.Module):
             for _ in range(nmessage_passing_steps)])
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+        if len(self.gnn_stacks) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks):
+            # rollout: every layer doubles the edge features (F7), so carry e0 and the scalar 2^l instead of 15 [E,128] passes
+            e0, scale = edge_features.contiguous(), 1.0
+            for gnn in self.gnn_stacks:
+                x = gnn.forward_inference(x, edge_index, e0, scale)
+                scale *= 2.0
+            return x, e0 * scale
         for gnn in self.gnn_stacks:
             x, edge_features = gnn(x, edge_index, edge_features)
         return x, edge_features

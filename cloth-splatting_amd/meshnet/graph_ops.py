@@ -108,3 +108,31 @@ class SegmentSum(torch.autograd.Function):
             _n.check(_n.lib.csplat_gnn_gather_rows(_n.stream_handle(g.device), csr.E, L, _n.ptr(g), csr.ei[1].data_ptr(),
                                                    _n.ptr(out)), "csplat_gnn_gather_rows")
         return out, None
+
+
+def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, out=None):
+    """Inference-only fused Linear for the 128-wide MeshNet MLP layers (csplat_linear128, include/csplat.h):
+        out = LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] ) )
+    A [M,128] fp32, weight [128,128] (torch Linear.weight), gather = (ga, ia, gb, ib) or None,
+    layer_norm = nn.LayerNorm(128) or None.  No autograd graph is recorded: callers use it under torch.no_grad()."""
+    _n.require_cuda(A)
+    assert A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == 128 and tuple(weight.shape) == (128, 128)
+    A, weight = A.contiguous(), weight.detach().contiguous()
+    M = A.shape[0]
+    out = torch.empty_like(A) if out is None else out
+    ga = ia = gb = ib = None
+    if gather is not None:
+        ga, ia, gb, ib = gather
+        ga, gb, ia, ib = _f32(ga), _f32(gb), ia.contiguous(), ib.contiguous()
+        assert ia.dtype == torch.int64 and ib.dtype == torch.int64 and ia.numel() == M and ib.numel() == M
+    g = b = None
+    eps = 0.0
+    if layer_norm is not None:
+        assert tuple(layer_norm.normalized_shape) == (128,) and layer_norm.elementwise_affine
+        g, b, eps = layer_norm.weight.detach().contiguous(), layer_norm.bias.detach().contiguous(), float(layer_norm.eps)
+    bias = None if bias is None else bias.detach().contiguous()
+    with torch.cuda.device(A.device):
+        _n.check(_n.lib.csplat_linear128(_n.stream_handle(A.device), M, _n.ptr(A), _n.ptr(weight), _n.ptr(bias), float(alpha),
+                                         int(relu), _n.ptr(ga), _n.ptr(ia), _n.ptr(gb), _n.ptr(ib), _n.ptr(g), _n.ptr(b), eps,
+                                         _n.ptr(out)), "csplat_linear128")
+    return out
