@@ -24,13 +24,16 @@ constexpr int GK = 128, GN = 128, WT_STRIDE = 129;   // W^T rows padded: conflic
 //   GATHER    : + ga[ia[row]][col] + gb[ib[row]][col]          (the x_i / x_j column blocks of the split first Linear)
 //   relu      : max(., 0)
 //   LN        : LayerNorm over the 128 columns of each row (biased variance, eps), then * gamma + beta
-template <bool GATHER, bool LN>
+//   ADD       : + add_pre[row][col] before the ReLU and/or + add_post[row][col] after the LayerNorm (row-aligned [M][128]
+//               operands: the second half of a split first Linear, the residual connection).  Loaded inline between the
+//               stores, i.e. off the tuned path: meant for the node-level calls (M = N nodes), not the edge-level ones.
+template <bool GATHER, bool LN, bool ADD>
 __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A, const float *__restrict__ W,
                                                     const float *__restrict__ bias, float alpha, int relu,
                                                     const float *__restrict__ ga, const int64_t *__restrict__ ia,
                                                     const float *__restrict__ gb, const int64_t *__restrict__ ib,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                    float *out) {
+                                                    const float *add_pre, const float *add_post, float *out) {
     extern __shared__ float s_wt[];   // [GK][WT_STRIDE]: s_wt[k * WT_STRIDE + j] = W[j][k]
     {   // all 16 float4 loads of a thread in flight at once; W[j][4i..4i+3] -> rows 4i..4i+3 of W^T
         float4 wv[16];
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
 #pragma unroll
                     for (int c = 0; c < 4; c++) bn[4 * u + c] = wrow[(2 * (g + 1) + u) * WT_STRIDE + 32 * c];
             }
+            __builtin_amdgcn_sched_barrier(0);     // reads first: they complete under this group's 512 MFMA cycles
             const float4 xq = X[g >> 1];
             const float av[2] = {(g & 1) ? xq.z : xq.x, (g & 1) ? xq.w : xq.y};
 #pragma unroll
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
 #pragma unroll
                 for (int c = 0; c < 4; c++)
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[4 * u + c], acc[c], 0, 0, 0);
-            if (g & 1) X[g >> 1] = apn[g >> 1];     // chunk consumed: fetch the next tile's into the same registers
+            if (g & 1) X[g >> 1] = apn[g >> 1];   // chunk consumed: fetch the next tile's into the same registers
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 8; i++) bc[i] = bn[i];
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
         }
         // The wait on this phase's loads, made explicit so that it precedes the stores.  The 6 youngest loads (chunks
         // 10..15 of the next tile, issued in the last third of the MFMA phase) may stay in flight: they are not needed
-        // before step 40 of the next tile, by which time these stores have drained.
+        // before step 40 of the next tile, by which time these stores have drained.  (A second register set filled at
+        // the top of the phase was measured: same time, 60 more VGPRs.)
         __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6)
         ja = jan; jb = jbn;
 #pragma unroll
@@ -160,7 +165,16 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
             const int64_t orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = relu ? fmaxf(o[r][c], 0.f) : o[r][c];
+            for (int c = 0; c < 4; c++) v[c] = o[r][c];
+            const int64_t arow = orow < M ? orow : M - 1;
+            if (ADD && add_pre) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] += add_pre[arow * GN + 32 * c + r32];
+            }
+            if (relu) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = fmaxf(v[c], 0.f);
+            }
             if (LN) {
                 float sum = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
@@ -175,6 +189,10 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
 #pragma unroll
                 for (int c = 0; c < 4; c++) v[c] = d[c] * rstd * gcol[c] + becol[c];
             }
+            if (ADD && add_post) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] += add_post[arow * GN + 32 * c + r32];
+            }
             if (orow < M) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) out[orow * GN + 32 * c + r32] = v[c];
@@ -183,11 +201,111 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
     }
 }
 
+
+// Node-level variant (M = N nodes, ~10^4 rows): with one 32-row tile per wave the persistent kernel above fills a third
+// of the chip and pays a 64 KB weight staging per workgroup.  Here a workgroup owns ONE tile and its 4 waves split the 128
+// output columns: each wave stages only its 16 KB of W^T, runs 64 MFMAs, and LayerNorm statistics cross the waves through
+// LDS.  Same arithmetic, same epilogue options minus the gathers.
+constexpr int SW_STRIDE = 33;
+template <bool LN>
+__global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float *A, const float *__restrict__ W,
+                                                           const float *__restrict__ bias, float alpha, int relu,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                           const float *add_pre, const float *add_post, float *out) {
+    extern __shared__ float s_dyn[];
+    float (*s_w)[GK * SW_STRIDE] = reinterpret_cast<float (*)[GK * SW_STRIDE]>(s_dyn);   // per wave: s_w[w][k * 33 + jj] = W[32w + jj][k]
+    float (*s_part)[32][4] = reinterpret_cast<float (*)[32][4]>(s_dyn + 4 * GK * SW_STRIDE);   // [pass][row][wave] partial sums
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
+    {
+        float4 wv[16];
+        const float4 *wp = reinterpret_cast<const float4 *>(W + (size_t)32 * w * GK);
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = wp[lane + 64 * i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx = lane + 64 * i, jj = idx >> 5, k = (idx & 31) * 4;
+            s_w[w][(k + 0) * SW_STRIDE + jj] = wv[i].x;
+            s_w[w][(k + 1) * SW_STRIDE + jj] = wv[i].y;
+            s_w[w][(k + 2) * SW_STRIDE + jj] = wv[i].z;
+            s_w[w][(k + 3) * SW_STRIDE + jj] = wv[i].w;
+        }
+    }
+    const int64_t tile = blockIdx.x;
+    int64_t row = tile * 32 + r32;
+    row = row < M ? row : M - 1;
+    float4 X[16];
+    const float4 *ap = reinterpret_cast<const float4 *>(A + row * GK + 64 * h);
+#pragma unroll
+    for (int q = 0; q < 16; q++) X[q] = ap[q];
+    const int col = 32 * w + r32;
+    const float bcol = bias ? bias[col] : 0.f, gcol = LN ? gamma[col] : 1.f, becol = LN ? beta[col] : 0.f;
+    // when out aliases A, every wave must have read the tile's rows before any wave overwrites them
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const float *wrow = &s_w[w][(64 * h) * SW_STRIDE + r32];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const float av[4] = {X[q].x, X[q].y, X[q].z, X[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wrow[(4 * q + u) * SW_STRIDE], acc, 0, 0, 0);
+    }
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * h;
+        int64_t orow = tile * 32 + trow;
+        orow = orow < M ? orow : M - 1;
+        v[r] = alpha * acc[r] + bcol;
+        if (add_pre) v[r] += add_pre[orow * GN + col];
+        if (relu) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (LN) {
+        float mean[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float sum = v[r];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            if (r32 == 0) s_part[0][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float *p = s_part[0][(r & 3) + 8 * (r >> 2) + 4 * h];
+            mean[r] = ((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN);
+            const float d = v[r] - mean[r];
+            float sq = d * d;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            if (r32 == 0) s_part[1][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sq;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float *p = s_part[1][(r & 3) + 8 * (r >> 2) + 4 * h];
+            const float rstd = rsqrtf(((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN) + eps);
+            v[r] = (v[r] - mean[r]) * rstd * gcol + becol;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < M) {
+            float o = v[r];
+            if (add_post) o += add_post[orow * GN + col];
+            out[orow * GN + col] = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, const float *bias, float alpha, int relu,
                                 const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
-                                const float *ln_gamma, const float *ln_beta, float ln_eps, float *out) {
+                                const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,
+                                const float *add_post, float *out) {
     CSPLAT_REQUIRE(M >= 0 && (M == 0 || (A && W && out)), "csplat_linear128: bad arguments");
     CSPLAT_REQUIRE((((uintptr_t)A | (uintptr_t)out | (uintptr_t)W) & 15u) == 0, "csplat_linear128: A / W / out must be 16-byte aligned");
     if (M == 0) return 0;
@@ -195,28 +313,44 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
     CSPLAT_REQUIRE(!gather || (index_a && gather_b && index_b), "csplat_linear128: gather needs both row sets and both index arrays");
     const bool ln = ln_gamma != nullptr;
     CSPLAT_REQUIRE(!ln || ln_beta, "csplat_linear128: LayerNorm needs gamma and beta");
+    const bool add = add_pre != nullptr || add_post != nullptr;
+    CSPLAT_REQUIRE(!(add && gather), "csplat_linear128: row-aligned addends and gathers are not combined (no caller needs it)");
     static int s_ok = -1;
     const size_t lds = (size_t)GK * WT_STRIDE * 4 + 4 * 64 * sizeof(int);   // W^T + the gather-index strips
     if (s_ok < 0) {
         s_ok = 1;
-        const void *fns[4] = {(const void *)k_linear128<false, false>, (const void *)k_linear128<false, true>,
-                              (const void *)k_linear128<true, false>, (const void *)k_linear128<true, true>};
+        const void *fns[6] = {(const void *)k_linear128<false, false, false>, (const void *)k_linear128<false, true, false>,
+                              (const void *)k_linear128<true, false, false>,  (const void *)k_linear128<true, true, false>,
+                              (const void *)k_linear128<false, false, true>,  (const void *)k_linear128<false, true, true>};
         for (const void *f : fns) s_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_linear128_rows32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_linear128_rows32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         (void)hipGetLastError();
     }
     CSPLAT_REQUIRE(s_ok, "csplat_linear128: 67 KB of dynamic LDS refused by the runtime");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_GNN, s);
     const int64_t ntile = (M + 31) / 32;
+    if (!gather && ntile <= 2048) {   // node-level sizes: one tile per workgroup, columns split across its waves
+        const size_t lds_small = (size_t)(4 * GK * SW_STRIDE + 2 * 32 * 4) * sizeof(float);
+        if (ln)
+            k_linear128_rows32<true><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);
+        else
+            k_linear128_rows32<false><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);
+        LAUNCH_CHECK();
+        return 0;
+    }
     int grid = (int)((ntile + 3) / 4);
     if (grid > 512) grid = 512;    // persistent: 2 workgroups per CU, W^T staged once each
-#define CSPLAT_L128(G, L)                                                                                                  \
-    k_linear128<G, L><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, ln_gamma, \
-                                             ln_beta, ln_eps, out)
-    if (gather && ln) CSPLAT_L128(true, true);
-    else if (gather) CSPLAT_L128(true, false);
-    else if (ln) CSPLAT_L128(false, true);
-    else CSPLAT_L128(false, false);
+#define CSPLAT_L128(G, L, D)                                                                                                 \
+    k_linear128<G, L, D><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, ln_gamma, \
+                                                ln_beta, ln_eps, add_pre, add_post, out)
+    if (add && ln) CSPLAT_L128(false, true, true);
+    else if (add) CSPLAT_L128(false, false, true);
+    else if (gather && ln) CSPLAT_L128(true, true, false);
+    else if (gather) CSPLAT_L128(true, false, false);
+    else if (ln) CSPLAT_L128(false, true, false);
+    else CSPLAT_L128(false, false, false);
 #undef CSPLAT_L128
     LAUNCH_CHECK();
     return 0;

@@ -18,7 +18,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, linear128
+from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, linear128, linear_rows
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -49,7 +49,10 @@ class Encoder(nn.Module):
                                                  nedge_out_features), nn.LayerNorm(nedge_out_features)])
 
     def forward(self, x: torch.Tensor, edge_features: torch.Tensor):
-        return self.node_fn(x), self.edge_fn(edge_features)
+        e = edge_features
+        for m in self.edge_fn[0].children():
+            e = linear_rows(e, m.weight, m.bias) if isinstance(m, nn.Linear) else m(e)
+        return self.node_fn(x), self.edge_fn[1](e)
 
 
 def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool) -> torch.Tensor:
@@ -57,7 +60,7 @@ def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool) -> torch
     mods = list(seq_mlp.children())
     start = 2 if first_has_act else 1  # skip NN-0 (+ Act-0 when it was fused)
     for m in mods[start:]:
-        h = m(h)
+        h = linear_rows(h, m.weight, m.bias) if isinstance(m, nn.Linear) else m(h)   # tall inputs: split-K weight gradient
     return h
 
 
@@ -76,12 +79,13 @@ def _fusable(seq: nn.Sequential, width: int = 128) -> bool:
         lins[0].weight.dtype == torch.float32 and lins[0].weight.is_cuda
 
 
-def _fused_tail(seq: nn.Sequential, h: torch.Tensor) -> torch.Tensor:
-    """layers 1.. of a _fusable MLP + its LayerNorm, in place on h (h = activated output of layer 0)."""
+def _fused_tail(seq: nn.Sequential, h: torch.Tensor, add_post: torch.Tensor = None) -> torch.Tensor:
+    """layers 1.. of a _fusable MLP + its LayerNorm (+ a residual), in place on h (h = activated output of layer 0)."""
     lins = list(seq[0].children())[0::2]
     for i, lin in enumerate(lins[1:], start=1):
         last = i == len(lins) - 1
-        h = linear128(h, lin.weight, lin.bias, relu=not last, layer_norm=seq[1] if last else None, out=h)
+        h = linear128(h, lin.weight, lin.bias, relu=not last, layer_norm=seq[1] if last else None,
+                      add_post=add_post if last else None, out=h)
     return h
 
 
@@ -108,7 +112,7 @@ class InteractionNetwork(nn.Module):
         W = lin0.weight
         xa = x @ W[:, :n].t()                       # contribution of x_i = x[edge_index[1]]
         xb = x @ W[:, n:2 * n].t()                  # contribution of x_j = x[edge_index[0]]
-        ec = torch.addmm(lin0.bias, edge_features, W[:, 2 * n:].t())
+        ec = linear_rows(edge_features, W[:, 2 * n:], lin0.bias)
         h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
         h = _tail(mlp_e, h, relu0)
         msg = self.edge_fn[1](h)
@@ -131,23 +135,32 @@ class InteractionNetwork(nn.Module):
             edge_features.dtype == torch.float32 and n == 128 and self._nedge_in == 128 and \
             _fusable(self.edge_fn) and _fusable(self.node_fn)
 
+    def _split_weights(self):
+        """contiguous column blocks of the two first-layer weights, re-cut only when an optimizer step changed them"""
+        we, wn = self.edge_fn[0][0].weight, self.node_fn[0][0].weight
+        key = (we._version, wn._version, we.data_ptr(), wn.data_ptr())
+        if getattr(self, "_wsplit_key", None) != key:
+            n, a = self._nnode_in, wn.shape[1] - self._nnode_in
+            with torch.no_grad():
+                self._wsplit = tuple(t.contiguous() for t in (we[:, :n], we[:, n:2 * n], we[:, 2 * n:], wn[:, :a], wn[:, a:]))
+            self._wsplit_key = key
+        return self._wsplit
+
     def forward_inference(self, x, edge_index, e0, scale: float):
         """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd, returns
         the updated nodes only.  Per layer the [E,128] activations make three read+write passes (one per Linear, with
-        gather / bias / ReLU / LayerNorm in the epilogues) and one read by the segmented sum."""
+        gather / bias / ReLU / LayerNorm in the epilogues) and one read by the segmented sum; the node level is six
+        launches of the same kernel (split first layers, residual in the last epilogue)."""
         csr = GraphCSR.get(edge_index, x.shape[0])
-        n = self._nnode_in
-        lin0 = self.edge_fn[0][0]
-        W = lin0.weight
-        xa = x @ W[:, :n].t()
-        xb = x @ W[:, n:2 * n].t()
-        h = linear128(e0, W[:, 2 * n:], lin0.bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
+        w_i, w_j, w_e, w_agg, w_x = self._split_weights()
+        xa = linear128(x, w_i)                                   # contribution of x_i = x[edge_index[1]]
+        xb = linear128(x, w_j)                                   # contribution of x_j = x[edge_index[0]]
+        h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
         msg = _fused_tail(self.edge_fn, h)
         agg = SegmentSum.apply(msg, csr)
-        l0 = self.node_fn[0][0]
-        a = agg.shape[1]
-        hn = torch.addmm(l0.bias, agg, l0.weight[:, :a].t()).addmm_(x, l0.weight[:, a:].t()).relu_()
-        return _fused_tail(self.node_fn, hn).add_(x)
+        t = linear128(x, w_x, out=xa)
+        hn = linear128(agg, w_agg, self.node_fn[0][0].bias, relu=True, add_pre=t, out=t)
+        return _fused_tail(self.node_fn, hn, add_post=x)
 
 
 class Processor(nn.Module):

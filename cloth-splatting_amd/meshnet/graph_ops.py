@@ -110,11 +110,11 @@ class SegmentSum(torch.autograd.Function):
         return out, None
 
 
-def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, out=None):
+def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, add_pre=None, add_post=None, out=None):
     """Inference-only fused Linear for the 128-wide MeshNet MLP layers (csplat_linear128, include/csplat.h):
-        out = LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] ) )
+        out = LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] + add_pre ) ) + add_post
     A [M,128] fp32, weight [128,128] (torch Linear.weight), gather = (ga, ia, gb, ib) or None,
-    layer_norm = nn.LayerNorm(128) or None.  No autograd graph is recorded: callers use it under torch.no_grad()."""
+    layer_norm = nn.LayerNorm(128) or None, add_pre / add_post [M,128] or None (node-level calls).  No autograd graph is recorded: callers use it under torch.no_grad()."""
     _n.require_cuda(A)
     assert A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == 128 and tuple(weight.shape) == (128, 128)
     A, weight = A.contiguous(), weight.detach().contiguous()
@@ -131,8 +131,49 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
         assert tuple(layer_norm.normalized_shape) == (128,) and layer_norm.elementwise_affine
         g, b, eps = layer_norm.weight.detach().contiguous(), layer_norm.bias.detach().contiguous(), float(layer_norm.eps)
     bias = None if bias is None else bias.detach().contiguous()
+    add_pre = None if add_pre is None else _f32(add_pre)
+    add_post = None if add_post is None else _f32(add_post)
     with torch.cuda.device(A.device):
         _n.check(_n.lib.csplat_linear128(_n.stream_handle(A.device), M, _n.ptr(A), _n.ptr(weight), _n.ptr(bias), float(alpha),
                                          int(relu), _n.ptr(ga), _n.ptr(ia), _n.ptr(gb), _n.ptr(ib), _n.ptr(g), _n.ptr(b), eps,
-                                         _n.ptr(out)), "csplat_linear128")
+                                         _n.ptr(add_pre), _n.ptr(add_post), _n.ptr(out)), "csplat_linear128")
     return out
+
+
+class SplitKLinear(torch.autograd.Function):
+    """y = x @ weight^T + bias for edge-level activations (rows = E ~ 3e5, 128 features) under autograd.
+    The weight gradient g^T @ x is a [128 x E] x [E x 128] product: a single GEMM call reduces over E inside a handful
+    of workgroups (630 us at E = 300k on MI355X); cut into row chunks and run as one batched GEMM + a sum it fills the
+    chip (122 us).  Forward and the input gradient are the plain library calls."""
+
+    CHUNK = 3072
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            M, C = x.shape[0], x.shape[0] // SplitKLinear.CHUNK
+            m0 = C * SplitKLinear.CHUNK
+            xc = x.contiguous()
+            dw = torch.bmm(g[:m0].view(C, SplitKLinear.CHUNK, -1).transpose(1, 2),
+                           xc[:m0].view(C, SplitKLinear.CHUNK, -1)).sum(0) if C else torch.zeros_like(weight)
+            if m0 < M:
+                dw = dw + g[m0:].t() @ xc[m0:]
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_rows(x, lin_weight, lin_bias, min_rows: int = 16384):
+    """nn.Linear forward that switches to SplitKLinear for tall inputs while a graph is being recorded."""
+    if x.shape[0] >= min_rows and torch.is_grad_enabled() and (lin_weight.requires_grad or x.requires_grad):
+        return SplitKLinear.apply(x, lin_weight, lin_bias)
+    return torch.nn.functional.linear(x, lin_weight, lin_bias)

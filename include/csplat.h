@@ -166,13 +166,16 @@ int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, co
 /* The 128-wide Linear layers of the MeshNet MLPs for inference (replaces the cuBLAS sgemm behind nn.Linear at
  * /root/reference/meshnet/graph_network.py:198,221 when no autograd graph is recorded), with everything that follows the
  * product fused into the accumulators:
- *   out[m][:] = LN?( relu?( alpha * (A[m][:] @ W^T) + bias + gather_a[index_a[m]][:] + gather_b[index_b[m]][:] ) )
+ *   out[m][:] = LN?( relu?( alpha * (A[m][:] @ W^T) + bias + gather_a[index_a[m]][:] + gather_b[index_b[m]][:]
+ *                           + add_pre[m][:] ) ) + add_post[m][:]
  * A [M][128], W [128][128] row-major (torch Linear.weight), bias [128] or NULL, gather_* [*][128] with int64 row indices
- * (both or neither), ln_gamma / ln_beta [128] (both or neither; biased variance, ln_eps), out [M][128].
- * fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate). A and out 16-byte aligned. */
+ * (both or neither), ln_gamma / ln_beta [128] (both or neither; biased variance, ln_eps), add_pre / add_post [M][128] or
+ * NULL (not together with the gathers), out [M][128]; out may alias A (and add_post may then alias both).
+ * fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate). A, W and out 16-byte aligned. */
 int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, const float *bias, float alpha, int relu,
                      const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
-                     const float *ln_gamma, const float *ln_beta, float ln_eps, float *out);
+                     const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,
+                     const float *add_post, float *out);
 
 #ifdef __cplusplus
 }

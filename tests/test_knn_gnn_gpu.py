@@ -155,7 +155,7 @@ def test_config4_size_rollout_step_properties():
     assert rel_err(a.cpu().numpy(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("M", [0, 1, 33, 4100])
+@pytest.mark.parametrize("M", [0, 1, 33, 4100, 70001])     # <= 65536 rows: one-tile-per-workgroup kernel; above: persistent kernel
 @pytest.mark.parametrize("gather,ln", [(False, False), (True, False), (False, True), (True, True)])
 def test_linear128_vs_fp64(M, gather, ln):
     """csplat_linear128 (fp32 MFMA, fused bias / gather / ReLU / LayerNorm) against fp64 torch; ragged M covers the row
@@ -176,9 +176,18 @@ def test_linear128_vs_fp64(M, gather, ln):
         ref = 4.0 * (A.double() @ W.double().t()) + b.double()
         if gather:
             ref = ref + ga.double()[ia] + gb.double()[ib]
+        pre = post = None
+        if not gather:                                    # row-aligned addends (node-level calls)
+            pre, post = torch.randn(M, 128, generator=gen).cuda(), torch.randn(M, 128, generator=gen).cuda()
+            out2 = linear128(A, W, b, alpha=4.0, relu=True, layer_norm=norm if ln else None, add_pre=pre, add_post=post)
         ref = ref.relu()
         if ln:
             ref = torch.nn.functional.layer_norm(ref, (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+        if pre is not None and M:
+            ref2 = (4.0 * (A.double() @ W.double().t()) + b.double() + pre.double()).relu()
+            if ln:
+                ref2 = torch.nn.functional.layer_norm(ref2, (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+            assert rel_err(out2.cpu().numpy(), (ref2 + post.double()).cpu().numpy()) < 1e-5
     assert out.shape == (M, 128)
     if M:
         assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
@@ -212,3 +221,23 @@ def test_rollout_inference_path_matches_autograd_path():
         xi, einf = proc(xl, ei, el)
     assert torch.equal(einf, eg.detach())                       # 2^l scaling is exact in fp32
     assert rel_err(xi.cpu().numpy(), xg.detach().cpu().numpy()) < 1e-5
+
+
+def test_splitk_linear_gradients_match_autograd():
+    """SplitKLinear (batched split-K weight gradient) against torch autograd of F.linear, ragged tail included."""
+    from meshnet.graph_ops import SplitKLinear, linear_rows
+    gen = torch.Generator().manual_seed(3)
+    M = 3 * SplitKLinear.CHUNK + 517
+    x = torch.randn(M, 128, generator=gen).cuda().requires_grad_()
+    W = (torch.randn(128, 128, generator=gen) * 0.1).cuda().requires_grad_()
+    b = torch.randn(128, generator=gen).cuda().requires_grad_()
+    gy = torch.randn(M, 128, generator=gen).cuda()
+    y = linear_rows(x, W, b, min_rows=1024)
+    assert y.grad_fn is not None and "SplitKLinear" in type(y.grad_fn).__name__
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, W, b)]
+    for t in (x, W, b):
+        t.grad = None
+    torch.nn.functional.linear(x.double(), W.double(), b.double()).backward(gy.double())
+    for a, r in zip(got, (x, W, b)):
+        assert rel_err(a.cpu().numpy(), r.grad.cpu().numpy()) < 1e-5
