@@ -195,10 +195,11 @@ def main():
     k7_avg_s = (k7_ms / max(k7_n, 1)) * 1e-3
     achieved = alg_bytes / k7_avg_s / 1e9 if k7_avg_s > 0 else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_k7_pmc_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k7_pmc_traffic.json")))   # newest round's PMC passes
+    if tpaths:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpaths[-1])).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {

@@ -58,13 +58,16 @@ def test_blur_kernel_matches_grouped_conv_and_is_self_adjoint():
         x = torch.rand(n, c, H, W, device="cuda", generator=g, requires_grad=True)
         w1 = torch.tensor([exp(-(k - 5) ** 2 / float(2 * 1.5 ** 2)) for k in range(11)])
         w1 = (w1 / w1.sum()).unsqueeze(1)
-        w = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(c, 1, 11, 11).contiguous().cuda()
-        ref = F.conv2d(x, w, padding=5, groups=c)
+        w = w1.mm(w1.t()).double().unsqueeze(0).unsqueeze(0).expand(c, 1, 11, 11).contiguous()
+        # the reference formulation runs on the CPU in fp64 (the GPU conv would go through MIOpen, whose grouped-conv
+        # backward aborts intermittently on this image: nothing of ours, and not something a parity test should depend on)
+        xc = x.detach().cpu().double().requires_grad_()
+        ref = F.conv2d(xc, w, padding=5, groups=c)
         got = tr.GaussianBlur11.apply(x)
-        assert float((ref - got).abs().max()) < 2e-6
-        wgt = torch.rand_like(ref)
-        g_ref, = torch.autograd.grad((ref * wgt).sum(), x)
+        assert float((ref.detach().float().cuda() - got).abs().max()) < 2e-6
+        wgt = torch.rand_like(got)
+        g_ref, = torch.autograd.grad((ref * wgt.cpu().double()).sum(), xc)
         g_got, = torch.autograd.grad((got * wgt).sum(), x)
-        assert float((g_ref - g_got).abs().max()) < 2e-6
+        assert float((g_ref.float().cuda() - g_got).abs().max()) < 2e-6
     a, b = torch.rand(2, 3, 96, 80, device="cuda", generator=g), torch.rand(2, 3, 96, 80, device="cuda", generator=g)
     assert abs(float(tr.ssim(a, b)) - float(tr.ssim(a.cpu(), b.cpu()))) < 1e-6     # HIP window == torch conv formulation

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run ON THE GPU BOX from the repo root:  bash tools/collect_profiles.sh r01
+# Writes everything under gpurun_out/<tag>/ (merged back by gpurun); tools/summarize_profiles.py then turns it into the
+# committed files under profiles/.  rocprofv3 gets the program itself after `--` and PMC passes carry no trace domains
+# other than --kernel-trace, as the pool requires.
+set -u
+TAG=${1:-r01}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+python3 bench.py                     > "$OUT/bench.json"       2> "$OUT/bench.err"
+python3 bench_gnn.py                 > "$OUT/bench_gnn.json"   2> /dev/null
+python3 bench_train.py               > "$OUT/bench_train.json" 2> /dev/null
+python3 tools/bench_linear128.py     > "$OUT/linear128.txt"    2> /dev/null
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w tools/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate > "$OUT/mfma_rate.txt"
+cd /tmp && export TMPDIR=/tmp
+# same command as the default bench (per-view streams on), so K7's average agrees with bench.py's HIP-event timing
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gnn" -o t -- python3 "$ROOT/bench_gnn.py" --steps 5 --warmup 2 > "$OUT/trace_gnn.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-view-streams > "$OUT/pmc_$c.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_l128_$c" -o p -- python3 "$ROOT/tools/bench_linear128.py" 300000 2 > /dev/null 2>&1
+done
+# keep the merge-back small: drop the per-dispatch traces, keep stats + counters
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
+ls -la "$OUT"
