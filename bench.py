@@ -112,28 +112,25 @@ def main():
     flat_names = ("means3D", "opacities", "shs", "scales", "rotations")
     R_per_view = [0] * V
 
-    # independent views run on separate HIP streams: the compositing kernels of one view leave most SIMDs idle
-    # (their critical path is the deepest 8x8 quadrant), so the views' kernels overlap on the chip
-    streams = [torch.cuda.Stream(device=dev) for _ in range(V)] if args.view_streams else None
+    # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views: every view's
+    # csplat_forward_begin is issued before the first csplat_forward_finish): the compositing kernels of one view leave
+    # most SIMDs idle (their critical path is the deepest 8x8 quadrant), so the views' kernels overlap on the chip
+    from diff_gaussian_rasterization import rasterize_views
+    from csplat.train import l1_loss
 
     def step():
         for p in params.values():
             p.grad = None
-        cur = torch.cuda.current_stream(dev)
-        m2ds, losses = [], []
-        for i in range(V):      # all forwards first (train_step renders every camera, then calls backward once)
-            if streams is not None:
-                streams[i].wait_stream(cur)
-            with torch.cuda.stream(streams[i]) if streams is not None else contextlib.nullcontext():
-                means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
-                color, radii, depth = render(i, means2D)
-                losses.append((color - targets[i]).abs().mean())
-                m2ds.append(means2D)
-        if streams is not None:
-            for st in streams:
-                cur.wait_stream(st)
+        m2ds = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in range(V)]
+        if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
+            outs = rasterize_views(settings, [dict(means3D=params["means3D"], means2D=m2ds[i], opacities=params["opacities"],
+                                                   shs=params["shs"], scales=params["scales"],
+                                                   rotations=params["rotations"]) for i in range(V)])
+        else:
+            outs = [render(i, m2ds[i]) for i in range(V)]
+        losses = [l1_loss(outs[i][0], targets[i]) for i in range(V)]      # fused HIP L1 (loss + gradient in one pass)
         loss = torch.stack(losses).sum()
-        loss.backward()         # each view's rasterizer backward runs on the stream of its forward
+        loss.backward()         # the batched node fans the views' K7/K8 out over the same per-view streams
         m2d_grads = [m.grad for m in m2ds]
         if world > 1:
             flat = torch.cat([params[k].grad.reshape(P, -1) for k in flat_names] + [sum(m2d_grads)], dim=1)
@@ -177,7 +174,7 @@ def main():
             ctx = type("C", (), {"save_for_backward": lambda s, *a: None, "mark_non_differentiable": lambda s, *a: None})()
             dgr._RasterizeGaussians.forward(ctx, params["means3D"], None, params["shs"], None, params["opacities"],
                                             params["scales"], params["rotations"], None, settings[i])
-            R_per_view[i] = ctx.num_rendered
+            R_per_view[i] = ctx.view_state.num_rendered
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -209,7 +206,7 @@ def main():
         "config": {"workload": f"scene_1 synthetic, P={P} Gaussians, {V} cams {W}x{H} per GPU, SH degree 3, "
                                "fwd (K1-K6) + L1 + bwd (K7-K8)" + (", + RCCL all-reduce of flat grads" if world > 1 else ""),
                    "tile_instances_per_view": R_per_view, "parallelism": f"view-parallel x{world}",
-                   "streams_per_gpu": V if streams is not None else 1},
+                   "streams_per_gpu": V if args.view_streams else 1},
         "roofline": {"bound": "hbm", "kernel": "k_render_bwd (K7 compositing backward)", "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),

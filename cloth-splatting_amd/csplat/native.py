@@ -34,6 +34,9 @@ EXPORTS = {
     "csplat_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                             _i, ALLOC_FN, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp),
                             C.POINTER(_vp)]),
+    "csplat_forward_begin": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                                  _i, ALLOC_FN, _vp, _vp, C.POINTER(_i)]),
+    "csplat_forward_finish": (_i, [_i, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
@@ -42,6 +45,8 @@ EXPORTS = {
     "csplat_mesh_transform_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_mesh_transform_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_blur11": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
+    "csplat_l1_scratch_bytes": (_sz, []),
+    "csplat_l1": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "csplat_prof_enable": (_i, [C.c_uint]),
     "csplat_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "csplat_gnn_csr_temp_bytes": (_sz, [_i, _i64]),

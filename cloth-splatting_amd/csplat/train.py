@@ -23,8 +23,12 @@ DEFAULT_PIPE = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=Fa
 
 
 def l1_loss(network_output, gt, mask=None):
+    """utils/loss_utils.py:20-23.  Unmasked fp32 GPU images go through the fused HIP kernel (loss + gradient, one pass)."""
     if mask is not None:
         return torch.abs((network_output - gt) * mask).mean()
+    if network_output.is_cuda and network_output.dtype == torch.float32 and gt.dtype == torch.float32 and \
+            network_output.shape == gt.shape and network_output.numel() > 0:
+        return FusedL1.apply(network_output, gt)
     return torch.abs(network_output - gt).mean()
 
 
@@ -43,6 +47,30 @@ def _taps(window_size=11, sigma=1.5):
         g = g / g.sum()
         _TAPS[window_size] = (_C.c_float * window_size)(*[float(v) for v in g])
     return _TAPS[window_size]
+
+
+class FusedL1(torch.autograd.Function):
+    """mean |a - b| through csplat_l1: the forward launch also writes sign(a - b) / n, the backward scales it."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _n.require_cuda(a)
+        a, b = a.contiguous(), b.contiguous()
+        need = a.requires_grad or b.requires_grad
+        grad = torch.empty_like(a) if need else None
+        scratch = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=a.device)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _n.check(_n.lib.csplat_l1(_n.stream_handle(a.device), a.numel(), _n.ptr(a), _n.ptr(b), _n.ptr(scratch), _n.ptr(loss),
+                                      _n.ptr(grad)), "csplat_l1")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = ctx.grad * g if ctx.needs_input_grad[0] else None
+        gb = -(ctx.grad * g) if ctx.needs_input_grad[1] else None
+        return ga, gb
 
 
 class GaussianBlur11(torch.autograd.Function):

@@ -40,6 +40,56 @@ __global__ __launch_bounds__(256) void k_blur11(int H, int W, Taps taps, const f
         }
     }
 }
+
+// ---- fused L1 loss: mean |a - b| and its gradient sign(a - b) / n in ONE pass (utils/loss_utils.py:20-23 is three
+// elementwise launches forward and three backward).  Deterministic: workgroup partials are summed in index order by
+// whichever workgroup finishes last (ticket counter), not with float atomics.
+constexpr int L1_BLOCKS = 256, L1_THREADS = 256;   // few workgroups: the ticket atomics serialise at one L2 address (~30 ns each)
+__global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
+                                                    float inv_n, float *__restrict__ partial, unsigned *__restrict__ ticket,
+                                                    float *__restrict__ loss, float *__restrict__ grad) {
+    __shared__ float s_red[L1_THREADS / 64];
+    __shared__ bool s_last;
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * L1_THREADS) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        if (grad) {
+            auto sg = [&](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
+            reinterpret_cast<float4 *>(grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+        }
+    }
+    if (blockIdx.x == 0) {   // tail (n not a multiple of 4)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += L1_THREADS) {
+            const float d = a[i] - b[i];
+            acc += fabsf(d);
+            if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+        __threadfence();
+        float t = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += L1_THREADS) t += __builtin_nontemporal_load(partial + i);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) { *loss = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_n; *ticket = 0u; }
+    }
+}
 }  // namespace
 
 extern "C" int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *in, float *out) {
@@ -50,6 +100,20 @@ extern "C" int csplat_blur11(void *stream, int64_t n_images, int H, int W, const
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
     k_blur11<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, in, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t csplat_l1_scratch_bytes(void) { return (size_t)(L1_BLOCKS + 1) * 4; }
+
+extern "C" int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad) {
+    CSPLAT_REQUIRE(n > 0 && a && b && scratch && loss, "csplat_l1: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad) & 15u) == 0, "csplat_l1: operands must be 16-byte aligned");
+    float *partial = (float *)scratch;
+    unsigned *ticket = (unsigned *)scratch + L1_BLOCKS;     // zero on entry; the kernel leaves it zero
+    const int64_t work = (n / 4 + L1_THREADS - 1) / L1_THREADS;
+    const int grid = (int)(work < 1 ? 1 : (work > L1_BLOCKS ? L1_BLOCKS : work));
+    k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, ticket, loss, grad);
     LAUNCH_CHECK();
     return 0;
 }

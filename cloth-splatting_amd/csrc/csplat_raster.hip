@@ -1456,15 +1456,41 @@ int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(
 int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[5]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
 int csplat_image_layout(int W, int H, size_t *o3) { size_t off[5]; image_offsets(W, H, off); o3[0] = off[0]; o3[1] = off[1]; o3[2] = off[2]; return 0; }
 
-int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
-                   const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
-                   float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
-                   const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
-                   csplat_alloc_fn alloc, void *alloc_ctx, float *out_color, float *out_depth, int32_t *radii,
-                   int *num_rendered, void **geom_out, void **binning_out, void **image_out) {
+// ---- two-phase forward.  begin: K1 + the counting half of the binning, everything that does not need num_rendered;
+// finish: reads num_rendered (mailbox poll), allocates the R-sized chunks, K3..K6.  A caller with several independent
+// views issues every begin (each on its own stream) before the first finish, so the one host round trip per view and
+// the under-filled compositing kernels of different views overlap.  csplat_forward = begin + finish.
+struct FwdTicket {
+    bool used = false;
+    hipStream_t s = nullptr;
+    int P = 0, W = 0, H = 0, tiles = 0, nb = 0;
+    bool can_bucket = false, use_mail = false;
+    uint32_t tag = 0;
+    volatile uint32_t *mb_host = nullptr;
+    Cam cam;
+    Geom g;
+    void *gbase = nullptr, *ibase = nullptr;
+    int2 *ranges = nullptr;
+    uint32_t *n_contrib = nullptr, *info = nullptr, *table = nullptr;
+    float *final_T = nullptr;
+    const float *bg = nullptr;
+    int32_t *radii = nullptr;
+    csplat_alloc_fn alloc = nullptr;
+    void *alloc_ctx = nullptr;
+};
+constexpr int MAX_TICKETS = 64;
+static FwdTicket g_tickets[MAX_TICKETS];
+static std::mutex g_ticket_mu;
+
+int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                         const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                         float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
+                         const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                         csplat_alloc_fn alloc, void *alloc_ctx, int32_t *radii, int *ticket_out) {
     hipStream_t s = (hipStream_t)stream;
     (void)prefiltered;
     CSPLAT_REQUIRE(P >= 0 && W > 0 && H > 0, "csplat_forward: bad sizes");
+    CSPLAT_REQUIRE(ticket_out != nullptr, "csplat_forward_begin: ticket_out missing");
     // (an empty input, P == 0, legitimately arrives with NULL data pointers)
     CSPLAT_REQUIRE(P == 0 || (shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
     CSPLAT_REQUIRE(P == 0 || (cov3D_precomp != nullptr) != (scales != nullptr && rotations != nullptr),
@@ -1488,7 +1514,6 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     const int nb = cdiv(P > 0 ? P : 1, BUCKET_G);
     const bool can_bucket = tiles <= BUCKET_TILES && !(g_debug_flags & 2u);
 
-    uint32_t host_info[2] = {0, 0};   // R, longest tile list
     if (!can_bucket) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
     if (P > 0) {
         ProfScope ps(PROF_K1, s);
@@ -1504,6 +1529,9 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         LAUNCH_CHECK();
     }
     uint32_t *table = nullptr;
+    bool use_mail_ = false;
+    uint32_t tag_ = 0;
+    volatile uint32_t *mb_host_ = nullptr;
     if (can_bucket) {
         table = (uint32_t *)alloc(alloc_ctx, CSPLAT_CHUNK_TABLE, bucket_table_bytes(P, tiles));
         CSPLAT_REQUIRE(table, "allocator returned NULL");
@@ -1530,6 +1558,51 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
         }
         k_tile_scan<<<1, 1024, 0, s>>>(tiles, tile_cnt, ranges, info, mb_dev, tag);
         LAUNCH_CHECK();
+        use_mail_ = use_mail; tag_ = tag; mb_host_ = mb_host;
+    }   // can_bucket
+    int tk = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        for (int i = 0; i < MAX_TICKETS && tk < 0; i++)
+            if (!g_tickets[i].used) tk = i;
+        if (tk >= 0) g_tickets[tk].used = true;
+    }
+    CSPLAT_REQUIRE(tk >= 0, "csplat_forward_begin: more than 64 forwards begun and not finished");
+    FwdTicket &t = g_tickets[tk];
+    t.s = s; t.P = P; t.W = W; t.H = H; t.tiles = tiles; t.nb = nb; t.can_bucket = can_bucket; t.use_mail = use_mail_;
+    t.tag = tag_; t.mb_host = mb_host_; t.cam = cam; t.g = g; t.gbase = gbase; t.ibase = ibase; t.ranges = ranges;
+    t.n_contrib = n_contrib; t.info = info; t.table = table; t.final_T = final_T; t.bg = bg; t.radii = radii;
+    t.alloc = alloc; t.alloc_ctx = alloc_ctx;
+    *ticket_out = tk;
+    return 0;
+}
+
+int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *num_rendered, void **geom_out,
+                          void **binning_out, void **image_out) {
+    CSPLAT_REQUIRE(ticket >= 0 && ticket < MAX_TICKETS && g_tickets[ticket].used, "csplat_forward_finish: unknown ticket");
+    const FwdTicket t = g_tickets[ticket];
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        g_tickets[ticket].used = false;   // released whatever happens below
+    }
+    hipStream_t s = t.s;
+    const int P = t.P, W = t.W, H = t.H, tiles = t.tiles, nb = t.nb;
+    const bool can_bucket = t.can_bucket;
+    const Cam cam = t.cam;
+    const Geom g = t.g;
+    void *gbase = t.gbase, *ibase = t.ibase;
+    int2 *ranges = t.ranges;
+    uint32_t *n_contrib = t.n_contrib, *info = t.info, *table = t.table;
+    float *final_T = t.final_T;
+    const float *bg = t.bg;
+    int32_t *radii = t.radii;
+    csplat_alloc_fn alloc = t.alloc;
+    void *alloc_ctx = t.alloc_ctx;
+    uint32_t host_info[2] = {0, 0};   // R, longest tile list
+    if (can_bucket) {
+        const bool use_mail = t.use_mail;
+        const uint32_t tag = t.tag;
+        volatile uint32_t *mb_host = t.mb_host;
         bool got = false;
         if (use_mail) {   // spin on the tag (bounded: fall back to a stream synchronise after 2 s)
             const auto t0 = std::chrono::steady_clock::now();
@@ -1633,6 +1706,20 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
     return 0;
+}
+
+int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                   const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                   float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
+                   const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                   csplat_alloc_fn alloc, void *alloc_ctx, float *out_color, float *out_depth, int32_t *radii,
+                   int *num_rendered, void **geom_out, void **binning_out, void **image_out) {
+    int ticket = -1;
+    if (int rc = csplat_forward_begin(stream, P, D, M, bg, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                      rotations, cov3D_precomp, view, proj, campos, tanfovx, tanfovy, prefiltered, alloc,
+                                      alloc_ctx, radii, &ticket))
+        return rc;
+    return csplat_forward_finish(ticket, out_color, out_depth, num_rendered, geom_out, binning_out, image_out);
 }
 
 int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,

@@ -7,7 +7,8 @@ Mirrors the interface the reference binds at gaussian_renderer/__init__.py:16 an
                                         scales=None, rotations=None, cov3D_precomp=None) -> (color, radii, depth)
 Gradients are delivered for means3D, means2D (NDC-space screen gradient used by densification,
 scene_reconstruction/train_utils.py:290-292), shs, colors_precomp, opacities, scales, rotations, cov3D_precomp.
-The depth image carries no gradient (as upstream).  All compute is in libcsplat.so (csplat_forward / csplat_backward).
+The depth image carries no gradient (as upstream).  All compute is in libcsplat.so (csplat_forward_begin / _finish / csplat_backward).
+`rasterize_views` renders several independent views in one call, one HIP stream per view.
 """
 import ctypes as C
 from typing import NamedTuple
@@ -47,55 +48,67 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
-class _RasterizeGaussians(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+class _View:
+    """Everything one view's forward produces and its backward needs (host side of csplat_forward_begin / _finish)."""
+
+    def __init__(self, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
         _n.require_cuda(means3D)
-        dev = means3D.device
-        P = int(means3D.shape[0])
-        H, W = int(rs.image_height), int(rs.image_width)
-        means3D = _f32c(means3D, dev); opacities = _f32c(opacities, dev)
-        sh = _f32c(sh, dev)
-        colors_precomp = _f32c(colors_precomp, dev)
-        scales = _f32c(scales, dev)
-        rotations = _f32c(rotations, dev)
-        cov3Ds_precomp = _f32c(cov3Ds_precomp, dev)
-        bg = _f32c(rs.bg, dev); view = _f32c(rs.viewmatrix, dev); proj = _f32c(rs.projmatrix, dev)
-        campos = _f32c(rs.campos, dev)
-        M = int(sh.shape[1]) if sh is not None else 0
-        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-        radii = torch.empty(P, dtype=torch.int32, device=dev)
-        alloc = _n.ChunkAllocator(dev)
+        dev = self.dev = means3D.device
+        self.rs = rs
+        self.P = int(means3D.shape[0])
+        self.H, self.W = int(rs.image_height), int(rs.image_width)
+        self.means3D = _f32c(means3D, dev); self.opacities = _f32c(opacities, dev)
+        self.sh = _f32c(sh, dev)
+        self.colors_precomp = _f32c(colors_precomp, dev)
+        self.scales = _f32c(scales, dev)
+        self.rotations = _f32c(rotations, dev)
+        self.cov3Ds_precomp = _f32c(cov3Ds_precomp, dev)
+        self.bg = _f32c(rs.bg, dev); self.view = _f32c(rs.viewmatrix, dev); self.proj = _f32c(rs.projmatrix, dev)
+        self.campos = _f32c(rs.campos, dev)
+        self.M = int(self.sh.shape[1]) if self.sh is not None else 0
+        self.ticket = None
+
+    def inputs(self):
+        return [t for t in (self.means3D, self.sh, self.colors_precomp, self.opacities, self.scales, self.rotations,
+                            self.cov3Ds_precomp, self.bg, self.view, self.proj, self.campos) if t is not None]
+
+    def begin(self):
+        """K1 + the counting half of the binning on the CURRENT stream; nothing here waits for the GPU."""
+        dev, rs = self.dev, self.rs
+        self.color = torch.empty(3, self.H, self.W, dtype=torch.float32, device=dev)
+        self.depth = torch.empty(1, self.H, self.W, dtype=torch.float32, device=dev)
+        self.radii = torch.empty(self.P, dtype=torch.int32, device=dev)
+        self.alloc = _n.ChunkAllocator(dev)
+        tk = C.c_int(-1)
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_forward_begin(
+                _n.stream_handle(dev), self.P, int(rs.sh_degree), self.M, _n.ptr(self.bg), self.W, self.H,
+                _n.ptr(self.means3D), _n.ptr(self.sh), _n.ptr(self.colors_precomp), _n.ptr(self.opacities),
+                _n.ptr(self.scales), float(rs.scale_modifier), _n.ptr(self.rotations), _n.ptr(self.cov3Ds_precomp),
+                _n.ptr(self.view), _n.ptr(self.proj), _n.ptr(self.campos), float(rs.tanfovx), float(rs.tanfovy),
+                int(bool(rs.prefiltered)), self.alloc.cb, None, _n.ptr(self.radii), C.byref(tk))
+        _n.check(rc, "csplat_forward_begin")
+        self.ticket = int(tk.value)
+
+    def finish(self):
+        """reads num_rendered (the one host round trip), allocates the R-sized chunks, K3..K6 on the begin() stream"""
         R = C.c_int(0)
         geom, binning, image = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        with torch.cuda.device(dev):
-            rc = _n.lib.csplat_forward(
-                _n.stream_handle(dev), P, int(rs.sh_degree), M, _n.ptr(bg), W, H, _n.ptr(means3D), _n.ptr(sh),
-                _n.ptr(colors_precomp), _n.ptr(opacities), _n.ptr(scales), float(rs.scale_modifier), _n.ptr(rotations),
-                _n.ptr(cov3Ds_precomp), _n.ptr(view), _n.ptr(proj), _n.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                int(bool(rs.prefiltered)), alloc.cb, None, _n.ptr(color), _n.ptr(depth), _n.ptr(radii), C.byref(R),
-                C.byref(geom), C.byref(binning), C.byref(image))
-        _n.check(rc, "csplat_forward")
-        ctx.rs = rs
-        ctx.num_rendered = int(R.value)
-        ctx.M = M
-        ctx.chunks = (alloc.chunks[_n_GEOM], alloc.chunks[_n_BINNING], alloc.chunks[_n_IMAGE])
-        ctx.consts = (bg, view, proj, campos)
-        ctx.save_for_backward(means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color)
-        ctx.mark_non_differentiable(radii, depth)
-        return color, radii, depth
+        with torch.cuda.device(self.dev):
+            rc = _n.lib.csplat_forward_finish(self.ticket, _n.ptr(self.color), _n.ptr(self.depth), C.byref(R),
+                                              C.byref(geom), C.byref(binning), C.byref(image))
+        self.ticket = None
+        _n.check(rc, "csplat_forward_finish")
+        self.num_rendered = int(R.value)
+        ch = self.alloc.chunks
+        self.chunks = (ch[_n_GEOM], ch[_n_BINNING], ch[_n_IMAGE])
+        self.alloc = None     # TEMP / TABLE die here (stream-ordered reuse)
 
-    @staticmethod
-    def backward(ctx, grad_color, _grad_radii, _grad_depth):
-        means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color = ctx.saved_tensors
-        rs = ctx.rs
-        dev = means3D.device
-        P = int(means3D.shape[0])
-        H, W = int(rs.image_height), int(rs.image_width)
-        M = ctx.M
-        bg, view, proj, campos = ctx.consts
-        geom, binning, image = ctx.chunks
+    def backward(self, grad_color, saved):
+        """K7 + K8 on the CURRENT stream; returns the per-input gradients in the Function's argument order."""
+        means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color = saved
+        rs, dev, P, M = self.rs, self.dev, self.P, self.M
+        geom, binning, image = self.chunks
         grad_color = _f32c(grad_color, dev)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         d_mean2D, d_conic, d_opac, d_color = new(P, 3), new(P, 4), new(P, 1), new(P, 3)
@@ -103,21 +116,148 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_sh = new(P, M, 3) if sh is not None else None
         d_scale = new(P, 3) if scales is not None else None
         d_rot = new(P, 4) if rotations is not None else None
-        scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, ctx.num_rendered)), 256), dtype=torch.uint8,
+        scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, self.num_rendered)), 256), dtype=torch.uint8,
                               device=dev)
         with torch.cuda.device(dev):
             rc = _n.lib.csplat_backward(
-                _n.stream_handle(dev), P, int(rs.sh_degree), M, ctx.num_rendered, _n.ptr(bg), W, H, _n.ptr(means3D),
-                _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(scales), float(rs.scale_modifier), _n.ptr(rotations),
-                _n.ptr(cov3Ds_precomp), _n.ptr(view), _n.ptr(proj), _n.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image), _n.ptr(color), _n.ptr(grad_color),
-                _n.ptr(scratch),
-                _n.ptr(d_mean2D),
-                _n.ptr(d_conic), _n.ptr(d_opac), _n.ptr(d_color), _n.ptr(d_mean3D), _n.ptr(d_cov3D), _n.ptr(d_sh),
-                _n.ptr(d_scale), _n.ptr(d_rot))
+                _n.stream_handle(dev), P, int(rs.sh_degree), M, self.num_rendered, _n.ptr(self.bg), self.W, self.H,
+                _n.ptr(means3D), _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(scales), float(rs.scale_modifier),
+                _n.ptr(rotations), _n.ptr(cov3Ds_precomp), _n.ptr(self.view), _n.ptr(self.proj), _n.ptr(self.campos),
+                float(rs.tanfovx), float(rs.tanfovy), _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image),
+                _n.ptr(color), _n.ptr(grad_color), _n.ptr(scratch), _n.ptr(d_mean2D), _n.ptr(d_conic), _n.ptr(d_opac),
+                _n.ptr(d_color), _n.ptr(d_mean3D), _n.ptr(d_cov3D), _n.ptr(d_sh), _n.ptr(d_scale), _n.ptr(d_rot))
         _n.check(rc, "csplat_backward")
         return (d_mean3D, d_mean2D, d_sh, d_color if colors_precomp is not None else None, d_opac, d_scale, d_rot,
-                d_cov3D if cov3Ds_precomp is not None else None, None)
+                d_cov3D if cov3Ds_precomp is not None else None)
+
+    def saved(self):
+        return (self.means3D, self.sh, self.colors_precomp, self.scales, self.rotations, self.cov3Ds_precomp, self.radii,
+                self.color)
+
+    def drop_inputs(self):
+        """the tensors travel through ctx.save_for_backward; keep only constants and chunks here"""
+        self.means3D = self.sh = self.colors_precomp = self.opacities = self.scales = self.rotations = None
+        self.cov3Ds_precomp = self.radii = self.color = self.depth = None
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+        v = _View(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs)
+        v.begin()
+        v.finish()
+        color, radii, depth = v.color, v.radii, v.depth
+        ctx.save_for_backward(*v.saved())
+        v.drop_inputs()
+        ctx.view_state = v
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, _grad_depth):
+        return ctx.view_state.backward(grad_color, ctx.saved_tensors) + (None,)
+
+
+_side_streams = {}
+
+
+def _view_streams(dev, n, main):
+    """the caller's stream + n-1 side streams: ROCm maps streams onto 4 hardware queues per device by default, and a
+    fifth stream shares a queue with (= is serialised behind) another one"""
+    pool = _side_streams.setdefault((dev.type, dev.index), [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    return [main] + pool[:n - 1]
+
+
+class _RasterizeGaussiansBatch(torch.autograd.Function):
+    """V independent views in one autograd node.  Every view runs on its own HIP stream; all csplat_forward_begin calls
+    are issued before the first csplat_forward_finish, so the per-view host round trip for num_rendered and the
+    compositing kernels (a single view's K6 keeps ~1000 wavefronts busy on a 256-CU part) overlap across views.
+    Results are bit-identical to V calls of _RasterizeGaussians (same kernels, same per-view order)."""
+
+    NIN = 8
+
+    @staticmethod
+    def forward(ctx, settings, *flat):
+        V, n = len(settings), _RasterizeGaussiansBatch.NIN
+        assert len(flat) == V * n
+        views = []
+        for i in range(V):
+            means3D, _means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds = flat[i * n:(i + 1) * n]
+            views.append(_View(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds, settings[i]))
+        dev = views[0].dev
+        main = torch.cuda.current_stream(dev)
+        streams = _view_streams(dev, V, main)
+        for v, st in zip(views, streams):
+            if st is not main:
+                st.wait_stream(main)
+                for t in v.inputs():
+                    t.record_stream(st)
+            with torch.cuda.stream(st):
+                v.begin()
+        for v, st in zip(views, streams):
+            with torch.cuda.stream(st):
+                v.finish()
+        outs, saved = [], []
+        for v, st in zip(views, streams):
+            if st is not main:
+                main.wait_stream(st)
+                for t in (v.color, v.radii, v.depth):
+                    t.record_stream(main)
+            outs += [v.color, v.radii, v.depth]
+            saved += list(v.saved())
+            ctx.mark_non_differentiable(v.radii, v.depth)
+        ctx.nsaved = len(views[0].saved())
+        ctx.save_for_backward(*saved)
+        for v in views:
+            v.drop_inputs()
+        ctx.views = views
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        views, k = ctx.views, ctx.nsaved
+        dev = views[0].dev
+        main = torch.cuda.current_stream(dev)
+        streams = _view_streams(dev, len(views), main)
+        out = [None] * (len(views) * _RasterizeGaussiansBatch.NIN)
+        # side streams first, the caller's stream last: its K7 then does not delay the launches of the others
+        for i in list(range(1, len(views))) + [0]:
+            v, st, g = views[i], streams[i], grads[3 * i]
+            if g is None:
+                continue
+            saved = ctx.saved_tensors[i * k:(i + 1) * k]
+            if st is not main:
+                st.wait_stream(main)
+                g.record_stream(st)
+            with torch.cuda.stream(st):
+                gi = v.backward(g, saved)
+            if st is not main:
+                for t in gi:
+                    if t is not None:
+                        t.record_stream(main)
+            out[i * _RasterizeGaussiansBatch.NIN:(i + 1) * _RasterizeGaussiansBatch.NIN] = list(gi)
+        for st in streams[1:]:
+            main.wait_stream(st)
+        return (None,) + tuple(out)
+
+
+def rasterize_views(settings, inputs):
+    """Batched entry (no counterpart upstream, where cameras are rendered one by one in a Python loop --
+    scene_reconstruction/train_utils.py:204-260): `settings` a list of GaussianRasterizationSettings, `inputs` a list of
+    dicts with the keyword names of GaussianRasterizer.forward.  Returns a list of (color, radii, depth)."""
+    flat = []
+    for kw in inputs:
+        shs, cp = kw.get("shs"), kw.get("colors_precomp")
+        sc, ro, cov = kw.get("scales"), kw.get("rotations"), kw.get("cov3D_precomp")
+        if (shs is None) == (cp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((sc is None or ro is None) and cov is None) or ((sc is not None or ro is not None) and cov is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        flat += [kw["means3D"], kw["means2D"], shs, cp, kw["opacities"], sc, ro, cov]
+    res = _RasterizeGaussiansBatch.apply(tuple(settings), *flat)
+    return [tuple(res[3 * i:3 * i + 3]) for i in range(len(settings))]
 
 
 _n_GEOM, _n_BINNING, _n_IMAGE = 0, 1, 2

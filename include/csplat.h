@@ -88,6 +88,21 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
                    csplat_alloc_fn alloc, void *alloc_ctx, float *out_color, float *out_depth, int32_t *radii,
                    int *num_rendered, void **geom, void **binning, void **image);
 
+/* Two-phase form of csplat_forward for callers with several independent views in flight (new; upstream renders cameras one
+ * by one: /root/reference/scene_reconstruction/train_utils.py:204-260).  _begin enqueues K1 and the counting half of the
+ * binning on `stream` and returns without waiting; _finish (same thread or another) reads num_rendered -- the path's only
+ * host round trip --, requests the R-sized chunks from the allocator given to _begin and enqueues K3..K6 on the same
+ * stream.  Issue every _begin before the first _finish and the round trips and the compositing kernels of the views
+ * overlap.  At most 64 tickets may be open; a ticket is released by _finish whatever it returns.
+ * csplat_forward(...) == csplat_forward_begin(...) followed by csplat_forward_finish(...). */
+int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                         const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                         float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
+                         const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                         csplat_alloc_fn alloc, void *alloc_ctx, int32_t *radii, int *ticket_out);
+int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *num_rendered, void **geom,
+                          void **binning, void **image);
+
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
  * out_color is the forward's colour image; dL_dpix[3][H][W] its gradient (the depth image carries no gradient,
  * as upstream).
@@ -112,6 +127,13 @@ int csplat_dist2(void *stream, int P, const float *xyz, float *out);
  * the n_images [H][W] planes.  taps11 is a HOST pointer to the 11 normalised window weights.  Self-adjoint: the backward
  * of the operator is the operator.  (SURVEY.md 8(f) "next" row N2.) */
 int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *in, float *out);
+
+/* l1_loss of /root/reference/utils/loss_utils.py:20-23 (unmasked case) with its gradient in the same pass:
+ *   *loss = mean_i |a[i] - b[i]|,   grad[i] = sign(a[i] - b[i]) / n   (grad may be NULL).
+ * scratch: csplat_l1_scratch_bytes() bytes whose last word is zero on entry (the kernel restores it), not shared between
+ * calls that may run concurrently.  Deterministic (fixed summation order). */
+size_t csplat_l1_scratch_bytes(void);
+int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad);
 
 /* Fused mesh -> Gaussian transform (SURVEY.md 8(f) "next" row N1): MultiGaussianMesh.get_xyz + get_rotation,
  * scene_reconstruction/gaussian_mesh.py:151-188.  face_vertex_ids[P][3] (int64, device) = mesh.face[:, face_ids].T.

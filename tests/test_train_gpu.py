@@ -71,3 +71,24 @@ def test_blur_kernel_matches_grouped_conv_and_is_self_adjoint():
         assert float((g_ref.float().cuda() - g_got).abs().max()) < 2e-6
     a, b = torch.rand(2, 3, 96, 80, device="cuda", generator=g), torch.rand(2, 3, 96, 80, device="cuda", generator=g)
     assert abs(float(tr.ssim(a, b)) - float(tr.ssim(a.cpu(), b.cpu()))) < 1e-6     # HIP window == torch conv formulation
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 53), (1,), (3, 800, 800), (7,)])
+def test_fused_l1_matches_torch(shape):
+    """csplat_l1 == torch.abs(a - b).mean() (utils/loss_utils.py:20-23) and its autograd gradient, ragged sizes, zeros
+    (sign(0) = 0) and an upstream scale included; value to 1e-6 relative (different summation tree), gradient exact."""
+    from csplat import train as tr
+    g = torch.Generator(device="cuda").manual_seed(len(shape) + shape[0])
+    a = torch.rand(*shape, device="cuda", generator=g, requires_grad=True)
+    b = torch.rand(*shape, device="cuda", generator=g)
+    with torch.no_grad():
+        b.view(-1)[0] = a.view(-1)[0]          # an exact tie
+    l1 = tr.l1_loss(a, b)
+    (2.5 * l1).backward()
+    g_fused, a.grad = a.grad.clone(), None
+    ref = torch.abs(a - b).mean()
+    (2.5 * ref).backward()
+    assert abs(float(l1) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-12
+    assert torch.equal(g_fused, a.grad)
+    l2 = tr.l1_loss(a.detach(), b)              # no-grad path, and the scratch word was restored
+    assert float(l2) == float(l1)

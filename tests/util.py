@@ -121,6 +121,7 @@ def gpu_forward_raw(case, inputs=None, settings=None, **over):
             ctx, inp["means3D"], inp["means2D"], args["sh"], args["colors_precomp"], inp["opacities"], args["scales"],
             args["rotations"], args["cov3Ds_precomp"], rs)
     torch.cuda.synchronize()
-    state = gpu_chunks(ctx.chunks, case["P"], case["W"], case["H"], ctx.num_rendered)
-    state["R"] = ctx.num_rendered
+    vs = ctx.view_state
+    state = gpu_chunks(vs.chunks, case["P"], case["W"], case["H"], vs.num_rendered)
+    state["R"] = vs.num_rendered
     return color, radii, depth, state
