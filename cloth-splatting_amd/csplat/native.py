@@ -37,6 +37,8 @@ EXPORTS = {
     "csplat_forward_begin": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                   _i, ALLOC_FN, _vp, _vp, C.POINTER(_i)]),
     "csplat_forward_finish": (_i, [_i, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "csplat_forward_views": (_i, [_i, _vp, ALLOC_FN, _vp]),
+    "csplat_backward_views": (_i, [_i, _vp, _vp]),
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
@@ -91,6 +93,21 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise CsplatError("csplat: expected a GPU (HIP) tensor; this path has no CPU fallback")
+
+
+class CsplatView(C.Structure):
+    """mirror of `csplat_view` (include/csplat.h)"""
+    _fields_ = ([("stream", _vp)] + [(n, _i) for n in ("P", "D", "M", "W", "H", "prefiltered")] +
+                [(n, _f) for n in ("scale_modifier", "tanfovx", "tanfovy")] +
+                [(n, _vp) for n in ("bg", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
+                                    "cov3D_precomp", "view", "proj", "campos", "alloc_ctx", "out_color", "out_depth", "radii")] +
+                [("num_rendered", _i)] + [(n, _vp) for n in ("geom", "binning", "image", "dL_dpix", "scratch")] +
+                [("accmask", C.c_uint)] +
+                [(n, _vp) for n in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D",
+                                    "dL_dsh", "dL_dscale", "dL_drot")])
+
+
+ACC_OPACITY, ACC_COLOR, ACC_MEAN3D, ACC_COV3D, ACC_SH, ACC_SCALE, ACC_ROT = 1, 2, 4, 8, 16, 32, 64
 
 
 class ChunkAllocator:

@@ -1125,7 +1125,11 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
                                                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolor,
                                                          float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D,
                                                          float *__restrict__ dL_dsh, float *__restrict__ dL_dscale,
-                                                         float *__restrict__ dL_drot) {
+                                                         float *__restrict__ dL_drot, unsigned accmask) {
+    // accmask (CSPLAT_ACC_*): outputs that are ADDED to instead of written -- several views of one step share the
+    // gradient buffer of a shared parameter (csplat_backward_views), which replaces autograd's per-view temporaries
+    // and its V-1 summation launches per parameter.
+#define PUT(ptr, idx, val, bit) do { float *p_ = (ptr) + (idx); *p_ = (accmask & (bit)) ? *p_ + (val) : (val); } while (0)
     // STAGE: SH coefficients in / SH gradients out go through LDS so that HBM sees contiguous 16-byte accesses (the
     // lane-per-Gaussian 4-byte stores at a 192-byte stride wrote 2.7x the algorithmic bytes)
     __shared__ float s_in[STAGE ? NT * SH_ROW : 1];
@@ -1144,19 +1148,20 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
     for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
-    dL_dopacity[i] = a9[5];
-    dL_dcolor[3 * i] = a9[6]; dL_dcolor[3 * i + 1] = a9[7]; dL_dcolor[3 * i + 2] = a9[8];
+    PUT(dL_dopacity, i, a9[5], CSPLAT_ACC_OPACITY);
+    PUT(dL_dcolor, 3 * i, a9[6], CSPLAT_ACC_COLOR); PUT(dL_dcolor, 3 * i + 1, a9[7], CSPLAT_ACC_COLOR);
+    PUT(dL_dcolor, 3 * i + 2, a9[8], CSPLAT_ACC_COLOR);
 
     float dmean[3] = {0.f, 0.f, 0.f};
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!vis) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = 0.f;
+        for (int k = 0; k < 3; k++) PUT(dL_dmean3D, 3 * i + k, 0.f, CSPLAT_ACC_MEAN3D);
 #pragma unroll
-        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
+        for (int k = 0; k < 6; k++) PUT(dL_dcov3D, 6 * i + k, 0.f, CSPLAT_ACC_COV3D);
         if (dL_dsh && !STAGE) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
-        if (dL_dscale) { dL_dscale[3 * i] = 0.f; dL_dscale[3 * i + 1] = 0.f; dL_dscale[3 * i + 2] = 0.f; }
-        if (dL_drot) { dL_drot[4 * i] = 0.f; dL_drot[4 * i + 1] = 0.f; dL_drot[4 * i + 2] = 0.f; dL_drot[4 * i + 3] = 0.f; }
+        if (dL_dscale) for (int k = 0; k < 3; k++) PUT(dL_dscale, 3 * i + k, 0.f, CSPLAT_ACC_SCALE);
+        if (dL_drot) for (int k = 0; k < 4; k++) PUT(dL_drot, 4 * i + k, 0.f, CSPLAT_ACC_ROT);
     } else {
     const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
     const float *view = cam.view, *proj = cam.proj;
@@ -1285,9 +1290,9 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
         dmean[2] += (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * invsum32;
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = dmean[k];
+    for (int k = 0; k < 3; k++) PUT(dL_dmean3D, 3 * i + k, dmean[k], CSPLAT_ACC_MEAN3D);
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = g6[k];
+    for (int k = 0; k < 6; k++) PUT(dL_dcov3D, 6 * i + k, g6[k], CSPLAT_ACC_COV3D);
 
     // ---- cov3D -> scale, quaternion
     if (!use_precomp_cov && dL_dscale && dL_drot) {
@@ -1305,20 +1310,22 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
             for (int k = 0; k < 3; k++)
                 dA[r][k] = 2.f * (dS[r][0] * R[0][k] * s[k] + dS[r][1] * R[1][k] * s[k] + dS[r][2] * R[2][k] * s[k]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) dL_dscale[3 * i + k] = dA[0][k] * R[0][k] + dA[1][k] * R[1][k] + dA[2][k] * R[2][k];
+        for (int k = 0; k < 3; k++) PUT(dL_dscale, 3 * i + k, dA[0][k] * R[0][k] + dA[1][k] * R[1][k] + dA[2][k] * R[2][k], CSPLAT_ACC_SCALE);
         float dR[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int k = 0; k < 3; k++) dR[r][k] = dA[r][k] * s[k];
         const float qr = q[0], qx = q[1], qy = q[2], qz = q[3];
-        dL_drot[4 * i + 0] = 2.f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
-        dL_drot[4 * i + 1] = 2.f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.f * qx * dR[1][1] - qr * dR[1][2] +
+        const float dq0 = 2.f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        const float dq1 = 2.f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.f * qx * dR[1][1] - qr * dR[1][2] +
                                     qz * dR[2][0] + qr * dR[2][1] - 2.f * qx * dR[2][2]);
-        dL_drot[4 * i + 2] = 2.f * (-2.f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
+        const float dq2 = 2.f * (-2.f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
                                     qr * dR[2][0] + qz * dR[2][1] - 2.f * qy * dR[2][2]);
-        dL_drot[4 * i + 3] = 2.f * (-2.f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.f * qz * dR[1][1] +
+        const float dq3 = 2.f * (-2.f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.f * qz * dR[1][1] +
                                     qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        PUT(dL_drot, 4 * i, dq0, CSPLAT_ACC_ROT); PUT(dL_drot, 4 * i + 1, dq1, CSPLAT_ACC_ROT);
+        PUT(dL_drot, 4 * i + 2, dq2, CSPLAT_ACC_ROT); PUT(dL_drot, 4 * i + 3, dq3, CSPLAT_ACC_ROT);
     }
     }   // visible
     }   // i < P
@@ -1328,9 +1335,12 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
         for (int t = threadIdx.x; t < rows * 12; t += NT) {
             const int row = t / 12, c = (t - row * 12) * 4;
             const float *sp = s_out + row * SH_ROW + c;
-            dst4[t] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            if (accmask & CSPLAT_ACC_SH) { const float4 u = dst4[t]; o.x += u.x; o.y += u.y; o.z += u.z; o.w += u.w; }
+            dst4[t] = o;
         }
     }
+#undef PUT
 }
 
 // ------------------------------------------------------------------------------------------- layouts
@@ -1437,6 +1447,18 @@ int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n
     int b = 0;
     while ((1u << b) < n && b < 31) b++;
     return b == 0 ? 1 : b;
+}
+
+// events for cross-stream ordering (no timing): a ring; a wait captures the record that precedes it, so reuse is safe
+hipEvent_t pooled_event() {
+    constexpr int N = 256;
+    static hipEvent_t ring[N];
+    static std::atomic<unsigned> next{0};
+    static std::mutex mu;
+    const unsigned k = next.fetch_add(1) % N;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ring[k] && hipEventCreateWithFlags(&ring[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return ring[k];
 }
 
 }  // namespace
@@ -1722,16 +1744,14 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
     return csplat_forward_finish(ticket, out_color, out_depth, num_rendered, geom_out, binning_out, image_out);
 }
 
-int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
-                    const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
-                    const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
-                    const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
-                    const void *binning, const void *image, const float *out_color, const float *dL_dpix, void *scratch,
-                    float *dL_dmean2D,
-                    float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
-                    float *dL_dsh, float *dL_dscale, float *dL_drot) {
-    hipStream_t s = (hipStream_t)stream;
-    (void)colors_precomp;
+// K7 on `stream`; K8 on `k8_stream` (after an event wait when it differs); accmask see k_preprocess_bwd
+static int backward_impl(hipStream_t s, hipStream_t k8s, unsigned accmask, int P, int D, int M, int R, const float *bg, int W, int H,
+                         const float *means3D, const float *shs, const float *scales, float scale_modifier,
+                         const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
+                         const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
+                         const void *binning, const void *image, const float *out_color, const float *dL_dpix, void *scratch,
+                         float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D,
+                         float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot) {
     CSPLAT_REQUIRE(geom && binning && image && out_color, "csplat_backward: missing saved state");
     CSPLAT_REQUIRE(dL_dmean2D && dL_dconic && dL_dopacity && dL_dcolor && dL_dmean3D && dL_dcov3D, "missing gradient outputs");
     CSPLAT_REQUIRE(scratch != nullptr, "csplat_backward: scratch (csplat_backward_scratch_bytes) missing");
@@ -1759,22 +1779,108 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
                                                                         n_contrib, out_color, dL_dpix, acc);
         LAUNCH_CHECK();
     }
+    if (k8s != s) {
+        hipEvent_t ev = pooled_event();
+        CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
+        HIP_TRY(hipEventRecord(ev, s));
+        HIP_TRY(hipStreamWaitEvent(k8s, ev, 0));
+    }
     {
-        ProfScope ps(PROF_K8, s);
+        ProfScope ps(PROF_K8, k8s);
         const bool stage = shs != nullptr && dL_dsh != nullptr && M == 16 && (((uintptr_t)shs | (uintptr_t)dL_dsh) & 15u) == 0;
+        CSPLAT_REQUIRE(stage || !(accmask & CSPLAT_ACC_SH), "accumulating dL_dsh needs M == 16 and 16-byte aligned buffers");
         if (stage)
-            k_preprocess_bwd<true, 128><<<cdiv(P, 128), 128, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
-                                                                      cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D,
-                                                                      dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
-                                                                      dL_dsh, dL_dscale, dL_drot);
+            k_preprocess_bwd<true, 128><<<cdiv(P, 128), 128, 0, k8s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                                        cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D,
+                                                                        dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                                                                        dL_dsh, dL_dscale, dL_drot, accmask);
         else
-            k_preprocess_bwd<false, 256><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
-                                                                       cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D,
-                                                                       dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
-                                                                       dL_dsh, dL_dscale, dL_drot);
+            k_preprocess_bwd<false, 256><<<cdiv(P, 256), 256, 0, k8s>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                                         cov3D_precomp != nullptr, cam, g, radii, acc, dL_dmean2D,
+                                                                         dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                                                                         dL_dsh, dL_dscale, dL_drot, accmask);
         LAUNCH_CHECK();
     }
     return 0;
+}
+
+int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
+                    const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                    const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
+                    const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
+                    const void *binning, const void *image, const float *out_color, const float *dL_dpix, void *scratch,
+                    float *dL_dmean2D,
+                    float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
+                    float *dL_dsh, float *dL_dscale, float *dL_drot) {
+    (void)colors_precomp;
+    return backward_impl((hipStream_t)stream, (hipStream_t)stream, 0u, P, D, M, R, bg, W, H, means3D, shs, scales, scale_modifier,
+                         rotations, cov3D_precomp, view, proj, campos, tanfovx, tanfovy, radii, geom, binning, image, out_color,
+                         dL_dpix, scratch, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                         dL_drot);
+}
+
+// ---- batched entry points: V independent views, one stream each, fenced against `join_stream`
+static int fence_in(int V, const csplat_view *v, hipStream_t join) {
+    hipEvent_t ev = pooled_event();
+    CSPLAT_REQUIRE(ev != nullptr, "csplat_*_views: no event");
+    HIP_TRY(hipEventRecord(ev, join));
+    for (int i = 0; i < V; i++) {
+        bool seen = (hipStream_t)v[i].stream == join;
+        for (int j = 0; j < i && !seen; j++) seen = v[j].stream == v[i].stream;
+        if (!seen) HIP_TRY(hipStreamWaitEvent((hipStream_t)v[i].stream, ev, 0));
+    }
+    return 0;
+}
+static int fence_out(int V, const csplat_view *v, hipStream_t join) {
+    for (int i = 0; i < V; i++) {
+        bool seen = (hipStream_t)v[i].stream == join;
+        for (int j = 0; j < i && !seen; j++) seen = v[j].stream == v[i].stream;
+        if (seen) continue;
+        hipEvent_t ev = pooled_event();
+        CSPLAT_REQUIRE(ev != nullptr, "csplat_*_views: no event");
+        HIP_TRY(hipEventRecord(ev, (hipStream_t)v[i].stream));
+        HIP_TRY(hipStreamWaitEvent(join, ev, 0));
+    }
+    return 0;
+}
+
+int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream) {
+    CSPLAT_REQUIRE(V >= 0 && V <= MAX_TICKETS && (V == 0 || v != nullptr), "csplat_forward_views: bad view count");
+    if (int rc = fence_in(V, v, (hipStream_t)join_stream)) return rc;
+    int tickets[MAX_TICKETS];
+    int rc = 0, begun = 0;
+    for (; begun < V && rc == 0; begun++) {
+        csplat_view &w = v[begun];
+        rc = csplat_forward_begin(w.stream, w.P, w.D, w.M, w.bg, w.W, w.H, w.means3D, w.shs, w.colors_precomp, w.opacities, w.scales,
+                                  w.scale_modifier, w.rotations, w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy,
+                                  w.prefiltered, alloc, w.alloc_ctx, w.radii, &tickets[begun]);
+        if (rc) break;
+    }
+    for (int i = 0; i < begun; i++) {   // every begun ticket is finished (= released) even after an error
+        csplat_view &w = v[i];
+        const int r2 = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
+        if (rc == 0) rc = r2;
+    }
+    if (rc) return rc;
+    return fence_out(V, v, (hipStream_t)join_stream);
+}
+
+int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
+    CSPLAT_REQUIRE(V >= 0 && (V == 0 || v != nullptr), "csplat_backward_views: bad view count");
+    hipStream_t join = (hipStream_t)join_stream;
+    if (int rc = fence_in(V, v, join)) return rc;
+    bool shared = false;   // any view adding into another view's buffers: all K8 run on the join stream, in view order
+    for (int i = 0; i < V; i++) shared |= v[i].accmask != 0u;
+    for (int i = 0; i < V; i++) {
+        const csplat_view &w = v[i];
+        if (int rc = backward_impl((hipStream_t)w.stream, shared ? join : (hipStream_t)w.stream, w.accmask, w.P, w.D, w.M,
+                                   w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
+                                   w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.radii, w.geom, w.binning,
+                                   w.image, w.out_color, w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic, w.dL_dopacity,
+                                   w.dL_dcolor, w.dL_dmean3D, w.dL_dcov3D, w.dL_dsh, w.dL_dscale, w.dL_drot))
+            return rc;
+    }
+    return fence_out(V, v, join);
 }
 
 }  // extern "C"

@@ -171,12 +171,17 @@ def _view_streams(dev, n, main):
 
 
 class _RasterizeGaussiansBatch(torch.autograd.Function):
-    """V independent views in one autograd node.  Every view runs on its own HIP stream; all csplat_forward_begin calls
-    are issued before the first csplat_forward_finish, so the per-view host round trip for num_rendered and the
-    compositing kernels (a single view's K6 keeps ~1000 wavefronts busy on a 256-CU part) overlap across views.
-    Results are bit-identical to V calls of _RasterizeGaussians (same kernels, same per-view order)."""
+    """V independent views in one autograd node and ONE library call each way (csplat_forward_views /
+    csplat_backward_views).  Every view runs on its own HIP stream (the caller's + V-1 side streams, fenced inside the
+    library): all K1/K2 are issued before the first num_rendered read, the under-filled compositing kernels of the views
+    overlap, and a parameter tensor passed to several views gets ONE gradient buffer that the views' K8 add into.
+    Images / radii / depth are bit-identical to V calls of _RasterizeGaussians."""
 
     NIN = 8
+    # slot in the per-view argument list -> (csplat_view gradient field, accumulate bit)
+    _GRAD = {0: ("dL_dmean3D", _n.ACC_MEAN3D), 2: ("dL_dsh", _n.ACC_SH), 3: ("dL_dcolor", _n.ACC_COLOR),
+             4: ("dL_dopacity", _n.ACC_OPACITY), 5: ("dL_dscale", _n.ACC_SCALE), 6: ("dL_drot", _n.ACC_ROT),
+             7: ("dL_dcov3D", _n.ACC_COV3D)}
 
     @staticmethod
     def forward(ctx, settings, *flat):
@@ -189,57 +194,101 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         dev = views[0].dev
         main = torch.cuda.current_stream(dev)
         streams = _view_streams(dev, V, main)
-        for v, st in zip(views, streams):
-            if st is not main:
-                st.wait_stream(main)
-                for t in v.inputs():
-                    t.record_stream(st)
-            with torch.cuda.stream(st):
-                v.begin()
-        for v, st in zip(views, streams):
-            with torch.cuda.stream(st):
-                v.finish()
+        arr = (_n.CsplatView * V)()
+        chunks = [dict() for _ in range(V)]
+
+        def _alloc(ctx_, chunk, nbytes):     # all on the caller's stream: the library fences the view streams around it
+            try:
+                buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+                chunks[int(ctx_ or 0)][int(chunk)] = buf
+                return buf.data_ptr()
+            except Exception:
+                return None
+        cb = _n.ALLOC_FN(_alloc)
+        for i, (v, st) in enumerate(zip(views, streams)):
+            rs, w = v.rs, arr[i]
+            v.color = torch.empty(3, v.H, v.W, dtype=torch.float32, device=dev)
+            v.depth = torch.empty(1, v.H, v.W, dtype=torch.float32, device=dev)
+            v.radii = torch.empty(v.P, dtype=torch.int32, device=dev)
+            w.stream = st.cuda_stream
+            w.P, w.D, w.M, w.W, w.H, w.prefiltered = v.P, int(rs.sh_degree), v.M, v.W, v.H, int(bool(rs.prefiltered))
+            w.scale_modifier, w.tanfovx, w.tanfovy = float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy)
+            w.bg, w.means3D, w.shs, w.colors_precomp = _n.ptr(v.bg), _n.ptr(v.means3D), _n.ptr(v.sh), _n.ptr(v.colors_precomp)
+            w.opacities, w.scales, w.rotations = _n.ptr(v.opacities), _n.ptr(v.scales), _n.ptr(v.rotations)
+            w.cov3D_precomp, w.view, w.proj, w.campos = _n.ptr(v.cov3Ds_precomp), _n.ptr(v.view), _n.ptr(v.proj), _n.ptr(v.campos)
+            w.alloc_ctx = i
+            w.out_color, w.out_depth, w.radii = _n.ptr(v.color), _n.ptr(v.depth), _n.ptr(v.radii)
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_forward_views(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream)
+        _n.check(rc, "csplat_forward_views")
         outs, saved = [], []
-        for v, st in zip(views, streams):
-            if st is not main:
-                main.wait_stream(st)
-                for t in (v.color, v.radii, v.depth):
-                    t.record_stream(main)
+        for i, v in enumerate(views):
+            v.num_rendered = int(arr[i].num_rendered)
+            v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
             outs += [v.color, v.radii, v.depth]
             saved += list(v.saved())
             ctx.mark_non_differentiable(v.radii, v.depth)
         ctx.nsaved = len(views[0].saved())
         ctx.save_for_backward(*saved)
+        # which view first received each input tensor OBJECT (shared parameters get one gradient buffer)
+        ctx.first_of = [[next(j for j in range(i + 1) if flat[j * n + k] is flat[i * n + k]) for k in range(n)] for i in range(V)]
         for v in views:
             v.drop_inputs()
-        ctx.views = views
+        ctx.views, ctx.arr = views, arr
+        ctx.set_materialize_grads(False)     # an unused view arrives as None in backward() and costs nothing
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        views, k = ctx.views, ctx.nsaved
+        views, k, arr, n = ctx.views, ctx.nsaved, ctx.arr, _RasterizeGaussiansBatch.NIN
+        V = len(views)
         dev = views[0].dev
         main = torch.cuda.current_stream(dev)
-        streams = _view_streams(dev, len(views), main)
-        out = [None] * (len(views) * _RasterizeGaussiansBatch.NIN)
-        # side streams first, the caller's stream last: its K7 then does not delay the launches of the others
-        for i in list(range(1, len(views))) + [0]:
-            v, st, g = views[i], streams[i], grads[3 * i]
-            if g is None:
-                continue
-            saved = ctx.saved_tensors[i * k:(i + 1) * k]
-            if st is not main:
-                st.wait_stream(main)
-                g.record_stream(st)
-            with torch.cuda.stream(st):
-                gi = v.backward(g, saved)
-            if st is not main:
-                for t in gi:
-                    if t is not None:
-                        t.record_stream(main)
-            out[i * _RasterizeGaussiansBatch.NIN:(i + 1) * _RasterizeGaussiansBatch.NIN] = list(gi)
-        for st in streams[1:]:
-            main.wait_stream(st)
+        active = [i for i in range(V) if grads[3 * i] is not None]
+        out = [None] * (V * n)
+        if not active:
+            return (None,) + tuple(out)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        keep, owner = [], {}
+        sub = (_n.CsplatView * len(active))()
+        for a, i in enumerate(active):
+            v = views[i]
+            means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii, color = ctx.saved_tensors[i * k:(i + 1) * k]
+            C.memmove(C.byref(sub[a]), C.byref(arr[i]), C.sizeof(_n.CsplatView))
+            w, P, M = sub[a], v.P, v.M
+            g = _f32c(grads[3 * i], dev)
+            scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, v.num_rendered)), 256), dtype=torch.uint8, device=dev)
+            d_mean2D, d_conic = new(P, 3), new(P, 4)
+            keep += [g, scratch, d_conic]
+            w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic = _n.ptr(g), _n.ptr(scratch), _n.ptr(d_mean2D), _n.ptr(d_conic)
+            out[i * n + 1] = d_mean2D
+            shapes = {0: (P, 3), 2: (P, M, 3) if sh is not None else None, 3: (P, 3), 4: (P, 1),
+                      5: (P, 3) if scales is not None else None, 6: (P, 4) if rotations is not None else None, 7: (P, 6)}
+            present = {0: True, 2: sh is not None, 3: colors_precomp is not None, 4: True, 5: scales is not None,
+                       6: rotations is not None, 7: cov3Ds is not None}
+            mask = 0
+            for slot, (field, bit) in _RasterizeGaussiansBatch._GRAD.items():
+                if shapes[slot] is None:
+                    setattr(w, field, None)
+                    continue
+                j = ctx.first_of[i][slot]
+                share = present[slot] and j != i and j in active and (slot != 2 or M == 16)
+                if share:
+                    buf = owner[(j, slot)]
+                    mask |= bit
+                else:
+                    buf = new(*shapes[slot])
+                    owner[(i, slot)] = buf
+                    if present[slot]:
+                        out[i * n + slot] = buf
+                    else:
+                        keep.append(buf)
+                setattr(w, field, _n.ptr(buf))
+            w.accmask = mask
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_backward_views(len(active), C.cast(sub, C.c_void_p), main.cuda_stream)
+        _n.check(rc, "csplat_backward_views")
+        del keep      # (freed on the caller's stream, i.e. after the join fence)
         return (None,) + tuple(out)
 
 

@@ -103,6 +103,33 @@ int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int
 int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *num_rendered, void **geom,
                           void **binning, void **image);
 
+/* Batched form: V independent views of one step in ONE call each way (the reference's loop over cameras,
+ * /root/reference/scene_reconstruction/train_utils.py:204-260 forward, :288 backward).  Every view names its own stream;
+ * the library fences them against `join_stream` on entry and exit (events), issues every view's K1/K2 before the first
+ * num_rendered read, and in the backward runs the views' K7 concurrently.  accmask (CSPLAT_ACC_*): gradient outputs of
+ * this view that are ADDED to a buffer an earlier view of the same call wrote (a parameter shared by several views then
+ * needs no per-view temporaries and no summation launches); when any view accumulates, K8 of all views runs on the join
+ * stream in view order.  dL_dmean2D / dL_dconic are always written.  Field meanings as in csplat_forward / csplat_backward. */
+enum { CSPLAT_ACC_OPACITY = 1, CSPLAT_ACC_COLOR = 2, CSPLAT_ACC_MEAN3D = 4, CSPLAT_ACC_COV3D = 8, CSPLAT_ACC_SH = 16,
+       CSPLAT_ACC_SCALE = 32, CSPLAT_ACC_ROT = 64 };
+typedef struct csplat_view {
+    void *stream;
+    int P, D, M, W, H, prefiltered;
+    float scale_modifier, tanfovx, tanfovy;
+    const float *bg, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp, *view, *proj, *campos;
+    void *alloc_ctx;
+    float *out_color, *out_depth;   /* forward outputs (caller-allocated) */
+    int32_t *radii;
+    int num_rendered;               /* written by the forward, read by the backward */
+    void *geom, *binning, *image;   /* chunk base pointers: written by the forward, read by the backward */
+    const float *dL_dpix;           /* backward inputs */
+    void *scratch;
+    unsigned accmask;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+} csplat_view;
+int csplat_forward_views(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream);
+int csplat_backward_views(int V, csplat_view *views, void *join_stream);
+
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
  * out_color is the forward's colour image; dL_dpix[3][H][W] its gradient (the depth image carries no gradient,
  * as upstream).

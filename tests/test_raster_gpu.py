@@ -328,6 +328,20 @@ def test_batched_views_equal_single_view_calls():
     for x, y, z in zip(g1, g2, g3):
         assert rel_err(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
         assert rel_err(z.cpu().numpy(), x.cpu().numpy()) < 1e-5
+    # a view whose image is not used gets no backward work, and sharing skips it
+    def run_partial(batched):
+        for k in names:
+            inp[k].grad = None
+        m2d = [torch.zeros(cases[0]["P"], 3, device="cuda", requires_grad=True) for _ in cases]
+        kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"],
+                    scales=inp["scales"], rotations=inp["rotations"]) for i in range(len(cases))]
+        outs = rasterize_views(settings, kws) if batched else [GaussianRasterizer(settings[i])(**kws[i]) for i in range(len(cases))]
+        (((outs[1][0] - tgt[1]) ** 2).mean() + ((outs[2][0] - tgt[2]) ** 2).mean()).backward()
+        torch.cuda.synchronize()
+        assert m2d[0].grad is None
+        return [inp[k].grad.clone() for k in names] + [m2d[1].grad.clone(), m2d[2].grad.clone()]
+    for x, y in zip(run_partial(False), run_partial(True)):
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
     with pytest.raises(Exception, match="excatly one of either SHs"):
         rasterize_views(settings[:1], [dict(means3D=inp["means3D"], means2D=None, opacities=inp["opacities"],
                                              scales=inp["scales"], rotations=inp["rotations"])])
