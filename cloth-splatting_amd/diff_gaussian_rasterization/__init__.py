@@ -248,43 +248,61 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         out = [None] * (V * n)
         if not active:
             return (None,) + tuple(out)
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        keep, owner = [], {}
-        sub = (_n.CsplatView * len(active))()
-        for a, i in enumerate(active):
+        # ONE allocation for every gradient, temporary and K7 record of the step (returned gradients are views of it)
+        plan, owner, total = [], {}, 0
+
+        def reserve(numel):
+            nonlocal total
+            off = total
+            total += (int(numel) + 63) & ~63          # 256-byte granules
+            return off
+        gs = []
+        for i in active:
             v = views[i]
             means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii, color = ctx.saved_tensors[i * k:(i + 1) * k]
-            C.memmove(C.byref(sub[a]), C.byref(arr[i]), C.sizeof(_n.CsplatView))
-            w, P, M = sub[a], v.P, v.M
-            g = _f32c(grads[3 * i], dev)
-            scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, v.num_rendered)), 256), dtype=torch.uint8, device=dev)
-            d_mean2D, d_conic = new(P, 3), new(P, 4)
-            keep += [g, scratch, d_conic]
-            w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic = _n.ptr(g), _n.ptr(scratch), _n.ptr(d_mean2D), _n.ptr(d_conic)
-            out[i * n + 1] = d_mean2D
+            P, M = v.P, v.M
+            ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.num_rendered)) // 4 + 64),
+                   "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {1: (None, (P, 3))}}
+            ent["ret"][1] = (ent["dL_dmean2D"], (P, 3))
             shapes = {0: (P, 3), 2: (P, M, 3) if sh is not None else None, 3: (P, 3), 4: (P, 1),
                       5: (P, 3) if scales is not None else None, 6: (P, 4) if rotations is not None else None, 7: (P, 6)}
             present = {0: True, 2: sh is not None, 3: colors_precomp is not None, 4: True, 5: scales is not None,
                        6: rotations is not None, 7: cov3Ds is not None}
-            mask = 0
             for slot, (field, bit) in _RasterizeGaussiansBatch._GRAD.items():
                 if shapes[slot] is None:
-                    setattr(w, field, None)
+                    ent[field] = None
                     continue
                 j = ctx.first_of[i][slot]
-                share = present[slot] and j != i and j in active and (slot != 2 or M == 16)
-                if share:
-                    buf = owner[(j, slot)]
-                    mask |= bit
+                if present[slot] and j != i and j in active and (slot != 2 or M == 16):
+                    ent[field] = owner[(j, slot)]
+                    ent["mask"] |= bit
                 else:
-                    buf = new(*shapes[slot])
-                    owner[(i, slot)] = buf
+                    numel = 1
+                    for d in shapes[slot]:
+                        numel *= d
+                    ent[field] = owner[(i, slot)] = reserve(numel)
                     if present[slot]:
-                        out[i * n + slot] = buf
-                    else:
-                        keep.append(buf)
-                setattr(w, field, _n.ptr(buf))
-            w.accmask = mask
+                        ent["ret"][slot] = (ent[field], shapes[slot])
+            plan.append(ent)
+            gs.append(_f32c(grads[3 * i], dev))
+        big = torch.empty(max(total, 64), dtype=torch.float32, device=dev)
+        base = big.data_ptr()
+        sub = (_n.CsplatView * len(active))()
+        for a, i in enumerate(active):
+            ent = plan[a]
+            C.memmove(C.byref(sub[a]), C.byref(arr[i]), C.sizeof(_n.CsplatView))
+            w = sub[a]
+            w.dL_dpix, w.scratch, w.accmask = _n.ptr(gs[a]), base + 4 * ent["scratch"], ent["mask"]
+            for field in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh",
+                          "dL_dscale", "dL_drot"):
+                off = ent.get(field)
+                setattr(w, field, None if off is None else base + 4 * off)
+            for slot, (off, shape) in ent["ret"].items():
+                numel = 1
+                for d in shape:
+                    numel *= d
+                out[i * n + slot] = big[off:off + numel].view(shape)
+        keep = (big, gs)
         with torch.cuda.device(dev):
             rc = _n.lib.csplat_backward_views(len(active), C.cast(sub, C.c_void_p), main.cuda_stream)
         _n.check(rc, "csplat_backward_views")
