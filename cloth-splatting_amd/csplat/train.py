@@ -12,7 +12,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from gaussian_renderer import render
+from gaussian_renderer import render, render_views
 from . import dist as cd
 
 # arguments/__init__.py:109-150 overlaid by arguments/cloth_splatting/default.py:1-43
@@ -171,16 +171,18 @@ def regularization(all_vertice_deform, gaussians, opt, static=False):
 
 
 def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT,
-               background=None, static=False, view_parallel=False):
+               background=None, static=False, view_parallel=False, batched_views=True):
     """One optimisation step.  Returns (psnr, loss, stats) where stats holds what densification consumes.
     view_parallel=True shards `viewpoint_cams` over the ranks of the default process group and all-reduces the
-    gradients / statistics (csplat/dist.py); with one rank it is the reference's single-GPU step."""
+    gradients / statistics (csplat/dist.py); with one rank it is the reference's single-GPU step.
+    batched_views=True renders the step's cameras in one rasterizer call (gaussian_renderer.render_views)."""
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
     images, gts, radii_l, vis_l, vsp_l, verts = [], [], [], [], [], []
-    for cam in cams:
-        pkg = render(cam, gaussians, simulator, pipe, background, render_static=static)
+    pkgs = render_views(cams, gaussians, simulator, pipe, background, render_static=static) if batched_views else \
+        [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
+    for cam, pkg in zip(cams, pkgs):
         images.append(pkg.render.unsqueeze(0))
         gts.append(cam.original_image.to(pkg.render.device).unsqueeze(0))
         radii_l.append(pkg.radii.unsqueeze(0))

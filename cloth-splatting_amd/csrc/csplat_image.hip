@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_blur11(int H, int W, Taps taps, const f
 // ---- fused L1 loss: mean |a - b| and its gradient sign(a - b) / n in ONE pass (utils/loss_utils.py:20-23 is three
 // elementwise launches forward and three backward).  Deterministic: workgroup partials are summed in index order by
 // whichever workgroup finishes last (ticket counter), not with float atomics.
-constexpr int L1_BLOCKS = 256, L1_THREADS = 256;   // few workgroups: the ticket atomics serialise at one L2 address (~30 ns each)
+constexpr int L1_BLOCKS = 256, L1_THREADS = 1024;  // few, fat workgroups: the ticket atomics serialise at one L2 address (~30 ns each)
 __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
                                                     float inv_n, float *__restrict__ partial, unsigned *__restrict__ ticket,
                                                     float *__restrict__ loss, float *__restrict__ grad) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        { float t_ = 0.f; for (int k_ = 0; k_ < L1_THREADS / 64; k_++) t_ += s_red[k_]; partial[blockIdx.x] = t_; }
         __threadfence();
         s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
         __syncthreads();
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
         __syncthreads();
-        if (threadIdx.x == 0) { *loss = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_n; *ticket = 0u; }
+        if (threadIdx.x == 0) { float t_ = 0.f; for (int k_ = 0; k_ < L1_THREADS / 64; k_++) t_ += s_red[k_]; *loss = t_ * inv_n; *ticket = 0u; }
     }
 }
 }  // namespace

@@ -8,7 +8,7 @@ from typing import NamedTuple, Optional
 
 import numpy as np
 import torch
-from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
 
 
 class RenderResults(NamedTuple):
@@ -37,9 +37,11 @@ def _project(cam, points):
     return torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], dim=1)
 
 
-def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-           log_deform_path=None, no_shadow=False, render_static=False, project_vertices=False) -> RenderResults:
-    """Render the scene (background tensor must be on the GPU)."""
+def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, override_color, log_deform_path,
+             render_static, shared=None):
+    """everything of render() up to the rasterizer call: settings, rasterizer keyword arguments, by-products.
+    `shared` carries the view-independent activations (features, opacity, scaling) so that several views of one step
+    pass the SAME tensor objects to the rasterizer (one gradient buffer for all of them, see rasterize_views)."""
     base_xyz = pc.get_xyz()
     dev = base_xyz.device
     # zero tensor whose gradient is the screen-space (NDC) gradient of the 2D means (used by densification)
@@ -55,13 +57,17 @@ def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scalin
         bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=viewpoint_camera.world_view_transform.to(dev), projmatrix=viewpoint_camera.full_proj_transform.to(dev),
         sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center.to(dev), prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
-    if pipe.compute_cov3D_python:
-        cov3D_precomp, scales = pc.get_covariance(scaling_modifier), None
-    else:
-        cov3D_precomp, scales = None, pc.get_scaling
-    opacity = pc.get_opacity
+    if shared is None:
+        shared = {}
+    if "opacity" not in shared:
+        if pipe.compute_cov3D_python:
+            shared["cov3D"], shared["scales"] = pc.get_covariance(scaling_modifier), None
+        else:
+            shared["cov3D"], shared["scales"] = None, pc.get_scaling
+        shared["opacity"] = pc.get_opacity
+        shared["features"] = pc.get_features if override_color is None else None
+    cov3D_precomp, scales, opacity = shared["cov3D"], shared["scales"], shared["opacity"]
 
     time = torch.tensor(viewpoint_camera.time).to(pc.mesh.pos.device).repeat(pc.mesh.pos.shape[0], 1)
     if render_static:
@@ -80,17 +86,45 @@ def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scalin
                  vertice_rotations=pc.get_vertice_rotation(vertice_deform).detach().cpu().numpy())
 
     # shadow scalars are disabled in the reference (always None): colours come from SH inside the rasterizer
-    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    shs, colors_precomp = (shared["features"], None) if override_color is None else (None, override_color)
+    kwargs = dict(means3D=means3D_deform, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+                  opacities=opacity, scales=scales, rotations=None if cov3D_precomp is not None else rotations_deform,
+                  cov3D_precomp=cov3D_precomp)
+    return raster_settings, kwargs, (screenspace_points, means3D_deform, vertice_deform, rotations_deform, opacity)
 
-    rendered_image, radii, depth = rasterizer(
-        means3D=means3D_deform, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=None if cov3D_precomp is not None else rotations_deform, cov3D_precomp=cov3D_precomp)
 
+def _package(viewpoint_camera, raster_out, extras, project_vertices):
+    rendered_image, radii, depth = raster_out
+    screenspace_points, means3D_deform, vertice_deform, rotations_deform, opacity = extras
     gaussian_projections = _project(viewpoint_camera, means3D_deform)
     vertice_projections = _project(viewpoint_camera, vertice_deform) if project_vertices else None
-
     return RenderResults(render=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
                          radii=radii, depth=depth, means3D_deform=means3D_deform, vertice_deform=vertice_deform,
                          shadows_mean=None, shadows_std=None, projections=gaussian_projections,
                          rotations=rotations_deform, opacities=opacity, shadows=None,
                          vertice_projections=vertice_projections)
+
+
+def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           log_deform_path=None, no_shadow=False, render_static=False, project_vertices=False) -> RenderResults:
+    """Render the scene (background tensor must be on the GPU)."""
+    settings, kwargs, extras = _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, override_color,
+                                        log_deform_path, render_static)
+    out = GaussianRasterizer(raster_settings=settings)(**kwargs)
+    return _package(viewpoint_camera, out, extras, project_vertices)
+
+
+def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+                 no_shadow=False, render_static=False, project_vertices=False):
+    """render() for every camera of a training step in one rasterizer call (diff_gaussian_rasterization.rasterize_views:
+    one HIP stream per view, the views' kernels overlap, shared parameters get one gradient buffer).  Same results as
+    [render(c, ...) for c in viewpoint_cameras]; no counterpart upstream, whose train loop renders camera by camera
+    (scene_reconstruction/train_utils.py:204-260)."""
+    shared, prepared = {}, []
+    for cam in viewpoint_cameras:
+        prepared.append(_prepare(cam, pc, simulator, pipe, bg_color, scaling_modifier, override_color, None, render_static,
+                                 shared))
+    if not prepared:
+        return []
+    outs = rasterize_views([p[0] for p in prepared], [p[1] for p in prepared])
+    return [_package(cam, out, p[2], project_vertices) for cam, out, p in zip(viewpoint_cameras, outs, prepared)]

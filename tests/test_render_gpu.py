@@ -141,3 +141,34 @@ def test_fused_mesh_transform_equals_torch_formulation():
         err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
         assert err < 2e-4, (n, err)       # fp32 both sides; vertex grads: atomics vs sort-based index_put
     assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
+
+
+def test_render_views_equals_render_per_camera():
+    """gaussian_renderer.render_views == [render(c) for c]: identical images / radii / depth, and the same gradients on
+    the Gaussian parameters and the simulator (shared activations get one accumulated gradient buffer)."""
+    from gaussian_renderer import render, render_views
+    sc = _scene()
+    pc, sim = _build(sc)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        sim.output.weight.normal_(0, 1e-3)
+    cams = [_camera(sc["cameras"][0], time=t) for t in (0.25, 0.5, 0.75)]
+    pipe = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+    bg = torch.ones(3, device="cuda")
+    plist = [pc.face_bary, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, sim.output.weight]
+
+    def run(batched):
+        for p in plist:
+            p.grad = None
+        res = render_views(cams, pc, sim, pipe, bg) if batched else [render(c, pc, sim, pipe, bg) for c in cams]
+        sum((r.render - 0.4).abs().mean() for r in res).backward()
+        return res, [p.grad.clone() for p in plist], [r.viewspace_points.grad.clone() for r in res]
+
+    r1, g1, v1 = run(False)
+    r2, g2, v2 = run(True)
+    for a, b in zip(r1, r2):
+        assert torch.equal(a.render, b.render) and torch.equal(a.radii, b.radii) and torch.equal(a.depth, b.depth)
+        assert torch.equal(a.visibility_filter, b.visibility_filter)
+    for a, b in zip(g1 + v1, g2 + v2):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    assert render_views([], pc, sim, pipe, bg) == []
