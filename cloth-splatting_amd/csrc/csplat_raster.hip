@@ -954,6 +954,14 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
+// one level of a butterfly "transpose-reduce": lanes with s == 0 keep a (own + partner's), lanes with s == 1 keep b;
+// the partner permutation CTRL must flip s.  Two values are folded by one DPP add instead of two.
+template <int CTRL>
+__device__ __forceinline__ float bfly(float a, float b, bool s) {
+    const float send = s ? a : b, keep = s ? b : a;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
+}
+
 // per-Gaussian gradient accumulator filled by K7 and consumed by K8 (one 48-byte record per Gaussian):
 //   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..11 pad
 constexpr int ACC_STRIDE = 12;
@@ -1019,7 +1027,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__rest
     // chunk c, lane l  <->  list position pos = wave_hi-1 - (64c + l), down to seg_lo   (back to front)
     const uint32_t *pl = point_list + range.x;
     const int cnt = wave_hi - seg_lo;
-    const int q16 = lane & 15;
+    static_assert(BWD_GROUP == 2, "the butterfly reduction below pairs exactly two survivors");
+    const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
+    // which total this lane owns after the reduction (see below): lanes 0..15 values 0..7, lanes 16 / 24 value 8
+    const bool red_active = lane < 16 || lane == 16 || lane == 24;
+    const int red_t = lane < 16 ? 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1) : 8;
     auto idx_of = [&](int e) { return wave_hi - 1 - e; };
     uint32_t id_cur = lane < cnt ? pl[idx_of(lane)] : 0u;
     uint32_t id_nxt = 64 + lane < cnt ? pl[idx_of(64 + lane)] : 0u;
@@ -1096,19 +1108,34 @@ __global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__rest
                     v[k][5] = Gv[k] * dL_dalpha;
                 }
             }
+            if ((any[0] | any[1]) != 0ull) {   // wave-uniform
+                // The 2 x 9 per-pixel partials of the two survivors are summed over the 64 lanes by a butterfly whose
+                // levels halve the number of live registers: row_mirror pairs the two survivors (lane bit 3 picks one),
+                // row_half_mirror / quad xor 2 / quad xor 1 pair the value indices (bits 2, 1, 0), the two gfx950 lane-swap
+                // instructions fold rows 16 and 32 apart.  18 + 9 row-level DPP adds instead of 2 x 36; afterwards lane l < 16
+                // holds the total of (survivor bit3(l), value 4*bit0 + 2*bit1 + bit2), lanes 16 and 24 value 8 of survivor
+                // 0 / 1, and ONE 18-lane atomic instruction updates both Gaussians' records.
+                float r1[9];
 #pragma unroll
-            for (int k = 0; k < BWD_GROUP; k++) {
-                if (any[k] == 0ull) continue;   // wave-uniform
-                float x = 0.f;
-#pragma unroll
-                for (int t = 0; t < 9; t++) {
-                    const float r = row_sum(v[k][t]);
-                    x = q16 == t ? r : x;
+                for (int t = 0; t < 9; t++) r1[t] = bfly<0x140>(v[0][t], v[1][t], lb3);
+                const float a0 = bfly<0x141>(r1[0], r1[1], lb2), a1 = bfly<0x141>(r1[2], r1[3], lb2);
+                const float a2 = bfly<0x141>(r1[4], r1[5], lb2), a3 = bfly<0x141>(r1[6], r1[7], lb2);
+                float l8 = dpp_add<0x141>(r1[8]);
+                const float b0 = bfly<0x4E>(a0, a1, lb1), b1 = bfly<0x4E>(a2, a3, lb1);
+                l8 = dpp_add<0x4E>(l8);
+                const float c0 = bfly<0xB1>(b0, b1, lb0);
+                l8 = dpp_add<0xB1>(l8);
+                // rows: after the swap x = {c0 row0, l8 row0, c0 row2, l8 row2}, y = {c0 row1, l8 row1, c0 row3, l8 row3}
+                const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_int(c0), __float_as_int(l8), false, false);
+                const float d = __int_as_float(s16[0]) + __int_as_float(s16[1]);
+                const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_int(d), __float_as_int(d), false, false);
+                const float tot = __int_as_float(s32[0]) + __int_as_float(s32[1]);
+                const bool kk = lb3;
+                const unsigned long long mine = kk ? any[1] : any[0];
+                if (red_active && mine != 0ull) {
+                    const uint32_t gid = __float_as_uint(kk ? colv[1].w : colv[0].w);
+                    atomicAdd(acc + (size_t)gid * ACC_STRIDE + red_t, tot);
                 }
-                x += __shfl_xor(x, 16, 64);
-                x += __shfl_xor(x, 32, 64);
-                const uint32_t gid = __float_as_uint(colv[k].w);
-                if (lane < 9) atomicAdd(acc + (size_t)gid * ACC_STRIDE + lane, x);
             }
         }
     }

@@ -102,7 +102,8 @@ class _View:
         self.num_rendered = int(R.value)
         ch = self.alloc.chunks
         self.chunks = (ch[_n_GEOM], ch[_n_BINNING], ch[_n_IMAGE])
-        self.alloc = None     # TEMP / TABLE die here (stream-ordered reuse)
+        self.alloc.cb = None  # break the allocator <-> callback cycle: TEMP / TABLE die here, not at the next cyclic GC
+        self.alloc = None
 
     def backward(self, grad_color, saved):
         """K7 + K8 on the CURRENT stream; returns the per-input gradients in the Function's argument order."""
