@@ -16,6 +16,10 @@ python3 tools/bench_linear128.py     > "$OUT/linear128.txt"    2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 # same command as the default bench (per-view streams on), so K7's average agrees with bench.py's HIP-event timing
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+# the same step with the views back to back on ONE stream: kernel durations free of cross-stream overlap (the profiler
+# serialises dispatches of different streams more than a free run does, so only this pair of numbers can agree exactly)
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-view-streams > "$OUT/bench_serial.json" 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-view-streams > "$OUT/trace_serial.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gnn" -o t -- python3 "$ROOT/bench_gnn.py" --steps 5 --warmup 2 > "$OUT/trace_gnn.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-view-streams > "$OUT/pmc_$c.log" 2>&1

@@ -23,11 +23,11 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-for f in ("bench.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "mfma_rate.txt"):
+for f in ("bench.json", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "mfma_rate.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
-for sub, out in (("trace", "kernel_stats.csv"), ("trace_gnn", "gnn_kernel_stats.csv")):
+for sub, out in (("trace", "kernel_stats.csv"), ("trace_serial", "kernel_stats_serial.csv"), ("trace_gnn", "gnn_kernel_stats.csv")):
     hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         rows = list(csv.reader(open(hits[0])))
