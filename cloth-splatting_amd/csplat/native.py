@@ -47,6 +47,9 @@ EXPORTS = {
     "csplat_mesh_transform_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_mesh_transform_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_blur11": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
+    "csplat_ssim_partial_count": (_sz, [_i64, _i, _i]),
+    "csplat_ssim_fwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "csplat_l1_scratch_bytes": (_sz, []),
     "csplat_l1": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "csplat_prof_enable": (_i, [C.c_uint]),

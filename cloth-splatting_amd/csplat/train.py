@@ -111,8 +111,45 @@ def _blur(x, wh, wv, pad, channel):
     return F.conv2d(F.conv2d(x, wh, padding=(0, pad), groups=channel), wv, padding=(pad, 0), groups=channel)
 
 
+class FusedSSIM(torch.autograd.Function):
+    """mean SSIM(img1, img2) through csplat_ssim_fwd / csplat_ssim_bwd: windows, map, mean and the three partial
+    derivatives in one launch; the backward (w.r.t. img1) in one more.  img2 is treated as a constant (ground truth)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        _n.require_cuda(img1)
+        x, y = img1.contiguous(), img2.contiguous()
+        H, W = x.shape[-2:]
+        n_img = x.numel() // (H * W)
+        need = img1.requires_grad
+        p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=x.device) if need else None
+        partial = torch.empty(int(_n.lib.csplat_ssim_partial_count(n_img, H, W)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_ssim_fwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y),
+                                            _n.ptr(p[0]) if need else None, _n.ptr(p[1]) if need else None,
+                                            _n.ptr(p[2]) if need else None, None, _n.ptr(partial)), "csplat_ssim_fwd")
+        ctx.save_for_backward(x, y, p)
+        ctx.dims = (n_img, H, W)
+        return partial.sum() / float(x.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, p = ctx.saved_tensors
+        n_img, H, W = ctx.dims
+        g = g.reshape(1).float().contiguous()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_ssim_bwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
+                                            _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(g), 1.0 / float(x.numel()), _n.ptr(dx)),
+                     "csplat_ssim_bwd")
+        return dx, None
+
+
 def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
     """utils/loss_utils.py:40-70: Gaussian-window SSIM (window 11, sigma 1.5), separable form."""
+    if window_size == 11 and size_average and not return_map and img1.is_cuda and img1.dtype == torch.float32 and \
+            img2.dtype == torch.float32 and img1.shape == img2.shape and img1.numel() > 0 and not img2.requires_grad:
+        return FusedSSIM.apply(img1, img2)
     channel = img1.size(-3)
     wh, wv = _window1d(window_size, channel, img1)
     pad = window_size // 2

@@ -41,6 +41,120 @@ __global__ __launch_bounds__(256) void k_blur11(int H, int W, Taps taps, const f
     }
 }
 
+// ---- fused SSIM (utils/loss_utils.py:40-70, size_average form).  Forward: ONE kernel loads an x / y tile with its 5-pixel
+// halo, forms x^2, y^2, xy in LDS, runs the five separable 11x11 windows, evaluates the SSIM map and its three partial
+// derivatives (w.r.t. mu1 = blur(x), s11 = blur(x^2), s12 = blur(xy)) and a per-workgroup sum of the map.  Backward: ONE
+// kernel blurs the three partials (the window is self-adjoint) and combines g * (b1 + 2x b2 + y b3).  The composed form
+// is a cat, a blur launch and ~25 elementwise launches forward, ~50 backward, each a full-image HBM round trip.
+constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
+
+__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
+                                                   float *__restrict__ P1, float *__restrict__ P2, float *__restrict__ P3,
+                                                   float *__restrict__ map_out, float *__restrict__ partial) {
+    __shared__ float s_x[(BH + 2 * R5)][BW + 2 * R5 + 1];
+    __shared__ float s_y[(BH + 2 * R5)][BW + 2 * R5 + 1];
+    __shared__ float s_h[5][(BH + 2 * R5)][BW + 1];
+    __shared__ float s_red[4];
+    const size_t img = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += 256) {
+        const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
+        const int y = y0 + ry - R5, x = x0 + rx - R5;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;       // zero padding (of the images AND of their products)
+        s_x[ry][rx] = in ? X[img + (size_t)y * W + x] : 0.f;
+        s_y[ry][rx] = in ? Y[img + (size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += 256) {
+        const int ry = t / BW, rx = t - ry * BW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = taps.w[k], xv = s_x[ry][rx + k], yv = s_y[ry][rx + k];
+            a0 += w * xv; a1 += w * yv; a2 += w * (xv * xv); a3 += w * (yv * yv); a4 += w * (xv * yv);
+        }
+        s_h[0][ry][rx] = a0; s_h[1][ry][rx] = a1; s_h[2][ry][rx] = a2; s_h[3][ry][rx] = a3; s_h[4][ry][rx] = a4;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < BH * BW; t += 256) {
+        const int ry = t / BW, rx = t - ry * BW;
+        const int y = y0 + ry, x = x0 + rx;
+        if (y < H && x < W) {
+            float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float w = taps.w[k];
+                mu1 += w * s_h[0][ry + k][rx]; mu2 += w * s_h[1][ry + k][rx]; s11 += w * s_h[2][ry + k][rx];
+                s22 += w * s_h[3][ry + k][rx]; s12 += w * s_h[4][ry + k][rx];
+            }
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * (s12 - mu12) + SSIM_C2;
+            const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = (s11 - mu1_sq) + (s22 - mu2_sq) + SSIM_C2;
+            const float inv = 1.f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            acc += S;
+            const size_t o = img + (size_t)y * W + x;
+            if (map_out) map_out[o] = S;
+            if (P1) {
+                P1[o] = 2.f * mu2 * (A2 - A1) * inv - S * 2.f * mu1 * (B2 - B1) * inv;   // dS/dmu1
+                P2[o] = -S / B2;                                                         // dS/ds11
+                P3[o] = 2.f * A1 * inv;                                                  // dS/ds12
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
+                                                   const float *__restrict__ P1, const float *__restrict__ P2,
+                                                   const float *__restrict__ P3, const float *__restrict__ gscalar, float inv_n,
+                                                   float *__restrict__ dX) {
+    __shared__ float s_p[3][(BH + 2 * R5)][BW + 2 * R5 + 1];
+    __shared__ float s_h[3][(BH + 2 * R5)][BW + 1];
+    const size_t img = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += 256) {
+        const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
+        const int y = y0 + ry - R5, x = x0 + rx - R5;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const size_t o = img + (size_t)y * W + x;
+        s_p[0][ry][rx] = in ? P1[o] : 0.f; s_p[1][ry][rx] = in ? P2[o] : 0.f; s_p[2][ry][rx] = in ? P3[o] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += 256) {
+        const int ry = t / BW, rx = t - ry * BW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = taps.w[k];
+            a0 += w * s_p[0][ry][rx + k]; a1 += w * s_p[1][ry][rx + k]; a2 += w * s_p[2][ry][rx + k];
+        }
+        s_h[0][ry][rx] = a0; s_h[1][ry][rx] = a1; s_h[2][ry][rx] = a2;
+    }
+    __syncthreads();
+    const float g = gscalar[0] * inv_n;
+    for (int t = threadIdx.x; t < BH * BW; t += 256) {
+        const int ry = t / BW, rx = t - ry * BW;
+        const int y = y0 + ry, x = x0 + rx;
+        if (y < H && x < W) {
+            float b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float w = taps.w[k];
+                b1 += w * s_h[0][ry + k][rx]; b2 += w * s_h[1][ry + k][rx]; b3 += w * s_h[2][ry + k][rx];
+            }
+            const size_t o = img + (size_t)y * W + x;
+            dX[o] = g * (b1 + 2.f * X[o] * b2 + Y[o] * b3);
+        }
+    }
+}
+
 // ---- fused L1 loss: mean |a - b| and its gradient sign(a - b) / n in ONE pass (utils/loss_utils.py:20-23 is three
 // elementwise launches forward and three backward).  Deterministic: workgroup partials are summed in index order by
 // whichever workgroup finishes last (ticket counter), not with float atomics.
@@ -114,6 +228,34 @@ extern "C" int csplat_l1(void *stream, int64_t n, const float *a, const float *b
     const int64_t work = (n / 4 + L1_THREADS - 1) / L1_THREADS;
     const int grid = (int)(work < 1 ? 1 : (work > L1_BLOCKS ? L1_BLOCKS : work));
     k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, ticket, loss, grad);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t csplat_ssim_partial_count(int64_t n_images, int H, int W) { return (size_t)n_images * cdiv(H, BH) * cdiv(W, BW); }
+
+extern "C" int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
+                               float *p1, float *p2, float *p3, float *map_out, float *partial) {
+    CSPLAT_REQUIRE(n_images >= 0 && n_images < 65536 && H > 0 && W > 0 && taps11 && x && y && partial, "csplat_ssim_fwd: bad arguments");
+    CSPLAT_REQUIRE((p1 != nullptr) == (p2 != nullptr) && (p1 != nullptr) == (p3 != nullptr), "csplat_ssim_fwd: all three partials or none");
+    if (n_images == 0) return 0;
+    Taps t;
+    memcpy(t.w, taps11, sizeof(t.w));
+    dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
+    k_ssim_fwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, map_out, partial);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
+                               const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n, float *dx) {
+    CSPLAT_REQUIRE(n_images >= 0 && n_images < 65536 && H > 0 && W > 0 && taps11 && x && y && p1 && p2 && p3 && g_scalar && dx,
+                   "csplat_ssim_bwd: bad arguments");
+    if (n_images == 0) return 0;
+    Taps t;
+    memcpy(t.w, taps11, sizeof(t.w));
+    dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
+    k_ssim_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, dx);
     LAUNCH_CHECK();
     return 0;
 }

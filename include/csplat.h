@@ -159,6 +159,18 @@ int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *tap
  *   *loss = mean_i |a[i] - b[i]|,   grad[i] = sign(a[i] - b[i]) / n   (grad may be NULL).
  * scratch: csplat_l1_scratch_bytes() bytes whose last word is zero on entry (the kernel restores it), not shared between
  * calls that may run concurrently.  Deterministic (fixed summation order). */
+/* SSIM of /root/reference/utils/loss_utils.py:40-70 (window 11, sigma 1.5, zero padding, size_average) on n_images [H][W]
+ * planes (n_images = batch * channels), fused:
+ *   forward:  map[i] = SSIM(x, y)[i] (optional), partial[b] = sum of the map over workgroup b's tile
+ *             (csplat_ssim_partial_count() floats; mean = sum(partial) / (n_images*H*W), summed by the caller in a fixed
+ *             order), and p1, p2, p3 = dSSIM/dblur(x), dSSIM/dblur(x*x), dSSIM/dblur(x*y) per pixel (all three or NULL).
+ *   backward: dx[i] = g_scalar[0] * inv_n * ( blur(p1) + 2 x blur(p2) + y blur(p3) )[i]   (gradient w.r.t. x only).
+ * taps11: the 11 host floats of the 1-D window, as csplat_blur11. */
+size_t csplat_ssim_partial_count(int64_t n_images, int H, int W);
+int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
+                    float *p1, float *p2, float *p3, float *map_out, float *partial);
+int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
+                    const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n, float *dx);
 size_t csplat_l1_scratch_bytes(void);
 int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad);
 

@@ -3,6 +3,7 @@ optimisers must fit a perturbed target: PSNR rises, loss falls, statistics have 
 import pytest
 
 import util  # noqa: F401
+from util import rel_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -92,3 +93,33 @@ def test_fused_l1_matches_torch(shape):
     assert torch.equal(g_fused, a.grad)
     l2 = tr.l1_loss(a.detach(), b)              # no-grad path, and the scratch word was restored
     assert float(l2) == float(l1)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 37, 53), (1, 3, 128, 200), (3, 1, 16, 64), (3, 3, 240, 200)])
+def test_fused_ssim_matches_composed_formula(shape):
+    """csplat_ssim_fwd/_bwd == the reference's SSIM formula (utils/loss_utils.py:40-70) evaluated in fp64 on the CPU with
+    the grouped-conv window: value to 1e-6, gradient w.r.t. the rendered image to 1e-5 relative (ragged tile edges, zero
+    padding of the images and of their products)."""
+    import torch.nn.functional as F
+    from math import exp
+    from csplat import train as tr
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    a = torch.rand(*shape, device="cuda", generator=g, requires_grad=True)
+    b = (a.detach() + 0.15 * torch.randn(*shape, device="cuda", generator=g)).clamp(0, 1)
+    s = tr.ssim(a, b)
+    assert type(s.grad_fn).__name__.startswith("FusedSSIM")
+    (3.0 * s).backward()
+    c = shape[1]
+    w1 = torch.tensor([exp(-(k - 5) ** 2 / float(2 * 1.5 ** 2)) for k in range(11)])
+    w1 = (w1 / w1.sum()).unsqueeze(1)                                        # float32 window, as the reference builds it
+    w = w1.mm(w1.t()).double().unsqueeze(0).unsqueeze(0).expand(c, 1, 11, 11).contiguous()
+    x, y = a.detach().cpu().double().requires_grad_(), b.cpu().double()
+    cv = lambda t: F.conv2d(t, w, padding=5, groups=c)  # noqa: E731
+    mu1, mu2 = cv(x), cv(y)
+    s1, s2, s12 = cv(x * x) - mu1 * mu1, cv(y * y) - mu2 * mu2, cv(x * y) - mu1 * mu2
+    ref = (((2 * mu1 * mu2 + 0.01 ** 2) * (2 * s12 + 0.03 ** 2)) / ((mu1 * mu1 + mu2 * mu2 + 0.01 ** 2) * (s1 + s2 + 0.03 ** 2))).mean()
+    (3.0 * ref).backward()
+    assert abs(float(s) - float(ref)) < 1e-6
+    assert rel_err(a.grad.cpu().numpy(), x.grad.numpy()) < 1e-5
+    with torch.no_grad():
+        assert abs(float(tr.ssim(a, b)) - float(ref)) < 1e-6                 # no-grad path (no partials written)
