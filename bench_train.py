@@ -65,7 +65,8 @@ def main():
             p.copy_(k)
     cams = cameras(sc, times, dev, targets)
     pc.training_setup(feature_lr=tr.DEFAULT_OPT.feature_lr)
-    mopt = torch.optim.Adam(sim.parameters(), lr=tr.DEFAULT_OPT.meshnet_lr)
+    from csplat.optim import GroupedAdam
+    mopt = GroupedAdam(sim.parameters(), lr=tr.DEFAULT_OPT.meshnet_lr)
     hist = []
     for it in range(1, args.warmup + 1):
         ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)

@@ -134,7 +134,8 @@ class MeshGaussians:
             {'params': [self._opacity], 'lr': opacity_lr, "name": "opacity"},
             {'params': [self._scaling], 'lr': scaling_lr, "name": "scaling"},
             {'params': [self._rotation], 'lr': rotation_lr, "name": "rotation"}]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        from .optim import GroupedAdam
+        self.optimizer = GroupedAdam(groups, lr=0.0, eps=1e-15)   # torch.optim.Adam semantics and state, one launch per step
         return self.optimizer
 
     # ---- activations (gaussian_model.py:96-121) -----------------------------------------------------------------

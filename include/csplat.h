@@ -159,6 +159,15 @@ int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *tap
  *   *loss = mean_i |a[i] - b[i]|,   grad[i] = sign(a[i] - b[i]) / n   (grad may be NULL).
  * scratch: csplat_l1_scratch_bytes() bytes whose last word is zero on entry (the kernel restores it), not shared between
  * calls that may run concurrently.  Deterministic (fixed summation order). */
+/* One Adam step (torch.optim.Adam semantics: no weight decay, no amsgrad, maximize = false) over n_tensors fp32 tensors in a
+ * single launch per CSPLAT_ADAM_MAX_TENSORS tensors.  Host arrays of device pointers / element counts / per-tensor learning
+ * rates (doubles, combined in double before the cast to fp32 as torch does; the reference keeps one parameter group per Gaussian attribute, /root/reference/scene_reconstruction/
+ * gaussian_mesh.py:126-136, stepped at train_utils.py:310-319).  `step` is the 1-based step count AFTER this update. */
+#define CSPLAT_ADAM_MAX_TENSORS 48
+int csplat_adam_step(void *stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                     float *const *exp_avg_sq, const int64_t *numel, const double *lr, double beta1, double beta2, double eps,
+                     int64_t step);
+
 /* SSIM of /root/reference/utils/loss_utils.py:40-70 (window 11, sigma 1.5, zero padding, size_average) on n_images [H][W]
  * planes (n_images = batch * channels), fused:
  *   forward:  map[i] = SSIM(x, y)[i] (optional), partial[b] = sum of the map over workgroup b's tile
