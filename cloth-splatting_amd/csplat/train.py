@@ -197,7 +197,8 @@ def regularization(all_vertice_deform, gaussians, opt, static=False):
         loss = loss + opt.lambda_deform_mag * 0.5 * (d0 + d1)
     if not static and opt.lambda_rigid > 0:
         ei = gaussians.mesh.edge_index
-        disp = all_vertice_deform[:, ei[1]] - all_vertice_deform[:, ei[0]]
+        # (index_select: its backward is an atomic index_add; advanced indexing would sort the 2E indices every step)
+        disp = all_vertice_deform.index_select(1, ei[1]) - all_vertice_deform.index_select(1, ei[0])
         deformed_norm = torch.linalg.norm(disp, dim=-1, keepdim=True)
         static_norm = gaussians.edge_norm.unsqueeze(0).expand(n_cams, -1, -1)
         loss = loss + opt.lambda_rigid * F.l1_loss(static_norm, deformed_norm)

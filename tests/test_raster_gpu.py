@@ -345,3 +345,27 @@ def test_batched_views_equal_single_view_calls():
     with pytest.raises(Exception, match="excatly one of either SHs"):
         rasterize_views(settings[:1], [dict(means3D=inp["means3D"], means2D=None, opacities=inp["opacities"],
                                              scales=inp["scales"], rotations=inp["rotations"])])
+
+
+def test_batched_views_mixed_sizes_and_empty_view():
+    """rasterize_views with views of different resolution / Gaussian count in one call, one of them empty (P = 0)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_views
+    c1 = util.make_case(P=1500, W=96, H=64, seed=3, scale_mul=2.0)
+    c2 = util.make_case(P=700, W=200, H=40, seed=9, theta=30.0, scale_mul=3.0)
+    s1, s2 = util.gpu_settings(c1), util.gpu_settings(c2)
+    i1, i2 = util.gpu_inputs(c1), util.gpu_inputs(c2)
+    e = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    empty = dict(means3D=e(0, 3), means2D=e(0, 3), opacities=e(0, 1), shs=e(0, 16, 3), scales=e(0, 3), rotations=e(0, 4))
+    kws = [{k: i1[k] for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}, empty,
+           {k: i2[k] for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}]
+    outs = rasterize_views([s1, s1, s2], kws)
+    ref1, ref2 = GaussianRasterizer(s1)(**kws[0]), GaussianRasterizer(s2)(**kws[2])
+    for a, b in zip(outs[0], ref1):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[2], ref2):
+        assert torch.equal(a, b)
+    bgimg = s1.bg.view(3, 1, 1).expand(3, 64, 96)
+    assert torch.equal(outs[1][0], bgimg) and outs[1][1].numel() == 0 and float(outs[1][2].abs().max()) == 0.0
+    (outs[0][0].mean() + outs[1][0].mean() + outs[2][0].mean()).backward()
+    assert i1["means3D"].grad is not None and i2["shs"].grad is not None
+    assert torch.isfinite(i1["means3D"].grad).all() and torch.isfinite(i2["shs"].grad).all()
