@@ -1,0 +1,186 @@
+"""Densification / pruning of mesh-anchored Gaussians with the Adam-state surgery that goes with it.
+
+Mirrors /root/reference/scene_reconstruction/gaussian_mesh.py:336-431 (prune_points, densification_postfix,
+densify_and_split, densify_and_clone) and gaussian_model.py:214-218, 266-341, 408-431 (reset_opacity,
+replace_tensor_to_optimizer, _prune_optimizer, cat_tensors_to_optimizer, prune, densify, add_densification_stats), and
+train_utils.py:324-345 (the schedule).  Device-agnostic torch (the reference hard-codes "cuda"): the parity test replays
+the reference's own run on CPU tensors (tests/golden/densify.npz).  The optimizer keeps torch.optim.Adam's state layout
+-- exp_avg / exp_avg_sq are cut or zero-extended with the parameter, `step` is kept -- so csplat.optim.GroupedAdam and
+torch.optim.Adam are interchangeable here.
+
+Multi-GPU note: every decision below is a pure function of (parameters, accumulated statistics, the RNG stream), and
+csplat.dist.reduce_densification_stats makes the statistics identical on all ranks; with the same seed the replicas stay
+bit-identical through densification without exchanging the new Gaussians."""
+import torch
+import torch.nn as nn
+
+
+def compute_barycentric_coordinates(points, triangles):
+    """meshnet/data_utils.py:494-530: (u, v, w) of `points [n,3]` in `triangles [n,3,3]` (projection onto the plane)."""
+    A, B, Cc = triangles[:, 0, :], triangles[:, 1, :], triangles[:, 2, :]
+    AB, AC, AP = B - A, Cc - A, points - A
+    dot00, dot01, dot02 = (AC * AC).sum(1), (AC * AB).sum(1), (AC * AP).sum(1)
+    dot11, dot12 = (AB * AB).sum(1), (AB * AP).sum(1)
+    denom = dot00 * dot11 - dot01 * dot01
+    v = (dot11 * dot02 - dot01 * dot12) / denom
+    w = (dot00 * dot12 - dot01 * dot02) / denom
+    return torch.stack([1.0 - v - w, v, w], dim=1)
+
+
+_ATTR = {"face_bary": "face_bary", "face_offset": "face_offset", "f_dc": "_features_dc", "f_rest": "_features_rest",
+         "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation"}
+
+
+class DensifyMixin:
+    percent_dense = 0.01
+
+    # ---- statistics (gaussian_mesh.py:121-124, gaussian_model.py:427-430, train_utils.py:326-328) -------------------
+    def densification_setup(self, percent_dense=0.01):
+        P, dev = self.face_bary.shape[0], self.face_bary.device
+        self.percent_dense = percent_dense
+        self.pos_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+        self.max_radii2D = torch.zeros((P,), device=dev)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        self.pos_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+
+    # ---- Adam-state surgery (gaussian_model.py:266-341) --------------------------------------------------------------
+    def _rebind(self, tensors):
+        for name, attr in _ATTR.items():
+            if name in tensors:
+                setattr(self, attr, tensors[name])
+
+    def replace_tensor_to_optimizer(self, tensor, name):
+        out = {}
+        for group in self.optimizer.param_groups:
+            if group["name"] == name:
+                stored = self.optimizer.state.get(group["params"][0], None)
+                stored["exp_avg"] = torch.zeros_like(tensor)
+                stored["exp_avg_sq"] = torch.zeros_like(tensor)
+                del self.optimizer.state[group["params"][0]]
+                group["params"][0] = nn.Parameter(tensor.requires_grad_(True))
+                self.optimizer.state[group["params"][0]] = stored
+                out[group["name"]] = group["params"][0]
+        return out
+
+    def _prune_optimizer(self, mask):
+        out = {}
+        for group in self.optimizer.param_groups:
+            if len(group["params"]) > 1:
+                continue
+            old = group["params"][0]
+            stored = self.optimizer.state.get(old, None)
+            if stored is not None:
+                stored["exp_avg"] = stored["exp_avg"][mask]
+                stored["exp_avg_sq"] = stored["exp_avg_sq"][mask]
+                del self.optimizer.state[old]
+                group["params"][0] = nn.Parameter(old[mask].requires_grad_(True))
+                self.optimizer.state[group["params"][0]] = stored
+            else:
+                group["params"][0] = nn.Parameter(old[mask].requires_grad_(True))
+            out[group["name"]] = group["params"][0]
+        return out
+
+    def cat_tensors_to_optimizer(self, tensors_dict):
+        out = {}
+        for group in self.optimizer.param_groups:
+            assert len(group["params"]) == 1
+            old, ext = group["params"][0], tensors_dict[group["name"]]
+            stored = self.optimizer.state.get(old, None)
+            if stored is not None:
+                stored["exp_avg"] = torch.cat((stored["exp_avg"], torch.zeros_like(ext)), dim=0)
+                stored["exp_avg_sq"] = torch.cat((stored["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+                del self.optimizer.state[old]
+                group["params"][0] = nn.Parameter(torch.cat((old, ext), dim=0).requires_grad_(True))
+                self.optimizer.state[group["params"][0]] = stored
+            else:
+                group["params"][0] = nn.Parameter(torch.cat((old, ext), dim=0).requires_grad_(True))
+            out[group["name"]] = group["params"][0]
+        return out
+
+    def reset_opacity(self):
+        """gaussian_model.py:214-217"""
+        from .gaussians import inverse_sigmoid
+        new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
+        self._rebind(self.replace_tensor_to_optimizer(new, "opacity"))
+
+    # ---- gaussian_mesh.py:336-431 -------------------------------------------------------------------------------------
+    def prune_points(self, mask):
+        valid = ~mask
+        self._rebind(self._prune_optimizer(valid))
+        self.face_ids = self.face_ids[valid]
+        self.denom = self.denom[valid]
+        self.max_radii2D = self.max_radii2D[valid]
+        self.pos_gradient_accum = self.pos_gradient_accum[valid]
+
+    def densification_postfix(self, new_face_bary, new_face_offset, new_face_ids, new_features_dc, new_features_rest,
+                              new_opacities, new_scaling, new_rotation):
+        self._rebind(self.cat_tensors_to_optimizer({
+            "face_bary": new_face_bary, "face_offset": new_face_offset, "f_dc": new_features_dc, "f_rest": new_features_rest,
+            "opacity": new_opacities, "scaling": new_scaling, "rotation": new_rotation}))
+        self.face_ids = torch.cat((self.face_ids, new_face_ids), dim=0)
+        P, dev = self.face_bary.shape[0], self.face_bary.device
+        self.pos_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+        self.max_radii2D = torch.zeros((P,), device=dev)
+
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        from .gaussians import build_rotation
+        n_init, dev = self.face_bary.shape[0], self.face_bary.device
+        padded = torch.zeros((n_init,), device=dev)
+        padded[:grads.shape[0]] = grads.squeeze()
+        sel = torch.where(padded >= grad_threshold, True, False)
+        sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
+        stds = self.get_scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+        rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
+        jitter = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1)
+        new_xyz = self.get_xyz()[sel].repeat(N, 1) + jitter
+        triangles = self.face_ids[sel]
+        triangle_edges = self.mesh.pos[self.mesh.face[:, triangles]].transpose(0, 1).repeat(N, 1, 1)
+        new_face_bary = compute_barycentric_coordinates(new_xyz, triangle_edges)
+        self.densification_postfix(
+            new_face_bary, self.face_offset[sel].repeat(N, 1), self.face_ids[sel].repeat(N),
+            self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1), self._opacity[sel].repeat(N, 1),
+            torch.log(self.get_scaling[sel].repeat(N, 1) / (0.8 * N)), self._rotation[sel].repeat(N, 1))
+        self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=dev, dtype=torch.bool))))
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        sel = torch.where(torch.norm(grads, dim=-1) >= grad_threshold, True, False)
+        sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
+        self.densification_postfix(self.face_bary[sel], self.face_offset[sel], self.face_ids[sel], self._features_dc[sel],
+                                   self._features_rest[sel], self._opacity[sel], self._scaling[sel], self._rotation[sel])
+
+    # ---- gaussian_model.py:408-425 ------------------------------------------------------------------------------------
+    def densify(self, max_grad, min_opacity, extent, max_screen_size):
+        grads = self.pos_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent)
+
+    def prune(self, max_grad, min_opacity, extent, max_screen_size):
+        mask = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            big_vs = self.max_radii2D > max_screen_size
+            big_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
+            mask = torch.logical_or(torch.logical_or(mask, big_vs), big_ws)
+        self.prune_points(mask)
+
+
+def densification(gaussians, iteration, visibility_filter, radii, viewspace_point_tensor_grad, opt, cameras_extent):
+    """train_utils.py:324-345: statistics every iteration, densify / prune on their intervals with the linearly annealed
+    thresholds.  `opt` carries the OptimizationParams fields of arguments/__init__.py:109-150."""
+    gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter])
+    gaussians.add_densification_stats(viewspace_point_tensor_grad, visibility_filter)
+    opacity_threshold = opt.opacity_threshold_fine_init - iteration * (
+        opt.opacity_threshold_fine_init - opt.opacity_threshold_fine_after) / opt.densify_until_iter
+    densify_threshold = opt.densify_grad_threshold_fine_init - iteration * (
+        opt.densify_grad_threshold_fine_init - opt.densify_grad_threshold_after) / opt.densify_until_iter
+    if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+        size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+        gaussians.densify(densify_threshold, opacity_threshold, cameras_extent, size_threshold)
+    if iteration > opt.pruning_from_iter and iteration % opt.pruning_interval == 0:
+        size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+        gaussians.prune(densify_threshold, opacity_threshold, cameras_extent, size_threshold)

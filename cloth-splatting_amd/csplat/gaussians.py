@@ -45,6 +45,9 @@ class MeshTransform(torch.autograd.Function):
         return d_v, d_b, d_r, None, None
 
 
+from .densify import DensifyMixin  # noqa: E402
+
+
 def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
@@ -59,7 +62,7 @@ def build_rotation(r):
     return R.reshape(-1, 3, 3)
 
 
-class MeshGaussians:
+class MeshGaussians(DensifyMixin):
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from gaussian_renderer import render, render_views
 from . import dist as cd
+from .densify import densification
 
 # arguments/__init__.py:109-150 overlaid by arguments/cloth_splatting/default.py:1-43
 DEFAULT_OPT = SimpleNamespace(lambda_dssim=0.05, lambda_rigid=0.3, lambda_deform_mag=0.01, lambda_momentum=0.1,
@@ -209,11 +210,13 @@ def regularization(all_vertice_deform, gaussians, opt, static=False):
 
 
 def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT,
-               background=None, static=False, view_parallel=False, batched_views=True):
+               background=None, static=False, view_parallel=False, batched_views=True, densify_opt=None):
     """One optimisation step.  Returns (psnr, loss, stats) where stats holds what densification consumes.
     view_parallel=True shards `viewpoint_cams` over the ranks of the default process group and all-reduces the
     gradients / statistics (csplat/dist.py); with one rank it is the reference's single-GPU step.
-    batched_views=True renders the step's cameras in one rasterizer call (gaussian_renderer.render_views)."""
+    batched_views=True renders the step's cameras in one rasterizer call (gaussian_renderer.render_views).
+    densify_opt: OptimizationParams-like namespace (+ cameras_extent, white_background) -> the reference's densification /
+    pruning / opacity-reset schedule runs between backward and the optimizer step (csplat/densify.py)."""
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
@@ -241,6 +244,12 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         if view_parallel and cd.is_dist():
             cd.allreduce_gradients(list(gaussians.parameters()) + list(simulator.parameters()))
             viewspace_grad, radii, visibility_filter = cd.reduce_densification_stats(viewspace_grad, radii, visibility_filter)
+        if densify_opt is not None and iteration < densify_opt.densify_until_iter:      # train_utils.py:295-304
+            densification(gaussians, iteration, visibility_filter, radii, viewspace_grad, densify_opt,
+                          getattr(densify_opt, "cameras_extent", 1.0))
+            if iteration % densify_opt.opacity_reset_interval == 0 or (
+                    getattr(densify_opt, "white_background", False) and iteration == densify_opt.densify_from_iter):
+                gaussians.reset_opacity()
         gaussians.optimizer.step()
         if not static:
             meshnet_optimizer.step()

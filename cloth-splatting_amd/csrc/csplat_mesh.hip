@@ -249,10 +249,10 @@ int csplat_mesh_transform_bwd(void *stream, int P, int V, const int64_t *face_ve
                               const float *bary, const float *rotation, const void *rest, const float *g_xyz,
                               const float *g_quat, float *d_vertices, float *d_bary, float *d_rotation) {
     CSPLAT_REQUIRE(P >= 0 && V >= 0, "csplat_mesh_transform_bwd: bad sizes");
-    CSPLAT_REQUIRE(d_vertices && d_bary && d_rotation, "csplat_mesh_transform_bwd: NULL outputs");
+    CSPLAT_REQUIRE((V == 0 || d_vertices) && (P == 0 || (d_bary && d_rotation)), "csplat_mesh_transform_bwd: NULL outputs");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(d_vertices, 0, (size_t)V * 3 * 4, s));
-    if (P == 0) return 0;
+    if (V > 0) HIP_TRY(hipMemsetAsync(d_vertices, 0, (size_t)V * 3 * 4, s));
+    if (P == 0) return 0;   // (every Gaussian pruned: the vertex gradient is zero)
     k_mesh_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, face_vertex_ids, vertices, bary, rotation, (const RestFace *)rest, g_xyz, g_quat,
                                             d_vertices, d_bary, d_rotation);
     LAUNCH_CHECK();

@@ -273,9 +273,119 @@ def gen_simulator():
     np.savez(os.path.join(OUT, "simulator.npz"), **out)
 
 
+def gen_densify():
+    """scene_reconstruction.gaussian_mesh.MultiGaussianMesh densify / prune / opacity reset + the Adam-state surgery of
+    gaussian_model.py:266-341, run HERE on CPU tensors: the module's hard imports that are not installed (h5py, roma,
+    plyfile, simple_knn, torch_geometric, meshnet.data_utils' plotting deps) are replaced by empty shim modules -- none of
+    their symbols is reached by the methods exercised -- and `device="cuda"` in the factory calls is mapped to the CPU.
+    compute_barycentric_coordinates is taken from meshnet/data_utils.py by exec'ing that one function's source."""
+    install_pyg_shim()
+    sys.modules["torch_geometric"].utils = types.ModuleType("torch_geometric.utils")
+    sys.modules["torch_geometric.utils"] = sys.modules["torch_geometric"].utils
+    for name in ("h5py", "roma", "plyfile", "simple_knn", "simple_knn._C"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    src = open(os.path.join(REF, "meshnet", "data_utils.py")).read()
+    m = re.search(r"^def compute_barycentric_coordinates\(.*?(?=^\S)", src, re.S | re.M)
+    du = types.ModuleType("meshnet.data_utils")
+    exec(compile("import torch\n" + m.group(0), "data_utils.py:compute_barycentric_coordinates", "exec"), du.__dict__)
+    for nm in ("compute_mesh", "compute_edge_features", "load_mesh_from_h5py", "vertice_rotation"):
+        setattr(du, nm, None)
+    import meshnet
+    sys.modules["meshnet.data_utils"] = du
+    meshnet.data_utils = du
+
+    def cpu_factory(fn):
+        def w(*a, **k):
+            if k.get("device") is not None and "cuda" in str(k["device"]):
+                k["device"] = "cpu"
+            return fn(*a, **k)
+        return w
+    saved = {n: getattr(torch, n) for n in ("zeros", "ones", "arange", "empty", "tensor", "normal")}
+    for n, f in saved.items():
+        setattr(torch, n, cpu_factory(f))
+    torch.cuda.empty_cache = lambda: None
+    try:
+        from scene_reconstruction.gaussian_mesh import MultiGaussianMesh
+        g = torch.Generator().manual_seed(77)
+        V, F, P = 12, 14, 60
+        pos = torch.rand(V, 3, generator=g)
+        face = torch.stack([torch.randperm(V, generator=g)[:3] for _ in range(F)], 1)          # [3, F]
+        pc = MultiGaussianMesh(3)
+        pc.mesh = types.SimpleNamespace(pos=pos, face=face)
+        pc.face_ids = torch.randint(0, F, (P,), generator=g)
+        mk = lambda *s, scale=1.0: torch.nn.Parameter((torch.randn(*s, generator=g) * scale))  # noqa: E731
+        bary = torch.rand(P, 3, generator=g) + 0.05
+        pc.face_bary = torch.nn.Parameter(bary / bary.sum(1, keepdim=True))
+        pc.face_offset = mk(P, 1, scale=0.01)
+        pc._features_dc, pc._features_rest = mk(P, 1, 3), mk(P, 15, 3, scale=0.1)
+        pc._opacity = mk(P, 1, scale=2.0)
+        pc._scaling = torch.nn.Parameter(torch.log(torch.rand(P, 3, generator=g) * 0.05 + 0.002))
+        pc._rotation = mk(P, 4)
+        pc.percent_dense = 0.01
+        pc.max_radii2D = torch.rand(P, generator=g) * 40.0
+        pc.pos_gradient_accum, pc.denom = torch.zeros(P, 1), torch.zeros(P, 1)
+        names = ["face_bary", "face_offset", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+        params = [pc.face_bary, pc.face_offset, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation]
+        lrs = [1.6e-4, 1.6e-4, 2.5e-3, 2.5e-3 / 20, 0.05, 0.005, 0.001]
+        pc.optimizer = torch.optim.Adam([{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(params, lrs, names)], lr=0.0,
+                                        eps=1e-15)
+        out = {"pos": pos, "face": face, "face_ids": pc.face_ids, "max_radii2D": pc.max_radii2D}
+        for n, p_ in zip(names, params):
+            out["init." + n] = p_.detach().clone()
+        grads = []
+        for it in range(3):                                    # three Adam steps so that the state is populated
+            for p_ in params:
+                p_.grad = torch.randn(p_.shape, generator=g) * 0.1
+                grads.append(p_.grad.clone())
+            pc.optimizer.step()
+        out["adam_grads"] = torch.cat([x.reshape(-1) for x in grads])
+
+        def dump(tag):
+            for grp in pc.optimizer.param_groups:
+                p_ = grp["params"][0]
+                st = pc.optimizer.state[p_]
+                out[f"{tag}.{grp['name']}"] = p_.detach().clone()
+                out[f"{tag}.{grp['name']}.exp_avg"] = st["exp_avg"].clone()
+                out[f"{tag}.{grp['name']}.exp_avg_sq"] = st["exp_avg_sq"].clone()
+                out[f"{tag}.{grp['name']}.step"] = torch.as_tensor(float(st["step"]))
+            out[f"{tag}.face_ids"] = pc.face_ids.clone()
+            out[f"{tag}.pos_gradient_accum"], out[f"{tag}.denom"] = pc.pos_gradient_accum.clone(), pc.denom.clone()
+            out[f"{tag}.max_radii2D"] = pc.max_radii2D.clone()
+        dump("stepped")
+        vsp = torch.randn(P, 3, generator=g) * 2e-4
+        upd = torch.rand(P, generator=g) > 0.3
+        out["vsp"], out["update_filter"] = vsp, upd
+        pc.add_densification_stats(vsp, upd)
+        pc.add_densification_stats(vsp * 0.5, upd)
+        dump("stats")
+        torch.manual_seed(4321)                                  # densify_and_split draws torch.normal from the global RNG
+        pc.densify(2e-4, 0.05, 1.0, None)
+        dump("densified")
+        pc.prune(2e-4, 0.3, 1.0, 20)
+        dump("pruned")
+        pc.reset_opacity()
+        dump("reset")
+        # one more Adam step after all the surgery: the state must still be consistent with the parameters
+        post = []
+        for grp in pc.optimizer.param_groups:
+            p_ = grp["params"][0]
+            p_.grad = torch.randn(p_.shape, generator=g) * 0.1
+            post.append(p_.grad.clone())
+        pc.optimizer.step()
+        out["post_grads"] = torch.cat([x.reshape(-1) for x in post])
+        dump("after_step")
+    finally:
+        for n, f in saved.items():
+            setattr(torch, n, f)
+    np.savez_compressed(os.path.join(OUT, "densify.npz"), **{k: npy(v) if torch.is_tensor(v) else v for k, v in out.items()})
+    print("densify.npz: P", P, "->", int(out["densified.face_ids"].shape[0]), "->", int(out["pruned.face_ids"].shape[0]))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
-    gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator()
+    gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

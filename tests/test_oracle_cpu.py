@@ -350,3 +350,73 @@ def test_cabi_exports_every_declared_symbol():
     o3 = (C.c_size_t * 3)()
     native.lib.csplat_image_layout(800, 800, o3)
     assert o3[0] == 0 and o3[1] >= 2500 * 8 and o3[2] - o3[1] >= 640000 * 4
+
+
+def test_densify_prune_and_adam_surgery_replay_the_reference():
+    """csplat/densify.py against the reference's own MultiGaussianMesh run (tests/golden/densify.npz, generated by
+    make_golden.gen_densify on CPU tensors): three Adam steps, two rounds of statistics, densify (clone + split, same
+    global RNG seed), prune with a screen-size limit, opacity reset, one more Adam step -- parameters, Adam moments, step
+    counters, face ids and statistics identical after every stage, for torch.optim.Adam and for GroupedAdam's state."""
+    import types
+    import torch
+    from csplat.gaussians import MeshGaussians
+    g = golden("densify.npz")
+    T = lambda a: torch.tensor(a)  # noqa: E731
+    pc = MeshGaussians(3)
+    pc.mesh = types.SimpleNamespace(pos=T(g["pos"]), face=T(g["face"]), edge_index=None)
+    pc.face_ids = T(g["face_ids"])
+    names = ["face_bary", "face_offset", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    attrs = ["face_bary", "face_offset", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    for n, a in zip(names, attrs):
+        setattr(pc, a, torch.nn.Parameter(T(g["init." + n])))
+    pc.fused = False
+    lrs = [1.6e-4, 1.6e-4, 2.5e-3, 2.5e-3 / 20, 0.05, 0.005, 0.001]
+    pc.optimizer = torch.optim.Adam([{"params": [getattr(pc, a)], "lr": lr, "name": n} for a, lr, n in zip(attrs, lrs, names)],
+                                    lr=0.0, eps=1e-15)
+    pc.densification_setup(percent_dense=0.01)
+    pc.max_radii2D = T(g["max_radii2D"])
+
+    def feed(flat):
+        off = 0
+        for grp in pc.optimizer.param_groups:
+            p = grp["params"][0]
+            p.grad = T(flat[off:off + p.numel()]).reshape(p.shape)
+            off += p.numel()
+        return off
+
+    def check(tag):
+        for grp in pc.optimizer.param_groups:
+            p, n = grp["params"][0], grp["name"]
+            st = pc.optimizer.state[p]
+            assert p is getattr(pc, dict(zip(names, attrs))[n])
+            np.testing.assert_array_equal(p.detach().numpy(), g[f"{tag}.{n}"])
+            np.testing.assert_array_equal(st["exp_avg"].numpy(), g[f"{tag}.{n}.exp_avg"])
+            np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), g[f"{tag}.{n}.exp_avg_sq"])
+            assert float(st["step"]) == float(g[f"{tag}.{n}.step"])
+        np.testing.assert_array_equal(pc.face_ids.numpy(), g[f"{tag}.face_ids"])
+        np.testing.assert_array_equal(pc.pos_gradient_accum.numpy(), g[f"{tag}.pos_gradient_accum"])
+        np.testing.assert_array_equal(pc.denom.numpy(), g[f"{tag}.denom"])
+        np.testing.assert_array_equal(pc.max_radii2D.numpy(), g[f"{tag}.max_radii2D"])
+
+    flat, per = g["adam_grads"], sum(getattr(pc, a).numel() for a in attrs)
+    for it in range(3):
+        feed(flat[it * per:(it + 1) * per])
+        pc.optimizer.step()
+    check("stepped")
+    vsp, upd = T(g["vsp"]), T(g["update_filter"])
+    pc.add_densification_stats(vsp, upd)
+    pc.add_densification_stats(vsp * 0.5, upd)
+    check("stats")
+    torch.manual_seed(4321)
+    pc.densify(2e-4, 0.05, 1.0, None)
+    assert pc.face_bary.shape[0] == g["densified.face_ids"].shape[0] == 81
+    check("densified")
+    pc.prune(2e-4, 0.3, 1.0, 20)
+    check("pruned")
+    pc.reset_opacity()
+    check("reset")
+    feed(g["post_grads"])
+    pc.optimizer.step()
+    check("after_step")
+    # the renderer-facing accessors still work on the re-created parameters
+    assert pc.get_xyz().shape == (pc.face_ids.shape[0], 3) and pc.get_features.shape[1:] == (16, 3)

@@ -163,3 +163,49 @@ def test_grouped_adam_matches_torch_adam():
         p.grad = torch.ones_like(p)
     oc.step()                                                 # torch path, must not raise
     assert all(torch.isfinite(p).all() for p in pc)
+
+
+def test_train_step_with_densification_on_gpu():
+    """The reference's densify / prune / opacity-reset schedule inside train_step on the GPU: the Gaussian count changes,
+    GroupedAdam's state follows the parameters, the fused mesh transform and the rasterizer pick up the new tensors, and
+    training keeps working (finite loss, gradients on the re-created parameters at the next step)."""
+    import bench_train as bt
+    from types import SimpleNamespace
+    from csplat import train as tr
+    from gaussian_renderer import render
+    from csplat.optim import GroupedAdam
+    dev = torch.device("cuda")
+    sc, pc, sim = bt.build(P=4000, W=160, H=128, grid=16, n_times=6, dev=dev)
+    with torch.no_grad():
+        pc._scaling.add_(0.9)
+    bg = torch.ones(3, device=dev)
+    times = [0.2, 0.4, 0.6]
+    with torch.no_grad():
+        keep = pc._features_dc.detach().clone()
+        torch.manual_seed(0)
+        pc._features_dc.add_(0.5 * torch.randn_like(pc._features_dc))
+        targets_ = [render(c, pc, sim, tr.DEFAULT_PIPE, bg).render.clamp(0, 1).clone() for c in bt.cameras(sc, times, dev)]
+        pc._features_dc.copy_(keep)
+    with torch.no_grad():
+        targets = targets_
+    cams = bt.cameras(sc, times, dev, targets)
+    pc.training_setup()
+    pc.densification_setup(percent_dense=0.01)
+    mopt = GroupedAdam(sim.parameters(), lr=3e-4)
+    dopt = SimpleNamespace(densify_until_iter=100, densify_from_iter=2, densification_interval=3, opacity_reset_interval=9,
+                           pruning_from_iter=2, pruning_interval=4, densify_grad_threshold_fine_init=2e-5,
+                           densify_grad_threshold_after=2e-5, opacity_threshold_fine_init=0.05, opacity_threshold_fine_after=0.05,
+                           cameras_extent=1.0, white_background=False)
+    counts = []
+    torch.manual_seed(0)
+    for it in range(1, 10):
+        p, l, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, densify_opt=dopt)
+        assert torch.isfinite(l) and torch.isfinite(p)
+        counts.append(pc.face_bary.shape[0])
+        for grp in pc.optimizer.param_groups:
+            q = grp["params"][0]
+            assert q.shape[0] == counts[-1]
+            st = pc.optimizer.state.get(q, {})
+            assert not st or st["exp_avg"].shape == q.shape == st["exp_avg_sq"].shape     # (face_offset never gets a gradient)
+        assert pc.face_ids.shape[0] == counts[-1] == pc.max_radii2D.shape[0] == pc.denom.shape[0]
+    assert len(set(counts)) > 1 and max(counts) > 4000          # it did densify (and prune)
