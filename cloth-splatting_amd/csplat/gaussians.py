@@ -122,6 +122,16 @@ class MeshGaussians(DensifyMixin):
         self._opacity = nn.Parameter(opacity_logits.clone().requires_grad_(True))
         return self
 
+    def save_ply(self, path):
+        """gaussian_mesh.py:438-465 (point_cloud.ply in plyfile's layout + the mesh side-car), csplat/ply.py"""
+        from .ply import save_gaussians
+        save_gaussians(self, path)
+
+    def load_ply(self, path, device="cuda"):
+        """gaussian_mesh.py:467-481"""
+        from .ply import load_gaussians
+        return load_gaussians(self, path, device)
+
     def parameters(self):
         return [self.face_bary, self.face_offset, self._features_dc, self._features_rest, self._opacity, self._scaling,
                 self._rotation]

@@ -420,3 +420,52 @@ def test_densify_prune_and_adam_surgery_replay_the_reference():
     check("after_step")
     # the renderer-facing accessors still work on the re-created parameters
     assert pc.get_xyz().shape == (pc.face_ids.shape[0], 3) and pc.get_features.shape[1:] == (16, 3)
+
+
+def test_ply_layout_and_round_trip(tmp_path):
+    """csplat/ply.py: the byte layout plyfile produces for PlyElement.describe(float32 records, 'vertex') written with
+    PlyData([el]).write(path) on a little-endian host (known-answer header + packed little-endian records), the
+    reference's attribute order (gaussian_model.py:181-193 + b1,b2,b3,o,id), and MeshGaussians.save_ply -> load_ply."""
+    import types
+    import torch
+    from csplat import ply
+    from csplat.gaussians import MeshGaussians
+    names = ["x", "y", "z"]
+    ply.write_ply(tmp_path / "t.ply", names, np.array([[1.0, 2.0, 3.0], [-0.5, 0.25, 4.0]]))
+    raw = (tmp_path / "t.ply").read_bytes()
+    head = b"ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+    assert raw == head + np.array([1.0, 2.0, 3.0, -0.5, 0.25, 4.0], "<f4").tobytes()
+    d = ply.read_ply(tmp_path / "t.ply")
+    assert list(d) == names and d["y"].tolist() == [2.0, 0.25]
+    (tmp_path / "a.ply").write_text("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 2\nproperty float x\nproperty uchar r\n"
+                                    "end_header\n0.5 7\n1.5 9\n")
+    d = ply.read_ply(tmp_path / "a.ply")
+    assert d["x"].tolist() == [0.5, 1.5] and d["r"].dtype == np.uint8 and d["r"].tolist() == [7, 9]
+    assert ply.attribute_names(3, 45) == (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] +
+                                          [f"f_rest_{i}" for i in range(45)] + ["opacity", "scale_0", "scale_1", "scale_2", "rot_0",
+                                                                              "rot_1", "rot_2", "rot_3", "b1", "b2", "b3", "o", "id"])
+    g = torch.Generator().manual_seed(1)
+    V, F, P = 9, 8, 17
+    pc = MeshGaussians(3)
+    pc.fused = False
+    pos = torch.rand(V, 3, generator=g)
+    face = torch.stack([torch.randperm(V, generator=g)[:3] for _ in range(F)], 1)
+    ei = torch.randint(0, V, (2, 20), generator=g)
+    pc.mesh = types.SimpleNamespace(pos=pos, face=face, edge_index=ei)
+    pc.face_ids = torch.randint(0, F, (P,), generator=g)
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g))  # noqa: E731
+    pc.face_bary, pc.face_offset = torch.nn.Parameter(torch.rand(P, 3, generator=g) + 0.1), mk(P, 1)
+    pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation = mk(P, 1, 3), mk(P, 15, 3), mk(P, 1), mk(P, 3), mk(P, 4)
+    pc.save_ply(str(tmp_path / "it"))
+    d = ply.read_ply(tmp_path / "it" / "point_cloud.ply")
+    assert len(d) == 6 + 3 + 45 + 1 + 3 + 4 + 5 and d["x"].shape == (P,)
+    np.testing.assert_array_equal(np.stack([d["x"], d["y"], d["z"]], 1), pc.get_xyz().detach().numpy())
+    np.testing.assert_array_equal(d["f_rest_1"], pc._features_rest.detach().transpose(1, 2).flatten(start_dim=1).numpy()[:, 1])
+    q = MeshGaussians(3)
+    q.fused = False
+    q.load_ply(str(tmp_path / "it"), device="cpu")
+    for a in ("face_bary", "face_offset", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert isinstance(getattr(q, a), torch.nn.Parameter)
+        np.testing.assert_array_equal(getattr(q, a).detach().numpy(), getattr(pc, a).detach().numpy())
+    assert torch.equal(q.face_ids, pc.face_ids) and torch.equal(q.mesh.face, face) and torch.equal(q.mesh.pos, pos)
+    np.testing.assert_array_equal(q.get_xyz().detach().numpy(), pc.get_xyz().detach().numpy())
