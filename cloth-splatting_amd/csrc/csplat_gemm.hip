@@ -27,15 +27,38 @@ constexpr int GK = 128, GN = 128, WT_STRIDE = 129;   // W^T rows padded: conflic
 //   ADD       : + add_pre[row][col] before the ReLU and/or + add_post[row][col] after the LayerNorm (row-aligned [M][128]
 //               operands: the second half of a split first Linear, the residual connection).  Loaded inline between the
 //               stores, i.e. off the tuned path: meant for the node-level calls (M = N nodes), not the edge-level ones.
-template <bool GATHER, bool LN, bool ADD>
-__global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A, const float *__restrict__ W,
+//   B3        : the product itself through bf16 MFMAs instead of fp32 MFMAs: both operands are cut into three bf16 pieces
+//               (x = x1 + x2 + x3 exactly to 24 bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)) and the six
+//               partial products that matter (x1w1, x1w2, x2w1, x1w3, x3w1, x2w2; the dropped ones are < 2^-24 relative) are
+//               accumulated in fp32 by v_mfma_f32_32x32x16_bf16, which runs at 16x the fp32 MFMA rate on gfx950 (measured
+//               2.4 PFLOP/s vs 155 TFLOP/s): 6/16 of the MFMA time for fp32-level accuracy (tested: 1e-5 vs fp64).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WB_STRIDE = 136;        // bf16 elements per W row in LDS (272 B: conflict-free 16-byte reads at row stride)
+constexpr size_t L128_LDS_F32 = (size_t)GK * WT_STRIDE * 4, L128_LDS_B3 = (size_t)3 * GN * WB_STRIDE * 2;
+
+template <bool GATHER, bool LN, bool ADD, bool B3>
+__global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, const float *A, const float *__restrict__ W,
                                                     const float *__restrict__ bias, float alpha, int relu,
                                                     const float *__restrict__ ga, const int64_t *__restrict__ ia,
                                                     const float *__restrict__ gb, const int64_t *__restrict__ ib,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                     const float *add_pre, const float *add_post, float *out) {
-    extern __shared__ float s_wt[];   // [GK][WT_STRIDE]: s_wt[k * WT_STRIDE + j] = W[j][k]
-    {   // all 16 float4 loads of a thread in flight at once; W[j][4i..4i+3] -> rows 4i..4i+3 of W^T
+    extern __shared__ float s_wt[];   // fp32 path: [GK][WT_STRIDE], s_wt[k * WT_STRIDE + j] = W[j][k];  B3: bf16 [3][GN][WB_STRIDE]
+    constexpr int NW = B3 ? 8 : 4;    // wavefronts per workgroup
+    if (B3) {
+        __bf16 *wb = reinterpret_cast<__bf16 *>(s_wt);
+        for (int t = threadIdx.x; t < GN * GK; t += NW * 64) {
+            const int j = t >> 7, k = t & 127;
+            const float x = W[t];
+            const __bf16 p1 = (__bf16)x;
+            const float r1 = x - (float)p1;
+            const __bf16 p2 = (__bf16)r1;
+            const __bf16 p3 = (__bf16)(r1 - (float)p2);
+            wb[(size_t)j * WB_STRIDE + k] = p1;
+            wb[(size_t)(GN + j) * WB_STRIDE + k] = p2;
+            wb[(size_t)(2 * GN + j) * WB_STRIDE + k] = p3;
+        }
+    } else {   // all 16 float4 loads of a thread in flight at once; W[j][4i..4i+3] -> rows 4i..4i+3 of W^T
         float4 wv[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) wv[i] = reinterpret_cast<const float4 *>(W)[threadIdx.x + 256 * i];
@@ -69,11 +92,11 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
         const int64_t row = tile * 32 + r32;
         return row < M ? row : M - 1;
     };
-    const int64_t tstride = (int64_t)gridDim.x * 4;
+    const int64_t tstride = (int64_t)gridDim.x * NW;
     float4 X[16];                                  // k = 64h .. 64h + 63 of this lane's row
     int ja = 0, jb = 0, jan = 0, jbn = 0;          // gather rows of tile row r32 (node ids: < 2^31)
     {
-        const int64_t row = row_of((int64_t)blockIdx.x * 4 + w);
+        const int64_t row = row_of((int64_t)blockIdx.x * NW + w);
         const float4 *ap = reinterpret_cast<const float4 *>(A + row * GK + 64 * h);
 #pragma unroll
         for (int q = 0; q < 16; q++) X[q] = ap[q];
@@ -81,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing from the prologue is pending at loop entry
     const float *wrow = s_wt + (64 * h) * WT_STRIDE + r32;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntile; tile += tstride) {
+    for (int64_t tile = (int64_t)blockIdx.x * NW + w; tile < ntile; tile += tstride) {
         const int64_t nrow = row_of(tile + tstride);
         const float4 *apn = reinterpret_cast<const float4 *>(A + nrow * GK + 64 * h);
         if (GATHER) { jan = (int)ia[nrow]; jbn = (int)ib[nrow]; }
@@ -90,34 +113,85 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
-        // B operand: step s (this lane contributes k = 64h + s) and column tile c read s_wt[(64h + s)][32c + r32].
-        // Explicitly double-buffered in groups of 2 steps: the 8 ds_reads of group g + 1 are issued before the 8 MFMAs
-        // (512 cycles) of group g, so the MFMA pipe never waits on LDS latency; sched_barrier pins the order.
-        float bc[8], bn[8];
+        if constexpr (B3) {
+            // step s covers k = 64h + 8s .. + 7 of this lane's row (chunks X[2s], X[2s + 1]); the B operand of (split p,
+            // column tile c, step s) is the 16 contiguous bytes wb[p][32c + r32][64h + 8s ..]: W is staged untransposed.
+            // The next tile's rows are fetched into a second register set at the top of the phase (the bf16 phase is too
+            // short to hide the last in-place re-fills).
+            float4 Y[16];
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+            for (int q = 0; q < 16; q++) Y[q] = apn[q];
+            const __bf16 *wlane = reinterpret_cast<const __bf16 *>(s_wt) + (size_t)r32 * WB_STRIDE + 64 * h;
+            auto ldw = [&](int p, int c, int st) {
+                return *reinterpret_cast<const bf16x8 *>(wlane + ((size_t)p * GN + 32 * c) * WB_STRIDE + 8 * st);
+            };
+            bf16x8 wc[3], wn[3];
 #pragma unroll
-            for (int c = 0; c < 4; c++) bc[4 * u + c] = wrow[u * WT_STRIDE + 32 * c];
+            for (int p = 0; p < 3; p++) wc[p] = ldw(p, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 32; g++) {
-            if (g < 31) {
+            for (int st = 0; st < 8; st++) {
+                const float x8[8] = {X[2 * st].x, X[2 * st].y, X[2 * st].z, X[2 * st].w,
+                                     X[2 * st + 1].x, X[2 * st + 1].y, X[2 * st + 1].z, X[2 * st + 1].w};
+                bf16x8 a1, a2, a3;
 #pragma unroll
-                for (int u = 0; u < 2; u++)
+                for (int j = 0; j < 8; j++) {
+                    a1[j] = (__bf16)x8[j];
+                    const float r1 = x8[j] - (float)a1[j];
+                    a2[j] = (__bf16)r1;
+                    a3[j] = (__bf16)(r1 - (float)a2[j]);
+                }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) bn[4 * u + c] = wrow[(2 * (g + 1) + u) * WT_STRIDE + 32 * c];
+                for (int c = 0; c < 4; c++) {
+                    const int cn = (c + 1) & 3, sn = c == 3 ? st + 1 : st;
+                    if (sn < 8) {
+#pragma unroll
+                        for (int p = 0; p < 3; p++) wn[p] = ldw(p, cn, sn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // next operands requested before this group's 6 MFMAs (192 cycles)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wc[0], acc[c], 0, 0, 0);   // small terms first
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wc[2], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wc[1], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wc[0], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wc[1], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wc[0], acc[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < 3; p++) wc[p] = wn[p];
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);     // reads first: they complete under this group's 512 MFMA cycles
-            const float4 xq = X[g >> 1];
-            const float av[2] = {(g & 1) ? xq.z : xq.x, (g & 1) ? xq.w : xq.y};
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's rows (requested a whole phase ago), before any store
 #pragma unroll
+            for (int q = 0; q < 16; q++) X[q] = Y[q];
+        } else {
+            // B operand: step s (this lane contributes k = 64h + s) and column tile c read s_wt[(64h + s)][32c + r32].
+            // Explicitly double-buffered in groups of 2 steps: the 8 ds_reads of group g + 1 are issued before the 8 MFMAs
+            // (512 cycles) of group g, so the MFMA pipe never waits on LDS latency; sched_barrier pins the order.
+            float bc[8], bn[8];
+    #pragma unroll
             for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[4 * u + c], acc[c], 0, 0, 0);
-            if (g & 1) X[g >> 1] = apn[g >> 1];   // chunk consumed: fetch the next tile's into the same registers
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 8; i++) bc[i] = bn[i];
+    #pragma unroll
+                for (int c = 0; c < 4; c++) bc[4 * u + c] = wrow[u * WT_STRIDE + 32 * c];
+    #pragma unroll
+            for (int g = 0; g < 32; g++) {
+                if (g < 31) {
+    #pragma unroll
+                    for (int u = 0; u < 2; u++)
+    #pragma unroll
+                        for (int c = 0; c < 4; c++) bn[4 * u + c] = wrow[(2 * (g + 1) + u) * WT_STRIDE + 32 * c];
+                }
+                __builtin_amdgcn_sched_barrier(0);     // reads first: they complete under this group's 512 MFMA cycles
+                const float4 xq = X[g >> 1];
+                const float av[2] = {(g & 1) ? xq.z : xq.x, (g & 1) ? xq.w : xq.y};
+    #pragma unroll
+                for (int u = 0; u < 2; u++)
+    #pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[4 * u + c], acc[c], 0, 0, 0);
+                if (g & 1) X[g >> 1] = apn[g >> 1];   // chunk consumed: fetch the next tile's into the same registers
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < 8; i++) bc[i] = bn[i];
+            }
         }
         // C/D layout of 32x32 tiles: column = lane & 31, tile row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         float o[16][4];
@@ -128,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
         if (GATHER) {
             // The gather rows of the tile go through a 256-byte wave-private LDS strip (DS ops of one wave execute in
             // order: no barrier), so each row's index is one broadcast ds_read instead of a cross-lane shuffle.
-            int *strip = reinterpret_cast<int *>(s_wt + GK * WT_STRIDE) + w * 64;
+            int *strip = reinterpret_cast<int *>(reinterpret_cast<char *>(s_wt) + (B3 ? L128_LDS_B3 : L128_LDS_F32)) + w * 64;
             if (h == 0) { strip[r32] = ja; strip[32 + r32] = jb; }
             // four batches of 4 rows: the 32 gather loads of a batch are in flight together (no stores pending here)
 #pragma unroll
@@ -158,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_linear128(int64_t M, const float *A,
         // 10..15 of the next tile, issued in the last third of the MFMA phase) may stay in flight: they are not needed
         // before step 40 of the next tile, by which time these stores have drained.  (A second register set filled at
         // the top of the phase was measured: same time, 60 more VGPRs.)
-        __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6)
+        if (!B3) __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6)
         ja = jan; jb = jbn;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -302,6 +376,9 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
 
 }  // namespace
 
+static unsigned g_linear128_mode = 1;   // bit 0: products through the 3-way bf16 split (csplat_linear128_mode); default on
+extern "C" int csplat_linear128_mode(unsigned mode) { g_linear128_mode = mode; return 0; }
+
 extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, const float *bias, float alpha, int relu,
                                 const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
                                 const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,
@@ -316,13 +393,18 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
     const bool add = add_pre != nullptr || add_post != nullptr;
     CSPLAT_REQUIRE(!(add && gather), "csplat_linear128: row-aligned addends and gathers are not combined (no caller needs it)");
     static int s_ok = -1;
-    const size_t lds = (size_t)GK * WT_STRIDE * 4 + 4 * 64 * sizeof(int);   // W^T + the gather-index strips
+    const size_t lds = L128_LDS_F32 + 4 * 64 * sizeof(int);      // W^T + the gather-index strips
+    const size_t lds_b3 = L128_LDS_B3 + 8 * 64 * sizeof(int);    // three bf16 pieces of W + strips (one workgroup per CU)
     if (s_ok < 0) {
         s_ok = 1;
-        const void *fns[6] = {(const void *)k_linear128<false, false, false>, (const void *)k_linear128<false, true, false>,
-                              (const void *)k_linear128<true, false, false>,  (const void *)k_linear128<true, true, false>,
-                              (const void *)k_linear128<false, false, true>,  (const void *)k_linear128<false, true, true>};
+        const void *fns[6] = {(const void *)k_linear128<false, false, false, false>, (const void *)k_linear128<false, true, false, false>,
+                              (const void *)k_linear128<true, false, false, false>,  (const void *)k_linear128<true, true, false, false>,
+                              (const void *)k_linear128<false, false, true, false>,  (const void *)k_linear128<false, true, true, false>};
         for (const void *f : fns) s_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        const void *fb[6] = {(const void *)k_linear128<false, false, false, true>, (const void *)k_linear128<false, true, false, true>,
+                             (const void *)k_linear128<true, false, false, true>,  (const void *)k_linear128<true, true, false, true>,
+                             (const void *)k_linear128<false, false, true, true>,  (const void *)k_linear128<false, true, true, true>};
+        for (const void *f : fb) s_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b3) == hipSuccess;
         s_ok &= hipFuncSetAttribute((const void *)k_linear128_rows32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         s_ok &= hipFuncSetAttribute((const void *)k_linear128_rows32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         (void)hipGetLastError();
@@ -340,11 +422,19 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
         LAUNCH_CHECK();
         return 0;
     }
-    int grid = (int)((ntile + 3) / 4);
-    if (grid > 512) grid = 512;    // persistent: 2 workgroups per CU, W^T staged once each
-#define CSPLAT_L128(G, L, D)                                                                                                 \
-    k_linear128<G, L, D><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, ln_gamma, \
-                                                ln_beta, ln_eps, add_pre, add_post, out)
+    const bool b3 = (g_linear128_mode & 1u) != 0;
+    int grid = b3 ? (int)((ntile + 7) / 8) : (int)((ntile + 3) / 4);
+    const int cap = b3 ? 256 : 512;    // persistent: 16 / 2 x 4 wavefronts per CU, weights staged once per workgroup
+    if (grid > cap) grid = cap;
+#define CSPLAT_L128(G, L, D)                                                                                                  \
+    do {                                                                                                                      \
+        if (b3)                                                                                                               \
+            k_linear128<G, L, D, true><<<grid, 512, lds_b3, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, \
+                                                                 ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);          \
+        else                                                                                                                  \
+            k_linear128<G, L, D, false><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b,  \
+                                                               ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);            \
+    } while (0)
     if (add && ln) CSPLAT_L128(false, true, true);
     else if (add) CSPLAT_L128(false, false, true);
     else if (gather && ln) CSPLAT_L128(true, true, false);

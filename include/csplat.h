@@ -242,6 +242,11 @@ int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, co
  * (both or neither), ln_gamma / ln_beta [128] (both or neither; biased variance, ln_eps), add_pre / add_post [M][128] or
  * NULL (not together with the gathers), out [M][128]; out may alias A (and add_post may then alias both).
  * fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate). A, W and out 16-byte aligned. */
+/* how csplat_linear128 forms its products: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products); 1 = three bf16 pieces per
+ * operand and the six significant partial products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; error ~3 x 2^-24 relative
+ * per term -- measured rms error vs fp64 1.2e-7, the fp32-MFMA path and the library sgemm 1.5e-7 --; 6/16 of the
+ * matrix-core time).  Default 1.  Applies to the persistent (edge-level) kernel. */
+int csplat_linear128_mode(unsigned mode);
 int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, const float *bias, float alpha, int relu,
                      const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
                      const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,

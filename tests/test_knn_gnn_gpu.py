@@ -157,10 +157,13 @@ def test_config4_size_rollout_step_properties():
 
 @pytest.mark.parametrize("M", [0, 1, 33, 4100, 70001])     # <= 65536 rows: one-tile-per-workgroup kernel; above: persistent kernel
 @pytest.mark.parametrize("gather,ln", [(False, False), (True, False), (False, True), (True, True)])
-def test_linear128_vs_fp64(M, gather, ln):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_linear128_vs_fp64(M, gather, ln, mode):
     """csplat_linear128 (fp32 MFMA, fused bias / gather / ReLU / LayerNorm) against fp64 torch; ragged M covers the row
     masking of the last 32-row tile.  Tolerance 1e-5 relative to the output scale (fp32 summation-order noise only)."""
     from meshnet.graph_ops import linear128
+    from csplat import native as _n
+    _n.check(_n.lib.csplat_linear128_mode(mode), "csplat_linear128_mode")   # 1: products through the 3-way bf16 split
     gen = torch.Generator().manual_seed(M + 7 * gather + 13 * ln)
     A = torch.randn(M, 128, generator=gen).cuda()
     W = (torch.randn(128, 128, generator=gen) * 0.1).cuda()
@@ -197,6 +200,7 @@ def test_linear128_vs_fp64(M, gather, ln):
             o2 = linear128(A2, W, b, alpha=4.0, relu=True, gather=(ga, ia, gb, ib) if gather else None,
                            layer_norm=norm if ln else None, out=A2)
         assert torch.equal(o2, out)
+    _n.check(_n.lib.csplat_linear128_mode(1), "csplat_linear128_mode")       # back to the default
 
 
 def test_rollout_inference_path_matches_autograd_path():

@@ -21,14 +21,20 @@ ia = torch.arange(M, device=dev) // 30
 ib = (ia + torch.randint(-64, 65, (M,), device=dev)).clamp_(0, Nn - 1)
 ln = torch.nn.LayerNorm(128).to(dev)
 out = torch.empty_like(A)
-for name, kw in (("plain", {}), ("ln", {"layer_norm": ln}), ("gather", {"gather": (ga, ia, gb, ib)})):
-    with torch.no_grad():
-        for _ in range(3):
-            linear128(A, W, b, relu=True, out=out, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            linear128(A, W, b, relu=True, out=out, **kw)
-        e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / reps * 1e3
-    print(f"{name:7s} {us:8.1f} us  {2 * M * 128 * 128 / us / 1e6:7.1f} TFLOP/s  {2 * M * 512 / us / 1e3:7.1f} GB/s", flush=True)
+from csplat import native as _n  # noqa: E402
+for mode in (0, 1):
+  _n.check(_n.lib.csplat_linear128_mode(mode), "mode")
+  print("mode", mode, "(0 = fp32 MFMA, 1 = 3-way bf16 split)", flush=True)
+  for name, kw in (("plain", {}), ("ln", {"layer_norm": ln}), ("gather", {"gather": (ga, ia, gb, ib)})):
+      with torch.no_grad():
+          for _ in range(3):
+              linear128(A, W, b, relu=True, out=out, **kw)
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          for _ in range(reps):
+              linear128(A, W, b, relu=True, out=out, **kw)
+          e1.record(); torch.cuda.synchronize()
+      us = e0.elapsed_time(e1) / reps * 1e3
+      print(f"{name:7s} {us:8.1f} us  {2 * M * 128 * 128 / us / 1e6:7.1f} TFLOP/s  {2 * M * 512 / us / 1e3:7.1f} GB/s", flush=True)
+
+_n.check(_n.lib.csplat_linear128_mode(1), "mode")

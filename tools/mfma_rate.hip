@@ -132,6 +132,39 @@ void run3(long long M, int wgs) {
     printf("mem probe MODE=%d wgs=%d: %.1f us  %.2f TB/s\n", MODE, wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
     hipFree(A); hipFree(out);
 }
+
+// ---- bf16 32x32x16 rate (the 3-way bf16 split that emulates fp32 products needs 6 of these per fp32 32x32x16 block)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int NACC>
+__global__ __launch_bounds__(256) void kb(int iters, float *out) {
+    f32x16 acc[NACC];
+    for (int c = 0; c < NACC; c++) for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (__bf16)(threadIdx.x * 1e-3f + i); b[i] = (__bf16)(blockIdx.x * 1e-3f - i); }
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int c = 0; c < NACC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int c = 0; c < NACC; c++) for (int r = 0; r < 16; r++) s += acc[c][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC>
+void runb(int wgs, int iters) {
+    float *out; hipMalloc(&out, (size_t)wgs * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kb<NACC><<<wgs, 256>>>(iters, out);
+    hipEventRecord(e0);
+    kb<NACC><<<wgs, 256>>>(iters, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double nmfma = (double)wgs * 4 * iters * 8.0 * NACC;
+    printf("bf16 32x32x16 NACC=%d wgs=%d: %.3f ms  %.1f TFLOP/s  %.1f cycles/MFMA/SIMD at 2.4 GHz\n", NACC, wgs, ms,
+           nmfma * 32768.0 / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (nmfma / 1024.0));
+    hipFree(out);
+}
 template <int NACC>
 void run(int wgs, int threads, int iters) {
     float *out; long long *clk, h[2];
@@ -155,6 +188,7 @@ int main() {
     run<4>(512, 256, 4096);    // 2 waves per SIMD
     run<1>(256, 256, 8192);    // dependent chain
     run<2>(256, 256, 8192);
+    runb<4>(512, 4096); runb<1>(256, 8192);
     run3<0>(300000, 2048); run3<0>(300000, 512);
     run3<1>(300000, 512); run3<2>(300000, 512); run3<3>(300000, 512);
     run3<1>(300000, 2048); run3<2>(300000, 2048); run3<3>(300000, 2048);
