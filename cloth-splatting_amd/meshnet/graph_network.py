@@ -49,18 +49,26 @@ class Encoder(nn.Module):
                                                  nedge_out_features), nn.LayerNorm(nedge_out_features)])
 
     def forward(self, x: torch.Tensor, edge_features: torch.Tensor):
-        e = edge_features
-        for m in self.edge_fn[0].children():
-            e = linear_rows(e, m.weight, m.bias) if isinstance(m, nn.Linear) else m(e)
+        e = _tail(self.edge_fn[0], edge_features, first_has_act=False, skip_first=False)
         return self.node_fn(x), self.edge_fn[1](e)
 
 
-def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool) -> torch.Tensor:
-    """run build_mlp's layers after the first Linear (whose activation has already been applied iff first_has_act)."""
+def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool, skip_first: bool = True) -> torch.Tensor:
+    """run build_mlp's layers after the first Linear (whose activation has already been applied iff first_has_act);
+    skip_first=False runs the whole MLP."""
     mods = list(seq_mlp.children())
-    start = 2 if first_has_act else 1  # skip NN-0 (+ Act-0 when it was fused)
-    for m in mods[start:]:
-        h = linear_rows(h, m.weight, m.bias) if isinstance(m, nn.Linear) else m(h)   # tall inputs: split-K weight gradient
+    start = (2 if first_has_act else 1) if skip_first else 0  # skip NN-0 (+ Act-0 when it was fused)
+    mods = mods[start:]
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):   # tall inputs: csplat_linear128 both ways (ReLU fused), split-K weight gradient
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            h = linear_rows(h, m.weight, m.bias, relu=fuse)
+            i += 2 if fuse else 1
+        else:
+            h = m(h)
+            i += 1
     return h
 
 

@@ -141,24 +141,41 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
 
 
 class SplitKLinear(torch.autograd.Function):
-    """y = x @ weight^T + bias for edge-level activations (rows = E ~ 3e5, 128 features) under autograd.
-    The weight gradient g^T @ x is a [128 x E] x [E x 128] product: a single GEMM call reduces over E inside a handful
-    of workgroups (630 us at E = 300k on MI355X); cut into row chunks and run as one batched GEMM + a sum it fills the
-    chip (122 us).  Forward and the input gradient are the plain library calls."""
+    """y = relu?(x @ weight^T + bias) for edge-level activations (rows = E ~ 3e5) under autograd.
+    128 -> 128 fp32 layers run through csplat_linear128 both ways (forward with bias / ReLU in the epilogue, input gradient
+    as the same kernel on the transposed weight): 76 us against 142 us + a ReLU pass for the library call.  The weight
+    gradient g^T @ x is a [128 x E] x [E x 128] product: a single GEMM call reduces over E inside a handful of workgroups
+    (630 us at E = 300k on MI355X); cut into row chunks and run as one batched GEMM + a sum it fills the chip (122 us)."""
 
     CHUNK = 3072
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+    def _fast(x, weight):
+        return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and \
+            x.shape[1] == 128 and tuple(weight.shape) == (128, 128)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu=False):
+        fast = SplitKLinear._fast(x, weight)
+        if fast:
+            out = linear128(x, weight, bias, relu=relu)
+        else:
+            out = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+            if relu:
+                out = out.relu_()
+        ctx.save_for_backward(x, weight, out if relu else None)
+        ctx.has_bias, ctx.relu, ctx.fast = bias is not None, bool(relu), fast
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight, out = ctx.saved_tensors
         g = g.contiguous()
-        dx = g @ weight if ctx.needs_input_grad[0] else None
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, out, 0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear128(g, weight.t()) if ctx.fast else g @ weight
         dw = None
         if ctx.needs_input_grad[1]:
             M, C = x.shape[0], x.shape[0] // SplitKLinear.CHUNK
@@ -169,11 +186,12 @@ class SplitKLinear(torch.autograd.Function):
             if m0 < M:
                 dw = dw + g[m0:].t() @ xc[m0:]
         db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear_rows(x, lin_weight, lin_bias, min_rows: int = 16384):
-    """nn.Linear forward that switches to SplitKLinear for tall inputs while a graph is being recorded."""
+def linear_rows(x, lin_weight, lin_bias, min_rows: int = 16384, relu: bool = False):
+    """nn.Linear (+ ReLU) forward that switches to SplitKLinear for tall inputs while a graph is being recorded."""
     if x.shape[0] >= min_rows and torch.is_grad_enabled() and (lin_weight.requires_grad or x.requires_grad):
-        return SplitKLinear.apply(x, lin_weight, lin_bias)
-    return torch.nn.functional.linear(x, lin_weight, lin_bias)
+        return SplitKLinear.apply(x, lin_weight, lin_bias, relu)
+    y = torch.nn.functional.linear(x, lin_weight, lin_bias)
+    return y.relu() if relu else y

@@ -236,12 +236,26 @@ def test_splitk_linear_gradients_match_autograd():
     W = (torch.randn(128, 128, generator=gen) * 0.1).cuda().requires_grad_()
     b = torch.randn(128, generator=gen).cuda().requires_grad_()
     gy = torch.randn(M, 128, generator=gen).cuda()
-    y = linear_rows(x, W, b, min_rows=1024)
-    assert y.grad_fn is not None and "SplitKLinear" in type(y.grad_fn).__name__
-    y.backward(gy)
-    got = [t.grad.clone() for t in (x, W, b)]
-    for t in (x, W, b):
-        t.grad = None
-    torch.nn.functional.linear(x.double(), W.double(), b.double()).backward(gy.double())
-    for a, r in zip(got, (x, W, b)):
-        assert rel_err(a.cpu().numpy(), r.grad.cpu().numpy()) < 1e-5
+    for relu in (False, True):
+        for t in (x, W, b):
+            t.grad = None
+        y = linear_rows(x, W, b, min_rows=1024, relu=relu)
+        assert y.grad_fn is not None and "SplitKLinear" in type(y.grad_fn).__name__
+        y.backward(gy)
+        got = [t.grad.clone() for t in (x, W, b)]
+        for t in (x, W, b):
+            t.grad = None
+        yr = torch.nn.functional.linear(x.double(), W.double(), b.double())
+        yr = yr.relu() if relu else yr
+        assert rel_err(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-5
+        yr.backward(gy.double())
+        for a, r in zip(got, (x, W, b)):
+            assert rel_err(a.cpu().numpy(), r.grad.cpu().numpy()) < 1e-5
+    # a width the fused kernel does not cover takes the library path inside the same Function
+    x2 = torch.randn(20000, 4, generator=gen).cuda().requires_grad_()
+    W2 = torch.randn(128, 4, generator=gen).cuda().requires_grad_()
+    y2 = linear_rows(x2, W2, None, min_rows=1024, relu=True)
+    y2.sum().backward()
+    ref = (x2.detach().double() @ W2.detach().double().t())
+    assert rel_err(y2.detach().cpu().numpy(), ref.relu().cpu().numpy()) < 1e-5
+    assert rel_err(W2.grad.cpu().numpy(), ((ref > 0).double().t() @ x2.detach().double()).cpu().numpy()) < 1e-5
