@@ -109,6 +109,7 @@ def main():
         for k, v in keep.items():
             params[k].copy_(v)
 
+    targets_stacked = torch.stack(targets).contiguous()
     flat_names = ("means3D", "opacities", "shs", "scales", "rotations")
     R_per_view = [0] * V
 
@@ -123,13 +124,16 @@ def main():
             p.grad = None
         m2ds = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in range(V)]
         if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
-            outs = rasterize_views(settings, [dict(means3D=params["means3D"], means2D=m2ds[i], opacities=params["opacities"],
-                                                   shs=params["shs"], scales=params["scales"],
-                                                   rotations=params["rotations"]) for i in range(V)])
+            colors, _ = rasterize_views(settings, [dict(means3D=params["means3D"], means2D=m2ds[i], opacities=params["opacities"],
+                                                        shs=params["shs"], scales=params["scales"],
+                                                        rotations=params["rotations"]) for i in range(V)], stacked=True)
+            # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285); x V = the sum of the
+            # per-view means that the camera-by-camera branch below forms
+            return_loss = l1_loss(colors, targets_stacked) * float(V)
         else:
             outs = [render(i, m2ds[i]) for i in range(V)]
-        losses = [l1_loss(outs[i][0], targets[i]) for i in range(V)]      # fused HIP L1 (loss + gradient in one pass)
-        loss = torch.stack(losses).sum()
+            return_loss = torch.stack([l1_loss(outs[i][0], targets[i]) for i in range(V)]).sum()
+        loss = return_loss
         loss.backward()         # the batched node fans the views' K7/K8 out over the same per-view streams
         m2d_grads = [m.grad for m in m2ds]
         if world > 1:

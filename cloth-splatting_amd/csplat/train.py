@@ -221,8 +221,11 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         gaussians.oneupSHdegree()
     cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
     images, gts, radii_l, vis_l, vsp_l, verts = [], [], [], [], [], []
-    pkgs = render_views(cams, gaussians, simulator, pipe, background, render_static=static) if batched_views else \
-        [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
+    stacked = None
+    if batched_views:
+        pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True)
+    else:
+        pkgs = [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
     for cam, pkg in zip(cams, pkgs):
         images.append(pkg.render.unsqueeze(0))
         gts.append(cam.original_image.to(pkg.render.device).unsqueeze(0))
@@ -233,7 +236,8 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     all_vertice_deform = torch.cat(verts, 0)
     radii = torch.cat(radii_l, 0).max(dim=0).values
     visibility_filter = torch.cat(vis_l).any(dim=0)
-    image_tensor, gt_image_tensor = torch.cat(images, 0), torch.cat(gts, 0)
+    image_tensor = stacked if stacked is not None else torch.cat(images, 0)
+    gt_image_tensor = torch.cat(gts, 0)
     psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
     loss = image_losses(image_tensor, gt_image_tensor, opt) + regularization(all_vertice_deform, gaussians, opt, static)
     loss.backward()

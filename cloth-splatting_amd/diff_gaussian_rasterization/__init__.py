@@ -185,7 +185,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
              7: ("dL_dcov3D", _n.ACC_COV3D)}
 
     @staticmethod
-    def forward(ctx, settings, *flat):
+    def forward(ctx, settings, stacked, *flat):
         V, n = len(settings), _RasterizeGaussiansBatch.NIN
         assert len(flat) == V * n
         views = []
@@ -197,6 +197,11 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         streams = _view_streams(dev, V, main)
         arr = (_n.CsplatView * V)()
         chunks = [dict() for _ in range(V)]
+        # stacked: the V images land in ONE [V, 3, H, W] tensor (what the reference builds with torch.cat before the loss,
+        # scene_reconstruction/train_utils.py:262-270) and that tensor is the node's first output
+        if stacked:
+            assert all((v.H, v.W) == (views[0].H, views[0].W) for v in views), "stacked output needs equal image sizes"
+            colors = torch.empty(V, 3, views[0].H, views[0].W, dtype=torch.float32, device=dev)
 
         def _alloc(ctx_, chunk, nbytes):     # all on the caller's stream: the library fences the view streams around it
             try:
@@ -208,7 +213,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         cb = _n.ALLOC_FN(_alloc)
         for i, (v, st) in enumerate(zip(views, streams)):
             rs, w = v.rs, arr[i]
-            v.color = torch.empty(3, v.H, v.W, dtype=torch.float32, device=dev)
+            v.color = colors[i] if stacked else torch.empty(3, v.H, v.W, dtype=torch.float32, device=dev)
             v.depth = torch.empty(1, v.H, v.W, dtype=torch.float32, device=dev)
             v.radii = torch.empty(v.P, dtype=torch.int32, device=dev)
             w.stream = st.cuda_stream
@@ -226,10 +231,14 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         for i, v in enumerate(views):
             v.num_rendered = int(arr[i].num_rendered)
             v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
-            outs += [v.color, v.radii, v.depth]
-            saved += list(v.saved())
+            outs += [v.radii, v.depth] if stacked else [v.color, v.radii, v.depth]
+            saved += list(v.saved()[:-1]) + ([] if stacked else [v.color])
             ctx.mark_non_differentiable(v.radii, v.depth)
-        ctx.nsaved = len(views[0].saved())
+        if stacked:
+            outs = [colors] + outs
+            saved.append(colors)
+        ctx.stacked = bool(stacked)
+        ctx.nsaved = len(views[0].saved()) - (1 if stacked else 0)
         ctx.save_for_backward(*saved)
         # which view first received each input tensor OBJECT (shared parameters get one gradient buffer)
         ctx.first_of = [[next(j for j in range(i + 1) if flat[j * n + k] is flat[i * n + k]) for k in range(n)] for i in range(V)]
@@ -245,10 +254,15 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         V = len(views)
         dev = views[0].dev
         main = torch.cuda.current_stream(dev)
-        active = [i for i in range(V) if grads[3 * i] is not None]
+        if ctx.stacked:
+            gcol = [None] * V if grads[0] is None else [grads[0][i] for i in range(V)]
+            colors = ctx.saved_tensors[-1]
+        else:
+            gcol = [grads[3 * i] for i in range(V)]
+        active = [i for i in range(V) if gcol[i] is not None]
         out = [None] * (V * n)
         if not active:
-            return (None,) + tuple(out)
+            return (None, None) + tuple(out)
         # ONE allocation for every gradient, temporary and K7 record of the step (returned gradients are views of it)
         plan, owner, total = [], {}, 0
 
@@ -260,7 +274,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         gs = []
         for i in active:
             v = views[i]
-            means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii, color = ctx.saved_tensors[i * k:(i + 1) * k]
+            means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = ctx.saved_tensors[i * k:i * k + 7]
             P, M = v.P, v.M
             ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.num_rendered)) // 4 + 64),
                    "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {1: (None, (P, 3))}}
@@ -285,7 +299,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     if present[slot]:
                         ent["ret"][slot] = (ent[field], shapes[slot])
             plan.append(ent)
-            gs.append(_f32c(grads[3 * i], dev))
+            gs.append(_f32c(gcol[i], dev))
         big = torch.empty(max(total, 64), dtype=torch.float32, device=dev)
         base = big.data_ptr()
         sub = (_n.CsplatView * len(active))()
@@ -308,13 +322,16 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             rc = _n.lib.csplat_backward_views(len(active), C.cast(sub, C.c_void_p), main.cuda_stream)
         _n.check(rc, "csplat_backward_views")
         del keep      # (freed on the caller's stream, i.e. after the join fence)
-        return (None,) + tuple(out)
+        return (None, None) + tuple(out)
 
 
-def rasterize_views(settings, inputs):
+def rasterize_views(settings, inputs, stacked=False):
     """Batched entry (no counterpart upstream, where cameras are rendered one by one in a Python loop --
     scene_reconstruction/train_utils.py:204-260): `settings` a list of GaussianRasterizationSettings, `inputs` a list of
-    dicts with the keyword names of GaussianRasterizer.forward.  Returns a list of (color, radii, depth)."""
+    dicts with the keyword names of GaussianRasterizer.forward.  Returns a list of (color, radii, depth); with
+    stacked=True (equal image sizes) returns (colors [V,3,H,W], [(colors[i], radii, depth), ...]) where `colors` is the
+    differentiable output -- the batch the reference assembles with torch.cat before its losses -- and colors[i] are
+    plain slices of it."""
     flat = []
     for kw in inputs:
         shs, cp = kw.get("shs"), kw.get("colors_precomp")
@@ -324,7 +341,10 @@ def rasterize_views(settings, inputs):
         if ((sc is None or ro is None) and cov is None) or ((sc is not None or ro is not None) and cov is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         flat += [kw["means3D"], kw["means2D"], shs, cp, kw["opacities"], sc, ro, cov]
-    res = _RasterizeGaussiansBatch.apply(tuple(settings), *flat)
+    res = _RasterizeGaussiansBatch.apply(tuple(settings), bool(stacked), *flat)
+    if stacked:
+        colors = res[0]
+        return colors, [(colors[i], res[1 + 2 * i], res[2 + 2 * i]) for i in range(len(settings))]
     return [tuple(res[3 * i:3 * i + 3]) for i in range(len(settings))]
 
 

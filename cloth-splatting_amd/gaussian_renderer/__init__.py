@@ -115,16 +115,22 @@ def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scalin
 
 
 def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-                 no_shadow=False, render_static=False, project_vertices=False):
+                 no_shadow=False, render_static=False, project_vertices=False, return_stacked=False):
     """render() for every camera of a training step in one rasterizer call (diff_gaussian_rasterization.rasterize_views:
     one HIP stream per view, the views' kernels overlap, shared parameters get one gradient buffer).  Same results as
     [render(c, ...) for c in viewpoint_cameras]; no counterpart upstream, whose train loop renders camera by camera
-    (scene_reconstruction/train_utils.py:204-260)."""
+    (scene_reconstruction/train_utils.py:204-260).  return_stacked=True also returns the [V,3,H,W] image batch (None when
+    the cameras differ in size) so that the caller's losses need no torch.cat."""
     shared, prepared = {}, []
     for cam in viewpoint_cameras:
         prepared.append(_prepare(cam, pc, simulator, pipe, bg_color, scaling_modifier, override_color, None, render_static,
                                  shared))
     if not prepared:
-        return []
-    outs = rasterize_views([p[0] for p in prepared], [p[1] for p in prepared])
-    return [_package(cam, out, p[2], project_vertices) for cam, out, p in zip(viewpoint_cameras, outs, prepared)]
+        return ([], None) if return_stacked else []
+    sizes = {(p[0].image_height, p[0].image_width) for p in prepared}
+    if len(sizes) == 1:   # the images of the step in ONE [V,3,H,W] tensor: each RenderResults.render is a slice of it
+        stacked, outs = rasterize_views([p[0] for p in prepared], [p[1] for p in prepared], stacked=True)
+    else:
+        stacked, outs = None, rasterize_views([p[0] for p in prepared], [p[1] for p in prepared])
+    res = [_package(cam, out, p[2], project_vertices) for cam, out, p in zip(viewpoint_cameras, outs, prepared)]
+    return (res, stacked) if return_stacked else res

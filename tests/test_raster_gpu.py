@@ -322,6 +322,23 @@ def test_batched_views_equal_single_view_calls():
     o1, g1 = run(False)
     o2, g2 = run(True)
     o3, g3 = run(True)      # stream pool reuse
+
+    def run_stacked():      # the [V,3,H,W] batch as the differentiable output
+        for k in names:
+            inp[k].grad = None
+        m2d = [torch.zeros(cases[0]["P"], 3, device="cuda", requires_grad=True) for _ in cases]
+        kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"],
+                    scales=inp["scales"], rotations=inp["rotations"]) for i in range(len(cases))]
+        colors, outs = rasterize_views(settings, kws, stacked=True)
+        assert colors.shape == (len(cases), 3, cases[0]["H"], cases[0]["W"]) and colors.requires_grad
+        (((colors - torch.stack(tgt)) ** 2).mean(dim=(1, 2, 3))).sum().backward()
+        torch.cuda.synchronize()
+        return colors, outs, [inp[k].grad.clone() for k in names] + [m.grad.clone() for m in m2d]
+    cs, os_, gs_ = run_stacked()
+    for i, a in enumerate(o1):
+        assert torch.equal(cs[i], a[0]) and torch.equal(os_[i][1], a[1]) and torch.equal(os_[i][2], a[2])
+    for x, y in zip(g1, gs_):
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
     for a, b, c in zip(o1, o2, o3):
         for x, y, z in zip(a, b, c):
             assert torch.equal(x, y) and torch.equal(x, z)
