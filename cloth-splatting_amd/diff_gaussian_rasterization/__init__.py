@@ -246,24 +246,19 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             v.drop_inputs()
         ctx.views, ctx.arr = views, arr
         ctx.set_materialize_grads(False)     # an unused view arrives as None in backward() and costs nothing
+        ctx.plan = None
+        if any(ctx.needs_input_grad):
+            # the GPU is busy with K3..K6 of the views right now: prepare the backward call in its shadow
+            ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, *grads):
-        views, k, arr, n = ctx.views, ctx.nsaved, ctx.arr, _RasterizeGaussiansBatch.NIN
-        V = len(views)
-        dev = views[0].dev
-        main = torch.cuda.current_stream(dev)
-        if ctx.stacked:
-            gcol = [None] * V if grads[0] is None else [grads[0][i] for i in range(V)]
-            colors = ctx.saved_tensors[-1]
-        else:
-            gcol = [grads[3 * i] for i in range(V)]
-        active = [i for i in range(V) if gcol[i] is not None]
-        out = [None] * (V * n)
-        if not active:
-            return (None, None) + tuple(out)
-        # ONE allocation for every gradient, temporary and K7 record of the step (returned gradients are views of it)
+    def _plan_backward(views, saved, k, arr, first_of, active, dev):
+        """Everything of the backward call that does not depend on the incoming gradient values: ONE allocation for every
+        gradient, temporary and K7 record of the step (returned gradients are views of it), the csplat_view array with all
+        pointers but dL_dpix, the accumulate masks of shared parameters.  Built at the end of forward(), while the
+        compositing kernels run, so that backward() is left with pointer patching and one library call."""
+        n = _RasterizeGaussiansBatch.NIN
         plan, owner, total = [], {}, 0
 
         def reserve(numel):
@@ -271,13 +266,12 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             off = total
             total += (int(numel) + 63) & ~63          # 256-byte granules
             return off
-        gs = []
         for i in active:
             v = views[i]
-            means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = ctx.saved_tensors[i * k:i * k + 7]
+            means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = saved[i * k:i * k + 7]
             P, M = v.P, v.M
             ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.num_rendered)) // 4 + 64),
-                   "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {1: (None, (P, 3))}}
+                   "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {}}
             ent["ret"][1] = (ent["dL_dmean2D"], (P, 3))
             shapes = {0: (P, 3), 2: (P, M, 3) if sh is not None else None, 3: (P, 3), 4: (P, 1),
                       5: (P, 3) if scales is not None else None, 6: (P, 4) if rotations is not None else None, 7: (P, 6)}
@@ -287,7 +281,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 if shapes[slot] is None:
                     ent[field] = None
                     continue
-                j = ctx.first_of[i][slot]
+                j = first_of[i][slot]
                 if present[slot] and j != i and j in active and (slot != 2 or M == 16):
                     ent[field] = owner[(j, slot)]
                     ent["mask"] |= bit
@@ -299,15 +293,15 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     if present[slot]:
                         ent["ret"][slot] = (ent[field], shapes[slot])
             plan.append(ent)
-            gs.append(_f32c(gcol[i], dev))
         big = torch.empty(max(total, 64), dtype=torch.float32, device=dev)
         base = big.data_ptr()
         sub = (_n.CsplatView * len(active))()
+        out = [None] * (len(views) * n)
         for a, i in enumerate(active):
             ent = plan[a]
             C.memmove(C.byref(sub[a]), C.byref(arr[i]), C.sizeof(_n.CsplatView))
             w = sub[a]
-            w.dL_dpix, w.scratch, w.accmask = _n.ptr(gs[a]), base + 4 * ent["scratch"], ent["mask"]
+            w.scratch, w.accmask = base + 4 * ent["scratch"], ent["mask"]
             for field in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh",
                           "dL_dscale", "dL_drot"):
                 off = ent.get(field)
@@ -317,12 +311,31 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 for d in shape:
                     numel *= d
                 out[i * n + slot] = big[off:off + numel].view(shape)
-        keep = (big, gs)
+        return {"active": list(active), "big": big, "sub": sub, "out": out}
+
+    @staticmethod
+    def backward(ctx, *grads):
+        views, k, arr = ctx.views, ctx.nsaved, ctx.arr
+        V = len(views)
+        dev = views[0].dev
+        main = torch.cuda.current_stream(dev)
+        if ctx.stacked:
+            gcol = [None] * V if grads[0] is None else [grads[0][i] for i in range(V)]
+        else:
+            gcol = [grads[3 * i] for i in range(V)]
+        active = [i for i in range(V) if gcol[i] is not None]
+        if not active:
+            return (None, None) + (None,) * (V * _RasterizeGaussiansBatch.NIN)
+        plan, ctx.plan = ctx.plan, None                         # (one use: the buffers are handed to autograd)
+        if plan is None or plan["active"] != active:            # a view's image went unused, or a second backward pass
+            plan = _RasterizeGaussiansBatch._plan_backward(views, ctx.saved_tensors, k, arr, ctx.first_of, active, dev)
+        gs = [_f32c(gcol[i], dev) for i in active]
+        for a, g in enumerate(gs):
+            plan["sub"][a].dL_dpix = _n.ptr(g)
         with torch.cuda.device(dev):
-            rc = _n.lib.csplat_backward_views(len(active), C.cast(sub, C.c_void_p), main.cuda_stream)
+            rc = _n.lib.csplat_backward_views(len(active), C.cast(plan["sub"], C.c_void_p), main.cuda_stream)
         _n.check(rc, "csplat_backward_views")
-        del keep      # (freed on the caller's stream, i.e. after the join fence)
-        return (None, None) + tuple(out)
+        return (None, None) + tuple(plan["out"])
 
 
 def rasterize_views(settings, inputs, stacked=False):
