@@ -374,6 +374,171 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
     }
 }
 
+// ---- the whole node update of an InteractionNetwork layer (graph_network.py:203-222) in ONE launch, plus the two
+// node-level products the NEXT layer's edge kernel gathers (x_i / x_j column blocks of its first Linear):
+//   h   = relu(agg @ Wa^T + x @ Wx^T + b0);  h = relu(h @ W2^T + b2);  x' = LN(h @ W3^T + b3) + x;
+//   xa' = x' @ Wi^T;  xb' = x' @ Wj^T                                    (skipped when Wi == NULL)
+// Six 32-row x 128 x 128 products per workgroup; a workgroup owns one 32-row tile, its 4 waves split the 128 output
+// columns (each stages only its own 16 KB slice of the current weight, wave-private), activations pass from layer to
+// layer through a 32 x 128 LDS tile.  Replaces six launches of k_linear128_rows32 (each ~10 us of fixed latency for
+// 10^4 rows) per message-passing step.
+constexpr int ACT_STRIDE = 132, NU_KH = 64;   // weights are staged half of K at a time: 52 KB of LDS, 3 workgroups per CU
+__global__ __launch_bounds__(256) void k_node_update(int64_t N, const float *__restrict__ agg, const float *__restrict__ x,
+                                                      const float *__restrict__ Wa, const float *__restrict__ Wx,
+                                                      const float *__restrict__ b0, const float *__restrict__ W2,
+                                                      const float *__restrict__ b2, const float *__restrict__ W3,
+                                                      const float *__restrict__ b3, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float eps, const float *__restrict__ Wi,
+                                                      const float *__restrict__ Wj, float *__restrict__ x_new,
+                                                      float *__restrict__ xa, float *__restrict__ xb) {
+    extern __shared__ float s_dyn[];
+    float (*s_w)[NU_KH * SW_STRIDE] = reinterpret_cast<float (*)[NU_KH * SW_STRIDE]>(s_dyn);   // per wave: half a W^T slice [64][33]
+    float (*s_act)[ACT_STRIDE] = reinterpret_cast<float (*)[ACT_STRIDE]>(s_dyn + 4 * NU_KH * SW_STRIDE);   // [32 rows][128 (+4)]
+    float (*s_part)[32][4] = reinterpret_cast<float (*)[32][4]>(s_dyn + 4 * NU_KH * SW_STRIDE + 32 * ACT_STRIDE);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
+    const int64_t tile = blockIdx.x;
+    const int col = 32 * w + r32;
+    int64_t row = tile * 32 + r32;
+    row = row < N ? row : N - 1;
+
+    // lane-half h of a wave contributes k = 64 kh + 32 h + (0..31) in K-half kh: registers X[8 kh + q] = k .. k + 3 at q
+    // weight staging is software-pipelined: `prefetch` issues the global loads of the NEXT half slice into registers while
+    // the MFMAs of the current one run; `commit` drops them into this wave's LDS slice (wave-private: no barrier)
+    float4 wv[8];
+    auto prefetch = [&](const float *W, int kh) {   // this wave's 32 output features, K-half kh
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = lane + 64 * i, jj = idx >> 4, k4 = (idx & 15) * 4;
+            wv[i] = *reinterpret_cast<const float4 *>(W + (size_t)(32 * w + jj) * GK + 64 * kh + k4);
+        }
+    };
+    auto commit = [&]() {                           // -> s_w[w][k'][jj]
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = lane + 64 * i, jj = idx >> 4, k4 = (idx & 15) * 4;
+            s_w[w][(k4 + 0) * SW_STRIDE + jj] = wv[i].x;
+            s_w[w][(k4 + 1) * SW_STRIDE + jj] = wv[i].y;
+            s_w[w][(k4 + 2) * SW_STRIDE + jj] = wv[i].z;
+            s_w[w][(k4 + 3) * SW_STRIDE + jj] = wv[i].w;
+        }
+    };
+    auto mma_half = [&](const float4 (&X)[16], int kh, f32x16 acc) {
+        const float *wrow = &s_w[w][(32 * h) * SW_STRIDE + r32];
+        float bv[32];                         // all 32 B operands of the half requested up front: the MFMA chain then
+#pragma unroll                                // only waits for the first one
+        for (int t = 0; t < 32; t++) bv[t] = wrow[t * SW_STRIDE];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float4 xq = X[8 * kh + q];
+            const float av[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[4 * q + u], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // acc += X @ W^T[:, this wave's columns]; half 0 of W is already in `wv`, half 0 of `Wnext` is requested on the way out
+    auto mma = [&](const float *W, const float *Wnext, const float4 (&X)[16], f32x16 acc) {
+        commit();
+        prefetch(W, 1);
+        acc = mma_half(X, 0, acc);
+        commit();
+        if (Wnext) prefetch(Wnext, 0);
+        return mma_half(X, 1, acc);
+    };
+    auto load_global = [&](const float *src, float4 (&X)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            X[q] = *reinterpret_cast<const float4 *>(src + row * GK + 64 * (q >> 3) + 32 * h + 4 * (q & 7));
+    };
+    auto load_act = [&](float4 (&X)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) X[q] = *reinterpret_cast<const float4 *>(&s_act[r32][64 * (q >> 3) + 32 * h + 4 * (q & 7)]);
+    };
+    auto zero = [&]() { f32x16 a; for (int r = 0; r < 16; r++) a[r] = 0.f; return a; };
+    // C/D layout: column = lane & 31 (+ 32w), tile row = (reg & 3) + 8 * (reg >> 2) + 4h
+    auto store_act = [&](const f32x16 &acc, const float *bias, bool relu) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc[r] + bv;
+            s_act[(r & 3) + 8 * (r >> 2) + 4 * h][col] = relu ? fmaxf(v, 0.f) : v;
+        }
+    };
+    float4 X[16], X2[16];
+    // ---- layer 0: two products into one accumulator
+    prefetch(Wa, 0);
+    load_global(agg, X);
+    load_global(x, X2);
+    f32x16 acc = mma(Wa, Wx, X, zero());
+    acc = mma(Wx, W2, X2, acc);
+    store_act(acc, b0, true);
+    __syncthreads();
+    // ---- layer 1
+    load_act(X);
+    acc = mma(W2, W3, X, zero());
+    __syncthreads();                          // every wave has read the tile before anyone overwrites it
+    store_act(acc, b2, true);
+    __syncthreads();
+    // ---- layer 2 + LayerNorm + residual
+    load_act(X);
+    acc = mma(W3, Wi, X, zero());
+    float v[16], mean[16];
+    {
+        const float bv = b3[col];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v[r] = acc[r] + bv;
+            float sum = v[r];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            if (r32 == 0) s_part[0][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sum;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float *p = s_part[0][(r & 3) + 8 * (r >> 2) + 4 * h];
+        mean[r] = ((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN);
+        const float d = v[r] - mean[r];
+        float sq = d * d;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+        if (r32 == 0) s_part[1][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sq;
+    }
+    __syncthreads();                          // (also: every wave is done reading s_act)
+    {
+        const float gcol = gamma[col], becol = beta[col];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int trow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float *p = s_part[1][trow];
+            const float rstd = rsqrtf(((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN) + eps);
+            const int64_t orow = tile * 32 + trow;
+            const int64_t crow = orow < N ? orow : N - 1;
+            const float o = (v[r] - mean[r]) * rstd * gcol + becol + x[crow * GN + col];
+            if (orow < N) x_new[orow * GN + col] = o;
+            s_act[trow][col] = o;
+        }
+    }
+    if (Wi == nullptr) return;                // (uniform)
+    __syncthreads();
+    // ---- the next layer's node-level products
+    load_act(X);
+    acc = mma(Wi, Wj, X, zero());
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < N) xa[orow * GN + col] = acc[r];
+    }
+    acc = mma(Wj, nullptr, X, zero());
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < N) xb[orow * GN + col] = acc[r];
+    }
+}
+
 }  // namespace
 
 static unsigned g_linear128_mode = 1;   // bit 0: products through the 3-way bf16 split (csplat_linear128_mode); default on
@@ -442,6 +607,34 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
     else if (ln) CSPLAT_L128(false, true, false);
     else CSPLAT_L128(false, false, false);
 #undef CSPLAT_L128
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const float *x, const float *Wa, const float *Wx,
+                                      const float *b0, const float *W2, const float *b2, const float *W3, const float *b3,
+                                      const float *ln_gamma, const float *ln_beta, float ln_eps, const float *Wi_next,
+                                      const float *Wj_next, float *x_new, float *xa_next, float *xb_next) {
+    CSPLAT_REQUIRE(N >= 0 && (N == 0 || (agg && x && Wa && Wx && b0 && W2 && b2 && W3 && b3 && ln_gamma && ln_beta && x_new)),
+                   "csplat_gnn_node_update: bad arguments");
+    CSPLAT_REQUIRE((Wi_next == nullptr) == (Wj_next == nullptr) && (Wi_next == nullptr || (xa_next && xb_next)),
+                   "csplat_gnn_node_update: next-layer weights and outputs come together");
+    CSPLAT_REQUIRE(x_new != x && x_new != agg, "csplat_gnn_node_update: x_new must not alias an input (the residual reads x)");
+    const uintptr_t al = (uintptr_t)agg | (uintptr_t)x | (uintptr_t)Wa | (uintptr_t)Wx | (uintptr_t)W2 | (uintptr_t)W3 |
+                         (uintptr_t)Wi_next | (uintptr_t)Wj_next;
+    CSPLAT_REQUIRE((al & 15u) == 0, "csplat_gnn_node_update: operands must be 16-byte aligned");
+    if (N == 0) return 0;
+    const size_t lds = (size_t)(4 * NU_KH * SW_STRIDE + 32 * ACT_STRIDE + 2 * 32 * 4) * sizeof(float);
+    static int s_ok = -1;
+    if (s_ok < 0) {
+        s_ok = hipFuncSetAttribute((const void *)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    CSPLAT_REQUIRE(s_ok, "csplat_gnn_node_update: 52 KB of dynamic LDS refused by the runtime");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    k_node_update<<<(unsigned)((N + 31) / 32), 256, lds, s>>>(N, agg, x, Wa, Wx, b0, W2, b2, W3, b3, ln_gamma, ln_beta, ln_eps,
+                                                             Wi_next, Wj_next, x_new, xa_next, xb_next);
     LAUNCH_CHECK();
     return 0;
 }

@@ -18,7 +18,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, linear128, linear_rows
+from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, linear128, linear_rows, node_update
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -154,21 +154,27 @@ class InteractionNetwork(nn.Module):
             self._wsplit_key = key
         return self._wsplit
 
-    def forward_inference(self, x, edge_index, e0, scale: float):
-        """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd, returns
-        the updated nodes only.  Per layer the [E,128] activations make three read+write passes (one per Linear, with
-        gather / bias / ReLU / LayerNorm in the epilogues) and one read by the segmented sum; the node level is six
-        launches of the same kernel (split first layers, residual in the last epilogue)."""
+    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None):
+        """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd.
+        Per layer the [E,128] activations make three read+write passes (one per Linear, with gather / bias / ReLU /
+        LayerNorm in the epilogues) and one read by the segmented sum; the node level is ONE launch
+        (csplat_gnn_node_update) that also forms the x_i / x_j column-block products of `next_layer`'s first edge
+        Linear.  Returns (x_new, xa_next, xb_next); xa / xb for this layer are computed here when not handed in."""
         csr = GraphCSR.get(edge_index, x.shape[0])
         w_i, w_j, w_e, w_agg, w_x = self._split_weights()
-        xa = linear128(x, w_i)                                   # contribution of x_i = x[edge_index[1]]
-        xb = linear128(x, w_j)                                   # contribution of x_j = x[edge_index[0]]
+        if xa is None:
+            xa = linear128(x, w_i)                               # contribution of x_i = x[edge_index[1]]
+            xb = linear128(x, w_j)                               # contribution of x_j = x[edge_index[0]]
         h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
         msg = _fused_tail(self.edge_fn, h)
         agg = SegmentSum.apply(msg, csr)
+        lins = list(self.node_fn[0].children())[0::2]
+        if len(lins) == 3:
+            nw = next_layer._split_weights() if next_layer is not None else (None, None)
+            return node_update(agg, x, w_agg, w_x, lins[0].bias, lins[1], lins[2], self.node_fn[1], nw[0], nw[1])
         t = linear128(x, w_x, out=xa)
         hn = linear128(agg, w_agg, self.node_fn[0][0].bias, relu=True, add_pre=t, out=t)
-        return _fused_tail(self.node_fn, hn, add_post=x)
+        return _fused_tail(self.node_fn, hn, add_post=x), None, None
 
 
 class Processor(nn.Module):
@@ -187,8 +193,10 @@ class Processor(nn.Module):
         if len(self.gnn_stacks) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks):
             # rollout: every layer doubles the edge features (F7), so carry e0 and the scalar 2^l instead of 15 [E,128] passes
             e0, scale = edge_features.contiguous(), 1.0
-            for gnn in self.gnn_stacks:
-                x = gnn.forward_inference(x, edge_index, e0, scale)
+            xa = xb = None
+            for l, gnn in enumerate(self.gnn_stacks):
+                nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
+                x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt)
                 scale *= 2.0
             return x, e0 * scale
         for gnn in self.gnn_stacks:

@@ -140,6 +140,29 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
     return out
 
 
+def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w_j_next=None):
+    """Inference-only node update of one InteractionNetwork layer in ONE launch (csplat_gnn_node_update, include/csplat.h):
+        x_new = LN(W3 relu(W2 relu(Wa agg + Wx x + b0) + b2) + b3) + x,   xa' = x_new Wi'^T,   xb' = x_new Wj'^T
+    Returns (x_new, xa', xb') (the last two None without next-layer weights).  All operands fp32, 128 wide."""
+    _n.require_cuda(x)
+    agg, x = _f32(agg), _f32(x)
+    N = x.shape[0]
+    assert tuple(agg.shape) == (N, 128) and x.shape[1] == 128
+    c = lambda t: t.detach().contiguous()  # noqa: E731
+    x_new = torch.empty_like(x)
+    have_next = w_i_next is not None
+    xa = torch.empty_like(x) if have_next else None
+    xb = torch.empty_like(x) if have_next else None
+    ops = [c(w_agg), c(w_x), c(b0), c(lin2.weight), c(lin2.bias), c(lin3.weight), c(lin3.bias), c(layer_norm.weight),
+           c(layer_norm.bias)]
+    nxt = [c(w_i_next), c(w_j_next)] if have_next else [None, None]
+    with torch.cuda.device(x.device):
+        _n.check(_n.lib.csplat_gnn_node_update(_n.stream_handle(x.device), N, _n.ptr(agg), _n.ptr(x), *[_n.ptr(t) for t in ops],
+                                               float(layer_norm.eps), _n.ptr(nxt[0]), _n.ptr(nxt[1]), _n.ptr(x_new), _n.ptr(xa),
+                                               _n.ptr(xb)), "csplat_gnn_node_update")
+    return x_new, xa, xb
+
+
 class SplitKLinear(torch.autograd.Function):
     """y = relu?(x @ weight^T + bias) for edge-level activations (rows = E ~ 3e5) under autograd.
     128 -> 128 fp32 layers run through csplat_linear128 both ways (forward with bias / ReLU in the epilogue, input gradient

@@ -242,6 +242,17 @@ int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, co
  * (both or neither), ln_gamma / ln_beta [128] (both or neither; biased variance, ln_eps), add_pre / add_post [M][128] or
  * NULL (not together with the gathers), out [M][128]; out may alias A (and add_post may then alias both).
  * fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate). A, W and out 16-byte aligned. */
+/* The node update of one InteractionNetwork layer (/root/reference/meshnet/graph_network.py:203-222, two hidden layers of
+ * width 128) in one launch, optionally followed by the next layer's node-level products:
+ *   h = relu(agg @ Wa^T + x @ Wx^T + b0);  h = relu(h @ W2^T + b2);  x_new = LayerNorm(h @ W3^T + b3) + x;
+ *   xa_next = x_new @ Wi_next^T;  xb_next = x_new @ Wj_next^T          (Wi_next, Wj_next both NULL: skipped)
+ * agg, x, x_new, xa_next, xb_next [N][128]; all weights [128][128] row-major, contiguous (Wa / Wx are the two column
+ * blocks of the first Linear's weight, cut by the caller); exact fp32 MFMA.  x_new must not alias agg or x. */
+int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const float *x, const float *Wa, const float *Wx,
+                           const float *b0, const float *W2, const float *b2, const float *W3, const float *b3,
+                           const float *ln_gamma, const float *ln_beta, float ln_eps, const float *Wi_next,
+                           const float *Wj_next, float *x_new, float *xa_next, float *xb_next);
+
 /* how csplat_linear128 forms its products: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products); 1 = three bf16 pieces per
  * operand and the six significant partial products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; error ~3 x 2^-24 relative
  * per term -- measured rms error vs fp64 1.2e-7, the fp32-MFMA path and the library sgemm 1.5e-7 --; 6/16 of the
