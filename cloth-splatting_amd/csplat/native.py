@@ -149,3 +149,8 @@ def prof_read(cls):
     ms, n = C.c_double(0), _i64(0)
     check(lib.csplat_prof_read(k, C.byref(ms), C.byref(n)), "csplat_prof_read")
     return ms.value, n.value
+
+
+# experiment hook: CSPLAT_DEBUG_FLAGS=<int> applies csplat_debug_flags at import (A/B runs of bench.py without code edits)
+if os.environ.get("CSPLAT_DEBUG_FLAGS"):
+    check(lib.csplat_debug_flags(int(os.environ["CSPLAT_DEBUG_FLAGS"], 0)), "csplat_debug_flags")

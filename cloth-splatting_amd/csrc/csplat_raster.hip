@@ -558,10 +558,38 @@ __device__ __forceinline__ float wave_max(float v) { return -wave_min(-v); }
 // power <= -0.5*d^2/lambda_max(cov2D); so it is irrelevant to EVERY pixel of an axis-aligned box whose distance to
 // the centre satisfies d^2 > cut2 = 2*lambda_max*ln(255*opacity) (K1 stores cut2 with a safety margin).  Lane l
 // tests entry l of a 64-entry group against the wave's box of still-live pixels; the ballot is the work list.
-__device__ __forceinline__ bool box_hit(float2 c, float cut2, float bx0, float bx1, float by0, float by1) {
-    const float dx = fmaxf(fmaxf(bx0 - c.x, c.x - bx1), 0.f);
-    const float dy = fmaxf(fmaxf(by0 - c.y, c.y - by1), 0.f);
-    return dx * dx + dy * dy <= cut2;
+//
+// Second, exact stage (scene_1: a quarter of the circle test's survivors reach no pixel -- the projected Gaussians are
+// anisotropic and the circle of radius sqrt(cut2) over-covers their ellipse): alpha >= 1/255 <=> q(d) = A dx^2 + 2B dx dy
+// + C dy^2 <= tau = 2 ln(255 opacity), so the entry is irrelevant to the whole box if the MINIMUM of q over the box
+// exceeds tau.  q is convex: the minimum is 0 if the centre is inside, else it lies on one of the (at most two) edges
+// facing the centre, where q is a 1-D quadratic whose minimiser is clamped to the edge.  ~35 VALU per entry per chunk,
+// against ~26 per survivor and pixel row saved.  Margins: 1e-3 relative + 1e-3 absolute on tau, 1e-5 of the sum of the
+// absolute terms of q (cancellation); culling must stay exact (tests compare against the un-culled run bit for bit).
+__device__ __forceinline__ bool box_hit(float2 c, float cut2, float4 co, float bx0, float bx1, float by0, float by1, bool exact) {
+    const float lx = bx0 - c.x, hx = bx1 - c.x, ly = by0 - c.y, hy = by1 - c.y;     // the box relative to the centre
+    const float ex = fmaxf(lx, fminf(0.f, hx)), ey = fmaxf(ly, fminf(0.f, hy));     // nearest point of the box, per axis
+    if (!(ex * ex + ey * ey <= cut2)) return false;
+    if (!exact || cut2 > 1.0e30f) return true;
+    const float A = co.x, B = co.y, C = co.z;
+    float qmin = 0.f, sabs = 0.f;
+    if (ex != 0.f || ey != 0.f) {
+        float q1 = 3.0e38f, s1 = 0.f, q2 = 3.0e38f, s2 = 0.f;
+        if (ex != 0.f) {
+            const float dy = fminf(fmaxf(-B * ex * __builtin_amdgcn_rcpf(fmaxf(C, 1e-30f)), ly), hy);
+            const float t0 = A * ex * ex, t1 = 2.f * B * ex * dy, t2 = C * dy * dy;
+            q1 = t0 + t1 + t2; s1 = t0 + fabsf(t1) + t2;
+        }
+        if (ey != 0.f) {
+            const float dx = fminf(fmaxf(-B * ey * __builtin_amdgcn_rcpf(fmaxf(A, 1e-30f)), lx), hx);
+            const float t0 = C * ey * ey, t1 = 2.f * B * ey * dx, t2 = A * dx * dx;
+            q2 = t0 + t1 + t2; s2 = t0 + fabsf(t1) + t2;
+        }
+        const bool first = q1 <= q2;
+        qmin = first ? q1 : q2; sabs = first ? s1 : s2;
+    }
+    const float tau = 2.f * __logf(255.f * co.w);
+    return qmin - 1e-5f * sabs <= tau * 1.001f + 1e-3f;
 }
 
 // ------------------------------------------------------------------------------------------- K6
@@ -622,7 +650,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
                                                     const float *__restrict__ cut2, const float *__restrict__ bg,
                                                     const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                    float *__restrict__ out_color, float *__restrict__ out_depth) {
+                                                    float *__restrict__ out_color, float *__restrict__ out_depth, int exact_cull) {
     // survivors of a chunk are COMPACTED into these arrays (slot = rank of the lane among the ballot's set bits), so the
     // compositing loop is a plain counted loop over contiguous LDS records with immediate offsets; slots past the
     // survivor count hold a harmless record (opacity 0).  +FWD_GROUP slots of padding for the last group.
@@ -659,7 +687,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
             // quadrant independently (depth-split backward)
             if ((base & (SEG - 1)) == 0)
                 ckpt[(size_t)(seg0 + base / SEG) * 256 + (blockIdx.x & 3) * 64 + lane] = make_float4(T, C0, C1, C2);
-            const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+            const bool hit = box_hit(c_cur, cut_cur, co_cur, bx0, bx1, by0, by1, exact_cull);
             const unsigned long long mask = __ballot(hit);
             const int nh = __popcll(mask);
             __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk before these writes
@@ -755,7 +783,7 @@ __device__ __forceinline__ void composite_range(const uint32_t *__restrict__ pl,
                                                 const float *__restrict__ depth, const float4 *__restrict__ conic_opacity,
                                                 const float *__restrict__ cut2, float4 *s_xyi, float4 *s_co, float4 *s_cd,
                                                 bool &done, float &T, float &C0, float &C1, float &C2, float &Dp,
-                                                uint32_t &last) {
+                                                uint32_t &last, bool exact_cull = true) {
     float bx0 = wave_min(done ? 3.0e38f : fx), bx1 = wave_max(done ? -3.0e38f : fx);
     float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
     unsigned long long live = __ballot(!done);
@@ -768,7 +796,7 @@ __device__ __forceinline__ void composite_range(const uint32_t *__restrict__ pl,
     float4 co_cur = conic_opacity[id_cur];
     float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
     for (int base = 0; base < n; base += 64) {
-        const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+        const bool hit = box_hit(c_cur, cut_cur, co_cur, bx0, bx1, by0, by1, exact_cull);
         const unsigned long long mask = __ballot(hit);
         const int nh = __popcll(mask);
         // wave-private LDS: a wave's LDS operations execute in order, only the compiler has to be told not to move the
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__rest
                                                     const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
                                                     const float *__restrict__ cut2, const float *__restrict__ final_T,
                                                     const uint32_t *__restrict__ n_contrib, const float *__restrict__ out_color,
-                                                    const float *__restrict__ dL_dpix, float *__restrict__ acc) {
+                                                    const float *__restrict__ dL_dpix, float *__restrict__ acc, int exact_cull) {
     __shared__ float2 s_xy[64];
     __shared__ float4 s_co[64];
     __shared__ float4 s_c[64];   // rgb + Gaussian id (bit pattern) in .w
@@ -1042,7 +1070,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__rest
     for (int base = 0; base < cnt; base += 64) {
         __syncthreads();   // single-wave workgroup: previous chunk's LDS reads precede these writes
         s_xy[lane] = c_cur; s_co[lane] = co_cur; s_c[lane] = col_cur;
-        const bool hit = box_hit(c_cur, cut_cur, bx0, bx1, by0, by1);
+        const bool hit = box_hit(c_cur, cut_cur, co_cur, bx0, bx1, by0, by1, exact_cull);
         const int nb = base + 64;
         const uint32_t id_n2 = nb + 64 + lane < cnt ? pl[idx_of(nb + 64 + lane)] : 0u;
         c_cur = xy[id_nxt];
@@ -1745,7 +1773,8 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     if (!(g_debug_flags & 8u)) {   // default: sequential forward (one wave walks a quadrant's whole list)
         ProfScope ps(PROF_K6, s);
         k_render_fwd<<<tiles * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, g.cut2,
-                                              bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth);
+                                              bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth,
+                                              (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
         LAUNCH_CHECK();
     } else {   // opt-in (measured 192 us vs 172 us on scene_1): four waves per quadrant, speculative rounds
         ProfScope ps(PROF_K6, s);
@@ -1803,7 +1832,8 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, unsigned accmask, int P
         ProfScope ps(PROF_K7, s);
         k_render_bwd<<<(unsigned)(max_slots(R, tiles) * 4), 64, 0, s>>>(tiles, ranges, ids_sorted, seg_offset, slot_tile, ckpt, W, H,
                                                                         cam.gx, bg, g.xy, g.conic_opacity, g.rgb, g.cut2, final_T,
-                                                                        n_contrib, out_color, dL_dpix, acc);
+                                                                        n_contrib, out_color, dL_dpix, acc,
+                                                                        (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
         LAUNCH_CHECK();
     }
     if (k8s != s) {

@@ -49,7 +49,8 @@ int csplat_abi_version(void);
  * bit 2: read R with a blocking stream synchronise instead of polling the pinned mailbox;
  * bit 3: depth-split forward compositing (four wavefronts per quadrant, rounds of speculative 256-entry segments with
  *        exact replay of terminating segments) instead of the sequential one-wavefront-per-quadrant kernel;
- * bit 4: quadruple the culling radius (sensitivity check of the culling bound) */
+ * bit 4: quadruple the culling radius (sensitivity check of the culling bound);
+ * bit 5: circle stage of the culling only (no exact ellipse-vs-box stage).  Bits 0 and 4 also switch the ellipse stage off. */
 int csplat_debug_flags(unsigned flags);
 const char *csplat_last_error(void);
 
