@@ -675,13 +675,19 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
         unsigned long long live = __ballot(!done);
         const uint32_t *pl = point_list + range.x;
         const int seg0 = seg_offset[tile];
-        // software pipeline: ids two chunks ahead, per-entry data one chunk ahead
+        // software pipeline: ids three chunks ahead, per-entry data two chunks ahead (the critical wave of a deep quadrant
+        // runs alone on its SIMD: a chunk is composited in less time than a gather round trip takes)
         uint32_t id_cur = lane < n ? pl[lane] : 0u;
-        uint32_t id_nxt = 64 + lane < n ? pl[64 + lane] : 0u;
+        uint32_t id_n1 = 64 + lane < n ? pl[64 + lane] : 0u;
+        uint32_t id_nxt = 128 + lane < n ? pl[128 + lane] : 0u;      // ids of chunk + 2
         float2 c_cur = xy[id_cur];
         float cut_cur = lane < n ? cut2[id_cur] : -1.f;
         float4 co_cur = conic_opacity[id_cur];
         float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
+        float2 c_n1 = xy[id_n1];
+        float cut_n1 = 64 + lane < n ? cut2[id_n1] : -1.f;
+        float4 co_n1 = conic_opacity[id_n1];
+        float4 cd_n1 = make_float4(rgb[3 * id_n1], rgb[3 * id_n1 + 1], rgb[3 * id_n1 + 2], depth[id_n1]);
         for (int base = 0; base < n; base += 64) {
             // segment boundary: checkpoint (T, colour so far) so that K7 can replay every SEG-entry segment of this
             // quadrant independently (depth-split backward)
@@ -702,14 +708,15 @@ __global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ rang
                 s_co[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_cd[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            // start the loads of the next chunk
-            const int nb = base + 64;
-            const uint32_t id_n2 = nb + 64 + lane < n ? pl[nb + 64 + lane] : 0u;
-            c_cur = xy[id_nxt];
-            cut_cur = nb + lane < n ? cut2[id_nxt] : -1.f;
-            co_cur = conic_opacity[id_nxt];
-            cd_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
-            id_nxt = id_n2;
+            // rotate the pipeline and start the loads of chunk + 2
+            const int nb = base + 128;
+            const uint32_t id_n3 = nb + 64 + lane < n ? pl[nb + 64 + lane] : 0u;
+            c_cur = c_n1; cut_cur = cut_n1; co_cur = co_n1; cd_cur = cd_n1;
+            c_n1 = xy[id_nxt];
+            cut_n1 = nb + lane < n ? cut2[id_nxt] : -1.f;
+            co_n1 = conic_opacity[id_nxt];
+            cd_n1 = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
+            id_nxt = id_n3;
             __syncthreads();
             for (int h0 = 0; h0 < nh; h0 += FWD_GROUP) {
                 float al[FWD_GROUP];
