@@ -17,6 +17,21 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// sum over the 32 lanes of a half wave (lanes 0..31 / 32..63), result in every lane of the half: four DPP adds inside each
+// 16-lane row, then the gfx950 row swap folds rows 0|1 and 2|3 (cheaper than five ds_bpermute round trips)
+template <int CTRL>
+__device__ __forceinline__ float l128_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    v = l128_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = l128_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = l128_dpp_add<0x141>(v);   // row_half_mirror
+    v = l128_dpp_add<0x140>(v);   // row_mirror
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(sw[0]) + __int_as_float(sw[1]);
+}
 constexpr int GK = 128, GN = 128, WT_STRIDE = 129;   // W^T rows padded: conflict-free transposed staging
 
 // Epilogue options (all fused into the accumulator registers, no extra HBM pass):
@@ -251,14 +266,12 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
             }
             if (LN) {
                 float sum = (v[0] + v[1]) + (v[2] + v[3]);
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                sum = half_sum(sum);
                 const float mean = sum * (1.f / GN);
                 float d[4], sq = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; c++) { d[c] = v[c] - mean; sq += d[c] * d[c]; }
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+                sq = half_sum(sq);
                 const float rstd = rsqrtf(sq * (1.f / GN) + eps);
 #pragma unroll
                 for (int c = 0; c < 4; c++) v[c] = d[c] * rstd * gcol[c] + becol[c];
@@ -340,8 +353,7 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             float sum = v[r];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            sum = half_sum(sum);
             if (r32 == 0) s_part[0][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sum;
         }
         __syncthreads();
@@ -351,8 +363,7 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
             mean[r] = ((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN);
             const float d = v[r] - mean[r];
             float sq = d * d;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            sq = half_sum(sq);
             if (r32 == 0) s_part[1][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sq;
         }
         __syncthreads();
@@ -490,8 +501,7 @@ __global__ __launch_bounds__(256) void k_node_update(int64_t N, const float *__r
         for (int r = 0; r < 16; r++) {
             v[r] = acc[r] + bv;
             float sum = v[r];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            sum = half_sum(sum);
             if (r32 == 0) s_part[0][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sum;
         }
     }
@@ -502,8 +512,7 @@ __global__ __launch_bounds__(256) void k_node_update(int64_t N, const float *__r
         mean[r] = ((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN);
         const float d = v[r] - mean[r];
         float sq = d * d;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+        sq = half_sum(sq);
         if (r32 == 0) s_part[1][(r & 3) + 8 * (r >> 2) + 4 * h][w] = sq;
     }
     __syncthreads();                          // (also: every wave is done reading s_act)
