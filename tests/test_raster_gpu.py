@@ -386,3 +386,52 @@ def test_batched_views_mixed_sizes_and_empty_view():
     (outs[0][0].mean() + outs[1][0].mean() + outs[2][0].mean()).backward()
     assert i1["means3D"].grad is not None and i2["shs"].grad is not None
     assert torch.isfinite(i1["means3D"].grad).all() and torch.isfinite(i2["shs"].grad).all()
+
+
+def test_two_phase_forward_tickets_and_errors():
+    """csplat_forward_begin / _finish bookkeeping: an unknown ticket is an error (text via csplat_last_error), at most 64
+    tickets may be open, finishing releases them, and a finished ticket cannot be finished twice."""
+    import ctypes as C
+    from csplat import native as n
+    case = util.make_case(P=300, W=64, H=48, seed=2, scale_mul=2.0)
+    inp = util.gpu_inputs(case, requires_grad=False)
+    st = util.gpu_settings(case)
+    P, W, H = case["P"], case["W"], case["H"]
+    keep = []
+
+    def begin():
+        alloc = n.ChunkAllocator(inp["means3D"].device)
+        radii = torch.empty(P, dtype=torch.int32, device="cuda")
+        tk = C.c_int(-1)
+        rc = n.lib.csplat_forward_begin(
+            n.stream_handle(radii.device), P, 3, 16, n.ptr(st.bg), W, H, n.ptr(inp["means3D"]), n.ptr(inp["shs"]), None,
+            n.ptr(inp["opacities"]), n.ptr(inp["scales"]), 1.0, n.ptr(inp["rotations"]), None, n.ptr(st.viewmatrix),
+            n.ptr(st.projmatrix), n.ptr(st.campos), float(st.tanfovx), float(st.tanfovy), 0, alloc.cb, None, n.ptr(radii), C.byref(tk))
+        keep.append((alloc, radii))
+        return rc, tk.value
+
+    def finish(tk):
+        color = torch.empty(3, H, W, device="cuda"); depth = torch.empty(1, H, W, device="cuda")
+        R = C.c_int(0); g, b, i = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rc = n.lib.csplat_forward_finish(tk, n.ptr(color), n.ptr(depth), C.byref(R), C.byref(g), C.byref(b), C.byref(i))
+        return rc, color, R.value
+
+    assert finish(7)[0] != 0 and b"unknown ticket" in n.lib.csplat_last_error()
+    tickets = []
+    for _ in range(64):
+        rc, tk = begin()
+        assert rc == 0
+        tickets.append(tk)
+    assert len(set(tickets)) == 64
+    rc, _ = begin()
+    assert rc != 0 and b"64" in n.lib.csplat_last_error()                     # the 65th open forward is refused
+    ref = None
+    for tk in tickets:
+        rc, color, R = finish(tk)
+        assert rc == 0 and R > 0
+        ref = color if ref is None else ref
+        assert torch.equal(color, ref)                                         # 64 interleaved forwards, one result
+    assert finish(tickets[0])[0] != 0                                          # released
+    rc, tk = begin()
+    assert rc == 0 and finish(tk)[0] == 0                                      # and usable again
+    torch.cuda.synchronize()
