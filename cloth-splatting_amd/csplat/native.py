@@ -42,6 +42,8 @@ EXPORTS = {
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),
+    "csplat_dist2_temp_bytes": (_sz, [_i]),
+    "csplat_dist2_ws": (_i, [_vp, _i, _vp, _vp, _vp]),
     "csplat_mesh_rest_bytes": (_sz, [_i]),
     "csplat_mesh_rest": (_i, [_vp, _i, _vp, _vp, _vp]),
     "csplat_mesh_transform_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

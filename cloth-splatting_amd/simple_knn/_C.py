@@ -11,5 +11,12 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     P = int(pts.shape[0])
     out = torch.empty(P, dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
-        _n.check(_n.lib.csplat_dist2(_n.stream_handle(pts.device), P, _n.ptr(pts), _n.ptr(out)), "csplat_dist2")
+        if P >= BOXED_FROM:   # Morton order + box pruning (what the upstream extension does); same bits, O(P) candidates
+            temp = torch.empty(int(_n.lib.csplat_dist2_temp_bytes(P)), dtype=torch.uint8, device=pts.device)
+            _n.check(_n.lib.csplat_dist2_ws(_n.stream_handle(pts.device), P, _n.ptr(pts), _n.ptr(out), _n.ptr(temp)), "csplat_dist2_ws")
+        else:
+            _n.check(_n.lib.csplat_dist2(_n.stream_handle(pts.device), P, _n.ptr(pts), _n.ptr(out)), "csplat_dist2")
     return out
+
+
+BOXED_FROM = 4096   # below this the single brute-force kernel is faster than sort + boxes

@@ -150,6 +150,10 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
 
 /* distCUDA2: out[i] = mean of squared distances from point i to its 3 nearest other points. */
 int csplat_dist2(void *stream, int P, const float *xyz, float *out);
+/* the same result (bit for bit) in O(P * pruned candidates): Morton order + bounding-box pruning as the upstream extension
+ * does; temp: csplat_dist2_temp_bytes(P) bytes of device memory. */
+size_t csplat_dist2_temp_bytes(int P);
+int csplat_dist2_ws(void *stream, int P, const float *xyz, float *out, void *temp);
 
 /* Separable 11-tap window of the SSIM loss (utils/loss_utils.py:30-58), zero padded: out = G (x) G * in for every one of
  * the n_images [H][W] planes.  taps11 is a HOST pointer to the 11 normalised window weights.  Self-adjoint: the backward

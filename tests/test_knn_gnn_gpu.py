@@ -23,6 +23,41 @@ def test_dist2_bit_exact_vs_oracle():
     assert distCUDA2(torch.zeros(0, 3, device="cuda")).numel() == 0
 
 
+def test_dist2_boxed_path_equals_brute_force_bit_for_bit():
+    """csplat_dist2_ws (Morton order + bounding-box pruning, the upstream extension's scheme) against the brute-force
+    kernel: identical bits on clustered, planar, duplicated and ragged inputs, and the timing that motivates it."""
+    import time
+    import simple_knn._C as knn
+    rng = np.random.default_rng(11)
+    sets = {"uniform 20001": rng.random((20001, 3)), "clusters": np.concatenate([rng.normal(c, 0.01, (3000, 3)) for c in rng.random((7, 3))]),
+            "planar": np.c_[rng.random((9000, 2)), np.zeros(9000)], "line+dups": np.repeat(np.c_[np.linspace(0, 1, 2500), np.zeros((2500, 2))], 2, 0),
+            "one box": rng.random((4096, 3))}
+    for name, pts in sets.items():
+        t = torch.tensor(pts.astype(np.float32), device="cuda")
+        old = knn.BOXED_FROM
+        try:
+            knn.BOXED_FROM = 1 << 30
+            ref = knn.distCUDA2(t)
+            knn.BOXED_FROM = 1
+            got = knn.distCUDA2(t)
+        finally:
+            knn.BOXED_FROM = old
+        assert torch.equal(got, ref), name
+    t = torch.tensor(rng.random((200_000, 3)).astype(np.float32), device="cuda")
+    knn.distCUDA2(t); torch.cuda.synchronize()
+    t0 = time.perf_counter(); got = knn.distCUDA2(t); torch.cuda.synchronize(); t_boxed = time.perf_counter() - t0
+    old = knn.BOXED_FROM
+    try:
+        knn.BOXED_FROM = 1 << 30
+        knn.distCUDA2(t); torch.cuda.synchronize()
+        t0 = time.perf_counter(); ref = knn.distCUDA2(t); torch.cuda.synchronize(); t_brute = time.perf_counter() - t0
+    finally:
+        knn.BOXED_FROM = old
+    assert torch.equal(got, ref)
+    print(f"distCUDA2 P=200k: boxed {t_boxed * 1e3:.2f} ms, brute force {t_brute * 1e3:.2f} ms")
+    assert t_boxed < t_brute
+
+
 def test_dist2_full_size_vs_kdtree():
     """config-2 size: 100k points of synthetic scene_1 against scipy's exact kd-tree (tolerance 1e-6 rel)."""
     from scipy.spatial import cKDTree
