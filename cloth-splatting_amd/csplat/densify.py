@@ -153,6 +153,65 @@ class DensifyMixin:
         self.densification_postfix(self.face_bary[sel], self.face_offset[sel], self.face_ids[sel], self._features_dc[sel],
                                    self._features_rest[sel], self._opacity[sel], self._scaling[sel], self._rotation[sel])
 
+    # ---- gaussian_mesh.py:267-322 -------------------------------------------------------------------------------------
+    def _face_neighbours(self):
+        """adj[f, b] = the face on the other side of the edge opposite to local vertex b of face f (-1 on a border edge).
+        The reference intersects per-vertex face lists in Python for every affected Gaussian; here the edge -> faces
+        relation is built once per mesh with a sort.  (On a non-manifold edge the reference takes `list(set)[0]`, i.e. an
+        arbitrary member; this takes the smallest face id.)"""
+        face = self.mesh.face
+        key = (face.data_ptr(), face._version, tuple(face.shape))
+        c = self.__dict__.get("_adj_cache")
+        if c is not None and c[0] == key:
+            return c[1]
+        V, F = int(self.mesh.pos.shape[0]), int(face.shape[1])
+        f = torch.arange(F, device=face.device)
+        keys, owners = [], []
+        for b in range(3):
+            a, c2 = face[(b + 1) % 3], face[(b + 2) % 3]
+            keys.append(torch.minimum(a, c2) * V + torch.maximum(a, c2))
+            owners.append(f)
+        keys, owners = torch.cat(keys), torch.cat(owners)                # entry e = b * F + f
+        order = torch.argsort(keys * F + owners)                         # by edge, then by face id
+        sk, so = keys[order], owners[order]
+        start = torch.searchsorted(sk, keys)                             # first entry of each entry's edge group
+        first = so[start]
+        nxt = torch.clamp(start + 1, max=sk.numel() - 1)
+        second = torch.where((start + 1 < sk.numel()) & (sk[nxt] == keys), so[nxt], torch.full_like(first, -1))
+        adj = torch.where(first != owners, first, second).view(3, F).t().contiguous()   # [F, 3]
+        self._adj_cache = (key, adj)
+        return adj
+
+    @torch.no_grad()
+    def cleanup_barycentric_coordinates(self):
+        """Re-assign every Gaussian whose barycentric coordinate went negative to the face across the offending edge, with
+        distance-based coordinates there; on a border edge the coordinate is pushed back inside (the reference writes 0.005
+        and then divides that scalar by its own sum, i.e. stores 1.0 -- reproduced).  Vectorised: the reference's per-Gaussian
+        Python loop (one .item() per affected Gaussian, train_utils.py:306 every `bary_cleanup` iterations) becomes at
+        most three batched passes (a row can have up to three negative coordinates; the loop handles them in column order
+        with the ORIGINAL face of the row, which the passes replicate)."""
+        mask = self.face_bary < 0
+        if not bool(mask.any()):
+            return
+        adj = self._face_neighbours()
+        orig_ids = self.face_ids.clone()
+        xyz = self.get_xyz()
+        rank = torch.cumsum(mask.to(torch.int64), dim=1) - 1
+        for r in range(3):
+            coord, bary = torch.where(mask & (rank == r))
+            if coord.numel() == 0:
+                break
+            nf = adj[orig_ids[coord], bary]
+            border = nf < 0
+            if bool(border.any()):
+                self.face_bary.data[coord[border], bary[border]] = 1.0
+            if bool((~border).any()):
+                cc, new_face = coord[~border], nf[~border]
+                self.face_ids[cc] = new_face
+                corners = self.mesh.pos[self.mesh.face[:, new_face].t()]            # [n, 3 (vertex), 3 (xyz)]
+                dist = torch.linalg.norm(xyz[cc].unsqueeze(1) - corners, dim=2)
+                self.face_bary.data[cc] = dist / dist.sum(dim=1, keepdim=True)
+
     # ---- gaussian_model.py:408-425 ------------------------------------------------------------------------------------
     def densify(self, max_grad, min_opacity, extent, max_screen_size):
         grads = self.pos_gradient_accum / self.denom

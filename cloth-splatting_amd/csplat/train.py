@@ -254,6 +254,8 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             if iteration % densify_opt.opacity_reset_interval == 0 or (
                     getattr(densify_opt, "white_background", False) and iteration == densify_opt.densify_from_iter):
                 gaussians.reset_opacity()
+        if densify_opt is not None and getattr(densify_opt, "bary_cleanup", 0) and iteration % densify_opt.bary_cleanup == 0:
+            gaussians.cleanup_barycentric_coordinates()                                  # train_utils.py:306-307
         gaussians.optimizer.step()
         if not static:
             meshnet_optimizer.step()

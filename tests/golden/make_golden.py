@@ -376,6 +376,29 @@ def gen_densify():
         pc.optimizer.step()
         out["post_grads"] = torch.cat([x.reshape(-1) for x in post])
         dump("after_step")
+        # ---- cleanup_barycentric_coordinates (gaussian_mesh.py:267-322) on a small grid mesh: Gaussians whose barycentric
+        # coordinates went negative hop to the face across the offending edge (or are pushed back on a border edge)
+        gm = 6
+        xs = torch.linspace(0, 1, gm)
+        gpos = torch.stack([xs.repeat(gm), xs.repeat_interleave(gm), 0.05 * torch.rand(gm * gm, generator=g)], 1)
+        quads = [(r * gm + c, r * gm + c + 1, (r + 1) * gm + c, (r + 1) * gm + c + 1) for r in range(gm - 1) for c in range(gm - 1)]
+        gface = torch.tensor([[a, b, c2] for a, b, c2, d in quads] + [[b, d, c2] for a, b, c2, d in quads]).t().contiguous()
+        Pc = 90
+        pc2 = MultiGaussianMesh(3)
+        pc2.mesh = types.SimpleNamespace(pos=gpos, face=gface)
+        pc2.face_ids = torch.randint(0, gface.shape[1], (Pc,), generator=g)
+        b = torch.rand(Pc, 3, generator=g)
+        b = b / b.sum(1, keepdim=True)
+        neg = torch.rand(Pc, 3, generator=g) < 0.22                      # some rows get one, two or three negatives
+        b = torch.where(neg, -0.3 * torch.rand(Pc, 3, generator=g) - 0.01, b)
+        pc2.face_bary = torch.nn.Parameter(b.clone())
+        out["cleanup.pos"], out["cleanup.face"] = gpos, gface
+        out["cleanup.face_ids_in"], out["cleanup.face_bary_in"] = pc2.face_ids.clone(), b.clone()
+        with torch.no_grad():
+            pc2.cleanup_barycentric_coordinates()
+        out["cleanup.face_ids_out"], out["cleanup.face_bary_out"] = pc2.face_ids.clone(), pc2.face_bary.detach().clone()
+        print("cleanup: rows with a negative coordinate", int((b < 0).any(1).sum()), "faces changed",
+              int((out["cleanup.face_ids_out"] != out["cleanup.face_ids_in"]).sum()))
     finally:
         for n, f in saved.items():
             setattr(torch, n, f)

@@ -469,3 +469,29 @@ def test_ply_layout_and_round_trip(tmp_path):
         np.testing.assert_array_equal(getattr(q, a).detach().numpy(), getattr(pc, a).detach().numpy())
     assert torch.equal(q.face_ids, pc.face_ids) and torch.equal(q.mesh.face, face) and torch.equal(q.mesh.pos, pos)
     np.testing.assert_array_equal(q.get_xyz().detach().numpy(), pc.get_xyz().detach().numpy())
+
+
+def test_cleanup_barycentric_coordinates_replays_the_reference():
+    """the vectorised cleanup_barycentric_coordinates against the reference's per-Gaussian Python loop, run on CPU tensors
+    by make_golden.gen_densify on a grid mesh with rows that have one, two and three negative coordinates: same faces,
+    same coordinates (border rows included: the reference's 0.005 / 0.005 = 1.0 is reproduced)."""
+    import types
+    import torch
+    from csplat.gaussians import MeshGaussians
+    g = golden("densify.npz")
+    T = lambda a: torch.tensor(a)  # noqa: E731
+    pc = MeshGaussians(3)
+    pc.fused = False
+    pc.mesh = types.SimpleNamespace(pos=T(g["cleanup.pos"]), face=T(g["cleanup.face"]), edge_index=None)
+    pc.face_ids = T(g["cleanup.face_ids_in"])
+    pc.face_bary = torch.nn.Parameter(T(g["cleanup.face_bary_in"]))
+    pc.cleanup_barycentric_coordinates()
+    np.testing.assert_array_equal(pc.face_ids.numpy(), g["cleanup.face_ids_out"])
+    np.testing.assert_allclose(pc.face_bary.detach().numpy(), g["cleanup.face_bary_out"], rtol=1e-6, atol=0)
+    assert (g["cleanup.face_ids_out"] != g["cleanup.face_ids_in"]).sum() > 20 and (g["cleanup.face_bary_out"] == 1.0).any()
+    before = pc.face_bary.detach().clone()
+    clean = MeshGaussians(3); clean.fused = False
+    clean.mesh, clean.face_ids = pc.mesh, pc.face_ids.clone()
+    clean.face_bary = torch.nn.Parameter(before.abs())
+    clean.cleanup_barycentric_coordinates()                       # nothing negative: untouched
+    assert torch.equal(clean.face_bary.detach(), before.abs())

@@ -195,7 +195,7 @@ def test_train_step_with_densification_on_gpu():
     dopt = SimpleNamespace(densify_until_iter=100, densify_from_iter=2, densification_interval=3, opacity_reset_interval=9,
                            pruning_from_iter=2, pruning_interval=4, densify_grad_threshold_fine_init=2e-5,
                            densify_grad_threshold_after=2e-5, opacity_threshold_fine_init=0.05, opacity_threshold_fine_after=0.05,
-                           cameras_extent=1.0, white_background=False)
+                           cameras_extent=1.0, white_background=False, bary_cleanup=2)
     counts = []
     torch.manual_seed(0)
     for it in range(1, 10):
