@@ -465,8 +465,29 @@ __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restr
         const int idx = wbase + i * 64 + lane;
         key[i] = (i < items && idx < n) ? comp[r.x + idx] : ~0ull;
     }
+    // digits on which every key of the tile agrees need no pass (a stable pass over a constant digit is the identity):
+    // typically the exponent byte of the depth, and more on short lists.  One OR-reduction of (key ^ first key).
+    uint32_t *s_diff = s_dig + 260;                                                           // [2]
+    if (threadIdx.x < 2) s_diff[threadIdx.x] = 0u;
+    __syncthreads();
+    {
+        const uint64_t k0 = comp[r.x];
+        uint64_t dv = 0ull;
+#pragma unroll
+        for (int i = 0; i < TSORT_ITEMS; i++) {
+            const int idx = wbase + i * 64 + lane;
+            if (i < items && idx < n) dv |= key[i] ^ k0;
+        }
+        uint32_t lo = (uint32_t)dv, hi32 = (uint32_t)(dv >> 32);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, o, 64); hi32 |= (uint32_t)__shfl_xor((int)hi32, o, 64); }
+        if (lane == 0) { atomicOr(&s_diff[0], lo); atomicOr(&s_diff[1], hi32); }
+    }
+    __syncthreads();
+    const uint64_t diffbits = (uint64_t)s_diff[0] | ((uint64_t)s_diff[1] << 32);
     for (int byte = 0; byte < 8; byte++) {
         if (byte == 3 && skip_byte3) continue;
+        if (((diffbits >> (byte * 8)) & 0xFFull) == 0ull) continue;   // workgroup-uniform
         const int shift = byte * 8;
         for (int t = threadIdx.x; t < TSORT_WAVES * 256; t += TSORT_THREADS) s_cnt[t] = 0u;
         __syncthreads();
