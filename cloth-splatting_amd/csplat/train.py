@@ -174,6 +174,17 @@ def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
 
 @torch.no_grad()
 def psnr(img1, img2):
+    """utils/image_utils.py:17-21: [B, 1] PSNR per image.  On the GPU one launch (csplat_psnr); otherwise torch ops."""
+    if img1.is_cuda and img1.dtype == torch.float32 and img2.dtype == torch.float32 and img1.shape == img2.shape \
+            and img1.dim() >= 2 and img1.numel() > 0:
+        a, b = img1.contiguous(), img2.contiguous()
+        B = int(a.shape[0])
+        out = torch.empty(B, 1, dtype=torch.float32, device=a.device)
+        scratch = torch.empty(_n.lib.csplat_psnr_scratch_bytes(B), dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            _n.check(_n.lib.csplat_psnr(_n.stream_handle(a.device), B, a.numel() // B, _n.ptr(a), _n.ptr(b), _n.ptr(scratch),
+                                        _n.ptr(out)), "csplat_psnr")
+        return out
     mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
 
@@ -189,8 +200,40 @@ def image_losses(image_tensor, gt_image_tensor, opt, mask_tensor=None):
     return loss
 
 
-def regularization(all_vertice_deform, gaussians, opt, static=False):
+class FusedClothRegs(torch.autograd.Function):
+    """the three cloth regularisers and their gradient in one launch (csplat_cloth_regs); backward scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom):
+        D = D.contiguous().float()
+        T, V = int(D.shape[0]), int(D.shape[1])
+        E = int(edge_index.shape[1])
+        loss = torch.empty((), dtype=torch.float32, device=D.device)
+        grad = torch.empty_like(D)
+        scratch = torch.empty(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=D.device)
+        with torch.cuda.device(D.device):
+            _n.check(_n.lib.csplat_cloth_regs(_n.stream_handle(D.device), T, V, E, _n.ptr(D), _n.ptr(edge_index.contiguous()),
+                                              _n.ptr(rest_len.contiguous().float()), float(lam_deform), float(lam_rigid),
+                                              float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch)), "csplat_cloth_regs")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None
+
+
+def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True):
+    """train_utils.py:76-237 (the active terms).  On the GPU the terms and their gradient come from one kernel
+    (FusedClothRegs); fused=False composes them from torch ops as upstream does (the parity reference of the tests)."""
     n_cams = all_vertice_deform.shape[0]
+    if fused and not static and all_vertice_deform.is_cuda and all_vertice_deform.dim() == 3:
+        lam_d = opt.lambda_deform_mag if opt.lambda_deform_mag > 0. else 0.
+        lam_r = opt.lambda_rigid if opt.lambda_rigid > 0 else 0.
+        lam_m = opt.lambda_momentum if opt.lambda_momentum > 0 else 0.
+        return FusedClothRegs.apply(all_vertice_deform, gaussians.mesh.edge_index, gaussians.edge_norm.reshape(-1), lam_d, lam_r,
+                                    lam_m)
     loss = torch.zeros([], device=all_vertice_deform.device)
     if not static and opt.lambda_deform_mag > 0. and n_cams >= 3:
         d0 = torch.linalg.norm(all_vertice_deform[1] - all_vertice_deform[0], dim=-1).mean()
@@ -222,8 +265,17 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
     images, gts, radii_l, vis_l, vsp_l, verts = [], [], [], [], [], []
     stacked = None
+    reg = None
     if batched_views:
-        pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True)
+        deforms = None
+        if not static and cams and hasattr(simulator, "forward_times"):
+            # simulator for all cameras at once, and the regularisers recorded BEFORE the rasterizer: autograd runs
+            # later-recorded nodes first, so the rasterizer's backward -- the long GPU work of the step -- is launched
+            # first and the small launches of everything else are issued under it
+            deforms = simulator.forward_times([cam.time for cam in cams])
+            reg = regularization(deforms, gaussians, opt, static)
+        pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True,
+                                     vertice_deforms=deforms)
     else:
         pkgs = [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
     for cam, pkg in zip(cams, pkgs):
@@ -233,13 +285,15 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         vis_l.append(pkg.visibility_filter.unsqueeze(0))
         vsp_l.append(pkg.viewspace_points)
         verts.append(pkg.vertice_deform[None])
-    all_vertice_deform = torch.cat(verts, 0)
+    all_vertice_deform = torch.cat(verts, 0) if reg is None else None
     radii = torch.cat(radii_l, 0).max(dim=0).values
     visibility_filter = torch.cat(vis_l).any(dim=0)
     image_tensor = stacked if stacked is not None else torch.cat(images, 0)
     gt_image_tensor = torch.cat(gts, 0)
     psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
-    loss = image_losses(image_tensor, gt_image_tensor, opt) + regularization(all_vertice_deform, gaussians, opt, static)
+    if reg is None:
+        reg = regularization(all_vertice_deform, gaussians, opt, static)
+    loss = image_losses(image_tensor, gt_image_tensor, opt) + reg
     loss.backward()
     viewspace_grad = torch.zeros_like(vsp_l[0])
     for v in vsp_l:

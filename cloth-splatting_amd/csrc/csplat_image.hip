@@ -206,6 +206,52 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
         if (threadIdx.x == 0) { float t_ = 0.f; for (int k_ = 0; k_ < L1_THREADS / 64; k_++) t_ += s_red[k_]; *loss = t_ * inv_n; *ticket = 0u; }
     }
 }
+// ---- PSNR per image (utils/image_utils.py psnr: mse over all channels and pixels of an image, 20 log10(1 / sqrt(mse))).
+// The reference logs it every training step; as torch ops it is ~10 launches.  gridDim.y = image, PSNR_BLOCKS slices per
+// image, last slice of an image (ticket) sums the slice partials in fixed order.
+constexpr int PSNR_BLOCKS = 64;
+__global__ __launch_bounds__(1024) void k_psnr(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
+                                               float *__restrict__ partial, unsigned *__restrict__ ticket, float *__restrict__ out) {
+    __shared__ float s_red[16];
+    __shared__ bool s_last;
+    const float *pa = a + (size_t)blockIdx.y * n, *pb = b + (size_t)blockIdx.y * n;
+    float acc = 0.f;
+    if ((((uintptr_t)pa | (uintptr_t)pb) & 15u) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 1024) {
+            const float4 x = reinterpret_cast<const float4 *>(pa)[i], y = reinterpret_cast<const float4 *>(pb)[i];
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            acc += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        if (blockIdx.x == 0)
+            for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) { const float d = pa[i] - pb[i]; acc += d * d; }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+            const float d = pa[i] - pb[i];
+            acc += d * d;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; k++) t += s_red[k];
+        partial[blockIdx.y * PSNR_BLOCKS + blockIdx.x] = t;
+        __threadfence();
+        s_last = atomicAdd(ticket + blockIdx.y, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        float t = 0.f;
+        for (unsigned k = 0; k < gridDim.x; k++) t += __builtin_nontemporal_load(partial + blockIdx.y * PSNR_BLOCKS + k);
+        const float mse = t / (float)n;
+        out[blockIdx.y] = 20.f * log10f(1.f / sqrtf(mse));
+        ticket[blockIdx.y] = 0u;
+    }
+}
 }  // namespace
 
 extern "C" int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *in, float *out) {
@@ -258,6 +304,23 @@ extern "C" int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, con
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
     k_ssim_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, dx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t csplat_psnr_scratch_bytes(int64_t n_images) { return (size_t)(n_images > 0 ? n_images : 1) * (PSNR_BLOCKS + 1) * 4; }
+
+extern "C" int csplat_psnr(void *stream, int64_t n_images, int64_t n_per_image, const float *a, const float *b, void *scratch,
+                           float *out) {
+    CSPLAT_REQUIRE(n_images >= 0 && n_images < 65536 && n_per_image > 0, "csplat_psnr: bad sizes");
+    if (n_images == 0) return 0;
+    CSPLAT_REQUIRE(a && b && scratch && out, "csplat_psnr: NULL");
+    float *partial = (float *)scratch;
+    unsigned *ticket = (unsigned *)scratch + n_images * PSNR_BLOCKS;
+    HIP_TRY(hipMemsetAsync(ticket, 0, (size_t)n_images * 4, (hipStream_t)stream));
+    const int64_t work = (n_per_image / 4 + 1023) / 1024;
+    dim3 grid((unsigned)(work < 1 ? 1 : (work > PSNR_BLOCKS ? PSNR_BLOCKS : work)), (unsigned)n_images);
+    k_psnr<<<grid, 1024, 0, (hipStream_t)stream>>>(n_per_image, a, b, partial, ticket, out);
     LAUNCH_CHECK();
     return 0;
 }

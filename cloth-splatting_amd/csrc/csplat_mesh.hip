@@ -174,12 +174,15 @@ __global__ __launch_bounds__(256) void k_mesh_fwd(int P, const int64_t *__restri
     for (int c = 0; c < 4; c++) out_quat[4 * (size_t)i + c] = quat[c];
 }
 
+// four threads per Gaussian, one per sweep of four tangent directions (inputs 4*sweep .. 4*sweep+3): 4x the wavefronts of a
+// thread-per-Gaussian launch (100k Gaussians are only 1.5 waves per SIMD, each a long dependent chain)
 __global__ __launch_bounds__(256) void k_mesh_bwd(int P, const int64_t *__restrict__ vid, const float *__restrict__ verts,
                                                    const float *__restrict__ bary, const float *__restrict__ rot,
                                                    const RestFace *__restrict__ rest, const float *__restrict__ g_pos,
                                                    const float *__restrict__ g_quat, float *__restrict__ d_verts,
                                                    float *__restrict__ d_bary, float *__restrict__ d_rot) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int i = gid >> 2, sweep = gid & 3;
     if (i >= P) return;
     typedef Dual<4> D;
     float in[16];
@@ -194,30 +197,26 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(int P, const int64_t *__restri
     for (int c = 0; c < 3; c++) g[c] = g_pos ? g_pos[3 * (size_t)i + c] : 0.f;
     for (int c = 0; c < 4; c++) g[3 + c] = g_quat ? g_quat[4 * (size_t)i + c] : 0.f;
     const RestFace rf = rest[i];
-    float grad[16];
+    D y[3][3], b[3], q0[4], pos[3], quat[4];
 #pragma unroll
-    for (int sweep = 0; sweep < 4; sweep++) {   // 4 tangent directions per sweep: inputs 4*sweep .. 4*sweep+3
-        D y[3][3], b[3], q0[4], pos[3], quat[4];
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            D x = mk<4>(in[t]);
-            if ((t >> 2) == sweep) x.d[t & 3] = 1.f;
-            if (t < 9) y[t / 3][t % 3] = x;
-            else if (t < 12) b[t - 9] = x;
-            else q0[t - 12] = x;
-        }
-        transform_one<D>(y, b, q0, rf, pos, quat);
-        for (int u = 0; u < 4; u++) {
-            float s = 0.f;
-            for (int c = 0; c < 3; c++) s += g[c] * pos[c].d[u];
-            for (int c = 0; c < 4; c++) s += g[3 + c] * quat[c].d[u];
-            grad[4 * sweep + u] = s;
-        }
+    for (int t = 0; t < 16; t++) {
+        D x = mk<4>(in[t]);
+        x.d[t & 3] = (t >> 2) == sweep ? 1.f : 0.f;
+        if (t < 9) y[t / 3][t % 3] = x;
+        else if (t < 12) b[t - 9] = x;
+        else q0[t - 12] = x;
     }
-    for (int k = 0; k < 3; k++)
-        for (int c = 0; c < 3; c++) atomicAdd(d_verts + 3 * v3[k] + c, grad[3 * k + c]);
-    for (int k = 0; k < 3; k++) d_bary[3 * (size_t)i + k] = grad[9 + k];
-    for (int k = 0; k < 4; k++) d_rot[4 * (size_t)i + k] = grad[12 + k];
+    transform_one<D>(y, b, q0, rf, pos, quat);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        float s = 0.f;
+        for (int c = 0; c < 3; c++) s += g[c] * pos[c].d[u];
+        for (int c = 0; c < 4; c++) s += g[3 + c] * quat[c].d[u];
+        const int t = 4 * sweep + u;   // input this derivative belongs to: 0-8 vertices, 9-11 barycentrics, 12-15 rotation
+        if (t < 9) atomicAdd(d_verts + 3 * (t < 3 ? v3[0] : (t < 6 ? v3[1] : v3[2])) + t % 3, s);
+        else if (t < 12) d_bary[3 * (size_t)i + (t - 9)] = s;
+        else d_rot[4 * (size_t)i + (t - 12)] = s;
+    }
 }
 
 }  // namespace
@@ -253,7 +252,7 @@ int csplat_mesh_transform_bwd(void *stream, int P, int V, const int64_t *face_ve
     hipStream_t s = (hipStream_t)stream;
     if (V > 0) HIP_TRY(hipMemsetAsync(d_vertices, 0, (size_t)V * 3 * 4, s));
     if (P == 0) return 0;   // (every Gaussian pruned: the vertex gradient is zero)
-    k_mesh_bwd<<<cdiv(P, 256), 256, 0, s>>>(P, face_vertex_ids, vertices, bary, rotation, (const RestFace *)rest, g_xyz, g_quat,
+    k_mesh_bwd<<<cdiv(4 * (int64_t)P, 256), 256, 0, s>>>(P, face_vertex_ids, vertices, bary, rotation, (const RestFace *)rest, g_xyz, g_quat,
                                             d_vertices, d_bary, d_rotation);
     LAUNCH_CHECK();
     return 0;

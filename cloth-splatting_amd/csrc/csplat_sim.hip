@@ -1,0 +1,312 @@
+// csplat_sim.hip -- output layer of the time-conditioned mesh simulator.
+//
+// ResidualMeshSimulator (reference meshnet/meshnet_network.py:327-373) ends in Linear(256, 3V): ONE time value feeds the
+// whole mesh, so the layer is a matrix-vector product over a [3V, 256] weight (30.7 MB at V = 10k).  A training step
+// renders T cameras (t-1, t, t+1), i.e. T such products and, in backward, T outer products into the same weight gradient.
+// As M = 1 GEMMs they run far below HBM rate and autograd adds T-1 full-size accumulation passes.  Here the T time rows are
+// handled together, the weight is streamed once per direction:
+//   forward   y[t][r]  = b[r] + sum_k W[r][k] h[t][k]                       reads W once          (R*K*4 bytes)
+//   backward  dW[r][k] = sum_t dy[t][r] h[t][k];  db[r] = sum_t dy[t][r];
+//             dh[t][k] = sum_r dy[t][r] W[r][k]                             reads W, writes dW    (2*R*K*4 bytes)
+// Both are HBM-bound streams; a wavefront owns a row (64 lanes x float4 = the 256 inputs).  dh is reduced deterministically:
+// per-workgroup partials, then a fixed-order sum.
+#include "csplat_common.h"
+
+namespace {
+constexpr int SIM_K = 256;        // inputs of the layer (hidden width of the simulator MLP)
+constexpr int SIM_TMAX = 8;       // time rows per call
+constexpr int SIM_BLOCKS = 512;   // 2 workgroups per CU, 4 waves each, 4 rows in flight per wave: 32 KB of loads per CU
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <int T>
+__global__ __launch_bounds__(256) void k_rows_dot_fwd(int R, const float4 *__restrict__ W, const float *__restrict__ b,
+                                                      const float4 *__restrict__ h, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float4 hr[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) hr[t] = h[t * 64 + lane];
+    for (int r0 = wave * 4; r0 < R; r0 += nwaves * 4) {
+        float4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = r0 + j < R ? W[(size_t)(r0 + j) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const float s = wave_sum(dot4(w[j], hr[t]));
+                if (lane == 0 && r0 + j < R) y[(size_t)t * R + r0 + j] = s + b[r0 + j];
+            }
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_rows_dot_bwd(int R, const float4 *__restrict__ W, const float4 *__restrict__ h,
+                                                      const float *__restrict__ dy, float4 *__restrict__ dW,
+                                                      float *__restrict__ db, float4 *__restrict__ part) {
+    __shared__ float4 s_acc[4][T][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    float4 hr[T], acc[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        hr[t] = h[t * 64 + lane];
+        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int r0 = wave * 4; r0 < R; r0 += nwaves * 4) {
+        float4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = r0 + j < R ? W[(size_t)(r0 + j) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (r0 + j < R) {   // (wave-uniform)
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                float sb = 0.f;
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const float d = dy[(size_t)t * R + r0 + j];
+                    sb += d;
+                    g.x += d * hr[t].x; g.y += d * hr[t].y; g.z += d * hr[t].z; g.w += d * hr[t].w;
+                    acc[t].x += d * w[j].x; acc[t].y += d * w[j].y; acc[t].z += d * w[j].z; acc[t].w += d * w[j].w;
+                }
+                dW[(size_t)(r0 + j) * 64 + lane] = g;
+                if (lane == 0) db[r0 + j] = sb;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) s_acc[wv][t][lane] = acc[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * 64; i += 256) {
+        const int t = i >> 6, l = i & 63;
+        float4 a = s_acc[0][t][l];
+        for (int k = 1; k < 4; k++) {
+            const float4 c = s_acc[k][t][l];
+            a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        }
+        part[(size_t)blockIdx.x * T * 64 + i] = a;
+    }
+}
+
+// dh[i] = sum over workgroups (fixed order) of part[g][i], i < T*256.  64 outputs per workgroup, 16 slices of the workgroup
+// list summed side by side (a single thread walking all 512 partials is a 40 us chain of dependent-latency loads).
+__global__ __launch_bounds__(1024) void k_rows_dot_dh(int n, int groups, const float *__restrict__ part, float *__restrict__ dh) {
+    __shared__ float s_part[16][64];
+    const int l = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int g = slice;
+        for (; g + 16 < groups; g += 32) {
+            s0 += part[(size_t)g * n + i];
+            s1 += part[(size_t)(g + 16) * n + i];
+        }
+        if (g < groups) s0 += part[(size_t)g * n + i];
+    }
+    s_part[slice][l] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s += s_part[k][l];
+        dh[i] = s;
+    }
+}
+
+// ---- cloth regularisers of the reconstruction loss (reference scene_reconstruction/train_utils.py:83-102) in one pass.
+// D [T][V][3] = deformed vertices of the step's T cameras (t-1, t, t+1):
+//   deform-magnitude  lambda_d * 0.5 * (mean_v |D1 - D0|_2 + mean_v |D2 - D1|_2)                    (T >= 3)
+//   rigidity          lambda_r * mean_{t,e} | rest_len[e] - |D[t][dst e] - D[t][src e]|_2 |
+//   momentum          lambda_m * mean_v |D2 - 2 D1 + D0|_1                                            (T >= 3)
+// As torch ops this is ~35 launches forward and ~55 backward of a few microseconds each.  Here: work items 0..V-1 are the
+// vertices (node terms), V..V+T*E-1 the (time, edge) pairs; every item adds its loss share to a per-workgroup partial and
+// its gradient to grad[T][V][3] (atomics: a vertex collects from ~6 edges + its node terms); the last workgroup to finish
+// sums the partials in fixed order -> the loss value is deterministic, the gradient is up to atomic summation order (as
+// index_add's is upstream).
+__global__ __launch_bounds__(256) void k_cloth_regs(int T, int V, long long E, const float *__restrict__ D,
+                                                    const int64_t *__restrict__ ei, const float *__restrict__ rest_len,
+                                                    float w_deform, float w_rigid, float w_mom, float *__restrict__ grad,
+                                                    float *__restrict__ partial, unsigned int *__restrict__ ticket,
+                                                    float *__restrict__ loss) {
+    __shared__ float s_red[4];
+    __shared__ bool s_last;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n_edge_items = w_rigid != 0.f ? (long long)T * E : 0;
+    float acc = 0.f;
+    if (i < V) {
+        if (T >= 3 && (w_deform != 0.f || w_mom != 0.f)) {
+            float d0[3], d1[3], d2[3];
+            for (int c = 0; c < 3; c++) {
+                d0[c] = D[(size_t)i * 3 + c];
+                d1[c] = D[((size_t)V + i) * 3 + c];
+                d2[c] = D[((size_t)2 * V + i) * 3 + c];
+            }
+            float g0[3] = {0.f, 0.f, 0.f}, g1[3] = {0.f, 0.f, 0.f}, g2[3] = {0.f, 0.f, 0.f};
+            if (w_deform != 0.f) {   // w_deform = 0.5 * lambda_d / V
+                const float a[3] = {d1[0] - d0[0], d1[1] - d0[1], d1[2] - d0[2]};
+                const float b[3] = {d2[0] - d1[0], d2[1] - d1[1], d2[2] - d1[2]};
+                const float na = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+                const float nb = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+                acc += w_deform * (na + nb);
+                const float ia = na > 0.f ? w_deform / na : 0.f, ib = nb > 0.f ? w_deform / nb : 0.f;   // d|x|/dx = 0 at x = 0
+                for (int c = 0; c < 3; c++) {
+                    g0[c] -= ia * a[c];
+                    g1[c] += ia * a[c] - ib * b[c];
+                    g2[c] += ib * b[c];
+                }
+            }
+            if (w_mom != 0.f) {      // w_mom = lambda_m / V
+                for (int c = 0; c < 3; c++) {
+                    const float m = d2[c] - 2.f * d1[c] + d0[c];
+                    acc += w_mom * fabsf(m);
+                    const float sg = m > 0.f ? w_mom : (m < 0.f ? -w_mom : 0.f);
+                    g0[c] += sg;
+                    g1[c] -= 2.f * sg;
+                    g2[c] += sg;
+                }
+            }
+            for (int c = 0; c < 3; c++) {
+                atomicAdd(grad + (size_t)i * 3 + c, g0[c]);
+                atomicAdd(grad + ((size_t)V + i) * 3 + c, g1[c]);
+                atomicAdd(grad + ((size_t)2 * V + i) * 3 + c, g2[c]);
+            }
+        }
+    } else if (i - V < n_edge_items) {   // w_rigid = lambda_r / (T * E)
+        const long long k = i - V;
+        const int t = (int)(k / E);
+        const long long e = k - (long long)t * E;
+        const int64_t a = ei[e], b = ei[E + e];   // disp = D[t][ei[1]] - D[t][ei[0]]
+        const float *Dt = D + (size_t)t * V * 3;
+        const float dx = Dt[b * 3] - Dt[a * 3], dy = Dt[b * 3 + 1] - Dt[a * 3 + 1], dz = Dt[b * 3 + 2] - Dt[a * 3 + 2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float diff = rest_len[e] - len;
+        acc += w_rigid * fabsf(diff);
+        // d|rest - len| / d len = -sign(rest - len);  d len / d disp = disp / len (0 at len = 0)
+        const float sl = diff > 0.f ? -w_rigid : (diff < 0.f ? w_rigid : 0.f);
+        const float k_ = len > 0.f ? sl / len : 0.f;
+        float *gt = grad + (size_t)t * V * 3;
+        atomicAdd(gt + b * 3, k_ * dx); atomicAdd(gt + b * 3 + 1, k_ * dy); atomicAdd(gt + b * 3 + 2, k_ * dz);
+        atomicAdd(gt + a * 3, -k_ * dx); atomicAdd(gt + a * 3 + 1, -k_ * dy); atomicAdd(gt + a * 3 + 2, -k_ * dz);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float s = 0.f;
+    for (unsigned j = threadIdx.x; j < gridDim.x; j += 256) s += __builtin_nontemporal_load(partial + j);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *loss = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        *ticket = 0u;   // ready for the next call
+    }
+}
+
+template <int T>
+int launch_fwd(hipStream_t s, int R, const float *W, const float *b, const float *h, float *y) {
+    k_rows_dot_fwd<T><<<SIM_BLOCKS, 256, 0, s>>>(R, (const float4 *)W, b, (const float4 *)h, y);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <int T>
+int launch_bwd(hipStream_t s, int R, const float *W, const float *h, const float *dy, float *dW, float *db, float *dh, void *scratch) {
+    k_rows_dot_bwd<T><<<SIM_BLOCKS, 256, 0, s>>>(R, (const float4 *)W, (const float4 *)h, dy, (float4 *)dW, db, (float4 *)scratch);
+    LAUNCH_CHECK();
+    k_rows_dot_dh<<<cdiv(T * SIM_K, 64), 1024, 0, s>>>(T * SIM_K, SIM_BLOCKS, (const float *)scratch, dh);
+    LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t csplat_rows_dot_scratch_bytes(int T) { return align256((size_t)SIM_BLOCKS * (T > 0 ? T : 1) * SIM_K * sizeof(float)); }
+
+int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y) {
+    CSPLAT_REQUIRE(K == SIM_K, "csplat_rows_dot_fwd: K must be 256");
+    CSPLAT_REQUIRE(T >= 0 && T <= SIM_TMAX && R >= 0, "csplat_rows_dot_fwd: T must be 0..8, R >= 0");
+    if (T == 0 || R == 0) return 0;
+    CSPLAT_REQUIRE(W && b && h && y, "csplat_rows_dot_fwd: NULL");
+    hipStream_t s = (hipStream_t)stream;
+    switch (T) {
+        case 1: return launch_fwd<1>(s, R, W, b, h, y);
+        case 2: return launch_fwd<2>(s, R, W, b, h, y);
+        case 3: return launch_fwd<3>(s, R, W, b, h, y);
+        case 4: return launch_fwd<4>(s, R, W, b, h, y);
+        case 5: return launch_fwd<5>(s, R, W, b, h, y);
+        case 6: return launch_fwd<6>(s, R, W, b, h, y);
+        case 7: return launch_fwd<7>(s, R, W, b, h, y);
+        default: return launch_fwd<8>(s, R, W, b, h, y);
+    }
+}
+
+int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const float *h, const float *dy, float *dW, float *db,
+                        float *dh, void *scratch) {
+    CSPLAT_REQUIRE(K == SIM_K, "csplat_rows_dot_bwd: K must be 256");
+    CSPLAT_REQUIRE(T >= 0 && T <= SIM_TMAX && R >= 0, "csplat_rows_dot_bwd: T must be 0..8, R >= 0");
+    if (T == 0) return 0;
+    CSPLAT_REQUIRE(h && dh && scratch && (R == 0 || (W && dy && dW && db)), "csplat_rows_dot_bwd: NULL");
+    hipStream_t s = (hipStream_t)stream;
+    switch (T) {
+        case 1: return launch_bwd<1>(s, R, W, h, dy, dW, db, dh, scratch);
+        case 2: return launch_bwd<2>(s, R, W, h, dy, dW, db, dh, scratch);
+        case 3: return launch_bwd<3>(s, R, W, h, dy, dW, db, dh, scratch);
+        case 4: return launch_bwd<4>(s, R, W, h, dy, dW, db, dh, scratch);
+        case 5: return launch_bwd<5>(s, R, W, h, dy, dW, db, dh, scratch);
+        case 6: return launch_bwd<6>(s, R, W, h, dy, dW, db, dh, scratch);
+        case 7: return launch_bwd<7>(s, R, W, h, dy, dW, db, dh, scratch);
+        default: return launch_bwd<8>(s, R, W, h, dy, dW, db, dh, scratch);
+    }
+}
+
+size_t csplat_cloth_regs_scratch_bytes(int T, int V, int64_t E) {
+    const int64_t items = (int64_t)V + (int64_t)(T > 0 ? T : 0) * (E > 0 ? E : 0);
+    return align256((size_t)(cdiv(items > 0 ? items : 1, 256) + 1) * sizeof(float)) + 256;
+}
+
+int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, const int64_t *edge_index, const float *rest_len,
+                      float lambda_deform, float lambda_rigid, float lambda_momentum, float *loss, float *grad, void *scratch) {
+    CSPLAT_REQUIRE(T >= 0 && V >= 0 && E >= 0, "csplat_cloth_regs: bad sizes");
+    CSPLAT_REQUIRE(loss && scratch, "csplat_cloth_regs: NULL loss / scratch");
+    hipStream_t s = (hipStream_t)stream;
+    const bool node_terms = T >= 3 && V > 0 && (lambda_deform != 0.f || lambda_momentum != 0.f);
+    const bool edge_terms = T > 0 && E > 0 && V > 0 && lambda_rigid != 0.f;
+    if (T > 0 && V > 0) {
+        CSPLAT_REQUIRE(D && grad, "csplat_cloth_regs: NULL D / grad");
+        HIP_TRY(hipMemsetAsync(grad, 0, (size_t)T * V * 3 * sizeof(float), s));
+    }
+    if (!node_terms && !edge_terms) {
+        HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+        return 0;
+    }
+    CSPLAT_REQUIRE(!edge_terms || (edge_index && rest_len), "csplat_cloth_regs: NULL edge arrays");
+    const int64_t items = (int64_t)V + (edge_terms ? (int64_t)T * E : 0);
+    const int blocks = cdiv(items, 256);
+    float *partial = (float *)scratch;
+    unsigned int *ticket = (unsigned int *)((char *)scratch + align256((size_t)(blocks + 1) * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), s));
+    k_cloth_regs<<<blocks, 256, 0, s>>>(T, V, (long long)E, D, edge_index, rest_len,
+                                        node_terms && lambda_deform != 0.f ? 0.5f * lambda_deform / (float)V : 0.f,
+                                        edge_terms ? lambda_rigid / ((float)T * (float)E) : 0.f,
+                                        node_terms && lambda_momentum != 0.f ? lambda_momentum / (float)V : 0.f, grad, partial, ticket,
+                                        loss);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -28,24 +28,43 @@ class RenderResults(NamedTuple):
     vertice_projections: Optional[torch.Tensor]
 
 
+_SIZES = {}
+
+
 def _project(cam, points):
     """pixel coordinates of world points (reference :166-179): p_h @ full_proj, /w, ndc -> ((v+1)*S-1)/2."""
     full = cam.full_proj_transform.to(points.device)
-    hom = torch.cat([points, torch.ones_like(points[:, 0:1])], dim=1) @ full
+    # columns x, y, w of [p, 1] @ full as three broadcast multiply-adds: the [P,4] x [4,4] product is a skinny GEMM that
+    # the BLAS runs in 72 us at P = 100k (more than K1 + K8 of the same view), the elementwise form in ~10
+    hom = torch.addcmul(torch.addcmul(torch.addcmul(full[3], points[:, 0:1], full[0]), points[:, 1:2], full[1]),
+                        points[:, 2:3], full[2])
     ndc = hom[:, :2] / hom[:, 3:4]
-    H, W = int(cam.image_height), int(cam.image_width)
-    return torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], dim=1)
+    W, H = int(cam.image_width), int(cam.image_height)
+    if W == H:
+        return ((ndc + 1.0) * float(W) - 1.0) * 0.5
+    size = _SIZES.get((W, H, points.device))
+    if size is None:   # (uploaded once per image size: a host->device copy stalls the stream)
+        size = _SIZES[(W, H, points.device)] = torch.tensor([float(W), float(H)], device=points.device)
+    return ((ndc + 1.0) * size - 1.0) * 0.5
 
 
 def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, override_color, log_deform_path,
-             render_static, shared=None):
+             render_static, shared=None, vertice_deform=None):
     """everything of render() up to the rasterizer call: settings, rasterizer keyword arguments, by-products.
     `shared` carries the view-independent activations (features, opacity, scaling) so that several views of one step
-    pass the SAME tensor objects to the rasterizer (one gradient buffer for all of them, see rasterize_views)."""
-    base_xyz = pc.get_xyz()
-    dev = base_xyz.device
+    pass the SAME tensor objects to the rasterizer (one gradient buffer for all of them, see rasterize_views);
+    `vertice_deform` is the simulator's output for this camera when the caller evaluated all cameras' times at once."""
+    if shared is None:
+        shared = {}
+    if "opacity" not in shared:
+        shared["opacity"] = pc.get_opacity
+    # (the reference builds the zero tensor below from pc.get_xyz -- a gather + barycentric blend of the REST mesh per call;
+    # only its shape is needed unless the static pose itself is rendered or logged)
+    base_xyz = pc.get_xyz() if (render_static or log_deform_path is not None) else None
+    dev = shared["opacity"].device
     # zero tensor whose gradient is the screen-space (NDC) gradient of the 2D means (used by densification)
-    screenspace_points = torch.zeros_like(base_xyz, dtype=base_xyz.dtype, requires_grad=True, device=dev) + 0
+    screenspace_points = torch.zeros(shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype, requires_grad=True,
+                                     device=dev) + 0
     try:
         screenspace_points.retain_grad()
     except Exception:
@@ -58,24 +77,22 @@ def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, 
         viewmatrix=viewpoint_camera.world_view_transform.to(dev), projmatrix=viewpoint_camera.full_proj_transform.to(dev),
         sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center.to(dev), prefiltered=False, debug=False)
 
-    if shared is None:
-        shared = {}
-    if "opacity" not in shared:
+    if "features" not in shared:
         if pipe.compute_cov3D_python:
             shared["cov3D"], shared["scales"] = pc.get_covariance(scaling_modifier), None
         else:
             shared["cov3D"], shared["scales"] = None, pc.get_scaling
-        shared["opacity"] = pc.get_opacity
         shared["features"] = pc.get_features if override_color is None else None
     cov3D_precomp, scales, opacity = shared["cov3D"], shared["scales"], shared["opacity"]
 
-    time = torch.tensor(viewpoint_camera.time).to(pc.mesh.pos.device).repeat(pc.mesh.pos.shape[0], 1)
     if render_static:
         vertice_deform = pc.mesh.pos
         means3D_deform = base_xyz
         rotations_deform = pc.get_rotation()
     else:
-        vertice_deform = simulator(time_vector=time)
+        if vertice_deform is None:
+            time = torch.tensor(viewpoint_camera.time).to(pc.mesh.pos.device).repeat(pc.mesh.pos.shape[0], 1)
+            vertice_deform = simulator(time_vector=time)
         means3D_deform = pc.get_xyz(vertice_deform)
         rotations_deform = pc.get_rotation(vertice_deform)
 
@@ -115,16 +132,20 @@ def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scalin
 
 
 def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-                 no_shadow=False, render_static=False, project_vertices=False, return_stacked=False):
+                 no_shadow=False, render_static=False, project_vertices=False, return_stacked=False, vertice_deforms=None):
     """render() for every camera of a training step in one rasterizer call (diff_gaussian_rasterization.rasterize_views:
     one HIP stream per view, the views' kernels overlap, shared parameters get one gradient buffer).  Same results as
     [render(c, ...) for c in viewpoint_cameras]; no counterpart upstream, whose train loop renders camera by camera
     (scene_reconstruction/train_utils.py:204-260).  return_stacked=True also returns the [V,3,H,W] image batch (None when
     the cameras differ in size) so that the caller's losses need no torch.cat."""
     shared, prepared = {}, []
-    for cam in viewpoint_cameras:
+    viewpoint_cameras = list(viewpoint_cameras)
+    deforms = vertice_deforms      # [T, V, 3] when the caller already evaluated the simulator for these cameras
+    if deforms is None and not render_static and viewpoint_cameras and hasattr(simulator, "forward_times"):
+        deforms = simulator.forward_times([cam.time for cam in viewpoint_cameras])   # [T, V, 3]: one pass over the output layer
+    for i, cam in enumerate(viewpoint_cameras):
         prepared.append(_prepare(cam, pc, simulator, pipe, bg_color, scaling_modifier, override_color, None, render_static,
-                                 shared))
+                                 shared, None if deforms is None else deforms[i]))
     if not prepared:
         return ([], None) if return_stacked else []
     sizes = {(p[0].image_height, p[0].image_width) for p in prepared}

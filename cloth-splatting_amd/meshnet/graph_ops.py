@@ -110,6 +110,43 @@ class SegmentSum(torch.autograd.Function):
         return out, None
 
 
+class RowsDot(torch.autograd.Function):
+    """y[T, R] = h[T, 256] @ W[R, 256]^T + b -- the simulator's 256 -> 3V output layer for the T time values of a step at once
+    (csplat_rows_dot_fwd / _bwd: the weight is streamed once per direction; deterministic)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        h, weight, bias = _f32(h), _f32(weight), _f32(bias)
+        T, K = h.shape
+        R = weight.shape[0]
+        y = torch.empty(T, R, dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            _n.check(_n.lib.csplat_rows_dot_fwd(_n.stream_handle(h.device), T, R, K, _n.ptr(weight), _n.ptr(bias), _n.ptr(h),
+                                                _n.ptr(y)), "csplat_rows_dot_fwd")
+        ctx.save_for_backward(h, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        h, weight = ctx.saved_tensors
+        g = _f32(g)
+        T, K = h.shape
+        R = weight.shape[0]
+        dW, db, dh = torch.empty_like(weight), torch.empty(R, dtype=torch.float32, device=g.device), torch.empty_like(h)
+        scratch = torch.empty(_n.lib.csplat_rows_dot_scratch_bytes(T), dtype=torch.uint8, device=g.device)
+        with torch.cuda.device(g.device):
+            _n.check(_n.lib.csplat_rows_dot_bwd(_n.stream_handle(g.device), T, R, K, _n.ptr(weight), _n.ptr(h), _n.ptr(g),
+                                                _n.ptr(dW), _n.ptr(db), _n.ptr(dh), _n.ptr(scratch)), "csplat_rows_dot_bwd")
+        return dh, dW, db
+
+
+def rows_dot(h, weight, bias):
+    """F.linear(h, weight, bias) for few rows of h (<= 8) against a tall 256-column weight, at HBM rate on the GPU."""
+    if h.is_cuda and h.dim() == 2 and h.shape[1] == 256 and weight.shape[1] == 256 and 0 < h.shape[0] <= 8 and bias is not None:
+        return RowsDot.apply(h, weight, bias)
+    return torch.nn.functional.linear(h, weight, bias)
+
+
 def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, add_pre=None, add_post=None, out=None):
     """Inference-only fused Linear for the 128-wide MeshNet MLP layers (csplat_linear128, include/csplat.h):
         out = LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] + add_pre ) ) + add_post

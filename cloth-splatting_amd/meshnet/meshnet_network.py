@@ -100,18 +100,48 @@ class ResidualMeshSimulator(torch.nn.Module):
         nn.init.normal_(self.output.weight, 0.0, 0.00001)
         nn.init.constant_(self.output.bias, 0.0)
 
+    def _residual(self, times):
+        """times [T, 1] -> residual deformation [T, V, 3].  One time value feeds the whole mesh, so the 256 -> 3V output layer
+        is a matrix-vector product per time; as an M = 1 GEMM (what nn.Linear issues) it runs at ~60 GB/s on this stack.
+        graph_ops.rows_dot streams the 3V x 256 weight once for all T rows (forward) / once more for their gradients."""
+        from meshnet.graph_ops import rows_dot
+        h = torch.relu(self.input(self.encoder(times)))
+        h = torch.relu(self.hidden(h))
+        return rows_dot(h, self.output.weight, self.output.bias).reshape(times.shape[0], -1, 3)
+
     def forward(self, time_vector):
         time = time_vector[0, :]
-        h = torch.relu(self.input(self.encoder(time)))
-        h = torch.relu(self.hidden(h))
-        # a single time value feeds the whole mesh: the 256 -> 3V output layer is a matrix-VECTOR product.  As an M = 1
-        # GEMM (what nn.Linear issues) or a gemv it runs at ~60 GB/s on this stack (0.5-0.9 ms forward, and again twice in
-        # backward); written as a broadcast multiply + row reduction it streams the 3V x 256 weights at HBM rate.
-        residual_deform = ((self.output.weight * h).sum(dim=1) + self.output.bias).reshape(-1, 3)
+        residual_deform = self._residual(time[None])[0]
         time_id = torch.round(time / self.time_delta).to(dtype=torch.long)
         if time_id >= self.n_times:
             raise ValueError(f"Time {time} is out of bounds for the mesh simulator.")
         return self.mesh_predictions[time_id].squeeze() + residual_deform
+
+    def forward_times(self, times):
+        """forward() for the T cameras of a training step at once: times = sequence of Python floats (Camera.time) ->
+        [T, V, 3].  Same arithmetic per time as forward(); the table index is computed on the host (fp32, round-half-even
+        like torch.round), so neither a host->device copy nor the device->host read of the bounds check is needed."""
+        import numpy as np
+        key = tuple(float(t) for t in times)
+        dev = self.output.weight.device
+        cache = self.__dict__.setdefault("_times_on_device", {})
+        hit = cache.get((key, dev))
+        if hit is None:
+            t32 = np.asarray(key, dtype=np.float32)
+            ids = np.round(t32 / np.float32(self.time_delta)).astype(np.int64)
+            if (ids >= self.n_times).any():
+                raise ValueError(f"Time {t32[ids >= self.n_times][0]} is out of bounds for the mesh simulator.")
+            # (a pageable host->device copy waits for the stream to drain: the time values of a camera set are uploaded once
+            # and kept -- a training run cycles through a bounded set of (t-1, t, t+1) triples)
+            if len(cache) >= 4096:
+                cache.clear()
+            hit = cache[(key, dev)] = (torch.tensor(t32, device=dev).reshape(-1, 1), torch.as_tensor(ids, device=dev))
+        tt, ids_dev = hit
+        out = []
+        for c0 in range(0, tt.shape[0], 8):   # (rows_dot takes up to 8 time rows per call)
+            out.append(self._residual(tt[c0:c0 + 8]))
+        residual = out[0] if len(out) == 1 else torch.cat(out, 0)
+        return self.mesh_predictions[ids_dev] + residual
 
     def save(self, path):
         torch.save(self.state_dict(), path)

@@ -173,6 +173,35 @@ int csplat_adam_step(void *stream, int n_tensors, float *const *params, const fl
                      float *const *exp_avg_sq, const int64_t *numel, const double *lr, double beta1, double beta2, double eps,
                      int64_t step);
 
+/* Output layer of the time-conditioned simulator MLP, T time rows at once (/root/reference/meshnet/meshnet_network.py:
+ * 339 `self.output = Linear(256, n_nodes * 3)`, applied at :367 to ONE time value per render() call; a training step makes
+ * T = 3 such calls, train_utils.py:204-260):
+ *   forward:  y[t][r] = b[r] + sum_k W[r][k] h[t][k]               W [R][K] row-major (torch Linear.weight), h [T][K], y [T][R]
+ *   backward: dW[r][k] = sum_t dy[t][r] h[t][k], db[r] = sum_t dy[t][r], dh[t][k] = sum_r dy[t][r] W[r][k]   (deterministic)
+ * K must be 256, 0 <= T <= 8.  scratch: csplat_rows_dot_scratch_bytes(T) bytes, not shared between concurrent calls. */
+size_t csplat_rows_dot_scratch_bytes(int T);
+int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y);
+int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const float *h, const float *dy, float *dW, float *db,
+                        float *dh, void *scratch);
+
+/* The cloth regularisers of the reconstruction loss with their gradient in one pass (/root/reference/scene_reconstruction/
+ * train_utils.py:83-102): D [T][V][3] deformed vertices of the step's T cameras, edge_index [2][E] int64, rest_len [E]:
+ *   *loss = lambda_deform * 0.5 * (mean_v |D1-D0|_2 + mean_v |D2-D1|_2)          (only when T >= 3)
+ *         + lambda_rigid * mean_{t,e} | rest_len[e] - |D[t][edge_index[1][e]] - D[t][edge_index[0][e]]|_2 |
+ *         + lambda_momentum * mean_v |D2 - 2 D1 + D0|_1                          (only when T >= 3)
+ *   grad [T][V][3] = d loss / d D (norms have gradient 0 at 0, as torch defines them).
+ * scratch: csplat_cloth_regs_scratch_bytes(T, V, E) bytes, not shared between concurrent calls.  The loss value is summed in a
+ * fixed order; the gradient's atomic summation order is not fixed. */
+size_t csplat_cloth_regs_scratch_bytes(int T, int V, int64_t E);
+int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, const int64_t *edge_index, const float *rest_len,
+                      float lambda_deform, float lambda_rigid, float lambda_momentum, float *loss, float *grad, void *scratch);
+
+/* psnr of /root/reference/utils/image_utils.py:19-21 per image: out[i] = 20 log10(1 / sqrt(mean((a_i - b_i)^2))) over the
+ * n_per_image values (channels x pixels) of image i; a, b [n_images][n_per_image].  One launch; fixed summation order.
+ * scratch: csplat_psnr_scratch_bytes(n_images) bytes, not shared between concurrent calls. */
+size_t csplat_psnr_scratch_bytes(int64_t n_images);
+int csplat_psnr(void *stream, int64_t n_images, int64_t n_per_image, const float *a, const float *b, void *scratch, float *out);
+
 /* SSIM of /root/reference/utils/loss_utils.py:40-70 (window 11, sigma 1.5, zero padding, size_average) on n_images [H][W]
  * planes (n_images = batch * channels), fused:
  *   forward:  map[i] = SSIM(x, y)[i] (optional), partial[b] = sum of the map over workgroup b's tile

@@ -294,3 +294,48 @@ def test_splitk_linear_gradients_match_autograd():
     ref = (x2.detach().double() @ W2.detach().double().t())
     assert rel_err(y2.detach().cpu().numpy(), ref.relu().cpu().numpy()) < 1e-5
     assert rel_err(W2.grad.cpu().numpy(), ((ref > 0).double().t() @ x2.detach().double()).cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("T,R", [(1, 30000), (3, 30000), (8, 777), (2, 3), (5, 4097)])
+def test_rows_dot_matches_linear_fwd_bwd(T, R):
+    """csplat_rows_dot_fwd/_bwd (the simulator's 256 -> 3V output layer for T time rows) against F.linear in fp64."""
+    from meshnet.graph_ops import rows_dot, RowsDot
+    g = torch.Generator(device="cuda").manual_seed(T * 1000 + R)
+    h = torch.randn(T, 256, device="cuda", generator=g).requires_grad_()
+    W = (0.1 * torch.randn(R, 256, device="cuda", generator=g)).requires_grad_()
+    b = torch.randn(R, device="cuda", generator=g).requires_grad_()
+    dy = torch.randn(T, R, device="cuda", generator=g)
+    y = rows_dot(h, W, b)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("RowsDot")      # the HIP path, not F.linear
+    y.backward(dy)
+    h64, W64, b64 = (t.detach().double().requires_grad_() for t in (h, W, b))
+    y64 = torch.nn.functional.linear(h64, W64, b64)
+    y64.backward(dy.double())
+    for got, ref, name in ((y, y64, "y"), (h.grad, h64.grad, "dh"), (W.grad, W64.grad, "dW"), (b.grad, b64.grad, "db")):
+        err = float((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        assert err < 2e-6, (name, err)
+    # deterministic: a second backward gives the same bits
+    h2 = h.detach().clone().requires_grad_()
+    rows_dot(h2, W.detach(), b.detach()).backward(dy)
+    assert torch.equal(h2.grad, h.grad)
+
+
+def test_simulator_forward_times_equals_forward_per_time_on_gpu():
+    from meshnet.meshnet_network import ResidualMeshSimulator
+    torch.manual_seed(3)
+    mesh = torch.randn(7, 500, 3, device="cuda")
+    sim = ResidualMeshSimulator(mesh, device="cuda")
+    with torch.no_grad():
+        sim.output.weight.mul_(1e4)          # (initialised at 1e-5: make the residual visible)
+    times = [k / 6 for k in (0, 3, 4, 6)]
+    both = sim.forward_times(times)
+    for i, t in enumerate(times):
+        one = sim(torch.tensor(t, device="cuda").repeat(500, 1))
+        assert float((both[i] - one).abs().max()) < 1e-5 * float(one.abs().max())
+    both.square().sum().backward()
+    g_batched = sim.output.weight.grad.clone()
+    sim.zero_grad()
+    sum(sim(torch.tensor(t, device="cuda").repeat(500, 1)).square().sum() for t in times).backward()
+    assert float((g_batched - sim.output.weight.grad).abs().max()) < 1e-4 * float(g_batched.abs().max())
+    with pytest.raises(ValueError):
+        sim.forward_times([0.5, 1.5])

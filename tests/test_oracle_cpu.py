@@ -230,6 +230,11 @@ def test_simulators_match_reference():
         got = sim(torch.tensor(float(tt)).repeat(V, 1))
         np.testing.assert_allclose(got.detach().numpy(), ref, atol=1e-5)
     assert ResidualMeshSimulator(mesh[:1], device="cpu").time_delta == float(g["res1_time_delta"]) == 1.0
+    # forward_times: the cameras of a step at once (what render_views uses) == forward() per time, same error behaviour
+    both = sim.forward_times([float(tt) for tt in g["res_times"]])
+    np.testing.assert_allclose(both.detach().numpy(), g["res_out"], atol=1e-5)
+    with pytest.raises(ValueError):
+        sim.forward_times([0.0, 1.3])
     with pytest.raises(ValueError):
         sim(torch.tensor(1.3).repeat(V, 1))
     assert int(g["res_oob_raises"]) == 1

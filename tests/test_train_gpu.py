@@ -46,6 +46,14 @@ def test_ssim_identity_and_psnr():
     assert float(tr.ssim(a, torch.rand_like(a))) < 0.2
     b = (a + 0.1).clamp(0, 1)
     assert 15 < float(tr.psnr(a, b).mean()) < 25
+    # csplat_psnr against the reference formula (utils/image_utils.py:17-21) in fp64, odd sizes and a misaligned batch stride
+    for shape in ((2, 3, 48, 40), (3, 3, 37, 21), (1, 1, 5, 1), (4, 3, 200, 200)):
+        x, y = torch.rand(*shape, device="cuda"), torch.rand(*shape, device="cuda")
+        got = tr.psnr(x, y)
+        mse = ((x.double() - y.double()) ** 2).view(shape[0], -1).mean(1, keepdim=True)
+        ref = 20 * torch.log10(1.0 / torch.sqrt(mse))
+        assert got.shape == ref.shape and float((got.double() - ref).abs().max()) < 1e-4, shape
+        assert torch.equal(got, tr.psnr(x, y))          # fixed summation order
 
 
 def test_blur_kernel_matches_grouped_conv_and_is_self_adjoint():
@@ -209,3 +217,40 @@ def test_train_step_with_densification_on_gpu():
             assert not st or st["exp_avg"].shape == q.shape == st["exp_avg_sq"].shape     # (face_offset never gets a gradient)
         assert pc.face_ids.shape[0] == counts[-1] == pc.max_radii2D.shape[0] == pc.denom.shape[0]
     assert len(set(counts)) > 1 and max(counts) > 4000          # it did densify (and prune)
+
+
+@pytest.mark.parametrize("T,lams", [(3, (0.1, 0.3, 0.2)), (3, (0.0, 0.3, 0.0)), (3, (0.1, 0.0, 0.2)), (1, (0.1, 0.3, 0.2)),
+                                    (2, (0.1, 0.3, 0.2)), (4, (0.1, 0.3, 0.2))])
+def test_fused_cloth_regularisers_match_composed_torch(T, lams):
+    """csplat_cloth_regs (deform-magnitude + rigidity + momentum, value and gradient in one launch) against the reference's
+    composition from torch ops (train_utils.py:83-102) evaluated in fp64."""
+    from types import SimpleNamespace
+    from csplat import train as tr
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(17 + T)
+    V, E = 3000, 17000
+    D = torch.randn(T, V, 3, device=dev, generator=g)
+    ei = torch.randint(0, V, (2, E), device=dev, generator=g)
+    ei[1, :5] = ei[0, :5]                                     # zero-length edges: norm gradient 0 there
+    if T >= 3:
+        D[1, :7] = D[0, :7]                                   # zero deformation deltas
+        D[1, 7:11] = D[0, 7:11]; D[2, 7:11] = D[0, 7:11]      # zero momentum (exactly, also in fp32: the sign of a rounding residue is not a parity question)
+    rest = torch.rand(E, 1, device=dev, generator=g) + 0.5
+    opt = SimpleNamespace(lambda_deform_mag=lams[0], lambda_rigid=lams[1], lambda_momentum=lams[2])
+    pc = SimpleNamespace(mesh=SimpleNamespace(edge_index=ei), edge_norm=rest)
+    Df = D.clone().requires_grad_()
+    lf = tr.regularization(Df, pc, opt)
+    assert type(lf.grad_fn).__name__.startswith("FusedClothRegs")
+    (lf * 1.7).backward()
+    D64 = D.double().requires_grad_()
+    pc64 = SimpleNamespace(mesh=SimpleNamespace(edge_index=ei), edge_norm=rest.double())
+    l64 = tr.regularization(D64, pc64, opt, fused=False)
+    (l64 * 1.7).backward()
+    assert abs(float(lf) - float(l64)) <= 2e-6 * max(abs(float(l64)), 1e-3), (float(lf), float(l64))
+    if D64.grad is not None:
+        err = float((Df.grad.double() - D64.grad).abs().max())
+        assert err <= 2e-6 * max(float(D64.grad.abs().max()), 1e-6), err
+    else:
+        assert float(Df.grad.abs().max()) == 0.0
+    # the loss value is summed in a fixed order
+    assert float(tr.regularization(D.clone(), pc, opt)) == float(lf)
