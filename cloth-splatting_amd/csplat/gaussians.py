@@ -16,33 +16,40 @@ from .native import require_cuda
 
 class MeshTransform(torch.autograd.Function):
     """(deformed vertices, face_bary, _rotation) -> (means3D, rotations): one HIP kernel each way
-    (csplat_mesh_transform_fwd / _bwd, include/csplat.h)."""
+    (csplat_mesh_transform_fwd_views / _bwd_views, include/csplat.h).  vertices [V,3] -> ([P,3], [P,4]), or the cameras of a
+    training step at once: vertices [T,V,3] -> ([T,P,3], [T,P,4])."""
 
     @staticmethod
-    def forward(ctx, vertices, bary, rotation, vid, rest):
+    def forward(ctx, vertices, bary, rotation, vid, rest, rowptr=None, corners=None):
         vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
+        batched = vertices.dim() == 3
+        T, V = (int(vertices.shape[0]), int(vertices.shape[1])) if batched else (1, int(vertices.shape[0]))
         P = int(vid.shape[0])
-        xyz = torch.empty(P, 3, dtype=torch.float32, device=vertices.device)
-        quat = torch.empty(P, 4, dtype=torch.float32, device=vertices.device)
+        xyz = torch.empty((T, P, 3) if batched else (P, 3), dtype=torch.float32, device=vertices.device)
+        quat = torch.empty((T, P, 4) if batched else (P, 4), dtype=torch.float32, device=vertices.device)
         with torch.cuda.device(vertices.device):
-            _n.check(_n.lib.csplat_mesh_transform_fwd(_n.stream_handle(vertices.device), P, _n.ptr(vid), _n.ptr(vertices),
-                                                      _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest), _n.ptr(xyz), _n.ptr(quat)),
-                     "csplat_mesh_transform_fwd")
-        ctx.save_for_backward(vertices, bary, rotation, vid, rest)
+            _n.check(_n.lib.csplat_mesh_transform_fwd_views(_n.stream_handle(vertices.device), T, P, V, _n.ptr(vid),
+                                                            _n.ptr(vertices), _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest),
+                                                            _n.ptr(xyz), _n.ptr(quat)), "csplat_mesh_transform_fwd_views")
+        ctx.save_for_backward(vertices, bary, rotation, vid, rest, rowptr, corners)
+        ctx.dims = (T, P, V)
         return xyz, quat
 
     @staticmethod
     def backward(ctx, g_xyz, g_quat):
-        vertices, bary, rotation, vid, rest = ctx.saved_tensors
-        P, V = int(vid.shape[0]), int(vertices.shape[0])
+        vertices, bary, rotation, vid, rest, rowptr, corners = ctx.saved_tensors
+        T, P, V = ctx.dims
         d_v, d_b, d_r = torch.empty_like(vertices), torch.empty_like(bary), torch.empty_like(rotation)
+        scratch = None if rowptr is None else torch.empty(max(T * P * 9, 1), dtype=torch.float32, device=vertices.device)
         g_xyz = None if g_xyz is None else g_xyz.contiguous().float()
         g_quat = None if g_quat is None else g_quat.contiguous().float()
         with torch.cuda.device(vertices.device):
-            _n.check(_n.lib.csplat_mesh_transform_bwd(_n.stream_handle(vertices.device), P, V, _n.ptr(vid), _n.ptr(vertices),
-                                                      _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest), _n.ptr(g_xyz), _n.ptr(g_quat),
-                                                      _n.ptr(d_v), _n.ptr(d_b), _n.ptr(d_r)), "csplat_mesh_transform_bwd")
-        return d_v, d_b, d_r, None, None
+            _n.check(_n.lib.csplat_mesh_transform_bwd_views(_n.stream_handle(vertices.device), T, P, V, _n.ptr(vid),
+                                                            _n.ptr(vertices), _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest),
+                                                            _n.ptr(g_xyz), _n.ptr(g_quat), _n.ptr(d_v), _n.ptr(d_b), _n.ptr(d_r),
+                                                            _n.ptr(rowptr), _n.ptr(corners), _n.ptr(scratch)),
+                     "csplat_mesh_transform_bwd_views")
+        return d_v, d_b, d_r, None, None, None, None
 
 
 from .densify import DensifyMixin  # noqa: E402
@@ -195,11 +202,23 @@ class MeshGaussians(DensifyMixin):
             with torch.cuda.device(vid.device):
                 _n.check(_n.lib.csplat_mesh_rest(_n.stream_handle(vid.device), int(vid.shape[0]), _n.ptr(vid),
                                                  _n.ptr(self.mesh.pos.contiguous().float()), _n.ptr(rest)), "csplat_mesh_rest")
-            r = (key, vid, rest)
+            # vertex <- (Gaussian, corner) incidence, grouped by vertex in ascending pair order: the backward gathers the
+            # vertex gradients through it instead of scattering them with atomics (static until the next densification)
+            flat = vid.reshape(-1)
+            nv = int(self.mesh.pos.shape[0])
+            corners = torch.argsort(flat, stable=True).to(torch.int32)
+            rowptr = torch.zeros(nv + 1, dtype=torch.int32, device=vid.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=nv), 0).to(torch.int32)
+            r = (key, vid, rest, rowptr, corners)
             self._rest_cache = r
-        out = MeshTransform.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2])
+        out = MeshTransform.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2], r[3], r[4])
         self._fused_cache = (deformed_vertices, deformed_vertices._version, out)
         return out
+
+    def transform_views(self, deformed_vertices):
+        """get_xyz + get_rotation for the cameras of a step at once: [T,V,3] -> (tuple of T [P,3], tuple of T [P,4])."""
+        xyz, quat = self._fused(deformed_vertices)
+        return xyz.unbind(0), quat.unbind(0)
 
     def get_xyz(self, deformed_vertices=None):
         if deformed_vertices is not None and deformed_vertices.is_cuda and self.fused:

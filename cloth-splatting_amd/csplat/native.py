@@ -48,17 +48,20 @@ EXPORTS = {
     "csplat_mesh_rest": (_i, [_vp, _i, _vp, _vp, _vp]),
     "csplat_mesh_transform_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_mesh_transform_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_mesh_transform_fwd_views": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_mesh_transform_bwd_views": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_blur11": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
     "csplat_ssim_partial_count": (_sz, [_i64, _i, _i]),
     "csplat_ssim_fwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "csplat_adam_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _i64]),
     "csplat_l1_scratch_bytes": (_sz, []),
+    "csplat_project_points": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "csplat_psnr_scratch_bytes": (_sz, [_i64]),
     "csplat_psnr": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "csplat_rows_dot_scratch_bytes": (_sz, [_i]),
     "csplat_cloth_regs_scratch_bytes": (_sz, [_i, _i, _i64]),
-    "csplat_cloth_regs": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    "csplat_cloth_regs": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_rows_dot_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "csplat_rows_dot_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_l1": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),

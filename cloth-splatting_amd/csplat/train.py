@@ -204,7 +204,7 @@ class FusedClothRegs(torch.autograd.Function):
     """the three cloth regularisers and their gradient in one launch (csplat_cloth_regs); backward scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom):
+    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr=None):
         D = D.contiguous().float()
         T, V = int(D.shape[0]), int(D.shape[1])
         E = int(edge_index.shape[1])
@@ -214,14 +214,27 @@ class FusedClothRegs(torch.autograd.Function):
         with torch.cuda.device(D.device):
             _n.check(_n.lib.csplat_cloth_regs(_n.stream_handle(D.device), T, V, E, _n.ptr(D), _n.ptr(edge_index.contiguous()),
                                               _n.ptr(rest_len.contiguous().float()), float(lam_deform), float(lam_rigid),
-                                              float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch)), "csplat_cloth_regs")
+                                              float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
+                                              *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])), "csplat_cloth_regs")
         ctx.save_for_backward(grad)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None, None
+        return grad * g, None, None, None, None, None, None
+
+
+def edge_csr(edge_index, n_nodes):
+    """(dst_rowptr, dst_perm, src_rowptr, src_perm), int32: edge ids grouped by target / source vertex, ascending in a group."""
+    out = []
+    for row in (1, 0):
+        idx = edge_index[row]
+        perm = torch.argsort(idx, stable=True).to(torch.int32)
+        rowptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device=idx.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(idx, minlength=n_nodes), 0).to(torch.int32)
+        out += [rowptr, perm]
+    return tuple(out)
 
 
 def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True):
@@ -232,8 +245,16 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True)
         lam_d = opt.lambda_deform_mag if opt.lambda_deform_mag > 0. else 0.
         lam_r = opt.lambda_rigid if opt.lambda_rigid > 0 else 0.
         lam_m = opt.lambda_momentum if opt.lambda_momentum > 0 else 0.
-        return FusedClothRegs.apply(all_vertice_deform, gaussians.mesh.edge_index, gaussians.edge_norm.reshape(-1), lam_d, lam_r,
-                                    lam_m)
+        ei = gaussians.mesh.edge_index
+        key = (ei.data_ptr(), ei._version, tuple(ei.shape), int(all_vertice_deform.shape[1]))
+        cache = getattr(gaussians, "_edge_csr", None)       # the cloth graph is static: its CSR is built once
+        if cache is None or cache[0] != key:
+            cache = (key, edge_csr(ei, int(all_vertice_deform.shape[1])))
+            try:
+                gaussians._edge_csr = cache
+            except Exception:
+                pass
+        return FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
     loss = torch.zeros([], device=all_vertice_deform.device)
     if not static and opt.lambda_deform_mag > 0. and n_cams >= 3:
         d0 = torch.linalg.norm(all_vertice_deform[1] - all_vertice_deform[0], dim=-1).mean()

@@ -9,44 +9,18 @@
 // autograd) plus two sort-based index_put backward passes; here it is ONE kernel each way.
 //
 // The Kabsch solution for 3 points is closed form (no SVD): see csplat/rotations.py::kabsch_triangles, which the tests
-// pin against the SVD formulation.  The backward is forward-mode automatic differentiation inside the kernel: the SAME
-// templated function is instantiated on a dual number carrying 4 tangent directions, swept 4 times over the 16 inputs of
-// a Gaussian (9 vertex coordinates, 3 barycentric weights, 4 quaternion components) and contracted with the incoming
-// gradient -- the backward cannot drift from the forward.  Vertex gradients are scattered with float atomics.
+// pin against the SVD formulation.  The backward is the hand-written adjoint of the same sequence of steps
+// (transform_one_bwd, step numbers matching transform_one): ~1/14 of the instructions of the forward-mode sweep over the 16
+// inputs it replaced (7800 -> ~550 per Gaussian) and a third of its registers.  Vertex gradients are scattered with float
+// atomics.  Both directions take the T cameras of a training step in one launch (vertices [T][V][3]).
 #include "csplat_common.h"
 
 namespace {
 
-template <int N>
-struct Dual {
-    float v;
-    float d[N];
-};
-template <int N> __device__ __forceinline__ Dual<N> mk(float v) { Dual<N> r; r.v = v; for (int i = 0; i < N; i++) r.d[i] = 0.f; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator+(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator-(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator-(Dual<N> a) { Dual<N> r; r.v = -a.v; for (int i = 0; i < N; i++) r.d[i] = -a.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator*(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator*(Dual<N> a, float b) { Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; i++) r.d[i] = a.d[i] * b; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator*(float b, Dual<N> a) { return a * b; }
-template <int N> __device__ __forceinline__ Dual<N> operator+(Dual<N> a, float b) { a.v += b; return a; }
-template <int N> __device__ __forceinline__ Dual<N> operator-(float b, Dual<N> a) { Dual<N> r = -a; r.v += b; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator/(Dual<N> a, Dual<N> b) {
-    Dual<N> r; const float inv = 1.f / b.v; r.v = a.v * inv;
-    for (int i = 0; i < N; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
-    return r;
-}
-template <int N> __device__ __forceinline__ Dual<N> rsqrt_(Dual<N> a) {
-    Dual<N> r; r.v = 1.f / sqrtf(a.v); const float k = -0.5f * r.v / a.v;
-    for (int i = 0; i < N; i++) r.d[i] = k * a.d[i];
-    return r;
-}
 __device__ __forceinline__ float rsqrt_(float a) { return 1.f / sqrtf(a); }
 __device__ __forceinline__ float val(float a) { return a; }
-template <int N> __device__ __forceinline__ float val(Dual<N> a) { return a.v; }
 template <typename T> __device__ __forceinline__ T lift(float v);
 template <> __device__ __forceinline__ float lift<float>(float v) { return v; }
-template <> __device__ __forceinline__ Dual<4> lift<Dual<4>>(float v) { return mk<4>(v); }
 
 // rest-face constants of one Gaussian (independent of the deformation): orthonormal in-plane basis + normal of the
 // centred rest triangle and the in-plane coordinates of its 3 points
@@ -158,65 +132,260 @@ __global__ __launch_bounds__(256) void k_rest_faces(int P, const int64_t *__rest
     out[i] = rf;
 }
 
-__global__ __launch_bounds__(256) void k_mesh_fwd(int P, const int64_t *__restrict__ vid, const float *__restrict__ verts,
+// blockIdx.y = camera t of the step: vertices [T][V][3] -> out_pos [T][P][3], out_quat [T][P][4]
+__global__ __launch_bounds__(256) void k_mesh_fwd(int P, int V, const int64_t *__restrict__ vid, const float *__restrict__ verts_all,
                                                    const float *__restrict__ bary, const float *__restrict__ rot,
                                                    const RestFace *__restrict__ rest, float *__restrict__ out_pos,
                                                    float *__restrict__ out_quat) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    const float *verts = verts_all + (size_t)blockIdx.y * V * 3;
+    const size_t o = (size_t)blockIdx.y * P + i;
     float y[3][3], b[3], q0[4], pos[3], quat[4];
     for (int k = 0; k < 3; k++)
         for (int c = 0; c < 3; c++) y[k][c] = verts[3 * vid[3 * (size_t)i + k] + c];
     for (int k = 0; k < 3; k++) b[k] = bary[3 * (size_t)i + k];
     for (int k = 0; k < 4; k++) q0[k] = rot[4 * (size_t)i + k];
     transform_one<float>(y, b, q0, rest[i], pos, quat);
-    for (int c = 0; c < 3; c++) out_pos[3 * (size_t)i + c] = pos[c];
-    for (int c = 0; c < 4; c++) out_quat[4 * (size_t)i + c] = quat[c];
+    for (int c = 0; c < 3; c++) out_pos[3 * o + c] = pos[c];
+    for (int c = 0; c < 4; c++) out_quat[4 * o + c] = quat[c];
 }
 
-// four threads per Gaussian, one per sweep of four tangent directions (inputs 4*sweep .. 4*sweep+3): 4x the wavefronts of a
-// thread-per-Gaussian launch (100k Gaussians are only 1.5 waves per SIMD, each a long dependent chain)
-__global__ __launch_bounds__(256) void k_mesh_bwd(int P, const int64_t *__restrict__ vid, const float *__restrict__ verts,
-                                                   const float *__restrict__ bary, const float *__restrict__ rot,
-                                                   const RestFace *__restrict__ rest, const float *__restrict__ g_pos,
-                                                   const float *__restrict__ g_quat, float *__restrict__ d_verts,
-                                                   float *__restrict__ d_bary, float *__restrict__ d_rot) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int i = gid >> 2, sweep = gid & 3;
-    if (i >= P) return;
-    typedef Dual<4> D;
-    float in[16];
-    int64_t v3[3];
+__device__ __forceinline__ float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// adjoint of transform_one: (gpos, gquat) -> (gy, gb, gq0).  The forward values are recomputed (same expressions, same
+// branches); the steps are undone in reverse order.
+__device__ __forceinline__ void transform_one_bwd(const float y[3][3], const float bary[3], const float q0[4], const RestFace &rf,
+                                                  const float gpos[3], const float gquat[4], float gy[3][3], float gb[3],
+                                                  float gq0[4]) {
+    // ================= forward recomputation
+    const float bs = bary[0] + bary[1] + bary[2], ibs = 1.f / bs;
+    float pos[3];
+    for (int c = 0; c < 3; c++) pos[c] = (bary[0] * y[0][c] + bary[1] * y[1][c] + bary[2] * y[2][c]) * ibs;
+    float yh[3][3];
+    for (int c = 0; c < 3; c++) {
+        const float m = (y[0][c] + y[1][c] + y[2][c]) * (1.f / 3.f);
+        for (int k = 0; k < 3; k++) yh[k][c] = y[k][c] - m;
+    }
+    // plane_basis(yh[0], yh[1]) with its intermediates kept
+    const float inv0 = rsqrt_(dot3(yh[0], yh[0]));
+    float u[3], t[3], v[3], n[3];
+    for (int k = 0; k < 3; k++) u[k] = yh[0][k] * inv0;
+    const float dt = dot3(yh[1], u);
+    for (int k = 0; k < 3; k++) t[k] = yh[1][k] - dt * u[k];
+    const float inv1 = rsqrt_(dot3(t, t));
+    for (int k = 0; k < 3; k++) v[k] = t[k] * inv1;
+    n[0] = u[1] * v[2] - u[2] * v[1]; n[1] = u[2] * v[0] - u[0] * v[2]; n[2] = u[0] * v[1] - u[1] * v[0];
+    float a = 0.f, b = 0.f, c_ = 0.f, d = 0.f;
     for (int k = 0; k < 3; k++) {
-        v3[k] = vid[3 * (size_t)i + k];
-        for (int c = 0; c < 3; c++) in[3 * k + c] = verts[3 * v3[k] + c];
+        const float yu = dot3(yh[k], u), yv = dot3(yh[k], v);
+        a += yu * rf.xu[k]; b += yu * rf.xv[k]; c_ += yv * rf.xu[k]; d += yv * rf.xv[k];
     }
-    for (int k = 0; k < 3; k++) in[9 + k] = bary[3 * (size_t)i + k];
-    for (int k = 0; k < 4; k++) in[12 + k] = rot[4 * (size_t)i + k];
-    float g[7];
-    for (int c = 0; c < 3; c++) g[c] = g_pos ? g_pos[3 * (size_t)i + c] : 0.f;
-    for (int c = 0; c < 4; c++) g[3 + c] = g_quat ? g_quat[4 * (size_t)i + c] : 0.f;
+    const bool pos_det = a * d - b * c_ > 0.f;
+    const float sgn = pos_det ? 1.f : -1.f;
+    const float r00 = a + sgn * d, r01 = b - sgn * c_;          // raw (q00, q01)
+    const float nrm = rsqrt_(r00 * r00 + r01 * r01);
+    const float q00 = r00 * nrm, q01 = r01 * nrm;
+    const float q10 = -sgn * q01, q11 = sgn * q00;
+    float R[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i][j] = q00 * (u[i] * rf.ux[j]) + q01 * (u[i] * rf.vx[j]) + q10 * (v[i] * rf.ux[j]) + q11 * (v[i] * rf.vx[j]) +
+                      n[i] * (sgn * rf.nx[j]);
+    const float tr = R[0][0] + R[1][1] + R[2][2];
+    int choice = 0;
+    float best = R[0][0];
+    if (R[1][1] > best) { best = R[1][1]; choice = 1; }
+    if (R[2][2] > best) { best = R[2][2]; choice = 2; }
+    if (tr > best) { best = tr; choice = 3; }
+    float qr[4];
+#define QBRANCH(I, J, K)                     \
+    {                                        \
+        qr[I] = (1.f - tr) + 2.f * R[I][I];  \
+        qr[J] = R[J][I] + R[I][J];           \
+        qr[K] = R[K][I] + R[I][K];           \
+        qr[3] = R[K][J] - R[J][K];           \
+    }
+    if (choice == 3) {
+        qr[0] = R[2][1] - R[1][2]; qr[1] = R[0][2] - R[2][0]; qr[2] = R[1][0] - R[0][1]; qr[3] = tr + 1.f;
+    } else if (choice == 0) QBRANCH(0, 1, 2)
+    else if (choice == 1) QBRANCH(1, 2, 0)
+    else QBRANCH(2, 0, 1)
+#undef QBRANCH
+    const float invq = rsqrt_(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
+    for (int i = 0; i < 4; i++) qr[i] *= invq;
+    const float invp = rsqrt_(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+    float p[4];
+    for (int i = 0; i < 4; i++) p[i] = q0[i] * invp;
+
+    // ================= adjoint, last step first
+    // 9. quat = Hamilton(p, qr) (bilinear)
+    const float *g = gquat;
+    float gp[4], gqr[4];
+    gp[0] = g[0] * qr[3] - g[1] * qr[2] + g[2] * qr[1] - g[3] * qr[0];
+    gp[1] = g[0] * qr[2] + g[1] * qr[3] - g[2] * qr[0] - g[3] * qr[1];
+    gp[2] = -g[0] * qr[1] + g[1] * qr[0] + g[2] * qr[3] - g[3] * qr[2];
+    gp[3] = g[0] * qr[0] + g[1] * qr[1] + g[2] * qr[2] + g[3] * qr[3];
+    gqr[0] = g[0] * p[3] + g[1] * p[2] - g[2] * p[1] - g[3] * p[0];
+    gqr[1] = -g[0] * p[2] + g[1] * p[3] + g[2] * p[0] - g[3] * p[1];
+    gqr[2] = g[0] * p[1] - g[1] * p[0] + g[2] * p[3] - g[3] * p[2];
+    gqr[3] = g[0] * p[0] + g[1] * p[1] + g[2] * p[2] + g[3] * p[3];
+    // 8. p = q0 / |q0|
+    {
+        const float pg = p[0] * gp[0] + p[1] * gp[1] + p[2] * gp[2] + p[3] * gp[3];
+        for (int i = 0; i < 4; i++) gq0[i] = invp * (gp[i] - p[i] * pg);
+    }
+    // 7. qr = raw / |raw|, raw linear in R (by branch)
+    float graw[4];
+    {
+        const float qg = qr[0] * gqr[0] + qr[1] * gqr[1] + qr[2] * gqr[2] + qr[3] * gqr[3];
+        for (int i = 0; i < 4; i++) graw[i] = invq * (gqr[i] - qr[i] * qg);
+    }
+    float gR[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) gR[i][j] = 0.f;
+#define QBRANCH_BWD(I, J, K)                                                        \
+    {                                                                               \
+        gR[0][0] -= graw[I]; gR[1][1] -= graw[I]; gR[2][2] -= graw[I];              \
+        gR[I][I] += 2.f * graw[I];                                                  \
+        gR[J][I] += graw[J]; gR[I][J] += graw[J];                                   \
+        gR[K][I] += graw[K]; gR[I][K] += graw[K];                                   \
+        gR[K][J] += graw[3]; gR[J][K] -= graw[3];                                   \
+    }
+    if (choice == 3) {
+        gR[2][1] += graw[0]; gR[1][2] -= graw[0];
+        gR[0][2] += graw[1]; gR[2][0] -= graw[1];
+        gR[1][0] += graw[2]; gR[0][1] -= graw[2];
+        gR[0][0] += graw[3]; gR[1][1] += graw[3]; gR[2][2] += graw[3];
+    } else if (choice == 0) QBRANCH_BWD(0, 1, 2)
+    else if (choice == 1) QBRANCH_BWD(1, 2, 0)
+    else QBRANCH_BWD(2, 0, 1)
+#undef QBRANCH_BWD
+    // 6. R = q00 u ux^T + q01 u vx^T + q10 v ux^T + q11 v vx^T + sgn n nx^T
+    float A[3], B[3], gn[3], gu[3], gv[3];
+    for (int i = 0; i < 3; i++) {
+        A[i] = gR[i][0] * rf.ux[0] + gR[i][1] * rf.ux[1] + gR[i][2] * rf.ux[2];
+        B[i] = gR[i][0] * rf.vx[0] + gR[i][1] * rf.vx[1] + gR[i][2] * rf.vx[2];
+        gn[i] = sgn * (gR[i][0] * rf.nx[0] + gR[i][1] * rf.nx[1] + gR[i][2] * rf.nx[2]);
+    }
+    const float gq00 = dot3(u, A), gq01 = dot3(u, B), gq10 = dot3(v, A), gq11 = dot3(v, B);
+    for (int i = 0; i < 3; i++) {
+        gu[i] = q00 * A[i] + q01 * B[i];
+        gv[i] = q10 * A[i] + q11 * B[i];
+    }
+    // 5. q10 = -sgn q01, q11 = sgn q00; (q00, q01) = (r00, r01) / |(r00, r01)|; r00 = a + sgn d, r01 = b - sgn c
+    const float gn00 = gq00 + sgn * gq11, gn01 = gq01 - sgn * gq10;
+    const float qg2 = q00 * gn00 + q01 * gn01;
+    const float gr00 = nrm * (gn00 - q00 * qg2), gr01 = nrm * (gn01 - q01 * qg2);
+    const float ga = gr00, gd = sgn * gr00, gbb = gr01, gc = -sgn * gr01;
+    // 4. a, b, c, d from yu_k = yh_k . u, yv_k = yh_k . v
+    float gyh[3][3];
+    for (int k = 0; k < 3; k++) {
+        const float gyu = ga * rf.xu[k] + gbb * rf.xv[k], gyv = gc * rf.xu[k] + gd * rf.xv[k];
+        for (int c = 0; c < 3; c++) {
+            gyh[k][c] = gyu * u[c] + gyv * v[c];
+            gu[c] += gyu * yh[k][c];
+            gv[c] += gyv * yh[k][c];
+        }
+    }
+    // 3. plane basis: n = u x v; v = t / |t|; t = p1 - dt u; dt = p1 . u; u = p0 / |p0|
+    gu[0] += v[1] * gn[2] - v[2] * gn[1]; gu[1] += v[2] * gn[0] - v[0] * gn[2]; gu[2] += v[0] * gn[1] - v[1] * gn[0];
+    gv[0] += gn[1] * u[2] - gn[2] * u[1]; gv[1] += gn[2] * u[0] - gn[0] * u[2]; gv[2] += gn[0] * u[1] - gn[1] * u[0];
+    float gt[3];
+    {
+        const float vg = dot3(v, gv);
+        for (int k = 0; k < 3; k++) gt[k] = inv1 * (gv[k] - v[k] * vg);
+    }
+    const float gdt = -dot3(gt, u);
+    for (int k = 0; k < 3; k++) {
+        gyh[1][k] += gt[k] + gdt * u[k];
+        gu[k] += -dt * gt[k] + gdt * yh[1][k];
+    }
+    {
+        const float ug = dot3(u, gu);
+        for (int k = 0; k < 3; k++) gyh[0][k] += inv0 * (gu[k] - u[k] * ug);
+    }
+    // 2. yh = y - mean;  1. pos = sum_k bary_k y_k / bs
+    for (int c = 0; c < 3; c++) {
+        const float m = (gyh[0][c] + gyh[1][c] + gyh[2][c]) * (1.f / 3.f);
+        for (int k = 0; k < 3; k++) gy[k][c] = gyh[k][c] - m + gpos[c] * bary[k] * ibs;
+    }
+    for (int k = 0; k < 3; k++)
+        gb[k] = (gpos[0] * (y[k][0] - pos[0]) + gpos[1] * (y[k][1] - pos[1]) + gpos[2] * (y[k][2] - pos[2])) * ibs;
+}
+
+// one thread per Gaussian, looping over the T cameras: d_bary / d_rot are summed over the cameras in registers (fixed
+// order), the vertex gradients of camera t go to d_verts[t] with atomics
+__global__ __launch_bounds__(256) void k_mesh_bwd(int T, int P, int V, const int64_t *__restrict__ vid,
+                                                   const float *__restrict__ verts_all, const float *__restrict__ bary,
+                                                   const float *__restrict__ rot, const RestFace *__restrict__ rest,
+                                                   const float *__restrict__ g_pos, const float *__restrict__ g_quat,
+                                                   float *__restrict__ d_verts, float *__restrict__ d_bary, float *__restrict__ d_rot,
+                                                   float *__restrict__ corner_grads) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    int64_t v3[3];
+    float b[3], q0[4];
+    for (int k = 0; k < 3; k++) v3[k] = vid[3 * (size_t)i + k];
+    for (int k = 0; k < 3; k++) b[k] = bary[3 * (size_t)i + k];
+    for (int k = 0; k < 4; k++) q0[k] = rot[4 * (size_t)i + k];
     const RestFace rf = rest[i];
-    D y[3][3], b[3], q0[4], pos[3], quat[4];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-        D x = mk<4>(in[t]);
-        x.d[t & 3] = (t >> 2) == sweep ? 1.f : 0.f;
-        if (t < 9) y[t / 3][t % 3] = x;
-        else if (t < 12) b[t - 9] = x;
-        else q0[t - 12] = x;
+    float sb[3] = {0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; t++) {
+        const float *verts = verts_all + (size_t)t * V * 3;
+        const size_t o = (size_t)t * P + i;
+        float y[3][3], gp[3], gq[4], gy[3][3], gb[3], gq0[4];
+        for (int k = 0; k < 3; k++)
+            for (int c = 0; c < 3; c++) y[k][c] = verts[3 * v3[k] + c];
+        for (int c = 0; c < 3; c++) gp[c] = g_pos ? g_pos[3 * o + c] : 0.f;
+        for (int c = 0; c < 4; c++) gq[c] = g_quat ? g_quat[4 * o + c] : 0.f;
+        transform_one_bwd(y, b, q0, rf, gp, gq, gy, gb, gq0);
+        if (corner_grads) {   // [T][P][3 corners][3]: summed per vertex by k_vertex_gather (no atomics, fixed order)
+            float *o9 = corner_grads + o * 9;
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < 3; c++) o9[3 * k + c] = gy[k][c];
+        } else {
+            float *dv = d_verts + (size_t)t * V * 3;
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < 3; c++) atomicAdd(dv + 3 * v3[k] + c, gy[k][c]);
+        }
+        for (int k = 0; k < 3; k++) sb[k] += gb[k];
+        for (int k = 0; k < 4; k++) sq[k] += gq0[k];
     }
-    transform_one<D>(y, b, q0, rf, pos, quat);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        float s = 0.f;
-        for (int c = 0; c < 3; c++) s += g[c] * pos[c].d[u];
-        for (int c = 0; c < 4; c++) s += g[3 + c] * quat[c].d[u];
-        const int t = 4 * sweep + u;   // input this derivative belongs to: 0-8 vertices, 9-11 barycentrics, 12-15 rotation
-        if (t < 9) atomicAdd(d_verts + 3 * (t < 3 ? v3[0] : (t < 6 ? v3[1] : v3[2])) + t % 3, s);
-        else if (t < 12) d_bary[3 * (size_t)i + (t - 9)] = s;
-        else d_rot[4 * (size_t)i + (t - 12)] = s;
+    for (int k = 0; k < 3; k++) d_bary[3 * (size_t)i + k] = sb[k];
+    for (int k = 0; k < 4; k++) d_rot[4 * (size_t)i + k] = sq[k];
+}
+
+// d_verts[t][v] = sum of the corner gradients of the (Gaussian, corner) pairs incident to vertex v, in the fixed order of the
+// incidence list (corners[rowptr[v] .. rowptr[v+1]) = 3 * gaussian + corner, ascending).  100k Gaussians on a 10k-vertex mesh
+// put ~30 contributions on every vertex coordinate: as float atomics that is 2.7 M serialised L2 operations per step (150 us);
+// as a gather over the static incidence it is 10 MB of reads.
+__global__ __launch_bounds__(256) void k_vertex_gather(int P, int V, const int *__restrict__ rowptr, const int *__restrict__ corners,
+                                                        const float *__restrict__ corner_grads, float *__restrict__ d_verts) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float *cg = corner_grads + (size_t)blockIdx.y * P * 9;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int e = rowptr[v], end = rowptr[v + 1]; e < end; e++) {
+        const float *g = cg + 3 * (size_t)corners[e];
+        s0 += g[0]; s1 += g[1]; s2 += g[2];
     }
+    float *o = d_verts + ((size_t)blockIdx.y * V + v) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+}
+
+// pixel coordinates of world points: [p, 1] @ full_proj (row-vector convention), perspective divide, ndc -> pixel
+// (reference gaussian_renderer/__init__.py:166-179).  `full` is the device-resident 4x4 as torch stores it (row-major).
+__global__ __launch_bounds__(256) void k_project_points(int64_t n, const float *__restrict__ full, float W, float H,
+                                                        const float *__restrict__ pts, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    const float hx = x * full[0] + y * full[4] + z * full[8] + full[12];
+    const float hy = x * full[1] + y * full[5] + z * full[9] + full[13];
+    const float hw = x * full[3] + y * full[7] + z * full[11] + full[15];
+    out[2 * i] = ((hx / hw + 1.f) * W - 1.f) * 0.5f;
+    out[2 * i + 1] = ((hy / hw + 1.f) * H - 1.f) * 0.5f;
 }
 
 }  // namespace
@@ -233,27 +402,56 @@ int csplat_mesh_rest(void *stream, int P, const int64_t *face_vertex_ids, const 
     return 0;
 }
 
-int csplat_mesh_transform_fwd(void *stream, int P, const int64_t *face_vertex_ids, const float *vertices, const float *bary,
-                              const float *rotation, const void *rest, float *out_xyz, float *out_quat) {
-    CSPLAT_REQUIRE(P >= 0, "csplat_mesh_transform_fwd: bad P");
-    if (P == 0) return 0;
-    CSPLAT_REQUIRE(face_vertex_ids && vertices && bary && rotation && rest && out_xyz && out_quat, "csplat_mesh_transform_fwd: NULL");
-    k_mesh_fwd<<<cdiv(P, 256), 256, 0, (hipStream_t)stream>>>(P, face_vertex_ids, vertices, bary, rotation, (const RestFace *)rest,
-                                                              out_xyz, out_quat);
+int csplat_mesh_transform_fwd_views(void *stream, int T, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
+                                    const float *bary, const float *rotation, const void *rest, float *out_xyz, float *out_quat) {
+    CSPLAT_REQUIRE(T >= 0 && T < 65536 && P >= 0 && V >= 0, "csplat_mesh_transform_fwd_views: bad sizes");
+    if (P == 0 || T == 0) return 0;
+    CSPLAT_REQUIRE(face_vertex_ids && vertices && bary && rotation && rest && out_xyz && out_quat, "csplat_mesh_transform_fwd_views: NULL");
+    k_mesh_fwd<<<dim3(cdiv(P, 256), T), 256, 0, (hipStream_t)stream>>>(P, V, face_vertex_ids, vertices, bary, rotation,
+                                                                       (const RestFace *)rest, out_xyz, out_quat);
     LAUNCH_CHECK();
     return 0;
+}
+
+int csplat_mesh_transform_bwd_views(void *stream, int T, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
+                                    const float *bary, const float *rotation, const void *rest, const float *g_xyz,
+                                    const float *g_quat, float *d_vertices, float *d_bary, float *d_rotation,
+                                    const int *vertex_rowptr, const int *vertex_corners, float *corner_scratch) {
+    CSPLAT_REQUIRE(T >= 0 && T < 65536 && P >= 0 && V >= 0, "csplat_mesh_transform_bwd_views: bad sizes");
+    CSPLAT_REQUIRE((V == 0 || T == 0 || d_vertices) && (P == 0 || (d_bary && d_rotation)), "csplat_mesh_transform_bwd_views: NULL outputs");
+    const bool gather = vertex_rowptr != nullptr;
+    CSPLAT_REQUIRE(!gather || (vertex_corners && corner_scratch), "csplat_mesh_transform_bwd_views: incidence without corners / scratch");
+    hipStream_t s = (hipStream_t)stream;
+    if (V > 0 && T > 0 && (!gather || P == 0)) HIP_TRY(hipMemsetAsync(d_vertices, 0, (size_t)T * V * 3 * 4, s));
+    if (P == 0) return 0;   // (every Gaussian pruned: the vertex gradient is zero)
+    CSPLAT_REQUIRE(T == 0 || (face_vertex_ids && vertices && bary && rotation && rest), "csplat_mesh_transform_bwd_views: NULL inputs");
+    k_mesh_bwd<<<cdiv(P, 256), 256, 0, s>>>(T, P, V, face_vertex_ids, vertices, bary, rotation, (const RestFace *)rest, g_xyz, g_quat,
+                                            d_vertices, d_bary, d_rotation, gather ? corner_scratch : nullptr);
+    LAUNCH_CHECK();
+    if (gather && V > 0 && T > 0) {
+        k_vertex_gather<<<dim3(cdiv(V, 256), T), 256, 0, s>>>(P, V, vertex_rowptr, vertex_corners, corner_scratch, d_vertices);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int csplat_mesh_transform_fwd(void *stream, int P, const int64_t *face_vertex_ids, const float *vertices, const float *bary,
+                              const float *rotation, const void *rest, float *out_xyz, float *out_quat) {
+    return csplat_mesh_transform_fwd_views(stream, 1, P, 0, face_vertex_ids, vertices, bary, rotation, rest, out_xyz, out_quat);
 }
 
 int csplat_mesh_transform_bwd(void *stream, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
                               const float *bary, const float *rotation, const void *rest, const float *g_xyz,
                               const float *g_quat, float *d_vertices, float *d_bary, float *d_rotation) {
-    CSPLAT_REQUIRE(P >= 0 && V >= 0, "csplat_mesh_transform_bwd: bad sizes");
-    CSPLAT_REQUIRE((V == 0 || d_vertices) && (P == 0 || (d_bary && d_rotation)), "csplat_mesh_transform_bwd: NULL outputs");
-    hipStream_t s = (hipStream_t)stream;
-    if (V > 0) HIP_TRY(hipMemsetAsync(d_vertices, 0, (size_t)V * 3 * 4, s));
-    if (P == 0) return 0;   // (every Gaussian pruned: the vertex gradient is zero)
-    k_mesh_bwd<<<cdiv(4 * (int64_t)P, 256), 256, 0, s>>>(P, face_vertex_ids, vertices, bary, rotation, (const RestFace *)rest, g_xyz, g_quat,
-                                            d_vertices, d_bary, d_rotation);
+    return csplat_mesh_transform_bwd_views(stream, 1, P, V, face_vertex_ids, vertices, bary, rotation, rest, g_xyz, g_quat, d_vertices,
+                                           d_bary, d_rotation, nullptr, nullptr, nullptr);
+}
+
+int csplat_project_points(void *stream, int64_t n, const float *full_proj, int W, int H, const float *points, float *out_pixels) {
+    CSPLAT_REQUIRE(n >= 0 && W > 0 && H > 0, "csplat_project_points: bad sizes");
+    if (n == 0) return 0;
+    CSPLAT_REQUIRE(full_proj && points && out_pixels, "csplat_project_points: NULL");
+    k_project_points<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(n, full_proj, (float)W, (float)H, points, out_pixels);
     LAUNCH_CHECK();
     return 0;
 }

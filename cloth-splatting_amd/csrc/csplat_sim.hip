@@ -217,6 +217,99 @@ __global__ __launch_bounds__(256) void k_cloth_regs(int T, int V, long long E, c
     }
 }
 
+// The same terms, node-centric: thread (t, v) visits the edges INTO v (loss + gradient) and OUT OF v (gradient) through the
+// static CSR of the cloth graph and writes grad[t][v] once -- no atomics, no zero-fill, every bit reproducible.  Each edge's
+// length is evaluated twice (once from either end); that is cheaper than 6 float atomics per (time, edge) on ~V addresses.
+__global__ __launch_bounds__(256) void k_cloth_regs_csr(int T, int V, long long E, const float *__restrict__ D,
+                                                        const int64_t *__restrict__ ei, const float *__restrict__ rest_len,
+                                                        const int *__restrict__ dst_rowptr, const int *__restrict__ dst_perm,
+                                                        const int *__restrict__ src_rowptr, const int *__restrict__ src_perm,
+                                                        float w_deform, float w_rigid, float w_mom, float *__restrict__ grad,
+                                                        float *__restrict__ partial, unsigned int *__restrict__ ticket,
+                                                        float *__restrict__ loss) {
+    __shared__ float s_red[4];
+    __shared__ bool s_last;
+    const int v = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+    float acc = 0.f;
+    if (v < V) {
+        const float *Dt = D + (size_t)t * V * 3;
+        const float px = Dt[3 * (size_t)v], py = Dt[3 * (size_t)v + 1], pz = Dt[3 * (size_t)v + 2];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (w_rigid != 0.f) {
+            for (int e = dst_rowptr[v], end = dst_rowptr[v + 1]; e < end; e++) {   // edges (a -> v): disp = D[v] - D[a]
+                const int id = dst_perm[e];
+                const int64_t a = ei[id];
+                const float dx = px - Dt[3 * a], dy = py - Dt[3 * a + 1], dz = pz - Dt[3 * a + 2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float diff = rest_len[id] - len;
+                acc += w_rigid * fabsf(diff);
+                const float sl = diff > 0.f ? -w_rigid : (diff < 0.f ? w_rigid : 0.f);
+                const float k = len > 0.f ? sl / len : 0.f;
+                gx += k * dx; gy += k * dy; gz += k * dz;
+            }
+            for (int e = src_rowptr[v], end = src_rowptr[v + 1]; e < end; e++) {   // edges (v -> b): disp = D[b] - D[v]
+                const int id = src_perm[e];
+                const int64_t b = ei[E + id];
+                const float dx = Dt[3 * b] - px, dy = Dt[3 * b + 1] - py, dz = Dt[3 * b + 2] - pz;
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float diff = rest_len[id] - len;
+                const float sl = diff > 0.f ? -w_rigid : (diff < 0.f ? w_rigid : 0.f);
+                const float k = len > 0.f ? sl / len : 0.f;
+                gx -= k * dx; gy -= k * dy; gz -= k * dz;
+            }
+        }
+        if (T >= 3 && t < 3 && (w_deform != 0.f || w_mom != 0.f)) {
+            float d0[3], d1[3], d2[3], g[3] = {0.f, 0.f, 0.f};
+            for (int c = 0; c < 3; c++) {
+                d0[c] = D[(size_t)v * 3 + c];
+                d1[c] = D[((size_t)V + v) * 3 + c];
+                d2[c] = D[((size_t)2 * V + v) * 3 + c];
+            }
+            if (w_deform != 0.f) {
+                const float a[3] = {d1[0] - d0[0], d1[1] - d0[1], d1[2] - d0[2]};
+                const float b[3] = {d2[0] - d1[0], d2[1] - d1[1], d2[2] - d1[2]};
+                const float na = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+                const float nb = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+                if (t == 0) acc += w_deform * (na + nb);
+                const float ia = na > 0.f ? w_deform / na : 0.f, ib = nb > 0.f ? w_deform / nb : 0.f;
+                for (int c = 0; c < 3; c++) g[c] += t == 0 ? -ia * a[c] : (t == 1 ? ia * a[c] - ib * b[c] : ib * b[c]);
+            }
+            if (w_mom != 0.f) {
+                for (int c = 0; c < 3; c++) {
+                    const float m = d2[c] - 2.f * d1[c] + d0[c];
+                    if (t == 0) acc += w_mom * fabsf(m);
+                    const float sg = m > 0.f ? w_mom : (m < 0.f ? -w_mom : 0.f);
+                    g[c] += t == 1 ? -2.f * sg : sg;
+                }
+            }
+            gx += g[0]; gy += g[1]; gz += g[2];
+        }
+        float *o = grad + ((size_t)t * V + v) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const unsigned nblocks = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+        partial[me] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == nblocks - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float s = 0.f;
+    for (unsigned j = threadIdx.x; j < nblocks; j += 256) s += __builtin_nontemporal_load(partial + j);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *loss = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        *ticket = 0u;
+    }
+}
+
 template <int T>
 int launch_fwd(hipStream_t s, int R, const float *W, const float *b, const float *h, float *y) {
     k_rows_dot_fwd<T><<<SIM_BLOCKS, 256, 0, s>>>(R, (const float4 *)W, b, (const float4 *)h, y);
@@ -276,19 +369,24 @@ int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const
 
 size_t csplat_cloth_regs_scratch_bytes(int T, int V, int64_t E) {
     const int64_t items = (int64_t)V + (int64_t)(T > 0 ? T : 0) * (E > 0 ? E : 0);
-    return align256((size_t)(cdiv(items > 0 ? items : 1, 256) + 1) * sizeof(float)) + 256;
+    const int64_t blocks = cdiv(items > 0 ? items : 1, 256) + (int64_t)(T > 0 ? T : 0) * cdiv(V > 0 ? V : 1, 256);
+    return align256((size_t)(blocks + 1) * sizeof(float)) + 256;
 }
 
 int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, const int64_t *edge_index, const float *rest_len,
-                      float lambda_deform, float lambda_rigid, float lambda_momentum, float *loss, float *grad, void *scratch) {
+                      float lambda_deform, float lambda_rigid, float lambda_momentum, float *loss, float *grad, void *scratch,
+                      const int *dst_rowptr, const int *dst_perm, const int *src_rowptr, const int *src_perm) {
     CSPLAT_REQUIRE(T >= 0 && V >= 0 && E >= 0, "csplat_cloth_regs: bad sizes");
     CSPLAT_REQUIRE(loss && scratch, "csplat_cloth_regs: NULL loss / scratch");
     hipStream_t s = (hipStream_t)stream;
     const bool node_terms = T >= 3 && V > 0 && (lambda_deform != 0.f || lambda_momentum != 0.f);
     const bool edge_terms = T > 0 && E > 0 && V > 0 && lambda_rigid != 0.f;
+    const bool csr = dst_rowptr != nullptr;
+    CSPLAT_REQUIRE(!csr || (dst_perm && src_rowptr && src_perm), "csplat_cloth_regs: incomplete CSR");
+    CSPLAT_REQUIRE(T < 65536, "csplat_cloth_regs: T too large");
     if (T > 0 && V > 0) {
         CSPLAT_REQUIRE(D && grad, "csplat_cloth_regs: NULL D / grad");
-        HIP_TRY(hipMemsetAsync(grad, 0, (size_t)T * V * 3 * sizeof(float), s));
+        if (!csr || !(node_terms || edge_terms)) HIP_TRY(hipMemsetAsync(grad, 0, (size_t)T * V * 3 * sizeof(float), s));
     }
     if (!node_terms && !edge_terms) {
         HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), s));
@@ -300,6 +398,17 @@ int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, con
     float *partial = (float *)scratch;
     unsigned int *ticket = (unsigned int *)((char *)scratch + align256((size_t)(blocks + 1) * sizeof(float)));
     HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), s));
+    if (csr) {
+        ticket = (unsigned int *)((char *)scratch + csplat_cloth_regs_scratch_bytes(T, V, E) - 256);   // behind all partials
+        HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), s));
+        k_cloth_regs_csr<<<dim3(cdiv(V, 256), T), 256, 0, s>>>(
+            T, V, (long long)E, D, edge_index, rest_len, dst_rowptr, dst_perm, src_rowptr, src_perm,
+            node_terms && lambda_deform != 0.f ? 0.5f * lambda_deform / (float)V : 0.f,
+            edge_terms ? lambda_rigid / ((float)T * (float)E) : 0.f,
+            node_terms && lambda_momentum != 0.f ? lambda_momentum / (float)V : 0.f, grad, partial, ticket, loss);
+        LAUNCH_CHECK();
+        return 0;
+    }
     k_cloth_regs<<<blocks, 256, 0, s>>>(T, V, (long long)E, D, edge_index, rest_len,
                                         node_terms && lambda_deform != 0.f ? 0.5f * lambda_deform / (float)V : 0.f,
                                         edge_terms ? lambda_rigid / ((float)T * (float)E) : 0.f,

@@ -31,15 +31,12 @@ class RenderResults(NamedTuple):
 _SIZES = {}
 
 
-def _project(cam, points):
-    """pixel coordinates of world points (reference :166-179): p_h @ full_proj, /w, ndc -> ((v+1)*S-1)/2."""
-    full = cam.full_proj_transform.to(points.device)
-    # columns x, y, w of [p, 1] @ full as three broadcast multiply-adds: the [P,4] x [4,4] product is a skinny GEMM that
-    # the BLAS runs in 72 us at P = 100k (more than K1 + K8 of the same view), the elementwise form in ~10
+def _project_torch(full, W, H, points):
+    # columns of [p, 1] @ full as three broadcast multiply-adds: the [P,4] x [4,4] product is a skinny GEMM that the BLAS
+    # runs in 72 us at P = 100k (more than K1 + K8 of the same view)
     hom = torch.addcmul(torch.addcmul(torch.addcmul(full[3], points[:, 0:1], full[0]), points[:, 1:2], full[1]),
                         points[:, 2:3], full[2])
     ndc = hom[:, :2] / hom[:, 3:4]
-    W, H = int(cam.image_width), int(cam.image_height)
     if W == H:
         return ((ndc + 1.0) * float(W) - 1.0) * 0.5
     size = _SIZES.get((W, H, points.device))
@@ -48,8 +45,42 @@ def _project(cam, points):
     return ((ndc + 1.0) * size - 1.0) * 0.5
 
 
+class _ProjectPoints(torch.autograd.Function):
+    """csplat_project_points: the projections by-product in one launch.  Its gradient is rarely asked for (nothing in the
+    reference's losses uses the projections): backward re-evaluates the torch formulation under autograd."""
+
+    @staticmethod
+    def forward(ctx, points, full, W, H):
+        from csplat import native as _n
+        pts = points.contiguous().float()
+        out = torch.empty(pts.shape[0], 2, dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            _n.check(_n.lib.csplat_project_points(_n.stream_handle(pts.device), pts.shape[0], _n.ptr(full), W, H, _n.ptr(pts),
+                                                  _n.ptr(out)), "csplat_project_points")
+        ctx.save_for_backward(points, full)
+        ctx.size = (W, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        points, full = ctx.saved_tensors
+        with torch.enable_grad():
+            p = points.detach().requires_grad_()
+            out = _project_torch(full, ctx.size[0], ctx.size[1], p)
+        return torch.autograd.grad(out, p, g)[0], None, None, None
+
+
+def _project(cam, points):
+    """pixel coordinates of world points (reference :166-179): p_h @ full_proj, /w, ndc -> ((v+1)*S-1)/2."""
+    full = cam.full_proj_transform.to(points.device)
+    W, H = int(cam.image_width), int(cam.image_height)
+    if points.is_cuda and points.dtype == torch.float32 and full.dtype == torch.float32 and full.is_contiguous():
+        return _ProjectPoints.apply(points, full, W, H)
+    return _project_torch(full, W, H, points)
+
+
 def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, override_color, log_deform_path,
-             render_static, shared=None, vertice_deform=None):
+             render_static, shared=None, vertice_deform=None, transformed=None):
     """everything of render() up to the rasterizer call: settings, rasterizer keyword arguments, by-products.
     `shared` carries the view-independent activations (features, opacity, scaling) so that several views of one step
     pass the SAME tensor objects to the rasterizer (one gradient buffer for all of them, see rasterize_views);
@@ -93,8 +124,11 @@ def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, 
         if vertice_deform is None:
             time = torch.tensor(viewpoint_camera.time).to(pc.mesh.pos.device).repeat(pc.mesh.pos.shape[0], 1)
             vertice_deform = simulator(time_vector=time)
-        means3D_deform = pc.get_xyz(vertice_deform)
-        rotations_deform = pc.get_rotation(vertice_deform)
+        if transformed is not None:      # (xyz, rotation) of this camera from the all-cameras transform of render_views
+            means3D_deform, rotations_deform = transformed
+        else:
+            means3D_deform = pc.get_xyz(vertice_deform)
+            rotations_deform = pc.get_rotation(vertice_deform)
 
     if log_deform_path is not None:
         np.savez(log_deform_path, means3D=base_xyz.detach().cpu().numpy(),
@@ -143,9 +177,14 @@ def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor,
     deforms = vertice_deforms      # [T, V, 3] when the caller already evaluated the simulator for these cameras
     if deforms is None and not render_static and viewpoint_cameras and hasattr(simulator, "forward_times"):
         deforms = simulator.forward_times([cam.time for cam in viewpoint_cameras])   # [T, V, 3]: one pass over the output layer
+    moved = None
+    if deforms is not None and deforms.is_cuda and getattr(pc, "fused", False) and hasattr(pc, "transform_views"):
+        moved = pc.transform_views(deforms)     # mesh -> Gaussian transform of all cameras in one launch each way
+    deform_views = None if deforms is None else deforms.unbind(0)
     for i, cam in enumerate(viewpoint_cameras):
         prepared.append(_prepare(cam, pc, simulator, pipe, bg_color, scaling_modifier, override_color, None, render_static,
-                                 shared, None if deforms is None else deforms[i]))
+                                 shared, None if deforms is None else deform_views[i],
+                                 None if moved is None else (moved[0][i], moved[1][i])))
     if not prepared:
         return ([], None) if return_stacked else []
     sizes = {(p[0].image_height, p[0].image_width) for p in prepared}

@@ -191,10 +191,18 @@ int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const
  *         + lambda_momentum * mean_v |D2 - 2 D1 + D0|_1                          (only when T >= 3)
  *   grad [T][V][3] = d loss / d D (norms have gradient 0 at 0, as torch defines them).
  * scratch: csplat_cloth_regs_scratch_bytes(T, V, E) bytes, not shared between concurrent calls.  The loss value is summed in a
- * fixed order; the gradient's atomic summation order is not fixed. */
+ * fixed order.  Gradient: with the CSR of the graph (dst_rowptr / src_rowptr [V+1], dst_perm / src_perm [E], int32: edge ids
+ * grouped by edge_index[1] / edge_index[0], ascending within a group) every vertex gathers its edges -- deterministic, no
+ * atomics; with NULLs the edges scatter with float atomics (summation order not fixed). */
 size_t csplat_cloth_regs_scratch_bytes(int T, int V, int64_t E);
 int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, const int64_t *edge_index, const float *rest_len,
-                      float lambda_deform, float lambda_rigid, float lambda_momentum, float *loss, float *grad, void *scratch);
+                      float lambda_deform, float lambda_rigid, float lambda_momentum, float *loss, float *grad, void *scratch,
+                      const int *dst_rowptr, const int *dst_perm, const int *src_rowptr, const int *src_perm);
+
+/* Pixel coordinates of n world points (the `projections` by-product of render(), /root/reference/gaussian_renderer/__init__.py:
+ * 166-179): hom = [p, 1] @ full_proj (device pointer to the row-major 4x4 the reference keeps as Camera.full_proj_transform),
+ * ndc = hom.xy / hom.w, out = ((ndc + 1) * (W, H) - 1) / 2.  points [n][3], out_pixels [n][2]. */
+int csplat_project_points(void *stream, int64_t n, const float *full_proj, int W, int H, const float *points, float *out_pixels);
 
 /* psnr of /root/reference/utils/image_utils.py:19-21 per image: out[i] = 20 log10(1 / sqrt(mean((a_i - b_i)^2))) over the
  * n_per_image values (channels x pixels) of image i; a, b [n_images][n_per_image].  One launch; fixed summation order.
@@ -231,6 +239,19 @@ int csplat_mesh_transform_fwd(void *stream, int P, const int64_t *face_vertex_id
 int csplat_mesh_transform_bwd(void *stream, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
                               const float *bary, const float *rotation, const void *rest, const float *g_xyz,
                               const float *g_quat, float *d_vertices, float *d_bary, float *d_rotation);
+/* The same for the T cameras of a training step in one launch each way (the reference calls get_xyz / get_rotation once per
+ * render(), train_utils.py:204-260): vertices [T][V][3] -> out_xyz [T][P][3], out_quat [T][P][4]; backward takes g_xyz
+ * [T][P][3] / g_quat [T][P][4] (either may be NULL) and returns d_vertices [T][V][3] and d_bary / d_rotation summed over the
+ * cameras in camera order.  Vertex gradients: with vertex_rowptr [V+1] / vertex_corners [3P] (int32; the (Gaussian, corner)
+ * pairs incident to each vertex as 3 * gaussian + corner, grouped by vertex: a stable sort of face_vertex_ids) and
+ * corner_scratch (T*P*9 floats) they are gathered in that fixed order -- deterministic, no atomics; with NULLs they are
+ * scattered with float atomics. */
+int csplat_mesh_transform_fwd_views(void *stream, int T, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
+                                    const float *bary, const float *rotation, const void *rest, float *out_xyz, float *out_quat);
+int csplat_mesh_transform_bwd_views(void *stream, int T, int P, int V, const int64_t *face_vertex_ids, const float *vertices,
+                                    const float *bary, const float *rotation, const void *rest, const float *g_xyz,
+                                    const float *g_quat, float *d_vertices, float *d_bary, float *d_rotation,
+                                    const int *vertex_rowptr, const int *vertex_corners, float *corner_scratch);
 
 /* ---- in-library kernel timing (HIP events on the launch stream; used by bench.py's roofline leg) ------
  * mask bit k enables bracketing of kernel class k with a start/stop event pair on the stream it is launched on:

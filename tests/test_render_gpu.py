@@ -119,7 +119,7 @@ def test_from_mesh_uses_dist2():
 
 
 def test_fused_mesh_transform_equals_torch_formulation():
-    """csplat_mesh_transform_fwd/_bwd (closed-form Kabsch, in-kernel forward-mode AD) == the torch formulation of
+    """csplat_mesh_transform_fwd/_bwd (closed-form Kabsch, hand-written adjoint) == the torch formulation of
     get_xyz / get_rotation (gaussian_mesh.py:151-188 with roma restated in csplat/rotations.py), values and gradients
     w.r.t. the deformed vertices, the barycentric weights and the rotation parameter."""
     sc = _scene(P=5000, W=64, H=64, grid=12)
@@ -141,6 +141,32 @@ def test_fused_mesh_transform_equals_torch_formulation():
         err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
         assert err < 2e-4, (n, err)       # fp32 both sides; vertex grads: atomics vs sort-based index_put
     assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
+
+
+def test_mesh_transform_of_all_cameras_equals_per_camera():
+    """transform_views([T,V,3]) (one launch each way) == get_xyz / get_rotation per camera: values, and the gradients on the
+    deformed vertices of every camera and on the (shared) barycentric weights / rotation parameters summed over cameras."""
+    sc = _scene(P=5000, W=64, H=64, grid=12)
+    V = sc["mesh_pos"].shape[1]
+    res = []
+    for batched in (True, False):
+        pc, sim = _build(sc)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            pc._rotation.copy_(torch.randn_like(pc._rotation))
+        verts = (pc.mesh.pos[None] + 0.05 * torch.randn(3, V, 3, device="cuda")).requires_grad_(True)
+        if batched:
+            xyz, rot = pc.transform_views(verts)
+        else:
+            xyz, rot = zip(*[(pc.get_xyz(verts[t]), pc.get_rotation(verts[t])) for t in range(3)])
+        ws = [torch.randn(5000, 7, device="cuda", generator=torch.Generator(device="cuda").manual_seed(t)) for t in range(3)]
+        sum((xyz[t] * ws[t][:, :3]).sum() + (rot[t] * ws[t][:, 3:]).sum() for t in range(3)).backward()
+        res.append((torch.stack(xyz).detach(), torch.stack(rot).detach(), verts.grad.clone(), pc.face_bary.grad.clone(),
+                    pc._rotation.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])          # same kernel, same bits
+    for n, a, b in zip(("d_vertices", "d_bary", "d_rotation"), res[0][2:], res[1][2:]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err < 1e-5, (n, err)        # (atomic order / sum over cameras in registers vs autograd accumulation)
 
 
 def test_render_views_equals_render_per_camera():
@@ -172,3 +198,27 @@ def test_render_views_equals_render_per_camera():
     for a, b in zip(g1 + v1, g2 + v2):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
     assert render_views([], pc, sim, pipe, bg) == []
+
+
+def test_projection_kernel_matches_reference_formula_and_has_a_gradient():
+    """csplat_project_points vs the reference's projections() (gaussian_renderer/__init__.py:166-179) restated in fp64."""
+    import gaussian_renderer as gr
+    from types import SimpleNamespace
+    from csplat import synthetic as syn
+    dev = torch.device("cuda")
+    for W, H in ((800, 800), (640, 360)):
+        c = syn.make_camera(33.0, W, H)
+        full = torch.tensor(c["full_proj_transform"], device=dev)
+        cam = SimpleNamespace(full_proj_transform=full, image_width=W, image_height=H)
+        pts = (torch.rand(5001, 3, device=dev) - 0.5).requires_grad_()
+        got = gr._project(cam, pts)
+        assert type(got.grad_fn).__name__.startswith("_ProjectPoints")
+        p64 = pts.detach().double().requires_grad_()
+        hom = (full.double().T @ torch.cat([p64, torch.ones_like(p64[:, :1])], 1).T)
+        ndc = (hom / hom[3, :])[:2].T
+        ref = torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], 1)
+        assert float((got.double() - ref).abs().max()) < 2e-4 * max(W, H) / 800            # pixels
+        w = torch.randn_like(got)
+        got.backward(w)
+        ref.backward(w.double())
+        assert float((pts.grad.double() - p64.grad).abs().max()) < 1e-4 * float(p64.grad.abs().max())

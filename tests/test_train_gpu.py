@@ -252,5 +252,15 @@ def test_fused_cloth_regularisers_match_composed_torch(T, lams):
         assert err <= 2e-6 * max(float(D64.grad.abs().max()), 1e-6), err
     else:
         assert float(Df.grad.abs().max()) == 0.0
-    # the loss value is summed in a fixed order
-    assert float(tr.regularization(D.clone(), pc, opt)) == float(lf)
+    # the loss value is summed in a fixed order; through the CSR of the graph the gradient is reproducible bit for bit too
+    D2 = D.clone().requires_grad_()
+    l2 = tr.regularization(D2, pc, opt)
+    (l2 * 1.7).backward()
+    assert float(l2) == float(lf) and torch.equal(D2.grad, Df.grad)
+    # the scatter (atomics) form of the same kernel, used when no CSR is passed
+    D3 = D.clone().requires_grad_()
+    l3 = tr.FusedClothRegs.apply(D3, ei, rest.reshape(-1), *[max(x, 0.0) for x in lams], None)
+    (l3 * 1.7).backward()
+    assert abs(float(l3) - float(l64)) <= 2e-6 * max(abs(float(l64)), 1e-3)
+    if D64.grad is not None:
+        assert float((D3.grad.double() - D64.grad).abs().max()) <= 2e-6 * max(float(D64.grad.abs().max()), 1e-6)
