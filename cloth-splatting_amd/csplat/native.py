@@ -53,7 +53,7 @@ EXPORTS = {
     "csplat_blur11": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
     "csplat_ssim_partial_count": (_sz, [_i64, _i, _i]),
     "csplat_ssim_fwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_adam_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _i64]),
     "csplat_l1_scratch_bytes": (_sz, []),
     "csplat_project_points": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

@@ -141,9 +141,51 @@ class FusedSSIM(torch.autograd.Function):
         dx = torch.empty_like(x)
         with torch.cuda.device(x.device):
             _n.check(_n.lib.csplat_ssim_bwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
-                                            _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(g), 1.0 / float(x.numel()), _n.ptr(dx)),
+                                            _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(g), 1.0 / float(x.numel()), None, None, _n.ptr(dx)),
                      "csplat_ssim_bwd")
         return dx, None
+
+
+class FusedImageLoss(torch.autograd.Function):
+    """Ll1 + lambda_dssim * (1 - ssim) of the reference's train step (train_utils.py:50-74, unmasked) as one node: forward =
+    csplat_l1 + csplat_ssim_fwd, backward = ONE launch (csplat_ssim_bwd with the L1 sign image as addend).  gt is a constant."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lam):
+        _n.require_cuda(image)
+        x, y = image.contiguous(), gt.contiguous()
+        H, W = x.shape[-2:]
+        n_img = x.numel() // (H * W)
+        need = image.requires_grad
+        dev = x.device
+        sign = torch.empty_like(x) if need else None
+        scratch = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=dev)
+        l1 = torch.empty((), dtype=torch.float32, device=dev)
+        p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=dev) if need else None
+        partial = torch.empty(int(_n.lib.csplat_ssim_partial_count(n_img, H, W)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _n.stream_handle(dev)
+            _n.check(_n.lib.csplat_l1(st, x.numel(), _n.ptr(x), _n.ptr(y), _n.ptr(scratch), _n.ptr(l1), _n.ptr(sign)), "csplat_l1")
+            _n.check(_n.lib.csplat_ssim_fwd(st, n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]) if need else None,
+                                            _n.ptr(p[1]) if need else None, _n.ptr(p[2]) if need else None, None,
+                                            _n.ptr(partial)), "csplat_ssim_fwd")
+        ctx.save_for_backward(x, y, p, sign)
+        ctx.dims = (n_img, H, W, float(lam))
+        # l1 + lam * (1 - sum(partial) / n)
+        return torch.add(l1 + float(lam), partial.sum(), alpha=-float(lam) / float(x.numel()))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, p, sign = ctx.saved_tensors
+        n_img, H, W, lam = ctx.dims
+        g = g.reshape(1).float().contiguous()
+        gs = g * (-lam)
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_ssim_bwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
+                                            _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(gs), 1.0 / float(x.numel()), _n.ptr(sign), _n.ptr(g),
+                                            _n.ptr(dx)), "csplat_ssim_bwd")
+        return dx, None, None
 
 
 def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
@@ -190,6 +232,10 @@ def psnr(img1, img2):
 
 
 def image_losses(image_tensor, gt_image_tensor, opt, mask_tensor=None):
+    if mask_tensor is None and opt.lambda_dssim != 0 and image_tensor.is_cuda and image_tensor.dtype == torch.float32 and \
+            gt_image_tensor.dtype == torch.float32 and image_tensor.shape == gt_image_tensor.shape and image_tensor.dim() >= 2 \
+            and image_tensor.numel() > 0 and not gt_image_tensor.requires_grad:
+        return FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim)
     loss = l1_loss(image_tensor, gt_image_tensor, mask_tensor)
     if opt.lambda_dssim != 0:
         if mask_tensor is None:

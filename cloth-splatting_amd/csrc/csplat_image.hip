@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, Taps taps, const
 __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
                                                    const float *__restrict__ P1, const float *__restrict__ P2,
                                                    const float *__restrict__ P3, const float *__restrict__ gscalar, float inv_n,
+                                                   const float *__restrict__ addend, const float *__restrict__ add_scale,
                                                    float *__restrict__ dX) {
     __shared__ float s_p[3][(BH + 2 * R5)][BW + 2 * R5 + 1];
     __shared__ float s_h[3][(BH + 2 * R5)][BW + 1];
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const
     }
     __syncthreads();
     const float g = gscalar[0] * inv_n;
+    const float ga = addend ? add_scale[0] : 0.f;
     for (int t = threadIdx.x; t < BH * BW; t += 256) {
         const int ry = t / BW, rx = t - ry * BW;
         const int y = y0 + ry, x = x0 + rx;
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const
                 b1 += w * s_h[0][ry + k][rx]; b2 += w * s_h[1][ry + k][rx]; b3 += w * s_h[2][ry + k][rx];
             }
             const size_t o = img + (size_t)y * W + x;
-            dX[o] = g * (b1 + 2.f * X[o] * b2 + Y[o] * b3);
+            const float d = g * (b1 + 2.f * X[o] * b2 + Y[o] * b3);
+            dX[o] = addend ? d + ga * addend[o] : d;
         }
     }
 }
@@ -296,14 +299,16 @@ extern "C" int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, con
 }
 
 extern "C" int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
-                               const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n, float *dx) {
+                               const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n,
+                               const float *addend, const float *add_scale, float *dx) {
     CSPLAT_REQUIRE(n_images >= 0 && n_images < 65536 && H > 0 && W > 0 && taps11 && x && y && p1 && p2 && p3 && g_scalar && dx,
                    "csplat_ssim_bwd: bad arguments");
     if (n_images == 0) return 0;
     Taps t;
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
-    k_ssim_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, dx);
+    CSPLAT_REQUIRE((addend == nullptr) == (add_scale == nullptr), "csplat_ssim_bwd: addend and add_scale go together");
+    k_ssim_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, addend, add_scale, dx);
     LAUNCH_CHECK();
     return 0;
 }

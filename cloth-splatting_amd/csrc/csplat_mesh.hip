@@ -362,16 +362,26 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(int T, int P, int V, const int
 // as a gather over the static incidence it is 10 MB of reads.
 __global__ __launch_bounds__(256) void k_vertex_gather(int P, int V, const int *__restrict__ rowptr, const int *__restrict__ corners,
                                                         const float *__restrict__ corner_grads, float *__restrict__ d_verts) {
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
+    // 8 lanes per vertex stride through its incidence list (one lane per vertex is a chain of ~30 dependent-latency
+    // gathers); the 8 partial sums meet in a fixed butterfly
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int v = gid >> 3, sub = gid & 7;
     const float *cg = corner_grads + (size_t)blockIdx.y * P * 9;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int e = rowptr[v], end = rowptr[v + 1]; e < end; e++) {
-        const float *g = cg + 3 * (size_t)corners[e];
-        s0 += g[0]; s1 += g[1]; s2 += g[2];
+    if (v < V) {
+        for (int e = rowptr[v] + sub, end = rowptr[v + 1]; e < end; e += 8) {
+            const float *g = cg + 3 * (size_t)corners[e];
+            s0 += g[0]; s1 += g[1]; s2 += g[2];
+        }
     }
-    float *o = d_verts + ((size_t)blockIdx.y * V + v) * 3;
-    o[0] = s0; o[1] = s1; o[2] = s2;
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1) {
+        s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64);
+    }
+    if (v < V && sub == 0) {
+        float *o = d_verts + ((size_t)blockIdx.y * V + v) * 3;
+        o[0] = s0; o[1] = s1; o[2] = s2;
+    }
 }
 
 // pixel coordinates of world points: [p, 1] @ full_proj (row-vector convention), perspective divide, ndc -> pixel
@@ -429,7 +439,7 @@ int csplat_mesh_transform_bwd_views(void *stream, int T, int P, int V, const int
                                             d_vertices, d_bary, d_rotation, gather ? corner_scratch : nullptr);
     LAUNCH_CHECK();
     if (gather && V > 0 && T > 0) {
-        k_vertex_gather<<<dim3(cdiv(V, 256), T), 256, 0, s>>>(P, V, vertex_rowptr, vertex_corners, corner_scratch, d_vertices);
+        k_vertex_gather<<<dim3(cdiv(8 * (int64_t)V, 256), T), 256, 0, s>>>(P, V, vertex_rowptr, vertex_corners, corner_scratch, d_vertices);
         LAUNCH_CHECK();
     }
     return 0;

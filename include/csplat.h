@@ -215,13 +215,17 @@ int csplat_psnr(void *stream, int64_t n_images, int64_t n_per_image, const float
  *   forward:  map[i] = SSIM(x, y)[i] (optional), partial[b] = sum of the map over workgroup b's tile
  *             (csplat_ssim_partial_count() floats; mean = sum(partial) / (n_images*H*W), summed by the caller in a fixed
  *             order), and p1, p2, p3 = dSSIM/dblur(x), dSSIM/dblur(x*x), dSSIM/dblur(x*y) per pixel (all three or NULL).
- *   backward: dx[i] = g_scalar[0] * inv_n * ( blur(p1) + 2 x blur(p2) + y blur(p3) )[i]   (gradient w.r.t. x only).
+ *   backward: dx[i] = g_scalar[0] * inv_n * ( blur(p1) + 2 x blur(p2) + y blur(p3) )[i]   (gradient w.r.t. x only)
+ *                     + add_scale[0] * addend[i]   when addend / add_scale (device pointers) are given: the gradient of the
+ *             reference's whole image loss Ll1 + lambda_dssim (1 - ssim) (train_utils.py:50-74) leaves in one pass, addend =
+ *             the sign(x - y) / n that csplat_l1 wrote.
  * taps11: the 11 host floats of the 1-D window, as csplat_blur11. */
 size_t csplat_ssim_partial_count(int64_t n_images, int H, int W);
 int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
                     float *p1, float *p2, float *p3, float *map_out, float *partial);
 int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
-                    const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n, float *dx);
+                    const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n,
+                    const float *addend, const float *add_scale, float *dx);
 size_t csplat_l1_scratch_bytes(void);
 int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad);
 

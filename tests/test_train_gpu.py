@@ -264,3 +264,24 @@ def test_fused_cloth_regularisers_match_composed_torch(T, lams):
     assert abs(float(l3) - float(l64)) <= 2e-6 * max(abs(float(l64)), 1e-3)
     if D64.grad is not None:
         assert float((D3.grad.double() - D64.grad).abs().max()) <= 2e-6 * max(float(D64.grad.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 64, 48), (1, 3, 37, 53)])
+def test_fused_image_loss_matches_l1_plus_dssim(shape):
+    """FusedImageLoss (csplat_l1 + csplat_ssim_fwd, one backward launch) == l1_loss + lambda (1 - ssim) composed from the
+    two fused nodes, which the tests above pin against the reference formulas: value and gradient."""
+    from types import SimpleNamespace
+    from csplat import train as tr
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    img = torch.rand(*shape, device="cuda", generator=g)
+    gt = (img + 0.2 * torch.randn(*shape, device="cuda", generator=g)).clamp(0, 1)
+    opt = SimpleNamespace(lambda_dssim=0.2)
+    a = img.clone().requires_grad_()
+    la = tr.image_losses(a, gt, opt)
+    assert type(la.grad_fn).__name__.startswith("FusedImageLoss")
+    (la * 1.3).backward()
+    b = img.clone().requires_grad_()
+    lb = tr.l1_loss(b, gt) + opt.lambda_dssim * (1.0 - tr.ssim(b, gt))
+    (lb * 1.3).backward()
+    assert abs(float(la) - float(lb)) < 1e-6
+    assert float((a.grad - b.grad).abs().max()) < 1e-6 * max(float(b.grad.abs().max()), 1e-12) + 1e-10
