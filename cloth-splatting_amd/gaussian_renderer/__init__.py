@@ -94,12 +94,9 @@ def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, 
     base_xyz = pc.get_xyz() if (render_static or log_deform_path is not None) else None
     dev = shared["opacity"].device
     # zero tensor whose gradient is the screen-space (NDC) gradient of the 2D means (used by densification)
-    screenspace_points = torch.zeros(shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype, requires_grad=True,
-                                     device=dev) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # (upstream writes zeros_like(xyz, requires_grad=True) + 0 and retain_grad(): a non-leaf whose .grad is kept by a Python
+    # hook.  A leaf gives the same .grad to train_step / densification without the extra launch and hook per camera.)
+    screenspace_points = torch.zeros(shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype, requires_grad=True, device=dev)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),

@@ -100,12 +100,13 @@ class ResidualMeshSimulator(torch.nn.Module):
         nn.init.normal_(self.output.weight, 0.0, 0.00001)
         nn.init.constant_(self.output.bias, 0.0)
 
-    def _residual(self, times):
+    def _residual(self, times, encoded=None):
         """times [T, 1] -> residual deformation [T, V, 3].  One time value feeds the whole mesh, so the 256 -> 3V output layer
         is a matrix-vector product per time; as an M = 1 GEMM (what nn.Linear issues) it runs at ~60 GB/s on this stack.
-        graph_ops.rows_dot streams the 3V x 256 weight once for all T rows (forward) / once more for their gradients."""
+        graph_ops.rows_dot streams the 3V x 256 weight once for all T rows (forward) / once more for their gradients.
+        encoded: encoder(times) when the caller kept it (the encoder has no parameters)."""
         from meshnet.graph_ops import rows_dot
-        h = torch.relu(self.input(self.encoder(times)))
+        h = torch.relu(self.input(self.encoder(times) if encoded is None else encoded))
         h = torch.relu(self.hidden(h))
         return rows_dot(h, self.output.weight, self.output.bias).reshape(times.shape[0], -1, 3)
 
@@ -135,13 +136,21 @@ class ResidualMeshSimulator(torch.nn.Module):
             # and kept -- a training run cycles through a bounded set of (t-1, t, t+1) triples)
             if len(cache) >= 4096:
                 cache.clear()
-            hit = cache[(key, dev)] = (torch.tensor(t32, device=dev).reshape(-1, 1), torch.as_tensor(ids, device=dev))
-        tt, ids_dev = hit
+            tt = torch.tensor(t32, device=dev).reshape(-1, 1)
+            ids_dev = torch.as_tensor(ids, device=dev)
+            with torch.no_grad():   # parameter-free parts, kept with the key: the sinusoidal code and the table rows
+                hit = (tt, self.encoder(tt), self.mesh_predictions[ids_dev], self.mesh_predictions)
+            cache[(key, dev)] = hit
+        tt, enc, base, table = hit
+        if table is not self.mesh_predictions:      # (the table was replaced: re-gather)
+            base = self.mesh_predictions[torch.as_tensor(
+                np.round(np.asarray(key, np.float32) / np.float32(self.time_delta)).astype(np.int64), device=dev)]
+            cache[(key, dev)] = (tt, enc, base, self.mesh_predictions)
         out = []
         for c0 in range(0, tt.shape[0], 8):   # (rows_dot takes up to 8 time rows per call)
-            out.append(self._residual(tt[c0:c0 + 8]))
+            out.append(self._residual(tt[c0:c0 + 8], enc[c0:c0 + 8]))
         residual = out[0] if len(out) == 1 else torch.cat(out, 0)
-        return self.mesh_predictions[ids_dev] + residual
+        return base + residual
 
     def save(self, path):
         torch.save(self.state_dict(), path)
