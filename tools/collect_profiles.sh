@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 python3 bench.py                     > "$OUT/bench.json"       2> "$OUT/bench.err"
 python3 bench_gnn.py                 > "$OUT/bench_gnn.json"   2> /dev/null
-python3 bench_train.py               > "$OUT/bench_train.json" 2> /dev/null
+python3 bench_train.py --steps 40 --warmup 5 > "$OUT/bench_train.json" 2> /dev/null
 python3 tools/bench_linear128.py     > "$OUT/linear128.txt"    2> /dev/null
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w tools/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate > "$OUT/mfma_rate.txt"
 cd /tmp && export TMPDIR=/tmp
@@ -21,6 +21,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 python3 "$ROOT/bench.py" --no-cpu-baseline --no-view-streams > "$OUT/bench_serial.json" 2> /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-view-streams > "$OUT/trace_serial.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gnn" -o t -- python3 "$ROOT/bench_gnn.py" --steps 5 --warmup 2 > "$OUT/trace_gnn.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_train" -o t -- python3 "$ROOT/bench_train.py" --steps 10 --warmup 3 > "$OUT/trace_train.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-view-streams > "$OUT/pmc_$c.log" 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_l128_$c" -o p -- python3 "$ROOT/tools/bench_linear128.py" 300000 2 > /dev/null 2>&1

@@ -27,7 +27,8 @@ for f in ("bench.json", "bench_serial.json", "bench_gnn.json", "bench_train.json
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
-for sub, out in (("trace", "kernel_stats.csv"), ("trace_serial", "kernel_stats_serial.csv"), ("trace_gnn", "gnn_kernel_stats.csv")):
+for sub, out in (("trace", "kernel_stats.csv"), ("trace_serial", "kernel_stats_serial.csv"), ("trace_gnn", "gnn_kernel_stats.csv"),
+                 ("trace_train", "train_kernel_stats.csv")):
     hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         rows = list(csv.reader(open(hits[0])))
