@@ -2,8 +2,8 @@
 that gaussian_renderer.render() and train_step touch -- parameters, activations (gaussian_model.py:27-48,96-121),
 get_xyz (barycentric gather, gaussian_mesh.py:151-169), get_rotation (per-Gaussian Kabsch of its face + quaternion
 composition, :171-188, incl. the wxyz/xyzw convention mix of SURVEY F8, reproduced not fixed) and the
-distCUDA2-based scale initialisation (:249-251).  Densification, PLY/HDF5 I/O and Adam-state surgery are "next" rows
-(SURVEY.md 8(f) N3/N4), not built here."""
+distCUDA2-based scale initialisation (:249-251).  Densification / pruning / Adam-state surgery come from
+csplat/densify.py (DensifyMixin), point_cloud.ply I/O from csplat/ply.py (N4)."""
 from types import SimpleNamespace
 
 import torch
