@@ -285,3 +285,44 @@ def test_fused_image_loss_matches_l1_plus_dssim(shape):
     (lb * 1.3).backward()
     assert abs(float(la) - float(lb)) < 1e-6
     assert float((a.grad - b.grad).abs().max()) < 1e-6 * max(float(b.grad.abs().max()), 1e-12) + 1e-10
+
+
+def test_train_step_camera_by_camera_equals_batched():
+    """train_step(batched_views=False) -- render() per camera, simulator per camera, composed losses as upstream's loop --
+    against the default batched step (render_views, forward_times, fused nodes): same PSNR, loss, statistics and the same
+    parameters after one optimisation step from the same state."""
+    import bench_train as bt
+    from csplat import train as tr
+    from gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    times = [0.2, 0.4, 0.6]
+    res = []
+    for batched in (True, False):
+        torch.manual_seed(123)            # (the simulator's input / hidden layers are randomly initialised)
+        sc, pc, sim = bt.build(P=3000, W=112, H=96, grid=14, n_times=6, dev=dev)
+        with torch.no_grad():
+            pc._scaling.add_(0.9)
+            torch.manual_seed(1)
+            sim.output.weight.copy_(1e-3 * torch.randn_like(sim.output.weight))
+        bg = torch.ones(3, device=dev)
+        with torch.no_grad():
+            keep = pc._features_dc.detach().clone()
+            torch.manual_seed(0)
+            pc._features_dc.add_(0.5 * torch.randn_like(pc._features_dc))
+            targets = [render(c, pc, sim, tr.DEFAULT_PIPE, bg).render.clamp(0, 1).clone() for c in bt.cameras(sc, times, dev)]
+            pc._features_dc.copy_(keep)
+        cams = bt.cameras(sc, times, dev, targets)
+        pc.training_setup(feature_lr=0.01)
+        mopt = torch.optim.Adam(sim.parameters(), lr=3e-4)
+        p, l, stats = tr.train_step(1, cams, pc, sim, mopt, background=bg, batched_views=batched)
+        res.append((float(p), float(l), stats, [q.detach().clone() for q in pc.parameters()],
+                    [q.detach().clone() for q in sim.parameters()]))
+    a, b = res
+    assert abs(a[0] - b[0]) < 1e-3 and abs(a[1] - b[1]) < 1e-6 * max(abs(b[1]), 1.0), (a[:2], b[:2])
+    assert torch.equal(a[2]["radii"], b[2]["radii"]) and torch.equal(a[2]["visibility_filter"], b[2]["visibility_filter"])
+    assert rel_err(a[2]["viewspace_grad"].cpu().numpy(), b[2]["viewspace_grad"].cpu().numpy()) < 1e-4
+    # parameters after the Adam step: the first step moves every entry by ~lr * sign(grad); entries whose gradient is at
+    # rounding level can flip sign between the two summation orders, so compare against the step size
+    for qa, qb in zip(a[3] + a[4], b[3] + b[4]):
+        d = (qa - qb).abs()
+        assert float((d > 1e-6 + 1e-3 * qb.abs()).float().mean()) < 0.02, float(d.max())
