@@ -354,7 +354,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         verts.append(pkg.vertice_deform[None])
     all_vertice_deform = torch.cat(verts, 0) if reg is None else None
     radii = torch.cat(radii_l, 0).max(dim=0).values
-    visibility_filter = torch.cat(vis_l).any(dim=0)
+    visibility_filter = radii > 0            # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
     image_tensor = stacked if stacked is not None else torch.cat(images, 0)
     gt_image_tensor = torch.cat(gts, 0)
     psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
@@ -362,9 +362,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         reg = regularization(all_vertice_deform, gaussians, opt, static)
     loss = image_losses(image_tensor, gt_image_tensor, opt) + reg
     loss.backward()
-    viewspace_grad = torch.zeros_like(vsp_l[0])
-    for v in vsp_l:
-        viewspace_grad = viewspace_grad + v.grad
+    viewspace_grad = torch.stack([v.grad for v in vsp_l]).sum(0) if len(vsp_l) > 1 else vsp_l[0].grad.clone()
     with torch.no_grad():
         if view_parallel and cd.is_dist():
             cd.allreduce_gradients(list(gaussians.parameters()) + list(simulator.parameters()))
