@@ -50,16 +50,17 @@ __global__ __launch_bounds__(256) void k_blur11(int H, int W, Taps taps, const f
 // is a cat, a blur launch and ~25 elementwise launches forward, ~50 backward, each a full-image HBM round trip.
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
 
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
+constexpr int SSIM_THREADS = 512;   // 8 waves share one tile's LDS: the load / horizontal / vertical phases of the 3 resident workgroups overlap better
+__global__ __launch_bounds__(SSIM_THREADS) void k_ssim_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
                                                    float *__restrict__ P1, float *__restrict__ P2, float *__restrict__ P3,
                                                    float *__restrict__ map_out, float *__restrict__ partial) {
     __shared__ float s_x[(BH + 2 * R5)][BW + 2 * R5 + 1];
     __shared__ float s_y[(BH + 2 * R5)][BW + 2 * R5 + 1];
     __shared__ float s_h[5][(BH + 2 * R5)][BW + 1];
-    __shared__ float s_red[4];
+    __shared__ float s_red[SSIM_THREADS / 64];
     const size_t img = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += 256) {
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += SSIM_THREADS) {
         const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
         const int y = y0 + ry - R5, x = x0 + rx - R5;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;       // zero padding (of the images AND of their products)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, Taps taps, const
         s_y[ry][rx] = in ? Y[img + (size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += 256) {
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += SSIM_THREADS) {
         const int ry = t / BW, rx = t - ry * BW;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, Taps taps, const
     }
     __syncthreads();
     float acc = 0.f;
-    for (int t = threadIdx.x; t < BH * BW; t += 256) {
+    for (int t = threadIdx.x; t < BH * BW; t += SSIM_THREADS) {
         const int ry = t / BW, rx = t - ry * BW;
         const int y = y0 + ry, x = x0 + rx;
         if (y < H && x < W) {
@@ -109,11 +110,14 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, Taps taps, const
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0)
-        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) {
+        float t_ = 0.f;
+        for (int k = 0; k < SSIM_THREADS / 64; k++) t_ += s_red[k];
+        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t_;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
+__global__ __launch_bounds__(SSIM_THREADS) void k_ssim_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
                                                    const float *__restrict__ P1, const float *__restrict__ P2,
                                                    const float *__restrict__ P3, const float *__restrict__ gscalar, float inv_n,
                                                    const float *__restrict__ addend, const float *__restrict__ add_scale,
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const
     __shared__ float s_h[3][(BH + 2 * R5)][BW + 1];
     const size_t img = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += 256) {
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += SSIM_THREADS) {
         const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
         const int y = y0 + ry - R5, x = x0 + rx - R5;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const
         s_p[0][ry][rx] = in ? P1[o] : 0.f; s_p[1][ry][rx] = in ? P2[o] : 0.f; s_p[2][ry][rx] = in ? P3[o] : 0.f;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += 256) {
+    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += SSIM_THREADS) {
         const int ry = t / BW, rx = t - ry * BW;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, Taps taps, const
     __syncthreads();
     const float g = gscalar[0] * inv_n;
     const float ga = addend ? add_scale[0] : 0.f;
-    for (int t = threadIdx.x; t < BH * BW; t += 256) {
+    for (int t = threadIdx.x; t < BH * BW; t += SSIM_THREADS) {
         const int ry = t / BW, rx = t - ry * BW;
         const int y = y0 + ry, x = x0 + rx;
         if (y < H && x < W) {
@@ -293,7 +297,7 @@ extern "C" int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, con
     Taps t;
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
-    k_ssim_fwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, map_out, partial);
+    k_ssim_fwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, map_out, partial);
     LAUNCH_CHECK();
     return 0;
 }
@@ -308,7 +312,7 @@ extern "C" int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, con
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
     CSPLAT_REQUIRE((addend == nullptr) == (add_scale == nullptr), "csplat_ssim_bwd: addend and add_scale go together");
-    k_ssim_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, addend, add_scale, dx);
+    k_ssim_bwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, addend, add_scale, dx);
     LAUNCH_CHECK();
     return 0;
 }
