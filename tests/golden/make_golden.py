@@ -21,6 +21,8 @@ What it pins; every fixture holds inputs + the referenc
                   are exec'd at generation time from the reference text with the conflict resolved to the
                   `9b63d7a` side.  Only tensors are stored.
   normalizer.npz  meshnet.model_utils.Normalizer accumulate / normalise / inverse
+  densify.npz     MultiGaussianMesh densify / prune / opacity reset / Adam-state surgery / cleanup (gen_densify)
+  scene_io.npz    dataset_readers.readCamerasFromTransforms / read_timeline on blender_scene/ (gen_scene_io)
 """
 import inspect
 import os
@@ -406,9 +408,98 @@ def gen_densify():
     print("densify.npz: P", P, "->", int(out["densified.face_ids"].shape[0]), "->", int(out["pruned.face_ids"].shape[0]))
 
 
+def gen_scene_io():
+    """scene_reconstruction.dataset_readers.readCamerasFromTransforms / read_timeline on a tiny Blender-style scene that this
+    function WRITES under tests/golden/blender_scene/ (2 views x 3 times, 8x6 RGBA PNGs, a gripper mask for one frame): the
+    fixture is the scene files + what the reference's reader returns for them.  The module's hard imports that are not
+    installed (h5py, plyfile, torchvision, simple_knn, ...) are replaced by empty modules -- none is reached by the two
+    functions exercised."""
+    import json
+    from PIL import Image
+    for name in ("h5py", "plyfile", "torchvision", "torchvision.transforms", "simple_knn", "simple_knn._C", "roma", "open3d"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["plyfile"], "PlyData"):
+        sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    if not hasattr(sys.modules["simple_knn._C"], "distCUDA2"):
+        sys.modules["simple_knn._C"].distCUDA2 = None
+    install_pyg_shim()
+    import scene_reconstruction.dataset_readers as dr
+    # dataset_readers.py:371 builds the composited image with Image.fromarray(np.array(arr * 255.0, dtype=np.byte), "RGB").
+    # Pillow < 10 took the int8 buffer as the 8-bit RGB bytes it is; the Pillow installed here (12) rejects the dtype.  The
+    # old behaviour is restored for the call ("shim-derived", like the PyG shim): same bytes, viewed as uint8.
+    real_fromarray = Image.fromarray
+
+    def fromarray_compat(obj, mode=None):
+        if isinstance(obj, np.ndarray) and obj.dtype == np.int8:
+            obj = obj.view(np.uint8)
+        return real_fromarray(obj, mode) if mode is not None and obj.dtype != np.uint8 else real_fromarray(obj)
+    dr.Image.fromarray = fromarray_compat
+    root = os.path.join(OUT, "blender_scene")
+    rng = np.random.default_rng(11)
+    W, H = 8, 6
+    views = []
+    for v in range(2):      # two camera-to-world matrices: rotation about z and x, translated
+        az, el = 0.7 + 1.1 * v, -0.4 + 0.3 * v
+        Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(el), -np.sin(el)], [0, np.sin(el), np.cos(el)]])
+        c2w = np.eye(4)
+        c2w[:3, :3] = Rz @ Rx
+        c2w[:3, 3] = [1.5 - v, 0.3 * v, 2.0 + 0.5 * v]
+        views.append(c2w)
+    for split, times, named in (("train", [0.0, 0.5, 1.0], True), ("test", [0.25, 1.0], False)):
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        frames = []
+        for vi, c2w in enumerate(views):
+            for ti, t in enumerate(times):
+                name = f"r_{vi}_{ti}" if named else f"img{vi}{ti}"      # the second form exercises the unique-transform ids
+                img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+                img[..., 3] = rng.choice([0, 128, 255], (H, W))
+                Image.fromarray(img, "RGBA").save(os.path.join(root, split, name + ".png"))
+                frames.append({"file_path": f"./{split}/{name}", "time": t, "transform_matrix": c2w.tolist()})
+        json.dump({"camera_angle_x": 0.6911, "camera_angle_y": 0.5273, "frames": frames},
+                  open(os.path.join(root, f"transforms_{split}.json"), "w"), indent=1)
+    os.makedirs(os.path.join(root, "masks_gripper"), exist_ok=True)
+    for vi in range(2):
+        for ti in range(3):
+            Image.fromarray((rng.random((H, W)) > 0.5).astype(np.uint8) * 255, "L").save(
+                os.path.join(root, "masks_gripper", f"r_{vi}_{ti}.png"))
+    out = {}
+    mapper, max_time = dr.read_timeline(root)
+    out["timeline.keys"] = np.array(sorted(mapper)); out["timeline.values"] = np.array([mapper[k] for k in sorted(mapper)])
+    out["timeline.max"] = np.array(max_time)
+    cases = (("train_white", "transforms_train.json", True, None, None), ("train_black_skip", "transforms_train.json", False, 2, 2),
+             ("test_white", "transforms_test.json", True, None, None))
+    import shutil
+    for tag, tf, white, tskip, vskip in cases:
+        if tag.startswith("test"):       # the mask directory only covers the train names
+            shutil.move(os.path.join(root, "masks_gripper"), os.path.join(root, "_masks_off"))
+        try:
+            infos = dr.readCamerasFromTransforms(root, tf, white, ".png", mapper, time_skip=tskip, view_skip=vskip)
+        finally:
+            if tag.startswith("test"):
+                shutil.move(os.path.join(root, "_masks_off"), os.path.join(root, "masks_gripper"))
+        out[f"{tag}.n"] = np.array(len(infos))
+        for i, c in enumerate(infos):
+            out[f"{tag}.{i}.R"], out[f"{tag}.{i}.T"] = np.asarray(c.R), np.asarray(c.T)
+            out[f"{tag}.{i}.fov"] = np.array([c.FovX, c.FovY])
+            out[f"{tag}.{i}.image"] = npy(c.image)
+            out[f"{tag}.{i}.ints"] = np.array([c.uid, c.width, c.height, int(c.view_id), int(c.time_id)])
+            out[f"{tag}.{i}.time"] = np.array(c.time)
+            out[f"{tag}.{i}.name"] = np.array(c.image_name)
+            if c.mask is not None:
+                out[f"{tag}.{i}.mask"] = npy(c.mask)
+    dr.Image.fromarray = real_fromarray
+    np.savez_compressed(os.path.join(OUT, "scene_io.npz"), **out)
+    print("scene_io.npz:", {t: int(out[f"{t}.n"]) for t, *_ in cases})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
-    gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify()
+    gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify(); gen_scene_io()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
