@@ -139,13 +139,13 @@ class ResidualMeshSimulator(torch.nn.Module):
             tt = torch.tensor(t32, device=dev).reshape(-1, 1)
             ids_dev = torch.as_tensor(ids, device=dev)
             with torch.no_grad():   # parameter-free parts, kept with the key: the sinusoidal code and the table rows
-                hit = (tt, self.encoder(tt), self.mesh_predictions[ids_dev], self.mesh_predictions)
+                hit = (tt, self.encoder(tt), self.mesh_predictions[ids_dev], self.mesh_predictions, self.mesh_predictions._version)
             cache[(key, dev)] = hit
-        tt, enc, base, table = hit
-        if table is not self.mesh_predictions:      # (the table was replaced: re-gather)
+        tt, enc, base, table, version = hit
+        if table is not self.mesh_predictions or version != self.mesh_predictions._version:   # table replaced / edited in place
             base = self.mesh_predictions[torch.as_tensor(
                 np.round(np.asarray(key, np.float32) / np.float32(self.time_delta)).astype(np.int64), device=dev)]
-            cache[(key, dev)] = (tt, enc, base, self.mesh_predictions)
+            cache[(key, dev)] = (tt, enc, base, self.mesh_predictions, self.mesh_predictions._version)
         out = []
         for c0 in range(0, tt.shape[0], 8):   # (rows_dot takes up to 8 time rows per call)
             out.append(self._residual(tt[c0:c0 + 8], enc[c0:c0 + 8]))

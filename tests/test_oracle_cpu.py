@@ -235,6 +235,18 @@ def test_simulators_match_reference():
     np.testing.assert_allclose(both.detach().numpy(), g["res_out"], atol=1e-5)
     with pytest.raises(ValueError):
         sim.forward_times([0.0, 1.3])
+    # the per-time-set cache follows the table: edit it in place, then replace it
+    t0 = float(g["res_times"][0])
+    before = sim.forward_times([t0]).detach().clone()
+    with torch.no_grad():
+        sim.mesh_predictions += 1.0
+    np.testing.assert_allclose(sim.forward_times([t0]).detach().numpy(), before.numpy() + 1.0, atol=1e-6)
+    sim.mesh_predictions = sim.mesh_predictions + 1.0                 # replaced by a new tensor
+    np.testing.assert_allclose(sim.forward_times([t0]).detach().numpy(), before.numpy() + 2.0, atol=1e-6)
+    with torch.no_grad():
+        mesh -= 1.0                                                   # (`mesh` is the tensor that was edited in place)
+    sim.mesh_predictions = mesh
+    np.testing.assert_allclose(sim.forward_times([t0]).detach().numpy(), before.numpy(), atol=1e-6)
     with pytest.raises(ValueError):
         sim(torch.tensor(1.3).repeat(V, 1))
     assert int(g["res_oob_raises"]) == 1
