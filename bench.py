@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
     args = ap.parse_args()
@@ -242,6 +244,17 @@ def main():
                               "(bytes of ONE launch / its own duration)") if args.view_streams and V > 1 else None},
         "kernel_us": breakdown,
     }
+    # the first half of BASELINE.json's metric ("train-step ms"): BASELINE configs[2], measured by bench_train.py (untimed
+    # here, its own timed region; 1 GPU only).  Auxiliary field -- `value` stays the rasterizer fwd+bwd throughput.
+    if rank == 0 and world == 1 and not args.no_train_step and (P, W, V) == (100_000, 800, 4):
+        try:
+            import bench_train
+            from types import SimpleNamespace as _NS
+            r = bench_train.run(_NS(steps=30, warmup=5, P=100_000, res=800, grid=100), dev)
+            out["train_step"] = {"ms": r["value"], "unit": "ms", "rendered_Mpix_per_s": r["rendered_Mpix_per_s"], "steps": r["steps"],
+                                 "psnr_first": r["psnr_first"], "psnr_last": r["psnr_last"], "workload": r["config"]["workload"]}
+        except Exception as e:      # never let the auxiliary leg take the headline line down
+            out["train_step"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, cams, P, W, H)
     elif rank == 0:

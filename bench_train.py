@@ -47,8 +47,12 @@ def main():
     ap.add_argument("--P", type=int, default=100_000)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--grid", type=int, default=100)
-    args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    print(json.dumps(run(ap.parse_args())), flush=True)
+
+
+def run(args, dev=None):
+    """the measurement; returns the JSON record (bench.py embeds it as its `train_step` field)"""
+    dev = dev or torch.device("cuda:0")
     from csplat import train as tr
     from gaussian_renderer import render
     n_times = 30
@@ -85,7 +89,7 @@ def main():
            "config": {"workload": f"train_step analogue: V={sc['mesh_pos'].shape[1]} mesh nodes, P={args.P}, 3 cams "
                                   f"{args.res}x{args.res}, ResidualMeshSimulator + Kabsch transform + rasterizer + L1 + "
                                   "0.05(1-SSIM) + rigid/momentum/deform regs + 2 Adam"}}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 if __name__ == "__main__":
