@@ -34,11 +34,16 @@ def allreduce_flat(tensors, op=None, group=None):
     flat = torch.cat([t.reshape(-1) for t in tensors])
     if is_dist():
         dist.all_reduce(flat, op=op or dist.ReduceOp.SUM, group=group)
-    o = 0
+    pieces, o = [], 0
     for t in tensors:
         n = t.numel()
-        t.copy_(flat[o:o + n].view_as(t))
+        pieces.append(flat[o:o + n].view_as(t))
         o += n
+    try:
+        torch._foreach_copy_(tensors, pieces)        # one multi-tensor launch instead of one copy per parameter
+    except (AttributeError, RuntimeError):
+        for t, src in zip(tensors, pieces):
+            t.copy_(src)
     return flat
 
 
