@@ -359,7 +359,13 @@ def _irregular_graph(seed):
     return N, np.stack([src, dst]).astype(np.int64)
 
 
-@pytest.mark.parametrize("seed", list(range(300, 310)))
+def _gnn_fuzz_seeds():
+    import os
+    lo, hi = (int(v) for v in os.environ.get("CSPLAT_GNN_FUZZ_SEEDS", "300:310").split(":"))   # (wider sweeps: 1000:1200 ...)
+    return list(range(lo, hi))
+
+
+@pytest.mark.parametrize("seed", _gnn_fuzz_seeds())
 def test_gnn_irregular_graphs_vs_oracle(seed):
     """EncodeProcessDecode at the config-4 width (L = 128: the csplat_linear128 / node-update kernels in the no-grad path, the
     EdgeCombine / SegmentSum / split-K functions under autograd) against oracle/gnn_ref.py in fp64, forward and backward."""
