@@ -1426,6 +1426,282 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
 #undef PUT
 }
 
+// K8 for ALL views of a step in one launch (csplat_backward_views).  The per-view kernels above add into shared gradient
+// buffers and therefore run one after the other behind the concurrent K7s (a tail of ~27 us per view).  Here a thread
+// keeps its Gaussian and loops over the views: inputs and SH rows are read once, gradients of parameters that all views
+// share are summed in registers (SH: in the LDS rows) and written once, per-view outputs (mean2D, conic, and mean3D /
+// rotation when every view has its own deformed copy) are written per view.  Same arithmetic per view as k_preprocess_bwd.
+constexpr int K8_MAX_VIEWS = 8;
+struct K8View {
+    Cam cam;
+    Geom g;
+    const int32_t *radii;
+    const float *acc, *means3D, *rotations;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dscale, *dL_drot;
+    unsigned accmask;
+};
+struct K8Table {
+    int n;
+    unsigned sharedmask;   // CSPLAT_ACC_* bits of the outputs whose buffer is the same in every view
+    K8View v[K8_MAX_VIEWS];
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M, const float *__restrict__ shs,
+                                                               const float *__restrict__ scales, float scale_mod,
+                                                               int use_precomp_cov, float *__restrict__ dL_dsh, K8Table tab) {
+    constexpr bool STAGE = true;
+    const unsigned smask = tab.sharedmask;
+    // shared output: add to the thread's running sum; per-view output: write (or add, by that view's accmask)
+#define PUTL(local, ptr, idx, val, bit)                                                    \
+    do {                                                                                   \
+        if (smask & (bit)) (local) += (val);                                               \
+        else { float *p_ = (ptr) + (idx); *p_ = (accmask & (bit)) ? *p_ + (val) : (val); } \
+    } while (0)
+    __shared__ float s_in[STAGE ? NT * SH_ROW : 1];
+    __shared__ float s_out[STAGE ? NT * SH_ROW : 1];
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int rows = min(NT, P - blockIdx.x * NT);
+    if (STAGE) {
+        stage_sh_rows<NT>(shs + (size_t)blockIdx.x * NT * 48, rows, s_in);
+        for (int k = 0; k < 48; k++) s_out[threadIdx.x * SH_ROW + k] = 0.f;
+        __syncthreads();
+    }
+    if (i < P) {
+    float L_op = 0.f, L_col[3] = {0.f, 0.f, 0.f}, L_m3[3] = {0.f, 0.f, 0.f}, L_c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float L_sc[3] = {0.f, 0.f, 0.f}, L_rt[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int vi = 0; vi < tab.n; vi++) {
+    const K8View &w = tab.v[vi];
+    const Cam cam = w.cam;
+    const Geom g = w.g;
+    const int32_t *radii = w.radii;
+    const float *acc = w.acc, *means3D = w.means3D, *rotations = w.rotations;
+    float *dL_dmean2D = w.dL_dmean2D, *dL_dconic = w.dL_dconic, *dL_dopacity = w.dL_dopacity, *dL_dcolor = w.dL_dcolor;
+    float *dL_dmean3D = w.dL_dmean3D, *dL_dcov3D = w.dL_dcov3D, *dL_dscale = w.dL_dscale, *dL_drot = w.dL_drot;
+    const unsigned accmask = w.accmask;
+    const bool vis = radii[i] > 0;
+    float a9[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
+    dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
+    dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
+    PUTL(L_op, dL_dopacity, i, a9[5], CSPLAT_ACC_OPACITY);
+    PUTL(L_col[0], dL_dcolor, 3 * i, a9[6], CSPLAT_ACC_COLOR); PUTL(L_col[1], dL_dcolor, 3 * i + 1, a9[7], CSPLAT_ACC_COLOR);
+    PUTL(L_col[2], dL_dcolor, 3 * i + 2, a9[8], CSPLAT_ACC_COLOR);
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!vis) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) PUTL(L_m3[k], dL_dmean3D, 3 * i + k, 0.f, CSPLAT_ACC_MEAN3D);
+#pragma unroll
+        for (int k = 0; k < 6; k++) PUTL(L_c6[k], dL_dcov3D, 6 * i + k, 0.f, CSPLAT_ACC_COV3D);
+        if (dL_dscale)
+#pragma unroll
+            for (int k = 0; k < 3; k++) PUTL(L_sc[k], dL_dscale, 3 * i + k, 0.f, CSPLAT_ACC_SCALE);
+        if (dL_drot)
+#pragma unroll
+            for (int k = 0; k < 4; k++) PUTL(L_rt[k], dL_drot, 4 * i + k, 0.f, CSPLAT_ACC_ROT);
+    } else {
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    const float *view = cam.view, *proj = cam.proj;
+
+    // ---- conic -> cov2D -> cov3D and view-space mean
+    {
+        float pv[3];
+        view_point(p, view, pv);
+        ProjJac pj;
+        proj_jacobian(pv, cam, pj);
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = g.cov3D[6 * i + k];
+        float a, b, c;
+        cov2d_from_cov3d(c6, pj, a, b, c);
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        const float gcx = a9[2], gcy = a9[3], gcz = a9[4];
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float *t0 = pj.t0, *t1 = pj.t1;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * gcx + 2.f * b * c * gcy + (denom - a * c) * gcz);
+            dL_dc = denom2inv * (-a * a * gcz + 2.f * a * b * gcy + (denom - a * c) * gcx);
+            dL_db = denom2inv * 2.f * (b * c * gcx - (denom + 2.f * b * b) * gcy + a * b * gcz);
+            g6[0] = t0[0] * t0[0] * dL_da + t0[0] * t1[0] * dL_db + t1[0] * t1[0] * dL_dc;
+            g6[3] = t0[1] * t0[1] * dL_da + t0[1] * t1[1] * dL_db + t1[1] * t1[1] * dL_dc;
+            g6[5] = t0[2] * t0[2] * dL_da + t0[2] * t1[2] * dL_db + t1[2] * t1[2] * dL_dc;
+            g6[1] = 2.f * t0[0] * t0[1] * dL_da + (t0[0] * t1[1] + t0[1] * t1[0]) * dL_db + 2.f * t1[0] * t1[1] * dL_dc;
+            g6[2] = 2.f * t0[0] * t0[2] * dL_da + (t0[0] * t1[2] + t0[2] * t1[0]) * dL_db + 2.f * t1[0] * t1[2] * dL_dc;
+            g6[4] = 2.f * t0[2] * t0[1] * dL_da + (t0[1] * t1[2] + t0[2] * t1[1]) * dL_db + 2.f * t1[1] * t1[2] * dL_dc;
+        }
+        const float Vm[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float Vt0 = Vm[r][0] * t0[0] + Vm[r][1] * t0[1] + Vm[r][2] * t0[2];
+            const float Vt1 = Vm[r][0] * t1[0] + Vm[r][1] * t1[1] + Vm[r][2] * t1[2];
+            dT0[r] = 2.f * Vt0 * dL_da + Vt1 * dL_db;
+            dT1[r] = 2.f * Vt1 * dL_dc + Vt0 * dL_db;
+        }
+        const float dJ00 = view[0] * dT0[0] + view[4] * dT0[1] + view[8] * dT0[2];
+        const float dJ02 = view[2] * dT0[0] + view[6] * dT0[1] + view[10] * dT0[2];
+        const float dJ11 = view[1] * dT1[0] + view[5] * dT1[1] + view[9] * dT1[2];
+        const float dJ12 = view[2] * dT1[0] + view[6] * dT1[1] + view[10] * dT1[2];
+        const float tz = 1.f / pj.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float xg = pj.x_in ? 1.f : 0.f, yg = pj.y_in ? 1.f : 0.f;
+        const float dtx = xg * -cam.fx * tz2 * dJ02;
+        const float dty = yg * -cam.fy * tz2 * dJ12;
+        const float dtz = -cam.fx * tz2 * dJ00 - cam.fy * tz2 * dJ11 + (2.f * cam.fx * pj.tx) * tz3 * dJ02 +
+                          (2.f * cam.fy * pj.ty) * tz3 * dJ12;
+        dmean[0] += view[0] * dtx + view[1] * dty + view[2] * dtz;
+        dmean[1] += view[4] * dtx + view[5] * dty + view[6] * dtz;
+        dmean[2] += view[8] * dtx + view[9] * dty + view[10] * dtz;
+    }
+    // ---- mean2D (NDC) -> mean3D
+    {
+        const float hw = proj[3] * p[0] + proj[7] * p[1] + proj[11] * p[2] + proj[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (proj[0] * p[0] + proj[4] * p[1] + proj[8] * p[2] + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * p[0] + proj[5] * p[1] + proj[9] * p[2] + proj[13]) * m_w * m_w;
+        const float gx2 = a9[0], gy2 = a9[1];
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gx2 + (proj[1] * m_w - proj[3] * mul2) * gy2;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
+    }
+    // ---- colour -> SH (+ view direction -> mean3D)
+    if (shs && dL_dsh) {
+        const float *sh = (const float *)(s_in + threadIdx.x * SH_ROW);
+        float *gsh = s_out + threadIdx.x * SH_ROW;
+        const uint32_t cl = g.clamped[i];
+        const float vx = p[0] - cam.campos[0], vy = p[1] - cam.campos[1], vz = p[2] - cam.campos[2];
+        const float sum2 = vx * vx + vy * vy + vz * vz;
+        const float len = sqrtf(sum2);
+        const float x = vx / len, y = vy / len, z = vz / len;
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float dRGB = ((cl >> ch) & 1u) ? 0.f : a9[6 + ch];
+            float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;
+#define S(k) sh[(k) * 3 + ch]
+#define GS(k) gsh[(k) * 3 + ch]
+            GS(0) += SH_C0 * dRGB;
+            if (D > 0) {
+                GS(1) += -SH_C1 * y * dRGB;
+                GS(2) += SH_C1 * z * dRGB;
+                GS(3) += -SH_C1 * x * dRGB;
+                dx_ = -SH_C1 * S(3); dy_ = -SH_C1 * S(1); dz_ = SH_C1 * S(2);
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    GS(4) += SH_C2[0] * xy * dRGB;
+                    GS(5) += SH_C2[1] * yz * dRGB;
+                    GS(6) += SH_C2[2] * (2.f * zz - xx - yy) * dRGB;
+                    GS(7) += SH_C2[3] * xz * dRGB;
+                    GS(8) += SH_C2[4] * (xx - yy) * dRGB;
+                    dx_ += SH_C2[0] * y * S(4) + SH_C2[2] * 2.f * -x * S(6) + SH_C2[3] * z * S(7) + SH_C2[4] * 2.f * x * S(8);
+                    dy_ += SH_C2[0] * x * S(4) + SH_C2[1] * z * S(5) + SH_C2[2] * 2.f * -y * S(6) + SH_C2[4] * 2.f * -y * S(8);
+                    dz_ += SH_C2[1] * y * S(5) + SH_C2[2] * 4.f * z * S(6) + SH_C2[3] * x * S(7);
+                    if (D > 2) {
+                        GS(9) += SH_C3[0] * y * (3.f * xx - yy) * dRGB;
+                        GS(10) += SH_C3[1] * xy * z * dRGB;
+                        GS(11) += SH_C3[2] * y * (4.f * zz - xx - yy) * dRGB;
+                        GS(12) += SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * dRGB;
+                        GS(13) += SH_C3[4] * x * (4.f * zz - xx - yy) * dRGB;
+                        GS(14) += SH_C3[5] * z * (xx - yy) * dRGB;
+                        GS(15) += SH_C3[6] * x * (xx - 3.f * yy) * dRGB;
+                        dx_ += SH_C3[0] * S(9) * 6.f * xy + SH_C3[1] * S(10) * yz + SH_C3[2] * S(11) * -2.f * xy +
+                               SH_C3[3] * S(12) * -6.f * xz + SH_C3[4] * S(13) * (-3.f * xx + 4.f * zz - yy) +
+                               SH_C3[5] * S(14) * 2.f * xz + SH_C3[6] * S(15) * 3.f * (xx - yy);
+                        dy_ += SH_C3[0] * S(9) * 3.f * (xx - yy) + SH_C3[1] * S(10) * xz +
+                               SH_C3[2] * S(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * S(12) * -6.f * yz +
+                               SH_C3[4] * S(13) * -2.f * xy + SH_C3[5] * S(14) * -2.f * yz + SH_C3[6] * S(15) * -6.f * xy;
+                        dz_ += SH_C3[1] * S(10) * xy + SH_C3[2] * S(11) * 8.f * yz +
+                               SH_C3[3] * S(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * S(13) * 8.f * xz +
+                               SH_C3[5] * S(14) * (xx - yy);
+                    }
+                }
+            }
+#undef S
+#undef GS
+            ddx += dx_ * dRGB; ddy += dy_ * dRGB; ddz += dz_ * dRGB;
+        }
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean[0] += ((sum2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * invsum32;
+        dmean[1] += (-vx * vy * ddx + (sum2 - vy * vy) * ddy - vz * vy * ddz) * invsum32;
+        dmean[2] += (-vx * vz * ddx - vy * vz * ddy + (sum2 - vz * vz) * ddz) * invsum32;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) PUTL(L_m3[k], dL_dmean3D, 3 * i + k, dmean[k], CSPLAT_ACC_MEAN3D);
+#pragma unroll
+    for (int k = 0; k < 6; k++) PUTL(L_c6[k], dL_dcov3D, 6 * i + k, g6[k], CSPLAT_ACC_COV3D);
+
+    // ---- cov3D -> scale, quaternion
+    if (!use_precomp_cov && dL_dscale && dL_drot) {
+        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        float R[3][3];
+        quat_to_rot(q, R);
+        const float s[3] = {scale_mod * scales[3 * i], scale_mod * scales[3 * i + 1], scale_mod * scales[3 * i + 2]};
+        const float dS[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
+                                {0.5f * g6[1], g6[3], 0.5f * g6[4]},
+                                {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
+        float dA[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dA[r][k] = 2.f * (dS[r][0] * R[0][k] * s[k] + dS[r][1] * R[1][k] * s[k] + dS[r][2] * R[2][k] * s[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) PUTL(L_sc[k], dL_dscale, 3 * i + k, dA[0][k] * R[0][k] + dA[1][k] * R[1][k] + dA[2][k] * R[2][k], CSPLAT_ACC_SCALE);
+        float dR[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) dR[r][k] = dA[r][k] * s[k];
+        const float qr = q[0], qx = q[1], qy = q[2], qz = q[3];
+        const float dq0 = 2.f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        const float dq1 = 2.f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.f * qx * dR[1][1] - qr * dR[1][2] +
+                                    qz * dR[2][0] + qr * dR[2][1] - 2.f * qx * dR[2][2]);
+        const float dq2 = 2.f * (-2.f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
+                                    qr * dR[2][0] + qz * dR[2][1] - 2.f * qy * dR[2][2]);
+        const float dq3 = 2.f * (-2.f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.f * qz * dR[1][1] +
+                                    qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        PUTL(L_rt[0], dL_drot, 4 * i, dq0, CSPLAT_ACC_ROT); PUTL(L_rt[1], dL_drot, 4 * i + 1, dq1, CSPLAT_ACC_ROT);
+        PUTL(L_rt[2], dL_drot, 4 * i + 2, dq2, CSPLAT_ACC_ROT); PUTL(L_rt[3], dL_drot, 4 * i + 3, dq3, CSPLAT_ACC_ROT);
+    }
+    }   // visible
+    }   // views
+    {   // gradients of the parameters every view shares: one write (added to the buffer only if the first view was asked to)
+        const unsigned accmask = tab.v[0].accmask;
+        const K8View &w = tab.v[0];
+#define PUTS(ptr, idx, val, bit) do { if (smask & (bit)) { float *p_ = (ptr) + (idx); *p_ = (accmask & (bit)) ? *p_ + (val) : (val); } } while (0)
+        PUTS(w.dL_dopacity, i, L_op, CSPLAT_ACC_OPACITY);
+#pragma unroll
+        for (int k = 0; k < 3; k++) PUTS(w.dL_dcolor, 3 * i + k, L_col[k], CSPLAT_ACC_COLOR);
+#pragma unroll
+        for (int k = 0; k < 3; k++) PUTS(w.dL_dmean3D, 3 * i + k, L_m3[k], CSPLAT_ACC_MEAN3D);
+#pragma unroll
+        for (int k = 0; k < 6; k++) PUTS(w.dL_dcov3D, 6 * i + k, L_c6[k], CSPLAT_ACC_COV3D);
+        if (w.dL_dscale)
+#pragma unroll
+            for (int k = 0; k < 3; k++) PUTS(w.dL_dscale, 3 * i + k, L_sc[k], CSPLAT_ACC_SCALE);
+        if (w.dL_drot)
+#pragma unroll
+            for (int k = 0; k < 4; k++) PUTS(w.dL_drot, 4 * i + k, L_rt[k], CSPLAT_ACC_ROT);
+#undef PUTS
+    }
+    }   // i < P
+    if (STAGE) {   // coalesced 16-byte stores of the workgroup's SH gradients
+        __syncthreads();
+        float4 *dst4 = reinterpret_cast<float4 *>(dL_dsh + (size_t)blockIdx.x * NT * 48);
+        for (int t = threadIdx.x; t < rows * 12; t += NT) {
+            const int row = t / 12, c = (t - row * 12) * 4;
+            const float *sp = s_out + row * SH_ROW + c;
+            float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            if (tab.v[0].accmask & CSPLAT_ACC_SH) { const float4 u = dst4[t]; o.x += u.x; o.y += u.y; o.z += u.z; o.w += u.w; }
+            dst4[t] = o;
+        }
+    }
+#undef PUTL
+}
+
 // ------------------------------------------------------------------------------------------- layouts
 enum { G_DEPTH, G_XY, G_CONIC, G_RGB, G_COV3D, G_CLAMPED, G_TOUCHED, G_OFFSETS, G_CUT2, G_SCANTMP, G_NFIELDS };
 
@@ -1829,7 +2105,7 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
 }
 
 // K7 on `stream`; K8 on `k8_stream` (after an event wait when it differs); accmask see k_preprocess_bwd
-static int backward_impl(hipStream_t s, hipStream_t k8s, unsigned accmask, int P, int D, int M, int R, const float *bg, int W, int H,
+static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k8, unsigned accmask, int P, int D, int M, int R, const float *bg, int W, int H,
                          const float *means3D, const float *shs, const float *scales, float scale_modifier,
                          const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
                          const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
@@ -1864,6 +2140,7 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, unsigned accmask, int P
                                                                         (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
         LAUNCH_CHECK();
     }
+    if (!with_k8) return 0;   // (csplat_backward_views runs one K8 over all views afterwards)
     if (k8s != s) {
         hipEvent_t ev = pooled_event();
         CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
@@ -1898,7 +2175,7 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
                     float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
                     float *dL_dsh, float *dL_dscale, float *dL_drot) {
     (void)colors_precomp;
-    return backward_impl((hipStream_t)stream, (hipStream_t)stream, 0u, P, D, M, R, bg, W, H, means3D, shs, scales, scale_modifier,
+    return backward_impl((hipStream_t)stream, (hipStream_t)stream, true, 0u, P, D, M, R, bg, W, H, means3D, shs, scales, scale_modifier,
                          rotations, cov3D_precomp, view, proj, campos, tanfovx, tanfovy, radii, geom, binning, image, out_color,
                          dL_dpix, scratch, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                          dL_drot);
@@ -1950,20 +2227,92 @@ int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *joi
     return fence_out(V, v, (hipStream_t)join_stream);
 }
 
+// Can ONE K8 serve all views?  Same Gaussians (P, D, M, scale modifier, SH and scale tensors), SH staging applicable, and every
+// gradient output either the SAME buffer in all views (then views after the first must have been asked to add into it) or
+// a DIFFERENT buffer in every view.  Fills the table and returns true; anything else keeps the per-view launches.
+static bool k8_views_table(int V, const csplat_view *v, K8Table &tab) {
+    if (V < 2 || V > K8_MAX_VIEWS || (g_debug_flags & 128u)) return false;
+    const csplat_view &a = v[0];
+    if (a.P <= 0 || a.cov3D_precomp || !a.shs || !a.dL_dsh || a.M != 16 || !a.scales || !a.rotations || !a.dL_dscale || !a.dL_drot ||
+        ((((uintptr_t)a.shs | (uintptr_t)a.dL_dsh) & 15u) != 0))
+        return false;
+    for (int i = 1; i < V; i++) {
+        const csplat_view &w = v[i];
+        if (w.P != a.P || w.D != a.D || w.M != a.M || w.scale_modifier != a.scale_modifier || w.shs != a.shs || w.dL_dsh != a.dL_dsh ||
+            w.scales != a.scales || w.cov3D_precomp || !w.rotations || !w.dL_dscale || !w.dL_drot || !(w.accmask & CSPLAT_ACC_SH))
+            return false;
+    }
+    unsigned sharedmask = 0;
+    auto classify = [&](auto get, unsigned bit) {      // -> false when the buffers are neither all equal nor all different
+        bool all_same = true, all_diff = true;
+        for (int i = 0; i < V; i++)
+            for (int j = i + 1; j < V; j++) {
+                if (get(v[i]) == get(v[j])) all_diff = false; else all_same = false;
+            }
+        if (all_same) {
+            for (int i = 1; i < V; i++)
+                if (bit && !(v[i].accmask & bit)) return false;
+            sharedmask |= bit;
+            return true;
+        }
+        return all_diff;
+    };
+    if (!classify([](const csplat_view &w) { return (const void *)w.dL_dopacity; }, CSPLAT_ACC_OPACITY)) return false;
+    if (!classify([](const csplat_view &w) { return (const void *)w.dL_dcolor; }, CSPLAT_ACC_COLOR)) return false;
+    if (!classify([](const csplat_view &w) { return (const void *)w.dL_dmean3D; }, CSPLAT_ACC_MEAN3D)) return false;
+    if (!classify([](const csplat_view &w) { return (const void *)w.dL_dcov3D; }, CSPLAT_ACC_COV3D)) return false;
+    if (!classify([](const csplat_view &w) { return (const void *)w.dL_dscale; }, CSPLAT_ACC_SCALE)) return false;
+    if (!classify([](const csplat_view &w) { return (const void *)w.dL_drot; }, CSPLAT_ACC_ROT)) return false;
+    for (int i = 0; i < V; i++)      // mean2D / conic are per-view by construction
+        for (int j = i + 1; j < V; j++)
+            if (v[i].dL_dmean2D == v[j].dL_dmean2D || v[i].dL_dconic == v[j].dL_dconic || v[i].scratch == v[j].scratch) return false;
+    tab.n = V;
+    tab.sharedmask = sharedmask;
+    for (int i = 0; i < V; i++) {
+        const csplat_view &w = v[i];
+        if (!w.geom || !w.scratch || !w.dL_dmean2D || !w.dL_dconic || !w.dL_dopacity || !w.dL_dcolor || !w.dL_dmean3D || !w.dL_dcov3D ||
+            !w.means3D || !w.radii)
+            return false;
+        K8View &k = tab.v[i];
+        make_cam(k.cam, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.W, w.H);
+        k.g = geom_view((void *)w.geom, w.P);
+        k.radii = w.radii; k.acc = (const float *)w.scratch; k.means3D = w.means3D; k.rotations = w.rotations;
+        k.dL_dmean2D = w.dL_dmean2D; k.dL_dconic = w.dL_dconic; k.dL_dopacity = w.dL_dopacity; k.dL_dcolor = w.dL_dcolor;
+        k.dL_dmean3D = w.dL_dmean3D; k.dL_dcov3D = w.dL_dcov3D; k.dL_dscale = w.dL_dscale; k.dL_drot = w.dL_drot;
+        k.accmask = w.accmask;
+    }
+    return true;
+}
+
 int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     CSPLAT_REQUIRE(V >= 0 && (V == 0 || v != nullptr), "csplat_backward_views: bad view count");
     hipStream_t join = (hipStream_t)join_stream;
     if (int rc = fence_in(V, v, join)) return rc;
     bool shared = false;   // any view adding into another view's buffers: all K8 run on the join stream, in view order
     for (int i = 0; i < V; i++) shared |= v[i].accmask != 0u;
+    K8Table tab;
+    const bool one_k8 = shared && k8_views_table(V, v, tab);
     for (int i = 0; i < V; i++) {
         const csplat_view &w = v[i];
-        if (int rc = backward_impl((hipStream_t)w.stream, shared ? join : (hipStream_t)w.stream, w.accmask, w.P, w.D, w.M,
+        if (int rc = backward_impl((hipStream_t)w.stream, shared ? join : (hipStream_t)w.stream, !one_k8, w.accmask, w.P, w.D, w.M,
                                    w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
                                    w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.radii, w.geom, w.binning,
                                    w.image, w.out_color, w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic, w.dL_dopacity,
                                    w.dL_dcolor, w.dL_dmean3D, w.dL_dcov3D, w.dL_dsh, w.dL_dscale, w.dL_drot))
             return rc;
+    }
+    if (one_k8) {   // every view's K7 is queued on its own stream: the join stream waits for all of them, then ONE K8
+        for (int i = 0; i < V; i++) {
+            if ((hipStream_t)v[i].stream == join) continue;
+            hipEvent_t ev = pooled_event();
+            CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
+            HIP_TRY(hipEventRecord(ev, (hipStream_t)v[i].stream));
+            HIP_TRY(hipStreamWaitEvent(join, ev, 0));
+        }
+        ProfScope ps(PROF_K8, join);
+        const csplat_view &a = v[0];
+        k_preprocess_bwd_views<128><<<cdiv(a.P, 128), 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab);
+        LAUNCH_CHECK();
     }
     return fence_out(V, v, join);
 }

@@ -518,3 +518,43 @@ def test_randomized_wild_scenes_forward_and_backward(seed):
         rest = ~well & ~noise
         assert (eg[rest] <= np.maximum(10.0 * TOL, 30.0 * eo[rest])).all(), (k, "ill-conditioned", float(eg[rest].max()))
         assert (eg[noise] < 1.0).all(), (k, "noise-level")
+
+
+@pytest.mark.parametrize("own_means", [False, True])
+def test_one_k8_for_all_views_equals_per_view_k8(own_means):
+    """csplat_backward_views runs ONE K8 over all views when they share the Gaussians (gradients of shared parameters summed in
+    registers, per-view outputs written per view); csplat_debug_flags bit 7 keeps the per-view K8 launches that add into the
+    shared buffers one after the other.  Same sums in the same view order: equal up to K7's atomic order (1e-6 here).
+    own_means: every view has its own means3D / rotations tensors (the train step's deformed copies), the rest is shared."""
+    from csplat import native
+    from diff_gaussian_rasterization import rasterize_views
+    cases = [util.make_case(P=2500, W=144, H=96, seed=21, theta=th, scale_mul=2.0) for th in (10.0, -50.0, 95.0, 170.0)]
+    settings = [util.gpu_settings(c) for c in cases]
+    inp = util.gpu_inputs(cases[0])
+    V = len(cases)
+    tgt = [torch.rand(3, c["H"], c["W"], device="cuda", generator=torch.Generator(device="cuda").manual_seed(40 + i))
+           for i, c in enumerate(cases)]
+    res = []
+    try:
+        for flag in (0, 128):
+            native.lib.csplat_debug_flags(flag)
+            for k in inp:
+                inp[k].grad = None
+            means = [(inp["means3D"] + 0.001 * i).detach().requires_grad_() for i in range(V)] if own_means else [inp["means3D"]] * V
+            rots = [(inp["rotations"] * (1.0 + 0.01 * i)).detach().requires_grad_() for i in range(V)] if own_means \
+                else [inp["rotations"]] * V
+            m2d = [torch.zeros(cases[0]["P"], 3, device="cuda", requires_grad=True) for _ in range(V)]
+            kws = [dict(means3D=means[i], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                        rotations=rots[i]) for i in range(V)]
+            outs = rasterize_views(settings, kws)
+            sum(((o[0] - t) ** 2).mean() for o, t in zip(outs, tgt)).backward()
+            torch.cuda.synchronize()
+            grads = [inp[k].grad.clone() for k in ("opacities", "shs", "scales")] + [m.grad.clone() for m in m2d]
+            grads += [m.grad.clone() for m in means] + [r.grad.clone() for r in rots] if own_means else \
+                [inp["means3D"].grad.clone(), inp["rotations"].grad.clone()]
+            res.append(grads)
+    finally:
+        native.lib.csplat_debug_flags(0)
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
