@@ -1470,6 +1470,12 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     if (i < P) {
     float L_op = 0.f, L_col[3] = {0.f, 0.f, 0.f}, L_m3[3] = {0.f, 0.f, 0.f}, L_c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float L_sc[3] = {0.f, 0.f, 0.f}, L_rt[4] = {0.f, 0.f, 0.f, 0.f};
+    // the per-view record (radius, the nine accumulated pixel-level gradients) of view vi+1 is requested while view vi is
+    // processed: otherwise the thread walks V dependent load -> compute rounds
+    bool vis_n = tab.v[0].radii[i] > 0;
+    float a9_n[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a9_n[k] = tab.v[0].acc[(size_t)i * ACC_STRIDE + k];
     for (int vi = 0; vi < tab.n; vi++) {
     const K8View &w = tab.v[vi];
     const Cam cam = w.cam;
@@ -1479,10 +1485,17 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     float *dL_dmean2D = w.dL_dmean2D, *dL_dconic = w.dL_dconic, *dL_dopacity = w.dL_dopacity, *dL_dcolor = w.dL_dcolor;
     float *dL_dmean3D = w.dL_dmean3D, *dL_dcov3D = w.dL_dcov3D, *dL_dscale = w.dL_dscale, *dL_drot = w.dL_drot;
     const unsigned accmask = w.accmask;
-    const bool vis = radii[i] > 0;
+    (void)radii; (void)acc;
+    const bool vis = vis_n;
     float a9[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
+    for (int k = 0; k < 9; k++) a9[k] = vis ? a9_n[k] : 0.f;
+    if (vi + 1 < tab.n) {
+        const K8View &wn = tab.v[vi + 1];
+        vis_n = wn.radii[i] > 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a9_n[k] = wn.acc[(size_t)i * ACC_STRIDE + k];
+    }
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
     PUTL(L_op, dL_dopacity, i, a9[5], CSPLAT_ACC_OPACITY);
