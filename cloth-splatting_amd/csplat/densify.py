@@ -34,6 +34,9 @@ _ATTR = {"face_bary": "face_bary", "face_offset": "face_offset", "f_dc": "_featu
 class DensifyMixin:
     percent_dense = 0.01
 
+    def invalidate_caches(self):      # MeshGaussians overrides; the golden replay drives the mixin on a bare object
+        pass
+
     # ---- statistics (gaussian_mesh.py:121-124, gaussian_model.py:427-430, train_utils.py:326-328) -------------------
     def densification_setup(self, percent_dense=0.01):
         P, dev = self.face_bary.shape[0], self.face_bary.device
@@ -111,6 +114,7 @@ class DensifyMixin:
         valid = ~mask
         self._rebind(self._prune_optimizer(valid))
         self.face_ids = self.face_ids[valid]
+        self.invalidate_caches()
         self.denom = self.denom[valid]
         self.max_radii2D = self.max_radii2D[valid]
         self.pos_gradient_accum = self.pos_gradient_accum[valid]
@@ -121,6 +125,7 @@ class DensifyMixin:
             "face_bary": new_face_bary, "face_offset": new_face_offset, "f_dc": new_features_dc, "f_rest": new_features_rest,
             "opacity": new_opacities, "scaling": new_scaling, "rotation": new_rotation}))
         self.face_ids = torch.cat((self.face_ids, new_face_ids), dim=0)
+        self.invalidate_caches()
         P, dev = self.face_bary.shape[0], self.face_bary.device
         self.pos_gradient_accum = torch.zeros((P, 1), device=dev)
         self.denom = torch.zeros((P, 1), device=dev)
@@ -208,6 +213,7 @@ class DensifyMixin:
             if bool((~border).any()):
                 cc, new_face = coord[~border], nf[~border]
                 self.face_ids[cc] = new_face
+                self.invalidate_caches()
                 corners = self.mesh.pos[self.mesh.face[:, new_face].t()]            # [n, 3 (vertex), 3 (xyz)]
                 dist = torch.linalg.norm(xyz[cc].unsqueeze(1) - corners, dim=2)
                 self.face_bary.data[cc] = dist / dist.sum(dim=1, keepdim=True)

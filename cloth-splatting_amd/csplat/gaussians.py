@@ -129,6 +129,11 @@ class MeshGaussians(DensifyMixin):
         self._opacity = nn.Parameter(opacity_logits.clone().requires_grad_(True))
         return self
 
+    def invalidate_caches(self):
+        """drop everything derived from (face_ids, mesh): called by the densification / pruning / loading code"""
+        self.__dict__.pop("_rest_cache", None)
+        self.__dict__.pop("_fused_cache", None)
+
     def save_ply(self, path):
         """gaussian_mesh.py:438-465 (point_cloud.ply in plyfile's layout + the mesh side-car), csplat/ply.py"""
         from .ply import save_gaussians
@@ -194,9 +199,12 @@ class MeshGaussians(DensifyMixin):
         c = self.__dict__.get("_fused_cache")
         if c is not None and c[0] is deformed_vertices and c[1] == deformed_vertices._version:
             return c[2]
-        key = (self.face_ids.data_ptr(), self.face_ids._version, self.mesh.pos.data_ptr(), self.mesh.pos._version)
+        # keyed on the tensor OBJECTS (held in the cache entry, so their storage cannot be recycled under the key) and their
+        # in-place version counters; densify.py also drops the entry whenever it re-creates face_ids
+        fi, mp = self.face_ids, self.mesh.pos
         r = self.__dict__.get("_rest_cache")
-        if r is None or r[0] != key:
+        key = (fi._version, mp._version, int(fi.shape[0]))
+        if r is None or r[0] != key or r[5] is not fi or r[6] is not mp:
             vid = self._vertex_ids().contiguous()
             rest = torch.empty(max(int(_n.lib.csplat_mesh_rest_bytes(vid.shape[0])), 256), dtype=torch.uint8, device=vid.device)
             with torch.cuda.device(vid.device):
@@ -209,8 +217,11 @@ class MeshGaussians(DensifyMixin):
             corners = torch.argsort(flat, stable=True).to(torch.int32)
             rowptr = torch.zeros(nv + 1, dtype=torch.int32, device=vid.device)
             rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=nv), 0).to(torch.int32)
-            r = (key, vid, rest, rowptr, corners)
+            r = (key, vid, rest, rowptr, corners, fi, mp)
             self._rest_cache = r
+        if r[1].shape[0] != self.face_bary.shape[0] or r[1].shape[0] != self._rotation.shape[0]:
+            raise _n.CsplatError(f"mesh transform: {r[1].shape[0]} face ids but {self.face_bary.shape[0]} barycentric rows / "
+                                 f"{self._rotation.shape[0]} rotations")
         out = MeshTransform.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2], r[3], r[4])
         self._fused_cache = (deformed_vertices, deformed_vertices._version, out)
         return out

@@ -118,4 +118,6 @@ def load_gaussians(pc, path, device="cuda"):
     if getattr(pc.mesh, "edge_index", None) is not None and getattr(pc.mesh, "pos", None) is not None:
         ei = pc.mesh.edge_index
         pc.edge_norm = torch.linalg.norm(pc.mesh.pos[ei[1]] - pc.mesh.pos[ei[0]], dim=-1, keepdim=True)
+    if hasattr(pc, "invalidate_caches"):
+        pc.invalidate_caches()
     return pc

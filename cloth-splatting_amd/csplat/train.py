@@ -23,12 +23,26 @@ DEFAULT_OPT = SimpleNamespace(lambda_dssim=0.05, lambda_rigid=0.3, lambda_deform
 DEFAULT_PIPE = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
 
 
+def _mask_layout(x, mask):
+    """(n_batch, channels, H*W, mask_channels) when `mask` is a [B,1,H,W] / [B,C,H,W] fp32 GPU companion of the image batch
+    x [B,C,H,W] (train_utils.py:256-285 stacks Camera.mask [1,H,W] per view), else None (composed torch ops are used)."""
+    if mask is None or x.dim() != 4 or mask.dim() != 4 or not mask.is_cuda or mask.dtype != torch.float32 or mask.requires_grad:
+        return None
+    B, Cc, H, W = x.shape
+    if tuple(mask.shape) not in ((B, 1, H, W), (B, Cc, H, W)):
+        return None
+    return B, Cc, H * W, int(mask.shape[1])
+
+
 def l1_loss(network_output, gt, mask=None):
-    """utils/loss_utils.py:20-23.  Unmasked fp32 GPU images go through the fused HIP kernel (loss + gradient, one pass)."""
+    """utils/loss_utils.py:20-23.  fp32 GPU images go through the fused HIP kernel (loss + gradient, one pass)."""
+    ok = network_output.is_cuda and network_output.dtype == torch.float32 and gt.dtype == torch.float32 and \
+        network_output.shape == gt.shape and network_output.numel() > 0
     if mask is not None:
+        if ok and _mask_layout(network_output, mask) is not None:
+            return FusedL1.apply(network_output, gt, mask)
         return torch.abs((network_output - gt) * mask).mean()
-    if network_output.is_cuda and network_output.dtype == torch.float32 and gt.dtype == torch.float32 and \
-            network_output.shape == gt.shape and network_output.numel() > 0:
+    if ok:
         return FusedL1.apply(network_output, gt)
     return torch.abs(network_output - gt).mean()
 
@@ -50,20 +64,31 @@ def _taps(window_size=11, sigma=1.5):
     return _TAPS[window_size]
 
 
+def _launch_l1(x, y, mask, scratch, loss, grad):
+    st = _n.stream_handle(x.device)
+    if mask is None:
+        _n.check(_n.lib.csplat_l1(st, x.numel(), _n.ptr(x), _n.ptr(y), _n.ptr(scratch), _n.ptr(loss), _n.ptr(grad)), "csplat_l1")
+    else:
+        B, Cc, hw, mc = _mask_layout(x, mask)
+        _n.check(_n.lib.csplat_l1_masked(st, B, Cc, hw, _n.ptr(x), _n.ptr(y), _n.ptr(mask), mc, _n.ptr(scratch), _n.ptr(loss),
+                                         _n.ptr(grad)), "csplat_l1_masked")
+
+
 class FusedL1(torch.autograd.Function):
-    """mean |a - b| through csplat_l1: the forward launch also writes sign(a - b) / n, the backward scales it."""
+    """mean |a - b| (mean |(a - b) * mask| with a mask) through csplat_l1 / csplat_l1_masked: the forward launch also writes
+    the gradient image sign(.) (* mask) / n, the backward scales it."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, mask=None):
         _n.require_cuda(a)
         a, b = a.contiguous(), b.contiguous()
+        mask = None if mask is None else mask.contiguous()
         need = a.requires_grad or b.requires_grad
         grad = torch.empty_like(a) if need else None
         scratch = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=a.device)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
-            _n.check(_n.lib.csplat_l1(_n.stream_handle(a.device), a.numel(), _n.ptr(a), _n.ptr(b), _n.ptr(scratch), _n.ptr(loss),
-                                      _n.ptr(grad)), "csplat_l1")
+            _launch_l1(a, b, mask, scratch, loss, grad)
         ctx.grad = grad
         return loss
 
@@ -71,7 +96,7 @@ class FusedL1(torch.autograd.Function):
     def backward(ctx, g):
         ga = ctx.grad * g if ctx.needs_input_grad[0] else None
         gb = -(ctx.grad * g) if ctx.needs_input_grad[1] else None
-        return ga, gb
+        return ga, gb, None
 
 
 class GaussianBlur11(torch.autograd.Function):
@@ -147,13 +172,15 @@ class FusedSSIM(torch.autograd.Function):
 
 
 class FusedImageLoss(torch.autograd.Function):
-    """Ll1 + lambda_dssim * (1 - ssim) of the reference's train step (train_utils.py:50-74, unmasked) as one node: forward =
-    csplat_l1 + csplat_ssim_fwd, backward = ONE launch (csplat_ssim_bwd with the L1 sign image as addend).  gt is a constant."""
+    """Ll1 + lambda_dssim * ssim_loss of the reference's train step (train_utils.py:50-74) as one node: forward = csplat_l1 +
+    csplat_ssim_fwd, backward = ONE launch (csplat_ssim_bwd with the L1 sign image as addend).  gt is a constant.  With a mask
+    (Camera.mask stacked to [B,1,H,W], :61-67) the two terms are mean |(x - y) m| and mean((1 - ssim_map) m)."""
 
     @staticmethod
-    def forward(ctx, image, gt, lam):
+    def forward(ctx, image, gt, lam, mask=None):
         _n.require_cuda(image)
         x, y = image.contiguous(), gt.contiguous()
+        mask = None if mask is None else mask.contiguous()
         H, W = x.shape[-2:]
         n_img = x.numel() // (H * W)
         need = image.requires_grad
@@ -163,14 +190,21 @@ class FusedImageLoss(torch.autograd.Function):
         l1 = torch.empty((), dtype=torch.float32, device=dev)
         p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=dev) if need else None
         partial = torch.empty(int(_n.lib.csplat_ssim_partial_count(n_img, H, W)), dtype=torch.float32, device=dev)
+        ps = [_n.ptr(p[k]) if need else None for k in range(3)]
         with torch.cuda.device(dev):
             st = _n.stream_handle(dev)
-            _n.check(_n.lib.csplat_l1(st, x.numel(), _n.ptr(x), _n.ptr(y), _n.ptr(scratch), _n.ptr(l1), _n.ptr(sign)), "csplat_l1")
-            _n.check(_n.lib.csplat_ssim_fwd(st, n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]) if need else None,
-                                            _n.ptr(p[1]) if need else None, _n.ptr(p[2]) if need else None, None,
-                                            _n.ptr(partial)), "csplat_ssim_fwd")
+            _launch_l1(x, y, mask, scratch, l1, sign)
+            if mask is None:
+                _n.check(_n.lib.csplat_ssim_fwd(st, n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), *ps, None, _n.ptr(partial)),
+                         "csplat_ssim_fwd")
+            else:
+                B, Cc, _, mc = _mask_layout(x, mask)
+                _n.check(_n.lib.csplat_ssim_fwd_masked(st, B, Cc, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(mask), mc, *ps, None,
+                                                       _n.ptr(partial)), "csplat_ssim_fwd_masked")
         ctx.save_for_backward(x, y, p, sign)
         ctx.dims = (n_img, H, W, float(lam))
+        if mask is not None:      # l1 + lam * sum((1 - S) m) / n
+            return torch.add(l1, partial.sum(), alpha=float(lam) / float(x.numel()))
         # l1 + lam * (1 - sum(partial) / n)
         return torch.add(l1 + float(lam), partial.sum(), alpha=-float(lam) / float(x.numel()))
 
@@ -185,7 +219,7 @@ class FusedImageLoss(torch.autograd.Function):
             _n.check(_n.lib.csplat_ssim_bwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
                                             _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(gs), 1.0 / float(x.numel()), _n.ptr(sign), _n.ptr(g),
                                             _n.ptr(dx)), "csplat_ssim_bwd")
-        return dx, None, None
+        return dx, None, None, None
 
 
 def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
@@ -197,7 +231,7 @@ def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
     wh, wv = _window1d(window_size, channel, img1)
     pad = window_size // 2
     stacked = torch.cat([img1, img2, img1 * img1, img2 * img2, img1 * img2], dim=0)
-    if window_size == 11 and stacked.is_cuda:
+    if window_size == 11 and stacked.is_cuda and stacked.dtype == torch.float32:
         both = GaussianBlur11.apply(stacked)                     # one HIP launch for all five windows (and one in backward)
     else:
         both = _blur(stacked, wh, wv, pad, channel)              # CPU tensors (tests) / other window sizes
@@ -232,10 +266,12 @@ def psnr(img1, img2):
 
 
 def image_losses(image_tensor, gt_image_tensor, opt, mask_tensor=None):
-    if mask_tensor is None and opt.lambda_dssim != 0 and image_tensor.is_cuda and image_tensor.dtype == torch.float32 and \
+    """train_utils.py:50-74 (returns the loss; the reference's loss_dict of .item() host reads is not built)."""
+    if opt.lambda_dssim != 0 and image_tensor.is_cuda and image_tensor.dtype == torch.float32 and \
             gt_image_tensor.dtype == torch.float32 and image_tensor.shape == gt_image_tensor.shape and image_tensor.dim() >= 2 \
-            and image_tensor.numel() > 0 and not gt_image_tensor.requires_grad:
-        return FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim)
+            and image_tensor.numel() > 0 and not gt_image_tensor.requires_grad and \
+            (mask_tensor is None or _mask_layout(image_tensor, mask_tensor) is not None):
+        return FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim, mask_tensor)
     loss = l1_loss(image_tensor, gt_image_tensor, mask_tensor)
     if opt.lambda_dssim != 0:
         if mask_tensor is None:
@@ -331,6 +367,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         gaussians.oneupSHdegree()
     cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
     images, gts, radii_l, vis_l, vsp_l, verts = [], [], [], [], [], []
+    masks = [] if cams and getattr(cams[0], "mask", None) is not None else None          # train_utils.py:256
     stacked = None
     reg = None
     if batched_views:
@@ -351,16 +388,19 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         radii_l.append(pkg.radii.unsqueeze(0))
         vis_l.append(pkg.visibility_filter.unsqueeze(0))
         vsp_l.append(pkg.viewspace_points)
+        if masks is not None:
+            masks.append(cam.mask.to(pkg.render.device).unsqueeze(0))                      # train_utils.py:273-274
         verts.append(pkg.vertice_deform[None])
     all_vertice_deform = torch.cat(verts, 0) if reg is None else None
     radii = torch.cat(radii_l, 0).max(dim=0).values
     visibility_filter = radii > 0            # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
     image_tensor = stacked if stacked is not None else torch.cat(images, 0)
     gt_image_tensor = torch.cat(gts, 0)
+    mask_tensor = torch.cat(masks, 0) if masks is not None else None
     psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
     if reg is None:
         reg = regularization(all_vertice_deform, gaussians, opt, static)
-    loss = image_losses(image_tensor, gt_image_tensor, opt) + reg
+    loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor) + reg
     loss.backward()
     viewspace_grad = torch.stack([v.grad for v in vsp_l]).sum(0) if len(vsp_l) > 1 else vsp_l[0].grad.clone()
     with torch.no_grad():

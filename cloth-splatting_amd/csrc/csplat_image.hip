@@ -53,7 +53,8 @@ constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
 constexpr int SSIM_THREADS = 512;   // 8 waves share one tile's LDS: the load / horizontal / vertical phases of the 3 resident workgroups overlap better
 __global__ __launch_bounds__(SSIM_THREADS) void k_ssim_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
                                                    float *__restrict__ P1, float *__restrict__ P2, float *__restrict__ P3,
-                                                   float *__restrict__ map_out, float *__restrict__ partial) {
+                                                   float *__restrict__ map_out, float *__restrict__ partial,
+                                                   const float *__restrict__ mask, int mask_channels, int channels) {
     __shared__ float s_x[(BH + 2 * R5)][BW + 2 * R5 + 1];
     __shared__ float s_y[(BH + 2 * R5)][BW + 2 * R5 + 1];
     __shared__ float s_h[5][(BH + 2 * R5)][BW + 1];
@@ -96,13 +97,19 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_ssim_fwd(int H, int W, Taps ta
             const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = (s11 - mu1_sq) + (s22 - mu2_sq) + SSIM_C2;
             const float inv = 1.f / (B1 * B2);
             const float S = A1 * A2 * inv;
-            acc += S;
             const size_t o = img + (size_t)y * W + x;
             if (map_out) map_out[o] = S;
+            // masked form (train_utils.py:64-67): the reduced quantity is sum((1 - S) * m) and the partials carry the weight m
+            float m = 1.f;
+            if (mask) {
+                const size_t plane = mask_channels == 1 ? blockIdx.z / channels : blockIdx.z;
+                m = mask[(plane * H + y) * W + x];
+                acc += (1.f - S) * m;
+            } else acc += S;
             if (P1) {
-                P1[o] = 2.f * mu2 * (A2 - A1) * inv - S * 2.f * mu1 * (B2 - B1) * inv;   // dS/dmu1
-                P2[o] = -S / B2;                                                         // dS/ds11
-                P3[o] = 2.f * A1 * inv;                                                  // dS/ds12
+                P1[o] = m * (2.f * mu2 * (A2 - A1) * inv - S * 2.f * mu1 * (B2 - B1) * inv);   // dS/dmu1
+                P2[o] = m * (-S / B2);                                                         // dS/ds11
+                P3[o] = m * (2.f * A1 * inv);                                                  // dS/ds12
             }
         }
     }
@@ -170,26 +177,38 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_ssim_bwd(int H, int W, Taps ta
 constexpr int L1_BLOCKS = 256, L1_THREADS = 1024;  // few, fat workgroups: the ticket atomics serialise at one L2 address (~30 ns each)
 __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
                                                     float inv_n, float *__restrict__ partial, unsigned *__restrict__ ticket,
-                                                    float *__restrict__ loss, float *__restrict__ grad) {
+                                                    float *__restrict__ loss, float *__restrict__ grad,
+                                                    const float *__restrict__ mask, int64_t hw, int channels, int mask_channels) {
     __shared__ float s_red[L1_THREADS / 64];
     __shared__ bool s_last;
     float acc = 0.f;
-    const int64_t n4 = n >> 2;
+    auto sg = [&](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
+    // masked form (utils/loss_utils.py:21-22): mean |(a - b) * m|, m one plane per image (mask_channels == 1) or per channel
+    auto moff = [&](int64_t e) {
+        const int64_t plane = e / hw;
+        return (mask_channels == 1 ? plane / channels : plane) * hw + (e - plane * hw);
+    };
+    const int64_t n4 = (mask && (hw & 3)) ? 0 : n >> 2;    // a 4-pixel group stays inside one image plane
     for (int64_t i = (int64_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * L1_THREADS) {
         const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
-        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
-        acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
-        if (grad) {
-            auto sg = [&](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
-            reinterpret_cast<float4 *>(grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+        float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        if (mask) {
+            const float4 m = *reinterpret_cast<const float4 *>(mask + moff(i << 2));
+            d0 *= m.x; d1 *= m.y; d2 *= m.z; d3 *= m.w;
+            acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+            if (grad) reinterpret_cast<float4 *>(grad)[i] = make_float4(sg(d0) * m.x, sg(d1) * m.y, sg(d2) * m.z, sg(d3) * m.w);
+        } else {
+            acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+            if (grad) reinterpret_cast<float4 *>(grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
         }
     }
-    if (blockIdx.x == 0) {   // tail (n not a multiple of 4)
-        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += L1_THREADS) {
-            const float d = a[i] - b[i];
-            acc += fabsf(d);
-            if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
-        }
+    // tail: n not a multiple of 4 (<= 3 elements, all on workgroup 0), or every element when the planes are not 4-aligned
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * L1_THREADS) {
+        float d = a[i] - b[i];
+        float m = 1.f;
+        if (mask) { m = mask[moff(i)]; d *= m; }
+        acc += fabsf(d);
+        if (grad) grad[i] = sg(d) * m;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -275,31 +294,62 @@ extern "C" int csplat_blur11(void *stream, int64_t n_images, int H, int W, const
 
 extern "C" size_t csplat_l1_scratch_bytes(void) { return (size_t)(L1_BLOCKS + 1) * 4; }
 
-extern "C" int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad) {
+static int l1_launch(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad,
+                     const float *mask, int64_t hw, int channels, int mask_channels, const char *who) {
     CSPLAT_REQUIRE(n > 0 && a && b && scratch && loss, "csplat_l1: bad arguments");
-    CSPLAT_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad) & 15u) == 0, "csplat_l1: operands must be 16-byte aligned");
+    CSPLAT_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad | (uintptr_t)mask) & 15u) == 0, "csplat_l1: operands must be 16-byte aligned");
     float *partial = (float *)scratch;
     unsigned *ticket = (unsigned *)scratch + L1_BLOCKS;     // zero on entry; the kernel leaves it zero
-    const int64_t work = (n / 4 + L1_THREADS - 1) / L1_THREADS;
+    const int64_t units = (mask && (hw & 3)) ? n : n / 4;
+    const int64_t work = (units + L1_THREADS - 1) / L1_THREADS;
     const int grid = (int)(work < 1 ? 1 : (work > L1_BLOCKS ? L1_BLOCKS : work));
-    k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, ticket, loss, grad);
+    k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, ticket, loss, grad, mask, hw, channels,
+                                                        mask_channels);
     LAUNCH_CHECK();
+    (void)who;
     return 0;
+}
+
+extern "C" int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad) {
+    return l1_launch(stream, n, a, b, scratch, loss, grad, nullptr, 1, 1, 1, "csplat_l1");
+}
+
+extern "C" int csplat_l1_masked(void *stream, int64_t n_batch, int channels, int64_t hw, const float *a, const float *b,
+                                const float *mask, int mask_channels, void *scratch, float *loss, float *grad) {
+    CSPLAT_REQUIRE(n_batch > 0 && channels > 0 && hw > 0 && mask, "csplat_l1_masked: bad arguments");
+    CSPLAT_REQUIRE(mask_channels == 1 || mask_channels == channels, "csplat_l1_masked: the mask has 1 plane per image or one per channel");
+    return l1_launch(stream, n_batch * channels * hw, a, b, scratch, loss, grad, mask, hw, channels, mask_channels, "csplat_l1_masked");
 }
 
 extern "C" size_t csplat_ssim_partial_count(int64_t n_images, int H, int W) { return (size_t)n_images * cdiv(H, BH) * cdiv(W, BW); }
 
-extern "C" int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
-                               float *p1, float *p2, float *p3, float *map_out, float *partial) {
+static int ssim_fwd_launch(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
+                           float *p1, float *p2, float *p3, float *map_out, float *partial, const float *mask, int mask_channels,
+                           int channels) {
     CSPLAT_REQUIRE(n_images >= 0 && n_images < 65536 && H > 0 && W > 0 && taps11 && x && y && partial, "csplat_ssim_fwd: bad arguments");
     CSPLAT_REQUIRE((p1 != nullptr) == (p2 != nullptr) && (p1 != nullptr) == (p3 != nullptr), "csplat_ssim_fwd: all three partials or none");
     if (n_images == 0) return 0;
     Taps t;
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
-    k_ssim_fwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, map_out, partial);
+    k_ssim_fwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, map_out, partial, mask, mask_channels, channels);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
+                               float *p1, float *p2, float *p3, float *map_out, float *partial) {
+    return ssim_fwd_launch(stream, n_images, H, W, taps11, x, y, p1, p2, p3, map_out, partial, nullptr, 1, 1);
+}
+
+// masked form: partial sums hold sum((1 - S) * m), the three partial-derivative images are pre-multiplied by m, so that
+// csplat_ssim_bwd serves both forms unchanged.  n_images = batch * channels planes; mask [batch, mask_channels, H, W].
+extern "C" int csplat_ssim_fwd_masked(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
+                                      const float *y, const float *mask, int mask_channels, float *p1, float *p2, float *p3,
+                                      float *map_out, float *partial) {
+    CSPLAT_REQUIRE(n_batch >= 0 && channels > 0 && mask, "csplat_ssim_fwd_masked: bad arguments");
+    CSPLAT_REQUIRE(mask_channels == 1 || mask_channels == channels, "csplat_ssim_fwd_masked: the mask has 1 plane per image or one per channel");
+    return ssim_fwd_launch(stream, n_batch * channels, H, W, taps11, x, y, p1, p2, p3, map_out, partial, mask, mask_channels, channels);
 }
 
 extern "C" int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,

@@ -160,10 +160,6 @@ int csplat_dist2_ws(void *stream, int P, const float *xyz, float *out, void *tem
  * of the operator is the operator.  (SURVEY.md 8(f) "next" row N2.) */
 int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *in, float *out);
 
-/* l1_loss of /root/reference/utils/loss_utils.py:20-23 (unmasked case) with its gradient in the same pass:
- *   *loss = mean_i |a[i] - b[i]|,   grad[i] = sign(a[i] - b[i]) / n   (grad may be NULL).
- * scratch: csplat_l1_scratch_bytes() bytes whose last word is zero on entry (the kernel restores it), not shared between
- * calls that may run concurrently.  Deterministic (fixed summation order). */
 /* One Adam step (torch.optim.Adam semantics: no weight decay, no amsgrad, maximize = false) over n_tensors fp32 tensors in a
  * single launch per CSPLAT_ADAM_MAX_TENSORS tensors.  Host arrays of device pointers / element counts / per-tensor learning
  * rates (doubles, combined in double before the cast to fp32 as torch does; the reference keeps one parameter group per Gaussian attribute, /root/reference/scene_reconstruction/
@@ -226,8 +222,24 @@ int csplat_ssim_fwd(void *stream, int64_t n_images, int H, int W, const float *t
 int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *taps11, const float *x, const float *y,
                     const float *p1, const float *p2, const float *p3, const float *g_scalar, float inv_n,
                     const float *addend, const float *add_scale, float *dx);
+/* masked form of the reference's image loss (train_utils.py:61-67: `((1.0 - ssim_map) * mask_tensor).mean()`): x, y
+ * [n_batch][channels][H][W], mask [n_batch][mask_channels][H][W] with mask_channels = 1 (Camera.mask, broadcast over the
+ * colour channels) or = channels.  partial sums hold sum((1 - SSIM) * mask) over the workgroup's tile (the loss term is
+ * sum(partial) / (n_batch*channels*H*W)); p1..p3 are pre-multiplied by the mask, so csplat_ssim_bwd (g_scalar = MINUS the
+ * incoming gradient of the loss term) serves both forms. */
+int csplat_ssim_fwd_masked(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
+                           const float *y, const float *mask, int mask_channels, float *p1, float *p2, float *p3,
+                           float *map_out, float *partial);
+/* l1_loss of /root/reference/utils/loss_utils.py:20-23 with its gradient in the same pass:
+ *   *loss = mean_i |a[i] - b[i]|,   grad[i] = sign(a[i] - b[i]) / n   (grad may be NULL).
+ * csplat_l1_masked: *loss = mean_i |(a[i] - b[i]) * m[i]|, grad[i] = sign((a-b)*m) * m / n, with the mask laid out as for
+ * csplat_ssim_fwd_masked (hw = H*W values per plane).
+ * scratch: csplat_l1_scratch_bytes() bytes whose last word is zero on entry (the kernel restores it), not shared between
+ * calls that may run concurrently.  Deterministic (fixed summation order). */
 size_t csplat_l1_scratch_bytes(void);
 int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad);
+int csplat_l1_masked(void *stream, int64_t n_batch, int channels, int64_t hw, const float *a, const float *b, const float *mask,
+                     int mask_channels, void *scratch, float *loss, float *grad);
 
 /* Fused mesh -> Gaussian transform (SURVEY.md 8(f) "next" row N1): MultiGaussianMesh.get_xyz + get_rotation,
  * scene_reconstruction/gaussian_mesh.py:151-188.  face_vertex_ids[P][3] (int64, device) = mesh.face[:, face_ids].T.

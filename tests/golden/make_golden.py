@@ -23,6 +23,9 @@ What it pins; every fixture holds inputs + the referenc
   normalizer.npz  meshnet.model_utils.Normalizer accumulate / normalise / inverse
   densify.npz     MultiGaussianMesh densify / prune / opacity reset / Adam-state surgery / cleanup (gen_densify)
   scene_io.npz    dataset_readers.readCamerasFromTransforms / read_timeline on blender_scene/ (gen_scene_io)
+  meshsim.npz     meshnet.meshnet_network.MeshSimulator predict_dx (train, noise) / predict_position (eval) (gen_meshsim)
+  mesh_transform.npz  MultiGaussianMesh.get_xyz (+ autograd gradients) and get_rotation with roma served by scipy
+  losses.npz      utils.loss_utils.l1_loss / ssim, train_utils.image_losses / regularization, masked and unmasked
 """
 import inspect
 import os
@@ -275,12 +278,8 @@ def gen_simulator():
     np.savez(os.path.join(OUT, "simulator.npz"), **out)
 
 
-def gen_densify():
-    """scene_reconstruction.gaussian_mesh.MultiGaussianMesh densify / prune / opacity reset + the Adam-state surgery of
-    gaussian_model.py:266-341, run HERE on CPU tensors: the module's hard imports that are not installed (h5py, roma,
-    plyfile, simple_knn, torch_geometric, meshnet.data_utils' plotting deps) are replaced by empty shim modules -- none of
-    their symbols is reached by the methods exercised -- and `device="cuda"` in the factory calls is mapped to the CPU.
-    compute_barycentric_coordinates is taken from meshnet/data_utils.py by exec'ing that one function's source."""
+def install_mesh_shims():
+    """the empty stand-ins gen_densify describes, so that scene_reconstruction.gaussian_mesh imports on this image"""
     install_pyg_shim()
     sys.modules["torch_geometric"].utils = types.ModuleType("torch_geometric.utils")
     sys.modules["torch_geometric.utils"] = sys.modules["torch_geometric"].utils
@@ -298,17 +297,36 @@ def gen_densify():
     sys.modules["meshnet.data_utils"] = du
     meshnet.data_utils = du
 
-    def cpu_factory(fn):
-        def w(*a, **k):
-            if k.get("device") is not None and "cuda" in str(k["device"]):
-                k["device"] = "cpu"
-            return fn(*a, **k)
-        return w
-    saved = {n: getattr(torch, n) for n in ("zeros", "ones", "arange", "empty", "tensor", "normal")}
-    for n, f in saved.items():
-        setattr(torch, n, cpu_factory(f))
-    torch.cuda.empty_cache = lambda: None
-    try:
+
+class cuda_as_cpu:
+    """`device="cuda"` in the reference's factory calls lands on the CPU while the block runs"""
+
+    def __enter__(self):
+        def cpu_factory(fn):
+            def w(*a, **k):
+                if k.get("device") is not None and "cuda" in str(k["device"]):
+                    k["device"] = "cpu"
+                return fn(*a, **k)
+            return w
+        self.saved = {n: getattr(torch, n) for n in ("zeros", "ones", "arange", "empty", "tensor", "normal")}
+        for n, f in self.saved.items():
+            setattr(torch, n, cpu_factory(f))
+        torch.cuda.empty_cache = lambda: None
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(torch, n, f)
+
+
+def gen_densify():
+    """scene_reconstruction.gaussian_mesh.MultiGaussianMesh densify / prune / opacity reset + the Adam-state surgery of
+    gaussian_model.py:266-341, run HERE on CPU tensors: the module's hard imports that are not installed (h5py, roma,
+    plyfile, simple_knn, torch_geometric, meshnet.data_utils' plotting deps) are replaced by empty shim modules -- none of
+    their symbols is reached by the methods exercised -- and `device="cuda"` in the factory calls is mapped to the CPU.
+    compute_barycentric_coordinates is taken from meshnet/data_utils.py by exec'ing that one function's source."""
+    install_mesh_shims()
+    with cuda_as_cpu():
         from scene_reconstruction.gaussian_mesh import MultiGaussianMesh
         g = torch.Generator().manual_seed(77)
         V, F, P = 12, 14, 60
@@ -401,9 +419,6 @@ def gen_densify():
         out["cleanup.face_ids_out"], out["cleanup.face_bary_out"] = pc2.face_ids.clone(), pc2.face_bary.detach().clone()
         print("cleanup: rows with a negative coordinate", int((b < 0).any(1).sum()), "faces changed",
               int((out["cleanup.face_ids_out"] != out["cleanup.face_ids_in"]).sum()))
-    finally:
-        for n, f in saved.items():
-            setattr(torch, n, f)
     np.savez_compressed(os.path.join(OUT, "densify.npz"), **{k: npy(v) if torch.is_tensor(v) else v for k, v in out.items()})
     print("densify.npz: P", P, "->", int(out["densified.face_ids"].shape[0]), "->", int(out["pruned.face_ids"].shape[0]))
 
@@ -497,9 +512,211 @@ def gen_scene_io():
     print("scene_io.npz:", {t: int(out[f"{t}.n"]) for t, *_ in cases})
 
 
+def gen_meshsim():
+    """meshnet.meshnet_network.MeshSimulator (:14-191): predict_dx in train mode (noise, online normaliser statistics, twice so
+    that the second call normalises with accumulated statistics) and predict_position in eval mode, under the PyG shim.  The
+    file does not parse as shipped (merge-conflict markers): its text is exec'd with the conflict resolved to the
+    `9b63d7a` side and `meshnet.viz` (matplotlib / imageio plotting helpers, not reached) replaced by an empty module."""
+    install_pyg_shim()
+    viz = types.ModuleType("meshnet.viz")
+    viz.plot_mesh = viz.plot_pcd_list = None
+    sys.modules["meshnet.viz"] = viz
+    src = open(os.path.join(REF, "meshnet/meshnet_network.py")).read()
+    src = re.sub(r"<<<<<<< HEAD\n.*?=======\n(.*?)>>>>>>> [^\n]*\n", r"\1", src, flags=re.S)
+    ns = {"__name__": "meshnet.meshnet_network"}
+    exec(compile(src, "<meshnet_network>", "exec"), ns)
+    MeshSimulator = ns["MeshSimulator"]
+    g = torch.Generator().manual_seed(21)
+    N, E = 40, 220
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ef = torch.randn(E, 4, generator=g)
+    torch.manual_seed(11)
+    # node features: 3 position + 1 time + 2 one-hot
+    sim = MeshSimulator(simulation_dimensions=3, nnode_in=6, nedge_in=4, latent_dim=32, nmessage_passing_steps=2,
+                        nmlp_layers=2, mlp_hidden_dim=32, nnode_types=2, node_type_embedding_size=2, device="cpu")
+    pos = torch.randn(N, 3, generator=g)
+    tvec = torch.full((N,), 0.35)                   # 1-D time vector: exercises the [:, None] branch (:97-98)
+    ntype = torch.randint(0, 2, (N, 1), generator=g)
+    tgt = pos + torch.randn(N, 3, generator=g) * 0.05
+    noise = torch.randn(N, 3, generator=g) * 0.01
+    out = dict(edge_index=npy(ei), edge_features=npy(ef), pos=npy(pos), time=npy(tvec), node_type=npy(ntype), target=npy(tgt),
+               noise=npy(noise))
+    for k, v in sim.state_dict().items():
+        out["sd." + k] = npy(v)
+    sim.train()
+    pd1, td1 = sim.predict_dx(pos, tvec, ntype, ei, ef, target_positions=tgt, position_noise=noise)
+    pos2 = pos * 1.3 + 0.2
+    tvec2 = torch.full((N, 1), 0.7)
+    pd2, td2 = sim.predict_dx(pos2, tvec2, ntype, ei, ef, target_positions=tgt, position_noise=noise)
+    out.update(dx1_pred=npy(pd1), dx1_target=npy(td1), pos2=npy(pos2), time2=npy(tvec2), dx2_pred=npy(pd2), dx2_target=npy(td2))
+    # gradient of sum(pred * w) + sum(target_norm * w2) w.r.t. one decoder and one encoder weight
+    w = torch.randn(N, 3, generator=g)
+    sim.zero_grad()
+    pd3, _ = sim.predict_dx(pos, tvec, ntype, ei, ef, target_positions=tgt, position_noise=noise)
+    (pd3 * w).sum().backward()
+    out.update(dx3_w=npy(w), dx3_pred=npy(pd3),
+               dx3_dW_dec=npy(sim._encode_process_decode._decoder.node_fn[0].weight.grad),
+               dx3_dW_enc=npy(sim._encode_process_decode._encoder.node_fn[0][0].weight.grad))
+    for nm in ("_output_normalizer", "_node_normalizer"):
+        for k, v in getattr(sim, nm).get_variable().items():
+            if torch.is_tensor(v):
+                out[f"{nm}.{k}"] = npy(v)
+    sim.eval()
+    pp = sim.predict_position(pos, tvec[:, None], ntype, ei, ef)
+    pd_eval, none = sim.predict_dx(pos, tvec, ntype, ei, ef)
+    assert none is None
+    out.update(position=npy(pp), dx_eval=npy(pd_eval))
+    np.savez_compressed(os.path.join(OUT, "meshsim.npz"), **out)
+
+
+def install_roma_scipy():
+    """`roma` is not installed and cannot be (no network).  For the get_rotation fixture its three entry points are served
+    by SCIPY (an independent, third-party implementation of the same published operations), in float64:
+      rigid_points_registration(x, y) -> (R, t) minimising |R x + t - y|   == Rotation.align_vectors on the centred sets
+      rotmat_to_unitquat(R)           -> xyzw                              == Rotation.from_matrix(R).as_quat()
+      quat_composition([p, q])        -> Hamilton product p*q, xyzw        == (Rotation.from_quat(p) * from_quat(q)).as_quat()
+    The fixture is therefore "scipy-derived": it pins the CALL PATTERN of gaussian_mesh.py:171-188 (which quaternion goes
+    where, in which convention -- SURVEY F8) and the Kabsch solution against code the build did not write."""
+    from scipy.spatial.transform import Rotation
+    roma = sys.modules.get("roma") or types.ModuleType("roma")
+
+    def rigid_points_registration(x, y, weights=None, compute_scaling=False):
+        xs, ys = x.detach().double().numpy(), y.detach().double().numpy()
+        Rs, ts = [], []
+        for xi, yi in zip(xs, ys):
+            cx, cy = xi.mean(0), yi.mean(0)
+            R, _ = Rotation.align_vectors(yi - cy, xi - cx)
+            Rs.append(R.as_matrix()); ts.append(cy - R.as_matrix() @ cx)
+        return torch.tensor(np.stack(Rs)), torch.tensor(np.stack(ts))
+
+    def rotmat_to_unitquat(R):
+        return torch.tensor(Rotation.from_matrix(R.detach().double().numpy()).as_quat())
+
+    def quat_composition(seq, normalize=False):
+        acc = Rotation.from_quat(seq[0].detach().double().numpy())
+        for q in seq[1:]:
+            acc = acc * Rotation.from_quat(q.detach().double().numpy())
+        return torch.tensor(acc.as_quat())
+    roma.rigid_points_registration, roma.rotmat_to_unitquat, roma.quat_composition = \
+        rigid_points_registration, rotmat_to_unitquat, quat_composition
+    sys.modules["roma"] = roma
+
+
+def gen_mesh_transform():
+    """MultiGaussianMesh.get_xyz (gaussian_mesh.py:151-169: rest pose and deformed, forward + autograd gradients -- pure torch,
+    the reference's own arithmetic) and get_rotation (:171-188, with roma served by scipy, see install_roma_scipy; its vertex
+    gradient is pinned by central differences of that float64 forward)."""
+    install_mesh_shims()
+    install_roma_scipy()
+    with cuda_as_cpu():
+        from scene_reconstruction.gaussian_mesh import MultiGaussianMesh
+        g = torch.Generator().manual_seed(31)
+        gm = 7
+        xs = torch.linspace(-0.5, 0.5, gm)
+        pos = torch.stack([xs.repeat(gm), xs.repeat_interleave(gm), 0.05 * torch.rand(gm * gm, generator=g)], 1)
+        quads = [(r * gm + c, r * gm + c + 1, (r + 1) * gm + c, (r + 1) * gm + c + 1) for r in range(gm - 1) for c in range(gm - 1)]
+        face = torch.tensor([[a, b, c2] for a, b, c2, d in quads] + [[b, d, c2] for a, b, c2, d in quads]).t().contiguous()
+        V, F, P = pos.shape[0], face.shape[1], 150
+        pc = MultiGaussianMesh(3)
+        pc.mesh = types.SimpleNamespace(pos=pos, face=face)
+        pc.face_ids = torch.randint(0, F, (P,), generator=g)
+        bary = torch.rand(P, 3, generator=g) + 0.02
+        bary = bary / bary.sum(1, keepdim=True) * (0.8 + 0.4 * torch.rand(P, 1, generator=g))   # rows that do NOT sum to 1
+        pc.face_bary = torch.nn.Parameter(bary.clone())
+        pc._rotation = torch.nn.Parameter(torch.randn(P, 4, generator=g))
+        # a rigid motion + a smooth wave + noise: large rotations incl. > 90 degrees for some faces
+        ang = 2.1
+        Rz = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=torch.float32)
+        Rx = torch.tensor([[1, 0, 0], [0, np.cos(0.9), -np.sin(0.9)], [0, np.sin(0.9), np.cos(0.9)]], dtype=torch.float32)
+        deformed = (pos @ (Rz @ Rx).T) + torch.tensor([0.1, -0.2, 0.3]) + 0.03 * torch.randn(V, 3, generator=g)
+        deformed[:, 2] += 0.1 * torch.sin(4 * pos[:, 0])
+        out = dict(pos=pos, face=face, face_ids=pc.face_ids, face_bary=bary, rotation=pc._rotation.detach().clone(),
+                   deformed=deformed)
+        out["xyz_rest"] = pc.get_xyz().detach()
+        dv = deformed.clone().requires_grad_(True)
+        xyz = pc.get_xyz(dv)
+        wx = torch.randn(P, 3, generator=g)
+        (xyz * wx).sum().backward()
+        out.update(xyz_deformed=xyz.detach(), xyz_w=wx, xyz_d_vertices=dv.grad.clone(), xyz_d_bary=pc.face_bary.grad.clone())
+        out["rot_rest"] = pc.get_rotation().detach()
+        q0 = pc.get_rotation(deformed).detach()
+        out["rot_deformed"] = q0                                             # float64, defined up to the sign of each row
+        wq = torch.randn(P, 4, generator=g).double()
+        out["rot_w"] = wq
+
+        def f(dvert):
+            q = pc.get_rotation(dvert).detach()
+            sgn = torch.sign((q * q0).sum(1, keepdim=True))
+            return float(((q * sgn) * wq).sum())
+        h = 1e-4
+        gnum = torch.zeros(V, 3, dtype=torch.float64)
+        for i in range(V):
+            for c in range(3):
+                dp, dm = deformed.double().clone(), deformed.double().clone()
+                dp[i, c] += h; dm[i, c] -= h
+                gnum[i, c] = (f(dp) - f(dm)) / (2 * h)
+        out["rot_d_vertices_fd"] = gnum
+    np.savez_compressed(os.path.join(OUT, "mesh_transform.npz"), **{k: npy(v) for k, v in out.items()})
+
+
+def gen_losses():
+    """utils.loss_utils.l1_loss / ssim (:20-70; `lpips` -- imported at module level, never called here -- is an empty module)
+    and scene_reconstruction.train_utils.image_losses / regularization (:50-102), whose two function bodies are exec'd from
+    the reference text (the module itself imports wandb, imageio, lpips, the CUDA extensions ...).  Values and autograd
+    gradients, masked and unmasked, for a [3,3,H,W] batch like the train step's."""
+    sys.modules.setdefault("lpips", types.ModuleType("lpips"))
+    from utils.loss_utils import l1_loss, ssim
+    src = open(os.path.join(REF, "scene_reconstruction", "train_utils.py")).read()
+    ns = {"torch": torch, "l1_loss": l1_loss, "ssim": ssim, "OptimizationParams": object}
+    for fn in ("image_losses", "regularization"):
+        m = re.search(r"^def %s\(.*?(?=^\S)" % fn, src, re.S | re.M)
+        exec(compile(m.group(0), f"train_utils.py:{fn}", "exec"), ns)
+    g = torch.Generator().manual_seed(41)
+    B, H, W = 3, 37, 45                       # not multiples of the kernel's tile sizes
+    gt = torch.rand(B, 3, H, W, generator=g)
+    img = (gt + 0.15 * torch.randn(B, 3, H, W, generator=g)).clamp(0, 1.2)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.4).float()            # Camera.mask is [1,H,W] per view (cameras.py)
+    out = dict(img=img, gt=gt, mask=mask)
+    opt = types.SimpleNamespace(lambda_dssim=0.05, lambda_lpips=0)
+    for tag, mk in (("plain", None), ("masked", mask)):
+        x = img.clone().requires_grad_(True)
+        l1 = l1_loss(x, gt, mk)
+        l1.backward()
+        out[f"{tag}.l1"], out[f"{tag}.l1_grad"] = l1.detach(), x.grad.clone()
+        x = img.clone().requires_grad_(True)
+        loss, d = ns["image_losses"](x, gt, opt, mk)
+        loss.backward()
+        out[f"{tag}.loss"], out[f"{tag}.loss_grad"] = loss.detach(), x.grad.clone()
+        out[f"{tag}.ssim_loss"] = torch.tensor(d["ssim_loss"])
+    x = img.clone().requires_grad_(True)
+    s = ssim(x, gt)
+    s.backward()
+    out["ssim"], out["ssim_grad"] = s.detach(), x.grad.clone()
+    out["ssim_map"] = ssim(img, gt, return_map=True)
+    out["ssim_per_image"] = ssim(img, gt, size_average=False)
+    # ---- regularization
+    with cuda_as_cpu():
+        V, E = 30, 140
+        ei = torch.randint(0, V, (2, E), generator=g)
+        rest = torch.randn(V, 3, generator=g)
+        gauss = types.SimpleNamespace(mesh=types.SimpleNamespace(edge_index=ei),
+                                      edge_norm=(rest[ei[1]] - rest[ei[0]]).norm(dim=-1, keepdim=True))
+        ropt = types.SimpleNamespace(lambda_deform_mag=0.01, lambda_rigid=0.3, lambda_momentum=0.1)
+        out.update(reg_edge_index=ei, reg_rest=rest)
+        for T in (3, 2, 1):
+            D = (rest[None] + 0.1 * torch.randn(T, V, 3, generator=g)).requires_grad_(True)
+            loss = ns["regularization"](D, gauss, ropt)
+            loss.backward()
+            out[f"reg{T}.D"], out[f"reg{T}.loss"], out[f"reg{T}.grad"] = D.detach().clone(), loss.detach(), D.grad.clone()
+        D = out["reg3.D"].clone().requires_grad_(True)
+        out["reg3.static_loss"] = ns["regularization"](D, gauss, ropt, static=True).detach()
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **{k: npy(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
     gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify(); gen_scene_io()
+    gen_meshsim(); gen_mesh_transform(); gen_losses()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
