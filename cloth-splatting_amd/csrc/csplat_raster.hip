@@ -7,9 +7,11 @@
 //   K2 (csplat_sort.hip)   inclusive scan of tiles_touched
 //   K3 k_emit_keys         (tile<<32 | depth bits, id) per touched tile
 //   K4 (csplat_sort.hip)   stable radix sort
-//   K5 k_tile_ranges       [first,last) per tile
-//   K6 k_render_fwd        front-to-back compositing of RGB + depth, 16x16 tile per workgroup
-//   K7 k_render_bwd        back-to-front replay, wavefront (64-lane) DPP reduction, one atomic set per wave
+//   K5 k_tile_ranges       [first,last) per tile; k_seg_plan (256-entry segments of every tile list);
+//      k_block_masks       per list entry: which of the tile's sixteen 4x4 pixel blocks it can reach + tile-ordered records
+//   K6 k_composite_fwd     front-to-back compositing of RGB + depth: one wavefront per 4x4 block, four survivors per step
+//   K7 k_composite_bwd     per (segment, quadrant) workgroup, forward-ordered replay from the checkpoints, row butterfly
+//                          reduction, LDS records, one atomic per (entry, quadrant)
 //   K8 k_preprocess_bwd    conic->cov2D->cov3D/mean, mean2D(NDC)->mean3D, colour->SH, cov3D->(scale,quat)
 //
 // Index-deciding arithmetic (radius, tile rectangle, sort key) is compiled with FP contraction OFF and is
@@ -322,8 +324,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint64_t *
 //   k_tile_colscan per tile: exclusive scan over the workgroups, in place (each workgroup's offset inside the tile's list)
 //   k_tile_scan    exclusive scan of the per-tile totals: tile ranges, R and the longest list
 //   k_emit_bucket  workgroup b reloads its bases into LDS and drops every instance at base[tile]++ (LDS atomic)
-//   k_tile_sort    each tile's list ordered by (depth bits, Gaussian id) with an in-LDS bitonic network.  The composite
-//                  key is unique, so the result is exactly the stable (tile | depth) radix order of the upstream pipeline.
+//   k_tile_sort    each tile's list ordered by (depth bits, Gaussian id) with a stable LSD radix sort in LDS + registers.
+//                  The composite key is unique, so the result is exactly the stable (tile | depth) radix order of the
+//                  upstream pipeline.
 constexpr int BUCKET_CAP = 8192;    // longest tile list the LDS sort takes (64 KB); longer lists -> global radix sort
 constexpr int BUCKET_TILES = 12288; // most tiles the per-workgroup LDS histogram takes (48 KB)
 constexpr int BUCKET_G = 1024;      // Gaussians per counting workgroup
@@ -613,13 +616,6 @@ __device__ __forceinline__ bool box_hit(float2 c, float cut2, float4 co, float b
     return qmin - 1e-5f * sabs <= tau * 1.001f + 1e-3f;
 }
 
-// ------------------------------------------------------------------------------------------- K6
-// One 64-lane wavefront per workgroup, one workgroup per 8x8 pixel quadrant of a 16x16 tile (4 independent
-// workgroups share a tile's list).  No workgroup barrier anywhere: the wave streams the tile list in 64-entry
-// chunks (lane l gathers entry l, two chunks of ids / one chunk of data prefetched ahead of use), culls the chunk
-// with one ballot against the box of its still-live pixels, and composites the surviving entries in groups of four
-// (four independent alpha evaluations in flight, then the short sequential transmittance chain).
-constexpr int FWD_GROUP = 8;
 constexpr int SEG = 256;   // tile-list entries per backward segment (multiple of 64)
 
 // per-tile segment plan: seg_offset[t] = first segment slot of tile t (exclusive scan of ceil(n_t / SEG)),
@@ -657,335 +653,200 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int tiles, const int2 *__rest
     if (threadIdx.x == 0) seg_offset[tiles] = carry;
 }
 
-__device__ __forceinline__ void quadrant_pixel(int quad, int gx, int lane, int &tile, int &px, int &py) {
-    tile = quad >> 2;
-    const int w = quad & 3;
-    px = (tile % gx) * CSPLAT_TILE + ((w & 1) << 3) + (lane & 7);
-    py = (tile / gx) * CSPLAT_TILE + ((w >> 1) << 3) + (lane >> 3);
+// =================================================================================================== K5b / K6 / K7, block form
+// The compositing kernels work on 4x4 PIXEL BLOCKS (16 per tile) instead of 8x8 quadrants: a wavefront owns ONE block and
+// advances through the block's survivors FOUR AT A TIME -- DPP row r (16 lanes = the 16 pixels of the block) evaluates
+// survivor r of the group.  On scene_1 a projected Gaussian covers ~16 of the 64 pixels of a quadrant (26 % of the lanes
+// did useful work per survivor); it covers ~8 of the 16 pixels of the blocks it reaches, and a quadrant's survivor reaches
+// 2.2 of the 4 blocks: ~1.8x fewer wave-instructions per (pixel, Gaussian) pair, 4x more waves, 4x shorter serial chains.
+//   * the per-pixel transmittance chain crosses the four rows: every lane all-gathers the four (1 - alpha) factors of its
+//     pixel (three v_permlane{16,32}_swap) and forms the running products in the sequential order T*F0*F1*F2*F3 -- the
+//     same association as a one-entry-at-a-time walk, so skipping culled entries (factor 1) cannot change a bit of T;
+//   * which entries reach which block is decided ONCE per view by k_block_masks (exact ellipse-vs-box test, one lane per
+//     tile-list entry, 16 boxes): a 16-bit mask per entry plus a tile-ordered copy of what compositing reads (40 B, so the
+//     walkers read contiguous records instead of gathering five arrays by Gaussian id).  K6 and K7 walk those masks on the
+//     SCALAR unit (ballot of the block's bit over a 64-entry chunk -> s_ff1 / s_andn2 pops): no LDS staging, no per-chunk
+//     re-culling, no 4x re-gather of a tile's entries by its quadrant waves;
+//   * K7 runs FORWARD through a 256-entry segment: with S_k = sum_{j<=k} (c_j . dL/dC) alpha_j T_j (restarted from the
+//     forward's checkpoint) the upstream back-to-front recurrence collapses to
+//         dL/dalpha_k = T_k (c_k . dL/dC) - (out_colour . dL/dC - S_k) / (1 - alpha_k),
+//     the same identity the depth-split restart already used once per segment;
+//   * the nine per-pixel partials of a survivor are summed over its 16-lane row by a 4-level butterfly (26 DPP adds for
+//     four survivors at once), added into an LDS record per list entry shared by the four blocks of a quadrant, and
+//     flushed with ONE 36-byte atomic per (entry, quadrant) into 64-byte-aligned per-Gaussian records (global float
+//     atomics are priced per 64-byte request at the memory side, MI355X_MICROARCH.md "Global float atomics").
+constexpr float T_EPS = 0.0001f;
+constexpr float ALPHA_MIN = 1.f / 255.f;
+
+struct Row4 { float v0, v1, v2, v3; };
+// every lane receives the values its pixel position holds in rows 0..3 (rows = 16-lane groups)
+__device__ __forceinline__ Row4 rows_allgather(float f) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(f), __float_as_uint(f), false, false);   // [f0 f0 f2 f2], [f1 f1 f3 f3]
+    const auto ev = __builtin_amdgcn_permlane32_swap(s16[0], s16[0], false, false);                           // f0 x4, f2 x4
+    const auto od = __builtin_amdgcn_permlane32_swap(s16[1], s16[1], false, false);                           // f1 x4, f3 x4
+    return {__uint_as_float(ev[0]), __uint_as_float(od[0]), __uint_as_float(ev[1]), __uint_as_float(od[1])};
+}
+__device__ __forceinline__ float rows_sum(float f) { const Row4 g = rows_allgather(f); return ((g.v0 + g.v1) + g.v2) + g.v3; }
+template <typename Tv>
+__device__ __forceinline__ Tv rowsel(int r, Tv a, Tv b, Tv c, Tv d) { return r == 0 ? a : (r == 1 ? b : (r == 2 ? c : d)); }
+
+// ------------------------------------------------------------------------------------------- K5b
+__global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
+                                                      const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
+                                                      const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                                                      const float *__restrict__ depth, const float *__restrict__ cut2,
+                                                      uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
+                                                      float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > R) return;
+    if (i == R) {   // the null record behind the list: opacity 0, pads incomplete groups of four
+        mask16[i] = 0;
+        recA[i] = make_float4(0.f, 0.f, 0.f, 0.f); recB[i] = make_float4(0.f, 0.f, 0.f, 0.f); recC[i] = make_float2(0.f, 0.f);
+        return;
+    }
+    const uint32_t tile = (uint32_t)(keys_sorted[i] >> 32), id = ids_sorted[i];
+    const float2 c = xy[id];
+    const float4 co = conic_opacity[id];
+    const float cut = cut2[id];
+    const float x0 = (float)((tile % (uint32_t)gx) * CSPLAT_TILE), y0 = (float)((tile / (uint32_t)gx) * CSPLAT_TILE);
+    uint32_t m = 0;
+#pragma unroll
+    for (int by = 0; by < 4; by++)
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++)
+            if (box_hit(c, cut, co, x0 + 4.f * bx, x0 + 4.f * bx + 3.f, y0 + 4.f * by, y0 + 4.f * by + 3.f, exact)) m |= 1u << (by * 4 + bx);
+    mask16[i] = (uint16_t)m;
+    recA[i] = make_float4(c.x, c.y, co.x, co.y);
+    recB[i] = make_float4(co.z, co.w, rgb[3 * id], rgb[3 * id + 1]);
+    recC[i] = make_float2(rgb[3 * id + 2], depth[id]);
 }
 
-__global__ __launch_bounds__(64) void k_render_fwd(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                    int W, int H, int gx, const float2 *__restrict__ xy,
-                                                    const float *__restrict__ rgb, const float *__restrict__ depth,
-                                                    const float4 *__restrict__ conic_opacity,
-                                                    const float *__restrict__ cut2, const float *__restrict__ bg,
-                                                    const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
-                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                    float *__restrict__ out_color, float *__restrict__ out_depth, int exact_cull) {
-    // survivors of a chunk are COMPACTED into these arrays (slot = rank of the lane among the ballot's set bits), so the
-    // compositing loop is a plain counted loop over contiguous LDS records with immediate offsets; slots past the
-    // survivor count hold a harmless record (opacity 0).  +FWD_GROUP slots of padding for the last group.
-    __shared__ float4 s_xyi[64 + FWD_GROUP];  // x, y, list index + 1 (as float bits), unused
-    __shared__ float4 s_co[64 + FWD_GROUP];
-    __shared__ float4 s_cd[64 + FWD_GROUP];   // rgb + depth
-    const int lane = threadIdx.x;
-    int tile, px, py;
-    quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
+// Walks the survivors of block `blk` in list positions [lo, hi) of one tile, four at a time, never across a SEG boundary.
+// Everything in here is wave-uniform (SGPRs); only the mask prefetch is a vector load.
+struct BlockWalker {
+    const uint16_t *m16;     // the tile's masks (already offset by range.x)
+    unsigned long long cur;  // unconsumed survivors of the current 64-entry chunk
+    int cbase, hi, blk, lane;
+    uint32_t m_next;         // masks of the chunk after the current one (prefetched)
+    __device__ __forceinline__ uint32_t load(int base) const { const int e = base + lane; return e < hi ? (uint32_t)m16[e] : 0u; }
+    __device__ __forceinline__ void start(const uint16_t *masks, int lo, int hi_, int blk_, int lane_) {
+        m16 = masks; hi = hi_; blk = blk_; lane = lane_; cbase = lo;
+        const uint32_t m0 = load(lo);
+        m_next = load(lo + 64);
+        cur = __ballot((m0 >> blk) & 1u);
+    }
+    __device__ __forceinline__ void refill() {
+        cbase += 64;
+        cur = __ballot((m_next >> blk) & 1u);
+        m_next = load(cbase + 64);
+    }
+    // next group of up to four survivors (list positions, -1 = none), all inside one SEG-entry segment; false = exhausted
+    __device__ __forceinline__ bool next(int (&ix)[4], int &seg) {
+        while (cur == 0ull) {
+            if (cbase + 64 >= hi) return false;
+            refill();
+        }
+        seg = cbase / SEG;
+        const int seg_end = min(hi, (seg + 1) * SEG);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            while (cur == 0ull && cbase + 64 < seg_end) refill();
+            if (cur != 0ull) {
+                ix[k] = cbase + (int)__builtin_ctzll(cur);
+                cur &= cur - 1ull;
+            } else ix[k] = -1;
+        }
+        return true;
+    }
+};
+
+struct Trip { float4 a, b; float2 c; int pos; };   // the lane's survivor of a group (row r's), pos = list position or -1
+
+// ------------------------------------------------------------------------------------------- K6
+// grid: 16 single-wave workgroups per tile; the 16 blocks of a tile have the same blockIdx % 8 (same XCD, shared L2 lines)
+__global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                       const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                       const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                       uint32_t null_rec, const float *__restrict__ bg,
+                                                       const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
+                                                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                       float *__restrict__ out_color, float *__restrict__ out_depth) {
+    const int wg = blockIdx.x;
+    const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
+    if (tile >= tiles) return;
+    const int lane = threadIdx.x, r = lane >> 4, l16 = lane & 15;
+    const int px = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4 + (l16 & 3);
+    const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
     const int pix = py * W + px;
     const float fx = (float)px, fy = (float)py;
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
+    const uint32_t rx = (uint32_t)range.x;
     bool done = !inside;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;   // T: the pixel's (same in its 4 lanes); C*, Dp: this row's share
     uint32_t last = 0;
-
     if (n > 0 && __ballot(!done) != 0ull) {
-        float bx0 = wave_min(done ? 3.0e38f : fx), bx1 = wave_max(done ? -3.0e38f : fx);
-        float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
-        unsigned long long live = __ballot(!done);
-        const uint32_t *pl = point_list + range.x;
         const int seg0 = seg_offset[tile];
-        // software pipeline: ids three chunks ahead, per-entry data two chunks ahead (the critical wave of a deep quadrant
-        // runs alone on its SIMD: a chunk is composited in less time than a gather round trip takes)
-        uint32_t id_cur = lane < n ? pl[lane] : 0u;
-        uint32_t id_n1 = 64 + lane < n ? pl[64 + lane] : 0u;
-        uint32_t id_nxt = 128 + lane < n ? pl[128 + lane] : 0u;      // ids of chunk + 2
-        float2 c_cur = xy[id_cur];
-        float cut_cur = lane < n ? cut2[id_cur] : -1.f;
-        float4 co_cur = conic_opacity[id_cur];
-        float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
-        float2 c_n1 = xy[id_n1];
-        float cut_n1 = 64 + lane < n ? cut2[id_n1] : -1.f;
-        float4 co_n1 = conic_opacity[id_n1];
-        float4 cd_n1 = make_float4(rgb[3 * id_n1], rgb[3 * id_n1 + 1], rgb[3 * id_n1 + 2], depth[id_n1]);
-        for (int base = 0; base < n; base += 64) {
-            // segment boundary: checkpoint (T, colour so far) so that K7 can replay every SEG-entry segment of this
-            // quadrant independently (depth-split backward)
-            if ((base & (SEG - 1)) == 0)
-                ckpt[(size_t)(seg0 + base / SEG) * 256 + (blockIdx.x & 3) * 64 + lane] = make_float4(T, C0, C1, C2);
-            const bool hit = box_hit(c_cur, cut_cur, co_cur, bx0, bx1, by0, by1, exact_cull);
-            const unsigned long long mask = __ballot(hit);
-            const int nh = __popcll(mask);
-            __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk before these writes
-            if (hit) {
-                const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                s_xyi[slot] = make_float4(c_cur.x, c_cur.y, __uint_as_float((uint32_t)(base + lane + 1)), 0.f);
-                s_co[slot] = co_cur;
-                s_cd[slot] = cd_cur;
+        BlockWalker wk;
+        wk.start(mask16 + rx, 0, n, blk, lane);
+        int seg_written = -1;
+        auto fetch = [&](Trip &t, const int (&ix)[4]) {
+            t.pos = rowsel(r, ix[0], ix[1], ix[2], ix[3]);
+            const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
+            t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+        };
+        auto process = [&](const Trip &t, int seg) {
+            if (seg != seg_written) {
+                // entering a new 256-entry segment: checkpoint (T, colour so far) for the depth-split backward, for every
+                // segment start passed since the last one (segments without a survivor of this block get the same state)
+                const float t0 = rows_sum(C0), t1 = rows_sum(C1), t2 = rows_sum(C2);
+                if (r == 0)
+                    for (int s = seg_written + 1; s <= seg; s++)
+                        ckpt[(size_t)(seg0 + s) * 256 + blk * 16 + l16] = make_float4(T, t0, t1, t2);
+                C0 = r == 0 ? t0 : 0.f; C1 = r == 0 ? t1 : 0.f; C2 = r == 0 ? t2 : 0.f;
+                seg_written = seg;
             }
-            if (lane < FWD_GROUP) {   // padding records behind the survivors: opacity 0 -> alpha 0 -> no effect
-                s_xyi[nh + lane] = make_float4(fx, fy, 0.f, 0.f);
-                s_co[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-                s_cd[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            // rotate the pipeline and start the loads of chunk + 2
-            const int nb = base + 128;
-            const uint32_t id_n3 = nb + 64 + lane < n ? pl[nb + 64 + lane] : 0u;
-            c_cur = c_n1; cut_cur = cut_n1; co_cur = co_n1; cd_cur = cd_n1;
-            c_n1 = xy[id_nxt];
-            cut_n1 = nb + lane < n ? cut2[id_nxt] : -1.f;
-            co_n1 = conic_opacity[id_nxt];
-            cd_n1 = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
-            id_nxt = id_n3;
-            __syncthreads();
-            for (int h0 = 0; h0 < nh; h0 += FWD_GROUP) {
-                float al[FWD_GROUP];
-                float4 cd[FWD_GROUP];
-                uint32_t idx[FWD_GROUP];
-#pragma unroll
-                for (int k = 0; k < FWD_GROUP; k++) {   // independent alpha evaluations: all loads / exps in flight together
-                    const float4 p = s_xyi[h0 + k];
-                    const float4 co = s_co[h0 + k];
-                    cd[k] = s_cd[h0 + k];
-                    idx[k] = __float_as_uint(p.z);
-                    const float dx = p.x - fx, dy = p.y - fy;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    const float a = fminf(0.99f, co.w * __expf(power));
-                    al[k] = (power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
-                }
-#pragma unroll
-                for (int k = 0; k < FWD_GROUP; k++) {
-                    // branch-free serial part: the only loop-carried chain is T -> test_T -> select (3 dependent ops);
-                    // the colour / depth accumulations hang off it
-                    const float test_T = T * (1.f - al[k]);
-                    const bool contributes = al[k] > 0.f;
-                    done = done || (contributes && test_T < 0.0001f);
-                    const bool blend = contributes && !done;
-                    const float wgt = blend ? al[k] * T : 0.f;
-                    C0 += cd[k].x * wgt; C1 += cd[k].y * wgt; C2 += cd[k].z * wgt; Dp += cd[k].w * wgt;
-                    T = blend ? test_T : T;
-                    last = blend ? idx[k] : last;
-                }
-            }
-            const unsigned long long now = __ballot(!done);
-            if (now == 0ull) break;
-            if (now != live) {  // some pixels finished: shrink the culling box to the survivors
-                live = now;
-                bx0 = wave_min(done ? 3.0e38f : fx); bx1 = wave_max(done ? -3.0e38f : fx);
-                by0 = wave_min(done ? 3.0e38f : fy); by1 = wave_max(done ? -3.0e38f : fy);
-            }
+            const float dx = t.a.x - fx, dy = t.a.y - fy;
+            const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
+            const float a = fminf(0.99f, t.b.y * __expf(power));
+            const float al = (!done && power <= 0.f && a >= ALPHA_MIN) ? a : 0.f;
+            const float F = 1.f - al;
+            const Row4 g = rows_allgather(F);
+            const float P1 = T * g.v0, P2 = P1 * g.v1, P3 = P2 * g.v2, P4 = P3 * g.v3;
+            const float Tr = rowsel(r, T, P1, P2, P3);
+            const bool blend = al > 0.f && Tr * F >= T_EPS;     // (Tr * F is this row's P_{r+1}, bit for bit)
+            const float wgt = blend ? al * Tr : 0.f;
+            C0 += t.b.z * wgt; C1 += t.b.w * wgt; C2 += t.c.x * wgt; Dp += t.c.y * wgt;
+            last = blend ? (uint32_t)(t.pos + 1) : last;
+            // the products only decrease: the pixel's T after the group is the last one still above the threshold
+            T = P4 >= T_EPS ? P4 : (P3 >= T_EPS ? P3 : (P2 >= T_EPS ? P2 : (P1 >= T_EPS ? P1 : T)));
+            done = done || !(P4 >= T_EPS);
+        };
+        // software pipeline, two groups in flight: the records of group k+1 are requested before group k is composited
+        Trip ta, tb;
+        int ixa[4], ixb[4], sa = 0, sb = 0;
+        bool va = wk.next(ixa, sa), vb = false;
+        if (va) fetch(ta, ixa);
+        while (va) {
+            vb = wk.next(ixb, sb);
+            if (vb) fetch(tb, ixb);
+            process(ta, sa);
+            if (__ballot(!done) == 0ull || !vb) break;
+            va = wk.next(ixa, sa);
+            if (va) fetch(ta, ixa);
+            process(tb, sb);
+            vb = false;
+            if (__ballot(!done) == 0ull) break;
         }
+        if (vb && __ballot(!done) != 0ull) process(tb, sb);
     }
-    if (inside) {
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        const size_t HW = (size_t)H * W;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
-        out_depth[pix] = Dp;
+    C0 = rows_sum(C0); C1 = rows_sum(C1); C2 = rows_sum(C2); Dp = rows_sum(Dp);
+    {
+        const Row4 g = rows_allgather(__uint_as_float(last));
+        last = max(max(__float_as_uint(g.v0), __float_as_uint(g.v1)), max(__float_as_uint(g.v2), __float_as_uint(g.v3)));
     }
-}
-
-// ------------------------------------------------------------------------------------------- K6, depth-split form
-// The sequential kernel above is bounded by the serial chain of the deepest quadrant (one wave walks the whole tile list).
-// This alternative forward (csplat_debug_flags bit 3) gives every 8x8 quadrant a workgroup of FOUR wavefronts that all map their lanes to the SAME 64
-// pixels and advance through the list in ROUNDS of four 256-entry segments:
-//   1. wave w composites segment 4r+w speculatively: from T = 1, no termination test -> per pixel the segment's
-//      transmittance product P, colour / depth partial sums and last contributing index, exchanged through LDS;
-//   2. every wave walks the four results in order for its 64 lanes (redundantly -- it is ~40 operations): checkpoint
-//      (T, colour so far; the same checkpoint K7 restarts from), then C += T * C_s, T *= P_s.  T only decreases, so a pixel's
-//      termination (first entry with T(1-alpha) < 1e-4) lies in the first segment with T * P_s < 1e-4;
-//   3. if some pixel terminates in this round, wave w replays ITS segment exactly (the upstream sequential rule, from the
-//      checkpointed T) for the pixels that terminate there -- each pixel is replayed by exactly one wave -- and the
-//      finished pixels are merged through LDS.
-// Everything before a pixel's terminating segment is exact by associativity of the compositing operator (rounding differs
-// in the last bits); speculation is bounded by three segments per quadrant, no serial chain is longer than one segment
-// per round, and a deep quadrant occupies four SIMDs instead of one.
-// EXACT = false: speculative (no termination test); EXACT = true: the upstream sequential rule.  Composites list entries
-// [lo, hi) of the tile for this wave's lanes; s_* are this wave's private LDS staging arrays.
-template <bool EXACT, int G>
-__device__ __forceinline__ void composite_range(const uint32_t *__restrict__ pl, int lo, int hi, int lane, float fx, float fy,
-                                                const float2 *__restrict__ xy, const float *__restrict__ rgb,
-                                                const float *__restrict__ depth, const float4 *__restrict__ conic_opacity,
-                                                const float *__restrict__ cut2, float4 *s_xyi, float4 *s_co, float4 *s_cd,
-                                                bool &done, float &T, float &C0, float &C1, float &C2, float &Dp,
-                                                uint32_t &last, bool exact_cull = true) {
-    float bx0 = wave_min(done ? 3.0e38f : fx), bx1 = wave_max(done ? -3.0e38f : fx);
-    float by0 = wave_min(done ? 3.0e38f : fy), by1 = wave_max(done ? -3.0e38f : fy);
-    unsigned long long live = __ballot(!done);
-    const int n = hi - lo;
-    const uint32_t *p0 = pl + lo;
-    uint32_t id_cur = lane < n ? p0[lane] : 0u;
-    uint32_t id_nxt = 64 + lane < n ? p0[64 + lane] : 0u;
-    float2 c_cur = xy[id_cur];
-    float cut_cur = lane < n ? cut2[id_cur] : -1.f;
-    float4 co_cur = conic_opacity[id_cur];
-    float4 cd_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], depth[id_cur]);
-    for (int base = 0; base < n; base += 64) {
-        const bool hit = box_hit(c_cur, cut_cur, co_cur, bx0, bx1, by0, by1, exact_cull);
-        const unsigned long long mask = __ballot(hit);
-        const int nh = __popcll(mask);
-        // wave-private LDS: a wave's LDS operations execute in order, only the compiler has to be told not to move the
-        // next chunk's writes above this chunk's reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (hit) {
-            const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            s_xyi[slot] = make_float4(c_cur.x, c_cur.y, __uint_as_float((uint32_t)(lo + base + lane + 1)), 0.f);
-            s_co[slot] = co_cur;
-            s_cd[slot] = cd_cur;
-        }
-        if (lane < G) {
-            s_xyi[nh + lane] = make_float4(fx, fy, 0.f, 0.f);
-            s_co[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_cd[nh + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const int nb = base + 64;
-        const uint32_t id_n2 = nb + 64 + lane < n ? p0[nb + 64 + lane] : 0u;
-        c_cur = xy[id_nxt];
-        cut_cur = nb + lane < n ? cut2[id_nxt] : -1.f;
-        co_cur = conic_opacity[id_nxt];
-        cd_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], depth[id_nxt]);
-        id_nxt = id_n2;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int h0 = 0; h0 < nh; h0 += G) {
-            float al[G];
-            float4 cd[G];
-            uint32_t idx[G];
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                const float4 p = s_xyi[h0 + k];
-                const float4 co = s_co[h0 + k];
-                cd[k] = s_cd[h0 + k];
-                idx[k] = __float_as_uint(p.z);
-                const float dx = p.x - fx, dy = p.y - fy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                const float a = fminf(0.99f, co.w * __expf(power));
-                al[k] = (power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                const float test_T = T * (1.f - al[k]);
-                const bool contributes = al[k] > 0.f;
-                if (EXACT) done = done || (contributes && test_T < 0.0001f);
-                const bool blend = contributes && !done;
-                const float wgt = blend ? al[k] * T : 0.f;
-                C0 += cd[k].x * wgt; C1 += cd[k].y * wgt; C2 += cd[k].z * wgt; Dp += cd[k].w * wgt;
-                T = blend ? test_T : T;
-                last = blend ? idx[k] : last;
-            }
-        }
-        if (EXACT) {
-            const unsigned long long now = __ballot(!done);
-            if (now == 0ull) break;
-            if (now != live) {
-                live = now;
-                bx0 = wave_min(done ? 3.0e38f : fx); bx1 = wave_max(done ? -3.0e38f : fx);
-                by0 = wave_min(done ? 3.0e38f : fy); by1 = wave_max(done ? -3.0e38f : fy);
-            }
-        }
-    }
-}
-
-constexpr int FWD_WAVES = 4;
-constexpr int RND_GROUP = 4;   // survivors per group in the 4-wave kernel (keeps it under 128 VGPRs: 4 workgroups per CU)
-
-__global__ __launch_bounds__(256, 4) void k_render_fwd_rounds(const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                           int W, int H, int gx, const float2 *__restrict__ xy,
-                                                           const float *__restrict__ rgb, const float *__restrict__ depth,
-                                                           const float4 *__restrict__ conic_opacity,
-                                                           const float *__restrict__ cut2, const float *__restrict__ bg,
-                                                           const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
-                                                           float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                           float *__restrict__ out_color, float *__restrict__ out_depth) {
-    __shared__ float4 s_xyi[FWD_WAVES][64 + FWD_GROUP];
-    __shared__ float4 s_co[FWD_WAVES][64 + FWD_GROUP];
-    __shared__ float4 s_cd[FWD_WAVES][64 + FWD_GROUP];
-    __shared__ float4 s_resA[FWD_WAVES][64];   // P, C0, C1, C2 of the wave's segment (speculative) / replay result
-    __shared__ float2 s_resB[FWD_WAVES][64];   // D, last index + 1
-    __shared__ float4 s_finA[64];              // T, C0, C1, C2 of pixels finished by a replay
-    __shared__ float2 s_finB[64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int tile, px, py;
-    quadrant_pixel(blockIdx.x, gx, lane, tile, px, py);
-    const bool inside = px < W && py < H;
-    const int pix = py * W + px;
-    const float fx = (float)px, fy = (float)py;
-    const int2 range = ranges[tile];
-    const int n = range.y - range.x;
-    const int wq = blockIdx.x & 3;
-    bool done = !inside;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
-    if (n > 0 && __ballot(!done) != 0ull) {   // (workgroup-uniform: all four waves see the same 64 pixels)
-        const uint32_t *pl = point_list + range.x;
-        const int seg0 = seg_offset[tile];
-        const int nseg = (n + SEG - 1) / SEG;
-        for (int r0 = 0; r0 < nseg; r0 += FWD_WAVES) {
-            // ---- 1. speculative composite of this wave's segment
-            const int seg = r0 + w;
-            {
-                bool sd = done;   // lanes already finished stay out of the culling box
-                float sT = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, aD = 0.f;
-                uint32_t sl = 0;
-                if (seg < nseg && __ballot(!sd) != 0ull)
-                    composite_range<false, RND_GROUP>(pl, seg * SEG, min(n, seg * SEG + SEG), lane, fx, fy, xy, rgb, depth, conic_opacity, cut2,
-                                           s_xyi[w], s_co[w], s_cd[w], sd, sT, a0, a1, a2, aD, sl);
-                s_resA[w][lane] = make_float4(sT, a0, a1, a2);
-                s_resB[w][lane] = make_float2(aD, __uint_as_float(sl));
-            }
-            __syncthreads();
-            // ---- 2. ordered combine (every wave, redundantly, for its copy of the 64 pixels)
-            int term = -1;           // segment (0..3 within the round) holding this pixel's termination
-            float tT = T, t0 = C0, t1 = C1, t2 = C2, tD = Dp;   // state at the start of the terminating segment
-            uint32_t tl = last;
-#pragma unroll
-            for (int k = 0; k < FWD_WAVES; k++) {
-                if (r0 + k < nseg) {
-                    if (w == k) ckpt[(size_t)(seg0 + r0 + k) * 256 + wq * 64 + lane] = make_float4(T, C0, C1, C2);
-                    const float4 a = s_resA[k][lane];
-                    const float2 b = s_resB[k][lane];
-                    const float test_T = T * a.x;
-                    const bool live = !done && term < 0;
-                    if (live && test_T < 0.0001f) { term = k; tT = T; t0 = C0; t1 = C1; t2 = C2; tD = Dp; tl = last; }
-                    if (live && term < 0) {
-                        C0 += T * a.y; C1 += T * a.z; C2 += T * a.w; Dp += T * b.x;
-                        const uint32_t l = __float_as_uint(b.y);
-                        last = l ? l : last;
-                        T = test_T;
-                    }
-                }
-            }
-            const bool any_term = __syncthreads_or(term >= 0);
-            // ---- 3. exact replay of terminating segments (wave w replays segment r0 + w for the pixels that end there)
-            if (any_term) {
-                const bool mine = term == w;
-                bool rd = !mine;
-                float rT = tT, q0 = t0, q1 = t1, q2 = t2, qD = tD;
-                uint32_t rl = tl;
-                if (__ballot(mine) != 0ull) {
-                    composite_range<true, RND_GROUP>(pl, seg * SEG, min(n, seg * SEG + SEG), lane, fx, fy, xy, rgb, depth, conic_opacity, cut2,
-                                          s_xyi[w], s_co[w], s_cd[w], rd, rT, q0, q1, q2, qD, rl);
-                    if (mine) {
-                        s_finA[lane] = make_float4(rT, q0, q1, q2);
-                        s_finB[lane] = make_float2(qD, __uint_as_float(rl));
-                    }
-                }
-                __syncthreads();
-                if (term >= 0) {
-                    const float4 fa = s_finA[lane];
-                    const float2 fb = s_finB[lane];
-                    T = fa.x; C0 = fa.y; C1 = fa.z; C2 = fa.w; Dp = fb.x; last = __float_as_uint(fb.y);
-                    done = true;   // (a replay that does not hit the threshold -- a rounding tie -- still ends the pixel here)
-                }
-            }
-            if (__syncthreads_and(done)) break;
-        }
-    }
-    if (inside && w == 0) {
+    if (inside && r == 0) {
         final_T[pix] = T;
         n_contrib[pix] = last;
         const size_t HW = (size_t)H * W;
@@ -997,19 +858,14 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_rounds(const int2 *__rest
 }
 
 // ------------------------------------------------------------------------------------------- K7
+// per-Gaussian gradient accumulator filled by K7 and consumed by K8 (one 64-byte record per Gaussian):
+//   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..15 pad
+constexpr int ACC_STRIDE = 16;
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
-// sum inside each 16-lane DPP row; every lane of a row ends up holding its row's sum
-__device__ __forceinline__ float row_sum(float v) {
-    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);  // row_half_mirror
-    v = dpp_add<0x140>(v);  // row_mirror
-    return v;
-}
-
 // one level of a butterfly "transpose-reduce": lanes with s == 0 keep a (own + partner's), lanes with s == 1 keep b;
 // the partner permutation CTRL must flip s.  Two values are folded by one DPP add instead of two.
 template <int CTRL>
@@ -1018,183 +874,189 @@ __device__ __forceinline__ float bfly(float a, float b, bool s) {
     return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
 }
 
-// per-Gaussian gradient accumulator filled by K7 and consumed by K8 (one 48-byte record per Gaussian):
-//   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..11 pad
-constexpr int ACC_STRIDE = 12;
-constexpr int BWD_GROUP = 2;
-
-// Same decomposition as K6 plus a DEPTH SPLIT: one wavefront per (8x8 quadrant, SEG-entry segment of the tile list).
-// Every segment restarts from the forward pass' checkpoint at the start of the NEXT segment: T there, and the colour
-// accumulated behind it, (C_final - C_prefix) / T.  The serial chain per wave is therefore at most SEG entries long
-// whatever the depth of the list, and a deep quadrant spreads over many SIMDs.  Inside a segment: back to front,
-// 64-entry chunks (prefetched), one ballot of box-culled survivors per chunk; per survivor the 64 per-pixel partials are
-// folded with DPP row sums, lane q of every row takes value q, two cross-row exchanges finish the sum and lanes 0..8
-// issue ONE 36-byte atomic instruction into the Gaussian's record (instead of one atomic per pixel as upstream does).
-__global__ __launch_bounds__(64) void k_render_bwd(int tiles, const int2 *__restrict__ ranges,
-                                                    const uint32_t *__restrict__ point_list, const int *__restrict__ seg_offset,
-                                                    const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt, int W,
-                                                    int H, int gx, const float *__restrict__ bg, const float2 *__restrict__ xy,
-                                                    const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
-                                                    const float *__restrict__ cut2, const float *__restrict__ final_T,
-                                                    const uint32_t *__restrict__ n_contrib, const float *__restrict__ out_color,
-                                                    const float *__restrict__ dL_dpix, float *__restrict__ acc, int exact_cull) {
-    __shared__ float2 s_xy[64];
-    __shared__ float4 s_co[64];
-    __shared__ float4 s_c[64];   // rgb + Gaussian id (bit pattern) in .w
-    const int slot = blockIdx.x >> 2, wq = blockIdx.x & 3;
+// grid: one 4-wave workgroup per (segment slot, 8x8 quadrant); wave w = one 4x4 block of the quadrant.  DET: every wave
+// keeps its own LDS records and the flush stores the four-wave sums (fixed order) per (list entry, quadrant) for
+// k_det_reduce -- the bit-reproducible mode (csplat_debug_flags bit 8); default: one shared LDS record per entry,
+// flushed with float atomics.
+template <bool DET>
+__global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                        const uint32_t *__restrict__ ids_sorted,
+                                                        const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                        const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                        uint32_t null_rec, const int *__restrict__ seg_offset,
+                                                        const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
+                                                        const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                        const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
+                                                        float *__restrict__ acc, float *__restrict__ det) {
+    __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
+    __shared__ int s_any;
+    const int wg = blockIdx.x;
+    const int slot = ((wg >> 5) << 3) + (wg & 7), quad = (wg >> 3) & 3;     // the 4 quadrants of a slot share blockIdx % 8
     if (slot >= seg_offset[tiles]) return;
     const int tile = slot_tile[slot];
     const int seg = slot - seg_offset[tile];
-    const int lane = threadIdx.x;
-    int tile_, px, py;
-    quadrant_pixel(tile * 4 + wq, gx, lane, tile_, px, py);
-    const int2 range = ranges[tile];
-    const int n = range.y - range.x;
-    const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 4, l16 = lane & 15;
+    const int blk = (2 * (quad >> 1) + (w >> 1)) * 4 + 2 * (quad & 1) + (w & 1);
+    const int px = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4 + (l16 & 3);
+    const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
     const int pix = py * W + px;
     const float fx = (float)px, fy = (float)py;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    const int lane_hi = min(last_contributor, seg_hi);      // this lane replays positions [seg_lo, lane_hi)
-    const int wave_hi = (int)wave_max((float)lane_hi);
-    if (wave_hi <= seg_lo) return;
-    const bool has = lane_hi > seg_lo;
-    const float bx0 = wave_min(has ? fx : 3.0e38f), bx1 = wave_max(has ? fx : -3.0e38f);
-    const float by0 = wave_min(has ? fy : 3.0e38f), by1 = wave_max(has ? fy : -3.0e38f);
-
-    const size_t HW = (size_t)H * W;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    float T = T_final;
-    float accr0 = 0.f, accr1 = 0.f, accr2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
-    if (last_contributor > seg_hi) {
-        // contributors exist behind this segment: resume from the checkpoint at the start of the next segment
-        const float4 ck = ckpt[(size_t)(slot + 1) * 256 + wq * 64 + lane];
-        T = ck.x;
-        const float inv = 1.f / ck.x;
-        accr0 = (out_color[pix] - T_final * bg[0] - ck.y) * inv;
-        accr1 = (out_color[HW + pix] - T_final * bg[1] - ck.z) * inv;
-        accr2 = (out_color[2 * HW + pix] - T_final * bg[2] - ck.w) * inv;
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    const uint32_t rx = (uint32_t)range.x;
+    const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
+    const int ncontrib = inside ? (int)n_contrib[pix] : 0;
+    const int wave_hi = min(seg_hi, (int)wave_max((float)ncontrib));   // no pixel of the block blends an entry at or behind it
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if (wave_hi > seg_lo && lane == 0) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;                                                 // (workgroup-uniform)
+    for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
+    __syncthreads();
+    float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
+    if (wave_hi > seg_lo) {
+        const size_t HW = (size_t)H * W;
+        const float dp0 = inside ? dL_dpix[pix] : 0.f, dp1 = inside ? dL_dpix[HW + pix] : 0.f, dp2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
+        const float OD = inside ? out_color[pix] * dp0 + out_color[HW + pix] * dp1 + out_color[2 * HW + pix] * dp2 : 0.f;
+        float T = 1.f, S = 0.f;
+        if (ncontrib > seg_lo) {
+            const float4 ck = ckpt[(size_t)slot * 256 + blk * 16 + l16];
+            T = ck.x;
+            S = ck.y * dp0 + ck.z * dp1 + ck.w * dp2;
+        }
+        const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+        const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
+        // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
+        const bool red_active = !lb0 || l16 == 1;
+        const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
+        BlockWalker wk;
+        wk.start(mask16 + rx, seg_lo, wave_hi, blk, lane);
+        auto fetch = [&](Trip &t, const int (&ix)[4]) {
+            t.pos = rowsel(r, ix[0], ix[1], ix[2], ix[3]);
+            const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
+            t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+        };
+        auto process = [&](const Trip &t) {
+            const float dx = t.a.x - fx, dy = t.a.y - fy;
+            const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
+            const float G = __expf(power);
+            const float a = fminf(0.99f, t.b.y * G);
+            const bool act = t.pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
+            const float al = act ? a : 0.f;
+            const float F = 1.f - al;
+            const Row4 g = rows_allgather(F);
+            const float P1 = T * g.v0, P2 = P1 * g.v1, P3 = P2 * g.v2, P4 = P3 * g.v3;
+            const float Tr = rowsel(r, T, P1, P2, P3);
+            const float gdot = t.b.z * dp0 + t.b.w * dp1 + t.c.x * dp2;
+            const float dchannel_dcolor = al * Tr;
+            const Row4 gw = rows_allgather(gdot * dchannel_dcolor);
+            const float S1 = S + gw.v0, S2 = S1 + gw.v1, S3 = S2 + gw.v2, S4 = S3 + gw.v3;
+            const float Sr = rowsel(r, S1, S2, S3, S4);
+            T = P4; S = S4;
+            if (__ballot(act) == 0ull) return;   // wave-uniform
+            const float dL_dalpha = act ? Tr * gdot - (OD - Sr) * __builtin_amdgcn_rcpf(F) : 0.f;
+            const float dL_dG = t.b.y * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * t.a.z - gdy * t.a.w;
+            const float dG_ddely = -gdy * t.b.x - gdx * t.a.w;
+            float v[9];
+            v[0] = dL_dG * dG_ddelx * ddelx_dx;
+            v[1] = dL_dG * dG_ddely * ddely_dy;
+            v[2] = -0.5f * gdx * dx * dL_dG;
+            v[3] = -0.5f * gdx * dy * dL_dG;
+            v[4] = -0.5f * gdy * dy * dL_dG;
+            v[5] = G * dL_dalpha;
+            v[6] = dchannel_dcolor * dp0; v[7] = dchannel_dcolor * dp1; v[8] = dchannel_dcolor * dp2;
+            // 9 values x 16 lanes -> 9 totals per row: each level folds two values into one register
+            const float a0 = bfly<0x140>(v[0], v[1], lb3), a1 = bfly<0x140>(v[2], v[3], lb3);
+            const float a2 = bfly<0x140>(v[4], v[5], lb3), a3 = bfly<0x140>(v[6], v[7], lb3);
+            float l8 = dpp_add<0x140>(v[8]);
+            const float b0 = bfly<0x141>(a0, a1, lb2), b1 = bfly<0x141>(a2, a3, lb2);
+            l8 = dpp_add<0x141>(l8);
+            float c0 = bfly<0x4E>(b0, b1, lb1);
+            l8 = dpp_add<0x4E>(l8);
+            c0 = dpp_add<0xB1>(c0);
+            l8 = dpp_add<0xB1>(l8);
+            const float tot = lb0 ? l8 : c0;
+            // the row's survivor contributed to one of its 16 pixels?  (bits 16r .. 16r+15 of the ballot)
+            const unsigned long long bal = __ballot(act);
+            const bool row_any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;
+            if (red_active && row_any) {
+                float *cell = my_acc + (t.pos - seg_lo) * 9 + red_t;
+                if (DET) *cell = tot;                  // one (entry, block) pair is visited exactly once
+                else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the quadrant meet here
+            }
+        };
+        Trip ta, tb;
+        int ixa[4], ixb[4], sdummy = 0;
+        bool va = wk.next(ixa, sdummy), vb = false;
+        if (va) fetch(ta, ixa);
+        while (va) {
+            vb = wk.next(ixb, sdummy);
+            if (vb) fetch(tb, ixb);
+            process(ta);
+            if (!vb) break;
+            va = wk.next(ixa, sdummy);
+            if (va) fetch(ta, ixa);
+            process(tb);
+            vb = false;
+        }
     }
-    const float dp0 = inside ? dL_dpix[pix] : 0.f, dp1 = inside ? dL_dpix[HW + pix] : 0.f,
-                dp2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-
-    // chunk c, lane l  <->  list position pos = wave_hi-1 - (64c + l), down to seg_lo   (back to front)
-    const uint32_t *pl = point_list + range.x;
-    const int cnt = wave_hi - seg_lo;
-    static_assert(BWD_GROUP == 2, "the butterfly reduction below pairs exactly two survivors");
-    const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
-    // which total this lane owns after the reduction (see below): lanes 0..15 values 0..7, lanes 16 / 24 value 8
-    const bool red_active = lane < 16 || lane == 16 || lane == 24;
-    const int red_t = lane < 16 ? 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1) : 8;
-    auto idx_of = [&](int e) { return wave_hi - 1 - e; };
-    uint32_t id_cur = lane < cnt ? pl[idx_of(lane)] : 0u;
-    uint32_t id_nxt = 64 + lane < cnt ? pl[idx_of(64 + lane)] : 0u;
-    float2 c_cur = xy[id_cur];
-    float cut_cur = lane < cnt ? cut2[id_cur] : -1.f;
-    float4 co_cur = conic_opacity[id_cur];
-    float4 col_cur = make_float4(rgb[3 * id_cur], rgb[3 * id_cur + 1], rgb[3 * id_cur + 2], __uint_as_float(id_cur));
-    for (int base = 0; base < cnt; base += 64) {
-        __syncthreads();   // single-wave workgroup: previous chunk's LDS reads precede these writes
-        s_xy[lane] = c_cur; s_co[lane] = co_cur; s_c[lane] = col_cur;
-        const bool hit = box_hit(c_cur, cut_cur, co_cur, bx0, bx1, by0, by1, exact_cull);
-        const int nb = base + 64;
-        const uint32_t id_n2 = nb + 64 + lane < cnt ? pl[idx_of(nb + 64 + lane)] : 0u;
-        c_cur = xy[id_nxt];
-        cut_cur = nb + lane < cnt ? cut2[id_nxt] : -1.f;
-        co_cur = conic_opacity[id_nxt];
-        col_cur = make_float4(rgb[3 * id_nxt], rgb[3 * id_nxt + 1], rgb[3 * id_nxt + 2], __uint_as_float(id_nxt));
-        id_nxt = id_n2;
-        unsigned long long mask = __ballot(hit);
-        __syncthreads();
-        while (mask) {
-            int j[BWD_GROUP];
-            bool ok[BWD_GROUP];
-            float al[BWD_GROUP], Gv[BWD_GROUP], dxv[BWD_GROUP], dyv[BWD_GROUP];
-            float4 cov[BWD_GROUP], colv[BWD_GROUP];
-#pragma unroll
-            for (int k = 0; k < BWD_GROUP; k++) {
-                ok[k] = mask != 0ull;
-                j[k] = ok[k] ? (__ffsll((long long)mask) - 1) : 0;
-                mask &= mask - 1ull;
-                const float2 p = s_xy[j[k]];
-                cov[k] = s_co[j[k]];
-                colv[k] = s_c[j[k]];
-                dxv[k] = p.x - fx; dyv[k] = p.y - fy;
-                const float power = -0.5f * (cov[k].x * dxv[k] * dxv[k] + cov[k].z * dyv[k] * dyv[k]) - cov[k].y * dxv[k] * dyv[k];
-                Gv[k] = __expf(power);
-                const float a = fminf(0.99f, cov[k].w * Gv[k]);
-                const int jpos = wave_hi - 1 - (base + j[k]);
-                al[k] = (ok[k] && jpos < lane_hi && power <= 0.f && a >= 1.f / 255.f) ? a : 0.f;
-            }
-            float v[BWD_GROUP][9];
-            unsigned long long any[BWD_GROUP];
-#pragma unroll
-            for (int k = 0; k < BWD_GROUP; k++) {   // short sequential chain (T, colour behind), then the partials
-                const bool act = al[k] > 0.f;
-                any[k] = __ballot(act);
-#pragma unroll
-                for (int t = 0; t < 9; t++) v[k][t] = 0.f;
-                if (act) {
-                    const float alpha = al[k];
-                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * inv;
-                    const float dchannel_dcolor = alpha * T;
-                    const float4 c = colv[k];
-                    accr0 = last_alpha * lc0 + (1.f - last_alpha) * accr0;
-                    accr1 = last_alpha * lc1 + (1.f - last_alpha) * accr1;
-                    accr2 = last_alpha * lc2 + (1.f - last_alpha) * accr2;
-                    lc0 = c.x; lc1 = c.y; lc2 = c.z;
-                    float dL_dalpha = (c.x - accr0) * dp0 + (c.y - accr1) * dp1 + (c.z - accr2) * dp2;
-                    v[k][6] = dchannel_dcolor * dp0; v[k][7] = dchannel_dcolor * dp1; v[k][8] = dchannel_dcolor * dp2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv) * bg_dot;
-                    const float4 co = cov[k];
-                    const float dL_dG = co.w * dL_dalpha;
-                    const float gdx = Gv[k] * dxv[k], gdy = Gv[k] * dyv[k];
-                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                    const float dG_ddely = -gdy * co.z - gdx * co.y;
-                    v[k][0] = dL_dG * dG_ddelx * ddelx_dx;
-                    v[k][1] = dL_dG * dG_ddely * ddely_dy;
-                    v[k][2] = -0.5f * gdx * dxv[k] * dL_dG;
-                    v[k][3] = -0.5f * gdx * dyv[k] * dL_dG;
-                    v[k][4] = -0.5f * gdy * dyv[k] * dL_dG;
-                    v[k][5] = Gv[k] * dL_dalpha;
-                }
-            }
-            if ((any[0] | any[1]) != 0ull) {   // wave-uniform
-                // The 2 x 9 per-pixel partials of the two survivors are summed over the 64 lanes by a butterfly whose
-                // levels halve the number of live registers: row_mirror pairs the two survivors (lane bit 3 picks one),
-                // row_half_mirror / quad xor 2 / quad xor 1 pair the value indices (bits 2, 1, 0), the two gfx950 lane-swap
-                // instructions fold rows 16 and 32 apart.  18 + 9 row-level DPP adds instead of 2 x 36; afterwards lane l < 16
-                // holds the total of (survivor bit3(l), value 4*bit0 + 2*bit1 + bit2), lanes 16 and 24 value 8 of survivor
-                // 0 / 1, and ONE 18-lane atomic instruction updates both Gaussians' records.
-                float r1[9];
-#pragma unroll
-                for (int t = 0; t < 9; t++) r1[t] = bfly<0x140>(v[0][t], v[1][t], lb3);
-                const float a0 = bfly<0x141>(r1[0], r1[1], lb2), a1 = bfly<0x141>(r1[2], r1[3], lb2);
-                const float a2 = bfly<0x141>(r1[4], r1[5], lb2), a3 = bfly<0x141>(r1[6], r1[7], lb2);
-                float l8 = dpp_add<0x141>(r1[8]);
-                const float b0 = bfly<0x4E>(a0, a1, lb1), b1 = bfly<0x4E>(a2, a3, lb1);
-                l8 = dpp_add<0x4E>(l8);
-                const float c0 = bfly<0xB1>(b0, b1, lb0);
-                l8 = dpp_add<0xB1>(l8);
-                // rows: after the swap x = {c0 row0, l8 row0, c0 row2, l8 row2}, y = {c0 row1, l8 row1, c0 row3, l8 row3}
-                const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_int(c0), __float_as_int(l8), false, false);
-                const float d = __int_as_float(s16[0]) + __int_as_float(s16[1]);
-                const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_int(d), __float_as_int(d), false, false);
-                const float tot = __int_as_float(s32[0]) + __int_as_float(s32[1]);
-                const bool kk = lb3;
-                const unsigned long long mine = kk ? any[1] : any[0];
-                if (red_active && mine != 0ull) {
-                    const uint32_t gid = __float_as_uint(kk ? colv[1].w : colv[0].w);
-                    atomicAdd(acc + (size_t)gid * ACC_STRIDE + red_t, tot);
-                }
+    __syncthreads();
+    // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
+    const int cnt = seg_hi - seg_lo;
+    const int sub = lane / 9, tq = lane - sub * 9;
+    if (lane < 63) {
+        for (int e0 = w * 7; e0 < cnt; e0 += 28) {
+            const int e = e0 + sub;
+            if (e >= cnt) continue;
+            if (DET) {
+                const float s = ((s_acc[e * 9 + tq] + s_acc[SEG * 9 + e * 9 + tq]) + s_acc[2 * SEG * 9 + e * 9 + tq]) + s_acc[3 * SEG * 9 + e * 9 + tq];
+                det[((size_t)(rx + seg_lo + e) * 4 + quad) * 9 + tq] = s;
+            } else {
+                const float s = s_acc[e * 9 + tq];
+                if (s != 0.f) atomicAdd(acc + (size_t)ids_sorted[rx + seg_lo + e] * ACC_STRIDE + tq, s);
             }
         }
     }
+}
+
+// DET mode, second half: Gaussian i sums the records of its tile instances in emission order (tiles y-major, x; quadrants
+// 0..3): a fixed order, whatever the scheduling of K7.  The instance of Gaussian i in a tile's sorted list is found by
+// binary search on the unique (depth bits, id) key.
+__global__ __launch_bounds__(256) void k_det_reduce(int P, Cam cam, const float2 *__restrict__ xy, const float *__restrict__ depth,
+                                                     const int32_t *__restrict__ radii, const int2 *__restrict__ ranges,
+                                                     const uint64_t *__restrict__ keys_sorted, const uint32_t *__restrict__ ids_sorted,
+                                                     const float *__restrict__ det, float *__restrict__ acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) s[t] = 0.f;
+    const int rad = radii[i];
+    if (rad > 0) {
+        const float2 p = xy[i];
+        int minx, miny, maxx, maxy;
+        tile_rect(p.x, p.y, rad, cam, minx, miny, maxx, maxy);
+        const uint64_t want = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+        for (int y = miny; y < maxy; y++)
+            for (int x = minx; x < maxx; x++) {
+                const int2 rg = ranges[y * cam.gx + x];
+                int lo = rg.x, hi = rg.y;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint64_t k = ((keys_sorted[mid] & 0xFFFFFFFFull) << 32) | ids_sorted[mid];
+                    if (k < want) lo = mid + 1; else hi = mid;
+                }
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int t = 0; t < 9; t++) s[t] += det[((size_t)lo * 4 + q) * 9 + t];
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[(size_t)i * ACC_STRIDE + t] = s[t];
 }
 
 // ------------------------------------------------------------------------------------------- K8
@@ -1753,7 +1615,9 @@ size_t image_offsets(int W, int H, size_t *off) {
 // per-(counting workgroup, tile) table of the bucketed binning path; requested as its own TEMP-class chunk
 size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 0 ? P : 1, BUCKET_G) + 1) * tiles * 4); }
 // binning: 0 keys_sorted u64[R] | 1 ids_sorted u32[R] | 2 seg_offset i32[tiles+1] | 3 slot_tile i32[slots]
-//          | 4 ckpt float4[slots][4 quadrants][64 lanes]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
+//          | 4 ckpt float4[slots][16 blocks][16 pixels]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
+//          | 5 mask16 u16[R+1] | 6 recA float4[R+1] | 7 recB float4[R+1] | 8 recC float2[R+1]   (entry R = the null record)
+constexpr int B_NFIELDS = 9;
 size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
     const size_t slots = (size_t)max_slots(R, tiles);
@@ -1762,7 +1626,11 @@ size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     off[2] = off[1] + align256(n * 4);
     off[3] = off[2] + align256((size_t)(tiles + 1) * 4);
     off[4] = off[3] + align256(slots * 4);
-    return off[4] + align256(slots * 256 * 16);
+    off[5] = off[4] + align256(slots * 256 * 16);
+    off[6] = off[5] + align256((n + 1) * 2);
+    off[7] = off[6] + align256((n + 1) * 16);
+    off[8] = off[7] + align256((n + 1) * 16);
+    return off[8] + align256((n + 1) * 8);
 }
 // temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
 size_t temp_offsets(int64_t R, size_t *off) {
@@ -1813,7 +1681,9 @@ bool mail_init() {
     return g_mail.host != nullptr;
 }
 
-unsigned g_debug_flags = 0;   // bit 0: disable wave-level culling (test hook, csplat_debug_flags)
+// csplat_debug_flags: bit 0 no culling; bit 1 force the global radix sort; bit 2 no mailbox; bit 4 culling radius x4;
+// bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics)
+unsigned g_debug_flags = 0;
 
 int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n (upstream getHigherMsb)
     int b = 0;
@@ -1843,11 +1713,16 @@ const char *csplat_last_error(void) { return g_csplat_err; }
 
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
 size_t csplat_image_bytes(int W, int H) { size_t off[5]; return image_offsets(W, H, off); }
-size_t csplat_binning_bytes(int64_t R, int W, int H) { size_t off[5]; return binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); }
+size_t csplat_binning_bytes(int64_t R, int W, int H) { size_t off[B_NFIELDS]; return binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); }
 size_t csplat_temp_bytes(int P, int64_t R, int W, int H) { (void)P; (void)W; (void)H; size_t off[5]; return temp_offsets(R, off); }
-size_t csplat_backward_scratch_bytes(int P, int64_t R) { (void)R; return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4); }
+// backward scratch: the per-Gaussian records; in the bit-reproducible mode (csplat_debug_flags bit 8) also one 9-float record
+// per (list entry, quadrant)
+static size_t det_bytes(int64_t R) { return align256((size_t)(R > 0 ? R : 1) * 4 * 9 * 4); }
+size_t csplat_backward_scratch_bytes(int P, int64_t R) {
+    return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4) + ((g_debug_flags & 256u) ? det_bytes(R) : 0);
+}
 int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
-int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[5]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
+int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[B_NFIELDS]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
 int csplat_image_layout(int W, int H, size_t *o3) { size_t off[5]; image_offsets(W, H, off); o3[0] = off[0]; o3[1] = off[1]; o3[2] = off[2]; return 0; }
 
 // ---- two-phase forward.  begin: K1 + the counting half of the binning, everything that does not need num_rendered;
@@ -2030,13 +1905,16 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     *num_rendered = (int)R;
     void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
     CSPLAT_REQUIRE(bbase, "allocator returned NULL");
-    size_t boff[5];
+    size_t boff[B_NFIELDS];
     binning_offsets(R, tiles, boff);
     uint64_t *keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
     uint32_t *ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
     int *seg_offset = (int *)((char *)bbase + boff[2]);
     int *slot_tile = (int *)((char *)bbase + boff[3]);
     float4 *ckpt = (float4 *)((char *)bbase + boff[4]);
+    uint16_t *mask16 = (uint16_t *)((char *)bbase + boff[5]);
+    float4 *recA = (float4 *)((char *)bbase + boff[6]), *recB = (float4 *)((char *)bbase + boff[7]);
+    float2 *recC = (float2 *)((char *)bbase + boff[8]);
     if (R > 0) {
         void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
         CSPLAT_REQUIRE(tbase, "allocator returned NULL");
@@ -2087,16 +1965,17 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
         k_seg_plan<<<1, 1024, 0, s>>>(tiles, ranges, seg_offset, slot_tile);
         LAUNCH_CHECK();
     }
-    if (!(g_debug_flags & 8u)) {   // default: sequential forward (one wave walks a quadrant's whole list)
-        ProfScope ps(PROF_K6, s);
-        k_render_fwd<<<tiles * 4, 64, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity, g.cut2,
-                                              bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth,
-                                              (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
+    {
+        ProfScope ps(PROF_K5, s);
+        k_block_masks<<<cdiv((int64_t)R + 1, 256), 256, 0, s>>>((int64_t)R, cam.gx, keys_sorted, ids_sorted, g.xy, g.conic_opacity, g.rgb,
+                                                                 g.depth, g.cut2, mask16, recA, recB, recC,
+                                                                 (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
         LAUNCH_CHECK();
-    } else {   // opt-in (measured 192 us vs 172 us on scene_1): four waves per quadrant, speculative rounds
+    }
+    {
         ProfScope ps(PROF_K6, s);
-        k_render_fwd_rounds<<<tiles * 4, 256, 0, s>>>(ranges, ids_sorted, W, H, cam.gx, g.xy, g.rgb, g.depth, g.conic_opacity,
-                                                      g.cut2, bg, seg_offset, ckpt, final_T, n_contrib, out_color, out_depth);
+        k_composite_fwd<<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
+                                                            final_T, n_contrib, out_color, out_depth);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
@@ -2133,7 +2012,7 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k8, unsigned 
     make_cam(cam, view, proj, campos, tanfovx, tanfovy, W, H);
     Geom g = geom_view((void *)geom, P);
     const int tiles = cam.gx * cam.gy;
-    size_t ioff[5], boff[5];
+    size_t ioff[5], boff[B_NFIELDS];
     image_offsets(W, H, ioff);
     binning_offsets(R, tiles, boff);
     const int2 *ranges = (const int2 *)((const char *)image + ioff[0]);
@@ -2143,15 +2022,31 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k8, unsigned 
     const int *seg_offset = (const int *)((const char *)binning + boff[2]);
     const int *slot_tile = (const int *)((const char *)binning + boff[3]);
     const float4 *ckpt = (const float4 *)((const char *)binning + boff[4]);
+    const uint64_t *keys_sorted = (const uint64_t *)((const char *)binning + boff[0]);
+    const uint16_t *mask16 = (const uint16_t *)((const char *)binning + boff[5]);
+    const float4 *recA = (const float4 *)((const char *)binning + boff[6]), *recB = (const float4 *)((const char *)binning + boff[7]);
+    const float2 *recC = (const float2 *)((const char *)binning + boff[8]);
     float *acc = (float *)scratch;
-    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
-    if (R > 0) {
+    const bool det_mode = (g_debug_flags & 256u) != 0;
+    float *det = det_mode ? (float *)((char *)scratch + align256((size_t)P * ACC_STRIDE * 4)) : nullptr;
+    if (det_mode) HIP_TRY(hipMemsetAsync(det, 0, (size_t)(R > 0 ? R : 1) * 4 * 9 * 4, s));
+    else HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
+    {
         ProfScope ps(PROF_K7, s);
-        k_render_bwd<<<(unsigned)(max_slots(R, tiles) * 4), 64, 0, s>>>(tiles, ranges, ids_sorted, seg_offset, slot_tile, ckpt, W, H,
-                                                                        cam.gx, bg, g.xy, g.conic_opacity, g.rgb, g.cut2, final_T,
-                                                                        n_contrib, out_color, dL_dpix, acc,
-                                                                        (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
-        LAUNCH_CHECK();
+        if (R > 0) {
+            const unsigned grid = (unsigned)cdiv(max_slots(R, tiles), 8) * 32u;
+            if (det_mode)
+                k_composite_bwd<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
+                                                           seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+            else
+                k_composite_bwd<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
+                                                            seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+            LAUNCH_CHECK();
+        }
+        if (det_mode) {   // fixed-order sum of every Gaussian's instance records (writes all of acc)
+            k_det_reduce<<<cdiv(P, 256), 256, 0, s>>>(P, cam, g.xy, g.depth, radii, ranges, keys_sorted, ids_sorted, det, acc);
+            LAUNCH_CHECK();
+        }
     }
     if (!with_k8) return 0;   // (csplat_backward_views runs one K8 over all views afterwards)
     if (k8s != s) {

@@ -161,8 +161,12 @@ def test_wave_culling_is_exact():
                         {k: inp[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}))
     finally:
         native.lib.csplat_debug_flags(0)
-    for a, b in zip(res[0][:4], res[1][:4]):
-        np.testing.assert_array_equal(a, b)
+    # n_contrib and final_T bit for bit: the transmittance products run in list order and a skipped entry is a factor 1.0, so
+    # any entry culled although it reaches a pixel would change bits here.  Colour / depth: a pixel's sum is formed from four
+    # row-partial sums whose membership depends on which entries were skipped -> equal up to fp32 re-association.
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    assert rel_err(res[0][0], res[1][0]) < 2e-6 and rel_err(res[0][1], res[1][1]) < 2e-6
     for k in res[0][4]:
         assert rel_err(res[0][4][k], res[1][4][k]) < 1e-5, k
     # the culling bound has slack: a 4x larger radius (debug bit 4) changes nothing either
@@ -171,34 +175,9 @@ def test_wave_culling_is_exact():
         color, radii, depth, st = util.gpu_forward_raw(case)
     finally:
         native.lib.csplat_debug_flags(0)
-    np.testing.assert_array_equal(color.cpu().numpy(), res[0][0])
+    assert rel_err(color.cpu().numpy(), res[0][0]) < 2e-6
     np.testing.assert_array_equal(st["n_contrib"], res[0][2])
-
-
-@pytest.mark.parametrize("cfg", CASES)
-def test_depth_split_forward_equals_sequential_forward(cfg):
-    """the depth-split forward (csplat_debug_flags bit 3: four waves per quadrant, rounds of speculative 256-entry segments,
-    ordered combine, exact replay of terminating segments) against the default sequential one-wave-per-quadrant kernel:
-    same image up to rounding / threshold ties, and the checkpoints both hand to the depth-split backward give the same
-    gradients."""
-    from csplat import native
-    case = make_case(**cfg)
-    dpix = np.random.default_rng(11).normal(size=(3, case["H"], case["W"])).astype(np.float32)
-    res = []
-    try:
-        for flag in (0, 8):
-            native.lib.csplat_debug_flags(flag)
-            color, radii, depth, st = util.gpu_forward_raw(case)
-            inp, kw, c2, _, _ = _run_gpu(case, dpix)
-            res.append((color.cpu().numpy(), depth.cpu().numpy(), st["final_T"], st["n_contrib"],
-                        {k: inp[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}))
-    finally:
-        native.lib.csplat_debug_flags(0)
-    assert image_err(res[0][0], res[1][0]) < 1e-5 and image_err(res[0][1], res[1][1]) < 1e-5
-    assert image_err(res[0][2], res[1][2]) < 1e-5
-    assert (res[0][3] != res[1][3]).mean() < 2e-4
-    for k in res[0][4]:
-        assert rel_err(res[0][4][k], res[1][4][k]) < 5e-5, k
+    np.testing.assert_array_equal(st["final_T"], res[0][3])
 
 
 def test_empty_and_all_culled():
