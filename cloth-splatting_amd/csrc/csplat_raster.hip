@@ -161,14 +161,14 @@ __device__ __forceinline__ void stage_sh_rows(const float *__restrict__ src, int
 
 // ------------------------------------------------------------------------------------------- K1
 template <bool STAGE>
-__global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const float *__restrict__ means3D,
-                                                     const float *__restrict__ shs,
-                                                     const float *__restrict__ colors_precomp,
-                                                     const float *__restrict__ opacities,
-                                                     const float *__restrict__ scales, float scale_mod,
-                                                     const float *__restrict__ rotations,
-                                                     const float *__restrict__ cov3D_precomp, Cam cam, Geom g,
-                                                     int32_t *__restrict__ radii, int nocull) {
+__device__ __forceinline__ void preprocess_body(int P, int D, int M, const float *__restrict__ means3D,
+                                                const float *__restrict__ shs,
+                                                const float *__restrict__ colors_precomp,
+                                                const float *__restrict__ opacities,
+                                                const float *__restrict__ scales, float scale_mod,
+                                                const float *__restrict__ rotations,
+                                                const float *__restrict__ cov3D_precomp, const Cam &cam, const Geom &g,
+                                                int32_t *__restrict__ radii, int nocull) {
 #pragma clang fp contract(off)
     __shared__ float s_shrows[STAGE ? 256 * SH_ROW : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,6 +283,43 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
     g.cut2[i] = cut;
 }
 
+template <bool STAGE>
+__global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const float *__restrict__ means3D,
+                                                     const float *__restrict__ shs,
+                                                     const float *__restrict__ colors_precomp,
+                                                     const float *__restrict__ opacities,
+                                                     const float *__restrict__ scales, float scale_mod,
+                                                     const float *__restrict__ rotations,
+                                                     const float *__restrict__ cov3D_precomp, Cam cam, Geom g,
+                                                     int32_t *__restrict__ radii, int nocull) {
+    preprocess_body<STAGE>(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_mod, rotations, cov3D_precomp, cam, g, radii,
+                           nocull);
+}
+
+// The first phase of the forward (K1 + the three counting kernels) for ALL views of a step, one launch each (blockIdx.y =
+// view): a 4-view step otherwise spends 16 launches (~10 us of host time each, the GPU idling in between) before its one
+// host read.  Views share the Gaussians' view-independent inputs; means / rotations / cameras / outputs come per view.
+constexpr int K1_MAX_VIEWS = 8;
+struct K1View {
+    const float *means3D, *rotations;
+    Cam cam;
+    Geom g;
+    int32_t *radii;
+    uint32_t *table, *info, *mailbox;
+    int2 *ranges;
+    uint32_t tag;
+};
+struct K1Table { K1View v[K1_MAX_VIEWS]; };
+
+template <bool STAGE>
+__global__ __launch_bounds__(256) void k_preprocess_views(int P, int D, int M, const float *__restrict__ shs,
+                                                           const float *__restrict__ opacities,
+                                                           const float *__restrict__ scales, float scale_mod, K1Table tab,
+                                                           int nocull) {
+    const K1View &w = tab.v[blockIdx.y];
+    preprocess_body<STAGE>(P, D, M, w.means3D, shs, nullptr, opacities, scales, scale_mod, w.rotations, nullptr, w.cam, w.g, w.radii, nocull);
+}
+
 // ------------------------------------------------------------------------------------------- K3
 __global__ __launch_bounds__(256) void k_emit_keys(int P, const float2 *__restrict__ xy, const float *__restrict__ depth,
                                                     const uint32_t *__restrict__ offsets,
@@ -331,9 +368,9 @@ constexpr int BUCKET_CAP = 8192;    // longest tile list the LDS sort takes (64 
 constexpr int BUCKET_TILES = 12288; // most tiles the per-workgroup LDS histogram takes (48 KB)
 constexpr int BUCKET_G = 1024;      // Gaussians per counting workgroup
 
-__global__ __launch_bounds__(BUCKET_G) void k_tile_count(int P, int tiles, const float2 *__restrict__ xy,
-                                                          const int32_t *__restrict__ radii, Cam cam,
-                                                          uint32_t *__restrict__ table) {
+__device__ __forceinline__ void tile_count_body(int P, int tiles, const float2 *__restrict__ xy,
+                                                const int32_t *__restrict__ radii, const Cam &cam,
+                                                uint32_t *__restrict__ table) {
     extern __shared__ uint32_t s_hist[];
     for (int t = threadIdx.x; t < tiles; t += BUCKET_G) s_hist[t] = 0u;
     __syncthreads();
@@ -352,10 +389,19 @@ __global__ __launch_bounds__(BUCKET_G) void k_tile_count(int P, int tiles, const
     uint32_t *row = table + (size_t)blockIdx.x * tiles;
     for (int t = threadIdx.x; t < tiles; t += BUCKET_G) row[t] = s_hist[t];
 }
+__global__ __launch_bounds__(BUCKET_G) void k_tile_count(int P, int tiles, const float2 *__restrict__ xy,
+                                                          const int32_t *__restrict__ radii, Cam cam,
+                                                          uint32_t *__restrict__ table) {
+    tile_count_body(P, tiles, xy, radii, cam, table);
+}
+__global__ __launch_bounds__(BUCKET_G) void k_tile_count_views(int P, int tiles, K1Table tab) {
+    const K1View &w = tab.v[blockIdx.y];
+    tile_count_body(P, tiles, w.g.xy, w.radii, w.cam, w.table);
+}
 
 // per tile (one lane each, coalesced across tiles): exclusive prefix over the nb counting workgroups, in place;
 // the column total goes to cnt[tile]
-__global__ __launch_bounds__(256) void k_tile_colscan(int tiles, int nb, uint32_t *__restrict__ table, uint32_t *__restrict__ cnt) {
+__device__ __forceinline__ void tile_colscan_body(int tiles, int nb, uint32_t *__restrict__ table, uint32_t *__restrict__ cnt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= tiles) return;
     uint32_t run = 0;
@@ -370,10 +416,17 @@ __global__ __launch_bounds__(256) void k_tile_colscan(int tiles, int nb, uint32_
     for (; b < nb; b++) { const uint32_t v = table[(size_t)b * tiles + t]; table[(size_t)b * tiles + t] = run; run += v; }
     cnt[t] = run;
 }
+__global__ __launch_bounds__(256) void k_tile_colscan(int tiles, int nb, uint32_t *__restrict__ table, uint32_t *__restrict__ cnt) {
+    tile_colscan_body(tiles, nb, table, cnt);
+}
+__global__ __launch_bounds__(256) void k_tile_colscan_views(int tiles, int nb, K1Table tab) {
+    uint32_t *table = tab.v[blockIdx.y].table;
+    tile_colscan_body(tiles, nb, table, table + (size_t)nb * tiles);
+}
 
 // single workgroup: exclusive scan of the per-tile totals -> tile ranges, R, longest list
-__global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
-                                                     uint32_t *__restrict__ info, volatile uint32_t *mailbox, uint32_t tag) {
+__device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
+                                               uint32_t *__restrict__ info, volatile uint32_t *mailbox, uint32_t tag) {
     __shared__ uint32_t s_w[17];
     __shared__ uint32_t s_max[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -416,6 +469,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t *_
             mailbox[2] = tag;
         }
     }
+}
+__global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
+                                                     uint32_t *__restrict__ info, volatile uint32_t *mailbox, uint32_t tag) {
+    tile_scan_body(tiles, cnt, ranges, info, mailbox, tag);
+}
+__global__ __launch_bounds__(1024) void k_tile_scan_views(int tiles, int nb, K1Table tab) {
+    const K1View &w = tab.v[blockIdx.x];
+    tile_scan_body(tiles, w.table + (size_t)nb * tiles, w.ranges, w.info, w.mailbox, w.tag);
 }
 
 __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket(int P, int tiles, const float2 *__restrict__ xy,
@@ -721,41 +782,43 @@ __global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const ui
     recC[i] = make_float2(rgb[3 * id + 2], depth[id]);
 }
 
-// Walks the survivors of block `blk` in list positions [lo, hi) of one tile, four at a time, never across a SEG boundary.
-// Everything in here is wave-uniform (SGPRs); only the mask prefetch is a vector load.
-struct BlockWalker {
+// The survivors of block `blk` among list positions [lo, hi) of one tile, as a stream of GROUPS OF FOUR that never cross a
+// SEG boundary (incomplete groups are padded with -1).  A 64-entry chunk of masks is turned into list positions with one
+// ballot + mbcnt and appended to a small ring in LDS (wave-private); group k is ring[4k .. 4k+3], so row r of the wave reads
+// its survivor with one ds_read_b32.  All counters are wave-uniform (SGPRs); the mask of the next chunk is prefetched.
+constexpr int RING = 128;   // >= 3 groups in flight (12) + one chunk (64) + padding (3)
+struct BlockStream {
     const uint16_t *m16;     // the tile's masks (already offset by range.x)
-    unsigned long long cur;  // unconsumed survivors of the current 64-entry chunk
-    int cbase, hi, blk, lane;
-    uint32_t m_next;         // masks of the chunk after the current one (prefetched)
+    int *ring;
+    int cbase, hi, blk, lane, tail;
+    uint32_t m_next;
     __device__ __forceinline__ uint32_t load(int base) const { const int e = base + lane; return e < hi ? (uint32_t)m16[e] : 0u; }
-    __device__ __forceinline__ void start(const uint16_t *masks, int lo, int hi_, int blk_, int lane_) {
-        m16 = masks; hi = hi_; blk = blk_; lane = lane_; cbase = lo;
-        const uint32_t m0 = load(lo);
-        m_next = load(lo + 64);
-        cur = __ballot((m0 >> blk) & 1u);
+    __device__ __forceinline__ void start(const uint16_t *masks, int lo, int hi_, int blk_, int lane_, int *ring_) {
+        m16 = masks; hi = hi_; blk = blk_; lane = lane_; ring = ring_; cbase = lo; tail = 0;
+        m_next = load(lo);
     }
-    __device__ __forceinline__ void refill() {
-        cbase += 64;
-        cur = __ballot((m_next >> blk) & 1u);
+    __device__ __forceinline__ void ingest() {   // one chunk
+        const uint32_t m = m_next;
         m_next = load(cbase + 64);
+        const bool hit = (m >> blk) & 1u;
+        const unsigned long long cur = __ballot(hit);
+        if (hit) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u));
+            ring[(tail + rank) & (RING - 1)] = cbase + lane;
+        }
+        tail += (int)__popcll(cur);
+        cbase += 64;
+        if ((cbase & (SEG - 1)) == 0 || cbase >= hi) {   // the segment (or the list) ends here: complete the group
+            const int pad = (-tail) & 3;
+            if (lane < pad) ring[(tail + lane) & (RING - 1)] = -1;
+            tail += pad;
+        }
     }
-    // next group of up to four survivors (list positions, -1 = none), all inside one SEG-entry segment; false = exhausted
-    __device__ __forceinline__ bool next(int (&ix)[4], int &seg) {
-        while (cur == 0ull) {
-            if (cbase + 64 >= hi) return false;
-            refill();
-        }
-        seg = cbase / SEG;
-        const int seg_end = min(hi, (seg + 1) * SEG);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            while (cur == 0ull && cbase + 64 < seg_end) refill();
-            if (cur != 0ull) {
-                ix[k] = cbase + (int)__builtin_ctzll(cur);
-                cur &= cur - 1ull;
-            } else ix[k] = -1;
-        }
+    // list position of row r's survivor in group k (-1 = padding); false when the stream ends before group k
+    __device__ __forceinline__ bool group(int k, int r, int &pos) {
+        while (4 * k + 4 > tail && cbase < hi) ingest();
+        if (4 * k >= tail) return false;
+        pos = ring[(4 * k + r) & (RING - 1)];
         return true;
     }
 };
@@ -771,6 +834,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
                                                        const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
                                                        float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                        float *__restrict__ out_color, float *__restrict__ out_depth) {
+    __shared__ int s_ring[RING];
     const int wg = blockIdx.x;
     const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
     if (tile >= tiles) return;
@@ -788,15 +852,17 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
     uint32_t last = 0;
     if (n > 0 && __ballot(!done) != 0ull) {
         const int seg0 = seg_offset[tile];
-        BlockWalker wk;
-        wk.start(mask16 + rx, 0, n, blk, lane);
+        BlockStream st;
+        st.start(mask16 + rx, 0, n, blk, lane, s_ring);
         int seg_written = -1;
-        auto fetch = [&](Trip &t, const int (&ix)[4]) {
-            t.pos = rowsel(r, ix[0], ix[1], ix[2], ix[3]);
+        auto fetch = [&](Trip &t, int k) -> bool {
+            if (!st.group(k, r, t.pos)) return false;
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
             t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+            return true;
         };
-        auto process = [&](const Trip &t, int seg) {
+        auto process = [&](const Trip &t) {
+            const int seg = __builtin_amdgcn_readfirstlane(t.pos) / SEG;   // (a group's first entry is never padding)
             if (seg != seg_written) {
                 // entering a new 256-entry segment: checkpoint (T, colour so far) for the depth-split backward, for every
                 // segment start passed since the last one (segments without a survivor of this block get the same state)
@@ -823,23 +889,23 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
             T = P4 >= T_EPS ? P4 : (P3 >= T_EPS ? P3 : (P2 >= T_EPS ? P2 : (P1 >= T_EPS ? P1 : T)));
             done = done || !(P4 >= T_EPS);
         };
-        // software pipeline, two groups in flight: the records of group k+1 are requested before group k is composited
-        Trip ta, tb;
-        int ixa[4], ixb[4], sa = 0, sb = 0;
-        bool va = wk.next(ixa, sa), vb = false;
-        if (va) fetch(ta, ixa);
+        // software pipeline, three groups in flight: the records of group k+3 are requested when group k has been composited
+        Trip ta, tb, tc;
+        bool va = fetch(ta, 0), vb = fetch(tb, 1), vc = fetch(tc, 2);
+        int k = 3;
         while (va) {
-            vb = wk.next(ixb, sb);
-            if (vb) fetch(tb, ixb);
-            process(ta, sa);
-            if (__ballot(!done) == 0ull || !vb) break;
-            va = wk.next(ixa, sa);
-            if (va) fetch(ta, ixa);
-            process(tb, sb);
-            vb = false;
+            process(ta);
             if (__ballot(!done) == 0ull) break;
+            va = fetch(ta, k++);
+            if (!vb) break;
+            process(tb);
+            if (__ballot(!done) == 0ull) break;
+            vb = fetch(tb, k++);
+            if (!vc) break;
+            process(tc);
+            if (__ballot(!done) == 0ull) break;
+            vc = fetch(tc, k++);
         }
-        if (vb && __ballot(!done) != 0ull) process(tb, sb);
     }
     C0 = rows_sum(C0); C1 = rows_sum(C1); C2 = rows_sum(C2); Dp = rows_sum(Dp);
     {
@@ -889,6 +955,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, 
                                                         const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
                                                         float *__restrict__ acc, float *__restrict__ det) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
+    __shared__ int s_ring[4][RING];
     __shared__ int s_any;
     const int wg = blockIdx.x;
     const int slot = ((wg >> 5) << 3) + (wg & 7), quad = (wg >> 3) & 3;     // the 4 quadrants of a slot share blockIdx % 8
@@ -931,12 +998,13 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, 
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
         const bool red_active = !lb0 || l16 == 1;
         const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
-        BlockWalker wk;
-        wk.start(mask16 + rx, seg_lo, wave_hi, blk, lane);
-        auto fetch = [&](Trip &t, const int (&ix)[4]) {
-            t.pos = rowsel(r, ix[0], ix[1], ix[2], ix[3]);
+        BlockStream st;
+        st.start(mask16 + rx, seg_lo, wave_hi, blk, lane, s_ring[w]);
+        auto fetch = [&](Trip &t, int k) -> bool {
+            if (!st.group(k, r, t.pos)) return false;
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
             t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+            return true;
         };
         auto process = [&](const Trip &t) {
             const float dx = t.a.x - fx, dy = t.a.y - fy;
@@ -989,19 +1057,18 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, 
                 else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the quadrant meet here
             }
         };
-        Trip ta, tb;
-        int ixa[4], ixb[4], sdummy = 0;
-        bool va = wk.next(ixa, sdummy), vb = false;
-        if (va) fetch(ta, ixa);
+        Trip ta, tb, tc;
+        bool va = fetch(ta, 0), vb = fetch(tb, 1), vc = fetch(tc, 2);
+        int k = 3;
         while (va) {
-            vb = wk.next(ixb, sdummy);
-            if (vb) fetch(tb, ixb);
             process(ta);
+            va = fetch(ta, k++);
             if (!vb) break;
-            va = wk.next(ixa, sdummy);
-            if (va) fetch(ta, ixa);
             process(tb);
-            vb = false;
+            vb = fetch(tb, k++);
+            if (!vc) break;
+            process(tc);
+            vc = fetch(tc, k++);
         }
     }
     __syncthreads();
@@ -1670,7 +1737,7 @@ bool mail_init() {
     if (!g_mail.tried) {
         g_mail.tried = true;
         void *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(&h, MAIL_SLOTS * MAIL_WORDS * 4, hipHostMallocMapped) == hipSuccess &&
+        if (hipHostMalloc(&h, MAIL_SLOTS * MAIL_WORDS * 4, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
             hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
             memset(h, 0, MAIL_SLOTS * MAIL_WORDS * 4);
             g_mail.host = (volatile uint32_t *)h;
@@ -1746,12 +1813,18 @@ struct FwdTicket {
     int32_t *radii = nullptr;
     csplat_alloc_fn alloc = nullptr;
     void *alloc_ctx = nullptr;
+    uint32_t *mb_dev = nullptr;
+    int D = 0, M = 0;
+    float scale_modifier = 1.f;
+    const float *means3D = nullptr, *shs = nullptr, *colors_precomp = nullptr, *opacities = nullptr, *scales = nullptr, *rotations = nullptr,
+                *cov3D_precomp = nullptr;
 };
 constexpr int MAX_TICKETS = 64;
 static FwdTicket g_tickets[MAX_TICKETS];
 static std::mutex g_ticket_mu;
 
-int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+// allocation + bookkeeping of a forward: nothing is launched
+static int begin_prepare(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
                          const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
                          float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
                          const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
@@ -1772,63 +1845,15 @@ int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int
     void *gbase = alloc(alloc_ctx, CSPLAT_CHUNK_GEOM, csplat_geom_bytes(P));
     void *ibase = alloc(alloc_ctx, CSPLAT_CHUNK_IMAGE, csplat_image_bytes(W, H));
     CSPLAT_REQUIRE(gbase && ibase, "allocator returned NULL");
-    Geom g = geom_view(gbase, P);
     size_t ioff[5];
     image_offsets(W, H, ioff);
-    int2 *ranges = (int2 *)((char *)ibase + ioff[0]);
-    uint32_t *n_contrib = (uint32_t *)((char *)ibase + ioff[1]);
-    float *final_T = (float *)((char *)ibase + ioff[2]);
-    uint32_t *info = (uint32_t *)((char *)ibase + ioff[3]);
     const int tiles = cam.gx * cam.gy;
-    const int nb = cdiv(P > 0 ? P : 1, BUCKET_G);
     const bool can_bucket = tiles <= BUCKET_TILES && !(g_debug_flags & 2u);
-
-    if (!can_bucket) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, s));
-    if (P > 0) {
-        ProfScope ps(PROF_K1, s);
-        const bool stage = shs != nullptr && M == 16 && ((uintptr_t)shs & 15u) == 0;
-        if (stage)
-            k_preprocess<true><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
-                                                             scale_modifier, rotations, cov3D_precomp, cam, g, radii,
-                                                             (int)((g_debug_flags & 1u) ? 1 : ((g_debug_flags & 16u) ? 2 : 0)));
-        else
-            k_preprocess<false><<<cdiv(P, 256), 256, 0, s>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
-                                                              scale_modifier, rotations, cov3D_precomp, cam, g, radii,
-                                                              (int)((g_debug_flags & 1u) ? 1 : ((g_debug_flags & 16u) ? 2 : 0)));
-        LAUNCH_CHECK();
-    }
     uint32_t *table = nullptr;
-    bool use_mail_ = false;
-    uint32_t tag_ = 0;
-    volatile uint32_t *mb_host_ = nullptr;
     if (can_bucket) {
         table = (uint32_t *)alloc(alloc_ctx, CSPLAT_CHUNK_TABLE, bucket_table_bytes(P, tiles));
         CSPLAT_REQUIRE(table, "allocator returned NULL");
-        ProfScope ps(PROF_K2, s);
-        if (P > 0) {
-            k_tile_count<<<nb, BUCKET_G, (size_t)tiles * 4, s>>>(P, tiles, g.xy, radii, cam, table);
-            LAUNCH_CHECK();
-        } else {
-            HIP_TRY(hipMemsetAsync(table, 0, (size_t)nb * tiles * 4, s));
-        }
-        uint32_t *tile_cnt = table + (size_t)nb * tiles;   // last row of the chunk: per-tile totals
-        k_tile_colscan<<<cdiv(tiles, 256), 256, 0, s>>>(tiles, nb, table, tile_cnt);
-        LAUNCH_CHECK();
-        const bool use_mail = !(g_debug_flags & 4u) && mail_init();
-        uint32_t tag = 0;
-        volatile uint32_t *mb_host = nullptr;
-        uint32_t *mb_dev = nullptr;
-        if (use_mail) {
-            tag = g_mail.next.fetch_add(1);
-            if (tag == 0) tag = g_mail.next.fetch_add(1);
-            const int slot = (int)(tag % MAIL_SLOTS);
-            mb_host = g_mail.host + slot * MAIL_WORDS;
-            mb_dev = g_mail.dev + slot * MAIL_WORDS;
-        }
-        k_tile_scan<<<1, 1024, 0, s>>>(tiles, tile_cnt, ranges, info, mb_dev, tag);
-        LAUNCH_CHECK();
-        use_mail_ = use_mail; tag_ = tag; mb_host_ = mb_host;
-    }   // can_bucket
+    }
     int tk = -1;
     {
         std::lock_guard<std::mutex> lk(g_ticket_mu);
@@ -1838,12 +1863,125 @@ int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int
     }
     CSPLAT_REQUIRE(tk >= 0, "csplat_forward_begin: more than 64 forwards begun and not finished");
     FwdTicket &t = g_tickets[tk];
-    t.s = s; t.P = P; t.W = W; t.H = H; t.tiles = tiles; t.nb = nb; t.can_bucket = can_bucket; t.use_mail = use_mail_;
-    t.tag = tag_; t.mb_host = mb_host_; t.cam = cam; t.g = g; t.gbase = gbase; t.ibase = ibase; t.ranges = ranges;
-    t.n_contrib = n_contrib; t.info = info; t.table = table; t.final_T = final_T; t.bg = bg; t.radii = radii;
-    t.alloc = alloc; t.alloc_ctx = alloc_ctx;
+    t.s = s; t.P = P; t.W = W; t.H = H; t.tiles = tiles; t.nb = cdiv(P > 0 ? P : 1, BUCKET_G); t.can_bucket = can_bucket;
+    t.use_mail = false; t.tag = 0; t.mb_host = nullptr; t.mb_dev = nullptr;
+    if (can_bucket && !(g_debug_flags & 4u) && mail_init()) {
+        t.use_mail = true;
+        t.tag = g_mail.next.fetch_add(1);
+        if (t.tag == 0) t.tag = g_mail.next.fetch_add(1);
+        const int slot = (int)(t.tag % MAIL_SLOTS);
+        t.mb_host = g_mail.host + slot * MAIL_WORDS;
+        t.mb_dev = g_mail.dev + slot * MAIL_WORDS;
+    }
+    t.cam = cam; t.g = geom_view(gbase, P); t.gbase = gbase; t.ibase = ibase;
+    t.ranges = (int2 *)((char *)ibase + ioff[0]);
+    t.n_contrib = (uint32_t *)((char *)ibase + ioff[1]);
+    t.final_T = (float *)((char *)ibase + ioff[2]);
+    t.info = (uint32_t *)((char *)ibase + ioff[3]);
+    t.table = table; t.bg = bg; t.radii = radii; t.alloc = alloc; t.alloc_ctx = alloc_ctx;
+    t.D = D; t.M = M; t.means3D = means3D; t.shs = shs; t.colors_precomp = colors_precomp; t.opacities = opacities; t.scales = scales;
+    t.scale_modifier = scale_modifier; t.rotations = rotations; t.cov3D_precomp = cov3D_precomp;
     *ticket_out = tk;
     return 0;
+}
+
+static int nocull_mode() { return (int)((g_debug_flags & 1u) ? 1 : ((g_debug_flags & 16u) ? 2 : 0)); }
+
+// K1 + the counting half of the binning of ONE view, on its stream
+static int begin_launch(const FwdTicket &t) {
+    hipStream_t s = t.s;
+    const int P = t.P, tiles = t.tiles, nb = t.nb;
+    if (!t.can_bucket) HIP_TRY(hipMemsetAsync(t.ranges, 0, (size_t)tiles * 8, s));
+    if (P > 0) {
+        ProfScope ps(PROF_K1, s);
+        const bool stage = t.shs != nullptr && t.M == 16 && ((uintptr_t)t.shs & 15u) == 0;
+        if (stage)
+            k_preprocess<true><<<cdiv(P, 256), 256, 0, s>>>(P, t.D, t.M, t.means3D, t.shs, t.colors_precomp, t.opacities, t.scales,
+                                                             t.scale_modifier, t.rotations, t.cov3D_precomp, t.cam, t.g, t.radii, nocull_mode());
+        else
+            k_preprocess<false><<<cdiv(P, 256), 256, 0, s>>>(P, t.D, t.M, t.means3D, t.shs, t.colors_precomp, t.opacities, t.scales,
+                                                              t.scale_modifier, t.rotations, t.cov3D_precomp, t.cam, t.g, t.radii, nocull_mode());
+        LAUNCH_CHECK();
+    }
+    if (t.can_bucket) {
+        ProfScope ps(PROF_K2, s);
+        if (P > 0) {
+            k_tile_count<<<nb, BUCKET_G, (size_t)tiles * 4, s>>>(P, tiles, t.g.xy, t.radii, t.cam, t.table);
+            LAUNCH_CHECK();
+        } else {
+            HIP_TRY(hipMemsetAsync(t.table, 0, (size_t)nb * tiles * 4, s));
+        }
+        uint32_t *tile_cnt = t.table + (size_t)nb * tiles;   // last row of the chunk: per-tile totals
+        k_tile_colscan<<<cdiv(tiles, 256), 256, 0, s>>>(tiles, nb, t.table, tile_cnt);
+        LAUNCH_CHECK();
+        k_tile_scan<<<1, 1024, 0, s>>>(tiles, tile_cnt, t.ranges, t.info, t.mb_dev, t.tag);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// the same for V views that share the Gaussians (P, SH, opacities, scales; own means / rotations / cameras): four launches on
+// `join` in all, then every view's stream waits for them.  false = the views do not qualify (the caller launches per view).
+static bool begin_views_compatible(int V, const int *tk) {
+    if (V < 2 || V > K1_MAX_VIEWS || (g_debug_flags & 512u)) return false;
+    const FwdTicket &a = g_tickets[tk[0]];
+    if (a.P <= 0 || !a.can_bucket || !a.shs || a.colors_precomp || a.cov3D_precomp || !a.scales || !a.rotations) return false;
+    for (int i = 1; i < V; i++) {
+        const FwdTicket &w = g_tickets[tk[i]];
+        if (w.P != a.P || w.D != a.D || w.M != a.M || w.W != a.W || w.H != a.H || w.shs != a.shs || w.opacities != a.opacities ||
+            w.scales != a.scales || w.scale_modifier != a.scale_modifier || w.colors_precomp || w.cov3D_precomp || !w.rotations ||
+            !w.can_bucket)
+            return false;
+    }
+    return true;
+}
+static int begin_launch_views(int V, const int *tk, hipStream_t join) {
+    const FwdTicket &a = g_tickets[tk[0]];
+    const int P = a.P, tiles = a.tiles, nb = a.nb;
+    K1Table tab;
+    for (int i = 0; i < V; i++) {
+        const FwdTicket &t = g_tickets[tk[i]];
+        K1View &k = tab.v[i];
+        k.means3D = t.means3D; k.rotations = t.rotations; k.cam = t.cam; k.g = t.g; k.radii = t.radii; k.table = t.table;
+        k.info = t.info; k.mailbox = t.mb_dev; k.ranges = t.ranges; k.tag = t.tag;
+    }
+    {
+        ProfScope ps(PROF_K1, join);
+        const bool stage = a.M == 16 && ((uintptr_t)a.shs & 15u) == 0;
+        if (stage)
+            k_preprocess_views<true><<<dim3(cdiv(P, 256), V), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
+                                                                              nocull_mode());
+        else
+            k_preprocess_views<false><<<dim3(cdiv(P, 256), V), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
+                                                                               nocull_mode());
+        LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(PROF_K2, join);
+        k_tile_count_views<<<dim3(nb, V), BUCKET_G, (size_t)tiles * 4, join>>>(P, tiles, tab);
+        LAUNCH_CHECK();
+        k_tile_colscan_views<<<dim3(cdiv(tiles, 256), V), 256, 0, join>>>(tiles, nb, tab);
+        LAUNCH_CHECK();
+        k_tile_scan_views<<<V, 1024, 0, join>>>(tiles, nb, tab);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                         const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                         float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *view,
+                         const float *proj, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                         csplat_alloc_fn alloc, void *alloc_ctx, int32_t *radii, int *ticket_out) {
+    if (int rc = begin_prepare(stream, P, D, M, bg, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                               cov3D_precomp, view, proj, campos, tanfovx, tanfovy, prefiltered, alloc, alloc_ctx, radii, ticket_out))
+        return rc;
+    const int rc = begin_launch(g_tickets[*ticket_out]);
+    if (rc) {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        g_tickets[*ticket_out].used = false;
+    }
+    return rc;
 }
 
 int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *num_rendered, void **geom_out,
@@ -2116,23 +2254,38 @@ static int fence_out(int V, const csplat_view *v, hipStream_t join) {
 
 int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream) {
     CSPLAT_REQUIRE(V >= 0 && V <= MAX_TICKETS && (V == 0 || v != nullptr), "csplat_forward_views: bad view count");
-    if (int rc = fence_in(V, v, (hipStream_t)join_stream)) return rc;
+    hipStream_t join = (hipStream_t)join_stream;
     int tickets[MAX_TICKETS];
     int rc = 0, begun = 0;
-    for (; begun < V && rc == 0; begun++) {
+    for (; begun < V; begun++) {
         csplat_view &w = v[begun];
-        rc = csplat_forward_begin(w.stream, w.P, w.D, w.M, w.bg, w.W, w.H, w.means3D, w.shs, w.colors_precomp, w.opacities, w.scales,
-                                  w.scale_modifier, w.rotations, w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy,
-                                  w.prefiltered, alloc, w.alloc_ctx, w.radii, &tickets[begun]);
+        rc = begin_prepare(w.stream, w.P, w.D, w.M, w.bg, w.W, w.H, w.means3D, w.shs, w.colors_precomp, w.opacities, w.scales,
+                           w.scale_modifier, w.rotations, w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy,
+                           w.prefiltered, alloc, w.alloc_ctx, w.radii, &tickets[begun]);
         if (rc) break;
     }
-    for (int i = 0; i < begun; i++) {   // every begun ticket is finished (= released) even after an error
-        csplat_view &w = v[i];
-        const int r2 = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
-        if (rc == 0) rc = r2;
+    bool fenced = false;
+    if (rc == 0 && begin_views_compatible(V, tickets)) {
+        // first phase of all views in four launches on the join stream, THEN the views' streams branch off
+        rc = begin_launch_views(V, tickets, join);
+        if (rc == 0) { rc = fence_in(V, v, join); fenced = rc == 0; }
+    } else if (rc == 0) {
+        rc = fence_in(V, v, join);
+        fenced = rc == 0;
+        for (int i = 0; i < V && rc == 0; i++) rc = begin_launch(g_tickets[tickets[i]]);
     }
-    if (rc) return rc;
-    return fence_out(V, v, (hipStream_t)join_stream);
+    for (int i = 0; i < begun; i++) {   // every prepared ticket is finished (= released) even after an error
+        csplat_view &w = v[i];
+        if (rc == 0) rc = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
+        else {
+            std::lock_guard<std::mutex> lk(g_ticket_mu);
+            g_tickets[tickets[i]].used = false;
+        }
+    }
+    // (also on the error path: the side streams may hold work on torch-owned chunks that the caller frees on its own stream as
+    // soon as the error propagates)
+    if (fenced) { const int r2 = fence_out(V, v, join); if (rc == 0) rc = r2; }
+    return rc;
 }
 
 // Can ONE K8 serve all views?  Same Gaussians (P, D, M, scale modifier, SH and scale tensors), SH staging applicable, and every
@@ -2200,29 +2353,35 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     for (int i = 0; i < V; i++) shared |= v[i].accmask != 0u;
     K8Table tab;
     const bool one_k8 = shared && k8_views_table(V, v, tab);
-    for (int i = 0; i < V; i++) {
-        const csplat_view &w = v[i];
-        if (int rc = backward_impl((hipStream_t)w.stream, shared ? join : (hipStream_t)w.stream, !one_k8, w.accmask, w.P, w.D, w.M,
-                                   w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
-                                   w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.radii, w.geom, w.binning,
-                                   w.image, w.out_color, w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic, w.dL_dopacity,
-                                   w.dL_dcolor, w.dL_dmean3D, w.dL_dcov3D, w.dL_dsh, w.dL_dscale, w.dL_drot))
-            return rc;
-    }
-    if (one_k8) {   // every view's K7 is queued on its own stream: the join stream waits for all of them, then ONE K8
+    // from here on side streams may hold work on caller-owned buffers: whatever fails, the exit fence is still issued
+    auto body = [&]() -> int {
         for (int i = 0; i < V; i++) {
-            if ((hipStream_t)v[i].stream == join) continue;
-            hipEvent_t ev = pooled_event();
-            CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
-            HIP_TRY(hipEventRecord(ev, (hipStream_t)v[i].stream));
-            HIP_TRY(hipStreamWaitEvent(join, ev, 0));
+            const csplat_view &w = v[i];
+            if (int rc = backward_impl((hipStream_t)w.stream, shared ? join : (hipStream_t)w.stream, !one_k8, w.accmask, w.P, w.D, w.M,
+                                       w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
+                                       w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.radii, w.geom, w.binning,
+                                       w.image, w.out_color, w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic, w.dL_dopacity,
+                                       w.dL_dcolor, w.dL_dmean3D, w.dL_dcov3D, w.dL_dsh, w.dL_dscale, w.dL_drot))
+                return rc;
         }
-        ProfScope ps(PROF_K8, join);
-        const csplat_view &a = v[0];
-        k_preprocess_bwd_views<128><<<cdiv(a.P, 128), 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab);
-        LAUNCH_CHECK();
-    }
-    return fence_out(V, v, join);
+        if (one_k8) {   // every view's K7 is queued on its own stream: the join stream waits for all of them, then ONE K8
+            for (int i = 0; i < V; i++) {
+                if ((hipStream_t)v[i].stream == join) continue;
+                hipEvent_t ev = pooled_event();
+                CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
+                HIP_TRY(hipEventRecord(ev, (hipStream_t)v[i].stream));
+                HIP_TRY(hipStreamWaitEvent(join, ev, 0));
+            }
+            ProfScope ps(PROF_K8, join);
+            const csplat_view &a = v[0];
+            k_preprocess_bwd_views<128><<<cdiv(a.P, 128), 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab);
+            LAUNCH_CHECK();
+        }
+        return 0;
+    };
+    const int rc = body();
+    const int r2 = fence_out(V, v, join);
+    return rc ? rc : r2;
 }
 
 }  // extern "C"
