@@ -180,6 +180,29 @@ def test_wave_culling_is_exact():
     np.testing.assert_array_equal(st["final_T"], res[0][3])
 
 
+def test_bit_reproducible_backward_mode():
+    """csplat_debug_flags bit 8: K7 keeps one record per (list entry, quadrant) and every Gaussian sums its records in emission
+    order (k_det_reduce) instead of meeting in float atomics -- two runs give the same bits in EVERY gradient, and the values
+    agree with the default (atomic) mode to rounding.  (the deterministic mode for tests.)"""
+    from csplat import native
+    case = make_case(P=3000, W=200, H=136, seed=8, grid=16, scale_mul=2.5)
+    dpix = np.random.default_rng(21).normal(size=(3, case["H"], case["W"])).astype(np.float32)
+    names = ("means3D", "means2D", "opacities", "shs", "scales", "rotations")
+    runs = []
+    try:
+        for flag in (256, 256, 0):
+            native.lib.csplat_debug_flags(flag)
+            inp, kw, color, _, _ = _run_gpu(case, dpix)
+            runs.append({k: inp[k].grad.cpu().numpy() for k in names})
+    finally:
+        native.lib.csplat_debug_flags(0)
+    for k in names:
+        np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)
+        assert rel_err(runs[0][k], runs[2][k]) < 1e-5, k
+    g64 = util.ro.backward(oracle_forward(case, dtype=np.float64), dpix)
+    assert rel_err(runs[0]["means3D"], g64.mean3D) < TOL and rel_err(runs[0]["shs"], g64.sh) < TOL
+
+
 def test_empty_and_all_culled():
     import diff_gaussian_rasterization as dgr
     case = make_case(P=64, W=48, H=32, seed=14, grid=6)
