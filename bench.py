@@ -4,11 +4,15 @@ backward, P = 100k Gaussians, 4 cameras 800x800 per GPU (BASELINE.json configs[1
 
 A "step" = one pass of the hot path over one batch: for each of the rank's 4 views, GaussianRasterizer forward
 (K1..K6), L1 loss against a fixed target image, backward (K7, K8); with N > 1 ranks (view-parallel, one process per
-GPU) the step ends with ONE RCCL all-reduce of the flat per-Gaussian gradient buffer.
-All inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+GPU) the step ends with ONE RCCL all-reduce of the flat per-Gaussian gradient buffer the `.grad` tensors are views of
+(csplat.dist.FlatGrads).  All inputs are resident in HBM before the timed region.  Prints ONE JSON line on
+rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+--mode scenes (BASELINE configs[4], scene-parallel): six seeded scene variants, scene s on rank s mod N, no collective
+(replicas only); `value` = all scenes' rendered Mpix over the slowest rank's time, "scaling": "strong".
 """
 import argparse
 import contextlib
@@ -44,6 +48,8 @@ def cpu_baseline(scene, cams, P, W, H):
     dt = time.perf_counter() - t0
     return {"value": round(len(cams) * W * H / 1e6 / dt, 4), "unit": "Mpix/s", "cores": int(ro.num_threads()),
             "kind": "port",
+            "what": "C/OpenMP restatement of the upstream algorithm (oracle/raster_ref.c); the reference ships no CPU rasterizer "
+                    "and no PyTorch-CPU path exists for this operator (SURVEY F2)",
             "sample": f"one full step: {len(cams)} views {W}x{H}, P={P}, fwd+bwd through oracle/raster_ref.c "
                       f"(OpenMP, fp32), {dt:.2f} s"}
 
@@ -61,13 +67,16 @@ def main():
                     help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
+    ap.add_argument("--mode", choices=("views", "scenes"), default="views",
+                    help="views: view-parallel weak scaling (default, the BASELINE metric); scenes: 6 scene variants dealt over the ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 ranks as\n  python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus {args.gpus} ...")
     # (CSPLAT_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box: ranks then share the device)
     backend = os.environ.get("CSPLAT_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
@@ -85,63 +94,87 @@ def main():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
     P, W, H, V = args.P, args.res, args.res, args.views
-    scene = syn.scene_1(P=P, W=W, H=H, n_cams=V)
-    # view-parallel: rank r renders its own 4 cameras (azimuth offset), Gaussians replicated
-    cams = [syn.make_camera(-180.0 + 360.0 * (k + rank / max(world, 1)) / V, W, H) for k in range(V)]
-    g = syn.gaussians_at(scene)
-    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)  # noqa: E731
-    params = {k: T(g[k], True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-    bg = T(scene["bg"])
-    settings = [GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
-        viewmatrix=T(c["world_view_transform"]), projmatrix=T(c["full_proj_transform"]), sh_degree=3,
-        campos=T(c["camera_center"]), prefiltered=False, debug=False) for c in cams]
-
-    def render(i, means2D):
-        return GaussianRasterizer(settings[i])(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
-                                               shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
-
-    # target images = render of a perturbed copy (so the loss and its gradient are non-trivial)
-    with torch.no_grad():
-        keep = {k: v.detach().clone() for k, v in params.items()}
-        gen = torch.Generator(device=dev).manual_seed(1234)
-        params["shs"].add_(0.2 * torch.randn(params["shs"].shape, device=dev, generator=gen))
-        params["means3D"].add_(0.003 * torch.randn(params["means3D"].shape, device=dev, generator=gen))
-        targets = [render(i, torch.zeros(P, 3, device=dev))[0].clone() for i in range(V)]
-        for k, v in keep.items():
-            params[k].copy_(v)
-
-    targets_stacked = torch.stack(targets).contiguous()
-    flat_names = ("means3D", "opacities", "shs", "scales", "rotations")
-    R_per_view = [0] * V
-
-    # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views: every view's
-    # csplat_forward_begin is issued before the first csplat_forward_finish): the compositing kernels of one view leave
-    # most SIMDs idle (their critical path is the deepest 8x8 quadrant), so the views' kernels overlap on the chip
-    from diff_gaussian_rasterization import rasterize_views
+    from csplat import dist as cd
     from csplat.train import l1_loss
+    from diff_gaussian_rasterization import rasterize_views
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)  # noqa: E731
+
+    class Workload:
+        """one scene replica: Gaussians, V cameras, target images, and step() = fwd + L1 + bwd (+ the all-reduce)"""
+
+        def __init__(self, seed, cam_phase, reduce_over_ranks):
+            self.scene = syn.scene_1(P=P, W=W, H=H, n_cams=V, seed=seed)
+            # view-parallel: rank r renders its own V cameras (azimuth offset), Gaussians replicated
+            self.cams = [syn.make_camera(-180.0 + 360.0 * (k + cam_phase) / V, W, H) for k in range(V)]
+            g = syn.gaussians_at(self.scene)
+            self.names = ("means3D", "opacities", "shs", "scales", "rotations")
+            self.params = {k: T(g[k], True) for k in self.names}
+            bg = T(self.scene["bg"])
+            self.settings = [GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+                viewmatrix=T(c["world_view_transform"]), projmatrix=T(c["full_proj_transform"]), sh_degree=3,
+                campos=T(c["camera_center"]), prefiltered=False, debug=False) for c in self.cams]
+            # target images = render of a perturbed copy (so the loss and its gradient are non-trivial)
+            with torch.no_grad():
+                keep = {k: v.detach().clone() for k, v in self.params.items()}
+                gen = torch.Generator(device=dev).manual_seed(1234)
+                self.params["shs"].add_(0.2 * torch.randn(self.params["shs"].shape, device=dev, generator=gen))
+                self.params["means3D"].add_(0.003 * torch.randn(self.params["means3D"].shape, device=dev, generator=gen))
+                self.targets = [self.render(i, torch.zeros(P, 3, device=dev))[0].clone() for i in range(V)]
+                for k, v in keep.items():
+                    self.params[k].copy_(v)
+            self.targets_stacked = torch.stack(self.targets).contiguous()
+            # N > 1: every gradient of the step is a view into ONE flat buffer (+ 3P floats for the summed screen-space
+            # gradient that densification consumes) and the step ends with one all-reduce of it -- no cat, no copy back
+            self.fg = cd.FlatGrads([self.params[k] for k in self.names], extra=3 * P) if reduce_over_ranks else None
+
+        def render(self, i, means2D):
+            pr = self.params
+            return GaussianRasterizer(self.settings[i])(means3D=pr["means3D"], means2D=means2D, opacities=pr["opacities"],
+                                                        shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
+
+        def step(self, timed_allreduce=False):
+            pr = self.params
+            if self.fg is not None:
+                self.fg.bind()
+            else:
+                for p_ in pr.values():
+                    p_.grad = None
+            zeros = torch.zeros(V, P, 3, device=dev)                           # ONE fill; V leaves that share its storage
+            m2ds = [zeros[i].detach().requires_grad_() for i in range(V)]
+            # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views): the first phase of
+            # all views goes out in four launches, then every view's binning / compositing kernels overlap on the chip
+            if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
+                colors, _ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
+                                                                 shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
+                                                            for i in range(V)], stacked=True)
+                # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285); x V = the sum of the
+                # per-view means that the camera-by-camera branch below forms
+                loss = l1_loss(colors, self.targets_stacked) * float(V)
+            else:
+                outs = [self.render(i, m2ds[i]) for i in range(V)]
+                loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).sum()
+            loss.backward()         # the batched node fans the views' K7/K8 out over the same per-view streams
+            if self.fg is not None:
+                with torch.no_grad():
+                    torch.sum(torch.stack([m.grad for m in m2ds]), dim=0, out=self.fg.tail.view(P, 3))
+                self.fg.all_reduce(timed=timed_allreduce)
+            return loss
+
+    scene_mode = args.mode == "scenes"
+    if scene_mode:      # BASELINE configs[4]: six seeded scene variants, scene s on rank s mod N, no data-path collective
+        n_scenes = 6
+        loads = [Workload(6666 + 17 * s_, 0.0, False) for s_ in range(n_scenes) if s_ % world == rank]
+    else:
+        n_scenes = world
+        loads = [Workload(syn.SEED, rank / max(world, 1), world > 1)]
+    wl = loads[0] if loads else None
 
     def step():
-        for p in params.values():
-            p.grad = None
-        m2ds = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in range(V)]
-        if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
-            colors, _ = rasterize_views(settings, [dict(means3D=params["means3D"], means2D=m2ds[i], opacities=params["opacities"],
-                                                        shs=params["shs"], scales=params["scales"],
-                                                        rotations=params["rotations"]) for i in range(V)], stacked=True)
-            # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285); x V = the sum of the
-            # per-view means that the camera-by-camera branch below forms
-            return_loss = l1_loss(colors, targets_stacked) * float(V)
-        else:
-            outs = [render(i, m2ds[i]) for i in range(V)]
-            return_loss = torch.stack([l1_loss(outs[i][0], targets[i]) for i in range(V)]).sum()
-        loss = return_loss
-        loss.backward()         # the batched node fans the views' K7/K8 out over the same per-view streams
-        m2d_grads = [m.grad for m in m2ds]
-        if world > 1:
-            flat = torch.cat([params[k].grad.reshape(P, -1) for k in flat_names] + [sum(m2d_grads)], dim=1)
-            dist.all_reduce(flat)
-        return loss
+        out_ = None
+        for w_ in loads:
+            out_ = w_.step()
+        return out_
 
     def sync():
         if world > 1:
@@ -156,7 +189,6 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    # R (tile instances) per view for the algorithmic-byte count; constant across steps (same inputs)
     import diff_gaussian_rasterization as dgr
     sync()
     if not os.environ.get("CSPLAT_BENCH_NOEVENTS"):
@@ -184,7 +216,7 @@ def main():
     # K7 launched ALONE (views back to back on one stream; untimed, supplementary): the kernel-level reading of the
     # roofline next to the contract's in-step figure, where the views' K7 overlap and each launch lasts longer
     k7_alone_us = None
-    if args.view_streams and V > 1:
+    if args.view_streams and V > 1 and wl is not None:
         args.view_streams = False
         step(); torch.cuda.synchronize()
         native.prof_enable(["K7_render_bwd"]); native.prof_read("K7_render_bwd")
@@ -193,19 +225,32 @@ def main():
         native.prof_enable([])
         args.view_streams = True
         k7_alone_us = ms_a / max(n_a, 1) * 1e3
-    with torch.no_grad():
-        for i in range(V):
-            ctx = type("C", (), {"save_for_backward": lambda s, *a: None, "mark_non_differentiable": lambda s, *a: None})()
-            dgr._RasterizeGaussians.forward(ctx, params["means3D"], None, params["shs"], None, params["opacities"],
-                                            params["scales"], params["rotations"], None, settings[i])
-            R_per_view[i] = ctx.view_state.num_rendered
+    # the collective on its own (untimed extra passes, bracketed by device synchronisation): bytes, ranks, wall time
+    collective = None
+    if world > 1 and not scene_mode:
+        ar = []
+        for _ in range(5):
+            wl.step(timed_allreduce=True)
+            ar.append(wl.fg.last_allreduce_ms)
+        collective = {"backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
+                      "bytes": int(wl.fg.flat.numel() * 4), "allreduce_ms": round(float(np.median(ar)), 4),
+                      "what": "one all-reduce(sum) per step over the flat gradient buffer (62 floats per Gaussian + 3 for the "
+                              "screen-space gradient); timed alone, after the step's kernels have drained"}
+    R_per_view = [0] * V
+    if wl is not None:
+        with torch.no_grad():
+            for i in range(V):
+                ctx = type("C", (), {"save_for_backward": lambda s, *a: None, "mark_non_differentiable": lambda s, *a: None})()
+                dgr._RasterizeGaussians.forward(ctx, wl.params["means3D"], None, wl.params["shs"], None, wl.params["opacities"],
+                                                wl.params["scales"], wl.params["rotations"], None, wl.settings[i])
+                R_per_view[i] = ctx.view_state.num_rendered
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    mpix = world * V * W * H / 1e6
+    mpix = n_scenes * V * W * H / 1e6
     value = mpix / (dt / args.steps)
 
     # roofline of the dominant kernel named by BASELINE.json north_star: compositing backward (K7).
@@ -215,7 +260,8 @@ def main():
     alg_bytes = float(np.mean([84.0 * r + 24.0 * X for r in R_per_view]))
     k7_avg_s = (k7_ms / max(k7_n, 1)) * 1e-3
     achieved = alg_bytes / k7_avg_s / 1e9 if k7_avg_s > 0 else 0.0
-    traffic = None
+    # committed counter passes of the same workload (tools/collect_profiles.sh): HBM traffic and VALU instruction count of K7
+    traffic = valu_insts = None
     import glob
     tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k7_pmc_traffic.json")))   # newest round's PMC passes
     if tpaths:
@@ -223,30 +269,46 @@ def main():
             traffic = json.load(open(tpaths[-1])).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    ipaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k67_issue.json")))
+    if ipaths:
+        try:
+            valu_insts = json.load(open(ipaths[-1]))["kernels"]["k_composite_bwd"]["SQ_INSTS_VALU"]
+        except Exception:
+            valu_insts = None
+    SIMDS, CLOCK_GHZ = 1024, 2.4         # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 4 cycles
+    issue = lambda us: None if not (valu_insts and us) else round(valu_insts * 4.0 / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
     out = {
         "metric": "rasterizer fwd+bwd rendered Mpix/s (scene_1, 800x800)", "value": round(value, 3), "unit": "Mpix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"scene_1 synthetic, P={P} Gaussians, {V} cams {W}x{H} per GPU, SH degree 3, "
-                               "fwd (K1-K6) + L1 + bwd (K7-K8)" + (", + RCCL all-reduce of flat grads" if world > 1 else ""),
-                   "tile_instances_per_view": R_per_view, "parallelism": f"view-parallel x{world}",
+        "higher_is_better": True, "scaling": "strong" if scene_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"6 seeded scene_1 variants dealt over {world} rank(s), " if scene_mode else "scene_1 synthetic, ") +
+                               f"P={P} Gaussians, {V} cams {W}x{H} per " + ("scene" if scene_mode else "GPU") + ", SH degree 3, "
+                               "fwd (K1-K6) + L1 + bwd (K7-K8)" +
+                               (", + ONE RCCL all-reduce of the flat gradient buffer" if world > 1 and not scene_mode else ""),
+                   "tile_instances_per_view": R_per_view,
+                   "parallelism": (f"scene-parallel x{world} (replicas only)" if scene_mode else f"view-parallel x{world}"),
                    "streams_per_gpu": V if args.view_streams else 1},
-        "roofline": {"bound": "hbm", "kernel": "k_render_bwd (K7 compositing backward)", "achieved": round(achieved, 3),
+        "roofline": {"bound": "hbm", "kernel": "k_composite_bwd (K7 compositing backward)", "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
                      "launches_timed": int(k7_n),
+                     "issue_frac": issue(k7_avg_s * 1e6),
+                     "issue_note": "VALU wave-instructions of one launch (SQ_INSTS_VALU, committed profiles/*_k67_issue.json) x 4 cycles / "
+                                   "(1024 SIMDs x 2.4 GHz x this launch duration): the share of the chip's vector issue slots the kernel "
+                                   "used -- the bound that actually binds this kernel (sort / composite arithmetic, no MFMA)",
                      "alone": None if not k7_alone_us else {
                          "avg_launch_us": round(k7_alone_us, 2), "achieved": round(alg_bytes / (k7_alone_us * 1e-6) / 1e9, 3),
-                         "frac": round(alg_bytes / (k7_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                         "frac": round(alg_bytes / (k7_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6), "issue_frac": issue(k7_alone_us),
                          "what": "same kernel, views back to back on one stream (untimed extra pass)"},
                      "note": (f"the {V} views' K7 launches of a step run CONCURRENTLY on {V} streams: each launch lasts "
                               "longer than alone (see 'alone') while the step gets shorter; achieved/frac follow the contract "
                               "(bytes of ONE launch / its own duration)") if args.view_streams and V > 1 else None},
         "kernel_us": breakdown,
+        "collective": collective,
     }
     # the first half of BASELINE.json's metric ("train-step ms"): BASELINE configs[2], measured by bench_train.py (untimed
     # here, its own timed region; 1 GPU only).  Auxiliary field -- `value` stays the rasterizer fwd+bwd throughput.
-    if rank == 0 and world == 1 and not args.no_train_step and (P, W, V) == (100_000, 800, 4):
+    if rank == 0 and world == 1 and not scene_mode and not args.no_train_step and (P, W, V) == (100_000, 800, 4):
         try:
             import bench_train
             from types import SimpleNamespace as _NS
@@ -256,7 +318,7 @@ def main():
         except Exception as e:      # never let the auxiliary leg take the headline line down
             out["train_step"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scene, cams, P, W, H)
+        out["cpu_baseline"] = cpu_baseline(wl.scene, wl.cams, P, W, H)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

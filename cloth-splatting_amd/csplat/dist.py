@@ -2,13 +2,16 @@
 over xGMI on the GPU box, "gloo" in the CPU tests).  The reference is single-GPU; this is the new
 capability described in SURVEY.md 5.8 / 8(e):
 
-  * Gaussians, mesh and simulator are replicated; the cameras of a step are sharded round-robin over ranks;
-  * after backward ONE all-reduce(sum) runs over a single flat fp32 buffer holding every parameter gradient
-    (240 B per Gaussian + simulator grads -- xGMI is point-to-point, a single large message per step is the
-    per-link-friendly shape; no bucketing is needed at 24-55 MB);
+  * Gaussians, mesh and simulator are replicated; the cameras of a step are dealt round-robin over the ranks;
+  * the gradients of ALL parameters live in ONE persistent flat fp32 buffer (FlatGrads): every `p.grad` is a view into it, so
+    autograd accumulates straight into the buffer and the step's single all-reduce(sum) needs no gather / scatter copies
+    (240 B per Gaussian + simulator gradients + a small tail for the step's scalars and the screen-space statistics --
+    xGMI is point-to-point, one large message per step is the per-link-friendly shape; no bucketing is needed at 24-55 MB);
   * densification statistics are reduced with the operator that keeps replicas bit-identical:
-    screen-space gradient norm accum -> sum, denom -> sum, max_radii2D -> max, visibility -> max (logical or).
+    screen-space gradient (part of the flat buffer) -> sum, max_radii2D -> max (visibility = radius > 0).
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -17,17 +20,88 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def world_rank():
+    return (dist.get_world_size(), dist.get_rank()) if is_dist() else (1, 0)
+
+
+def shard_indices(n, rank=None, world=None):
+    """indices i < n with i mod world == rank; ranks beyond n get an empty list and still join the collectives."""
+    w, r = world_rank()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    return [i for i in range(n) if i % world == rank]
+
+
 def shard_views(views, rank=None, world=None):
-    """views i with i mod world == rank."""
-    if rank is None:
-        rank = dist.get_rank() if is_dist() else 0
-    if world is None:
-        world = dist.get_world_size() if is_dist() else 1
-    return [v for i, v in enumerate(views) if i % world == rank]
+    views = list(views)
+    return [views[i] for i in shard_indices(len(views), rank, world)]
+
+
+class FlatGrads:
+    """One flat fp32 buffer whose slices ARE the `.grad` tensors of `params` (+ `extra` trailing floats for whatever else has
+    to be summed over ranks in the same message).  bind() zeroes the buffer and (re-)attaches the views -- call it before
+    backward(), because `optimizer.zero_grad(set_to_none=True)` detaches them; autograd then accumulates in place.
+    Rebuilt by the owner when the parameter set changes shape (densification)."""
+
+    def __init__(self, params, extra=0):
+        self.params = [p for p in params]
+        assert self.params, "FlatGrads: no parameters"
+        dev = self.params[0].device
+        assert all(p.device == dev and p.dtype == self.params[0].dtype for p in self.params), "FlatGrads: mixed devices / dtypes"
+        self.shapes = [tuple(p.shape) for p in self.params]
+        self.sizes = [p.numel() for p in self.params]
+        self.n_param = sum(self.sizes)
+        self.extra = int(extra)
+        self.flat = torch.zeros(self.n_param + self.extra, dtype=self.params[0].dtype, device=dev)
+        self.views, o = [], 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[o:o + n].view(p.shape))
+            o += n
+        self.tail = self.flat[self.n_param:]
+        self.last_allreduce_ms = 0.0
+
+    def matches(self, params, extra=0):
+        params = list(params)
+        return len(params) == len(self.params) and int(extra) == self.extra and \
+            all(a is b and tuple(a.shape) == s for a, b, s in zip(params, self.params, self.shapes))
+
+    def bind(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def all_reduce(self, group=None, timed=False):
+        """sum over ranks, in place.  timed=True brackets the collective with device synchronisation and records its wall time
+        (bench.py's `allreduce_ms`); the default leaves it asynchronous with respect to the host."""
+        if not is_dist():
+            return self.flat
+        if timed and self.flat.is_cuda:
+            torch.cuda.synchronize(self.flat.device)
+            t0 = time.perf_counter()
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(self.flat.device)
+            self.last_allreduce_ms = (time.perf_counter() - t0) * 1e3
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        return self.flat
+
+
+def flat_grads_for(owner, params, extra=0):
+    """the FlatGrads cached on `owner` for exactly these parameter objects (rebuilt when they were replaced or resized)"""
+    params = list(params)
+    fg = owner.__dict__.get("_flat_grads") if hasattr(owner, "__dict__") else None
+    if fg is None or not fg.matches(params, extra):
+        fg = FlatGrads(params, extra)
+        try:
+            owner._flat_grads = fg
+        except Exception:
+            pass
+    return fg
 
 
 def allreduce_flat(tensors, op=None, group=None):
-    """All-reduce a list of same-dtype tensors as ONE flat buffer, in place.  Returns the flat buffer."""
+    """All-reduce a list of same-dtype tensors as ONE flat buffer, in place (copying variant for ad-hoc tensor lists; the
+    training step uses FlatGrads, which needs no copies).  Returns the flat buffer."""
     tensors = [t for t in tensors if t is not None]
     if not tensors:
         return None
@@ -56,6 +130,13 @@ def allreduce_gradients(params, group=None):
             p.grad = torch.zeros_like(p)
         grads.append(p.grad)
     return allreduce_flat(grads, group=group)
+
+
+def reduce_max_radii(radii, group=None):
+    """train_utils.py:276-277: the largest screen radius of every Gaussian over the step's cameras -> max over ranks."""
+    if is_dist():
+        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
+    return radii
 
 
 def reduce_densification_stats(viewspace_grad, radii, visibility, group=None):

@@ -121,7 +121,7 @@ class MeshGaussians(DensifyMixin):
         self.edge_norm = (pos[edge_index[1]] - pos[edge_index[0]]).norm(dim=-1, keepdim=True)
         self.face_ids = face_ids
         self.face_bary = nn.Parameter(bary.clone().requires_grad_(True))
-        self.face_offset = nn.Parameter(torch.zeros(bary.shape[0], 1, device=bary.device).requires_grad_(True))
+        self.face_offset = nn.Parameter(torch.zeros(bary.shape[0], 1, device=bary.device, dtype=bary.dtype).requires_grad_(True))
         self._features_dc = nn.Parameter(sh[:, 0:1].contiguous().clone().requires_grad_(True))
         self._features_rest = nn.Parameter(sh[:, 1:].contiguous().clone().requires_grad_(True))
         self._scaling = nn.Parameter(log_scales.clone().requires_grad_(True))

@@ -356,57 +356,97 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True)
 
 
 def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT,
-               background=None, static=False, view_parallel=False, batched_views=True, densify_opt=None):
+               background=None, static=False, view_parallel=False, batched_views=True, densify_opt=None, time_allreduce=False):
     """One optimisation step.  Returns (psnr, loss, stats) where stats holds what densification consumes.
-    view_parallel=True shards `viewpoint_cams` over the ranks of the default process group and all-reduces the
-    gradients / statistics (csplat/dist.py); with one rank it is the reference's single-GPU step.
     batched_views=True renders the step's cameras in one rasterizer call (gaussian_renderer.render_views).
     densify_opt: OptimizationParams-like namespace (+ cameras_extent, white_background) -> the reference's densification /
-    pruning / opacity-reset schedule runs between backward and the optimizer step (csplat/densify.py)."""
+    pruning / opacity-reset schedule runs between backward and the optimizer step (csplat/densify.py).
+
+    view_parallel=True with more than one rank in the default process group reproduces the SINGLE-GPU step on the full camera
+    list (train_utils.py:240-321) with the cameras dealt round-robin over the ranks (csplat/dist.py):
+      * the simulator and the cloth regularisers run on ALL cameras on every rank -- the regularisers couple the (t-1, t, t+1)
+        triple, which a shard would break -- and enter the local loss with weight 1/world;
+      * the image loss is a mean over all images: the local mean enters with weight n_local / n_total; a rank without a camera
+        contributes zero but joins the collectives;
+      * every parameter gradient, the screen-space gradient sum, the PSNR and the loss value travel in ONE all-reduce(sum) of
+        the persistent flat buffer the `.grad` tensors are views of; the radii take one all-reduce(max).
+    After the reduction every rank holds exactly the gradients and statistics of the one-rank step (up to summation order)
+    and takes the same optimizer / densification decisions, so the replicas stay identical without exchanging parameters."""
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
-    cams = cd.shard_views(viewpoint_cams) if view_parallel else list(viewpoint_cams)
-    images, gts, radii_l, vis_l, vsp_l, verts = [], [], [], [], [], []
-    masks = [] if cams and getattr(cams[0], "mask", None) is not None else None          # train_utils.py:256
-    stacked = None
-    reg = None
-    if batched_views:
-        deforms = None
-        if not static and cams and hasattr(simulator, "forward_times"):
-            # simulator for all cameras at once, and the regularisers recorded BEFORE the rasterizer: autograd runs
-            # later-recorded nodes first, so the rasterizer's backward -- the long GPU work of the step -- is launched
-            # first and the small launches of everything else are issued under it
-            deforms = simulator.forward_times([cam.time for cam in cams])
-            reg = regularization(deforms, gaussians, opt, static)
+    all_cams = list(viewpoint_cams)
+    n_total = len(all_cams)
+    world, rank = cd.world_rank() if view_parallel else (1, 0)
+    dist_mode = world > 1
+    idx = cd.shard_indices(n_total, rank, world) if dist_mode else list(range(n_total))
+    cams = [all_cams[i] for i in idx]
+    P = int(gaussians.num_gaussians)
+    fg = None
+    if dist_mode:
+        fg = cd.flat_grads_for(gaussians, list(gaussians.parameters()) + list(simulator.parameters()), extra=3 * P + 2)
+        fg.bind()
+    images, gts, radii_l, vsp_l, verts = [], [], [], [], []
+    masks = [] if all_cams and getattr(all_cams[0], "mask", None) is not None else None          # train_utils.py:256
+    stacked = reg = deforms = None
+    if not static and all_cams and (dist_mode or (batched_views and hasattr(simulator, "forward_times"))):
+        # simulator for all cameras at once, and the regularisers recorded BEFORE the rasterizer: autograd runs
+        # later-recorded nodes first, so the rasterizer's backward -- the long GPU work of the step -- is launched
+        # first and the small launches of everything else are issued under it
+        if hasattr(simulator, "forward_times"):
+            deforms_all = simulator.forward_times([cam.time for cam in all_cams])
+        else:
+            nv, dev0 = gaussians.mesh.pos.shape[0], gaussians.mesh.pos.device
+            deforms_all = torch.stack([simulator(time_vector=torch.tensor(cam.time).to(dev0).repeat(nv, 1)) for cam in all_cams])
+        reg = regularization(deforms_all, gaussians, opt, static)
+        deforms = deforms_all if not dist_mode else (deforms_all[idx] if idx else None)
+    if dist_mode or batched_views:
         pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True,
-                                     vertice_deforms=deforms)
+                                     vertice_deforms=deforms) if cams else ([], None)
     else:
         pkgs = [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
     for cam, pkg in zip(cams, pkgs):
         images.append(pkg.render.unsqueeze(0))
         gts.append(cam.original_image.to(pkg.render.device).unsqueeze(0))
         radii_l.append(pkg.radii.unsqueeze(0))
-        vis_l.append(pkg.visibility_filter.unsqueeze(0))
         vsp_l.append(pkg.viewspace_points)
         if masks is not None:
             masks.append(cam.mask.to(pkg.render.device).unsqueeze(0))                      # train_utils.py:273-274
         verts.append(pkg.vertice_deform[None])
-    all_vertice_deform = torch.cat(verts, 0) if reg is None else None
-    radii = torch.cat(radii_l, 0).max(dim=0).values
-    visibility_filter = radii > 0            # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
-    image_tensor = stacked if stacked is not None else torch.cat(images, 0)
-    gt_image_tensor = torch.cat(gts, 0)
-    mask_tensor = torch.cat(masks, 0) if masks is not None else None
-    psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
+    dev = gaussians.face_bary.device
+    if cams:
+        radii = torch.cat(radii_l, 0).max(dim=0).values
+        image_tensor = stacked if stacked is not None else torch.cat(images, 0)
+        gt_image_tensor = torch.cat(gts, 0)
+        mask_tensor = torch.cat(masks, 0) if masks is not None else None
+        psnr_sum = psnr(image_tensor, gt_image_tensor).sum().double()
+        image_loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor)
+        if len(cams) != n_total:
+            image_loss = image_loss * (len(cams) / n_total)
+    else:   # a rank without a camera of this step
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        psnr_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        image_loss = torch.zeros((), dtype=gaussians.face_bary.dtype, device=dev)
     if reg is None:
-        reg = regularization(all_vertice_deform, gaussians, opt, static)
-    loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor) + reg
-    loss.backward()
-    viewspace_grad = torch.stack([v.grad for v in vsp_l]).sum(0) if len(vsp_l) > 1 else vsp_l[0].grad.clone()
+        reg = regularization(torch.cat(verts, 0), gaussians, opt, static) if verts else torch.zeros((), device=dev)
+    loss = image_loss + (reg / world if dist_mode else reg)
+    if loss.requires_grad:
+        loss.backward()
+    if vsp_l:
+        viewspace_grad = torch.stack([v.grad for v in vsp_l]).sum(0) if len(vsp_l) > 1 else vsp_l[0].grad.clone()
+    else:
+        viewspace_grad = torch.zeros(P, 3, dtype=gaussians.face_bary.dtype, device=dev)
+    psnr_ = psnr_sum / max(n_total, 1)
+    loss_value = loss.detach()
     with torch.no_grad():
-        if view_parallel and cd.is_dist():
-            cd.allreduce_gradients(list(gaussians.parameters()) + list(simulator.parameters()))
-            viewspace_grad, radii, visibility_filter = cd.reduce_densification_stats(viewspace_grad, radii, visibility_filter)
+        if dist_mode:
+            fg.tail[:3 * P].copy_(viewspace_grad.reshape(-1))
+            fg.tail[3 * P] = psnr_.to(fg.tail.dtype)
+            fg.tail[3 * P + 1] = loss_value.to(fg.tail.dtype)
+            fg.all_reduce(timed=time_allreduce)
+            viewspace_grad = fg.tail[:3 * P].view(P, 3).clone()
+            psnr_, loss_value = fg.tail[3 * P].double(), fg.tail[3 * P + 1].clone()
+            radii = cd.reduce_max_radii(radii.contiguous())
+        visibility_filter = radii > 0            # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
         if densify_opt is not None and iteration < densify_opt.densify_until_iter:      # train_utils.py:295-304
             densification(gaussians, iteration, visibility_filter, radii, viewspace_grad, densify_opt,
                           getattr(densify_opt, "cameras_extent", 1.0))
@@ -420,4 +460,5 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             meshnet_optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
         meshnet_optimizer.zero_grad()
-    return psnr_, loss.detach(), dict(viewspace_grad=viewspace_grad, radii=radii, visibility_filter=visibility_filter)
+    return psnr_, loss_value, dict(viewspace_grad=viewspace_grad, radii=radii, visibility_filter=visibility_filter,
+                                   allreduce_ms=fg.last_allreduce_ms if fg is not None else 0.0)

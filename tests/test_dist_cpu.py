@@ -62,3 +62,81 @@ def test_single_process_is_identity():
     p = torch.nn.Parameter(torch.ones(4)); (p * 2).sum().backward()
     cd.allreduce_gradients([p])
     np.testing.assert_allclose(p.grad.numpy(), 2.0)
+
+
+# ---- a REAL train step on two ranks (VERDICT r1 item 6 / ADVICE: view_parallel must reproduce the single-process step) ----------
+def _scene_and_models(n_cams, with_masks):
+    import bench_train as bt
+    from csplat import synthetic as syn
+    from csplat.gaussians import MeshGaussians
+    from meshnet.meshnet_network import ResidualMeshSimulator
+    P, W, H = 300, 32, 32
+    sc = syn.scene_1(P=P, W=W, H=H, n_cams=1, grid=6, n_times=4, seed=31)
+    sc["log_scales"] = sc["log_scales"] + np.log(8.0)
+    dt = torch.float64
+    T = lambda a, d=dt: torch.tensor(a, dtype=d)  # noqa: E731
+    pc = MeshGaussians(3).from_arrays(T(sc["mesh_pos"][0]), T(sc["faces"].T.copy(), torch.long), T(sc["edge_index"], torch.long),
+                                      T(sc["face_ids"], torch.long), T(sc["bary"]), T(sc["log_scales"]), T(sc["quats"]),
+                                      T(sc["opacity_logits"]), T(sc["sh"]))
+    pc.active_sh_degree, pc.fused = 3, False
+    torch.manual_seed(123)                       # (nn.Linear draws its initial weights from the global generator)
+    sim = ResidualMeshSimulator(T(sc["mesh_pos"]), device="cpu").double()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        sim.output.weight.copy_(torch.randn(sim.output.weight.shape, generator=g, dtype=dt) * 1e-3)
+    times = [1 / 3, 2 / 3, 1.0][:n_cams]
+    targets = [torch.rand(3, H, W, generator=g, dtype=dt) for _ in times]
+    cams = bt.cameras(sc, times, "cpu", targets)
+    for c in cams:
+        c.world_view_transform, c.full_proj_transform, c.camera_center = (x.double() for x in (c.world_view_transform, c.full_proj_transform,
+                                                                                                 c.camera_center))
+        c.mask = (torch.rand(1, H, W, generator=g) > 0.3).double() if with_masks else None
+    pc.training_setup()
+    pc.densification_setup()
+    mopt = torch.optim.Adam(sim.parameters(), lr=3e-4)
+    return pc, sim, mopt, cams
+
+
+def _run_steps(view_parallel, n_cams, with_masks, steps=2):
+    from csplat import train as tr
+    tr.render_views = util.oracle_render_views          # the rasterizer stand-in for CPU tensors (tests only)
+    pc, sim, mopt, cams = _scene_and_models(n_cams, with_masks)
+    bg = torch.ones(3, dtype=torch.float64)
+    out = {}
+    for it in range(1, steps + 1):
+        ps, loss, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, view_parallel=view_parallel)
+        out[f"psnr{it}"], out[f"loss{it}"] = float(ps), float(loss)
+        out[f"vsg{it}"], out[f"radii{it}"] = stats["viewspace_grad"].numpy().copy(), stats["radii"].numpy().copy()
+    for i, p in enumerate(list(pc.parameters()) + list(sim.parameters())):
+        out[f"p{i}"] = p.detach().numpy().copy()
+    return out
+
+
+def _step_worker(rank, world, port, out_dir, n_cams, with_masks):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (os.path.join(util.ROOT, "cloth-splatting_amd"), util.ROOT):
+        sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), **_run_steps(True, n_cams, with_masks))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cams,with_masks", [(3, False), (3, True), (1, False)])
+def test_view_parallel_train_step_equals_single_process_step(tmp_path, n_cams, with_masks):
+    """two ranks (cameras 0,2 | 1; or one camera and an EMPTY rank), two optimisation steps of csplat.train.train_step with the
+    oracle as the rasterizer: parameters, Adam trajectories, screen-space gradient sums, radii, PSNR and loss equal the
+    one-process step on the full camera list (fp64; only the order of the sums over cameras differs), and the two replicas are
+    bit-identical."""
+    import torch.multiprocessing as mp
+    port = 29500 + ((os.getpid() * 7 + n_cams * 3 + int(with_masks)) % 2000)
+    mp.spawn(_step_worker, args=(2, port, str(tmp_path), n_cams, with_masks), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
+    ref = _run_steps(False, n_cams, with_masks)
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)                     # replicas identical
+        a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
+        assert np.abs(a - b).max() <= 1e-9 * (np.abs(b).max() + 1e-30) + 1e-12, (k, np.abs(a - b).max())

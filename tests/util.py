@@ -125,3 +125,53 @@ def gpu_forward_raw(case, inputs=None, settings=None, **over):
     state = gpu_chunks(vs.chunks, case["P"], case["W"], case["H"], vs.num_rendered)
     state["R"] = vs.num_rendered
     return color, radii, depth, state
+
+
+# ---------------------------------------------------------------- CPU stand-in for the rasterizer (oracle-backed, tests only)
+def oracle_raster_function():
+    """torch.autograd.Function over oracle/raster_ref.c (fp64 build): forward AND analytic backward, incl. the NDC-space
+    gradient of means2D.  Lets the host logic around the rasterizer (train_step, view-parallel sharding) run on CPU tensors in
+    the world_size-2 gloo tests; the product has no CPU path."""
+    import torch
+
+    class OracleRaster(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, opacity, shs, scales, rots, cam, bg_np, sh_degree):
+            n = lambda t: t.detach().numpy()  # noqa: E731
+            H, W = int(cam.image_height), int(cam.image_width)
+            o = ro.forward(n(means3D), n(opacity), n(cam.world_view_transform), n(cam.full_proj_transform), n(cam.camera_center),
+                           np.tan(cam.FoVx * 0.5), np.tan(cam.FoVy * 0.5), W, H, bg_np, shs=n(shs), sh_degree=sh_degree,
+                           scales=n(scales), rotations=n(rots), dtype=np.float64)
+            ctx.o = o
+            radii = torch.from_numpy(o.radii.copy())
+            ctx.mark_non_differentiable(radii)
+            return torch.from_numpy(o.color.copy()), radii
+
+        @staticmethod
+        def backward(ctx, g_color, _g_radii):
+            g = ro.backward(ctx.o, g_color.contiguous().numpy())
+            t = torch.from_numpy
+            return t(g.mean3D), t(g.mean2D), t(g.opacity).reshape(-1, 1), t(g.sh), t(g.scale), t(g.rot), None, None, None
+    return OracleRaster
+
+
+def oracle_render_views(cams, pc, sim, pipe, bg, render_static=False, return_stacked=True, vertice_deforms=None):
+    """gaussian_renderer.render_views on CPU fp64 tensors through the oracle (same return convention)."""
+    import torch
+    from types import SimpleNamespace
+    F = oracle_raster_function()
+    bg_np = np.asarray(bg.detach().numpy(), np.float64)
+    res = []
+    for i, cam in enumerate(cams):
+        if render_static:
+            verts = pc.mesh.pos
+        elif vertice_deforms is not None:
+            verts = vertice_deforms[i]
+        else:
+            verts = sim(time_vector=torch.tensor(cam.time, dtype=pc.mesh.pos.dtype).repeat(pc.mesh.pos.shape[0], 1))
+        xyz = pc.get_xyz(verts if not render_static else None)
+        rots = pc.get_rotation(verts if not render_static else None)
+        m2d = torch.zeros(xyz.shape[0], 3, dtype=xyz.dtype, requires_grad=True)
+        color, radii = F.apply(xyz, m2d, pc.get_opacity, pc.get_features, pc.get_scaling, rots, cam, bg_np, pc.active_sh_degree)
+        res.append(SimpleNamespace(render=color, radii=radii, visibility_filter=radii > 0, viewspace_points=m2d, vertice_deform=verts))
+    return (res, None) if return_stacked else res
