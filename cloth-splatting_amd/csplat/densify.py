@@ -1,18 +1,20 @@
-"""Densification / pruning of mesh-anchored Gaussians with the Adam-state surgery that goes with it.
+"""Densification / pruning of mesh-anchored Gaussians on capacity-based storage.
 
-Mirrors /root/reference/scene_reconstruction/gaussian_mesh.py:336-431 (prune_points, densification_postfix,
-densify_and_split, densify_and_clone) and gaussian_model.py:214-218, 266-341, 408-431 (reset_opacity,
-replace_tensor_to_optimizer, _prune_optimizer, cat_tensors_to_optimizer, prune, densify, add_densification_stats), and
-train_utils.py:324-345 (the schedule).  Device-agnostic torch (the reference hard-codes "cuda"): the parity test replays
-the reference's own run on CPU tensors (tests/golden/densify.npz).  The optimizer keeps torch.optim.Adam's state layout
--- exp_avg / exp_avg_sq are cut or zero-extended with the parameter, `step` is kept -- so csplat.optim.GroupedAdam and
-torch.optim.Adam are interchangeable here.
+What it computes is the reference's: /root/reference/scene_reconstruction/gaussian_mesh.py:336-431 (which Gaussians are
+cloned / split / pruned, where the new ones go, how their attributes are derived) and gaussian_model.py:214-218, 408-431
+(opacity reset, thresholds, statistics), on the schedule of train_utils.py:324-345.  HOW the rows move is not the reference's:
+its Adam-state surgery (gaussian_model.py:266-341: new nn.Parameters, masked / concatenated copies of both moments, optimizer
+state entries deleted and re-inserted) is replaced by csplat/store.py -- rows are compacted or appended inside capacity
+buffers by two HIP entry points and the Parameter objects are re-pointed, never re-created.  Row order after every operation
+equals the reference's (`tensor[mask]` / `torch.cat` order), so its own run is replayed bit for bit (tests/golden/densify.npz:
+parameters, both Adam moments, step counters, face ids, statistics after every stage; on CPU tensors and on the GPU).
 
 Multi-GPU note: every decision below is a pure function of (parameters, accumulated statistics, the RNG stream), and
-csplat.dist.reduce_densification_stats makes the statistics identical on all ranks; with the same seed the replicas stay
-bit-identical through densification without exchanging the new Gaussians."""
+csplat.dist makes the statistics identical on all ranks; with the same seed the replicas stay bit-identical through
+densification without exchanging the new Gaussians."""
 import torch
-import torch.nn as nn
+
+from .store import GaussianStore
 
 
 def compute_barycentric_coordinates(points, triangles):
@@ -25,10 +27,6 @@ def compute_barycentric_coordinates(points, triangles):
     v = (dot11 * dot02 - dot01 * dot12) / denom
     w = (dot00 * dot12 - dot01 * dot02) / denom
     return torch.stack([1.0 - v - w, v, w], dim=1)
-
-
-_ATTR = {"face_bary": "face_bary", "face_offset": "face_offset", "f_dc": "_features_dc", "f_rest": "_features_rest",
-         "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation"}
 
 
 class DensifyMixin:
@@ -49,114 +47,68 @@ class DensifyMixin:
         self.pos_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor[update_filter, :2], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
 
-    # ---- Adam-state surgery (gaussian_model.py:266-341) --------------------------------------------------------------
-    def _rebind(self, tensors):
-        for name, attr in _ATTR.items():
-            if name in tensors:
-                setattr(self, attr, tensors[name])
-
-    def replace_tensor_to_optimizer(self, tensor, name):
-        out = {}
-        for group in self.optimizer.param_groups:
-            if group["name"] == name:
-                stored = self.optimizer.state.get(group["params"][0], None)
-                stored["exp_avg"] = torch.zeros_like(tensor)
-                stored["exp_avg_sq"] = torch.zeros_like(tensor)
-                del self.optimizer.state[group["params"][0]]
-                group["params"][0] = nn.Parameter(tensor.requires_grad_(True))
-                self.optimizer.state[group["params"][0]] = stored
-                out[group["name"]] = group["params"][0]
-        return out
-
-    def _prune_optimizer(self, mask):
-        out = {}
-        for group in self.optimizer.param_groups:
-            if len(group["params"]) > 1:
-                continue
-            old = group["params"][0]
-            stored = self.optimizer.state.get(old, None)
-            if stored is not None:
-                stored["exp_avg"] = stored["exp_avg"][mask]
-                stored["exp_avg_sq"] = stored["exp_avg_sq"][mask]
-                del self.optimizer.state[old]
-                group["params"][0] = nn.Parameter(old[mask].requires_grad_(True))
-                self.optimizer.state[group["params"][0]] = stored
-            else:
-                group["params"][0] = nn.Parameter(old[mask].requires_grad_(True))
-            out[group["name"]] = group["params"][0]
-        return out
-
-    def cat_tensors_to_optimizer(self, tensors_dict):
-        out = {}
-        for group in self.optimizer.param_groups:
-            assert len(group["params"]) == 1
-            old, ext = group["params"][0], tensors_dict[group["name"]]
-            stored = self.optimizer.state.get(old, None)
-            if stored is not None:
-                stored["exp_avg"] = torch.cat((stored["exp_avg"], torch.zeros_like(ext)), dim=0)
-                stored["exp_avg_sq"] = torch.cat((stored["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
-                del self.optimizer.state[old]
-                group["params"][0] = nn.Parameter(torch.cat((old, ext), dim=0).requires_grad_(True))
-                self.optimizer.state[group["params"][0]] = stored
-            else:
-                group["params"][0] = nn.Parameter(torch.cat((old, ext), dim=0).requires_grad_(True))
-            out[group["name"]] = group["params"][0]
-        return out
+    # ---- storage ------------------------------------------------------------------------------------------------------
+    @property
+    def store(self):
+        """the capacity buffers behind the parameters (created at the first surgery: 2x the current size)"""
+        st = self.__dict__.get("_store")
+        if st is None or st.owner is not self or st.P != self.face_bary.shape[0] or \
+                st._param("face_bary").data_ptr() != st.sets[st.live]["p:face_bary"].data_ptr():
+            if not hasattr(self, "pos_gradient_accum") or self.pos_gradient_accum.shape[0] != self.face_bary.shape[0]:
+                self.densification_setup(self.percent_dense)
+            st = GaussianStore(self)
+            self._store = st
+        return st
 
     def reset_opacity(self):
-        """gaussian_model.py:214-217"""
+        """gaussian_model.py:214-217: opacities capped at 0.01, both Adam moments of the group zeroed, its step count kept"""
         from .gaussians import inverse_sigmoid
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
-        self._rebind(self.replace_tensor_to_optimizer(new, "opacity"))
+        self._opacity.data.copy_(new)
+        state = self.optimizer.state.get(self._opacity, None)
+        if state is not None and "exp_avg" in state:
+            state["exp_avg"].zero_()
+            state["exp_avg_sq"].zero_()
+        self._opacity.grad = None      # (upstream swaps in a fresh Parameter: the optimizer step that follows skips the group)
 
-    # ---- gaussian_mesh.py:336-431 -------------------------------------------------------------------------------------
+    # ---- which rows go where (gaussian_mesh.py:336-431) ---------------------------------------------------------------------
     def prune_points(self, mask):
-        valid = ~mask
-        self._rebind(self._prune_optimizer(valid))
-        self.face_ids = self.face_ids[valid]
-        self.invalidate_caches()
-        self.denom = self.denom[valid]
-        self.max_radii2D = self.max_radii2D[valid]
-        self.pos_gradient_accum = self.pos_gradient_accum[valid]
+        """drop the Gaussians with mask set (attributes, moments, face ids, statistics), order preserved"""
+        self.store.compact(~mask)
 
     def densification_postfix(self, new_face_bary, new_face_offset, new_face_ids, new_features_dc, new_features_rest,
                               new_opacities, new_scaling, new_rotation):
-        self._rebind(self.cat_tensors_to_optimizer({
-            "face_bary": new_face_bary, "face_offset": new_face_offset, "f_dc": new_features_dc, "f_rest": new_features_rest,
-            "opacity": new_opacities, "scaling": new_scaling, "rotation": new_rotation}))
-        self.face_ids = torch.cat((self.face_ids, new_face_ids), dim=0)
-        self.invalidate_caches()
-        P, dev = self.face_bary.shape[0], self.face_bary.device
-        self.pos_gradient_accum = torch.zeros((P, 1), device=dev)
-        self.denom = torch.zeros((P, 1), device=dev)
-        self.max_radii2D = torch.zeros((P,), device=dev)
+        """append the given Gaussians; statistics restart from zero for ALL rows (gaussian_mesh.py:359-361)"""
+        st = self.store
+        st.append_rows({"face_bary": new_face_bary, "face_offset": new_face_offset, "f_dc": new_features_dc, "f_rest": new_features_rest,
+                        "opacity": new_opacities, "scaling": new_scaling, "rotation": new_rotation}, new_face_ids)
+        st.reset_stats()
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        """large Gaussians with a large screen-space gradient are replaced by N samples of themselves (scale / (0.8 N)),
+        re-anchored on their face by barycentric coordinates of the sampled position"""
         from .gaussians import build_rotation
         n_init, dev = self.face_bary.shape[0], self.face_bary.device
         padded = torch.zeros((n_init,), device=dev)
         padded[:grads.shape[0]] = grads.squeeze()
-        sel = torch.where(padded >= grad_threshold, True, False)
-        sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
-        stds = self.get_scaling[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
-        rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
-        jitter = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1)
+        sel = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
+        scale_sel = self.get_scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((scale_sel.size(0), 3), device=dev), std=scale_sel)    # (global RNG, as upstream)
+        jitter = torch.bmm(build_rotation(self._rotation[sel]).repeat(N, 1, 1), samples.unsqueeze(-1)).squeeze(-1)
         new_xyz = self.get_xyz()[sel].repeat(N, 1) + jitter
-        triangles = self.face_ids[sel]
-        triangle_edges = self.mesh.pos[self.mesh.face[:, triangles]].transpose(0, 1).repeat(N, 1, 1)
-        new_face_bary = compute_barycentric_coordinates(new_xyz, triangle_edges)
+        corners = self.mesh.pos[self.mesh.face[:, self.face_ids[sel]]].transpose(0, 1).repeat(N, 1, 1)
         self.densification_postfix(
-            new_face_bary, self.face_offset[sel].repeat(N, 1), self.face_ids[sel].repeat(N),
+            compute_barycentric_coordinates(new_xyz, corners), self.face_offset[sel].repeat(N, 1), self.face_ids[sel].repeat(N),
             self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1), self._opacity[sel].repeat(N, 1),
-            torch.log(self.get_scaling[sel].repeat(N, 1) / (0.8 * N)), self._rotation[sel].repeat(N, 1))
+            torch.log(scale_sel / (0.8 * N)), self._rotation[sel].repeat(N, 1))
         self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=dev, dtype=torch.bool))))
 
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
-        sel = torch.where(torch.norm(grads, dim=-1) >= grad_threshold, True, False)
-        sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
-        self.densification_postfix(self.face_bary[sel], self.face_offset[sel], self.face_ids[sel], self._features_dc[sel],
-                                   self._features_rest[sel], self._opacity[sel], self._scaling[sel], self._rotation[sel])
+        """small Gaussians with a large screen-space gradient are duplicated in place (one launch appends all attributes)"""
+        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
+        st = self.store
+        st.append_selected(sel)
+        st.reset_stats()
 
     # ---- gaussian_mesh.py:267-322 -------------------------------------------------------------------------------------
     def _face_neighbours(self):

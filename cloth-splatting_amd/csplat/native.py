@@ -56,6 +56,9 @@ EXPORTS = {
     "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_adam_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _i64]),
     "csplat_l1_scratch_bytes": (_sz, []),
+    "csplat_mask_to_map_temp_bytes": (_sz, [_i64]),
+    "csplat_mask_to_map": (_i, [_vp, _i64, _vp, C.c_int32, _vp, _vp, _vp]),
+    "csplat_rows_scatter": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _vp]),
     "csplat_project_points": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "csplat_psnr_scratch_bytes": (_sz, [_i64]),
     "csplat_psnr": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),

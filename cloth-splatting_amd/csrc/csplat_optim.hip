@@ -52,3 +52,71 @@ extern "C" int csplat_adam_step(void *stream, int n_tensors, float *const *param
     }
     return 0;
 }
+
+// ---- capacity-based densify / prune (second half).  The reference re-creates every nn.Parameter and both
+// Adam moments of all 7 attribute groups with boolean-mask indexing / torch.cat whenever the number of Gaussians changes
+// (scene_reconstruction/gaussian_model.py:266-341, gaussian_mesh.py:336-431): ~60 allocations and gathers per surgery.  Here
+// the attributes, their moments and the per-Gaussian statistics live in capacity buffers (csplat/store.py); a surgery is
+//   csplat_mask_to_map   keep / select mask -> destination row of every source row (stable: order is preserved), count
+//   csplat_rows_scatter  ONE launch moving (or zero-filling) the rows of up to CSPLAT_ROWS_MAX_TENSORS tensors
+// and the Parameter objects are re-pointed at the first `count` rows of the destination buffers.
+namespace {
+__global__ __launch_bounds__(256) void k_mask_flags(int64_t n, const uint8_t *__restrict__ mask, uint32_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = mask[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_mask_map(int64_t n, const uint8_t *__restrict__ mask, const uint32_t *__restrict__ scan,
+                                                   int32_t base, int32_t *__restrict__ map, int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) map[i] = mask[i] ? base + (int32_t)scan[i] - 1 : -1;
+    if (i == n - 1) *count = (int32_t)scan[i];
+}
+struct RowsDesc { const uint32_t *src; uint32_t *dst; long long words; };      // words per row (4-byte units); src NULL = zero fill
+struct RowsTable { RowsDesc d[CSPLAT_ROWS_MAX_TENSORS]; };
+__global__ __launch_bounds__(256) void k_rows_scatter(RowsTable tab, int64_t n_rows, const int32_t *__restrict__ map) {
+    const RowsDesc d = tab.d[blockIdx.y];
+    const long long total = d.words * n_rows;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / d.words;
+        const int32_t to = map[row];
+        if (to >= 0) d.dst[(long long)to * d.words + (e - row * d.words)] = d.src ? d.src[e] : 0u;
+    }
+}
+}  // namespace
+
+extern "C" size_t csplat_mask_to_map_temp_bytes(int64_t n) { return align256((size_t)(n > 0 ? n : 1) * 4) * 2 + csplat_scan_temp_bytes(n) + 256; }
+
+extern "C" int csplat_mask_to_map(void *stream, int64_t n, const uint8_t *mask, int32_t base, int32_t *map, int32_t *count_dev, void *temp) {
+    CSPLAT_REQUIRE(n >= 0 && (n == 0 || (mask && map && temp)) && count_dev, "csplat_mask_to_map: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { HIP_TRY(hipMemsetAsync(count_dev, 0, 4, s)); return 0; }
+    uint32_t *flags = (uint32_t *)temp;
+    uint32_t *scan = (uint32_t *)((char *)temp + align256((size_t)n * 4));
+    void *stmp = (char *)temp + 2 * align256((size_t)n * 4);
+    k_mask_flags<<<cdiv(n, 256), 256, 0, s>>>(n, mask, flags);
+    LAUNCH_CHECK();
+    if (int rc = csplat_inclusive_scan_u32(s, flags, scan, n, stmp)) return rc;
+    k_mask_map<<<cdiv(n, 256), 256, 0, s>>>(n, mask, scan, base, map, count_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int csplat_rows_scatter(void *stream, int n_tensors, const void *const *src, void *const *dst, const int64_t *row_bytes,
+                                   int64_t n_rows, const int32_t *map) {
+    CSPLAT_REQUIRE(n_tensors >= 0 && n_tensors <= CSPLAT_ROWS_MAX_TENSORS && n_rows >= 0, "csplat_rows_scatter: bad sizes");
+    if (n_tensors == 0 || n_rows == 0) return 0;
+    CSPLAT_REQUIRE(src && dst && row_bytes && map, "csplat_rows_scatter: NULL");
+    RowsTable tab;
+    memset(&tab, 0, sizeof(tab));
+    long long longest = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        CSPLAT_REQUIRE(dst[i] && row_bytes[i] > 0 && row_bytes[i] % 4 == 0, "csplat_rows_scatter: rows are whole 4-byte words");
+        tab.d[i] = RowsDesc{(const uint32_t *)src[i], (uint32_t *)dst[i], (long long)(row_bytes[i] / 4)};
+        longest = tab.d[i].words > longest ? tab.d[i].words : longest;
+    }
+    const long long want = (longest * n_rows + 1023) / 1024;
+    dim3 grid((unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want)), (unsigned)n_tensors);
+    k_rows_scatter<<<grid, 256, 0, (hipStream_t)stream>>>(tab, n_rows, map);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -169,6 +169,20 @@ int csplat_adam_step(void *stream, int n_tensors, float *const *params, const fl
                      float *const *exp_avg_sq, const int64_t *numel, const double *lr, double beta1, double beta2, double eps,
                      int64_t step);
 
+/* Capacity-based densify / prune: replaces the boolean-mask indexing / torch.cat re-creation of every
+ * parameter and Adam moment in /root/reference/scene_reconstruction/gaussian_model.py:266-341 and gaussian_mesh.py:336-431.
+ *   csplat_mask_to_map: map[i] = base + (number of set mask bytes before i) where mask[i] != 0, else -1; *count_dev = number of
+ *                       set bytes (device int32).  Stable.  temp: csplat_mask_to_map_temp_bytes(n) bytes.
+ *   csplat_rows_scatter: for every tensor t and source row i with map[i] >= 0: dst[t][map[i]] = src[t][i] (row_bytes[t] bytes,
+ *                       a multiple of 4); src[t] == NULL writes zeros (fresh Adam moments of appended rows).  ONE launch for up
+ *                       to CSPLAT_ROWS_MAX_TENSORS tensors.  Source and destination rows must not overlap (ping-pong buffers
+ *                       for compaction, rows beyond the live range for appends).  src / dst / row_bytes are HOST arrays. */
+#define CSPLAT_ROWS_MAX_TENSORS 32
+size_t csplat_mask_to_map_temp_bytes(int64_t n);
+int csplat_mask_to_map(void *stream, int64_t n, const uint8_t *mask, int32_t base, int32_t *map, int32_t *count_dev, void *temp);
+int csplat_rows_scatter(void *stream, int n_tensors, const void *const *src, void *const *dst, const int64_t *row_bytes,
+                        int64_t n_rows, const int32_t *map);
+
 /* Output layer of the time-conditioned simulator MLP, T time rows at once (/root/reference/meshnet/meshnet_network.py:
  * 339 `self.output = Linear(256, n_nodes * 3)`, applied at :367 to ONE time value per render() call; a training step makes
  * T = 3 such calls, train_utils.py:204-260):

@@ -1,5 +1,6 @@
 """train_step analogue on a small scene: the whole hot path under autograd + two Adam
 optimisers must fit a perturbed target: PSNR rises, loss falls, statistics have the reference's shapes."""
+import numpy as np
 import pytest
 
 import util  # noqa: F401
@@ -217,6 +218,114 @@ def test_train_step_with_densification_on_gpu():
             assert not st or st["exp_avg"].shape == q.shape == st["exp_avg_sq"].shape     # (face_offset never gets a gradient)
         assert pc.face_ids.shape[0] == counts[-1] == pc.max_radii2D.shape[0] == pc.denom.shape[0]
     assert len(set(counts)) > 1 and max(counts) > 4000          # it did densify (and prune)
+
+
+def test_capacity_store_kernels_and_reference_replay_on_gpu():
+    """SURVEY 8(f) N3 on the device: (1) csplat_mask_to_map / csplat_rows_scatter against numpy on ragged row widths;
+    (2) the reference's own densify / prune / opacity-reset run (tests/golden/densify.npz) replayed on GPU tensors through the
+    capacity store: which rows survive, their order, the face ids, both Adam moments and the step counters as in the
+    reference's run (values to fp32 rounding: the split's sampling arithmetic runs on another device than the fixture's), the
+    SAME nn.Parameter objects before and after, and no allocation while the capacity suffices."""
+    import ctypes as C
+    import types
+    from util import golden
+    from csplat import native as n_, densify as dz
+    from csplat.gaussians import MeshGaussians
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(3)
+    # ---- (1) raw kernels
+    for n in (1, 5, 1000, 70_001):
+        mask = rng.random(n) < 0.37
+        m8 = torch.tensor(mask.astype(np.uint8), device=dev)
+        mp = torch.empty(n, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        tmp = torch.empty(int(n_.lib.csplat_mask_to_map_temp_bytes(n)), dtype=torch.uint8, device=dev)
+        n_.check(n_.lib.csplat_mask_to_map(n_.stream_handle(dev), n, n_.ptr(m8), 11, n_.ptr(mp), n_.ptr(cnt), n_.ptr(tmp)), "map")
+        want = np.where(mask, np.cumsum(mask) - 1 + 11, -1)
+        np.testing.assert_array_equal(mp.cpu().numpy(), want)
+        assert int(cnt.item()) == int(mask.sum())
+        srcs = [torch.tensor(rng.normal(size=(n, w)).astype(np.float32), device=dev) for w in (1, 3, 45)] + \
+               [torch.tensor(rng.integers(0, 1 << 40, n), device=dev)]
+        dsts = [torch.full((n + 20,) + tuple(t.shape[1:]), 7, dtype=t.dtype, device=dev) for t in srcs] + [torch.full((n + 20, 4), 7.0, device=dev)]
+        k = len(dsts)
+        sp = (C.c_void_p * k)(*([t.data_ptr() for t in srcs] + [None]))
+        dp = (C.c_void_p * k)(*[t.data_ptr() for t in dsts])
+        rb = (C.c_int64 * k)(*[t[0].numel() * t.element_size() for t in dsts])
+        n_.check(n_.lib.csplat_rows_scatter(n_.stream_handle(dev), k, C.cast(sp, C.c_void_p), C.cast(dp, C.c_void_p), C.cast(rb, C.c_void_p),
+                                            n, n_.ptr(mp)), "scatter")
+        for t, d in zip(srcs + [None], dsts):
+            ref = np.full(tuple(d.shape), 7, dtype=d.cpu().numpy().dtype)
+            ref[want[mask]] = 0 if t is None else t.cpu().numpy()[mask]
+            np.testing.assert_array_equal(d.cpu().numpy(), ref)
+    # ---- (2) the reference's run on the GPU
+    g = golden("densify.npz")
+    T = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    pc = MeshGaussians(3)
+    pc.mesh = types.SimpleNamespace(pos=T(g["pos"]), face=T(g["face"]), edge_index=None)
+    pc.face_ids = T(g["face_ids"])
+    names = ["face_bary", "face_offset", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    attrs = ["face_bary", "face_offset", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    for nm, a in zip(names, attrs):
+        setattr(pc, a, torch.nn.Parameter(T(g["init." + nm])))
+    pc.fused = False
+    lrs = [1.6e-4, 1.6e-4, 2.5e-3, 2.5e-3 / 20, 0.05, 0.005, 0.001]
+    from csplat.optim import GroupedAdam
+    pc.optimizer = GroupedAdam([{"params": [getattr(pc, a)], "lr": lr, "name": nm} for a, lr, nm in zip(attrs, lrs, names)], lr=0.0, eps=1e-15)
+    pc.densification_setup(percent_dense=0.01)
+    pc.max_radii2D = T(g["max_radii2D"])
+    objects = [getattr(pc, a) for a in attrs]
+
+    def feed(flat):
+        off = 0
+        for grp in pc.optimizer.param_groups:
+            p = grp["params"][0]
+            p.grad = T(flat[off:off + p.numel()]).reshape(p.shape)
+            off += p.numel()
+
+    def check(tag, exact):
+        for grp, obj in zip(pc.optimizer.param_groups, objects):
+            p, nm = grp["params"][0], grp["name"]
+            assert p is obj and p is getattr(pc, dict(zip(names, attrs))[nm])          # never re-created
+            st = pc.optimizer.state[p]
+            for got, key in ((p.detach(), f"{tag}.{nm}"), (st["exp_avg"], f"{tag}.{nm}.exp_avg"), (st["exp_avg_sq"], f"{tag}.{nm}.exp_avg_sq")):
+                if exact:
+                    np.testing.assert_array_equal(got.cpu().numpy(), g[key], err_msg=key)
+                else:
+                    np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=2e-5, atol=1e-7, err_msg=key)
+            assert float(st["step"]) == float(g[f"{tag}.{nm}.step"])
+        np.testing.assert_array_equal(pc.face_ids.cpu().numpy(), g[f"{tag}.face_ids"])
+        np.testing.assert_allclose(pc.pos_gradient_accum.cpu().numpy(), g[f"{tag}.pos_gradient_accum"], rtol=1e-6)
+        np.testing.assert_array_equal(pc.denom.cpu().numpy(), g[f"{tag}.denom"])
+        np.testing.assert_array_equal(pc.max_radii2D.cpu().numpy(), g[f"{tag}.max_radii2D"])
+
+    flat, per = g["adam_grads"], sum(getattr(pc, a).numel() for a in attrs)
+    for it in range(3):
+        feed(flat[it * per:(it + 1) * per])
+        pc.optimizer.step()
+    check("stepped", exact=False)        # (GroupedAdam vs torch.optim.Adam on the CPU: 1e-6)
+    vsp, upd = T(g["vsp"]), T(g["update_filter"])
+    pc.add_densification_stats(vsp, upd)
+    pc.add_densification_stats(vsp * 0.5, upd)
+    real_normal = torch.normal
+    try:     # the split draws from the global generator: replay the CPU stream the fixture was made with
+        torch.manual_seed(4321)
+        dz.torch.normal = lambda mean, std: real_normal(mean=mean.cpu(), std=std.cpu()).to(mean.device)
+        pc.densify(2e-4, 0.05, 1.0, None)
+    finally:
+        dz.torch.normal = real_normal
+    st_ = pc.store
+    allocs = st_.allocations
+    assert pc.face_bary.shape[0] == 81
+    check("densified", exact=False)
+    pc.prune(2e-4, 0.3, 1.0, 20)
+    check("pruned", exact=False)
+    pc.reset_opacity()
+    check("reset", exact=False)
+    feed(g["post_grads"])
+    pc.optimizer.step()
+    check("after_step", exact=False)
+    assert pc.store is st_ and st_.allocations == allocs == 1                     # 60 -> 81 -> 65 rows inside capacity 1024
+    assert pc.face_bary.data_ptr() == st_.sets[st_.live]["p:face_bary"].data_ptr()
 
 
 @pytest.mark.parametrize("T,lams", [(3, (0.1, 0.3, 0.2)), (3, (0.0, 0.3, 0.0)), (3, (0.1, 0.0, 0.2)), (1, (0.1, 0.3, 0.2)),
