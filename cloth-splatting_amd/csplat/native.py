@@ -78,6 +78,7 @@ EXPORTS = {
     "csplat_gnn_edge_combine_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_gnn_segment_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "csplat_gnn_gather_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "csplat_gnn_edge_features": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "csplat_linear128_mode": (_i, [C.c_uint]),
     "csplat_gnn_node_update": (_i, [_vp, _i64] + [_vp] * 11 + [_f] + [_vp] * 5),
     "csplat_linear128": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),

@@ -42,6 +42,17 @@ __global__ __launch_bounds__(256) void k_sort_rows(int N, const int32_t *__restr
     }
 }
 
+// K14: the per-step graph features of the rollout (PyG Cartesian(norm=False) + Distance(norm=False) on the current node
+// positions, /root/reference/train_meshnet_sim.py:152 `graph = transformer(graph)`): one edge per lane
+__global__ __launch_bounds__(256) void k_edge_features(int64_t E, const float *__restrict__ pos, const int64_t *__restrict__ ei,
+                                                        float4 *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int64_t r = ei[e], c = ei[E + e];
+    const float dx = pos[3 * r] - pos[3 * c], dy = pos[3 * r + 1] - pos[3 * c + 1], dz = pos[3 * r + 2] - pos[3 * c + 2];
+    out[e] = make_float4(dx, dy, dz, sqrtf(dx * dx + dy * dy + dz * dz));
+}
+
 // row movers are templated on the per-lane vector: float4 (16 B/lane) when L % 4 == 0, float otherwise
 __device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float vadd(float a, float b) { return a + b; }
@@ -110,6 +121,15 @@ __global__ __launch_bounds__(256) void k_gather_rows(int64_t E, int LV, const VT
 }  // namespace
 
 extern "C" {
+
+int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const int64_t *edge_index, float *out) {
+    CSPLAT_REQUIRE(E >= 0 && (E == 0 || (pos && edge_index && out)), "csplat_gnn_edge_features: bad arguments");
+    CSPLAT_REQUIRE(((uintptr_t)out & 15u) == 0, "csplat_gnn_edge_features: out must be 16-byte aligned");
+    if (E == 0) return 0;
+    k_edge_features<<<cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, (float4 *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
 
 size_t csplat_gnn_csr_temp_bytes(int N, int64_t E) {
     (void)E;

@@ -317,6 +317,10 @@ int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *m
                            const int32_t *perm, float *agg);
 /* its backward: dmsg[e][:] = dagg[key[e]][:]   (row gather) */
 int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out);
+/* Edge features of one rollout step (PyG Cartesian(norm=False) + Distance(norm=False), the `transformer(graph)` of
+ * /root/reference/train_meshnet_sim.py:152 and dataloader_sim.py): out[e] = (pos[row] - pos[col], |pos[row] - pos[col]|) with
+ * row = edge_index[0][e], col = edge_index[1][e]; pos [N][3], out [E][4] (16-byte aligned). */
+int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const int64_t *edge_index, float *out);
 
 /* The 128-wide Linear layers of the MeshNet MLPs for inference (replaces the cuBLAS sgemm behind nn.Linear at
  * /root/reference/meshnet/graph_network.py:198,221 when no autograd graph is recorded), with everything that follows the

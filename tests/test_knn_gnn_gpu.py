@@ -422,3 +422,38 @@ def test_gnn_irregular_graphs_vs_oracle(seed):
     floor = 0.5 * worst_plain if worst_plain > 1e-3 else 0.0
     for n_, eh, ep in errs:
         assert eh <= max(2e-4, 5.0 * ep, floor), (n_, eh, ep, worst_plain)
+
+
+def test_edge_features_kernel_and_rollout_loop():
+    """csplat_gnn_edge_features == PyG Cartesian(norm=False) + Distance(norm=False) (pos[row] - pos[col] and its norm), and
+    meshnet.rollout.rollout == the reference's loop (train_meshnet_sim.py:126-265) written out in plain torch around the same
+    simulator: per step features from the current positions, predict_velocity, grasp pinning, integration, history shift."""
+    from meshnet.cloth_network import ClothMeshSimulator
+    from meshnet.rollout import edge_features, rollout
+    dev = "cuda"
+    g = torch.Generator().manual_seed(12)
+    N, E = 300, 2100
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+    ef = edge_features(pos, ei)
+    d = pos.double()[ei[0]] - pos.double()[ei[1]]
+    ref = torch.cat([d, d.norm(dim=1, keepdim=True)], 1)
+    assert float((ef.double() - ref).abs().max()) < 1e-6
+    torch.manual_seed(3)
+    sim = ClothMeshSimulator(3, 8, 4, 32, 2, 2, 32, 2, 2, normalize=False, device=dev).eval()
+    hist = (torch.randn(2, N, 3, generator=g) * 0.01).to(dev)
+    ntype = torch.randint(0, 2, (N, 1), generator=g).to(dev)
+    actions = (torch.randn(4, 3, generator=g) * 0.01).to(dev)
+    preds, pos_end = rollout(sim, pos, hist, ntype, ei, actions, 7, 4)
+    with torch.no_grad():
+        p, h, outs = pos.clone(), hist.clone(), []
+        for step in range(4):
+            dd = p[ei[0]] - p[ei[1]]
+            feats = torch.cat([dd, dd.norm(dim=1, keepdim=True)], 1)
+            v = sim.predict_velocity(torch.cat([h[0], h[1]], 1), ntype, ei, feats)
+            v[7] = actions[step]
+            outs.append(v); p = p + v
+            h = torch.stack([h[1], v])
+    assert rel_err(preds.cpu().numpy(), torch.stack(outs).cpu().numpy()) < 1e-5
+    assert rel_err(pos_end.cpu().numpy(), p.cpu().numpy()) < 1e-5
+    assert torch.equal(preds[:, 7], actions)
