@@ -212,11 +212,9 @@ class MeshGaussians(DensifyMixin):
                                                  _n.ptr(self.mesh.pos.contiguous().float()), _n.ptr(rest)), "csplat_mesh_rest")
             # vertex <- (Gaussian, corner) incidence, grouped by vertex in ascending pair order: the backward gathers the
             # vertex gradients through it instead of scattering them with atomics (static until the next densification)
-            flat = vid.reshape(-1)
+            flat = vid.reshape(-1).contiguous()
             nv = int(self.mesh.pos.shape[0])
-            corners = torch.argsort(flat, stable=True).to(torch.int32)
-            rowptr = torch.zeros(nv + 1, dtype=torch.int32, device=vid.device)
-            rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=nv), 0).to(torch.int32)
+            rowptr, corners = _n.group_by_key(flat, nv)      # (csplat_gnn_build_csr: counting sort, ascending ids inside a group)
             r = (key, vid, rest, rowptr, corners, fi, mp)
             self._rest_cache = r
         if r[1].shape[0] != self.face_bary.shape[0] or r[1].shape[0] != self._rotation.shape[0]:

@@ -151,6 +151,21 @@ class ChunkAllocator:
             return None
 
 
+def group_by_key(keys, n_keys):
+    """(rowptr int32 [n_keys+1], perm int32 [len(keys)]): element ids grouped by key, ascending inside a group -- the stable
+    argsort of `keys` as a counting sort on the device (csplat_gnn_build_csr); keys int64 in [0, n_keys)."""
+    require_cuda(keys)
+    assert keys.dtype == torch.int64 and keys.dim() == 1
+    keys = keys.contiguous()
+    E, dev = int(keys.shape[0]), keys.device
+    rowptr = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    tmp = torch.empty(max(int(lib.csplat_gnn_csr_temp_bytes(n_keys, E)), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.csplat_gnn_build_csr(stream_handle(dev), n_keys, E, ptr(keys), ptr(rowptr), ptr(perm), ptr(tmp)), "csplat_gnn_build_csr")
+    return rowptr, perm[:E]
+
+
 PROF_CLASSES = ["K1_preprocess", "K2_scan", "K3_emit_keys", "K4_radix_sort", "K5_tile_ranges", "K6_render_fwd",
                 "K7_render_bwd", "K8_preprocess_bwd", "K9_dist2", "GNN"]
 

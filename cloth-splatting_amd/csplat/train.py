@@ -311,11 +311,7 @@ def edge_csr(edge_index, n_nodes):
     """(dst_rowptr, dst_perm, src_rowptr, src_perm), int32: edge ids grouped by target / source vertex, ascending in a group."""
     out = []
     for row in (1, 0):
-        idx = edge_index[row]
-        perm = torch.argsort(idx, stable=True).to(torch.int32)
-        rowptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device=idx.device)
-        rowptr[1:] = torch.cumsum(torch.bincount(idx, minlength=n_nodes), 0).to(torch.int32)
-        out += [rowptr, perm]
+        out += list(_n.group_by_key(edge_index[row], n_nodes))
     return tuple(out)
 
 

@@ -2032,6 +2032,8 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
         host_info[1] = 0xFFFFFFFFu;
     }
     const uint32_t R = host_info[0];
+    // list positions, tile ranges and the int `num_rendered` of the ABI are 32-bit (as upstream's): refuse instead of wrapping
+    CSPLAT_REQUIRE(R <= 0x7FFFFFFFu, "csplat_forward: more than 2^31 - 1 tile instances (Gaussian x tile pairs) in one view");
     static int s_lds_big = -1;   // can k_tile_sort get 64 KB of keys + 17 KB of counters?
     if (s_lds_big < 0)
     {

@@ -457,3 +457,35 @@ def test_edge_features_kernel_and_rollout_loop():
     assert rel_err(preds.cpu().numpy(), torch.stack(outs).cpu().numpy()) < 1e-5
     assert rel_err(pos_end.cpu().numpy(), p.cpu().numpy()) < 1e-5
     assert torch.equal(preds[:, 7], actions)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_linear128_wide_dynamic_range_rows(mode):
+    """the 3-way bf16 split (default) reconstructs fp32 operands to 24 bits, but its three pieces share ONE exponent range per
+    value: rows whose entries span many orders of magnitude (1e-6 .. 1e+4 inside a row, denormal-adjacent and huge rows side by
+    side) are where a split scheme would lose small terms if pieces were dropped.  Against fp64, error relative to each ROW's
+    own output scale (not the matrix's): <= 1e-5, both product modes.  """
+    from meshnet.graph_ops import linear128
+    from csplat import native as _n
+    _n.check(_n.lib.csplat_linear128_mode(mode), "csplat_linear128_mode")
+    try:
+        gen = torch.Generator().manual_seed(99)
+        M = 4096
+        mag = 10.0 ** (torch.rand(M, 128, generator=gen) * 10.0 - 6.0)                     # 1e-6 .. 1e+4 within a row
+        A = (torch.randn(M, 128, generator=gen) * mag)
+        A[:64] *= 1e-30                                                                     # tiny rows (products near 1e-36)
+        A[64:128] *= 1e+20                                                                  # huge rows
+        A[128:192] = 0.0
+        A[128:192, 5] = 1e-3                                                                # one-hot-ish rows
+        W = torch.randn(128, 128, generator=gen) * 10.0 ** (torch.rand(128, 128, generator=gen) * 6.0 - 3.0)
+        b = torch.zeros(128)
+        with torch.no_grad():
+            out = linear128(A.cuda(), W.cuda(), b.cuda()).cpu().double()
+        ref = A.double() @ W.double().t()
+        # fp32 accumulation bound: error <= ~K * eps * sum_k |a_k w_k| per output; compare against that magnitude row-wise
+        bound = (A.double().abs() @ W.double().abs().t()).amax(dim=1, keepdim=True) + 1e-300
+        err = ((out - ref).abs() / bound).max().item()
+        assert err < 1e-5, err
+        assert torch.isfinite(out).all()
+    finally:
+        _n.check(_n.lib.csplat_linear128_mode(1), "csplat_linear128_mode")
