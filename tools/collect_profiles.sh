@@ -10,22 +10,26 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 python3 bench.py                     > "$OUT/bench.json"       2> "$OUT/bench.err"
 python3 bench_gnn.py                 > "$OUT/bench_gnn.json"   2> /dev/null
+python3 tools/gnn_train_trace.py 10  > "$OUT/gnn_train.txt"    2> /dev/null
 python3 bench_train.py --steps 40 --warmup 5 > "$OUT/bench_train.json" 2> /dev/null
 python3 tools/bench_linear128.py     > "$OUT/linear128.txt"    2> /dev/null
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w tools/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate > "$OUT/mfma_rate.txt"
 cd /tmp && export TMPDIR=/tmp
 # same command as the default bench (per-view streams on), so K7's average agrees with bench.py's HIP-event timing
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+# (--no-train-step: ONLY the headline workload's launches, so the per-kernel averages are one clean population)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-train-step > "$OUT/trace.log" 2>&1
 # the same step with the views back to back on ONE stream: kernel durations free of cross-stream overlap (the profiler
 # serialises dispatches of different streams more than a free run does, so only this pair of numbers can agree exactly)
-python3 "$ROOT/bench.py" --no-cpu-baseline --no-view-streams > "$OUT/bench_serial.json" 2> /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-view-streams > "$OUT/trace_serial.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gnn" -o t -- python3 "$ROOT/bench_gnn.py" --steps 5 --warmup 2 > "$OUT/trace_gnn.log" 2>&1
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-train-step --no-view-streams > "$OUT/bench_serial.json" 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --no-view-streams > "$OUT/trace_serial.log" 2>&1
+# config 4: the product's training step alone (no PyG-like comparison leg in the population)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gnn" -o t -- python3 "$ROOT/tools/gnn_train_trace.py" 10 > "$OUT/trace_gnn.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_train" -o t -- python3 "$ROOT/bench_train.py" --steps 10 --warmup 3 > "$OUT/trace_train.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-view-streams > "$OUT/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-view-streams > "$OUT/pmc_$c.log" 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_l128_$c" -o p -- python3 "$ROOT/tools/bench_linear128.py" 300000 2 > /dev/null 2>&1
 done
+cd "$ROOT" && bash tools/collect_issue_counters.sh "$TAG" > /dev/null 2>&1
 # keep the merge-back small: drop the per-dispatch traces, keep stats + counters
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
 ls -la "$OUT"

@@ -23,7 +23,7 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-for f in ("bench.json", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "mfma_rate.txt"):
+for f in ("bench.json", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "mfma_rate.txt", "gnn_train.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
@@ -58,8 +58,8 @@ def pmc(sub_prefix):
 raster = pmc("pmc_")
 raster = {k: v for k, v in raster.items() if "linear128" not in k}
 if raster:
-    k7 = next((v for k, v in raster.items() if k.startswith("k_render_bwd")), None)
-    doc = {"kernel": "k_render_bwd (K7, depth-split)",
+    k7 = next((v for k, v in raster.items() if k.startswith("k_composite_bwd") or k.startswith("k_render_bwd")), None)
+    doc = {"kernel": "k_composite_bwd (K7)",
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python3 bench.py "
                      "--steps 2 --warmup 1 --no-cpu-baseline --no-view-streams` (tools/collect_profiles.sh)",
            "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE tallies 64 B per 128-B request on gfx950 -> doubled; "
@@ -76,4 +76,6 @@ if l128:
     json.dump({"source": "rocprofv3 --pmc passes of tools/bench_linear128.py 300000 2 (M = 300,000 rows: 153.6 MB in, "
                          "153.6 MB out algorithmic)", "kernels": l128},
               open(os.path.join(dst, f"{tag}_linear128_pmc_traffic.json"), "w"), indent=1)
+import subprocess
+subprocess.call([sys.executable, os.path.join(root, "tools", "summarize_issue_counters.py"), tag])
 print("profiles/ now holds:", sorted(os.listdir(dst)))
