@@ -257,7 +257,10 @@ def main():
     # algorithmic bytes per launch = 84*R + 24*X (instance re-read 44 B + 40 B partials per instance;
     # dL_dpix 16 B (incl. unused depth grad slot) + T 4 B + n_contrib 4 B per pixel), R = that view's tile instances.
     X = W * H
-    alg_bytes = float(np.mean([84.0 * r + 24.0 * X for r in R_per_view]))
+    # (with the views batched into one K7 launch per step the launch carries all views' bytes)
+    k7_launches_per_step = max(1, int(round(k7_n / max(args.steps * max(len(loads), 1), 1))))
+    views_per_launch = max(1, V // k7_launches_per_step)
+    alg_bytes = float(np.mean([84.0 * r + 24.0 * X for r in R_per_view])) * views_per_launch
     k7_avg_s = (k7_ms / max(k7_n, 1)) * 1e-3
     achieved = alg_bytes / k7_avg_s / 1e9 if k7_avg_s > 0 else 0.0
     # committed counter passes of the same workload (tools/collect_profiles.sh): HBM traffic and VALU instruction count of K7
@@ -276,7 +279,7 @@ def main():
         except Exception:
             valu_insts = None
     SIMDS, CLOCK_GHZ = 1024, 2.4         # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 4 cycles
-    issue = lambda us: None if not (valu_insts and us) else round(valu_insts * 4.0 / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
+    issue = lambda us, nv=1: None if not (valu_insts and us) else round(nv * valu_insts * 4.0 / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
     out = {
         "metric": "rasterizer fwd+bwd rendered Mpix/s (scene_1, 800x800)", "value": round(value, 3), "unit": "Mpix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -292,17 +295,20 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
                      "launches_timed": int(k7_n),
-                     "issue_frac": issue(k7_avg_s * 1e6),
+                     "views_per_launch": views_per_launch,
+                     "issue_frac": issue(k7_avg_s * 1e6, views_per_launch),
                      "issue_note": "VALU wave-instructions of one launch (SQ_INSTS_VALU, committed profiles/*_k67_issue.json) x 4 cycles / "
                                    "(1024 SIMDs x 2.4 GHz x this launch duration): the share of the chip's vector issue slots the kernel "
                                    "used -- the bound that actually binds this kernel (sort / composite arithmetic, no MFMA)",
                      "alone": None if not k7_alone_us else {
-                         "avg_launch_us": round(k7_alone_us, 2), "achieved": round(alg_bytes / (k7_alone_us * 1e-6) / 1e9, 3),
-                         "frac": round(alg_bytes / (k7_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6), "issue_frac": issue(k7_alone_us),
+                         "avg_launch_us": round(k7_alone_us, 2),
+                         "achieved": round(alg_bytes / views_per_launch / (k7_alone_us * 1e-6) / 1e9, 3),
+                         "frac": round(alg_bytes / views_per_launch / (k7_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                         "issue_frac": issue(k7_alone_us),
                          "what": "same kernel, views back to back on one stream (untimed extra pass)"},
-                     "note": (f"the {V} views' K7 launches of a step run CONCURRENTLY on {V} streams: each launch lasts "
-                              "longer than alone (see 'alone') while the step gets shorter; achieved/frac follow the contract "
-                              "(bytes of ONE launch / its own duration)") if args.view_streams and V > 1 else None},
+                     "note": (f"the K7 work of the step's {V} views is ONE launch (blockIdx.y = view): bytes and instructions of "
+                              f"{views_per_launch} view(s) per launch over that launch's duration; 'alone' = one view per launch, views "
+                              "back to back") if args.view_streams and V > 1 else None},
         "kernel_us": breakdown,
         "collective": collective,
     }

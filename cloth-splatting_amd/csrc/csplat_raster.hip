@@ -479,10 +479,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan_views(int tiles, int nb, K1T
     tile_scan_body(tiles, w.table + (size_t)nb * tiles, w.ranges, w.info, w.mailbox, w.tag);
 }
 
-__global__ __launch_bounds__(BUCKET_G) void k_emit_bucket(int P, int tiles, const float2 *__restrict__ xy,
-                                                           const float *__restrict__ depth, const int32_t *__restrict__ radii,
-                                                           Cam cam, const uint32_t *__restrict__ table,
-                                                           const int2 *__restrict__ ranges, uint64_t *__restrict__ comp) {
+__device__ __forceinline__ void emit_bucket_body(int P, int tiles, const float2 *__restrict__ xy,
+                                                 const float *__restrict__ depth, const int32_t *__restrict__ radii,
+                                                 const Cam &cam, const uint32_t *__restrict__ table,
+                                                 const int2 *__restrict__ ranges, uint64_t *__restrict__ comp) {
     extern __shared__ uint32_t s_base[];
     const uint32_t *row = table + (size_t)blockIdx.x * tiles;
     for (int t = threadIdx.x; t < tiles; t += BUCKET_G) s_base[t] = (uint32_t)ranges[t].x + row[t];
@@ -498,6 +498,41 @@ __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket(int P, int tiles, cons
     for (int y = miny; y < maxy; y++)
         for (int x = minx; x < maxx; x++) comp[atomicAdd(&s_base[y * cam.gx + x], 1u)] = v;
 }
+__global__ __launch_bounds__(BUCKET_G) void k_emit_bucket(int P, int tiles, const float2 *__restrict__ xy,
+                                                           const float *__restrict__ depth, const int32_t *__restrict__ radii,
+                                                           Cam cam, const uint32_t *__restrict__ table,
+                                                           const int2 *__restrict__ ranges, uint64_t *__restrict__ comp) {
+    emit_bucket_body(P, tiles, xy, depth, radii, cam, table, ranges, comp);
+}
+
+// The second phase of the forward (after the one host read of the instance counts) for ALL views of a step, one launch per
+// stage (blockIdx.y = view): the GPU's dispatcher packs the views' workgroups instead of 4 x 5 launches staggered by the
+// host's launch rate.
+constexpr int P2_MAX_VIEWS = 8;
+struct P2View {
+    Geom g;
+    Cam cam;
+    const int32_t *radii;
+    const uint32_t *table;
+    int2 *ranges;
+    uint64_t *keys_u, *keys_sorted;
+    uint32_t *ids_sorted;
+    int *seg_offset, *slot_tile;
+    float4 *ckpt;
+    uint16_t *mask16;
+    float4 *recA, *recB;
+    float2 *recC;
+    const float *bg;
+    float *final_T;
+    uint32_t *n_contrib;
+    float *out_color, *out_depth;
+    uint32_t R;
+};
+struct P2Table { P2View v[P2_MAX_VIEWS]; };
+__global__ __launch_bounds__(BUCKET_G) void k_emit_bucket_views(int P, int tiles, P2Table tab) {
+    const P2View &w = tab.v[blockIdx.y];
+    emit_bucket_body(P, tiles, w.g.xy, w.g.depth, w.radii, w.cam, w.table, w.ranges, w.keys_u);
+}
 
 constexpr int TSORT_THREADS = 1024;
 constexpr int TSORT_WAVES = TSORT_THREADS / 64;
@@ -508,9 +543,9 @@ constexpr int TSORT_ITEMS = BUCKET_CAP / TSORT_THREADS;   // 8 keys per lane at 
 // (wave, item, lane) order, which is what makes the in-wave match ranking stable); every pass ranks the 8-bit digit with
 // 8 ballots per key and per-wave LDS counters, turns the [wave][digit] counts into offsets, scatters through LDS and
 // reloads.  Byte 3 (ids >= 2^24) is skipped when P < 2^24.  ~10x less LDS traffic than a bitonic network at n = 8192.
-__global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
-                                                              uint64_t *__restrict__ keys_sorted,
-                                                              uint32_t *__restrict__ ids_sorted, int skip_byte3) {
+__device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
+                                               uint64_t *__restrict__ keys_sorted,
+                                               uint32_t *__restrict__ ids_sorted, int skip_byte3) {
     extern __shared__ uint64_t s_key[];                 // [m] keys, then the counters
     const int tile = blockIdx.x;
     const int2 r = ranges[tile];
@@ -622,6 +657,15 @@ __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restr
         }
     }
 }
+__global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
+                                                              uint64_t *__restrict__ keys_sorted,
+                                                              uint32_t *__restrict__ ids_sorted, int skip_byte3) {
+    tile_sort_body(ranges, comp, keys_sorted, ids_sorted, skip_byte3);
+}
+__global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort_views(P2Table tab, int skip_byte3) {
+    const P2View &w = tab.v[blockIdx.y];
+    tile_sort_body(w.ranges, w.keys_u, w.keys_sorted, w.ids_sorted, skip_byte3);
+}
 
 template <int CTRL, int RMASK>
 __device__ __forceinline__ float dpp_mov(float v, float old) {
@@ -681,8 +725,8 @@ constexpr int SEG = 256;   // tile-list entries per backward segment (multiple o
 
 // per-tile segment plan: seg_offset[t] = first segment slot of tile t (exclusive scan of ceil(n_t / SEG)),
 // slot_tile[slot] = owning tile.  One workgroup; tiles are few (2500 at 800x800).
-__global__ __launch_bounds__(1024) void k_seg_plan(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
-                                                    int *__restrict__ slot_tile) {
+__device__ __forceinline__ void seg_plan_body(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
+                                              int *__restrict__ slot_tile) {
     __shared__ int s_w[17];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int carry = 0;
@@ -712,6 +756,14 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int tiles, const int2 *__rest
         __syncthreads();
     }
     if (threadIdx.x == 0) seg_offset[tiles] = carry;
+}
+__global__ __launch_bounds__(1024) void k_seg_plan(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
+                                                    int *__restrict__ slot_tile) {
+    seg_plan_body(tiles, ranges, seg_offset, slot_tile);
+}
+__global__ __launch_bounds__(1024) void k_seg_plan_views(int tiles, P2Table tab) {
+    const P2View &w = tab.v[blockIdx.x];
+    seg_plan_body(tiles, w.ranges, w.seg_offset, w.slot_tile);
 }
 
 // =================================================================================================== K5b / K6 / K7, block form
@@ -752,12 +804,12 @@ template <typename Tv>
 __device__ __forceinline__ Tv rowsel(int r, Tv a, Tv b, Tv c, Tv d) { return r == 0 ? a : (r == 1 ? b : (r == 2 ? c : d)); }
 
 // ------------------------------------------------------------------------------------------- K5b
-__global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
-                                                      const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
-                                                      const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
-                                                      const float *__restrict__ depth, const float *__restrict__ cut2,
-                                                      uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
-                                                      float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
+__device__ __forceinline__ void block_masks_body(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
+                                                 const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
+                                                 const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                                                 const float *__restrict__ depth, const float *__restrict__ cut2,
+                                                 uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
+                                                 float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i > R) return;
     if (i == R) {   // the null record behind the list: opacity 0, pads incomplete groups of four
@@ -780,6 +832,19 @@ __global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const ui
     recA[i] = make_float4(c.x, c.y, co.x, co.y);
     recB[i] = make_float4(co.z, co.w, rgb[3 * id], rgb[3 * id + 1]);
     recC[i] = make_float2(rgb[3 * id + 2], depth[id]);
+}
+__global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
+                                                      const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
+                                                      const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                                                      const float *__restrict__ depth, const float *__restrict__ cut2,
+                                                      uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
+                                                      float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
+    block_masks_body(R, gx, keys_sorted, ids_sorted, xy, conic_opacity, rgb, depth, cut2, mask16, recA, recB, recC, exact);
+}
+__global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exact) {
+    const P2View &w = tab.v[blockIdx.y];
+    block_masks_body((int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.xy, w.g.conic_opacity, w.g.rgb, w.g.depth, w.g.cut2, w.mask16,
+                     w.recA, w.recB, w.recC, exact);
 }
 
 // The survivors of block `blk` among list positions [lo, hi) of one tile, as a stream of GROUPS OF FOUR that never cross a
@@ -827,13 +892,13 @@ struct Trip { float4 a, b; float2 c; int pos; };   // the lane's survivor of a g
 
 // ------------------------------------------------------------------------------------------- K6
 // grid: 16 single-wave workgroups per tile; the 16 blocks of a tile have the same blockIdx % 8 (same XCD, shared L2 lines)
-__global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
-                                                       const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
-                                                       const float4 *__restrict__ recB, const float2 *__restrict__ recC,
-                                                       uint32_t null_rec, const float *__restrict__ bg,
-                                                       const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
-                                                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                       float *__restrict__ out_color, float *__restrict__ out_depth) {
+__device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                   const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                   const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                   uint32_t null_rec, const float *__restrict__ bg,
+                                                   const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
+                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                   float *__restrict__ out_color, float *__restrict__ out_depth) {
     __shared__ int s_ring[RING];
     const int wg = blockIdx.x;
     const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
@@ -922,6 +987,21 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
         out_depth[pix] = Dp;
     }
 }
+__global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                       const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                       const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                       uint32_t null_rec, const float *__restrict__ bg,
+                                                       const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
+                                                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                       float *__restrict__ out_color, float *__restrict__ out_depth) {
+    composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
+                       out_depth);
+}
+__global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab) {
+    const P2View &w = tab.v[blockIdx.y];
+    composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                       w.n_contrib, w.out_color, w.out_depth);
+}
 
 // ------------------------------------------------------------------------------------------- K7
 // per-Gaussian gradient accumulator filled by K7 and consumed by K8 (one 64-byte record per Gaussian):
@@ -945,15 +1025,15 @@ __device__ __forceinline__ float bfly(float a, float b, bool s) {
 // k_det_reduce -- the bit-reproducible mode (csplat_debug_flags bit 8); default: one shared LDS record per entry,
 // flushed with float atomics.
 template <bool DET>
-__global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
-                                                        const uint32_t *__restrict__ ids_sorted,
-                                                        const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
-                                                        const float4 *__restrict__ recB, const float2 *__restrict__ recC,
-                                                        uint32_t null_rec, const int *__restrict__ seg_offset,
-                                                        const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
-                                                        const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                                                        const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
-                                                        float *__restrict__ acc, float *__restrict__ det) {
+__device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                   const uint32_t *__restrict__ ids_sorted,
+                                                   const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                   const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                   uint32_t null_rec, const int *__restrict__ seg_offset,
+                                                   const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
+                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                   const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
+                                                   float *__restrict__ acc, float *__restrict__ det) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING];
     __shared__ int s_any;
@@ -1088,6 +1168,47 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, 
             }
         }
     }
+}
+
+template <bool DET>
+__global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                        const uint32_t *__restrict__ ids_sorted,
+                                                        const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                        const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                        uint32_t null_rec, const int *__restrict__ seg_offset,
+                                                        const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
+                                                        const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                        const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
+                                                        float *__restrict__ acc, float *__restrict__ det) {
+    composite_bwd_body<DET>(tiles, W, H, gx, ranges, ids_sorted, mask16, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
+                            n_contrib, out_color, dL_dpix, acc, det);
+}
+
+// K7 for ALL views of a step in one launch (blockIdx.y = view), preceded by one launch that clears every view's records
+constexpr int B2_MAX_VIEWS = 8;
+struct B2View {
+    const int2 *ranges;
+    const uint32_t *ids_sorted;
+    const uint16_t *mask16;
+    const float4 *recA, *recB;
+    const float2 *recC;
+    const int *seg_offset, *slot_tile;
+    const float4 *ckpt;
+    const float *final_T;
+    const uint32_t *n_contrib;
+    const float *out_color, *dL_dpix;
+    float *acc;
+    uint32_t R;
+};
+struct B2Table { B2View v[B2_MAX_VIEWS]; };
+__global__ __launch_bounds__(256) void k_composite_bwd_views(int tiles, int W, int H, int gx, B2Table tab) {
+    const B2View &w = tab.v[blockIdx.y];
+    composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
+                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
+}
+__global__ __launch_bounds__(256) void k_zero_acc_views(int64_t n4, B2Table tab) {
+    float4 *p = reinterpret_cast<float4 *>(tab.v[blockIdx.y].acc);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // DET mode, second half: Gaussian i sums the records of its tile instances in emission order (tiles y-major, x; quadrants
@@ -1984,6 +2105,123 @@ int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int
     return rc;
 }
 
+// the one host read of a forward: R and the longest tile list of a view whose first phase has been launched
+static int finish_read(const FwdTicket &t, uint32_t host_info[2], hipStream_t launched_on = nullptr) {
+    hipStream_t s = launched_on ? launched_on : t.s;     // the stream the first phase was launched on
+    host_info[0] = host_info[1] = 0;
+    if (t.can_bucket) {
+        bool got = false;
+        if (t.use_mail) {   // spin on the tag (bounded: fall back to a stream synchronise after 2 s)
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (!(got = (t.mb_host[2] == t.tag))) {
+                if ((++spins & 0x3FFu) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+            }
+            if (got) { host_info[0] = t.mb_host[0]; host_info[1] = t.mb_host[1]; }
+        }
+        if (!got) {
+            HIP_TRY(hipMemcpyAsync(host_info, t.info, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    } else if (t.P > 0) {
+        ProfScope ps(PROF_K2, s);
+        if (int rc = csplat_inclusive_scan_u32(s, t.g.tiles_touched, t.g.offsets, t.P, t.g.scan_tmp)) return rc;
+        HIP_TRY(hipMemcpyAsync(host_info, t.g.offsets + (t.P - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        host_info[1] = 0xFFFFFFFFu;
+    }
+    // list positions, tile ranges and the int `num_rendered` of the ABI are 32-bit (as upstream's): refuse instead of wrapping
+    CSPLAT_REQUIRE(host_info[0] <= 0x7FFFFFFFu, "csplat_forward: more than 2^31 - 1 tile instances (Gaussian x tile pairs) in one view");
+    return 0;
+}
+// longest tile list the in-LDS sort takes (64 KB of keys + 17 KB of counters when the device grants 96 KB per workgroup)
+static uint32_t tile_sort_cap() {
+    static int s_lds_big = -1;
+    if (s_lds_big < 0) {
+        s_lds_big = hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)k_tile_sort_views, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        (void)hipGetLastError();   // a refusal must not poison the launch checks below
+    }
+    return s_lds_big ? (uint32_t)BUCKET_CAP : 5120u;
+}
+
+// Second phase of ALL views in one launch per stage on `join` (see P2Table).  *done = false (and nothing launched or
+// allocated) when the views do not qualify -- a tile list too long for the LDS sort, different sizes -- and the caller
+// finishes view by view.
+static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done) {
+    *done = false;
+    if (V < 2 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
+    const FwdTicket &a = g_tickets[tk[0]];
+    uint32_t info[P2_MAX_VIEWS][2];
+    uint32_t longest = 0, maxR = 0;
+    const uint32_t cap = tile_sort_cap();
+    for (int i = 0; i < V; i++) {
+        const FwdTicket &t = g_tickets[tk[i]];
+        if (!t.can_bucket || t.P != a.P || t.W != a.W || t.H != a.H || t.P <= 0) return 0;
+        if (int rc = finish_read(t, info[i], join)) return rc;
+        if (info[i][1] > cap || info[i][0] == 0) return 0;
+        longest = info[i][1] > longest ? info[i][1] : longest;
+        maxR = info[i][0] > maxR ? info[i][0] : maxR;
+    }
+    const int P = a.P, W = a.W, H = a.H, tiles = a.tiles, nb = a.nb;
+    P2Table tab;
+    for (int i = 0; i < V; i++) {
+        const FwdTicket &t = g_tickets[tk[i]];
+        const uint32_t R = info[i][0];
+        void *bbase = t.alloc(t.alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
+        void *tbase = t.alloc(t.alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
+        CSPLAT_REQUIRE(bbase && tbase, "allocator returned NULL");
+        size_t boff[B_NFIELDS], toff[5];
+        binning_offsets(R, tiles, boff);
+        temp_offsets(R, toff);
+        P2View &k = tab.v[i];
+        k.g = t.g; k.cam = t.cam; k.radii = t.radii; k.table = t.table; k.ranges = t.ranges;
+        k.keys_u = (uint64_t *)((char *)tbase + toff[0]);
+        k.keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
+        k.ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
+        k.seg_offset = (int *)((char *)bbase + boff[2]);
+        k.slot_tile = (int *)((char *)bbase + boff[3]);
+        k.ckpt = (float4 *)((char *)bbase + boff[4]);
+        k.mask16 = (uint16_t *)((char *)bbase + boff[5]);
+        k.recA = (float4 *)((char *)bbase + boff[6]); k.recB = (float4 *)((char *)bbase + boff[7]);
+        k.recC = (float2 *)((char *)bbase + boff[8]);
+        k.bg = t.bg; k.final_T = t.final_T; k.n_contrib = t.n_contrib; k.out_color = v[i].out_color; k.out_depth = v[i].out_depth;
+        k.R = R;
+        v[i].num_rendered = (int)R; v[i].geom = t.gbase; v[i].binning = bbase; v[i].image = t.ibase;
+    }
+    {
+        ProfScope ps(PROF_K3, join);
+        k_emit_bucket_views<<<dim3(nb, V), BUCKET_G, (size_t)tiles * 4, join>>>(P, tiles, tab);
+        LAUNCH_CHECK();
+    }
+    {
+        const int items = cdiv((int)longest > 0 ? (int)longest : 1, TSORT_THREADS);
+        const size_t lds = (size_t)items * TSORT_THREADS * 8 + (size_t)(TSORT_WAVES * 256 + 256 + 8) * 4;
+        ProfScope ps(PROF_K4, join);
+        k_tile_sort_views<<<dim3(tiles, V), TSORT_THREADS, lds, join>>>(tab, P < (1 << 24));
+        LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(PROF_K5, join);
+        k_seg_plan_views<<<V, 1024, 0, join>>>(tiles, tab);
+        LAUNCH_CHECK();
+        k_block_masks_views<<<dim3(cdiv((int64_t)maxR + 1, 256), V), 256, 0, join>>>(tab, (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
+        LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(PROF_K6, join);
+        k_composite_fwd_views<<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
+        LAUNCH_CHECK();
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        for (int i = 0; i < V; i++) g_tickets[tk[i]].used = false;
+    }
+    *done = true;
+    return 0;
+}
+
 int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *num_rendered, void **geom_out,
                           void **binning_out, void **image_out) {
     CSPLAT_REQUIRE(ticket >= 0 && ticket < MAX_TICKETS && g_tickets[ticket].used, "csplat_forward_finish: unknown ticket");
@@ -2006,41 +2244,9 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     csplat_alloc_fn alloc = t.alloc;
     void *alloc_ctx = t.alloc_ctx;
     uint32_t host_info[2] = {0, 0};   // R, longest tile list
-    if (can_bucket) {
-        const bool use_mail = t.use_mail;
-        const uint32_t tag = t.tag;
-        volatile uint32_t *mb_host = t.mb_host;
-        bool got = false;
-        if (use_mail) {   // spin on the tag (bounded: fall back to a stream synchronise after 2 s)
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            while (!(got = (mb_host[2] == tag))) {
-                if ((++spins & 0x3FFu) == 0 &&
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
-            }
-            if (got) { host_info[0] = mb_host[0]; host_info[1] = mb_host[1]; }
-        }
-        if (!got) {
-            HIP_TRY(hipMemcpyAsync(host_info, info, 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        }
-    } else if (P > 0) {
-        ProfScope ps(PROF_K2, s);
-        if (int rc = csplat_inclusive_scan_u32(s, g.tiles_touched, g.offsets, P, g.scan_tmp)) return rc;
-        HIP_TRY(hipMemcpyAsync(host_info, g.offsets + (P - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        host_info[1] = 0xFFFFFFFFu;
-    }
+    if (int rc = finish_read(t, host_info)) return rc;
     const uint32_t R = host_info[0];
-    // list positions, tile ranges and the int `num_rendered` of the ABI are 32-bit (as upstream's): refuse instead of wrapping
-    CSPLAT_REQUIRE(R <= 0x7FFFFFFFu, "csplat_forward: more than 2^31 - 1 tile instances (Gaussian x tile pairs) in one view");
-    static int s_lds_big = -1;   // can k_tile_sort get 64 KB of keys + 17 KB of counters?
-    if (s_lds_big < 0)
-    {
-        s_lds_big = hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        (void)hipGetLastError();   // a refusal must not poison the launch checks below
-    }
-    const uint32_t cap = s_lds_big ? (uint32_t)BUCKET_CAP : 5120u;
+    const uint32_t cap = tile_sort_cap();
     const bool bucketed = can_bucket && host_info[1] <= cap;
     *num_rendered = (int)R;
     void *bbase = alloc(alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
@@ -2137,7 +2343,7 @@ int csplat_forward(void *stream, int P, int D, int M, const float *bg, int W, in
 }
 
 // K7 on `stream`; K8 on `k8_stream` (after an event wait when it differs); accmask see k_preprocess_bwd
-static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k8, unsigned accmask, int P, int D, int M, int R, const float *bg, int W, int H,
+static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with_k8, unsigned accmask, int P, int D, int M, int R, const float *bg, int W, int H,
                          const float *means3D, const float *shs, const float *scales, float scale_modifier,
                          const float *rotations, const float *cov3D_precomp, const float *view, const float *proj,
                          const float *campos, float tanfovx, float tanfovy, const int32_t *radii, const void *geom,
@@ -2167,11 +2373,12 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k8, unsigned 
     const float4 *recA = (const float4 *)((const char *)binning + boff[6]), *recB = (const float4 *)((const char *)binning + boff[7]);
     const float2 *recC = (const float2 *)((const char *)binning + boff[8]);
     float *acc = (float *)scratch;
+    // (with_k7 = false: K7 of all views was launched as one batch by the caller)
     const bool det_mode = (g_debug_flags & 256u) != 0;
     float *det = det_mode ? (float *)((char *)scratch + align256((size_t)P * ACC_STRIDE * 4)) : nullptr;
-    if (det_mode) HIP_TRY(hipMemsetAsync(det, 0, (size_t)(R > 0 ? R : 1) * 4 * 9 * 4, s));
-    else HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
-    {
+    if (with_k7 && det_mode) HIP_TRY(hipMemsetAsync(det, 0, (size_t)(R > 0 ? R : 1) * 4 * 9 * 4, s));
+    else if (with_k7) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
+    if (with_k7) {
         ProfScope ps(PROF_K7, s);
         if (R > 0) {
             const unsigned grid = (unsigned)cdiv(max_slots(R, tiles), 8) * 32u;
@@ -2189,7 +2396,7 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k8, unsigned 
         }
     }
     if (!with_k8) return 0;   // (csplat_backward_views runs one K8 over all views afterwards)
-    if (k8s != s) {
+    if (with_k7 && k8s != s) {
         hipEvent_t ev = pooled_event();
         CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
         HIP_TRY(hipEventRecord(ev, s));
@@ -2223,7 +2430,7 @@ int csplat_backward(void *stream, int P, int D, int M, int R, const float *bg, i
                     float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
                     float *dL_dsh, float *dL_dscale, float *dL_drot) {
     (void)colors_precomp;
-    return backward_impl((hipStream_t)stream, (hipStream_t)stream, true, 0u, P, D, M, R, bg, W, H, means3D, shs, scales, scale_modifier,
+    return backward_impl((hipStream_t)stream, (hipStream_t)stream, true, true, 0u, P, D, M, R, bg, W, H, means3D, shs, scales, scale_modifier,
                          rotations, cov3D_precomp, view, proj, campos, tanfovx, tanfovy, radii, geom, binning, image, out_color,
                          dL_dpix, scratch, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                          dL_drot);
@@ -2268,9 +2475,21 @@ int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *joi
     }
     bool fenced = false;
     if (rc == 0 && begin_views_compatible(V, tickets)) {
-        // first phase of all views in four launches on the join stream, THEN the views' streams branch off
+        // first phase of all views in four launches on the join stream ...
         rc = begin_launch_views(V, tickets, join);
-        if (rc == 0) { rc = fence_in(V, v, join); fenced = rc == 0; }
+        // ... and, when every tile list fits the in-LDS sort, the second phase in five more, also on the join stream: no
+        // side stream is involved at all
+        bool done = false;
+        if (rc == 0) rc = finish_views_batched(V, tickets, v, join, &done);
+        if (done || rc) {
+            if (rc) {
+                std::lock_guard<std::mutex> lk(g_ticket_mu);
+                for (int i = 0; i < begun; i++) g_tickets[tickets[i]].used = false;
+            }
+            return rc;
+        }
+        rc = fence_in(V, v, join);     // otherwise the views' streams branch off here
+        fenced = rc == 0;
     } else if (rc == 0) {
         rc = fence_in(V, v, join);
         fenced = rc == 0;
@@ -2355,11 +2574,44 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     for (int i = 0; i < V; i++) shared |= v[i].accmask != 0u;
     K8Table tab;
     const bool one_k8 = shared && k8_views_table(V, v, tab);
+    // K7 of all views in ONE launch on the join stream (plus one launch clearing the records) when the views are alike
+    bool batch_k7 = V >= 2 && V <= B2_MAX_VIEWS && !(g_debug_flags & (256u | 512u));
+    for (int i = 0; i < V && batch_k7; i++)
+        batch_k7 = v[i].P == v[0].P && v[i].P > 0 && v[i].W == v[0].W && v[i].H == v[0].H && v[i].num_rendered > 0 && v[i].geom &&
+                   v[i].binning && v[i].image && v[i].out_color && v[i].scratch && v[i].dL_dpix;
     // from here on side streams may hold work on caller-owned buffers: whatever fails, the exit fence is still issued
     auto body = [&]() -> int {
-        for (int i = 0; i < V; i++) {
+        if (batch_k7) {
+            const int W = v[0].W, H = v[0].H, P = v[0].P, gx = cdiv(W, CSPLAT_TILE), tiles = gx * cdiv(H, CSPLAT_TILE);
+            B2Table bt;
+            int64_t slots = 0;
+            size_t ioff[5];
+            image_offsets(W, H, ioff);
+            for (int i = 0; i < V; i++) {
+                const csplat_view &w = v[i];
+                size_t boff[B_NFIELDS];
+                binning_offsets(w.num_rendered, tiles, boff);
+                const char *b = (const char *)w.binning, *im = (const char *)w.image;
+                B2View &k = bt.v[i];
+                k.ranges = (const int2 *)(im + ioff[0]); k.n_contrib = (const uint32_t *)(im + ioff[1]); k.final_T = (const float *)(im + ioff[2]);
+                k.ids_sorted = (const uint32_t *)(b + boff[1]); k.seg_offset = (const int *)(b + boff[2]); k.slot_tile = (const int *)(b + boff[3]);
+                k.ckpt = (const float4 *)(b + boff[4]); k.mask16 = (const uint16_t *)(b + boff[5]);
+                k.recA = (const float4 *)(b + boff[6]); k.recB = (const float4 *)(b + boff[7]); k.recC = (const float2 *)(b + boff[8]);
+                k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)w.num_rendered;
+                const int64_t sl = max_slots(w.num_rendered, tiles);
+                slots = sl > slots ? sl : slots;
+            }
+            ProfScope ps(PROF_K7, join);
+            const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
+            k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
+            LAUNCH_CHECK();
+            k_composite_bwd_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            LAUNCH_CHECK();
+        }
+        for (int i = 0; i < V && !(batch_k7 && one_k8); i++) {
             const csplat_view &w = v[i];
-            if (int rc = backward_impl((hipStream_t)w.stream, shared ? join : (hipStream_t)w.stream, !one_k8, w.accmask, w.P, w.D, w.M,
+            if (int rc = backward_impl((hipStream_t)w.stream, (shared || batch_k7) ? join : (hipStream_t)w.stream, !batch_k7, !one_k8,
+                                       w.accmask, w.P, w.D, w.M,
                                        w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
                                        w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.radii, w.geom, w.binning,
                                        w.image, w.out_color, w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic, w.dL_dopacity,
@@ -2367,7 +2619,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 return rc;
         }
         if (one_k8) {   // every view's K7 is queued on its own stream: the join stream waits for all of them, then ONE K8
-            for (int i = 0; i < V; i++) {
+            for (int i = 0; i < V && !batch_k7; i++) {
                 if ((hipStream_t)v[i].stream == join) continue;
                 hipEvent_t ev = pooled_event();
                 CSPLAT_REQUIRE(ev != nullptr, "csplat_backward_views: no event");
