@@ -18,7 +18,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, linear128, linear_rows, node_update
+from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, layer_norm_rows, linear128, linear_rows, node_update
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -50,7 +50,7 @@ class Encoder(nn.Module):
 
     def forward(self, x: torch.Tensor, edge_features: torch.Tensor):
         e = _tail(self.edge_fn[0], edge_features, first_has_act=False, skip_first=False)
-        return self.node_fn(x), self.edge_fn[1](e)
+        return self.node_fn(x), layer_norm_rows(e, self.edge_fn[1])
 
 
 def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool, skip_first: bool = True) -> torch.Tensor:
@@ -123,7 +123,7 @@ class InteractionNetwork(nn.Module):
         ec = linear_rows(edge_features, W[:, 2 * n:], lin0.bias)
         h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
         h = _tail(mlp_e, h, relu0)
-        msg = self.edge_fn[1](h)
+        msg = layer_norm_rows(h, self.edge_fn[1])
         # ---- aggregate: sum over destination nodes
         agg = SegmentSum.apply(msg, csr)
         # ---- update: LN(MLP(cat[agg, x])), concat folded into two GEMMs
@@ -133,7 +133,7 @@ class InteractionNetwork(nn.Module):
         hn = torch.addmm(l0.bias, agg, l0.weight[:, :a].t()) + x @ l0.weight[:, a:].t()
         hn = mlp_n[1](hn)
         hn = _tail(mlp_n, hn, True)
-        x_updated = self.node_fn[1](hn)
+        x_updated = layer_norm_rows(hn, self.node_fn[1])
         # PyG hands update() the ORIGINAL edge features: edge output = input + input
         return x_updated + x_residual, edge_features + edge_features_residual
 

@@ -200,6 +200,57 @@ def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w
     return x_new, xa, xb
 
 
+class LayerNorm128(torch.autograd.Function):
+    """nn.LayerNorm(128) on [M, 128] fp32 rows under autograd: one HBM pass forward (csplat_ln128_fwd, keeps mean / rstd per row),
+    one backward (csplat_ln128_bwd: input gradient + deterministic gamma / beta gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
+        M = x.shape[0]
+        y = torch.empty_like(x)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_ln128_fwd(_n.stream_handle(x.device), M, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), float(eps), _n.ptr(y),
+                                             _n.ptr(stats)), "csplat_ln128_fwd")
+        ctx.save_for_backward(x, stats, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, gamma = ctx.saved_tensors
+        g = _f32(g)
+        M = x.shape[0]
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        part = torch.empty(2 * int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_ln128_bwd(_n.stream_handle(x.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(stats), _n.ptr(gamma), _n.ptr(dx),
+                                             _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(part)), "csplat_ln128_bwd")
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm_rows(x, ln: torch.nn.LayerNorm):
+    """ln(x); 128-wide fp32 GPU rows go through LayerNorm128 (same parameters, same state_dict)"""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 128 and tuple(ln.normalized_shape) == (128,) and \
+            ln.elementwise_affine and ln.bias is not None and torch.is_grad_enabled() and x.shape[0] > 0:
+        return LayerNorm128.apply(x, ln.weight, ln.bias, ln.eps)
+    return ln(x)
+
+
+def relu_mask_bias128(g, out):
+    """(g masked by out > 0, column sums of the masked g): ReLU backward + bias gradient in one pass; out None = no mask"""
+    g = _f32(g)
+    M = g.shape[0]
+    gm = torch.empty_like(g) if out is not None else None
+    db = torch.empty(128, dtype=torch.float32, device=g.device)
+    part = torch.empty(int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _n.check(_n.lib.csplat_relu_mask_bias128(_n.stream_handle(g.device), M, _n.ptr(g), _n.ptr(out), _n.ptr(gm), _n.ptr(db), _n.ptr(part)),
+                 "csplat_relu_mask_bias128")
+    return (gm if gm is not None else g), db
+
+
 class SplitKLinear(torch.autograd.Function):
     """y = relu?(x @ weight^T + bias) for edge-level activations (rows = E ~ 3e5) under autograd.
     128 -> 128 fp32 layers run through csplat_linear128 both ways (forward with bias / ReLU in the epilogue, input gradient
@@ -231,7 +282,11 @@ class SplitKLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, weight, out = ctx.saved_tensors
         g = g.contiguous()
-        if ctx.relu:
+        db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.fast and g.shape[1] == 128 and g.dtype == torch.float32 and (ctx.relu or want_db):
+            g, db = relu_mask_bias128(g, out if ctx.relu else None)      # ReLU backward + bias gradient: one pass
+        elif ctx.relu:
             g = torch.ops.aten.threshold_backward(g, out, 0)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -245,8 +300,9 @@ class SplitKLinear(torch.autograd.Function):
                            xc[:m0].view(C, SplitKLinear.CHUNK, -1)).sum(0) if C else torch.zeros_like(weight)
             if m0 < M:
                 dw = dw + g[m0:].t() @ xc[m0:]
-        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        if db is None and want_db:
+            db = g.sum(0)
+        return dx, dw, (db if want_db else None), None
 
 
 def linear_rows(x, lin_weight, lin_bias, min_rows: int = 16384, relu: bool = False):

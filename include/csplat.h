@@ -342,6 +342,19 @@ int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const floa
                            const float *ln_gamma, const float *ln_beta, float ln_eps, const float *Wi_next,
                            const float *Wj_next, float *x_new, float *xa_next, float *xb_next);
 
+/* LayerNorm(128) of the MeshNet MLPs under autograd (/root/reference/meshnet/graph_network.py:86-97,139-150: every edge / node
+ * MLP ends in nn.LayerNorm), single HBM passes over [M][128] rows:
+ *   csplat_ln128_fwd   y = (x - mean) * rstd * gamma + beta; stats[row] = (mean, rstd)  (biased variance, as torch)
+ *   csplat_ln128_bwd   dx; dgamma[128] = sum_rows g * xhat; dbeta[128] = sum_rows g  (fixed summation order: deterministic)
+ *   csplat_relu_mask_bias128   gm = out > 0 ? g : 0 and dbias[128] = column sums of gm: ReLU backward + bias gradient of a
+ *                      Linear + ReLU layer in one pass (out NULL: no mask; gm NULL: sums only)
+ * partials: 2 x csplat_ln128_partial_floats(M) floats of scratch (1 x for csplat_relu_mask_bias128). */
+size_t csplat_ln128_partial_floats(int64_t M);
+int csplat_ln128_fwd(void *stream, int64_t M, const float *x, const float *gamma, const float *beta, float eps, float *y, float *stats);
+int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, const float *stats, const float *gamma, float *dx,
+                     float *dgamma, float *dbeta, float *partials);
+int csplat_relu_mask_bias128(void *stream, int64_t M, const float *g, const float *out, float *gm, float *dbias, float *partials);
+
 /* how csplat_linear128 forms its products: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products); 1 = three bf16 pieces per
  * operand and the six significant partial products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; error ~3 x 2^-24 relative
  * per term -- measured rms error vs fp64 1.2e-7, the fp32-MFMA path and the library sgemm 1.5e-7 --; 6/16 of the

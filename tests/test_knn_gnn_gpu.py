@@ -489,3 +489,35 @@ def test_linear128_wide_dynamic_range_rows(mode):
         assert torch.isfinite(out).all()
     finally:
         _n.check(_n.lib.csplat_linear128_mode(1), "csplat_linear128_mode")
+
+
+@pytest.mark.parametrize("M", [1, 7, 300, 70_001])
+def test_layernorm128_and_relu_mask_bias_vs_fp64(M):
+    """csplat_ln128_fwd / _bwd against torch.nn.functional.layer_norm in fp64 (value 1e-6, gradients 1e-5 relative), run to run
+    bit-identical gamma / beta gradients; csplat_relu_mask_bias128 against threshold_backward + sum(0)."""
+    from meshnet.graph_ops import LayerNorm128, relu_mask_bias128
+    gen = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, 128, generator=gen) * 3 + 0.5).cuda().requires_grad_(True)
+    ga = torch.randn(128, generator=gen).cuda().requires_grad_(True)
+    be = torch.randn(128, generator=gen).cuda().requires_grad_(True)
+    w = torch.randn(M, 128, generator=gen).cuda()
+    y = LayerNorm128.apply(x, ga, be, 1e-5)
+    (y * w).sum().backward()
+    x64, g64, b64 = (t.detach().double().requires_grad_(True) for t in (x, ga, be))
+    y64 = torch.nn.functional.layer_norm(x64, (128,), g64, b64, 1e-5)
+    (y64 * w.double()).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), y64.detach().cpu().numpy()) < 2e-6
+    assert rel_err(x.grad.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-5
+    assert rel_err(ga.grad.cpu().numpy(), g64.grad.cpu().numpy()) < 1e-5
+    assert rel_err(be.grad.cpu().numpy(), b64.grad.cpu().numpy()) < 1e-5
+    first = (ga.grad.clone(), be.grad.clone())
+    x.grad = ga.grad = be.grad = None
+    (LayerNorm128.apply(x, ga, be, 1e-5) * w).sum().backward()
+    assert torch.equal(ga.grad, first[0]) and torch.equal(be.grad, first[1])
+    out = torch.randn(M, 128, generator=gen).cuda()
+    gm, db = relu_mask_bias128(w, out)
+    ref = torch.ops.aten.threshold_backward(w, out, 0)
+    assert torch.equal(gm, ref)
+    assert rel_err(db.cpu().numpy(), ref.double().sum(0).cpu().numpy()) < 1e-5
+    g2, db2 = relu_mask_bias128(w, None)
+    assert g2.data_ptr() == w.data_ptr() and rel_err(db2.cpu().numpy(), w.double().sum(0).cpu().numpy()) < 1e-5
