@@ -2,8 +2,9 @@
 /root/reference/scene_reconstruction/gaussian_model.py:181-212 (attribute list, save) and :219-262 (load),
 gaussian_mesh.py:433-481 (+ b1, b2, b3, o, id; every property float32, one `vertex` element, binary little endian --
 plyfile's default on a little-endian host).  `plyfile` and `h5py` are not installed in this image: the PLY container is
-small enough to write directly (header text + packed records); the mesh side-car the reference stores as `mesh.hdf5` is
-written as `mesh.npz` with the same dataset names unless h5py is importable."""
+small enough to write directly (header text + packed records); the mesh side-car `mesh.hdf5` (gaussian_mesh.py:462-465,481)
+is written and read by csplat/hdf5min.py -- the flat-root-group, contiguous-dataset subset of HDF5 that file uses -- or by h5py
+when it is importable.  (Directories saved by round 1 hold `mesh.npz`; it is still read.)"""
 import os
 
 import numpy as np
@@ -83,7 +84,8 @@ def save_gaussians(pc, path):
             for k, v in mesh.items():
                 f.create_dataset(k, data=v)
     except ImportError:
-        np.savez(os.path.join(path, "mesh.npz"), **mesh)
+        from . import hdf5min
+        hdf5min.save(os.path.join(path, "mesh.hdf5"), mesh)
 
 
 def load_gaussians(pc, path, device="cuda"):
@@ -106,13 +108,12 @@ def load_gaussians(pc, path, device="cuda"):
     pc.face_ids = torch.tensor(d["id"], dtype=torch.long, device=device)
     pc.face_bary = par(np.stack([d["b1"], d["b2"], d["b3"]], 1))
     pc.face_offset = par(d["o"][:, None])
-    if os.path.exists(os.path.join(path, "mesh.npz")):
+    if os.path.exists(os.path.join(path, "mesh.hdf5")):
+        from . import hdf5min
+        mesh = {k: torch.tensor(v, device=device) for k, v in hdf5min.load(os.path.join(path, "mesh.hdf5")).items()}
+    else:
         m = np.load(os.path.join(path, "mesh.npz"))
         mesh = {k: torch.tensor(m[k], device=device) for k in m.files}
-    else:
-        import h5py
-        with h5py.File(os.path.join(path, "mesh.hdf5"), "r") as f:
-            mesh = {k: torch.tensor(np.asarray(f[k]), device=device) for k in f.keys()}
     for k, v in mesh.items():
         setattr(pc.mesh, k, v)
     if getattr(pc.mesh, "edge_index", None) is not None and getattr(pc.mesh, "pos", None) is not None:

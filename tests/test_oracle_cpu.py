@@ -541,6 +541,52 @@ def test_ply_layout_and_round_trip(tmp_path):
     np.testing.assert_array_equal(q.get_xyz().detach().numpy(), pc.get_xyz().detach().numpy())
 
 
+def test_hdf5min_known_answer_structure_and_round_trip(tmp_path):
+    """csplat/hdf5min.py (the `mesh.hdf5` side-car, gaussian_mesh.py:462-465 / data_utils.py:450-457): structural known answers
+    from the HDF5 file-format specification -- signature, version-0 superblock fields, the root entry's cached B-tree / heap
+    addresses landing on "TREE" / "HEAP", one "SNOD" with the datasets in name order, end-of-file address == file size, 8-byte
+    aligned raw data -- and a bit-exact round trip of the four datasets the reference stores (float32 pos / norm, int64 face /
+    edge_index), a float64 and an int32 array, a 0-d and an empty one.  (libhdf5 / h5py are not installed: interoperability with
+    them is by construction from the specification, not tested.)"""
+    import struct
+    from csplat import hdf5min
+    rng = np.random.default_rng(2)
+    arrays = {"pos": rng.normal(size=(37, 3)).astype(np.float32), "norm": rng.normal(size=(37, 3)).astype(np.float32),
+              "face": rng.integers(0, 37, (3, 50)).astype(np.int64), "edge_index": rng.integers(0, 37, (2, 120)).astype(np.int64),
+              "f64": rng.normal(size=(4, 2, 3)), "i32": np.arange(-5, 6, dtype=np.int32), "scalar": np.array(3.5, np.float32),
+              "empty": np.zeros((0, 3), np.float32)}
+    path = str(tmp_path / "mesh.hdf5")
+    hdf5min.save(path, arrays)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n" and raw[8:16] == bytes([0, 0, 0, 0, 0, 8, 8, 0])
+    leaf_k, internal_k, flags = struct.unpack_from("<HHI", raw, 16)
+    assert (leaf_k, internal_k, flags) == (4, 16, 0)
+    base, free, eof, drv = struct.unpack_from("<QQQQ", raw, 24)
+    assert base == 0 and free == drv == 0xFFFFFFFFFFFFFFFF and eof == len(raw)
+    name_off, hdr, ctype, _, btree, heap = struct.unpack_from("<QQIIQQ", raw, 56)
+    assert ctype == 1 and raw[btree:btree + 4] == b"TREE" and raw[heap:heap + 4] == b"HEAP"
+    assert raw[hdr] == 1 and struct.unpack_from("<H", raw, hdr + 2)[0] == 1                 # v1 object header, one message
+    assert struct.unpack_from("<HH", raw, hdr + 16) == (0x0011, 16)                          # ... the symbol-table message
+    snod = struct.unpack_from("<Q", raw, btree + 32)[0]
+    assert raw[snod:snod + 4] == b"SNOD" and struct.unpack_from("<H", raw, snod + 6)[0] == len(arrays)
+    heap_data = struct.unpack_from("<Q", raw, heap + 24)[0]
+    names = []
+    for e in range(len(arrays)):
+        off = struct.unpack_from("<Q", raw, snod + 8 + 40 * e)[0]
+        names.append(raw[heap_data + off:raw.index(b"\0", heap_data + off)].decode())
+    assert names == sorted(arrays)
+    back = hdf5min.load(path, prefer_h5py=False)
+    assert set(back) == set(arrays)
+    for k, v in arrays.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape
+        np.testing.assert_array_equal(back[k], v)
+    with pytest.raises(ValueError):
+        hdf5min.save(path, {f"d{i}": np.zeros(1) for i in range(9)})
+    open(path, "wb").write(b"not hdf5 at all")
+    with pytest.raises(ValueError):
+        hdf5min.load(path, prefer_h5py=False)
+
+
 def test_cleanup_barycentric_coordinates_replays_the_reference():
     """the vectorised cleanup_barycentric_coordinates against the reference's per-Gaussian Python loop, run on CPU tensors
     by make_golden.gen_densify on a grid mesh with rows that have one, two and three negative coordinates: same faces,
