@@ -800,8 +800,14 @@ __device__ __forceinline__ Row4 rows_allgather(float f) {
     return {__uint_as_float(ev[0]), __uint_as_float(od[0]), __uint_as_float(ev[1]), __uint_as_float(od[1])};
 }
 __device__ __forceinline__ float rows_sum(float f) { const Row4 g = rows_allgather(f); return ((g.v0 + g.v1) + g.v2) + g.v3; }
-template <typename Tv>
-__device__ __forceinline__ Tv rowsel(int r, Tv a, Tv b, Tv c, Tv d) { return r == 0 ? a : (r == 1 ? b : (r == 2 ? c : d)); }
+// row r of the wave takes the r-th argument: three DPP moves with a row mask (lanes of the other rows keep the old value)
+__device__ __forceinline__ float rowsel(int, float a, float b, float c, float d) {
+    int x = __float_as_int(a);
+    x = __builtin_amdgcn_update_dpp(x, __float_as_int(b), 0xE4, 0x2, 0xF, false);
+    x = __builtin_amdgcn_update_dpp(x, __float_as_int(c), 0xE4, 0x4, 0xF, false);
+    x = __builtin_amdgcn_update_dpp(x, __float_as_int(d), 0xE4, 0x8, 0xF, false);
+    return __int_as_float(x);
+}
 
 // ------------------------------------------------------------------------------------------- K5b
 __device__ __forceinline__ void block_masks_body(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
