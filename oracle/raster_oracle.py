@@ -47,6 +47,12 @@ def num_threads():
     return lib(np.float32).oracle_num_threads()
 
 
+def set_threads(n):
+    """OpenMP threads of both builds (small problems run faster on a few threads than on all of a 128-thread host)"""
+    for dt in (np.float32, np.float64):
+        lib(dt).oracle_set_threads(C.c_int(int(n)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

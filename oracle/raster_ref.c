@@ -77,6 +77,15 @@ int oracle_num_threads(void) {
 #endif
 }
 
+/* small problems (a 200x200 image, a few thousand Gaussians) run slower on 100+ threads than on a few */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* quaternion (r,x,y,z) -> rotation rows; utils/general_utils.py:81-102 (without the normalise) */
 static void quat_to_rot(const REAL *q, REAL R[3][3]) {
     REAL r = q[0], x = q[1], y = q[2], z = q[3];
@@ -385,19 +394,15 @@ void oracle_render_bwd(int P, int W, int H, const int32_t *ranges, const uint32_
     memset(dL_dopacity, 0, (size_t)P * sizeof(REAL));
     memset(dL_dcolor, 0, (size_t)P * 3 * sizeof(REAL));
     const REAL ddelx_dx = (REAL)0.5 * (REAL)W, ddely_dy = (REAL)0.5 * (REAL)H;
-    int nthreads = 1;
-#ifdef _OPENMP
-    nthreads = omp_get_max_threads();
-#endif
-    /* per-thread private accumulators: [nthreads][P][9] in double to keep the reduction benign */
-    double *acc = (double *)calloc((size_t)nthreads * P * 9, sizeof(double));
+    /* one accumulator row per LIST ENTRY (a tile's entries are only touched by the thread that owns the tile: no races, no
+     * per-thread copies), in double; afterwards every Gaussian's rows are summed in list order by one thread -- the result does
+     * not depend on the number of threads or on which thread took which tile */
+    size_t Rtot = 0;
+    for (int t = 0; t < gx * gy; t++)
+        if ((size_t)ranges[2 * t + 1] > Rtot) Rtot = (size_t)ranges[2 * t + 1];
+    double *inst = (double *)calloc((Rtot ? Rtot : 1) * 9, sizeof(double));
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
-        double *A = acc + (size_t)tid * P * 9;
         int s = ranges[2 * tile], e = ranges[2 * tile + 1];
         if (e <= s) continue;
         int tx0 = (tile % gx) * TILE, ty0 = (tile / gx) * TILE;
@@ -414,6 +419,7 @@ void oracle_render_bwd(int P, int W, int H, const int32_t *ranges, const uint32_
                 REAL bg_dot = bg[0] * dpx[0] + bg[1] * dpx[1] + bg[2] * dpx[2];
                 for (int j = s + last - 1; j >= s; j--) {
                     uint32_t g = ids_sorted[j];
+                    double *A = inst + (size_t)j * 9;
                     REAL dx = xy[2 * g] - (REAL)px, dy = xy[2 * g + 1] - (REAL)py;
                     const REAL *co = conic_opacity + 4 * g;
                     REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
@@ -429,7 +435,7 @@ void oracle_render_bwd(int P, int W, int H, const int32_t *ranges, const uint32_
                         accum_rec[ch] = last_alpha * last_color[ch] + ((REAL)1 - last_alpha) * accum_rec[ch];
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
-                        A[(size_t)g * 9 + 6 + ch] += (double)(dchannel_dcolor * dpx[ch]);
+                        A[6 + ch] += (double)(dchannel_dcolor * dpx[ch]);
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -438,20 +444,24 @@ void oracle_render_bwd(int P, int W, int H, const int32_t *ranges, const uint32_
                     REAL gdx = G * dx, gdy = G * dy;
                     REAL dG_ddelx = -gdx * co[0] - gdy * co[1];
                     REAL dG_ddely = -gdy * co[2] - gdx * co[1];
-                    A[(size_t)g * 9 + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-                    A[(size_t)g * 9 + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
-                    A[(size_t)g * 9 + 2] += (double)((REAL)-0.5 * gdx * dx * dL_dG);
-                    A[(size_t)g * 9 + 3] += (double)((REAL)-0.5 * gdx * dy * dL_dG);
-                    A[(size_t)g * 9 + 4] += (double)((REAL)-0.5 * gdy * dy * dL_dG);
-                    A[(size_t)g * 9 + 5] += (double)(G * dL_dalpha);
+                    A[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                    A[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                    A[2] += (double)((REAL)-0.5 * gdx * dx * dL_dG);
+                    A[3] += (double)((REAL)-0.5 * gdx * dy * dL_dG);
+                    A[4] += (double)((REAL)-0.5 * gdy * dy * dL_dG);
+                    A[5] += (double)(G * dL_dalpha);
                 }
             }
     }
+    double *acc = (double *)calloc((size_t)(P ? P : 1) * 9, sizeof(double));
+    for (size_t j = 0; j < Rtot; j++) {
+        const double *A = inst + j * 9;
+        double *D = acc + (size_t)ids_sorted[j] * 9;
+        for (int k = 0; k < 9; k++) D[k] += A[k];
+    }
 #pragma omp parallel for schedule(static)
     for (int g = 0; g < P; g++) {
-        double s9[9] = {0};
-        for (int t = 0; t < nthreads; t++)
-            for (int k = 0; k < 9; k++) s9[k] += acc[((size_t)t * P + g) * 9 + k];
+        const double *s9 = acc + (size_t)g * 9;
         dL_dmean2D[3 * g + 0] = (REAL)s9[0];
         dL_dmean2D[3 * g + 1] = (REAL)s9[1];
         dL_dconic[4 * g + 0] = (REAL)s9[2];
@@ -461,6 +471,7 @@ void oracle_render_bwd(int P, int W, int H, const int32_t *ranges, const uint32_
         for (int ch = 0; ch < 3; ch++) dL_dcolor[3 * g + ch] = (REAL)s9[6 + ch];
     }
     free(acc);
+    free(inst);
 }
 
 /* ------------------------------------------------------------------------------------------

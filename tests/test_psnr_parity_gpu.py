@@ -119,6 +119,11 @@ def test_psnr_parity_hip_vs_oracle_training():
         np.testing.assert_array_equal(a, b)
 
     # ---- (b) oracle training on the CPU (fp64), same step structure as csplat.train.train_step
+    import os
+    from oracle import raster_oracle as ro
+    nthr = min(16, os.cpu_count() or 1)          # 208x208 / 5k Gaussians: a few threads beat all 128 of the host
+    ro.set_threads(nthr)
+    torch.set_num_threads(nthr)
     pc_c, sim_c = build("cpu", torch.float64)
     pc_c.fused = False
     pc_c.training_setup(**LRS)
