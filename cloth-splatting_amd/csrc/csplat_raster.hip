@@ -584,10 +584,7 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
     }
     __syncthreads();
     const uint64_t diffbits = (uint64_t)s_diff[0] | ((uint64_t)s_diff[1] << 32);
-    for (int byte = 0; byte < 8; byte++) {
-        if (byte == 3 && skip_byte3) continue;
-        if (((diffbits >> (byte * 8)) & 0xFFull) == 0ull) continue;   // workgroup-uniform
-        const int shift = byte * 8;
+    auto pass = [&](int shift) {
         for (int t = threadIdx.x; t < TSORT_WAVES * 256; t += TSORT_THREADS) s_cnt[t] = 0u;
         __syncthreads();
 #pragma unroll
@@ -646,7 +643,52 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
             if (i < items && idx < n) key[i] = s_key[idx];
         }
         __syncthreads();
+    };
+    auto varies = [&](int byte) { return ((diffbits >> (byte * 8)) & 0xFFull) != 0ull && !(byte == 3 && skip_byte3); };   // workgroup-uniform
+    // The key is (depth bits, Gaussian id) and the id only breaks ties between EQUAL depths, which are rare (exact clones right
+    // after a densification step, coplanar centres): sort on the depth bytes alone (3 passes on a typical tile instead of 6),
+    // then put the runs of equal depth into id order.  Short runs are fixed in place by the lane that owns the run's first
+    // element; a run longer than TIE_RUN (or a tile whose depths are all equal) falls back to the full LSD sort over every
+    // varying byte -- the composite key is unique, so the result is the same whatever order the keys are in by then.
+    constexpr int TIE_RUN = 8;
+    bool full = (diffbits >> 32) == 0ull;        // no depth byte varies: nothing but the ids to sort on
+    if (!full) {
+        for (int byte = 4; byte < 8; byte++)
+            if (varies(byte)) pass(byte * 8);
+        // (s_key now holds the keys in depth order, key[] = this lane's elements of it)
+        bool long_run = false;
+#pragma unroll
+        for (int i = 0; i < TSORT_ITEMS; i++) {
+            const int idx = wbase + i * 64 + lane;
+            if (i < items && idx + 1 < n) {
+                const uint32_t d = (uint32_t)(key[i] >> 32);
+                const bool starts = (idx == 0 || (uint32_t)(s_key[idx - 1] >> 32) != d) && (uint32_t)(s_key[idx + 1] >> 32) == d;
+                if (starts) {
+                    int j = idx + 2;
+                    while (j < n && j - idx <= TIE_RUN && (uint32_t)(s_key[j] >> 32) == d) j++;
+                    if (j - idx > TIE_RUN) long_run = true;
+                    else
+                        for (int a2 = idx + 1; a2 < j; a2++) {          // insertion sort of the run by id (low word)
+                            const uint64_t v = s_key[a2];
+                            int b2 = a2 - 1;
+                            while (b2 >= idx && s_key[b2] > v) { s_key[b2 + 1] = s_key[b2]; b2--; }
+                            s_key[b2 + 1] = v;
+                        }
+                }
+            }
+        }
+        full = __syncthreads_or(long_run);
+        if (!full) {
+#pragma unroll
+            for (int i = 0; i < TSORT_ITEMS; i++) {
+                const int idx = wbase + i * 64 + lane;
+                if (i < items && idx < n) key[i] = s_key[idx];
+            }
+        }
     }
+    if (full)
+        for (int byte = 0; byte < 8; byte++)
+            if (varies(byte)) pass(byte * 8);
     const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
 #pragma unroll
     for (int i = 0; i < TSORT_ITEMS; i++) {
