@@ -174,7 +174,7 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_ssim_bwd(int H, int W, Taps ta
 // ---- fused L1 loss: mean |a - b| and its gradient sign(a - b) / n in ONE pass (utils/loss_utils.py:20-23 is three
 // elementwise launches forward and three backward).  Deterministic: workgroup partials are summed in index order by
 // whichever workgroup finishes last (ticket counter), not with float atomics.
-constexpr int L1_BLOCKS = 256, L1_THREADS = 1024;  // few, fat workgroups: the ticket atomics serialise at one L2 address (~30 ns each)
+constexpr int L1_BLOCKS = 1024, L1_THREADS = 256;  // 4 workgroups per CU; the ticket atomics (one per workgroup) stay cheap
 __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
                                                     float inv_n, float *__restrict__ partial, unsigned *__restrict__ ticket,
                                                     float *__restrict__ loss, float *__restrict__ grad,
@@ -189,8 +189,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
         return (mask_channels == 1 ? plane / channels : plane) * hw + (e - plane * hw);
     };
     const int64_t n4 = (mask && (hw & 3)) ? 0 : n >> 2;    // a 4-pixel group stays inside one image plane
-    for (int64_t i = (int64_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * L1_THREADS) {
-        const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+    auto one = [&](int64_t i, const float4 x, const float4 y) {
         float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
         if (mask) {
             const float4 m = *reinterpret_cast<const float4 *>(mask + moff(i << 2));
@@ -201,7 +200,16 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
             acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
             if (grad) reinterpret_cast<float4 *>(grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
         }
+    };
+    const int64_t stride = (int64_t)gridDim.x * L1_THREADS;
+    int64_t i = (int64_t)blockIdx.x * L1_THREADS + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {   // two independent pairs of 16-byte loads in flight
+        const float4 x0 = reinterpret_cast<const float4 *>(a)[i], y0 = reinterpret_cast<const float4 *>(b)[i];
+        const float4 x1 = reinterpret_cast<const float4 *>(a)[i + stride], y1 = reinterpret_cast<const float4 *>(b)[i + stride];
+        one(i, x0, y0);
+        one(i + stride, x1, y1);
     }
+    if (i < n4) one(i, reinterpret_cast<const float4 *>(a)[i], reinterpret_cast<const float4 *>(b)[i]);
     // tail: n not a multiple of 4 (<= 3 elements, all on workgroup 0), or every element when the planes are not 4-aligned
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * L1_THREADS) {
         float d = a[i] - b[i];
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
     if (s_last) {
         __threadfence();
         float t = 0.f;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += L1_THREADS) t += __builtin_nontemporal_load(partial + i);
+        for (int i2 = threadIdx.x; i2 < (int)gridDim.x; i2 += L1_THREADS) t += __builtin_nontemporal_load(partial + i2);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
         __syncthreads();

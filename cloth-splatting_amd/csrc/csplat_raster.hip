@@ -160,6 +160,8 @@ __device__ __forceinline__ void stage_sh_rows(const float *__restrict__ src, int
 }
 
 // ------------------------------------------------------------------------------------------- K1
+// s_shrows: the workgroup's SH rows in LDS when STAGE (filled by the caller: once per workgroup, also when it serves
+// several views)
 template <bool STAGE>
 __device__ __forceinline__ void preprocess_body(int P, int D, int M, const float *__restrict__ means3D,
                                                 const float *__restrict__ shs,
@@ -168,15 +170,9 @@ __device__ __forceinline__ void preprocess_body(int P, int D, int M, const float
                                                 const float *__restrict__ scales, float scale_mod,
                                                 const float *__restrict__ rotations,
                                                 const float *__restrict__ cov3D_precomp, const Cam &cam, const Geom &g,
-                                                int32_t *__restrict__ radii, int nocull) {
+                                                int32_t *__restrict__ radii, int nocull, const float *s_shrows) {
 #pragma clang fp contract(off)
-    __shared__ float s_shrows[STAGE ? 256 * SH_ROW : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (STAGE) {
-        const int base = blockIdx.x * 256;
-        stage_sh_rows<256>(shs + (size_t)base * 48, min(256, P - base), s_shrows);
-        __syncthreads();
-    }
     if (i >= P) return;
     float depth = 0.f, px = 0.f, py = 0.f, cut = -1.f;
     float4 co = {0.f, 0.f, 0.f, 0.f};
@@ -292,8 +288,14 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
                                                      const float *__restrict__ rotations,
                                                      const float *__restrict__ cov3D_precomp, Cam cam, Geom g,
                                                      int32_t *__restrict__ radii, int nocull) {
+    __shared__ float s_shrows[STAGE ? 256 * SH_ROW : 1];
+    if (STAGE) {
+        const int base = blockIdx.x * 256;
+        stage_sh_rows<256>(shs + (size_t)base * 48, min(256, P - base), s_shrows);
+        __syncthreads();
+    }
     preprocess_body<STAGE>(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_mod, rotations, cov3D_precomp, cam, g, radii,
-                           nocull);
+                           nocull, s_shrows);
 }
 
 // The first phase of the forward (K1 + the three counting kernels) for ALL views of a step, one launch each (blockIdx.y =
@@ -309,15 +311,25 @@ struct K1View {
     int2 *ranges;
     uint32_t tag;
 };
-struct K1Table { K1View v[K1_MAX_VIEWS]; };
+struct K1Table { int n; K1View v[K1_MAX_VIEWS]; };
 
+// (the 192-byte SH row of a Gaussian is staged ONCE per workgroup and evaluated for every view's direction)
 template <bool STAGE>
 __global__ __launch_bounds__(256) void k_preprocess_views(int P, int D, int M, const float *__restrict__ shs,
                                                            const float *__restrict__ opacities,
                                                            const float *__restrict__ scales, float scale_mod, K1Table tab,
                                                            int nocull) {
-    const K1View &w = tab.v[blockIdx.y];
-    preprocess_body<STAGE>(P, D, M, w.means3D, shs, nullptr, opacities, scales, scale_mod, w.rotations, nullptr, w.cam, w.g, w.radii, nocull);
+    __shared__ float s_shrows[STAGE ? 256 * SH_ROW : 1];
+    if (STAGE) {
+        const int base = blockIdx.x * 256;
+        stage_sh_rows<256>(shs + (size_t)base * 48, min(256, P - base), s_shrows);
+        __syncthreads();
+    }
+    for (int vi = 0; vi < tab.n; vi++) {
+        const K1View &w = tab.v[vi];
+        preprocess_body<STAGE>(P, D, M, w.means3D, shs, nullptr, opacities, scales, scale_mod, w.rotations, nullptr, w.cam, w.g, w.radii, nocull,
+                               s_shrows);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- K3
@@ -2108,6 +2120,7 @@ static int begin_launch_views(int V, const int *tk, hipStream_t join) {
     const FwdTicket &a = g_tickets[tk[0]];
     const int P = a.P, tiles = a.tiles, nb = a.nb;
     K1Table tab;
+    tab.n = V;
     for (int i = 0; i < V; i++) {
         const FwdTicket &t = g_tickets[tk[i]];
         K1View &k = tab.v[i];
@@ -2118,11 +2131,11 @@ static int begin_launch_views(int V, const int *tk, hipStream_t join) {
         ProfScope ps(PROF_K1, join);
         const bool stage = a.M == 16 && ((uintptr_t)a.shs & 15u) == 0;
         if (stage)
-            k_preprocess_views<true><<<dim3(cdiv(P, 256), V), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
-                                                                              nocull_mode());
+            k_preprocess_views<true><<<cdiv(P, 256), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
+                                                                     nocull_mode());
         else
-            k_preprocess_views<false><<<dim3(cdiv(P, 256), V), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
-                                                                               nocull_mode());
+            k_preprocess_views<false><<<cdiv(P, 256), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
+                                                                      nocull_mode());
         LAUNCH_CHECK();
     }
     {
