@@ -148,12 +148,12 @@ def main():
                 colors, _ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
                                                                  shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
                                                             for i in range(V)], stacked=True)
-                # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285); x V = the sum of the
-                # per-view means that the camera-by-camera branch below forms
-                loss = l1_loss(colors, self.targets_stacked) * float(V)
+                # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285) = the mean of the per-view
+                # means that the camera-by-camera branch below forms
+                loss = l1_loss(colors, self.targets_stacked)
             else:
                 outs = [self.render(i, m2ds[i]) for i in range(V)]
-                loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).sum()
+                loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).mean()
             loss.backward()         # the batched node fans the views' K7/K8 out over the same per-view streams
             if self.fg is not None:
                 with torch.no_grad():
