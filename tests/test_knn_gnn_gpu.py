@@ -131,7 +131,7 @@ def test_cloth_simulator_vs_reference():
 
 @pytest.mark.parametrize("L,N,E", [(128, 500, 6000), (32, 64, 0), (20, 300, 2000), (6, 50, 400)])
 def test_gnn_kernels_vs_numpy(L, N, E):
-    """raw C-ABI kernels: CSR build, edge combine fwd/bwd, segment sum (== sequential index_add, bit-exact), row gather.
+    """raw C-ABI kernels: CSR build, edge combine fwd/bwd, segment sum (compensated: == the fp64 sum to an ulp), row gather.
     Ragged degrees incl. isolated nodes, empty edge list, widths that are / are not multiples of 4."""
     from meshnet.graph_ops import EdgeCombine, GraphCSR, SegmentSum
     rng = np.random.default_rng(L)
@@ -145,9 +145,12 @@ def test_gnn_kernels_vs_numpy(L, N, E):
     msg = rng.normal(size=(E, L)).astype(np.float32)
     m = torch.tensor(msg, device="cuda", requires_grad=True)
     agg = SegmentSum.apply(m, csr)
-    ref = np.zeros((N, L), np.float32)
-    np.add.at(ref, ei_np[1], msg)                                             # sequential fp32 adds in edge order
-    np.testing.assert_array_equal(agg.detach().cpu().numpy(), ref)
+    ref = np.zeros((N, L), np.float64)
+    np.add.at(ref, ei_np[1], msg.astype(np.float64))
+    # compensated summation in ascending edge order: the fp32 result is the fp64 sum to within an ulp, for ANY degree
+    got_agg = agg.detach().cpu().numpy()
+    assert np.all(np.abs(got_agg - ref) <= 1.2e-7 * np.abs(ref) + 1e-30)
+    assert torch.equal(SegmentSum.apply(m, csr), agg)                         # and run-to-run identical
     gout = rng.normal(size=(N, L)).astype(np.float32)
     agg.backward(torch.tensor(gout, device="cuda"))
     np.testing.assert_array_equal(m.grad.cpu().numpy(), gout[ei_np[1]])
@@ -160,11 +163,11 @@ def test_gnn_kernels_vs_numpy(L, N, E):
     gh = rng.normal(size=(E, L)).astype(np.float32)
     h.backward(torch.tensor(gh, device="cuda"))
     gm = gh * (href > 0)
-    dxa = np.zeros((N, L), np.float32); np.add.at(dxa, ei_np[1], gm)
-    dxb = np.zeros((N, L), np.float32); np.add.at(dxb, ei_np[0], gm)
+    dxa = np.zeros((N, L), np.float64); np.add.at(dxa, ei_np[1], gm.astype(np.float64))
+    dxb = np.zeros((N, L), np.float64); np.add.at(dxb, ei_np[0], gm.astype(np.float64))
     np.testing.assert_array_equal(tec.grad.cpu().numpy(), gm)
-    np.testing.assert_array_equal(txa.grad.cpu().numpy(), dxa)
-    np.testing.assert_array_equal(txb.grad.cpu().numpy(), dxb)
+    assert np.all(np.abs(txa.grad.cpu().numpy() - dxa) <= 1.2e-7 * np.abs(dxa) + 1e-30)
+    assert np.all(np.abs(txb.grad.cpu().numpy() - dxb) <= 1.2e-7 * np.abs(dxb) + 1e-30)
 
 
 def test_config4_size_rollout_step_properties():
@@ -415,13 +418,22 @@ def test_gnn_irregular_graphs_vs_oracle(seed):
         if c_ is None or c_.numel() == 0 or float(c_.abs().max()) == 0:
             continue
         errs.append((n_, rel_err(a_.cpu().numpy(), c_.numpy()), rel_err(b_.cpu().numpy(), c_.numpy())))
-    # (a graph on which the plain fp32 composition is itself off by more than 1e-3 somewhere is rounding noise throughout its
-    # backward, and that noise is not reproducible from run to run -- the library GEMMs pick their split by the state of the
-    # process: every gradient is then held to half of that worst plain-fp32 error)
-    worst_plain = max(ep for _, _, ep in errs)
-    floor = 0.5 * worst_plain if worst_plain > 1e-3 else 0.0
+    # How accurate CAN an fp32 implementation be on this graph?  A hub collecting thousands of messages makes the backward
+    # ill-conditioned: the EXACT (fp64) gradients themselves move by `sens` when every weight is perturbed by one fp32 rounding
+    # (1.2e-7 relative) -- measured here, per graph (seed 305: 4e-4 on x, 1.2e-2 on e; regular graphs: 4e-7).  No fp32 code path
+    # is owed more than a small multiple of that; the plain fp32 composition sometimes lands far below it and sometimes at it,
+    # depending on which split the library GEMMs pick (not reproducible from run to run), so it is only a second yardstick.
+    net64p = EncodeProcessDecode(8, 3, 4, 128, 3, 2, 128).double()
+    gp = torch.Generator().manual_seed(seed + 1)
+    net64p.load_state_dict({k: v.double().cpu() * (1 + 1.2e-7 * torch.randn(v.shape, generator=gp, dtype=torch.float64))
+                            for k, v in net.state_dict().items()})
+    x64p, e64p = x.detach().cpu().double().requires_grad_(), e.detach().cpu().double().requires_grad_()
+    (composed(net64p, x64p, torch.tensor(ei_np), e64p) * w.double()).sum().backward()
+    moved = [x64p.grad, e64p.grad] + [p_.grad for p_ in net64p.parameters()]
+    sens = max(rel_err(m_.numpy(), c_.numpy()) for m_, c_ in zip(moved, exact)
+               if c_ is not None and c_.numel() and float(c_.abs().max()) > 0)
     for n_, eh, ep in errs:
-        assert eh <= max(2e-4, 5.0 * ep, floor), (n_, eh, ep, worst_plain)
+        assert eh <= max(2e-4, 5.0 * ep, 4.0 * sens), (n_, eh, ep, sens)
 
 
 def test_edge_features_kernel_and_rollout_loop():
