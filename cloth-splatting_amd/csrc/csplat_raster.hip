@@ -554,7 +554,7 @@ constexpr int TSORT_ITEMS = BUCKET_CAP / TSORT_THREADS;   // 8 keys per lane at 
 // Keys live in registers between passes (lane l of wave w owns positions w*64*items + i*64 + l, i.e. memory order =
 // (wave, item, lane) order, which is what makes the in-wave match ranking stable); every pass ranks the 8-bit digit with
 // 8 ballots per key and per-wave LDS counters, turns the [wave][digit] counts into offsets, scatters through LDS and
-// reloads.  Byte 3 (ids >= 2^24) is skipped when P < 2^24.  ~10x less LDS traffic than a bitonic network at n = 8192.
+// reloads.  Byte 3 (ids >= 2^24) is skipped when P < 2^24.
 __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
                                                uint64_t *__restrict__ keys_sorted,
                                                uint32_t *__restrict__ ids_sorted, int skip_byte3) {

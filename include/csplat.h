@@ -44,13 +44,17 @@ extern "C" {
 typedef void *(*csplat_alloc_fn)(void *ctx, int chunk, size_t bytes);
 
 int csplat_abi_version(void);
-/* test hook (results must not change).  bit 0: disable the wave-level culling of K6/K7;
+/* test hooks (results must not change beyond fp32 re-association).  bit 0: no culling -- every block mask of K5b is all ones;
  * bit 1: force the global radix-sort binning path instead of the tile-bucketed LDS sort;
  * bit 2: read R with a blocking stream synchronise instead of polling the pinned mailbox;
- * bit 3: depth-split forward compositing (four wavefronts per quadrant, rounds of speculative 256-entry segments with
- *        exact replay of terminating segments) instead of the sequential one-wavefront-per-quadrant kernel;
+ * bit 3: unused (round 1's experimental four-wave forward was removed);
  * bit 4: quadruple the culling radius (sensitivity check of the culling bound);
- * bit 5: circle stage of the culling only (no exact ellipse-vs-box stage).  Bits 0 and 4 also switch the ellipse stage off. */
+ * bit 5: circle stage of the culling only (no exact ellipse-vs-box stage).  Bits 0 and 4 also switch the ellipse stage off;
+ * bit 7: one K8 launch per view instead of one for all views of a step;
+ * bit 8: bit-reproducible backward -- K7 stores one record per (list entry, quadrant) and every Gaussian sums its records in
+ *        emission order instead of meeting in float atomics (csplat_backward_scratch_bytes grows accordingly: set the flag
+ *        before sizing the scratch);
+ * bit 9: per-view launches on per-view streams instead of one launch per stage for all views of a step. */
 int csplat_debug_flags(unsigned flags);
 const char *csplat_last_error(void);
 
@@ -134,8 +138,9 @@ int csplat_backward_views(int V, csplat_view *views, void *join_stream);
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
  * out_color is the forward's colour image; dL_dpix[3][H][W] its gradient (the depth image carries no gradient,
  * as upstream).
- * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes (one 48-byte accumulation record per Gaussian:
- * K7 adds one wave-reduced 36-byte partial per (quadrant, surviving list entry), K8 consumes the records).
+ * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes (one 64-byte-aligned accumulation record per Gaussian:
+ * K7 adds one 36-byte partial per (8x8 quadrant, list entry that reached it) with a single atomic request, K8 consumes the
+ * records).
  * Gradient outputs (device, fully overwritten): dL_dmean2D[P][3] (NDC units, .z = 0), dL_dconic[P][4],
  * dL_dopacity[P], dL_dcolor[P][3], dL_dmean3D[P][3], dL_dcov3D[P][6], dL_dsh[P][M][3] (may be NULL when
  * colors_precomp was used), dL_dscale[P][3], dL_drot[P][4] (may be NULL when cov3D_precomp was used). */
