@@ -292,7 +292,10 @@ def main():
                    "parallelism": (f"scene-parallel x{world} (replicas only)" if scene_mode else f"view-parallel x{world}"),
                    "streams_per_gpu": V if args.view_streams else 1},
         "roofline": {"bound": "hbm", "kernel": "k_composite_bwd (K7 compositing backward)", "achieved": round(achieved, 3),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                     # PMC bytes (2 x FETCH_SIZE + WRITE_SIZE, committed counter passes of the one-view-per-launch command) scaled to
+                     # the views this launch carries, like `achieved`
+                     "traffic": None if traffic is None else int(traffic * views_per_launch),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
                      "launches_timed": int(k7_n),
                      "views_per_launch": views_per_launch,
