@@ -594,3 +594,45 @@ def test_equal_depth_ties_sort_by_id(copies):
         _, _, _, st2 = util.gpu_forward_raw(flat)
         np.testing.assert_array_equal(st2["keys"], o2.keys)
         np.testing.assert_array_equal(st2["ids"], o2.ids)
+
+
+@pytest.mark.parametrize("V,flag", [(8, 0), (9, 0), (4, 512)])
+def test_all_views_launches_vs_per_view_calls(V, flag):
+    """The three ways a step's views are issued -- ONE launch per stage with blockIdx.y = view (V <= 8 like views), per-view
+    launches on per-view streams (V > 8, or csplat_debug_flags bit 9) and one GaussianRasterizer call per view -- give the same
+    images / radii / depth bit for bit and the same gradients up to atomic order; every view has its OWN means3D and rotations
+    (as the deformed cloth of a training step has) and shares SH / opacity / scales."""
+    from csplat import native
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_views
+    cases = [util.make_case(P=2500, W=144, H=96, seed=5, theta=-80.0 + 21.0 * i, scale_mul=2.0) for i in range(V)]
+    settings = [util.gpu_settings(c) for c in cases]
+    inp = util.gpu_inputs(cases[0])
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    means = [(inp["means3D"].detach() + 0.01 * torch.randn(2500, 3, device="cuda", generator=gen)).requires_grad_() for _ in range(V)]
+    rots = [torch.nn.functional.normalize(inp["rotations"].detach() + 0.1 * torch.randn(2500, 4, device="cuda", generator=gen)).requires_grad_()
+            for _ in range(V)]
+    tgt = torch.rand(V, 3, 96, 144, device="cuda", generator=gen)
+    shared = ("opacities", "shs", "scales")
+
+    def run(batched):
+        for k in shared:
+            inp[k].grad = None
+        for t in means + rots:
+            t.grad = None
+        m2d = [torch.zeros(2500, 3, device="cuda", requires_grad=True) for _ in range(V)]
+        kws = [dict(means3D=means[i], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"], rotations=rots[i])
+               for i in range(V)]
+        outs = rasterize_views(settings, kws) if batched else [GaussianRasterizer(settings[i])(**kws[i]) for i in range(V)]
+        sum(((o[0] - tgt[i]) ** 2).mean() for i, o in enumerate(outs)).backward()
+        torch.cuda.synchronize()
+        return outs, [inp[k].grad.clone() for k in shared] + [t.grad.clone() for t in means + rots + m2d]
+    try:
+        native.lib.csplat_debug_flags(flag)
+        o_b, g_b = run(True)
+    finally:
+        native.lib.csplat_debug_flags(0)
+    o_s, g_s = run(False)
+    for a, b in zip(o_b, o_s):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for a, b in zip(g_b, g_s):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
