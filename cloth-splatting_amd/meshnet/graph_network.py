@@ -110,7 +110,15 @@ class InteractionNetwork(nn.Module):
         self._nnode_in, self._nedge_in = nnode_in, nedge_in
 
     def forward(self, x, edge_index, edge_features):
-        x_residual, edge_features_residual = x, edge_features
+        # PyG hands update() the ORIGINAL edge features (SURVEY F7): edge output = input + input
+        return self.message_update(x, edge_index, edge_features, 1.0), edge_features + edge_features
+
+    def message_update(self, x, edge_index, e_base, scale: float = 1.0):
+        """the node half of forward() for edge features `scale * e_base`.  Because every layer only doubles its edge features (F7),
+        Processor carries the encoder's edge latents e_base and the scalar 2^l through the stack instead of materialising
+        [E, L] sums per layer (and, under autograd, two [E, L] gradient accumulations per layer on the way back): the scale is
+        folded into the 128 x 128 weight block that multiplies the edge features."""
+        x_residual = x
         csr = GraphCSR.get(edge_index, x.shape[0])
         n = self._nnode_in
         # ---- message: LN(MLP(cat[x_i, x_j, e])) with the first Linear split into three column blocks
@@ -120,7 +128,8 @@ class InteractionNetwork(nn.Module):
         W = lin0.weight
         xa = x @ W[:, :n].t()                       # contribution of x_i = x[edge_index[1]]
         xb = x @ W[:, n:2 * n].t()                  # contribution of x_j = x[edge_index[0]]
-        ec = linear_rows(edge_features, W[:, 2 * n:], lin0.bias)
+        We = W[:, 2 * n:] if scale == 1.0 else W[:, 2 * n:] * scale
+        ec = linear_rows(e_base, We, lin0.bias)
         h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
         h = _tail(mlp_e, h, relu0)
         msg = layer_norm_rows(h, self.edge_fn[1])
@@ -134,8 +143,7 @@ class InteractionNetwork(nn.Module):
         hn = mlp_n[1](hn)
         hn = _tail(mlp_n, hn, True)
         x_updated = layer_norm_rows(hn, self.node_fn[1])
-        # PyG hands update() the ORIGINAL edge features (SURVEY F7): edge output = input + input
-        return x_updated + x_residual, edge_features + edge_features_residual
+        return x_updated + x_residual
 
     def inference_ok(self, x, edge_features) -> bool:
         n = self._nnode_in
@@ -199,9 +207,11 @@ class Processor(nn.Module):
                 x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt)
                 scale *= 2.0
             return x, e0 * scale
+        e_base, scale = edge_features, 1.0
         for gnn in self.gnn_stacks:
-            x, edge_features = gnn(x, edge_index, edge_features)
-        return x, edge_features
+            x = gnn.message_update(x, edge_index, e_base, scale)
+            scale *= 2.0
+        return x, (e_base * scale if len(self.gnn_stacks) else e_base)
 
 
 class Decoder(nn.Module):
