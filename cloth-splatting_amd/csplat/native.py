@@ -79,6 +79,8 @@ EXPORTS = {
     "csplat_gnn_segment_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "csplat_gnn_gather_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "csplat_gnn_edge_features": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "csplat_dw128_workspace_bytes": (_sz, [_i64]),
+    "csplat_dw128": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "csplat_ln128_partial_floats": (_sz, [_i64]),
     "csplat_ln128_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _vp]),
     "csplat_ln128_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

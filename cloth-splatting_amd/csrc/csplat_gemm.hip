@@ -647,3 +647,151 @@ extern "C" int csplat_gnn_node_update(void *stream, int64_t N, const float *agg,
     LAUNCH_CHECK();
     return 0;
 }
+
+// ---- weight gradient of the 128 -> 128 Linear layers under autograd: dW[o][i] = sum_e g[e][o] * x[e][i]  (g, x [M][128]; M = E
+// = 3e5 for the edge MLPs, M = N = 1e4 for the node MLPs).  A [128 x M] x [M x 128] product whose reduction runs over the ROWS:
+// as a library call it is reduced inside 16 workgroups (630 us at M = 3e5, 56 us at M = 1e4), as a batched split-K call + sum
+// 235 us (round 1).  Here: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) fed from the row-major inputs as they stand.  The MFMA wants
+// lane l to supply A[m = l % 32][k = l / 32] and B[k = l / 32][n = l % 32]; k is the ROW of the pair (e, e + 1), and which output
+// row a lane's m stands for is ours to choose -- so lane l loads ONE float4 of g and one of x (columns 4c .. 4c + 3 of row e + l / 32,
+// c = l % 32: a wave reads two whole 512-byte rows per instruction) and component i of the g vector against component j of the x
+// vector is the MFMA for output rows {4m + i} x columns {4n + j}: 16 MFMAs on 16 independent accumulator tiles per row pair, the
+// whole 128 x 128 result in one wave's accumulators (256 registers), no LDS, no transposes, every input byte loaded once.
+// The 4 waves of a workgroup take different row ranges and are summed through LDS in wave order; per-workgroup partials go to a
+// workspace and k_dw128_reduce sums them in workgroup order (deterministic).  Next group's loads are issued before this group's
+// MFMAs (one wave per SIMD: the prefetch is what hides HBM latency).  9.8 GFLOP at the 157 TFLOP/s fp32-MFMA rate = 63 us;
+// 307 MB at the ~4.5 TB/s a streaming read sustains = 68 us.
+namespace {
+constexpr int DW_GROUP = 4;        // row pairs per prefetch group
+constexpr int DW_WG_MAX = 256;     // one workgroup per CU
+__global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__restrict__ G, const float4 *__restrict__ X,
+                                                  float4 *__restrict__ part, int64_t rows_per_wave) {
+    __shared__ float4 s_acc[4 * 16 * 64];                               // a quarter of every wave's accumulators: [wave][r][lane]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int kk = lane >> 5, c = lane & 31;
+    // the wave's row range, in scalar registers: loop control and the group base addresses stay on the scalar unit
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+    const int64_t r1 = r0 + rows_per_wave < M ? r0 + rows_per_wave : M;
+    const int rows = r1 > r0 ? (int)(r1 - r0) : 0;
+    const int n_full = rows / (2 * DW_GROUP);                           // groups of DW_GROUP row pairs that need no bounds
+    const int total = n_full + (rows % (2 * DW_GROUP) ? 1 : 0);         // + one ragged group
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int lane_at = kk * 32 + c;                                    // float4 index of this lane inside a row pair
+    auto issue = [&](float4 (&gv)[DW_GROUP], float4 (&xv)[DW_GROUP], int g) {
+        const float4 *gp = G + (r0 + (int64_t)g * 2 * DW_GROUP) * 32, *xp = X + (r0 + (int64_t)g * 2 * DW_GROUP) * 32;
+#pragma unroll
+        for (int u = 0; u < DW_GROUP; u++) { gv[u] = gp[u * 64 + lane_at]; xv[u] = xp[u * 64 + lane_at]; }
+    };
+    auto issue_ragged = [&](float4 (&gv)[DW_GROUP], float4 (&xv)[DW_GROUP], int g) {
+        const float4 *gp = G + (r0 + (int64_t)g * 2 * DW_GROUP) * 32, *xp = X + (r0 + (int64_t)g * 2 * DW_GROUP) * 32;
+        const int left = rows - g * 2 * DW_GROUP;
+#pragma unroll
+        for (int u = 0; u < DW_GROUP; u++) {                            // rows past r1 re-read the last row with a zeroed g operand
+            const int e = 2 * u + kk;
+            const int at = (e < left ? e : left - 1) * 32 + c;
+            const float4 gl = gp[at];
+            xv[u] = xp[at];
+            gv[u] = e < left ? gl : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto mfma = [&](const float4 (&gv)[DW_GROUP], const float4 (&xv)[DW_GROUP]) {
+#pragma unroll
+        for (int u = 0; u < DW_GROUP; u++) {
+            const float a[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, b[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // full groups: group g + 1 is in flight under group g's 16 * DW_GROUP MFMAs (the last one re-reads itself: no branch)
+    float4 gq[DW_GROUP], xq[DW_GROUP];
+    if (n_full > 0) issue(gq, xq, 0);
+    for (int g = 0; g < n_full; g++) {
+        float4 gn[DW_GROUP], xn[DW_GROUP];
+        issue(gn, xn, g + 1 < n_full ? g + 1 : g);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(gq, xq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < DW_GROUP; u++) { gq[u] = gn[u]; xq[u] = xn[u]; }
+    }
+    if (total > n_full) {                                               // the ragged group, once per wave
+        issue_ragged(gq, xq, n_full);
+        mfma(gq, xq);
+    }
+    // the four waves' tiles are summed through LDS a quarter (one i) at a time: every wave parks acc[i][0..3][0..15] as 16 float4 per
+    // lane, then wave w sums registers r = w, w + 4, w + 8, w + 12 of the four copies in wave order and stores them (plain LDS reads
+    // and writes straight from the accumulator registers: LDS float atomics cost ~200 cycles per wave instruction here).
+    // Accumulator register r of lane l holds D[m = 8 * (r / 4) + 4 * (l / 32) + r % 4][n = l % 32] = dW[4 m + i][4 n + j].
+    float4 *P = part + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            s_acc[(wave * 16 + r) * 64 + lane] = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int r = wave + 4 * t;
+            float4 v = s_acc[r * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                const float4 o = s_acc[(w * 16 + r) * 64 + lane];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            const int m = 8 * (r / 4) + 4 * kk + (r % 4);
+            P[(4 * m + i) * 32 + c] = v;
+        }
+        __syncthreads();
+    }
+}
+// dW[t] = sum over partials in workgroup order: 256 blocks x (16 outputs x 16 partial lanes), lanes then combined in lane order
+__global__ __launch_bounds__(256) void k_dw128_reduce(int nparts, const float4 *__restrict__ part, float4 *__restrict__ dW) {
+    __shared__ float4 s[256];
+    const int o = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + o;                                  // one float4 of the 128 x 128 result
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = pl; p < nparts; p += 16) {
+        const float4 v = part[(size_t)p * 4096 + t];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    s[threadIdx.x] = a;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < 16; k++) {
+            const float4 v = s[k * 16 + o];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        dW[t] = a;
+    }
+}
+// workgroups: one per CU at most, and at least 2 * DW_GROUP row pairs per wave before another workgroup is worth its partial
+int dw128_parts(int64_t M) {
+    const int64_t want = (M + 4 * 4 * DW_GROUP - 1) / (4 * 4 * DW_GROUP);
+    return (int)(want < 1 ? 1 : (want > DW_WG_MAX ? DW_WG_MAX : want));
+}
+}  // namespace
+
+extern "C" size_t csplat_dw128_workspace_bytes(int64_t M) { return (size_t)dw128_parts(M) * 128 * 128 * 4; }
+
+extern "C" int csplat_dw128(void *stream, int64_t M, const float *g, const float *x, float *dW, void *workspace) {
+    CSPLAT_REQUIRE(M >= 0 && dW && (M == 0 || (g && x && workspace)), "csplat_dw128: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)dW | (uintptr_t)workspace | (uintptr_t)g | (uintptr_t)x) & 15u) == 0, "csplat_dw128: 16-byte aligned buffers");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) { HIP_TRY(hipMemsetAsync(dW, 0, 128 * 128 * 4, s)); return 0; }
+    const int parts = dw128_parts(M);
+    int64_t rows = (M + (int64_t)parts * 4 - 1) / ((int64_t)parts * 4);
+    rows += rows & 1;                                         // whole row pairs per wave
+    k_dw128<<<parts, 256, 0, s>>>(M, (const float4 *)g, (const float4 *)x, (float4 *)workspace, rows);
+    LAUNCH_CHECK();
+    k_dw128_reduce<<<256, 256, 0, s>>>(parts, (const float4 *)workspace, (float4 *)dW);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -11,7 +11,8 @@ Semantics reproduced from PyG `MessagePassing(aggr='add')`:
 MI355X design: the [E, 3L] concat is never built.  W1 of the edge MLP is applied as three column blocks:
 x @ W_i^T and x @ W_j^T at node level (N rows), e @ W_e^T at edge level; csplat_gnn_edge_combine_fwd gathers and
 adds them (+ReLU) in one HBM pass.  The scatter-add is csplat_gnn_segment_sum over a CSR-by-destination order
-(deterministic).  The node MLP's cat[agg, x] is likewise split.  GEMMs stay on rocBLAS (torch.addmm).
+(deterministic).  The node MLP's cat[agg, x] is likewise split.  Node-level y and dx GEMMs stay on rocBLAS; every 128 x 128
+weight gradient (edge AND node level) is csplat_dw128.
 """
 from typing import List
 
@@ -126,8 +127,8 @@ class InteractionNetwork(nn.Module):
         lin0 = mlp_e[0]
         relu0 = isinstance(mlp_e[1], nn.ReLU)
         W = lin0.weight
-        xa = x @ W[:, :n].t()                       # contribution of x_i = x[edge_index[1]]
-        xb = x @ W[:, n:2 * n].t()                  # contribution of x_j = x[edge_index[0]]
+        xa = linear_rows(x, W[:, :n], None)         # contribution of x_i = x[edge_index[1]]
+        xb = linear_rows(x, W[:, n:2 * n], None)    # contribution of x_j = x[edge_index[0]]
         We = W[:, 2 * n:] if scale == 1.0 else W[:, 2 * n:] * scale
         ec = linear_rows(e_base, We, lin0.bias)
         h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
@@ -139,7 +140,7 @@ class InteractionNetwork(nn.Module):
         mlp_n = self.node_fn[0]
         l0 = mlp_n[0]
         a = agg.shape[1]
-        hn = torch.addmm(l0.bias, agg, l0.weight[:, :a].t()) + x @ l0.weight[:, a:].t()
+        hn = linear_rows(agg, l0.weight[:, :a], l0.bias) + linear_rows(x, l0.weight[:, a:], None)
         hn = mlp_n[1](hn)
         hn = _tail(mlp_n, hn, True)
         x_updated = layer_norm_rows(hn, self.node_fn[1])

@@ -251,14 +251,27 @@ def relu_mask_bias128(g, out):
     return (gm if gm is not None else g), db
 
 
+def dw128(g, x):
+    """g^T @ x for [M, 128] fp32 rows -> [128, 128] (csplat_dw128: fp32 MFMA on the row-major operands, deterministic split-K)"""
+    g, x = _f32(g), _f32(x)
+    M = g.shape[0]
+    dW = torch.empty(128, 128, dtype=torch.float32, device=g.device)
+    ws = torch.empty(max(int(_n.lib.csplat_dw128_workspace_bytes(M)), 256), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device):
+        _n.check(_n.lib.csplat_dw128(_n.stream_handle(g.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(dW), _n.ptr(ws)), "csplat_dw128")
+    return dW
+
+
 class SplitKLinear(torch.autograd.Function):
-    """y = relu?(x @ weight^T + bias) for edge-level activations (rows = E ~ 3e5) under autograd.
-    128 -> 128 fp32 layers run through csplat_linear128 both ways (forward with bias / ReLU in the epilogue, input gradient
-    as the same kernel on the transposed weight): 76 us against 142 us + a ReLU pass for the library call.  The weight
-    gradient g^T @ x is a [128 x E] x [E x 128] product: a single GEMM call reduces over E inside a handful of workgroups
-    (630 us at E = 300k on MI355X); cut into row chunks and run as one batched GEMM + a sum it fills the chip (122 us)."""
+    """y = relu?(x @ weight^T + bias) for 128 -> 128 fp32 layers under autograd (edge level: rows = E ~ 3e5; node level: N ~ 1e4).
+    Tall inputs (>= BIG_ROWS) run through csplat_linear128 both ways (forward with bias / ReLU in the epilogue, input gradient as
+    the same kernel on the transposed weight): 76 us against 142 us + a ReLU pass for the library call; shorter ones keep the
+    library GEMM for y and dx.  The weight gradient g^T @ x is a [128 x M] x [M x 128] product reduced over the ROWS: the library
+    call reduces inside 16 workgroups (630 us at M = 3e5, 56 us at M = 1e4) -- csplat_dw128 splits the rows over the chip at every
+    M.  Other shapes / dtypes: plain torch, with the weight gradient as a chunked batched GEMM."""
 
     CHUNK = 3072
+    BIG_ROWS = 16384
 
     @staticmethod
     def _fast(x, weight):
@@ -267,7 +280,8 @@ class SplitKLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
-        fast = SplitKLinear._fast(x, weight)
+        kern = SplitKLinear._fast(x, weight)
+        fast = kern and x.shape[0] >= SplitKLinear.BIG_ROWS
         if fast:
             out = linear128(x, weight, bias, relu=relu)
         else:
@@ -275,7 +289,7 @@ class SplitKLinear(torch.autograd.Function):
             if relu:
                 out = out.relu_()
         ctx.save_for_backward(x, weight, out if relu else None)
-        ctx.has_bias, ctx.relu, ctx.fast = bias is not None, bool(relu), fast
+        ctx.has_bias, ctx.relu, ctx.fast, ctx.kern = bias is not None, bool(relu), fast, kern
         return out
 
     @staticmethod
@@ -284,7 +298,8 @@ class SplitKLinear(torch.autograd.Function):
         g = g.contiguous()
         db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.fast and g.shape[1] == 128 and g.dtype == torch.float32 and (ctx.relu or want_db):
+        kern = ctx.kern and g.dtype == torch.float32 and g.shape[0] > 0
+        if kern and (ctx.relu or want_db):
             g, db = relu_mask_bias128(g, out if ctx.relu else None)      # ReLU backward + bias gradient: one pass
         elif ctx.relu:
             g = torch.ops.aten.threshold_backward(g, out, 0)
@@ -292,7 +307,9 @@ class SplitKLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = linear128(g, weight.t()) if ctx.fast else g @ weight
         dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and kern:
+            dw = dw128(g, x.contiguous())
+        elif ctx.needs_input_grad[1]:
             M, C = x.shape[0], x.shape[0] // SplitKLinear.CHUNK
             m0 = C * SplitKLinear.CHUNK
             xc = x.contiguous()
@@ -300,14 +317,17 @@ class SplitKLinear(torch.autograd.Function):
                            xc[:m0].view(C, SplitKLinear.CHUNK, -1)).sum(0) if C else torch.zeros_like(weight)
             if m0 < M:
                 dw = dw + g[m0:].t() @ xc[m0:]
-        if db is None and want_db:
+        if want_db and db is None:
             db = g.sum(0)
         return dx, dw, (db if want_db else None), None
 
 
 def linear_rows(x, lin_weight, lin_bias, min_rows: int = 16384, relu: bool = False):
-    """nn.Linear (+ ReLU) forward that switches to SplitKLinear for tall inputs while a graph is being recorded."""
-    if x.shape[0] >= min_rows and torch.is_grad_enabled() and (lin_weight.requires_grad or x.requires_grad):
+    """nn.Linear (+ ReLU) forward that switches to SplitKLinear while a graph is being recorded: for tall inputs of any width, and
+    for 128 -> 128 fp32 GPU layers from 512 rows up (the library's weight-gradient GEMM reduces the rows inside 16 workgroups)."""
+    rows = x.shape[0]
+    if torch.is_grad_enabled() and (lin_weight.requires_grad or x.requires_grad) and \
+            (rows >= min_rows or (rows >= 512 and lin_weight.requires_grad and SplitKLinear._fast(x, lin_weight))):
         return SplitKLinear.apply(x, lin_weight, lin_bias, relu)
     y = torch.nn.functional.linear(x, lin_weight, lin_bias)
     return y.relu() if relu else y

@@ -360,6 +360,12 @@ int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, co
                      float *dgamma, float *dbeta, float *partials);
 int csplat_relu_mask_bias128(void *stream, int64_t M, const float *g, const float *out, float *gm, float *dbias, float *partials);
 
+/* Weight gradient of a 128 -> 128 Linear layer under autograd: dW[o][i] = sum_e g[e][o] * x[e][i], g and x [M][128] row-major,
+ * dW [128][128] (torch Linear.weight layout).  Exact-fp32 MFMA, split over row slices, partial results summed in slice order
+ * (deterministic).  workspace: csplat_dw128_workspace_bytes(M) bytes. */
+size_t csplat_dw128_workspace_bytes(int64_t M);
+int csplat_dw128(void *stream, int64_t M, const float *g, const float *x, float *dW, void *workspace);
+
 /* how csplat_linear128 forms its products: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products); 1 = three bf16 pieces per
  * operand and the six significant partial products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; error ~3 x 2^-24 relative
  * per term -- measured rms error vs fp64 1.2e-7, the fp32-MFMA path and the library sgemm 1.5e-7 --; 6/16 of the
