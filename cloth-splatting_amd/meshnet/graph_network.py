@@ -19,7 +19,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, layer_norm_rows, linear128, linear_rows, node_update
+from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, edge_latent_linear, layer_norm_rows, linear128, linear_rows, node_update
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -112,25 +112,26 @@ class InteractionNetwork(nn.Module):
 
     def forward(self, x, edge_index, edge_features):
         # PyG hands update() the ORIGINAL edge features: edge output = input + input
-        return self.message_update(x, edge_index, edge_features, 1.0), edge_features + edge_features
+        return self.message_update(x, edge_index, edge_features, 1.0)[0], edge_features + edge_features
 
     def message_update(self, x, edge_index, e_base, scale: float = 1.0):
-        """the node half of forward() for edge features `scale * e_base`.  Because every layer only doubles its edge features (F7),
-        Processor carries the encoder's edge latents e_base and the scalar 2^l through the stack instead of materialising
-        [E, L] sums per layer (and, under autograd, two [E, L] gradient accumulations per layer on the way back): the scale is
-        folded into the 128 x 128 weight block that multiplies the edge features."""
+        """the node half of forward() for edge features `scale * e_base`; returns (x_new, e_base to hand to the next layer).
+        Because every layer only doubles its edge features (F7), Processor carries the encoder's edge latents e_base and the scalar
+        2^l through the stack instead of materialising [E, L] sums per layer; the scale rides in the GEMM's alpha, and e_base is
+        CHAINED through the layers (graph_ops.EdgeLatentLinear) so that its gradient is summed inside the layers' input-gradient
+        GEMMs instead of by 14 separate [E, L] additions."""
         x_residual = x
         csr = GraphCSR.get(edge_index, x.shape[0])
         n = self._nnode_in
-        # ---- message: LN(MLP(cat[x_i, x_j, e])) with the first Linear split into three column blocks
+        # ---- message: LN(MLP(cat[x_i, x_j, e])) with the first Linear split into three column blocks; its bias rides on the x_i
+        # block (N rows, and its gradient is a column sum over N rows instead of E)
         mlp_e = self.edge_fn[0]
         lin0 = mlp_e[0]
         relu0 = isinstance(mlp_e[1], nn.ReLU)
         W = lin0.weight
-        xa = linear_rows(x, W[:, :n], None)         # contribution of x_i = x[edge_index[1]]
+        xa = linear_rows(x, W[:, :n], lin0.bias)    # contribution of x_i = x[edge_index[1]]
         xb = linear_rows(x, W[:, n:2 * n], None)    # contribution of x_j = x[edge_index[0]]
-        We = W[:, 2 * n:] if scale == 1.0 else W[:, 2 * n:] * scale
-        ec = linear_rows(e_base, We, lin0.bias)
+        ec, e_next = edge_latent_linear(e_base, W[:, 2 * n:], scale)
         h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
         h = _tail(mlp_e, h, relu0)
         msg = layer_norm_rows(h, self.edge_fn[1])
@@ -144,7 +145,7 @@ class InteractionNetwork(nn.Module):
         hn = mlp_n[1](hn)
         hn = _tail(mlp_n, hn, True)
         x_updated = layer_norm_rows(hn, self.node_fn[1])
-        return x_updated + x_residual
+        return x_updated + x_residual, e_next
 
     def inference_ok(self, x, edge_features) -> bool:
         n = self._nnode_in
@@ -210,7 +211,7 @@ class Processor(nn.Module):
             return x, e0 * scale
         e_base, scale = edge_features, 1.0
         for gnn in self.gnn_stacks:
-            x = gnn.message_update(x, edge_index, e_base, scale)
+            x, e_base = gnn.message_update(x, edge_index, e_base, scale)
             scale *= 2.0
         return x, (e_base * scale if len(self.gnn_stacks) else e_base)
 

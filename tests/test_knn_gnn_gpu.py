@@ -372,8 +372,23 @@ def _gnn_fuzz_seeds():
 def test_gnn_irregular_graphs_vs_oracle(seed):
     """EncodeProcessDecode at the config-4 width (L = 128: the csplat_linear128 / node-update kernels in the no-grad path, the
     EdgeCombine / SegmentSum / split-K functions under autograd) against oracle/gnn_ref.py in fp64, forward and backward."""
-    from meshnet.graph_network import EncodeProcessDecode
     N, ei_np = _irregular_graph(seed)
+    _training_path_vs_fp64(seed, N, ei_np)
+
+
+def test_gnn_tall_graph_training_path_vs_oracle():
+    """the same check on a graph with E >= 16384 edges: the edge-level layers take csplat_linear128 both ways, csplat_dw128, and the
+    chained edge-latent gradient (graph_ops.EdgeLatentLinear) -- the functions the config-4 train step runs"""
+    from meshnet.graph_ops import SplitKLinear
+    rng = np.random.default_rng(77)
+    N, E = 2500, 40_000
+    assert E >= SplitKLinear.BIG_ROWS
+    ei_np = np.stack([rng.integers(0, N, E), rng.integers(0, N, E)]).astype(np.int64)
+    _training_path_vs_fp64(77, N, ei_np)
+
+
+def _training_path_vs_fp64(seed, N, ei_np):
+    from meshnet.graph_network import EncodeProcessDecode
     E = ei_np.shape[1]
     torch.manual_seed(seed)
     net = EncodeProcessDecode(8, 3, 4, 128, 3, 2, 128).cuda()

@@ -28,7 +28,7 @@ def run(n_, x_, ei_, e_, w_, product):
     scale = 1.0
     for li, g_ in enumerate(n_._processor.gnn_stacks):
         if product:
-            h = g_.message_update(h, ei_, ee, scale); scale *= 2.0
+            h, ee = g_.message_update(h, ei_, ee, scale); scale *= 2.0
         else:
             pre = torch.cat([h.index_select(0, ei_[1]), h.index_select(0, ei_[0]), ee * scale], -1)
             mlp = g_.edge_fn[0]
