@@ -57,14 +57,17 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
                                                     const float *__restrict__ ga, const int64_t *__restrict__ ia,
                                                     const float *__restrict__ gb, const int64_t *__restrict__ ib,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                    const float *add_pre, const float *add_post, float *out) {
+                                                    const float *add_pre, const float *add_post, float *out,
+                                                    int ldw, int wt, const float *mask) {
+    // W is read as W[j][k] = W[j * ldw + k] (wt = 0: a torch Linear.weight, or a column slice of a wider one) or as
+    // W[k * ldw + j] (wt = 1: the TRANSPOSE of such a matrix -- the input-gradient product -- without a transposed copy)
     extern __shared__ float s_wt[];   // fp32 path: [GK][WT_STRIDE], s_wt[k * WT_STRIDE + j] = W[j][k];  B3: bf16 [3][GN][WB_STRIDE]
     constexpr int NW = B3 ? 8 : 4;    // wavefronts per workgroup
     if (B3) {
         __bf16 *wb = reinterpret_cast<__bf16 *>(s_wt);
         for (int t = threadIdx.x; t < GN * GK; t += NW * 64) {
             const int j = t >> 7, k = t & 127;
-            const float x = W[t];
+            const float x = wt ? W[(size_t)k * ldw + j] : W[(size_t)j * ldw + k];
             const __bf16 p1 = (__bf16)x;
             const float r1 = x - (float)p1;
             const __bf16 p2 = (__bf16)r1;
@@ -76,7 +79,12 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
     } else {   // all 16 float4 loads of a thread in flight at once; W[j][4i..4i+3] -> rows 4i..4i+3 of W^T
         float4 wv[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) wv[i] = reinterpret_cast<const float4 *>(W)[threadIdx.x + 256 * i];
+        for (int i = 0; i < 16; i++) {
+            const int t = threadIdx.x + 256 * i, j = t >> 5, k = (t & 31) * 4;
+            if (!wt && !(ldw & 3)) wv[i] = *reinterpret_cast<const float4 *>(W + (size_t)j * ldw + k);
+            else if (!wt) wv[i] = make_float4(W[(size_t)j * ldw + k], W[(size_t)j * ldw + k + 1], W[(size_t)j * ldw + k + 2], W[(size_t)j * ldw + k + 3]);
+            else wv[i] = make_float4(W[(size_t)k * ldw + j], W[(size_t)(k + 1) * ldw + j], W[(size_t)(k + 2) * ldw + j], W[(size_t)(k + 3) * ldw + j]);
+        }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int t = threadIdx.x + 256 * i, j = t >> 5, k = (t & 31) * 4;
@@ -280,6 +288,10 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
 #pragma unroll
                 for (int c = 0; c < 4; c++) v[c] += add_post[arow * GN + 32 * c + r32];
             }
+            if (ADD && mask) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = mask[arow * GN + 32 * c + r32] > 0.f ? v[c] : 0.f;
+            }
             if (orow < M) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) out[orow * GN + 32 * c + r32] = v[c];
@@ -298,16 +310,21 @@ template <bool LN>
 __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float *A, const float *__restrict__ W,
                                                            const float *__restrict__ bias, float alpha, int relu,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                           const float *add_pre, const float *add_post, float *out) {
+                                                           const float *add_pre, const float *add_post, float *out,
+                                                           int ldw, int wt, const float *mask) {
     extern __shared__ float s_dyn[];
     float (*s_w)[GK * SW_STRIDE] = reinterpret_cast<float (*)[GK * SW_STRIDE]>(s_dyn);   // per wave: s_w[w][k * 33 + jj] = W[32w + jj][k]
     float (*s_part)[32][4] = reinterpret_cast<float (*)[32][4]>(s_dyn + 4 * GK * SW_STRIDE);   // [pass][row][wave] partial sums
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
     {
         float4 wv[16];
-        const float4 *wp = reinterpret_cast<const float4 *>(W + (size_t)32 * w * GK);
 #pragma unroll
-        for (int i = 0; i < 16; i++) wv[i] = wp[lane + 64 * i];
+        for (int i = 0; i < 16; i++) {
+            const int idx = lane + 64 * i, j = 32 * w + (idx >> 5), k = (idx & 31) * 4;
+            if (!wt && !(ldw & 3)) wv[i] = *reinterpret_cast<const float4 *>(W + (size_t)j * ldw + k);
+            else if (!wt) wv[i] = make_float4(W[(size_t)j * ldw + k], W[(size_t)j * ldw + k + 1], W[(size_t)j * ldw + k + 2], W[(size_t)j * ldw + k + 3]);
+            else wv[i] = make_float4(W[(size_t)k * ldw + j], W[(size_t)(k + 1) * ldw + j], W[(size_t)(k + 2) * ldw + j], W[(size_t)(k + 3) * ldw + j]);
+        }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int idx = lane + 64 * i, jj = idx >> 5, k = (idx & 31) * 4;
@@ -380,6 +397,7 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
         if (orow < M) {
             float o = v[r];
             if (add_post) o += add_post[orow * GN + col];
+            if (mask) o = mask[orow * GN + col] > 0.f ? o : 0.f;
             out[orow * GN + col] = o;
         }
     }
@@ -557,14 +575,23 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
                                 const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
                                 const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,
                                 const float *add_post, float *out) {
-    CSPLAT_REQUIRE(M >= 0 && (M == 0 || (A && W && out)), "csplat_linear128: bad arguments");
+    return csplat_linear128_ex(stream, M, A, W, 128, 0, bias, alpha, relu, gather_a, index_a, gather_b, index_b, ln_gamma, ln_beta, ln_eps,
+                               add_pre, add_post, nullptr, out);
+}
+
+extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
+                                   float alpha, int relu, const float *gather_a, const int64_t *index_a, const float *gather_b,
+                                   const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                                   const float *add_pre, const float *add_post, const float *mask, float *out) {
+    CSPLAT_REQUIRE(M >= 0 && (M == 0 || (A && W && out)) && ldw >= 128, "csplat_linear128: bad arguments");
     CSPLAT_REQUIRE((((uintptr_t)A | (uintptr_t)out | (uintptr_t)W) & 15u) == 0, "csplat_linear128: A / W / out must be 16-byte aligned");
+    const int wt = w_transposed ? 1 : 0;
     if (M == 0) return 0;
     const bool gather = gather_a != nullptr;
     CSPLAT_REQUIRE(!gather || (index_a && gather_b && index_b), "csplat_linear128: gather needs both row sets and both index arrays");
     const bool ln = ln_gamma != nullptr;
     CSPLAT_REQUIRE(!ln || ln_beta, "csplat_linear128: LayerNorm needs gamma and beta");
-    const bool add = add_pre != nullptr || add_post != nullptr;
+    const bool add = add_pre != nullptr || add_post != nullptr || mask != nullptr;
     CSPLAT_REQUIRE(!(add && gather), "csplat_linear128: row-aligned addends and gathers are not combined (no caller needs it)");
     static int s_ok = -1;
     const size_t lds = L128_LDS_F32 + 4 * 64 * sizeof(int);      // W^T + the gather-index strips
@@ -590,9 +617,9 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
     if (!gather && ntile <= 2048) {   // node-level sizes: one tile per workgroup, columns split across its waves
         const size_t lds_small = (size_t)(4 * GK * SW_STRIDE + 2 * 32 * 4) * sizeof(float);
         if (ln)
-            k_linear128_rows32<true><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);
+            k_linear128_rows32<true><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask);
         else
-            k_linear128_rows32<false><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);
+            k_linear128_rows32<false><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask);
         LAUNCH_CHECK();
         return 0;
     }
@@ -604,10 +631,10 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
     do {                                                                                                                      \
         if (b3)                                                                                                               \
             k_linear128<G, L, D, true><<<grid, 512, lds_b3, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, \
-                                                                 ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);          \
+                                                                 ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask); \
         else                                                                                                                  \
             k_linear128<G, L, D, false><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b,  \
-                                                               ln_gamma, ln_beta, ln_eps, add_pre, add_post, out);            \
+                                                               ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask); \
     } while (0)
     if (add && ln) CSPLAT_L128(false, true, true);
     else if (add) CSPLAT_L128(false, false, true);
@@ -664,6 +691,8 @@ extern "C" int csplat_gnn_node_update(void *stream, int64_t N, const float *agg,
 namespace {
 constexpr int DW_GROUP = 4;        // row pairs per prefetch group
 constexpr int DW_WG_MAX = 256;     // one workgroup per CU
+constexpr int DW_PART = 4096 + 32;  // float4 per workgroup partial: the 128 x 128 tile + the 128 column sums of g
+template <bool BIAS, bool XRELU>
 __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__restrict__ G, const float4 *__restrict__ X,
                                                   float4 *__restrict__ part, int64_t rows_per_wave) {
     __shared__ float4 s_acc[4 * 16 * 64];                               // a quarter of every wave's accumulators: [wave][r][lane]
@@ -683,6 +712,7 @@ __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__res
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int lane_at = kk * 32 + c;                                    // float4 index of this lane inside a row pair
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);                      // BIAS: this lane's share of the column sums of g
     auto issue = [&](float4 (&gv)[DW_GROUP], float4 (&xv)[DW_GROUP], int g) {
         const float4 *gp = G + (r0 + (int64_t)g * 2 * DW_GROUP) * 32, *xp = X + (r0 + (int64_t)g * 2 * DW_GROUP) * 32;
 #pragma unroll
@@ -703,7 +733,13 @@ __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__res
     auto mfma = [&](const float4 (&gv)[DW_GROUP], const float4 (&xv)[DW_GROUP]) {
 #pragma unroll
         for (int u = 0; u < DW_GROUP; u++) {
-            const float a[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, b[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            const float a[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            float b[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            if (XRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = fmaxf(b[j], 0.f);
+            }
+            if (BIAS) { gsum.x += a[0]; gsum.y += a[1]; gsum.z += a[2]; gsum.w += a[3]; }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -730,7 +766,18 @@ __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__res
     // lane, then wave w sums registers r = w, w + 4, w + 8, w + 12 of the four copies in wave order and stores them (plain LDS reads
     // and writes straight from the accumulator registers: LDS float atomics cost ~200 cycles per wave instruction here).
     // Accumulator register r of lane l holds D[m = 8 * (r / 4) + 4 * (l / 32) + r % 4][n = l % 32] = dW[4 m + i][4 n + j].
-    float4 *P = part + (size_t)blockIdx.x * 4096;
+    float4 *P = part + (size_t)blockIdx.x * DW_PART;
+    if (BIAS) {                                                         // columns 4c .. 4c + 3: the 8 (wave, row parity) shares in order
+        s_acc[wave * 64 + lane] = gsum;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float4 t = s_acc[threadIdx.x];
+#pragma unroll
+            for (int k = 1; k < 8; k++) { const float4 o = s_acc[k * 32 + threadIdx.x]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            P[4096 + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -752,14 +799,16 @@ __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__res
         __syncthreads();
     }
 }
-// dW[t] = sum over partials in workgroup order: 256 blocks x (16 outputs x 16 partial lanes), lanes then combined in lane order
-__global__ __launch_bounds__(256) void k_dw128_reduce(int nparts, const float4 *__restrict__ part, float4 *__restrict__ dW) {
+// out[t] = sum over partials in workgroup order: blocks x (16 outputs x 16 partial lanes), lanes then combined in lane order;
+// float4 t < 4096 is the weight gradient, 4096 .. 4127 the bias gradient
+__global__ __launch_bounds__(256) void k_dw128_reduce(int nparts, const float4 *__restrict__ part, float4 *__restrict__ dW,
+                                                      float4 *__restrict__ dbias) {
     __shared__ float4 s[256];
     const int o = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int t = blockIdx.x * 16 + o;                                  // one float4 of the 128 x 128 result
+    const int t = blockIdx.x * 16 + o;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = pl; p < nparts; p += 16) {
-        const float4 v = part[(size_t)p * 4096 + t];
+        const float4 v = part[(size_t)p * DW_PART + t];
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     s[threadIdx.x] = a;
@@ -769,7 +818,7 @@ __global__ __launch_bounds__(256) void k_dw128_reduce(int nparts, const float4 *
             const float4 v = s[k * 16 + o];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        dW[t] = a;
+        if (t < 4096) dW[t] = a; else dbias[t - 4096] = a;
     }
 }
 // workgroups: one per CU at most, and at least 2 * DW_GROUP row pairs per wave before another workgroup is worth its partial
@@ -779,19 +828,32 @@ int dw128_parts(int64_t M) {
 }
 }  // namespace
 
-extern "C" size_t csplat_dw128_workspace_bytes(int64_t M) { return (size_t)dw128_parts(M) * 128 * 128 * 4; }
+extern "C" size_t csplat_dw128_workspace_bytes(int64_t M) { return (size_t)dw128_parts(M) * DW_PART * 16; }
 
-extern "C" int csplat_dw128(void *stream, int64_t M, const float *g, const float *x, float *dW, void *workspace) {
+extern "C" int csplat_dw128_bias(void *stream, int64_t M, const float *g, const float *x, int x_relu, float *dW, float *dbias, void *workspace) {
     CSPLAT_REQUIRE(M >= 0 && dW && (M == 0 || (g && x && workspace)), "csplat_dw128: bad arguments");
-    CSPLAT_REQUIRE((((uintptr_t)dW | (uintptr_t)workspace | (uintptr_t)g | (uintptr_t)x) & 15u) == 0, "csplat_dw128: 16-byte aligned buffers");
+    CSPLAT_REQUIRE((((uintptr_t)dW | (uintptr_t)dbias | (uintptr_t)workspace | (uintptr_t)g | (uintptr_t)x) & 15u) == 0, "csplat_dw128: 16-byte aligned buffers");
     hipStream_t s = (hipStream_t)stream;
-    if (M == 0) { HIP_TRY(hipMemsetAsync(dW, 0, 128 * 128 * 4, s)); return 0; }
+    if (M == 0) {
+        HIP_TRY(hipMemsetAsync(dW, 0, 128 * 128 * 4, s));
+        if (dbias) HIP_TRY(hipMemsetAsync(dbias, 0, 512, s));
+        return 0;
+    }
     const int parts = dw128_parts(M);
     int64_t rows = (M + (int64_t)parts * 4 - 1) / ((int64_t)parts * 4);
     rows += rows & 1;                                         // whole row pairs per wave
-    k_dw128<<<parts, 256, 0, s>>>(M, (const float4 *)g, (const float4 *)x, (float4 *)workspace, rows);
+    const float4 *G = (const float4 *)g, *X = (const float4 *)x;
+    float4 *P = (float4 *)workspace;
+    if (dbias && x_relu) k_dw128<true, true><<<parts, 256, 0, s>>>(M, G, X, P, rows);
+    else if (dbias) k_dw128<true, false><<<parts, 256, 0, s>>>(M, G, X, P, rows);
+    else if (x_relu) k_dw128<false, true><<<parts, 256, 0, s>>>(M, G, X, P, rows);
+    else k_dw128<false, false><<<parts, 256, 0, s>>>(M, G, X, P, rows);
     LAUNCH_CHECK();
-    k_dw128_reduce<<<256, 256, 0, s>>>(parts, (const float4 *)workspace, (float4 *)dW);
+    k_dw128_reduce<<<dbias ? 258 : 256, 256, 0, s>>>(parts, P, (float4 *)dW, (float4 *)dbias);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int csplat_dw128(void *stream, int64_t M, const float *g, const float *x, float *dW, void *workspace) {
+    return csplat_dw128_bias(stream, M, g, x, 0, dW, nullptr, workspace);
 }

@@ -272,32 +272,37 @@ __global__ __launch_bounds__(LN_THREADS) void k_ln128_fwd(int64_t M, const float
 __global__ __launch_bounds__(LN_THREADS) void k_ln128_bwd(int64_t M, const float4 *__restrict__ g, const float4 *__restrict__ x,
                                                            const float2 *__restrict__ stats, const float4 *__restrict__ gamma,
                                                            float4 *__restrict__ dx, float4 *__restrict__ part_gamma,
-                                                           float4 *__restrict__ part_beta) {
-    __shared__ float4 s_g[LN_THREADS], s_b[LN_THREADS];
+                                                           float4 *__restrict__ part_beta, float4 *__restrict__ part_dx,
+                                                           const int64_t *__restrict__ g_rows) {
+    __shared__ float4 s_g[LN_THREADS], s_b[LN_THREADS], s_x[LN_THREADS];
     const int sub = threadIdx.x & 31;
     const float4 ga = gamma[sub];
-    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, ax = ag;
     for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK_ITER + (threadIdx.x >> 5); row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK_ITER) {
-        const float4 gv = g[row * 32 + sub], xv = x[row * 32 + sub];
+        const float4 gv = g[(g_rows ? g_rows[row] : row) * 32 + sub], xv = x[row * 32 + sub];
         const float2 st = stats[row];
         const float h0 = (xv.x - st.x) * st.y, h1 = (xv.y - st.x) * st.y, h2 = (xv.z - st.x) * st.y, h3 = (xv.w - st.x) * st.y;
         const float w0 = gv.x * ga.x, w1 = gv.y * ga.y, w2 = gv.z * ga.z, w3 = gv.w * ga.w;
         const float m1 = half_sum((w0 + w1) + (w2 + w3)) * (1.f / 128.f);
         const float m2 = half_sum((w0 * h0 + w1 * h1) + (w2 * h2 + w3 * h3)) * (1.f / 128.f);
-        dx[row * 32 + sub] = make_float4(st.y * (w0 - m1 - h0 * m2), st.y * (w1 - m1 - h1 * m2), st.y * (w2 - m1 - h2 * m2), st.y * (w3 - m1 - h3 * m2));
+        const float4 dv = make_float4(st.y * (w0 - m1 - h0 * m2), st.y * (w1 - m1 - h1 * m2), st.y * (w2 - m1 - h2 * m2), st.y * (w3 - m1 - h3 * m2));
+        dx[row * 32 + sub] = dv;
+        ax.x += dv.x; ax.y += dv.y; ax.z += dv.z; ax.w += dv.w;
         ag.x += gv.x * h0; ag.y += gv.y * h1; ag.z += gv.z * h2; ag.w += gv.w * h3;
         ab.x += gv.x; ab.y += gv.y; ab.z += gv.z; ab.w += gv.w;
     }
-    s_g[threadIdx.x] = ag; s_b[threadIdx.x] = ab;
+    s_g[threadIdx.x] = ag; s_b[threadIdx.x] = ab; s_x[threadIdx.x] = ax;
     __syncthreads();
     if (threadIdx.x < 32) {   // the block's 8 row-slots, in order
-        float4 tg = s_g[threadIdx.x], tb = s_b[threadIdx.x];
+        float4 tg = s_g[threadIdx.x], tb = s_b[threadIdx.x], tx = s_x[threadIdx.x];
         for (int k = 1; k < LN_ROWS_PER_BLOCK_ITER; k++) {
-            const float4 a = s_g[k * 32 + threadIdx.x], b = s_b[k * 32 + threadIdx.x];
+            const float4 a = s_g[k * 32 + threadIdx.x], b = s_b[k * 32 + threadIdx.x], c = s_x[k * 32 + threadIdx.x];
             tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w; tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
+            tx.x += c.x; tx.y += c.y; tx.z += c.z; tx.w += c.w;
         }
         part_gamma[(size_t)blockIdx.x * 32 + threadIdx.x] = tg;
         part_beta[(size_t)blockIdx.x * 32 + threadIdx.x] = tb;
+        if (part_dx) part_dx[(size_t)blockIdx.x * 32 + threadIdx.x] = tx;
     }
 }
 // column sums of [nblocks][128] partials: 8 slices of the block range summed in parallel (ascending inside a slice), then the
@@ -365,17 +370,25 @@ int csplat_ln128_fwd(void *stream, int64_t M, const float *x, const float *gamma
 }
 
 int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, const float *stats, const float *gamma, float *dx,
-                     float *dgamma, float *dbeta, float *partials) {
+                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, float *partials) {
     CSPLAT_REQUIRE(M >= 0 && (M == 0 || (g && x && stats && gamma && dx && dgamma && dbeta && partials)), "csplat_ln128_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (M == 0) { HIP_TRY(hipMemsetAsync(dgamma, 0, 512, s)); HIP_TRY(hipMemsetAsync(dbeta, 0, 512, s)); return 0; }
+    if (M == 0) {
+        HIP_TRY(hipMemsetAsync(dgamma, 0, 512, s)); HIP_TRY(hipMemsetAsync(dbeta, 0, 512, s));
+        if (dxsum) HIP_TRY(hipMemsetAsync(dxsum, 0, 512, s));
+        return 0;
+    }
     const int nb = ln_blocks(M);
-    float *pg = partials, *pb = partials + (size_t)nb * 128;
+    float *pg = partials, *pb = partials + (size_t)nb * 128, *px = dxsum ? partials + (size_t)2 * nb * 128 : nullptr;
     k_ln128_bwd<<<nb, LN_THREADS, 0, s>>>(M, (const float4 *)g, (const float4 *)x, (const float2 *)stats, (const float4 *)gamma, (float4 *)dx,
-                                          (float4 *)pg, (float4 *)pb);
+                                          (float4 *)pg, (float4 *)pb, (float4 *)px, g_rows);
     LAUNCH_CHECK();
     k_colsum128<<<2, 1024, 0, s>>>(nb, pg, pb, dgamma, dbeta);
     LAUNCH_CHECK();
+    if (dxsum) {
+        k_colsum128<<<1, 1024, 0, s>>>(nb, px, nullptr, dxsum, nullptr);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -19,7 +19,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import EdgeCombine, GraphCSR, SegmentSum, edge_latent_linear, layer_norm_rows, linear128, linear_rows, node_update
+from .graph_ops import (EdgeCombine, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows,
+                        linear128, linear_rows, node_update)
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -132,11 +133,16 @@ class InteractionNetwork(nn.Module):
         xa = linear_rows(x, W[:, :n], lin0.bias)    # contribution of x_i = x[edge_index[1]]
         xb = linear_rows(x, W[:, n:2 * n], None)    # contribution of x_j = x[edge_index[0]]
         ec, e_next = edge_latent_linear(e_base, W[:, 2 * n:], scale)
-        h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
-        h = _tail(mlp_e, h, relu0)
-        msg = layer_norm_rows(h, self.edge_fn[1])
-        # ---- aggregate: sum over destination nodes
-        agg = SegmentSum.apply(msg, csr)
+        if relu0 and edge_tail_ok(ec, self.edge_fn):
+            # tall fp32 GPU rows: the rest of the message MLP, its LayerNorm and the sum over destination nodes are one autograd node
+            h = EdgeCombine.apply(xa, xb, ec, csr, True, True)
+            agg = edge_tail_aggregate(h, csr, self.edge_fn, a0_relu=True)
+        else:
+            h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
+            h = _tail(mlp_e, h, relu0)
+            msg = layer_norm_rows(h, self.edge_fn[1])
+            # ---- aggregate: sum over destination nodes
+            agg = SegmentSum.apply(msg, csr)
         # ---- update: LN(MLP(cat[agg, x])), concat folded into two GEMMs
         mlp_n = self.node_fn[0]
         l0 = mlp_n[0]

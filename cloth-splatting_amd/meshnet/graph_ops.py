@@ -54,7 +54,9 @@ class EdgeCombine(torch.autograd.Function):
     """h[e] = relu?(xa[dst[e]] + xb[src[e]] + ec[e]) -- first edge-MLP layer with the [x_i, x_j, e] concat folded away."""
 
     @staticmethod
-    def forward(ctx, xa, xb, ec, csr, relu):
+    def forward(ctx, xa, xb, ec, csr, relu, grad_premasked=False):
+        """grad_premasked: the consumer (EdgeTailAggregate) hands back the gradient of the PRE-activation -- it folds this ReLU's
+        backward into the GEMM that produces the gradient -- so backward() must not mask again"""
         xa, xb, ec = _f32(xa), _f32(xb), _f32(ec)
         E, L = ec.shape
         out = torch.empty_like(ec)
@@ -62,7 +64,7 @@ class EdgeCombine(torch.autograd.Function):
             _n.check(_n.lib.csplat_gnn_edge_combine_fwd(_n.stream_handle(ec.device), csr.N, E, L, _n.ptr(csr.ei), _n.ptr(xa),
                                                         _n.ptr(xb), _n.ptr(ec), int(relu), _n.ptr(out)),
                      "csplat_gnn_edge_combine_fwd")
-        ctx.csr, ctx.relu = csr, bool(relu)
+        ctx.csr, ctx.relu = csr, bool(relu) and not grad_premasked
         ctx.save_for_backward(out)
         return out
 
@@ -80,7 +82,7 @@ class EdgeCombine(torch.autograd.Function):
                 _n.stream_handle(g.device), csr.N, E, L, _n.ptr(g), _n.ptr(out), int(ctx.relu), _n.ptr(csr.rowptr["dst"]),
                 _n.ptr(csr.perm["dst"]), _n.ptr(csr.rowptr["src"]), _n.ptr(csr.perm["src"]), _n.ptr(gm), _n.ptr(dxa),
                 _n.ptr(dxb)), "csplat_gnn_edge_combine_bwd")
-        return dxa, dxb, gm, None, None
+        return dxa, dxb, gm, None, None, None
 
 
 class SegmentSum(torch.autograd.Function):
@@ -147,14 +149,28 @@ def rows_dot(h, weight, bias):
     return torch.nn.functional.linear(h, weight, bias)
 
 
-def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, add_pre=None, add_post=None, out=None):
-    """Inference-only fused Linear for the 128-wide MeshNet MLP layers (csplat_linear128, include/csplat.h):
-        out = LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] + add_pre ) ) + add_post
-    A [M,128] fp32, weight [128,128] (torch Linear.weight), gather = (ga, ia, gb, ib) or None,
-    layer_norm = nn.LayerNorm(128) or None, add_pre / add_post [M,128] or None (node-level calls).  No autograd graph is recorded: callers use it under torch.no_grad()."""
+def _weight_layout(weight):
+    """(tensor whose data_ptr is W, ldw, w_transposed) for csplat_linear128_ex: row-major matrices, column slices of wider ones and
+    transposes of either are read in place; anything else is copied"""
+    w = weight.detach()
+    if w.stride(1) == 1 and w.stride(0) >= 128 and w.data_ptr() % 16 == 0:
+        return w, int(w.stride(0)), 0
+    if w.stride(0) == 1 and w.stride(1) >= 128 and w.data_ptr() % 16 == 0:
+        return w, int(w.stride(1)), 1
+    return w.contiguous(), 128, 0
+
+
+def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, add_pre=None, add_post=None, out=None,
+              mask=None):
+    """Fused Linear for the 128-wide MeshNet MLP layers (csplat_linear128_ex, include/csplat.h):
+        out = [mask > 0] * ( LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] + add_pre ) ) + add_post )
+    A [M,128] fp32, weight [128,128] (torch Linear.weight, a column slice of one, or .t() of either: read in place), gather =
+    (ga, ia, gb, ib) or None, layer_norm = nn.LayerNorm(128) or None, add_pre / add_post / mask [M,128] or None.  No autograd graph
+    is recorded: callers use it under torch.no_grad() or inside an autograd Function."""
     _n.require_cuda(A)
     assert A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == 128 and tuple(weight.shape) == (128, 128)
-    A, weight = A.contiguous(), weight.detach().contiguous()
+    A = A.contiguous()
+    weight, ldw, wt = _weight_layout(weight)
     M = A.shape[0]
     out = torch.empty_like(A) if out is None else out
     ga = ia = gb = ib = None
@@ -170,10 +186,11 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
     bias = None if bias is None else bias.detach().contiguous()
     add_pre = None if add_pre is None else _f32(add_pre)
     add_post = None if add_post is None else _f32(add_post)
+    mask = None if mask is None else _f32(mask)
     with torch.cuda.device(A.device):
-        _n.check(_n.lib.csplat_linear128(_n.stream_handle(A.device), M, _n.ptr(A), _n.ptr(weight), _n.ptr(bias), float(alpha),
-                                         int(relu), _n.ptr(ga), _n.ptr(ia), _n.ptr(gb), _n.ptr(ib), _n.ptr(g), _n.ptr(b), eps,
-                                         _n.ptr(add_pre), _n.ptr(add_post), _n.ptr(out)), "csplat_linear128")
+        _n.check(_n.lib.csplat_linear128_ex(_n.stream_handle(A.device), M, _n.ptr(A), weight.data_ptr(), ldw, wt, _n.ptr(bias), float(alpha),
+                                            int(relu), _n.ptr(ga), _n.ptr(ia), _n.ptr(gb), _n.ptr(ib), _n.ptr(g), _n.ptr(b), eps,
+                                            _n.ptr(add_pre), _n.ptr(add_post), _n.ptr(mask), _n.ptr(out)), "csplat_linear128_ex")
     return out
 
 
@@ -200,6 +217,31 @@ def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w
     return x_new, xa, xb
 
 
+def ln128_fwd(x, gamma, beta, eps):
+    """(LayerNorm(x), per-row (mean, rstd)) for [M, 128] fp32 rows: csplat_ln128_fwd"""
+    M = x.shape[0]
+    y = torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _n.check(_n.lib.csplat_ln128_fwd(_n.stream_handle(x.device), M, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), float(eps), _n.ptr(y),
+                                         _n.ptr(stats)), "csplat_ln128_fwd")
+    return y, stats
+
+
+def ln128_bwd(g, x, stats, gamma, want_dxsum=False, g_rows=None):
+    """(dx, dgamma, dbeta, column sums of dx or None) of LayerNorm over [M, 128] rows: csplat_ln128_bwd.  g_rows: row r of the incoming
+    gradient is g[g_rows[r]] (g then has as many rows as g_rows addresses)."""
+    M = x.shape[0]
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    dxsum = torch.empty_like(gamma) if want_dxsum else None
+    part = torch.empty(3 * int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _n.check(_n.lib.csplat_ln128_bwd(_n.stream_handle(x.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(stats), _n.ptr(gamma), _n.ptr(dx),
+                                         _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dxsum), _n.ptr(g_rows), _n.ptr(part)), "csplat_ln128_bwd")
+    return dx, dgamma, dbeta, dxsum
+
+
 class LayerNorm128(torch.autograd.Function):
     """nn.LayerNorm(128) on [M, 128] fp32 rows under autograd: one HBM pass forward (csplat_ln128_fwd, keeps mean / rstd per row),
     one backward (csplat_ln128_bwd: input gradient + deterministic gamma / beta gradients)."""
@@ -207,26 +249,14 @@ class LayerNorm128(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
         x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
-        M = x.shape[0]
-        y = torch.empty_like(x)
-        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _n.check(_n.lib.csplat_ln128_fwd(_n.stream_handle(x.device), M, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), float(eps), _n.ptr(y),
-                                             _n.ptr(stats)), "csplat_ln128_fwd")
+        y, stats = ln128_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, stats, gamma)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, stats, gamma = ctx.saved_tensors
-        g = _f32(g)
-        M = x.shape[0]
-        dx = torch.empty_like(x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        part = torch.empty(2 * int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _n.check(_n.lib.csplat_ln128_bwd(_n.stream_handle(x.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(stats), _n.ptr(gamma), _n.ptr(dx),
-                                             _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(part)), "csplat_ln128_bwd")
+        dx, dgamma, dbeta, _ = ln128_bwd(_f32(g), x, stats, gamma)
         return dx, dgamma, dbeta, None
 
 
@@ -251,15 +281,18 @@ def relu_mask_bias128(g, out):
     return (gm if gm is not None else g), db
 
 
-def dw128(g, x):
-    """g^T @ x for [M, 128] fp32 rows -> [128, 128] (csplat_dw128: fp32 MFMA on the row-major operands, deterministic split-K)"""
+def dw128(g, x, bias=False, x_relu=False):
+    """g^T @ x for [M, 128] fp32 rows -> [128, 128] (csplat_dw128: fp32 MFMA on the row-major operands, deterministic split over rows);
+    bias=True: (dW, column sums of g); x_relu=True: max(x, 0) in place of x"""
     g, x = _f32(g), _f32(x)
     M = g.shape[0]
     dW = torch.empty(128, 128, dtype=torch.float32, device=g.device)
+    db = torch.empty(128, dtype=torch.float32, device=g.device) if bias else None
     ws = torch.empty(max(int(_n.lib.csplat_dw128_workspace_bytes(M)), 256), dtype=torch.uint8, device=g.device)
     with torch.cuda.device(g.device):
-        _n.check(_n.lib.csplat_dw128(_n.stream_handle(g.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(dW), _n.ptr(ws)), "csplat_dw128")
-    return dW
+        _n.check(_n.lib.csplat_dw128_bias(_n.stream_handle(g.device), M, _n.ptr(g), _n.ptr(x), int(x_relu), _n.ptr(dW), _n.ptr(db), _n.ptr(ws)),
+                 "csplat_dw128_bias")
+    return (dW, db) if bias else dW
 
 
 class SplitKLinear(torch.autograd.Function):
@@ -320,6 +353,79 @@ class SplitKLinear(torch.autograd.Function):
         if want_db and db is None:
             db = g.sum(0)
         return dx, dw, (db if want_db else None), None
+
+
+class EdgeTailAggregate(torch.autograd.Function):
+    """agg = segment_sum_dst( LayerNorm( Linear_k( relu(... relu(Linear_1(a0)) ...) ) ) ): everything of an InteractionNetwork's message
+    path behind the first (split) edge Linear, as ONE autograd node over [E, 128] fp32 rows (graph_network.py:139-150 +
+    aggr='add').  What one node buys, per layer of the processor:
+      * the ReLU backward of every hidden layer is the mask epilogue of the GEMM that produces its incoming gradient
+        (csplat_linear128_ex: mask = the layer's saved output) -- no separate [E, 128] masking pass;
+      * bias gradients are column sums taken where the rows are read anyway: inside csplat_dw128_bias for the hidden layers, inside
+        csplat_ln128_bwd (dxsum) for the last one;
+      * the backward of the segmented sum (every edge takes its destination node's row) is a gathered read inside csplat_ln128_bwd,
+        not an [E, 128] copy;
+      * transposed weights are read in place.
+    a0_relu: a0 is itself the output of a ReLU (EdgeCombine with grad_premasked=True): the returned gradient is then the one of
+    its pre-activation."""
+
+    @staticmethod
+    def forward(ctx, a0, csr, eps, a0_relu, gamma, beta, *wb):
+        ctx.set_materialize_grads(False)
+        k = len(wb) // 2
+        acts = [_f32(a0)]
+        for i in range(k):
+            acts.append(linear128(acts[-1], wb[2 * i], wb[2 * i + 1], relu=i + 1 < k))
+        msg, stats = ln128_fwd(acts[-1], _f32(gamma), _f32(beta), eps)
+        E, L = msg.shape
+        agg = torch.empty(csr.N, L, dtype=torch.float32, device=msg.device)
+        with torch.cuda.device(msg.device):
+            _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(msg.device), csr.N, E, L, _n.ptr(msg),
+                                                   _n.ptr(csr.rowptr["dst"]), _n.ptr(csr.perm["dst"]), _n.ptr(agg)),
+                     "csplat_gnn_segment_sum")
+        ctx.csr, ctx.k, ctx.a0_relu = csr, k, bool(a0_relu)
+        ctx.save_for_backward(stats, gamma, *acts, *wb[0::2])
+        return agg
+
+    @staticmethod
+    def backward(ctx, g_agg):
+        k, csr = ctx.k, ctx.csr
+        saved = ctx.saved_tensors
+        stats, gamma, acts, weights = saved[0], saved[1], saved[2:3 + k], saved[3 + k:]
+        if g_agg is None:
+            return (None,) * (6 + 2 * k)
+        d, dgamma, dbeta, db_last = ln128_bwd(_f32(g_agg), acts[k], stats, _f32(gamma), want_dxsum=True, g_rows=csr.ei[1])
+        grads = [None] * (2 * k)
+        for i in range(k - 1, -1, -1):                     # Linear i + 1 maps acts[i] -> acts[i + 1]
+            if i == k - 1:
+                grads[2 * i], grads[2 * i + 1] = dw128(d, acts[i]), db_last
+            else:
+                grads[2 * i], grads[2 * i + 1] = dw128(d, acts[i], bias=True)
+            if i > 0 or ctx.needs_input_grad[0]:
+                d = linear128(d, weights[i].t(), mask=acts[i] if (i > 0 or ctx.a0_relu) else None)
+        return (d if ctx.needs_input_grad[0] else None, None, None, None, dgamma, dbeta, *grads)
+
+
+def edge_tail_ok(a0, seq) -> bool:
+    """[build_mlp(...), LayerNorm] whose layers behind the first are 128 -> 128 fp32 Linear (+ ReLU, Identity last) with biases, on
+    tall GPU rows under autograd: the shape EdgeTailAggregate covers"""
+    mlp, ln = seq[0], seq[1]
+    mods = list(mlp.children())
+    lins, acts = mods[2::2], mods[3::2]
+    return torch.is_grad_enabled() and a0.is_cuda and a0.dtype == torch.float32 and a0.dim() == 2 and a0.shape[1] == 128 and \
+        a0.shape[0] >= SplitKLinear.BIG_ROWS and len(lins) >= 1 and isinstance(ln, torch.nn.LayerNorm) and \
+        tuple(ln.normalized_shape) == (128,) and ln.elementwise_affine and ln.bias is not None and \
+        all(isinstance(m, torch.nn.Linear) and tuple(m.weight.shape) == (128, 128) and m.bias is not None and
+            m.weight.dtype == torch.float32 for m in lins) and \
+        all(isinstance(a, torch.nn.ReLU) for a in acts[:-1]) and isinstance(acts[-1], torch.nn.Identity) and \
+        isinstance(mods[1], torch.nn.ReLU)
+
+
+def edge_tail_aggregate(a0, csr, seq, a0_relu=True):
+    """EdgeTailAggregate over the layers of seq = [build_mlp, LayerNorm] behind the first Linear (+ ReLU)"""
+    lins = list(seq[0].children())[2::2]
+    wb = [t for m in lins for t in (m.weight, m.bias)]
+    return EdgeTailAggregate.apply(a0, csr, float(seq[1].eps), a0_relu, seq[1].weight, seq[1].bias, *wb)
 
 
 class EdgeLatentLinear(torch.autograd.Function):

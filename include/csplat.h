@@ -350,14 +350,17 @@ int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const floa
 /* LayerNorm(128) of the MeshNet MLPs under autograd (/root/reference/meshnet/graph_network.py:86-97,139-150: every edge / node
  * MLP ends in nn.LayerNorm), single HBM passes over [M][128] rows:
  *   csplat_ln128_fwd   y = (x - mean) * rstd * gamma + beta; stats[row] = (mean, rstd)  (biased variance, as torch)
- *   csplat_ln128_bwd   dx; dgamma[128] = sum_rows g * xhat; dbeta[128] = sum_rows g  (fixed summation order: deterministic)
+ *   csplat_ln128_bwd   dx; dgamma[128] = sum_rows g * xhat; dbeta[128] = sum_rows g  (fixed summation order: deterministic);
+ *                      dxsum[128] (or NULL) = column sums of dx: the bias gradient of the Linear layer whose output was normalised;
+ *                      g_rows[M] (or NULL): row r of the incoming gradient is g[g_rows[r]] -- the backward of the segmented sum
+ *                      that follows the edge LayerNorm (every edge reads its destination node's row) without a gathered copy
  *   csplat_relu_mask_bias128   gm = out > 0 ? g : 0 and dbias[128] = column sums of gm: ReLU backward + bias gradient of a
  *                      Linear + ReLU layer in one pass (out NULL: no mask; gm NULL: sums only)
- * partials: 2 x csplat_ln128_partial_floats(M) floats of scratch (1 x for csplat_relu_mask_bias128). */
+ * partials: 3 x csplat_ln128_partial_floats(M) floats of scratch (1 x for csplat_relu_mask_bias128). */
 size_t csplat_ln128_partial_floats(int64_t M);
 int csplat_ln128_fwd(void *stream, int64_t M, const float *x, const float *gamma, const float *beta, float eps, float *y, float *stats);
 int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, const float *stats, const float *gamma, float *dx,
-                     float *dgamma, float *dbeta, float *partials);
+                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, float *partials);
 int csplat_relu_mask_bias128(void *stream, int64_t M, const float *g, const float *out, float *gm, float *dbias, float *partials);
 
 /* Weight gradient of a 128 -> 128 Linear layer under autograd: dW[o][i] = sum_e g[e][o] * x[e][i], g and x [M][128] row-major,
@@ -365,6 +368,9 @@ int csplat_relu_mask_bias128(void *stream, int64_t M, const float *g, const floa
  * (deterministic).  workspace: csplat_dw128_workspace_bytes(M) bytes. */
 size_t csplat_dw128_workspace_bytes(int64_t M);
 int csplat_dw128(void *stream, int64_t M, const float *g, const float *x, float *dW, void *workspace);
+/* the same with dbias[128] = column sums of g (the bias gradient, from the g rows the product reads anyway) and, when x_relu != 0,
+ * max(x, 0) in place of x (a layer whose saved input is the PRE-activation of the ReLU in front of it) */
+int csplat_dw128_bias(void *stream, int64_t M, const float *g, const float *x, int x_relu, float *dW, float *dbias, void *workspace);
 
 /* how csplat_linear128 forms its products: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products); 1 = three bf16 pieces per
  * operand and the six significant partial products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; error ~3 x 2^-24 relative
@@ -375,6 +381,15 @@ int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, co
                      const float *gather_a, const int64_t *index_a, const float *gather_b, const int64_t *index_b,
                      const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,
                      const float *add_post, float *out);
+/* The same product for the autograd path, where the weight is seldom a contiguous [128][128] matrix of its own: W is read as
+ * W[j * ldw + k] (w_transposed = 0: a Linear.weight, or a 128-column slice of a wider one, ldw = its row stride) or as W[k * ldw + j]
+ * (w_transposed = 1: the transpose, i.e. the input-gradient product g @ W, without materialising W^T); and `mask` [M][128] (or NULL)
+ * zeroes the outputs whose mask entry is not positive, after everything else: the ReLU backward of the layer whose saved
+ * output is handed in, folded into the GEMM that produces its incoming gradient. */
+int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
+                        float alpha, int relu, const float *gather_a, const int64_t *index_a, const float *gather_b,
+                        const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                        const float *add_pre, const float *add_post, const float *mask, float *out);
 
 #ifdef __cplusplus
 }

@@ -241,6 +241,38 @@ def test_linear128_vs_fp64(M, gather, ln, mode):
     _n.check(_n.lib.csplat_linear128_mode(1), "csplat_linear128_mode")       # back to the default
 
 
+@pytest.mark.parametrize("M", [33, 4100, 70_001])     # node-level kernel, persistent kernel
+@pytest.mark.parametrize("mode", [0, 1])
+def test_linear128_weight_layouts_and_mask(M, mode):
+    """csplat_linear128_ex reads column slices of a wider weight and transposes in place (no copies on the autograd path), and its
+    mask epilogue is the ReLU backward of the layer whose output is handed in -- against fp64"""
+    from meshnet.graph_ops import linear128, _weight_layout
+    from csplat import native as _n
+    _n.check(_n.lib.csplat_linear128_mode(mode), "csplat_linear128_mode")
+    try:
+        gen = torch.Generator().manual_seed(M + mode)
+        Wf = (torch.randn(128, 384, generator=gen) * 0.2).cuda()
+        Wc = (torch.randn(128, 128, generator=gen) * 0.2).cuda()
+        A = torch.randn(M, 128, generator=gen).cuda()
+        b = torch.randn(128, generator=gen).cuda()
+        msk = torch.randn(M, 128, generator=gen).cuda()
+        acc = torch.randn(M, 128, generator=gen).cuda()
+        for name, W in (("slice", Wf[:, 128:256]), ("transpose", Wc.t()), ("transposed slice", Wf[:, 256:].t()), ("plain", Wc)):
+            w_used, ldw, wt = _weight_layout(W)
+            assert w_used.data_ptr() == W.data_ptr(), name                    # read in place
+            ref = A.double() @ W.double().t() + b.double()
+            got = linear128(A, W, b)
+            assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 2e-6, name
+            refm = (0.5 * (A.double() @ W.double().t()) + acc.double()) * (msk > 0).double()
+            gotm = linear128(A, W, None, alpha=0.5, add_post=acc, mask=msk)
+            assert rel_err(gotm.cpu().numpy(), refm.cpu().numpy()) < 2e-6, name
+            assert bool(((gotm == 0) | (msk > 0)).all())
+            gotm2 = linear128(A, W, None, mask=msk)
+            assert rel_err(gotm2.cpu().numpy(), ((A.double() @ W.double().t()) * (msk > 0).double()).cpu().numpy()) < 2e-6, name
+    finally:
+        _n.check(_n.lib.csplat_linear128_mode(1), "csplat_linear128_mode")
+
+
 def test_rollout_inference_path_matches_autograd_path():
     """The no-grad rollout path (csplat_linear128 + carried 2^l edge scale) and the autograd path (rocBLAS GEMMs,
     EdgeCombine) are the same function: outputs within 1e-5 rel, edge output identical."""
@@ -568,6 +600,20 @@ def test_layernorm128_and_relu_mask_bias_vs_fp64(M):
     assert rel_err(db.cpu().numpy(), ref.double().sum(0).cpu().numpy()) < 1e-5
     g2, db2 = relu_mask_bias128(w, None)
     assert g2.data_ptr() == w.data_ptr() and rel_err(db2.cpu().numpy(), w.double().sum(0).cpu().numpy()) < 1e-5
+    # the two extras of csplat_ln128_bwd the fused message path uses: column sums of dx, and the incoming gradient read through a
+    # row index (the backward of the segmented sum behind the LayerNorm)
+    from meshnet.graph_ops import ln128_bwd, ln128_fwd
+    xd = x.detach()
+    _, stats = ln128_fwd(xd, ga.detach(), be.detach(), 1e-5)
+    dx, dga, dbe, dxs = ln128_bwd(w, xd, stats, ga.detach(), want_dxsum=True)
+    assert torch.equal(dx, x.grad) and torch.equal(dga, first[0]) and torch.equal(dbe, first[1])
+    assert float((dxs.double() - dx.double().sum(0)).abs().max()) <= 1e-5 * float(dx.double().abs().sum(0).max()) + 1e-12
+    R = max(M // 3, 1)
+    rows = torch.randint(0, R, (M,), generator=gen).cuda()
+    small = torch.randn(R, 128, generator=gen).cuda()
+    dxg, dgg, dbg, _ = ln128_bwd(small, xd, stats, ga.detach(), g_rows=rows)
+    dxr, dgr, dbr, _ = ln128_bwd(small[rows].contiguous(), xd, stats, ga.detach())
+    assert torch.equal(dxg, dxr) and torch.equal(dgg, dgr) and torch.equal(dbg, dbr)
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 31, 63, 64, 65, 127, 1000, 10_000, 16_385, 70_001, 300_000])
@@ -583,3 +629,10 @@ def test_dw128_vs_fp64(M):
     bound = (g.double().abs().t() @ x.double().abs()).clamp_min(1e-30)
     assert float(((dW.double() - ref).abs() / bound).max()) < 2e-6
     assert torch.equal(dW, dw128(g, x))
+    # bias gradient from the same pass; max(x, 0) as the second operand
+    dW2, db = dw128(g, x, bias=True)
+    assert torch.equal(dW2, dW)
+    assert float(((db.double() - g.double().sum(0)).abs() / g.double().abs().sum(0).clamp_min(1e-30)).max()) < 2e-6
+    dW3, db3 = dw128(g, x, bias=True, x_relu=True)
+    assert torch.equal(db3, db) and torch.equal(dW3, dw128(g, x.relu()))
+    assert torch.equal(dw128(g, x, x_relu=True), dW3)
