@@ -84,12 +84,12 @@ EXPORTS = {
     "csplat_dw128_bias": (_i, [_vp, _i64, _vp, _vp, _i, _vp, _vp, _vp]),
     "csplat_ln128_partial_floats": (_sz, [_i64]),
     "csplat_ln128_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _vp]),
-    "csplat_ln128_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_ln128_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "csplat_relu_mask_bias128": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "csplat_linear128_mode": (_i, [C.c_uint]),
     "csplat_gnn_node_update": (_i, [_vp, _i64] + [_vp] * 11 + [_f] + [_vp] * 5),
     "csplat_linear128": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
-    "csplat_linear128_ex": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "csplat_linear128_ex": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }
 for _name, (_res, _args) in EXPORTS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what include/csplat.h declares

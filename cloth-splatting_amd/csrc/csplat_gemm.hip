@@ -58,7 +58,7 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
                                                     const float *__restrict__ gb, const int64_t *__restrict__ ib,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                     const float *add_pre, const float *add_post, float *out,
-                                                    int ldw, int wt, const float *mask) {
+                                                    int ldw, int wt, const float *mask, float2 *ln_stats) {
     // W is read as W[j][k] = W[j * ldw + k] (wt = 0: a torch Linear.weight, or a column slice of a wider one) or as
     // W[k * ldw + j] (wt = 1: the TRANSPOSE of such a matrix -- the input-gradient product -- without a transposed copy)
     extern __shared__ float s_wt[];   // fp32 path: [GK][WT_STRIDE], s_wt[k * WT_STRIDE + j] = W[j][k];  B3: bf16 [3][GN][WB_STRIDE]
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
     if (B3) {
         __bf16 *wb = reinterpret_cast<__bf16 *>(s_wt);
         for (int t = threadIdx.x; t < GN * GK; t += NW * 64) {
-            const int j = t >> 7, k = t & 127;
+            const int j = wt ? t & 127 : t >> 7, k = wt ? t >> 7 : t & 127;   // consecutive threads read consecutive addresses either way
             const float x = wt ? W[(size_t)k * ldw + j] : W[(size_t)j * ldw + k];
             const __bf16 p1 = (__bf16)x;
             const float r1 = x - (float)p1;
@@ -281,6 +281,7 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
                 for (int c = 0; c < 4; c++) { d[c] = v[c] - mean; sq += d[c] * d[c]; }
                 sq = half_sum(sq);
                 const float rstd = rsqrtf(sq * (1.f / GN) + eps);
+                if (ln_stats && r32 == 0 && orow < M) ln_stats[orow] = make_float2(mean, rstd);
 #pragma unroll
                 for (int c = 0; c < 4; c++) v[c] = d[c] * rstd * gcol[c] + becol[c];
             }
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
                                                            const float *__restrict__ bias, float alpha, int relu,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                            const float *add_pre, const float *add_post, float *out,
-                                                           int ldw, int wt, const float *mask) {
+                                                           int ldw, int wt, const float *mask, float2 *ln_stats) {
     extern __shared__ float s_dyn[];
     float (*s_w)[GK * SW_STRIDE] = reinterpret_cast<float (*)[GK * SW_STRIDE]>(s_dyn);   // per wave: s_w[w][k * 33 + jj] = W[32w + jj][k]
     float (*s_part)[32][4] = reinterpret_cast<float (*)[32][4]>(s_dyn + 4 * GK * SW_STRIDE);   // [pass][row][wave] partial sums
@@ -388,6 +389,8 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
         for (int r = 0; r < 16; r++) {
             const float *p = s_part[1][(r & 3) + 8 * (r >> 2) + 4 * h];
             const float rstd = rsqrtf(((p[0] + p[1]) + (p[2] + p[3])) * (1.f / GN) + eps);
+            const int64_t srow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ln_stats && w == 0 && r32 == 0 && srow < M) ln_stats[srow] = make_float2(mean[r], rstd);
             v[r] = (v[r] - mean[r]) * rstd * gcol + becol;
         }
     }
@@ -576,13 +579,13 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
                                 const float *ln_gamma, const float *ln_beta, float ln_eps, const float *add_pre,
                                 const float *add_post, float *out) {
     return csplat_linear128_ex(stream, M, A, W, 128, 0, bias, alpha, relu, gather_a, index_a, gather_b, index_b, ln_gamma, ln_beta, ln_eps,
-                               add_pre, add_post, nullptr, out);
+                               add_pre, add_post, nullptr, nullptr, out);
 }
 
 extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
                                    float alpha, int relu, const float *gather_a, const int64_t *index_a, const float *gather_b,
                                    const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
-                                   const float *add_pre, const float *add_post, const float *mask, float *out) {
+                                   const float *add_pre, const float *add_post, const float *mask, float *ln_stats, float *out) {
     CSPLAT_REQUIRE(M >= 0 && (M == 0 || (A && W && out)) && ldw >= 128, "csplat_linear128: bad arguments");
     CSPLAT_REQUIRE((((uintptr_t)A | (uintptr_t)out | (uintptr_t)W) & 15u) == 0, "csplat_linear128: A / W / out must be 16-byte aligned");
     const int wt = w_transposed ? 1 : 0;
@@ -617,9 +620,9 @@ extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, cons
     if (!gather && ntile <= 2048) {   // node-level sizes: one tile per workgroup, columns split across its waves
         const size_t lds_small = (size_t)(4 * GK * SW_STRIDE + 2 * 32 * 4) * sizeof(float);
         if (ln)
-            k_linear128_rows32<true><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask);
+            k_linear128_rows32<true><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask, (float2 *)ln_stats);
         else
-            k_linear128_rows32<false><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask);
+            k_linear128_rows32<false><<<(int)ntile, 256, lds_small, s>>>(M, A, W, bias, alpha, relu, ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask, (float2 *)ln_stats);
         LAUNCH_CHECK();
         return 0;
     }
@@ -631,10 +634,10 @@ extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, cons
     do {                                                                                                                      \
         if (b3)                                                                                                               \
             k_linear128<G, L, D, true><<<grid, 512, lds_b3, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b, \
-                                                                 ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask); \
+                                                                 ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask, (float2 *)ln_stats); \
         else                                                                                                                  \
             k_linear128<G, L, D, false><<<grid, 256, lds, s>>>(M, A, W, bias, alpha, relu, gather_a, index_a, gather_b, index_b,  \
-                                                               ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask); \
+                                                               ln_gamma, ln_beta, ln_eps, add_pre, add_post, out, ldw, wt, mask, (float2 *)ln_stats); \
     } while (0)
     if (add && ln) CSPLAT_L128(false, true, true);
     else if (add) CSPLAT_L128(false, false, true);

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_ln128_bwd(int64_t M, const float
                                                            const float2 *__restrict__ stats, const float4 *__restrict__ gamma,
                                                            float4 *__restrict__ dx, float4 *__restrict__ part_gamma,
                                                            float4 *__restrict__ part_beta, float4 *__restrict__ part_dx,
-                                                           const int64_t *__restrict__ g_rows) {
+                                                           const int64_t *__restrict__ g_rows, int x_normalized) {
     __shared__ float4 s_g[LN_THREADS], s_b[LN_THREADS], s_x[LN_THREADS];
     const int sub = threadIdx.x & 31;
     const float4 ga = gamma[sub];
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(LN_THREADS) void k_ln128_bwd(int64_t M, const float
     for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK_ITER + (threadIdx.x >> 5); row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK_ITER) {
         const float4 gv = g[(g_rows ? g_rows[row] : row) * 32 + sub], xv = x[row * 32 + sub];
         const float2 st = stats[row];
-        const float h0 = (xv.x - st.x) * st.y, h1 = (xv.y - st.x) * st.y, h2 = (xv.z - st.x) * st.y, h3 = (xv.w - st.x) * st.y;
+        const float sub_mean = x_normalized ? 0.f : st.x, mul = x_normalized ? 1.f : st.y;   // x_normalized: x already is xhat
+        const float h0 = (xv.x - sub_mean) * mul, h1 = (xv.y - sub_mean) * mul, h2 = (xv.z - sub_mean) * mul, h3 = (xv.w - sub_mean) * mul;
         const float w0 = gv.x * ga.x, w1 = gv.y * ga.y, w2 = gv.z * ga.z, w3 = gv.w * ga.w;
         const float m1 = half_sum((w0 + w1) + (w2 + w3)) * (1.f / 128.f);
         const float m2 = half_sum((w0 * h0 + w1 * h1) + (w2 * h2 + w3 * h3)) * (1.f / 128.f);
@@ -370,7 +371,7 @@ int csplat_ln128_fwd(void *stream, int64_t M, const float *x, const float *gamma
 }
 
 int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, const float *stats, const float *gamma, float *dx,
-                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, float *partials) {
+                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, int x_normalized, float *partials) {
     CSPLAT_REQUIRE(M >= 0 && (M == 0 || (g && x && stats && gamma && dx && dgamma && dbeta && partials)), "csplat_ln128_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) {
@@ -381,7 +382,7 @@ int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, co
     const int nb = ln_blocks(M);
     float *pg = partials, *pb = partials + (size_t)nb * 128, *px = dxsum ? partials + (size_t)2 * nb * 128 : nullptr;
     k_ln128_bwd<<<nb, LN_THREADS, 0, s>>>(M, (const float4 *)g, (const float4 *)x, (const float2 *)stats, (const float4 *)gamma, (float4 *)dx,
-                                          (float4 *)pg, (float4 *)pb, (float4 *)px, g_rows);
+                                          (float4 *)pg, (float4 *)pb, (float4 *)px, g_rows, x_normalized);
     LAUNCH_CHECK();
     k_colsum128<<<2, 1024, 0, s>>>(nb, pg, pb, dgamma, dbeta);
     LAUNCH_CHECK();

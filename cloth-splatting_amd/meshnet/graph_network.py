@@ -19,7 +19,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows,
                         linear128, linear_rows, node_update)
 
 
@@ -132,12 +132,13 @@ class InteractionNetwork(nn.Module):
         W = lin0.weight
         xa = linear_rows(x, W[:, :n], lin0.bias)    # contribution of x_i = x[edge_index[1]]
         xb = linear_rows(x, W[:, n:2 * n], None)    # contribution of x_j = x[edge_index[0]]
-        ec, e_next = edge_latent_linear(e_base, W[:, 2 * n:], scale)
-        if relu0 and edge_tail_ok(ec, self.edge_fn):
-            # tall fp32 GPU rows: the rest of the message MLP, its LayerNorm and the sum over destination nodes are one autograd node
-            h = EdgeCombine.apply(xa, xb, ec, csr, True, True)
+        if relu0 and edge_tail_ok(e_base, self.edge_fn):
+            # tall fp32 GPU rows: two autograd nodes for the whole message path -- the e-block GEMM with the gathers / ReLU in its
+            # epilogue, then the rest of the MLP, the LayerNorm and the sum over destination nodes
+            h, e_next = EdgeFirstLayer.apply(e_base, W[:, 2 * n:], scale, xa, xb, csr)
             agg = edge_tail_aggregate(h, csr, self.edge_fn, a0_relu=True)
         else:
+            ec, e_next = edge_latent_linear(e_base, W[:, 2 * n:], scale)
             h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
             h = _tail(mlp_e, h, relu0)
             msg = layer_norm_rows(h, self.edge_fn[1])

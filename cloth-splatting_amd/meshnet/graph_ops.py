@@ -29,6 +29,15 @@ class GraphCSR:
                 _n.check(_n.lib.csplat_gnn_build_csr(_n.stream_handle(dev), self.N, self.E, self.ei[row].data_ptr(),
                                                      _n.ptr(rp), _n.ptr(pm), _n.ptr(tmp)), "csplat_gnn_build_csr")
                 self.rowptr[name], self.perm[name] = rp, pm
+        self._deg_dst = None
+
+    @property
+    def deg_dst(self):
+        """[N] float32: number of edges arriving at each node"""
+        if self._deg_dst is None:
+            rp = self.rowptr["dst"]
+            self._deg_dst = (rp[1:] - rp[:-1]).to(torch.float32)
+        return self._deg_dst
 
     @classmethod
     def get(cls, edge_index, num_nodes):
@@ -160,12 +169,27 @@ def _weight_layout(weight):
     return w.contiguous(), 128, 0
 
 
+_UNIT_LN = {}
+
+
+def _unit_ln(device, eps):
+    """LayerNorm(128) with gamma = 1, beta = 0: the normalisation alone"""
+    key = (str(device), float(eps))
+    if key not in _UNIT_LN:
+        ln = torch.nn.LayerNorm(128, eps=eps).to(device)
+        for p_ in ln.parameters():
+            p_.requires_grad_(False)
+        _UNIT_LN[key] = ln
+    return _UNIT_LN[key]
+
+
 def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_norm=None, add_pre=None, add_post=None, out=None,
-              mask=None):
+              mask=None, ln_stats=None):
     """Fused Linear for the 128-wide MeshNet MLP layers (csplat_linear128_ex, include/csplat.h):
         out = [mask > 0] * ( LN?( relu?( alpha * A @ weight^T + bias + ga[ia] + gb[ib] + add_pre ) ) + add_post )
     A [M,128] fp32, weight [128,128] (torch Linear.weight, a column slice of one, or .t() of either: read in place), gather =
-    (ga, ia, gb, ib) or None, layer_norm = nn.LayerNorm(128) or None, add_pre / add_post / mask [M,128] or None.  No autograd graph
+    (ga, ia, gb, ib) or None, layer_norm = nn.LayerNorm(128) or None, add_pre / add_post / mask [M,128] or None, ln_stats [M,2] or
+    None (receives each row's (mean, rstd) of the LayerNorm epilogue).  No autograd graph
     is recorded: callers use it under torch.no_grad() or inside an autograd Function."""
     _n.require_cuda(A)
     assert A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == 128 and tuple(weight.shape) == (128, 128)
@@ -190,7 +214,8 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
     with torch.cuda.device(A.device):
         _n.check(_n.lib.csplat_linear128_ex(_n.stream_handle(A.device), M, _n.ptr(A), weight.data_ptr(), ldw, wt, _n.ptr(bias), float(alpha),
                                             int(relu), _n.ptr(ga), _n.ptr(ia), _n.ptr(gb), _n.ptr(ib), _n.ptr(g), _n.ptr(b), eps,
-                                            _n.ptr(add_pre), _n.ptr(add_post), _n.ptr(mask), _n.ptr(out)), "csplat_linear128_ex")
+                                            _n.ptr(add_pre), _n.ptr(add_post), _n.ptr(mask), _n.ptr(ln_stats), _n.ptr(out)),
+                 "csplat_linear128_ex")
     return out
 
 
@@ -228,9 +253,9 @@ def ln128_fwd(x, gamma, beta, eps):
     return y, stats
 
 
-def ln128_bwd(g, x, stats, gamma, want_dxsum=False, g_rows=None):
+def ln128_bwd(g, x, stats, gamma, want_dxsum=False, g_rows=None, x_normalized=False):
     """(dx, dgamma, dbeta, column sums of dx or None) of LayerNorm over [M, 128] rows: csplat_ln128_bwd.  g_rows: row r of the incoming
-    gradient is g[g_rows[r]] (g then has as many rows as g_rows addresses)."""
+    gradient is g[g_rows[r]] (g then has as many rows as g_rows addresses); x_normalized: x is the normalised row xhat itself."""
     M = x.shape[0]
     dx = torch.empty_like(x)
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
@@ -238,7 +263,8 @@ def ln128_bwd(g, x, stats, gamma, want_dxsum=False, g_rows=None):
     part = torch.empty(3 * int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _n.check(_n.lib.csplat_ln128_bwd(_n.stream_handle(x.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(stats), _n.ptr(gamma), _n.ptr(dx),
-                                         _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dxsum), _n.ptr(g_rows), _n.ptr(part)), "csplat_ln128_bwd")
+                                         _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dxsum), _n.ptr(g_rows), int(x_normalized), _n.ptr(part)),
+                 "csplat_ln128_bwd")
     return dx, dgamma, dbeta, dxsum
 
 
@@ -356,54 +382,100 @@ class SplitKLinear(torch.autograd.Function):
 
 
 class EdgeTailAggregate(torch.autograd.Function):
-    """agg = segment_sum_dst( LayerNorm( Linear_k( relu(... relu(Linear_1(a0)) ...) ) ) ): everything of an InteractionNetwork's message
+    """S = segment_sum_dst( normalise( Linear_k( relu(... relu(Linear_1(a0)) ...) ) ) ): everything of an InteractionNetwork's message
     path behind the first (split) edge Linear, as ONE autograd node over [E, 128] fp32 rows (graph_network.py:139-150 +
-    aggr='add').  What one node buys, per layer of the processor:
-      * the ReLU backward of every hidden layer is the mask epilogue of the GEMM that produces its incoming gradient
-        (csplat_linear128_ex: mask = the layer's saved output) -- no separate [E, 128] masking pass;
+    aggr='add').  `normalise` is the LayerNorm WITHOUT its affine part: sum_e (gamma * xhat_e + beta) = gamma * S + deg * beta is
+    applied by the caller on [N, 128] rows, where autograd also finds dgamma and dbeta (edge_tail_aggregate()).
+    What one node buys, per layer of the processor:
+      * the normalisation is the epilogue of the last Linear's GEMM (csplat_linear128_ex, which also leaves each row's rstd): no
+        separate [E, 128] LayerNorm pass, and only xhat is kept for the backward;
+      * the ReLU backward of every hidden layer is the mask epilogue of the GEMM that produces its incoming gradient (mask = the
+        layer's saved output) -- no separate [E, 128] masking pass;
       * bias gradients are column sums taken where the rows are read anyway: inside csplat_dw128_bias for the hidden layers, inside
         csplat_ln128_bwd (dxsum) for the last one;
       * the backward of the segmented sum (every edge takes its destination node's row) is a gathered read inside csplat_ln128_bwd,
         not an [E, 128] copy;
       * transposed weights are read in place.
-    a0_relu: a0 is itself the output of a ReLU (EdgeCombine with grad_premasked=True): the returned gradient is then the one of
-    its pre-activation."""
+    a0_relu: a0 is itself the output of a ReLU whose producer expects the gradient of its PRE-activation (EdgeFirstLayer, or EdgeCombine
+    with grad_premasked=True)."""
 
     @staticmethod
-    def forward(ctx, a0, csr, eps, a0_relu, gamma, beta, *wb):
+    def forward(ctx, a0, csr, eps, a0_relu, *wb):
         ctx.set_materialize_grads(False)
         k = len(wb) // 2
         acts = [_f32(a0)]
-        for i in range(k):
-            acts.append(linear128(acts[-1], wb[2 * i], wb[2 * i + 1], relu=i + 1 < k))
-        msg, stats = ln128_fwd(acts[-1], _f32(gamma), _f32(beta), eps)
-        E, L = msg.shape
-        agg = torch.empty(csr.N, L, dtype=torch.float32, device=msg.device)
-        with torch.cuda.device(msg.device):
-            _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(msg.device), csr.N, E, L, _n.ptr(msg),
-                                                   _n.ptr(csr.rowptr["dst"]), _n.ptr(csr.perm["dst"]), _n.ptr(agg)),
+        for i in range(k - 1):
+            acts.append(linear128(acts[-1], wb[2 * i], wb[2 * i + 1], relu=True))
+        E = acts[0].shape[0]
+        stats = torch.empty(E, 2, dtype=torch.float32, device=a0.device)
+        unit = _unit_ln(a0.device, eps)
+        xhat = linear128(acts[-1], wb[2 * k - 2], wb[2 * k - 1], layer_norm=unit, ln_stats=stats)
+        S = torch.empty(csr.N, 128, dtype=torch.float32, device=a0.device)
+        with torch.cuda.device(a0.device):
+            _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(a0.device), csr.N, E, 128, _n.ptr(xhat),
+                                                   _n.ptr(csr.rowptr["dst"]), _n.ptr(csr.perm["dst"]), _n.ptr(S)),
                      "csplat_gnn_segment_sum")
-        ctx.csr, ctx.k, ctx.a0_relu = csr, k, bool(a0_relu)
-        ctx.save_for_backward(stats, gamma, *acts, *wb[0::2])
-        return agg
+        ctx.csr, ctx.k, ctx.a0_relu, ctx.unit = csr, k, bool(a0_relu), unit
+        ctx.save_for_backward(stats, xhat, *acts, *wb[0::2])
+        return S
 
     @staticmethod
-    def backward(ctx, g_agg):
+    def backward(ctx, g_S):
         k, csr = ctx.k, ctx.csr
         saved = ctx.saved_tensors
-        stats, gamma, acts, weights = saved[0], saved[1], saved[2:3 + k], saved[3 + k:]
-        if g_agg is None:
-            return (None,) * (6 + 2 * k)
-        d, dgamma, dbeta, db_last = ln128_bwd(_f32(g_agg), acts[k], stats, _f32(gamma), want_dxsum=True, g_rows=csr.ei[1])
+        stats, xhat, acts, weights = saved[0], saved[1], saved[2:2 + k], saved[2 + k:]
+        if g_S is None:
+            return (None,) * (4 + 2 * k)
+        d, _, _, db_last = ln128_bwd(_f32(g_S), xhat, stats, ctx.unit.weight, want_dxsum=True, g_rows=csr.ei[1], x_normalized=True)
         grads = [None] * (2 * k)
-        for i in range(k - 1, -1, -1):                     # Linear i + 1 maps acts[i] -> acts[i + 1]
+        for i in range(k - 1, -1, -1):                     # Linear i + 1 maps acts[i] to the next activation
             if i == k - 1:
                 grads[2 * i], grads[2 * i + 1] = dw128(d, acts[i]), db_last
             else:
                 grads[2 * i], grads[2 * i + 1] = dw128(d, acts[i], bias=True)
             if i > 0 or ctx.needs_input_grad[0]:
                 d = linear128(d, weights[i].t(), mask=acts[i] if (i > 0 or ctx.a0_relu) else None)
-        return (d if ctx.needs_input_grad[0] else None, None, None, None, dgamma, dbeta, *grads)
+        return (d if ctx.needs_input_grad[0] else None, None, None, None, *grads)
+
+
+class EdgeFirstLayer(torch.autograd.Function):
+    """(a0, e_next) = (relu(scale * e @ weight^T + xa[dst] + xb[src]), e): the first edge Linear of an InteractionNetwork with the
+    [x_i, x_j, e] concat folded away (xa / xb: the node-level products of the x_i / x_j column blocks, bias included) -- gathers, sum and
+    ReLU are the epilogue of the e-block GEMM, so the [E, 128] product is never written or re-read on its own.  e is chained through
+    the layers like in EdgeLatentLinear.  backward() expects the gradient of the PRE-activation (EdgeTailAggregate(a0_relu=True))."""
+
+    @staticmethod
+    def forward(ctx, e, weight, scale, xa, xb, csr):
+        ctx.set_materialize_grads(False)
+        a0 = linear128(e, weight, alpha=float(scale), relu=True, gather=(_f32(xa), csr.ei[1], _f32(xb), csr.ei[0]))
+        ctx.save_for_backward(e, weight)
+        ctx.scale, ctx.csr = float(scale), csr
+        return a0, e.view_as(e)
+
+    @staticmethod
+    def backward(ctx, g, g_next):
+        e, weight = ctx.saved_tensors
+        csr = ctx.csr
+        de = dw = dxa = dxb = None
+        if g is not None:
+            g = _f32(g)
+            E = g.shape[0]
+            dxa = torch.empty(csr.N, 128, dtype=torch.float32, device=g.device)
+            dxb = torch.empty_like(dxa)
+            with torch.cuda.device(g.device):
+                _n.check(_n.lib.csplat_gnn_edge_combine_bwd(
+                    _n.stream_handle(g.device), csr.N, E, 128, _n.ptr(g), None, 0, _n.ptr(csr.rowptr["dst"]),
+                    _n.ptr(csr.perm["dst"]), _n.ptr(csr.rowptr["src"]), _n.ptr(csr.perm["src"]), None, _n.ptr(dxa),
+                    _n.ptr(dxb)), "csplat_gnn_edge_combine_bwd")
+            if ctx.needs_input_grad[0]:
+                de = linear128(g, weight.t(), alpha=ctx.scale, add_post=g_next)
+            if ctx.needs_input_grad[1]:
+                dw = dw128(g, e)
+                if ctx.scale != 1.0:
+                    dw = dw * ctx.scale
+        elif ctx.needs_input_grad[0]:
+            de = g_next
+        return de, dw, None, dxa, dxb, None
 
 
 def edge_tail_ok(a0, seq) -> bool:
@@ -422,10 +494,12 @@ def edge_tail_ok(a0, seq) -> bool:
 
 
 def edge_tail_aggregate(a0, csr, seq, a0_relu=True):
-    """EdgeTailAggregate over the layers of seq = [build_mlp, LayerNorm] behind the first Linear (+ ReLU)"""
+    """sum over destination nodes of seq's output, seq = [build_mlp, LayerNorm] entered behind its first Linear (+ ReLU):
+    EdgeTailAggregate for the [E, 128] work, the LayerNorm's affine part on the [N, 128] sums"""
     lins = list(seq[0].children())[2::2]
     wb = [t for m in lins for t in (m.weight, m.bias)]
-    return EdgeTailAggregate.apply(a0, csr, float(seq[1].eps), a0_relu, seq[1].weight, seq[1].bias, *wb)
+    S = EdgeTailAggregate.apply(a0, csr, float(seq[1].eps), a0_relu, *wb)
+    return S * seq[1].weight + csr.deg_dst[:, None] * seq[1].bias
 
 
 class EdgeLatentLinear(torch.autograd.Function):

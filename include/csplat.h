@@ -353,14 +353,16 @@ int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const floa
  *   csplat_ln128_bwd   dx; dgamma[128] = sum_rows g * xhat; dbeta[128] = sum_rows g  (fixed summation order: deterministic);
  *                      dxsum[128] (or NULL) = column sums of dx: the bias gradient of the Linear layer whose output was normalised;
  *                      g_rows[M] (or NULL): row r of the incoming gradient is g[g_rows[r]] -- the backward of the segmented sum
- *                      that follows the edge LayerNorm (every edge reads its destination node's row) without a gathered copy
+ *                      that follows the edge LayerNorm (every edge reads its destination node's row) without a gathered copy;
+ *                      x_normalized != 0: `x` holds xhat = (x - mean) * rstd itself (what csplat_linear128_ex's LayerNorm
+ *                      epilogue leaves with gamma = 1, beta = 0), stats only supplies rstd
  *   csplat_relu_mask_bias128   gm = out > 0 ? g : 0 and dbias[128] = column sums of gm: ReLU backward + bias gradient of a
  *                      Linear + ReLU layer in one pass (out NULL: no mask; gm NULL: sums only)
  * partials: 3 x csplat_ln128_partial_floats(M) floats of scratch (1 x for csplat_relu_mask_bias128). */
 size_t csplat_ln128_partial_floats(int64_t M);
 int csplat_ln128_fwd(void *stream, int64_t M, const float *x, const float *gamma, const float *beta, float eps, float *y, float *stats);
 int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, const float *stats, const float *gamma, float *dx,
-                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, float *partials);
+                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, int x_normalized, float *partials);
 int csplat_relu_mask_bias128(void *stream, int64_t M, const float *g, const float *out, float *gm, float *dbias, float *partials);
 
 /* Weight gradient of a 128 -> 128 Linear layer under autograd: dW[o][i] = sum_e g[e][o] * x[e][i], g and x [M][128] row-major,
@@ -385,11 +387,12 @@ int csplat_linear128(void *stream, int64_t M, const float *A, const float *W, co
  * W[j * ldw + k] (w_transposed = 0: a Linear.weight, or a 128-column slice of a wider one, ldw = its row stride) or as W[k * ldw + j]
  * (w_transposed = 1: the transpose, i.e. the input-gradient product g @ W, without materialising W^T); and `mask` [M][128] (or NULL)
  * zeroes the outputs whose mask entry is not positive, after everything else: the ReLU backward of the layer whose saved
- * output is handed in, folded into the GEMM that produces its incoming gradient. */
+ * output is handed in, folded into the GEMM that produces its incoming gradient.  ln_stats [M][2] (or NULL): with a LayerNorm
+ * epilogue, the (mean, rstd) of every row -- what csplat_ln128_bwd needs, so that training can take the fused epilogue too. */
 int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
                         float alpha, int relu, const float *gather_a, const int64_t *index_a, const float *gather_b,
                         const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
-                        const float *add_pre, const float *add_post, const float *mask, float *out);
+                        const float *add_pre, const float *add_post, const float *mask, float *ln_stats, float *out);
 
 #ifdef __cplusplus
 }

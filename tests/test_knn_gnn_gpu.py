@@ -269,6 +269,15 @@ def test_linear128_weight_layouts_and_mask(M, mode):
             assert bool(((gotm == 0) | (msk > 0)).all())
             gotm2 = linear128(A, W, None, mask=msk)
             assert rel_err(gotm2.cpu().numpy(), ((A.double() @ W.double().t()) * (msk > 0).double()).cpu().numpy()) < 2e-6, name
+        # the LayerNorm epilogue leaves every row's (mean, rstd) for the backward: against the separate kernel on the plain product
+        from meshnet.graph_ops import _unit_ln, ln128_fwd
+        unit = _unit_ln(A.device, 1e-5)
+        stats = torch.empty(M, 2, device="cuda")
+        xhat = linear128(A, Wc, b, layer_norm=unit, ln_stats=stats)
+        xhat2, stats2 = ln128_fwd(linear128(A, Wc, b), unit.weight, unit.bias, 1e-5)
+        assert rel_err(xhat.cpu().numpy(), xhat2.cpu().numpy()) < 1e-5
+        assert float(((stats[:, 0] - stats2[:, 0]).abs() * stats2[:, 1]).max()) < 1e-6      # mean, in units of the row's std
+        assert float(((stats[:, 1] - stats2[:, 1]).abs() / stats2[:, 1]).max()) < 1e-5      # rstd
     finally:
         _n.check(_n.lib.csplat_linear128_mode(1), "csplat_linear128_mode")
 
