@@ -759,7 +759,13 @@ __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__res
         mfma(gq, xq);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < DW_GROUP; u++) { gq[u] = gn[u]; xq[u] = xn[u]; }
+        for (int u = 0; u < DW_GROUP; u++) {
+            // the prefetched operands must be in registers HERE: without the pin the compiler is free to sink the loads to their first
+            // use at the top of the next iteration (it does in the BIAS variant), i.e. to wait on them right in front of the MFMAs
+            asm volatile("" : "+v"(gn[u].x), "+v"(gn[u].y), "+v"(gn[u].z), "+v"(gn[u].w));
+            asm volatile("" : "+v"(xn[u].x), "+v"(xn[u].y), "+v"(xn[u].z), "+v"(xn[u].w));
+            gq[u] = gn[u]; xq[u] = xn[u];
+        }
     }
     if (total > n_full) {                                               // the ragged group, once per wave
         issue_ragged(gq, xq, n_full);
