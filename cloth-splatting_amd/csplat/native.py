@@ -133,7 +133,7 @@ class CsplatView(C.Structure):
                 [(n, _f) for n in ("scale_modifier", "tanfovx", "tanfovy")] +
                 [(n, _vp) for n in ("bg", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
                                     "cov3D_precomp", "view", "proj", "campos", "alloc_ctx", "out_color", "out_depth", "radii")] +
-                [("num_rendered", _i)] + [(n, _vp) for n in ("geom", "binning", "image", "dL_dpix", "scratch")] +
+                [("num_rendered", _i), ("layout_rendered", _i)] + [(n, _vp) for n in ("geom", "binning", "image", "dL_dpix", "scratch")] +
                 [("accmask", C.c_uint)] +
                 [(n, _vp) for n in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D",
                                     "dL_dsh", "dL_dscale", "dL_drot")])

@@ -64,6 +64,19 @@ def _taps(window_size=11, sigma=1.5):
     return _TAPS[window_size]
 
 
+_L1_SCRATCH = {}
+
+
+def _l1_scratch(device):
+    """partial sums + ticket counter of csplat_l1 for the CURRENT stream of `device`: zeroed once -- the kernel's last workgroup
+    leaves the ticket at zero again, and launches on one stream cannot overlap -- instead of a fill launch per loss"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _L1_SCRATCH.get(key)
+    if buf is None:
+        buf = _L1_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=device)
+    return buf
+
+
 def _launch_l1(x, y, mask, scratch, loss, grad):
     st = _n.stream_handle(x.device)
     if mask is None:
@@ -85,7 +98,7 @@ class FusedL1(torch.autograd.Function):
         mask = None if mask is None else mask.contiguous()
         need = a.requires_grad or b.requires_grad
         grad = torch.empty_like(a) if need else None
-        scratch = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=a.device)
+        scratch = _l1_scratch(a.device)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
             _launch_l1(a, b, mask, scratch, loss, grad)
@@ -186,7 +199,7 @@ class FusedImageLoss(torch.autograd.Function):
         need = image.requires_grad
         dev = x.device
         sign = torch.empty_like(x) if need else None
-        scratch = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=dev)
+        scratch = _l1_scratch(dev)
         l1 = torch.empty((), dtype=torch.float32, device=dev)
         p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=dev) if need else None
         partial = torch.empty(int(_n.lib.csplat_ssim_partial_count(n_img, H, W)), dtype=torch.float32, device=dev)

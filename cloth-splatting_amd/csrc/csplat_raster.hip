@@ -538,11 +538,19 @@ struct P2View {
     float *final_T;
     uint32_t *n_contrib;
     float *out_color, *out_depth;
-    uint32_t R;
+    uint32_t R;                 // list capacity the binning chunk was laid out for (the null record sits at index R)
+    // speculative launch (finish_views_batched): the host has not read the counts yet and sized the chunks from the previous call;
+    // every kernel of the second phase checks the counts the scan left in `info` against those capacities and leaves the view
+    // alone when they do not fit (the host notices the same way and repeats the phase with exact sizes)
+    const uint32_t *info;       // [0] tile instances, [1] longest tile list
+    uint32_t Lcap;              // longest tile list the sort's LDS was sized for
+    int spec;
 };
 struct P2Table { P2View v[P2_MAX_VIEWS]; };
+__device__ __forceinline__ bool p2_live(const P2View &w) { return !w.spec || (w.info[0] - 1u < w.R && w.info[1] <= w.Lcap); }
 __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket_views(int P, int tiles, P2Table tab) {
     const P2View &w = tab.v[blockIdx.y];
+    if (!p2_live(w)) return;
     emit_bucket_body(P, tiles, w.g.xy, w.g.depth, w.radii, w.cam, w.table, w.ranges, w.keys_u);
 }
 
@@ -718,6 +726,7 @@ __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restr
 }
 __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort_views(P2Table tab, int skip_byte3) {
     const P2View &w = tab.v[blockIdx.y];
+    if (!p2_live(w)) return;
     tile_sort_body(w.ranges, w.keys_u, w.keys_sorted, w.ids_sorted, skip_byte3);
 }
 
@@ -817,6 +826,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int tiles, const int2 *__rest
 }
 __global__ __launch_bounds__(1024) void k_seg_plan_views(int tiles, P2Table tab) {
     const P2View &w = tab.v[blockIdx.x];
+    if (!p2_live(w)) return;
     seg_plan_body(tiles, w.ranges, w.seg_offset, w.slot_tile);
 }
 
@@ -864,15 +874,15 @@ __device__ __forceinline__ float rowsel(int, float a, float b, float c, float d)
 }
 
 // ------------------------------------------------------------------------------------------- K5b
-__device__ __forceinline__ void block_masks_body(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
+__device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int gx, const uint64_t *__restrict__ keys_sorted,
                                                  const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
                                                  const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
                                                  const float *__restrict__ depth, const float *__restrict__ cut2,
                                                  uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
                                                  float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i > R) return;
-    if (i == R) {   // the null record behind the list: opacity 0, pads incomplete groups of four
+    if (i >= R && i != null_at) return;
+    if (i == null_at) {   // the null record behind the list (at the list's CAPACITY): opacity 0, pads incomplete groups of four
         mask16[i] = 0;
         recA[i] = make_float4(0.f, 0.f, 0.f, 0.f); recB[i] = make_float4(0.f, 0.f, 0.f, 0.f); recC[i] = make_float2(0.f, 0.f);
         return;
@@ -899,11 +909,12 @@ __global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const ui
                                                       const float *__restrict__ depth, const float *__restrict__ cut2,
                                                       uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
                                                       float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
-    block_masks_body(R, gx, keys_sorted, ids_sorted, xy, conic_opacity, rgb, depth, cut2, mask16, recA, recB, recC, exact);
+    block_masks_body(R, R, gx, keys_sorted, ids_sorted, xy, conic_opacity, rgb, depth, cut2, mask16, recA, recB, recC, exact);
 }
 __global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exact) {
     const P2View &w = tab.v[blockIdx.y];
-    block_masks_body((int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.xy, w.g.conic_opacity, w.g.rgb, w.g.depth, w.g.cut2, w.mask16,
+    if (!p2_live(w)) return;
+    block_masks_body(w.spec ? (int64_t)w.info[0] : (int64_t)w.R, (int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.xy, w.g.conic_opacity, w.g.rgb, w.g.depth, w.g.cut2, w.mask16,
                      w.recA, w.recB, w.recC, exact);
 }
 
@@ -1059,6 +1070,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
 }
 __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab) {
     const P2View &w = tab.v[blockIdx.y];
+    if (!p2_live(w)) return;
     composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
                        w.n_contrib, w.out_color, w.out_depth);
 }
@@ -2210,75 +2222,136 @@ static uint32_t tile_sort_cap() {
 // Second phase of ALL views in one launch per stage on `join` (see P2Table).  *done = false (and nothing launched or
 // allocated) when the views do not qualify -- a tile list too long for the LDS sort, different sizes -- and the caller
 // finishes view by view.
+// What the last batched call saw, per image size: the capacities the next one is launched with BEFORE its counts are read.
+struct SpecHist { int W = 0, H = 0, P = 0; uint32_t R = 0, longest = 0; };
+static SpecHist g_spec_hist;
+static std::mutex g_spec_mu;
+
 static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done) {
     *done = false;
     if (V < 2 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
     const FwdTicket &a = g_tickets[tk[0]];
-    uint32_t info[P2_MAX_VIEWS][2];
-    uint32_t longest = 0, maxR = 0;
-    const uint32_t cap = tile_sort_cap();
     for (int i = 0; i < V; i++) {
         const FwdTicket &t = g_tickets[tk[i]];
         if (!t.can_bucket || t.P != a.P || t.W != a.W || t.H != a.H || t.P <= 0) return 0;
-        if (int rc = finish_read(t, info[i], join)) return rc;
-        if (info[i][1] > cap || info[i][0] == 0) return 0;
-        longest = info[i][1] > longest ? info[i][1] : longest;
-        maxR = info[i][0] > maxR ? info[i][0] : maxR;
     }
     const int P = a.P, W = a.W, H = a.H, tiles = a.tiles, nb = a.nb;
-    P2Table tab;
-    for (int i = 0; i < V; i++) {
-        const FwdTicket &t = g_tickets[tk[i]];
-        const uint32_t R = info[i][0];
-        void *bbase = t.alloc(t.alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
-        void *tbase = t.alloc(t.alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
-        CSPLAT_REQUIRE(bbase && tbase, "allocator returned NULL");
-        size_t boff[B_NFIELDS], toff[5];
-        binning_offsets(R, tiles, boff);
-        temp_offsets(R, toff);
-        P2View &k = tab.v[i];
-        k.g = t.g; k.cam = t.cam; k.radii = t.radii; k.table = t.table; k.ranges = t.ranges;
-        k.keys_u = (uint64_t *)((char *)tbase + toff[0]);
-        k.keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
-        k.ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
-        k.seg_offset = (int *)((char *)bbase + boff[2]);
-        k.slot_tile = (int *)((char *)bbase + boff[3]);
-        k.ckpt = (float4 *)((char *)bbase + boff[4]);
-        k.mask16 = (uint16_t *)((char *)bbase + boff[5]);
-        k.recA = (float4 *)((char *)bbase + boff[6]); k.recB = (float4 *)((char *)bbase + boff[7]);
-        k.recC = (float2 *)((char *)bbase + boff[8]);
-        k.bg = t.bg; k.final_T = t.final_T; k.n_contrib = t.n_contrib; k.out_color = v[i].out_color; k.out_depth = v[i].out_depth;
-        k.R = R;
-        v[i].num_rendered = (int)R; v[i].geom = t.gbase; v[i].binning = bbase; v[i].image = t.ibase;
-    }
-    {
-        ProfScope ps(PROF_K3, join);
-        k_emit_bucket_views<<<dim3(nb, V), BUCKET_G, (size_t)tiles * 4, join>>>(P, tiles, tab);
-        LAUNCH_CHECK();
-    }
-    {
-        const int items = cdiv((int)longest > 0 ? (int)longest : 1, TSORT_THREADS);
-        const size_t lds = (size_t)items * TSORT_THREADS * 8 + (size_t)(TSORT_WAVES * 256 + 256 + 8) * 4;
-        ProfScope ps(PROF_K4, join);
-        k_tile_sort_views<<<dim3(tiles, V), TSORT_THREADS, lds, join>>>(tab, P < (1 << 24));
-        LAUNCH_CHECK();
-    }
-    {
-        ProfScope ps(PROF_K5, join);
-        k_seg_plan_views<<<V, 1024, 0, join>>>(tiles, tab);
-        LAUNCH_CHECK();
-        k_block_masks_views<<<dim3(cdiv((int64_t)maxR + 1, 256), V), 256, 0, join>>>(tab, (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
-        LAUNCH_CHECK();
-    }
-    {
-        ProfScope ps(PROF_K6, join);
-        k_composite_fwd_views<<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
-        LAUNCH_CHECK();
-    }
-    {
+    const uint32_t cap = tile_sort_cap();
+    uint32_t info[P2_MAX_VIEWS][2];
+    bool have_info = false;
+    auto read_counts = [&]() -> int {   // the one host read of the call: instances and longest tile list of every view
+        for (int i = 0; i < V && !have_info; i++)
+            if (int rc = finish_read(g_tickets[tk[i]], info[i], join)) return rc;
+        have_info = true;
+        return 0;
+    };
+    // lays the chunks of every view out for `Rcap[i]` list entries and launches the five stages
+    auto launch = [&](const uint32_t *Rcap, uint32_t Lcap, int spec) -> int {
+        P2Table tab;
+        uint32_t maxR = 0;
+        for (int i = 0; i < V; i++) {
+            const FwdTicket &t = g_tickets[tk[i]];
+            const uint32_t R = Rcap[i];
+            maxR = R > maxR ? R : maxR;
+            void *bbase = t.alloc(t.alloc_ctx, CSPLAT_CHUNK_BINNING, csplat_binning_bytes(R, W, H));
+            void *tbase = t.alloc(t.alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
+            CSPLAT_REQUIRE(bbase && tbase, "allocator returned NULL");
+            size_t boff[B_NFIELDS], toff[5];
+            binning_offsets(R, tiles, boff);
+            temp_offsets(R, toff);
+            P2View &k = tab.v[i];
+            k.g = t.g; k.cam = t.cam; k.radii = t.radii; k.table = t.table; k.ranges = t.ranges;
+            k.keys_u = (uint64_t *)((char *)tbase + toff[0]);
+            k.keys_sorted = (uint64_t *)((char *)bbase + boff[0]);
+            k.ids_sorted = (uint32_t *)((char *)bbase + boff[1]);
+            k.seg_offset = (int *)((char *)bbase + boff[2]);
+            k.slot_tile = (int *)((char *)bbase + boff[3]);
+            k.ckpt = (float4 *)((char *)bbase + boff[4]);
+            k.mask16 = (uint16_t *)((char *)bbase + boff[5]);
+            k.recA = (float4 *)((char *)bbase + boff[6]); k.recB = (float4 *)((char *)bbase + boff[7]);
+            k.recC = (float2 *)((char *)bbase + boff[8]);
+            k.bg = t.bg; k.final_T = t.final_T; k.n_contrib = t.n_contrib; k.out_color = v[i].out_color; k.out_depth = v[i].out_depth;
+            k.R = R; k.info = t.info; k.Lcap = Lcap; k.spec = spec;
+            v[i].layout_rendered = (int)R; v[i].geom = t.gbase; v[i].binning = bbase; v[i].image = t.ibase;
+        }
+        {
+            ProfScope ps(PROF_K3, join);
+            k_emit_bucket_views<<<dim3(nb, V), BUCKET_G, (size_t)tiles * 4, join>>>(P, tiles, tab);
+            LAUNCH_CHECK();
+        }
+        {
+            const int items = cdiv((int)Lcap > 0 ? (int)Lcap : 1, TSORT_THREADS);
+            const size_t lds = (size_t)items * TSORT_THREADS * 8 + (size_t)(TSORT_WAVES * 256 + 256 + 8) * 4;
+            ProfScope ps(PROF_K4, join);
+            k_tile_sort_views<<<dim3(tiles, V), TSORT_THREADS, lds, join>>>(tab, P < (1 << 24));
+            LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(PROF_K5, join);
+            k_seg_plan_views<<<V, 1024, 0, join>>>(tiles, tab);
+            LAUNCH_CHECK();
+            k_block_masks_views<<<dim3(cdiv((int64_t)maxR + 1, 256), V), 256, 0, join>>>(tab, (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
+            LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(PROF_K6, join);
+            k_composite_fwd_views<<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
+            LAUNCH_CHECK();
+        }
+        return 0;
+    };
+    auto remember = [&]() {
+        std::lock_guard<std::mutex> lk(g_spec_mu);
+        g_spec_hist.W = W; g_spec_hist.H = H; g_spec_hist.P = P; g_spec_hist.R = 0; g_spec_hist.longest = 0;
+        for (int i = 0; i < V; i++) {
+            g_spec_hist.R = info[i][0] > g_spec_hist.R ? info[i][0] : g_spec_hist.R;
+            g_spec_hist.longest = info[i][1] > g_spec_hist.longest ? info[i][1] : g_spec_hist.longest;
+        }
+    };
+    auto release = [&]() {
         std::lock_guard<std::mutex> lk(g_ticket_mu);
         for (int i = 0; i < V; i++) g_tickets[tk[i]].used = false;
+    };
+    // ---- speculative launch: in a training loop the counts of consecutive steps differ by a few per cent, and waiting for them
+    // leaves the GPU idle for a host round trip (~40 us of a 1 ms step).  With the previous call's counts + 1/8 as capacities the
+    // second phase is queued straight behind the first; the counts are read AFTER that (the GPU is busy with the phase by then),
+    // and a view whose counts do not fit was left untouched by the kernels (p2_live) -- the phase is then repeated with exact
+    // sizes.  csplat_debug_flags bit 10 switches the speculation off.
+    SpecHist hist;
+    {
+        std::lock_guard<std::mutex> lk(g_spec_mu);
+        hist = g_spec_hist;
     }
+    if (!(g_debug_flags & 1024u) && hist.R > 0 && hist.W == W && hist.H == H && hist.P == P) {
+        uint32_t Rcap[P2_MAX_VIEWS];
+        const uint64_t want = (uint64_t)hist.R + hist.R / 8 + 4096;
+        const uint32_t rc32 = (uint32_t)(want > 0x7FFFFF00ull ? 0x7FFFFF00ull : want);
+        for (int i = 0; i < V; i++) Rcap[i] = rc32;
+        uint32_t Lcap = hist.longest + hist.longest / 4 + 64;
+        Lcap = Lcap > cap ? cap : Lcap;
+        if (int rc = launch(Rcap, Lcap, 1)) return rc;
+        if (int rc = read_counts()) return rc;
+        bool fits = true;
+        for (int i = 0; i < V; i++) fits = fits && info[i][0] - 1u < Rcap[i] && info[i][1] <= Lcap;
+        remember();
+        if (fits) {
+            for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
+            release();
+            *done = true;
+            return 0;
+        }
+    }
+    if (int rc = read_counts()) return rc;
+    uint32_t longest = 0, Rex[P2_MAX_VIEWS];
+    for (int i = 0; i < V; i++) {
+        if (info[i][1] > cap || info[i][0] == 0) return 0;      // a list too long for the in-LDS sort, an empty view: view by view
+        longest = info[i][1] > longest ? info[i][1] : longest;
+        Rex[i] = info[i][0];
+    }
+    remember();
+    if (int rc = launch(Rex, longest, 0)) return rc;
+    for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
+    release();
     *done = true;
     return 0;
 }
@@ -2558,8 +2631,10 @@ int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *joi
     }
     for (int i = 0; i < begun; i++) {   // every prepared ticket is finished (= released) even after an error
         csplat_view &w = v[i];
-        if (rc == 0) rc = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
-        else {
+        if (rc == 0) {
+            rc = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
+            w.layout_rendered = w.num_rendered;
+        } else {
             std::lock_guard<std::mutex> lk(g_ticket_mu);
             g_tickets[tickets[i]].used = false;
         }
@@ -2651,15 +2726,16 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             for (int i = 0; i < V; i++) {
                 const csplat_view &w = v[i];
                 size_t boff[B_NFIELDS];
-                binning_offsets(w.num_rendered, tiles, boff);
+                const int Rl = w.layout_rendered > 0 ? w.layout_rendered : w.num_rendered;   // what the chunk was laid out for
+                binning_offsets(Rl, tiles, boff);
                 const char *b = (const char *)w.binning, *im = (const char *)w.image;
                 B2View &k = bt.v[i];
                 k.ranges = (const int2 *)(im + ioff[0]); k.n_contrib = (const uint32_t *)(im + ioff[1]); k.final_T = (const float *)(im + ioff[2]);
                 k.ids_sorted = (const uint32_t *)(b + boff[1]); k.seg_offset = (const int *)(b + boff[2]); k.slot_tile = (const int *)(b + boff[3]);
                 k.ckpt = (const float4 *)(b + boff[4]); k.mask16 = (const uint16_t *)(b + boff[5]);
                 k.recA = (const float4 *)(b + boff[6]); k.recB = (const float4 *)(b + boff[7]); k.recC = (const float2 *)(b + boff[8]);
-                k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)w.num_rendered;
-                const int64_t sl = max_slots(w.num_rendered, tiles);
+                k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)Rl;
+                const int64_t sl = max_slots(Rl, tiles);
                 slots = sl > slots ? sl : slots;
             }
             ProfScope ps(PROF_K7, join);
@@ -2673,7 +2749,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             const csplat_view &w = v[i];
             if (int rc = backward_impl((hipStream_t)w.stream, (shared || batch_k7) ? join : (hipStream_t)w.stream, !batch_k7, !one_k8,
                                        w.accmask, w.P, w.D, w.M,
-                                       w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
+                                       w.layout_rendered > 0 ? w.layout_rendered : w.num_rendered, w.bg, w.W, w.H, w.means3D, w.shs, w.scales, w.scale_modifier, w.rotations,
                                        w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.radii, w.geom, w.binning,
                                        w.image, w.out_color, w.dL_dpix, w.scratch, w.dL_dmean2D, w.dL_dconic, w.dL_dopacity,
                                        w.dL_dcolor, w.dL_dmean3D, w.dL_dcov3D, w.dL_dsh, w.dL_dscale, w.dL_drot))

@@ -230,6 +230,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         outs, saved = [], []
         for i, v in enumerate(views):
             v.num_rendered = int(arr[i].num_rendered)
+            v.layout_rendered = int(arr[i].layout_rendered)      # >= num_rendered: what the binning chunk was laid out for
             v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
             outs += [v.radii, v.depth] if stacked else [v.color, v.radii, v.depth]
             saved += list(v.saved()[:-1]) + ([] if stacked else [v.color])
@@ -270,7 +271,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             v = views[i]
             means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = saved[i * k:i * k + 7]
             P, M = v.P, v.M
-            ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.num_rendered)) // 4 + 64),
+            ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.layout_rendered)) // 4 + 64),
                    "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {}}
             ent["ret"][1] = (ent["dL_dmean2D"], (P, 3))
             shapes = {0: (P, 3), 2: (P, M, 3) if sh is not None else None, 3: (P, 3), 4: (P, 1),

@@ -54,7 +54,9 @@ int csplat_abi_version(void);
  * bit 8: bit-reproducible backward -- K7 stores one record per (list entry, quadrant) and every Gaussian sums its records in
  *        emission order instead of meeting in float atomics (csplat_backward_scratch_bytes grows accordingly: set the flag
  *        before sizing the scratch);
- * bit 9: per-view launches on per-view streams instead of one launch per stage for all views of a step. */
+ * bit 9: per-view launches on per-view streams instead of one launch per stage for all views of a step;
+ * bit 10: csplat_forward_views always waits for a call's counts before launching its second phase (no speculative launch with
+ * the previous call's counts as capacities). */
 int csplat_debug_flags(unsigned flags);
 const char *csplat_last_error(void);
 
@@ -125,7 +127,10 @@ typedef struct csplat_view {
     void *alloc_ctx;
     float *out_color, *out_depth;   /* forward outputs (caller-allocated) */
     int32_t *radii;
-    int num_rendered;               /* written by the forward, read by the backward */
+    int num_rendered;               /* written by the forward: R, the number of (Gaussian, tile) instances */
+    int layout_rendered;            /* written by the forward, read by the backward: the list capacity (>= R) the binning chunk
+                                     * was laid out for -- csplat_forward_views may size it from the previous call's counts so
+                                     * as not to wait for this call's (use it for csplat_backward_scratch_bytes too) */
     void *geom, *binning, *image;   /* chunk base pointers: written by the forward, read by the backward */
     const float *dL_dpix;           /* backward inputs */
     void *scratch;

@@ -636,3 +636,50 @@ def test_all_views_launches_vs_per_view_calls(V, flag):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for a, b in zip(g_b, g_s):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_speculative_second_phase_equals_waiting_for_the_counts():
+    """csplat_forward_views sizes the second phase from the PREVIOUS call's counts and reads this call's afterwards.  A sequence of
+    calls whose scenes shrink, stay, and grow by 4x (the capacities no longer fit: the kernels leave the views alone and the phase
+    is repeated with exact sizes) gives, call by call, the images / radii / depth / gradients of the same sequence with the
+    speculation off (csplat_debug_flags bit 10), bit for bit up to the atomic order of the gradients; num_rendered stays the exact
+    count while layout_rendered (>= it) is what the backward lays the chunks out with."""
+    from csplat import native
+    from diff_gaussian_rasterization import rasterize_views
+    V = 3
+    seq = [1.0, 0.9, 0.9, 2.0, 0.4, 1.1]                    # scale multipliers: list lengths go down, stay, up 4x, down, up
+
+    def run(flags):
+        out = []
+        try:
+            native.lib.csplat_debug_flags(flags)
+            for step, mul in enumerate(seq):
+                cases = [util.make_case(P=3000, W=160, H=112, seed=9, theta=-40.0 + 25.0 * i, scale_mul=2.0 * mul) for i in range(V)]
+                settings = [util.gpu_settings(c) for c in cases]
+                inp = util.gpu_inputs(cases[0])
+                m2d = [torch.zeros(3000, 3, device="cuda", requires_grad=True) for _ in range(V)]
+                kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                            rotations=inp["rotations"]) for i in range(V)]
+                outs = rasterize_views(settings, kws)
+                views = outs[0][0].grad_fn.views
+                counts = [(v.num_rendered, v.layout_rendered) for v in views]
+                gen = torch.Generator(device="cuda").manual_seed(step)
+                tgt = torch.rand(V, 3, 112, 160, device="cuda", generator=gen)
+                sum(((o[0] - tgt[i]) ** 2).mean() for i, o in enumerate(outs)).backward()
+                torch.cuda.synchronize()
+                out.append(([tuple(t.detach().clone() for t in o) for o in outs], counts,
+                            [inp[k].grad.clone() for k in ("means3D", "opacities", "shs", "scales", "rotations")] + [t.grad.clone() for t in m2d]))
+        finally:
+            native.lib.csplat_debug_flags(0)
+        return out
+    spec, plain = run(0), run(1024)
+    grew = 0
+    for (o_s, c_s, g_s), (o_p, c_p, g_p) in zip(spec, plain):
+        for a, b in zip(o_s, o_p):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert [c[0] for c in c_s] == [c[0] for c in c_p] and all(l >= r > 0 for r, l in c_s) and all(l == r for r, l in c_p)
+        grew += any(l > r for r, l in c_s)
+        for a, b in zip(g_s, g_p):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert grew >= 2                                         # the speculation was actually taken on some calls
+
