@@ -683,3 +683,20 @@ def test_speculative_second_phase_equals_waiting_for_the_counts():
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     assert grew >= 2                                         # the speculation was actually taken on some calls
 
+
+@pytest.mark.parametrize("P,lo,hi", [(1500, 1, 2048), (5000, 2049, 4096), (9000, 4097, 8192)])
+def test_tile_sort_list_lengths(P, lo, hi):
+    """the in-LDS tile sort keeps 1 .. 8 keys per lane depending on the tile's list length (up to 8192 entries): short, medium and
+    near-capacity lists against the oracle's sorted lists, bit for bit (the case asserts that its longest list is in the range it is
+    meant for)"""
+    case = make_case(P=P, W=64, H=48, seed=21, grid=12, scale_mul=6.0, radius=3.0)
+    o = oracle_forward(case)
+    longest = int((o.ranges[:, 1] - o.ranges[:, 0]).max())
+    assert lo <= longest <= hi, longest
+    color, radii, depth, st = util.gpu_forward_raw(case)
+    assert st["R"] == o.R
+    np.testing.assert_array_equal(st["keys"], o.keys)
+    np.testing.assert_array_equal(st["ids"], o.ids)
+    np.testing.assert_array_equal(st["ranges"], o.ranges)
+    assert image_err(color.cpu().numpy(), o.color) < TOL
+
