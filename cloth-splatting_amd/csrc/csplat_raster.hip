@@ -45,6 +45,8 @@ struct Geom {
     uint32_t *offsets;      // [P] inclusive scan
     float *cut2;            // [P] squared cut-off distance for wave-level culling (see box_hit)
     void *scan_tmp;
+    float4 *pack;           // [P][3] (x, y, conic a, conic b | conic c, opacity, r, g | b, depth, cut2, 0): what k_block_masks needs of a
+                            // Gaussian in ONE 48-byte record -- it visits the Gaussians in list order (a random gather per field otherwise)
 };
 
 struct Cam {
@@ -277,6 +279,9 @@ __device__ __forceinline__ void preprocess_body(int P, int D, int M, const float
     g.clamped[i] = clampbits;
     g.tiles_touched[i] = touched;
     g.cut2[i] = cut;
+    g.pack[3 * (size_t)i] = make_float4(px, py, co.x, co.y);
+    g.pack[3 * (size_t)i + 1] = make_float4(co.z, co.w, rgb[0], rgb[1]);
+    g.pack[3 * (size_t)i + 2] = make_float4(rgb[2], depth, cut, 0.f);
 }
 
 template <bool STAGE>
@@ -875,9 +880,7 @@ __device__ __forceinline__ float rowsel(int, float a, float b, float c, float d)
 
 // ------------------------------------------------------------------------------------------- K5b
 __device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int gx, const uint64_t *__restrict__ keys_sorted,
-                                                 const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
-                                                 const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
-                                                 const float *__restrict__ depth, const float *__restrict__ cut2,
+                                                 const uint32_t *__restrict__ ids_sorted, const float4 *__restrict__ pack,
                                                  uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
                                                  float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -888,9 +891,10 @@ __device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int
         return;
     }
     const uint32_t tile = (uint32_t)(keys_sorted[i] >> 32), id = ids_sorted[i];
-    const float2 c = xy[id];
-    const float4 co = conic_opacity[id];
-    const float cut = cut2[id];
+    const float4 pa = pack[3 * (size_t)id], pb = pack[3 * (size_t)id + 1], pc = pack[3 * (size_t)id + 2];
+    const float2 c = make_float2(pa.x, pa.y);
+    const float4 co = make_float4(pa.z, pa.w, pb.x, pb.y);
+    const float cut = pc.z;
     const float x0 = (float)((tile % (uint32_t)gx) * CSPLAT_TILE), y0 = (float)((tile / (uint32_t)gx) * CSPLAT_TILE);
     uint32_t m = 0;
 #pragma unroll
@@ -899,22 +903,20 @@ __device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int
         for (int bx = 0; bx < 4; bx++)
             if (box_hit(c, cut, co, x0 + 4.f * bx, x0 + 4.f * bx + 3.f, y0 + 4.f * by, y0 + 4.f * by + 3.f, exact)) m |= 1u << (by * 4 + bx);
     mask16[i] = (uint16_t)m;
-    recA[i] = make_float4(c.x, c.y, co.x, co.y);
-    recB[i] = make_float4(co.z, co.w, rgb[3 * id], rgb[3 * id + 1]);
-    recC[i] = make_float2(rgb[3 * id + 2], depth[id]);
+    recA[i] = pa;
+    recB[i] = pb;
+    recC[i] = make_float2(pc.x, pc.y);
 }
 __global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
-                                                      const uint32_t *__restrict__ ids_sorted, const float2 *__restrict__ xy,
-                                                      const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
-                                                      const float *__restrict__ depth, const float *__restrict__ cut2,
+                                                      const uint32_t *__restrict__ ids_sorted, const float4 *__restrict__ pack,
                                                       uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
                                                       float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
-    block_masks_body(R, R, gx, keys_sorted, ids_sorted, xy, conic_opacity, rgb, depth, cut2, mask16, recA, recB, recC, exact);
+    block_masks_body(R, R, gx, keys_sorted, ids_sorted, pack, mask16, recA, recB, recC, exact);
 }
 __global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exact) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
-    block_masks_body(w.spec ? (int64_t)w.info[0] : (int64_t)w.R, (int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.xy, w.g.conic_opacity, w.g.rgb, w.g.depth, w.g.cut2, w.mask16,
+    block_masks_body(w.spec ? (int64_t)w.info[0] : (int64_t)w.R, (int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.pack, w.mask16,
                      w.recA, w.recB, w.recC, exact);
 }
 
@@ -1838,14 +1840,14 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
 }
 
 // ------------------------------------------------------------------------------------------- layouts
-enum { G_DEPTH, G_XY, G_CONIC, G_RGB, G_COV3D, G_CLAMPED, G_TOUCHED, G_OFFSETS, G_CUT2, G_SCANTMP, G_NFIELDS };
+enum { G_DEPTH, G_XY, G_CONIC, G_RGB, G_COV3D, G_CLAMPED, G_TOUCHED, G_OFFSETS, G_CUT2, G_SCANTMP, G_PACK, G_NFIELDS };
 
 int64_t max_slots(int64_t R, int tiles) { return R / SEG + tiles + 1; }
 size_t geom_offsets(int P, size_t *off) {
     size_t o = 0;
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t sz[G_NFIELDS] = {n * 4, n * 8, n * 16, n * 12, n * 24, n * 4, n * 4, n * 4, n * 4,
-                                  csplat_scan_temp_bytes(P)};
+                                  csplat_scan_temp_bytes(P), n * 48};
     for (int k = 0; k < G_NFIELDS; k++) { off[k] = o; o += align256(sz[k]); }
     return o;
 }
@@ -1860,6 +1862,7 @@ Geom geom_view(void *base, int P) {
     g.tiles_touched = (uint32_t *)(b + off[G_TOUCHED]); g.offsets = (uint32_t *)(b + off[G_OFFSETS]);
     g.cut2 = (float *)(b + off[G_CUT2]);
     g.scan_tmp = (void *)(b + off[G_SCANTMP]);
+    g.pack = (float4 *)(b + off[G_PACK]);
     return g;
 }
 // image: 0 ranges | 1 n_contrib | 2 final_T | 3 info u32[4] (R, longest tile list)
@@ -2447,8 +2450,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     }
     {
         ProfScope ps(PROF_K5, s);
-        k_block_masks<<<cdiv((int64_t)R + 1, 256), 256, 0, s>>>((int64_t)R, cam.gx, keys_sorted, ids_sorted, g.xy, g.conic_opacity, g.rgb,
-                                                                 g.depth, g.cut2, mask16, recA, recB, recC,
+        k_block_masks<<<cdiv((int64_t)R + 1, 256), 256, 0, s>>>((int64_t)R, cam.gx, keys_sorted, ids_sorted, g.pack, mask16, recA, recB, recC,
                                                                  (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
         LAUNCH_CHECK();
     }
