@@ -65,9 +65,20 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
     constexpr int NW = B3 ? 8 : 4;    // wavefronts per workgroup
     if (B3) {
         __bf16 *wb = reinterpret_cast<__bf16 *>(s_wt);
-        for (int t = threadIdx.x; t < GN * GK; t += NW * 64) {
-            const int j = wt ? t & 127 : t >> 7, k = wt ? t >> 7 : t & 127;   // consecutive threads read consecutive addresses either way
-            const float x = wt ? W[(size_t)k * ldw + j] : W[(size_t)j * ldw + k];
+        // element t of the 128 x 128 matrix AS STORED sits at (t >> 7) * ldw + (t & 127) whichever way it is read (consecutive
+        // threads read consecutive addresses); only its place in LDS differs.  All 32 loads of a thread are in flight together.
+        constexpr int PER = GN * GK / (NW * 64);
+        float xs[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int t = threadIdx.x + i * NW * 64;
+            xs[i] = W[(size_t)(t >> 7) * ldw + (t & 127)];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int t = threadIdx.x + i * NW * 64;
+            const int j = wt ? t & 127 : t >> 7, k = wt ? t >> 7 : t & 127;
+            const float x = xs[i];
             const __bf16 p1 = (__bf16)x;
             const float r1 = x - (float)p1;
             const __bf16 p2 = (__bf16)r1;

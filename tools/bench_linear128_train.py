@@ -12,6 +12,7 @@ A = torch.randn(M, 128, device=dev); W = torch.randn(128, 128, device=dev) * 0.1
 Wf = torch.randn(128, 384, device=dev) * 0.1
 acc = torch.randn(M, 128, device=dev)
 out = torch.empty_like(A)
+Wt = W.t().contiguous()
 stats = torch.empty(M, 2, device=dev)
 N = 10_000
 xa, xb = torch.randn(N, 128, device=dev), torch.randn(N, 128, device=dev)
@@ -27,7 +28,9 @@ def timed(fn, n=30):
 
 cases = {
     "plain fwd (W, bias, relu)": lambda: linear128(A, W, b, relu=True, out=out),
+    "plain, no bias / relu": lambda: linear128(A, W, out=out),
     "W.t() in place": lambda: linear128(A, W.t(), out=out),
+    "W.t().contiguous()": lambda: linear128(A, Wt, out=out),
     "W.t() + float mask": lambda: linear128(A, W.t(), mask=acc, out=out),
     "W.t() + add_post": lambda: linear128(A, W.t(), add_post=acc, out=out),
     "column slice": lambda: linear128(A, Wf[:, 256:], out=out),

@@ -13,6 +13,8 @@ python3 bench_gnn.py                 > "$OUT/bench_gnn.json"   2> /dev/null
 python3 tools/gnn_train_trace.py 10  > "$OUT/gnn_train.txt"    2> /dev/null
 python3 bench_train.py --steps 40 --warmup 5 > "$OUT/bench_train.json" 2> /dev/null
 python3 tools/bench_linear128.py     > "$OUT/linear128.txt"    2> /dev/null
+python3 tools/bench_linear128_train.py > "$OUT/linear128_train.txt" 2> /dev/null
+python3 tools/bench_dw128.py 1000 10000 100000 300000 > "$OUT/dw128.txt" 2> /dev/null
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w tools/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate > "$OUT/mfma_rate.txt"
 cd /tmp && export TMPDIR=/tmp
 # same command as the default bench (per-view streams on), so K7's average agrees with bench.py's HIP-event timing
