@@ -1570,7 +1570,10 @@ struct K8Table {
     K8View v[K8_MAX_VIEWS];
 };
 
-template <int NT>
+// VL lanes per Gaussian, lane vl takes the views vl, vl + VL, ...: with one lane per Gaussian the launch has P / 64 = 1564 waves (1.5 per
+// SIMD) that each walk V dependent load -> compute rounds; with VL = 4 it has four times the waves and (V <= 4) one round each.  The
+// sums over the views of the shared-parameter gradients cross the VL lanes with quad DPP adds (fixed association), the SH rows in LDS.
+template <int NT, int VL>
 __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M, const float *__restrict__ shs,
                                                                const float *__restrict__ scales, float scale_mod,
                                                                int use_precomp_cov, float *__restrict__ dL_dsh, K8Table tab) {
@@ -1582,12 +1585,15 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
         if (smask & (bit)) (local) += (val);                                               \
         else { float *p_ = (ptr) + (idx); *p_ = (accmask & (bit)) ? *p_ + (val) : (val); } \
     } while (0)
-    __shared__ float s_in[STAGE ? NT * SH_ROW : 1];
+    static_assert(VL == 1 || VL == 4, "one lane or one quad per Gaussian");
+    constexpr int NG = NT / VL;                   // Gaussians per workgroup
+    __shared__ float s_in[STAGE ? NG * SH_ROW : 1];
     __shared__ float s_out[STAGE ? NT * SH_ROW : 1];
-    const int i = blockIdx.x * NT + threadIdx.x;
-    const int rows = min(NT, P - blockIdx.x * NT);
+    const int gi = threadIdx.x / VL, vl = threadIdx.x % VL;
+    const int i = blockIdx.x * NG + gi;
+    const int rows = min(NG, P - blockIdx.x * NG);
     if (STAGE) {
-        stage_sh_rows<NT>(shs + (size_t)blockIdx.x * NT * 48, rows, s_in);
+        stage_sh_rows<NT>(shs + (size_t)blockIdx.x * NG * 48, rows, s_in);
         for (int k = 0; k < 48; k++) s_out[threadIdx.x * SH_ROW + k] = 0.f;
         __syncthreads();
     }
@@ -1596,11 +1602,14 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     float L_sc[3] = {0.f, 0.f, 0.f}, L_rt[4] = {0.f, 0.f, 0.f, 0.f};
     // the per-view record (radius, the nine accumulated pixel-level gradients) of view vi+1 is requested while view vi is
     // processed: otherwise the thread walks V dependent load -> compute rounds
-    bool vis_n = tab.v[0].radii[i] > 0;
+    bool vis_n = false;
     float a9_n[9];
+    if (vl < tab.n) {
+        vis_n = tab.v[vl].radii[i] > 0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) a9_n[k] = tab.v[0].acc[(size_t)i * ACC_STRIDE + k];
-    for (int vi = 0; vi < tab.n; vi++) {
+        for (int k = 0; k < 9; k++) a9_n[k] = tab.v[vl].acc[(size_t)i * ACC_STRIDE + k];
+    }
+    for (int vi = vl; vi < tab.n; vi += VL) {
     const K8View &w = tab.v[vi];
     const Cam cam = w.cam;
     const Geom g = w.g;
@@ -1614,8 +1623,8 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     float a9[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? a9_n[k] : 0.f;
-    if (vi + 1 < tab.n) {
-        const K8View &wn = tab.v[vi + 1];
+    if (vi + VL < tab.n) {
+        const K8View &wn = tab.v[vi + VL];
         vis_n = wn.radii[i] > 0;
 #pragma unroll
         for (int k = 0; k < 9; k++) a9_n[k] = wn.acc[(size_t)i * ACC_STRIDE + k];
@@ -1706,7 +1715,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     }
     // ---- colour -> SH (+ view direction -> mean3D)
     if (shs && dL_dsh) {
-        const float *sh = (const float *)(s_in + threadIdx.x * SH_ROW);
+        const float *sh = (const float *)(s_in + gi * SH_ROW);
         float *gsh = s_out + threadIdx.x * SH_ROW;
         const uint32_t cl = g.clamped[i];
         const float vx = p[0] - cam.campos[0], vy = p[1] - cam.campos[1], vz = p[2] - cam.campos[2];
@@ -1805,7 +1814,21 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     }
     }   // visible
     }   // views
-    {   // gradients of the parameters every view shares: one write (added to the buffer only if the first view was asked to)
+    if (VL == 4) {   // the four lanes' sums over their views: ((v0 + v1) + (v2 + v3)) in every lane
+        auto quad_sum = [](float v) {
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+            return v;
+        };
+        L_op = quad_sum(L_op);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { L_col[k] = quad_sum(L_col[k]); L_m3[k] = quad_sum(L_m3[k]); L_sc[k] = quad_sum(L_sc[k]); }
+#pragma unroll
+        for (int k = 0; k < 6; k++) L_c6[k] = quad_sum(L_c6[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) L_rt[k] = quad_sum(L_rt[k]);
+    }
+    if (vl == 0) {   // gradients of the parameters every view shares: one write (added to the buffer only if the first view was asked to)
         const unsigned accmask = tab.v[0].accmask;
         const K8View &w = tab.v[0];
 #define PUTS(ptr, idx, val, bit) do { if (smask & (bit)) { float *p_ = (ptr) + (idx); *p_ = (accmask & (bit)) ? *p_ + (val) : (val); } } while (0)
@@ -1827,11 +1850,16 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     }   // i < P
     if (STAGE) {   // coalesced 16-byte stores of the workgroup's SH gradients
         __syncthreads();
-        float4 *dst4 = reinterpret_cast<float4 *>(dL_dsh + (size_t)blockIdx.x * NT * 48);
+        float4 *dst4 = reinterpret_cast<float4 *>(dL_dsh + (size_t)blockIdx.x * NG * 48);
         for (int t = threadIdx.x; t < rows * 12; t += NT) {
             const int row = t / 12, c = (t - row * 12) * 4;
-            const float *sp = s_out + row * SH_ROW + c;
+            const float *sp = s_out + row * VL * SH_ROW + c;
             float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+#pragma unroll
+            for (int v2 = 1; v2 < VL; v2++) {            // the rows of the Gaussian's other view lanes, in lane order
+                const float *sq = sp + v2 * SH_ROW;
+                o.x += sq[0]; o.y += sq[1]; o.z += sq[2]; o.w += sq[3];
+            }
             if (tab.v[0].accmask & CSPLAT_ACC_SH) { const float4 u = dst4[t]; o.x += u.x; o.y += u.y; o.z += u.z; o.w += u.w; }
             dst4[t] = o;
         }
@@ -2767,7 +2795,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             }
             ProfScope ps(PROF_K8, join);
             const csplat_view &a = v[0];
-            k_preprocess_bwd_views<128><<<cdiv(a.P, 128), 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab);
+            k_preprocess_bwd_views<128, 4><<<cdiv(a.P, 32), 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab);
             LAUNCH_CHECK();
         }
         return 0;
