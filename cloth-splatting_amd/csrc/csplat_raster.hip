@@ -2402,7 +2402,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     const Geom g = t.g;
     void *gbase = t.gbase, *ibase = t.ibase;
     int2 *ranges = t.ranges;
-    uint32_t *n_contrib = t.n_contrib, *info = t.info, *table = t.table;
+    uint32_t *n_contrib = t.n_contrib, *table = t.table;
     float *final_T = t.final_T;
     const float *bg = t.bg;
     int32_t *radii = t.radii;

@@ -356,7 +356,7 @@ def test_rows_dot_matches_linear_fwd_bwd(T, R):
     y64 = torch.nn.functional.linear(h64, W64, b64)
     y64.backward(dy.double())
     for got, ref, name in ((y, y64, "y"), (h.grad, h64.grad, "dh"), (W.grad, W64.grad, "dW"), (b.grad, b64.grad, "db")):
-        err = float((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        err = float((got.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max().clamp_min(1e-30))
         assert err < 2e-6, (name, err)
     # deterministic: a second backward gives the same bits
     h2 = h.detach().clone().requires_grad_()
