@@ -596,7 +596,7 @@ def test_equal_depth_ties_sort_by_id(copies):
         np.testing.assert_array_equal(st2["ids"], o2.ids)
 
 
-@pytest.mark.parametrize("V,flag", [(8, 0), (9, 0), (4, 512)])
+@pytest.mark.parametrize("V,flag", [(2, 0), (3, 0), (5, 0), (8, 0), (9, 0), (4, 512)])
 def test_all_views_launches_vs_per_view_calls(V, flag):
     """The three ways a step's views are issued -- ONE launch per stage with blockIdx.y = view (V <= 8 like views), per-view
     launches on per-view streams (V > 8, or csplat_debug_flags bit 9) and one GaussianRasterizer call per view -- give the same
