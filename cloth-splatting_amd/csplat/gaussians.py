@@ -69,6 +69,39 @@ def build_rotation(r):
     return R.reshape(-1, 3, 3)
 
 
+class _GaussianActivations(torch.autograd.Function):
+    """sigmoid(_opacity), exp(_scaling), cat(_features_dc, _features_rest): gaussian_model.py:96-121, one HIP launch each way"""
+
+    @staticmethod
+    def forward(ctx, op_raw, sc_raw, f_dc, f_rest):
+        from . import native as _n
+        P = op_raw.shape[0]
+        opacity, scales = torch.empty_like(op_raw), torch.empty_like(sc_raw)
+        shs = torch.empty(P, 16, 3, dtype=torch.float32, device=op_raw.device)
+        with torch.cuda.device(op_raw.device):
+            _n.check(_n.lib.csplat_gauss_act_fwd(_n.stream_handle(op_raw.device), P, _n.ptr(op_raw), _n.ptr(sc_raw), _n.ptr(f_dc),
+                                                 _n.ptr(f_rest), _n.ptr(opacity), _n.ptr(scales), _n.ptr(shs)), "csplat_gauss_act_fwd")
+        ctx.save_for_backward(opacity, scales)
+        ctx.set_materialize_grads(False)
+        return opacity, scales, shs
+
+    @staticmethod
+    def backward(ctx, g_op, g_sc, g_shs):
+        from . import native as _n
+        opacity, scales = ctx.saved_tensors
+        P, dev = opacity.shape[0], opacity.device
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        g_op, g_sc, g_shs = c(g_op), c(g_sc), c(g_shs)
+        d_op, d_sc = torch.empty_like(opacity), torch.empty_like(scales)
+        d_dc = torch.empty(P, 1, 3, dtype=torch.float32, device=dev)
+        d_rest = torch.empty(P, 15, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _n.check(_n.lib.csplat_gauss_act_bwd(_n.stream_handle(dev), P, _n.ptr(opacity), _n.ptr(scales), _n.ptr(g_op), _n.ptr(g_sc),
+                                                 _n.ptr(g_shs), _n.ptr(d_op), _n.ptr(d_sc), _n.ptr(d_dc), _n.ptr(d_rest)),
+                     "csplat_gauss_act_bwd")
+        return d_op, d_sc, d_dc, d_rest
+
+
 class MeshGaussians(DensifyMixin):
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
@@ -179,6 +212,15 @@ class MeshGaussians(DensifyMixin):
     @property
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def activations(self):
+        """(get_opacity, get_scaling, get_features) in one launch each way on the GPU (csplat_gauss_act_fwd/_bwd) -- the three
+        tensors render() hands the rasterizer every step; None when the fused form does not apply (CPU, dtype, layout)"""
+        ts = (self._opacity, self._scaling, self._features_dc, self._features_rest)
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) or self._features_rest.shape[1:] != (15, 3) or \
+                self._features_dc.shape[1:] != (1, 3) or self._opacity.shape[0] == 0:
+            return None
+        return _GaussianActivations.apply(*ts)
 
     def get_covariance(self, scaling_modifier=1):
         L = build_rotation(self._rotation) @ torch.diag_embed(scaling_modifier * self.get_scaling)

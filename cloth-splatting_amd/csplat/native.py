@@ -59,6 +59,8 @@ EXPORTS = {
     "csplat_mask_to_map_temp_bytes": (_sz, [_i64]),
     "csplat_mask_to_map": (_i, [_vp, _i64, _vp, C.c_int32, _vp, _vp, _vp]),
     "csplat_rows_scatter": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _vp]),
+    "csplat_gauss_act_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_gauss_act_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_project_points": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "csplat_psnr_scratch_bytes": (_sz, [_i64]),
     "csplat_psnr": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),

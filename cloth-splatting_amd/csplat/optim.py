@@ -31,14 +31,31 @@ class GroupedAdam(torch.optim.Adam):
                     return False
         return True
 
+    def _step_count(self, st):
+        """the parameter's step count AFTER this step, as a Python int.  torch keeps it as a CPU tensor in the state (that is what
+        state_dict() saves), and reading it back with .item() costs more than the rest of this function: a mirror keyed on the tensor
+        OBJECT and its in-place version supplies it (a loaded state dict brings new tensors, an in-place edit bumps the version: both
+        are read back once)."""
+        t = st["step"]
+        mirror = self.__dict__.setdefault("_py_steps", {})
+        hit = mirror.get(id(t))
+        # (valid while it is the same tensor object and nobody but our own _foreach_add_ has written to it since)
+        n = (hit[1] if hit is not None and hit[0] is t and hit[2] == t._version else int(t.item())) + 1
+        mirror[id(t)] = (t, n, t._version + 1)
+        return n
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None or not self._fusable():
+            self.__dict__.pop("_py_steps", None)
             return super().step(closure)
         buckets = {}
         keep = []
+        steps = []
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
+            bkey = (float(beta1), float(beta2), float(group["eps"]))
+            lr = float(group["lr"])
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -47,14 +64,16 @@ class GroupedAdam(torch.optim.Adam):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                n = self._step_count(st)
+                steps.append(st["step"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32 and v.dtype == torch.float32):
                     raise RuntimeError("GroupedAdam: optimizer state must be contiguous fp32")
                 keep.append(g)
-                key = (p.device, float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()))
-                buckets.setdefault(key, []).append((p, g, m, v, float(group["lr"])))
+                buckets.setdefault((p.device,) + bkey + (n,), []).append((p, g, m, v, lr))
+        if steps:
+            torch._foreach_add_(steps, 1)              # the state's own counters, all in one call
         for (dev, beta1, beta2, eps, step), items in buckets.items():
             n = len(items)
             arr = lambda k: (C.c_void_p * n)(*[it[k].data_ptr() for it in items])  # noqa: E731

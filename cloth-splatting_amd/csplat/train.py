@@ -410,7 +410,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         deforms = deforms_all if not dist_mode else (deforms_all[idx] if idx else None)
     if dist_mode or batched_views:
         pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True,
-                                     vertice_deforms=deforms) if cams else ([], None)
+                                     vertice_deforms=deforms, by_products=False) if cams else ([], None)
     else:
         pkgs = [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
     for cam, pkg in zip(cams, pkgs):

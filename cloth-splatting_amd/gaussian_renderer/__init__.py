@@ -96,7 +96,10 @@ def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, 
     # zero tensor whose gradient is the screen-space (NDC) gradient of the 2D means (used by densification)
     # (upstream writes zeros_like(xyz, requires_grad=True) + 0 and retain_grad(): a non-leaf whose .grad is kept by a Python
     # hook.  A leaf gives the same .grad to train_step / densification without the extra launch and hook per camera.)
-    screenspace_points = torch.zeros(shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype, requires_grad=True, device=dev)
+    if "screenspace_pool" in shared:   # render_views: ONE zero fill for all cameras, every camera's leaf is a slice of it
+        screenspace_points = shared["screenspace_pool"].pop().detach().requires_grad_()
+    else:
+        screenspace_points = torch.zeros(shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype, requires_grad=True, device=dev)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -141,12 +144,14 @@ def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, 
     return raster_settings, kwargs, (screenspace_points, means3D_deform, vertice_deform, rotations_deform, opacity)
 
 
-def _package(viewpoint_camera, raster_out, extras, project_vertices):
+def _package(viewpoint_camera, raster_out, extras, project_vertices, by_products=True):
     rendered_image, radii, depth = raster_out
     screenspace_points, means3D_deform, vertice_deform, rotations_deform, opacity = extras
-    gaussian_projections = _project(viewpoint_camera, means3D_deform)
+    # by_products=False (render_views for a caller that only trains on the record, csplat.train.train_step): the projections and
+    # the per-view visibility mask -- two launches per view that nothing in the step reads -- are left out (None)
+    gaussian_projections = _project(viewpoint_camera, means3D_deform) if by_products else None
     vertice_projections = _project(viewpoint_camera, vertice_deform) if project_vertices else None
-    return RenderResults(render=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
+    return RenderResults(render=rendered_image, viewspace_points=screenspace_points, visibility_filter=(radii > 0) if by_products else None,
                          radii=radii, depth=depth, means3D_deform=means3D_deform, vertice_deform=vertice_deform,
                          shadows_mean=None, shadows_std=None, projections=gaussian_projections,
                          rotations=rotations_deform, opacities=opacity, shadows=None,
@@ -163,7 +168,8 @@ def render(viewpoint_camera, pc, simulator, pipe, bg_color: torch.Tensor, scalin
 
 
 def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-                 no_shadow=False, render_static=False, project_vertices=False, return_stacked=False, vertice_deforms=None):
+                 no_shadow=False, render_static=False, project_vertices=False, return_stacked=False, vertice_deforms=None,
+                 by_products=True):
     """render() for every camera of a training step in one rasterizer call (diff_gaussian_rasterization.rasterize_views:
     one HIP stream per view, the views' kernels overlap, shared parameters get one gradient buffer).  Same results as
     [render(c, ...) for c in viewpoint_cameras]; no counterpart upstream, whose train loop renders camera by camera
@@ -178,6 +184,14 @@ def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor,
     if deforms is not None and deforms.is_cuda and getattr(pc, "fused", False) and hasattr(pc, "transform_views"):
         moved = pc.transform_views(deforms)     # mesh -> Gaussian transform of all cameras in one launch each way
     deform_views = None if deforms is None else deforms.unbind(0)
+    if viewpoint_cameras:
+        acts = pc.activations() if (hasattr(pc, "activations") and override_color is None and not pipe.compute_cov3D_python) else None
+        if acts is not None:    # sigmoid / exp / cat of the Gaussian parameters in one launch each way
+            shared["opacity"], shared["scales"], shared["features"], shared["cov3D"] = acts[0], acts[1], acts[2], None
+        else:
+            shared["opacity"] = pc.get_opacity
+        shared["screenspace_pool"] = list(torch.zeros(len(viewpoint_cameras), shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype,
+                                                      device=shared["opacity"].device).unbind(0))
     for i, cam in enumerate(viewpoint_cameras):
         prepared.append(_prepare(cam, pc, simulator, pipe, bg_color, scaling_modifier, override_color, None, render_static,
                                  shared, None if deforms is None else deform_views[i],
@@ -189,5 +203,5 @@ def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor,
         stacked, outs = rasterize_views([p[0] for p in prepared], [p[1] for p in prepared], stacked=True)
     else:
         stacked, outs = None, rasterize_views([p[0] for p in prepared], [p[1] for p in prepared])
-    res = [_package(cam, out, p[2], project_vertices) for cam, out, p in zip(viewpoint_cameras, outs, prepared)]
+    res = [_package(cam, out, p[2], project_vertices, by_products) for cam, out, p in zip(viewpoint_cameras, outs, prepared)]
     return (res, stacked) if return_stacked else res

@@ -399,6 +399,16 @@ int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W,
                         const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
                         const float *add_pre, const float *add_post, const float *mask, float *ln_stats, float *out);
 
+/* The per-step activations of the Gaussian parameters as render() consumes them (/root/reference/scene_reconstruction/
+ * gaussian_model.py:96-121 via gaussian_renderer/__init__.py:92-118): opacity[P] = sigmoid(opacity_raw), scales[P][3] = exp(scaling_raw),
+ * shs[P][16][3] = cat(features_dc[P][1][3], features_rest[P][15][3]) in one launch, and their backward in one launch (any incoming
+ * gradient may be NULL = zero). */
+int csplat_gauss_act_fwd(void *stream, int64_t P, const float *opacity_raw, const float *scaling_raw, const float *features_dc,
+                         const float *features_rest, float *opacity, float *scales, float *shs);
+int csplat_gauss_act_bwd(void *stream, int64_t P, const float *opacity, const float *scales, const float *g_opacity,
+                         const float *g_scales, const float *g_shs, float *d_opacity_raw, float *d_scaling_raw,
+                         float *d_features_dc, float *d_features_rest);
+
 #ifdef __cplusplus
 }
 #endif

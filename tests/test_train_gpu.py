@@ -435,3 +435,31 @@ def test_train_step_camera_by_camera_equals_batched():
     for qa, qb in zip(a[3] + a[4], b[3] + b[4]):
         d = (qa - qb).abs()
         assert float((d > 1e-6 + 1e-3 * qb.abs()).float().mean()) < 0.02, float(d.max())
+
+
+def test_fused_gaussian_activations_match_the_properties():
+    """MeshGaussians.activations() (csplat_gauss_act_fwd / _bwd: one launch each way) == (get_opacity, get_scaling, get_features) of
+    gaussian_model.py:96-121, values to 1 ulp-level and gradients to 1e-6 relative"""
+    from csplat.gaussians import _GaussianActivations
+    gen = torch.Generator().manual_seed(4)
+    P = 1237
+    raw = [torch.randn(P, 1, generator=gen) * 3, torch.randn(P, 3, generator=gen), torch.randn(P, 1, 3, generator=gen),
+           torch.randn(P, 15, 3, generator=gen)]
+    a = [t.clone().cuda().requires_grad_() for t in raw]
+    b = [t.clone().cuda().requires_grad_() for t in raw]
+    w = [torch.randn(P, 1, generator=gen).cuda(), torch.randn(P, 3, generator=gen).cuda(), torch.randn(P, 16, 3, generator=gen).cuda()]
+    out = _GaussianActivations.apply(*a)
+    ref = (torch.sigmoid(b[0]), torch.exp(b[1]), torch.cat((b[2], b[3]), dim=1))
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape and float((o - r).abs().max()) <= 2e-7 * float(r.abs().max())
+    sum((o * wi).sum() for o, wi in zip(out, w)).backward()
+    sum((r * wi).sum() for r, wi in zip(ref, w)).backward()
+    for x, y in zip(a, b):
+        assert float((x.grad - y.grad).abs().max()) <= 1e-6 * float(y.grad.abs().max())
+    # an output nothing depends on: its incoming gradient is None inside the node
+    c = [t.clone().cuda().requires_grad_() for t in raw]
+    o2 = _GaussianActivations.apply(*c)
+    (o2[1] * w[1]).sum().backward()
+    assert float(c[0].grad.abs().max()) == 0.0 and float(c[3].grad.abs().max()) == 0.0
+    assert float((c[1].grad - b[1].grad).abs().max()) <= 1e-6 * float(b[1].grad.abs().max())
+
