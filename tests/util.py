@@ -155,7 +155,7 @@ def oracle_raster_function():
     return OracleRaster
 
 
-def oracle_render_views(cams, pc, sim, pipe, bg, render_static=False, return_stacked=True, vertice_deforms=None):
+def oracle_render_views(cams, pc, sim, pipe, bg, render_static=False, return_stacked=True, vertice_deforms=None, by_products=True):
     """gaussian_renderer.render_views on CPU fp64 tensors through the oracle (same return convention)."""
     import torch
     from types import SimpleNamespace
