@@ -2254,8 +2254,12 @@ static uint32_t tile_sort_cap() {
 // allocated) when the views do not qualify -- a tile list too long for the LDS sort, different sizes -- and the caller
 // finishes view by view.
 // What the last batched call saw, per image size: the capacities the next one is launched with BEFORE its counts are read.
+// (a short ring: a process that alternates between scenes of different density -- bench.py --mode scenes -- is served by the largest
+// of its recent calls with the same shape instead of failing the speculation at every switch)
 struct SpecHist { int W = 0, H = 0, P = 0; uint32_t R = 0, longest = 0; };
-static SpecHist g_spec_hist;
+constexpr int SPEC_RING = 8;
+static SpecHist g_spec_ring[SPEC_RING];
+static int g_spec_next = 0;
 static std::mutex g_spec_mu;
 
 static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done) {
@@ -2333,10 +2337,12 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
     };
     auto remember = [&]() {
         std::lock_guard<std::mutex> lk(g_spec_mu);
-        g_spec_hist.W = W; g_spec_hist.H = H; g_spec_hist.P = P; g_spec_hist.R = 0; g_spec_hist.longest = 0;
+        SpecHist &e = g_spec_ring[g_spec_next];
+        g_spec_next = (g_spec_next + 1) % SPEC_RING;
+        e.W = W; e.H = H; e.P = P; e.R = 0; e.longest = 0;
         for (int i = 0; i < V; i++) {
-            g_spec_hist.R = info[i][0] > g_spec_hist.R ? info[i][0] : g_spec_hist.R;
-            g_spec_hist.longest = info[i][1] > g_spec_hist.longest ? info[i][1] : g_spec_hist.longest;
+            e.R = info[i][0] > e.R ? info[i][0] : e.R;
+            e.longest = info[i][1] > e.longest ? info[i][1] : e.longest;
         }
     };
     auto release = [&]() {
@@ -2351,9 +2357,14 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
     SpecHist hist;
     {
         std::lock_guard<std::mutex> lk(g_spec_mu);
-        hist = g_spec_hist;
+        for (const SpecHist &e : g_spec_ring)
+            if (e.R > 0 && e.W == W && e.H == H && e.P == P) {
+                hist.W = W; hist.H = H; hist.P = P;
+                hist.R = e.R > hist.R ? e.R : hist.R;
+                hist.longest = e.longest > hist.longest ? e.longest : hist.longest;
+            }
     }
-    if (!(g_debug_flags & 1024u) && hist.R > 0 && hist.W == W && hist.H == H && hist.P == P) {
+    if (!(g_debug_flags & 1024u) && hist.R > 0) {
         uint32_t Rcap[P2_MAX_VIEWS];
         const uint64_t want = (uint64_t)hist.R + hist.R / 8 + 4096;
         const uint32_t rc32 = (uint32_t)(want > 0x7FFFFF00ull ? 0x7FFFFF00ull : want);
