@@ -63,6 +63,11 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
     // W[k * ldw + j] (wt = 1: the TRANSPOSE of such a matrix -- the input-gradient product -- without a transposed copy)
     extern __shared__ float s_wt[];   // fp32 path: [GK][WT_STRIDE], s_wt[k * WT_STRIDE + j] = W[j][k];  B3: bf16 [3][GN][WB_STRIDE]
     constexpr int NW = B3 ? 8 : 4;    // wavefronts per workgroup
+    // TR: the variant with row-aligned [M][128] epilogue operands (the autograd path's mask / running-sum addends) forms the product
+    // transposed -- MFMA A operand = weight, B operand = rows -- so that a lane ends up with 64 outputs of ITS OWN row in groups of
+    // four consecutive columns (register r of tile c <-> column 32 c + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): the operands are then
+    // 16 float4 loads and the result 16 float4 stores per lane instead of 64 scalar ones each
+    constexpr bool TR = B3 && ADD && !LN && !GATHER;
     if (B3) {
         __bf16 *wb = reinterpret_cast<__bf16 *>(s_wt);
         // element t of the 128 x 128 matrix AS STORED sits at (t >> 7) * ldw + (t & 127) whichever way it is read (consecutive
@@ -182,12 +187,21 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
                         for (int p = 0; p < 3; p++) wn[p] = ldw(p, cn, sn);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // next operands requested before this group's 6 MFMAs (192 cycles)
+                    if constexpr (TR) {   // weights as the A operand: the accumulators hold the TRANSPOSED tile (see the epilogue)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[0], a3, acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2], a1, acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[1], a2, acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[0], a2, acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[1], a1, acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[0], a1, acc[c], 0, 0, 0);
+                    } else {
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wc[0], acc[c], 0, 0, 0);   // small terms first
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wc[2], acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wc[1], acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wc[0], acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wc[1], acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wc[0], acc[c], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int p = 0; p < 3; p++) wc[p] = wn[p];
@@ -226,6 +240,40 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
     #pragma unroll
                 for (int i = 0; i < 8; i++) bc[i] = bn[i];
             }
+        }
+        if constexpr (TR) {
+            const int64_t orow = tile * 32 + r32;
+            const bool live = orow < M;
+            const int64_t arow = live ? orow : M - 1;
+            auto row4 = [&](const float *p, float4 (&v)[16]) __attribute__((always_inline)) {   // the lane's 64 columns of its row
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[4 * c + q] = *reinterpret_cast<const float4 *>(p + arow * GN + 32 * c + 8 * q + 4 * h);
+            };
+            auto each = [&](auto fn) __attribute__((always_inline)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[c][4 * q + j] = fn(acc[c][4 * q + j], 4 * c + q, j, 32 * c + 8 * q + 4 * h + j);
+            };
+            auto comp = [](const float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+            each([&](float a, int, int, int f) { return alpha * a + (bias ? bias[f] : 0.f); });
+            if (add_pre) { float4 t[16]; row4(add_pre, t); each([&](float a, int i, int j, int) { return a + comp(t[i], j); }); }
+            if (relu) each([&](float a, int, int, int) { return fmaxf(a, 0.f); });
+            if (add_post) { float4 t[16]; row4(add_post, t); each([&](float a, int i, int j, int) { return a + comp(t[i], j); }); }
+            if (mask) { float4 t[16]; row4(mask, t); each([&](float a, int i, int j, int) { return comp(t[i], j) > 0.f ? a : 0.f; }); }
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        *reinterpret_cast<float4 *>(out + orow * GN + 32 * c + 8 * q + 4 * h) =
+                            make_float4(acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]);
+            }
+            continue;
         }
         // C/D layout of 32x32 tiles: column = lane & 31, tile row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         float o[16][4];
