@@ -260,7 +260,16 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
                         for (int j = 0; j < 4; j++) acc[c][4 * q + j] = fn(acc[c][4 * q + j], 4 * c + q, j, 32 * c + 8 * q + 4 * h + j);
             };
             auto comp = [](const float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
-            each([&](float a, int, int, int f) { return alpha * a + (bias ? bias[f] : 0.f); });
+            if (bias) {
+                float4 t[16];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[4 * c + q] = *reinterpret_cast<const float4 *>(bias + 32 * c + 8 * q + 4 * h);
+                each([&](float a, int i, int j, int) { return alpha * a + comp(t[i], j); });
+            } else {
+                each([&](float a, int, int, int) { return alpha * a; });
+            }
             if (add_pre) { float4 t[16]; row4(add_pre, t); each([&](float a, int i, int j, int) { return a + comp(t[i], j); }); }
             if (relu) each([&](float a, int, int, int) { return fmaxf(a, 0.f); });
             if (add_post) { float4 t[16]; row4(add_post, t); each([&](float a, int i, int j, int) { return a + comp(t[i], j); }); }
