@@ -127,42 +127,42 @@ extern "C" int csplat_rows_scatter(void *stream, int n_tensors, const void *cons
 // in a training step that is bound by the host's launch rate.  One launch each way: element e of the [P][52] row (opacity | 3 scales |
 // 48 SH values, dc first).
 namespace {
-constexpr int ACT_ROW = 52;
+// one grid-stride pass over the P * 48 SH values (coalesced writes, reads in two nearly contiguous streams), with the opacity and the
+// three scales of Gaussian i handled by the thread that copies its first SH value
 __global__ __launch_bounds__(256) void k_gauss_act_fwd(int64_t P, const float *__restrict__ op_raw, const float *__restrict__ sc_raw,
                                                         const float *__restrict__ f_dc, const float *__restrict__ f_rest,
                                                         float *__restrict__ opacity, float *__restrict__ scales, float *__restrict__ shs) {
-    const int64_t n = P * ACT_ROW;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        const int64_t i = e / ACT_ROW;
-        const int k = (int)(e - i * ACT_ROW);
+    const uint32_t n = (uint32_t)(P * 48);            // (the host refuses P * 48 >= 2^31: 32-bit index arithmetic, division by a constant)
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+        const uint32_t i = e / 48u;
+        const int k = (int)(e - i * 48u);
+        shs[e] = k < 3 ? f_dc[3 * i + k] : f_rest[45 * i + k - 3];
         if (k == 0) opacity[i] = 1.f / (1.f + expf(-op_raw[i]));
         else if (k < 4) scales[3 * i + k - 1] = expf(sc_raw[3 * i + k - 1]);
-        else if (k < 7) shs[48 * i + k - 4] = f_dc[3 * i + k - 4];
-        else shs[48 * i + k - 4] = f_rest[45 * i + k - 7];
     }
 }
 __global__ __launch_bounds__(256) void k_gauss_act_bwd(int64_t P, const float *__restrict__ opacity, const float *__restrict__ scales,
                                                         const float *__restrict__ g_op, const float *__restrict__ g_sc,
                                                         const float *__restrict__ g_shs, float *__restrict__ d_op_raw,
                                                         float *__restrict__ d_sc_raw, float *__restrict__ d_dc, float *__restrict__ d_rest) {
-    const int64_t n = P * ACT_ROW;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        const int64_t i = e / ACT_ROW;
-        const int k = (int)(e - i * ACT_ROW);
+    const uint32_t n = (uint32_t)(P * 48);            // (the host refuses P * 48 >= 2^31: 32-bit index arithmetic, division by a constant)
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+        const uint32_t i = e / 48u;
+        const int k = (int)(e - i * 48u);
+        const float g = g_shs ? g_shs[e] : 0.f;
+        if (k < 3) d_dc[3 * i + k] = g; else d_rest[45 * i + k - 3] = g;
         if (k == 0) { const float o = opacity[i]; d_op_raw[i] = g_op ? g_op[i] * ((1.f - o) * o) : 0.f; }     // torch: grad * (1 - y) * y
         else if (k < 4) d_sc_raw[3 * i + k - 1] = g_sc ? g_sc[3 * i + k - 1] * scales[3 * i + k - 1] : 0.f;
-        else if (k < 7) d_dc[3 * i + k - 4] = g_shs ? g_shs[48 * i + k - 4] : 0.f;
-        else d_rest[45 * i + k - 7] = g_shs ? g_shs[48 * i + k - 4] : 0.f;
     }
 }
 }  // namespace
 
 extern "C" int csplat_gauss_act_fwd(void *stream, int64_t P, const float *opacity_raw, const float *scaling_raw, const float *features_dc,
                                     const float *features_rest, float *opacity, float *scales, float *shs) {
-    CSPLAT_REQUIRE(P >= 0 && (P == 0 || (opacity_raw && scaling_raw && features_dc && features_rest && opacity && scales && shs)),
+    CSPLAT_REQUIRE(P >= 0 && P < (int64_t)0x7FFFFFFF / 48 && (P == 0 || (opacity_raw && scaling_raw && features_dc && features_rest && opacity && scales && shs)),
                    "csplat_gauss_act_fwd: bad arguments");
     if (P == 0) return 0;
-    const int64_t want = cdiv(P * ACT_ROW, 256);
+    const int64_t want = cdiv(P * 48, 256);
     k_gauss_act_fwd<<<(unsigned)(want > 8192 ? 8192 : want), 256, 0, (hipStream_t)stream>>>(P, opacity_raw, scaling_raw, features_dc,
                                                                                             features_rest, opacity, scales, shs);
     LAUNCH_CHECK();
@@ -172,10 +172,10 @@ extern "C" int csplat_gauss_act_fwd(void *stream, int64_t P, const float *opacit
 extern "C" int csplat_gauss_act_bwd(void *stream, int64_t P, const float *opacity, const float *scales, const float *g_opacity,
                                     const float *g_scales, const float *g_shs, float *d_opacity_raw, float *d_scaling_raw,
                                     float *d_features_dc, float *d_features_rest) {
-    CSPLAT_REQUIRE(P >= 0 && (P == 0 || (opacity && scales && d_opacity_raw && d_scaling_raw && d_features_dc && d_features_rest)),
+    CSPLAT_REQUIRE(P >= 0 && P < (int64_t)0x7FFFFFFF / 48 && (P == 0 || (opacity && scales && d_opacity_raw && d_scaling_raw && d_features_dc && d_features_rest)),
                    "csplat_gauss_act_bwd: bad arguments");
     if (P == 0) return 0;
-    const int64_t want = cdiv(P * ACT_ROW, 256);
+    const int64_t want = cdiv(P * 48, 256);
     k_gauss_act_bwd<<<(unsigned)(want > 8192 ? 8192 : want), 256, 0, (hipStream_t)stream>>>(P, opacity, scales, g_opacity, g_scales, g_shs,
                                                                                             d_opacity_raw, d_scaling_raw, d_features_dc,
                                                                                             d_features_rest);
