@@ -38,6 +38,8 @@ class GroupedAdam(torch.optim.Adam):
         are read back once)."""
         t = st["step"]
         mirror = self.__dict__.setdefault("_py_steps", {})
+        if len(mirror) > 4096:      # (entries of replaced state tensors are never looked up again)
+            mirror.clear()
         hit = mirror.get(id(t))
         # (valid while it is the same tensor object and nobody but our own _foreach_add_ has written to it since)
         n = (hit[1] if hit is not None and hit[0] is t and hit[2] == t._version else int(t.item())) + 1
