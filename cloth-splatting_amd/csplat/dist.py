@@ -59,6 +59,22 @@ class FlatGrads:
             o += n
         self.tail = self.flat[self.n_param:]
         self.last_allreduce_ms = 0.0
+        # which parameters autograd actually wrote during the current backward (bind() hands EVERY parameter a zero-filled view;
+        # a parameter outside the graph -- `face_offset`, a frozen group -- must end the step with grad None exactly as in the
+        # one-rank step, or Adam would create state for it and advance its step count)
+        self._touched = [False] * len(self.params)
+        self._union = {}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._mark(i)) for i, p in enumerate(self.params)]
+
+    def _mark(self, i):
+        def hook(_p):
+            self._touched[i] = True
+        return hook
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def matches(self, params, extra=0):
         params = list(params)
@@ -67,8 +83,22 @@ class FlatGrads:
 
     def bind(self):
         self.flat.zero_()
+        self._touched = [False] * len(self.params)
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def drop_untouched(self, key=None, group=None):
+        """after backward + all_reduce: `p.grad = None` for every parameter that NO rank's backward wrote.  The union over ranks
+        is one tiny all-reduce(max) + host read the first time a step shape `key` is seen (the graph of a step is static: same
+        cameras per rank, same parameters in it) and is served from a cache afterwards."""
+        if key not in self._union:
+            t = torch.tensor([int(b) for b in self._touched], dtype=torch.int32, device=self.flat.device)
+            if is_dist():
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            self._union[key] = [bool(b) for b in t.tolist()]
+        for p, hit in zip(self.params, self._union[key]):
+            if not hit:
+                p.grad = None
 
     def all_reduce(self, group=None, timed=False):
         """sum over ranks, in place.  timed=True brackets the collective with device synchronisation and records its wall time
@@ -91,6 +121,8 @@ def flat_grads_for(owner, params, extra=0):
     params = list(params)
     fg = owner.__dict__.get("_flat_grads") if hasattr(owner, "__dict__") else None
     if fg is None or not fg.matches(params, extra):
+        if fg is not None:
+            fg.close()
         fg = FlatGrads(params, extra)
         try:
             owner._flat_grads = fg

@@ -452,6 +452,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             fg.tail[3 * P] = psnr_.to(fg.tail.dtype)
             fg.tail[3 * P + 1] = loss_value.to(fg.tail.dtype)
             fg.all_reduce(timed=time_allreduce)
+            fg.drop_untouched(key=(bool(static), n_total))
             viewspace_grad = fg.tail[:3 * P].view(P, 3).clone()
             psnr_, loss_value = fg.tail[3 * P].double(), fg.tail[3 * P + 1].clone()
             radii = cd.reduce_max_radii(radii.contiguous())

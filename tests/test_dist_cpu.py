@@ -109,6 +109,9 @@ def _run_steps(view_parallel, n_cams, with_masks, steps=2):
         out[f"vsg{it}"], out[f"radii{it}"] = stats["viewspace_grad"].numpy().copy(), stats["radii"].numpy().copy()
     for i, p in enumerate(list(pc.parameters()) + list(sim.parameters())):
         out[f"p{i}"] = p.detach().numpy().copy()
+    #  Adam state exists for exactly the parameters the step gives a gradient: `face_offset` is outside the graph
+    out["adam_has_state"] = np.array([int(len(pc.optimizer.state.get(p, {})) > 0) for p in pc.parameters()])
+    out["has_grad_none"] = np.array([int(p.grad is None) for p in pc.parameters()])
     return out
 
 

@@ -700,3 +700,68 @@ def test_tile_sort_list_lengths(P, lo, hi):
     np.testing.assert_array_equal(st["ranges"], o.ranges)
     assert image_err(color.cpu().numpy(), o.color) < TOL
 
+
+
+def test_config2_full_size_vs_oracle():
+    """BASELINE configs[1] at FULL size through the path bench.py times: P = 100k, 4 cameras 800x800, `rasterize_views`
+    (one launch per stage, blockIdx.y = view), called twice so that the second call takes the SPECULATIVE second phase
+    (chunks laid out for the previous call's counts).  Reference call being matched: gaussian_renderer/__init__.py:156-164
+    (one GaussianRasterizer call per camera, train_utils.py:259-292 sums the cameras' gradients through autograd).
+    Per view: keys / ids / ranges / radii / tiles touched bit-exact vs the fp32 oracle, n_contrib ties < 2e-4, image /
+    depth / final_T <= 1e-4 vs the fp64 oracle; the six gradients (shared parameters: sums over the 4 views; means2D:
+    per view) <= 1e-4 vs the fp64 oracle."""
+    from csplat import synthetic as syn
+    from diff_gaussian_rasterization import rasterize_views
+    P, W, H, V = 100_000, 800, 800, 4
+    sc = syn.scene_1(P=P, W=W, H=H, n_cams=V)
+    g = syn.gaussians_at(sc)
+    cases = [dict(g=g, cam=sc["cameras"][i], W=W, H=H, P=P, bg=sc["bg"], sh_degree=3) for i in range(V)]
+    rng = np.random.default_rng(11)
+    dpix = rng.normal(size=(V, 3, H, W)).astype(np.float32)
+    settings = [util.gpu_settings(c) for c in cases]
+    inp = util.gpu_inputs(cases[0])
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    dp = torch.tensor(dpix, device="cuda")
+
+    def run():
+        for k in names:
+            inp[k].grad = None
+        m2d = [torch.zeros(P, 3, device="cuda", requires_grad=True) for _ in range(V)]
+        kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                    rotations=inp["rotations"]) for i in range(V)]
+        colors, outs = rasterize_views(settings, kws, stacked=True)
+        views = colors.grad_fn.views
+        (colors * dp).sum().backward()
+        torch.cuda.synchronize()
+        return colors.detach(), outs, views, m2d
+
+    run()                                   # first call: waits for the counts
+    colors, outs, views, m2d = run()        # second call: speculative layout
+    assert any(v.layout_rendered > v.num_rendered for v in views), "the speculative phase was not taken"
+    sums = {k: 0.0 for k in ("mean3D", "opacity", "sh", "scale", "rot")}
+    for i, case in enumerate(cases):
+        o = oracle_forward(case)
+        v = views[i]
+        assert v.num_rendered == o.R
+        st = util.gpu_chunks(v.chunks, P, W, H, v.layout_rendered)
+        np.testing.assert_array_equal(outs[i][1].cpu().numpy(), o.radii)
+        np.testing.assert_array_equal(st["tiles_touched"], o.tiles_touched)
+        np.testing.assert_array_equal(st["keys"][:o.R], o.keys)
+        np.testing.assert_array_equal(st["ids"][:o.R], o.ids)
+        np.testing.assert_array_equal(st["ranges"], o.ranges)
+        mism = st["n_contrib"] != o.n_contrib
+        assert mism.mean() < 2e-4, f"view {i}: {mism.sum()} n_contrib mismatches"
+        o64 = oracle_forward(case, dtype=np.float64)
+        assert image_err(colors[i].cpu().numpy(), o64.color) < TOL
+        assert image_err(outs[i][2].cpu().numpy(), o64.out_depth) < TOL
+        assert image_err(st["final_T"], o64.final_T) < TOL
+        g64 = util.ro.backward(o64, dpix[i])
+        e = rel_err(m2d[i].grad.cpu().numpy(), g64.mean2D)
+        assert e < TOL, ("mean2D", i, e)
+        for k in sums:
+            sums[k] = sums[k] + np.asarray(getattr(g64, k), np.float64)
+    got = dict(mean3D=inp["means3D"].grad, opacity=inp["opacities"].grad.reshape(-1), sh=inp["shs"].grad,
+               scale=inp["scales"].grad, rot=inp["rotations"].grad)
+    for k, v in got.items():
+        e = rel_err(v.cpu().numpy(), sums[k])
+        assert e < TOL, (k, e)

@@ -1,15 +1,16 @@
 #!/bin/bash
 # Run ON THE GPU BOX from the repo root:  bash tools/collect_issue_counters.sh <tag>
-# Instruction-issue counters of the rasterizer kernels (VERDICT r1 item 2): PMC-only passes (no trace domain besides
-# --kernel-trace) of the ONE-STREAM bench command, <= 8 SQ counters per pass.  tools/summarize_issue_counters.py reduces
-# gpurun_out/<tag>/issue_* to profiles/<tag>_k67_issue.json.
+# Instruction-issue counters of the rasterizer kernels (VERDICT r1 item 2, r2 item 2b): PMC-only passes (no trace domain besides
+# --kernel-trace), <= 8 SQ counters per pass, of the DEFAULT bench command (one launch per stage for all views:
+# k_composite_bwd_views / k_composite_fwd_views -> issue_*) and of the one-view-per-launch command (--no-view-streams ->
+# issue_serial_*).  tools/summarize_issue_counters.py reduces them to profiles/<tag>_k67_issue.json.
 set -u
 TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-view-streams"
+CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step"
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SMEM"
 P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"
 P3="SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INSTS_BRANCH GRBM_GUI_ACTIVE"
@@ -18,6 +19,11 @@ i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/issue_$i" -o p -- $CMD > "$OUT/issue_$i.log" 2>&1
+done
+i=0
+for P in "$P1" "$P2"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/issue_serial_$i" -o p -- $CMD --no-view-streams > "$OUT/issue_serial_$i.log" 2>&1
 done
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
 ls "$OUT"

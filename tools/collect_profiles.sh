@@ -27,8 +27,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 # config 4: the product's training step alone (no PyG-like comparison leg in the population)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gnn" -o t -- python3 "$ROOT/tools/gnn_train_trace.py" 10 > "$OUT/trace_gnn.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_train" -o t -- python3 "$ROOT/bench_train.py" --steps 10 --warmup 3 > "$OUT/trace_train.log" 2>&1
+sha1sum "$ROOT/cloth-splatting_amd/csrc/csplat_raster.hip" | cut -d" " -f1 > "$OUT/raster_src_sha1.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-view-streams > "$OUT/pmc_$c.log" 2>&1
+  # the DEFAULT command: the launches bench.py times (k_composite_bwd_views = all views of a step in one launch)
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step > "$OUT/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmcserial_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-view-streams > "$OUT/pmcserial_$c.log" 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_l128_$c" -o p -- python3 "$ROOT/tools/bench_linear128.py" 300000 2 > /dev/null 2>&1
 done
 cd "$ROOT" && bash tools/collect_issue_counters.sh "$TAG" > /dev/null 2>&1

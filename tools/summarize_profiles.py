@@ -57,11 +57,21 @@ def pmc(sub_prefix):
 
 raster = pmc("pmc_")
 raster = {k: v for k, v in raster.items() if "linear128" not in k}
+serial = {k: v for k, v in pmc("pmcserial_").items() if "linear128" not in k}
+sha = None
+if os.path.exists(os.path.join(src, "raster_src_sha1.txt")):
+    sha = open(os.path.join(src, "raster_src_sha1.txt")).read().strip()
 if raster:
-    k7 = next((v for k, v in raster.items() if k.startswith("k_composite_bwd") or k.startswith("k_render_bwd")), None)
-    doc = {"kernel": "k_composite_bwd (K7)",
+    k7 = next((v for k, v in raster.items() if k.startswith("k_composite_bwd_views")), None) or \
+        next((v for k, v in raster.items() if k.startswith("k_composite_bwd") or k.startswith("k_render_bwd")), None)
+    k6 = next((v for k, v in raster.items() if k.startswith("k_composite_fwd_views")), None)
+    doc = {"kernel": "k_composite_bwd_views (K7, all views of a step in ONE launch -- the launch bench.py times)",
+           "raster_src_sha1": sha,
+           "k6_hbm_bytes_per_launch": k6["hbm_bytes_per_launch"] if k6 else None,
+           "one_view_per_launch": serial or None,
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python3 bench.py "
-                     "--steps 2 --warmup 1 --no-cpu-baseline --no-view-streams` (tools/collect_profiles.sh)",
+                     "--steps 2 --warmup 1 --no-cpu-baseline --no-train-step` (the default command; `one_view_per_launch`: the same "
+                     "with --no-view-streams) (tools/collect_profiles.sh)",
            "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE tallies 64 B per 128-B request on gfx950 -> doubled; "
                          "WRITE_SIZE exact for float atomics. K7's reads are 4-16 B/lane gathers (width not calibrated), "
                          "so the doubled figure is an upper estimate",
