@@ -138,9 +138,11 @@ def _prepare(viewpoint_camera, pc, simulator, pipe, bg_color, scaling_modifier, 
 
     # shadow scalars are disabled in the reference (always None): colours come from SH inside the rasterizer
     shs, colors_precomp = (shared["features"], None) if override_color is None else (None, override_color)
+    # (as the reference, :156-164: `rotations` is passed in the python-covariance branch too -- upstream's rasterizer then raises
+    # its "exactly one of either scale/rotation pair or precomputed 3D covariance" error, and so does the drop-in;
+    # tests/golden/render_wiring.npz holds what the reference's own render() hands over in every branch)
     kwargs = dict(means3D=means3D_deform, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
-                  opacities=opacity, scales=scales, rotations=None if cov3D_precomp is not None else rotations_deform,
-                  cov3D_precomp=cov3D_precomp)
+                  opacities=opacity, scales=scales, rotations=rotations_deform, cov3D_precomp=cov3D_precomp)
     return raster_settings, kwargs, (screenspace_points, means3D_deform, vertice_deform, rotations_deform, opacity)
 
 

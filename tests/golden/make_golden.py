@@ -26,6 +26,7 @@ What it pins; every fixture holds inputs + the referenc
   meshsim.npz     meshnet.meshnet_network.MeshSimulator predict_dx (train, noise) / predict_position (eval) (gen_meshsim)
   mesh_transform.npz  MultiGaussianMesh.get_xyz (+ autograd gradients) and get_rotation with roma served by scipy
   losses.npz      utils.loss_utils.l1_loss / ssim, train_utils.image_losses / regularization, masked and unmasked
+  render_wiring.npz  gaussian_renderer.render itself with a RECORDING stand-in for the rasterizer extension (gen_render_wiring)
 """
 import inspect
 import os
@@ -659,6 +660,184 @@ def gen_mesh_transform():
     np.savez_compressed(os.path.join(OUT, "mesh_transform.npz"), **{k: npy(v) for k, v in out.items()})
 
 
+class RecordingRasterizer:
+    """stand-in for the absent `diff_gaussian_rasterization` extension: records the settings record and every tensor the
+    reference's render() hands the rasterizer, returns zeros of the documented shapes (color [3,H,W], radii [P] int32, depth [1,H,W])"""
+    calls = []
+
+    def __init__(self, raster_settings):
+        self.raster_settings = raster_settings
+
+    def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        RecordingRasterizer.calls.append((self.raster_settings, dict(means3D=means3D, means2D=means2D, opacities=opacities, shs=shs,
+                                                                     colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+                                                                     cov3D_precomp=cov3D_precomp)))
+        rs = self.raster_settings
+        P = means3D.shape[0]
+        return (torch.zeros(3, rs.image_height, rs.image_width), torch.zeros(P, dtype=torch.int32),
+                torch.zeros(1, rs.image_height, rs.image_width))
+
+
+def install_render_shims():
+    """what `import gaussian_renderer` (the reference's) needs on this image: the mesh shims + roma-by-scipy of the fixtures above,
+    a recording `diff_gaussian_rasterization`, and `meshnet.meshnet_network` exec'd from the reference text with its merge
+    conflict resolved to the 9b63d7a side (as gen_meshsim does)."""
+    from typing import NamedTuple
+    install_mesh_shims()
+    install_roma_scipy()
+
+    class GaussianRasterizationSettings(NamedTuple):       # the 12 fields of the upstream record, in upstream's order
+        image_height: int
+        image_width: int
+        tanfovx: float
+        tanfovy: float
+        bg: torch.Tensor
+        scale_modifier: float
+        viewmatrix: torch.Tensor
+        projmatrix: torch.Tensor
+        sh_degree: int
+        campos: torch.Tensor
+        prefiltered: bool
+        debug: bool
+    dgr = types.ModuleType("diff_gaussian_rasterization")
+    dgr.GaussianRasterizationSettings, dgr.GaussianRasterizer = GaussianRasterizationSettings, RecordingRasterizer
+    sys.modules["diff_gaussian_rasterization"] = dgr
+    viz = types.ModuleType("meshnet.viz")
+    viz.plot_mesh = viz.plot_pcd_list = None
+    sys.modules["meshnet.viz"] = viz
+    src = open(os.path.join(REF, "meshnet/meshnet_network.py")).read()
+    src = re.sub(r"<<<<<<< HEAD\n.*?=======\n(.*?)>>>>>>> [^\n]*\n", r"\1", src, flags=re.S)
+    mm = types.ModuleType("meshnet.meshnet_network")
+    exec(compile(src, "<meshnet_network>", "exec"), mm.__dict__)
+    import meshnet
+    sys.modules["meshnet.meshnet_network"] = mm
+    meshnet.meshnet_network = mm
+
+
+class cuda_calls_as_cpu(cuda_as_cpu):
+    """cuda_as_cpu + `tensor.cuda()` -> the tensor itself and `zeros_like(..., device="cuda")` on the CPU (render() uses both)"""
+
+    def __enter__(self):
+        super().__enter__()
+        self.saved_cuda, self.saved_zl = torch.Tensor.cuda, torch.zeros_like
+        torch.Tensor.cuda = lambda t, *a, **k: t
+
+        def zeros_like(x, **k):
+            if "cuda" in str(k.get("device", "")):
+                k["device"] = "cpu"
+            return self.saved_zl(x, **k)
+        torch.zeros_like = zeros_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda, torch.zeros_like = self.saved_cuda, self.saved_zl
+        super().__exit__(*exc)
+
+
+def render_wiring_scene():
+    """the seeded inputs of render_wiring.npz as plain tensors (also imported by tests/test_render_wiring_cpu.py, which feeds the
+    reference's own MultiGaussianMesh / Camera objects built from them to the BUILD's render())"""
+    g = torch.Generator().manual_seed(77)
+    gm = 6
+    xs = torch.linspace(-0.5, 0.5, gm)
+    pos = torch.stack([xs.repeat(gm), xs.repeat_interleave(gm), 0.05 * torch.rand(gm * gm, generator=g)], 1)
+    quads = [(r * gm + c, r * gm + c + 1, (r + 1) * gm + c, (r + 1) * gm + c + 1) for r in range(gm - 1) for c in range(gm - 1)]
+    face = torch.tensor([[a, b, c2] for a, b, c2, d in quads] + [[b, d, c2] for a, b, c2, d in quads]).t().contiguous()
+    F, P = face.shape[1], 90
+    bary = torch.rand(P, 3, generator=g) + 0.05
+    d = dict(pos=pos, face=face, face_ids=torch.randint(0, F, (P,), generator=g), face_bary=bary / bary.sum(1, keepdim=True),
+             rotation=torch.randn(P, 4, generator=g), scaling=torch.log(0.02 + 0.03 * torch.rand(P, 3, generator=g)),
+             opacity=torch.randn(P, 1, generator=g), features_dc=torch.randn(P, 1, 3, generator=g),
+             features_rest=0.1 * torch.randn(P, 15, 3, generator=g), override_color=torch.rand(P, 3, generator=g),
+             wave=0.08 * torch.randn(pos.shape[0], 3, generator=g), bg=torch.tensor([1.0, 0.5, 0.25]))
+    # camera: the pose_spherical-style look-at of the synthetic scenes, through the reference's Camera class
+    th, phi, rad = np.deg2rad(35.0), np.deg2rad(-30.0), 4.0
+    c2w = np.eye(4)
+    c2w[2, 3] = rad
+    rot_phi = np.array([[1, 0, 0, 0], [0, np.cos(phi), -np.sin(phi), 0], [0, np.sin(phi), np.cos(phi), 0], [0, 0, 0, 1]])
+    rot_th = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ rot_th @ rot_phi @ c2w
+    c2w[:3, 1:3] *= -1
+    w2c = np.linalg.inv(c2w)
+    d.update(cam_R=torch.tensor(np.transpose(w2c[:3, :3])), cam_T=torch.tensor(w2c[:3, 3]), cam_FoVx=torch.tensor(0.6911),
+             cam_FoVy=torch.tensor(0.52), cam_W=torch.tensor(72), cam_H=torch.tensor(56), cam_time=torch.tensor(0.4))
+    return d
+
+
+def render_wiring_objects(d, MultiGaussianMesh, Camera):
+    """the reference's own `pc` and camera objects from the seeded arrays, and a simulator stand-in (any callable taking
+    time_vector [V,1] and returning [V,3], which is all render() asks of it)"""
+    pc = MultiGaussianMesh(3)
+    pc.mesh = types.SimpleNamespace(pos=d["pos"], face=d["face"])
+    pc.face_ids, pc.face_bary = d["face_ids"], torch.nn.Parameter(d["face_bary"].clone())
+    pc._rotation, pc._scaling = torch.nn.Parameter(d["rotation"].clone()), torch.nn.Parameter(d["scaling"].clone())
+    pc._opacity = torch.nn.Parameter(d["opacity"].clone())
+    pc._features_dc, pc._features_rest = torch.nn.Parameter(d["features_dc"].clone()), torch.nn.Parameter(d["features_rest"].clone())
+    pc.active_sh_degree = 2                                  # != max_sh_degree: settings.sh_degree must be the ACTIVE degree
+    H, W = int(d["cam_H"]), int(d["cam_W"])
+    cam = Camera(colmap_id=0, R=d["cam_R"].numpy(), T=d["cam_T"].numpy(), FoVx=float(d["cam_FoVx"]), FoVy=float(d["cam_FoVy"]),
+                 image=torch.zeros(3, H, W), gt_alpha_mask=None, image_name="wiring", uid=0, data_device="cpu", time=float(d["cam_time"]))
+    seen = []
+
+    def simulator(time_vector):
+        seen.append(time_vector.detach().clone())
+        return d["pos"] + d["wave"] * time_vector            # [V,3] + [V,3] * [V,1]
+    simulator.seen = seen
+    return pc, cam, simulator
+
+
+WIRING_CASES = {
+    "default": dict(),
+    "scale_mod": dict(scaling_modifier=1.7),
+    "override_color": dict(override_color="override_color"),
+    "static": dict(render_static=True),
+    "project_vertices": dict(project_vertices=True),
+    "cov_python": dict(pipe_cov=True),
+}
+
+
+def gen_render_wiring():
+    """gaussian_renderer.render (:39-206), the reference's OWN function, run here with a recording stand-in for the rasterizer
+    extension: what it puts into GaussianRasterizationSettings (tanfov = tan(FoV/2), bg, scale_modifier, the transposed matrices,
+    sh_degree = ACTIVE degree, campos), which tensors it hands the rasterizer in which keyword (shs vs colors_precomp, scales vs
+    cov3D_precomp, the deformed means / composed rotations, the zero screen-space tensor), what it asks of the simulator, and its
+    by-products (projections, vertice_projections, the 14-field record).  roma is served by scipy (install_roma_scipy)."""
+    install_render_shims()
+    with cuda_calls_as_cpu():
+        from gaussian_renderer import render
+        from scene_reconstruction.cameras import Camera
+        from scene_reconstruction.gaussian_mesh import MultiGaussianMesh
+        d = render_wiring_scene()
+        out = {"in." + k: npy(v) for k, v in d.items()}
+        for name, kw in WIRING_CASES.items():
+            pc, cam, sim = render_wiring_objects(d, MultiGaussianMesh, Camera)
+            kw = dict(kw)
+            pipe = types.SimpleNamespace(compute_cov3D_python=bool(kw.pop("pipe_cov", False)), convert_SHs_python=False, debug=False)
+            if "override_color" in kw:
+                kw["override_color"] = d["override_color"]
+            RecordingRasterizer.calls.clear()
+            res = render(cam, pc, sim, pipe, d["bg"], **kw)
+            assert len(RecordingRasterizer.calls) == 1
+            rs, args = RecordingRasterizer.calls[0]
+            for f in rs._fields:
+                v = getattr(rs, f)
+                out[f"{name}.settings.{f}"] = npy(v) if torch.is_tensor(v) else np.asarray(v)
+            for k, v in args.items():
+                out[f"{name}.arg.{k}.none"] = np.asarray(v is None)
+                if v is not None:
+                    out[f"{name}.arg.{k}"] = npy(v)
+            out[f"{name}.sim_calls"] = np.asarray(len(sim.seen))
+            if sim.seen:
+                out[f"{name}.sim_time_vector"] = npy(sim.seen[0])
+            for f in res._fields:
+                v = getattr(res, f)
+                out[f"{name}.res.{f}.none"] = np.asarray(v is None)
+                if v is not None:
+                    out[f"{name}.res.{f}"] = npy(v)
+            out[f"{name}.res.viewspace_points.requires_grad"] = np.asarray(res.viewspace_points.requires_grad)
+    np.savez_compressed(os.path.join(OUT, "render_wiring.npz"), **out)
+
+
 def gen_losses():
     """utils.loss_utils.l1_loss / ssim (:20-70; `lpips` -- imported at module level, never called here -- is an empty module)
     and scene_reconstruction.train_utils.image_losses / regularization (:50-102), whose two function bodies are exec'd from
@@ -716,7 +895,7 @@ def gen_losses():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
     gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify(); gen_scene_io()
-    gen_meshsim(); gen_mesh_transform(); gen_losses()
+    gen_meshsim(); gen_mesh_transform(); gen_losses(); gen_render_wiring()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

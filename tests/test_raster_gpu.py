@@ -702,6 +702,25 @@ def test_tile_sort_list_lengths(P, lo, hi):
 
 
 
+def _grad_vs_oracles(name, got, g32, g64, P, tie_frac=1e-3, tie_tol=2e-2):
+    """Gradient parity at sizes where pixels go a thousand entries deep.  (1) against the fp32 oracle -- the same arithmetic, so it
+    lands on the same side of every alpha < 1/255 / T < 1e-4 decision: <= 1e-4 relative, no exceptions.  (2) against the fp64 oracle:
+    <= 1e-4 except for THRESHOLD-TIE Gaussians -- a pixel where fp32 and fp64 decide one of the two discontinuous tests differently
+    moves the gradient of the Gaussians on it by an O(alpha) amount; tools/config2_diag.py shows the fp32 ORACLE off by the same
+    amounts on the same ~20 of 100,000 Gaussians.  Ties are counted (<= tie_frac of P), bounded (<= tie_tol of the gradient scale)
+    and must be ties of the fp32 oracle as well."""
+    got, a32, a64 = (np.asarray(x, np.float64).reshape(P, -1) for x in (got, g32, g64))
+    scale = np.abs(a64).max() + 1e-30
+    e32 = np.abs(got - a32).max() / (np.abs(a32).max() + 1e-30)
+    assert e32 < TOL, (name, "vs fp32 oracle", e32)
+    d = np.abs(got - a64).max(1) / scale
+    ties = d > TOL
+    assert ties.sum() <= tie_frac * P, (name, int(ties.sum()))
+    assert d.max() <= tie_tol, (name, float(d.max()))
+    d32 = np.abs(a32 - a64).max(1) / scale
+    assert np.all(d32[ties] > 0.5 * TOL), (name, "a deviation from fp64 that the fp32 oracle does not share")
+
+
 def test_config2_full_size_vs_oracle():
     """BASELINE configs[1] at FULL size through the path bench.py times: P = 100k, 4 cameras 800x800, `rasterize_views`
     (one launch per stage, blockIdx.y = view), called twice so that the second call takes the SPECULATIVE second phase
@@ -739,6 +758,7 @@ def test_config2_full_size_vs_oracle():
     colors, outs, views, m2d = run()        # second call: speculative layout
     assert any(v.layout_rendered > v.num_rendered for v in views), "the speculative phase was not taken"
     sums = {k: 0.0 for k in ("mean3D", "opacity", "sh", "scale", "rot")}
+    sums32 = dict(sums)
     for i, case in enumerate(cases):
         o = oracle_forward(case)
         v = views[i]
@@ -753,15 +773,14 @@ def test_config2_full_size_vs_oracle():
         assert mism.mean() < 2e-4, f"view {i}: {mism.sum()} n_contrib mismatches"
         o64 = oracle_forward(case, dtype=np.float64)
         assert image_err(colors[i].cpu().numpy(), o64.color) < TOL
-        assert image_err(outs[i][2].cpu().numpy(), o64.out_depth) < TOL
+        assert image_err(outs[i][2].detach().cpu().numpy(), o64.out_depth) < TOL
         assert image_err(st["final_T"], o64.final_T) < TOL
-        g64 = util.ro.backward(o64, dpix[i])
-        e = rel_err(m2d[i].grad.cpu().numpy(), g64.mean2D)
-        assert e < TOL, ("mean2D", i, e)
+        g64, g32 = util.ro.backward(o64, dpix[i]), util.ro.backward(o, dpix[i])
+        _grad_vs_oracles(f"mean2D[{i}]", m2d[i].grad.cpu().numpy(), g32.mean2D, g64.mean2D, P)
         for k in sums:
             sums[k] = sums[k] + np.asarray(getattr(g64, k), np.float64)
+            sums32[k] = sums32[k] + np.asarray(getattr(g32, k), np.float64)
     got = dict(mean3D=inp["means3D"].grad, opacity=inp["opacities"].grad.reshape(-1), sh=inp["shs"].grad,
                scale=inp["scales"].grad, rot=inp["rotations"].grad)
     for k, v in got.items():
-        e = rel_err(v.cpu().numpy(), sums[k])
-        assert e < TOL, (k, e)
+        _grad_vs_oracles(k, v.cpu().numpy(), sums32[k], sums[k], P, tie_frac=4e-3)

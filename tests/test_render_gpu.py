@@ -97,10 +97,19 @@ def test_render_static_no_grad_and_override_color():
         col = torch.rand(1000, 3, device="cuda")
         b = render(cam, pc, sim, pipe, bg, render_static=True, override_color=col)
         pipe2 = SimpleNamespace(compute_cov3D_python=True, convert_SHs_python=False, debug=False)
-        c = render(cam, pc, sim, pipe2, bg, render_static=True)
+        # the reference's python-covariance branch hands the rasterizer rotations AND cov3D_precomp (gaussian_renderer/__init__.py:
+        # 83-88,156-164; recorded in tests/golden/render_wiring.npz), which upstream's wrapper rejects: same error here
+        with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+            render(cam, pc, sim, pipe2, bg, render_static=True)
+        # the covariance itself (gaussian_model.py:27-33) through the rasterizer's own cov3D_precomp input == the scale/rotation path
+        from diff_gaussian_rasterization import GaussianRasterizer
+        import gaussian_renderer as gr
+        st, kw, _ = gr._prepare(cam, pc, sim, pipe, bg, 1.0, None, None, True)
+        kw.update(scales=None, rotations=None, cov3D_precomp=pc.get_covariance(1.0))
+        c_img = GaussianRasterizer(st)(**kw)[0]
     assert torch.isfinite(a.render).all() and a.vertice_projections is None
     assert not torch.allclose(a.render, b.render)
-    assert image_err(c.render.cpu().numpy(), a.render.cpu().numpy()) < 1e-4       # python covariance path == scale/rot path
+    assert image_err(c_img.cpu().numpy(), a.render.cpu().numpy()) < 1e-4       # python covariance == scale/rot path
     with pytest.raises(ValueError):
         render(_camera(sc["cameras"][0], time=1.4), pc, sim, pipe, bg)          # time beyond the mesh table
 
@@ -222,3 +231,104 @@ def test_projection_kernel_matches_reference_formula_and_has_a_gradient():
         got.backward(w)
         ref.backward(w.double())
         assert float((pts.grad.double() - p64.grad).abs().max()) < 1e-4 * float(p64.grad.abs().max())
+
+
+WIRING_CASES = {"default": {}, "scale_mod": dict(scaling_modifier=1.7), "override_color": dict(override_color=True),
+                "static": dict(render_static=True), "project_vertices": dict(project_vertices=True), "cov_python": dict(pipe_cov=True)}
+
+
+@pytest.mark.parametrize("case", sorted(WIRING_CASES))
+def test_render_wiring_equals_the_references_own_render(case):
+    """What the build's render() puts into GaussianRasterizationSettings and hands the rasterizer, its call of the simulator and its
+    by-products, against a RUN OF THE REFERENCE'S OWN render() (gaussian_renderer/__init__.py:39-206) under a recording stand-in for the
+    rasterizer extension (tests/golden/make_golden.py:gen_render_wiring -> render_wiring.npz): tanfov = tan(FoV/2), bg,
+    scale_modifier, the transposed matrices, sh_degree = the ACTIVE degree, campos; shs vs colors_precomp; scales vs cov3D_precomp;
+    the deformed means and the composed rotations (roma served by scipy, fp64: quaternions equal up to sign); the zero screen-space
+    tensor; projections / vertice_projections; which record fields are None."""
+    import gaussian_renderer as gr
+    from csplat.gaussians import MeshGaussians
+    G = util.golden("render_wiring.npz")
+    dev = torch.device("cuda")
+    I = lambda k, dt=torch.float32: torch.tensor(G["in." + k], device=dev, dtype=dt)  # noqa: E731
+    pos, face = I("pos"), I("face", torch.long)
+    ei = torch.cat([face[[0, 1]], face[[1, 2]], face[[2, 0]]], 1)
+    pc = MeshGaussians(3).from_arrays(pos, face, ei, I("face_ids", torch.long), I("face_bary"), I("scaling"), I("rotation"), I("opacity"),
+                                      torch.cat([I("features_dc"), I("features_rest")], 1))
+    pc.active_sh_degree = 2
+    # the camera as the reference's Camera object presents itself to render(): these eight attributes
+    cam = SimpleNamespace(image_height=int(G["in.cam_H"]), image_width=int(G["in.cam_W"]), FoVx=float(G["in.cam_FoVx"]),
+                          FoVy=float(G["in.cam_FoVy"]), time=float(G["in.cam_time"]),
+                          world_view_transform=torch.tensor(G["default.settings.viewmatrix"]),
+                          full_proj_transform=torch.tensor(G["default.settings.projmatrix"]),
+                          camera_center=torch.tensor(G["default.settings.campos"]))
+    wave, seen, calls = I("wave"), [], []
+
+    def simulator(time_vector):
+        seen.append(time_vector.detach().clone())
+        return pos + wave * time_vector
+
+    class Recorder(gr.GaussianRasterizer):
+        def forward(self, **kw):
+            calls.append((self.raster_settings, kw))
+            return super().forward(**kw)
+    kw = dict(WIRING_CASES[case])
+    pipe = SimpleNamespace(compute_cov3D_python=bool(kw.pop("pipe_cov", False)), convert_SHs_python=False, debug=False)
+    if kw.get("override_color"):
+        kw["override_color"] = I("override_color")
+    real = gr.GaussianRasterizer
+    gr.GaussianRasterizer = Recorder
+    try:
+        if case == "cov_python":
+            with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+                gr.render(cam, pc, simulator, pipe, I("bg"), **kw)
+            res = None
+        else:
+            res = gr.render(cam, pc, simulator, pipe, I("bg"), **kw)
+    finally:
+        gr.GaussianRasterizer = real
+    assert len(calls) == 1
+    rs, args = calls[0]
+    g = lambda k: G[f"{case}.{k}"]  # noqa: E731
+    close = lambda a, b, tol=1e-6: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) <= \
+        tol * (float(np.abs(np.asarray(b, np.float64)).max()) + 1e-30)  # noqa: E731
+    for f in ("image_height", "image_width", "sh_degree"):
+        assert int(getattr(rs, f)) == int(g(f"settings.{f}")), f
+    for f in ("prefiltered", "debug"):
+        assert bool(getattr(rs, f)) == bool(g(f"settings.{f}")), f
+    for f in ("tanfovx", "tanfovy", "scale_modifier"):
+        assert abs(float(getattr(rs, f)) - float(g(f"settings.{f}"))) <= 1e-12 * abs(float(g(f"settings.{f}"))), f
+    for f in ("bg", "viewmatrix", "projmatrix", "campos"):
+        np.testing.assert_array_equal(getattr(rs, f).cpu().numpy(), g(f"settings.{f}"), err_msg=f)
+        assert getattr(rs, f).is_cuda, f                      # (the reference calls .cuda() on the camera's matrices, :68-71)
+
+    def same_quats(a, b, tol):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        sgn = np.sign((a * b).sum(1, keepdims=True))
+        return float(np.abs(a * sgn - b).max()) <= tol
+    for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        assert (args.get(k) is None) == bool(g(f"arg.{k}.none")), k
+        if args.get(k) is None:
+            continue
+        got = args[k].detach().cpu().numpy()
+        assert got.shape == g(f"arg.{k}").shape, k
+        if k == "rotations":
+            assert same_quats(got, g("arg.rotations"), 5e-6)
+        else:
+            assert close(got, g(f"arg.{k}"), 2e-6), k
+    assert float(args["means2D"].abs().max()) == 0.0 and args["means2D"].requires_grad
+    assert len(seen) == int(g("sim_calls"))
+    if seen:
+        np.testing.assert_array_equal(seen[0].cpu().numpy(), g("sim_time_vector"))
+    if res is None:
+        return
+    for f in res._fields:
+        assert (getattr(res, f) is None) == bool(g(f"res.{f}.none")), f
+    assert res.viewspace_points is args["means2D"] and res.viewspace_points.shape == g("res.viewspace_points").shape
+    for f in ("means3D_deform", "vertice_deform", "opacities"):
+        assert close(getattr(res, f).detach().cpu().numpy(), g(f"res.{f}"), 2e-6), f
+    assert same_quats(res.rotations.detach().cpu().numpy(), g("res.rotations"), 5e-6)
+    for f in ("projections", "vertice_projections"):
+        if getattr(res, f) is not None:
+            assert float(np.abs(getattr(res, f).detach().cpu().numpy() - g(f"res.{f}")).max()) < 2e-3, f       # pixels
+    for f in ("render", "radii", "depth", "visibility_filter"):
+        assert getattr(res, f).shape == g(f"res.{f}").shape and str(getattr(res, f).dtype).endswith(str(g(f"res.{f}").dtype)), f
