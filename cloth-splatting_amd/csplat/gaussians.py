@@ -219,6 +219,8 @@ class MeshGaussians(DensifyMixin):
         ts = (self._opacity, self._scaling, self._features_dc, self._features_rest)
         if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) or self._features_rest.shape[1:] != (15, 3) or \
                 self._features_dc.shape[1:] != (1, 3) or self._opacity.shape[0] == 0:
+            if self._opacity.shape[0]:
+                _n.composed_fallback("MeshGaussians.activations", _n.why_not_f32c(*ts) or "shape", *ts)
             return None
         return _GaussianActivations.apply(*ts)
 

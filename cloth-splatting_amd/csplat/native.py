@@ -106,6 +106,56 @@ class CsplatError(RuntimeError):
     pass
 
 
+# ---- dispatch visibility: every product function that can take a composed-torch branch on a GPU tensor
+# reports it here.  FALLBACK_COUNTS[(site, kind)] counts them; with CSPLAT_STRICT=1 (or native.STRICT = True; the `-m gpu` tests
+# run that way) the branch raises instead, unless its kind is inside an `allow_fallbacks(...)` block.  kind: "dtype" (not fp32),
+# "layout" (stride / contiguity), "shape" (a width or form no HIP kernel of this library covers, e.g. latent size != 128),
+# "mode" (an option the fused kernels do not implement).  Size thresholds below which the library GEMM is the faster GPU path are
+# tuned dispatch, not fallbacks, and are not reported.
+import collections as _collections
+import contextlib as _contextlib
+
+STRICT = os.environ.get("CSPLAT_STRICT", "0") not in ("", "0")
+FALLBACK_COUNTS = _collections.Counter()
+_ALLOWED = _collections.Counter()
+
+
+@_contextlib.contextmanager
+def allow_fallbacks(*kinds):
+    """inside the block the given kinds of composed-torch branches ("shape", "dtype", "layout", "mode"; none given = all) are
+    counted but do not raise under STRICT -- for callers that knowingly run a form the HIP kernels do not cover"""
+    kinds = kinds or ("shape", "dtype", "layout", "mode")
+    for k in kinds:
+        _ALLOWED[k] += 1
+    try:
+        yield FALLBACK_COUNTS
+    finally:
+        for k in kinds:
+            _ALLOWED[k] -= 1
+
+
+def composed_fallback(site, kind, *tensors):
+    """a product function is about to take its composed-torch branch for `tensors`.  CPU tensors (host-logic tests) are not the
+    product path and are not reported."""
+    if not any(torch.is_tensor(t) and t.is_cuda for t in tensors):
+        return
+    FALLBACK_COUNTS[(site, kind)] += 1
+    if STRICT and _ALLOWED[kind] <= 0:
+        raise CsplatError(f"csplat (strict): {site} would leave the HIP path ({kind}); pass fp32 contiguous tensors of a supported "
+                          "shape, or wrap the call in csplat.native.allow_fallbacks()")
+
+
+def why_not_f32c(*tensors):
+    """None when every given GPU tensor is fp32 and contiguous, else the kind of the first obstacle"""
+    for t in tensors:
+        if torch.is_tensor(t) and t.is_cuda:
+            if t.dtype != torch.float32:
+                return "dtype"
+            if not t.is_contiguous():
+                return "layout"
+    return None
+
+
 def check(rc, what):
     if rc != 0:
         raise CsplatError(f"{what} failed (rc={rc}): {lib.csplat_last_error().decode(errors='replace')}")

@@ -28,6 +28,7 @@ class GroupedAdam(torch.optim.Adam):
                 g = p.grad
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32 and
                         not g.is_sparse and g.device == p.device):
+                    _n.composed_fallback("GroupedAdam.step", "dtype" if (p.dtype != torch.float32 or g.dtype != torch.float32) else "layout", p)
                     return False
         return True
 

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from gaussian_renderer import render, render_views
 from . import dist as cd
+from . import native as _n
 from .densify import densification
 
 # arguments/__init__.py:109-150 overlaid by arguments/cloth_splatting/default.py:1-43
@@ -41,16 +42,16 @@ def l1_loss(network_output, gt, mask=None):
     if mask is not None:
         if ok and _mask_layout(network_output, mask) is not None:
             return FusedL1.apply(network_output, gt, mask)
+        _n.composed_fallback("train.l1_loss", "dtype" if not ok and network_output.shape == gt.shape else "shape", network_output)
         return torch.abs((network_output - gt) * mask).mean()
     if ok:
         return FusedL1.apply(network_output, gt)
+    _n.composed_fallback("train.l1_loss", "dtype" if network_output.shape == gt.shape and network_output.numel() else "shape", network_output)
     return torch.abs(network_output - gt).mean()
 
 
 import ctypes as _C
 from math import exp as _exp
-
-from . import native as _n
 
 _TAPS = {}
 
@@ -240,6 +241,8 @@ def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
     if window_size == 11 and size_average and not return_map and img1.is_cuda and img1.dtype == torch.float32 and \
             img2.dtype == torch.float32 and img1.shape == img2.shape and img1.numel() > 0 and not img2.requires_grad:
         return FusedSSIM.apply(img1, img2)
+    if window_size == 11 and size_average and not return_map:     # the fused kernel's form, missed on dtype / shape
+        _n.composed_fallback("train.ssim", "dtype" if img1.shape == img2.shape and img1.numel() else "shape", img1)
     channel = img1.size(-3)
     wh, wv = _window1d(window_size, channel, img1)
     pad = window_size // 2
@@ -247,6 +250,7 @@ def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
     if window_size == 11 and stacked.is_cuda and stacked.dtype == torch.float32:
         both = GaussianBlur11.apply(stacked)                     # one HIP launch for all five windows (and one in backward)
     else:
+        _n.composed_fallback("train.ssim.window", "mode" if window_size != 11 else "dtype", stacked)
         both = _blur(stacked, wh, wv, pad, channel)              # CPU tensors (tests) / other window sizes
     n = img1.shape[0]
     mu1, mu2 = both[:n], both[n:2 * n]
@@ -274,6 +278,7 @@ def psnr(img1, img2):
             _n.check(_n.lib.csplat_psnr(_n.stream_handle(a.device), B, a.numel() // B, _n.ptr(a), _n.ptr(b), _n.ptr(scratch),
                                         _n.ptr(out)), "csplat_psnr")
         return out
+    _n.composed_fallback("train.psnr", "dtype" if img1.shape == img2.shape and img1.numel() else "shape", img1)
     mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
 
@@ -285,6 +290,9 @@ def image_losses(image_tensor, gt_image_tensor, opt, mask_tensor=None):
             and image_tensor.numel() > 0 and not gt_image_tensor.requires_grad and \
             (mask_tensor is None or _mask_layout(image_tensor, mask_tensor) is not None):
         return FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim, mask_tensor)
+    if opt.lambda_dssim != 0:
+        _n.composed_fallback("train.image_losses", "dtype" if image_tensor.shape == gt_image_tensor.shape and image_tensor.numel() else "shape",
+                             image_tensor)
     loss = l1_loss(image_tensor, gt_image_tensor, mask_tensor)
     if opt.lambda_dssim != 0:
         if mask_tensor is None:
@@ -346,6 +354,8 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True)
             except Exception:
                 pass
         return FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
+    if fused and not static:
+        _n.composed_fallback("train.regularization", "shape", all_vertice_deform)
     loss = torch.zeros([], device=all_vertice_deform.device)
     if not static and opt.lambda_deform_mag > 0. and n_cams >= 3:
         d0 = torch.linalg.norm(all_vertice_deform[1] - all_vertice_deform[0], dim=-1).mean()

@@ -562,23 +562,40 @@ __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket_views(int P, int tiles
 constexpr int TSORT_THREADS = 1024;
 constexpr int TSORT_WAVES = TSORT_THREADS / 64;
 constexpr int TSORT_ITEMS = BUCKET_CAP / TSORT_THREADS;   // 8 keys per lane at most
+constexpr int TSORT_NB = 4 * TSORT_THREADS;               // interpolation buckets: every thread owns 4 consecutive ones
+constexpr int TSORT_LONG = 48;                            // longest thread region the in-place fix takes before the radix fallback
+constexpr int TSORT_WORDS = TSORT_NB + 256 + 8 + 2 + 2 + TSORT_WAVES + 2;   // u32 words of LDS behind the keys
+__host__ __device__ inline size_t tsort_lds_bytes(int longest) {
+    const int items = (longest > 0 ? longest : 1) + TSORT_THREADS - 1;
+    return (size_t)(items / TSORT_THREADS) * TSORT_THREADS * 8 + (size_t)TSORT_WORDS * 4;
+}
 
-// Stable LSD radix sort of one tile's (depth bits << 32 | Gaussian id) keys, entirely in LDS + registers.
-// Keys live in registers between passes (lane l of wave w owns positions w*64*items + i*64 + l, i.e. memory order =
-// (wave, item, lane) order, which is what makes the in-wave match ranking stable); every pass ranks the 8-bit digit with
-// 8 ballots per key and per-wave LDS counters, turns the [wave][digit] counts into offsets, scatters through LDS and
-// reloads.  Byte 3 (ids >= 2^24) is skipped when P < 2^24.
+// One tile's (depth bits << 32 | Gaussian id) keys put into ascending order entirely in LDS + registers.  The result is the
+// unique sorted order of the (unique) composite keys, i.e. exactly the stable (tile | depth) radix order of the upstream
+// pipeline -- however it is reached:
+//   * default (round 3): an INTERPOLATION BUCKET sort.  A tile holds 1 .. 8192 keys whose depths span a narrow range; the
+//     depth bits (positive floats: unsigned order = numeric order) are mapped monotonically onto 4096 buckets between the tile's
+//     own minimum and maximum, every key takes a slot in its bucket with ONE LDS atomic (the order inside a bucket is whatever
+//     the atomics made it), an exclusive scan of the bucket counts gives the bucket starts, the keys are dropped at start +
+//     slot, and every thread insertion-sorts the few keys of its 4 consecutive buckets on the full 64-bit key.  Buckets are
+//     ordered and complete, so the outcome does not depend on the atomic order: bit-identical to the radix sort, in ~7
+//     barriers instead of ~6 per radix pass x 3 passes (25-45 k cycles per busy tile -> see DESIGN section 6).
+//   * fallback (a thread region longer than TSORT_LONG keys: depths piled onto a few buckets by an outlier; all depths equal;
+//     csplat_debug_flags bit 11): the round-2 stable LSD radix sort -- keys live in registers between passes (lane l of wave w
+//     owns positions w*64*items + i*64 + l), every pass ranks the 8-bit digit with 8 ballots per key and per-wave LDS counters.
+// mode: bit 0 = ids < 2^24 (radix: skip byte 3), bit 1 = radix only, bit 2 = fallback limit 1 (tests the fallback path)
 __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
                                                uint64_t *__restrict__ keys_sorted,
-                                               uint32_t *__restrict__ ids_sorted, int skip_byte3) {
+                                               uint32_t *__restrict__ ids_sorted, int mode) {
     extern __shared__ uint64_t s_key[];                 // [m] keys, then the counters
     const int tile = blockIdx.x;
     const int2 r = ranges[tile];
     const int n = r.y - r.x;
     if (n <= 0) return;
+    const int skip_byte3 = mode & 1;
     const int items = (n + TSORT_THREADS - 1) / TSORT_THREADS;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key + (size_t)items * TSORT_THREADS);   // [TSORT_WAVES][256]
-    uint32_t *s_dig = s_cnt + TSORT_WAVES * 256;                                              // [256] + [4]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key + (size_t)items * TSORT_THREADS);   // [TSORT_NB] buckets / [TSORT_WAVES][256]
+    uint32_t *s_dig = s_cnt + TSORT_NB;                                                       // [256] + [4] (+ 4 spare)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wbase = w * items * 64;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -589,9 +606,94 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
         const int idx = wbase + i * 64 + lane;
         key[i] = (i < items && idx < n) ? comp[r.x + idx] : ~0ull;
     }
+    uint32_t *s_diff = s_dig + 264;                                                           // [2]
+    uint32_t *s_mm = s_diff + 2;                                                              // [2] min, max of the depth bits
+    uint32_t *s_wtot = s_mm + 2;                                                              // [TSORT_WAVES]
+    const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
+    if (!(mode & 2)) {
+        // ---- interpolation bucket sort
+        uint32_t dmin = ~0u, dmax = 0u;
+#pragma unroll
+        for (int i = 0; i < TSORT_ITEMS; i++) {
+            const int idx = wbase + i * 64 + lane;
+            if (i < items && idx < n) { const uint32_t d = (uint32_t)(key[i] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
+        }
+        if (threadIdx.x == 0) { s_mm[0] = ~0u; s_mm[1] = 0u; }
+        reinterpret_cast<uint4 *>(s_cnt)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        if (lane == 0) { atomicMin(&s_mm[0], dmin); atomicMax(&s_mm[1], dmax); }
+        __syncthreads();
+        dmin = s_mm[0]; dmax = s_mm[1];
+        if (dmax != dmin) {                                   // (workgroup-uniform)
+            // monotone map of the depth bits onto [0, TSORT_NB): uint -> float conversion, a positive scale and truncation
+            // are all non-decreasing, so bucket order never contradicts depth order
+            const float scale = (float)TSORT_NB / ((float)(dmax - dmin) + 1.0f);
+            uint32_t bs[TSORT_ITEMS];                         // bucket << 16 | slot inside the bucket
+#pragma unroll
+            for (int i = 0; i < TSORT_ITEMS; i++) {
+                const int idx = wbase + i * 64 + lane;
+                if (i < items && idx < n) {
+                    const uint32_t b = min((uint32_t)(TSORT_NB - 1), (uint32_t)((float)((uint32_t)(key[i] >> 32) - dmin) * scale));
+                    bs[i] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the bucket counts: 4 buckets per thread, a wave scan, the wave totals
+            const uint4 c = reinterpret_cast<const uint4 *>(s_cnt)[threadIdx.x];
+            const uint32_t tot = c.x + c.y + c.z + c.w;
+            uint32_t inc = tot;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t o = __shfl_up(inc, dd, 64); if (lane >= dd) inc += o; }
+            if (lane == 63) s_wtot[w] = inc;
+            __syncthreads();
+            uint32_t ex = inc - tot;
+            for (int k = 0; k < w; k++) ex += s_wtot[k];
+            reinterpret_cast<uint4 *>(s_cnt)[threadIdx.x] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TSORT_ITEMS; i++) {
+                const int idx = wbase + i * 64 + lane;
+                if (i < items && idx < n) s_key[s_cnt[bs[i] >> 16] + (bs[i] & 0xFFFFu)] = key[i];
+            }
+            __syncthreads();
+            // the keys of this thread's 4 buckets: already in bucket order, arbitrary inside a bucket -> insertion sort on the
+            // full key (adaptive: a region costs its length + its inversions)
+            const int limit = (mode & 4) ? 1 : TSORT_LONG;
+            bool long_run = (int)tot > limit;
+            if (!long_run && tot >= 2u) {
+                const int lo = (int)ex, hi_ = (int)(ex + tot);
+                for (int a2 = lo + 1; a2 < hi_; a2++) {
+                    const uint64_t v = s_key[a2];
+                    int b2 = a2 - 1;
+                    while (b2 >= lo && s_key[b2] > v) { s_key[b2 + 1] = s_key[b2]; b2--; }
+                    s_key[b2 + 1] = v;
+                }
+            }
+            if (!__syncthreads_or(long_run)) {
+#pragma unroll
+                for (int i = 0; i < TSORT_ITEMS; i++) {
+                    const int idx = wbase + i * 64 + lane;
+                    if (i < items && idx < n) {
+                        const uint64_t k = s_key[idx];
+                        keys_sorted[r.x + idx] = hi | (k >> 32);
+                        ids_sorted[r.x + idx] = (uint32_t)k;
+                    }
+                }
+                return;
+            }
+            // (fallback: key[] still holds the tile's keys; the composite key is unique, so the radix sort below gives the
+            // same order whatever order they are in)
+        }
+    }
+    // ---- stable LSD radix sort (fallback)
     // digits on which every key of the tile agrees need no pass (a stable pass over a constant digit is the identity):
     // typically the exponent byte of the depth, and more on short lists.  One OR-reduction of (key ^ first key).
-    uint32_t *s_diff = s_dig + 260;                                                           // [2]
+    __syncthreads();
     if (threadIdx.x < 2) s_diff[threadIdx.x] = 0u;
     __syncthreads();
     {
@@ -714,7 +816,6 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
     if (full)
         for (int byte = 0; byte < 8; byte++)
             if (varies(byte)) pass(byte * 8);
-    const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
 #pragma unroll
     for (int i = 0; i < TSORT_ITEMS; i++) {
         const int idx = wbase + i * 64 + lane;
@@ -726,13 +827,13 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
 }
 __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
                                                               uint64_t *__restrict__ keys_sorted,
-                                                              uint32_t *__restrict__ ids_sorted, int skip_byte3) {
-    tile_sort_body(ranges, comp, keys_sorted, ids_sorted, skip_byte3);
+                                                              uint32_t *__restrict__ ids_sorted, int mode) {
+    tile_sort_body(ranges, comp, keys_sorted, ids_sorted, mode);
 }
-__global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort_views(P2Table tab, int skip_byte3) {
+__global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort_views(P2Table tab, int mode) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
-    tile_sort_body(w.ranges, w.keys_u, w.keys_sorted, w.ids_sorted, skip_byte3);
+    tile_sort_body(w.ranges, w.keys_u, w.keys_sorted, w.ids_sorted, mode);
 }
 
 template <int CTRL, int RMASK>
@@ -1973,8 +2074,13 @@ bool mail_init() {
 }
 
 // csplat_debug_flags: bit 0 no culling; bit 1 force the global radix sort; bit 2 no mailbox; bit 4 culling radius x4;
-// bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics)
+// bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics);
+// bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
+// bit 12 tile sort: every multi-key thread region takes the radix fallback (test hook)
 unsigned g_debug_flags = 0;
+
+// `mode` argument of the tile sort kernels: bit 0 ids < 2^24, bit 1 radix only, bit 2 fallback limit 1
+int tsort_mode(int P) { return (P < (1 << 24) ? 1 : 0) | ((g_debug_flags & 2048u) ? 2 : 0) | ((g_debug_flags & 4096u) ? 4 : 0); }
 
 int higher_msb(uint32_t n) {  // number of bits needed to represent tile ids < n (upstream getHigherMsb)
     int b = 0;
@@ -2315,10 +2421,9 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
             LAUNCH_CHECK();
         }
         {
-            const int items = cdiv((int)Lcap > 0 ? (int)Lcap : 1, TSORT_THREADS);
-            const size_t lds = (size_t)items * TSORT_THREADS * 8 + (size_t)(TSORT_WAVES * 256 + 256 + 8) * 4;
+            const size_t lds = tsort_lds_bytes((int)Lcap);
             ProfScope ps(PROF_K4, join);
-            k_tile_sort_views<<<dim3(tiles, V), TSORT_THREADS, lds, join>>>(tab, P < (1 << 24));
+            k_tile_sort_views<<<dim3(tiles, V), TSORT_THREADS, lds, join>>>(tab, tsort_mode(P));
             LAUNCH_CHECK();
         }
         {
@@ -2449,10 +2554,9 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
                 k_emit_bucket<<<nb, BUCKET_G, (size_t)tiles * 4, s>>>(P, tiles, g.xy, g.depth, radii, cam, table, ranges, keys_u);
                 LAUNCH_CHECK();
             }
-            const int items = cdiv((int)host_info[1] > 0 ? (int)host_info[1] : 1, TSORT_THREADS);
-            const size_t lds = (size_t)items * TSORT_THREADS * 8 + (size_t)(TSORT_WAVES * 256 + 256 + 8) * 4;
+            const size_t lds = tsort_lds_bytes((int)host_info[1]);
             ProfScope ps(PROF_K4, s);
-            k_tile_sort<<<tiles, TSORT_THREADS, lds, s>>>(ranges, keys_u, keys_sorted, ids_sorted, P < (1 << 24));
+            k_tile_sort<<<tiles, TSORT_THREADS, lds, s>>>(ranges, keys_u, keys_sorted, ids_sorted, tsort_mode(P));
             LAUNCH_CHECK();
         } else {
             // a tile list longer than the LDS sort takes: the global stable radix sort (upstream's pipeline shape)

@@ -19,7 +19,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows, report_missed_edge_tail,
                         linear128, linear_rows, node_update)
 
 
@@ -138,6 +138,7 @@ class InteractionNetwork(nn.Module):
             h, e_next = EdgeFirstLayer.apply(e_base, W[:, 2 * n:], scale, xa, xb, csr)
             agg = edge_tail_aggregate(h, csr, self.edge_fn, a0_relu=True)
         else:
+            report_missed_edge_tail(e_base)
             ec, e_next = edge_latent_linear(e_base, W[:, 2 * n:], scale)
             h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
             h = _tail(mlp_e, h, relu0)
@@ -216,6 +217,11 @@ class Processor(nn.Module):
                 x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt)
                 scale *= 2.0
             return x, e0 * scale
+        if len(self.gnn_stacks) and not torch.is_grad_enabled():
+            # inference on a form the one-pass rollout kernels do not cover (they are built for the 128-wide fp32 network of config 4)
+            from csplat import native as _n
+            _n.composed_fallback("graph_network.Processor.forward", "dtype" if (x.dtype != torch.float32 or edge_features.dtype != torch.float32)
+                                 else "shape", x)
         e_base, scale = edge_features, 1.0
         for gnn in self.gnn_stacks:
             x, e_base = gnn.message_update(x, edge_index, e_base, scale)

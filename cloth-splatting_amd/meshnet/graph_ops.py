@@ -155,6 +155,7 @@ def rows_dot(h, weight, bias):
     """F.linear(h, weight, bias) for few rows of h (<= 8) against a tall 256-column weight, at HBM rate on the GPU."""
     if h.is_cuda and h.dim() == 2 and h.shape[1] == 256 and weight.shape[1] == 256 and 0 < h.shape[0] <= 8 and bias is not None:
         return RowsDot.apply(h, weight, bias)
+    _n.composed_fallback("graph_ops.rows_dot", "shape", h)
     return torch.nn.functional.linear(h, weight, bias)
 
 
@@ -291,6 +292,8 @@ def layer_norm_rows(x, ln: torch.nn.LayerNorm):
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 128 and tuple(ln.normalized_shape) == (128,) and \
             ln.elementwise_affine and ln.bias is not None and torch.is_grad_enabled() and x.shape[0] > 0:
         return LayerNorm128.apply(x, ln.weight, ln.bias, ln.eps)
+    if torch.is_grad_enabled() and x.dim() == 2 and x.shape[0] > 0:
+        _n.composed_fallback("graph_ops.layer_norm_rows", "dtype" if x.dtype != torch.float32 else "shape", x)
     return ln(x)
 
 
@@ -491,6 +494,12 @@ def edge_tail_ok(a0, seq) -> bool:
             m.weight.dtype == torch.float32 for m in lins) and \
         all(isinstance(a, torch.nn.ReLU) for a in acts[:-1]) and isinstance(acts[-1], torch.nn.Identity) and \
         isinstance(mods[1], torch.nn.ReLU)
+
+
+def report_missed_edge_tail(a0):
+    """InteractionNetwork.message_update took the per-layer path for TALL rows (the fused nodes cover 128-wide fp32 MLPs only)"""
+    if torch.is_grad_enabled() and a0.dim() == 2 and a0.shape[0] >= SplitKLinear.BIG_ROWS:
+        _n.composed_fallback("graph_network.message_update", "dtype" if a0.dtype != torch.float32 else "shape", a0)
 
 
 def edge_tail_aggregate(a0, csr, seq, a0_relu=True):

@@ -24,6 +24,7 @@ def edge_features(pos, edge_index):
             _n.check(_n.lib.csplat_gnn_edge_features(_n.stream_handle(pos.device), E, _n.ptr(pos), _n.ptr(edge_index), _n.ptr(out)),
                      "csplat_gnn_edge_features")
         return out
+    _n.composed_fallback("rollout.edge_features", "dtype", pos)
     d = pos[edge_index[0]] - pos[edge_index[1]]
     return torch.cat([d, d.norm(dim=1, keepdim=True)], 1)
 

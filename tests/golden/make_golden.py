@@ -26,6 +26,7 @@ What it pins; every fixture holds inputs + the referenc
   meshsim.npz     meshnet.meshnet_network.MeshSimulator predict_dx (train, noise) / predict_position (eval) (gen_meshsim)
   mesh_transform.npz  MultiGaussianMesh.get_xyz (+ autograd gradients) and get_rotation with roma served by scipy
   losses.npz      utils.loss_utils.l1_loss / ssim, train_utils.image_losses / regularization, masked and unmasked
+  gnn128.npz      EncodeProcessDecode at latent 128 on a tall graph, closed-form weights: forward + gradients (gen_gnn128)
   render_wiring.npz  gaussian_renderer.render itself with a RECORDING stand-in for the rasterizer extension (gen_render_wiring)
 """
 import inspect
@@ -215,6 +216,62 @@ def gen_gnn():
     for k, v in sim2.state_dict().items():
         out["sim2." + k] = npy(v)
     np.savez(os.path.join(OUT, "gnn.npz"), **out)
+
+
+def closed_form_weights(module, salt=0):
+    """fill every parameter of `module` with values that any host can regenerate exactly: an integer hash of (parameter index,
+    element index) mapped to [-0.5, 0.5) in float64, scaled by 2 / sqrt(fan_in) (LayerNorm: 1 + 0.2 h / 0.2 h), cast to float32.
+    Lets a fixture pin a 128-wide network WITHOUT storing its ~0.5 M weights; tests/util.py holds the identical function."""
+    with torch.no_grad():
+        for k, (name, p) in enumerate(module.named_parameters()):
+            i = np.arange(p.numel(), dtype=np.uint64)
+            h = ((i * np.uint64(2654435761) + np.uint64(40503 * (k + 1) + 977 * salt)) % np.uint64(1 << 32)).astype(np.float64) / float(1 << 32) - 0.5
+            if p.dim() == 2:
+                v = h * (2.0 / np.sqrt(p.shape[1]))
+            elif name.endswith("weight"):           # LayerNorm gain
+                v = 1.0 + 0.2 * h
+            else:
+                v = 0.2 * h
+            p.copy_(torch.from_numpy(v.astype(np.float32)).reshape(p.shape))
+    return module
+
+
+def gen_gnn128():
+    """EncodeProcessDecode at the config-4 width (latent 128, 2 hidden layers of 128) on a TALL graph (E = 16,640 >= the row count
+    from which the build's training path runs its fused MFMA autograd nodes; rollout kernels have no row threshold): the
+    reference's own module under the PyG shim, weights in closed form (closed_form_weights), forward output, and the gradients of
+    sum(y * w) w.r.t. the node / edge inputs, one edge-MLP weight of every kind (first-layer block, hidden, last), a node-MLP weight,
+    a LayerNorm gain and a bias."""
+    install_pyg_shim()
+    from meshnet.graph_network import EncodeProcessDecode
+    g = torch.Generator().manual_seed(128)
+    N, deg = 520, 32
+    E = N * deg
+    dst = torch.arange(N).repeat_interleave(deg)
+    src = (dst + torch.randint(1, 40, (E,), generator=g)) % N
+    perm = torch.randperm(E, generator=g)
+    ei = torch.stack([src, dst])[:, perm].contiguous()
+    net = closed_form_weights(EncodeProcessDecode(nnode_in_features=8, nnode_out_features=3, nedge_in_features=4, latent_dim=128,
+                                                  nmessage_passing_steps=2, nmlp_layers=2, mlp_hidden_dim=128))
+    x = torch.randn(N, 8, generator=g)
+    ef = torch.randn(E, 4, generator=g)
+    w = torch.randn(N, 3, generator=g)
+    with torch.no_grad():
+        y_eval = net(x, ei, ef)
+    xg, eg = x.clone().requires_grad_(True), ef.clone().requires_grad_(True)
+    y = net(xg, ei, eg)
+    (y * w).sum().backward()
+    l0 = net._processor.gnn_stacks[0]
+    l1 = net._processor.gnn_stacks[1]
+    out = dict(edge_index=npy(ei).astype(np.int32), x=npy(x), e=npy(ef), w=npy(w), y=npy(y), y_eval=npy(y_eval), dx=npy(xg.grad),
+               de=npy(eg.grad),
+               dW_edge_first0=npy(l0.edge_fn[0][0].weight.grad), dW_edge_hidden0=npy(l0.edge_fn[0][2].weight.grad),
+               dW_edge_last1=npy(l1.edge_fn[0][4].weight.grad), db_edge_last1=npy(l1.edge_fn[0][4].bias.grad),
+               dW_node_first1=npy(l1.node_fn[0][0].weight.grad), dgamma_edge0=npy(l0.edge_fn[1].weight.grad),
+               dbeta_node1=npy(l1.node_fn[1].bias.grad), dW_enc_edge=npy(net._encoder.edge_fn[0][0].weight.grad),
+               dW_dec_last=npy(net._decoder.node_fn[4].weight.grad),
+               w_probe=npy(l0.edge_fn[0][2].weight[:2, :5]))         # a few weights, so that the test can check its regeneration
+    np.savez_compressed(os.path.join(OUT, "gnn128.npz"), **out)
 
 
 def gen_normalizer():
@@ -895,7 +952,7 @@ def gen_losses():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
     gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify(); gen_scene_io()
-    gen_meshsim(); gen_mesh_transform(); gen_losses(); gen_render_wiring()
+    gen_meshsim(); gen_mesh_transform(); gen_losses(); gen_render_wiring(); gen_gnn128()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -104,6 +104,65 @@ def test_encode_process_decode_forward_backward_vs_reference():
     assert rel_err(dW, g["epd_dW_first"]) < 1e-4
 
 
+def test_encode_process_decode_latent128_tall_graph_vs_reference():
+    """The 128-wide MFMA paths held to a REFERENCE-RUN vector: gnn128.npz = the reference's EncodeProcessDecode
+    (latent 128, 2 x 128 hidden, 2 message-passing steps) under the PyG shim on a graph with E = 16,640 edges -- tall enough for the
+    training path's fused autograd nodes (EdgeFirstLayer / EdgeTailAggregate / csplat_dw128) -- with closed-form weights.  Rollout
+    (no_grad: csplat_linear128 / csplat_gnn_node_update) and training path (forward + every kind of gradient) <= 1e-4; strict
+    dispatch: nothing may leave the HIP path."""
+    from csplat import native
+    from meshnet.graph_network import EncodeProcessDecode
+    g = golden("gnn128.npz")
+    net = util.closed_form_weights(EncodeProcessDecode(8, 3, 4, 128, 2, 2, 128).to("cuda"))
+    l0, l1 = net._processor.gnn_stacks
+    np.testing.assert_array_equal(l0.edge_fn[0][2].weight[:2, :5].detach().cpu().numpy(), g["w_probe"])      # same weights as the generator's
+    ei = torch.tensor(g["edge_index"].astype(np.int64), device="cuda")
+    before = sum(native.FALLBACK_COUNTS.values())
+    with torch.no_grad():
+        y_eval = net(torch.tensor(g["x"], device="cuda"), ei, torch.tensor(g["e"], device="cuda"))
+    assert rel_err(y_eval.cpu().numpy(), g["y_eval"]) < 1e-4
+    x = torch.tensor(g["x"], device="cuda", requires_grad=True)
+    e = torch.tensor(g["e"], device="cuda", requires_grad=True)
+    y = net(x, ei, e)
+    assert rel_err(y.detach().cpu().numpy(), g["y"]) < 1e-4
+    # the fused nodes are in the graph
+    names, stack, seen = set(), [y.grad_fn], set()
+    while stack:
+        f = stack.pop()
+        if f is None or id(f) in seen:
+            continue
+        seen.add(id(f)); names.add(type(f).__name__)
+        stack += [nf for nf, _ in f.next_functions]
+    assert any(n.startswith("EdgeFirstLayer") for n in names) and any(n.startswith("EdgeTailAggregate") for n in names), sorted(names)
+    (y * torch.tensor(g["w"], device="cuda")).sum().backward()
+    got = dict(dx=x.grad, de=e.grad, dW_edge_first0=l0.edge_fn[0][0].weight.grad, dW_edge_hidden0=l0.edge_fn[0][2].weight.grad,
+               dW_edge_last1=l1.edge_fn[0][4].weight.grad, db_edge_last1=l1.edge_fn[0][4].bias.grad,
+               dW_node_first1=l1.node_fn[0][0].weight.grad, dgamma_edge0=l0.edge_fn[1].weight.grad, dbeta_node1=l1.node_fn[1].bias.grad,
+               dW_enc_edge=net._encoder.edge_fn[0][0].weight.grad, dW_dec_last=net._decoder.node_fn[4].weight.grad)
+    for k, v in got.items():
+        err = rel_err(v.cpu().numpy(), g[k])
+        assert err < 1e-4, (k, err)
+    assert sum(native.FALLBACK_COUNTS.values()) == before
+
+
+def test_strict_dispatch_raises_and_counts():
+    """csplat.native.STRICT (set for every -m gpu test by conftest): a product function that would compose torch ops for a GPU tensor
+    raises; inside allow_fallbacks() it is counted and runs"""
+    from csplat import native, train as tr
+    a = torch.rand(2, 3, 16, 16, device="cuda", dtype=torch.float64)
+    b = torch.rand(2, 3, 16, 16, device="cuda", dtype=torch.float64)
+    assert native.STRICT
+    with pytest.raises(native.CsplatError, match="strict"):
+        tr.l1_loss(a, b)
+    n0 = native.FALLBACK_COUNTS[("train.l1_loss", "dtype")]
+    with native.allow_fallbacks("dtype"):
+        v = tr.l1_loss(a, b)
+    assert native.FALLBACK_COUNTS[("train.l1_loss", "dtype")] == n0 + 1
+    assert abs(float(v) - float((a - b).abs().mean())) < 1e-12
+    assert float(tr.l1_loss(a.float(), b.float())) > 0          # the fp32 form is the HIP kernel: no report
+    assert native.FALLBACK_COUNTS[("train.l1_loss", "dtype")] == n0 + 1
+
+
 def test_cloth_simulator_vs_reference():
     g = golden("gnn.npz")
     from meshnet.cloth_network import ClothMeshSimulator

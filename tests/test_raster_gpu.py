@@ -684,22 +684,58 @@ def test_speculative_second_phase_equals_waiting_for_the_counts():
     assert grew >= 2                                         # the speculation was actually taken on some calls
 
 
+@pytest.mark.parametrize("flags", [0, 2048, 4096], ids=["bucket_sort", "radix_only", "bucket_sort_forced_fallback"])
 @pytest.mark.parametrize("P,lo,hi", [(1500, 1, 2048), (5000, 2049, 4096), (9000, 4097, 8192)])
-def test_tile_sort_list_lengths(P, lo, hi):
+def test_tile_sort_list_lengths(P, lo, hi, flags):
     """the in-LDS tile sort keeps 1 .. 8 keys per lane depending on the tile's list length (up to 8192 entries): short, medium and
     near-capacity lists against the oracle's sorted lists, bit for bit (the case asserts that its longest list is in the range it is
-    meant for)"""
+    meant for) -- through the interpolation bucket sort (default), the LSD radix sort alone (csplat_debug_flags bit 11) and the bucket
+    sort with every multi-key thread region sent to the radix fallback (bit 12)"""
+    from csplat import native
     case = make_case(P=P, W=64, H=48, seed=21, grid=12, scale_mul=6.0, radius=3.0)
     o = oracle_forward(case)
     longest = int((o.ranges[:, 1] - o.ranges[:, 0]).max())
     assert lo <= longest <= hi, longest
-    color, radii, depth, st = util.gpu_forward_raw(case)
+    try:
+        native.lib.csplat_debug_flags(flags)
+        color, radii, depth, st = util.gpu_forward_raw(case)
+    finally:
+        native.lib.csplat_debug_flags(0)
     assert st["R"] == o.R
     np.testing.assert_array_equal(st["keys"], o.keys)
     np.testing.assert_array_equal(st["ids"], o.ids)
     np.testing.assert_array_equal(st["ranges"], o.ranges)
     assert image_err(color.cpu().numpy(), o.color) < TOL
 
+
+def test_tile_sort_depth_outliers_and_clusters():
+    """the interpolation bucket sort maps depths linearly between the tile's min and max: a far OUTLIER squeezes every other key of
+    the tile into a handful of buckets (thread regions longer than the in-place limit -> the radix fallback, taken by construction
+    here), two depth CLUSTERS leave most buckets empty, and clones add equal-depth runs on top.  Sorted lists bit-exact vs the oracle."""
+    case = make_case(P=6000, W=64, H=48, seed=33, grid=12, scale_mul=6.0, radius=3.0)
+    g = case["g"]
+    cam = case["cam"]
+    Vm = np.asarray(cam["world_view_transform"], np.float64).reshape(4, 4)
+    axis = Vm[:3, 2] / np.dot(Vm[:3, 2], Vm[:3, 2])          # moving a centre by t * axis adds t to its view-space depth
+    m = g["means3D"].astype(np.float64)
+    # squeeze the sheet to a depth slab 1e-4 thick (so that ~5000 keys share a few dozen fp32 depth values apart), then send a few
+    # Gaussians far behind it and a cluster halfway
+    pv = m @ Vm[:3, :3] + Vm[3, :3]
+    m = m + np.outer((3.0 + (pv[:, 2] - pv[:, 2].mean()) * 1e-4) - pv[:, 2], axis)
+    m[:5] += 60.0 * axis                                       # outliers: depth 63
+    m[5:800] += 2.0 * axis                                     # second cluster at depth 5
+    g["means3D"] = m.astype(np.float32)
+    g["scales"] = (g["scales"] * 0.5).astype(np.float32)
+    rep = lambda a: np.concatenate([a, a[1000:1200]], 0)  # noqa: E731   (200 clones: bit-equal depths)
+    case["g"] = {k: rep(v) for k, v in g.items()}
+    case["P"] = 6200
+    o = oracle_forward(case)
+    assert int((o.ranges[:, 1] - o.ranges[:, 0]).max()) > 1500
+    color, radii, depth, st = util.gpu_forward_raw(case)
+    assert st["R"] == o.R
+    np.testing.assert_array_equal(st["keys"], o.keys)
+    np.testing.assert_array_equal(st["ids"], o.ids)
+    np.testing.assert_array_equal(st["ranges"], o.ranges)
 
 
 def _grad_vs_oracles(name, got, g32, g64, P, tie_frac=1e-3, tie_tol=2e-2):

@@ -37,6 +37,24 @@ def oracle_forward(case, dtype=np.float32, **over):
                       dtype=dtype, **kw)
 
 
+def closed_form_weights(module, salt=0):
+    """the weights of tests/golden/make_golden.py:closed_form_weights (identical arithmetic: an integer hash -> float64 -> float32),
+    so that gnn128.npz pins a 128-wide network without storing its weights"""
+    import torch
+    with torch.no_grad():
+        for k, (name, p) in enumerate(module.named_parameters()):
+            i = np.arange(p.numel(), dtype=np.uint64)
+            h = ((i * np.uint64(2654435761) + np.uint64(40503 * (k + 1) + 977 * salt)) % np.uint64(1 << 32)).astype(np.float64) / float(1 << 32) - 0.5
+            if p.dim() == 2:
+                v = h * (2.0 / np.sqrt(p.shape[1]))
+            elif name.endswith("weight"):
+                v = 1.0 + 0.2 * h
+            else:
+                v = 0.2 * h
+            p.copy_(torch.from_numpy(v.astype(np.float32)).reshape(p.shape).to(p.device))
+    return module
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
