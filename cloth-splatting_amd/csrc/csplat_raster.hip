@@ -442,31 +442,41 @@ __global__ __launch_bounds__(256) void k_tile_colscan_views(int tiles, int nb, K
 }
 
 // single workgroup: exclusive scan of the per-tile totals -> tile ranges, R, longest list
+constexpr int INFO_BUSY = 64;   // word offset of the non-empty-tile list inside the info block: [count, tile ids ...]
 __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
                                                uint32_t *__restrict__ info, volatile uint32_t *mailbox, uint32_t tag) {
-    __shared__ uint32_t s_w[17];
+    // ONE scan over the tiles of two running sums packed in 64 bits: low word = instances (the tile ranges), high word = number of
+    // non-empty tiles (their compact list: the tile sort launches over it instead of over a grid that is ~90 % empty on scene_1)
+    __shared__ unsigned long long s_w[17];
     __shared__ uint32_t s_max[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t carry = 0, mx = 0;
+    unsigned long long carry = 0ull;
+    uint32_t mx = 0;
+    uint32_t *busy = info + INFO_BUSY;
     for (int base = 0; base < tiles; base += 1024) {
         const int t = base + threadIdx.x;
         const uint32_t c = t < tiles ? cnt[t] : 0u;
         mx = max(mx, c);
-        uint32_t inc = c;
+        const unsigned long long v0 = (unsigned long long)c | ((unsigned long long)(c ? 1u : 0u) << 32);
+        unsigned long long inc = v0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
         if (lane == 63) s_w[w] = inc;
         __syncthreads();
         if (w == 0) {
-            uint32_t v = lane < 16 ? s_w[lane] : 0u, vi = v;
+            unsigned long long v = lane < 16 ? s_w[lane] : 0ull, vi = v;
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { const uint32_t o = __shfl_up(vi, d, 64); if (lane >= d) vi += o; }
+            for (int d = 1; d < 16; d <<= 1) { const unsigned long long o = __shfl_up(vi, d, 64); if (lane >= d) vi += o; }
             if (lane < 16) s_w[lane] = vi - v;
             if (lane == 15) s_w[16] = vi;
         }
         __syncthreads();
-        const uint32_t ex = carry + s_w[w] + inc - c;
-        if (t < tiles) ranges[t] = c ? make_int2((int)ex, (int)(ex + c)) : make_int2(0, 0);
+        const unsigned long long exl = carry + s_w[w] + inc - v0;
+        const uint32_t ex = (uint32_t)exl;
+        if (t < tiles) {
+            ranges[t] = c ? make_int2((int)ex, (int)(ex + c)) : make_int2(0, 0);
+            if (c) busy[1 + (uint32_t)(exl >> 32)] = (uint32_t)t;
+        }
         carry += s_w[16];
         __syncthreads();
     }
@@ -477,10 +487,11 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
     if (threadIdx.x == 0) {
         uint32_t m = 0;
         for (int k = 0; k < 16; k++) m = max(m, s_max[k]);
-        info[0] = carry;
+        info[0] = (uint32_t)carry;
         info[1] = m;
+        busy[0] = (uint32_t)(carry >> 32);
         if (mailbox) {   // host-mapped pinned memory: the host polls the tag instead of blocking in a stream synchronise
-            mailbox[0] = carry;
+            mailbox[0] = (uint32_t)carry;
             mailbox[1] = m;
             __threadfence_system();
             mailbox[2] = tag;
@@ -563,8 +574,9 @@ constexpr int TSORT_THREADS = 1024;
 constexpr int TSORT_WAVES = TSORT_THREADS / 64;
 constexpr int TSORT_ITEMS = BUCKET_CAP / TSORT_THREADS;   // 8 keys per lane at most
 constexpr int TSORT_NB = 4 * TSORT_THREADS;               // interpolation buckets: every thread owns 4 consecutive ones
-constexpr int TSORT_LONG = 48;                            // longest thread region the in-place fix takes before the radix fallback
-constexpr int TSORT_WORDS = TSORT_NB + 256 + 8 + 2 + 2 + TSORT_WAVES + 2;   // u32 words of LDS behind the keys
+constexpr int TSORT_GRID = 512;                           // workgroups per view striding over the non-empty tiles
+constexpr int TSORT_LONG = 64;                            // most keys in one bucket before the tile takes the radix fallback
+constexpr int TSORT_WORDS = TSORT_NB + 4 + 256 + 8 + 2 + 2 + TSORT_WAVES + 2;   // u32 words of LDS behind the keys
 __host__ __device__ inline size_t tsort_lds_bytes(int longest) {
     const int items = (longest > 0 ? longest : 1) + TSORT_THREADS - 1;
     return (size_t)(items / TSORT_THREADS) * TSORT_THREADS * 8 + (size_t)TSORT_WORDS * 4;
@@ -577,25 +589,24 @@ __host__ __device__ inline size_t tsort_lds_bytes(int longest) {
 //     depth bits (positive floats: unsigned order = numeric order) are mapped monotonically onto 4096 buckets between the tile's
 //     own minimum and maximum, every key takes a slot in its bucket with ONE LDS atomic (the order inside a bucket is whatever
 //     the atomics made it), an exclusive scan of the bucket counts gives the bucket starts, the keys are dropped at start +
-//     slot, and every thread insertion-sorts the few keys of its 4 consecutive buckets on the full 64-bit key.  Buckets are
-//     ordered and complete, so the outcome does not depend on the atomic order: bit-identical to the radix sort, in ~7
-//     barriers instead of ~6 per radix pass x 3 passes (25-45 k cycles per busy tile -> see DESIGN section 6).
-//   * fallback (a thread region longer than TSORT_LONG keys: depths piled onto a few buckets by an outlier; all depths equal;
+//     slot, and every key then counts the keys of its bucket that are smaller (its rank: ~1 independent LDS read per key) and
+//     moves to start + rank.  Buckets are ordered and complete and the composite keys unique, so the outcome does not depend
+//     on the atomic order: bit-identical to the radix sort, in 8 barriers instead of ~6 per radix pass x 3 passes.
+//   * fallback (a bucket with more than TSORT_LONG keys: depths piled onto a few buckets by an outlier; all depths equal;
 //     csplat_debug_flags bit 11): the round-2 stable LSD radix sort -- keys live in registers between passes (lane l of wave w
 //     owns positions w*64*items + i*64 + l), every pass ranks the 8-bit digit with 8 ballots per key and per-wave LDS counters.
-// mode: bit 0 = ids < 2^24 (radix: skip byte 3), bit 1 = radix only, bit 2 = fallback limit 1 (tests the fallback path)
+// mode: bit 0 = ids < 2^24 (radix: skip byte 3), bit 1 = radix only, bit 2 = bucket limit 1 (tests the fallback path)
 __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
                                                uint64_t *__restrict__ keys_sorted,
-                                               uint32_t *__restrict__ ids_sorted, int mode) {
+                                               uint32_t *__restrict__ ids_sorted, int mode, int tile) {
     extern __shared__ uint64_t s_key[];                 // [m] keys, then the counters
-    const int tile = blockIdx.x;
     const int2 r = ranges[tile];
     const int n = r.y - r.x;
     if (n <= 0) return;
     const int skip_byte3 = mode & 1;
     const int items = (n + TSORT_THREADS - 1) / TSORT_THREADS;
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_key + (size_t)items * TSORT_THREADS);   // [TSORT_NB] buckets / [TSORT_WAVES][256]
-    uint32_t *s_dig = s_cnt + TSORT_NB;                                                       // [256] + [4] (+ 4 spare)
+    uint32_t *s_dig = s_cnt + TSORT_NB + 4;                                                   // [256] + [4] (+ 4 spare)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wbase = w * items * 64;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -654,6 +665,7 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
             uint32_t ex = inc - tot;
             for (int k = 0; k < w; k++) ex += s_wtot[k];
             reinterpret_cast<uint4 *>(s_cnt)[threadIdx.x] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+            if (threadIdx.x == 0) s_cnt[TSORT_NB] = (uint32_t)n;
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TSORT_ITEMS; i++) {
@@ -661,20 +673,32 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
                 if (i < items && idx < n) s_key[s_cnt[bs[i] >> 16] + (bs[i] & 0xFFFFu)] = key[i];
             }
             __syncthreads();
-            // the keys of this thread's 4 buckets: already in bucket order, arbitrary inside a bucket -> insertion sort on the
-            // full key (adaptive: a region costs its length + its inversions)
+            // inside a bucket the order is whatever the atomics made it: every key finds its RANK among the keys of its bucket
+            // (independent LDS reads, a bucket holds ~1 key on average; the composite keys are unique) ...
             const int limit = (mode & 4) ? 1 : TSORT_LONG;
-            bool long_run = (int)tot > limit;
-            if (!long_run && tot >= 2u) {
-                const int lo = (int)ex, hi_ = (int)(ex + tot);
-                for (int a2 = lo + 1; a2 < hi_; a2++) {
-                    const uint64_t v = s_key[a2];
-                    int b2 = a2 - 1;
-                    while (b2 >= lo && s_key[b2] > v) { s_key[b2 + 1] = s_key[b2]; b2--; }
-                    s_key[b2 + 1] = v;
+            bool long_run = false;
+            uint32_t dst[TSORT_ITEMS];
+#pragma unroll
+            for (int i = 0; i < TSORT_ITEMS; i++) {
+                const int idx = wbase + i * 64 + lane;
+                if (i < items && idx < n) {
+                    const uint32_t b = bs[i] >> 16;
+                    const uint32_t lo = s_cnt[b], cb = s_cnt[b + 1] - lo;     // (s_cnt[TSORT_NB] = n)
+                    uint32_t rk = 0;
+                    if (cb > (uint32_t)limit) long_run = true;
+                    else
+                        for (uint32_t j = 0; j < cb; j++) rk += s_key[lo + j] < key[i] ? 1u : 0u;
+                    dst[i] = lo + rk;
                 }
             }
             if (!__syncthreads_or(long_run)) {
+                // ... and moves there (the keys are still in registers: in place, behind a barrier)
+#pragma unroll
+                for (int i = 0; i < TSORT_ITEMS; i++) {
+                    const int idx = wbase + i * 64 + lane;
+                    if (i < items && idx < n) s_key[dst[i]] = key[i];
+                }
+                __syncthreads();
 #pragma unroll
                 for (int i = 0; i < TSORT_ITEMS; i++) {
                     const int idx = wbase + i * 64 + lane;
@@ -827,13 +851,24 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
 }
 __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort(const int2 *__restrict__ ranges, const uint64_t *__restrict__ comp,
                                                               uint64_t *__restrict__ keys_sorted,
-                                                              uint32_t *__restrict__ ids_sorted, int mode) {
-    tile_sort_body(ranges, comp, keys_sorted, ids_sorted, mode);
+                                                              uint32_t *__restrict__ ids_sorted, const uint32_t *__restrict__ info, int mode) {
+    // the workgroups stride over the compact list of non-empty tiles the tile scan left behind the counts
+    const uint32_t *busy = info + INFO_BUSY;
+    const int nbusy = (int)busy[0];
+    for (int b = blockIdx.x; b < nbusy; b += gridDim.x) {
+        tile_sort_body(ranges, comp, keys_sorted, ids_sorted, mode, (int)busy[1 + b]);
+        __syncthreads();
+    }
 }
 __global__ __launch_bounds__(TSORT_THREADS) void k_tile_sort_views(P2Table tab, int mode) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
-    tile_sort_body(w.ranges, w.keys_u, w.keys_sorted, w.ids_sorted, mode);
+    const uint32_t *busy = w.info + INFO_BUSY;
+    const int nbusy = (int)busy[0];
+    for (int b = blockIdx.x; b < nbusy; b += gridDim.x) {
+        tile_sort_body(w.ranges, w.keys_u, w.keys_sorted, w.ids_sorted, mode, (int)busy[1 + b]);
+        __syncthreads();
+    }
 }
 
 template <int CTRL, int RMASK>
@@ -2001,7 +2036,7 @@ size_t image_offsets(int W, int H, size_t *off) {
     off[1] = align256(tiles * 8);
     off[2] = off[1] + align256(X * 4);
     off[3] = off[2] + align256(X * 4);
-    off[4] = off[3] + 256;
+    off[4] = off[3] + align256(256 + (tiles + 4) * 4);   // info: [0] R, [1] longest list; word 64: number of non-empty tiles, then their ids
     return off[4];
 }
 // per-(counting workgroup, tile) table of the bucketed binning path; requested as its own TEMP-class chunk
@@ -2076,7 +2111,7 @@ bool mail_init() {
 // csplat_debug_flags: bit 0 no culling; bit 1 force the global radix sort; bit 2 no mailbox; bit 4 culling radius x4;
 // bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics);
 // bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
-// bit 12 tile sort: every multi-key thread region takes the radix fallback (test hook)
+// bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook)
 unsigned g_debug_flags = 0;
 
 // `mode` argument of the tile sort kernels: bit 0 ids < 2^24, bit 1 radix only, bit 2 fallback limit 1
@@ -2423,7 +2458,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         {
             const size_t lds = tsort_lds_bytes((int)Lcap);
             ProfScope ps(PROF_K4, join);
-            k_tile_sort_views<<<dim3(tiles, V), TSORT_THREADS, lds, join>>>(tab, tsort_mode(P));
+            k_tile_sort_views<<<dim3(tiles < TSORT_GRID ? tiles : TSORT_GRID, V), TSORT_THREADS, lds, join>>>(tab, tsort_mode(P));
             LAUNCH_CHECK();
         }
         {
@@ -2556,7 +2591,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
             }
             const size_t lds = tsort_lds_bytes((int)host_info[1]);
             ProfScope ps(PROF_K4, s);
-            k_tile_sort<<<tiles, TSORT_THREADS, lds, s>>>(ranges, keys_u, keys_sorted, ids_sorted, tsort_mode(P));
+            k_tile_sort<<<tiles < TSORT_GRID ? tiles : TSORT_GRID, TSORT_THREADS, lds, s>>>(ranges, keys_u, keys_sorted, ids_sorted, t.info, tsort_mode(P));
             LAUNCH_CHECK();
         } else {
             // a tile list longer than the LDS sort takes: the global stable radix sort (upstream's pipeline shape)

@@ -738,23 +738,25 @@ def test_tile_sort_depth_outliers_and_clusters():
     np.testing.assert_array_equal(st["ranges"], o.ranges)
 
 
-def _grad_vs_oracles(name, got, g32, g64, P, tie_frac=1e-3, tie_tol=2e-2):
-    """Gradient parity at sizes where pixels go a thousand entries deep.  (1) against the fp32 oracle -- the same arithmetic, so it
-    lands on the same side of every alpha < 1/255 / T < 1e-4 decision: <= 1e-4 relative, no exceptions.  (2) against the fp64 oracle:
-    <= 1e-4 except for THRESHOLD-TIE Gaussians -- a pixel where fp32 and fp64 decide one of the two discontinuous tests differently
-    moves the gradient of the Gaussians on it by an O(alpha) amount; tools/config2_diag.py shows the fp32 ORACLE off by the same
-    amounts on the same ~20 of 100,000 Gaussians.  Ties are counted (<= tie_frac of P), bounded (<= tie_tol of the gradient scale)
-    and must be ties of the fp32 oracle as well."""
+def _grad_vs_oracles(name, got, g32, g64, P, tie_frac=1e-3, tie_tol=2e-2, exp_tie_frac=2e-4):
+    """Gradient parity at sizes where pixels go a thousand entries deep.  The compositing rule has two discontinuous tests
+    (alpha < 1/255, T(1 - alpha) < 1e-4); a pixel where two evaluations decide one of them differently moves the gradient of the
+    Gaussians on it by an O(alpha) amount -- a THRESHOLD TIE, not an error.  (1) Against the fp32 oracle (the same arithmetic): <= 1e-4
+    relative, except ties between v_exp_f32 and glibc's expf -- the same events the n_contrib comparison counts, and bounded by the same
+    rate (exp_tie_frac of the Gaussians).  (2) Against the fp64 oracle: <= 1e-4 except the ties of fp32 arithmetic itself:
+    tools/config2_diag.py shows the fp32 ORACLE off by the same amounts on the same ~20 of 100,000 Gaussians; counted (<= tie_frac of
+    P), and each must be a tie of the fp32 oracle (or of the exp) as well.  Every tie is bounded by tie_tol of the gradient scale."""
     got, a32, a64 = (np.asarray(x, np.float64).reshape(P, -1) for x in (got, g32, g64))
     scale = np.abs(a64).max() + 1e-30
-    e32 = np.abs(got - a32).max() / (np.abs(a32).max() + 1e-30)
-    assert e32 < TOL, (name, "vs fp32 oracle", e32)
+    e32 = np.abs(got - a32).max(1) / scale
+    t32 = e32 > TOL
+    assert t32.sum() <= max(exp_tie_frac * P, 2), (name, "vs fp32 oracle", int(t32.sum()), float(e32.max()))
     d = np.abs(got - a64).max(1) / scale
     ties = d > TOL
     assert ties.sum() <= tie_frac * P, (name, int(ties.sum()))
-    assert d.max() <= tie_tol, (name, float(d.max()))
+    assert max(d.max(), e32.max()) <= tie_tol, (name, float(d.max()), float(e32.max()))
     d32 = np.abs(a32 - a64).max(1) / scale
-    assert np.all(d32[ties] > 0.5 * TOL), (name, "a deviation from fp64 that the fp32 oracle does not share")
+    assert np.all((d32[ties] > 0.5 * TOL) | t32[ties]), (name, "a deviation from fp64 that neither the fp32 oracle nor an exp tie explains")
 
 
 def test_config2_full_size_vs_oracle():
@@ -808,9 +810,12 @@ def test_config2_full_size_vs_oracle():
         mism = st["n_contrib"] != o.n_contrib
         assert mism.mean() < 2e-4, f"view {i}: {mism.sum()} n_contrib mismatches"
         o64 = oracle_forward(case, dtype=np.float64)
-        assert image_err(colors[i].cpu().numpy(), o64.color) < TOL
-        assert image_err(outs[i][2].detach().cpu().numpy(), o64.out_depth) < TOL
-        assert image_err(st["final_T"], o64.final_T) < TOL
+        # images: <= 1e-4 vs the fp32 oracle (threshold-tie pixels: < 1e-4 of the pixels); vs the fp64 oracle the ties of fp32 arithmetic
+        # itself add to them (pixels go ~1200 entries deep here): < 1e-3 of the pixels
+        assert image_err(colors[i].cpu().numpy(), o.color) < TOL and image_err(colors[i].cpu().numpy(), o64.color, outlier_frac=1e-3) < TOL
+        dimg = outs[i][2].detach().cpu().numpy()
+        assert image_err(dimg, o.out_depth) < TOL and image_err(dimg, o64.out_depth, outlier_frac=1e-3) < TOL
+        assert image_err(st["final_T"], o.final_T) < TOL and image_err(st["final_T"], o64.final_T, outlier_frac=1e-3) < TOL
         g64, g32 = util.ro.backward(o64, dpix[i]), util.ro.backward(o, dpix[i])
         _grad_vs_oracles(f"mean2D[{i}]", m2d[i].grad.cpu().numpy(), g32.mean2D, g64.mean2D, P)
         for k in sums:
