@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
                                                    const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
                                                    const float4 *__restrict__ recB, const float2 *__restrict__ recC,
                                                    uint32_t null_rec, const float *__restrict__ bg,
-                                                   const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
+                                                   int *seg_offset, float4 *__restrict__ ckpt,
                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                    float *__restrict__ out_color, float *__restrict__ out_depth) {
     __shared__ int s_ring[RING];
@@ -1186,6 +1186,12 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
         const Row4 g = rows_allgather(__uint_as_float(last));
         last = max(max(__float_as_uint(g.v0), __float_as_uint(g.v1)), max(__float_as_uint(g.v2), __float_as_uint(g.v3)));
     }
+    {   // the block's largest n_contrib, for K7's workgroups (seg_offset[tiles + 1 ...] = blk_hi[tile][blk])
+        uint32_t m = inside ? last : 0u;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 0) reinterpret_cast<uint32_t *>(seg_offset)[tiles + 1 + tile * 16 + blk] = m;
+    }
     if (inside && r == 0) {
         final_T[pix] = T;
         n_contrib[pix] = last;
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
                                                        const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
                                                        const float4 *__restrict__ recB, const float2 *__restrict__ recC,
                                                        uint32_t null_rec, const float *__restrict__ bg,
-                                                       const int *__restrict__ seg_offset, float4 *__restrict__ ckpt,
+                                                       int *seg_offset, float4 *__restrict__ ckpt,
                                                        float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                        float *__restrict__ out_color, float *__restrict__ out_depth) {
     composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
@@ -1228,6 +1234,39 @@ template <int CTRL>
 __device__ __forceinline__ float bfly(float a, float b, bool s) {
     const float send = s ? a : b, keep = s ? b : a;
     return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
+}
+
+// the end of K7: the segment's LDS records -> the per-Gaussian records.  The (up to ten) rounds of a wave are independent: all LDS reads
+// and all id loads are issued before the first atomic, so the wave waits for ONE memory round trip instead of one per round
+template <bool DET, bool CLEAR = false>
+__device__ __forceinline__ void flush_segment(float *s_acc, int cnt, int w, int lane, int quad, uint32_t first,
+                                              const uint32_t *__restrict__ ids_sorted, float *__restrict__ acc, float *__restrict__ det) {
+    const int sub = lane / 9, tq = lane - sub * 9;
+    constexpr int ROUNDS = (SEG + 27) / 28;
+    float sv_[ROUNDS];
+    uint32_t id_[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; k++) {
+        const int e = w * 7 + 28 * k + sub;
+        const bool ok = lane < 63 && e < cnt;
+        if (DET) {
+            sv_[k] = ok ? ((s_acc[e * 9 + tq] + s_acc[SEG * 9 + e * 9 + tq]) + s_acc[2 * SEG * 9 + e * 9 + tq]) + s_acc[3 * SEG * 9 + e * 9 + tq] : 0.f;
+            id_[k] = ok ? 1u : 0u;
+        } else {
+            sv_[k] = ok ? s_acc[e * 9 + tq] : 0.f;
+            if (CLEAR && sv_[k] != 0.f) s_acc[e * 9 + tq] = 0.f;       // (the thread that read a cell leaves it clean for the segment after next)
+            id_[k] = sv_[k] != 0.f ? ids_sorted[first + e] : 0xFFFFFFFFu;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ROUNDS; k++) {
+        const int e = w * 7 + 28 * k + sub;
+        if (DET) {
+            if (id_[k]) det[((size_t)(first + e) * 4 + quad) * 9 + tq] = sv_[k];
+        } else if (id_[k] != 0xFFFFFFFFu) {
+            atomicAdd(acc + (size_t)id_[k] * ACC_STRIDE + tq, sv_[k]);
+        }
+    }
 }
 
 // grid: one 4-wave workgroup per (segment slot, 8x8 quadrant); wave w = one 4x4 block of the quadrant.  DET: every wave
@@ -1263,6 +1302,11 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
     const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
+    {   // (round 3) the workgroups behind every pixel's n_contrib end on scalar loads: K6 leaves the blocks' largest n_contrib
+        const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
+        const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);
+        if ((int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])) <= seg_lo) return;
+    }
     const int ncontrib = inside ? (int)n_contrib[pix] : 0;
     const int wave_hi = min(seg_hi, (int)wave_max((float)ncontrib));   // no pixel of the block blends an entry at or behind it
     if (threadIdx.x == 0) s_any = 0;
@@ -1363,20 +1407,264 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     }
     __syncthreads();
     // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
-    const int cnt = seg_hi - seg_lo;
-    const int sub = lane / 9, tq = lane - sub * 9;
-    if (lane < 63) {
-        for (int e0 = w * 7; e0 < cnt; e0 += 28) {
-            const int e = e0 + sub;
-            if (e >= cnt) continue;
-            if (DET) {
-                const float s = ((s_acc[e * 9 + tq] + s_acc[SEG * 9 + e * 9 + tq]) + s_acc[2 * SEG * 9 + e * 9 + tq]) + s_acc[3 * SEG * 9 + e * 9 + tq];
-                det[((size_t)(rx + seg_lo + e) * 4 + quad) * 9 + tq] = s;
-            } else {
-                const float s = s_acc[e * 9 + tq];
-                if (s != 0.f) atomicAdd(acc + (size_t)ids_sorted[rx + seg_lo + e] * ACC_STRIDE + tq, s);
+    flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
+}
+
+// ------------------------------------------------------------------------------------------- K7, survivor-column form (round 3)
+// Same grid, same inputs and outputs as composite_bwd_body, different lane mapping.  What bounded the row form (four survivors
+// x 16 pixels per step) was not bandwidth but the price of its cross-lane work on gfx950's vector pipe (tools/valu_rate.hip: a
+// plain v_fma / v_mul / v_add occupies a SIMD for 2.3 cycles, every DPP operation, v_cmp, v_min/max and v_cndmask e64 for 4.2,
+// v_permlane*_swap, v_exp and v_rcp for 8.2): per group of four survivors two all-gathers (6 swaps), two row selects (6 DPP
+// moves) and a 26-DPP-add + 14-select butterfly -- ~250 of ~520 cycles.  Here a step takes SIXTEEN consecutive survivors of the
+// block: lane l holds survivor l & 15 and the four pixels of block row l >> 4, so that
+//   * the front-to-back transmittance and the S sums of a pixel run ALONG a DPP row: a 4-level row_shr scan (+ one shift and one
+//     row_newbcast) per pixel instead of all-gathers + selects per group of four;
+//   * a survivor's nine gradient sums are first summed over the lane's own four pixels (plain adds) and then over the four rows by
+//     the MATRIX pipe: v_mfma_f32_16x16x4_f32 contracts exactly over lane >> 4, D[i][j] += A[i][k] B[k][j] with A = the lane's
+//     partial and B[k][j] = (j == value index) puts the total of value j of survivor i into column j -- nine MFMAs (exact fp32, on a
+//     pipe this kernel otherwise leaves idle) replace the butterfly;
+//   * K7 never tests T against a threshold (activity = list position < n_contrib, alpha from the same expression as K6), so the
+//     scan's association of the products is free to differ from the forward's sequential one (gradients are held to 1e-4).
+// The block's survivors of the 256-entry segment are compacted into an LDS ring once (<= 256 positions), then walked in steps.
+// One level of a row scan (x[lane] op= x[lane - N] inside every DPP row of 16; lanes without a source keep their value) for FOUR
+// independent registers at once: the four instructions are independent, so three of them cover the two wait states a DPP read
+// needs after a VALU write of the same register (FIRST: the registers were last written by ordinary VALU code -> s_nop 1).
+#define CSPLAT_ROW_SCAN4(OP, N, FIRST, a, b, c, d)                                                                                  \
+    asm(FIRST "v_" OP "_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
+              "v_" OP "_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
+              "v_" OP "_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
+              "v_" OP "_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf"                                               \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void row_scan4_mul(float (&x)[4]) {
+    CSPLAT_ROW_SCAN4("mul", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("mul", 2, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("mul", 4, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("mul", 8, "", x[0], x[1], x[2], x[3]);
+}
+__device__ __forceinline__ void row_scan4_add(float (&x)[4]) {
+    CSPLAT_ROW_SCAN4("add", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("add", 2, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("add", 4, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("add", 8, "", x[0], x[1], x[2], x[3]);
+}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// TILEWISE = false: one workgroup per (256-entry segment, quadrant), restarted from K6's checkpoint (the depth-split form: the
+//   bit-reproducible mode and the per-view path).
+// TILEWISE = true (the default path): one workgroup per (tile, quadrant) walks ALL segments up to the quadrant's largest
+//   n_contrib front to back, T and S simply carried -- no checkpoints, the pixel constants loaded once, two barriers per
+//   segment (double-buffered LDS records), ~17 k waves per step instead of ~300 k whose ~10 k cycles of life were mostly fixed
+//   cost (three dependent scalar loads, the pixel loads, record zeroing, two barriers, the flush).  A step covers 16 survivors,
+//   so the deepest (tile, block) chain of scene_1 -- ~3000 entries -> ~25 steps -- stays short of K6's own.
+template <bool DET, bool TILEWISE>
+__device__ __forceinline__ void composite_bwd16_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                     const uint32_t *__restrict__ ids_sorted,
+                                                     const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                     const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                     uint32_t null_rec, const int *__restrict__ seg_offset,
+                                                     const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
+                                                     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                     const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
+                                                     float *__restrict__ acc, float *__restrict__ det) {
+    static_assert(!(DET && TILEWISE), "the bit-reproducible mode uses the depth-split form");
+    __shared__ float s_acc[(DET ? 4 : (TILEWISE ? 2 : 1)) * SEG * 9];
+    __shared__ __attribute__((aligned(16))) int s_ring[4][SEG + 16];
+    const int wg = blockIdx.x;
+    const int quad = (wg >> 3) & 3;                                      // the 4 quadrants of a tile / slot share blockIdx % 8
+    int tile, seg_first, slot = 0;
+    if (TILEWISE) {
+        tile = ((wg >> 5) << 3) + (wg & 7);
+        if (tile >= tiles) return;
+        seg_first = 0;
+    } else {
+        slot = ((wg >> 5) << 3) + (wg & 7);
+        if (slot >= seg_offset[tiles]) return;
+        tile = slot_tile[slot];
+        seg_first = slot - seg_offset[tile];
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, sv = lane & 15, q = lane >> 4;
+    const int blk = (2 * (quad >> 1) + (w >> 1)) * 4 + 2 * (quad & 1) + (w & 1);
+    const int px0 = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4;
+    const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + q;
+    const float fy = (float)py;
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    const uint32_t rx = (uint32_t)range.x;
+    // which blocks of the quadrant still blend anything: K6 left every block's largest n_contrib.  Workgroups (and, tile-wise, the
+    // segment loop) end on scalar loads instead of behind vector loads, a wave reduction and barriers
+    const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
+    const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);               // first block of the quadrant: blocks qb, qb+1, qb+4, qb+5
+    const int quad_hi = min(n, (int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])));
+    if (quad_hi <= seg_first * SEG) return;                              // (workgroup-uniform)
+    const int block_hi = min(n, (int)blk_hi[blk]);                       // no pixel of the block blends an entry at or behind it
+    const int seg_end = TILEWISE ? (quad_hi + SEG - 1) / SEG : seg_first + 1;
+    // every load that depends only on (tile, pixel) goes out together: the kernel is latency-bound
+    int nc[4], pix[4];
+    bool inside[4];
+    const size_t HW = (size_t)H * W;
+    float dp0[4], dp1[4], dp2[4], OD[4], T[4], S[4], fx[4];
+    uint32_t mk[SEG / 64];
+    auto load_masks = [&](int sg) {
+#pragma unroll
+        for (int c = 0; c < SEG / 64; c++) { const int e = sg * SEG + 64 * c + lane; mk[c] = e < block_hi ? (uint32_t)mask16[rx + e] : 0u; }
+    };
+    load_masks(seg_first);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        inside[j] = px0 + j < W && py < H && block_hi > seg_first * SEG;
+        pix[j] = py * W + px0 + j;
+        nc[j] = inside[j] ? (int)n_contrib[pix[j]] : 0;
+        dp0[j] = inside[j] ? dL_dpix[pix[j]] : 0.f;
+        dp1[j] = inside[j] ? dL_dpix[HW + pix[j]] : 0.f;
+        dp2[j] = inside[j] ? dL_dpix[2 * HW + pix[j]] : 0.f;
+        OD[j] = inside[j] ? out_color[pix[j]] * dp0[j] + out_color[HW + pix[j]] * dp1[j] + out_color[2 * HW + pix[j]] * dp2[j] : 0.f;
+        T[j] = 1.f; S[j] = 0.f;
+        if (!TILEWISE) {
+            const float4 ck = inside[j] ? ckpt[(size_t)slot * 256 + blk * 16 + q * 4 + j] : make_float4(1.f, 0.f, 0.f, 0.f);
+            const bool live = nc[j] > seg_first * SEG;
+            T[j] = live ? ck.x : 1.f;
+            S[j] = live ? ck.y * dp0[j] + ck.z * dp1[j] + ck.w * dp2[j] : 0.f;
+        }
+        fx[j] = (float)(px0 + j);
+    }
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    // B operands of the reducing MFMAs: column sv of the result takes value index sv
+    float sel[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) sel[t] = sv == t ? 1.f : 0.f;
+    int *ring = s_ring[w];
+    if (TILEWISE) {   // both record buffers start clean; afterwards the flush leaves them clean
+        for (int t = threadIdx.x; t < 2 * SEG * 9; t += 256) s_acc[t] = 0.f;
+        __syncthreads();
+    }
+    for (int sg = seg_first; sg < seg_end; sg++) {
+        const int seg_lo = sg * SEG, seg_hi = min(n, seg_lo + SEG);
+        const int wave_hi = min(seg_hi, block_hi);
+        float *buf = s_acc + ((TILEWISE && (sg & 1)) ? SEG * 9 : 0);     // tile-wise: the records of consecutive segments alternate
+        if (!TILEWISE) {
+            for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) buf[t] = 0.f;
+            __syncthreads();
+        }
+        float *my_acc = buf + (DET ? w * SEG * 9 : 0);
+        int steps = 0;
+        Trip cur, nxt;
+        auto fetch = [&](Trip &t, int s_) {
+            t.pos = ring[16 * s_ + sv];
+            const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
+            t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+        };
+        if (wave_hi > seg_lo) {
+            // ---- the block's survivors of [seg_lo, wave_hi): list positions, in list order
+            int tail = 0;
+#pragma unroll
+            for (int c = 0; c < SEG / 64; c++) {
+                const int e = seg_lo + 64 * c + lane;
+                const bool hit = e < wave_hi && ((mk[c] >> blk) & 1u);
+                const unsigned long long cur = __ballot(hit);
+                if (hit) ring[tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u))] = e;
+                tail += (int)__popcll(cur);
+            }
+            if (lane < 16) ring[tail + lane] = -1;                       // the last step's padding
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            steps = (tail + 15) >> 4;
+            if (steps > 0) fetch(cur, 0);
+            if (steps > 1) fetch(nxt, 1);
+        }
+        if (TILEWISE) {
+            if (sg + 1 < seg_end) load_masks(sg + 1);                    // the next segment's masks travel under this one's steps
+            // the PREVIOUS segment's records leave now, behind this segment's loads in the memory queue (vmcnt counts in order: a
+            // load issued after the atomics could only be waited for together with them)
+            if (sg > seg_first)
+                flush_segment<false, true>(s_acc + (((sg - 1) & 1) ? SEG * 9 : 0), SEG, w, lane, quad, rx + (uint32_t)(seg_lo - SEG), ids_sorted, acc, det);
+        }
+        if (wave_hi > seg_lo) {
+            for (int s_ = 0; s_ < steps; s_++) {
+                const Trip t = cur;
+                cur = nxt;
+                if (s_ + 2 < steps) fetch(nxt, s_ + 2);                  // the records of two steps travel under this step's arithmetic
+                const float dy = t.a.y - fy;
+                float G[4], al[4], dxs[4];
+                bool act[4];
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float dx = t.a.x - fx[j];
+                    const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
+                    G[j] = __expf(power);
+                    const float a = fminf(0.99f, t.b.y * G[j]);
+                    act[j] = t.pos < nc[j] && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
+                    al[j] = act[j] ? a : 0.f;
+                    dxs[j] = dx;
+                    any = any || act[j];
+                }
+                if (__ballot(any) == 0ull) continue;                     // nobody blends anything of this step: T, S unchanged
+                // (phase by phase over the lane's four pixels: four independent chains for the scans, the exp and the rcp)
+                float inc[4], Tr[4], gdot[4], dch[4], sc[4], Sr[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) inc[j] = 1.f - al[j];
+                float F[4] = {inc[0], inc[1], inc[2], inc[3]};
+                row_scan4_mul(inc);                                      // transmittance factor up to and including every survivor
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    Tr[j] = T[j] * dpp_mov<0x111, 0xF>(inc[j], 1.f);     // in FRONT of it: row_shr:1, lane 0 of the row keeps 1
+                    T[j] *= dpp_mov<0x15F, 0xF>(inc[j], inc[j]);         // row_newbcast:15: behind the step
+                    gdot[j] = t.b.z * dp0[j] + t.b.w * dp1[j] + t.c.x * dp2[j];
+                    dch[j] = al[j] * Tr[j];
+                    sc[j] = gdot[j] * dch[j];
+                }
+                row_scan4_add(sc);
+                float v[9];
+#pragma unroll
+                for (int t9 = 0; t9 < 9; t9++) v[t9] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    Sr[j] = S[j] + sc[j];
+                    S[j] += dpp_mov<0x15F, 0xF>(sc[j], sc[j]);
+                    const float dL_dalpha = act[j] ? Tr[j] * gdot[j] - (OD[j] - Sr[j]) * __builtin_amdgcn_rcpf(F[j]) : 0.f;
+                    const float dL_dG = t.b.y * dL_dalpha;
+                    const float dx = dxs[j];
+                    const float gdx = G[j] * dx, gdy = G[j] * dy;
+                    const float dG_ddelx = -gdx * t.a.z - gdy * t.a.w;
+                    const float dG_ddely = -gdy * t.b.x - gdx * t.a.w;
+                    v[0] += dL_dG * dG_ddelx * ddelx_dx;
+                    v[1] += dL_dG * dG_ddely * ddely_dy;
+                    v[2] += -0.5f * gdx * dx * dL_dG;
+                    v[3] += -0.5f * gdx * dy * dL_dG;
+                    v[4] += -0.5f * gdy * dy * dL_dG;
+                    v[5] += G[j] * dL_dalpha;
+                    v[6] += dch[j] * dp0[j]; v[7] += dch[j] * dp1[j]; v[8] += dch[j] * dp2[j];
+                }
+                // sums over the four rows on the matrix pipe: lane (q, c) receives, in register r, value c of survivor 4q + r
+                f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], sel[0], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], sel[1], d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], sel[2], d2, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[3], sel[3], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4], sel[4], d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[5], sel[5], d2, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[6], sel[6], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[7], sel[7], d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[8], sel[8], d2, 0, 0, 0);
+                const int4 pr = *reinterpret_cast<const int4 *>(&ring[16 * s_ + 4 * q]);
+                if (sv < 9) {
+                    const int prr[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float tot = d0[r] + d1[r] + d2[r];      // (column sv holds ONE value index: two of the three are zero)
+                        if (prr[r] >= 0 && tot != 0.f) {
+                            float *cell = my_acc + (prr[r] - seg_lo) * 9 + sv;
+                            if (DET) *cell = tot;                  // one (entry, block) pair is visited exactly once
+                            else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the quadrant meet here
+                        }
+                    }
+                }
             }
         }
+        __syncthreads();     // tile-wise: the segment's sums are complete AND the buffer of the segment before is clean again
+        // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
+        if (!TILEWISE) flush_segment<DET>(buf, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
+        else if (sg + 1 == seg_end) flush_segment<false>(buf, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
     }
 }
 
@@ -1390,6 +1678,21 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, 
                                                         const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                         const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
                                                         float *__restrict__ acc, float *__restrict__ det) {
+    composite_bwd16_body<DET, false>(tiles, W, H, gx, ranges, ids_sorted, mask16, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
+                                     n_contrib, out_color, dL_dpix, acc, det);
+}
+// (the row form: four survivors x 16 pixels per step -- the default; k_composite_bwd above is the survivor-column form, behind
+// csplat_debug_flags bit 13: 29 % fewer VALU instructions but 112 VGPRs = 4 waves per SIMD against 7, and slower)
+template <bool DET>
+__global__ __launch_bounds__(256) void k_composite_bwd_rows(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                             const uint32_t *__restrict__ ids_sorted,
+                                                             const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                             const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                             uint32_t null_rec, const int *__restrict__ seg_offset,
+                                                             const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
+                                                             const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                             const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
+                                                             float *__restrict__ acc, float *__restrict__ det) {
     composite_bwd_body<DET>(tiles, W, H, gx, ranges, ids_sorted, mask16, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
                             n_contrib, out_color, dL_dpix, acc, det);
 }
@@ -1412,6 +1715,16 @@ struct B2View {
 };
 struct B2Table { B2View v[B2_MAX_VIEWS]; };
 __global__ __launch_bounds__(256) void k_composite_bwd_views(int tiles, int W, int H, int gx, B2Table tab) {
+    const B2View &w = tab.v[blockIdx.y];
+    composite_bwd16_body<false, true>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
+                                      w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
+}
+__global__ __launch_bounds__(256) void k_composite_bwd_seg_views(int tiles, int W, int H, int gx, B2Table tab) {
+    const B2View &w = tab.v[blockIdx.y];
+    composite_bwd16_body<false, false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
+                                       w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
+}
+__global__ __launch_bounds__(256) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
                               w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
@@ -2041,7 +2354,8 @@ size_t image_offsets(int W, int H, size_t *off) {
 }
 // per-(counting workgroup, tile) table of the bucketed binning path; requested as its own TEMP-class chunk
 size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 0 ? P : 1, BUCKET_G) + 1) * tiles * 4); }
-// binning: 0 keys_sorted u64[R] | 1 ids_sorted u32[R] | 2 seg_offset i32[tiles+1] | 3 slot_tile i32[slots]
+// binning: 0 keys_sorted u64[R] | 1 ids_sorted u32[R] | 2 seg_offset i32[tiles+1] + blk_hi u32[tiles][16] (largest n_contrib of every
+//          4x4 pixel block, written by K6: K7 drops the (segment, quadrant) workgroups behind it on ONE scalar load) | 3 slot_tile i32[slots]
 //          | 4 ckpt float4[slots][16 blocks][16 pixels]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
 //          | 5 mask16 u16[R+1] | 6 recA float4[R+1] | 7 recB float4[R+1] | 8 recC float2[R+1]   (entry R = the null record)
 constexpr int B_NFIELDS = 9;
@@ -2051,7 +2365,7 @@ size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     off[0] = 0;
     off[1] = align256(n * 8);
     off[2] = off[1] + align256(n * 4);
-    off[3] = off[2] + align256((size_t)(tiles + 1) * 4);
+    off[3] = off[2] + align256((size_t)(tiles + 1) * 4 + (size_t)tiles * 16 * 4);   // seg_offset[tiles + 1], then blk_hi[tiles][16]
     off[4] = off[3] + align256(slots * 4);
     off[5] = off[4] + align256(slots * 256 * 16);
     off[6] = off[5] + align256((n + 1) * 2);
@@ -2111,7 +2425,8 @@ bool mail_init() {
 // csplat_debug_flags: bit 0 no culling; bit 1 force the global radix sort; bit 2 no mailbox; bit 4 culling radius x4;
 // bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics);
 // bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
-// bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook)
+// bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook); bit 13 K7 in the survivor-column form
+// (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant)
 unsigned g_debug_flags = 0;
 
 // `mode` argument of the tile sort kernels: bit 0 ids < 2^24, bit 1 radix only, bit 2 fallback limit 1
@@ -2696,9 +3011,16 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with
         ProfScope ps(PROF_K7, s);
         if (R > 0) {
             const unsigned grid = (unsigned)cdiv(max_slots(R, tiles), 8) * 32u;
-            if (det_mode)
+            const bool rows = (g_debug_flags & (8192u | 16384u)) == 0;     // default: the row form; bits 13 / 14: the survivor-column form
+            if (det_mode && rows)
+                k_composite_bwd_rows<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
+                                                                seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+            else if (det_mode)
                 k_composite_bwd<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
                                                            seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+            else if (rows)
+                k_composite_bwd_rows<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
+                                                                 seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
             else
                 k_composite_bwd<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
                                                             seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
@@ -2926,7 +3248,12 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
             k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
             LAUNCH_CHECK();
-            k_composite_bwd_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            if (g_debug_flags & 16384u)       // survivor-column form, one workgroup per (tile, quadrant) walking every segment
+                k_composite_bwd_views<<<dim3((unsigned)cdiv(tiles, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            else if (g_debug_flags & 8192u)   // survivor-column form, one workgroup per (segment, quadrant)
+                k_composite_bwd_seg_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            else                              // row form (default)
+                k_composite_bwd_rows_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
             LAUNCH_CHECK();
         }
         for (int i = 0; i < V && !(batch_k7 && one_k8); i++) {

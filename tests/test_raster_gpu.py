@@ -83,8 +83,21 @@ def test_forward_image(cfg):
     assert mism.mean() < 2e-4, f"{mism.sum()} n_contrib mismatches"
 
 
+@pytest.mark.parametrize("k7", [0, 8192, 16384], ids=["k7_rows", "k7_columns_depth_split", "k7_columns_tilewise"])
 @pytest.mark.parametrize("cfg", CASES)
-def test_backward_grads(cfg):
+def test_backward_grads(cfg, k7):
+    """(k7: the default row form of the compositing backward, and the survivor-column form -- 16 survivors per step, DPP row scans,
+    MFMA reduction -- depth-split per segment and walking whole tiles; csplat_debug_flags bits 13 / 14.  The batched entry point is
+    covered by test_all_k7_forms_through_the_batched_entry_point.)"""
+    from csplat import native
+    native.lib.csplat_debug_flags(k7)
+    try:
+        _test_backward_grads(cfg)
+    finally:
+        native.lib.csplat_debug_flags(0)
+
+
+def _test_backward_grads(cfg):
     case = make_case(**cfg)
     rng = np.random.default_rng(3)
     dpix = rng.normal(size=(3, case["H"], case["W"])).astype(np.float32)
@@ -825,3 +838,40 @@ def test_config2_full_size_vs_oracle():
                scale=inp["scales"].grad, rot=inp["rotations"].grad)
     for k, v in got.items():
         _grad_vs_oracles(k, v.cpu().numpy(), sums32[k], sums[k], P, tie_frac=4e-3)
+
+
+@pytest.mark.parametrize("k7", [8192, 16384], ids=["k7_columns_depth_split", "k7_columns_tilewise"])
+def test_all_k7_forms_through_the_batched_entry_point(k7):
+    """rasterize_views (one K7 launch for all views) with the survivor-column forms of K7 (csplat_debug_flags bits 13 / 14) against
+    the default row form: images identical (K7 does not touch them), every gradient equal up to the summation order (1e-5 of scale),
+    on a scene deep enough for several 256-entry segments per tile."""
+    from csplat import native
+    from diff_gaussian_rasterization import rasterize_views
+    V = 3
+    cases = [util.make_case(P=6000, W=96, H=80, seed=13, grid=12, scale_mul=5.0, theta=-30.0 + 30.0 * i, radius=3.0) for i in range(V)]
+    o = oracle_forward(cases[0])
+    assert int((o.ranges[:, 1] - o.ranges[:, 0]).max()) > 3 * 256
+    settings = [util.gpu_settings(c) for c in cases]
+    inp = util.gpu_inputs(cases[0])
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    tgt = torch.rand(V, 3, 80, 96, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+
+    def run(flags):
+        native.lib.csplat_debug_flags(flags)
+        try:
+            for k in names:
+                inp[k].grad = None
+            m2d = [torch.zeros(6000, 3, device="cuda", requires_grad=True) for _ in range(V)]
+            kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                        rotations=inp["rotations"]) for i in range(V)]
+            colors, _ = rasterize_views(settings, kws, stacked=True)
+            ((colors - tgt) ** 2).mean().backward()
+            torch.cuda.synchronize()
+            return colors.detach().clone(), [inp[k].grad.clone() for k in names] + [m.grad.clone() for m in m2d]
+        finally:
+            native.lib.csplat_debug_flags(0)
+    c0, g0 = run(0)
+    c1, g1 = run(k7)
+    assert torch.equal(c0, c1)
+    for a, b in zip(g1, g0):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
