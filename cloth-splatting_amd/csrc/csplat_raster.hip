@@ -1285,7 +1285,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                                                    float *__restrict__ acc, float *__restrict__ det) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING];
-    __shared__ int s_any;
     const int wg = blockIdx.x;
     const int slot = ((wg >> 5) << 3) + (wg & 7), quad = (wg >> 3) & 3;     // the 4 quadrants of a slot share blockIdx % 8
     if (slot >= seg_offset[tiles]) return;
@@ -1302,18 +1301,13 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
     const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
-    {   // (round 3) the workgroups behind every pixel's n_contrib end on scalar loads: K6 leaves the blocks' largest n_contrib
-        const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
-        const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);
-        if ((int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])) <= seg_lo) return;
-    }
+    // (round 3) K6 leaves every block's largest n_contrib: the workgroups behind all of their pixels end here on scalar loads, and a
+    // wave knows where its block ends without a reduction over its pixels' n_contrib and two barriers
+    const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
+    const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);
+    if ((int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])) <= seg_lo) return;   // (workgroup-uniform)
+    const int wave_hi = min(seg_hi, (int)blk_hi[blk]);                  // no pixel of the block blends an entry at or behind it
     const int ncontrib = inside ? (int)n_contrib[pix] : 0;
-    const int wave_hi = min(seg_hi, (int)wave_max((float)ncontrib));   // no pixel of the block blends an entry at or behind it
-    if (threadIdx.x == 0) s_any = 0;
-    __syncthreads();
-    if (wave_hi > seg_lo && lane == 0) s_any = 1;
-    __syncthreads();
-    if (!s_any) return;                                                 // (workgroup-uniform)
     for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
     __syncthreads();
     float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
