@@ -124,6 +124,8 @@ def main():
                 for k, v in keep.items():
                     self.params[k].copy_(v)
             self.targets_stacked = torch.stack(self.targets).contiguous()
+            self.zeros = torch.zeros(V, P, 3, device=dev)
+            self.one = torch.ones((), device=dev)
             # N > 1: every gradient of the step is a view into ONE flat buffer (+ 3P floats for the summed screen-space
             # gradient that densification consumes) and the step ends with one all-reduce of it -- no cat, no copy back
             self.fg = cd.FlatGrads([self.params[k] for k in self.names], extra=3 * P) if reduce_over_ranks else None
@@ -140,8 +142,9 @@ def main():
             else:
                 for p_ in pr.values():
                     p_.grad = None
-            zeros = torch.zeros(V, P, 3, device=dev)                           # ONE fill; V leaves that share its storage
-            m2ds = [zeros[i].detach().requires_grad_() for i in range(V)]
+            # the screen-space leaves: V detached views of ONE zero buffer that nothing ever writes into (the rasterizer reads no value
+            # of means2D, it returns its gradient) -- resident like every other input, no fill launch per step
+            m2ds = [self.zeros[i].detach().requires_grad_() for i in range(V)]
             # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views): the first phase of
             # all views goes out in four launches, then every view's binning / compositing kernels overlap on the chip
             if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
@@ -154,7 +157,7 @@ def main():
             else:
                 outs = [self.render(i, m2ds[i]) for i in range(V)]
                 loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).mean()
-            loss.backward()         # the batched node fans the views' K7/K8 out over the same per-view streams
+            loss.backward(gradient=self.one)   # (a resident 1.0: autograd would launch a fill for the root gradient every step)
             if self.fg is not None:
                 with torch.no_grad():
                     torch.sum(torch.stack([m.grad for m in m2ds]), dim=0, out=self.fg.tail.view(P, 3))

@@ -71,6 +71,8 @@ EXPORTS = {
     "csplat_rows_dot_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_l1": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "csplat_l1_masked": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "csplat_l1_signs": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "csplat_l1_signs_bwd": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _i, _vp, _vp]),
     "csplat_ssim_fwd_masked": (_i, [_vp, _i64, _i, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "csplat_prof_enable": (_i, [C.c_uint]),
     "csplat_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -89,8 +89,9 @@ def _launch_l1(x, y, mask, scratch, loss, grad):
 
 
 class FusedL1(torch.autograd.Function):
-    """mean |a - b| (mean |(a - b) * mask| with a mask) through csplat_l1 / csplat_l1_masked: the forward launch also writes
-    the gradient image sign(.) (* mask) / n, the backward scales it."""
+    """mean |a - b| (mean |(a - b) * mask| with a mask).  Forward: csplat_l1_signs -- the loss and ONE BYTE per element
+    (sign((a - b) m)); backward: csplat_l1_signs_bwd writes g * sign * m / n in one pass (g = the incoming gradient, read on the
+    device).  The reference's l1_loss is three elementwise launches each way (utils/loss_utils.py:20-23)."""
 
     @staticmethod
     def forward(ctx, a, b, mask=None):
@@ -98,18 +99,34 @@ class FusedL1(torch.autograd.Function):
         a, b = a.contiguous(), b.contiguous()
         mask = None if mask is None else mask.contiguous()
         need = a.requires_grad or b.requires_grad
-        grad = torch.empty_like(a) if need else None
         scratch = _l1_scratch(a.device)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
+        if mask is not None:
+            B, Cc, hw, mc = _mask_layout(a, mask)
+        else:
+            B, Cc, hw, mc = 1, 1, a.numel(), 1
         with torch.cuda.device(a.device):
-            _launch_l1(a, b, mask, scratch, loss, grad)
-        ctx.grad = grad
+            if need:
+                sign8 = torch.empty(a.numel(), dtype=torch.int8, device=a.device)
+                _n.check(_n.lib.csplat_l1_signs(_n.stream_handle(a.device), B, Cc, hw, _n.ptr(a), _n.ptr(b), _n.ptr(mask), mc, _n.ptr(scratch),
+                                                _n.ptr(loss), _n.ptr(sign8)), "csplat_l1_signs")
+                ctx.save_for_backward(sign8, mask)
+                ctx.layout = (B, Cc, hw, mc, tuple(a.shape))
+            else:
+                _launch_l1(a, b, mask, scratch, loss, None)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        ga = ctx.grad * g if ctx.needs_input_grad[0] else None
-        gb = -(ctx.grad * g) if ctx.needs_input_grad[1] else None
+        sign8, mask = ctx.saved_tensors
+        B, Cc, hw, mc, shape = ctx.layout
+        g = g.reshape(1).float().contiguous()
+        out = torch.empty(shape, dtype=torch.float32, device=sign8.device)
+        with torch.cuda.device(sign8.device):
+            _n.check(_n.lib.csplat_l1_signs_bwd(_n.stream_handle(sign8.device), B, Cc, hw, _n.ptr(sign8), _n.ptr(mask), mc, _n.ptr(g), _n.ptr(out)),
+                     "csplat_l1_signs_bwd")
+        ga = out if ctx.needs_input_grad[0] else None
+        gb = -out if ctx.needs_input_grad[1] else None
         return ga, gb, None
 
 
@@ -374,6 +391,17 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True)
     return loss
 
 
+_ONES = {}
+
+
+def _root_one(loss):
+    """a resident 1.0 as the root gradient of `loss.backward()` (autograd otherwise launches a fill for it every step)"""
+    key = (loss.device, loss.dtype)
+    if key not in _ONES:
+        _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return _ONES[key]
+
+
 def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT,
                background=None, static=False, view_parallel=False, batched_views=True, densify_opt=None, time_allreduce=False):
     """One optimisation step.  Returns (psnr, loss, stats) where stats holds what densification consumes.
@@ -449,7 +477,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         reg = regularization(torch.cat(verts, 0), gaussians, opt, static) if verts else torch.zeros((), device=dev)
     loss = image_loss + (reg / world if dist_mode else reg)
     if loss.requires_grad:
-        loss.backward()
+        loss.backward(gradient=_root_one(loss))
     if vsp_l:
         viewspace_grad = torch.stack([v.grad for v in vsp_l]).sum(0) if len(vsp_l) > 1 else vsp_l[0].grad.clone()
     else:

@@ -178,11 +178,13 @@ constexpr int L1_BLOCKS = 256, L1_THREADS = 1024;  // few, fat workgroups: the t
 __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
                                                     float inv_n, float *__restrict__ partial, unsigned *__restrict__ ticket,
                                                     float *__restrict__ loss, float *__restrict__ grad,
-                                                    const float *__restrict__ mask, int64_t hw, int channels, int mask_channels) {
+                                                    const float *__restrict__ mask, int64_t hw, int channels, int mask_channels,
+                                                    signed char *__restrict__ sign8) {
     __shared__ float s_red[L1_THREADS / 64];
     __shared__ bool s_last;
     float acc = 0.f;
     auto sg = [&](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
+    auto s8 = [&](float d) { return (signed char)(d > 0.f ? 1 : (d < 0.f ? -1 : 0)); };   // the backward's input when the caller asks for 1 byte per element
     // masked form (utils/loss_utils.py:21-22): mean |(a - b) * m|, m one plane per image (mask_channels == 1) or per channel
     auto moff = [&](int64_t e) {
         const int64_t plane = e / hw;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
             acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
             if (grad) reinterpret_cast<float4 *>(grad)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
         }
+        if (sign8) reinterpret_cast<char4 *>(sign8)[i] = make_char4(s8(d0), s8(d1), s8(d2), s8(d3));
     };
     const int64_t stride = (int64_t)gridDim.x * L1_THREADS;
     int64_t i = (int64_t)blockIdx.x * L1_THREADS + threadIdx.x;
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
         if (mask) { m = mask[moff(i)]; d *= m; }
         acc += fabsf(d);
         if (grad) grad[i] = sg(d) * m;
+        if (sign8) sign8[i] = s8(d);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -302,8 +306,34 @@ extern "C" int csplat_blur11(void *stream, int64_t n_images, int H, int W, const
 
 extern "C" size_t csplat_l1_scratch_bytes(void) { return (size_t)(L1_BLOCKS + 1) * 4; }
 
+// backward of the fused L1 when the forward kept one BYTE per element (csplat_l1_signs): out[i] = g[0] * sign[i] * m[i] / n -- the
+// upstream gradient g is a device scalar, so the reference's three elementwise backward launches (and the multiply by the incoming
+// gradient that a stored float gradient image needs) are this one pass: 1 (+4 masked) bytes read, 4 written per element
+__global__ __launch_bounds__(256) void k_l1_bwd(int64_t n, const signed char *__restrict__ sign8, const float *__restrict__ g, float inv_n,
+                                                const float *__restrict__ mask, int64_t hw, int channels, int mask_channels,
+                                                float *__restrict__ out) {
+    const float sc = g[0] * inv_n;
+    auto moff = [&](int64_t e) {
+        const int64_t plane = e / hw;
+        return (mask_channels == 1 ? plane / channels : plane) * hw + (e - plane * hw);
+    };
+    const int64_t n4 = (mask && (hw & 3)) ? 0 : n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const char4 s = reinterpret_cast<const char4 *>(sign8)[i];
+        float4 o = make_float4(sc * (float)s.x, sc * (float)s.y, sc * (float)s.z, sc * (float)s.w);
+        if (mask) {
+            const float4 m = *reinterpret_cast<const float4 *>(mask + moff(i << 2));
+            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = sc * (float)sign8[i] * (mask ? mask[moff(i)] : 1.f);
+}
+
 static int l1_launch(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad,
-                     const float *mask, int64_t hw, int channels, int mask_channels, const char *who) {
+                     const float *mask, int64_t hw, int channels, int mask_channels, const char *who, signed char *sign8 = nullptr) {
     CSPLAT_REQUIRE(n > 0 && a && b && scratch && loss, "csplat_l1: bad arguments");
     CSPLAT_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad | (uintptr_t)mask) & 15u) == 0, "csplat_l1: operands must be 16-byte aligned");
     float *partial = (float *)scratch;
@@ -311,8 +341,9 @@ static int l1_launch(void *stream, int64_t n, const float *a, const float *b, vo
     const int64_t units = (mask && (hw & 3)) ? n : n / 4;
     const int64_t work = (units + L1_THREADS - 1) / L1_THREADS;
     const int grid = (int)(work < 1 ? 1 : (work > L1_BLOCKS ? L1_BLOCKS : work));
+    CSPLAT_REQUIRE(((uintptr_t)sign8 & 3u) == 0, "csplat_l1: the sign buffer must be 4-byte aligned");
     k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, ticket, loss, grad, mask, hw, channels,
-                                                        mask_channels);
+                                                        mask_channels, sign8);
     LAUNCH_CHECK();
     (void)who;
     return 0;
@@ -327,6 +358,24 @@ extern "C" int csplat_l1_masked(void *stream, int64_t n_batch, int channels, int
     CSPLAT_REQUIRE(n_batch > 0 && channels > 0 && hw > 0 && mask, "csplat_l1_masked: bad arguments");
     CSPLAT_REQUIRE(mask_channels == 1 || mask_channels == channels, "csplat_l1_masked: the mask has 1 plane per image or one per channel");
     return l1_launch(stream, n_batch * channels * hw, a, b, scratch, loss, grad, mask, hw, channels, mask_channels, "csplat_l1_masked");
+}
+
+extern "C" int csplat_l1_signs(void *stream, int64_t n_batch, int channels, int64_t hw, const float *a, const float *b, const float *mask,
+                               int mask_channels, void *scratch, float *loss, signed char *sign8) {
+    CSPLAT_REQUIRE(n_batch > 0 && channels > 0 && hw > 0 && sign8, "csplat_l1_signs: bad arguments");
+    CSPLAT_REQUIRE(!mask || mask_channels == 1 || mask_channels == channels, "csplat_l1_signs: the mask has 1 plane per image or one per channel");
+    return l1_launch(stream, n_batch * channels * hw, a, b, scratch, loss, nullptr, mask, hw, channels, mask ? mask_channels : 1, "csplat_l1_signs", sign8);
+}
+extern "C" int csplat_l1_signs_bwd(void *stream, int64_t n_batch, int channels, int64_t hw, const signed char *sign8, const float *mask,
+                                   int mask_channels, const float *g_scalar, float *out) {
+    CSPLAT_REQUIRE(n_batch > 0 && channels > 0 && hw > 0 && sign8 && g_scalar && out, "csplat_l1_signs_bwd: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)out | (uintptr_t)mask) & 15u) == 0 && ((uintptr_t)sign8 & 3u) == 0, "csplat_l1_signs_bwd: operands must be aligned");
+    const int64_t n = n_batch * channels * hw;
+    const int64_t work = (n / 4 + 255) / 256;
+    const int grid = (int)(work < 1 ? 1 : (work > 4096 ? 4096 : work));
+    k_l1_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(n, sign8, g_scalar, 1.0f / (float)n, mask, hw, channels, mask ? mask_channels : 1, out);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t csplat_ssim_partial_count(int64_t n_images, int H, int W) { return (size_t)n_images * cdiv(H, BH) * cdiv(W, BW); }

@@ -29,6 +29,19 @@ class RenderResults(NamedTuple):
 
 
 _SIZES = {}
+_ZEROS = {}
+
+
+def _screenspace_zeros(n_views, like):
+    """[n_views, P, 3] zeros for the screen-space leaves of a step.  Nothing ever writes into them (the rasterizer reads no value of
+    means2D, it only returns its gradient; every camera's leaf is a detached view), so ONE buffer per (device, dtype) serves every step
+    instead of a fill launch per step; re-made when the step needs more room (densification)."""
+    key = (like.device, like.dtype)
+    need = n_views * int(like.shape[0]) * 3
+    buf = _ZEROS.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _ZEROS[key] = torch.zeros(need + need // 4, dtype=like.dtype, device=like.device)
+    return buf[:need].view(n_views, int(like.shape[0]), 3)
 
 
 def _project_torch(full, W, H, points):
@@ -192,8 +205,7 @@ def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor,
             shared["opacity"], shared["scales"], shared["features"], shared["cov3D"] = acts[0], acts[1], acts[2], None
         else:
             shared["opacity"] = pc.get_opacity
-        shared["screenspace_pool"] = list(torch.zeros(len(viewpoint_cameras), shared["opacity"].shape[0], 3, dtype=shared["opacity"].dtype,
-                                                      device=shared["opacity"].device).unbind(0))
+        shared["screenspace_pool"] = list(_screenspace_zeros(len(viewpoint_cameras), shared["opacity"]).unbind(0))
     for i, cam in enumerate(viewpoint_cameras):
         prepared.append(_prepare(cam, pc, simulator, pipe, bg_color, scaling_modifier, override_color, None, render_static,
                                  shared, None if deforms is None else deform_views[i],

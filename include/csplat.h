@@ -264,6 +264,14 @@ size_t csplat_l1_scratch_bytes(void);
 int csplat_l1(void *stream, int64_t n, const float *a, const float *b, void *scratch, float *loss, float *grad);
 int csplat_l1_masked(void *stream, int64_t n_batch, int channels, int64_t hw, const float *a, const float *b, const float *mask,
                      int mask_channels, void *scratch, float *loss, float *grad);
+/* The same loss for a caller that runs the backward later (autograd, `loss.backward()` of train_utils.py:288): the forward keeps ONE
+ * BYTE per element, sign8[i] = sign((a[i] - b[i]) * m[i]) in {-1, 0, 1}, instead of a float gradient image, and
+ *   csplat_l1_signs_bwd: out[i] = g_scalar[0] * sign8[i] * m[i] / n     (g_scalar: the incoming gradient of the loss, a device scalar)
+ * is the whole backward -- no separate multiply by the incoming gradient.  mask may be NULL (then mask_channels is ignored). */
+int csplat_l1_signs(void *stream, int64_t n_batch, int channels, int64_t hw, const float *a, const float *b, const float *mask,
+                    int mask_channels, void *scratch, float *loss, signed char *sign8);
+int csplat_l1_signs_bwd(void *stream, int64_t n_batch, int channels, int64_t hw, const signed char *sign8, const float *mask,
+                        int mask_channels, const float *g_scalar, float *out);
 
 /* Fused mesh -> Gaussian transform (SURVEY.md 8(f) "next" row N1): MultiGaussianMesh.get_xyz + get_rotation,
  * scene_reconstruction/gaussian_mesh.py:151-188.  face_vertex_ids[P][3] (int64, device) = mesh.face[:, face_ids].T.

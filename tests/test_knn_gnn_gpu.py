@@ -78,6 +78,7 @@ def _load(net, g, prefix):
     return net.cuda()
 
 
+@pytest.mark.allow_fallbacks("shape")      # latent size 16 / 32 (the reference-run fixtures): the generic path, knowingly
 def test_interaction_network_matches_reference_incl_f7():
     g = golden("gnn.npz")
     from meshnet.graph_network import InteractionNetwork
@@ -88,6 +89,7 @@ def test_interaction_network_matches_reference_incl_f7():
     np.testing.assert_array_equal(e1.detach().cpu().numpy(), g["in_e_out"])     # edge output = 2 x edge input (F7)
 
 
+@pytest.mark.allow_fallbacks("shape")      # latent size 16 / 32 (the reference-run fixtures): the generic path, knowingly
 def test_encode_process_decode_forward_backward_vs_reference():
     g = golden("gnn.npz")
     from meshnet.graph_network import EncodeProcessDecode
@@ -126,11 +128,12 @@ def test_encode_process_decode_latent128_tall_graph_vs_reference():
     y = net(x, ei, e)
     assert rel_err(y.detach().cpu().numpy(), g["y"]) < 1e-4
     # the fused nodes are in the graph
-    names, stack, seen = set(), [y.grad_fn], set()
+    names, stack, seen, keep = set(), [y.grad_fn], set(), []
     while stack:
         f = stack.pop()
         if f is None or id(f) in seen:
             continue
+        keep.append(f)                       # (the wrappers of graph nodes are created on demand: hold them, or ids get recycled)
         seen.add(id(f)); names.add(type(f).__name__)
         stack += [nf for nf, _ in f.next_functions]
     assert any(n.startswith("EdgeFirstLayer") for n in names) and any(n.startswith("EdgeTailAggregate") for n in names), sorted(names)
@@ -163,6 +166,7 @@ def test_strict_dispatch_raises_and_counts():
     assert native.FALLBACK_COUNTS[("train.l1_loss", "dtype")] == n0 + 1
 
 
+@pytest.mark.allow_fallbacks("shape")      # latent size 16 / 32 (the reference-run fixtures): the generic path, knowingly
 def test_cloth_simulator_vs_reference():
     g = golden("gnn.npz")
     from meshnet.cloth_network import ClothMeshSimulator
@@ -571,6 +575,7 @@ def _training_path_vs_fp64(seed, N, ei_np):
         assert eh <= max(2e-4, 5.0 * ep, 4.0 * sens, 2.0 * flip), (n_, eh, ep, sens, flip)
 
 
+@pytest.mark.allow_fallbacks("shape")      # latent size 16 / 32 (the reference-run fixtures): the generic path, knowingly
 def test_edge_features_kernel_and_rollout_loop():
     """csplat_gnn_edge_features == PyG Cartesian(norm=False) + Distance(norm=False) (pos[row] - pos[col] and its norm), and
     meshnet.rollout.rollout == the reference's loop (train_meshnet_sim.py:126-265) written out in plain torch around the same

@@ -23,6 +23,7 @@ def T(a, dt=None):
     return torch.tensor(a, device="cuda", dtype=dt)
 
 
+@pytest.mark.allow_fallbacks("shape")      # latent size 32 (the reference-run fixture): the generic path, knowingly
 def test_mesh_simulator_predict_dx_and_position_vs_reference_run():
     from meshnet.meshnet_network import MeshSimulator
     g = golden("meshsim.npz")
@@ -82,7 +83,7 @@ def test_fused_mesh_transform_vs_reference_run():
 def test_fused_image_losses_vs_reference_run(tag):
     """FusedL1 / FusedSSIM / FusedImageLoss (csplat_l1[_masked], csplat_ssim_fwd[_masked], csplat_ssim_bwd) against the values
     and autograd gradients of the reference's l1_loss / ssim / image_losses on a [3,3,37,45] batch (ragged tiles)."""
-    from csplat import train as tr
+    from csplat import native, train as tr
     g = golden("losses.npz")
     img, gt = T(g["img"]), T(g["gt"])
     mask = T(g["mask"]) if tag == "masked" else None
@@ -119,8 +120,9 @@ def test_fused_image_losses_vs_reference_run(tag):
         a = tr.image_losses(x1, ga, SimpleNamespace(lambda_dssim=0.05), ma)
         d = xa.double()
         x2d = d.clone().requires_grad_(True)
-        b = (torch.abs((x2d - ga.double()) * ma.double()).mean() +
-             0.05 * ((1.0 - tr.ssim(x2d, ga.double(), return_map=True)) * ma.double()).mean())    # composed fp64 form
+        with native.allow_fallbacks("dtype"):          # the composed form in fp64 is the cross-check here, knowingly off the HIP path
+            b = (torch.abs((x2d - ga.double()) * ma.double()).mean() +
+                 0.05 * ((1.0 - tr.ssim(x2d, ga.double(), return_map=True)) * ma.double()).mean())    # composed fp64 form
         a.backward(); b.backward()
         assert abs(float(a) - float(b)) < 1e-6
         assert rel_err(x1.grad.cpu().numpy(), x2d.grad.cpu().numpy()) < 1e-4
