@@ -71,6 +71,14 @@ def main():
                     help="views: view-parallel weak scaling (default, the BASELINE metric); scenes: 6 scene variants dealt over the ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as FRESH children (this process has not touched the GPU: importing
+        # torch does not initialise it) and pass their exit code on -- one rank per GPU, exactly what the driver's torchrun line does
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,6 +256,24 @@ def main():
                                                 wl.params["scales"], wl.params["rotations"], None, wl.settings[i])
                 R_per_view[i] = ctx.view_state.num_rendered
 
+    # forward-only (evaluation) rate, auxiliary: what the reference's render.py prints as FPS (render.py:195,301: render() under no_grad,
+    # camera by camera) -- here the V cameras of the batch per call, K1-K6 only
+    eval_fwd = None
+    if wl is not None and args.view_streams and world == 1:
+        with torch.no_grad():
+            kws = [dict(means3D=wl.params["means3D"], means2D=None, opacities=wl.params["opacities"], shs=wl.params["shs"],
+                        scales=wl.params["scales"], rotations=wl.params["rotations"]) for _ in range(V)]
+            for _ in range(3):
+                rasterize_views(wl.settings, kws, stacked=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                rasterize_views(wl.settings, kws, stacked=True)
+            torch.cuda.synchronize()
+            dt_e = (time.perf_counter() - t1) / 20
+        eval_fwd = {"ms_per_call": round(dt_e * 1e3, 4), "views_per_call": V, "fps": round(V / dt_e, 1),
+                    "Mpix_per_s": round(V * W * H / 1e6 / dt_e, 1), "what": "rasterizer forward only under no_grad (K1-K6), all views of the batch per call"}
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -266,23 +292,51 @@ def main():
     alg_bytes = float(np.mean([84.0 * r + 24.0 * X for r in R_per_view])) * views_per_launch
     k7_avg_s = (k7_ms / max(k7_n, 1)) * 1e-3
     achieved = alg_bytes / k7_avg_s / 1e9 if k7_avg_s > 0 else 0.0
-    # committed counter passes of the same workload (tools/collect_profiles.sh): HBM traffic and VALU instruction count of K7
-    traffic = valu_insts = None
+    # committed counter passes of the same workload on the DEFAULT command (tools/collect_profiles.sh, tools/collect_issue_counters.sh):
+    # HBM traffic and VALU instruction count of the K7 launch this run timed.  They are measurements of an earlier run of the same
+    # kernel: the profile records the SHA-1 of csplat_raster.hip it was taken with, and the values are withheld (null, with the reason)
+    # when the source has changed since.
     import glob
-    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k7_pmc_traffic.json")))   # newest round's PMC passes
-    if tpaths:
+    import hashlib
+    K7_NAMES = ("k_composite_bwd_rows_views", "k_composite_bwd_views") if (args.view_streams and V > 1) else ("k_composite_bwd_rows", "k_composite_bwd")
+    src_sha = hashlib.sha1(open(os.path.join(ROOT, "cloth-splatting_amd", "csrc", "csplat_raster.hip"), "rb").read()).hexdigest()
+    traffic = valu_insts = None
+    counters_from = {}
+
+    def newest(pattern):
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return paths[-1] if paths else None
+    tp = newest("r*_k7_pmc_traffic.json")
+    if tp:
         try:
-            traffic = json.load(open(tpaths[-1])).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    ipaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k67_issue.json")))
-    if ipaths:
+            doc = json.load(open(tp))
+            fresh = doc.get("raster_src_sha1") == src_sha
+            counters_from["traffic"] = {"file": os.path.basename(tp), "same_kernel_source": fresh}
+            table = doc.get("all_kernels", {}) if (args.view_streams and V > 1) else (doc.get("one_view_per_launch") or {})
+            hit = next((v for k, v in table.items() if any(k.startswith(n) and "<true>" not in k for n in K7_NAMES[:1])), None) or \
+                next((v for k, v in table.items() if any(k.startswith(n) for n in K7_NAMES)), None)
+            if fresh and hit:
+                traffic = int(hit["hbm_bytes_per_launch"])
+        except Exception as e:
+            counters_from["traffic"] = {"error": repr(e)[:120]}
+    ip = newest("r*_k67_issue.json")
+    if ip:
         try:
-            valu_insts = json.load(open(ipaths[-1]))["kernels"]["k_composite_bwd"]["SQ_INSTS_VALU"]
-        except Exception:
-            valu_insts = None
-    SIMDS, CLOCK_GHZ = 1024, 2.4         # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 4 cycles
-    issue = lambda us, nv=1: None if not (valu_insts and us) else round(nv * valu_insts * 4.0 / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
+            doc = json.load(open(ip))
+            fresh = doc.get("raster_src_sha1") == src_sha
+            counters_from["issue"] = {"file": os.path.basename(ip), "same_kernel_source": fresh}
+            table = doc.get("kernels", {}) if (args.view_streams and V > 1) else doc.get("kernels_one_view_per_launch", {})
+            hit = next((table[n] for n in K7_NAMES if n in table), None)
+            if fresh and hit:
+                valu_insts = hit["SQ_INSTS_VALU"]
+        except Exception as e:
+            counters_from["issue"] = {"error": repr(e)[:120]}
+    # what a wave64 VALU instruction costs a SIMD's vector pipe on this part (tools/valu_rate.hip, profiles/r03_valu_rate.txt, >= 2 waves
+    # per SIMD): 2.3 cycles for plain v_fma / v_mul / v_add / v_mov, 4.2 for every DPP form, v_cmp, v_min / v_max, v_cndmask_e64, shifts and
+    # conversions, 8.2 for v_exp / v_rcp / v_permlane*_swap.  K7's loop (156 VALU per group of four survivors: 82 / 66 / 8 of the three
+    # classes, from the ISA) averages 3.4 cycles per instruction.
+    SIMDS, CLOCK_GHZ, K7_CYC_PER_VALU = 1024, 2.4, 3.4
+    issue = lambda us: None if not (valu_insts and us) else round(valu_insts * K7_CYC_PER_VALU / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
     out = {
         "metric": "rasterizer fwd+bwd rendered Mpix/s (scene_1, 800x800)", "value": round(value, 3), "unit": "Mpix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -294,28 +348,31 @@ def main():
                    "tile_instances_per_view": R_per_view,
                    "parallelism": (f"scene-parallel x{world} (replicas only)" if scene_mode else f"view-parallel x{world}"),
                    "streams_per_gpu": V if args.view_streams else 1},
-        "roofline": {"bound": "hbm", "kernel": "k_composite_bwd (K7 compositing backward)", "achieved": round(achieved, 3),
+        "roofline": {"bound": "hbm", "kernel": "k_composite_bwd_rows_views (K7 compositing backward, all views of the step in one launch)", "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     # PMC bytes (2 x FETCH_SIZE + WRITE_SIZE, committed counter passes of the one-view-per-launch command) scaled to
-                     # the views this launch carries, like `achieved`
-                     "traffic": None if traffic is None else int(traffic * views_per_launch),
+                     # PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of THIS launch (all views of the step), from the committed counter pass of
+                     # the default command; null when that pass was taken with a different csplat_raster.hip
+                     "traffic": traffic, "counters_from": counters_from,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
                      "launches_timed": int(k7_n),
                      "views_per_launch": views_per_launch,
-                     "issue_frac": issue(k7_avg_s * 1e6, views_per_launch),
-                     "issue_note": "VALU wave-instructions of one launch (SQ_INSTS_VALU, committed profiles/*_k67_issue.json) x 4 cycles / "
-                                   "(1024 SIMDs x 2.4 GHz x this launch duration): the share of the chip's vector issue slots the kernel "
-                                   "used -- the bound that actually binds this kernel (sort / composite arithmetic, no MFMA)",
+                     "issue_frac": issue(k7_avg_s * 1e6),
+                     "issue_note": "VALU wave-instructions of this launch (SQ_INSTS_VALU of the committed counter pass) x 3.4 cycles (the "
+                                   "instruction mix of K7's loop priced with tools/valu_rate.hip: 2.3 plain / 4.2 DPP, compare, select, "
+                                   "min-max / 8.2 exp, rcp, permlane swap) / (1024 SIMDs x 2.4 GHz x this launch's duration): the share of "
+                                   "the vector pipes' cycles the kernel's arithmetic occupies -- the bound that binds it (composite "
+                                   "arithmetic, no contraction), not HBM",
                      "alone": None if not k7_alone_us else {
                          "avg_launch_us": round(k7_alone_us, 2),
                          "achieved": round(alg_bytes / views_per_launch / (k7_alone_us * 1e-6) / 1e9, 3),
                          "frac": round(alg_bytes / views_per_launch / (k7_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
-                         "issue_frac": issue(k7_alone_us),
+                         "issue_frac": None,
                          "what": "same kernel, views back to back on one stream (untimed extra pass)"},
                      "note": (f"the K7 work of the step's {V} views is ONE launch (blockIdx.y = view): bytes and instructions of "
                               f"{views_per_launch} view(s) per launch over that launch's duration; 'alone' = one view per launch, views "
                               "back to back") if args.view_streams and V > 1 else None},
         "kernel_us": breakdown,
+        "eval_forward": eval_fwd,
         "collective": collective,
     }
     # the first half of BASELINE.json's metric ("train-step ms"): BASELINE configs[2], measured by bench_train.py (untimed
