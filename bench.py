@@ -143,7 +143,7 @@ def main():
             return GaussianRasterizer(self.settings[i])(means3D=pr["means3D"], means2D=means2D, opacities=pr["opacities"],
                                                         shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
 
-        def step(self, timed_allreduce=False):
+        def step(self, timed_allreduce=False, skip_allreduce=False):
             pr = self.params
             if self.fg is not None:
                 self.fg.bind()
@@ -169,7 +169,8 @@ def main():
             if self.fg is not None:
                 with torch.no_grad():
                     torch.sum(torch.stack([m.grad for m in m2ds]), dim=0, out=self.fg.tail.view(P, 3))
-                self.fg.all_reduce(timed=timed_allreduce)
+                if not skip_allreduce:
+                    self.fg.all_reduce(timed=timed_allreduce)
             return loss
 
     scene_mode = args.mode == "scenes"
@@ -243,8 +244,21 @@ def main():
         for _ in range(5):
             wl.step(timed_allreduce=True)
             ar.append(wl.fg.last_allreduce_ms)
+        # the same steps WITHOUT the exchange: what the collective adds to the step as launched (its exposed time).  In this workload
+        # every gradient is finished by ONE kernel (K8) at the very end of backward, so nothing is left to hide the exchange behind;
+        # the train step (csplat.train.train_step, view_parallel) sends the Gaussian gradients' slice from a backward hook, under the
+        # simulator's and the regularisers' backward (csplat/dist.py: early bucket)
+        sync(); t_n = time.perf_counter()
+        for _ in range(5):
+            wl.step(skip_allreduce=True)
+        sync(); ms_noar = (time.perf_counter() - t_n) / 5 * 1e3
+        sync(); t_n = time.perf_counter()
+        for _ in range(5):
+            wl.step()
+        sync(); ms_ar = (time.perf_counter() - t_n) / 5 * 1e3
         collective = {"backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
                       "bytes": int(wl.fg.flat.numel() * 4), "allreduce_ms": round(float(np.median(ar)), 4),
+                      "exposed_allreduce_ms": round(ms_ar - ms_noar, 4), "step_ms_without_allreduce": round(ms_noar, 4),
                       "what": "one all-reduce(sum) per step over the flat gradient buffer (62 floats per Gaussian + 3 for the "
                               "screen-space gradient); timed alone, after the step's kernels have drained"}
     R_per_view = [0] * V

@@ -430,7 +430,12 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     P = int(gaussians.num_gaussians)
     fg = None
     if dist_mode:
-        fg = cd.flat_grads_for(gaussians, list(gaussians.parameters()) + list(simulator.parameters()), extra=3 * P + 2)
+        # one flat buffer: [Gaussian parameters | simulator parameters | tail].  The Gaussian gradients -- ~95 % of the bytes -- are final
+        # as soon as the rasterizer's backward and the mesh-transform adjoint have run: their slice is exchanged then (early bucket),
+        # under the simulator's and the regularisers' backward.  Tail: the summed screen-space gradient [3P], PSNR, loss, and every
+        # rank's largest radii in its own [P] slot (zeros elsewhere), so that the max over ranks rides in the SAME sum
+        gparams = list(gaussians.parameters())
+        fg = cd.flat_grads_for(gaussians, gparams + list(simulator.parameters()), extra=3 * P + 2 + world * P, early=len(gparams))
         fg.bind()
     images, gts, radii_l, vsp_l, verts = [], [], [], [], []
     masks = [] if all_cams and getattr(all_cams[0], "mask", None) is not None else None          # train_utils.py:256
@@ -489,11 +494,13 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             fg.tail[:3 * P].copy_(viewspace_grad.reshape(-1))
             fg.tail[3 * P] = psnr_.to(fg.tail.dtype)
             fg.tail[3 * P + 1] = loss_value.to(fg.tail.dtype)
+            slots = fg.tail[3 * P + 2:].view(world, P)
+            slots[rank].copy_(radii)                          # (radii < 2^24: exact in fp32; the other ranks' slots stay zero)
             fg.all_reduce(timed=time_allreduce)
             fg.drop_untouched(key=(bool(static), n_total))
             viewspace_grad = fg.tail[:3 * P].view(P, 3).clone()
             psnr_, loss_value = fg.tail[3 * P].double(), fg.tail[3 * P + 1].clone()
-            radii = cd.reduce_max_radii(radii.contiguous())
+            radii = slots.max(dim=0).values.to(radii.dtype)   # train_utils.py:276-277 over all ranks' cameras
         visibility_filter = radii > 0            # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
         if densify_opt is not None and iteration < densify_opt.densify_until_iter:      # train_utils.py:295-304
             densification(gaussians, iteration, visibility_filter, radii, viewspace_grad, densify_opt,

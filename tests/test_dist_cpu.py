@@ -112,6 +112,8 @@ def _run_steps(view_parallel, n_cams, with_masks, steps=2):
     #  Adam state exists for exactly the parameters the step gives a gradient: `face_offset` is outside the graph
     out["adam_has_state"] = np.array([int(len(pc.optimizer.state.get(p, {})) > 0) for p in pc.parameters()])
     out["has_grad_none"] = np.array([int(p.grad is None) for p in pc.parameters()])
+    fg = getattr(pc, "_flat_grads", None)
+    out["early_fired"] = np.array(-1 if fg is None else fg.early_fired)
     return out
 
 
@@ -139,7 +141,14 @@ def test_view_parallel_train_step_equals_single_process_step(tmp_path, n_cams, w
     mp.spawn(_step_worker, args=(2, port, str(tmp_path), n_cams, with_masks), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
     ref = _run_steps(False, n_cams, with_masks)
+    # the Gaussian gradients' slice left from the backward HOOK (under the simulator's backward) on the rank(s) that render a camera
+    # in every step after the first of the buffer; a rank without a camera sends it at the end -- same collectives, same order
+    assert int(r0["early_fired"]) == 1 and int(r1["early_fired"]) == (1 if n_cams > 1 else 0), (r0["early_fired"], r1["early_fired"])
     for k in r0.files:
+        if k == "early_fired":
+            continue
         np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)                     # replicas identical
+        if k == "early_fired":
+            continue
         a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
         assert np.abs(a - b).max() <= 1e-9 * (np.abs(b).max() + 1e-30) + 1e-12, (k, np.abs(a - b).max())
