@@ -392,6 +392,24 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True)
 
 
 _ONES = {}
+_GT_STACKS = {}
+
+
+def _gt_stack(cams, device):
+    """torch.cat of the cameras' ground-truth images (train_utils.py:262-270 builds it every step).  A training run cycles through a
+    bounded set of camera triples whose images never change: the stack of a camera set is built once and kept, keyed on the image
+    tensor OBJECTS and their in-place versions (held in the entry, so a recycled id cannot alias)."""
+    imgs = [cam.original_image for cam in cams]
+    key = tuple((id(t), t._version) for t in imgs) + (str(device),)
+    hit = _GT_STACKS.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], imgs)):
+        return hit[1]
+    if len(_GT_STACKS) >= 512:
+        _GT_STACKS.clear()
+    stack = torch.cat([t.to(device).unsqueeze(0) for t in imgs], 0)
+    _GT_STACKS[key] = (imgs, stack)
+    return stack
+
 
 
 def _root_one(loss):
@@ -458,7 +476,6 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         pkgs = [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
     for cam, pkg in zip(cams, pkgs):
         images.append(pkg.render.unsqueeze(0))
-        gts.append(cam.original_image.to(pkg.render.device).unsqueeze(0))
         radii_l.append(pkg.radii.unsqueeze(0))
         vsp_l.append(pkg.viewspace_points)
         if masks is not None:
@@ -468,7 +485,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     if cams:
         radii = torch.cat(radii_l, 0).max(dim=0).values
         image_tensor = stacked if stacked is not None else torch.cat(images, 0)
-        gt_image_tensor = torch.cat(gts, 0)
+        gt_image_tensor = _gt_stack(cams, image_tensor.device)
         mask_tensor = torch.cat(masks, 0) if masks is not None else None
         psnr_sum = psnr(image_tensor, gt_image_tensor).sum().double()
         image_loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor)

@@ -324,6 +324,93 @@ int launch_bwd(hipStream_t s, int R, const float *W, const float *h, const float
     LAUNCH_CHECK();
     return 0;
 }
+// ---- the two hidden layers of the simulator MLP for the T time rows of a step, ONE launch each way
+// (meshnet_network.py:337-338,364-366: relu(Linear(13, 256)) -> relu(Linear(256, 256)) on the sinusoidal code of one time value per
+// camera).  As torch ops the step pays ~20 launches for them (two [T,*] GEMMs and their four backward GEMMs at M = T = 3, bias sums,
+// ReLU masks): ~100 us of GPU time at ~5 us per launch floor and more on the host, for 70 k multiply-adds.  One 256-thread
+// workgroup: thread j owns hidden unit j.
+//   forward : h1[t][j] = relu(b1[j] + sum_c W1[j][c] e[t][c]),  h2[t][j] = relu(b2[j] + sum_k W2[j][k] h1[t][k])
+//   backward: dz2 = dh2 * (h2 > 0); db2 = sum_t dz2; dW2[j][k] = sum_t dz2[t][j] h1[t][k]; dh1[t][k] = sum_j W2[j][k] dz2[t][j];
+//             dz1 = dh1 * (h1 > 0); db1 = sum_t dz1; dW1[k][c] = sum_t dz1[t][k] e[t][c]          (fixed summation order)
+constexpr int SIM_H = 256, SIM_K0MAX = 16;
+template <int T>
+__global__ __launch_bounds__(SIM_H) void k_sim_hidden_fwd(int K0, const float *__restrict__ e, const float *__restrict__ W1,
+                                                          const float *__restrict__ b1, const float *__restrict__ W2,
+                                                          const float *__restrict__ b2, float *__restrict__ h1, float *__restrict__ h2) {
+    __shared__ float s_h1[T][SIM_H];
+    const int j = threadIdx.x;
+    float a[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) a[t] = b1[j];
+    for (int c = 0; c < K0; c++) {
+        const float w = W1[j * K0 + c];
+#pragma unroll
+        for (int t = 0; t < T; t++) a[t] = __fmaf_rn(w, e[t * K0 + c], a[t]);    // (explicit fma chains: the same bits for every T)
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) { a[t] = fmaxf(a[t], 0.f); s_h1[t][j] = a[t]; h1[t * SIM_H + j] = a[t]; }
+    __syncthreads();
+    float o[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) o[t] = b2[j];
+    const float4 *row = reinterpret_cast<const float4 *>(W2 + (size_t)j * SIM_H);
+#pragma unroll 4
+    for (int k4 = 0; k4 < SIM_H / 4; k4++) {
+        const float4 w = row[k4];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const float4 x = *reinterpret_cast<const float4 *>(&s_h1[t][4 * k4]);    // (same address in every lane: a broadcast)
+            o[t] = __fmaf_rn(w.w, x.w, __fmaf_rn(w.z, x.z, __fmaf_rn(w.y, x.y, __fmaf_rn(w.x, x.x, o[t]))));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) h2[t * SIM_H + j] = fmaxf(o[t], 0.f);
+}
+
+template <int T>
+__global__ __launch_bounds__(SIM_H) void k_sim_hidden_bwd(int K0, const float *__restrict__ e, const float *__restrict__ W2,
+                                                          const float *__restrict__ h1, const float *__restrict__ h2,
+                                                          const float *__restrict__ dh2, float *__restrict__ dW1, float *__restrict__ db1,
+                                                          float *__restrict__ dW2, float *__restrict__ db2) {
+    __shared__ float s_dz2[T][SIM_H];
+    const int k = threadIdx.x;
+    float x1[T], d1[T];
+    float sb = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const float dz = h2[t * SIM_H + k] > 0.f ? dh2[t * SIM_H + k] : 0.f;
+        s_dz2[t][k] = dz;
+        sb += dz;
+        x1[t] = h1[t * SIM_H + k];
+        d1[t] = 0.f;
+    }
+    db2[k] = sb;
+    __syncthreads();
+    // row j of W2 / dW2 at a time: every access is one coalesced 1 KB row, dz2[.][j] is a broadcast
+#pragma unroll 4
+    for (int j = 0; j < SIM_H; j++) {
+        const float w = W2[(size_t)j * SIM_H + k];
+        float g = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const float dz = s_dz2[t][j];
+            g += dz * x1[t];
+            d1[t] += w * dz;
+        }
+        dW2[(size_t)j * SIM_H + k] = g;
+    }
+    float sb1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; t++) { d1[t] = x1[t] > 0.f ? d1[t] : 0.f; sb1 += d1[t]; }
+    db1[k] = sb1;
+    for (int c = 0; c < K0; c++) {
+        float g = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; t++) g += d1[t] * e[t * K0 + c];
+        dW1[k * K0 + c] = g;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -414,6 +501,29 @@ int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, con
                                         edge_terms ? lambda_rigid / ((float)T * (float)E) : 0.f,
                                         node_terms && lambda_momentum != 0.f ? lambda_momentum / (float)V : 0.f, grad, partial, ticket,
                                         loss);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_sim_hidden_fwd(void *stream, int T, int K0, const float *e, const float *W1, const float *b1, const float *W2, const float *b2,
+                          float *h1, float *h2) {
+    CSPLAT_REQUIRE(T >= 1 && T <= SIM_TMAX && K0 >= 1 && K0 <= SIM_K0MAX, "csplat_sim_hidden_fwd: 1 <= T <= 8 time rows, 1 <= K0 <= 16 inputs");
+    CSPLAT_REQUIRE(e && W1 && b1 && W2 && b2 && h1 && h2 && ((uintptr_t)W2 & 15u) == 0, "csplat_sim_hidden_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+#define CSPLAT_SIMH(TT) case TT: k_sim_hidden_fwd<TT><<<1, SIM_H, 0, s>>>(K0, e, W1, b1, W2, b2, h1, h2); break;
+    switch (T) { CSPLAT_SIMH(1) CSPLAT_SIMH(2) CSPLAT_SIMH(3) CSPLAT_SIMH(4) CSPLAT_SIMH(5) CSPLAT_SIMH(6) CSPLAT_SIMH(7) CSPLAT_SIMH(8) }
+#undef CSPLAT_SIMH
+    LAUNCH_CHECK();
+    return 0;
+}
+int csplat_sim_hidden_bwd(void *stream, int T, int K0, const float *e, const float *W2, const float *h1, const float *h2, const float *dh2,
+                          float *dW1, float *db1, float *dW2, float *db2) {
+    CSPLAT_REQUIRE(T >= 1 && T <= SIM_TMAX && K0 >= 1 && K0 <= SIM_K0MAX, "csplat_sim_hidden_bwd: 1 <= T <= 8 time rows, 1 <= K0 <= 16 inputs");
+    CSPLAT_REQUIRE(e && W2 && h1 && h2 && dh2 && dW1 && db1 && dW2 && db2, "csplat_sim_hidden_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+#define CSPLAT_SIMH(TT) case TT: k_sim_hidden_bwd<TT><<<1, SIM_H, 0, s>>>(K0, e, W2, h1, h2, dh2, dW1, db1, dW2, db2); break;
+    switch (T) { CSPLAT_SIMH(1) CSPLAT_SIMH(2) CSPLAT_SIMH(3) CSPLAT_SIMH(4) CSPLAT_SIMH(5) CSPLAT_SIMH(6) CSPLAT_SIMH(7) CSPLAT_SIMH(8) }
+#undef CSPLAT_SIMH
     LAUNCH_CHECK();
     return 0;
 }

@@ -151,6 +151,47 @@ class RowsDot(torch.autograd.Function):
         return dh, dW, db
 
 
+class SimHidden(torch.autograd.Function):
+    """relu(Linear(K0, 256)) -> relu(Linear(256, 256)) of the time-conditioned simulator (meshnet_network.py:337-338,364-366) for the
+    T <= 8 time rows of a step: csplat_sim_hidden_fwd / _bwd, one launch each way instead of ~20 torch launches."""
+
+    @staticmethod
+    def forward(ctx, e, W1, b1, W2, b2):
+        e, W1, b1, W2, b2 = (_f32(t) for t in (e, W1, b1, W2, b2))
+        T, K0 = int(e.shape[0]), int(e.shape[1])
+        h1 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
+        h2 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
+        with torch.cuda.device(e.device):
+            _n.check(_n.lib.csplat_sim_hidden_fwd(_n.stream_handle(e.device), T, K0, _n.ptr(e), _n.ptr(W1), _n.ptr(b1), _n.ptr(W2), _n.ptr(b2),
+                                                  _n.ptr(h1), _n.ptr(h2)), "csplat_sim_hidden_fwd")
+        ctx.save_for_backward(e, W2, h1, h2)
+        return h2
+
+    @staticmethod
+    def backward(ctx, g):
+        e, W2, h1, h2 = ctx.saved_tensors
+        T, K0 = int(e.shape[0]), int(e.shape[1])
+        g = _f32(g)
+        dev = g.device
+        dW1 = torch.empty(256, K0, dtype=torch.float32, device=dev)
+        dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
+        db = torch.empty(2, 256, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _n.check(_n.lib.csplat_sim_hidden_bwd(_n.stream_handle(dev), T, K0, _n.ptr(e), _n.ptr(W2), _n.ptr(h1), _n.ptr(h2), _n.ptr(g),
+                                                  _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1])), "csplat_sim_hidden_bwd")
+        return None, dW1, db[0], dW2, db[1]
+
+
+def sim_hidden(e, lin1, lin2):
+    """relu(lin2(relu(lin1(e)))) for the simulator's two hidden layers; the fused HIP form for T <= 8 fp32 GPU rows of the reference's
+    shape (K0 <= 16 -> 256 -> 256), composed torch otherwise"""
+    if e.is_cuda and e.dim() == 2 and 0 < e.shape[0] <= 8 and e.shape[1] <= 16 and tuple(lin1.weight.shape) == (256, e.shape[1]) and \
+            tuple(lin2.weight.shape) == (256, 256) and lin1.bias is not None and lin2.bias is not None and not e.requires_grad:
+        return SimHidden.apply(e, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    _n.composed_fallback("graph_ops.sim_hidden", "shape", e)
+    return torch.relu(lin2(torch.relu(lin1(e))))
+
+
 def rows_dot(h, weight, bias):
     """F.linear(h, weight, bias) for few rows of h (<= 8) against a tall 256-column weight, at HBM rate on the GPU."""
     if h.is_cuda and h.dim() == 2 and h.shape[1] == 256 and weight.shape[1] == 256 and 0 < h.shape[0] <= 8 and bias is not None:

@@ -105,9 +105,12 @@ class ResidualMeshSimulator(torch.nn.Module):
         is a matrix-vector product per time; as an M = 1 GEMM (what nn.Linear issues) it runs at ~60 GB/s on this stack.
         graph_ops.rows_dot streams the 3V x 256 weight once for all T rows (forward) / once more for their gradients.
         encoded: encoder(times) when the caller kept it (the encoder has no parameters)."""
-        from meshnet.graph_ops import rows_dot
-        h = torch.relu(self.input(self.encoder(times) if encoded is None else encoded))
-        h = torch.relu(self.hidden(h))
+        from meshnet.graph_ops import rows_dot, sim_hidden
+        enc = self.encoder(times) if encoded is None else encoded
+        if enc.is_cuda:      # the two hidden layers in one launch each way (csplat_sim_hidden_fwd / _bwd)
+            h = sim_hidden(enc, self.input, self.hidden)
+        else:
+            h = torch.relu(self.hidden(torch.relu(self.input(enc))))
         return rows_dot(h, self.output.weight, self.output.bias).reshape(times.shape[0], -1, 3)
 
     def forward(self, time_vector):

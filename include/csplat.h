@@ -199,6 +199,14 @@ int csplat_rows_scatter(void *stream, int n_tensors, const void *const *src, voi
  *   forward:  y[t][r] = b[r] + sum_k W[r][k] h[t][k]               W [R][K] row-major (torch Linear.weight), h [T][K], y [T][R]
  *   backward: dW[r][k] = sum_t dy[t][r] h[t][k], db[r] = sum_t dy[t][r], dh[t][k] = sum_r dy[t][r] W[r][k]   (deterministic)
  * K must be 256, 0 <= T <= 8.  scratch: csplat_rows_dot_scratch_bytes(T) bytes, not shared between concurrent calls. */
+/* The two hidden layers in front of it (meshnet_network.py:337-338,364-366), for the same T time rows, one launch each way:
+ *   forward : h1 = relu(e W1^T + b1) [T][256], h2 = relu(h1 W2^T + b2) [T][256]      e [T][K0] (the sinusoidal code, K0 <= 16),
+ *             W1 [256][K0], W2 [256][256] row-major (torch Linear.weight)
+ *   backward: from dh2 = dL/dh2 [T][256]: dW1 [256][K0], db1 [256], dW2 [256][256], db2 [256]   (e has no gradient: parameter-free code) */
+int csplat_sim_hidden_fwd(void *stream, int T, int K0, const float *e, const float *W1, const float *b1, const float *W2, const float *b2,
+                          float *h1, float *h2);
+int csplat_sim_hidden_bwd(void *stream, int T, int K0, const float *e, const float *W2, const float *h1, const float *h2, const float *dh2,
+                          float *dW1, float *db1, float *dW2, float *db2);
 size_t csplat_rows_dot_scratch_bytes(int T);
 int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y);
 int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const float *h, const float *dy, float *dW, float *db,

@@ -271,6 +271,23 @@ def gen_gnn128():
                dbeta_node1=npy(l1.node_fn[1].bias.grad), dW_enc_edge=npy(net._encoder.edge_fn[0][0].weight.grad),
                dW_dec_last=npy(net._decoder.node_fn[4].weight.grad),
                w_probe=npy(l0.edge_fn[0][2].weight[:2, :5]))         # a few weights, so that the test can check its regeneration
+    # the same network in float64 (same weights): how far the reference's OWN fp32 gradients are from exact arithmetic -- ~10^6 ReLU
+    # pre-activations, some within fp32 rounding of zero, make the gradient a discontinuous function of the rounding; the test holds
+    # the build to the larger of 1e-4 and a small multiple of this distance
+    net64 = EncodeProcessDecode(nnode_in_features=8, nnode_out_features=3, nedge_in_features=4, latent_dim=128,
+                                nmessage_passing_steps=2, nmlp_layers=2, mlp_hidden_dim=128).double()
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    xg6, eg6 = x.double().requires_grad_(True), ef.double().requires_grad_(True)
+    y6 = net64(xg6, ei, eg6)
+    (y6 * w.double()).sum().backward()
+    m0, m1 = net64._processor.gnn_stacks
+    f64 = dict(y=y6, dx=xg6.grad, de=eg6.grad, dW_edge_first0=m0.edge_fn[0][0].weight.grad, dW_edge_hidden0=m0.edge_fn[0][2].weight.grad,
+               dW_edge_last1=m1.edge_fn[0][4].weight.grad, db_edge_last1=m1.edge_fn[0][4].bias.grad,
+               dW_node_first1=m1.node_fn[0][0].weight.grad, dgamma_edge0=m0.edge_fn[1].weight.grad, dbeta_node1=m1.node_fn[1].bias.grad,
+               dW_enc_edge=net64._encoder.edge_fn[0][0].weight.grad, dW_dec_last=net64._decoder.node_fn[4].weight.grad)
+    for k, v in f64.items():
+        ref32 = np.asarray(out[k], np.float64)
+        out["f64dist." + k] = np.asarray(np.abs(npy(v) - ref32).max() / (np.abs(npy(v)).max() + 1e-30))
     np.savez_compressed(os.path.join(OUT, "gnn128.npz"), **out)
 
 

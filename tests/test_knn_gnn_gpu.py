@@ -142,9 +142,13 @@ def test_encode_process_decode_latent128_tall_graph_vs_reference():
                dW_edge_last1=l1.edge_fn[0][4].weight.grad, db_edge_last1=l1.edge_fn[0][4].bias.grad,
                dW_node_first1=l1.node_fn[0][0].weight.grad, dgamma_edge0=l0.edge_fn[1].weight.grad, dbeta_node1=l1.node_fn[1].bias.grad,
                dW_enc_edge=net._encoder.edge_fn[0][0].weight.grad, dW_dec_last=net._decoder.node_fn[4].weight.grad)
+    # bar: 1e-4, or three times the distance of the reference's own fp32 run from the same network in fp64 (stored with the fixture:
+    # ReLU pre-activations within rounding of zero make the gradients discontinuous in the rounding -- the reference's run is one
+    # sample of that, ours another)
     for k, v in got.items():
         err = rel_err(v.cpu().numpy(), g[k])
-        assert err < 1e-4, (k, err)
+        bar = max(1e-4, 3.0 * float(g["f64dist." + k]))
+        assert err < bar, (k, err, bar)
     assert sum(native.FALLBACK_COUNTS.values()) == before
 
 
@@ -709,3 +713,28 @@ def test_dw128_vs_fp64(M):
     dW3, db3 = dw128(g, x, bias=True, x_relu=True)
     assert torch.equal(db3, db) and torch.equal(dW3, dw128(g, x.relu()))
     assert torch.equal(dw128(g, x, x_relu=True), dW3)
+
+
+@pytest.mark.parametrize("T", [1, 3, 8])
+def test_sim_hidden_layers_match_composed_torch_fwd_bwd(T):
+    """csplat_sim_hidden_fwd / _bwd (relu(Linear(13, 256)) -> relu(Linear(256, 256)) of the time-conditioned simulator,
+    meshnet_network.py:337-338,364-366, one launch each way) against the same two layers composed in fp64: output and the four
+    parameter gradients; the node is the one the simulator's _residual() takes on the GPU."""
+    from meshnet.graph_ops import sim_hidden
+    g = torch.Generator().manual_seed(40 + T)
+    lin1, lin2 = torch.nn.Linear(13, 256), torch.nn.Linear(256, 256)
+    with torch.no_grad():
+        lin1.bias.add_(0.3 * torch.randn(256, generator=g)); lin2.bias.add_(0.3 * torch.randn(256, generator=g))
+    e = torch.randn(T, 13, generator=g)
+    w = torch.randn(T, 256, generator=g)
+    d1, d2 = torch.nn.Linear(13, 256).double(), torch.nn.Linear(256, 256).double()
+    d1.load_state_dict({k: v.double() for k, v in lin1.state_dict().items()}); d2.load_state_dict({k: v.double() for k, v in lin2.state_dict().items()})
+    ref = torch.relu(d2(torch.relu(d1(e.double()))))
+    (ref * w.double()).sum().backward()
+    lin1, lin2 = lin1.cuda(), lin2.cuda()
+    out = sim_hidden(e.cuda(), lin1, lin2)
+    assert type(out.grad_fn).__name__.startswith("SimHidden")
+    (out * w.cuda()).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    for a, b in ((lin1.weight, d1.weight), (lin1.bias, d1.bias), (lin2.weight, d2.weight), (lin2.bias, d2.bias)):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 1e-5
