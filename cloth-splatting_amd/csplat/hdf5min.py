@@ -110,7 +110,8 @@ def save(path, arrays):
     for k in names:
         assert len(out) == hdr_at[k]
         space, dtm = headers[k]
-        layout = struct.pack("<BBQQ", 3, 1, data_at[k], arrs[k].nbytes)
+        # (a dataset without elements has no storage: libhdf5 records the undefined address for it)
+        layout = struct.pack("<BBQQ", 3, 1, data_at[k] if arrs[k].nbytes else UNDEF, arrs[k].nbytes)
         fill = struct.pack("<BBBB", 2, 1, 0, 0)                         # v2: early allocation, write at allocation, undefined value
         out += _object_header([_message(0x0001, space), _message(0x0003, dtm, flags=1), _message(0x0005, fill), _message(0x0008, layout)])
     for k in names:

@@ -32,6 +32,17 @@ class GroupedAdam(torch.optim.Adam):
                     return False
         return True
 
+    def state_dict(self):
+        """torch's state dict, with every moment that is a VIEW into a larger buffer (the capacity buffers of csplat/store.py after
+        the first densification) replaced by a compact copy: `torch.save` serialises a tensor's whole storage, i.e. the spare
+        capacity and its stale rows would otherwise travel in every checkpoint (gaussian_model.py:64-75 saves this dict)."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            for k, v in st.items():
+                if torch.is_tensor(v) and v.numel() and v.untyped_storage().nbytes() > v.numel() * v.element_size():
+                    st[k] = v.clone()
+        return sd
+
     def _step_count(self, st):
         """the parameter's step count AFTER this step, as a Python int.  torch keeps it as a CPU tensor in the state (that is what
         state_dict() saves), and reading it back with .item() costs more than the rest of this function: a mirror keyed on the tensor

@@ -86,6 +86,9 @@ def save_gaussians(pc, path):
     except ImportError:
         from . import hdf5min
         hdf5min.save(os.path.join(path, "mesh.hdf5"), mesh)
+        # hdf5min is written from the file-format specification and has never been opened by libhdf5 (neither it nor h5py exists on
+        # this image): the same arrays also go out as `mesh.npz`, which load_gaussians prefers when both are present
+        np.savez(os.path.join(path, "mesh.npz"), **mesh)
 
 
 def load_gaussians(pc, path, device="cuda"):
@@ -108,12 +111,12 @@ def load_gaussians(pc, path, device="cuda"):
     pc.face_ids = torch.tensor(d["id"], dtype=torch.long, device=device)
     pc.face_bary = par(np.stack([d["b1"], d["b2"], d["b3"]], 1))
     pc.face_offset = par(d["o"][:, None])
-    if os.path.exists(os.path.join(path, "mesh.hdf5")):
-        from . import hdf5min
-        mesh = {k: torch.tensor(v, device=device) for k, v in hdf5min.load(os.path.join(path, "mesh.hdf5")).items()}
-    else:
+    if os.path.exists(os.path.join(path, "mesh.npz")):      # written by this library (next to mesh.hdf5 when h5py is absent)
         m = np.load(os.path.join(path, "mesh.npz"))
         mesh = {k: torch.tensor(m[k], device=device) for k in m.files}
+    else:                                                    # a directory saved by the reference: h5py's file
+        from . import hdf5min
+        mesh = {k: torch.tensor(v, device=device) for k, v in hdf5min.load(os.path.join(path, "mesh.hdf5")).items()}
     for k, v in mesh.items():
         setattr(pc.mesh, k, v)
     if getattr(pc.mesh, "edge_index", None) is not None and getattr(pc.mesh, "pos", None) is not None:

@@ -575,6 +575,21 @@ def test_hdf5min_known_answer_structure_and_round_trip(tmp_path):
         off = struct.unpack_from("<Q", raw, snod + 8 + 40 * e)[0]
         names.append(raw[heap_data + off:raw.index(b"\0", heap_data + off)].decode())
     assert names == sorted(arrays)
+    # datatype messages: the byte strings libhdf5 emits for H5T_IEEE_F32LE / H5T_STD_I64LE (HDF5 File Format Specification, IV.A.2.d:
+    # class + version, class bit fields, size; then bit offset / precision (+ exponent location 23, size 8, mantissa location 0, size
+    # 23, bias 127 for the float))
+    assert hdf5min._dtype_message(np.float32) == bytes.fromhex("11201f00040000000000200017080017" "7f000000")
+    assert hdf5min._dtype_message(np.int64) == bytes.fromhex("1008000008000000" "00004000")
+    assert hdf5min._dtype_message(np.float64) == bytes.fromhex("11203f000800000000004000340b0034" "ff030000")
+    # the empty dataset has no storage: its layout message carries the undefined address (as libhdf5 writes it)
+    e_hdr = struct.unpack_from("<Q", raw, snod + 8 + 40 * sorted(arrays).index("empty") + 8)[0]
+    at, found = e_hdr + 16, None
+    for _ in range(struct.unpack_from("<H", raw, e_hdr + 2)[0]):
+        mtype, msize = struct.unpack_from("<HH", raw, at)
+        if mtype == 0x0008:
+            found = struct.unpack_from("<BBQQ", raw, at + 8)
+        at += 8 + msize
+    assert found == (3, 1, 0xFFFFFFFFFFFFFFFF, 0)
     back = hdf5min.load(path, prefer_h5py=False)
     assert set(back) == set(arrays)
     for k, v in arrays.items():
