@@ -8,7 +8,13 @@ TAG=${1:-r01}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
 python3 bench.py                     > "$OUT/bench.json"       2> "$OUT/bench.err"
+# the N > 1 code paths of bench.py as far as ONE GPU allows: two ranks sharing the device, gloo as the transport (FlatGrads, the
+# `collective` object with allreduce_ms / exposed_allreduce_ms) and the scene-parallel mode (6 scenes dealt over 2 ranks)
+CSPLAT_BENCH_BACKEND=gloo timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 10 --warmup 3 > "$OUT/bench_2rank_gloo.json" 2> "$OUT/bench_2rank_gloo.err"
+CSPLAT_BENCH_BACKEND=gloo timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29532 bench.py --gpus 2 --mode scenes --steps 5 --warmup 2 > "$OUT/bench_2rank_scenes.json" 2> "$OUT/bench_2rank_scenes.err"
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w tools/valu_rate.hip -o /tmp/valu_rate && timeout 300 /tmp/valu_rate > "$OUT/valu_rate.txt" 2>&1
 python3 bench_gnn.py                 > "$OUT/bench_gnn.json"   2> /dev/null
 python3 tools/gnn_train_trace.py 10  > "$OUT/gnn_train.txt"    2> /dev/null
 python3 bench_train.py --steps 40 --warmup 5 > "$OUT/bench_train.json" 2> /dev/null

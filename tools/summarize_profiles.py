@@ -23,7 +23,7 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-for f in ("bench.json", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "linear128_train.txt", "dw128.txt", "mfma_rate.txt", "gnn_train.txt"):
+for f in ("bench.json", "bench_2rank_gloo.json", "bench_2rank_scenes.json", "valu_rate.txt", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "linear128_train.txt", "dw128.txt", "mfma_rate.txt", "gnn_train.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
