@@ -26,7 +26,12 @@ def short(name):
 for f in ("bench.json", "bench_2rank_gloo.json", "bench_2rank_scenes.json", "valu_rate.txt", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "linear128_train.txt", "dw128.txt", "mfma_rate.txt", "gnn_train.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
-        shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
+        if f.endswith(".json"):      # keep the JSON line only (the gloo transport prints its own lines on stdout)
+            lines = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]
+            if lines:
+                open(os.path.join(dst, f"{tag}_{f}"), "w").write(lines[-1] + "\n")
+        else:
+            shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
 for sub, out in (("trace", "kernel_stats.csv"), ("trace_serial", "kernel_stats_serial.csv"), ("trace_gnn", "gnn_kernel_stats.csv"),
                  ("trace_train", "train_kernel_stats.csv")):
     hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
