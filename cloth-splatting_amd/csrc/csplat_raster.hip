@@ -1061,7 +1061,9 @@ __global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exac
 // ballot + mbcnt and appended to a small ring in LDS (wave-private); group k is ring[4k .. 4k+3], so row r of the wave reads
 // its survivor with one ds_read_b32.  All counters are wave-uniform (SGPRs); the mask of the next chunk is prefetched.
 constexpr int RING = 128;   // >= 3 groups in flight (12) + one chunk (64) + padding (3)
-struct BlockStream {
+constexpr int RING16 = 256; // groups of sixteen: 3 x 16 in flight + one chunk + padding (15)
+template <int G, int RN>
+struct BlockStreamT {
     const uint16_t *m16;     // the tile's masks (already offset by range.x)
     int *ring;
     int cbase, hi, blk, lane, tail;
@@ -1078,24 +1080,25 @@ struct BlockStream {
         const unsigned long long cur = __ballot(hit);
         if (hit) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u));
-            ring[(tail + rank) & (RING - 1)] = cbase + lane;
+            ring[(tail + rank) & (RN - 1)] = cbase + lane;
         }
         tail += (int)__popcll(cur);
         cbase += 64;
         if ((cbase & (SEG - 1)) == 0 || cbase >= hi) {   // the segment (or the list) ends here: complete the group
-            const int pad = (-tail) & 3;
-            if (lane < pad) ring[(tail + lane) & (RING - 1)] = -1;
+            const int pad = (-tail) & (G - 1);
+            if (lane < pad) ring[(tail + lane) & (RN - 1)] = -1;
             tail += pad;
         }
     }
-    // list position of row r's survivor in group k (-1 = padding); false when the stream ends before group k
-    __device__ __forceinline__ bool group(int k, int r, int &pos) {
-        while (4 * k + 4 > tail && cbase < hi) ingest();
-        if (4 * k >= tail) return false;
-        pos = ring[(4 * k + r) & (RING - 1)];
+    // list position of survivor `slot` of group k (-1 = padding); false when the stream ends before group k
+    __device__ __forceinline__ bool group(int k, int slot, int &pos) {
+        while (G * k + G > tail && cbase < hi) ingest();
+        if (G * k >= tail) return false;
+        pos = ring[(G * k + slot) & (RN - 1)];
         return true;
     }
 };
+typedef BlockStreamT<4, RING> BlockStream;
 
 struct Trip { float4 a, b; float2 c; int pos; };   // the lane's survivor of a group (row r's), pos = list position or -1
 
@@ -1202,6 +1205,198 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
         out_depth[pix] = Dp;
     }
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// One level of a row scan (x[lane] op= x[lane - N] inside every DPP row of 16; lanes without a source keep their value) for FOUR
+// independent registers at once: the four instructions are independent, so three of them cover the two wait states a DPP read
+// needs after a VALU write of the same register (FIRST: the registers were last written by ordinary VALU code -> s_nop 1).
+#define CSPLAT_ROW_SCAN4(OP, N, FIRST, a, b, c, d)                                                                                  \
+    asm(FIRST "v_" OP "_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
+              "v_" OP "_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
+              "v_" OP "_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
+              "v_" OP "_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf"                                               \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void row_scan4_mul(float (&x)[4]) {
+    CSPLAT_ROW_SCAN4("mul", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("mul", 2, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("mul", 4, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("mul", 8, "", x[0], x[1], x[2], x[3]);
+}
+__device__ __forceinline__ void row_scan4_add(float (&x)[4]) {
+    CSPLAT_ROW_SCAN4("add", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("add", 2, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("add", 4, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("add", 8, "", x[0], x[1], x[2], x[3]);
+}
+// ------------------------------------------------------------------------------------------- K6, survivor-column form (round 3)
+// The lane mapping of composite_bwd16_body for the forward: a step takes SIXTEEN consecutive survivors of the block, lane l holds
+// survivor l & 15 and the four pixels of block row l >> 4.  The transmittance of a pixel in front of every survivor is a 4-level
+// row_shr product scan along its DPP row (+ one shift, one row_newbcast) instead of an all-gather of four factors + a row select per
+// group of four, a lane accumulates colour and depth for ITS survivor only (summed over the row's lanes once per tile and at the
+// segment checkpoints), and the serial chain a wave walks -- what bounds this kernel: one wave per block goes through the whole
+// tile list -- is a quarter as many steps long.  The products of a step associate as a scan tree, not front to back: final_T and the
+// alpha / transmittance decisions can differ from a sequential walk in the last bit (the tests hold n_contrib to the oracle up to
+// counted threshold ties and final_T to 1e-4, as they do for v_exp_f32 against expf).  Measured (profiles/r03*): 45 %
+// fewer VALU instructions than the row form (composite_fwd_body) but 96-106 VGPRs against 62, i.e. 4-5 waves per SIMD against 8, and
+// 188-197 us against 182 us for the four views of a step: the ROW FORM STAYS THE DEFAULT, this one is behind csplat_debug_flags bit 15.
+__device__ __forceinline__ void row_scan4_min(float (&x)[4]) {
+    CSPLAT_ROW_SCAN4("min", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("min", 2, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("min", 4, "", x[0], x[1], x[2], x[3]);
+    CSPLAT_ROW_SCAN4("min", 8, "", x[0], x[1], x[2], x[3]);
+}
+// sum over the 16 lanes of every DPP row, result in all of them
+__device__ __forceinline__ float row_total(float v) {
+    v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
+                                                     const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                     const float4 *__restrict__ recB, const float2 *__restrict__ recC,
+                                                     uint32_t null_rec, const float *__restrict__ bg,
+                                                     int *seg_offset, float4 *__restrict__ ckpt,
+                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                     float *__restrict__ out_color, float *__restrict__ out_depth) {
+    __shared__ int s_ring[RING16];
+    const int wg = blockIdx.x;
+    const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
+    if (tile >= tiles) return;
+    const int lane = threadIdx.x, sv = lane & 15, q = lane >> 4;
+    const int px0 = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4;
+    const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + q;
+    const float fy = (float)py;
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    const uint32_t rx = (uint32_t)range.x;
+    bool inside[4], done[4];
+    float T[4], C0[4], C1[4], C2[4], Dp[4], fx[4];
+    uint32_t last[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        inside[j] = px0 + j < W && py < H;
+        done[j] = !inside[j];
+        T[j] = 1.f; C0[j] = C1[j] = C2[j] = Dp[j] = 0.f;      // T: the pixel's (same in its 16 lanes); C*, Dp: this lane's survivors' share
+        last[j] = 0u;
+        fx[j] = (float)(px0 + j);
+    }
+    if (n > 0 && __ballot(!(done[0] && done[1] && done[2] && done[3])) != 0ull) {
+        const int seg0 = seg_offset[tile];
+        BlockStreamT<16, RING16> st;
+        st.start(mask16 + rx, 0, n, blk, lane, s_ring);
+        int seg_written = -1;
+        auto fetch = [&](Trip &t, int k) -> bool {
+            if (!st.group(k, sv, t.pos)) return false;
+            const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
+            t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+            return true;
+        };
+        auto process = [&](const Trip &t) {
+            const int seg = __builtin_amdgcn_readfirstlane(t.pos) / SEG;   // (a group's first entry is never padding)
+            if (seg != seg_written) {
+                // entering a new 256-entry segment: checkpoint (T, colour so far) of every pixel for the depth-split backward, for
+                // every segment start passed since the last one.  The colour so far is spread over the row's lanes: sum it, keep
+                // the total in lane 0 of the row
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float t0 = row_total(C0[j]), t1 = row_total(C1[j]), t2 = row_total(C2[j]);
+                    if (sv == 0)
+                        for (int s_ = seg_written + 1; s_ <= seg; s_++)
+                            ckpt[(size_t)(seg0 + s_) * 256 + blk * 16 + q * 4 + j] = make_float4(T[j], t0, t1, t2);
+                    C0[j] = sv == 0 ? t0 : 0.f; C1[j] = sv == 0 ? t1 : 0.f; C2[j] = sv == 0 ? t2 : 0.f;
+                }
+                seg_written = seg;
+            }
+            const float dy = t.a.y - fy;
+            float al[4], inc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float dx = t.a.x - fx[j];
+                const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
+                const float a = fminf(0.99f, t.b.y * __expf(power));
+                al[j] = (!done[j] && power <= 0.f && a >= ALPHA_MIN) ? a : 0.f;
+                inc[j] = 1.f - al[j];
+            }
+            row_scan4_mul(inc);                                          // the pixel's factor up to and including every survivor
+            float P[4];
+            bool fin = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float Tr = T[j] * dpp_mov<0x111, 0xF>(inc[j], 1.f);        // transmittance in front of the lane's survivor
+                P[j] = T[j] * inc[j];                                            // ... and behind it (what the T test looks at)
+                const bool blend = al[j] > 0.f && P[j] >= T_EPS;
+                const float wgt = blend ? al[j] * Tr : 0.f;
+                C0[j] += t.b.z * wgt; C1[j] += t.b.w * wgt; C2[j] += t.c.x * wgt; Dp[j] += t.c.y * wgt;
+                last[j] = blend ? (uint32_t)(t.pos + 1) : last[j];
+                const float Pend = dpp_mov<0x15F, 0xF>(P[j], P[j]);              // row_newbcast:15: behind the step's last survivor
+                const bool ends = !done[j] && !(Pend >= T_EPS);                  // the pixel's walk ends inside this step
+                fin = fin || ends;
+                if (!ends) T[j] = done[j] ? T[j] : Pend;
+                else P[j] = P[j] >= T_EPS ? P[j] : T[j];                         // candidates for the T it keeps: the last product above
+                done[j] = done[j] || ends;                                       //   the threshold (the products only decrease)
+                if (!ends) P[j] = 3.0e38f;
+            }
+            if (__ballot(fin) != 0ull) {     // rare (once per pixel): the final T of the pixels that ended = the smallest candidate of the row
+                float m[4] = {P[0], P[1], P[2], P[3]};
+                row_scan4_min(m);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float mend = dpp_mov<0x15F, 0xF>(m[j], m[j]);
+                    if (mend < 1.0e38f) T[j] = mend;
+                }
+            }
+        };
+        // software pipeline, two steps in flight (a step is ~16 survivors x 4 pixels of arithmetic: one step ahead covers the fetch)
+        Trip ta, tb;
+        bool va = fetch(ta, 0), vb = fetch(tb, 1);
+        int k = 2;
+        auto all_done = [&]() { return __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull; };
+        while (va) {
+            process(ta);
+            if (all_done()) break;
+            va = fetch(ta, k++);
+            if (!vb) break;
+            process(tb);
+            if (all_done()) break;
+            vb = fetch(tb, k++);
+        }
+    }
+    uint32_t hi_ = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        C0[j] = row_total(C0[j]); C1[j] = row_total(C1[j]); C2[j] = row_total(C2[j]); Dp[j] = row_total(Dp[j]);
+        uint32_t m = last[j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        last[j] = m;
+        hi_ = max(hi_, inside[j] ? m : 0u);
+    }
+    {   // the block's largest n_contrib, for K7's workgroups (seg_offset[tiles + 1 ...] = blk_hi[tile][blk])
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) hi_ = max(hi_, (uint32_t)__shfl_xor((int)hi_, o, 64));
+        if (lane == 0) reinterpret_cast<uint32_t *>(seg_offset)[tiles + 1 + tile * 16 + blk] = hi_;
+    }
+    if (sv < 4) {   // lane j of every row writes pixel j of that row
+        const size_t HW = (size_t)H * W;
+        float t_ = T[0], c0 = C0[0], c1 = C1[0], c2 = C2[0], dp = Dp[0];
+        uint32_t la = last[0];
+        bool in_ = inside[0];
+#pragma unroll
+        for (int j = 1; j < 4; j++)
+            if (sv == j) { t_ = T[j]; c0 = C0[j]; c1 = C1[j]; c2 = C2[j]; dp = Dp[j]; la = last[j]; in_ = inside[j]; }
+        if (in_) {
+            const int pix = py * W + px0 + sv;
+            final_T[pix] = t_;
+            n_contrib[pix] = la;
+            out_color[pix] = c0 + t_ * bg[0];
+            out_color[HW + pix] = c1 + t_ * bg[1];
+            out_color[2 * HW + pix] = c2 + t_ * bg[2];
+            out_depth[pix] = dp;
+        }
+    }
+}
+template <bool ROWS>
 __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
                                                        const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
                                                        const float4 *__restrict__ recB, const float2 *__restrict__ recC,
@@ -1209,14 +1404,23 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
                                                        int *seg_offset, float4 *__restrict__ ckpt,
                                                        float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                        float *__restrict__ out_color, float *__restrict__ out_depth) {
-    composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
-                       out_depth);
+    if (ROWS)
+        composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
+                           out_depth);
+    else
+        composite_fwd16_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
+                             out_depth);
 }
+template <bool ROWS>
 __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
-    composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                       w.n_contrib, w.out_color, w.out_depth);
+    if (ROWS)
+        composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                           w.n_contrib, w.out_color, w.out_depth);
+    else
+        composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                             w.n_contrib, w.out_color, w.out_depth);
 }
 
 // ------------------------------------------------------------------------------------------- K7
@@ -1224,10 +1428,6 @@ __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, in
 //   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..15 pad
 constexpr int ACC_STRIDE = 16;
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
 // one level of a butterfly "transpose-reduce": lanes with s == 0 keep a (own + partner's), lanes with s == 1 keep b;
 // the partner permutation CTRL must flip s.  Two values are folded by one DPP add instead of two.
 template <int CTRL>
@@ -1420,27 +1620,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
 //   * K7 never tests T against a threshold (activity = list position < n_contrib, alpha from the same expression as K6), so the
 //     scan's association of the products is free to differ from the forward's sequential one (gradients are held to 1e-4).
 // The block's survivors of the 256-entry segment are compacted into an LDS ring once (<= 256 positions), then walked in steps.
-// One level of a row scan (x[lane] op= x[lane - N] inside every DPP row of 16; lanes without a source keep their value) for FOUR
-// independent registers at once: the four instructions are independent, so three of them cover the two wait states a DPP read
-// needs after a VALU write of the same register (FIRST: the registers were last written by ordinary VALU code -> s_nop 1).
-#define CSPLAT_ROW_SCAN4(OP, N, FIRST, a, b, c, d)                                                                                  \
-    asm(FIRST "v_" OP "_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
-              "v_" OP "_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
-              "v_" OP "_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"                                          \
-              "v_" OP "_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf"                                               \
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-__device__ __forceinline__ void row_scan4_mul(float (&x)[4]) {
-    CSPLAT_ROW_SCAN4("mul", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
-    CSPLAT_ROW_SCAN4("mul", 2, "", x[0], x[1], x[2], x[3]);
-    CSPLAT_ROW_SCAN4("mul", 4, "", x[0], x[1], x[2], x[3]);
-    CSPLAT_ROW_SCAN4("mul", 8, "", x[0], x[1], x[2], x[3]);
-}
-__device__ __forceinline__ void row_scan4_add(float (&x)[4]) {
-    CSPLAT_ROW_SCAN4("add", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
-    CSPLAT_ROW_SCAN4("add", 2, "", x[0], x[1], x[2], x[3]);
-    CSPLAT_ROW_SCAN4("add", 4, "", x[0], x[1], x[2], x[3]);
-    CSPLAT_ROW_SCAN4("add", 8, "", x[0], x[1], x[2], x[3]);
-}
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // TILEWISE = false: one workgroup per (256-entry segment, quadrant), restarted from K6's checkpoint (the depth-split form: the
@@ -2420,7 +2599,8 @@ bool mail_init() {
 // bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics);
 // bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
 // bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook); bit 13 K7 in the survivor-column form
-// (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant)
+// (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant);
+// bit 15 K6 in the survivor-column form (16 survivors per step, DPP row scans; products associate as a scan tree)
 unsigned g_debug_flags = 0;
 
 // `mode` argument of the tile sort kernels: bit 0 ids < 2^24, bit 1 radix only, bit 2 fallback limit 1
@@ -2779,7 +2959,8 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         {
             ProfScope ps(PROF_K6, join);
-            k_composite_fwd_views<<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
+            if (g_debug_flags & 32768u) k_composite_fwd_views<false><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
+            else k_composite_fwd_views<true><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
             LAUNCH_CHECK();
         }
         return 0;
@@ -2943,8 +3124,12 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     }
     {
         ProfScope ps(PROF_K6, s);
-        k_composite_fwd<<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
-                                                            final_T, n_contrib, out_color, out_depth);
+        if (!(g_debug_flags & 32768u))
+            k_composite_fwd<true><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
+                                                                      final_T, n_contrib, out_color, out_depth);
+        else
+            k_composite_fwd<false><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
+                                                                       final_T, n_contrib, out_color, out_depth);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
