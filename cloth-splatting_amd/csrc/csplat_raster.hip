@@ -1482,10 +1482,21 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                                                    const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
-                                                   float *__restrict__ acc, float *__restrict__ det) {
+                                                   float *__restrict__ acc, float *__restrict__ det,
+                                                   unsigned long long *stamp = nullptr) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING];
     const int wg = blockIdx.x;
+    // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
+    unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 : nullptr;
+    auto mark = [&](int k) {
+        if (my_stamp && threadIdx.x == 0) {
+            asm volatile("" ::: "memory");
+            my_stamp[k] = (unsigned long long)__builtin_amdgcn_s_memtime();
+            asm volatile("" ::: "memory");
+        }
+    };
+    mark(0);
     const int slot = ((wg >> 5) << 3) + (wg & 7), quad = (wg >> 3) & 3;     // the 4 quadrants of a slot share blockIdx % 8
     if (slot >= seg_offset[tiles]) return;
     const int tile = slot_tile[slot];
@@ -1507,9 +1518,11 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);
     if ((int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])) <= seg_lo) return;   // (workgroup-uniform)
     const int wave_hi = min(seg_hi, (int)blk_hi[blk]);                  // no pixel of the block blends an entry at or behind it
+    mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi) has returned
     const int ncontrib = inside ? (int)n_contrib[pix] : 0;
     for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
     __syncthreads();
+    mark(2);
     float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
     if (wave_hi > seg_lo) {
         const size_t HW = (size_t)H * W;
@@ -1521,6 +1534,8 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             T = ck.x;
             S = ck.y * dp0 + ck.z * dp1 + ck.w * dp2;
         }
+        if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(S), "v"(T)); }
+        mark(3);                                                        // the pixel constants and the checkpoint have arrived
         const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
         const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
@@ -1588,6 +1603,8 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         Trip ta, tb, tc;
         bool va = fetch(ta, 0), vb = fetch(tb, 1), vc = fetch(tc, 2);
         int k = 3;
+        if (my_stamp && threadIdx.x == 0 && va) { asm volatile("" :: "v"(ta.a.x), "v"(ta.c.x)); }
+        mark(4);                                                        // masks -> ring -> the first group's records have arrived
         while (va) {
             process(ta);
             va = fetch(ta, k++);
@@ -1599,9 +1616,13 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             vc = fetch(tc, k++);
         }
     }
+    mark(5);                                                            // this wave's groups are done
     __syncthreads();
+    mark(6);                                                            // ... and the other three waves' too
     // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
     flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
+    mark(7);
+    if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)(wave_hi > seg_lo ? wave_hi - seg_lo : 0); my_stamp[9] = 1ull; }
 }
 
 // ------------------------------------------------------------------------------------------- K7, survivor-column form (round 3)
@@ -1886,7 +1907,7 @@ struct B2View {
     float *acc;
     uint32_t R;
 };
-struct B2Table { B2View v[B2_MAX_VIEWS]; };
+struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; };
 __global__ __launch_bounds__(256) void k_composite_bwd_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd16_body<false, true>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
@@ -1900,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_seg_views(int tiles, int 
 __global__ __launch_bounds__(256) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
-                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
+                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp);
 }
 __global__ __launch_bounds__(256) void k_zero_acc_views(int64_t n4, B2Table tab) {
     float4 *p = reinterpret_cast<float4 *>(tab.v[blockIdx.y].acc);
@@ -2602,6 +2623,8 @@ bool mail_init() {
 // (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant);
 // bit 15 K6 in the survivor-column form (16 survivors per step, DPP row scans; products associate as a scan tree)
 unsigned g_debug_flags = 0;
+unsigned long long *g_stamp_buf = nullptr;     // csplat_debug_stamps: 12 u64 per K7 workgroup (rows form, batched launch)
+size_t g_stamp_words = 0;
 
 // `mode` argument of the tile sort kernels: bit 0 ids < 2^24, bit 1 radix only, bit 2 fallback limit 1
 int tsort_mode(int P) { return (P < (1 << 24) ? 1 : 0) | ((g_debug_flags & 2048u) ? 2 : 0) | ((g_debug_flags & 4096u) ? 4 : 0); }
@@ -2630,6 +2653,9 @@ extern "C" {
 
 int csplat_abi_version(void) { return CSPLAT_ABI_VERSION; }
 int csplat_debug_flags(unsigned flags) { g_debug_flags = flags; return 0; }
+// measurement hook: a device buffer that the batched row-form K7 fills with s_memtime stamps (12 u64 per workgroup, launch order
+// [view][workgroup]); NULL switches it off.  Not part of the operator interface.
+int csplat_debug_stamps(void *buf, size_t bytes) { g_stamp_buf = (unsigned long long *)buf; g_stamp_words = bytes / 8; return 0; }
 const char *csplat_last_error(void) { return g_csplat_err; }
 
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }
@@ -3422,6 +3448,10 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)Rl;
                 const int64_t sl = max_slots(Rl, tiles);
                 slots = sl > slots ? sl : slots;
+            }
+            {   // (measurement hook, off unless csplat_debug_stamps handed over a buffer large enough for this launch)
+                const size_t need = (size_t)V * ((size_t)cdiv(slots, 8) * 32u) * 12;
+                bt.stamp = (g_stamp_buf && g_stamp_words >= need) ? g_stamp_buf : nullptr;
             }
             ProfScope ps(PROF_K7, join);
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;

@@ -58,6 +58,9 @@ int csplat_abi_version(void);
  * bit 10: csplat_forward_views always waits for a call's counts before launching its second phase (no speculative launch with
  * the previous call's counts as capacities). */
 int csplat_debug_flags(unsigned flags);
+/* measurement hook (not part of the operator interface): a device buffer the batched compositing backward fills with s_memtime stamps,
+ * 12 uint64 per workgroup in launch order [view][workgroup] (tools/k7_stamps.py); NULL / 0 switches it off */
+int csplat_debug_stamps(void *device_buffer, size_t bytes);
 const char *csplat_last_error(void);
 
 /* Sizes of the chunks (bytes) so that a caller may pre-allocate instead of answering the callback lazily. */
