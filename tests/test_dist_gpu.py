@@ -96,7 +96,13 @@ def test_view_parallel_hip_train_step_two_ranks_one_gpu(tmp_path):
         assert abs(float(r0[f"psnr{it}"]) - ref[f"psnr{it}"]) < 1e-3
         assert abs(float(r0[f"loss{it}"]) - ref[f"loss{it}"]) < 1e-5 * max(abs(ref[f"loss{it}"]), 1.0)
         np.testing.assert_array_equal(r0[f"radii{it}"], ref[f"radii{it}"])
-        assert rel_err(r0[f"vsg{it}"], ref[f"vsg{it}"]) < 1e-4
+        if it == 1:      # identical parameters on both sides: only the order of the sums over cameras differs
+            assert rel_err(r0[f"vsg{it}"], ref[f"vsg{it}"]) < 1e-4
+        else:            # after an Adam step the parameters agree to rounding only (below): a compositing threshold (alpha < 1/255,
+            #              T < 1e-4) may fall on the other side at an isolated pixel -> a few Gaussians move by O(alpha); counted, bounded
+            a, b = np.asarray(r0[f"vsg{it}"], np.float64), np.asarray(ref[f"vsg{it}"], np.float64)
+            d = np.abs(a - b).max(1) / (np.abs(b).max() + 1e-30)
+            assert (d > 1e-4).sum() <= max(2, 1e-3 * len(d)) and d.max() < 2e-2, (int((d > 1e-4).sum()), float(d.max()))
     # parameters after two Adam steps: entries whose gradient is at rounding level can flip sign between the summation orders
     # (Adam's first steps move every entry by ~lr), so compare against the step size
     for k in r0.files:
