@@ -1483,9 +1483,10 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
                                                    float *__restrict__ acc, float *__restrict__ det,
-                                                   unsigned long long *stamp = nullptr) {
+                                                   unsigned long long *stamp = nullptr, int barrier_flush = 0) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING];
+    __shared__ int s_done;
     const int wg = blockIdx.x;
     // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
     unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 : nullptr;
@@ -1521,6 +1522,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi) has returned
     const int ncontrib = inside ? (int)n_contrib[pix] : 0;
     for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
+    if (threadIdx.x == 0) s_done = 0;
     __syncthreads();
     mark(2);
     float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
@@ -1617,10 +1619,27 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         }
     }
     mark(5);                                                            // this wave's groups are done
-    __syncthreads();
-    mark(6);                                                            // ... and the other three waves' too
-    // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
-    flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
+    if (barrier_flush) {      // (default: all four waves meet at a barrier and flush a quarter each)
+        __syncthreads();
+        mark(6);
+        // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
+        flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
+    } else {
+        // csplat_debug_flags bit 16 (an experiment that did NOT pay, kept for A/B): no barrier at the end.  The blocks of a quadrant
+        // finish ~10 k cycles apart (tools/k7_stamps.py: a quarter of a live wave's life is this wait) -- here a wave that is done
+        // publishes its LDS adds, counts itself out and RETIRES; the wave that counts last flushes the whole segment (four passes of the
+        // same rounds).  Same-box A/B, three alternations: 318-321 us against 308-312 us with the barrier -- the lone flusher's four
+        // round trips outlast what the retired waves' slots are worth (a new workgroup needs four of them at once).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int last = 0;
+        if (lane == 0) last = atomicAdd(&s_done, 1) == 3;
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (!last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        mark(6);
+        for (int vw = 0; vw < 4; vw++)
+            flush_segment<DET>(s_acc, seg_hi - seg_lo, vw, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
+    }
     mark(7);
     if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)(wave_hi > seg_lo ? wave_hi - seg_lo : 0); my_stamp[9] = 1ull; }
 }
@@ -1886,9 +1905,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd_rows(int tiles, int W, in
                                                              const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
                                                              const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                              const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
-                                                             float *__restrict__ acc, float *__restrict__ det) {
+                                                             float *__restrict__ acc, float *__restrict__ det, int barrier_flush) {
     composite_bwd_body<DET>(tiles, W, H, gx, ranges, ids_sorted, mask16, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
-                            n_contrib, out_color, dL_dpix, acc, det);
+                            n_contrib, out_color, dL_dpix, acc, det, nullptr, barrier_flush);
 }
 
 // K7 for ALL views of a step in one launch (blockIdx.y = view), preceded by one launch that clears every view's records
@@ -1907,7 +1926,7 @@ struct B2View {
     float *acc;
     uint32_t R;
 };
-struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; };
+struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; int barrier_flush; };
 __global__ __launch_bounds__(256) void k_composite_bwd_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd16_body<false, true>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
@@ -1921,7 +1940,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_seg_views(int tiles, int 
 __global__ __launch_bounds__(256) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
-                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp);
+                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp, tab.barrier_flush);
 }
 __global__ __launch_bounds__(256) void k_zero_acc_views(int64_t n4, B2Table tab) {
     float4 *p = reinterpret_cast<float4 *>(tab.v[blockIdx.y].acc);
@@ -2621,7 +2640,8 @@ bool mail_init() {
 // bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
 // bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook); bit 13 K7 in the survivor-column form
 // (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant);
-// bit 15 K6 in the survivor-column form (16 survivors per step, DPP row scans; products associate as a scan tree)
+// bit 15 K6 in the survivor-column form (16 survivors per step, DPP row scans; products associate as a scan tree); bit 16 K7 (row
+// form) retires the waves that are done and lets the last one flush, instead of the barrier + four-wave flush
 unsigned g_debug_flags = 0;
 unsigned long long *g_stamp_buf = nullptr;     // csplat_debug_stamps: 12 u64 per K7 workgroup (rows form, batched launch)
 size_t g_stamp_words = 0;
@@ -3219,13 +3239,15 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with
             const bool rows = (g_debug_flags & (8192u | 16384u)) == 0;     // default: the row form; bits 13 / 14: the survivor-column form
             if (det_mode && rows)
                 k_composite_bwd_rows<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
-                                                                seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+                                                                seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det,
+                                                                (g_debug_flags & 65536u) ? 0 : 1);
             else if (det_mode)
                 k_composite_bwd<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
                                                            seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
             else if (rows)
                 k_composite_bwd_rows<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
-                                                                 seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+                                                                 seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det,
+                                                                 (g_debug_flags & 65536u) ? 0 : 1);
             else
                 k_composite_bwd<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
                                                             seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
@@ -3452,6 +3474,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             {   // (measurement hook, off unless csplat_debug_stamps handed over a buffer large enough for this launch)
                 const size_t need = (size_t)V * ((size_t)cdiv(slots, 8) * 32u) * 12;
                 bt.stamp = (g_stamp_buf && g_stamp_words >= need) ? g_stamp_buf : nullptr;
+                bt.barrier_flush = (g_debug_flags & 65536u) ? 0 : 1;
             }
             ProfScope ps(PROF_K7, join);
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
