@@ -564,9 +564,14 @@ struct P2View {
 };
 struct P2Table { P2View v[P2_MAX_VIEWS]; };
 __device__ __forceinline__ bool p2_live(const P2View &w) { return !w.spec || (w.info[0] - 1u < w.R && w.info[1] <= w.Lcap); }
+__device__ __forceinline__ void seg_plan_body(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
+                                              int *__restrict__ slot_tile);
+// (the LAST workgroup of every view does not emit: it lays out the view's 256-entry segments -- the former k_seg_plan launch; both only
+// need the tile ranges)
 __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket_views(int P, int tiles, P2Table tab) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
+    if (blockIdx.x == gridDim.x - 1) { seg_plan_body(tiles, w.ranges, w.seg_offset, w.slot_tile); return; }
     emit_bucket_body(P, tiles, w.g.xy, w.g.depth, w.radii, w.cam, w.table, w.ranges, w.keys_u);
 }
 
@@ -2987,7 +2992,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         {
             ProfScope ps(PROF_K3, join);
-            k_emit_bucket_views<<<dim3(nb, V), BUCKET_G, (size_t)tiles * 4, join>>>(P, tiles, tab);
+            k_emit_bucket_views<<<dim3(nb + 1, V), BUCKET_G, (size_t)tiles * 4, join>>>(P, tiles, tab);
             LAUNCH_CHECK();
         }
         {
@@ -2998,8 +3003,6 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         {
             ProfScope ps(PROF_K5, join);
-            k_seg_plan_views<<<V, 1024, 0, join>>>(tiles, tab);
-            LAUNCH_CHECK();
             k_block_masks_views<<<dim3(cdiv((int64_t)maxR + 1, 256), V), 256, 0, join>>>(tab, (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
             LAUNCH_CHECK();
         }
