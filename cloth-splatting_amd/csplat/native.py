@@ -66,7 +66,8 @@ EXPORTS = {
     "csplat_psnr_scratch_bytes": (_sz, [_i64]),
     "csplat_psnr": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "csplat_sim_hidden_fwd": (_i, [_vp, _i, _i] + [_vp] * 7),
-    "csplat_sim_hidden_bwd": (_i, [_vp, _i, _i] + [_vp] * 9),
+    "csplat_sim_hidden_bwd": (_i, [_vp, _i, _i] + [_vp] * 10),
+    "csplat_sim_hidden_scratch_bytes": (_sz, [_i]),
     "csplat_rows_dot_scratch_bytes": (_sz, [_i]),
     "csplat_cloth_regs_scratch_bytes": (_sz, [_i, _i, _i64]),
     "csplat_cloth_regs": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -367,48 +367,72 @@ __global__ __launch_bounds__(SIM_H) void k_sim_hidden_fwd(int K0, const float *_
     for (int t = 0; t < T; t++) h2[t * SIM_H + j] = fmaxf(o[t], 0.f);
 }
 
+constexpr int SIM_BWD_WGS = 16;           // workgroups of the backward: 16 rows of W2 / dW2 each
 template <int T>
 __global__ __launch_bounds__(SIM_H) void k_sim_hidden_bwd(int K0, const float *__restrict__ e, const float *__restrict__ W2,
                                                           const float *__restrict__ h1, const float *__restrict__ h2,
                                                           const float *__restrict__ dh2, float *__restrict__ dW1, float *__restrict__ db1,
-                                                          float *__restrict__ dW2, float *__restrict__ db2) {
-    __shared__ float s_dz2[T][SIM_H];
-    const int k = threadIdx.x;
+                                                          float *__restrict__ dW2, float *__restrict__ db2,
+                                                          float *__restrict__ part, unsigned *__restrict__ ticket) {
+    // workgroup g owns rows j = 16 g .. 16 g + 15 of W2: their dW2 rows and db2 entries are complete here; its share of
+    // dh1[t][k] = sum_j W2[j][k] dz2[t][j] goes to part[g][t][k], and the workgroup that finishes LAST (ticket) adds the 16 shares in index
+    // order (deterministic) and does the first layer (one workgroup took 34 us for the whole thing: a 256-iteration chain of row loads)
+    __shared__ float s_dz2[T][SIM_H / SIM_BWD_WGS];
+    __shared__ bool s_last;
+    const int k = threadIdx.x, g = blockIdx.x;
+    constexpr int RW = SIM_H / SIM_BWD_WGS;
     float x1[T], d1[T];
-    float sb = 0.f;
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-        const float dz = h2[t * SIM_H + k] > 0.f ? dh2[t * SIM_H + k] : 0.f;
-        s_dz2[t][k] = dz;
-        sb += dz;
-        x1[t] = h1[t * SIM_H + k];
-        d1[t] = 0.f;
-    }
-    db2[k] = sb;
-    __syncthreads();
-    // row j of W2 / dW2 at a time: every access is one coalesced 1 KB row, dz2[.][j] is a broadcast
-#pragma unroll 4
-    for (int j = 0; j < SIM_H; j++) {
-        const float w = W2[(size_t)j * SIM_H + k];
-        float g = 0.f;
+    for (int t = 0; t < T; t++) { x1[t] = h1[t * SIM_H + k]; d1[t] = 0.f; }
+    if (k < RW) {
+        const int j = g * RW + k;
+        float sb = 0.f;
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            const float dz = s_dz2[t][j];
-            g += dz * x1[t];
-            d1[t] += w * dz;
+            const float dz = h2[t * SIM_H + j] > 0.f ? dh2[t * SIM_H + j] : 0.f;
+            s_dz2[t][k] = dz;
+            sb += dz;
         }
-        dW2[(size_t)j * SIM_H + k] = g;
+        db2[j] = sb;
     }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < RW; jj++) {
+        const int j = g * RW + jj;
+        const float w = W2[(size_t)j * SIM_H + k];
+        float gsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const float dz = s_dz2[t][jj];
+            gsum = __fmaf_rn(dz, x1[t], gsum);
+            d1[t] = __fmaf_rn(w, dz, d1[t]);
+        }
+        dW2[(size_t)j * SIM_H + k] = gsum;
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) part[((size_t)g * T + t) * SIM_H + k] = d1[t];
+    __threadfence();
+    __syncthreads();
+    if (k == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     float sb1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < T; t++) { d1[t] = x1[t] > 0.f ? d1[t] : 0.f; sb1 += d1[t]; }
+    for (int t = 0; t < T; t++) {
+        float a = 0.f;
+        for (int gg = 0; gg < SIM_BWD_WGS; gg++) a += __builtin_nontemporal_load(part + ((size_t)gg * T + t) * SIM_H + k);
+        d1[t] = x1[t] > 0.f ? a : 0.f;
+        sb1 += d1[t];
+    }
     db1[k] = sb1;
     for (int c = 0; c < K0; c++) {
-        float g = 0.f;
+        float gsum = 0.f;
 #pragma unroll
-        for (int t = 0; t < T; t++) g += d1[t] * e[t * K0 + c];
-        dW1[k * K0 + c] = g;
+        for (int t = 0; t < T; t++) gsum = __fmaf_rn(d1[t], e[t * K0 + c], gsum);
+        dW1[k * K0 + c] = gsum;
     }
+    if (k == 0) *ticket = 0u;          // (left at zero for the next call on this scratch)
 }
 
 }  // namespace
@@ -516,12 +540,15 @@ int csplat_sim_hidden_fwd(void *stream, int T, int K0, const float *e, const flo
     LAUNCH_CHECK();
     return 0;
 }
+size_t csplat_sim_hidden_scratch_bytes(int T) { return ((size_t)SIM_BWD_WGS * (size_t)(T > 0 ? T : 1) * SIM_H + 64) * 4; }
 int csplat_sim_hidden_bwd(void *stream, int T, int K0, const float *e, const float *W2, const float *h1, const float *h2, const float *dh2,
-                          float *dW1, float *db1, float *dW2, float *db2) {
+                          float *dW1, float *db1, float *dW2, float *db2, void *scratch) {
     CSPLAT_REQUIRE(T >= 1 && T <= SIM_TMAX && K0 >= 1 && K0 <= SIM_K0MAX, "csplat_sim_hidden_bwd: 1 <= T <= 8 time rows, 1 <= K0 <= 16 inputs");
-    CSPLAT_REQUIRE(e && W2 && h1 && h2 && dh2 && dW1 && db1 && dW2 && db2, "csplat_sim_hidden_bwd: bad arguments");
+    CSPLAT_REQUIRE(e && W2 && h1 && h2 && dh2 && dW1 && db1 && dW2 && db2 && scratch, "csplat_sim_hidden_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-#define CSPLAT_SIMH(TT) case TT: k_sim_hidden_bwd<TT><<<1, SIM_H, 0, s>>>(K0, e, W2, h1, h2, dh2, dW1, db1, dW2, db2); break;
+    unsigned *ticket = (unsigned *)scratch;                 // first word: zero on entry, left at zero
+    float *part = (float *)scratch + 64;
+#define CSPLAT_SIMH(TT) case TT: k_sim_hidden_bwd<TT><<<SIM_BWD_WGS, SIM_H, 0, s>>>(K0, e, W2, h1, h2, dh2, dW1, db1, dW2, db2, part, ticket); break;
     switch (T) { CSPLAT_SIMH(1) CSPLAT_SIMH(2) CSPLAT_SIMH(3) CSPLAT_SIMH(4) CSPLAT_SIMH(5) CSPLAT_SIMH(6) CSPLAT_SIMH(7) CSPLAT_SIMH(8) }
 #undef CSPLAT_SIMH
     LAUNCH_CHECK();

@@ -151,6 +151,9 @@ class RowsDot(torch.autograd.Function):
         return dh, dW, db
 
 
+_SIMH_SCRATCH = {}
+
+
 class SimHidden(torch.autograd.Function):
     """relu(Linear(K0, 256)) -> relu(Linear(256, 256)) of the time-conditioned simulator (meshnet_network.py:337-338,364-366) for the
     T <= 8 time rows of a step: csplat_sim_hidden_fwd / _bwd, one launch each way instead of ~20 torch launches."""
@@ -177,8 +180,12 @@ class SimHidden(torch.autograd.Function):
         dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
         db = torch.empty(2, 256, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+            scratch = _SIMH_SCRATCH.get(key)        # zeroed once per stream: the kernel leaves its ticket word at zero
+            if scratch is None:
+                scratch = _SIMH_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_sim_hidden_scratch_bytes(8)) // 4, dtype=torch.int32, device=dev)
             _n.check(_n.lib.csplat_sim_hidden_bwd(_n.stream_handle(dev), T, K0, _n.ptr(e), _n.ptr(W2), _n.ptr(h1), _n.ptr(h2), _n.ptr(g),
-                                                  _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1])), "csplat_sim_hidden_bwd")
+                                                  _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1]), _n.ptr(scratch)), "csplat_sim_hidden_bwd")
         return None, dW1, db[0], dW2, db[1]
 
 

@@ -208,8 +208,11 @@ int csplat_rows_scatter(void *stream, int n_tensors, const void *const *src, voi
  *   backward: from dh2 = dL/dh2 [T][256]: dW1 [256][K0], db1 [256], dW2 [256][256], db2 [256]   (e has no gradient: parameter-free code) */
 int csplat_sim_hidden_fwd(void *stream, int T, int K0, const float *e, const float *W1, const float *b1, const float *W2, const float *b2,
                           float *h1, float *h2);
+/* scratch: csplat_sim_hidden_scratch_bytes(T) bytes whose first word is zero on entry (the kernel leaves it zero), not shared between
+ * calls that may run concurrently */
+size_t csplat_sim_hidden_scratch_bytes(int T);
 int csplat_sim_hidden_bwd(void *stream, int T, int K0, const float *e, const float *W2, const float *h1, const float *h2, const float *dh2,
-                          float *dW1, float *db1, float *dW2, float *db2);
+                          float *dW1, float *db1, float *dW2, float *db2, void *scratch);
 size_t csplat_rows_dot_scratch_bytes(int T);
 int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y);
 int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const float *h, const float *dy, float *dW, float *db,
