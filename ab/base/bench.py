@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on synthetic scene_1: rendered Mpix/s of the rasterizer hot path, forward +
+backward, P = 100k Gaussians, 4 cameras 800x800 per GPU (BASELINE.json configs[1]).
+
+A "step" = one pass of the hot path over one batch: for each of the rank's 4 views, GaussianRasterizer forward
+(K1..K6), L1 loss against a fixed target image, backward (K7, K8); with N > 1 ranks (view-parallel, one process per
+GPU) the step ends with ONE RCCL all-reduce of the flat per-Gaussian gradient buffer the `.grad` tensors are views of
+(csplat.dist.FlatGrads).  All inputs are resident in HBM before the timed region.  Prints ONE JSON line on
+rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+--mode scenes (BASELINE configs[4], scene-parallel): six seeded scene variants, scene s on rank s mod N, no collective
+(replicas only); `value` = all scenes' rendered Mpix over the slowest rank's time, "scaling": "strong".
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+
+
+def cpu_baseline(scene, cams, P, W, H):
+    """Oracle (C restatement, OpenMP) timed on the host cores: ONE step (all views, fwd+bwd) of the same workload."""
+    from csplat import synthetic as syn
+    from oracle import raster_oracle as ro
+    ro.build()
+    g = syn.gaussians_at(scene)
+    rng = np.random.default_rng(0)
+    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    t0 = time.perf_counter()
+    for cam in cams:
+        o = ro.forward(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
+                       cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H, scene["bg"], shs=g["shs"],
+                       sh_degree=3, scales=g["scales"], rotations=g["rotations"])
+        ro.backward(o, dpix)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(cams) * W * H / 1e6 / dt, 4), "unit": "Mpix/s", "cores": int(ro.num_threads()),
+            "kind": "port",
+            "what": "C/OpenMP restatement of the upstream algorithm (oracle/raster_ref.c); the reference ships no CPU rasterizer "
+                    "and no PyTorch-CPU path exists for this operator (SURVEY F2)",
+            "sample": f"one full step: {len(cams)} views {W}x{H}, P={P}, fwd+bwd through oracle/raster_ref.c "
+                      f"(OpenMP, fp32), {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--P", type=int, default=100_000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
+    ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
+                    help="run the views of a step back to back on one stream instead of one HIP stream per view")
+    ap.add_argument("--mode", choices=("views", "scenes"), default="views",
+                    help="views: view-parallel weak scaling (default, the BASELINE metric); scenes: 6 scene variants dealt over the ranks")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as FRESH children (this process has not touched the GPU: importing
+        # torch does not initialise it) and pass their exit code on -- one rank per GPU, exactly what the driver's torchrun line does
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 ranks as\n  python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus {args.gpus} ...")
+    # (CSPLAT_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box: ranks then share the device)
+    backend = os.environ.get("CSPLAT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    from csplat import native, synthetic as syn
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    P, W, H, V = args.P, args.res, args.res, args.views
+    from csplat import dist as cd
+    from csplat.train import l1_loss
+    from diff_gaussian_rasterization import rasterize_views
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)  # noqa: E731
+
+    class Workload:
+        """one scene replica: Gaussians, V cameras, target images, and step() = fwd + L1 + bwd (+ the all-reduce)"""
+
+        def __init__(self, seed, cam_phase, reduce_over_ranks):
+            self.scene = syn.scene_1(P=P, W=W, H=H, n_cams=V, seed=seed)
+            # view-parallel: rank r renders its own V cameras (azimuth offset), Gaussians replicated
+            self.cams = [syn.make_camera(-180.0 + 360.0 * (k + cam_phase) / V, W, H) for k in range(V)]
+            g = syn.gaussians_at(self.scene)
+            self.names = ("means3D", "opacities", "shs", "scales", "rotations")
+            self.params = {k: T(g[k], True) for k in self.names}
+            bg = T(self.scene["bg"])
+            self.settings = [GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+                viewmatrix=T(c["world_view_transform"]), projmatrix=T(c["full_proj_transform"]), sh_degree=3,
+                campos=T(c["camera_center"]), prefiltered=False, debug=False) for c in self.cams]
+            # target images = render of a perturbed copy (so the loss and its gradient are non-trivial)
+            with torch.no_grad():
+                keep = {k: v.detach().clone() for k, v in self.params.items()}
+                gen = torch.Generator(device=dev).manual_seed(1234)
+                self.params["shs"].add_(0.2 * torch.randn(self.params["shs"].shape, device=dev, generator=gen))
+                self.params["means3D"].add_(0.003 * torch.randn(self.params["means3D"].shape, device=dev, generator=gen))
+                self.targets = [self.render(i, torch.zeros(P, 3, device=dev))[0].clone() for i in range(V)]
+                for k, v in keep.items():
+                    self.params[k].copy_(v)
+            self.targets_stacked = torch.stack(self.targets).contiguous()
+            self.zeros = torch.zeros(V, P, 3, device=dev)
+            self.one = torch.ones((), device=dev)
+            # N > 1: every gradient of the step is a view into ONE flat buffer (+ 3P floats for the summed screen-space
+            # gradient that densification consumes) and the step ends with one all-reduce of it -- no cat, no copy back
+            self.fg = cd.FlatGrads([self.params[k] for k in self.names], extra=3 * P) if reduce_over_ranks else None
+
+        def render(self, i, means2D):
+            pr = self.params
+            return GaussianRasterizer(self.settings[i])(means3D=pr["means3D"], means2D=means2D, opacities=pr["opacities"],
+                                                        shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
+
+        def step(self, timed_allreduce=False, skip_allreduce=False):
+            pr = self.params
+            if self.fg is not None:
+                self.fg.bind()
+            else:
+                for p_ in pr.values():
+                    p_.grad = None
+            # the screen-space leaves: V detached views of ONE zero buffer that nothing ever writes into (the rasterizer reads no value
+            # of means2D, it returns its gradient) -- resident like every other input, no fill launch per step
+            m2ds = [self.zeros[i].detach().requires_grad_() for i in range(V)]
+            # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views): the first phase of
+            # all views goes out in four launches, then every view's binning / compositing kernels overlap on the chip
+            if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
+                colors, _ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
+                                                                 shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
+                                                            for i in range(V)], stacked=True)
+                # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285) = the mean of the per-view
+                # means that the camera-by-camera branch below forms
+                loss = l1_loss(colors, self.targets_stacked)
+            else:
+                outs = [self.render(i, m2ds[i]) for i in range(V)]
+                loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).mean()
+            loss.backward(gradient=self.one)   # (a resident 1.0: autograd would launch a fill for the root gradient every step)
+            if self.fg is not None:
+                with torch.no_grad():
+                    torch.sum(torch.stack([m.grad for m in m2ds]), dim=0, out=self.fg.tail.view(P, 3))
+                if not skip_allreduce:
+                    self.fg.all_reduce(timed=timed_allreduce)
+            return loss
+
+    scene_mode = args.mode == "scenes"
+    if scene_mode:      # BASELINE configs[4]: six seeded scene variants, scene s on rank s mod N, no data-path collective
+        n_scenes = 6
+        loads = [Workload(6666 + 17 * s_, 0.0, False) for s_ in range(n_scenes) if s_ % world == rank]
+    else:
+        n_scenes = world
+        loads = [Workload(syn.SEED, rank / max(world, 1), world > 1)]
+    wl = loads[0] if loads else None
+
+    def step():
+        out_ = None
+        for w_ in loads:
+            out_ = w_.step()
+        return out_
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # steady state reached: park everything allocated so far (torch, the scene, the warm-up graphs) in the permanent
+    # generation, so that the cyclic collector's periodic full passes do not walk ~10^5 long-lived objects inside the
+    # timed region (measured: +1.1 ms/step on the per-view path).  Nothing is skipped: young garbage is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
+    import diff_gaussian_rasterization as dgr
+    sync()
+    if not os.environ.get("CSPLAT_BENCH_NOEVENTS"):
+        native.prof_enable(["K7_render_bwd"])
+    native.prof_read("K7_render_bwd")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    k7_ms, k7_n = native.prof_read("K7_render_bwd")
+    native.prof_enable([])
+
+    # per-kernel breakdown (separate, untimed pass) and R per view
+    native.prof_enable(native.PROF_CLASSES[:8])
+    for c in native.PROF_CLASSES[:8]:
+        native.prof_read(c)
+    step(); torch.cuda.synchronize()
+    breakdown = {}
+    for c in native.PROF_CLASSES[:8]:
+        ms, n = native.prof_read(c)
+        breakdown[c] = round(ms / max(n, 1) * 1e3, 2)  # us per launch-bracket
+    native.prof_enable([])
+    # K7 launched ALONE (views back to back on one stream; untimed, supplementary): the kernel-level reading of the
+    # roofline next to the contract's in-step figure, where the views' K7 overlap and each launch lasts longer
+    k7_alone_us = None
+    if args.view_streams and V > 1 and wl is not None:
+        args.view_streams = False
+        step(); torch.cuda.synchronize()
+        native.prof_enable(["K7_render_bwd"]); native.prof_read("K7_render_bwd")
+        step(); torch.cuda.synchronize()
+        ms_a, n_a = native.prof_read("K7_render_bwd")
+        native.prof_enable([])
+        args.view_streams = True
+        k7_alone_us = ms_a / max(n_a, 1) * 1e3
+    # the collective on its own (untimed extra passes, bracketed by device synchronisation): bytes, ranks, wall time
+    collective = None
+    if world > 1 and not scene_mode:
+        ar = []
+        for _ in range(5):
+            wl.step(timed_allreduce=True)
+            ar.append(wl.fg.last_allreduce_ms)
+        # the same steps WITHOUT the exchange: what the collective adds to the step as launched (its exposed time).  In this workload
+        # every gradient is finished by ONE kernel (K8) at the very end of backward, so nothing is left to hide the exchange behind;
+        # the train step (csplat.train.train_step, view_parallel) sends the Gaussian gradients' slice from a backward hook, under the
+        # simulator's and the regularisers' backward (csplat/dist.py: early bucket)
+        sync(); t_n = time.perf_counter()
+        for _ in range(5):
+            wl.step(skip_allreduce=True)
+        sync(); ms_noar = (time.perf_counter() - t_n) / 5 * 1e3
+        sync(); t_n = time.perf_counter()
+        for _ in range(5):
+            wl.step()
+        sync(); ms_ar = (time.perf_counter() - t_n) / 5 * 1e3
+        collective = {"backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
+                      "bytes": int(wl.fg.flat.numel() * 4), "allreduce_ms": round(float(np.median(ar)), 4),
+                      "exposed_allreduce_ms": round(ms_ar - ms_noar, 4), "step_ms_without_allreduce": round(ms_noar, 4),
+                      "what": "one all-reduce(sum) per step over the flat gradient buffer (62 floats per Gaussian + 3 for the "
+                              "screen-space gradient); timed alone, after the step's kernels have drained"}
+    R_per_view = [0] * V
+    if wl is not None:
+        with torch.no_grad():
+            for i in range(V):
+                ctx = type("C", (), {"save_for_backward": lambda s, *a: None, "mark_non_differentiable": lambda s, *a: None})()
+                dgr._RasterizeGaussians.forward(ctx, wl.params["means3D"], None, wl.params["shs"], None, wl.params["opacities"],
+                                                wl.params["scales"], wl.params["rotations"], None, wl.settings[i])
+                R_per_view[i] = ctx.view_state.num_rendered
+
+    # forward-only (evaluation) rate, auxiliary: what the reference's render.py prints as FPS (render.py:195,301: render() under no_grad,
+    # camera by camera) -- here the V cameras of the batch per call, K1-K6 only
+    eval_fwd = None
+    if wl is not None and args.view_streams and world == 1:
+        with torch.no_grad():
+            kws = [dict(means3D=wl.params["means3D"], means2D=None, opacities=wl.params["opacities"], shs=wl.params["shs"],
+                        scales=wl.params["scales"], rotations=wl.params["rotations"]) for _ in range(V)]
+            for _ in range(3):
+                rasterize_views(wl.settings, kws, stacked=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                rasterize_views(wl.settings, kws, stacked=True)
+            torch.cuda.synchronize()
+            dt_e = (time.perf_counter() - t1) / 20
+        eval_fwd = {"ms_per_call": round(dt_e * 1e3, 4), "views_per_call": V, "fps": round(V / dt_e, 1),
+                    "Mpix_per_s": round(V * W * H / 1e6 / dt_e, 1), "what": "rasterizer forward only under no_grad (K1-K6), all views of the batch per call"}
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    mpix = n_scenes * V * W * H / 1e6
+    value = mpix / (dt / args.steps)
+
+    # roofline of the dominant kernel named by BASELINE.json north_star: compositing backward (K7).
+    # algorithmic bytes per launch = 84*R + 24*X (instance re-read 44 B + 40 B partials per instance;
+    # dL_dpix 16 B (incl. unused depth grad slot) + T 4 B + n_contrib 4 B per pixel), R = that view's tile instances.
+    X = W * H
+    # (with the views batched into one K7 launch per step the launch carries all views' bytes)
+    k7_launches_per_step = max(1, int(round(k7_n / max(args.steps * max(len(loads), 1), 1))))
+    views_per_launch = max(1, V // k7_launches_per_step)
+    alg_bytes = float(np.mean([84.0 * r + 24.0 * X for r in R_per_view])) * views_per_launch
+    k7_avg_s = (k7_ms / max(k7_n, 1)) * 1e-3
+    achieved = alg_bytes / k7_avg_s / 1e9 if k7_avg_s > 0 else 0.0
+    # committed counter passes of the same workload on the DEFAULT command (tools/collect_profiles.sh, tools/collect_issue_counters.sh):
+    # HBM traffic and VALU instruction count of the K7 launch this run timed.  They are measurements of an earlier run of the same
+    # kernel: the profile records the SHA-1 of csplat_raster.hip it was taken with, and the values are withheld (null, with the reason)
+    # when the source has changed since.
+    import glob
+    import hashlib
+    K7_NAMES = ("k_composite_bwd_rows_views", "k_composite_bwd_views") if (args.view_streams and V > 1) else ("k_composite_bwd_rows", "k_composite_bwd")
+    src_sha = hashlib.sha1(open(os.path.join(ROOT, "cloth-splatting_amd", "csrc", "csplat_raster.hip"), "rb").read()).hexdigest()
+    traffic = valu_insts = None
+    counters_from = {}
+
+    def newest(pattern):
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return paths[-1] if paths else None
+    tp = newest("r*_k7_pmc_traffic.json")
+    if tp:
+        try:
+            doc = json.load(open(tp))
+            fresh = doc.get("raster_src_sha1") == src_sha
+            counters_from["traffic"] = {"file": os.path.basename(tp), "same_kernel_source": fresh}
+            table = doc.get("all_kernels", {}) if (args.view_streams and V > 1) else (doc.get("one_view_per_launch") or {})
+            hit = next((v for k, v in table.items() if any(k.startswith(n) and "<true>" not in k for n in K7_NAMES[:1])), None) or \
+                next((v for k, v in table.items() if any(k.startswith(n) for n in K7_NAMES)), None)
+            if fresh and hit:
+                traffic = int(hit["hbm_bytes_per_launch"])
+        except Exception as e:
+            counters_from["traffic"] = {"error": repr(e)[:120]}
+    ip = newest("r*_k67_issue.json")
+    if ip:
+        try:
+            doc = json.load(open(ip))
+            fresh = doc.get("raster_src_sha1") == src_sha
+            counters_from["issue"] = {"file": os.path.basename(ip), "same_kernel_source": fresh}
+            table = doc.get("kernels", {}) if (args.view_streams and V > 1) else doc.get("kernels_one_view_per_launch", {})
+            hit = next((table[n] for n in K7_NAMES if n in table), None)
+            if fresh and hit:
+                valu_insts = hit["SQ_INSTS_VALU"]
+        except Exception as e:
+            counters_from["issue"] = {"error": repr(e)[:120]}
+    # what a wave64 VALU instruction costs a SIMD's vector pipe on this part (tools/valu_rate.hip, profiles/r03_valu_rate.txt, >= 2 waves
+    # per SIMD): 2.3 cycles for plain v_fma / v_mul / v_add / v_mov, 4.2 for every DPP form, v_cmp, v_min / v_max, v_cndmask_e64, shifts and
+    # conversions, 8.2 for v_exp / v_rcp / v_permlane*_swap.  K7's loop (156 VALU per group of four survivors: 82 / 66 / 8 of the three
+    # classes, from the ISA) averages 3.4 cycles per instruction.
+    SIMDS, CLOCK_GHZ, K7_CYC_PER_VALU = 1024, 2.4, 3.4
+    issue = lambda us: None if not (valu_insts and us) else round(valu_insts * K7_CYC_PER_VALU / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
+    out = {
+        "metric": "rasterizer fwd+bwd rendered Mpix/s (scene_1, 800x800)", "value": round(value, 3), "unit": "Mpix/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong" if scene_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"6 seeded scene_1 variants dealt over {world} rank(s), " if scene_mode else "scene_1 synthetic, ") +
+                               f"P={P} Gaussians, {V} cams {W}x{H} per " + ("scene" if scene_mode else "GPU") + ", SH degree 3, "
+                               "fwd (K1-K6) + L1 + bwd (K7-K8)" +
+                               (", + ONE RCCL all-reduce of the flat gradient buffer" if world > 1 and not scene_mode else ""),
+                   "tile_instances_per_view": R_per_view,
+                   "parallelism": (f"scene-parallel x{world} (replicas only)" if scene_mode else f"view-parallel x{world}"),
+                   "streams_per_gpu": V if args.view_streams else 1},
+        "roofline": {"bound": "hbm", "kernel": "k_composite_bwd_rows_views (K7 compositing backward, all views of the step in one launch)", "achieved": round(achieved, 3),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                     # PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of THIS launch (all views of the step), from the committed counter pass of
+                     # the default command; null when that pass was taken with a different csplat_raster.hip
+                     "traffic": traffic, "counters_from": counters_from,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
+                     "launches_timed": int(k7_n),
+                     "views_per_launch": views_per_launch,
+                     "issue_frac": issue(k7_avg_s * 1e6),
+                     "issue_note": "VALU wave-instructions of this launch (SQ_INSTS_VALU of the committed counter pass) x 3.4 cycles (the "
+                                   "instruction mix of K7's loop priced with tools/valu_rate.hip: 2.3 plain / 4.2 DPP, compare, select, "
+                                   "min-max / 8.2 exp, rcp, permlane swap) / (1024 SIMDs x 2.4 GHz x this launch's duration): the share of "
+                                   "the vector pipes' cycles the kernel's arithmetic occupies -- the bound that binds it (composite "
+                                   "arithmetic, no contraction), not HBM",
+                     "alone": None if not k7_alone_us else {
+                         "avg_launch_us": round(k7_alone_us, 2),
+                         "achieved": round(alg_bytes / views_per_launch / (k7_alone_us * 1e-6) / 1e9, 3),
+                         "frac": round(alg_bytes / views_per_launch / (k7_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                         "issue_frac": None,
+                         "what": "same kernel, views back to back on one stream (untimed extra pass)"},
+                     "note": (f"the K7 work of the step's {V} views is ONE launch (blockIdx.y = view): bytes and instructions of "
+                              f"{views_per_launch} view(s) per launch over that launch's duration; 'alone' = one view per launch, views "
+                              "back to back") if args.view_streams and V > 1 else None},
+        "kernel_us": breakdown,
+        "eval_forward": eval_fwd,
+        "collective": collective,
+    }
+    # the first half of BASELINE.json's metric ("train-step ms"): BASELINE configs[2], measured by bench_train.py (untimed
+    # here, its own timed region; 1 GPU only).  Auxiliary field -- `value` stays the rasterizer fwd+bwd throughput.
+    if rank == 0 and world == 1 and not scene_mode and not args.no_train_step and (P, W, V) == (100_000, 800, 4):
+        try:
+            import bench_train
+            from types import SimpleNamespace as _NS
+            r = bench_train.run(_NS(steps=30, warmup=5, P=100_000, res=800, grid=100), dev)
+            out["train_step"] = {"ms": r["value"], "unit": "ms", "rendered_Mpix_per_s": r["rendered_Mpix_per_s"], "steps": r["steps"],
+                                 "psnr_first": r["psnr_first"], "psnr_last": r["psnr_last"], "workload": r["config"]["workload"]}
+        except Exception as e:      # never let the auxiliary leg take the headline line down
+            out["train_step"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl.scene, wl.cams, P, W, H)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

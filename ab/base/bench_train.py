@@ -89,8 +89,6 @@ def run(args, dev=None):
     out = {"metric": "train-step ms (scene_1, 3 cams 800x800, P=100k)", "value": round(ms, 3), "unit": "ms",
            "higher_is_better": False, "dtype": "f32", "data": "synthetic", "steps": args.steps, "warmup": args.warmup,
            "rendered_Mpix_per_s": round(3 * args.res * args.res / 1e6 / (ms * 1e-3), 1),
-           # the step is bound by the HOST (Python + launches: ~1.1 ms with a trivial scene): the mean moves with whatever else runs on
-           # the box's cores; the median and the fastest decile of the same steps say what the code costs
            "median_ms": round(per_step[len(per_step) // 2] * 1e3, 3), "p10_ms": round(per_step[len(per_step) // 10] * 1e3, 3),
            "psnr_first": round(hist[0], 3), "psnr_last": round(hist[-1], 3),
            "config": {"workload": f"train_step analogue: V={sc['mesh_pos'].shape[1]} mesh nodes, P={args.P}, 3 cams "

@@ -1,0 +1,228 @@
+"""View-parallel execution over the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).  The reference is single-GPU; this is the new
+capability described in SURVEY.md 5.8 / 8(e):
+
+  * Gaussians, mesh and simulator are replicated; the cameras of a step are dealt round-robin over the ranks;
+  * the gradients of ALL parameters live in ONE persistent flat fp32 buffer (FlatGrads): every `p.grad` is a view into it, so
+    autograd accumulates straight into the buffer and the step's single all-reduce(sum) needs no gather / scatter copies
+    (240 B per Gaussian + simulator gradients + a small tail for the step's scalars and the screen-space statistics --
+    xGMI is point-to-point, one large message per step is the per-link-friendly shape; no bucketing is needed at 24-55 MB);
+  * densification statistics are reduced with the operator that keeps replicas bit-identical:
+    screen-space gradient (part of the flat buffer) -> sum, max_radii2D -> max (visibility = radius > 0).
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_rank():
+    return (dist.get_world_size(), dist.get_rank()) if is_dist() else (1, 0)
+
+
+def shard_indices(n, rank=None, world=None):
+    """indices i < n with i mod world == rank; ranks beyond n get an empty list and still join the collectives."""
+    w, r = world_rank()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    return [i for i in range(n) if i % world == rank]
+
+
+def shard_views(views, rank=None, world=None):
+    views = list(views)
+    return [views[i] for i in shard_indices(len(views), rank, world)]
+
+
+class FlatGrads:
+    """One flat fp32 buffer whose slices ARE the `.grad` tensors of `params` (+ `extra` trailing floats for whatever else has
+    to be summed over ranks in the same message).  bind() zeroes the buffer and (re-)attaches the views -- call it before
+    backward(), because `optimizer.zero_grad(set_to_none=True)` detaches them; autograd then accumulates in place.
+    Rebuilt by the owner when the parameter set changes shape (densification).
+
+    `early` = how many LEADING parameters form the early bucket: their gradients are complete long before the backward pass ends
+    (the Gaussian parameters: final when the rasterizer's K8 and the activation / mesh-transform adjoints have run, while the
+    simulator MLP and the regularisers are still in backward).  The post-accumulate hook of the LAST of them to receive its gradient
+    starts the all-reduce of that slice right away (async: RCCL runs it on its own stream behind the kernels queued so far), so the
+    exchange of ~95 % of the bytes overlaps the rest of backward; all_reduce() then sends the remainder (simulator gradients + tail)
+    and waits for both.  The sums are the same sums: results equal the one-shot all-reduce bit for bit."""
+
+    def __init__(self, params, extra=0, early=0):
+        self.params = [p for p in params]
+        assert self.params, "FlatGrads: no parameters"
+        dev = self.params[0].device
+        assert all(p.device == dev and p.dtype == self.params[0].dtype for p in self.params), "FlatGrads: mixed devices / dtypes"
+        self.shapes = [tuple(p.shape) for p in self.params]
+        self.sizes = [p.numel() for p in self.params]
+        self.n_param = sum(self.sizes)
+        self.extra = int(extra)
+        self.early = int(early)
+        self.n_early = sum(self.sizes[:self.early])
+        self.flat = torch.zeros(self.n_param + self.extra, dtype=self.params[0].dtype, device=dev)
+        self.views, o = [], 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[o:o + n].view(p.shape))
+            o += n
+        self.tail = self.flat[self.n_param:]
+        self.last_allreduce_ms = 0.0
+        self.early_fired = 0           # how many steps sent their early slice from the backward hook (tests, bench)
+        # which parameters autograd actually wrote during the current backward (bind() hands EVERY parameter a zero-filled view;
+        # a parameter outside the graph -- `face_offset`, a frozen group -- must end the step with grad None exactly as in the
+        # one-rank step, or Adam would create state for it and advance its step count)
+        self._touched = [False] * len(self.params)
+        self._union = {}
+        self._early_expect = None      # which early parameters receive a gradient in a step (learned on the first step)
+        self._early_left = None
+        self._early_work = None
+        self._group = None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._mark(i)) for i, p in enumerate(self.params)]
+
+    def _mark(self, i):
+        def hook(_p):
+            self._touched[i] = True
+            if self._early_left is not None and i in self._early_left:
+                self._early_left.discard(i)
+                if not self._early_left:
+                    self._start_early()
+        return hook
+
+    def _start_early(self):
+        """every early parameter that gets a gradient has it: send the early slice now, under the rest of backward"""
+        self._early_left = None
+        if is_dist() and self.n_early > 0:
+            self.early_fired += 1
+            self._early_work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def matches(self, params, extra=0, early=0):
+        params = list(params)
+        return len(params) == len(self.params) and int(extra) == self.extra and int(early) == self.early and \
+            all(a is b and tuple(a.shape) == s for a, b, s in zip(params, self.params, self.shapes))
+
+    def bind(self, group=None):
+        self.flat.zero_()
+        self._touched = [False] * len(self.params)
+        self._early_work = None
+        self._group = group
+        # the early bucket fires when the same early parameters as in the previous step have their gradients (a step's graph is
+        # static); the first step of a buffer learns the set and sends everything at the end
+        self._early_left = set(self._early_expect) if (self.early and self._early_expect) else None
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def drop_untouched(self, key=None, group=None):
+        """after backward + all_reduce: `p.grad = None` for every parameter that NO rank's backward wrote.  The union over ranks
+        is one tiny all-reduce(max) + host read the first time a step shape `key` is seen (the graph of a step is static: same
+        cameras per rank, same parameters in it) and is served from a cache afterwards."""
+        if key not in self._union:
+            t = torch.tensor([int(b) for b in self._touched], dtype=torch.int32, device=self.flat.device)
+            if is_dist():
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            self._union[key] = [bool(b) for b in t.tolist()]
+        for p, hit in zip(self.params, self._union[key]):
+            if not hit:
+                p.grad = None
+
+    def all_reduce(self, group=None, timed=False):
+        """sum over ranks, in place: the part of the buffer the early bucket has not already sent, then wait for both.  timed=True
+        brackets the call with device synchronisation and records its wall time -- `last_allreduce_ms` = what this call took with
+        the device drained first, i.e. the EXPOSED time of the step's exchange when the early bucket was in flight (bench.py reports
+        the one-shot time next to it); the default leaves it asynchronous with respect to the host."""
+        if self.early and self._early_expect is None:      # learned once per buffer: which early parameters a step touches
+            self._early_expect = [i for i in range(self.early) if self._touched[i]]
+        if not is_dist():
+            return self.flat
+        if timed and self.flat.is_cuda:
+            torch.cuda.synchronize(self.flat.device)
+            t0 = time.perf_counter()
+        # the protocol is the same on every rank whatever its share of the cameras: with an early bucket, ALWAYS two collectives in
+        # this order -- the early slice (already in flight where the hook fired; sent now where it did not: the first step of a buffer,
+        # a rank without a camera) and then the rest
+        self._early_left = None
+        if self.early and self.n_early > 0:
+            if self._early_work is None:
+                self._early_work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            rest = self.flat[self.n_early:]
+        else:
+            rest = self.flat
+        if rest.numel():
+            dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=group)
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
+        if timed and self.flat.is_cuda:
+            torch.cuda.synchronize(self.flat.device)
+            self.last_allreduce_ms = (time.perf_counter() - t0) * 1e3
+        return self.flat
+
+
+def flat_grads_for(owner, params, extra=0, early=0):
+    """the FlatGrads cached on `owner` for exactly these parameter objects (rebuilt when they were replaced or resized)"""
+    params = list(params)
+    fg = owner.__dict__.get("_flat_grads") if hasattr(owner, "__dict__") else None
+    if fg is None or not fg.matches(params, extra, early):
+        if fg is not None:
+            fg.close()
+        fg = FlatGrads(params, extra, early)
+        try:
+            owner._flat_grads = fg
+        except Exception:
+            pass
+    return fg
+
+
+def allreduce_flat(tensors, op=None, group=None):
+    """All-reduce a list of same-dtype tensors as ONE flat buffer, in place (copying variant for ad-hoc tensor lists; the
+    training step uses FlatGrads, which needs no copies).  Returns the flat buffer."""
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return None
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    if is_dist():
+        dist.all_reduce(flat, op=op or dist.ReduceOp.SUM, group=group)
+    pieces, o = [], 0
+    for t in tensors:
+        n = t.numel()
+        pieces.append(flat[o:o + n].view_as(t))
+        o += n
+    try:
+        torch._foreach_copy_(tensors, pieces)        # one multi-tensor launch instead of one copy per parameter
+    except (AttributeError, RuntimeError):
+        for t, src in zip(tensors, pieces):
+            t.copy_(src)
+    return flat
+
+
+def allreduce_gradients(params, group=None):
+    """sum the .grad of every parameter over ranks (parameters without grad contribute zeros so that all ranks
+    issue the same collective)."""
+    grads = []
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        grads.append(p.grad)
+    return allreduce_flat(grads, group=group)
+
+
+def reduce_max_radii(radii, group=None):
+    """train_utils.py:276-277: the largest screen radius of every Gaussian over the step's cameras -> max over ranks."""
+    if is_dist():
+        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
+    return radii
+
+
+def reduce_densification_stats(viewspace_grad, radii, visibility, group=None):
+    """train_utils.py:276-277,290-292: viewspace gradient (sum over cams -> sum over ranks), radii (max), visibility (any)."""
+    if not is_dist():
+        return viewspace_grad, radii, visibility
+    dist.all_reduce(viewspace_grad, op=dist.ReduceOp.SUM, group=group)
+    packed = torch.stack([radii.to(torch.int32), visibility.to(torch.int32)])
+    dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
+    return viewspace_grad, packed[0].to(radii.dtype), packed[1].to(torch.bool)

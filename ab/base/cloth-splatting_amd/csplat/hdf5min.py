@@ -1,0 +1,244 @@
+"""hdf5min -- the small subset of HDF5 the reference's `mesh.hdf5` side-car needs, without h5py.
+
+The reference writes its mesh next to `point_cloud.ply` with
+    with h5py.File(os.path.join(path, "mesh.hdf5"), "w") as f:
+        for key, value in mesh.items(): f.create_dataset(key, data=value...numpy())
+(/root/reference/scene_reconstruction/gaussian_mesh.py:462-465) and reads it back with `h5py.File(path)[name][:]`
+(meshnet/data_utils.py:450-457): a flat root group of a few dense float32 / int64 arrays.  h5py is not installed in this image
+and cannot be (no network), so this module writes and reads exactly that shape of file, following the HDF5 File Format
+Specification (version 0 superblock, symbol-table root group = one v1 B-tree node + one symbol-table node + a local heap,
+version-1 object headers, contiguous version-3 data layout, little-endian fixed / floating point types) -- the "earliest"
+format libhdf5 itself emits by default for such a file.
+
+STATUS: written from the specification; verified against its own reader and structural known-answer checks
+(tests/test_oracle_cpu.py), NOT against libhdf5 -- neither libhdf5 nor h5py exists here to open the files.  `load()` prefers
+h5py when it is importable.  Not supported (clear errors): more than 8 datasets, groups, chunked / compressed layouts,
+superblock versions 2+, big-endian or compound types."""
+import struct
+
+import numpy as np
+
+SIG = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+LEAF_K, INTERNAL_K = 4, 16
+
+
+def _pad8(b):
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _dtype_message(dt):
+    dt = np.dtype(dt)
+    if dt.byteorder == ">":
+        raise ValueError("hdf5min: big-endian arrays are not supported")
+    if dt.kind in "iu":
+        bits = (0x08 if dt.kind == "i" else 0x00)                       # little-endian, signed flag in bit 3
+        head = struct.pack("<BBBBI", (1 << 4) | 0, bits, 0, 0, dt.itemsize)
+        return head + struct.pack("<HH", 0, dt.itemsize * 8)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        exp_bits, mant_bits, bias = (8, 23, 127) if dt.itemsize == 4 else (11, 52, 1023)
+        # byte 0: little-endian (bit 0 = 0), mantissa normalisation "msb implied" = 2 in bits 4-5; byte 1: sign bit position
+        head = struct.pack("<BBBBI", (1 << 4) | 1, 0x20, dt.itemsize * 8 - 1, 0, dt.itemsize)
+        return head + struct.pack("<HHBBBBI", 0, dt.itemsize * 8, mant_bits, exp_bits, 0, mant_bits, bias)
+    raise ValueError(f"hdf5min: dtype {dt} is not supported")
+
+
+def _message(mtype, data, flags=0):
+    data = _pad8(data)
+    return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+
+def _object_header(messages):
+    body = b"".join(messages)
+    return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body
+
+
+def save(path, arrays):
+    """write {name: ndarray} as datasets of the root group of a new HDF5 file"""
+    names = sorted(arrays)                                              # symbol-table entries are ordered by name
+    if not 0 < len(names) <= 2 * LEAF_K:
+        raise ValueError(f"hdf5min.save: 1..{2 * LEAF_K} datasets, got {len(names)}")
+    arrs = {k: np.require(arrays[k], requirements="C") for k in names}         # (keeps 0-d arrays 0-d: scalar dataspace)
+    # ---- local heap data: "" at offset 0, then the names; a trailing free block closes the segment
+    heap, name_off = bytearray(8), {}
+    for k in names:
+        name_off[k] = len(heap)
+        heap += _pad8(k.encode("ascii") + b"\0")
+    free_off = len(heap)
+    heap += struct.pack("<QQ", 1, 32) + bytes(16)                       # free block: next = 1 (end of list), size 32
+    # ---- layout of the file
+    off = 96                                                            # superblock (56) + root symbol-table entry (40)
+    root_hdr_at = off
+    root_hdr_len = 16 + 8 + 16
+    off += root_hdr_len
+    btree_at = off
+    btree_len = 24 + (2 * INTERNAL_K + 1) * 8 + 2 * INTERNAL_K * 8
+    off += btree_len
+    heap_at = off
+    off += 32
+    heap_data_at = off
+    off += len(heap)
+    snod_at = off
+    off += 8 + 2 * LEAF_K * 40
+    headers, hdr_at, data_at = {}, {}, {}
+    for k in names:                                                     # object headers first (their size does not depend on addresses)
+        a = arrs[k]
+        space = struct.pack("<BBB5x", 1, a.ndim, 0) + b"".join(struct.pack("<Q", d) for d in a.shape)
+        hdr_at[k] = off
+        headers[k] = (space, _dtype_message(a.dtype))
+        off += 16 + (8 + len(_pad8(space))) + (8 + len(_pad8(headers[k][1]))) + (8 + 8) + (8 + 24)
+    for k in names:
+        off += -off % 8
+        data_at[k] = off
+        off += arrs[k].nbytes
+    eof = off
+    # ---- emit
+    out = bytearray()
+    out += SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, LEAF_K, INTERNAL_K, 0)
+    out += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+    out += struct.pack("<QQII", 0, root_hdr_at, 1, 0) + struct.pack("<QQ", btree_at, heap_at)        # root entry, cached B-tree / heap
+    assert len(out) == 96
+    out += _object_header([_message(0x0011, struct.pack("<QQ", btree_at, heap_at))])
+    bt = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_at, name_off[names[-1]])
+    out += bt + bytes(btree_len - len(bt))
+    out += b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), free_off, heap_data_at)
+    out += heap
+    sn = b"SNOD" + struct.pack("<BBH", 1, 0, len(names))
+    for k in names:
+        sn += struct.pack("<QQII16x", name_off[k], hdr_at[k], 0, 0)
+    out += sn + bytes(8 + 2 * LEAF_K * 40 - len(sn))
+    for k in names:
+        assert len(out) == hdr_at[k]
+        space, dtm = headers[k]
+        # (a dataset without elements has no storage: libhdf5 records the undefined address for it)
+        layout = struct.pack("<BBQQ", 3, 1, data_at[k] if arrs[k].nbytes else UNDEF, arrs[k].nbytes)
+        fill = struct.pack("<BBBB", 2, 1, 0, 0)                         # v2: early allocation, write at allocation, undefined value
+        out += _object_header([_message(0x0001, space), _message(0x0003, dtm, flags=1), _message(0x0005, fill), _message(0x0008, layout)])
+    for k in names:
+        out += bytes(data_at[k] - len(out))
+        out += arrs[k].tobytes()
+    assert len(out) == eof
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+# ------------------------------------------------------------------------------------------------------------ reader
+def _read_dtype(b):
+    cls, ver = b[0] & 0x0F, b[0] >> 4
+    size = struct.unpack_from("<I", b, 4)[0]
+    if b[1] & 1:
+        raise ValueError("hdf5min: big-endian data")
+    if cls == 0:
+        return np.dtype(("<i" if b[1] & 0x08 else "<u") + str(size))
+    if cls == 1:
+        return np.dtype("<f" + str(size))
+    raise ValueError(f"hdf5min: datatype class {cls} (version {ver}) is not supported")
+
+
+def _messages(buf, at):
+    """(type, data) of a version-1 object header at `at`, following continuation blocks"""
+    ver, _, nmsg, _, size = struct.unpack_from("<BBHII", buf, at)
+    if ver != 1:
+        raise ValueError(f"hdf5min: object header version {ver} is not supported (file written with libver='latest'?)")
+    blocks, out = [(at + 16, size)], []
+    while blocks and len(out) < nmsg:
+        p, left = blocks.pop(0)
+        end = p + left
+        while p + 8 <= end and len(out) < nmsg:
+            mtype, msize = struct.unpack_from("<HH", buf, p)
+            data = bytes(buf[p + 8:p + 8 + msize])
+            p += 8 + msize
+            if mtype == 0x0010:                                         # continuation: (address, length)
+                blocks.append(struct.unpack("<QQ", data[:16]))
+            out.append((mtype, data))
+    return out
+
+
+def _dataset(buf, at):
+    shape = dt = None
+    addr = size = None
+    inline = None
+    for mtype, d in _messages(buf, at):
+        if mtype == 0x0001:
+            ver, rank = d[0], d[1]
+            base = 8 if ver == 1 else 4
+            shape = struct.unpack_from("<" + "Q" * rank, d, base)
+        elif mtype == 0x0003:
+            dt = _read_dtype(d)
+        elif mtype == 0x0008:
+            ver, cls = d[0], d[1]
+            if ver != 3:
+                raise ValueError(f"hdf5min: data layout version {ver} is not supported")
+            if cls == 1:
+                addr, size = struct.unpack_from("<QQ", d, 2)
+            elif cls == 0:
+                n = struct.unpack_from("<H", d, 2)[0]
+                inline = d[4:4 + n]
+            else:
+                raise ValueError("hdf5min: chunked datasets are not supported")
+    if shape is None or dt is None or (addr is None and inline is None):
+        raise ValueError("hdf5min: incomplete dataset header")
+    count = int(np.prod(shape)) if len(shape) else 1
+    raw = inline if inline is not None else (b"" if addr == UNDEF else bytes(buf[addr:addr + count * dt.itemsize]))
+    return np.frombuffer(raw, dtype=dt, count=count).reshape(shape).copy()
+
+
+def _walk(buf, btree_at, heap_data_at, out):
+    if buf[btree_at:btree_at + 4] != b"TREE":
+        raise ValueError("hdf5min: group B-tree node expected")
+    ntype, level, used = struct.unpack_from("<BBH", buf, btree_at + 4)
+    if ntype != 0:
+        raise ValueError("hdf5min: not a group B-tree")
+    p = btree_at + 24 + 8
+    for _ in range(used):
+        child = struct.unpack_from("<Q", buf, p)[0]
+        p += 16
+        if level > 0:
+            _walk(buf, child, heap_data_at, out)
+            continue
+        if buf[child:child + 4] != b"SNOD":
+            raise ValueError("hdf5min: symbol-table node expected")
+        n = struct.unpack_from("<H", buf, child + 6)[0]
+        for e in range(n):
+            noff, hdr, ctype = struct.unpack_from("<QQI", buf, child + 8 + 40 * e)
+            end = buf.index(b"\0", heap_data_at + noff)
+            name = bytes(buf[heap_data_at + noff:end]).decode("ascii")
+            if ctype == 1:
+                raise ValueError(f"hdf5min: '{name}' is a group; only datasets in the root group are supported")
+            out[name] = _dataset(buf, hdr)
+
+
+def load(path, prefer_h5py=True):
+    """{name: ndarray} of the datasets in the root group"""
+    if prefer_h5py:
+        try:
+            import h5py
+            with h5py.File(path, "r") as f:
+                return {k: np.asarray(f[k]) for k in f.keys()}
+        except ImportError:
+            pass
+    buf = open(path, "rb").read()
+    if bytes(buf[:8]) != SIG:
+        raise ValueError("hdf5min: not an HDF5 file")
+    ver = buf[8]
+    if ver > 1:
+        raise ValueError(f"hdf5min: superblock version {ver} is not supported (written with libver='latest'?)")
+    if buf[13] != 8 or buf[14] != 8:
+        raise ValueError("hdf5min: only 8-byte offsets / lengths are supported")
+    entry = 24 + (4 if ver == 1 else 0) + 32                                # root group symbol-table entry
+    hdr_at, ctype = struct.unpack_from("<QI", buf, entry + 8)
+    btree_at = heap_at = None
+    if ctype == 1:
+        btree_at, heap_at = struct.unpack_from("<QQ", buf, entry + 24)
+    else:
+        for mtype, d in _messages(buf, hdr_at):
+            if mtype == 0x0011:
+                btree_at, heap_at = struct.unpack("<QQ", d[:16])
+    if btree_at is None:
+        raise ValueError("hdf5min: root group without a symbol table")
+    if bytes(buf[heap_at:heap_at + 4]) != b"HEAP":
+        raise ValueError("hdf5min: local heap expected")
+    heap_data_at = struct.unpack_from("<Q", buf, heap_at + 24)[0]
+    out = {}
+    _walk(buf, btree_at, heap_data_at, out)
+    return out

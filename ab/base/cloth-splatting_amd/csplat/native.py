@@ -63,10 +63,6 @@ EXPORTS = {
     "csplat_gauss_act_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_gauss_act_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_project_points": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
-    "csplat_image_loss_scratch_bytes": (_sz, [_i64, _i, _i, _i]),
-    "csplat_image_loss_fwd": (_i, [_vp, _i64, _i, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _i, _f, _f, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "csplat_image_loss_bwd": (_i, [_vp, _i64, _i, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
-    "csplat_step_stats": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "csplat_psnr_scratch_bytes": (_sz, [_i64]),
     "csplat_psnr": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "csplat_sim_hidden_fwd": (_i, [_vp, _i, _i] + [_vp] * 7),
@@ -75,7 +71,7 @@ EXPORTS = {
     "csplat_rows_dot_scratch_bytes": (_sz, [_i]),
     "csplat_cloth_regs_scratch_bytes": (_sz, [_i, _i, _i64]),
     "csplat_cloth_regs": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "csplat_rows_dot_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_rows_dot_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "csplat_rows_dot_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_l1": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "csplat_l1_masked": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

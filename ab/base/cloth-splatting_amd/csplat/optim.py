@@ -63,24 +63,6 @@ class GroupedAdam(torch.optim.Adam):
         if closure is not None or not self._fusable():
             self.__dict__.pop("_py_steps", None)
             return super().step(closure)
-        return self._fused_step()
-
-    @torch.no_grad()
-    def step_now(self):
-        """step() minus torch.optim's per-call wrapper (profiler record, hook dispatch: ~35 us of host time per call on a step that is
-        bound by the host) -- what csplat.train.train_step calls.  With step hooks registered, or anything the kernel does not cover,
-        this IS step()."""
-        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_step_hooks() or not self._fusable():
-            return self.step()
-        return self._fused_step()
-
-    def zero_grad_now(self):
-        """zero_grad(set_to_none=True) without the wrapper's bookkeeping"""
-        for group in self.param_groups:
-            for p in group["params"]:
-                p.grad = None
-
-    def _fused_step(self):
         buckets = {}
         keep = []
         steps = []
@@ -116,11 +98,3 @@ class GroupedAdam(torch.optim.Adam):
                                                  C.cast(arr(2), C.c_void_p), C.cast(arr(3), C.c_void_p), C.cast(numel, C.c_void_p),
                                                  C.cast(lrs, C.c_void_p), beta1, beta2, eps, step), "csplat_adam_step")
         return None
-
-
-def _global_step_hooks():
-    try:
-        from torch.optim import optimizer as _o
-        return bool(_o._global_optimizer_pre_hooks) or bool(_o._global_optimizer_post_hooks)
-    except Exception:
-        return True

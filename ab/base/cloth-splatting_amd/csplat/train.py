@@ -9,8 +9,6 @@ Host-side torch only; the compute is in the drop-in modules."""
 from math import exp
 from types import SimpleNamespace
 
-import ctypes as C
-
 import torch
 import torch.nn.functional as F
 
@@ -204,85 +202,55 @@ class FusedSSIM(torch.autograd.Function):
         return dx, None
 
 
-_IMG_SCRATCH = {}
-
-
-def _image_loss_scratch(dev, shape):
-    """workgroup partials of csplat_image_loss_fwd: one buffer per (device, stream, shape)"""
-    B, Cc, H, W = shape
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream, B, Cc, H, W)
-    buf = _IMG_SCRATCH.get(key)
-    if buf is None:
-        if len(_IMG_SCRATCH) >= 64:
-            _IMG_SCRATCH.clear()
-        buf = _IMG_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_image_loss_scratch_bytes(B, Cc, H, W)), dtype=torch.uint8, device=dev)
-    return buf
-
-
 class FusedImageLoss(torch.autograd.Function):
-    """Ll1 + lambda_dssim * ssim_loss of the reference's train step (train_utils.py:50-74), the PSNR it logs (:262-283) and the sum with
-    the regularisers as ONE node: csplat_image_loss_fwd (tile kernel + a one-workgroup sum) and csplat_image_loss_bwd (one launch).  gt is a constant.  With a mask (Camera.mask
-    stacked to [B,1,H,W], :61-67) the two terms are mean |(x - y) m| and mean((1 - ssim_map) m).
-    Returns (img_weight * image_loss + add_weight * add, psnr_scale * sum_b PSNR_b, image_loss); only the first is differentiable."""
+    """Ll1 + lambda_dssim * ssim_loss of the reference's train step (train_utils.py:50-74) as one node: forward = csplat_l1 +
+    csplat_ssim_fwd, backward = ONE launch (csplat_ssim_bwd with the L1 sign image as addend).  gt is a constant.  With a mask
+    (Camera.mask stacked to [B,1,H,W], :61-67) the two terms are mean |(x - y) m| and mean((1 - ssim_map) m)."""
 
     @staticmethod
-    def forward(ctx, image, gt, lam, mask=None, add=None, img_weight=1.0, add_weight=1.0, psnr_scale=1.0):
+    def forward(ctx, image, gt, lam, mask=None):
         _n.require_cuda(image)
         x, y = image.contiguous(), gt.contiguous()
         mask = None if mask is None else mask.contiguous()
-        if x.dim() == 3:
-            x, y = x.unsqueeze(0), y.unsqueeze(0)
         H, W = x.shape[-2:]
-        Cc = int(x.shape[-3])
-        B = x.numel() // (Cc * H * W)
+        n_img = x.numel() // (H * W)
         need = image.requires_grad
         dev = x.device
-        mc = 1 if mask is None else _mask_layout(x, mask)[3]
-        out = torch.empty(4, dtype=torch.float32, device=dev)
+        sign = torch.empty_like(x) if need else None
+        scratch = _l1_scratch(dev)
+        l1 = torch.empty((), dtype=torch.float32, device=dev)
         p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=dev) if need else None
-        sign = torch.empty(x.shape, dtype=torch.int8, device=dev) if need else None
-        addc = None if add is None else add.reshape(1).float()
+        partial = torch.empty(int(_n.lib.csplat_ssim_partial_count(n_img, H, W)), dtype=torch.float32, device=dev)
+        ps = [_n.ptr(p[k]) if need else None for k in range(3)]
         with torch.cuda.device(dev):
-            scratch = _image_loss_scratch(dev, (B, Cc, H, W))
-            _n.check(_n.lib.csplat_image_loss_fwd(_n.stream_handle(dev), B, Cc, H, W, _taps(), _n.ptr(x), _n.ptr(y),
-                                                  None if mask is None else _n.ptr(mask), mc, float(lam), float(img_weight),
-                                                  None if addc is None else _n.ptr(addc), float(add_weight), float(psnr_scale),
-                                                  *([_n.ptr(p[k]) for k in range(3)] if need else [None] * 3),
-                                                  _n.ptr(sign) if need else None, _n.ptr(scratch), _n.ptr(out)), "csplat_image_loss_fwd")
-        ctx.save_for_backward(x, y, p, sign, mask)
-        ctx.dims = (B, Cc, H, W, mc, float(lam), float(img_weight), float(add_weight), add is not None, image.shape)
-        loss, ps, il = out[0], out[1], out[2]
-        ctx.mark_non_differentiable(ps, il)
-        ctx.set_materialize_grads(False)
-        return loss, ps, il
+            st = _n.stream_handle(dev)
+            _launch_l1(x, y, mask, scratch, l1, sign)
+            if mask is None:
+                _n.check(_n.lib.csplat_ssim_fwd(st, n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), *ps, None, _n.ptr(partial)),
+                         "csplat_ssim_fwd")
+            else:
+                B, Cc, _, mc = _mask_layout(x, mask)
+                _n.check(_n.lib.csplat_ssim_fwd_masked(st, B, Cc, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(mask), mc, *ps, None,
+                                                       _n.ptr(partial)), "csplat_ssim_fwd_masked")
+        ctx.save_for_backward(x, y, p, sign)
+        ctx.dims = (n_img, H, W, float(lam))
+        if mask is not None:      # l1 + lam * sum((1 - S) m) / n
+            return torch.add(l1, partial.sum(), alpha=float(lam) / float(x.numel()))
+        # l1 + lam * (1 - sum(partial) / n)
+        return torch.add(l1 + float(lam), partial.sum(), alpha=-float(lam) / float(x.numel()))
 
     @staticmethod
-    def backward(ctx, g, _gp, _gi):
-        x, y, p, sign, mask = ctx.saved_tensors
-        B, Cc, H, W, mc, lam, w_img, w_add, has_add, shape = ctx.dims
-        if g is None:
-            return (None,) * 8
-        g = g.reshape(1).float()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            with torch.cuda.device(x.device):
-                _n.check(_n.lib.csplat_image_loss_bwd(_n.stream_handle(x.device), B, Cc, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
-                                                      _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(sign), None if mask is None else _n.ptr(mask), mc,
-                                                      lam, w_img, _n.ptr(g), _n.ptr(dx)), "csplat_image_loss_bwd")
-            dx = dx.reshape(shape)
-        gadd = None
-        if has_add and ctx.needs_input_grad[4]:
-            gadd = g.reshape(()) if w_add == 1.0 else g.reshape(()) * w_add
-        return dx, None, None, None, gadd, None, None, None
-
-
-def _image_loss_fusable(image_tensor, gt_image_tensor, opt, mask_tensor):
-    return bool(opt.lambda_dssim != 0 and image_tensor.is_cuda and image_tensor.dtype == torch.float32 and
-                gt_image_tensor.dtype == torch.float32 and image_tensor.shape == gt_image_tensor.shape and image_tensor.dim() in (3, 4)
-                and image_tensor.numel() > 0 and image_tensor.numel() // (image_tensor.shape[-1] * image_tensor.shape[-2]) < 65536
-                and not gt_image_tensor.requires_grad and
-                (mask_tensor is None or (image_tensor.dim() == 4 and _mask_layout(image_tensor, mask_tensor) is not None)))
+    def backward(ctx, g):
+        x, y, p, sign = ctx.saved_tensors
+        n_img, H, W, lam = ctx.dims
+        g = g.reshape(1).float().contiguous()
+        gs = g * (-lam)
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _n.check(_n.lib.csplat_ssim_bwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
+                                            _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(gs), 1.0 / float(x.numel()), _n.ptr(sign), _n.ptr(g),
+                                            _n.ptr(dx)), "csplat_ssim_bwd")
+        return dx, None, None, None
 
 
 def ssim(img1, img2, window_size=11, size_average=True, return_map=False):
@@ -334,8 +302,11 @@ def psnr(img1, img2):
 
 def image_losses(image_tensor, gt_image_tensor, opt, mask_tensor=None):
     """train_utils.py:50-74 (returns the loss; the reference's loss_dict of .item() host reads is not built)."""
-    if _image_loss_fusable(image_tensor, gt_image_tensor, opt, mask_tensor):
-        return FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim, mask_tensor)[0]
+    if opt.lambda_dssim != 0 and image_tensor.is_cuda and image_tensor.dtype == torch.float32 and \
+            gt_image_tensor.dtype == torch.float32 and image_tensor.shape == gt_image_tensor.shape and image_tensor.dim() >= 2 \
+            and image_tensor.numel() > 0 and not gt_image_tensor.requires_grad and \
+            (mask_tensor is None or _mask_layout(image_tensor, mask_tensor) is not None):
+        return FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim, mask_tensor)
     if opt.lambda_dssim != 0:
         _n.composed_fallback("train.image_losses", "dtype" if image_tensor.shape == gt_image_tensor.shape and image_tensor.numel() else "shape",
                              image_tensor)
@@ -359,13 +330,8 @@ class FusedClothRegs(torch.autograd.Function):
         E = int(edge_index.shape[1])
         loss = torch.empty((), dtype=torch.float32, device=D.device)
         grad = torch.empty_like(D)
+        scratch = torch.empty(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=D.device)
         with torch.cuda.device(D.device):
-            key = ("regs", D.device, torch.cuda.current_stream(D.device).cuda_stream, T, V, E)
-            scratch = _IMG_SCRATCH.get(key)              # zeroed once per (device, stream, sizes): the kernel leaves its ticket at zero
-            if scratch is None:
-                if len(_IMG_SCRATCH) >= 64:
-                    _IMG_SCRATCH.clear()
-                scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=D.device)
             _n.check(_n.lib.csplat_cloth_regs(_n.stream_handle(D.device), T, V, E, _n.ptr(D), _n.ptr(edge_index.contiguous()),
                                               _n.ptr(rest_len.contiguous().float()), float(lam_deform), float(lam_rigid),
                                               float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
@@ -446,33 +412,6 @@ def _gt_stack(cams, device):
 
 
 
-@torch.no_grad()
-def step_stats(grads, radii_list, P, dev, dtype=torch.float32):
-    """train_utils.py:276-285 for the cameras of a step: (sum of the screen-space gradients [P,3], largest radii [P], visible [P] bool).
-    On the GPU one launch (csplat_step_stats) for up to 16 cameras; a camera whose gradient is None counts as zero."""
-    if not radii_list:
-        return (torch.zeros(P, 3, dtype=dtype, device=dev), torch.zeros(P, dtype=torch.int32, device=dev),
-                torch.zeros(P, dtype=torch.bool, device=dev))
-    V = len(radii_list)
-    ok = V <= 16 and all(r.is_cuda and r.dtype == torch.int32 and r.is_contiguous() and r.numel() == P for r in radii_list) and \
-        all(g is None or (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == 3 * P) for g in grads)
-    if ok:
-        vsg = torch.empty(P, 3, dtype=torch.float32, device=dev)
-        radii = torch.empty(P, dtype=torch.int32, device=dev)
-        vis = torch.empty(P, dtype=torch.bool, device=dev)
-        gp = (C.c_void_p * V)(*[None if g is None else g.data_ptr() for g in grads])
-        rp = (C.c_void_p * V)(*[r.data_ptr() for r in radii_list])
-        with torch.cuda.device(dev):
-            _n.check(_n.lib.csplat_step_stats(_n.stream_handle(dev), P, V, gp, rp, _n.ptr(vsg), _n.ptr(radii), _n.ptr(vis)), "csplat_step_stats")
-        return vsg.to(dtype), radii, vis
-    if radii_list[0].is_cuda:
-        _n.composed_fallback("train.step_stats", "shape" if V > 16 else "dtype", radii_list[0])
-    live = [g for g in grads if g is not None]
-    vsg = torch.stack(live).sum(0) if live else torch.zeros(P, 3, dtype=dtype, device=dev)
-    radii = torch.stack(list(radii_list), 0).max(dim=0).values
-    return vsg, radii, radii > 0
-
-
 def _root_one(loss):
     """a resident 1.0 as the root gradient of `loss.backward()` (autograd otherwise launches a fill for it every step)"""
     key = (loss.device, loss.dtype)
@@ -543,33 +482,29 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             masks.append(cam.mask.to(pkg.render.device).unsqueeze(0))                      # train_utils.py:273-274
         verts.append(pkg.vertice_deform[None])
     dev = gaussians.face_bary.device
-    if reg is None:
-        reg = regularization(torch.cat(verts, 0), gaussians, opt, static) if verts else torch.zeros((), device=dev)
-    psnr_ = None
     if cams:
+        radii = torch.cat(radii_l, 0).max(dim=0).values
         image_tensor = stacked if stacked is not None else torch.cat(images, 0)
         gt_image_tensor = _gt_stack(cams, image_tensor.device)
         mask_tensor = torch.cat(masks, 0) if masks is not None else None
-        w_img = 1.0 if len(cams) == n_total else len(cams) / n_total
-        if _image_loss_fusable(image_tensor, gt_image_tensor, opt, mask_tensor) and reg.dtype == torch.float32:
-            # image loss + PSNR + the sum with the regularisers: one launch (and one in backward)
-            loss, psnr_, _ = FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim, mask_tensor, reg, w_img,
-                                                  1.0 / world if dist_mode else 1.0, 1.0 / max(n_total, 1))
-        else:
-            psnr_sum = psnr(image_tensor, gt_image_tensor).sum().double()
-            image_loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor)
-            if len(cams) != n_total:
-                image_loss = image_loss * (len(cams) / n_total)
+        psnr_sum = psnr(image_tensor, gt_image_tensor).sum().double()
+        image_loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor)
+        if len(cams) != n_total:
+            image_loss = image_loss * (len(cams) / n_total)
     else:   # a rank without a camera of this step
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
         psnr_sum = torch.zeros((), dtype=torch.float64, device=dev)
         image_loss = torch.zeros((), dtype=gaussians.face_bary.dtype, device=dev)
-    if psnr_ is None:
-        loss = image_loss + (reg / world if dist_mode else reg)
-        psnr_ = psnr_sum / max(n_total, 1)
+    if reg is None:
+        reg = regularization(torch.cat(verts, 0), gaussians, opt, static) if verts else torch.zeros((), device=dev)
+    loss = image_loss + (reg / world if dist_mode else reg)
     if loss.requires_grad:
         loss.backward(gradient=_root_one(loss))
-    viewspace_grad, radii, visibility_filter = step_stats([v.grad for v in vsp_l], [r.reshape(-1) for r in radii_l], P, dev,
-                                                          gaussians.face_bary.dtype)
+    if vsp_l:
+        viewspace_grad = torch.stack([v.grad for v in vsp_l]).sum(0) if len(vsp_l) > 1 else vsp_l[0].grad.clone()
+    else:
+        viewspace_grad = torch.zeros(P, 3, dtype=gaussians.face_bary.dtype, device=dev)
+    psnr_ = psnr_sum / max(n_total, 1)
     loss_value = loss.detach()
     with torch.no_grad():
         if dist_mode:
@@ -583,7 +518,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             viewspace_grad = fg.tail[:3 * P].view(P, 3).clone()
             psnr_, loss_value = fg.tail[3 * P].double(), fg.tail[3 * P + 1].clone()
             radii = slots.max(dim=0).values.to(radii.dtype)   # train_utils.py:276-277 over all ranks' cameras
-            visibility_filter = radii > 0        # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
+        visibility_filter = radii > 0            # == torch.cat(vis_l).any(dim=0): some camera sees it <=> its largest radius > 0
         if densify_opt is not None and iteration < densify_opt.densify_until_iter:      # train_utils.py:295-304
             densification(gaussians, iteration, visibility_filter, radii, viewspace_grad, densify_opt,
                           getattr(densify_opt, "cameras_extent", 1.0))
@@ -592,13 +527,10 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
                 gaussians.reset_opacity()
         if densify_opt is not None and getattr(densify_opt, "bary_cleanup", 0) and iteration % densify_opt.bary_cleanup == 0:
             gaussians.cleanup_barycentric_coordinates()                                  # train_utils.py:306-307
-        # (GroupedAdam.step_now / zero_grad_now: the same step without torch.optim's per-call wrapper; any other optimizer: its own)
-        getattr(gaussians.optimizer, "step_now", gaussians.optimizer.step)()
+        gaussians.optimizer.step()
         if not static:
-            getattr(meshnet_optimizer, "step_now", meshnet_optimizer.step)()
-        zg = getattr(gaussians.optimizer, "zero_grad_now", None)
-        zg() if zg is not None else gaussians.optimizer.zero_grad(set_to_none=True)
-        zg = getattr(meshnet_optimizer, "zero_grad_now", None)
-        zg() if zg is not None else meshnet_optimizer.zero_grad()
+            meshnet_optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+        meshnet_optimizer.zero_grad()
     return psnr_, loss_value, dict(viewspace_grad=viewspace_grad, radii=radii, visibility_filter=visibility_filter,
                                    allreduce_ms=fg.last_allreduce_ms if fg is not None else 0.0)

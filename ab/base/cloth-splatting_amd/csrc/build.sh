@@ -1,0 +1,26 @@
+#!/bin/bash
+# Builds libcsplat.so (gfx950 only) next to this script's parent: cloth-splatting_amd/csplat/libcsplat.so
+# One object per .hip file under csrc/build/ (recompiled when the source, a header or this script is newer), compiled in
+# parallel, then linked.  FORCE=1 rebuilds everything.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../csplat/libcsplat.so"
+OBJ="$HERE/build"
+mkdir -p "$OBJ"
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -Wall -Wno-unused-function"
+pids=()
+objs=()
+for src in "$HERE"/*.hip; do
+    o="$OBJ/$(basename "${src%.hip}").o"
+    objs+=("$o")
+    stale=0
+    if [ -n "$FORCE" ] || [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$0" -nt "$o" ]; then stale=1; fi
+    for h in "$HERE"/*.h "$HERE"/../../include/*.h; do [ "$h" -nt "$o" ] && stale=1; done
+    if [ $stale = 1 ]; then
+        /opt/rocm/bin/hipcc $FLAGS "$@" -c "$src" -o "$o" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
+echo "built $OUT"

@@ -1,0 +1,408 @@
+// csplat_gnn.hip -- MeshNet message-passing data movement for gfx950.
+//
+// Replaces the torch_geometric MessagePassing machinery inside InteractionNetwork.propagate
+// (/root/reference/meshnet/graph_network.py:173-174 gather x_i/x_j, :197 concat, :136 aggr='add';
+// SURVEY.md 2.1 K10-K12).  The [E,3L] concat is never materialised: the first edge-MLP layer is split into
+// node-level products (xa = x W_i^T, xb = x W_j^T, done by rocBLAS on the Python side) and this file's
+// gather-add kernel; the scatter-add is a segmented sum over a CSR-by-destination ordering with a fixed
+// (ascending edge id) order, i.e. deterministic and without float atomics.  All kernels are HBM-bound row
+// movers: 16 B per lane, a row of L floats is read by L/4 consecutive lanes (full 128-B lines at L >= 32).
+#include "csplat_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_count(int64_t E, const int64_t *__restrict__ keys, uint32_t *__restrict__ cnt) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&cnt[keys[e]], 1u);
+}
+__global__ __launch_bounds__(256) void k_rowptr(int N, const uint32_t *__restrict__ incl, int32_t *__restrict__ rowptr) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) rowptr[0] = 0;
+    if (n < N) rowptr[n + 1] = (int32_t)incl[n];
+}
+__global__ __launch_bounds__(256) void k_fill(int64_t E, const int64_t *__restrict__ keys, const int32_t *__restrict__ rowptr,
+                                               uint32_t *__restrict__ cursor, int32_t *__restrict__ perm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const int64_t k = keys[e];
+        const uint32_t slot = atomicAdd(&cursor[k], 1u);
+        perm[rowptr[k] + slot] = (int32_t)e;
+    }
+}
+// each row is put into ascending edge-id order (rows are short: mesh degree), making the summation order fixed
+__global__ __launch_bounds__(256) void k_sort_rows(int N, const int32_t *__restrict__ rowptr, int32_t *__restrict__ perm) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int s = rowptr[n], e = rowptr[n + 1];
+    for (int i = s + 1; i < e; i++) {
+        const int32_t v = perm[i];
+        int j = i - 1;
+        while (j >= s && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+        perm[j + 1] = v;
+    }
+}
+
+// K14: the per-step graph features of the rollout (PyG Cartesian(norm=False) + Distance(norm=False) on the current node
+// positions, /root/reference/train_meshnet_sim.py:152 `graph = transformer(graph)`): one edge per lane
+__global__ __launch_bounds__(256) void k_edge_features(int64_t E, const float *__restrict__ pos, const int64_t *__restrict__ ei,
+                                                        float4 *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int64_t r = ei[e], c = ei[E + e];
+    const float dx = pos[3 * r] - pos[3 * c], dy = pos[3 * r + 1] - pos[3 * c + 1], dz = pos[3 * r + 2] - pos[3 * c + 2];
+    out[e] = make_float4(dx, dy, dz, sqrtf(dx * dx + dy * dy + dz * dz));
+}
+
+// row movers are templated on the per-lane vector: float4 (16 B/lane) when L % 4 == 0, float otherwise
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vrelu(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float vrelu(float a) { return fmaxf(a, 0.f); }
+__device__ __forceinline__ float4 vmask(float4 g, float4 o) {
+    return make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+}
+__device__ __forceinline__ float vmask(float g, float o) { return o > 0.f ? g : 0.f; }
+__device__ __forceinline__ void vzero(float4 &a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(float &a) { a = 0.f; }
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_edge_combine_fwd(int64_t E, int LV, const int64_t *__restrict__ ei,
+                                                           const VT *__restrict__ xa, const VT *__restrict__ xb,
+                                                           const VT *__restrict__ ec, int relu, VT *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * LV) return;
+    const int64_t e = t / LV;
+    const int c = (int)(t - e * LV);
+    const int64_t src = ei[e], dst = ei[E + e];
+    VT r = vadd(vadd(xa[dst * LV + c], xb[src * LV + c]), ec[t]);
+    if (relu) r = vrelu(r);
+    out[t] = r;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_relu_mask(int64_t nv, const VT *__restrict__ g, const VT *__restrict__ out,
+                                                    VT *__restrict__ gm) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nv) gm[t] = vmask(g[t], out[t]);
+}
+
+// agg[n][c] = sum over the row's edges, ascending edge id, plain sequential fp32 adds (== index_add_ on the CPU)
+// compensated (Neumaier) accumulation: acc carries the running fp32 sum, comp the rounding errors of every add; acc + comp is
+// the exact sum to within ~1 ulp whatever the number of terms -- a hub node of an irregular graph collects thousands of
+// messages, where a plain fp32 running sum is off by n * eps (1.5e-4 at n = 2500) and that error then rides through the
+// whole backward.  Order: ascending edge id (fixed), so the result is deterministic.
+__device__ __forceinline__ void kadd(float &acc, float &comp, float v) {
+#pragma clang fp contract(off)
+    const float t = acc + v;
+    comp += fabsf(acc) >= fabsf(v) ? (acc - t) + v : (v - t) + acc;
+    acc = t;
+}
+__device__ __forceinline__ void kadd(float4 &acc, float4 &comp, float4 v) {
+    kadd(acc.x, comp.x, v.x); kadd(acc.y, comp.y, v.y); kadd(acc.z, comp.z, v.z); kadd(acc.w, comp.w, v.w);
+}
+template <typename VT>
+__global__ __launch_bounds__(256) void k_segment_sum(int N, int LV, const VT *__restrict__ msg,
+                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
+                                                      VT *__restrict__ agg) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * LV) return;
+    const int n = (int)(t / LV), c = (int)(t - (int64_t)n * LV);
+    const int s = rowptr[n], e = rowptr[n + 1];
+    VT acc, comp;
+    vzero(acc); vzero(comp);
+    int i = s;
+    for (; i + 4 <= e; i += 4) {  // 4 independent row loads in flight per lane, summed in list order
+        const int p0 = perm[i], p1 = perm[i + 1], p2 = perm[i + 2], p3 = perm[i + 3];
+        const VT v0 = msg[(int64_t)p0 * LV + c], v1 = msg[(int64_t)p1 * LV + c], v2 = msg[(int64_t)p2 * LV + c],
+                 v3 = msg[(int64_t)p3 * LV + c];
+        kadd(acc, comp, v0); kadd(acc, comp, v1); kadd(acc, comp, v2); kadd(acc, comp, v3);
+    }
+    for (; i < e; i++) kadd(acc, comp, msg[(int64_t)perm[i] * LV + c]);
+    agg[t] = vadd(acc, comp);
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_gather_rows(int64_t E, int LV, const VT *__restrict__ rows,
+                                                      const int64_t *__restrict__ keys, VT *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * LV) return;
+    const int64_t e = t / LV;
+    const int c = (int)(t - e * LV);
+    out[t] = rows[keys[e] * LV + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const int64_t *edge_index, float *out) {
+    CSPLAT_REQUIRE(E >= 0 && (E == 0 || (pos && edge_index && out)), "csplat_gnn_edge_features: bad arguments");
+    CSPLAT_REQUIRE(((uintptr_t)out & 15u) == 0, "csplat_gnn_edge_features: out must be 16-byte aligned");
+    if (E == 0) return 0;
+    k_edge_features<<<cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, (float4 *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+size_t csplat_gnn_csr_temp_bytes(int N, int64_t E) {
+    (void)E;
+    return 2 * align256((size_t)(N + 1) * 4) + csplat_scan_temp_bytes(N);
+}
+
+int csplat_gnn_build_csr(void *stream, int N, int64_t E, const int64_t *keys, int32_t *rowptr, int32_t *perm, void *temp) {
+    hipStream_t s = (hipStream_t)stream;
+    CSPLAT_REQUIRE(N > 0 && E >= 0 && E < (int64_t)1 << 31, "csplat_gnn_build_csr: bad sizes");
+    uint32_t *cnt = (uint32_t *)temp;
+    uint32_t *incl = (uint32_t *)((char *)temp + align256((size_t)(N + 1) * 4));
+    void *scan_tmp = (char *)temp + 2 * align256((size_t)(N + 1) * 4);
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)N * 4, s));
+    if (E > 0) { k_count<<<cdiv(E, 256), 256, 0, s>>>(E, keys, cnt); LAUNCH_CHECK(); }
+    if (int rc = csplat_inclusive_scan_u32(s, cnt, incl, N, scan_tmp)) return rc;
+    k_rowptr<<<cdiv(N, 256), 256, 0, s>>>(N, incl, rowptr);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)N * 4, s));
+    if (E > 0) {
+        k_fill<<<cdiv(E, 256), 256, 0, s>>>(E, keys, rowptr, cnt, perm);
+        LAUNCH_CHECK();
+        k_sort_rows<<<cdiv(N, 256), 256, 0, s>>>(N, rowptr, perm);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int csplat_gnn_edge_combine_fwd(void *stream, int N, int64_t E, int L, const int64_t *edge_index, const float *xa,
+                                const float *xb, const float *ec, int relu, float *out) {
+    (void)N;
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
+    if (E == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    if (L % 4 == 0)
+        k_edge_combine_fwd<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E, L / 4, edge_index, (const float4 *)xa,
+                                                                          (const float4 *)xb, (const float4 *)ec, relu,
+                                                                          (float4 *)out);
+    else
+        k_edge_combine_fwd<float><<<cdiv(E * L, 256), 256, 0, s>>>(E, L, edge_index, xa, xb, ec, relu, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *msg, const int32_t *rowptr,
+                           const int32_t *perm, float *agg) {
+    (void)E;
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    if (L % 4 == 0)
+        k_segment_sum<float4><<<cdiv((int64_t)N * (L / 4), 256), 256, 0, s>>>(N, L / 4, (const float4 *)msg, rowptr, perm,
+                                                                              (float4 *)agg);
+    else
+        k_segment_sum<float><<<cdiv((int64_t)N * L, 256), 256, 0, s>>>(N, L, msg, rowptr, perm, agg);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_gnn_edge_combine_bwd(void *stream, int N, int64_t E, int L, const float *g, const float *out, int relu,
+                                const int32_t *rowptr_dst, const int32_t *perm_dst, const int32_t *rowptr_src,
+                                const int32_t *perm_src, float *g_masked, float *dxa, float *dxb) {
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const float *gm = g;
+    if (relu) {
+        if (E > 0) {
+            ProfScope ps(PROF_GNN, s);
+            if (L % 4 == 0)
+                k_relu_mask<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E * (L / 4), (const float4 *)g,
+                                                                           (const float4 *)out, (float4 *)g_masked);
+            else
+                k_relu_mask<float><<<cdiv(E * L, 256), 256, 0, s>>>(E * L, g, out, g_masked);
+            LAUNCH_CHECK();
+        }
+        gm = g_masked;
+    }
+    if (int rc = csplat_gnn_segment_sum(stream, N, E, L, gm, rowptr_dst, perm_dst, dxa)) return rc;
+    return csplat_gnn_segment_sum(stream, N, E, L, gm, rowptr_src, perm_src, dxb);
+}
+
+int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out) {
+    CSPLAT_REQUIRE(L > 0, "latent width must be positive");
+    if (E == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    if (L % 4 == 0)
+        k_gather_rows<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E, L / 4, (const float4 *)rows, keys, (float4 *)out);
+    else
+        k_gather_rows<float><<<cdiv(E * L, 256), 256, 0, s>>>(E, L, rows, keys, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- LayerNorm over 128-wide rows for the TRAINING path of the MeshNet MLPs (nn.LayerNorm(128) after every edge / node MLP,
+// /root/reference/meshnet/graph_network.py:86-97,139-150).  On [E = 3e5, 128] rows the library kernels take 165 us forward and
+// 170 + 177 us backward (two passes: gamma/beta partials, then the input gradient); these are single HBM passes:
+//   forward  y = (x - mean) * rstd * gamma + beta, stats[row] = (mean, rstd)               read 512 B + write 520 B per row
+//   backward dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat)), and per-workgroup partial column sums of
+//            g*xhat (dgamma) and g (dbeta), reduced in a fixed order by a second tiny launch (deterministic)
+// A row = 32 lanes x float4; a wave holds two rows; row statistics by 5 xor-shuffles inside the 32-lane half.
+namespace {
+constexpr int LN_THREADS = 256, LN_ROWS_PER_BLOCK_ITER = LN_THREADS / 32;
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(LN_THREADS) void k_ln128_fwd(int64_t M, const float4 *__restrict__ x, const float4 *__restrict__ gamma,
+                                                           const float4 *__restrict__ beta, float eps, float4 *__restrict__ y,
+                                                           float2 *__restrict__ stats) {
+    const int sub = threadIdx.x & 31;
+    const float4 ga = gamma[sub], be = beta[sub];
+    for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK_ITER + (threadIdx.x >> 5); row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK_ITER) {
+        const float4 v = x[row * 32 + sub];
+        const float mean = half_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 128.f);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        const float var = half_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.f / 128.f);
+        const float rstd = rsqrtf(var + eps);
+        y[row * 32 + sub] = make_float4(d0 * rstd * ga.x + be.x, d1 * rstd * ga.y + be.y, d2 * rstd * ga.z + be.z, d3 * rstd * ga.w + be.w);
+        if (sub == 0) stats[row] = make_float2(mean, rstd);
+    }
+}
+__global__ __launch_bounds__(LN_THREADS) void k_ln128_bwd(int64_t M, const float4 *__restrict__ g, const float4 *__restrict__ x,
+                                                           const float2 *__restrict__ stats, const float4 *__restrict__ gamma,
+                                                           float4 *__restrict__ dx, float4 *__restrict__ part_gamma,
+                                                           float4 *__restrict__ part_beta, float4 *__restrict__ part_dx,
+                                                           const int64_t *__restrict__ g_rows, int x_normalized) {
+    __shared__ float4 s_g[LN_THREADS], s_b[LN_THREADS], s_x[LN_THREADS];
+    const int sub = threadIdx.x & 31;
+    const float4 ga = gamma[sub];
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, ax = ag;
+    for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK_ITER + (threadIdx.x >> 5); row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK_ITER) {
+        const float4 gv = g[(g_rows ? g_rows[row] : row) * 32 + sub], xv = x[row * 32 + sub];
+        const float2 st = stats[row];
+        const float sub_mean = x_normalized ? 0.f : st.x, mul = x_normalized ? 1.f : st.y;   // x_normalized: x already is xhat
+        const float h0 = (xv.x - sub_mean) * mul, h1 = (xv.y - sub_mean) * mul, h2 = (xv.z - sub_mean) * mul, h3 = (xv.w - sub_mean) * mul;
+        const float w0 = gv.x * ga.x, w1 = gv.y * ga.y, w2 = gv.z * ga.z, w3 = gv.w * ga.w;
+        const float m1 = half_sum((w0 + w1) + (w2 + w3)) * (1.f / 128.f);
+        const float m2 = half_sum((w0 * h0 + w1 * h1) + (w2 * h2 + w3 * h3)) * (1.f / 128.f);
+        const float4 dv = make_float4(st.y * (w0 - m1 - h0 * m2), st.y * (w1 - m1 - h1 * m2), st.y * (w2 - m1 - h2 * m2), st.y * (w3 - m1 - h3 * m2));
+        dx[row * 32 + sub] = dv;
+        ax.x += dv.x; ax.y += dv.y; ax.z += dv.z; ax.w += dv.w;
+        ag.x += gv.x * h0; ag.y += gv.y * h1; ag.z += gv.z * h2; ag.w += gv.w * h3;
+        ab.x += gv.x; ab.y += gv.y; ab.z += gv.z; ab.w += gv.w;
+    }
+    s_g[threadIdx.x] = ag; s_b[threadIdx.x] = ab; s_x[threadIdx.x] = ax;
+    __syncthreads();
+    if (threadIdx.x < 32) {   // the block's 8 row-slots, in order
+        float4 tg = s_g[threadIdx.x], tb = s_b[threadIdx.x], tx = s_x[threadIdx.x];
+        for (int k = 1; k < LN_ROWS_PER_BLOCK_ITER; k++) {
+            const float4 a = s_g[k * 32 + threadIdx.x], b = s_b[k * 32 + threadIdx.x], c = s_x[k * 32 + threadIdx.x];
+            tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w; tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
+            tx.x += c.x; tx.y += c.y; tx.z += c.z; tx.w += c.w;
+        }
+        part_gamma[(size_t)blockIdx.x * 32 + threadIdx.x] = tg;
+        part_beta[(size_t)blockIdx.x * 32 + threadIdx.x] = tb;
+        if (part_dx) part_dx[(size_t)blockIdx.x * 32 + threadIdx.x] = tx;
+    }
+}
+// column sums of [nblocks][128] partials: 8 slices of the block range summed in parallel (ascending inside a slice), then the
+// 8 slice sums in order -- a fixed association, independent of scheduling
+__global__ __launch_bounds__(1024) void k_colsum128(int nblocks, const float *__restrict__ pa, const float *__restrict__ pb,
+                                                     float *__restrict__ oa, float *__restrict__ ob) {
+    __shared__ float s_part[8][128];
+    const float *p = blockIdx.x == 0 ? pa : pb;
+    float *o = blockIdx.x == 0 ? oa : ob;
+    if (!p || !o) return;
+    const int col = threadIdx.x & 127, slice = threadIdx.x >> 7;
+    const int per = (nblocks + 7) / 8, b0 = slice * per, b1 = min(nblocks, b0 + per);
+    float acc = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {   // 4 independent loads in flight
+        const float v0 = p[(size_t)b * 128 + col], v1 = p[(size_t)(b + 1) * 128 + col], v2 = p[(size_t)(b + 2) * 128 + col],
+                    v3 = p[(size_t)(b + 3) * 128 + col];
+        acc = (((acc + v0) + v1) + v2) + v3;
+    }
+    for (; b < b1; b++) acc += p[(size_t)b * 128 + col];
+    s_part[slice][col] = acc;
+    __syncthreads();
+    if (slice == 0) {
+        float t = s_part[0][col];
+        for (int k = 1; k < 8; k++) t += s_part[k][col];
+        o[col] = t;
+    }
+}
+// g_out = relu_mask(g, out); partial column sums of g_out (the bias gradient) per workgroup: the ReLU backward and the bias
+// gradient of a Linear + ReLU layer in one pass over the [E, 128] gradient
+__global__ __launch_bounds__(LN_THREADS) void k_relu_mask_bias128(int64_t M, const float4 *__restrict__ g, const float4 *__restrict__ out,
+                                                                   float4 *__restrict__ gm, float4 *__restrict__ part_bias) {
+    __shared__ float4 s_b[LN_THREADS];
+    const int sub = threadIdx.x & 31;
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK_ITER + (threadIdx.x >> 5); row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK_ITER) {
+        float4 gv = g[row * 32 + sub];
+        if (out) { const float4 o = out[row * 32 + sub]; gv = vmask(gv, o); }
+        if (gm) gm[row * 32 + sub] = gv;
+        ab.x += gv.x; ab.y += gv.y; ab.z += gv.z; ab.w += gv.w;
+    }
+    s_b[threadIdx.x] = ab;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float4 tb = s_b[threadIdx.x];
+        for (int k = 1; k < LN_ROWS_PER_BLOCK_ITER; k++) { const float4 b = s_b[k * 32 + threadIdx.x]; tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w; }
+        part_bias[(size_t)blockIdx.x * 32 + threadIdx.x] = tb;
+    }
+}
+int ln_blocks(int64_t M) { const int64_t want = (M + 63) / 64; return (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want)); }
+}  // namespace
+
+extern "C" {
+size_t csplat_ln128_partial_floats(int64_t M) { return (size_t)ln_blocks(M) * 128; }
+
+int csplat_ln128_fwd(void *stream, int64_t M, const float *x, const float *gamma, const float *beta, float eps, float *y, float *stats) {
+    CSPLAT_REQUIRE(M >= 0 && (M == 0 || (x && gamma && beta && y && stats)), "csplat_ln128_fwd: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15u) == 0 && ((uintptr_t)stats & 7u) == 0,
+                   "csplat_ln128_fwd: 16-byte aligned rows");
+    if (M == 0) return 0;
+    k_ln128_fwd<<<ln_blocks(M), LN_THREADS, 0, (hipStream_t)stream>>>(M, (const float4 *)x, (const float4 *)gamma, (const float4 *)beta, eps,
+                                                                     (float4 *)y, (float2 *)stats);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_ln128_bwd(void *stream, int64_t M, const float *g, const float *x, const float *stats, const float *gamma, float *dx,
+                     float *dgamma, float *dbeta, float *dxsum, const int64_t *g_rows, int x_normalized, float *partials) {
+    CSPLAT_REQUIRE(M >= 0 && (M == 0 || (g && x && stats && gamma && dx && dgamma && dbeta && partials)), "csplat_ln128_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        HIP_TRY(hipMemsetAsync(dgamma, 0, 512, s)); HIP_TRY(hipMemsetAsync(dbeta, 0, 512, s));
+        if (dxsum) HIP_TRY(hipMemsetAsync(dxsum, 0, 512, s));
+        return 0;
+    }
+    const int nb = ln_blocks(M);
+    float *pg = partials, *pb = partials + (size_t)nb * 128, *px = dxsum ? partials + (size_t)2 * nb * 128 : nullptr;
+    k_ln128_bwd<<<nb, LN_THREADS, 0, s>>>(M, (const float4 *)g, (const float4 *)x, (const float2 *)stats, (const float4 *)gamma, (float4 *)dx,
+                                          (float4 *)pg, (float4 *)pb, (float4 *)px, g_rows, x_normalized);
+    LAUNCH_CHECK();
+    k_colsum128<<<2, 1024, 0, s>>>(nb, pg, pb, dgamma, dbeta);
+    LAUNCH_CHECK();
+    if (dxsum) {
+        k_colsum128<<<1, 1024, 0, s>>>(nb, px, nullptr, dxsum, nullptr);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+/* gm = out > 0 ? g : 0 (out NULL: gm = g; gm NULL: not written), dbias[c] = sum_rows gm[row][c]; partials: csplat_ln128_partial_floats(M) floats */
+int csplat_relu_mask_bias128(void *stream, int64_t M, const float *g, const float *out, float *gm, float *dbias, float *partials) {
+    CSPLAT_REQUIRE(M >= 0 && (M == 0 || (g && dbias && partials)), "csplat_relu_mask_bias128: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) { HIP_TRY(hipMemsetAsync(dbias, 0, 512, s)); return 0; }
+    const int nb = ln_blocks(M);
+    k_relu_mask_bias128<<<nb, LN_THREADS, 0, s>>>(M, (const float4 *)g, (const float4 *)out, (float4 *)gm, (float4 *)partials);
+    LAUNCH_CHECK();
+    k_colsum128<<<1, 1024, 0, s>>>(nb, partials, nullptr, dbias, nullptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+}  // extern "C"

@@ -171,183 +171,6 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_ssim_bwd(int H, int W, Taps ta
     }
 }
 
-// ---- the WHOLE image loss of a train step in one launch each way (train_utils.py:50-74 + the PSNR the reference logs every step,
-// :262-283): Ll1 + lambda (1 - SSIM) [masked: mean|(x - y) m| + lambda mean((1 - S) m)], the per-camera PSNR, and -- optionally -- the
-// sum with another device scalar (the regularisers), so that the loss the step differentiates leaves the library finished.  k_ssim_fwd's
-// tile already holds x and y: the L1 term, the sign byte of its gradient and the squared error ride on the third phase.  Workgroup
-// partials (3 floats) are summed in index order by k_image_loss_finish: bit-reproducible, no float atomics.
-// Replaces k_l1 + k_psnr + k_ssim_fwd and eight stock reductions / elementwise launches.
-__global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
-                                                         float *__restrict__ P1, float *__restrict__ P2, float *__restrict__ P3,
-                                                         signed char *__restrict__ sign8, const float *__restrict__ mask, int mask_channels,
-                                                         int channels, float *__restrict__ partial) {
-    __shared__ float s_x[(BH + 2 * R5)][BW + 2 * R5 + 1];
-    __shared__ float s_y[(BH + 2 * R5)][BW + 2 * R5 + 1];
-    __shared__ float s_h[5][(BH + 2 * R5)][BW + 1];
-    __shared__ float s_red[3][SSIM_THREADS / 64];
-    const size_t img = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += SSIM_THREADS) {
-        const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
-        const int y = y0 + ry - R5, x = x0 + rx - R5;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        s_x[ry][rx] = in ? X[img + (size_t)y * W + x] : 0.f;
-        s_y[ry][rx] = in ? Y[img + (size_t)y * W + x] : 0.f;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = taps.w[k], xv = s_x[ry][rx + k], yv = s_y[ry][rx + k];
-            a0 += w * xv; a1 += w * yv; a2 += w * (xv * xv); a3 += w * (yv * yv); a4 += w * (xv * yv);
-        }
-        s_h[0][ry][rx] = a0; s_h[1][ry][rx] = a1; s_h[2][ry][rx] = a2; s_h[3][ry][rx] = a3; s_h[4][ry][rx] = a4;
-    }
-    __syncthreads();
-    float acc_s = 0.f, acc_l = 0.f, acc_q = 0.f;
-    for (int t = threadIdx.x; t < BH * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        const int y = y0 + ry, x = x0 + rx;
-        if (y < H && x < W) {
-            float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float w = taps.w[k];
-                mu1 += w * s_h[0][ry + k][rx]; mu2 += w * s_h[1][ry + k][rx]; s11 += w * s_h[2][ry + k][rx];
-                s22 += w * s_h[3][ry + k][rx]; s12 += w * s_h[4][ry + k][rx];
-            }
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * (s12 - mu12) + SSIM_C2;
-            const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = (s11 - mu1_sq) + (s22 - mu2_sq) + SSIM_C2;
-            const float inv = 1.f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            const size_t o = img + (size_t)y * W + x;
-            float m = 1.f;
-            if (mask) {
-                const size_t plane = mask_channels == 1 ? blockIdx.z / channels : blockIdx.z;
-                m = mask[(plane * H + y) * W + x];
-                acc_s += (1.f - S) * m;
-            } else acc_s += S;
-            const float d0 = s_x[ry + R5][rx + R5] - s_y[ry + R5][rx + R5];
-            const float d = d0 * m;                               // (utils/loss_utils.py:21-22: |(x - y) m|; the PSNR is unmasked)
-            acc_l += fabsf(d);
-            acc_q += d0 * d0;
-            if (sign8) sign8[o] = (signed char)(d > 0.f ? 1 : (d < 0.f ? -1 : 0));
-            if (P1) {
-                P1[o] = m * (2.f * mu2 * (A2 - A1) * inv - S * 2.f * mu1 * (B2 - B1) * inv);
-                P2[o] = m * (-S / B2);
-                P3[o] = m * (2.f * A1 * inv);
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { acc_s += __shfl_xor(acc_s, o, 64); acc_l += __shfl_xor(acc_l, o, 64); acc_q += __shfl_xor(acc_q, o, 64); }
-    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = acc_s; s_red[1][threadIdx.x >> 6] = acc_l; s_red[2][threadIdx.x >> 6] = acc_q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const size_t nwg = (size_t)gridDim.y * gridDim.x * gridDim.z;
-        const size_t me = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        for (int q = 0; q < 3; q++) {
-            float t_ = 0.f;
-            for (int k = 0; k < SSIM_THREADS / 64; k++) t_ += s_red[q][k];
-            partial[q * nwg + me] = t_;
-        }
-    }
-}
-
-// the second (one-workgroup) launch of the image loss: sums the workgroup partials in index order.  NOT a ticket in the kernel above:
-// a device-scope release on gfx950 writes the XCD's dirty L2 lines back, and ~6000 workgroups each fencing while all of them stream the
-// three partial-derivative images out cost 4x the kernel itself (measured 268-351 us against 75 + 4 for the two launches).
-__global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_finish(size_t per_plane, int planes, int channels, int H, int W, int masked, float lam,
-                                                            float img_weight, const float *__restrict__ add, float add_weight,
-                                                            float psnr_scale, const float *__restrict__ partial, float *__restrict__ out) {
-    __shared__ float s_red[SSIM_THREADS / 64];
-    const size_t nwg = per_plane * planes;
-    auto block_sum = [&](const float *p, size_t lo, size_t hi) -> float {     // fixed-order sum of p[lo, hi)
-        float t = 0.f;
-        for (size_t i = lo + threadIdx.x; i < hi; i += SSIM_THREADS) t += p[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
-        __syncthreads();
-        float r = 0.f;
-        for (int k = 0; k < SSIM_THREADS / 64; k++) r += s_red[k];
-        return r;
-    };
-    const float ssim_sum = block_sum(partial, 0, nwg);
-    const float l1_sum = block_sum(partial + nwg, 0, nwg);
-    const int n_batch = planes / channels;
-    float psnr_sum = 0.f;
-    for (int b = 0; b < n_batch; b++) {
-        const float q = block_sum(partial + 2 * nwg, (size_t)b * channels * per_plane, (size_t)(b + 1) * channels * per_plane);
-        const float mse = q / ((float)channels * (float)H * (float)W);
-        psnr_sum += 20.f * log10f(1.f / sqrtf(mse));
-    }
-    if (threadIdx.x == 0) {
-        const float n = (float)planes * (float)H * (float)W;
-        const float l1 = l1_sum / n;
-        const float image_loss = masked ? l1 + lam * (ssim_sum / n) : l1 + lam * (1.f - ssim_sum / n);
-        out[0] = img_weight * image_loss + (add ? add_weight * add[0] : 0.f);
-        out[1] = psnr_scale * psnr_sum;
-        out[2] = image_loss;
-        out[3] = l1;
-    }
-}
-
-// backward of k_image_loss_fwd: dX = g w / n * (sign m - lambda (blur(P1) + 2 x blur(P2) + y blur(P3)))   (P* carry the mask already)
-__global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
-                                                         const float *__restrict__ P1, const float *__restrict__ P2,
-                                                         const float *__restrict__ P3, const signed char *__restrict__ sign8,
-                                                         const float *__restrict__ mask, int mask_channels, int channels,
-                                                         const float *__restrict__ gscalar, float g_l1, float g_ssim, float *__restrict__ dX) {
-    __shared__ float s_p[3][(BH + 2 * R5)][BW + 2 * R5 + 1];
-    __shared__ float s_h[3][(BH + 2 * R5)][BW + 1];
-    const size_t img = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += SSIM_THREADS) {
-        const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
-        const int y = y0 + ry - R5, x = x0 + rx - R5;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const size_t o = img + (size_t)y * W + x;
-        s_p[0][ry][rx] = in ? P1[o] : 0.f; s_p[1][ry][rx] = in ? P2[o] : 0.f; s_p[2][ry][rx] = in ? P3[o] : 0.f;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = taps.w[k];
-            a0 += w * s_p[0][ry][rx + k]; a1 += w * s_p[1][ry][rx + k]; a2 += w * s_p[2][ry][rx + k];
-        }
-        s_h[0][ry][rx] = a0; s_h[1][ry][rx] = a1; s_h[2][ry][rx] = a2;
-    }
-    __syncthreads();
-    const float gs = gscalar[0] * g_ssim, gl = gscalar[0] * g_l1;
-    for (int t = threadIdx.x; t < BH * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        const int y = y0 + ry, x = x0 + rx;
-        if (y < H && x < W) {
-            float b1 = 0.f, b2 = 0.f, b3 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float w = taps.w[k];
-                b1 += w * s_h[0][ry + k][rx]; b2 += w * s_h[1][ry + k][rx]; b3 += w * s_h[2][ry + k][rx];
-            }
-            const size_t o = img + (size_t)y * W + x;
-            float m = 1.f;
-            if (mask) {
-                const size_t plane = mask_channels == 1 ? blockIdx.z / channels : blockIdx.z;
-                m = mask[(plane * H + y) * W + x];
-            }
-            dX[o] = gs * (b1 + 2.f * X[o] * b2 + Y[o] * b3) + gl * (float)sign8[o] * m;
-        }
-    }
-}
-
 // ---- fused L1 loss: mean |a - b| and its gradient sign(a - b) / n in ONE pass (utils/loss_utils.py:20-23 is three
 // elementwise launches forward and three backward).  Deterministic: workgroup partials are summed in index order by
 // whichever workgroup finishes last (ticket counter), not with float atomics.
@@ -597,48 +420,6 @@ extern "C" int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, con
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)n_images);
     CSPLAT_REQUIRE((addend == nullptr) == (add_scale == nullptr), "csplat_ssim_bwd: addend and add_scale go together");
     k_ssim_bwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, g_scalar, inv_n, addend, add_scale, dx);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-// image loss of a train step (k_image_loss_fwd + k_image_loss_finish / k_image_loss_bwd).  out[4] = {img_weight * image_loss +
-// add_weight * add[0], psnr_scale * sum_b PSNR_b, image_loss, Ll1}; scratch: csplat_image_loss_scratch_bytes (no initial state).
-// p1..p3 / sign8 may be NULL when no gradient will be asked for.
-extern "C" size_t csplat_image_loss_scratch_bytes(int64_t n_batch, int channels, int H, int W) {
-    const size_t planes = (size_t)(n_batch > 0 ? n_batch : 1) * channels;
-    return align256(3 * planes * cdiv(H, BH) * cdiv(W, BW) * 4);      // [3][workgroups] partial sums
-}
-extern "C" int csplat_image_loss_fwd(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
-                                     const float *y, const float *mask, int mask_channels, float lam, float img_weight, const float *add,
-                                     float add_weight, float psnr_scale, float *p1, float *p2, float *p3, signed char *sign8, void *scratch,
-                                     float *out) {
-    CSPLAT_REQUIRE(n_batch > 0 && channels > 0 && n_batch * channels < 65536 && H > 0 && W > 0 && taps11 && x && y && scratch && out,
-                   "csplat_image_loss_fwd: bad arguments");
-    CSPLAT_REQUIRE((p1 != nullptr) == (p2 != nullptr) && (p1 != nullptr) == (p3 != nullptr) && (p1 != nullptr) == (sign8 != nullptr),
-                   "csplat_image_loss_fwd: the three partials and the sign bytes go together");
-    CSPLAT_REQUIRE(!mask || mask_channels == 1 || mask_channels == channels, "csplat_image_loss_fwd: the mask has 1 plane per image or one per channel");
-    Taps t;
-    memcpy(t.w, taps11, sizeof(t.w));
-    dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)(n_batch * channels));
-    float *partial = (float *)scratch;
-    k_image_loss_fwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, sign8, mask, mask ? mask_channels : 1, channels, partial);
-    LAUNCH_CHECK();
-    k_image_loss_finish<<<1, SSIM_THREADS, 0, (hipStream_t)stream>>>((size_t)grid.x * grid.y, (int)grid.z, channels, H, W, mask ? 1 : 0, lam, img_weight,
-                                                                     add, add_weight, psnr_scale, partial, out);
-    LAUNCH_CHECK();
-    return 0;
-}
-extern "C" int csplat_image_loss_bwd(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
-                                     const float *y, const float *p1, const float *p2, const float *p3, const signed char *sign8,
-                                     const float *mask, int mask_channels, float lam, float img_weight, const float *g_scalar, float *dx) {
-    CSPLAT_REQUIRE(n_batch > 0 && channels > 0 && n_batch * channels < 65536 && H > 0 && W > 0 && taps11 && x && y && p1 && p2 && p3 &&
-                   sign8 && g_scalar && dx, "csplat_image_loss_bwd: bad arguments");
-    Taps t;
-    memcpy(t.w, taps11, sizeof(t.w));
-    dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)(n_batch * channels));
-    const float inv_n = 1.0f / ((float)(n_batch * channels) * (float)H * (float)W);
-    k_image_loss_bwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, sign8, mask, mask ? mask_channels : 1, channels, g_scalar,
-                                                                      img_weight * inv_n, -lam * img_weight * inv_n, dx);
     LAUNCH_CHECK();
     return 0;
 }

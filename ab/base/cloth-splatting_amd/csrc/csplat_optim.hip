@@ -182,47 +182,3 @@ extern "C" int csplat_gauss_act_bwd(void *stream, int64_t P, const float *opacit
     LAUNCH_CHECK();
     return 0;
 }
-
-// ---- the densification statistics of a training step in ONE launch (scene_reconstruction/train_utils.py:276-285: radii =
-// cat(radii_list).max(0), visibility = cat(filters).any(0), viewspace gradient = sum over the step's cameras): as torch ops two cats,
-// two reductions and a compare.  V <= CSPLAT_STATS_MAX_VIEWS views: their screen-space gradients [P][3] are summed in view order,
-// the radii [P] take the maximum, visible = max > 0.
-namespace {
-constexpr int STATS_MAX_VIEWS = 16;
-struct StatsTable { const float *g[STATS_MAX_VIEWS]; const int *r[STATS_MAX_VIEWS]; };
-__global__ __launch_bounds__(256) void k_step_stats(int64_t P, int V, StatsTable tab, float *__restrict__ grad_sum, int *__restrict__ radii_max,
-                                                    uint8_t *__restrict__ visible) {
-    const int64_t n = 3 * P;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (grad_sum) {
-            float s = tab.g[0] ? tab.g[0][i] : 0.f;
-            for (int v = 1; v < V; v++) s += tab.g[v] ? tab.g[v][i] : 0.f;
-            grad_sum[i] = s;
-        }
-        if (i < P && radii_max) {
-            int m = tab.r[0][i];
-            for (int v = 1; v < V; v++) m = max(m, tab.r[v][i]);
-            radii_max[i] = m;
-            if (visible) visible[i] = m > 0 ? 1 : 0;
-        }
-    }
-}
-}  // namespace
-
-extern "C" int csplat_step_stats(void *stream, int64_t P, int V, const float *const *mean2d_grads, const int *const *radii, float *grad_sum,
-                                 int *radii_max, uint8_t *visible) {
-    CSPLAT_REQUIRE(P >= 0 && V >= 1 && V <= STATS_MAX_VIEWS, "csplat_step_stats: 1 <= V <= 16 views");
-    CSPLAT_REQUIRE((grad_sum == nullptr || mean2d_grads) && (radii_max == nullptr || radii) && (visible == nullptr || radii_max),
-                   "csplat_step_stats: bad arguments");
-    if (P == 0) return 0;
-    StatsTable tab;
-    memset(&tab, 0, sizeof(tab));
-    for (int v = 0; v < V; v++) {
-        if (grad_sum) tab.g[v] = mean2d_grads[v];          // (a NULL entry = a view without a gradient: counts as zero)
-        if (radii_max) { CSPLAT_REQUIRE(radii[v], "csplat_step_stats: NULL radii"); tab.r[v] = radii[v]; }
-    }
-    const int64_t work = (3 * P + 255) / 256;
-    k_step_stats<<<(int)(work > 4096 ? 4096 : work), 256, 0, (hipStream_t)stream>>>(P, V, tab, grad_sum, radii_max, visible);
-    LAUNCH_CHECK();
-    return 0;
-}

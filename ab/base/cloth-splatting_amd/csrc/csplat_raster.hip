@@ -1078,11 +1078,6 @@ struct BlockStreamT {
         m16 = masks; hi = hi_; blk = blk_; lane = lane_; ring = ring_; cbase = lo; tail = 0;
         m_next = load(lo);
     }
-    // (the caller has already requested the first chunk: first = load(lo))
-    __device__ __forceinline__ void start(const uint16_t *masks, int lo, int hi_, int blk_, int lane_, int *ring_, uint32_t first) {
-        m16 = masks; hi = hi_; blk = blk_; lane = lane_; ring = ring_; cbase = lo; tail = 0;
-        m_next = first;
-    }
     __device__ __forceinline__ void ingest() {   // one chunk
         const uint32_t m = m_next;
         m_next = load(cbase + 64);
@@ -1450,9 +1445,7 @@ __device__ __forceinline__ float bfly(float a, float b, bool s) {
 // and all id loads are issued before the first atomic, so the wave waits for ONE memory round trip instead of one per round
 template <bool DET, bool CLEAR = false>
 __device__ __forceinline__ void flush_segment(float *s_acc, int cnt, int w, int lane, int quad, uint32_t first,
-                                              const uint32_t *__restrict__ ids_sorted, float *__restrict__ acc, float *__restrict__ det,
-                                              const uint32_t *lds_ids = nullptr) {
-    // lds_ids: the segment's ids already staged in LDS by the caller (entry e at lds_ids[e]) -- the flush is then LDS reads -> atomics
+                                              const uint32_t *__restrict__ ids_sorted, float *__restrict__ acc, float *__restrict__ det) {
     const int sub = lane / 9, tq = lane - sub * 9;
     constexpr int ROUNDS = (SEG + 27) / 28;
     float sv_[ROUNDS];
@@ -1467,7 +1460,7 @@ __device__ __forceinline__ void flush_segment(float *s_acc, int cnt, int w, int 
         } else {
             sv_[k] = ok ? s_acc[e * 9 + tq] : 0.f;
             if (CLEAR && sv_[k] != 0.f) s_acc[e * 9 + tq] = 0.f;       // (the thread that read a cell leaves it clean for the segment after next)
-            id_[k] = sv_[k] != 0.f ? (lds_ids ? lds_ids[e] : ids_sorted[first + e]) : 0xFFFFFFFFu;
+            id_[k] = sv_[k] != 0.f ? ids_sorted[first + e] : 0xFFFFFFFFu;
         }
     }
 #pragma unroll
@@ -1498,7 +1491,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                                                    unsigned long long *stamp = nullptr, int barrier_flush = 0) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING];
-    __shared__ uint32_t s_ids[DET ? 1 : SEG];   // the segment's Gaussian ids, for the flush
     __shared__ int s_done;
     const int wg = blockIdx.x;
     // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
@@ -1533,36 +1525,19 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     if ((int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])) <= seg_lo) return;   // (workgroup-uniform)
     const int wave_hi = min(seg_hi, (int)blk_hi[blk]);                  // no pixel of the block blends an entry at or behind it
     mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi) has returned
-    // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint, the first chunk of
-    // masks and (one per thread) the ids the flush will need are requested together, BEFORE the records are zeroed and the barrier
-    // (tools/k7_stamps.py: these were three dependent round trips, ~8 k cycles of a live wave's ~46 k)
-    const bool live = wave_hi > seg_lo;
-    const size_t HW = (size_t)H * W;
-    int ncontrib = 0;
-    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, oc0 = 0.f, oc1 = 0.f, oc2 = 0.f;
-    float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);
-    uint32_t m_first = 0u;
-    if (live) {
-        if (inside) {
-            ncontrib = (int)n_contrib[pix];
-            dp0 = dL_dpix[pix]; dp1 = dL_dpix[HW + pix]; dp2 = dL_dpix[2 * HW + pix];
-            oc0 = out_color[pix]; oc1 = out_color[HW + pix]; oc2 = out_color[2 * HW + pix];
-        }
-        ck = ckpt[(size_t)slot * 256 + blk * 16 + l16];
-        m_first = seg_lo + lane < wave_hi ? (uint32_t)mask16[rx + seg_lo + lane] : 0u;
-    }
-    uint32_t my_id = 0u;
-    if (!DET && seg_lo + (int)threadIdx.x < seg_hi) my_id = ids_sorted[rx + seg_lo + threadIdx.x];
+    const int ncontrib = inside ? (int)n_contrib[pix] : 0;
     for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
     if (threadIdx.x == 0) s_done = 0;
-    if (!DET) s_ids[threadIdx.x] = my_id;
     __syncthreads();
     mark(2);
     float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
-    if (live) {
-        const float OD = oc0 * dp0 + oc1 * dp1 + oc2 * dp2;
+    if (wave_hi > seg_lo) {
+        const size_t HW = (size_t)H * W;
+        const float dp0 = inside ? dL_dpix[pix] : 0.f, dp1 = inside ? dL_dpix[HW + pix] : 0.f, dp2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
+        const float OD = inside ? out_color[pix] * dp0 + out_color[HW + pix] * dp1 + out_color[2 * HW + pix] * dp2 : 0.f;
         float T = 1.f, S = 0.f;
         if (ncontrib > seg_lo) {
+            const float4 ck = ckpt[(size_t)slot * 256 + blk * 16 + l16];
             T = ck.x;
             S = ck.y * dp0 + ck.z * dp1 + ck.w * dp2;
         }
@@ -1574,7 +1549,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         const bool red_active = !lb0 || l16 == 1;
         const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
         BlockStream st;
-        st.start(mask16 + rx, seg_lo, wave_hi, blk, lane, s_ring[w], m_first);
+        st.start(mask16 + rx, seg_lo, wave_hi, blk, lane, s_ring[w]);
         auto fetch = [&](Trip &t, int k) -> bool {
             if (!st.group(k, r, t.pos)) return false;
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
@@ -1653,7 +1628,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         __syncthreads();
         mark(6);
         // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
-        flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det, DET ? nullptr : s_ids);
+        flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
     } else {
         // csplat_debug_flags bit 16 (an experiment that did NOT pay, kept for A/B): no barrier at the end.  The blocks of a quadrant
         // finish ~10 k cycles apart (tools/k7_stamps.py: a quarter of a live wave's life is this wait) -- here a wave that is done
@@ -1668,7 +1643,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         mark(6);
         for (int vw = 0; vw < 4; vw++)
-            flush_segment<DET>(s_acc, seg_hi - seg_lo, vw, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det, DET ? nullptr : s_ids);
+            flush_segment<DET>(s_acc, seg_hi - seg_lo, vw, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
     }
     mark(7);
     if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)(wave_hi > seg_lo ? wave_hi - seg_lo : 0); my_stamp[9] = 1ull; }

@@ -26,8 +26,7 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a
 
 template <int T>
 __global__ __launch_bounds__(256) void k_rows_dot_fwd(int R, const float4 *__restrict__ W, const float *__restrict__ b,
-                                                      const float4 *__restrict__ h, float *__restrict__ y,
-                                                      const float *__restrict__ add) {
+                                                      const float4 *__restrict__ h, float *__restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     float4 hr[T];
@@ -42,10 +41,7 @@ __global__ __launch_bounds__(256) void k_rows_dot_fwd(int R, const float4 *__res
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 const float s = wave_sum(dot4(w[j], hr[t]));
-                if (lane == 0 && r0 + j < R) {      // (+ add: the simulator's table row, meshnet_network.py:371 `mesh_predictions[t] + residual`)
-                    const float v = s + b[r0 + j];
-                    y[(size_t)t * R + r0 + j] = add ? add[(size_t)t * R + r0 + j] + v : v;
-                }
+                if (lane == 0 && r0 + j < R) y[(size_t)t * R + r0 + j] = s + b[r0 + j];
             }
         }
     }
@@ -315,8 +311,8 @@ __global__ __launch_bounds__(256) void k_cloth_regs_csr(int T, int V, long long 
 }
 
 template <int T>
-int launch_fwd(hipStream_t s, int R, const float *W, const float *b, const float *h, float *y, const float *add) {
-    k_rows_dot_fwd<T><<<SIM_BLOCKS, 256, 0, s>>>(R, (const float4 *)W, b, (const float4 *)h, y, add);
+int launch_fwd(hipStream_t s, int R, const float *W, const float *b, const float *h, float *y) {
+    k_rows_dot_fwd<T><<<SIM_BLOCKS, 256, 0, s>>>(R, (const float4 *)W, b, (const float4 *)h, y);
     LAUNCH_CHECK();
     return 0;
 }
@@ -445,21 +441,21 @@ extern "C" {
 
 size_t csplat_rows_dot_scratch_bytes(int T) { return align256((size_t)SIM_BLOCKS * (T > 0 ? T : 1) * SIM_K * sizeof(float)); }
 
-int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y, const float *add) {
+int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y) {
     CSPLAT_REQUIRE(K == SIM_K, "csplat_rows_dot_fwd: K must be 256");
     CSPLAT_REQUIRE(T >= 0 && T <= SIM_TMAX && R >= 0, "csplat_rows_dot_fwd: T must be 0..8, R >= 0");
     if (T == 0 || R == 0) return 0;
     CSPLAT_REQUIRE(W && b && h && y, "csplat_rows_dot_fwd: NULL");
     hipStream_t s = (hipStream_t)stream;
     switch (T) {
-        case 1: return launch_fwd<1>(s, R, W, b, h, y, add);
-        case 2: return launch_fwd<2>(s, R, W, b, h, y, add);
-        case 3: return launch_fwd<3>(s, R, W, b, h, y, add);
-        case 4: return launch_fwd<4>(s, R, W, b, h, y, add);
-        case 5: return launch_fwd<5>(s, R, W, b, h, y, add);
-        case 6: return launch_fwd<6>(s, R, W, b, h, y, add);
-        case 7: return launch_fwd<7>(s, R, W, b, h, y, add);
-        default: return launch_fwd<8>(s, R, W, b, h, y, add);
+        case 1: return launch_fwd<1>(s, R, W, b, h, y);
+        case 2: return launch_fwd<2>(s, R, W, b, h, y);
+        case 3: return launch_fwd<3>(s, R, W, b, h, y);
+        case 4: return launch_fwd<4>(s, R, W, b, h, y);
+        case 5: return launch_fwd<5>(s, R, W, b, h, y);
+        case 6: return launch_fwd<6>(s, R, W, b, h, y);
+        case 7: return launch_fwd<7>(s, R, W, b, h, y);
+        default: return launch_fwd<8>(s, R, W, b, h, y);
     }
 }
 
@@ -511,9 +507,11 @@ int csplat_cloth_regs(void *stream, int T, int V, int64_t E, const float *D, con
     const int64_t items = (int64_t)V + (edge_terms ? (int64_t)T * E : 0);
     const int blocks = cdiv(items, 256);
     float *partial = (float *)scratch;
-    // the ticket word sits behind all partials, in the last 256 bytes: ZERO on entry (the caller zeroes the scratch once), left at zero
-    unsigned int *ticket = (unsigned int *)((char *)scratch + csplat_cloth_regs_scratch_bytes(T, V, E) - 256);
+    unsigned int *ticket = (unsigned int *)((char *)scratch + align256((size_t)(blocks + 1) * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), s));
     if (csr) {
+        ticket = (unsigned int *)((char *)scratch + csplat_cloth_regs_scratch_bytes(T, V, E) - 256);   // behind all partials
+        HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), s));
         k_cloth_regs_csr<<<dim3(cdiv(V, 256), T), 256, 0, s>>>(
             T, V, (long long)E, D, edge_index, rest_len, dst_rowptr, dst_perm, src_rowptr, src_perm,
             node_terms && lambda_deform != 0.f ? 0.5f * lambda_deform / (float)V : 0.f,

@@ -1,0 +1,388 @@
+"""Drop-in for `diff_gaussian_rasterization` (the depth fork), MI355X-native.
+
+Mirrors the interface the reference binds at gaussian_renderer/__init__.py:16 and calls at :61-76,156-164:
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+                                  projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                        scales=None, rotations=None, cov3D_precomp=None) -> (color, radii, depth)
+Gradients are delivered for means3D, means2D (NDC-space screen gradient used by densification,
+scene_reconstruction/train_utils.py:290-292), shs, colors_precomp, opacities, scales, rotations, cov3D_precomp.
+The depth image carries no gradient (as upstream).  All compute is in libcsplat.so (csplat_forward_begin / _finish / csplat_backward).
+`rasterize_views` renders several independent views in one call, one HIP stream per view.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from csplat import native as _n
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t, device):
+    if t is None:
+        return None
+    if t.device != device or t.dtype != torch.float32:
+        t = t.to(device=device, dtype=torch.float32)
+    return t.contiguous()
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _View:
+    """Everything one view's forward produces and its backward needs (host side of csplat_forward_begin / _finish)."""
+
+    def __init__(self, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+        _n.require_cuda(means3D)
+        dev = self.dev = means3D.device
+        self.rs = rs
+        self.P = int(means3D.shape[0])
+        self.H, self.W = int(rs.image_height), int(rs.image_width)
+        self.means3D = _f32c(means3D, dev); self.opacities = _f32c(opacities, dev)
+        self.sh = _f32c(sh, dev)
+        self.colors_precomp = _f32c(colors_precomp, dev)
+        self.scales = _f32c(scales, dev)
+        self.rotations = _f32c(rotations, dev)
+        self.cov3Ds_precomp = _f32c(cov3Ds_precomp, dev)
+        self.bg = _f32c(rs.bg, dev); self.view = _f32c(rs.viewmatrix, dev); self.proj = _f32c(rs.projmatrix, dev)
+        self.campos = _f32c(rs.campos, dev)
+        self.M = int(self.sh.shape[1]) if self.sh is not None else 0
+        self.ticket = None
+
+    def inputs(self):
+        return [t for t in (self.means3D, self.sh, self.colors_precomp, self.opacities, self.scales, self.rotations,
+                            self.cov3Ds_precomp, self.bg, self.view, self.proj, self.campos) if t is not None]
+
+    def begin(self):
+        """K1 + the counting half of the binning on the CURRENT stream; nothing here waits for the GPU."""
+        dev, rs = self.dev, self.rs
+        self.color = torch.empty(3, self.H, self.W, dtype=torch.float32, device=dev)
+        self.depth = torch.empty(1, self.H, self.W, dtype=torch.float32, device=dev)
+        self.radii = torch.empty(self.P, dtype=torch.int32, device=dev)
+        self.alloc = _n.ChunkAllocator(dev)
+        tk = C.c_int(-1)
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_forward_begin(
+                _n.stream_handle(dev), self.P, int(rs.sh_degree), self.M, _n.ptr(self.bg), self.W, self.H,
+                _n.ptr(self.means3D), _n.ptr(self.sh), _n.ptr(self.colors_precomp), _n.ptr(self.opacities),
+                _n.ptr(self.scales), float(rs.scale_modifier), _n.ptr(self.rotations), _n.ptr(self.cov3Ds_precomp),
+                _n.ptr(self.view), _n.ptr(self.proj), _n.ptr(self.campos), float(rs.tanfovx), float(rs.tanfovy),
+                int(bool(rs.prefiltered)), self.alloc.cb, None, _n.ptr(self.radii), C.byref(tk))
+        _n.check(rc, "csplat_forward_begin")
+        self.ticket = int(tk.value)
+
+    def finish(self):
+        """reads num_rendered (the one host round trip), allocates the R-sized chunks, K3..K6 on the begin() stream"""
+        R = C.c_int(0)
+        geom, binning, image = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        with torch.cuda.device(self.dev):
+            rc = _n.lib.csplat_forward_finish(self.ticket, _n.ptr(self.color), _n.ptr(self.depth), C.byref(R),
+                                              C.byref(geom), C.byref(binning), C.byref(image))
+        self.ticket = None
+        _n.check(rc, "csplat_forward_finish")
+        self.num_rendered = int(R.value)
+        ch = self.alloc.chunks
+        self.chunks = (ch[_n_GEOM], ch[_n_BINNING], ch[_n_IMAGE])
+        self.alloc.cb = None  # break the allocator <-> callback cycle: TEMP / TABLE die here, not at the next cyclic GC
+        self.alloc = None
+
+    def backward(self, grad_color, saved):
+        """K7 + K8 on the CURRENT stream; returns the per-input gradients in the Function's argument order."""
+        means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color = saved
+        rs, dev, P, M = self.rs, self.dev, self.P, self.M
+        geom, binning, image = self.chunks
+        grad_color = _f32c(grad_color, dev)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        d_mean2D, d_conic, d_opac, d_color = new(P, 3), new(P, 4), new(P, 1), new(P, 3)
+        d_mean3D, d_cov3D = new(P, 3), new(P, 6)
+        d_sh = new(P, M, 3) if sh is not None else None
+        d_scale = new(P, 3) if scales is not None else None
+        d_rot = new(P, 4) if rotations is not None else None
+        scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, self.num_rendered)), 256), dtype=torch.uint8,
+                              device=dev)
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_backward(
+                _n.stream_handle(dev), P, int(rs.sh_degree), M, self.num_rendered, _n.ptr(self.bg), self.W, self.H,
+                _n.ptr(means3D), _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(scales), float(rs.scale_modifier),
+                _n.ptr(rotations), _n.ptr(cov3Ds_precomp), _n.ptr(self.view), _n.ptr(self.proj), _n.ptr(self.campos),
+                float(rs.tanfovx), float(rs.tanfovy), _n.ptr(radii), _n.ptr(geom), _n.ptr(binning), _n.ptr(image),
+                _n.ptr(color), _n.ptr(grad_color), _n.ptr(scratch), _n.ptr(d_mean2D), _n.ptr(d_conic), _n.ptr(d_opac),
+                _n.ptr(d_color), _n.ptr(d_mean3D), _n.ptr(d_cov3D), _n.ptr(d_sh), _n.ptr(d_scale), _n.ptr(d_rot))
+        _n.check(rc, "csplat_backward")
+        return (d_mean3D, d_mean2D, d_sh, d_color if colors_precomp is not None else None, d_opac, d_scale, d_rot,
+                d_cov3D if cov3Ds_precomp is not None else None)
+
+    def saved(self):
+        return (self.means3D, self.sh, self.colors_precomp, self.scales, self.rotations, self.cov3Ds_precomp, self.radii,
+                self.color)
+
+    def drop_inputs(self):
+        """the tensors travel through ctx.save_for_backward; keep only constants and chunks here"""
+        self.means3D = self.sh = self.colors_precomp = self.opacities = self.scales = self.rotations = None
+        self.cov3Ds_precomp = self.radii = self.color = self.depth = None
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+        v = _View(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs)
+        v.begin()
+        v.finish()
+        color, radii, depth = v.color, v.radii, v.depth
+        ctx.save_for_backward(*v.saved())
+        v.drop_inputs()
+        ctx.view_state = v
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, _grad_depth):
+        return ctx.view_state.backward(grad_color, ctx.saved_tensors) + (None,)
+
+
+_side_streams = {}
+
+
+def _view_streams(dev, n, main):
+    """the caller's stream + n-1 side streams: ROCm maps streams onto 4 hardware queues per device by default, and a
+    fifth stream shares a queue with (= is serialised behind) another one"""
+    pool = _side_streams.setdefault((dev.type, dev.index), [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    return [main] + pool[:n - 1]
+
+
+class _RasterizeGaussiansBatch(torch.autograd.Function):
+    """V independent views in one autograd node and ONE library call each way (csplat_forward_views /
+    csplat_backward_views).  Every view runs on its own HIP stream (the caller's + V-1 side streams, fenced inside the
+    library): all K1/K2 are issued before the first num_rendered read, the under-filled compositing kernels of the views
+    overlap, and a parameter tensor passed to several views gets ONE gradient buffer that the views' K8 add into.
+    Images / radii / depth are bit-identical to V calls of _RasterizeGaussians."""
+
+    NIN = 8
+    # slot in the per-view argument list -> (csplat_view gradient field, accumulate bit)
+    _GRAD = {0: ("dL_dmean3D", _n.ACC_MEAN3D), 2: ("dL_dsh", _n.ACC_SH), 3: ("dL_dcolor", _n.ACC_COLOR),
+             4: ("dL_dopacity", _n.ACC_OPACITY), 5: ("dL_dscale", _n.ACC_SCALE), 6: ("dL_drot", _n.ACC_ROT),
+             7: ("dL_dcov3D", _n.ACC_COV3D)}
+
+    @staticmethod
+    def forward(ctx, settings, stacked, *flat):
+        V, n = len(settings), _RasterizeGaussiansBatch.NIN
+        assert len(flat) == V * n
+        views = []
+        for i in range(V):
+            means3D, _means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds = flat[i * n:(i + 1) * n]
+            views.append(_View(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds, settings[i]))
+        dev = views[0].dev
+        main = torch.cuda.current_stream(dev)
+        streams = _view_streams(dev, V, main)
+        arr = (_n.CsplatView * V)()
+        chunks = [dict() for _ in range(V)]
+        # stacked: the V images land in ONE [V, 3, H, W] tensor (what the reference builds with torch.cat before the loss,
+        # scene_reconstruction/train_utils.py:262-270) and that tensor is the node's first output
+        if stacked:
+            assert all((v.H, v.W) == (views[0].H, views[0].W) for v in views), "stacked output needs equal image sizes"
+            colors = torch.empty(V, 3, views[0].H, views[0].W, dtype=torch.float32, device=dev)
+
+        def _alloc(ctx_, chunk, nbytes):     # all on the caller's stream: the library fences the view streams around it
+            try:
+                buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+                chunks[int(ctx_ or 0)][int(chunk)] = buf
+                return buf.data_ptr()
+            except Exception:
+                return None
+        cb = _n.ALLOC_FN(_alloc)
+        for i, (v, st) in enumerate(zip(views, streams)):
+            rs, w = v.rs, arr[i]
+            v.color = colors[i] if stacked else torch.empty(3, v.H, v.W, dtype=torch.float32, device=dev)
+            v.depth = torch.empty(1, v.H, v.W, dtype=torch.float32, device=dev)
+            v.radii = torch.empty(v.P, dtype=torch.int32, device=dev)
+            w.stream = st.cuda_stream
+            w.P, w.D, w.M, w.W, w.H, w.prefiltered = v.P, int(rs.sh_degree), v.M, v.W, v.H, int(bool(rs.prefiltered))
+            w.scale_modifier, w.tanfovx, w.tanfovy = float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy)
+            w.bg, w.means3D, w.shs, w.colors_precomp = _n.ptr(v.bg), _n.ptr(v.means3D), _n.ptr(v.sh), _n.ptr(v.colors_precomp)
+            w.opacities, w.scales, w.rotations = _n.ptr(v.opacities), _n.ptr(v.scales), _n.ptr(v.rotations)
+            w.cov3D_precomp, w.view, w.proj, w.campos = _n.ptr(v.cov3Ds_precomp), _n.ptr(v.view), _n.ptr(v.proj), _n.ptr(v.campos)
+            w.alloc_ctx = i
+            w.out_color, w.out_depth, w.radii = _n.ptr(v.color), _n.ptr(v.depth), _n.ptr(v.radii)
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_forward_views(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream)
+        _n.check(rc, "csplat_forward_views")
+        outs, saved = [], []
+        for i, v in enumerate(views):
+            v.num_rendered = int(arr[i].num_rendered)
+            v.layout_rendered = int(arr[i].layout_rendered)      # >= num_rendered: what the binning chunk was laid out for
+            v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
+            outs += [v.radii, v.depth] if stacked else [v.color, v.radii, v.depth]
+            saved += list(v.saved()[:-1]) + ([] if stacked else [v.color])
+            ctx.mark_non_differentiable(v.radii, v.depth)
+        if stacked:
+            outs = [colors] + outs
+            saved.append(colors)
+        ctx.stacked = bool(stacked)
+        ctx.nsaved = len(views[0].saved()) - (1 if stacked else 0)
+        ctx.save_for_backward(*saved)
+        # which view first received each input tensor OBJECT (shared parameters get one gradient buffer)
+        ctx.first_of = [[next(j for j in range(i + 1) if flat[j * n + k] is flat[i * n + k]) for k in range(n)] for i in range(V)]
+        for v in views:
+            v.drop_inputs()
+        ctx.views, ctx.arr = views, arr
+        ctx.set_materialize_grads(False)     # an unused view arrives as None in backward() and costs nothing
+        ctx.plan = None
+        if any(ctx.needs_input_grad):
+            # the GPU is busy with K3..K6 of the views right now: prepare the backward call in its shadow
+            ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
+        return tuple(outs)
+
+    @staticmethod
+    def _plan_backward(views, saved, k, arr, first_of, active, dev):
+        """Everything of the backward call that does not depend on the incoming gradient values: ONE allocation for every
+        gradient, temporary and K7 record of the step (returned gradients are views of it), the csplat_view array with all
+        pointers but dL_dpix, the accumulate masks of shared parameters.  Built at the end of forward(), while the
+        compositing kernels run, so that backward() is left with pointer patching and one library call."""
+        n = _RasterizeGaussiansBatch.NIN
+        plan, owner, total = [], {}, 0
+
+        def reserve(numel):
+            nonlocal total
+            off = total
+            total += (int(numel) + 63) & ~63          # 256-byte granules
+            return off
+        for i in active:
+            v = views[i]
+            means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = saved[i * k:i * k + 7]
+            P, M = v.P, v.M
+            ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.layout_rendered)) // 4 + 64),
+                   "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {}}
+            ent["ret"][1] = (ent["dL_dmean2D"], (P, 3))
+            shapes = {0: (P, 3), 2: (P, M, 3) if sh is not None else None, 3: (P, 3), 4: (P, 1),
+                      5: (P, 3) if scales is not None else None, 6: (P, 4) if rotations is not None else None, 7: (P, 6)}
+            present = {0: True, 2: sh is not None, 3: colors_precomp is not None, 4: True, 5: scales is not None,
+                       6: rotations is not None, 7: cov3Ds is not None}
+            for slot, (field, bit) in _RasterizeGaussiansBatch._GRAD.items():
+                if shapes[slot] is None:
+                    ent[field] = None
+                    continue
+                j = first_of[i][slot]
+                if present[slot] and j != i and j in active and (slot != 2 or M == 16):
+                    ent[field] = owner[(j, slot)]
+                    ent["mask"] |= bit
+                else:
+                    numel = 1
+                    for d in shapes[slot]:
+                        numel *= d
+                    ent[field] = owner[(i, slot)] = reserve(numel)
+                    if present[slot]:
+                        ent["ret"][slot] = (ent[field], shapes[slot])
+            plan.append(ent)
+        big = torch.empty(max(total, 64), dtype=torch.float32, device=dev)
+        base = big.data_ptr()
+        sub = (_n.CsplatView * len(active))()
+        out = [None] * (len(views) * n)
+        for a, i in enumerate(active):
+            ent = plan[a]
+            C.memmove(C.byref(sub[a]), C.byref(arr[i]), C.sizeof(_n.CsplatView))
+            w = sub[a]
+            w.scratch, w.accmask = base + 4 * ent["scratch"], ent["mask"]
+            for field in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh",
+                          "dL_dscale", "dL_drot"):
+                off = ent.get(field)
+                setattr(w, field, None if off is None else base + 4 * off)
+            for slot, (off, shape) in ent["ret"].items():
+                numel = 1
+                for d in shape:
+                    numel *= d
+                out[i * n + slot] = big[off:off + numel].view(shape)
+        return {"active": list(active), "big": big, "sub": sub, "out": out}
+
+    @staticmethod
+    def backward(ctx, *grads):
+        views, k, arr = ctx.views, ctx.nsaved, ctx.arr
+        V = len(views)
+        dev = views[0].dev
+        main = torch.cuda.current_stream(dev)
+        if ctx.stacked:
+            gcol = [None] * V if grads[0] is None else [grads[0][i] for i in range(V)]
+        else:
+            gcol = [grads[3 * i] for i in range(V)]
+        active = [i for i in range(V) if gcol[i] is not None]
+        if not active:
+            return (None, None) + (None,) * (V * _RasterizeGaussiansBatch.NIN)
+        plan, ctx.plan = ctx.plan, None                         # (one use: the buffers are handed to autograd)
+        if plan is None or plan["active"] != active:            # a view's image went unused, or a second backward pass
+            plan = _RasterizeGaussiansBatch._plan_backward(views, ctx.saved_tensors, k, arr, ctx.first_of, active, dev)
+        gs = [_f32c(gcol[i], dev) for i in active]
+        for a, g in enumerate(gs):
+            plan["sub"][a].dL_dpix = _n.ptr(g)
+        with torch.cuda.device(dev):
+            rc = _n.lib.csplat_backward_views(len(active), C.cast(plan["sub"], C.c_void_p), main.cuda_stream)
+        _n.check(rc, "csplat_backward_views")
+        return (None, None) + tuple(plan["out"])
+
+
+def rasterize_views(settings, inputs, stacked=False):
+    """Batched entry (no counterpart upstream, where cameras are rendered one by one in a Python loop --
+    scene_reconstruction/train_utils.py:204-260): `settings` a list of GaussianRasterizationSettings, `inputs` a list of
+    dicts with the keyword names of GaussianRasterizer.forward.  Returns a list of (color, radii, depth); with
+    stacked=True (equal image sizes) returns (colors [V,3,H,W], [(colors[i], radii, depth), ...]) where `colors` is the
+    differentiable output -- the batch the reference assembles with torch.cat before its losses -- and colors[i] are
+    plain slices of it."""
+    flat = []
+    for kw in inputs:
+        shs, cp = kw.get("shs"), kw.get("colors_precomp")
+        sc, ro, cov = kw.get("scales"), kw.get("rotations"), kw.get("cov3D_precomp")
+        if (shs is None) == (cp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((sc is None or ro is None) and cov is None) or ((sc is not None or ro is not None) and cov is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        flat += [kw["means3D"], kw["means2D"], shs, cp, kw["opacities"], sc, ro, cov]
+    res = _RasterizeGaussiansBatch.apply(tuple(settings), bool(stacked), *flat)
+    if stacked:
+        colors = res[0]
+        return colors, [(colors[i], res[1 + 2 * i], res[2 + 2 * i]) for i in range(len(settings))]
+    return [tuple(res[3 * i:3 * i + 3]) for i in range(len(settings))]
+
+
+_n_GEOM, _n_BINNING, _n_IMAGE = 0, 1, 2
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test of the upstream extension: visible iff view-space z > 0.2."""
+        with torch.no_grad():
+            V = self.raster_settings.viewmatrix.to(positions.device, torch.float32)
+            z = positions @ V[:3, 2] + V[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

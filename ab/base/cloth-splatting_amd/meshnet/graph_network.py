@@ -1,0 +1,262 @@
+"""Drop-in for /root/reference/meshnet/graph_network.py with the torch_geometric dependency replaced by the
+csplat HIP kernels.  Class names, constructor / forward signatures and state_dict keys are the reference's
+(`_encoder.node_fn.0.NN-0.weight`, `_processor.gnn_stacks.K.edge_fn.0.NN-0.weight`, ...), so `model-N.pt`
+checkpoints load unchanged (cloth_network.py:242-243).
+
+Semantics reproduced from PyG `MessagePassing(aggr='add')`:
+  x_j = x[edge_index[0]], x_i = x[edge_index[1]];  message = LN(MLP(cat[x_i, x_j, e]))   (graph_network.py:178-199)
+  aggregate = sum over edge_index[1], dim_size = N                                    (graph_network.py:136)
+  update gets the ORIGINAL edge features -> every layer returns edge_out = 2 * edge_in  (graph_network.py:173-176,222)
+
+MI355X design: the [E, 3L] concat is never built.  W1 of the edge MLP is applied as three column blocks:
+x @ W_i^T and x @ W_j^T at node level (N rows), e @ W_e^T at edge level; csplat_gnn_edge_combine_fwd gathers and
+adds them (+ReLU) in one HBM pass.  The scatter-add is csplat_gnn_segment_sum over a CSR-by-destination order
+(deterministic).  The node MLP's cat[agg, x] is likewise split.  Node-level y and dx GEMMs stay on rocBLAS; every 128 x 128
+weight gradient (edge AND node level) is csplat_dw128.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows, report_missed_edge_tail,
+                        linear128, linear_rows, node_update)
+
+
+def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
+              output_activation: nn.Module = nn.Identity, activation: nn.Module = nn.ReLU) -> nn.Module:
+    """graph_network.py:7-45 -- Sequential of Linear "NN-i" / activation "Act-i"."""
+    layer_sizes = [input_size] + hidden_layer_sizes
+    if output_size:
+        layer_sizes.append(output_size)
+    nlayers = len(layer_sizes) - 1
+    act = [activation for _ in range(nlayers)]
+    act[-1] = output_activation
+    mlp = nn.Sequential()
+    for i in range(nlayers):
+        mlp.add_module("NN-" + str(i), nn.Linear(layer_sizes[i], layer_sizes[i + 1]))
+        mlp.add_module("Act-" + str(i), act[i]())
+    return mlp
+
+
+class Encoder(nn.Module):
+    """graph_network.py:48-111"""
+
+    def __init__(self, nnode_in_features: int, nnode_out_features: int, nedge_in_features: int, nedge_out_features: int,
+                 nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.node_fn = nn.Sequential(*[build_mlp(nnode_in_features, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nnode_out_features), nn.LayerNorm(nnode_out_features)])
+        self.edge_fn = nn.Sequential(*[build_mlp(nedge_in_features, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nedge_out_features), nn.LayerNorm(nedge_out_features)])
+
+    def forward(self, x: torch.Tensor, edge_features: torch.Tensor):
+        e = _tail(self.edge_fn[0], edge_features, first_has_act=False, skip_first=False)
+        return self.node_fn(x), layer_norm_rows(e, self.edge_fn[1])
+
+
+def _tail(seq_mlp: nn.Sequential, h: torch.Tensor, first_has_act: bool, skip_first: bool = True) -> torch.Tensor:
+    """run build_mlp's layers after the first Linear (whose activation has already been applied iff first_has_act);
+    skip_first=False runs the whole MLP."""
+    mods = list(seq_mlp.children())
+    start = (2 if first_has_act else 1) if skip_first else 0  # skip NN-0 (+ Act-0 when it was fused)
+    mods = mods[start:]
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):   # tall inputs: csplat_linear128 both ways (ReLU fused), split-K weight gradient
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            h = linear_rows(h, m.weight, m.bias, relu=fuse)
+            i += 2 if fuse else 1
+        else:
+            h = m(h)
+            i += 1
+    return h
+
+
+def _fusable(seq: nn.Sequential, width: int = 128) -> bool:
+    """[build_mlp(...), LayerNorm] whose layers after the first are 128 -> 128 Linear + ReLU (Identity last)."""
+    mlp, ln = seq[0], seq[1]
+    mods = list(mlp.children())
+    lins, acts = mods[0::2], mods[1::2]
+    if not (isinstance(ln, nn.LayerNorm) and tuple(ln.normalized_shape) == (width,) and ln.elementwise_affine):
+        return False
+    if len(lins) < 2 or not all(isinstance(m, nn.Linear) and m.out_features == width for m in lins):
+        return False
+    if not all(m.in_features == width for m in lins[1:]):
+        return False
+    return all(isinstance(a, nn.ReLU) for a in acts[:-1]) and isinstance(acts[-1], nn.Identity) and \
+        lins[0].weight.dtype == torch.float32 and lins[0].weight.is_cuda
+
+
+def _fused_tail(seq: nn.Sequential, h: torch.Tensor, add_post: torch.Tensor = None) -> torch.Tensor:
+    """layers 1.. of a _fusable MLP + its LayerNorm (+ a residual), in place on h (h = activated output of layer 0)."""
+    lins = list(seq[0].children())[0::2]
+    for i, lin in enumerate(lins[1:], start=1):
+        last = i == len(lins) - 1
+        h = linear128(h, lin.weight, lin.bias, relu=not last, layer_norm=seq[1] if last else None,
+                      add_post=add_post if last else None, out=h)
+    return h
+
+
+class InteractionNetwork(nn.Module):
+    """graph_network.py:114-222 (PyG MessagePassing, aggr='add')."""
+
+    def __init__(self, nnode_in: int, nnode_out: int, nedge_in: int, nedge_out: int, nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.aggr = 'add'
+        self.node_fn = nn.Sequential(*[build_mlp(nnode_in + nedge_out, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nnode_out), nn.LayerNorm(nnode_out)])
+        self.edge_fn = nn.Sequential(*[build_mlp(nnode_in + nnode_in + nedge_in, [mlp_hidden_dim for _ in range(nmlp_layers)],
+                                                 nedge_out), nn.LayerNorm(nedge_out)])
+        self._nnode_in, self._nedge_in = nnode_in, nedge_in
+
+    def forward(self, x, edge_index, edge_features):
+        # PyG hands update() the ORIGINAL edge features: edge output = input + input
+        return self.message_update(x, edge_index, edge_features, 1.0)[0], edge_features + edge_features
+
+    def message_update(self, x, edge_index, e_base, scale: float = 1.0):
+        """the node half of forward() for edge features `scale * e_base`; returns (x_new, e_base to hand to the next layer).
+        Because every layer only doubles its edge features (F7), Processor carries the encoder's edge latents e_base and the scalar
+        2^l through the stack instead of materialising [E, L] sums per layer; the scale rides in the GEMM's alpha, and e_base is
+        CHAINED through the layers (graph_ops.EdgeLatentLinear) so that its gradient is summed inside the layers' input-gradient
+        GEMMs instead of by 14 separate [E, L] additions."""
+        x_residual = x
+        csr = GraphCSR.get(edge_index, x.shape[0])
+        n = self._nnode_in
+        # ---- message: LN(MLP(cat[x_i, x_j, e])) with the first Linear split into three column blocks; its bias rides on the x_i
+        # block (N rows, and its gradient is a column sum over N rows instead of E)
+        mlp_e = self.edge_fn[0]
+        lin0 = mlp_e[0]
+        relu0 = isinstance(mlp_e[1], nn.ReLU)
+        W = lin0.weight
+        xa = linear_rows(x, W[:, :n], lin0.bias)    # contribution of x_i = x[edge_index[1]]
+        xb = linear_rows(x, W[:, n:2 * n], None)    # contribution of x_j = x[edge_index[0]]
+        if relu0 and edge_tail_ok(e_base, self.edge_fn):
+            # tall fp32 GPU rows: two autograd nodes for the whole message path -- the e-block GEMM with the gathers / ReLU in its
+            # epilogue, then the rest of the MLP, the LayerNorm and the sum over destination nodes
+            h, e_next = EdgeFirstLayer.apply(e_base, W[:, 2 * n:], scale, xa, xb, csr)
+            agg = edge_tail_aggregate(h, csr, self.edge_fn, a0_relu=True)
+        else:
+            report_missed_edge_tail(e_base)
+            ec, e_next = edge_latent_linear(e_base, W[:, 2 * n:], scale)
+            h = EdgeCombine.apply(xa, xb, ec, csr, relu0)
+            h = _tail(mlp_e, h, relu0)
+            msg = layer_norm_rows(h, self.edge_fn[1])
+            # ---- aggregate: sum over destination nodes
+            agg = SegmentSum.apply(msg, csr)
+        # ---- update: LN(MLP(cat[agg, x])), concat folded into two GEMMs
+        mlp_n = self.node_fn[0]
+        l0 = mlp_n[0]
+        a = agg.shape[1]
+        hn = linear_rows(agg, l0.weight[:, :a], l0.bias) + linear_rows(x, l0.weight[:, a:], None)
+        hn = mlp_n[1](hn)
+        hn = _tail(mlp_n, hn, True)
+        x_updated = layer_norm_rows(hn, self.node_fn[1])
+        return x_updated + x_residual, e_next
+
+    def inference_ok(self, x, edge_features) -> bool:
+        n = self._nnode_in
+        return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and \
+            edge_features.dtype == torch.float32 and n == 128 and self._nedge_in == 128 and \
+            _fusable(self.edge_fn) and _fusable(self.node_fn)
+
+    def _split_weights(self):
+        """contiguous column blocks of the two first-layer weights, re-cut only when an optimizer step changed them"""
+        we, wn = self.edge_fn[0][0].weight, self.node_fn[0][0].weight
+        key = (we._version, wn._version, we.data_ptr(), wn.data_ptr())
+        if getattr(self, "_wsplit_key", None) != key:
+            n, a = self._nnode_in, wn.shape[1] - self._nnode_in
+            with torch.no_grad():
+                self._wsplit = tuple(t.contiguous() for t in (we[:, :n], we[:, n:2 * n], we[:, 2 * n:], wn[:, :a], wn[:, a:]))
+            self._wsplit_key = key
+        return self._wsplit
+
+    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None):
+        """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd.
+        Per layer the [E,128] activations make three read+write passes (one per Linear, with gather / bias / ReLU /
+        LayerNorm in the epilogues) and one read by the segmented sum; the node level is ONE launch
+        (csplat_gnn_node_update) that also forms the x_i / x_j column-block products of `next_layer`'s first edge
+        Linear.  Returns (x_new, xa_next, xb_next); xa / xb for this layer are computed here when not handed in."""
+        csr = GraphCSR.get(edge_index, x.shape[0])
+        w_i, w_j, w_e, w_agg, w_x = self._split_weights()
+        if xa is None:
+            xa = linear128(x, w_i)                               # contribution of x_i = x[edge_index[1]]
+            xb = linear128(x, w_j)                               # contribution of x_j = x[edge_index[0]]
+        h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
+        msg = _fused_tail(self.edge_fn, h)
+        agg = SegmentSum.apply(msg, csr)
+        lins = list(self.node_fn[0].children())[0::2]
+        if len(lins) == 3:
+            nw = next_layer._split_weights() if next_layer is not None else (None, None)
+            return node_update(agg, x, w_agg, w_x, lins[0].bias, lins[1], lins[2], self.node_fn[1], nw[0], nw[1])
+        t = linear128(x, w_x, out=xa)
+        hn = linear128(agg, w_agg, self.node_fn[0][0].bias, relu=True, add_pre=t, out=t)
+        return _fused_tail(self.node_fn, hn, add_post=x), None, None
+
+
+class Processor(nn.Module):
+    """graph_network.py:225-292 (declared aggr='max' upstream but never propagates itself)."""
+
+    def __init__(self, nnode_in: int, nnode_out: int, nedge_in: int, nedge_out: int, nmessage_passing_steps: int,
+                 nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.aggr = 'max'
+        self.gnn_stacks = nn.ModuleList([
+            InteractionNetwork(nnode_in=nnode_in, nnode_out=nnode_out, nedge_in=nedge_in, nedge_out=nedge_out,
+                               nmlp_layers=nmlp_layers, mlp_hidden_dim=mlp_hidden_dim)
+            for _ in range(nmessage_passing_steps)])
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+        if len(self.gnn_stacks) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks):
+            # rollout: every layer doubles the edge features (F7), so carry e0 and the scalar 2^l instead of 15 [E,128] passes
+            e0, scale = edge_features.contiguous(), 1.0
+            xa = xb = None
+            for l, gnn in enumerate(self.gnn_stacks):
+                nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
+                x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt)
+                scale *= 2.0
+            return x, e0 * scale
+        if len(self.gnn_stacks) and not torch.is_grad_enabled():
+            # inference on a form the one-pass rollout kernels do not cover (they are built for the 128-wide fp32 network of config 4)
+            from csplat import native as _n
+            _n.composed_fallback("graph_network.Processor.forward", "dtype" if (x.dtype != torch.float32 or edge_features.dtype != torch.float32)
+                                 else "shape", x)
+        e_base, scale = edge_features, 1.0
+        for gnn in self.gnn_stacks:
+            x, e_base = gnn.message_update(x, edge_index, e_base, scale)
+            scale *= 2.0
+        return x, (e_base * scale if len(self.gnn_stacks) else e_base)
+
+
+class Decoder(nn.Module):
+    """graph_network.py:295-332"""
+
+    def __init__(self, nnode_in: int, nnode_out: int, nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self.node_fn = build_mlp(nnode_in, [mlp_hidden_dim for _ in range(nmlp_layers)], nnode_out)
+
+    def forward(self, x: torch.Tensor):
+        return self.node_fn(x)
+
+
+class EncodeProcessDecode(nn.Module):
+    """graph_network.py:335-408"""
+
+    def __init__(self, nnode_in_features: int, nnode_out_features: int, nedge_in_features: int, latent_dim: int,
+                 nmessage_passing_steps: int, nmlp_layers: int, mlp_hidden_dim: int):
+        super().__init__()
+        self._encoder = Encoder(nnode_in_features=nnode_in_features, nnode_out_features=latent_dim,
+                                nedge_in_features=nedge_in_features, nedge_out_features=latent_dim,
+                                nmlp_layers=nmlp_layers, mlp_hidden_dim=mlp_hidden_dim)
+        self._processor = Processor(nnode_in=latent_dim, nnode_out=latent_dim, nedge_in=latent_dim, nedge_out=latent_dim,
+                                    nmessage_passing_steps=nmessage_passing_steps, nmlp_layers=nmlp_layers,
+                                    mlp_hidden_dim=mlp_hidden_dim)
+        self._decoder = Decoder(nnode_in=latent_dim, nnode_out=nnode_out_features, nmlp_layers=nmlp_layers,
+                                mlp_hidden_dim=mlp_hidden_dim)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+        x, edge_features = self._encoder(x, edge_features)
+        x, edge_features = self._processor(x, edge_index, edge_features)
+        x = self._decoder(x)
+        return x

@@ -126,16 +126,14 @@ class RowsDot(torch.autograd.Function):
     (csplat_rows_dot_fwd / _bwd: the weight is streamed once per direction; deterministic)."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, add=None):
+    def forward(ctx, h, weight, bias):
         h, weight, bias = _f32(h), _f32(weight), _f32(bias)
         T, K = h.shape
         R = weight.shape[0]
         y = torch.empty(T, R, dtype=torch.float32, device=h.device)
-        add = None if add is None else _f32(add.reshape(T, R))
         with torch.cuda.device(h.device):
             _n.check(_n.lib.csplat_rows_dot_fwd(_n.stream_handle(h.device), T, R, K, _n.ptr(weight), _n.ptr(bias), _n.ptr(h),
-                                                _n.ptr(y), None if add is None else _n.ptr(add)), "csplat_rows_dot_fwd")
-        ctx.add_shape = None if add is None else add.shape
+                                                _n.ptr(y)), "csplat_rows_dot_fwd")
         ctx.save_for_backward(h, weight)
         return y
 
@@ -150,7 +148,7 @@ class RowsDot(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _n.check(_n.lib.csplat_rows_dot_bwd(_n.stream_handle(g.device), T, R, K, _n.ptr(weight), _n.ptr(h), _n.ptr(g),
                                                 _n.ptr(dW), _n.ptr(db), _n.ptr(dh), _n.ptr(scratch)), "csplat_rows_dot_bwd")
-        return dh, dW, db, (g if ctx.add_shape is not None and ctx.needs_input_grad[3] else None)
+        return dh, dW, db
 
 
 _SIMH_SCRATCH = {}
@@ -201,15 +199,12 @@ def sim_hidden(e, lin1, lin2):
     return torch.relu(lin2(torch.relu(lin1(e))))
 
 
-def rows_dot(h, weight, bias, add=None):
-    """F.linear(h, weight, bias) [+ add, shaped like the result] for few rows of h (<= 8) against a tall 256-column weight, at HBM rate
-    on the GPU."""
-    if h.is_cuda and h.dim() == 2 and h.shape[1] == 256 and weight.shape[1] == 256 and 0 < h.shape[0] <= 8 and bias is not None and \
-            (add is None or (add.is_cuda and add.numel() == h.shape[0] * weight.shape[0])):
-        return RowsDot.apply(h, weight, bias, add)
+def rows_dot(h, weight, bias):
+    """F.linear(h, weight, bias) for few rows of h (<= 8) against a tall 256-column weight, at HBM rate on the GPU."""
+    if h.is_cuda and h.dim() == 2 and h.shape[1] == 256 and weight.shape[1] == 256 and 0 < h.shape[0] <= 8 and bias is not None:
+        return RowsDot.apply(h, weight, bias)
     _n.composed_fallback("graph_ops.rows_dot", "shape", h)
-    y = torch.nn.functional.linear(h, weight, bias)
-    return y if add is None else add.reshape(y.shape) + y
+    return torch.nn.functional.linear(h, weight, bias)
 
 
 def _weight_layout(weight):

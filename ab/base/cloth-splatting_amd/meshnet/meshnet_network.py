@@ -100,7 +100,7 @@ class ResidualMeshSimulator(torch.nn.Module):
         nn.init.normal_(self.output.weight, 0.0, 0.00001)
         nn.init.constant_(self.output.bias, 0.0)
 
-    def _residual(self, times, encoded=None, base=None):
+    def _residual(self, times, encoded=None):
         """times [T, 1] -> residual deformation [T, V, 3].  One time value feeds the whole mesh, so the 256 -> 3V output layer
         is a matrix-vector product per time; as an M = 1 GEMM (what nn.Linear issues) it runs at ~60 GB/s on this stack.
         graph_ops.rows_dot streams the 3V x 256 weight once for all T rows (forward) / once more for their gradients.
@@ -111,8 +111,7 @@ class ResidualMeshSimulator(torch.nn.Module):
             h = sim_hidden(enc, self.input, self.hidden)
         else:
             h = torch.relu(self.hidden(torch.relu(self.input(enc))))
-        # base [T, V, 3]: the table rows the residual is added to (forward_times) -- inside the output layer's launch
-        return rows_dot(h, self.output.weight, self.output.bias, base).reshape(times.shape[0], -1, 3)
+        return rows_dot(h, self.output.weight, self.output.bias).reshape(times.shape[0], -1, 3)
 
     def forward(self, time_vector):
         time = time_vector[0, :]
@@ -152,8 +151,9 @@ class ResidualMeshSimulator(torch.nn.Module):
             cache[(key, dev)] = (tt, enc, base, self.mesh_predictions, self.mesh_predictions._version)
         out = []
         for c0 in range(0, tt.shape[0], 8):   # (rows_dot takes up to 8 time rows per call)
-            out.append(self._residual(tt[c0:c0 + 8], enc[c0:c0 + 8], base[c0:c0 + 8]))
-        return out[0] if len(out) == 1 else torch.cat(out, 0)
+            out.append(self._residual(tt[c0:c0 + 8], enc[c0:c0 + 8]))
+        residual = out[0] if len(out) == 1 else torch.cat(out, 0)
+        return base + residual
 
     def save(self, path):
         torch.save(self.state_dict(), path)

@@ -214,7 +214,8 @@ size_t csplat_sim_hidden_scratch_bytes(int T);
 int csplat_sim_hidden_bwd(void *stream, int T, int K0, const float *e, const float *W2, const float *h1, const float *h2, const float *dh2,
                           float *dW1, float *db1, float *dW2, float *db2, void *scratch);
 size_t csplat_rows_dot_scratch_bytes(int T);
-int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y);
+/* add: NULL, or [T][R] added to the result (the simulator's `mesh_predictions[time_id] + residual`, meshnet_network.py:371) */
+int csplat_rows_dot_fwd(void *stream, int T, int R, int K, const float *W, const float *b, const float *h, float *y, const float *add);
 int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const float *h, const float *dy, float *dW, float *db,
                         float *dh, void *scratch);
 
@@ -224,8 +225,8 @@ int csplat_rows_dot_bwd(void *stream, int T, int R, int K, const float *W, const
  *         + lambda_rigid * mean_{t,e} | rest_len[e] - |D[t][edge_index[1][e]] - D[t][edge_index[0][e]]|_2 |
  *         + lambda_momentum * mean_v |D2 - 2 D1 + D0|_1                          (only when T >= 3)
  *   grad [T][V][3] = d loss / d D (norms have gradient 0 at 0, as torch defines them).
- * scratch: csplat_cloth_regs_scratch_bytes(T, V, E) bytes, not shared between concurrent calls.  The loss value is summed in a
- * fixed order.  Gradient: with the CSR of the graph (dst_rowptr / src_rowptr [V+1], dst_perm / src_perm [E], int32: edge ids
+ * scratch: csplat_cloth_regs_scratch_bytes(T, V, E) bytes, ZERO before the first call (every call leaves it reusable), not shared
+ * between concurrent calls.  The loss value is summed in a fixed order.  Gradient: with the CSR of the graph (dst_rowptr / src_rowptr [V+1], dst_perm / src_perm [E], int32: edge ids
  * grouped by edge_index[1] / edge_index[0], ascending within a group) every vertex gathers its edges -- deterministic, no
  * atomics; with NULLs the edges scatter with float atomics (summation order not fixed). */
 size_t csplat_cloth_regs_scratch_bytes(int T, int V, int64_t E);
@@ -268,6 +269,32 @@ int csplat_ssim_bwd(void *stream, int64_t n_images, int H, int W, const float *t
 int csplat_ssim_fwd_masked(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
                            const float *y, const float *mask, int mask_channels, float *p1, float *p2, float *p3,
                            float *map_out, float *partial);
+/* The densification statistics of a training step (/root/reference/scene_reconstruction/train_utils.py:276-285:
+ * `radii = torch.cat(radii_list, 0).max(dim=0).values`, `visibility_filter = torch.cat(visibility_filter_list).any(dim=0)`, the
+ * viewspace-gradient sum over the step's cameras) in one launch.  mean2d_grads / radii: HOST arrays of V (<= 16) device pointers,
+ * [P][3] float / [P] int32 each (a NULL gradient entry counts as zero); outputs: grad_sum [P][3], radii_max [P], visible [P] (0 / 1
+ * bytes).  grad_sum or (radii_max, visible) may be NULL. */
+int csplat_step_stats(void *stream, int64_t P, int V, const float *const *mean2d_grads, const int *const *radii, float *grad_sum,
+                      int *radii_max, uint8_t *visible);
+/* The whole image loss of a training step in two launches forward, one backward -- the reference's Ll1 + lambda_dssim * (1 - ssim) (masked:
+ * mean|(x - y) m| + lambda_dssim * mean((1 - ssim_map) m)), /root/reference/scene_reconstruction/train_utils.py:50-74, the per-camera
+ * PSNR it logs every step (:262-283, utils/image_utils.py:17-21, unmasked) and the sum with one more device scalar (the regularisers,
+ * :76-237):
+ *   out[0] = img_weight * image_loss + add_weight * add[0]   (add may be NULL)      out[1] = psnr_scale * sum_b PSNR_b
+ *   out[2] = image_loss                                                              out[3] = Ll1
+ * x, y [n_batch][channels][H][W]; mask NULL or [n_batch][mask_channels][H][W] (mask_channels 1 or channels).  p1..p3 (float images) and
+ * sign8 (one byte per element) are what csplat_image_loss_bwd needs; all four NULL = no gradient wanted.  scratch:
+ * csplat_image_loss_scratch_bytes bytes (no initial state, not shared between concurrent calls).  Bit-reproducible (workgroup
+ * partials summed in index order by a one-workgroup second launch).
+ * csplat_image_loss_bwd: dx = g_scalar[0] * img_weight * d(image_loss)/dx. */
+size_t csplat_image_loss_scratch_bytes(int64_t n_batch, int channels, int H, int W);
+int csplat_image_loss_fwd(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
+                          const float *y, const float *mask, int mask_channels, float lam, float img_weight, const float *add,
+                          float add_weight, float psnr_scale, float *p1, float *p2, float *p3, signed char *sign8, void *scratch,
+                          float *out);
+int csplat_image_loss_bwd(void *stream, int64_t n_batch, int channels, int H, int W, const float *taps11, const float *x,
+                          const float *y, const float *p1, const float *p2, const float *p3, const signed char *sign8,
+                          const float *mask, int mask_channels, float lam, float img_weight, const float *g_scalar, float *dx);
 /* l1_loss of /root/reference/utils/loss_utils.py:20-23 with its gradient in the same pass:
  *   *loss = mean_i |a[i] - b[i]|,   grad[i] = sign(a[i] - b[i]) / n   (grad may be NULL).
  * csplat_l1_masked: *loss = mean_i |(a[i] - b[i]) * m[i]|, grad[i] = sign((a-b)*m) * m / n, with the mask laid out as for

@@ -396,6 +396,43 @@ def test_fused_image_loss_matches_l1_plus_dssim(shape):
     assert float((a.grad - b.grad).abs().max()) < 1e-6 * max(float(b.grad.abs().max()), 1e-12) + 1e-10
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_fused_image_loss_side_outputs_and_weights(masked):
+    """the one-launch step loss (csplat_image_loss_fwd / _bwd): out = w_img * (Ll1 + lambda dssim) + w_add * reg, the logged PSNR
+    (utils/image_utils.py:17-21, unmasked, per camera) scaled, and the gradients towards the image AND the added scalar -- against the
+    separately pinned nodes (FusedL1 / FusedSSIM / csplat_psnr) composed in torch.  Bit-reproducible from call to call."""
+    from csplat import train as tr
+    shape = (3, 3, 70, 90)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand(*shape, device="cuda", generator=g)
+    gt = (img + 0.1 * torch.randn(*shape, device="cuda", generator=g)).clamp(0, 1)
+    mask = (torch.rand(shape[0], 1, *shape[2:], device="cuda", generator=g) > 0.3).float() if masked else None
+    lam, w_img, w_add, ps = 0.05, 2.0 / 3.0, 0.5, 1.0 / 3.0
+    a = img.clone().requires_grad_()
+    reg = torch.tensor(0.37, device="cuda", requires_grad=True)
+    loss, psnr, il = tr.FusedImageLoss.apply(a, gt, lam, mask, reg, w_img, w_add, ps)
+    (loss * 1.7).backward()
+    b = img.clone().requires_grad_()
+    reg_b = torch.tensor(0.37, device="cuda", requires_grad=True)
+    if masked:
+        ssim_term = ((1.0 - tr.ssim(b, gt, return_map=True)) * mask).mean()
+    else:
+        ssim_term = 1.0 - tr.ssim(b, gt)
+    il_b = tr.l1_loss(b, gt, mask) + lam * ssim_term
+    want = w_img * il_b + w_add * reg_b
+    (want * 1.7).backward()
+    assert abs(float(loss) - float(want)) < 2e-6 and abs(float(il) - float(il_b)) < 2e-6
+    assert abs(float(psnr) - ps * float(tr.psnr(img, gt).sum())) < 1e-4
+    assert float((a.grad - b.grad).abs().max()) < 2e-6 * max(float(b.grad.abs().max()), 1e-12) + 1e-10
+    assert abs(float(reg.grad) - float(reg_b.grad)) < 1e-6
+    again = tr.FusedImageLoss.apply(img, gt, lam, mask, reg.detach(), w_img, w_add, ps)
+    assert float(again[0]) == float(loss) and float(again[1]) == float(psnr)
+    # a single [C, H, W] image (render() of one camera)
+    one = tr.FusedImageLoss.apply(img[0], gt[0], lam)
+    assert abs(float(one[0]) - float(tr.l1_loss(img[0], gt[0]) + lam * (1.0 - tr.ssim(img[0], gt[0])))) < 2e-6
+    assert abs(float(one[1]) - float(tr.psnr(img[:1], gt[:1]))) < 1e-4
+
+
 def test_train_step_camera_by_camera_equals_batched():
     """train_step(batched_views=False) -- render() per camera, simulator per camera, composed losses as upstream's loop --
     against the default batched step (render_views, forward_times, fused nodes): same PSNR, loss, statistics and the same
