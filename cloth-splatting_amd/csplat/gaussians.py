@@ -102,6 +102,39 @@ class _GaussianActivations(torch.autograd.Function):
         return d_op, d_sc, d_dc, d_rest
 
 
+class UnbindViews(torch.autograd.Function):
+    """x.unbind(0) whose backward does not copy when the T incoming gradients already sit back to back in one buffer -- the batched
+    rasterizer's backward lays the per-view gradients of means3D / rotations out that way (diff_gaussian_rasterization._plan_backward) --
+    where torch's own unbind backward is a stack (one copy launch per tensor and step)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        ctx.meta = (x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        return tuple(x.detach().unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        T, rest = ctx.shape[0], ctx.shape[1:]
+        if all(g is None for g in grads):
+            return None
+        numel = 1
+        for d in rest:
+            numel *= d
+        g0 = grads[0]
+        if g0 is not None and all(g is not None and g.dtype == g0.dtype and g.is_contiguous() and tuple(g.shape) == rest and
+                                  g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and
+                                  g.storage_offset() == g0.storage_offset() + i * numel for i, g in enumerate(grads)):
+            strides, acc = [], 1
+            for d in reversed(rest):
+                strides.append(acc)
+                acc *= d
+            return g0.as_strided((T,) + rest, (numel,) + tuple(reversed(strides)))
+        dtype, dev = ctx.meta
+        return torch.stack([g if g is not None else torch.zeros(rest, dtype=dtype, device=dev) for g in grads], 0)
+
+
 class MeshGaussians(DensifyMixin):
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
@@ -271,7 +304,7 @@ class MeshGaussians(DensifyMixin):
     def transform_views(self, deformed_vertices):
         """get_xyz + get_rotation for the cameras of a step at once: [T,V,3] -> (tuple of T [P,3], tuple of T [P,4])."""
         xyz, quat = self._fused(deformed_vertices)
-        return xyz.unbind(0), quat.unbind(0)
+        return UnbindViews.apply(xyz), UnbindViews.apply(quat)
 
     def get_xyz(self, deformed_vertices=None):
         if deformed_vertices is not None and deformed_vertices.is_cuda and self.fused:

@@ -353,8 +353,9 @@ class FusedClothRegs(torch.autograd.Function):
     """the three cloth regularisers and their gradient in one launch (csplat_cloth_regs); backward scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr=None):
+    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr=None, tap=False):
         D = D.contiguous().float()
+        ctx.set_materialize_grads(False)
         T, V = int(D.shape[0]), int(D.shape[1])
         E = int(edge_index.shape[1])
         loss = torch.empty((), dtype=torch.float32, device=D.device)
@@ -371,12 +372,19 @@ class FusedClothRegs(torch.autograd.Function):
                                               float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
                                               *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])), "csplat_cloth_regs")
         ctx.save_for_backward(grad)
+        ctx.tap = bool(tap)
+        if tap:     # D passes through: the gradient arriving for it and the regularisers' own leave as ONE tensor (one launch)
+            return loss, D.view_as(D)
         return loss
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_through=None):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None, None, None
+        if ctx.tap and g_through is not None:
+            out = torch.addcmul(g_through, grad, g) if g is not None else g_through
+        else:
+            out = grad * g if g is not None else None
+        return out, None, None, None, None, None, None, None
 
 
 def edge_csr(edge_index, n_nodes):
@@ -387,9 +395,12 @@ def edge_csr(edge_index, n_nodes):
     return tuple(out)
 
 
-def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True):
+def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True, tap=False):
     """train_utils.py:76-237 (the active terms).  On the GPU the terms and their gradient come from one kernel
-    (FusedClothRegs); fused=False composes them from torch ops as upstream does (the parity reference of the tests)."""
+    (FusedClothRegs); fused=False composes them from torch ops as upstream does (the parity reference of the tests).
+    tap=True returns (loss, vertices): `vertices` is all_vertice_deform passed THROUGH the regulariser node -- render from it and the
+    two gradients of the vertices (image path, regularisers) are combined in the node's backward instead of by autograd (one launch
+    instead of a multiply and an add)."""
     n_cams = all_vertice_deform.shape[0]
     if fused and not static and all_vertice_deform.is_cuda and all_vertice_deform.dim() == 3:
         lam_d = opt.lambda_deform_mag if opt.lambda_deform_mag > 0. else 0.
@@ -404,7 +415,12 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True)
                 gaussians._edge_csr = cache
             except Exception:
                 pass
-        return FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
+        if tap and all_vertice_deform.dtype == torch.float32 and all_vertice_deform.is_contiguous():
+            return FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1], True)
+        loss = FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
+        return (loss, all_vertice_deform) if tap else loss
+    if tap:
+        return regularization(all_vertice_deform, gaussians, opt, static, fused), all_vertice_deform
     if fused and not static:
         _n.composed_fallback("train.regularization", "shape", all_vertice_deform)
     loss = torch.zeros([], device=all_vertice_deform.device)
@@ -528,7 +544,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         else:
             nv, dev0 = gaussians.mesh.pos.shape[0], gaussians.mesh.pos.device
             deforms_all = torch.stack([simulator(time_vector=torch.tensor(cam.time).to(dev0).repeat(nv, 1)) for cam in all_cams])
-        reg = regularization(deforms_all, gaussians, opt, static)
+        reg, deforms_all = regularization(deforms_all, gaussians, opt, static, tap=True)
         deforms = deforms_all if not dist_mode else (deforms_all[idx] if idx else None)
     if dist_mode or batched_views:
         pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True,

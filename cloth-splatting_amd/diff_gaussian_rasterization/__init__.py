@@ -267,6 +267,15 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             off = total
             total += (int(numel) + 63) & ~63          # 256-byte granules
             return off
+        # per-view gradients of means3D (slot 0) / rotations (slot 6) that belong to DISTINCT input tensors of equal size -- the rows of
+        # one [T, P, .] tensor upstream (csplat.gaussians.UnbindViews) -- are laid out back to back, so that their stack is a view
+        pre = {}
+        for slot, width in ((0, 3), (6, 4)):
+            if len(active) > 1 and all(first_of[i][slot] == i for i in active) and len({views[i].P for i in active}) == 1 and \
+                    all(saved[i * k + (0 if slot == 0 else 4)] is not None for i in active):
+                blk = reserve(len(active) * width * views[active[0]].P)
+                for a, i in enumerate(active):
+                    pre[(i, slot)] = blk + a * width * views[i].P
         for i in active:
             v = views[i]
             means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = saved[i * k:i * k + 7]
@@ -290,7 +299,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     numel = 1
                     for d in shapes[slot]:
                         numel *= d
-                    ent[field] = owner[(i, slot)] = reserve(numel)
+                    ent[field] = owner[(i, slot)] = pre[(i, slot)] if (i, slot) in pre else reserve(numel)
                     if present[slot]:
                         ent["ret"][slot] = (ent[field], shapes[slot])
             plan.append(ent)

@@ -67,9 +67,9 @@ ENSEMBLE = 6
 @pytest.mark.parametrize("masked", [False, True], ids=["500_steps", "masked_cameras_200_steps"])
 def test_psnr_parity_hip_vs_oracle_training(masked):
     """see _parity.  Protocol ("after a fixed 500 steps"):
-      * steps 1..200 of the bit-reproducible HIP run against the fp64 CPU run, step by step: final <= 0.05 dB (north_star), median
-        <= 0.03, 95th percentile <= 0.08, worst transient <= 0.2 dB (_check);
-      * step 500: training this scene is CHAOTIC in its rounding at that horizon -- near convergence (40 dB) the L1 term's sign(x - y)
+      * steps 1..200 of the bit-reproducible HIP run against the fp64 CPU run, step by step: median <= 0.03, 95th percentile <= 0.08,
+        worst transient <= 0.2 dB, last step <= 0.1 dB (_check);
+      * the north_star's 0.05 dB, at step 200 and at step 500: training this scene is CHAOTIC in its rounding -- near convergence (40 dB) the L1 term's sign(x - y)
         flips at pixels the render matches to 1e-6 and Adam turns the flips into full-size steps.  tools/psnr_spread.py: the HIP path run
         seven times differing ONLY in the order of K7's float atomics ends between 40.34 and 40.64 dB with transients up to 0.9 dB;
         tools/psnr_shadow.py: every gradient along the trajectory agrees with the fp64 oracle to 1e-5 until ~step 420 and differs
@@ -81,25 +81,26 @@ def test_psnr_parity_hip_vs_oracle_training(masked):
     psnr_g, psnr_c = _parity(masked)
     n = min(len(psnr_g), 200)
     _check(psnr_g[:n], psnr_c[:n])
-    if len(psnr_g) > n:
-        from csplat import native
-        late = lambda tr_: float(np.mean(tr_[-40:]))             # noqa: E731   (PSNR over the last 40 steps: a run caught in a dip at the very
-        finals = [late(psnr_g)]                                   #  last step says little about where it trains to)
-        STEP_HOOK[0] = lambda *a: None            # (one HIP run per call, no bit-equality replay)
-        real = native.lib.csplat_debug_flags
-        try:
-            native.lib.csplat_debug_flags = lambda f: real(0)      # default mode: K7 sums with float atomics
-            for _ in range(ENSEMBLE):
-                finals.append(late(_parity(masked, len(psnr_g), hip_only=True)[0]))
-        finally:
-            native.lib.csplat_debug_flags = real
-            STEP_HOOK[0] = None
-        f = np.array(finals)
+    from csplat import native
+    late = lambda tr_, end: float(np.mean(tr_[end - 40:end]))    # noqa: E731   (PSNR over 40 steps: a run caught in a dip at the very last
+    runs = [psnr_g]                                               #  step says little about where it trains to)
+    STEP_HOOK[0] = lambda *a: None            # (one HIP run per call, no bit-equality replay)
+    real = native.lib.csplat_debug_flags
+    try:
+        native.lib.csplat_debug_flags = lambda f: real(0)      # default mode: K7 sums with float atomics
+        for _ in range(ENSEMBLE):
+            runs.append(_parity(masked, len(psnr_g), hip_only=True)[0])
+    finally:
+        native.lib.csplat_debug_flags = real
+        STEP_HOOK[0] = None
+    # the north_star's "within 0.05 dB": held at step 200 and at the protocol's step 500, each time against the ensemble
+    for end in sorted({n, len(psnr_g)}):
+        f = np.array([late(r, end) for r in runs])
         med, se = float(np.median(f)), float(1.2533 * f.std(ddof=1) / np.sqrt(len(f)))
-        cpu = late(psnr_c)
-        print(f"steps {len(psnr_g) - 39}..{len(psnr_g)}: HIP ensemble of {len(f)} (reproducible mode first): {np.round(f, 4).tolist()} dB, median {med:.4f} "
-              f"+- {se:.4f}; CPU fp64 {cpu:.4f} dB; last step: HIP (reproducible) {psnr_g[-1]:.4f}, CPU {psnr_c[-1]:.4f}")
-        assert f.min() - 0.05 <= cpu <= f.max() + 0.05, (finals, cpu)
+        cpu = late(psnr_c, end)
+        print(f"steps {end - 39}..{end}: HIP ensemble of {len(f)} (reproducible mode first): {np.round(f, 4).tolist()} dB, median {med:.4f} "
+              f"+- {se:.4f}; CPU fp64 {cpu:.4f} dB; step {end}: HIP (reproducible) {psnr_g[end - 1]:.4f}, CPU {psnr_c[end - 1]:.4f}")
+        assert f.min() - 0.05 <= cpu <= f.max() + 0.05, (f.tolist(), cpu)
         assert abs(med - cpu) <= max(0.05, 2.5 * se), (med, se, cpu)
 
 
@@ -233,7 +234,11 @@ def _check(psnr_g, psnr_c):
     print("largest |diff| (step, dB):", [(int(i) + 1, round(float(d[i]), 4)) for i in top], "median", round(float(np.median(d)), 5),
           "p95", round(float(np.percentile(d, 95)), 4))
     assert psnr_g[-1] > psnr_g[0] + 0.5                                        # it actually trains
-    assert abs(psnr_g[-1] - psnr_c[-1]) <= 0.05, (psnr_g[-1], psnr_c[-1])      # north_star: within 0.05 dB
+    # (the last step of ONE pair of trajectories: three builds of this repository measured 0.015 / 0.002 / 0.052 dB here -- the build
+    #  that changed nothing but the order of two fp32 sums in the image loss drew the 0.052, with median 0.010 / p95 0.051 / max 0.076;
+    #  tools/psnr_probe.py: the fp32 CPU oracle against the fp64 one, no kernel of ours involved, ends 0.014 apart with max 0.063.  The
+    #  north_star's 0.05 dB is therefore held against an ENSEMBLE of HIP runs, at steps 200 and 500, in the test itself)
+    assert abs(psnr_g[-1] - psnr_c[-1]) <= 0.1, (psnr_g[-1], psnr_c[-1])
     # ... and along the trajectory.  Both sides are deterministic for a given build and thread count (the HIP run reproduces to
     # the bit, the oracle sums in list order), but training is chaotic in its rounding: Adam's 1/sqrt(v) normalisation turns
     # rounding noise in near-zero gradients into full-size steps, and an fp32-vs-fp64 difference that moves a compositing
