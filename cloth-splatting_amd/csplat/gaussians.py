@@ -27,7 +27,7 @@ class MeshTransform(torch.autograd.Function):
         P = int(vid.shape[0])
         xyz = torch.empty((T, P, 3) if batched else (P, 3), dtype=torch.float32, device=vertices.device)
         quat = torch.empty((T, P, 4) if batched else (P, 4), dtype=torch.float32, device=vertices.device)
-        with torch.cuda.device(vertices.device):
+        with _n.on_device(vertices.device):
             _n.check(_n.lib.csplat_mesh_transform_fwd_views(_n.stream_handle(vertices.device), T, P, V, _n.ptr(vid),
                                                             _n.ptr(vertices), _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest),
                                                             _n.ptr(xyz), _n.ptr(quat)), "csplat_mesh_transform_fwd_views")
@@ -43,7 +43,7 @@ class MeshTransform(torch.autograd.Function):
         scratch = None if rowptr is None else torch.empty(max(T * P * 9, 1), dtype=torch.float32, device=vertices.device)
         g_xyz = None if g_xyz is None else g_xyz.contiguous().float()
         g_quat = None if g_quat is None else g_quat.contiguous().float()
-        with torch.cuda.device(vertices.device):
+        with _n.on_device(vertices.device):
             _n.check(_n.lib.csplat_mesh_transform_bwd_views(_n.stream_handle(vertices.device), T, P, V, _n.ptr(vid),
                                                             _n.ptr(vertices), _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest),
                                                             _n.ptr(g_xyz), _n.ptr(g_quat), _n.ptr(d_v), _n.ptr(d_b), _n.ptr(d_r),
@@ -78,7 +78,7 @@ class _GaussianActivations(torch.autograd.Function):
         P = op_raw.shape[0]
         opacity, scales = torch.empty_like(op_raw), torch.empty_like(sc_raw)
         shs = torch.empty(P, 16, 3, dtype=torch.float32, device=op_raw.device)
-        with torch.cuda.device(op_raw.device):
+        with _n.on_device(op_raw.device):
             _n.check(_n.lib.csplat_gauss_act_fwd(_n.stream_handle(op_raw.device), P, _n.ptr(op_raw), _n.ptr(sc_raw), _n.ptr(f_dc),
                                                  _n.ptr(f_rest), _n.ptr(opacity), _n.ptr(scales), _n.ptr(shs)), "csplat_gauss_act_fwd")
         ctx.save_for_backward(opacity, scales)
@@ -95,7 +95,7 @@ class _GaussianActivations(torch.autograd.Function):
         d_op, d_sc = torch.empty_like(opacity), torch.empty_like(scales)
         d_dc = torch.empty(P, 1, 3, dtype=torch.float32, device=dev)
         d_rest = torch.empty(P, 15, 3, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             _n.check(_n.lib.csplat_gauss_act_bwd(_n.stream_handle(dev), P, _n.ptr(opacity), _n.ptr(scales), _n.ptr(g_op), _n.ptr(g_sc),
                                                  _n.ptr(g_shs), _n.ptr(d_op), _n.ptr(d_sc), _n.ptr(d_dc), _n.ptr(d_rest)),
                      "csplat_gauss_act_bwd")
@@ -284,7 +284,7 @@ class MeshGaussians(DensifyMixin):
         if r is None or r[0] != key or r[5] is not fi or r[6] is not mp:
             vid = self._vertex_ids().contiguous()
             rest = torch.empty(max(int(_n.lib.csplat_mesh_rest_bytes(vid.shape[0])), 256), dtype=torch.uint8, device=vid.device)
-            with torch.cuda.device(vid.device):
+            with _n.on_device(vid.device):
                 _n.check(_n.lib.csplat_mesh_rest(_n.stream_handle(vid.device), int(vid.shape[0]), _n.ptr(vid),
                                                  _n.ptr(self.mesh.pos.contiguous().float()), _n.ptr(rest)), "csplat_mesh_rest")
             # vertex <- (Gaussian, corner) incidence, grouped by vertex in ascending pair order: the backward gathers the

@@ -43,25 +43,10 @@ class GroupedAdam(torch.optim.Adam):
                     st[k] = v.clone()
         return sd
 
-    def _step_count(self, st):
-        """the parameter's step count AFTER this step, as a Python int.  torch keeps it as a CPU tensor in the state (that is what
-        state_dict() saves), and reading it back with .item() costs more than the rest of this function: a mirror keyed on the tensor
-        OBJECT and its in-place version supplies it (a loaded state dict brings new tensors, an in-place edit bumps the version: both
-        are read back once)."""
-        t = st["step"]
-        mirror = self.__dict__.setdefault("_py_steps", {})
-        if len(mirror) > 4096:      # (entries of replaced state tensors are never looked up again)
-            mirror.clear()
-        hit = mirror.get(id(t))
-        # (valid while it is the same tensor object and nobody but our own _foreach_add_ has written to it since)
-        n = (hit[1] if hit is not None and hit[0] is t and hit[2] == t._version else int(t.item())) + 1
-        mirror[id(t)] = (t, n, t._version + 1)
-        return n
-
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None or not self._fusable():
-            self.__dict__.pop("_py_steps", None)
+            self.__dict__.pop("_step_cache", None)
             return super().step(closure)
         return self._fused_step()
 
@@ -82,39 +67,55 @@ class GroupedAdam(torch.optim.Adam):
 
     def _fused_step(self):
         buckets = {}
-        keep = []
         steps = []
+        state = self.state
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             bkey = (float(beta1), float(beta2), float(group["eps"]))
             lr = float(group["lr"])
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                st = self.state[p]
+                st = state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                n = self._step_count(st)
-                steps.append(st["step"])
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not g.is_contiguous():
+                    g = g.contiguous()
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32 and v.dtype == torch.float32):
                     raise RuntimeError("GroupedAdam: optimizer state must be contiguous fp32")
-                keep.append(g)
-                buckets.setdefault((p.device,) + bkey + (n,), []).append((p, g, m, v, lr))
-        if steps:
-            torch._foreach_add_(steps, 1)              # the state's own counters, all in one call
-        for (dev, beta1, beta2, eps, step), items in buckets.items():
-            n = len(items)
-            arr = lambda k: (C.c_void_p * n)(*[it[k].data_ptr() for it in items])  # noqa: E731
-            numel = (C.c_int64 * n)(*[it[0].numel() for it in items])
-            lrs = (C.c_double * n)(*[it[4] for it in items])
-            with torch.cuda.device(dev):
-                _n.check(_n.lib.csplat_adam_step(_n.stream_handle(dev), n, C.cast(arr(0), C.c_void_p), C.cast(arr(1), C.c_void_p),
-                                                 C.cast(arr(2), C.c_void_p), C.cast(arr(3), C.c_void_p), C.cast(numel, C.c_void_p),
-                                                 C.cast(lrs, C.c_void_p), beta1, beta2, eps, step), "csplat_adam_step")
+                steps.append(st["step"])
+                buckets.setdefault((p.device,) + bkey, []).append((p, g, m, v, lr, st))
+        if not steps:
+            return None
+        # the step counts AFTER this step as Python ints.  torch keeps them as CPU tensors in the state (that is what state_dict()
+        # saves) and reading them back costs more than the rest of this function.  Usual case: the same state tensors as last time,
+        # written by nobody but our own _foreach_add_ -> every count is last time's + 1 (ONE identity / version check for all)
+        sig = (tuple(map(id, steps)), sum(t._version for t in steps))
+        cache = self.__dict__.get("_step_cache")
+        if cache is not None and cache[0] == sig[0] and cache[1] == sig[1] and all(a is b for a, b in zip(cache[3], steps)):
+            counts = [n + 1 for n in cache[2]]
+        else:
+            counts = [int(t.item()) + 1 for t in steps]
+        torch._foreach_add_(steps, 1)              # the state's own counters, all in one call
+        self._step_cache = (sig[0], sig[1] + len(steps), counts, steps)
+        count_of = {id(t): n for t, n in zip(steps, counts)}
+        for (dev, beta1, beta2, eps), all_items in buckets.items():
+            by_step = {}
+            for it in all_items:
+                by_step.setdefault(count_of[id(it[5]["step"])], []).append(it)
+            for step, items in by_step.items():
+                n = len(items)
+                ptrs = [(C.c_void_p * n)(*[it[k].data_ptr() for it in items]) for k in range(4)]
+                numel = (C.c_int64 * n)(*[it[0].numel() for it in items])
+                lrs = (C.c_double * n)(*[it[4] for it in items])
+                with _n.on_device(dev):
+                    _n.check(_n.lib.csplat_adam_step(_n.stream_handle(dev), n, C.cast(ptrs[0], C.c_void_p), C.cast(ptrs[1], C.c_void_p),
+                                                     C.cast(ptrs[2], C.c_void_p), C.cast(ptrs[3], C.c_void_p), C.cast(numel, C.c_void_p),
+                                                     C.cast(lrs, C.c_void_p), beta1, beta2, eps, step), "csplat_adam_step")
         return None
 
 

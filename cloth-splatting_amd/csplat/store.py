@@ -113,7 +113,7 @@ class GaussianStore:
             out = torch.empty(n, dtype=torch.int32, device=mask.device)
             cnt = torch.zeros(1, dtype=torch.int32, device=mask.device)
             tmp = torch.empty(int(_n.lib.csplat_mask_to_map_temp_bytes(n)), dtype=torch.uint8, device=mask.device)
-            with torch.cuda.device(mask.device):
+            with _n.on_device(mask.device):
                 _n.check(_n.lib.csplat_mask_to_map(_n.stream_handle(mask.device), n, _n.ptr(m8), int(base), _n.ptr(out), _n.ptr(cnt),
                                                    _n.ptr(tmp)), "csplat_mask_to_map")
             return out, int(cnt.item())
@@ -135,7 +135,7 @@ class GaussianStore:
                 srcs = (C.c_void_p * n)(*[None if k is None else k.data_ptr() for k in keep[c0:c0 + 32]])
                 dsts = (C.c_void_p * n)(*[d.data_ptr() for _, d in chunk])
                 rb = (C.c_int64 * n)(*[d[0].numel() * d.element_size() for _, d in chunk])
-                with torch.cuda.device(dev):
+                with _n.on_device(dev):
                     _n.check(_n.lib.csplat_rows_scatter(_n.stream_handle(dev), n, C.cast(srcs, C.c_void_p), C.cast(dsts, C.c_void_p),
                                                         C.cast(rb, C.c_void_p), int(n_rows), _n.ptr(row_map)), "csplat_rows_scatter")
             return

@@ -107,7 +107,7 @@ class FusedL1(torch.autograd.Function):
             B, Cc, hw, mc = _mask_layout(a, mask)
         else:
             B, Cc, hw, mc = 1, 1, a.numel(), 1
-        with torch.cuda.device(a.device):
+        with _n.on_device(a.device):
             if need:
                 sign8 = torch.empty(a.numel(), dtype=torch.int8, device=a.device)
                 _n.check(_n.lib.csplat_l1_signs(_n.stream_handle(a.device), B, Cc, hw, _n.ptr(a), _n.ptr(b), _n.ptr(mask), mc, _n.ptr(scratch),
@@ -124,7 +124,7 @@ class FusedL1(torch.autograd.Function):
         B, Cc, hw, mc, shape = ctx.layout
         g = g.reshape(1).float().contiguous()
         out = torch.empty(shape, dtype=torch.float32, device=sign8.device)
-        with torch.cuda.device(sign8.device):
+        with _n.on_device(sign8.device):
             _n.check(_n.lib.csplat_l1_signs_bwd(_n.stream_handle(sign8.device), B, Cc, hw, _n.ptr(sign8), _n.ptr(mask), mc, _n.ptr(g), _n.ptr(out)),
                      "csplat_l1_signs_bwd")
         ga = out if ctx.needs_input_grad[0] else None
@@ -141,7 +141,7 @@ class GaussianBlur11(torch.autograd.Function):
         x = x.contiguous().float()
         H, W = x.shape[-2:]
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _n.on_device(x.device):
             _n.check(_n.lib.csplat_blur11(_n.stream_handle(x.device), x.numel() // (H * W), H, W, _taps(), _n.ptr(x), _n.ptr(out)),
                      "csplat_blur11")
         return out
@@ -183,7 +183,7 @@ class FusedSSIM(torch.autograd.Function):
         need = img1.requires_grad
         p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=x.device) if need else None
         partial = torch.empty(int(_n.lib.csplat_ssim_partial_count(n_img, H, W)), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _n.on_device(x.device):
             _n.check(_n.lib.csplat_ssim_fwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y),
                                             _n.ptr(p[0]) if need else None, _n.ptr(p[1]) if need else None,
                                             _n.ptr(p[2]) if need else None, None, _n.ptr(partial)), "csplat_ssim_fwd")
@@ -197,7 +197,7 @@ class FusedSSIM(torch.autograd.Function):
         n_img, H, W = ctx.dims
         g = g.reshape(1).float().contiguous()
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _n.on_device(x.device):
             _n.check(_n.lib.csplat_ssim_bwd(_n.stream_handle(x.device), n_img, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
                                             _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(g), 1.0 / float(x.numel()), None, None, _n.ptr(dx)),
                      "csplat_ssim_bwd")
@@ -242,7 +242,7 @@ class FusedImageLoss(torch.autograd.Function):
         p = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=dev) if need else None
         sign = torch.empty(x.shape, dtype=torch.int8, device=dev) if need else None
         addc = None if add is None else add.reshape(1).float()
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             scratch = _image_loss_scratch(dev, (B, Cc, H, W))
             _n.check(_n.lib.csplat_image_loss_fwd(_n.stream_handle(dev), B, Cc, H, W, _taps(), _n.ptr(x), _n.ptr(y),
                                                   None if mask is None else _n.ptr(mask), mc, float(lam), float(img_weight),
@@ -266,7 +266,7 @@ class FusedImageLoss(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            with torch.cuda.device(x.device):
+            with _n.on_device(x.device):
                 _n.check(_n.lib.csplat_image_loss_bwd(_n.stream_handle(x.device), B, Cc, H, W, _taps(), _n.ptr(x), _n.ptr(y), _n.ptr(p[0]),
                                                       _n.ptr(p[1]), _n.ptr(p[2]), _n.ptr(sign), None if mask is None else _n.ptr(mask), mc,
                                                       lam, w_img, _n.ptr(g), _n.ptr(dx)), "csplat_image_loss_bwd")
@@ -323,7 +323,7 @@ def psnr(img1, img2):
         B = int(a.shape[0])
         out = torch.empty(B, 1, dtype=torch.float32, device=a.device)
         scratch = torch.empty(_n.lib.csplat_psnr_scratch_bytes(B), dtype=torch.uint8, device=a.device)
-        with torch.cuda.device(a.device):
+        with _n.on_device(a.device):
             _n.check(_n.lib.csplat_psnr(_n.stream_handle(a.device), B, a.numel() // B, _n.ptr(a), _n.ptr(b), _n.ptr(scratch),
                                         _n.ptr(out)), "csplat_psnr")
         return out
@@ -360,7 +360,7 @@ class FusedClothRegs(torch.autograd.Function):
         E = int(edge_index.shape[1])
         loss = torch.empty((), dtype=torch.float32, device=D.device)
         grad = torch.empty_like(D)
-        with torch.cuda.device(D.device):
+        with _n.on_device(D.device):
             key = ("regs", D.device, torch.cuda.current_stream(D.device).cuda_stream, T, V, E)
             scratch = _IMG_SCRATCH.get(key)              # zeroed once per (device, stream, sizes): the kernel leaves its ticket at zero
             if scratch is None:
@@ -478,7 +478,7 @@ def step_stats(grads, radii_list, P, dev, dtype=torch.float32):
         vis = torch.empty(P, dtype=torch.bool, device=dev)
         gp = (C.c_void_p * V)(*[None if g is None else g.data_ptr() for g in grads])
         rp = (C.c_void_p * V)(*[r.data_ptr() for r in radii_list])
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             _n.check(_n.lib.csplat_step_stats(_n.stream_handle(dev), P, V, gp, rp, _n.ptr(vsg), _n.ptr(radii), _n.ptr(vis)), "csplat_step_stats")
         return vsg.to(dtype), radii, vis
     if radii_list[0].is_cuda:

@@ -80,7 +80,7 @@ class _View:
         self.radii = torch.empty(self.P, dtype=torch.int32, device=dev)
         self.alloc = _n.ChunkAllocator(dev)
         tk = C.c_int(-1)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             rc = _n.lib.csplat_forward_begin(
                 _n.stream_handle(dev), self.P, int(rs.sh_degree), self.M, _n.ptr(self.bg), self.W, self.H,
                 _n.ptr(self.means3D), _n.ptr(self.sh), _n.ptr(self.colors_precomp), _n.ptr(self.opacities),
@@ -94,7 +94,7 @@ class _View:
         """reads num_rendered (the one host round trip), allocates the R-sized chunks, K3..K6 on the begin() stream"""
         R = C.c_int(0)
         geom, binning, image = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        with torch.cuda.device(self.dev):
+        with _n.on_device(self.dev):
             rc = _n.lib.csplat_forward_finish(self.ticket, _n.ptr(self.color), _n.ptr(self.depth), C.byref(R),
                                               C.byref(geom), C.byref(binning), C.byref(image))
         self.ticket = None
@@ -119,7 +119,7 @@ class _View:
         d_rot = new(P, 4) if rotations is not None else None
         scratch = torch.empty(max(int(_n.lib.csplat_backward_scratch_bytes(P, self.num_rendered)), 256), dtype=torch.uint8,
                               device=dev)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             rc = _n.lib.csplat_backward(
                 _n.stream_handle(dev), P, int(rs.sh_degree), M, self.num_rendered, _n.ptr(self.bg), self.W, self.H,
                 _n.ptr(means3D), _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(scales), float(rs.scale_modifier),
@@ -224,7 +224,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             w.cov3D_precomp, w.view, w.proj, w.campos = _n.ptr(v.cov3Ds_precomp), _n.ptr(v.view), _n.ptr(v.proj), _n.ptr(v.campos)
             w.alloc_ctx = i
             w.out_color, w.out_depth, w.radii = _n.ptr(v.color), _n.ptr(v.depth), _n.ptr(v.radii)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             rc = _n.lib.csplat_forward_views(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream)
         _n.check(rc, "csplat_forward_views")
         outs, saved = [], []
@@ -342,7 +342,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         gs = [_f32c(gcol[i], dev) for i in active]
         for a, g in enumerate(gs):
             plan["sub"][a].dL_dpix = _n.ptr(g)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             rc = _n.lib.csplat_backward_views(len(active), C.cast(plan["sub"], C.c_void_p), main.cuda_stream)
         _n.check(rc, "csplat_backward_views")
         return (None, None) + tuple(plan["out"])

@@ -67,7 +67,7 @@ class _ProjectPoints(torch.autograd.Function):
         from csplat import native as _n
         pts = points.contiguous().float()
         out = torch.empty(pts.shape[0], 2, dtype=torch.float32, device=pts.device)
-        with torch.cuda.device(pts.device):
+        with _n.on_device(pts.device):
             _n.check(_n.lib.csplat_project_points(_n.stream_handle(pts.device), pts.shape[0], _n.ptr(full), W, H, _n.ptr(pts),
                                                   _n.ptr(out)), "csplat_project_points")
         ctx.save_for_backward(points, full)

@@ -22,7 +22,7 @@ class GraphCSR:
         dev = edge_index.device
         self.rowptr, self.perm = {}, {}
         tmp = torch.empty(max(int(_n.lib.csplat_gnn_csr_temp_bytes(self.N, self.E)), 256), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             for name, row in (("src", 0), ("dst", 1)):
                 rp = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
                 pm = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
@@ -69,7 +69,7 @@ class EdgeCombine(torch.autograd.Function):
         xa, xb, ec = _f32(xa), _f32(xb), _f32(ec)
         E, L = ec.shape
         out = torch.empty_like(ec)
-        with torch.cuda.device(ec.device):
+        with _n.on_device(ec.device):
             _n.check(_n.lib.csplat_gnn_edge_combine_fwd(_n.stream_handle(ec.device), csr.N, E, L, _n.ptr(csr.ei), _n.ptr(xa),
                                                         _n.ptr(xb), _n.ptr(ec), int(relu), _n.ptr(out)),
                      "csplat_gnn_edge_combine_fwd")
@@ -86,7 +86,7 @@ class EdgeCombine(torch.autograd.Function):
         gm = torch.empty_like(g) if ctx.relu else g
         dxa = torch.empty(csr.N, L, dtype=torch.float32, device=g.device)
         dxb = torch.empty_like(dxa)
-        with torch.cuda.device(g.device):
+        with _n.on_device(g.device):
             _n.check(_n.lib.csplat_gnn_edge_combine_bwd(
                 _n.stream_handle(g.device), csr.N, E, L, _n.ptr(g), _n.ptr(out), int(ctx.relu), _n.ptr(csr.rowptr["dst"]),
                 _n.ptr(csr.perm["dst"]), _n.ptr(csr.rowptr["src"]), _n.ptr(csr.perm["src"]), _n.ptr(gm), _n.ptr(dxa),
@@ -102,7 +102,7 @@ class SegmentSum(torch.autograd.Function):
         msg = _f32(msg)
         E, L = msg.shape
         agg = torch.empty(csr.N, L, dtype=torch.float32, device=msg.device)
-        with torch.cuda.device(msg.device):
+        with _n.on_device(msg.device):
             _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(msg.device), csr.N, E, L, _n.ptr(msg),
                                                    _n.ptr(csr.rowptr["dst"]), _n.ptr(csr.perm["dst"]), _n.ptr(agg)),
                      "csplat_gnn_segment_sum")
@@ -115,7 +115,7 @@ class SegmentSum(torch.autograd.Function):
         g = _f32(g)
         L = g.shape[1]
         out = torch.empty(csr.E, L, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _n.on_device(g.device):
             _n.check(_n.lib.csplat_gnn_gather_rows(_n.stream_handle(g.device), csr.E, L, _n.ptr(g), csr.ei[1].data_ptr(),
                                                    _n.ptr(out)), "csplat_gnn_gather_rows")
         return out, None
@@ -132,7 +132,7 @@ class RowsDot(torch.autograd.Function):
         R = weight.shape[0]
         y = torch.empty(T, R, dtype=torch.float32, device=h.device)
         add = None if add is None else _f32(add.reshape(T, R))
-        with torch.cuda.device(h.device):
+        with _n.on_device(h.device):
             _n.check(_n.lib.csplat_rows_dot_fwd(_n.stream_handle(h.device), T, R, K, _n.ptr(weight), _n.ptr(bias), _n.ptr(h),
                                                 _n.ptr(y), None if add is None else _n.ptr(add)), "csplat_rows_dot_fwd")
         ctx.add_shape = None if add is None else add.shape
@@ -147,7 +147,7 @@ class RowsDot(torch.autograd.Function):
         R = weight.shape[0]
         dW, db, dh = torch.empty_like(weight), torch.empty(R, dtype=torch.float32, device=g.device), torch.empty_like(h)
         scratch = torch.empty(_n.lib.csplat_rows_dot_scratch_bytes(T), dtype=torch.uint8, device=g.device)
-        with torch.cuda.device(g.device):
+        with _n.on_device(g.device):
             _n.check(_n.lib.csplat_rows_dot_bwd(_n.stream_handle(g.device), T, R, K, _n.ptr(weight), _n.ptr(h), _n.ptr(g),
                                                 _n.ptr(dW), _n.ptr(db), _n.ptr(dh), _n.ptr(scratch)), "csplat_rows_dot_bwd")
         return dh, dW, db, (g if ctx.add_shape is not None and ctx.needs_input_grad[3] else None)
@@ -166,7 +166,7 @@ class SimHidden(torch.autograd.Function):
         T, K0 = int(e.shape[0]), int(e.shape[1])
         h1 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
         h2 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
-        with torch.cuda.device(e.device):
+        with _n.on_device(e.device):
             _n.check(_n.lib.csplat_sim_hidden_fwd(_n.stream_handle(e.device), T, K0, _n.ptr(e), _n.ptr(W1), _n.ptr(b1), _n.ptr(W2), _n.ptr(b2),
                                                   _n.ptr(h1), _n.ptr(h2)), "csplat_sim_hidden_fwd")
         ctx.save_for_backward(e, W2, h1, h2)
@@ -181,7 +181,7 @@ class SimHidden(torch.autograd.Function):
         dW1 = torch.empty(256, K0, dtype=torch.float32, device=dev)
         dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
         db = torch.empty(2, 256, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _n.on_device(dev):
             key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
             scratch = _SIMH_SCRATCH.get(key)        # zeroed once per stream: the kernel leaves its ticket word at zero
             if scratch is None:
@@ -265,7 +265,7 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
     add_pre = None if add_pre is None else _f32(add_pre)
     add_post = None if add_post is None else _f32(add_post)
     mask = None if mask is None else _f32(mask)
-    with torch.cuda.device(A.device):
+    with _n.on_device(A.device):
         _n.check(_n.lib.csplat_linear128_ex(_n.stream_handle(A.device), M, _n.ptr(A), weight.data_ptr(), ldw, wt, _n.ptr(bias), float(alpha),
                                             int(relu), _n.ptr(ga), _n.ptr(ia), _n.ptr(gb), _n.ptr(ib), _n.ptr(g), _n.ptr(b), eps,
                                             _n.ptr(add_pre), _n.ptr(add_post), _n.ptr(mask), _n.ptr(ln_stats), _n.ptr(out)),
@@ -289,7 +289,7 @@ def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w
     ops = [c(w_agg), c(w_x), c(b0), c(lin2.weight), c(lin2.bias), c(lin3.weight), c(lin3.bias), c(layer_norm.weight),
            c(layer_norm.bias)]
     nxt = [c(w_i_next), c(w_j_next)] if have_next else [None, None]
-    with torch.cuda.device(x.device):
+    with _n.on_device(x.device):
         _n.check(_n.lib.csplat_gnn_node_update(_n.stream_handle(x.device), N, _n.ptr(agg), _n.ptr(x), *[_n.ptr(t) for t in ops],
                                                float(layer_norm.eps), _n.ptr(nxt[0]), _n.ptr(nxt[1]), _n.ptr(x_new), _n.ptr(xa),
                                                _n.ptr(xb)), "csplat_gnn_node_update")
@@ -301,7 +301,7 @@ def ln128_fwd(x, gamma, beta, eps):
     M = x.shape[0]
     y = torch.empty_like(x)
     stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _n.on_device(x.device):
         _n.check(_n.lib.csplat_ln128_fwd(_n.stream_handle(x.device), M, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), float(eps), _n.ptr(y),
                                          _n.ptr(stats)), "csplat_ln128_fwd")
     return y, stats
@@ -315,7 +315,7 @@ def ln128_bwd(g, x, stats, gamma, want_dxsum=False, g_rows=None, x_normalized=Fa
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
     dxsum = torch.empty_like(gamma) if want_dxsum else None
     part = torch.empty(3 * int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _n.on_device(x.device):
         _n.check(_n.lib.csplat_ln128_bwd(_n.stream_handle(x.device), M, _n.ptr(g), _n.ptr(x), _n.ptr(stats), _n.ptr(gamma), _n.ptr(dx),
                                          _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dxsum), _n.ptr(g_rows), int(x_normalized), _n.ptr(part)),
                  "csplat_ln128_bwd")
@@ -357,7 +357,7 @@ def relu_mask_bias128(g, out):
     gm = torch.empty_like(g) if out is not None else None
     db = torch.empty(128, dtype=torch.float32, device=g.device)
     part = torch.empty(int(_n.lib.csplat_ln128_partial_floats(M)), dtype=torch.float32, device=g.device)
-    with torch.cuda.device(g.device):
+    with _n.on_device(g.device):
         _n.check(_n.lib.csplat_relu_mask_bias128(_n.stream_handle(g.device), M, _n.ptr(g), _n.ptr(out), _n.ptr(gm), _n.ptr(db), _n.ptr(part)),
                  "csplat_relu_mask_bias128")
     return (gm if gm is not None else g), db
@@ -371,7 +371,7 @@ def dw128(g, x, bias=False, x_relu=False):
     dW = torch.empty(128, 128, dtype=torch.float32, device=g.device)
     db = torch.empty(128, dtype=torch.float32, device=g.device) if bias else None
     ws = torch.empty(max(int(_n.lib.csplat_dw128_workspace_bytes(M)), 256), dtype=torch.uint8, device=g.device)
-    with torch.cuda.device(g.device):
+    with _n.on_device(g.device):
         _n.check(_n.lib.csplat_dw128_bias(_n.stream_handle(g.device), M, _n.ptr(g), _n.ptr(x), int(x_relu), _n.ptr(dW), _n.ptr(db), _n.ptr(ws)),
                  "csplat_dw128_bias")
     return (dW, db) if bias else dW
@@ -467,7 +467,7 @@ class EdgeTailAggregate(torch.autograd.Function):
         unit = _unit_ln(a0.device, eps)
         xhat = linear128(acts[-1], wb[2 * k - 2], wb[2 * k - 1], layer_norm=unit, ln_stats=stats)
         S = torch.empty(csr.N, 128, dtype=torch.float32, device=a0.device)
-        with torch.cuda.device(a0.device):
+        with _n.on_device(a0.device):
             _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(a0.device), csr.N, E, 128, _n.ptr(xhat),
                                                    _n.ptr(csr.rowptr["dst"]), _n.ptr(csr.perm["dst"]), _n.ptr(S)),
                      "csplat_gnn_segment_sum")
@@ -518,7 +518,7 @@ class EdgeFirstLayer(torch.autograd.Function):
             E = g.shape[0]
             dxa = torch.empty(csr.N, 128, dtype=torch.float32, device=g.device)
             dxb = torch.empty_like(dxa)
-            with torch.cuda.device(g.device):
+            with _n.on_device(g.device):
                 _n.check(_n.lib.csplat_gnn_edge_combine_bwd(
                     _n.stream_handle(g.device), csr.N, E, 128, _n.ptr(g), None, 0, _n.ptr(csr.rowptr["dst"]),
                     _n.ptr(csr.perm["dst"]), _n.ptr(csr.rowptr["src"]), _n.ptr(csr.perm["src"]), None, _n.ptr(dxa),

@@ -20,7 +20,7 @@ def edge_features(pos, edge_index):
         pos, edge_index = pos.contiguous(), edge_index.contiguous()
         E = int(edge_index.shape[1])
         out = torch.empty(E, 4, dtype=torch.float32, device=pos.device)
-        with torch.cuda.device(pos.device):
+        with _n.on_device(pos.device):
             _n.check(_n.lib.csplat_gnn_edge_features(_n.stream_handle(pos.device), E, _n.ptr(pos), _n.ptr(edge_index), _n.ptr(out)),
                      "csplat_gnn_edge_features")
         return out

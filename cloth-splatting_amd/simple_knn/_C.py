@@ -10,7 +10,7 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     pts = points.detach().to(torch.float32).contiguous()
     P = int(pts.shape[0])
     out = torch.empty(P, dtype=torch.float32, device=pts.device)
-    with torch.cuda.device(pts.device):
+    with _n.on_device(pts.device):
         if P >= BOXED_FROM:   # Morton order + box pruning (what the upstream extension does); same bits, O(P) candidates
             temp = torch.empty(int(_n.lib.csplat_dist2_temp_bytes(P)), dtype=torch.uint8, device=pts.device)
             _n.check(_n.lib.csplat_dist2_ws(_n.stream_handle(pts.device), P, _n.ptr(pts), _n.ptr(out), _n.ptr(temp)), "csplat_dist2_ws")
