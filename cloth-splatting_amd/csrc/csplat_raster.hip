@@ -1120,9 +1120,8 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
                                                    uint32_t null_rec, const float *__restrict__ bg,
                                                    int *seg_offset, float4 *__restrict__ ckpt,
                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                   float *__restrict__ out_color, float *__restrict__ out_depth) {
+                                                   float *__restrict__ out_color, float *__restrict__ out_depth, int wg) {
     __shared__ int s_ring[RING];
-    const int wg = blockIdx.x;
     const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
     if (tile >= tiles) return;
     const int lane = threadIdx.x, r = lane >> 4, l16 = lane & 15;
@@ -1416,7 +1415,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
                                                        float *__restrict__ out_color, float *__restrict__ out_depth) {
     if (ROWS)
         composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
-                           out_depth);
+                           out_depth, (int)blockIdx.x);
     else
         composite_fwd16_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
                              out_depth);
@@ -1425,10 +1424,14 @@ template <bool ROWS>
 __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
-    if (ROWS)
-        composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                           w.n_contrib, w.out_color, w.out_depth);
-    else
+    if (ROWS) {
+        // gridDim.x may be smaller than the number of (tile, block) items: a wave then walks items blockIdx.x, + gridDim.x, ... (gridDim.x
+        // a multiple of 128: the item's XCD stays blockIdx.x % 8)
+        const int total = ((tiles + 7) >> 3) * 128;
+        for (int wg = blockIdx.x; wg < total; wg += gridDim.x)
+            composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                               w.n_contrib, w.out_color, w.out_depth, wg);
+    } else
         composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
                              w.n_contrib, w.out_color, w.out_depth);
 }
@@ -3034,7 +3037,13 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         {
             ProfScope ps(PROF_K6, join);
             if (g_debug_flags & 32768u) k_composite_fwd_views<false><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
-            else k_composite_fwd_views<true><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
+            else {
+                // (an experiment that did NOT pay, csplat_debug_flags bits 17-19 = n: 1024 * n waves per view walk the items instead of
+                //  one wave per item -- same-box A/B, step of four views: 0.725 ms with one wave per item, 0.81 / 0.767 / 0.755 / 0.73 ms
+                //  for n = 1 / 2 / 4 / 7: K6 is not bound by wave dispatch, and half the waves resident cost only 1.5 x)
+                const int total = cdiv(tiles, 8) * 128, cap = (int)((g_debug_flags >> 17) & 7u) * 1024;
+                k_composite_fwd_views<true><<<dim3(cap > 0 && cap < total ? cap : total, V), 64, 0, join>>>(tiles, W, H, tab);
+            }
             LAUNCH_CHECK();
         }
         return 0;
