@@ -1023,8 +1023,8 @@ __device__ __forceinline__ float rowsel(int, float a, float b, float c, float d)
 __device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int gx, const uint64_t *__restrict__ keys_sorted,
                                                  const uint32_t *__restrict__ ids_sorted, const float4 *__restrict__ pack,
                                                  uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
-                                                 float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                 float4 *__restrict__ recB, float2 *__restrict__ recC, int exact, int64_t block) {
+    const int64_t i = block * 256 + threadIdx.x;
     if (i >= R && i != null_at) return;
     if (i == null_at) {   // the null record behind the list (at the list's CAPACITY): opacity 0, pads incomplete groups of four
         mask16[i] = 0;
@@ -1052,13 +1052,24 @@ __global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const ui
                                                       const uint32_t *__restrict__ ids_sorted, const float4 *__restrict__ pack,
                                                       uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
                                                       float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
-    block_masks_body(R, R, gx, keys_sorted, ids_sorted, pack, mask16, recA, recB, recC, exact);
+    block_masks_body(R, R, gx, keys_sorted, ids_sorted, pack, mask16, recA, recB, recC, exact, blockIdx.x);
 }
-__global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exact) {
-    const P2View &w = tab.v[blockIdx.y];
+// xcd_views = V (1, 2, 4 or 8) on a 1-D grid: a workgroup's XCD is blockIdx.x % 8 and XCD x serves ONLY view x % V.  The list entries of
+// a tile gather their Gaussians' 48-byte records in depth order (random), and a Gaussian recurs in the tiles next to and below it -- one
+// tile row later, ~2 MB of gathers per view: inside one XCD's 4 MB L2 when that L2 sees one view, outside it when the workgroups of all
+// the step's views interleave on every XCD.  xcd_views = 0: blockIdx.y = view.
+__global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exact, int xcd_views) {
+    int view = blockIdx.y;
+    int64_t block = blockIdx.x;
+    if (xcd_views > 0) {
+        const int xcd = blockIdx.x & 7;
+        view = xcd % xcd_views;
+        block = (int64_t)(blockIdx.x >> 3) * (8 / xcd_views) + xcd / xcd_views;
+    }
+    const P2View &w = tab.v[view];
     if (!p2_live(w)) return;
     block_masks_body(w.spec ? (int64_t)w.info[0] : (int64_t)w.R, (int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.pack, w.mask16,
-                     w.recA, w.recB, w.recC, exact);
+                     w.recA, w.recB, w.recC, exact, block);
 }
 
 // The survivors of block `blk` among list positions [lo, hi) of one tile, as a stream of GROUPS OF FOUR that never cross a
@@ -3031,7 +3042,11 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         {
             ProfScope ps(PROF_K5, join);
-            k_block_masks_views<<<dim3(cdiv((int64_t)maxR + 1, 256), V), 256, 0, join>>>(tab, (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
+            const int exact = (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1, nbm = cdiv((int64_t)maxR + 1, 256);
+            if ((V == 1 || V == 2 || V == 4 || V == 8) && !(g_debug_flags & (1u << 20)))     // (bit 20: blockIdx.y = view, for A/B)
+                k_block_masks_views<<<dim3((unsigned)(((int64_t)nbm * V + 7) / 8 * 8)), 256, 0, join>>>(tab, exact, V);
+            else
+                k_block_masks_views<<<dim3(nbm, V), 256, 0, join>>>(tab, exact, 0);
             LAUNCH_CHECK();
         }
         {
