@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exac
 // SEG boundary (incomplete groups are padded with -1).  A 64-entry chunk of masks is turned into list positions with one
 // ballot + mbcnt and appended to a small ring in LDS (wave-private); group k is ring[4k .. 4k+3], so row r of the wave reads
 // its survivor with one ds_read_b32.  All counters are wave-uniform (SGPRs); the mask of the next chunk is prefetched.
-constexpr int RING = 128;   // >= 3 groups in flight (12) + one chunk (64) + padding (3)
+constexpr int RING = 128;   // >= 3 groups in flight (12; K7 keeps 2) + one chunk (64) + padding (3)
 constexpr int RING16 = 256; // groups of sixteen: 3 x 16 in flight + one chunk + padding (15)
 template <int G, int RN>
 struct BlockStreamT {
@@ -1592,7 +1592,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         auto fetch = [&](Trip &t, int k) -> bool {
             if (!st.group(k, r, t.pos)) return false;
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
-            t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
+            t.a = recA[ri]; t.b = recB[ri]; t.c.x = reinterpret_cast<const float *>(recC)[2 * (size_t)ri];   // (c.y, the depth, is K6's)
             return true;
         };
         auto process = [&](const Trip &t) {
@@ -1646,9 +1646,12 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                 else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the quadrant meet here
             }
         };
-        Trip ta, tb, tc;
-        bool va = fetch(ta, 0), vb = fetch(tb, 1), vc = fetch(tc, 2);
-        int k = 3;
+        // software pipeline, TWO groups in flight: the records of group k+2 are requested when group k has been composited.  (Three in
+        // flight -- K6's depth -- cost 11 more registers: 67 VGPRs = 7 waves per SIMD; two = 57 VGPRs = 8 waves: 306 -> 294 us, same-box
+        // A/B, three alternations.  Forcing the three-deep form under 64 registers spills 7 of them: 365 us.)
+        Trip ta, tb;
+        bool va = fetch(ta, 0), vb = fetch(tb, 1);
+        int k = 2;
         if (my_stamp && threadIdx.x == 0 && va) { asm volatile("" :: "v"(ta.a.x), "v"(ta.c.x)); }
         mark(4);                                                        // masks -> ring -> the first group's records have arrived
         while (va) {
@@ -1657,9 +1660,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             if (!vb) break;
             process(tb);
             vb = fetch(tb, k++);
-            if (!vc) break;
-            process(tc);
-            vc = fetch(tc, k++);
         }
     }
     mark(5);                                                            // this wave's groups are done
@@ -1981,7 +1981,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_seg_views(int tiles, int 
     composite_bwd16_body<false, false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
                                        w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
 }
-__global__ __launch_bounds__(256) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
+__global__ __launch_bounds__(256, 8) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
                               w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp, tab.barrier_flush);
