@@ -429,6 +429,12 @@ def test_rows_dot_matches_linear_fwd_bwd(T, R):
     h2 = h.detach().clone().requires_grad_()
     rows_dot(h2, W.detach(), b.detach()).backward(dy)
     assert torch.equal(h2.grad, h.grad)
+    # `add` (the simulator's table rows, meshnet_network.py:371): the same bits as the separate addition, gradient passed through
+    base = torch.randn(T, R, device="cuda", generator=g).requires_grad_()
+    ya = rows_dot(h.detach(), W.detach(), b.detach(), base)
+    assert torch.equal(ya, base + y.detach())
+    ya.backward(dy)
+    assert torch.equal(base.grad, dy)
 
 
 def test_simulator_forward_times_equals_forward_per_time_on_gpu():

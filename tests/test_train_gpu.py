@@ -433,6 +433,47 @@ def test_fused_image_loss_side_outputs_and_weights(masked):
     assert abs(float(one[1]) - float(tr.psnr(img[:1], gt[:1]))) < 1e-4
 
 
+def test_step_stats_and_no_copy_unbind():
+    """csplat_step_stats (train_utils.py:276-285 in one launch) against the torch composition, with a camera that received no
+    gradient; UnbindViews' backward returns a VIEW when the incoming gradients sit back to back (the batched rasterizer's plan lays
+    them out that way) and the stack otherwise; the regularisers' tap joins both gradients of the vertices in one tensor."""
+    from types import SimpleNamespace
+    from csplat import train as tr
+    from csplat.gaussians import UnbindViews
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    P = 1237
+    grads = [torch.randn(P, 3, device=dev, generator=g), None, torch.randn(P, 3, device=dev, generator=g)]
+    radii = [torch.randint(0, 40, (P,), device=dev, dtype=torch.int32, generator=g) * (torch.rand(P, device=dev, generator=g) > 0.5).int()
+             for _ in range(3)]
+    vsg, rmax, vis = tr.step_stats(grads, radii, P, dev)
+    assert torch.equal(vsg, grads[0] + grads[2])
+    want = torch.stack(radii).max(0).values
+    assert torch.equal(rmax, want) and torch.equal(vis, want > 0) and vis.dtype == torch.bool
+    # --- UnbindViews
+    x = torch.randn(3, P, 4, device=dev, generator=g, requires_grad=True)
+    ys = UnbindViews.apply(x)
+    assert all(torch.equal(a, b) for a, b in zip(ys, x.unbind(0)))
+    buf = torch.randn(3 * P * 4 + 64, device=dev, generator=g)
+    gs = [buf[i * P * 4:(i + 1) * P * 4].view(P, 4) for i in range(3)]
+    (gx,) = torch.autograd.grad(ys, x, gs, retain_graph=True)
+    assert gx.data_ptr() == buf.data_ptr() and torch.equal(gx, torch.stack(gs))            # a view, no copy
+    gs2 = [gs[0], gs[2].clone(), None]
+    (gx2,) = torch.autograd.grad(ys, x, gs2)
+    assert torch.equal(gx2, torch.stack([gs2[0], gs2[1], torch.zeros_like(gs2[0])]))
+    # --- the regulariser tap: d(reg + f(vertices)) / d vertices in one tensor == the two-path autograd sum
+    T, V = 3, 400
+    D = (0.1 * torch.randn(T, V, 3, device=dev, generator=g)).requires_grad_()
+    ei = torch.stack([torch.arange(V - 1, device=dev), torch.arange(1, V, device=dev)])
+    pc = SimpleNamespace(mesh=SimpleNamespace(edge_index=ei), edge_norm=torch.rand(V - 1, 1, device=dev, generator=g) * 0.1)
+    w = torch.randn(T, V, 3, device=dev, generator=g)
+    reg, Dt = tr.regularization(D, pc, tr.DEFAULT_OPT, tap=True)
+    (1.3 * reg + (Dt * w).sum()).backward()
+    D2 = D.detach().clone().requires_grad_()
+    (1.3 * tr.regularization(D2, pc, tr.DEFAULT_OPT) + (D2 * w).sum()).backward()
+    assert float((D.grad - D2.grad).abs().max()) <= 1e-6 * float(D2.grad.abs().max())
+
+
 def test_train_step_camera_by_camera_equals_batched():
     """train_step(batched_views=False) -- render() per camera, simulator per camera, composed losses as upstream's loop --
     against the default batched step (render_views, forward_times, fused nodes): same PSNR, loss, statistics and the same
