@@ -52,6 +52,57 @@ class MeshTransform(torch.autograd.Function):
         return d_v, d_b, d_r, None, None, None, None
 
 
+def _join_views(grads, rest, dtype, dev):
+    """the [T, *rest] gradient of T unbound rows: a VIEW when the T incoming gradients sit back to back in one buffer (the batched
+    rasterizer's backward lays the per-view gradients of means3D / rotations out that way, diff_gaussian_rasterization._plan_backward),
+    their stack otherwise (None rows = zeros); None when every row is None"""
+    if all(g is None for g in grads):
+        return None
+    numel = 1
+    for d in rest:
+        numel *= d
+    g0 = grads[0]
+    if g0 is not None and all(g is not None and g.dtype == g0.dtype and g.is_contiguous() and tuple(g.shape) == tuple(rest) and
+                              g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and
+                              g.storage_offset() == g0.storage_offset() + i * numel for i, g in enumerate(grads)):
+        strides, acc = [], 1
+        for d in reversed(rest):
+            strides.append(acc)
+            acc *= d
+        return g0.as_strided((len(grads),) + tuple(rest), (numel,) + tuple(reversed(strides)))
+    return torch.stack([g if g is not None else torch.zeros(rest, dtype=dtype, device=dev) for g in grads], 0)
+
+
+class MeshTransformViews(torch.autograd.Function):
+    """MeshTransform for the T cameras of a step with the per-camera rows as SEPARATE outputs (T means3D [P,3], then T rotations [P,4]):
+    one autograd node where MeshTransform + two unbinds are three, and a backward that reads the rasterizer's per-view gradients in place."""
+
+    @staticmethod
+    def forward(ctx, vertices, bary, rotation, vid, rest, rowptr=None, corners=None):
+        vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
+        T, V, P = int(vertices.shape[0]), int(vertices.shape[1]), int(vid.shape[0])
+        xyz = torch.empty(T, P, 3, dtype=torch.float32, device=vertices.device)
+        quat = torch.empty(T, P, 4, dtype=torch.float32, device=vertices.device)
+        with _n.on_device(vertices.device):
+            _n.check(_n.lib.csplat_mesh_transform_fwd_views(_n.stream_handle(vertices.device), T, P, V, _n.ptr(vid),
+                                                            _n.ptr(vertices), _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest),
+                                                            _n.ptr(xyz), _n.ptr(quat)), "csplat_mesh_transform_fwd_views")
+        ctx.save_for_backward(vertices, bary, rotation, vid, rest, rowptr, corners)
+        ctx.dims = (T, P, V)
+        ctx.set_materialize_grads(False)
+        return tuple(xyz.unbind(0)) + tuple(quat.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        T, P, V = ctx.dims
+        dev = ctx.saved_tensors[0].device
+        g_xyz = _join_views(grads[:T], (P, 3), torch.float32, dev)
+        g_quat = _join_views(grads[T:], (P, 4), torch.float32, dev)
+        if g_xyz is None and g_quat is None:
+            return (None,) * 7
+        return MeshTransform.backward(ctx, g_xyz, g_quat)
+
+
 from .densify import DensifyMixin  # noqa: E402
 
 
@@ -103,8 +154,7 @@ class _GaussianActivations(torch.autograd.Function):
 
 
 class UnbindViews(torch.autograd.Function):
-    """x.unbind(0) whose backward does not copy when the T incoming gradients already sit back to back in one buffer -- the batched
-    rasterizer's backward lays the per-view gradients of means3D / rotations out that way (diff_gaussian_rasterization._plan_backward) --
+    """x.unbind(0) whose backward does not copy when the T incoming gradients already sit back to back in one buffer (_join_views) --
     where torch's own unbind backward is a stack (one copy launch per tensor and step)."""
 
     @staticmethod
@@ -116,23 +166,7 @@ class UnbindViews(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        T, rest = ctx.shape[0], ctx.shape[1:]
-        if all(g is None for g in grads):
-            return None
-        numel = 1
-        for d in rest:
-            numel *= d
-        g0 = grads[0]
-        if g0 is not None and all(g is not None and g.dtype == g0.dtype and g.is_contiguous() and tuple(g.shape) == rest and
-                                  g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and
-                                  g.storage_offset() == g0.storage_offset() + i * numel for i, g in enumerate(grads)):
-            strides, acc = [], 1
-            for d in reversed(rest):
-                strides.append(acc)
-                acc *= d
-            return g0.as_strided((T,) + rest, (numel,) + tuple(reversed(strides)))
-        dtype, dev = ctx.meta
-        return torch.stack([g if g is not None else torch.zeros(rest, dtype=dtype, device=dev) for g in grads], 0)
+        return _join_views(grads, ctx.shape[1:], *ctx.meta)
 
 
 class MeshGaussians(DensifyMixin):
@@ -270,11 +304,11 @@ class MeshGaussians(DensifyMixin):
     def _vertex_ids(self):
         return self.mesh.face[:, self.face_ids].transpose(0, 1)  # [P, 3]
 
-    def _fused(self, deformed_vertices):
+    def _fused(self, deformed_vertices, views=False):
         """(xyz, rotation) on the deformed mesh through the fused HIP kernel; render() asks for both, one after the other
         with the same vertex tensor, so the pair is computed once and cached on that tensor object."""
         c = self.__dict__.get("_fused_cache")
-        if c is not None and c[0] is deformed_vertices and c[1] == deformed_vertices._version:
+        if c is not None and c[0] is deformed_vertices and c[1] == deformed_vertices._version and c[3] == bool(views):
             return c[2]
         # keyed on the tensor OBJECTS (held in the cache entry, so their storage cannot be recycled under the key) and their
         # in-place version counters; densify.py also drops the entry whenever it re-creates face_ids
@@ -297,14 +331,16 @@ class MeshGaussians(DensifyMixin):
         if r[1].shape[0] != self.face_bary.shape[0] or r[1].shape[0] != self._rotation.shape[0]:
             raise _n.CsplatError(f"mesh transform: {r[1].shape[0]} face ids but {self.face_bary.shape[0]} barycentric rows / "
                                  f"{self._rotation.shape[0]} rotations")
-        out = MeshTransform.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2], r[3], r[4])
-        self._fused_cache = (deformed_vertices, deformed_vertices._version, out)
+        fn = MeshTransformViews if views else MeshTransform       # (views: T rows of means3D, then T rows of rotations)
+        out = fn.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2], r[3], r[4])
+        self._fused_cache = (deformed_vertices, deformed_vertices._version, out, bool(views))
         return out
 
     def transform_views(self, deformed_vertices):
         """get_xyz + get_rotation for the cameras of a step at once: [T,V,3] -> (tuple of T [P,3], tuple of T [P,4])."""
-        xyz, quat = self._fused(deformed_vertices)
-        return UnbindViews.apply(xyz), UnbindViews.apply(quat)
+        T = int(deformed_vertices.shape[0])
+        rows = self._fused(deformed_vertices, views=True)
+        return rows[:T], rows[T:]
 
     def get_xyz(self, deformed_vertices=None):
         if deformed_vertices is not None and deformed_vertices.is_cuda and self.fused:

@@ -180,39 +180,91 @@ class RowsDot(torch.autograd.Function):
 _SIMH_SCRATCH = {}
 
 
+def _sim_hidden_fwd(e, W1, b1, W2, b2):
+    e, W1, b1, W2, b2 = (_f32(t) for t in (e, W1, b1, W2, b2))
+    T, K0 = int(e.shape[0]), int(e.shape[1])
+    h1 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
+    h2 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
+    with _n.on_device(e.device):
+        _n.check(_n.lib.csplat_sim_hidden_fwd(_n.stream_handle(e.device), T, K0, _n.ptr(e), _n.ptr(W1), _n.ptr(b1), _n.ptr(W2), _n.ptr(b2),
+                                              _n.ptr(h1), _n.ptr(h2)), "csplat_sim_hidden_fwd")
+    return e, W2, h1, h2
+
+
+def _sim_hidden_bwd(e, W2, h1, h2, g):
+    T, K0 = int(e.shape[0]), int(e.shape[1])
+    g = _f32(g)
+    dev = g.device
+    dW1 = torch.empty(256, K0, dtype=torch.float32, device=dev)
+    dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
+    db = torch.empty(2, 256, dtype=torch.float32, device=dev)
+    with _n.on_device(dev):
+        key = (str(dev), _n.stream_handle(dev))
+        scratch = _SIMH_SCRATCH.get(key)        # zeroed once per stream: the kernel leaves its ticket word at zero
+        if scratch is None:
+            scratch = _SIMH_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_sim_hidden_scratch_bytes(8)) // 4, dtype=torch.int32, device=dev)
+        _n.check(_n.lib.csplat_sim_hidden_bwd(_n.stream_handle(dev), T, K0, _n.ptr(e), _n.ptr(W2), _n.ptr(h1), _n.ptr(h2), _n.ptr(g),
+                                              _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1]), _n.ptr(scratch)), "csplat_sim_hidden_bwd")
+    return dW1, db[0], dW2, db[1]
+
+
 class SimHidden(torch.autograd.Function):
     """relu(Linear(K0, 256)) -> relu(Linear(256, 256)) of the time-conditioned simulator (meshnet_network.py:337-338,364-366) for the
     T <= 8 time rows of a step: csplat_sim_hidden_fwd / _bwd, one launch each way instead of ~20 torch launches."""
 
     @staticmethod
     def forward(ctx, e, W1, b1, W2, b2):
-        e, W1, b1, W2, b2 = (_f32(t) for t in (e, W1, b1, W2, b2))
-        T, K0 = int(e.shape[0]), int(e.shape[1])
-        h1 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
-        h2 = torch.empty(T, 256, dtype=torch.float32, device=e.device)
-        with _n.on_device(e.device):
-            _n.check(_n.lib.csplat_sim_hidden_fwd(_n.stream_handle(e.device), T, K0, _n.ptr(e), _n.ptr(W1), _n.ptr(b1), _n.ptr(W2), _n.ptr(b2),
-                                                  _n.ptr(h1), _n.ptr(h2)), "csplat_sim_hidden_fwd")
-        ctx.save_for_backward(e, W2, h1, h2)
-        return h2
+        saved = _sim_hidden_fwd(e, W1, b1, W2, b2)
+        ctx.save_for_backward(*saved)
+        return saved[3]
 
     @staticmethod
     def backward(ctx, g):
-        e, W2, h1, h2 = ctx.saved_tensors
-        T, K0 = int(e.shape[0]), int(e.shape[1])
+        return (None,) + _sim_hidden_bwd(*ctx.saved_tensors, g)
+
+
+class SimResidual(torch.autograd.Function):
+    """the simulator's whole residual MLP for the T time rows of a step as ONE autograd node:
+        y = Linear(256, 3V)(relu(Linear(256, 256)(relu(Linear(K0, 256)(e))))) [+ base]          (meshnet_network.py:337-339,364-371)
+    = SimHidden followed by RowsDot (the same two launches each way); one node less to record and to walk in a step that is bound
+    by the host.  e (the sinusoidal code of the time values) gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, e, W1, b1, W2, b2, Wo, bo, base=None):
+        e, W2, h1, h2 = _sim_hidden_fwd(e, W1, b1, W2, b2)
+        Wo, bo = _f32(Wo), _f32(bo)
+        T, R = int(h2.shape[0]), int(Wo.shape[0])
+        y = torch.empty(T, R, dtype=torch.float32, device=h2.device)
+        add = None if base is None else _f32(base.reshape(T, R))
+        with _n.on_device(h2.device):
+            _n.check(_n.lib.csplat_rows_dot_fwd(_n.stream_handle(h2.device), T, R, 256, _n.ptr(Wo), _n.ptr(bo), _n.ptr(h2), _n.ptr(y),
+                                                None if add is None else _n.ptr(add)), "csplat_rows_dot_fwd")
+        ctx.save_for_backward(e, W2, h1, h2, Wo)
+        ctx.has_base = base is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        e, W2, h1, h2, Wo = ctx.saved_tensors
         g = _f32(g)
-        dev = g.device
-        dW1 = torch.empty(256, K0, dtype=torch.float32, device=dev)
-        dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
-        db = torch.empty(2, 256, dtype=torch.float32, device=dev)
-        with _n.on_device(dev):
-            key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
-            scratch = _SIMH_SCRATCH.get(key)        # zeroed once per stream: the kernel leaves its ticket word at zero
-            if scratch is None:
-                scratch = _SIMH_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_sim_hidden_scratch_bytes(8)) // 4, dtype=torch.int32, device=dev)
-            _n.check(_n.lib.csplat_sim_hidden_bwd(_n.stream_handle(dev), T, K0, _n.ptr(e), _n.ptr(W2), _n.ptr(h1), _n.ptr(h2), _n.ptr(g),
-                                                  _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1]), _n.ptr(scratch)), "csplat_sim_hidden_bwd")
-        return None, dW1, db[0], dW2, db[1]
+        T, R = int(h2.shape[0]), int(Wo.shape[0])
+        dWo, dbo, dh = torch.empty_like(Wo), torch.empty(R, dtype=torch.float32, device=g.device), torch.empty_like(h2)
+        scratch = torch.empty(_n.lib.csplat_rows_dot_scratch_bytes(T), dtype=torch.uint8, device=g.device)
+        with _n.on_device(g.device):
+            _n.check(_n.lib.csplat_rows_dot_bwd(_n.stream_handle(g.device), T, R, 256, _n.ptr(Wo), _n.ptr(h2), _n.ptr(g),
+                                                _n.ptr(dWo), _n.ptr(dbo), _n.ptr(dh), _n.ptr(scratch)), "csplat_rows_dot_bwd")
+        dW1, db1, dW2, db2 = _sim_hidden_bwd(e, W2, h1, h2, dh)
+        return None, dW1, db1, dW2, db2, dWo, dbo, (g if ctx.has_base and ctx.needs_input_grad[7] else None)
+
+
+def sim_residual(e, lin1, lin2, lin_out, base=None):
+    """rows_dot(sim_hidden(e, lin1, lin2), lin_out.weight, lin_out.bias, base) as one autograd node when both fused forms apply"""
+    if e.is_cuda and e.dim() == 2 and 0 < e.shape[0] <= 8 and e.shape[1] <= 16 and tuple(lin1.weight.shape) == (256, e.shape[1]) and \
+            tuple(lin2.weight.shape) == (256, 256) and lin1.bias is not None and lin2.bias is not None and not e.requires_grad and \
+            lin_out.weight.shape[1] == 256 and lin_out.bias is not None and \
+            (base is None or (base.is_cuda and base.numel() == e.shape[0] * lin_out.weight.shape[0])):
+        return SimResidual.apply(e, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin_out.weight, lin_out.bias, base)
+    return rows_dot(sim_hidden(e, lin1, lin2), lin_out.weight, lin_out.bias, base)
 
 
 def sim_hidden(e, lin1, lin2):

@@ -105,10 +105,11 @@ class ResidualMeshSimulator(torch.nn.Module):
         is a matrix-vector product per time; as an M = 1 GEMM (what nn.Linear issues) it runs at ~60 GB/s on this stack.
         graph_ops.rows_dot streams the 3V x 256 weight once for all T rows (forward) / once more for their gradients.
         encoded: encoder(times) when the caller kept it (the encoder has no parameters)."""
-        from meshnet.graph_ops import rows_dot, sim_hidden
+        from meshnet.graph_ops import rows_dot, sim_residual
         enc = self.encoder(times) if encoded is None else encoded
-        if enc.is_cuda:      # the two hidden layers in one launch each way (csplat_sim_hidden_fwd / _bwd)
-            h = sim_hidden(enc, self.input, self.hidden)
+        if enc.is_cuda:      # the two hidden layers in one launch each way (csplat_sim_hidden_fwd / _bwd), the output layer in another:
+            #                  one autograd node for the three
+            return sim_residual(enc, self.input, self.hidden, self.output, base).reshape(times.shape[0], -1, 3)
         else:
             h = torch.relu(self.hidden(torch.relu(self.input(enc))))
         # base [T, V, 3]: the table rows the residual is added to (forward_times) -- inside the output layer's launch

@@ -804,3 +804,22 @@ def test_sim_hidden_layers_match_composed_torch_fwd_bwd(T):
     assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
     for a, b in ((lin1.weight, d1.weight), (lin1.bias, d1.bias), (lin2.weight, d2.weight), (lin2.bias, d2.bias)):
         assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 1e-5
+    # the one-node form of the whole residual MLP (SimResidual = these two layers + the 256 -> 3V output layer + the table rows): the same
+    # bits as the two nodes chained
+    from meshnet.graph_ops import rows_dot, sim_residual
+    lo = torch.nn.Linear(256, 3 * 211).cuda()
+    base = torch.randn(T, 3 * 211, device="cuda", generator=torch.Generator(device="cuda").manual_seed(T)).requires_grad_()
+    wy = torch.randn(T, 3 * 211, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9 + T))
+    params = list(lin1.parameters()) + list(lin2.parameters()) + list(lo.parameters())
+    for p_ in params:
+        p_.grad = None
+    y2 = rows_dot(sim_hidden(e.cuda(), lin1, lin2), lo.weight, lo.bias, base)
+    (y2 * wy).sum().backward()
+    two = [p_.grad.clone() for p_ in params] + [base.grad.clone()]
+    for p_ in params + [base]:
+        p_.grad = None
+    y1 = sim_residual(e.cuda(), lin1, lin2, lo, base)
+    assert type(y1.grad_fn).__name__.startswith("SimResidual") and torch.equal(y1, y2)
+    (y1 * wy).sum().backward()
+    for a, b in zip([p_.grad for p_ in params] + [base.grad], two):
+        assert torch.equal(a, b)
