@@ -39,6 +39,8 @@ EXPORTS = {
                                   _i, ALLOC_FN, _vp, _vp, C.POINTER(_i)]),
     "csplat_forward_finish": (_i, [_i, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "csplat_forward_views": (_i, [_i, _vp, ALLOC_FN, _vp]),
+    "csplat_forward_views_deferred": (_i, [_i, _vp, ALLOC_FN, _vp, _vp]),
+    "csplat_forward_views_settle": (_i, [_i, _vp, _vp, _vp]),
     "csplat_backward_views": (_i, [_i, _vp, _vp]),
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -2982,7 +2982,23 @@ static SpecHist g_spec_ring[SPEC_RING];
 static int g_spec_next = 0;
 static std::mutex g_spec_mu;
 
-static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done) {
+// A call whose speculative second phase has been launched but whose counts have not been read yet (csplat_forward_views_deferred):
+// what csplat_forward_views_settle needs to finish it.  Keyed by the caller's view array.
+struct PendingViews {
+    bool used = false;
+    const csplat_view *key = nullptr;
+    int V = 0, tk[P2_MAX_VIEWS];
+    uint32_t Rcap[P2_MAX_VIEWS], Lcap = 0;
+};
+constexpr int MAX_PENDING = 8;
+static PendingViews g_pending[MAX_PENDING];
+static std::mutex g_pending_mu;
+
+// mode 0: the whole second phase (launch, read the counts, repeat with exact sizes if the speculation missed);
+// mode 1: as 0, but when the speculative launch is possible return right after it with *pend filled (pend->used) -- nothing is read;
+// mode 2: finish a mode-1 call: read the counts, accept or repeat (*relaunched)
+static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done, int mode = 0,
+                                PendingViews *pend = nullptr, int *relaunched = nullptr) {
     *done = false;
     if (V < 2 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
     const FwdTicket &a = g_tickets[tk[0]];
@@ -3092,14 +3108,26 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
                 hist.longest = e.longest > hist.longest ? e.longest : hist.longest;
             }
     }
-    if (!(g_debug_flags & 1024u) && hist.R > 0) {
+    if (mode == 2 || (!(g_debug_flags & 1024u) && hist.R > 0)) {
         uint32_t Rcap[P2_MAX_VIEWS];
-        const uint64_t want = (uint64_t)hist.R + hist.R / 8 + 4096;
-        const uint32_t rc32 = (uint32_t)(want > 0x7FFFFF00ull ? 0x7FFFFF00ull : want);
-        for (int i = 0; i < V; i++) Rcap[i] = rc32;
-        uint32_t Lcap = hist.longest + hist.longest / 4 + 64;
-        Lcap = Lcap > cap ? cap : Lcap;
-        if (int rc = launch(Rcap, Lcap, 1)) return rc;
+        uint32_t Lcap;
+        if (mode == 2) {        // the capacities the pending call was launched with
+            for (int i = 0; i < V; i++) Rcap[i] = pend->Rcap[i];
+            Lcap = pend->Lcap;
+        } else {
+            const uint64_t want = (uint64_t)hist.R + hist.R / 8 + 4096;
+            const uint32_t rc32 = (uint32_t)(want > 0x7FFFFF00ull ? 0x7FFFFF00ull : want);
+            for (int i = 0; i < V; i++) Rcap[i] = rc32;
+            Lcap = hist.longest + hist.longest / 4 + 64;
+            Lcap = Lcap > cap ? cap : Lcap;
+            if (int rc = launch(Rcap, Lcap, 1)) return rc;
+            if (mode == 1) {    // deferred: the caller reads the counts later (csplat_forward_views_settle), the GPU has its work
+                pend->used = true; pend->key = v; pend->V = V; pend->Lcap = Lcap;
+                for (int i = 0; i < V; i++) { pend->tk[i] = tk[i]; pend->Rcap[i] = Rcap[i]; v[i].num_rendered = -1; }
+                *done = true;
+                return 0;
+            }
+        }
         if (int rc = read_counts()) return rc;
         bool fits = true;
         for (int i = 0; i < V; i++) fits = fits && info[i][0] - 1u < Rcap[i] && info[i][1] <= Lcap;
@@ -3120,6 +3148,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
     }
     remember();
     if (int rc = launch(Rex, longest, 0)) return rc;
+    if (relaunched) *relaunched = 1;
     for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
     release();
     *done = true;
@@ -3376,11 +3405,30 @@ static int fence_out(int V, const csplat_view *v, hipStream_t join) {
     return 0;
 }
 
-int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream) {
+// the per-view tail of a forward call: every prepared ticket is finished (= released) even after an error
+static int finish_views_one_by_one(int V, csplat_view *v, const int *tickets, int begun, hipStream_t join, bool fenced, int rc) {
+    for (int i = 0; i < begun; i++) {
+        csplat_view &w = v[i];
+        if (rc == 0) {
+            rc = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
+            w.layout_rendered = w.num_rendered;
+        } else {
+            std::lock_guard<std::mutex> lk(g_ticket_mu);
+            g_tickets[tickets[i]].used = false;
+        }
+    }
+    // (also on the error path: the side streams may hold work on torch-owned chunks that the caller frees on its own stream as
+    // soon as the error propagates)
+    if (fenced) { const int r2 = fence_out(V, v, join); if (rc == 0) rc = r2; }
+    return rc;
+}
+
+static int forward_views_impl(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream, int *pending) {
     CSPLAT_REQUIRE(V >= 0 && V <= MAX_TICKETS && (V == 0 || v != nullptr), "csplat_forward_views: bad view count");
     hipStream_t join = (hipStream_t)join_stream;
     int tickets[MAX_TICKETS];
     int rc = 0, begun = 0;
+    if (pending) *pending = 0;
     for (; begun < V; begun++) {
         csplat_view &w = v[begun];
         rc = begin_prepare(w.stream, w.P, w.D, w.M, w.bg, w.W, w.H, w.means3D, w.shs, w.colors_precomp, w.opacities, w.scales,
@@ -3395,7 +3443,24 @@ int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *joi
         // ... and, when every tile list fits the in-LDS sort, the second phase in five more, also on the join stream: no
         // side stream is involved at all
         bool done = false;
-        if (rc == 0) rc = finish_views_batched(V, tickets, v, join, &done);
+        PendingViews pend;
+        if (rc == 0) rc = finish_views_batched(V, tickets, v, join, &done, pending ? 1 : 0, &pend);
+        if (rc == 0 && done && pend.used) {      // deferred: park the call until csplat_forward_views_settle
+            std::lock_guard<std::mutex> lk(g_pending_mu);
+            int slot = -1;
+            for (int i = 0; i < MAX_PENDING && slot < 0; i++)
+                if (!g_pending[i].used) slot = i;
+            if (slot >= 0) {
+                g_pending[slot] = pend;
+                *pending = 1;
+                return 0;
+            }
+        }
+        if (rc == 0 && done && pend.used) {      // (no free slot: settle right here)
+            int rl = 0;
+            done = false;
+            rc = finish_views_batched(V, tickets, v, join, &done, 2, &pend, &rl);
+        }
         if (done || rc) {
             if (rc) {
                 std::lock_guard<std::mutex> lk(g_ticket_mu);
@@ -3410,20 +3475,52 @@ int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *joi
         fenced = rc == 0;
         for (int i = 0; i < V && rc == 0; i++) rc = begin_launch(g_tickets[tickets[i]]);
     }
-    for (int i = 0; i < begun; i++) {   // every prepared ticket is finished (= released) even after an error
-        csplat_view &w = v[i];
-        if (rc == 0) {
-            rc = csplat_forward_finish(tickets[i], w.out_color, w.out_depth, &w.num_rendered, &w.geom, &w.binning, &w.image);
-            w.layout_rendered = w.num_rendered;
-        } else {
-            std::lock_guard<std::mutex> lk(g_ticket_mu);
-            g_tickets[tickets[i]].used = false;
-        }
+    return finish_views_one_by_one(V, v, tickets, begun, join, fenced, rc);
+}
+
+int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream) {
+    return forward_views_impl(V, v, alloc, join_stream, nullptr);
+}
+
+// csplat_forward_views with the one host read DEFERRED.  When the second phase can be launched speculatively (capacities from the
+// previous call of the same shape) the call returns right behind that launch with *pending = 1: views[i].layout_rendered is the capacity,
+// views[i].num_rendered is -1, and the caller does whatever host work it has (the GPU is busy with K1..K6) before it calls
+// csplat_forward_views_settle with the SAME array.  *pending = 0: the call was complete (first call of a shape, views that do not qualify).
+int csplat_forward_views_deferred(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream, int *pending) {
+    CSPLAT_REQUIRE(pending != nullptr, "csplat_forward_views_deferred: pending missing");
+    return forward_views_impl(V, v, alloc, join_stream, pending);
+}
+
+// Reads the counts of a pending call.  They fit the capacities: num_rendered is filled in, nothing else changes (*relaunched = 0).
+// They do not: the second phase is repeated with exact sizes -- new BINNING chunks through the allocator of the call, layout_rendered /
+// binning updated -- and *relaunched = 1: whatever the caller derived from layout_rendered must be rebuilt.
+int csplat_forward_views_settle(int V, csplat_view *v, void *join_stream, int *relaunched) {
+    CSPLAT_REQUIRE(v != nullptr && relaunched != nullptr, "csplat_forward_views_settle: bad arguments");
+    *relaunched = 0;
+    PendingViews pend;
+    {
+        std::lock_guard<std::mutex> lk(g_pending_mu);
+        int slot = -1;
+        for (int i = 0; i < MAX_PENDING && slot < 0; i++)
+            if (g_pending[i].used && g_pending[i].key == v && g_pending[i].V == V) slot = i;
+        CSPLAT_REQUIRE(slot >= 0, "csplat_forward_views_settle: no pending call for this view array");
+        pend = g_pending[slot];
+        g_pending[slot].used = false;
     }
-    // (also on the error path: the side streams may hold work on torch-owned chunks that the caller frees on its own stream as
-    // soon as the error propagates)
-    if (fenced) { const int r2 = fence_out(V, v, join); if (rc == 0) rc = r2; }
-    return rc;
+    hipStream_t join = (hipStream_t)join_stream;
+    bool done = false;
+    int rc = finish_views_batched(V, pend.tk, v, join, &done, 2, &pend, relaunched);
+    if (done || rc) {
+        if (rc) {
+            std::lock_guard<std::mutex> lk(g_ticket_mu);
+            for (int i = 0; i < V; i++) g_tickets[pend.tk[i]].used = false;
+        }
+        return rc;
+    }
+    // the exact counts do not qualify for the batched phase (a list too long for the in-LDS sort, an empty view): view by view
+    *relaunched = 1;
+    rc = fence_in(V, v, join);
+    return finish_views_one_by_one(V, v, pend.tk, V, join, rc == 0, rc);
 }
 
 // Can ONE K8 serve all views?  Same Gaussians (P, D, M, scale modifier, SH and scale tensors), SH staging applicable, and every

@@ -224,12 +224,32 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             w.cov3D_precomp, w.view, w.proj, w.campos = _n.ptr(v.cov3Ds_precomp), _n.ptr(v.view), _n.ptr(v.proj), _n.ptr(v.campos)
             w.alloc_ctx = i
             w.out_color, w.out_depth, w.radii = _n.ptr(v.color), _n.ptr(v.depth), _n.ptr(v.radii)
+        # the one host read of the call (its counts) is DEFERRED when the library can launch the second phase on the previous call's
+        # capacities: everything below that does not need the counts -- the output lists, the backward plan -- is host work done
+        # while the GPU runs K1..K6, instead of after a ~45 us wait for K1 / K2
+        pending = C.c_int(0)
         with _n.on_device(dev):
-            rc = _n.lib.csplat_forward_views(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream)
-        _n.check(rc, "csplat_forward_views")
+            rc = _n.lib.csplat_forward_views_deferred(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream, C.byref(pending))
+        _n.check(rc, "csplat_forward_views_deferred")
+        try:
+            return _RasterizeGaussiansBatch._finish_forward(ctx, views, arr, chunks, flat, stacked, colors if stacked else None, dev, main,
+                                                            pending, cb)
+        except BaseException:
+            if pending.value:        # never leave a call pending in the library (its tickets stay reserved otherwise)
+                dummy = C.c_int(0)
+                try:
+                    with _n.on_device(dev):
+                        _n.lib.csplat_forward_views_settle(V, C.cast(arr, C.c_void_p), main.cuda_stream, C.byref(dummy))
+                except Exception:
+                    pass
+            raise
+
+    @staticmethod
+    def _finish_forward(ctx, views, arr, chunks, flat, stacked, colors, dev, main, pending, cb):
+        V, n = len(views), _RasterizeGaussiansBatch.NIN
         outs, saved = [], []
         for i, v in enumerate(views):
-            v.num_rendered = int(arr[i].num_rendered)
+            v.num_rendered = int(arr[i].num_rendered)            # (-1 while the call is pending)
             v.layout_rendered = int(arr[i].layout_rendered)      # >= num_rendered: what the binning chunk was laid out for
             v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
             outs += [v.radii, v.depth] if stacked else [v.color, v.radii, v.depth]
@@ -249,8 +269,25 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # an unused view arrives as None in backward() and costs nothing
         ctx.plan = None
         if any(ctx.needs_input_grad):
-            # the GPU is busy with K3..K6 of the views right now: prepare the backward call in its shadow
+            # the GPU is busy with K1..K6 of the views right now: prepare the backward call in its shadow
             ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
+        if pending.value:
+            relaunched = C.c_int(0)
+            with _n.on_device(dev):
+                rc = _n.lib.csplat_forward_views_settle(V, C.cast(arr, C.c_void_p), main.cuda_stream, C.byref(relaunched))
+            _n.check(rc, "csplat_forward_views_settle")
+            for i, v in enumerate(views):
+                v.num_rendered = int(arr[i].num_rendered)
+            pending.value = 0
+            if relaunched.value:     # the speculation missed: new binning chunks, new layout -> the plan is rebuilt (rare)
+                for i, v in enumerate(views):
+                    v.layout_rendered = int(arr[i].layout_rendered)
+                    v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
+                if ctx.plan is not None:
+                    ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
+            elif ctx.plan is not None:
+                for a, i in enumerate(ctx.plan["active"]):
+                    ctx.plan["sub"][a].num_rendered = arr[i].num_rendered
         return tuple(outs)
 
     @staticmethod

@@ -141,6 +141,15 @@ typedef struct csplat_view {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 } csplat_view;
 int csplat_forward_views(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream);
+/* The same call with its one host read (the views' counts) DEFERRED.  When the second phase can be launched on the previous call's
+ * capacities (speculative launch, see above), csplat_forward_views_deferred returns right behind that launch with *pending = 1:
+ * layout_rendered is filled in (the capacity), num_rendered is -1; the caller does the host work that does not need the counts while
+ * the GPU runs K1..K6 and then calls csplat_forward_views_settle with the SAME array on the same join stream -- before
+ * csplat_backward_views and before reading num_rendered.  settle: counts fit -> num_rendered filled in, *relaunched = 0; they do not ->
+ * the second phase is repeated with exact sizes (new BINNING chunks through the allocator of the call, which must still be callable;
+ * layout_rendered / binning updated) and *relaunched = 1.  *pending = 0: the call was complete, nothing to settle. */
+int csplat_forward_views_deferred(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream, int *pending);
+int csplat_forward_views_settle(int V, csplat_view *views, void *join_stream, int *relaunched);
 int csplat_backward_views(int V, csplat_view *views, void *join_stream);
 
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
