@@ -353,24 +353,31 @@ class FusedClothRegs(torch.autograd.Function):
     """the three cloth regularisers and their gradient in one launch (csplat_cloth_regs); backward scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr=None, tap=False):
+    def forward(ctx, D, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr=None, tap=False, defer=False):
         D = D.contiguous().float()
         ctx.set_materialize_grads(False)
         T, V = int(D.shape[0]), int(D.shape[1])
         E = int(edge_index.shape[1])
         loss = torch.empty((), dtype=torch.float32, device=D.device)
         grad = torch.empty_like(D)
-        with _n.on_device(D.device):
-            key = ("regs", D.device, torch.cuda.current_stream(D.device).cuda_stream, T, V, E)
-            scratch = _IMG_SCRATCH.get(key)              # zeroed once per (device, stream, sizes): the kernel leaves its ticket at zero
-            if scratch is None:
-                if len(_IMG_SCRATCH) >= 64:
-                    _IMG_SCRATCH.clear()
-                scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=D.device)
-            _n.check(_n.lib.csplat_cloth_regs(_n.stream_handle(D.device), T, V, E, _n.ptr(D), _n.ptr(edge_index.contiguous()),
-                                              _n.ptr(rest_len.contiguous().float()), float(lam_deform), float(lam_rigid),
-                                              float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
-                                              *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])), "csplat_cloth_regs")
+        ei, rl = edge_index.contiguous(), rest_len.contiguous().float()
+        dev, stream = D.device, _n.stream_handle(D.device)
+
+        def launch():
+            with _n.on_device(dev):
+                key = ("regs", dev, stream, T, V, E)
+                scratch = _IMG_SCRATCH.get(key)          # zeroed once per (device, stream, sizes): the kernel leaves its ticket at zero
+                if scratch is None:
+                    if len(_IMG_SCRATCH) >= 64:
+                        _IMG_SCRATCH.clear()
+                    scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=dev)
+                _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
+                                                  float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
+                                                  *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])), "csplat_cloth_regs")
+        if defer:       # the kernel writes into `loss` / `grad`, which exist already: WHEN it is launched is the caller's choice
+            _DEFERRED.append(launch)                     # (launch_deferred(): e.g. behind the rasterizer's forward, off the step's critical path)
+        else:
+            launch()
         ctx.save_for_backward(grad)
         ctx.tap = bool(tap)
         if tap:     # D passes through: the gradient arriving for it and the regularisers' own leave as ONE tensor (one launch)
@@ -384,7 +391,16 @@ class FusedClothRegs(torch.autograd.Function):
             out = torch.addcmul(g_through, grad, g) if g is not None else g_through
         else:
             out = grad * g if g is not None else None
-        return out, None, None, None, None, None, None, None
+        return out, None, None, None, None, None, None, None, None
+
+
+_DEFERRED = []
+
+
+def launch_deferred():
+    """launches what FusedClothRegs(defer=True) queued (same stream, in order); a no-op otherwise"""
+    while _DEFERRED:
+        _DEFERRED.pop(0)()
 
 
 def edge_csr(edge_index, n_nodes):
@@ -395,12 +411,13 @@ def edge_csr(edge_index, n_nodes):
     return tuple(out)
 
 
-def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True, tap=False):
+def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True, tap=False, defer=False):
     """train_utils.py:76-237 (the active terms).  On the GPU the terms and their gradient come from one kernel
     (FusedClothRegs); fused=False composes them from torch ops as upstream does (the parity reference of the tests).
     tap=True returns (loss, vertices): `vertices` is all_vertice_deform passed THROUGH the regulariser node -- render from it and the
     two gradients of the vertices (image path, regularisers) are combined in the node's backward instead of by autograd (one launch
-    instead of a multiply and an add)."""
+    instead of a multiply and an add).  defer=True (with tap, on the fused path): the kernel is queued, not launched -- the caller runs
+    launch_deferred() once the work that must not wait for it (the rasterizer's forward) has been issued."""
     n_cams = all_vertice_deform.shape[0]
     if fused and not static and all_vertice_deform.is_cuda and all_vertice_deform.dim() == 3:
         lam_d = opt.lambda_deform_mag if opt.lambda_deform_mag > 0. else 0.
@@ -416,7 +433,8 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True,
             except Exception:
                 pass
         if tap and all_vertice_deform.dtype == torch.float32 and all_vertice_deform.is_contiguous():
-            return FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1], True)
+            return FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1], True,
+                                        bool(defer))
         loss = FusedClothRegs.apply(all_vertice_deform, ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
         return (loss, all_vertice_deform) if tap else loss
     if tap:
@@ -516,6 +534,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     and takes the same optimizer / densification decisions, so the replicas stay identical without exchanging parameters."""
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
+    _DEFERRED.clear()                 # (a launch queued by a step that raised before issuing it)
     all_cams = list(viewpoint_cams)
     n_total = len(all_cams)
     world, rank = cd.world_rank() if view_parallel else (1, 0)
@@ -544,13 +563,16 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         else:
             nv, dev0 = gaussians.mesh.pos.shape[0], gaussians.mesh.pos.device
             deforms_all = torch.stack([simulator(time_vector=torch.tensor(cam.time).to(dev0).repeat(nv, 1)) for cam in all_cams])
-        reg, deforms_all = regularization(deforms_all, gaussians, opt, static, tap=True)
+        # (defer: the regularisers feed nothing before the loss -- their launch waits until the rasterizer's forward has been issued,
+        #  the step being bound by the latency between its start and the first rasterizer kernel)
+        reg, deforms_all = regularization(deforms_all, gaussians, opt, static, tap=True, defer=True)
         deforms = deforms_all if not dist_mode else (deforms_all[idx] if idx else None)
     if dist_mode or batched_views:
         pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True,
                                      vertice_deforms=deforms, by_products=False) if cams else ([], None)
     else:
         pkgs = [render(cam, gaussians, simulator, pipe, background, render_static=static) for cam in cams]
+    launch_deferred()
     for cam, pkg in zip(cams, pkgs):
         images.append(pkg.render.unsqueeze(0))
         radii_l.append(pkg.radii.unsqueeze(0))
