@@ -120,37 +120,89 @@ def build_rotation(r):
     return R.reshape(-1, 3, 3)
 
 
+def _act_fwd(op_raw, sc_raw, f_dc, f_rest):
+    P = op_raw.shape[0]
+    opacity, scales = torch.empty_like(op_raw), torch.empty_like(sc_raw)
+    shs = torch.empty(P, 16, 3, dtype=torch.float32, device=op_raw.device)
+    with _n.on_device(op_raw.device):
+        _n.check(_n.lib.csplat_gauss_act_fwd(_n.stream_handle(op_raw.device), P, _n.ptr(op_raw), _n.ptr(sc_raw), _n.ptr(f_dc),
+                                             _n.ptr(f_rest), _n.ptr(opacity), _n.ptr(scales), _n.ptr(shs)), "csplat_gauss_act_fwd")
+    return opacity, scales, shs
+
+
+def _act_bwd(opacity, scales, g_op, g_sc, g_shs):
+    P, dev = opacity.shape[0], opacity.device
+    c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+    g_op, g_sc, g_shs = c(g_op), c(g_sc), c(g_shs)
+    d_op, d_sc = torch.empty_like(opacity), torch.empty_like(scales)
+    d_dc = torch.empty(P, 1, 3, dtype=torch.float32, device=dev)
+    d_rest = torch.empty(P, 15, 3, dtype=torch.float32, device=dev)
+    with _n.on_device(dev):
+        _n.check(_n.lib.csplat_gauss_act_bwd(_n.stream_handle(dev), P, _n.ptr(opacity), _n.ptr(scales), _n.ptr(g_op), _n.ptr(g_sc),
+                                             _n.ptr(g_shs), _n.ptr(d_op), _n.ptr(d_sc), _n.ptr(d_dc), _n.ptr(d_rest)),
+                 "csplat_gauss_act_bwd")
+    return d_op, d_sc, d_dc, d_rest
+
+
 class _GaussianActivations(torch.autograd.Function):
     """sigmoid(_opacity), exp(_scaling), cat(_features_dc, _features_rest): gaussian_model.py:96-121, one HIP launch each way"""
 
     @staticmethod
     def forward(ctx, op_raw, sc_raw, f_dc, f_rest):
-        from . import native as _n
-        P = op_raw.shape[0]
-        opacity, scales = torch.empty_like(op_raw), torch.empty_like(sc_raw)
-        shs = torch.empty(P, 16, 3, dtype=torch.float32, device=op_raw.device)
-        with _n.on_device(op_raw.device):
-            _n.check(_n.lib.csplat_gauss_act_fwd(_n.stream_handle(op_raw.device), P, _n.ptr(op_raw), _n.ptr(sc_raw), _n.ptr(f_dc),
-                                                 _n.ptr(f_rest), _n.ptr(opacity), _n.ptr(scales), _n.ptr(shs)), "csplat_gauss_act_fwd")
+        opacity, scales, shs = _act_fwd(op_raw, sc_raw, f_dc, f_rest)
         ctx.save_for_backward(opacity, scales)
         ctx.set_materialize_grads(False)
         return opacity, scales, shs
 
     @staticmethod
     def backward(ctx, g_op, g_sc, g_shs):
-        from . import native as _n
-        opacity, scales = ctx.saved_tensors
-        P, dev = opacity.shape[0], opacity.device
-        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
-        g_op, g_sc, g_shs = c(g_op), c(g_sc), c(g_shs)
-        d_op, d_sc = torch.empty_like(opacity), torch.empty_like(scales)
-        d_dc = torch.empty(P, 1, 3, dtype=torch.float32, device=dev)
-        d_rest = torch.empty(P, 15, 3, dtype=torch.float32, device=dev)
-        with _n.on_device(dev):
-            _n.check(_n.lib.csplat_gauss_act_bwd(_n.stream_handle(dev), P, _n.ptr(opacity), _n.ptr(scales), _n.ptr(g_op), _n.ptr(g_sc),
-                                                 _n.ptr(g_shs), _n.ptr(d_op), _n.ptr(d_sc), _n.ptr(d_dc), _n.ptr(d_rest)),
-                     "csplat_gauss_act_bwd")
-        return d_op, d_sc, d_dc, d_rest
+        return _act_bwd(*ctx.saved_tensors, g_op, g_sc, g_shs)
+
+
+class GaussianStepInputs(torch.autograd.Function):
+    """What the rasterizer receives from the Gaussian model for the T cameras of a step, as ONE autograd node: the mesh -> Gaussian
+    transform (MeshTransformViews: T rows of means3D, T rows of rotations) and the activations (_GaussianActivations: opacity, scales,
+    SH) -- the same two launches each way, one node less to record and to walk (the step is bound by the host's cost per node).
+    Outputs: T means3D [P,3], T rotations [P,4], opacity [P,1], scales [P,3], shs [P,16,3]."""
+
+    @staticmethod
+    def forward(ctx, vertices, bary, rotation, vid, rest, rowptr, corners, op_raw, sc_raw, f_dc, f_rest):
+        vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
+        T, V, P = int(vertices.shape[0]), int(vertices.shape[1]), int(vid.shape[0])
+        xyz = torch.empty(T, P, 3, dtype=torch.float32, device=vertices.device)
+        quat = torch.empty(T, P, 4, dtype=torch.float32, device=vertices.device)
+        with _n.on_device(vertices.device):
+            _n.check(_n.lib.csplat_mesh_transform_fwd_views(_n.stream_handle(vertices.device), T, P, V, _n.ptr(vid),
+                                                            _n.ptr(vertices), _n.ptr(bary), _n.ptr(rotation), _n.ptr(rest),
+                                                            _n.ptr(xyz), _n.ptr(quat)), "csplat_mesh_transform_fwd_views")
+        opacity, scales, shs = _act_fwd(op_raw, sc_raw, f_dc, f_rest)
+        ctx.save_for_backward(vertices, bary, rotation, vid, rest, rowptr, corners, opacity, scales)
+        ctx.dims = (T, P, V)
+        ctx.set_materialize_grads(False)
+        return tuple(xyz.unbind(0)) + tuple(quat.unbind(0)) + (opacity, scales, shs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        T, P, V = ctx.dims
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        g_xyz = _join_views(grads[:T], (P, 3), torch.float32, dev)
+        g_quat = _join_views(grads[T:2 * T], (P, 4), torch.float32, dev)
+        d_mesh = (None, None, None)
+        if g_xyz is not None or g_quat is not None:
+            d_mesh = MeshTransform.backward(_Saved(saved[:7], ctx.dims), g_xyz, g_quat)[:3]
+        g_op, g_sc, g_shs = grads[2 * T:]
+        d_act = (None,) * 4
+        if g_op is not None or g_sc is not None or g_shs is not None:
+            d_act = _act_bwd(saved[7], saved[8], g_op, g_sc, g_shs)
+        return tuple(d_mesh) + (None, None, None, None) + tuple(d_act)
+
+
+class _Saved:
+    """stand-in ctx: hands MeshTransform.backward its saved tensors and dims"""
+
+    def __init__(self, saved, dims):
+        self.saved_tensors, self.dims = saved, dims
 
 
 class UnbindViews(torch.autograd.Function):
@@ -304,12 +356,9 @@ class MeshGaussians(DensifyMixin):
     def _vertex_ids(self):
         return self.mesh.face[:, self.face_ids].transpose(0, 1)  # [P, 3]
 
-    def _fused(self, deformed_vertices, views=False):
-        """(xyz, rotation) on the deformed mesh through the fused HIP kernel; render() asks for both, one after the other
-        with the same vertex tensor, so the pair is computed once and cached on that tensor object."""
-        c = self.__dict__.get("_fused_cache")
-        if c is not None and c[0] is deformed_vertices and c[1] == deformed_vertices._version and c[3] == bool(views):
-            return c[2]
+    def _rest(self):
+        """(key, vertex ids [P,3], rest-pose record, vertex<-corner CSR rowptr, corners, ...): what the fused transform needs of the static
+        mesh, rebuilt only when face_ids / mesh.pos changed"""
         # keyed on the tensor OBJECTS (held in the cache entry, so their storage cannot be recycled under the key) and their
         # in-place version counters; densify.py also drops the entry whenever it re-creates face_ids
         fi, mp = self.face_ids, self.mesh.pos
@@ -331,10 +380,32 @@ class MeshGaussians(DensifyMixin):
         if r[1].shape[0] != self.face_bary.shape[0] or r[1].shape[0] != self._rotation.shape[0]:
             raise _n.CsplatError(f"mesh transform: {r[1].shape[0]} face ids but {self.face_bary.shape[0]} barycentric rows / "
                                  f"{self._rotation.shape[0]} rotations")
+        return r
+
+    def _fused(self, deformed_vertices, views=False):
+        """(xyz, rotation) on the deformed mesh through the fused HIP kernel; render() asks for both, one after the other
+        with the same vertex tensor, so the pair is computed once and cached on that tensor object."""
+        c = self.__dict__.get("_fused_cache")
+        if c is not None and c[0] is deformed_vertices and c[1] == deformed_vertices._version and c[3] == bool(views):
+            return c[2]
+        r = self._rest()
         fn = MeshTransformViews if views else MeshTransform       # (views: T rows of means3D, then T rows of rotations)
         out = fn.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2], r[3], r[4])
         self._fused_cache = (deformed_vertices, deformed_vertices._version, out, bool(views))
         return out
+
+    def step_inputs(self, deformed_vertices):
+        """transform_views + activations as ONE autograd node (GaussianStepInputs): ((T means3D), (T rotations), opacity, scales, shs),
+        or None when one of the two fused forms does not apply"""
+        ts = (self._opacity, self._scaling, self._features_dc, self._features_rest)
+        if not (self.fused and deformed_vertices.is_cuda and deformed_vertices.dim() == 3 and
+                all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)) or \
+                self._features_rest.shape[1:] != (15, 3) or self._features_dc.shape[1:] != (1, 3) or self._opacity.shape[0] == 0:
+            return None
+        r = self._rest()
+        T = int(deformed_vertices.shape[0])
+        out = GaussianStepInputs.apply(deformed_vertices, self.face_bary, self._rotation, r[1], r[2], r[3], r[4], *ts)
+        return out[:T], out[T:2 * T], out[2 * T], out[2 * T + 1], out[2 * T + 2]
 
     def transform_views(self, deformed_vertices):
         """get_xyz + get_rotation for the cameras of a step at once: [T,V,3] -> (tuple of T [P,3], tuple of T [P,4])."""

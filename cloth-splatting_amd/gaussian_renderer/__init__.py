@@ -195,12 +195,18 @@ def render_views(viewpoint_cameras, pc, simulator, pipe, bg_color: torch.Tensor,
     deforms = vertice_deforms      # [T, V, 3] when the caller already evaluated the simulator for these cameras
     if deforms is None and not render_static and viewpoint_cameras and hasattr(simulator, "forward_times"):
         deforms = simulator.forward_times([cam.time for cam in viewpoint_cameras])   # [T, V, 3]: one pass over the output layer
-    moved = None
+    moved = acts = None
+    want_acts = bool(viewpoint_cameras) and hasattr(pc, "activations") and override_color is None and not pipe.compute_cov3D_python
     if deforms is not None and deforms.is_cuda and getattr(pc, "fused", False) and hasattr(pc, "transform_views"):
-        moved = pc.transform_views(deforms)     # mesh -> Gaussian transform of all cameras in one launch each way
+        both = pc.step_inputs(deforms) if (want_acts and hasattr(pc, "step_inputs")) else None
+        if both is not None:        # the transform of all cameras AND the activations: one autograd node, two launches each way
+            moved, acts = (both[0], both[1]), both[2:]
+        else:
+            moved = pc.transform_views(deforms)     # mesh -> Gaussian transform of all cameras in one launch each way
     deform_views = None if deforms is None else deforms.unbind(0)
     if viewpoint_cameras:
-        acts = pc.activations() if (hasattr(pc, "activations") and override_color is None and not pipe.compute_cov3D_python) else None
+        if acts is None:
+            acts = pc.activations() if want_acts else None
         if acts is not None:    # sigmoid / exp / cat of the Gaussian parameters in one launch each way
             shared["opacity"], shared["scales"], shared["features"], shared["cov3D"] = acts[0], acts[1], acts[2], None
         else:
