@@ -394,6 +394,85 @@ class FusedClothRegs(torch.autograd.Function):
         return out, None, None, None, None, None, None, None, None
 
 
+class SimulatorStep(torch.autograd.Function):
+    """The head of a training step as ONE autograd node: the time-conditioned simulator for the step's T cameras
+    (meshnet_network.py:361-373 per time: hidden layers, output layer, + the table rows) AND the cloth regularisers of its output
+    (train_utils.py:83-102) -- graph_ops.SimResidual followed by FusedClothRegs(tap=True): the same three forward launches (the
+    regularisers' queued for launch_deferred()) and three backward launches, two nodes less to record and to walk.
+    Returns (vertices [T,V,3], regulariser loss)."""
+
+    @staticmethod
+    def forward(ctx, e, W1, b1, W2, b2, Wo, bo, base, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr):
+        from meshnet import graph_ops as go
+        e, W2s, h1, h2 = go._sim_hidden_fwd(e, W1, b1, W2, b2)
+        y, Wo = go._rows_dot_fwd(h2, Wo, bo, base)
+        T = int(e.shape[0])
+        D = y.view(T, -1, 3)
+        V, E = int(D.shape[1]), int(edge_index.shape[1])
+        loss = torch.empty((), dtype=torch.float32, device=D.device)
+        grad = torch.empty_like(D)
+        ei, rl = edge_index.contiguous(), rest_len.contiguous().float()
+        dev, stream = D.device, _n.stream_handle(D.device)
+
+        def launch():
+            with _n.on_device(dev):
+                key = ("regs", dev, stream, T, V, E)
+                scratch = _IMG_SCRATCH.get(key)
+                if scratch is None:
+                    if len(_IMG_SCRATCH) >= 64:
+                        _IMG_SCRATCH.clear()
+                    scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=dev)
+                _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
+                                                  float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch), *[_n.ptr(c) for c in csr]),
+                         "csplat_cloth_regs")
+        _DEFERRED.append(launch)
+        ctx.save_for_backward(e, W2s, h1, h2, Wo, grad)
+        ctx.set_materialize_grads(False)
+        return D, loss
+
+    @staticmethod
+    def backward(ctx, g_D, g_loss):
+        from meshnet import graph_ops as go
+        e, W2s, h1, h2, Wo, grad = ctx.saved_tensors
+        if g_D is None and g_loss is None:
+            return (None,) * 14
+        if g_D is None:
+            g = grad * g_loss
+        else:
+            g = g_D.contiguous().float() if g_loss is None else torch.addcmul(g_D, grad, g_loss)
+        dWo, dbo, dh = go._rows_dot_bwd(Wo, h2, g)
+        dW1, db1, dW2, db2 = go._sim_hidden_bwd(e, W2s, h1, h2, dh)
+        return (None, dW1, db1, dW2, db2, dWo, dbo) + (None,) * 7
+
+
+def simulator_step(simulator, times, gaussians, opt):
+    """(vertices [T,V,3], regulariser loss) through SimulatorStep when the simulator is the time-conditioned residual MLP on the GPU and
+    the fused regularisers apply; None otherwise (the caller composes forward_times + regularization)"""
+    from meshnet import graph_ops as go
+    need = ("times_on_device", "input", "hidden", "output")
+    if not all(hasattr(simulator, a) for a in need) or len(times) > 8 or len(times) == 0:
+        return None
+    tt, enc, base = simulator.times_on_device(times)
+    if not go.sim_residual_applies(enc, simulator.input, simulator.hidden, simulator.output, base):
+        return None
+    ei = gaussians.mesh.edge_index
+    nv = int(base.shape[1])
+    key = (ei.data_ptr(), ei._version, tuple(ei.shape), nv)
+    cache = getattr(gaussians, "_edge_csr", None)       # the cloth graph is static: its CSR is built once
+    if cache is None or cache[0] != key:
+        cache = (key, edge_csr(ei, nv))
+        try:
+            gaussians._edge_csr = cache
+        except Exception:
+            pass
+    lam_d = opt.lambda_deform_mag if opt.lambda_deform_mag > 0. else 0.
+    lam_r = opt.lambda_rigid if opt.lambda_rigid > 0 else 0.
+    lam_m = opt.lambda_momentum if opt.lambda_momentum > 0 else 0.
+    s = simulator
+    return SimulatorStep.apply(enc, s.input.weight, s.input.bias, s.hidden.weight, s.hidden.bias, s.output.weight, s.output.bias, base,
+                               ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
+
+
 _DEFERRED = []
 
 
@@ -558,14 +637,17 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         # simulator for all cameras at once, and the regularisers recorded BEFORE the rasterizer: autograd runs
         # later-recorded nodes first, so the rasterizer's backward -- the long GPU work of the step -- is launched
         # first and the small launches of everything else are issued under it
-        if hasattr(simulator, "forward_times"):
-            deforms_all = simulator.forward_times([cam.time for cam in all_cams])
+        head = simulator_step(simulator, [cam.time for cam in all_cams], gaussians, opt) if gaussians.mesh.pos.is_cuda else None
+        if head is not None:      # simulator + regularisers: one autograd node (the regularisers' launch queued, see launch_deferred)
+            deforms_all, reg = head
         else:
-            nv, dev0 = gaussians.mesh.pos.shape[0], gaussians.mesh.pos.device
-            deforms_all = torch.stack([simulator(time_vector=torch.tensor(cam.time).to(dev0).repeat(nv, 1)) for cam in all_cams])
-        # (defer: the regularisers feed nothing before the loss -- their launch waits until the rasterizer's forward has been issued,
-        #  the step being bound by the latency between its start and the first rasterizer kernel)
-        reg, deforms_all = regularization(deforms_all, gaussians, opt, static, tap=True, defer=True)
+            if hasattr(simulator, "forward_times"):
+                deforms_all = simulator.forward_times([cam.time for cam in all_cams])
+            else:
+                nv, dev0 = gaussians.mesh.pos.shape[0], gaussians.mesh.pos.device
+                deforms_all = torch.stack([simulator(time_vector=torch.tensor(cam.time).to(dev0).repeat(nv, 1)) for cam in all_cams])
+            # (defer: the regularisers feed nothing before the loss -- their launch waits until the rasterizer's forward has been issued)
+            reg, deforms_all = regularization(deforms_all, gaussians, opt, static, tap=True, defer=True)
         deforms = deforms_all if not dist_mode else (deforms_all[idx] if idx else None)
     if dist_mode or batched_views:
         pkgs, stacked = render_views(cams, gaussians, simulator, pipe, background, render_static=static, return_stacked=True,

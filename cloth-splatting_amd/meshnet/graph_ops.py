@@ -223,6 +223,35 @@ class SimHidden(torch.autograd.Function):
         return (None,) + _sim_hidden_bwd(*ctx.saved_tensors, g)
 
 
+def _rows_dot_fwd(h2, Wo, bo, base=None):
+    Wo, bo = _f32(Wo), _f32(bo)
+    T, R = int(h2.shape[0]), int(Wo.shape[0])
+    y = torch.empty(T, R, dtype=torch.float32, device=h2.device)
+    add = None if base is None else _f32(base.reshape(T, R))
+    with _n.on_device(h2.device):
+        _n.check(_n.lib.csplat_rows_dot_fwd(_n.stream_handle(h2.device), T, R, 256, _n.ptr(Wo), _n.ptr(bo), _n.ptr(h2), _n.ptr(y),
+                                            None if add is None else _n.ptr(add)), "csplat_rows_dot_fwd")
+    return y, Wo
+
+
+def _rows_dot_bwd(Wo, h2, g):
+    g = _f32(g)
+    T, R = int(h2.shape[0]), int(Wo.shape[0])
+    dWo, dbo, dh = torch.empty_like(Wo), torch.empty(R, dtype=torch.float32, device=g.device), torch.empty_like(h2)
+    scratch = torch.empty(_n.lib.csplat_rows_dot_scratch_bytes(T), dtype=torch.uint8, device=g.device)
+    with _n.on_device(g.device):
+        _n.check(_n.lib.csplat_rows_dot_bwd(_n.stream_handle(g.device), T, R, 256, _n.ptr(Wo), _n.ptr(h2), _n.ptr(g.reshape(T, R)),
+                                            _n.ptr(dWo), _n.ptr(dbo), _n.ptr(dh), _n.ptr(scratch)), "csplat_rows_dot_bwd")
+    return dWo, dbo, dh
+
+
+def sim_residual_applies(e, lin1, lin2, lin_out, base=None):
+    return bool(e.is_cuda and e.dim() == 2 and 0 < e.shape[0] <= 8 and e.shape[1] <= 16 and tuple(lin1.weight.shape) == (256, e.shape[1]) and
+                tuple(lin2.weight.shape) == (256, 256) and lin1.bias is not None and lin2.bias is not None and not e.requires_grad and
+                lin_out.weight.shape[1] == 256 and lin_out.bias is not None and
+                (base is None or (base.is_cuda and base.numel() == e.shape[0] * lin_out.weight.shape[0])))
+
+
 class SimResidual(torch.autograd.Function):
     """the simulator's whole residual MLP for the T time rows of a step as ONE autograd node:
         y = Linear(256, 3V)(relu(Linear(256, 256)(relu(Linear(K0, 256)(e))))) [+ base]          (meshnet_network.py:337-339,364-371)

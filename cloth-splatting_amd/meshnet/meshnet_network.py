@@ -127,6 +127,15 @@ class ResidualMeshSimulator(torch.nn.Module):
         """forward() for the T cameras of a training step at once: times = sequence of Python floats (Camera.time) ->
         [T, V, 3].  Same arithmetic per time as forward(); the table index is computed on the host (fp32, round-half-even
         like torch.round), so neither a host->device copy nor the device->host read of the bounds check is needed."""
+        tt, enc, base = self.times_on_device(times)
+        out = []
+        for c0 in range(0, tt.shape[0], 8):   # (rows_dot takes up to 8 time rows per call)
+            out.append(self._residual(tt[c0:c0 + 8], enc[c0:c0 + 8], base[c0:c0 + 8]))
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+    def times_on_device(self, times):
+        """(time values [T,1], their sinusoidal code [T,K0], the table rows mesh_predictions[time_id] [T,V,3]) of a camera set, on the
+        device -- the parameter-free inputs of forward_times, uploaded / computed once per set of times and kept"""
         import numpy as np
         key = tuple(float(t) for t in times)
         dev = self.output.weight.device
@@ -151,10 +160,7 @@ class ResidualMeshSimulator(torch.nn.Module):
             base = self.mesh_predictions[torch.as_tensor(
                 np.round(np.asarray(key, np.float32) / np.float32(self.time_delta)).astype(np.int64), device=dev)]
             cache[(key, dev)] = (tt, enc, base, self.mesh_predictions, self.mesh_predictions._version)
-        out = []
-        for c0 in range(0, tt.shape[0], 8):   # (rows_dot takes up to 8 time rows per call)
-            out.append(self._residual(tt[c0:c0 + 8], enc[c0:c0 + 8], base[c0:c0 + 8]))
-        return out[0] if len(out) == 1 else torch.cat(out, 0)
+        return tt, enc, base
 
     def save(self, path):
         torch.save(self.state_dict(), path)
