@@ -402,7 +402,7 @@ class SimulatorStep(torch.autograd.Function):
     Returns (vertices [T,V,3], regulariser loss)."""
 
     @staticmethod
-    def forward(ctx, e, W1, b1, W2, b2, Wo, bo, base, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr):
+    def forward(ctx, e, W1, b1, W2, b2, Wo, bo, base, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr, defer=False):
         from meshnet import graph_ops as go
         e, W2s, h1, h2 = go._sim_hidden_fwd(e, W1, b1, W2, b2)
         y, Wo = go._rows_dot_fwd(h2, Wo, bo, base)
@@ -425,7 +425,10 @@ class SimulatorStep(torch.autograd.Function):
                 _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
                                                   float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch), *[_n.ptr(c) for c in csr]),
                          "csplat_cloth_regs")
-        _DEFERRED.append(launch)
+        if defer:      # (the caller issues it with launch_deferred(), e.g. behind the rasterizer's forward)
+            _DEFERRED.append(launch)
+        else:
+            launch()
         ctx.save_for_backward(e, W2s, h1, h2, Wo, grad)
         ctx.set_materialize_grads(False)
         return D, loss
@@ -435,19 +438,20 @@ class SimulatorStep(torch.autograd.Function):
         from meshnet import graph_ops as go
         e, W2s, h1, h2, Wo, grad = ctx.saved_tensors
         if g_D is None and g_loss is None:
-            return (None,) * 14
+            return (None,) * 15
         if g_D is None:
             g = grad * g_loss
         else:
             g = g_D.contiguous().float() if g_loss is None else torch.addcmul(g_D, grad, g_loss)
         dWo, dbo, dh = go._rows_dot_bwd(Wo, h2, g)
         dW1, db1, dW2, db2 = go._sim_hidden_bwd(e, W2s, h1, h2, dh)
-        return (None, dW1, db1, dW2, db2, dWo, dbo) + (None,) * 7
+        return (None, dW1, db1, dW2, db2, dWo, dbo) + (None,) * 8
 
 
-def simulator_step(simulator, times, gaussians, opt):
+def simulator_step(simulator, times, gaussians, opt, defer=False):
     """(vertices [T,V,3], regulariser loss) through SimulatorStep when the simulator is the time-conditioned residual MLP on the GPU and
-    the fused regularisers apply; None otherwise (the caller composes forward_times + regularization)"""
+    the fused regularisers apply; None otherwise (the caller composes forward_times + regularization).  defer=True: the regularisers'
+    kernel is queued, the caller MUST run launch_deferred() before the loss is consumed."""
     from meshnet import graph_ops as go
     need = ("times_on_device", "input", "hidden", "output")
     if not all(hasattr(simulator, a) for a in need) or len(times) > 8 or len(times) == 0:
@@ -470,7 +474,7 @@ def simulator_step(simulator, times, gaussians, opt):
     lam_m = opt.lambda_momentum if opt.lambda_momentum > 0 else 0.
     s = simulator
     return SimulatorStep.apply(enc, s.input.weight, s.input.bias, s.hidden.weight, s.hidden.bias, s.output.weight, s.output.bias, base,
-                               ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1])
+                               ei, gaussians.edge_norm.reshape(-1), lam_d, lam_r, lam_m, cache[1], bool(defer))
 
 
 _DEFERRED = []
@@ -637,7 +641,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         # simulator for all cameras at once, and the regularisers recorded BEFORE the rasterizer: autograd runs
         # later-recorded nodes first, so the rasterizer's backward -- the long GPU work of the step -- is launched
         # first and the small launches of everything else are issued under it
-        head = simulator_step(simulator, [cam.time for cam in all_cams], gaussians, opt) if gaussians.mesh.pos.is_cuda else None
+        head = simulator_step(simulator, [cam.time for cam in all_cams], gaussians, opt, defer=True) if gaussians.mesh.pos.is_cuda else None
         if head is not None:      # simulator + regularisers: one autograd node (the regularisers' launch queued, see launch_deferred)
             deforms_all, reg = head
         else:

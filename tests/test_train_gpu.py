@@ -474,6 +474,57 @@ def test_step_stats_and_no_copy_unbind():
     assert float((D.grad - D2.grad).abs().max()) <= 1e-6 * float(D2.grad.abs().max())
 
 
+def test_step_head_nodes_equal_the_chained_nodes():
+    """SimulatorStep (simulator + regularisers) and GaussianStepInputs (mesh transform + activations) -- the two autograd nodes the
+    batched train step starts with -- against the nodes they replace (forward_times + regularization(tap), transform_views +
+    activations): the same launches, hence the same bits forward and the same parameter gradients."""
+    import bench_train as bt
+    from csplat import train as tr
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    sc, pc, sim = bt.build(P=2000, W=64, H=64, grid=12, n_times=6, dev=dev)
+    with torch.no_grad():
+        sim.output.weight.mul_(300.0)
+    times = [0.2, 0.4, 0.6]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    params = list(sim.parameters()) + list(pc.parameters())
+
+    def grads():
+        out = [None if p.grad is None else p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        return out
+    # chained
+    D1 = sim.forward_times(times)
+    reg1, D1t = tr.regularization(D1, pc, tr.DEFAULT_OPT, tap=True)
+    xyz1, quat1 = pc.transform_views(D1t)
+    op1, sc1, sh1 = pc.activations()
+    w = [torch.randn(t.shape, device=dev, generator=g) for t in (xyz1[0], quat1[0], op1, sc1, sh1)]
+    val = lambda xyz, quat, op, sc_, sh, reg: (sum((x * w[0]).sum() for x in xyz) + sum((q * w[1]).sum() for q in quat) + (op * w[2]).sum() +  # noqa: E731
+                                               (sc_ * w[3]).sum() + (sh * w[4]).sum() + 1.7 * reg)
+    val(xyz1, quat1, op1, sc1, sh1, reg1).backward()
+    g1 = grads()
+    # one node each
+    head = tr.simulator_step(sim, times, pc, tr.DEFAULT_OPT)
+    assert head is not None and type(head[0].grad_fn).__name__.startswith("SimulatorStep")
+    D2, reg2 = head
+    both = pc.step_inputs(D2)
+    assert both is not None and type(both[2].grad_fn).__name__.startswith("GaussianStepInputs")
+    assert torch.equal(D2, D1) and torch.equal(reg2, reg1)
+    for a, b in zip(list(both[0]) + list(both[1]) + list(both[2:]), list(xyz1) + list(quat1) + [op1, sc1, sh1]):
+        assert torch.equal(a, b)
+    val(both[0], both[1], both[2], both[3], both[4], reg2).backward()
+    g2 = grads()
+    for a, b, p in zip(g1, g2, params):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 1e-6 * max(float(a.abs().max()), 1e-20), tuple(p.shape)
+    # deferred form: nothing is computed until launch_deferred()
+    D3, reg3 = tr.simulator_step(sim, times, pc, tr.DEFAULT_OPT, defer=True)
+    tr.launch_deferred()
+    assert torch.equal(reg3, reg1)
+
+
 def test_train_step_camera_by_camera_equals_batched():
     """train_step(batched_views=False) -- render() per camera, simulator per camera, composed losses as upstream's loop --
     against the default batched step (render_views, forward_times, fused nodes): same PSNR, loss, statistics and the same
