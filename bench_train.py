@@ -87,9 +87,11 @@ def run(args, dev=None):
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     per_step.sort()
     # the same loop with the log read ONE STEP LATE (step k's PSNR is read after step k+1 has been issued: same values, one step later) --
-    # to see whether the per-step read is what costs: it is not (1.09-1.15 against 1.11 ms).  Host (0.91 ms) and GPU (0.94 ms) are
+    # to see whether the per-step read is what costs: it is not (1.09-1.38 against 1.09-1.16 ms).  Host (0.9 ms) and GPU (0.94 ms) are
     # matched per step but not per PHASE: the small kernels of the front and of the backward's tail take 5-15 us each where the host
-    # needs ~25 us per launch, the rasterizer's long kernels the other way round; the step is the sum of the phase-wise maxima.
+    # needs ~25 us per launch, the rasterizer's long kernels the other way round; and a host that runs a step ahead only gets as far
+    # as the forward's read of its counts (behind the previous step's whole backward on the stream), then has the loss and the backward
+    # still to issue when the GPU arrives.
     pending, t1 = None, time.perf_counter()
     base_it = args.warmup + args.steps
     for it in range(base_it + 1, base_it + args.steps + 1):
