@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void k_tile_colscan_views(int tiles, int nb, K
 
 // single workgroup: exclusive scan of the per-tile totals -> tile ranges, R, longest list
 constexpr int INFO_BUSY = 64;   // word offset of the non-empty-tile list inside the info block: [count, tile ids ...]
+constexpr int LPT_BINS = 512;   // bins of the longest-list-first order (list length / 16, BUCKET_CAP / 16 = 512)
 __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__restrict__ cnt, int2 *__restrict__ ranges,
                                                uint32_t *__restrict__ info, volatile uint32_t *mailbox, uint32_t tag) {
     // ONE scan over the tiles of two running sums packed in 64 bits: low word = instances (the tile ranges), high word = number of
@@ -476,9 +477,43 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
         if (t < tiles) {
             ranges[t] = c ? make_int2((int)ex, (int)(ex + c)) : make_int2(0, 0);
             if (c) busy[1 + (uint32_t)(exl >> 32)] = (uint32_t)t;
+            else busy[tiles + 4 + tiles - 1 - (t - (int)(uint32_t)(exl >> 32))] = (uint32_t)t;   // launch-order list: empty tiles from the end
         }
         carry += s_w[16];
         __syncthreads();
+    }
+    // the non-empty tiles once more, LONGEST LIST FIRST (a counting sort on length / 16): the launch order of the compositing forward.
+    // Its waves -- one per (tile, 4x4 block), ~14 k of them with work on scene_1 for 8192 wave slots, 40-75 us each -- are handed out in
+    // grid order to whichever slot frees: in tile order the longest lists (the middle of the image) start in the middle of the launch and
+    // the slots that draw three of them in a row set the kernel's duration while the others idle (4.5 of 8 waves resident on average);
+    // longest first, what is still running at the end are the short lists.
+    {
+        __shared__ uint32_t s_bin[LPT_BINS + 1];
+        const uint32_t nbusy = (uint32_t)(carry >> 32);
+        uint32_t *lpt = busy + tiles + 4;          // (its tail, the empty tiles, was filled in the loop above)
+        for (int i = threadIdx.x; i <= LPT_BINS; i += 1024) s_bin[i] = 0u;
+        __syncthreads();                                   // (also: the busy list written above is visible to the whole workgroup)
+        for (uint32_t i = threadIdx.x; i < nbusy; i += 1024) {
+            const uint32_t c = cnt[busy[1 + i]];
+            atomicAdd(&s_bin[LPT_BINS - 1 - min(c >> 4, (uint32_t)(LPT_BINS - 1))], 1u);
+        }
+        __syncthreads();
+        if (w == 0) {                                      // exclusive scan of the bins by one wave: 8 consecutive bins per lane
+            uint32_t v[LPT_BINS / 64], run = 0;
+#pragma unroll
+            for (int k = 0; k < LPT_BINS / 64; k++) { v[k] = s_bin[lane * (LPT_BINS / 64) + k]; run += v[k]; }
+            uint32_t inc = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+            uint32_t base = inc - run;
+#pragma unroll
+            for (int k = 0; k < LPT_BINS / 64; k++) { s_bin[lane * (LPT_BINS / 64) + k] = base; base += v[k]; }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nbusy; i += 1024) {
+            const uint32_t t = busy[1 + i], c = cnt[t];
+            lpt[atomicAdd(&s_bin[LPT_BINS - 1 - min(c >> 4, (uint32_t)(LPT_BINS - 1))], 1u)] = t;
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
@@ -489,10 +524,12 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
         for (int k = 0; k < 16; k++) m = max(m, s_max[k]);
         info[0] = (uint32_t)carry;
         info[1] = m;
+        info[2] = (uint32_t)(carry >> 32);               // non-empty tiles
         busy[0] = (uint32_t)(carry >> 32);
         if (mailbox) {   // host-mapped pinned memory: the host polls the tag instead of blocking in a stream synchronise
             mailbox[0] = (uint32_t)carry;
             mailbox[1] = m;
+            mailbox[3] = (uint32_t)(carry >> 32);
             __threadfence_system();
             mailbox[2] = tag;
         }
@@ -558,12 +595,13 @@ struct P2View {
     // speculative launch (finish_views_batched): the host has not read the counts yet and sized the chunks from the previous call;
     // every kernel of the second phase checks the counts the scan left in `info` against those capacities and leaves the view
     // alone when they do not fit (the host notices the same way and repeats the phase with exact sizes)
-    const uint32_t *info;       // [0] tile instances, [1] longest tile list
+    const uint32_t *info;       // [0] tile instances, [1] longest tile list, [2] non-empty tiles
     uint32_t Lcap;              // longest tile list the sort's LDS was sized for
+    uint32_t Bcap;              // non-empty tiles the compositing forward's grid was sized for
     int spec;
 };
 struct P2Table { P2View v[P2_MAX_VIEWS]; };
-__device__ __forceinline__ bool p2_live(const P2View &w) { return !w.spec || (w.info[0] - 1u < w.R && w.info[1] <= w.Lcap); }
+__device__ __forceinline__ bool p2_live(const P2View &w) { return !w.spec || (w.info[0] - 1u < w.R && w.info[1] <= w.Lcap && w.info[2] <= w.Bcap); }
 __device__ __forceinline__ void seg_plan_body(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
                                               int *__restrict__ slot_tile);
 // (the LAST workgroup of every view does not emit: it lays out the view's 256-entry segments -- the former k_seg_plan launch; both only
@@ -1131,10 +1169,14 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
                                                    uint32_t null_rec, const float *__restrict__ bg,
                                                    int *seg_offset, float4 *__restrict__ ckpt,
                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                   float *__restrict__ out_color, float *__restrict__ out_depth, int wg) {
+                                                   float *__restrict__ out_color, float *__restrict__ out_depth, int wg,
+                                                   const uint32_t *__restrict__ order = nullptr) {
     __shared__ int s_ring[RING];
-    const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
-    if (tile >= tiles) return;
+    // item (wg >> 7) * 8 + (wg & 7), block (wg >> 3) & 15: the 16 blocks of an item share blockIdx % 8 (one XCD).  order: a permutation
+    // of the tiles, longest list first, the empty tiles (background only) last (k_tile_scan)
+    const int item = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
+    if (item >= tiles) return;
+    const int tile = order ? (int)order[item] : item;
     const int lane = threadIdx.x, r = lane >> 4, l16 = lane & 15;
     const int px = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4 + (l16 & 3);
     const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + (l16 >> 2);
@@ -1431,17 +1473,48 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
         composite_fwd16_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
                              out_depth);
 }
+constexpr int K6_EXTRA = 256;   // waves that paint the empty tiles (see the launch)
 template <bool ROWS>
-__global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab) {
+__global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab, int lpt, int busy_grid) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
     if (ROWS) {
-        // gridDim.x may be smaller than the number of (tile, block) items: a wave then walks items blockIdx.x, + gridDim.x, ... (gridDim.x
-        // a multiple of 128: the item's XCD stays blockIdx.x % 8)
         const int total = ((tiles + 7) >> 3) * 128;
+        if (lpt) {
+            // blockIdx.x < busy_grid: one wave per (item, block) of the first busy_grid / 16 entries of the launch-order list -- every
+            // non-empty tile is among them (p2_live: info[2] <= Bcap); the waves behind paint what is left of the list, the empty tiles
+            const uint32_t *order = w.info + INFO_BUSY + tiles + 4;
+            if ((int)blockIdx.x < busy_grid) {
+                composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                                   w.n_contrib, w.out_color, w.out_depth, (int)blockIdx.x, order);
+                return;
+            }
+            const int lane = threadIdx.x, gx = w.cam.gx;
+            const size_t HW = (size_t)H * W;
+            const float b0 = w.bg[0], b1 = w.bg[1], b2 = w.bg[2];
+            uint32_t *blk_hi = reinterpret_cast<uint32_t *>(w.seg_offset) + tiles + 1;
+            for (int pos = (busy_grid >> 7 << 3) + ((int)blockIdx.x - busy_grid); pos < tiles; pos += (int)gridDim.x - busy_grid) {
+                const int tile = (int)order[pos];
+                if (lane < 16) blk_hi[tile * 16 + lane] = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int px = (tile % gx) * CSPLAT_TILE + (lane & 15), py = (tile / gx) * CSPLAT_TILE + 4 * q + (lane >> 4);
+                    if (px < W && py < H) {
+                        const int pix = py * W + px;
+                        w.final_T[pix] = 1.f;
+                        w.n_contrib[pix] = 0u;
+                        w.out_color[pix] = b0; w.out_color[HW + pix] = b1; w.out_color[2 * HW + pix] = b2;
+                        w.out_depth[pix] = 0.f;
+                    }
+                }
+            }
+            return;
+        }
+        // (tile order, for A/B: gridDim.x may be smaller than the number of (tile, block) items: a wave then walks items blockIdx.x,
+        // + gridDim.x, ... -- gridDim.x a multiple of 128: the item's XCD stays blockIdx.x % 8)
         for (int wg = blockIdx.x; wg < total; wg += gridDim.x)
             composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                               w.n_contrib, w.out_color, w.out_depth, wg);
+                               w.n_contrib, w.out_color, w.out_depth, wg, nullptr);
     } else
         composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
                              w.n_contrib, w.out_color, w.out_depth);
@@ -2606,7 +2679,8 @@ size_t image_offsets(int W, int H, size_t *off) {
     off[1] = align256(tiles * 8);
     off[2] = off[1] + align256(X * 4);
     off[3] = off[2] + align256(X * 4);
-    off[4] = off[3] + align256(256 + (tiles + 4) * 4);   // info: [0] R, [1] longest list; word 64: number of non-empty tiles, then their ids
+    off[4] = off[3] + align256(256 + 2 * (tiles + 4) * 4);   // info: [0] R, [1] longest list; word 64: number of non-empty tiles, their ids in
+                                                             // tile order; word 64 + tiles + 4: the same ids, longest list first (K6's launch order)
     return off[4];
 }
 // per-(counting workgroup, tile) table of the bucketed binning path; requested as its own TEMP-class chunk
@@ -2930,9 +3004,9 @@ int csplat_forward_begin(void *stream, int P, int D, int M, const float *bg, int
 }
 
 // the one host read of a forward: R and the longest tile list of a view whose first phase has been launched
-static int finish_read(const FwdTicket &t, uint32_t host_info[2], hipStream_t launched_on = nullptr) {
+static int finish_read(const FwdTicket &t, uint32_t host_info[3], hipStream_t launched_on = nullptr) {
     hipStream_t s = launched_on ? launched_on : t.s;     // the stream the first phase was launched on
-    host_info[0] = host_info[1] = 0;
+    host_info[0] = host_info[1] = host_info[2] = 0;
     if (t.can_bucket) {
         bool got = false;
         if (t.use_mail) {   // spin on the tag (bounded: fall back to a stream synchronise after 2 s)
@@ -2942,10 +3016,10 @@ static int finish_read(const FwdTicket &t, uint32_t host_info[2], hipStream_t la
                 if ((++spins & 0x3FFu) == 0 &&
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
             }
-            if (got) { host_info[0] = t.mb_host[0]; host_info[1] = t.mb_host[1]; }
+            if (got) { host_info[0] = t.mb_host[0]; host_info[1] = t.mb_host[1]; host_info[2] = t.mb_host[3]; }
         }
         if (!got) {
-            HIP_TRY(hipMemcpyAsync(host_info, t.info, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(host_info, t.info, 12, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
     } else if (t.P > 0) {
@@ -2954,6 +3028,7 @@ static int finish_read(const FwdTicket &t, uint32_t host_info[2], hipStream_t la
         HIP_TRY(hipMemcpyAsync(host_info, t.g.offsets + (t.P - 1), 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         host_info[1] = 0xFFFFFFFFu;
+        host_info[2] = 0xFFFFFFFFu;
     }
     // list positions, tile ranges and the int `num_rendered` of the ABI are 32-bit (as upstream's): refuse instead of wrapping
     CSPLAT_REQUIRE(host_info[0] <= 0x7FFFFFFFu, "csplat_forward: more than 2^31 - 1 tile instances (Gaussian x tile pairs) in one view");
@@ -2976,7 +3051,7 @@ static uint32_t tile_sort_cap() {
 // What the last batched call saw, per image size: the capacities the next one is launched with BEFORE its counts are read.
 // (a short ring: a process that alternates between scenes of different density -- bench.py --mode scenes -- is served by the largest
 // of its recent calls with the same shape instead of failing the speculation at every switch)
-struct SpecHist { int W = 0, H = 0, P = 0; uint32_t R = 0, longest = 0; };
+struct SpecHist { int W = 0, H = 0, P = 0; uint32_t R = 0, longest = 0, busy = 0; };
 constexpr int SPEC_RING = 8;
 static SpecHist g_spec_ring[SPEC_RING];
 static int g_spec_next = 0;
@@ -2988,7 +3063,7 @@ struct PendingViews {
     bool used = false;
     const csplat_view *key = nullptr;
     int V = 0, tk[P2_MAX_VIEWS];
-    uint32_t Rcap[P2_MAX_VIEWS], Lcap = 0;
+    uint32_t Rcap[P2_MAX_VIEWS], Lcap = 0, Bcap = 0;
 };
 constexpr int MAX_PENDING = 8;
 static PendingViews g_pending[MAX_PENDING];
@@ -3008,7 +3083,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
     }
     const int P = a.P, W = a.W, H = a.H, tiles = a.tiles, nb = a.nb;
     const uint32_t cap = tile_sort_cap();
-    uint32_t info[P2_MAX_VIEWS][2];
+    uint32_t info[P2_MAX_VIEWS][3];
     bool have_info = false;
     auto read_counts = [&]() -> int {   // the one host read of the call: instances and longest tile list of every view
         for (int i = 0; i < V && !have_info; i++)
@@ -3017,7 +3092,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         return 0;
     };
     // lays the chunks of every view out for `Rcap[i]` list entries and launches the five stages
-    auto launch = [&](const uint32_t *Rcap, uint32_t Lcap, int spec) -> int {
+    auto launch = [&](const uint32_t *Rcap, uint32_t Lcap, int spec, uint32_t Bcap) -> int {
         P2Table tab;
         uint32_t maxR = 0;
         for (int i = 0; i < V; i++) {
@@ -3042,7 +3117,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
             k.recA = (float4 *)((char *)bbase + boff[6]); k.recB = (float4 *)((char *)bbase + boff[7]);
             k.recC = (float2 *)((char *)bbase + boff[8]);
             k.bg = t.bg; k.final_T = t.final_T; k.n_contrib = t.n_contrib; k.out_color = v[i].out_color; k.out_depth = v[i].out_depth;
-            k.R = R; k.info = t.info; k.Lcap = Lcap; k.spec = spec;
+            k.R = R; k.info = t.info; k.Lcap = Lcap; k.Bcap = Bcap; k.spec = spec;
             v[i].layout_rendered = (int)R; v[i].geom = t.gbase; v[i].binning = bbase; v[i].image = t.ibase;
         }
         {
@@ -3067,13 +3142,21 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         {
             ProfScope ps(PROF_K6, join);
-            if (g_debug_flags & 32768u) k_composite_fwd_views<false><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab);
+            if (g_debug_flags & 32768u) k_composite_fwd_views<false><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab, 0, cdiv(tiles, 8) * 128);
             else {
                 // (an experiment that did NOT pay, csplat_debug_flags bits 17-19 = n: 1024 * n waves per view walk the items instead of
                 //  one wave per item -- same-box A/B, step of four views: 0.725 ms with one wave per item, 0.81 / 0.767 / 0.755 / 0.73 ms
                 //  for n = 1 / 2 / 4 / 7: K6 is not bound by wave dispatch, and half the waves resident cost only 1.5 x)
                 const int total = cdiv(tiles, 8) * 128, cap = (int)((g_debug_flags >> 17) & 7u) * 1024;
-                k_composite_fwd_views<true><<<dim3(cap > 0 && cap < total ? cap : total, V), 64, 0, join>>>(tiles, W, H, tab);
+                if ((g_debug_flags & (1u << 21)) || cap > 0)    // (bit 21: one wave per (tile, block) of EVERY tile, in tile order, for A/B)
+                    k_composite_fwd_views<true><<<dim3(cap > 0 && cap < total ? cap : total, V), 64, 0, join>>>(tiles, W, H, tab, 0, total);
+                else {
+                    // waves for the NON-EMPTY tiles only (Bcap of them, longest list first) + K6_EXTRA waves that paint the empty tiles'
+                    // pixels: on scene_1 nine tiles in ten are empty, and launching 16 waves for each of them cost ~50 us of the launch
+                    // (the same launch on a scene of 500 Gaussians: 51 us)
+                    const int bg_ = cdiv((int)Bcap, 8) * 128, busy_grid = bg_ < total ? bg_ : total;
+                    k_composite_fwd_views<true><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, 1, busy_grid);
+                }
             }
             LAUNCH_CHECK();
         }
@@ -3083,10 +3166,11 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         std::lock_guard<std::mutex> lk(g_spec_mu);
         SpecHist &e = g_spec_ring[g_spec_next];
         g_spec_next = (g_spec_next + 1) % SPEC_RING;
-        e.W = W; e.H = H; e.P = P; e.R = 0; e.longest = 0;
+        e.W = W; e.H = H; e.P = P; e.R = 0; e.longest = 0; e.busy = 0;
         for (int i = 0; i < V; i++) {
             e.R = info[i][0] > e.R ? info[i][0] : e.R;
             e.longest = info[i][1] > e.longest ? info[i][1] : e.longest;
+            e.busy = info[i][2] > e.busy ? info[i][2] : e.busy;
         }
     };
     auto release = [&]() {
@@ -3106,23 +3190,27 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
                 hist.W = W; hist.H = H; hist.P = P;
                 hist.R = e.R > hist.R ? e.R : hist.R;
                 hist.longest = e.longest > hist.longest ? e.longest : hist.longest;
+                hist.busy = e.busy > hist.busy ? e.busy : hist.busy;
             }
     }
     if (mode == 2 || (!(g_debug_flags & 1024u) && hist.R > 0)) {
         uint32_t Rcap[P2_MAX_VIEWS];
-        uint32_t Lcap;
+        uint32_t Lcap, Bcap;
         if (mode == 2) {        // the capacities the pending call was launched with
             for (int i = 0; i < V; i++) Rcap[i] = pend->Rcap[i];
             Lcap = pend->Lcap;
+            Bcap = pend->Bcap;
         } else {
             const uint64_t want = (uint64_t)hist.R + hist.R / 8 + 4096;
             const uint32_t rc32 = (uint32_t)(want > 0x7FFFFF00ull ? 0x7FFFFF00ull : want);
             for (int i = 0; i < V; i++) Rcap[i] = rc32;
             Lcap = hist.longest + hist.longest / 4 + 64;
             Lcap = Lcap > cap ? cap : Lcap;
-            if (int rc = launch(Rcap, Lcap, 1)) return rc;
+            Bcap = hist.busy + hist.busy / 8 + 16;          // non-empty tiles: sizes the compositing forward's grid
+            Bcap = Bcap > (uint32_t)tiles ? (uint32_t)tiles : Bcap;
+            if (int rc = launch(Rcap, Lcap, 1, Bcap)) return rc;
             if (mode == 1) {    // deferred: the caller reads the counts later (csplat_forward_views_settle), the GPU has its work
-                pend->used = true; pend->key = v; pend->V = V; pend->Lcap = Lcap;
+                pend->used = true; pend->key = v; pend->V = V; pend->Lcap = Lcap; pend->Bcap = Bcap;
                 for (int i = 0; i < V; i++) { pend->tk[i] = tk[i]; pend->Rcap[i] = Rcap[i]; v[i].num_rendered = -1; }
                 *done = true;
                 return 0;
@@ -3130,7 +3218,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         if (int rc = read_counts()) return rc;
         bool fits = true;
-        for (int i = 0; i < V; i++) fits = fits && info[i][0] - 1u < Rcap[i] && info[i][1] <= Lcap;
+        for (int i = 0; i < V; i++) fits = fits && info[i][0] - 1u < Rcap[i] && info[i][1] <= Lcap && info[i][2] <= Bcap;
         remember();
         if (fits) {
             for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
@@ -3140,14 +3228,15 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
     }
     if (int rc = read_counts()) return rc;
-    uint32_t longest = 0, Rex[P2_MAX_VIEWS];
+    uint32_t longest = 0, busiest = 0, Rex[P2_MAX_VIEWS];
     for (int i = 0; i < V; i++) {
         if (info[i][1] > cap || info[i][0] == 0) return 0;      // a list too long for the in-LDS sort, an empty view: view by view
         longest = info[i][1] > longest ? info[i][1] : longest;
+        busiest = info[i][2] > busiest ? info[i][2] : busiest;
         Rex[i] = info[i][0];
     }
     remember();
-    if (int rc = launch(Rex, longest, 0)) return rc;
+    if (int rc = launch(Rex, longest, 0, busiest)) return rc;
     if (relaunched) *relaunched = 1;
     for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
     release();
@@ -3176,7 +3265,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     int32_t *radii = t.radii;
     csplat_alloc_fn alloc = t.alloc;
     void *alloc_ctx = t.alloc_ctx;
-    uint32_t host_info[2] = {0, 0};   // R, longest tile list
+    uint32_t host_info[3] = {0, 0, 0};   // R, longest tile list, non-empty tiles
     if (int rc = finish_read(t, host_info)) return rc;
     const uint32_t R = host_info[0];
     const uint32_t cap = tile_sort_cap();
