@@ -229,7 +229,7 @@ class CsplatView(C.Structure):
                 [("num_rendered", _i), ("layout_rendered", _i)] + [(n, _vp) for n in ("geom", "binning", "image", "dL_dpix", "scratch")] +
                 [("accmask", C.c_uint)] +
                 [(n, _vp) for n in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D",
-                                    "dL_dsh", "dL_dscale", "dL_drot")])
+                                    "dL_dsh", "dL_dscale", "dL_drot")] + [("busy_tiles", _i)])
 
 
 ACC_OPACITY, ACC_COLOR, ACC_MEAN3D, ACC_COV3D, ACC_SH, ACC_SCALE, ACC_ROT = 1, 2, 4, 8, 16, 32, 64

@@ -3211,7 +3211,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
             if (int rc = launch(Rcap, Lcap, 1, Bcap)) return rc;
             if (mode == 1) {    // deferred: the caller reads the counts later (csplat_forward_views_settle), the GPU has its work
                 pend->used = true; pend->key = v; pend->V = V; pend->Lcap = Lcap; pend->Bcap = Bcap;
-                for (int i = 0; i < V; i++) { pend->tk[i] = tk[i]; pend->Rcap[i] = Rcap[i]; v[i].num_rendered = -1; }
+                for (int i = 0; i < V; i++) { pend->tk[i] = tk[i]; pend->Rcap[i] = Rcap[i]; v[i].num_rendered = -1; v[i].busy_tiles = 0; }
                 *done = true;
                 return 0;
             }
@@ -3221,7 +3221,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         for (int i = 0; i < V; i++) fits = fits && info[i][0] - 1u < Rcap[i] && info[i][1] <= Lcap && info[i][2] <= Bcap;
         remember();
         if (fits) {
-            for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
+            for (int i = 0; i < V; i++) { v[i].num_rendered = (int)info[i][0]; v[i].busy_tiles = (int)info[i][2]; }
             release();
             *done = true;
             return 0;
@@ -3238,7 +3238,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
     remember();
     if (int rc = launch(Rex, longest, 0, busiest)) return rc;
     if (relaunched) *relaunched = 1;
-    for (int i = 0; i < V; i++) v[i].num_rendered = (int)info[i][0];
+    for (int i = 0; i < V; i++) { v[i].num_rendered = (int)info[i][0]; v[i].busy_tiles = (int)info[i][2]; }
     release();
     *done = true;
     return 0;
@@ -3706,7 +3706,9 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 k.ckpt = (const float4 *)(b + boff[4]); k.mask16 = (const uint16_t *)(b + boff[5]);
                 k.recA = (const float4 *)(b + boff[6]); k.recB = (const float4 *)(b + boff[7]); k.recC = (const float2 *)(b + boff[8]);
                 k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)Rl;
-                const int64_t sl = max_slots(Rl, tiles);
+                // segments of the view: <= R / SEG + (non-empty tiles) + 1 with the EXACT counts the forward read -- the layout's bound
+                // (capacity / SEG + all tiles + 1) launches twice as many workgroups that find no segment
+                const int64_t sl = (w.busy_tiles > 0 && w.num_rendered > 0) ? (int64_t)w.num_rendered / SEG + w.busy_tiles + 1 : max_slots(Rl, tiles);
                 slots = sl > slots ? sl : slots;
             }
             {   // (measurement hook, off unless csplat_debug_stamps handed over a buffer large enough for this launch)

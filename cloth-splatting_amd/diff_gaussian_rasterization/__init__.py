@@ -288,6 +288,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             elif ctx.plan is not None:
                 for a, i in enumerate(ctx.plan["active"]):
                     ctx.plan["sub"][a].num_rendered = arr[i].num_rendered
+                    ctx.plan["sub"][a].busy_tiles = arr[i].busy_tiles
         return tuple(outs)
 
     @staticmethod

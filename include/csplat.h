@@ -139,6 +139,8 @@ typedef struct csplat_view {
     void *scratch;
     unsigned accmask;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+    int busy_tiles;                 /* written by the forward (0 = not known): tiles with a non-empty list -- the backward sizes the
+                                     * compositing backward's grid with it (segments <= R / 256 + busy_tiles + 1) */
 } csplat_view;
 int csplat_forward_views(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream);
 /* The same call with its one host read (the views' counts) DEFERRED.  When the second phase can be launched on the previous call's
