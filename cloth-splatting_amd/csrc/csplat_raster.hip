@@ -1301,8 +1301,10 @@ __device__ __forceinline__ void row_scan4_add(float (&x)[4]) {
 // tile list -- is a quarter as many steps long.  The products of a step associate as a scan tree, not front to back: final_T and the
 // alpha / transmittance decisions can differ from a sequential walk in the last bit (the tests hold n_contrib to the oracle up to
 // counted threshold ties and final_T to 1e-4, as they do for v_exp_f32 against expf).  Measured (profiles/r03*): 45 %
-// fewer VALU instructions than the row form (composite_fwd_body) but 96-106 VGPRs against 62, i.e. 4-5 waves per SIMD against 8, and
-// 188-197 us against 182 us for the four views of a step: the ROW FORM STAYS THE DEFAULT, this one is behind csplat_debug_flags bit 15.
+// fewer VALU instructions than the row form (composite_fwd_body) but 96-106 VGPRs against 62, i.e. 4-5 waves per SIMD against 8.  While
+// the launch still handed 16 waves to every empty tile it lost (188-197 us against 182 us for the four views of a step); launched for
+// the non-empty tiles only -- ~17 k long waves for 8192 slots, where the length of a wave is what counts and not how many fit -- it
+// wins: 137 against 158 us.  It is the DEFAULT; csplat_debug_flags bit 15 selects the row form.
 __device__ __forceinline__ void row_scan4_min(float (&x)[4]) {
     CSPLAT_ROW_SCAN4("min", 1, "s_nop 1\n\t", x[0], x[1], x[2], x[3]);
     CSPLAT_ROW_SCAN4("min", 2, "", x[0], x[1], x[2], x[3]);
@@ -1320,11 +1322,13 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
                                                      uint32_t null_rec, const float *__restrict__ bg,
                                                      int *seg_offset, float4 *__restrict__ ckpt,
                                                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                     float *__restrict__ out_color, float *__restrict__ out_depth) {
+                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
+                                                     const uint32_t *__restrict__ order = nullptr) {
     __shared__ int s_ring[RING16];
     const int wg = blockIdx.x;
-    const int tile = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
-    if (tile >= tiles) return;
+    const int item = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
+    if (item >= tiles) return;
+    const int tile = order ? (int)order[item] : item;
     const int lane = threadIdx.x, sv = lane & 15, q = lane >> 4;
     const int px0 = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4;
     const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + q;
@@ -1473,7 +1477,33 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
         composite_fwd16_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
                              out_depth);
 }
-constexpr int K6_EXTRA = 256;   // waves that paint the empty tiles (see the launch)
+// the waves behind the first busy_grid of a K6 launch: the tiles of the launch-order list that got no waves of their own -- the empty
+// ones -- receive what K6 writes for a tile without a list (background colour, T = 1, no contributor, blk_hi = 0), 256 pixels a pass
+constexpr int K6_EXTRA = 256;
+__device__ __forceinline__ void paint_empty_tiles(int tiles, int W, int H, int gx, const uint32_t *__restrict__ order, int busy_grid,
+                                                  const float *__restrict__ bg, int *seg_offset, float *__restrict__ final_T,
+                                                  uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
+                                                  float *__restrict__ out_depth) {
+    const int lane = threadIdx.x;
+    const size_t HW = (size_t)H * W;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    uint32_t *blk_hi = reinterpret_cast<uint32_t *>(seg_offset) + tiles + 1;
+    for (int pos = (busy_grid >> 7 << 3) + ((int)blockIdx.x - busy_grid); pos < tiles; pos += (int)gridDim.x - busy_grid) {
+        const int tile = (int)order[pos];
+        if (lane < 16) blk_hi[tile * 16 + lane] = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int px = (tile % gx) * CSPLAT_TILE + (lane & 15), py = (tile / gx) * CSPLAT_TILE + 4 * q + (lane >> 4);
+            if (px < W && py < H) {
+                const int pix = py * W + px;
+                final_T[pix] = 1.f;
+                n_contrib[pix] = 0u;
+                out_color[pix] = b0; out_color[HW + pix] = b1; out_color[2 * HW + pix] = b2;
+                out_depth[pix] = 0.f;
+            }
+        }
+    }
+}
 template <bool ROWS>
 __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab, int lpt, int busy_grid) {
     const P2View &w = tab.v[blockIdx.y];
@@ -1489,25 +1519,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, in
                                    w.n_contrib, w.out_color, w.out_depth, (int)blockIdx.x, order);
                 return;
             }
-            const int lane = threadIdx.x, gx = w.cam.gx;
-            const size_t HW = (size_t)H * W;
-            const float b0 = w.bg[0], b1 = w.bg[1], b2 = w.bg[2];
-            uint32_t *blk_hi = reinterpret_cast<uint32_t *>(w.seg_offset) + tiles + 1;
-            for (int pos = (busy_grid >> 7 << 3) + ((int)blockIdx.x - busy_grid); pos < tiles; pos += (int)gridDim.x - busy_grid) {
-                const int tile = (int)order[pos];
-                if (lane < 16) blk_hi[tile * 16 + lane] = 0u;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int px = (tile % gx) * CSPLAT_TILE + (lane & 15), py = (tile / gx) * CSPLAT_TILE + 4 * q + (lane >> 4);
-                    if (px < W && py < H) {
-                        const int pix = py * W + px;
-                        w.final_T[pix] = 1.f;
-                        w.n_contrib[pix] = 0u;
-                        w.out_color[pix] = b0; w.out_color[HW + pix] = b1; w.out_color[2 * HW + pix] = b2;
-                        w.out_depth[pix] = 0.f;
-                    }
-                }
-            }
+            paint_empty_tiles(tiles, W, H, w.cam.gx, order, busy_grid, w.bg, w.seg_offset, w.final_T, w.n_contrib, w.out_color, w.out_depth);
             return;
         }
         // (tile order, for A/B: gridDim.x may be smaller than the number of (tile, block) items: a wave then walks items blockIdx.x,
@@ -1515,9 +1527,19 @@ __global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, in
         for (int wg = blockIdx.x; wg < total; wg += gridDim.x)
             composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
                                w.n_contrib, w.out_color, w.out_depth, wg, nullptr);
-    } else
+    } else {
+        if (lpt) {      // (experiment) the column form on the non-empty-tiles-only grid
+            const uint32_t *order = w.info + INFO_BUSY + tiles + 4;
+            if ((int)blockIdx.x < busy_grid)
+                composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                                     w.n_contrib, w.out_color, w.out_depth, order);
+            else
+                paint_empty_tiles(tiles, W, H, w.cam.gx, order, busy_grid, w.bg, w.seg_offset, w.final_T, w.n_contrib, w.out_color, w.out_depth);
+            return;
+        }
         composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
                              w.n_contrib, w.out_color, w.out_depth);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- K7
@@ -2758,7 +2780,7 @@ bool mail_init() {
 // bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
 // bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook); bit 13 K7 in the survivor-column form
 // (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant);
-// bit 15 K6 in the survivor-column form (16 survivors per step, DPP row scans; products associate as a scan tree); bit 16 K7 (row
+// bit 15 K6 in the ROW form (four survivors per step; default: the survivor-column form, 16 per step, DPP row scans); bit 16 K7 (row
 // form) retires the waves that are done and lets the last one flush, instead of the barrier + four-wave flush
 unsigned g_debug_flags = 0;
 unsigned long long *g_stamp_buf = nullptr;     // csplat_debug_stamps: 12 u64 per K7 workgroup (rows form, batched launch)
@@ -3142,7 +3164,20 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         }
         {
             ProfScope ps(PROF_K6, join);
-            if (g_debug_flags & 32768u) k_composite_fwd_views<false><<<dim3(cdiv(tiles, 8) * 128, V), 64, 0, join>>>(tiles, W, H, tab, 0, cdiv(tiles, 8) * 128);
+            // Waves for the NON-EMPTY tiles only (Bcap of them, longest list first) + K6_EXTRA waves that paint the empty tiles' pixels: on
+            // scene_1 nine tiles in ten are empty, and launching 16 waves for each of them cost ~50 us of the launch (the same launch on a
+            // scene of 500 Gaussians: 51 us).  What is left is ~17 k waves with work for 8192 wave slots, 40-75 us each in the row form
+            // (four survivors a step): the launch is as long as a few of those in a row on the unluckiest slot.  Hence the SURVIVOR-COLUMN
+            // form by default (sixteen survivors a step: a quarter of the steps, each longer; 96 VGPRs, which no longer matters with two
+            // waves per slot to place): 158 -> 137 us for four views, step 0.685 -> 0.665 ms (same box, three alternations).  Bit 15 of
+            // csplat_debug_flags selects the row form.
+            if (!(g_debug_flags & 32768u)) {
+                const int total = cdiv(tiles, 8) * 128, bg_ = cdiv((int)Bcap, 8) * 128, busy_grid = bg_ < total ? bg_ : total;
+                if (g_debug_flags & (1u << 21))     // (bit 21: 16 waves for EVERY tile, in tile order, for A/B)
+                    k_composite_fwd_views<false><<<dim3(total, V), 64, 0, join>>>(tiles, W, H, tab, 0, total);
+                else
+                    k_composite_fwd_views<false><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, 1, busy_grid);
+            }
             else {
                 // (an experiment that did NOT pay, csplat_debug_flags bits 17-19 = n: 1024 * n waves per view walk the items instead of
                 //  one wave per item -- same-box A/B, step of four views: 0.725 ms with one wave per item, 0.81 / 0.767 / 0.755 / 0.73 ms
@@ -3151,9 +3186,6 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
                 if ((g_debug_flags & (1u << 21)) || cap > 0)    // (bit 21: one wave per (tile, block) of EVERY tile, in tile order, for A/B)
                     k_composite_fwd_views<true><<<dim3(cap > 0 && cap < total ? cap : total, V), 64, 0, join>>>(tiles, W, H, tab, 0, total);
                 else {
-                    // waves for the NON-EMPTY tiles only (Bcap of them, longest list first) + K6_EXTRA waves that paint the empty tiles'
-                    // pixels: on scene_1 nine tiles in ten are empty, and launching 16 waves for each of them cost ~50 us of the launch
-                    // (the same launch on a scene of 500 Gaussians: 51 us)
                     const int bg_ = cdiv((int)Bcap, 8) * 128, busy_grid = bg_ < total ? bg_ : total;
                     k_composite_fwd_views<true><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, 1, busy_grid);
                 }
@@ -3340,7 +3372,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     }
     {
         ProfScope ps(PROF_K6, s);
-        if (!(g_debug_flags & 32768u))
+        if (g_debug_flags & 32768u)       // (bit 15: the row form, four survivors a step; default: the survivor-column form, 74 -> 67 us alone)
             k_composite_fwd<true><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
                                                                       final_T, n_contrib, out_color, out_depth);
         else

@@ -102,7 +102,10 @@ def test_view_parallel_hip_train_step_two_ranks_one_gpu(tmp_path):
             #              T < 1e-4) may fall on the other side at an isolated pixel -> a few Gaussians move by O(alpha); counted, bounded
             a, b = np.asarray(r0[f"vsg{it}"], np.float64), np.asarray(ref[f"vsg{it}"], np.float64)
             d = np.abs(a - b).max(1) / (np.abs(b).max() + 1e-30)
-            assert (d > 1e-4).sum() <= max(2, 1e-3 * len(d)) and d.max() < 2e-2, (int((d > 1e-4).sum()), float(d.max()))
+            # (rounding first: the survivor-column form of K6 multiplies a step's sixteen transmittance factors as a scan tree, which carries
+            #  the rounding-level difference of the two parameter sets a little further than a sequential product -- a few rows at 1-2e-4)
+            assert (d > 1e-4).sum() <= max(2, 1e-2 * len(d)) and (d > 3e-4).sum() <= max(2, 1e-3 * len(d)) and d.max() < 2e-2, \
+                (int((d > 1e-4).sum()), int((d > 3e-4).sum()), float(d.max()))
     # parameters after two Adam steps: entries whose gradient is at rounding level can flip sign between the summation orders
     # (Adam's first steps move every entry by ~lr), so compare against the step size
     for k in r0.files:
