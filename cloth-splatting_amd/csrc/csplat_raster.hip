@@ -1625,7 +1625,25 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int tile = slot_tile[slot];
     const int seg = slot - seg_offset[tile];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 4, l16 = lane & 15;
-    const int blk = (2 * (quad >> 1) + (w >> 1)) * 4 + 2 * (quad & 1) + (w & 1);
+    const int seg_lo_ = seg * SEG;
+    // (round 3) K6 leaves every block's largest n_contrib (blk_hi).  The blocks of the tile that still blend something in this segment
+    // -- blk_hi > seg_lo -- are PACKED four to a workgroup in index order: workgroup `quad` of the slot takes the live blocks 4 quad ..
+    // 4 quad + 3, whichever quadrant of the tile they lie in (they only share the segment's LDS records).  With the blocks of a spatial
+    // quadrant per workgroup, a quadrant with ONE block left kept four waves, a record array and a flush busy for it, and a wave whose
+    // block was done waited a quarter of its life at the final barrier (tools/k7_stamps.py).
+    const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
+    uint32_t livemask = 0u;
+#pragma unroll
+    for (int b = 0; b < 16; b++) livemask |= ((int)blk_hi[b] > seg_lo_ ? 1u : 0u) << b;
+    const int n_live = __builtin_popcount(livemask);
+    if (4 * quad >= n_live) return;                                      // (workgroup-uniform)
+    const int kth = 4 * quad + __builtin_amdgcn_readfirstlane(w);
+    uint32_t m_ = livemask;
+    for (int i = 0; i < kth && m_; i++) m_ &= m_ - 1u;
+    const bool has_block = kth < n_live;
+    const int blk = has_block ? __builtin_ctz(m_) : 0;
+    // (ordering the live blocks by how far into the segment they go, so that the four waves of a workgroup have about the same number
+    //  of entries to walk, was measured: the 16 x 16 rank computation costs more than the skew -- 330 against 280 us)
     const int px = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4 + (l16 & 3);
     const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
@@ -1635,12 +1653,9 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
     const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
-    // (round 3) K6 leaves every block's largest n_contrib: the workgroups behind all of their pixels end here on scalar loads, and a
-    // wave knows where its block ends without a reduction over its pixels' n_contrib and two barriers
-    const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
-    const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);
-    if ((int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])) <= seg_lo) return;   // (workgroup-uniform)
-    const int wave_hi = min(seg_hi, (int)blk_hi[blk]);                  // no pixel of the block blends an entry at or behind it
+    // (the workgroups behind all of their blocks' pixels have ended above on scalar loads, and a wave knows where its block ends without
+    // a reduction over its pixels' n_contrib and two barriers)
+    const int wave_hi = has_block ? min(seg_hi, (int)blk_hi[blk]) : seg_lo;   // no pixel of the block blends an entry at or behind it
     mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi) has returned
     // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint, the first chunk of
     // masks and (one per thread) the ids the flush will need are requested together, BEFORE the records are zeroed and the barrier
