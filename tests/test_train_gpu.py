@@ -474,6 +474,47 @@ def test_step_stats_and_no_copy_unbind():
     assert float((D.grad - D2.grad).abs().max()) <= 1e-6 * float(D2.grad.abs().max())
 
 
+def test_train_step_static_stage_on_gpu():
+    """train_step(static=True) -- the reference's static stage (train_utils.py:240-321 with render_static: the rest mesh, no simulator,
+    no regularisers): the Gaussian parameters train, the simulator's stay untouched, batched and camera-by-camera agree."""
+    import bench_train as bt
+    from csplat import train as tr
+    from gaussian_renderer import render
+    dev = torch.device("cuda")
+
+    def setup():
+        torch.manual_seed(4)
+        sc, pc, sim = bt.build(P=1500, W=80, H=64, grid=10, n_times=5, dev=dev)
+        with torch.no_grad():
+            pc._scaling.add_(0.8)
+        bg = torch.ones(3, device=dev)
+        cams = bt.cameras(sc, [0.25, 0.5, 0.75], dev)
+        with torch.no_grad():
+            keep = pc._features_dc.detach().clone()
+            torch.manual_seed(0)
+            pc._features_dc.add_(0.5 * torch.randn_like(pc._features_dc))
+            targets = [render(c, pc, sim, tr.DEFAULT_PIPE, bg, render_static=True).render.clamp(0, 1).clone() for c in cams]
+            pc._features_dc.copy_(keep)
+        cams = bt.cameras(sc, [0.25, 0.5, 0.75], dev, targets)
+        pc.training_setup(feature_lr=0.02)
+        mopt = torch.optim.Adam(sim.parameters(), lr=3e-4)
+        return pc, sim, mopt, cams, bg
+    runs = []
+    for batched in (True, False):
+        pc, sim, mopt, cams, bg = setup()
+        before = [p.detach().clone() for p in sim.parameters()]
+        ps = []
+        for it in range(1, 9):
+            p_, loss, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, static=True, batched_views=batched)
+            ps.append(float(p_))
+        assert ps[-1] > ps[0] + 0.2, ps
+        for a, b in zip(before, sim.parameters()):
+            assert torch.equal(a, b.detach())
+        assert stats["radii"].shape == (1500,) and stats["viewspace_grad"].shape == (1500, 3)
+        runs.append(ps)
+    assert max(abs(a - b) for a, b in zip(*runs)) < 2e-3, runs
+
+
 def test_step_head_nodes_equal_the_chained_nodes():
     """SimulatorStep (simulator + regularisers) and GaussianStepInputs (mesh transform + activations) -- the two autograd nodes the
     batched train step starts with -- against the nodes they replace (forward_times + regularization(tap), transform_views +
