@@ -56,7 +56,11 @@ int csplat_abi_version(void);
  *        before sizing the scratch);
  * bit 9: per-view launches on per-view streams instead of one launch per stage for all views of a step;
  * bit 10: csplat_forward_views always waits for a call's counts before launching its second phase (no speculative launch with
- * the previous call's counts as capacities). */
+ * the previous call's counts as capacities);
+ * bits 11-22: A/B switches of kernel forms and experiments (csplat_raster.hip): 11 tile sort by LSD radix only,
+ *        12 forced fallback of the bucket sort, 13 / 14 K7 in its survivor-column forms, 15 K6 in the row form (default: survivor
+ *        columns), 16 K7 retire-waves flush, 17-19 K6 (row form) items per wave, 20 block masks with blockIdx.y = view, 21 K6 with 16
+ *        waves for every tile in tile order (default: the non-empty tiles only, longest list first). */
 int csplat_debug_flags(unsigned flags);
 /* measurement hook (not part of the operator interface): a device buffer the batched compositing backward fills with s_memtime stamps,
  * 12 uint64 per workgroup in launch order [view][workgroup] (tools/k7_stamps.py); NULL / 0 switches it off */
