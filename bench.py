@@ -91,12 +91,16 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    # CSPLAT_FORCE_DIST=1 with one rank: the N > 1 code path (FlatGrads + one all-reduce per step + the `collective` leg) with the
+    # collectives really issued -- RCCL exercised on a 1-GPU box (csplat/dist.py, tests/test_rccl_gpu.py)
+    dist_on = world > 1 or os.environ.get("CSPLAT_FORCE_DIST", "") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from csplat import native, synthetic as syn
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
@@ -179,7 +183,7 @@ def main():
         loads = [Workload(6666 + 17 * s_, 0.0, False) for s_ in range(n_scenes) if s_ % world == rank]
     else:
         n_scenes = world
-        loads = [Workload(syn.SEED, rank / max(world, 1), world > 1)]
+        loads = [Workload(syn.SEED, rank / max(world, 1), dist_on)]
     wl = loads[0] if loads else None
 
     def step():
@@ -189,7 +193,7 @@ def main():
         return out_
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -239,7 +243,7 @@ def main():
         k7_alone_us = ms_a / max(n_a, 1) * 1e3
     # the collective on its own (untimed extra passes, bracketed by device synchronisation): bytes, ranks, wall time
     collective = None
-    if world > 1 and not scene_mode:
+    if dist_on and not scene_mode:
         ar = []
         for _ in range(5):
             wl.step(timed_allreduce=True)
@@ -289,7 +293,7 @@ def main():
                     "Mpix_per_s": round(V * W * H / 1e6 / dt_e, 1), "what": "rasterizer forward only under no_grad (K1-K6), all views of the batch per call"}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -358,7 +362,7 @@ def main():
         "config": {"workload": (f"6 seeded scene_1 variants dealt over {world} rank(s), " if scene_mode else "scene_1 synthetic, ") +
                                f"P={P} Gaussians, {V} cams {W}x{H} per " + ("scene" if scene_mode else "GPU") + ", SH degree 3, "
                                "fwd (K1-K6) + L1 + bwd (K7-K8)" +
-                               (", + ONE RCCL all-reduce of the flat gradient buffer" if world > 1 and not scene_mode else ""),
+                               (", + ONE RCCL all-reduce of the flat gradient buffer" if dist_on and not scene_mode else ""),
                    "tile_instances_per_view": R_per_view,
                    "parallelism": (f"scene-parallel x{world} (replicas only)" if scene_mode else f"view-parallel x{world}"),
                    "streams_per_gpu": V if args.view_streams else 1},
@@ -410,7 +414,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -10,14 +10,20 @@ capability described in SURVEY.md 5.8 / 8(e):
   * densification statistics are reduced with the operator that keeps replicas bit-identical:
     screen-space gradient (part of the flat buffer) -> sum, max_radii2D -> max (visibility = radius > 0).
 """
+import os
 import time
 
 import torch
 import torch.distributed as dist
 
+# CSPLAT_FORCE_DIST=1: treat an initialised process group of ONE rank as distributed -- every collective of the view-parallel step is
+# then really issued (RCCL on a 1-GPU box: library load, communicator, the all-reduce started from the autograd hook and its stream
+# ordering), where the product would otherwise skip them as the identity they are.  Tests and bench.py's 1-rank `collective` leg.
+FORCE_DIST = os.environ.get("CSPLAT_FORCE_DIST", "") == "1"
+
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_DIST)
 
 
 def world_rank():
@@ -74,15 +80,21 @@ class FlatGrads:
         # one-rank step, or Adam would create state for it and advance its step count)
         self._touched = [False] * len(self.params)
         self._union = {}
-        self._early_expect = None      # which early parameters receive a gradient in a step (learned on the first step)
+        # which early parameters receive a gradient in a step, per step SHAPE (the `key` of bind(): static / dynamic stage, number of
+        # cameras -- whatever changes the graph); learned on the first step of each shape
+        self._early_expect = {}
+        self._key = None
         self._early_left = None
         self._early_work = None
+        self._early_late = []          # early parameters that received a gradient AFTER the early slice had left (must stay empty)
         self._group = None
         self._hooks = [p.register_post_accumulate_grad_hook(self._mark(i)) for i, p in enumerate(self.params)]
 
     def _mark(self, i):
         def hook(_p):
             self._touched[i] = True
+            if i < self.early and self._early_work is not None:
+                self._early_late.append(i)
             if self._early_left is not None and i in self._early_left:
                 self._early_left.discard(i)
                 if not self._early_left:
@@ -106,14 +118,17 @@ class FlatGrads:
         return len(params) == len(self.params) and int(extra) == self.extra and int(early) == self.early and \
             all(a is b and tuple(a.shape) == s for a, b, s in zip(params, self.params, self.shapes))
 
-    def bind(self, group=None):
+    def bind(self, group=None, key=None):
         self.flat.zero_()
         self._touched = [False] * len(self.params)
         self._early_work = None
+        self._early_late = []
         self._group = group
-        # the early bucket fires when the same early parameters as in the previous step have their gradients (a step's graph is
-        # static); the first step of a buffer learns the set and sends everything at the end
-        self._early_left = set(self._early_expect) if (self.early and self._early_expect) else None
+        self._key = key
+        # the early bucket fires when the same early parameters as in the previous step OF THIS SHAPE have their gradients (the graph
+        # of a step shape is static); the first step of a shape learns the set and sends everything at the end
+        expect = self._early_expect.get(key)
+        self._early_left = set(expect) if (self.early and expect) else None
         for p, v in zip(self.params, self.views):
             p.grad = v
 
@@ -135,8 +150,17 @@ class FlatGrads:
         brackets the call with device synchronisation and records its wall time -- `last_allreduce_ms` = what this call took with
         the device drained first, i.e. the EXPOSED time of the step's exchange when the early bucket was in flight (bench.py reports
         the one-shot time next to it); the default leaves it asynchronous with respect to the host."""
-        if self.early and self._early_expect is None:      # learned once per buffer: which early parameters a step touches
-            self._early_expect = [i for i in range(self.early) if self._touched[i]]
+        if self._early_late:
+            # the slice that left from the hook did not hold this gradient yet: the sums the other ranks are about to use are wrong.
+            # A step whose graph differs from the one its `key` was learned on -- give bind() a key that tells them apart.
+            late, self._early_late = self._early_late, []
+            raise RuntimeError(f"FlatGrads: early parameter(s) {sorted(set(late))} received a gradient after the early slice had been "
+                               f"sent (step shape {self._key!r}): the step's graph changed under one bind() key")
+        if self.early and self._key not in self._early_expect:      # learned once per step shape: which early parameters it touches
+            self._early_expect[self._key] = [i for i in range(self.early) if self._touched[i]]
+        elif self.early and self._early_work is None and self._early_expect[self._key] and \
+                not all(self._touched[i] for i in self._early_expect[self._key]):
+            self._early_expect[self._key] = [i for i in range(self.early) if self._touched[i]]      # (the hook never fired: relearn)
         if not is_dist():
             return self.flat
         if timed and self.flat.is_cuda:

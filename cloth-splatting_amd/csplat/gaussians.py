@@ -424,6 +424,28 @@ class MeshGaussians(DensifyMixin):
         # hipBLASLt -- the same contraction as a broadcast multiply + sum streams at HBM rate)
         return (nb.unsqueeze(-1) * face_pos).sum(dim=1)
 
+    def vertex_normals(self, vertices):
+        """unit vertex normals as torch_geometric.transforms.GenerateMeshNormals defines them (the transform the reference applies,
+        gaussian_mesh.py:199-200): unit face normals (v1 - v0) x (v2 - v0), summed onto the face's three vertices, normalised."""
+        face = self.mesh.face
+        v0, v1, v2 = vertices[face[0]], vertices[face[1]], vertices[face[2]]
+        fn = torch.nn.functional.normalize(torch.cross(v1 - v0, v2 - v0, dim=1), p=2, dim=-1)
+        vn = torch.zeros_like(vertices).index_add_(0, torch.cat([face[0], face[1], face[2]]), fn.repeat(3, 1))
+        return torch.nn.functional.normalize(vn, p=2, dim=-1)
+
+    def get_vertice_rotation(self, deformed_vertices):
+        """gaussian_mesh.py:190-201: per-vertex rotation (quaternion, XYZW) from the rest-pose vertex normal to the deformed one --
+        axis = n_rest x n_def (normalised), angle = acos(clamp(n_rest . n_def)) (meshnet/data_utils.py:460-491).  A debug by-product:
+        render(log_deform_path=...) stores it (gaussian_renderer/__init__.py:118-127); plain torch ops, no kernel."""
+        rest = getattr(self.mesh, "norm", None)
+        if rest is None:            # (the reference's compute_mesh stores mesh.norm at load time; a mesh built from arrays has none)
+            rest = self.vertex_normals(self.mesh.pos)
+        deformed = self.vertex_normals(deformed_vertices)
+        cross = torch.cross(rest, deformed, dim=1)
+        angle = torch.acos(torch.clamp((rest * deformed).sum(dim=1), -1.0, 1.0))
+        axis = cross / torch.linalg.norm(cross, dim=1, keepdim=True)
+        return torch.cat([axis * torch.sin(angle / 2).unsqueeze(1), torch.cos(angle / 2).unsqueeze(1)], dim=1)
+
     def get_rotation(self, deformed_vertices=None):
         if deformed_vertices is not None and deformed_vertices.is_cuda and self.fused:
             return self._fused(deformed_vertices)[1]

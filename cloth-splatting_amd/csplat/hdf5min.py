@@ -10,9 +10,12 @@ Specification (version 0 superblock, symbol-table root group = one v1 B-tree nod
 version-1 object headers, contiguous version-3 data layout, little-endian fixed / floating point types) -- the "earliest"
 format libhdf5 itself emits by default for such a file.
 
-STATUS: written from the specification; verified against its own reader and structural known-answer checks
-(tests/test_oracle_cpu.py), NOT against libhdf5 -- neither libhdf5 nor h5py exists here to open the files.  `load()` prefers
-h5py when it is importable.  Not supported (clear errors): more than 8 datasets, groups, chunked / compressed layouts,
+STATUS: written from the specification and held to the REAL library since round 4: the image's conda environment carries h5py 3.3.0
+on libhdf5 1.10.6 (a separate Python 3.9 interpreter; the build's own has none), and tests/test_oracle_cpu.py checks both directions --
+files written by `save()` are opened by h5py (names, dtypes, shapes, contiguous storage, values), files h5py writes with the reference's
+call pattern are read by `load(prefer_h5py=False)`; a file written by h5py is committed as tests/golden/mesh_h5py.hdf5 so that the
+reader is held to libhdf5's bytes wherever the tests run.  `load()` prefers h5py when it is importable.
+Not supported (clear errors): more than 8 datasets, groups, chunked / compressed layouts,
 superblock versions 2+, big-endian or compound types."""
 import struct
 

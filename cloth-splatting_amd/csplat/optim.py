@@ -37,10 +37,10 @@ class GroupedAdam(torch.optim.Adam):
         the first densification) replaced by a compact copy: `torch.save` serialises a tensor's whole storage, i.e. the spare
         capacity and its stale rows would otherwise travel in every checkpoint (gaussian_model.py:64-75 saves this dict)."""
         sd = super().state_dict()
-        for st in sd["state"].values():
-            for k, v in st.items():
-                if torch.is_tensor(v) and v.numel() and v.untyped_storage().nbytes() > v.numel() * v.element_size():
-                    st[k] = v.clone()
+        # (torch returns the per-parameter dicts BY REFERENCE: sd["state"][i] is self.state[p].  They are rebuilt here, never edited --
+        #  replacing a live moment by its clone would detach the optimizer from the store's buffers until the next compaction)
+        over = lambda v: torch.is_tensor(v) and v.numel() and v.untyped_storage().nbytes() > v.numel() * v.element_size()  # noqa: E731
+        sd["state"] = {i: {k: (v.clone() if over(v) else v) for k, v in st.items()} for i, st in sd["state"].items()}
         return sd
 
     @torch.no_grad()

@@ -543,24 +543,30 @@ def regularization(all_vertice_deform, gaussians, opt, static=False, fused=True,
 
 
 _ONES = {}
-_GT_STACKS = {}
+_GT_STACKS = {}          # insertion-ordered: least recently used first
+_GT_STACKS_MAX = 8
 
 
 def _gt_stack(cams, device):
-    """torch.cat of the cameras' ground-truth images (train_utils.py:262-270 builds it every step).  A training run cycles through a
-    bounded set of camera triples whose images never change: the stack of a camera set is built once and kept, keyed on the image
-    tensor OBJECTS and their in-place versions (held in the entry, so a recycled id cannot alias)."""
+    """torch.cat of the cameras' ground-truth images (train_utils.py:262-270 builds it every step).  A caller that cycles through a few
+    camera OBJECTS whose images never change (bench_train, the parity runs) gets the stack of a camera set built once: a small LRU
+    (8 sets) keyed on the image tensors' identities and in-place versions.  The entry holds WEAK references to the source images -- an id
+    recycled by a new tensor cannot alias (the dead reference no longer matches) and nothing of the caller's is pinned.  The
+    reference's dataset builds a fresh Camera per item (scene_reconstruction/dataset.py:89-): such a caller never hits, and then the
+    cache costs eight stale stacks at most (it used to hold up to 512 entries with strong references to the sources)."""
+    import weakref
     imgs = [cam.original_image for cam in cams]
     key = tuple((id(t), t._version) for t in imgs) + (str(device),)
     hit = _GT_STACKS.get(key)
-    if hit is not None and all(a is b for a, b in zip(hit[0], imgs)):
+    if hit is not None and all(r() is t for r, t in zip(hit[0], imgs)):
+        _GT_STACKS[key] = _GT_STACKS.pop(key)          # most recently used: to the back
         return hit[1]
-    if len(_GT_STACKS) >= 512:
-        _GT_STACKS.clear()
     stack = torch.cat([t.to(device).unsqueeze(0) for t in imgs], 0)
-    _GT_STACKS[key] = (imgs, stack)
+    _GT_STACKS.pop(key, None)
+    while len(_GT_STACKS) >= _GT_STACKS_MAX:
+        _GT_STACKS.pop(next(iter(_GT_STACKS)))
+    _GT_STACKS[key] = ([weakref.ref(t) for t in imgs], stack)
     return stack
-
 
 
 @torch.no_grad()
@@ -621,7 +627,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     all_cams = list(viewpoint_cams)
     n_total = len(all_cams)
     world, rank = cd.world_rank() if view_parallel else (1, 0)
-    dist_mode = world > 1
+    dist_mode = view_parallel and cd.is_dist()          # (world > 1, or one rank under CSPLAT_FORCE_DIST: csplat/dist.py)
     idx = cd.shard_indices(n_total, rank, world) if dist_mode else list(range(n_total))
     cams = [all_cams[i] for i in idx]
     P = int(gaussians.num_gaussians)
@@ -633,7 +639,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         # rank's largest radii in its own [P] slot (zeros elsewhere), so that the max over ranks rides in the SAME sum
         gparams = list(gaussians.parameters())
         fg = cd.flat_grads_for(gaussians, gparams + list(simulator.parameters()), extra=3 * P + 2 + world * P, early=len(gparams))
-        fg.bind()
+        fg.bind(key=(bool(static), n_total))
     images, gts, radii_l, vsp_l, verts = [], [], [], [], []
     masks = [] if all_cams and getattr(all_cams[0], "mask", None) is not None else None          # train_utils.py:256
     stacked = reg = deforms = None

@@ -34,7 +34,27 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-def _f32c(t, device):
+def _f32c(t, device, what="input", per_gaussian=True):
+    """fp32, contiguous, on `device`.  The upstream binding takes `.contiguous().data<float>()` of every argument: a non-fp32 tensor
+    is REJECTED there and a strided one silently copied.  Here a tensor of another dtype or on another device is converted -- which
+    is a torch launch outside the HIP path, so it is reported (csplat.native.composed_fallback: counted, and an error under STRICT,
+    kind "dtype"); a strided per-Gaussian tensor is copied like upstream does and reported as kind "layout"; the camera constants
+    (4x4 matrices: the reference builds them as `.transpose(0, 1)` views, scene_reconstruction/cameras.py:63-67) are copied
+    without a report, exactly upstream's behaviour."""
+    if t is None:
+        return None
+    if t.device != device or t.dtype != torch.float32:
+        _n.composed_fallback("diff_gaussian_rasterization." + what, "dtype", t if t.is_cuda else torch.empty(0, device=device))
+        t = t.to(device=device, dtype=torch.float32)
+    if not t.is_contiguous():
+        if per_gaussian:
+            _n.composed_fallback("diff_gaussian_rasterization." + what, "layout", t)
+        t = t.contiguous()
+    return t
+
+
+def _f32c_grad(t, device):
+    """the incoming image gradient: whatever autograd hands over (an expanded scalar, a slice) is made dense -- not the caller's input"""
     if t is None:
         return None
     if t.device != device or t.dtype != torch.float32:
@@ -57,14 +77,15 @@ class _View:
         self.rs = rs
         self.P = int(means3D.shape[0])
         self.H, self.W = int(rs.image_height), int(rs.image_width)
-        self.means3D = _f32c(means3D, dev); self.opacities = _f32c(opacities, dev)
-        self.sh = _f32c(sh, dev)
-        self.colors_precomp = _f32c(colors_precomp, dev)
-        self.scales = _f32c(scales, dev)
-        self.rotations = _f32c(rotations, dev)
-        self.cov3Ds_precomp = _f32c(cov3Ds_precomp, dev)
-        self.bg = _f32c(rs.bg, dev); self.view = _f32c(rs.viewmatrix, dev); self.proj = _f32c(rs.projmatrix, dev)
-        self.campos = _f32c(rs.campos, dev)
+        self.means3D = _f32c(means3D, dev, "means3D"); self.opacities = _f32c(opacities, dev, "opacities")
+        self.sh = _f32c(sh, dev, "shs")
+        self.colors_precomp = _f32c(colors_precomp, dev, "colors_precomp")
+        self.scales = _f32c(scales, dev, "scales")
+        self.rotations = _f32c(rotations, dev, "rotations")
+        self.cov3Ds_precomp = _f32c(cov3Ds_precomp, dev, "cov3D_precomp")
+        self.bg = _f32c(rs.bg, dev, "bg", False); self.view = _f32c(rs.viewmatrix, dev, "viewmatrix", False)
+        self.proj = _f32c(rs.projmatrix, dev, "projmatrix", False)
+        self.campos = _f32c(rs.campos, dev, "campos", False)
         self.M = int(self.sh.shape[1]) if self.sh is not None else 0
         self.ticket = None
 
@@ -110,7 +131,7 @@ class _View:
         means3D, sh, colors_precomp, scales, rotations, cov3Ds_precomp, radii, color = saved
         rs, dev, P, M = self.rs, self.dev, self.P, self.M
         geom, binning, image = self.chunks
-        grad_color = _f32c(grad_color, dev)
+        grad_color = _f32c_grad(grad_color, dev)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         d_mean2D, d_conic, d_opac, d_color = new(P, 3), new(P, 4), new(P, 1), new(P, 3)
         d_mean3D, d_cov3D = new(P, 3), new(P, 6)
@@ -377,7 +398,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         plan, ctx.plan = ctx.plan, None                         # (one use: the buffers are handed to autograd)
         if plan is None or plan["active"] != active:            # a view's image went unused, or a second backward pass
             plan = _RasterizeGaussiansBatch._plan_backward(views, ctx.saved_tensors, k, arr, ctx.first_of, active, dev)
-        gs = [_f32c(gcol[i], dev) for i in active]
+        gs = [_f32c_grad(gcol[i], dev) for i in active]
         for a, g in enumerate(gs):
             plan["sub"][a].dL_dpix = _n.ptr(g)
         with _n.on_device(dev):

@@ -734,6 +734,52 @@ def gen_mesh_transform():
     np.savez_compressed(os.path.join(OUT, "mesh_transform.npz"), **{k: npy(v) for k, v in out.items()})
 
 
+def gen_vertice_rotation():
+    """MultiGaussianMesh.get_vertice_rotation (gaussian_mesh.py:190-201) run here: `vertice_rotation` / `axis_angle_to_quat` are the
+    reference's own text (exec'd from meshnet/data_utils.py:460-491); torch_geometric's GenerateMeshNormals is absent and served by a
+    stand-in with PyG's published semantics (unit face normals summed onto the vertices, normalised) -- "shim-derived" for the normals,
+    the reference's arithmetic for the quaternion and the call pattern (rest normals first)."""
+    install_mesh_shims()
+    import torch.nn.functional as F
+    src = open(os.path.join(REF, "meshnet", "data_utils.py")).read()
+    ns = {}
+    for fn in ("axis_angle_to_quat", "vertice_rotation"):
+        m = re.search(r"^def %s\(.*?(?=^\S)" % fn, src, re.S | re.M)
+        exec(compile("import torch\n" + m.group(0), "data_utils.py:" + fn, "exec"), ns)
+
+    class GenerateMeshNormals:
+        def __call__(self, data):
+            pos, face = data.pos, data.face
+            fn = F.normalize(torch.cross(pos[face[1]] - pos[face[0]], pos[face[2]] - pos[face[0]], dim=1), p=2, dim=-1)
+            idx = torch.cat([face[0], face[1], face[2]], dim=0)
+            norm = torch.zeros_like(pos).index_add_(0, idx, fn.repeat(3, 1))
+            data.norm = F.normalize(norm, p=2, dim=-1)
+            return data
+    tg = sys.modules["torch_geometric"]
+    tg.transforms = types.ModuleType("torch_geometric.transforms")
+    tg.transforms.GenerateMeshNormals = GenerateMeshNormals
+    sys.modules["torch_geometric.transforms"] = tg.transforms
+    with cuda_as_cpu():
+        import scene_reconstruction.gaussian_mesh as gmod
+        gmod.vertice_rotation = ns["vertice_rotation"]
+        g = torch.Generator().manual_seed(17)
+        gm = 6
+        xs = torch.linspace(-0.5, 0.5, gm)
+        pos = torch.stack([xs.repeat(gm), xs.repeat_interleave(gm), 0.08 * torch.rand(gm * gm, generator=g)], 1)
+        quads = [(r * gm + c, r * gm + c + 1, (r + 1) * gm + c, (r + 1) * gm + c + 1) for r in range(gm - 1) for c in range(gm - 1)]
+        face = torch.tensor([[a, b, c2] for a, b, c2, d in quads] + [[b, d, c2] for a, b, c2, d in quads]).t().contiguous()
+        pc = gmod.MultiGaussianMesh(3)
+        rest = GenerateMeshNormals()(types.SimpleNamespace(pos=pos, face=face)).norm       # what compute_mesh leaves in mesh.norm
+        pc.mesh = types.SimpleNamespace(pos=pos, face=face, norm=rest)
+        ang = 0.7
+        Rx = torch.tensor([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]], dtype=torch.float32)
+        deformed = pos @ Rx.T + 0.02 * torch.randn(pos.shape[0], 3, generator=g)
+        deformed[:, 2] += 0.15 * torch.sin(5 * pos[:, 0])
+        q = pc.get_vertice_rotation(deformed)
+    np.savez_compressed(os.path.join(OUT, "vertice_rotation.npz"), pos=npy(pos), face=npy(face), deformed=npy(deformed), rest_norm=npy(rest),
+                        quat=npy(q))
+
+
 class RecordingRasterizer:
     """stand-in for the absent `diff_gaussian_rasterization` extension: records the settings record and every tensor the
     reference's render() hands the rasterizer, returns zeros of the documented shapes (color [3,H,W], radii [P] int32, depth [1,H,W])"""
@@ -969,7 +1015,7 @@ def gen_losses():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
     gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify(); gen_scene_io()
-    gen_meshsim(); gen_mesh_transform(); gen_losses(); gen_render_wiring(); gen_gnn128()
+    gen_meshsim(); gen_mesh_transform(); gen_losses(); gen_render_wiring(); gen_gnn128(); gen_vertice_rotation()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -670,3 +670,144 @@ def test_blender_scene_loader_matches_reference():
         assert abs(float(torch.det(cam.world_view_transform[:3, :3])) - 1.0) < 1e-5
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_grouped_adam_state_dict_leaves_the_live_state_alone():
+    """torch's Optimizer.state_dict() hands out the per-parameter state dicts by reference; GroupedAdam.state_dict()
+    must not replace the live moments (views into the capacity buffers of csplat/store.py) by compact clones -- the optimizer would go on
+    updating the clones and the next compaction would scatter the store's stale rows back.  A checkpoint save between two steps of the
+    densification phase must change nothing: state_dict() -> steps -> prune == the same run without state_dict(), bit for bit; and the
+    saved copy is compact (no spare capacity in the checkpoint, gaussian_model.py:64-75)."""
+    import types
+    import torch
+    from csplat.gaussians import MeshGaussians
+    from csplat.optim import GroupedAdam
+    g = golden("densify.npz")
+    T = lambda a: torch.tensor(a)  # noqa: E731
+    names = ["face_bary", "face_offset", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    attrs = ["face_bary", "face_offset", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    lrs = [1.6e-4, 1.6e-4, 2.5e-3, 2.5e-3 / 20, 0.05, 0.005, 0.001]
+
+    def run(save):
+        pc = MeshGaussians(3)
+        pc.mesh = types.SimpleNamespace(pos=T(g["pos"]), face=T(g["face"]), edge_index=None)
+        pc.face_ids = T(g["face_ids"])
+        for n, a in zip(names, attrs):
+            setattr(pc, a, torch.nn.Parameter(T(g["init." + n])))
+        pc.fused = False
+        pc.optimizer = GroupedAdam([{"params": [getattr(pc, a)], "lr": lr, "name": n} for a, lr, n in zip(attrs, lrs, names)], lr=0.0, eps=1e-15)
+        pc.densification_setup(percent_dense=0.01)
+        pc.max_radii2D = T(g["max_radii2D"])
+        gen = torch.Generator().manual_seed(3)
+
+        def step():
+            for grp in pc.optimizer.param_groups:
+                p = grp["params"][0]
+                p.grad = torch.randn(p.shape, generator=gen)
+            pc.optimizer.step()
+        for _ in range(3):
+            step()
+        vsp, upd = T(g["vsp"]), T(g["update_filter"])
+        pc.add_densification_stats(vsp, upd)
+        torch.manual_seed(4321)
+        pc.densify(2e-4, 0.05, 1.0, None)            # from here on every moment is a view into a capacity buffer
+        step()
+        sd = None
+        if save:
+            live = {n: pc.optimizer.state[grp["params"][0]]["exp_avg"] for grp, n in zip(pc.optimizer.param_groups, names)}
+            sd = pc.optimizer.state_dict()
+            for grp, n in zip(pc.optimizer.param_groups, names):        # the live state is untouched ...
+                assert pc.optimizer.state[grp["params"][0]]["exp_avg"] is live[n]
+            for st in sd["state"].values():                             # ... and the saved one is compact
+                for k in ("exp_avg", "exp_avg_sq"):
+                    assert st[k].untyped_storage().nbytes() == st[k].numel() * st[k].element_size()
+        for _ in range(5):
+            step()
+        pc.prune(2e-4, 0.3, 1.0, 20)
+        step()
+        out = {}
+        for grp, n in zip(pc.optimizer.param_groups, names):
+            p = grp["params"][0]
+            st = pc.optimizer.state[p]
+            out[n] = (p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), float(st["step"]))
+        return out, sd
+    a, sd = run(True)
+    b, _ = run(False)
+    for n in names:
+        for x, y in zip(a[n][:3], b[n][:3]):
+            assert torch.equal(x, y), n
+        assert a[n][3] == b[n][3]
+    # the saved state loads into a fresh optimizer of the same shape (torch's own contract)
+    fresh = GroupedAdam([{"params": [torch.nn.Parameter(torch.zeros_like(sd["state"][i]["exp_avg"]))], "lr": lr, "name": n}
+                         for i, (lr, n) in enumerate(zip(lrs, names))], lr=0.0, eps=1e-15)
+    fresh.load_state_dict(sd)
+
+
+H5PY_PYTHON = "/opt/conda/bin/python3.9"          # an interpreter WITH the real h5py (3.3.0 on libhdf5 1.10.6) on this image
+
+
+def _real_h5py():
+    import subprocess
+    if not os.path.exists(H5PY_PYTHON):
+        return False
+    try:
+        return subprocess.run([H5PY_PYTHON, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        return False
+
+
+def test_hdf5min_reads_a_file_written_by_the_real_h5py():
+    """N4 interop, direction 1 (always runs): tests/golden/mesh_h5py.hdf5 was written by the REAL h5py / libhdf5 with the reference's
+    call pattern (gaussian_mesh.py:462-465; generator tests/golden/make_h5py_fixture.py) -- csplat/hdf5min.py's own reader must
+    return its four datasets bit for bit (what meshnet/data_utils.py:450-457 reads back with h5py)."""
+    from csplat import hdf5min
+    ref = golden("mesh_h5py.npz")
+    got = hdf5min.load(os.path.join(util.GOLDEN, "mesh_h5py.hdf5"), prefer_h5py=False)
+    assert sorted(got) == sorted(ref.files) == ["edge_index", "face", "norm", "pos"]
+    for k in ref.files:
+        assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape
+        np.testing.assert_array_equal(got[k], ref[k])
+
+
+@pytest.mark.skipif(not _real_h5py(), reason="no interpreter with the real h5py on this machine")
+def test_hdf5min_round_trips_through_the_real_h5py(tmp_path):
+    """N4 interop, both directions LIVE against the real h5py 3.3.0 / libhdf5 1.10.6 found in the image's conda environment (a
+    separate interpreter: the build's Python has no h5py): (1) a file written by hdf5min.save -- the reference's four datasets plus a
+    float64, an int32, a 0-d and an empty array -- is opened by h5py, which must list the same names, dtypes, shapes, contiguous
+    (unchunked) storage and values; (2) a file h5py writes with the reference's call pattern is read by hdf5min's own reader."""
+    import subprocess
+    from csplat import hdf5min
+    rng = np.random.default_rng(5)
+    arrays = {"pos": rng.normal(size=(37, 3)).astype(np.float32), "norm": rng.normal(size=(37, 3)).astype(np.float32),
+              "face": rng.integers(0, 37, (3, 50)).astype(np.int64), "edge_index": rng.integers(0, 37, (2, 120)).astype(np.int64),
+              "f64": rng.normal(size=(4, 2, 3)), "i32": np.arange(-5, 6, dtype=np.int32), "scalar": np.array(3.5, np.float32),
+              "empty": np.zeros((0, 3), np.float32)}
+    ours, theirs, dump = str(tmp_path / "ours.hdf5"), str(tmp_path / "theirs.hdf5"), str(tmp_path / "dump.npz")
+    hdf5min.save(ours, arrays)
+    np.savez(str(tmp_path / "in.npz"), **arrays)
+    code = ("import sys, h5py, numpy as np\n"
+            "ours, theirs, dump, inp = sys.argv[1:5]\n"
+            "out = {}\n"
+            "with h5py.File(ours, 'r') as f:\n"
+            "    for k in f.keys():\n"
+            "        d = f[k]\n"
+            "        assert d.chunks is None and d.compression is None, k\n"
+            "        out[k] = d[()]\n"
+            "np.savez(dump, **out)\n"
+            "src = np.load(inp)\n"
+            "with h5py.File(theirs, 'w') as f:\n"
+            "    for k in src.files:\n"
+            "        f.create_dataset(k, data=src[k])\n")
+    r = subprocess.run([H5PY_PYTHON, "-c", code, ours, theirs, dump, str(tmp_path / "in.npz")], capture_output=True, text=True, timeout=300,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = np.load(dump)
+    assert sorted(seen.files) == sorted(arrays)
+    for k, v in arrays.items():
+        assert seen[k].dtype == v.dtype and seen[k].shape == v.shape, k
+        np.testing.assert_array_equal(seen[k], v)
+    back = hdf5min.load(theirs, prefer_h5py=False)
+    assert sorted(back) == sorted(arrays)
+    for k, v in arrays.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape, k
+        np.testing.assert_array_equal(back[k], v)

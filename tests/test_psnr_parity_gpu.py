@@ -19,6 +19,8 @@ LRS = dict(position_lr=0.00016, feature_lr=0.00025, opacity_lr=0.05, scaling_lr=
 
 
 STEP_HOOK = [None]              # tools/psnr_shadow.py: called after every HIP step with (it, pc, sim, cams, bg, build, psnr)
+PRE_STEP = [None]               # (it, pc, sim) -> context manager entered around the HIP step (tests/teacher.py: capture), or None
+HIP_FLAGS = [256]               # csplat_debug_flags of the HIP run (bit 8: bit-reproducible K7)
 TORCH_DTYPE = [None]            # (None = torch.float64; the probe also runs the whole CPU side in float32, like the reference's own arithmetic)
 ORACLE_DTYPE = [np.float64]     # (tools/psnr_probe.py also runs the fp32 build of the oracle: how far fp32 ARITHMETIC alone moves a trajectory)
 
@@ -172,15 +174,21 @@ def _parity(masked, steps=None, hip_only=False):
         mopt = torch.optim.Adam(sim.parameters(), lr=3e-4)
         ps = []
         for it in range(1, STEPS + 1):
-            ps.append(float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0]))
+            ctx = PRE_STEP[0](it, pc, sim) if PRE_STEP[0] is not None else None
+            if ctx is None:
+                ps.append(float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0]))
+            else:
+                with ctx as cap:
+                    ps.append(float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0]))
+                PRE_STEP[1:] = [cap]
             if STEP_HOOK[0] is not None:
                 STEP_HOOK[0](it, pc, sim, cams_g, bg, build, ps[-1])
         return np.array(ps), [p.detach().cpu().numpy().copy() for p in pc.parameters()]
 
     try:
-        native.lib.csplat_debug_flags(256)
+        native.lib.csplat_debug_flags(HIP_FLAGS[0])
         psnr_g, params_g = hip_run()
-        if STEP_HOOK[0] is None:
+        if STEP_HOOK[0] is None and HIP_FLAGS[0] & 256:
             psnr_g2, params_g2 = hip_run()
             np.testing.assert_array_equal(psnr_g, psnr_g2)          # the whole trajectory, twice: the same bits
             for a, b in zip(params_g, params_g2):
@@ -248,3 +256,68 @@ def _check(psnr_g, psnr_c):
     # 0.100 dB.  The bars leave that spread some room; the north_star's 0.05 dB is held on the final value.
     assert float(np.median(d)) <= 0.03 and float(np.percentile(d, 95)) <= 0.08, (float(np.median(d)), float(np.percentile(d, 95)))
     assert worst <= 0.2, worst
+
+
+CHECKPOINTS = (1, 50, 100, 200, 350, 500)
+
+
+@pytest.mark.parametrize("flags", [256, 0], ids=["reproducible_k7", "default_k7_atomics"])
+def test_teacher_forced_gradient_parity_along_the_trajectory(flags):
+    """an ensemble PSNR bar would not catch a small systematic gradient bias; this does.  Along the SAME
+    500-step HIP training run as above (P = 5,000, 3 x 208^2, the reference's learning rates; reference step:
+    scene_reconstruction/train_utils.py:240-321), at steps 1, 50, 100, 200, 350 and 500 the real train_step is captured
+    (tests/teacher.py) and replayed on the CPU FROM THE HIP STATE of that step -- simulator, mesh transform, losses as fp64 torch, the
+    rasterizer = the C oracle with its analytic backward:
+      * every parameter gradient (7 Gaussian groups + the simulator's tensors) <= 1e-4 of its group's scale against the fp64 oracle
+        driven with the step's own dL/dimage; threshold ties counted (<= 1e-3 of the Gaussians), bounded, and required to show in
+        the fp32 build of the oracle too;
+      * dL/dimage of the fused image loss <= 1e-4 against autograd over the fp64 torch formulation at the HIP image;
+      * images <= 1e-4, loss <= 1e-4 relative, PSNR <= 1e-3 dB, radii exact.
+    The end-to-end fp64 gradient (its own L1 signs) is printed with the number of flipped signs: near convergence the render matches
+    the target to 1e-6 at many pixels and sign(render - gt) is decided by rounding -- that, not a kernel, is where fp32 and fp64
+    trajectories part, and why the chain is teacher-forced at the image as well.  Both K7 modes."""
+    import contextlib
+    import teacher
+    from util import image_err
+    seen = []
+
+    def pre(it, pc, sim):
+        return teacher.capture(pc, sim) if it in CHECKPOINTS else None
+
+    def post(it, pc, sim, cams, bg, build, psnr):
+        if it not in CHECKPOINTS:
+            return
+        cap = PRE_STEP[1]
+        assert cap.params is not None and cap.image is not None and cap.dimage is not None
+        cams_c = [type(c)(**{k: (v.detach().cpu().double() if torch.is_tensor(v) else v) for k, v in vars(c).items()}) for c in cams]
+        build_c = lambda: build("cpu", torch.float64)  # noqa: E731
+        P = cap.params[0].shape[0]
+        o64 = teacher.oracle_step(build_c, cams_c, cap.params, dimage=cap.dimage, image_for_loss=cap.image)
+        o32 = teacher.oracle_step(build_c, cams_c, cap.params, dimage=cap.dimage, oracle_dtype=np.float32)
+        e2e = teacher.oracle_step(build_c, cams_c, cap.params)
+        img = cap.image.cpu().numpy()
+        for b in range(img.shape[0]):
+            assert image_err(img[b], o64["image"][b].numpy(), outlier_frac=1e-3) < 1e-4
+        d = cap.dimage.cpu().double().reshape(o64["dimage_ref"].shape)
+        e_loss = float((d - o64["dimage_ref"]).abs().max() / o64["dimage_ref"].abs().max())
+        gt = torch.stack([c.original_image for c in cams_c])
+        flips = int((torch.sign(cap.image.cpu().double() - gt) != torch.sign(e2e["image"] - gt)).sum())
+        e2e_rows = [(n, float((g.cpu().double() - r).abs().max() / (r.abs().max() + 1e-30)))
+                    for n, g, r in zip(cap.names, cap.grads, e2e["grads"]) if g is not None]
+        print(f"step {it:3d}: PSNR HIP {psnr:.4f} fp64-at-this-state {o64['psnr']:.4f} dB; image loss node {e_loss:.1e}; "
+              f"{flips} L1 signs differ; end-to-end worst {max(e2e_rows, key=lambda r: r[1])[0]} {max(e for _, e in e2e_rows):.1e}")
+        assert abs(psnr - o64["psnr"]) <= 1e-3, (it, psnr, o64["psnr"])
+        assert e_loss <= 1e-4, (it, e_loss)
+        res = teacher.compare_chain(cap, o64, o32, P, tol=1e-4, tie_frac=1e-3)
+        seen.append((it, res))
+
+    PRE_STEP[:] = [pre]
+    STEP_HOOK[0] = post
+    HIP_FLAGS[0] = flags
+    try:
+        _parity(False, max(CHECKPOINTS), hip_only=True)
+    finally:
+        PRE_STEP[:] = [None]
+        STEP_HOOK[0] = None
+        HIP_FLAGS[0] = 256
+    assert [it for it, _ in seen] == list(CHECKPOINTS)

@@ -901,3 +901,29 @@ def test_all_k7_forms_through_the_batched_entry_point(k7):
         tol = 1e-5
     for a, b in zip(g1, g0):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < tol
+
+
+def test_strict_dispatch_rejects_non_fp32_and_strided_inputs():
+    """the rasterizer wrapper used to cast / move / re-lay-out any input silently.  Upstream's binding rejects a
+    non-fp32 tensor (`.data<float>()`); under STRICT (every -m gpu test) so does the drop-in, and a strided per-Gaussian tensor is
+    reported as a "layout" fallback; with the fallback allowed the call computes the same image.  The camera matrices, which the
+    reference builds as transposed VIEWS (scene_reconstruction/cameras.py:63-67), pass as they do upstream."""
+    from csplat import native
+    from diff_gaussian_rasterization import GaussianRasterizer
+    case = make_case(P=800, W=64, H=48, seed=5)
+    rs = util.gpu_settings(case)
+    inp = util.gpu_inputs(case, requires_grad=False)
+    kw = dict(means3D=inp["means3D"], means2D=None, opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"], rotations=inp["rotations"])
+    ref = GaussianRasterizer(rs)(**kw)[0]
+    with pytest.raises(native.CsplatError, match="dtype"):
+        GaussianRasterizer(rs)(**dict(kw, means3D=inp["means3D"].double()))
+    wide = torch.zeros(800, 6, device="cuda")
+    wide[:, ::2] = inp["scales"]
+    with pytest.raises(native.CsplatError, match="layout"):
+        GaussianRasterizer(rs)(**dict(kw, scales=wide[:, ::2]))
+    with native.allow_fallbacks("dtype", "layout"):
+        assert torch.equal(GaussianRasterizer(rs)(**dict(kw, means3D=inp["means3D"].double(), scales=wide[:, ::2]))[0], ref)
+    # transposed-view camera matrices, as the reference's Camera builds them: no report, same image
+    rs_t = rs._replace(viewmatrix=rs.viewmatrix.t().contiguous().t(), projmatrix=rs.projmatrix.t().contiguous().t())
+    assert not rs_t.viewmatrix.is_contiguous()
+    assert torch.equal(GaussianRasterizer(rs_t)(**kw)[0], ref)

@@ -97,3 +97,22 @@ def test_regularization_composed_form_matches_reference_run(T):
     assert _rel(D.grad.numpy(), g[f"reg{T}.grad"]) < 1e-5
     if T == 3:
         assert float(regularization(D, gauss, opt, static=True, fused=False)) == float(g["reg3.static_loss"]) == 0.0
+
+
+def test_get_vertice_rotation_matches_reference_run():
+    """MeshGaussians.get_vertice_rotation against the reference's own MultiGaussianMesh.get_vertice_rotation run
+    (gaussian_mesh.py:190-201; tests/golden/make_golden.py: gen_vertice_rotation -- the quaternion arithmetic is the reference's text,
+    the vertex normals come from a stand-in with PyG's GenerateMeshNormals semantics: shim-derived), with the rest normals stored on
+    the mesh as the reference's loader leaves them AND recomputed from the rest pose (a mesh built from arrays)."""
+    from csplat.gaussians import MeshGaussians
+    g = golden("vertice_rotation.npz")
+    T = lambda k, dt=torch.float32: torch.tensor(g[k], dtype=dt)  # noqa: E731
+    pc = MeshGaussians(3)
+    pc.mesh = SimpleNamespace(pos=T("pos"), face=T("face", torch.long), edge_index=None, norm=T("rest_norm"))
+    q = pc.get_vertice_rotation(T("deformed"))
+    assert q.shape == (g["pos"].shape[0], 4)
+    np.testing.assert_allclose(q.numpy(), g["quat"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pc.vertex_normals(T("pos")).numpy(), g["rest_norm"], rtol=0, atol=1e-6)
+    pc.mesh = SimpleNamespace(pos=T("pos"), face=T("face", torch.long), edge_index=None)
+    np.testing.assert_allclose(pc.get_vertice_rotation(T("deformed")).numpy(), g["quat"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(q.numpy(), axis=1), 1.0, atol=1e-6)
