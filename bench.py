@@ -412,10 +412,19 @@ def main():
         out["cpu_baseline"] = cpu_baseline(wl.scene, wl.cams, P, W, H)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # (RCCL writes a line of its own -- "Librccl path : ..." -- to stdout when the process group goes down: the JSON line comes AFTER
+    #  it, so that it is the last line of the output whatever the library prints)
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        try:        # (the library prints through C stdio, which is block-buffered on a pipe: push its buffer out first)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

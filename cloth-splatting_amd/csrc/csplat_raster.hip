@@ -585,6 +585,7 @@ struct P2View {
     int *seg_offset, *slot_tile;
     float4 *ckpt;
     uint16_t *mask16;
+    unsigned long long *bbits;  // [slots][16 blocks][4]: which entries of a segment each block blended (K6 -> K7)
     float4 *recA, *recB;
     float2 *recC;
     const float *bg;
@@ -1161,6 +1162,27 @@ typedef BlockStreamT<4, RING> BlockStream;
 
 struct Trip { float4 a, b; float2 c; int pos; };   // the lane's survivor of a group (row r's), pos = list position or -1
 
+// ---- which entries a block BLENDED (round 4).  K5b's masks say which entries can REACH a 4x4 block (ellipse vs box); K6 finds out which
+// of them any pixel of the block actually blends -- alpha >= 1/255 at some pixel centre that is still open -- and K7 only ever does
+// arithmetic for those: a survivor that no pixel blended has factor 1 and addend 0 at all sixteen pixels (bit for bit: same exp, same
+// tests), so dropping it changes no bit of T, S or any gradient.  K6 marks a blended survivor with ONE BIT in a 256-bit LDS strip (the
+// segment's list positions); when its walk leaves a segment the strip is stored as four 64-bit words bbits[slot][block][0..3] -- the
+// TRANSPOSE of mask16 restricted to what was blended -- and K7's waves read their segment's survivor set with one scalar 32-byte load
+// instead of four vector loads of masks + ballots.  Segments a block's walk skipped (no survivor) get zero words; K7 never looks behind
+// the block's last blended entry (blk_hi).
+// (the strip is kept as 8 x 32 BITS, set with ds_or_b32: the flush is then one LDS read and one 4-byte store by eight lanes -- ballots
+// over a byte strip, four 64-bit selects and their addresses cost the survivor-column K6 22 VGPRs at the flush point, i.e. its fifth wave)
+__device__ __forceinline__ void bbits_mark(uint32_t *s_bits, int pos) { atomicOr(&s_bits[(pos & (SEG - 1)) >> 5], 1u << (pos & 31)); }
+__device__ __forceinline__ void bbits_flush(uint32_t *s_bits, unsigned long long *__restrict__ bbits, size_t slot, int blk, int lane) {
+    if (lane < 8) {
+        reinterpret_cast<uint32_t *>(bbits)[(slot * 16 + (size_t)blk) * 8 + lane] = s_bits[lane];
+        s_bits[lane] = 0u;
+    }
+}
+__device__ __forceinline__ void bbits_zero(unsigned long long *__restrict__ bbits, size_t slot, int blk, int lane) {
+    if (lane < 8) reinterpret_cast<uint32_t *>(bbits)[(slot * 16 + (size_t)blk) * 8 + lane] = 0u;
+}
+
 // ------------------------------------------------------------------------------------------- K6
 // grid: 16 single-wave workgroups per tile; the 16 blocks of a tile have the same blockIdx % 8 (same XCD, shared L2 lines)
 __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -1170,8 +1192,10 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
                                                    int *seg_offset, float4 *__restrict__ ckpt,
                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                    float *__restrict__ out_color, float *__restrict__ out_depth, int wg,
+                                                   unsigned long long *__restrict__ bbits,
                                                    const uint32_t *__restrict__ order = nullptr) {
     __shared__ int s_ring[RING];
+    __shared__ uint32_t s_hit[SEG / 32];
     // item (wg >> 7) * 8 + (wg & 7), block (wg >> 3) & 15: the 16 blocks of an item share blockIdx % 8 (one XCD).  order: a permutation
     // of the tiles, longest list first, the empty tiles (background only) last (k_tile_scan)
     const int item = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
@@ -1194,6 +1218,7 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
         BlockStream st;
         st.start(mask16 + rx, 0, n, blk, lane, s_ring);
         int seg_written = -1;
+        if (lane < SEG / 32) s_hit[lane] = 0u;
         auto fetch = [&](Trip &t, int k) -> bool {
             if (!st.group(k, r, t.pos)) return false;
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
@@ -1210,6 +1235,8 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
                     for (int s = seg_written + 1; s <= seg; s++)
                         ckpt[(size_t)(seg0 + s) * 256 + blk * 16 + l16] = make_float4(T, t0, t1, t2);
                 C0 = r == 0 ? t0 : 0.f; C1 = r == 0 ? t1 : 0.f; C2 = r == 0 ? t2 : 0.f;
+                if (seg_written >= 0) bbits_flush(s_hit, bbits, (size_t)(seg0 + seg_written), blk, lane);
+                for (int s = seg_written + 1; s < seg; s++) bbits_zero(bbits, (size_t)(seg0 + s), blk, lane);
                 seg_written = seg;
             }
             const float dx = t.a.x - fx, dy = t.a.y - fy;
@@ -1224,6 +1251,10 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
             const float wgt = blend ? al * Tr : 0.f;
             C0 += t.b.z * wgt; C1 += t.b.w * wgt; C2 += t.c.x * wgt; Dp += t.c.y * wgt;
             last = blend ? (uint32_t)(t.pos + 1) : last;
+            {   // the row's survivor was blended at one of its 16 pixels: its byte in the segment's strip
+                const unsigned long long bal = __ballot(blend);
+                if (l16 == 0 && ((bal >> (lane & 48)) & 0xFFFFull) != 0ull) bbits_mark(s_hit, t.pos);
+            }
             // the products only decrease: the pixel's T after the group is the last one still above the threshold
             T = P4 >= T_EPS ? P4 : (P3 >= T_EPS ? P3 : (P2 >= T_EPS ? P2 : (P1 >= T_EPS ? P1 : T)));
             done = done || !(P4 >= T_EPS);
@@ -1245,6 +1276,7 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
             if (__ballot(!done) == 0ull) break;
             vc = fetch(tc, k++);
         }
+        if (seg_written >= 0) bbits_flush(s_hit, bbits, (size_t)(seg0 + seg_written), blk, lane);
     }
     C0 = rows_sum(C0); C1 = rows_sum(C1); C2 = rows_sum(C2); Dp = rows_sum(Dp);
     {
@@ -1323,8 +1355,10 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
                                                      int *seg_offset, float4 *__restrict__ ckpt,
                                                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                      float *__restrict__ out_color, float *__restrict__ out_depth,
+                                                     unsigned long long *__restrict__ bbits,
                                                      const uint32_t *__restrict__ order = nullptr) {
     __shared__ int s_ring[RING16];
+    __shared__ uint32_t s_hit[SEG / 32];
     const int wg = blockIdx.x;
     const int item = ((wg >> 7) << 3) + (wg & 7), blk = (wg >> 3) & 15;
     if (item >= tiles) return;
@@ -1347,11 +1381,12 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
         last[j] = 0u;
         fx[j] = (float)(px0 + j);
     }
+    int seg0 = 0, seg_written = -1;
     if (n > 0 && __ballot(!(done[0] && done[1] && done[2] && done[3])) != 0ull) {
-        const int seg0 = seg_offset[tile];
+        seg0 = seg_offset[tile];
         BlockStreamT<16, RING16> st;
         st.start(mask16 + rx, 0, n, blk, lane, s_ring);
-        int seg_written = -1;
+        if (lane < SEG / 32) s_hit[lane] = 0u;
         auto fetch = [&](Trip &t, int k) -> bool {
             if (!st.group(k, sv, t.pos)) return false;
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
@@ -1372,6 +1407,8 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
                             ckpt[(size_t)(seg0 + s_) * 256 + blk * 16 + q * 4 + j] = make_float4(T[j], t0, t1, t2);
                     C0[j] = sv == 0 ? t0 : 0.f; C1[j] = sv == 0 ? t1 : 0.f; C2[j] = sv == 0 ? t2 : 0.f;
                 }
+                if (seg_written >= 0) bbits_flush(s_hit, bbits, (size_t)(seg0 + seg_written), blk, lane);
+                for (int s_ = seg_written + 1; s_ < seg; s_++) bbits_zero(bbits, (size_t)(seg0 + s_), blk, lane);
                 seg_written = seg;
             }
             const float dy = t.a.y - fy;
@@ -1386,12 +1423,13 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
             }
             row_scan4_mul(inc);                                          // the pixel's factor up to and including every survivor
             float P[4];
-            bool fin = false;
+            bool fin = false, blended = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float Tr = T[j] * dpp_mov<0x111, 0xF>(inc[j], 1.f);        // transmittance in front of the lane's survivor
                 P[j] = T[j] * inc[j];                                            // ... and behind it (what the T test looks at)
                 const bool blend = al[j] > 0.f && P[j] >= T_EPS;
+                blended = blended || blend;
                 const float wgt = blend ? al[j] * Tr : 0.f;
                 C0[j] += t.b.z * wgt; C1[j] += t.b.w * wgt; C2[j] += t.c.x * wgt; Dp[j] += t.c.y * wgt;
                 last[j] = blend ? (uint32_t)(t.pos + 1) : last[j];
@@ -1402,6 +1440,11 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
                 else P[j] = P[j] >= T_EPS ? P[j] : T[j];                         // candidates for the T it keeps: the last product above
                 done[j] = done[j] || ends;                                       //   the threshold (the products only decrease)
                 if (!ends) P[j] = 3.0e38f;
+            }
+            {   // survivor sv was blended at one of the block's 16 pixels (its four lanes, four pixels each): its byte in the strip
+                const unsigned long long bal = __ballot(blended);
+                const uint32_t any16 = (uint32_t)(bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFu;
+                if (lane < 16 && ((any16 >> lane) & 1u)) bbits_mark(s_hit, t.pos);
             }
             if (__ballot(fin) != 0ull) {     // rare (once per pixel): the final T of the pixels that ended = the smallest candidate of the row
                 float m[4] = {P[0], P[1], P[2], P[3]};
@@ -1461,6 +1504,8 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
             out_depth[pix] = dp;
         }
     }
+    // (the last segment's strip leaves here, where nothing else is live: flushed right behind the loop it cost the kernel 18 VGPRs)
+    if (seg_written >= 0) bbits_flush(s_hit, bbits, (size_t)(seg0 + seg_written), blk, lane);
 }
 template <bool ROWS>
 __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -1469,13 +1514,14 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
                                                        uint32_t null_rec, const float *__restrict__ bg,
                                                        int *seg_offset, float4 *__restrict__ ckpt,
                                                        float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                       float *__restrict__ out_color, float *__restrict__ out_depth) {
+                                                       float *__restrict__ out_color, float *__restrict__ out_depth,
+                                                       unsigned long long *__restrict__ bbits) {
     if (ROWS)
         composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
-                           out_depth, (int)blockIdx.x);
+                           out_depth, (int)blockIdx.x, bbits);
     else
         composite_fwd16_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
-                             out_depth);
+                             out_depth, bbits);
 }
 // the waves behind the first busy_grid of a K6 launch: the tiles of the launch-order list that got no waves of their own -- the empty
 // ones -- receive what K6 writes for a tile without a list (background colour, T = 1, no contributor, blk_hi = 0), 256 pixels a pass
@@ -1504,42 +1550,25 @@ __device__ __forceinline__ void paint_empty_tiles(int tiles, int W, int H, int g
         }
     }
 }
+// blockIdx.x < busy_grid: one wave per (item, block) of the first busy_grid / 16 entries of the launch-order list (the non-empty tiles,
+// longest list first: every one of them is among the entries, p2_live: info[2] <= Bcap); the waves behind paint what is left of the list,
+// the empty tiles.  (Round 3 measured the alternatives that left the library in round 4: 16 waves for every tile in tile order, and
+// 1024 n persistent waves per view walking the items -- DESIGN section 6.)
 template <bool ROWS>
-__global__ __launch_bounds__(64) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab, int lpt, int busy_grid) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab, int busy_grid) {
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
-    if (ROWS) {
-        const int total = ((tiles + 7) >> 3) * 128;
-        if (lpt) {
-            // blockIdx.x < busy_grid: one wave per (item, block) of the first busy_grid / 16 entries of the launch-order list -- every
-            // non-empty tile is among them (p2_live: info[2] <= Bcap); the waves behind paint what is left of the list, the empty tiles
-            const uint32_t *order = w.info + INFO_BUSY + tiles + 4;
-            if ((int)blockIdx.x < busy_grid) {
-                composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                                   w.n_contrib, w.out_color, w.out_depth, (int)blockIdx.x, order);
-                return;
-            }
-            paint_empty_tiles(tiles, W, H, w.cam.gx, order, busy_grid, w.bg, w.seg_offset, w.final_T, w.n_contrib, w.out_color, w.out_depth);
-            return;
-        }
-        // (tile order, for A/B: gridDim.x may be smaller than the number of (tile, block) items: a wave then walks items blockIdx.x,
-        // + gridDim.x, ... -- gridDim.x a multiple of 128: the item's XCD stays blockIdx.x % 8)
-        for (int wg = blockIdx.x; wg < total; wg += gridDim.x)
-            composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                               w.n_contrib, w.out_color, w.out_depth, wg, nullptr);
-    } else {
-        if (lpt) {      // (experiment) the column form on the non-empty-tiles-only grid
-            const uint32_t *order = w.info + INFO_BUSY + tiles + 4;
-            if ((int)blockIdx.x < busy_grid)
-                composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                                     w.n_contrib, w.out_color, w.out_depth, order);
-            else
-                paint_empty_tiles(tiles, W, H, w.cam.gx, order, busy_grid, w.bg, w.seg_offset, w.final_T, w.n_contrib, w.out_color, w.out_depth);
-            return;
-        }
-        composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                             w.n_contrib, w.out_color, w.out_depth);
+    const uint32_t *order = w.info + INFO_BUSY + tiles + 4;
+    if ((int)blockIdx.x >= busy_grid) {
+        paint_empty_tiles(tiles, W, H, w.cam.gx, order, busy_grid, w.bg, w.seg_offset, w.final_T, w.n_contrib, w.out_color, w.out_depth);
+        return;
     }
+    if (ROWS)
+        composite_fwd_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                           w.n_contrib, w.out_color, w.out_depth, (int)blockIdx.x, w.bbits, order);
+    else
+        composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
+                             w.n_contrib, w.out_color, w.out_depth, w.bbits, order);
 }
 
 // ------------------------------------------------------------------------------------------- K7
@@ -1590,25 +1619,29 @@ __device__ __forceinline__ void flush_segment(float *s_acc, int cnt, int w, int 
     }
 }
 
-// grid: one 4-wave workgroup per (segment slot, 8x8 quadrant); wave w = one 4x4 block of the quadrant.  DET: every wave
+// grid: one 4-wave workgroup per (segment slot, group of four live blocks); wave w = one 4x4 block.  DET: every wave
 // keeps its own LDS records and the flush stores the four-wave sums (fixed order) per (list entry, quadrant) for
 // k_det_reduce -- the bit-reproducible mode (csplat_debug_flags bit 8); default: one shared LDS record per entry,
 // flushed with float atomics.
+// Round 4: a wave's survivors are the entries of the segment its block BLENDED (bbits, written by K6 -- see bbits_flush), not the
+// entries that reach the block: the four ballot words arrive with one scalar load, the whole segment's survivor list is laid out in the
+// wave's LDS ring before the first group (no mask loads, no ingest inside the loop, a counted loop), and every group of four does
+// arithmetic that lands in a gradient.
+constexpr int RING7 = SEG;     // a segment's survivors of one block, padded to a multiple of four: at most SEG
 template <bool DET>
 __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
                                                    const uint32_t *__restrict__ ids_sorted,
-                                                   const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                   const unsigned long long *__restrict__ bbits, const float4 *__restrict__ recA,
                                                    const float4 *__restrict__ recB, const float2 *__restrict__ recC,
                                                    uint32_t null_rec, const int *__restrict__ seg_offset,
                                                    const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
                                                    float *__restrict__ acc, float *__restrict__ det,
-                                                   unsigned long long *stamp = nullptr, int barrier_flush = 0) {
+                                                   unsigned long long *stamp = nullptr) {
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
-    __shared__ int s_ring[4][RING];
+    __shared__ int s_ring[4][RING7];
     __shared__ uint32_t s_ids[DET ? 1 : SEG];   // the segment's Gaussian ids, for the flush
-    __shared__ int s_done;
     const int wg = blockIdx.x;
     // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
     unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 : nullptr;
@@ -1620,21 +1653,19 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         }
     };
     mark(0);
-    const int slot = ((wg >> 5) << 3) + (wg & 7), quad = (wg >> 3) & 3;     // the 4 quadrants of a slot share blockIdx % 8
+    const int slot = ((wg >> 5) << 3) + (wg & 7), quad = (wg >> 3) & 3;     // the 4 workgroups of a slot share blockIdx % 8
     if (slot >= seg_offset[tiles]) return;
     const int tile = slot_tile[slot];
     const int seg = slot - seg_offset[tile];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 4, l16 = lane & 15;
-    const int seg_lo_ = seg * SEG;
-    // (round 3) K6 leaves every block's largest n_contrib (blk_hi).  The blocks of the tile that still blend something in this segment
-    // -- blk_hi > seg_lo -- are PACKED four to a workgroup in index order: workgroup `quad` of the slot takes the live blocks 4 quad ..
-    // 4 quad + 3, whichever quadrant of the tile they lie in (they only share the segment's LDS records).  With the blocks of a spatial
-    // quadrant per workgroup, a quadrant with ONE block left kept four waves, a record array and a flush busy for it, and a wave whose
-    // block was done waited a quarter of its life at the final barrier (tools/k7_stamps.py).
+    const int seg_lo = seg * SEG;
+    // (round 3) K6 leaves every block's largest n_contrib (blk_hi).  The blocks of the tile that still blend something at or behind this
+    // segment -- blk_hi > seg_lo -- are PACKED four to a workgroup in index order: workgroup `quad` of the slot takes the live blocks
+    // 4 quad .. 4 quad + 3, whichever quadrant of the tile they lie in (they only share the segment's LDS records).
     const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
     uint32_t livemask = 0u;
 #pragma unroll
-    for (int b = 0; b < 16; b++) livemask |= ((int)blk_hi[b] > seg_lo_ ? 1u : 0u) << b;
+    for (int b = 0; b < 16; b++) livemask |= ((int)blk_hi[b] > seg_lo ? 1u : 0u) << b;
     const int n_live = __builtin_popcount(livemask);
     if (4 * quad >= n_live) return;                                      // (workgroup-uniform)
     const int kth = 4 * quad + __builtin_amdgcn_readfirstlane(w);
@@ -1642,8 +1673,10 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     for (int i = 0; i < kth && m_; i++) m_ &= m_ - 1u;
     const bool has_block = kth < n_live;
     const int blk = has_block ? __builtin_ctz(m_) : 0;
-    // (ordering the live blocks by how far into the segment they go, so that the four waves of a workgroup have about the same number
-    //  of entries to walk, was measured: the 16 x 16 rank computation costs more than the skew -- 330 against 280 us)
+    // the entries of this segment the block blended: four 64-bit words, one scalar load
+    const unsigned long long *bw = bbits + ((size_t)slot * 16 + (size_t)blk) * 4;
+    unsigned long long sw[4] = {0ull, 0ull, 0ull, 0ull};
+    if (has_block) { sw[0] = bw[0]; sw[1] = bw[1]; sw[2] = bw[2]; sw[3] = bw[3]; }
     const int px = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4 + (l16 & 3);
     const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
@@ -1652,20 +1685,15 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
-    const int seg_lo = seg * SEG, seg_hi = min(n, seg_lo + SEG);
-    // (the workgroups behind all of their blocks' pixels have ended above on scalar loads, and a wave knows where its block ends without
-    // a reduction over its pixels' n_contrib and two barriers)
-    const int wave_hi = has_block ? min(seg_hi, (int)blk_hi[blk]) : seg_lo;   // no pixel of the block blends an entry at or behind it
-    mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi) has returned
-    // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint, the first chunk of
-    // masks and (one per thread) the ids the flush will need are requested together, BEFORE the records are zeroed and the barrier
-    // (tools/k7_stamps.py: these were three dependent round trips, ~8 k cycles of a live wave's ~46 k)
-    const bool live = wave_hi > seg_lo;
+    const int seg_hi = min(n, seg_lo + SEG);
+    mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi, bbits) has returned
+    // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint and (one per
+    // thread) the ids the flush will need are requested together, BEFORE the records are zeroed and the barrier
+    const bool live = (sw[0] | sw[1] | sw[2] | sw[3]) != 0ull;
     const size_t HW = (size_t)H * W;
     int ncontrib = 0;
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, oc0 = 0.f, oc1 = 0.f, oc2 = 0.f;
     float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);
-    uint32_t m_first = 0u;
     if (live) {
         if (inside) {
             ncontrib = (int)n_contrib[pix];
@@ -1673,12 +1701,28 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             oc0 = out_color[pix]; oc1 = out_color[HW + pix]; oc2 = out_color[2 * HW + pix];
         }
         ck = ckpt[(size_t)slot * 256 + blk * 16 + l16];
-        m_first = seg_lo + lane < wave_hi ? (uint32_t)mask16[rx + seg_lo + lane] : 0u;
     }
     uint32_t my_id = 0u;
     if (!DET && seg_lo + (int)threadIdx.x < seg_hi) my_id = ids_sorted[rx + seg_lo + threadIdx.x];
+    // the wave's survivor list: list positions of the set bits, in order, padded with -1 to a multiple of four (wave-private LDS)
+    int *ring = s_ring[w];
+    int total = 0;
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const unsigned long long cur = sw[c];
+            if ((cur >> lane) & 1ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u));
+                ring[total + rank] = seg_lo + 64 * c + lane;
+            }
+            total += (int)__popcll(cur);
+        }
+        const int pad = (-total) & 3;
+        if (lane < pad) ring[total + lane] = -1;
+        total += pad;
+    }
+    const int ngroups = total >> 2;
     for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
-    if (threadIdx.x == 0) s_done = 0;
     if (!DET) s_ids[threadIdx.x] = my_id;
     __syncthreads();
     mark(2);
@@ -1697,13 +1741,10 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
         const bool red_active = !lb0 || l16 == 1;
         const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
-        BlockStream st;
-        st.start(mask16 + rx, seg_lo, wave_hi, blk, lane, s_ring[w], m_first);
-        auto fetch = [&](Trip &t, int k) -> bool {
-            if (!st.group(k, r, t.pos)) return false;
+        auto fetch = [&](Trip &t, int k) {
+            t.pos = ring[4 * k + r];
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
             t.a = recA[ri]; t.b = recB[ri]; t.c.x = reinterpret_cast<const float *>(recC)[2 * (size_t)ri];   // (c.y, the depth, is K6's)
-            return true;
         };
         auto process = [&](const Trip &t) {
             const float dx = t.a.x - fx, dy = t.a.y - fy;
@@ -1722,7 +1763,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             const float S1 = S + gw.v0, S2 = S1 + gw.v1, S3 = S2 + gw.v2, S4 = S3 + gw.v3;
             const float Sr = rowsel(r, S1, S2, S3, S4);
             T = P4; S = S4;
-            if (__ballot(act) == 0ull) return;   // wave-uniform
             const float dL_dalpha = act ? Tr * gdot - (OD - Sr) * __builtin_amdgcn_rcpf(F) : 0.f;
             const float dL_dG = t.b.y * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
@@ -1747,321 +1787,54 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             c0 = dpp_add<0xB1>(c0);
             l8 = dpp_add<0xB1>(l8);
             const float tot = lb0 ? l8 : c0;
-            // the row's survivor contributed to one of its 16 pixels?  (bits 16r .. 16r+15 of the ballot)
-            const unsigned long long bal = __ballot(act);
-            const bool row_any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;
-            if (red_active && row_any) {
+            // (every survivor of the list was blended at one of the block's pixels: the row always has something to add, padding aside)
+            if (red_active && t.pos >= 0) {
                 float *cell = my_acc + (t.pos - seg_lo) * 9 + red_t;
                 if (DET) *cell = tot;                  // one (entry, block) pair is visited exactly once
-                else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the quadrant meet here
+                else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the workgroup meet here
             }
         };
         // software pipeline, TWO groups in flight: the records of group k+2 are requested when group k has been composited.  (Three in
         // flight -- K6's depth -- cost 11 more registers: 67 VGPRs = 7 waves per SIMD; two = 57 VGPRs = 8 waves: 306 -> 294 us, same-box
         // A/B, three alternations.  Forcing the three-deep form under 64 registers spills 7 of them: 365 us.)
         Trip ta, tb;
-        bool va = fetch(ta, 0), vb = fetch(tb, 1);
-        int k = 2;
-        if (my_stamp && threadIdx.x == 0 && va) { asm volatile("" :: "v"(ta.a.x), "v"(ta.c.x)); }
-        mark(4);                                                        // masks -> ring -> the first group's records have arrived
-        while (va) {
+        fetch(ta, 0);
+        if (ngroups > 1) fetch(tb, 1);
+        if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(ta.a.x), "v"(ta.c.x)); }
+        mark(4);                                                        // ring -> the first group's records have arrived
+        for (int k = 0; k < ngroups; k += 2) {
             process(ta);
-            va = fetch(ta, k++);
-            if (!vb) break;
+            if (k + 2 < ngroups) fetch(ta, k + 2);
+            if (k + 1 >= ngroups) break;
             process(tb);
-            vb = fetch(tb, k++);
+            if (k + 3 < ngroups) fetch(tb, k + 3);
         }
     }
     mark(5);                                                            // this wave's groups are done
-    if (barrier_flush) {      // (default: all four waves meet at a barrier and flush a quarter each)
-        __syncthreads();
-        mark(6);
-        // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
-        flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det, DET ? nullptr : s_ids);
-    } else {
-        // csplat_debug_flags bit 16 (an experiment that did NOT pay, kept for A/B): no barrier at the end.  The blocks of a quadrant
-        // finish ~10 k cycles apart (tools/k7_stamps.py: a quarter of a live wave's life is this wait) -- here a wave that is done
-        // publishes its LDS adds, counts itself out and RETIRES; the wave that counts last flushes the whole segment (four passes of the
-        // same rounds).  Same-box A/B, three alternations: 318-321 us against 308-312 us with the barrier -- the lone flusher's four
-        // round trips outlast what the retired waves' slots are worth (a new workgroup needs four of them at once).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        int last = 0;
-        if (lane == 0) last = atomicAdd(&s_done, 1) == 3;
-        last = __builtin_amdgcn_readfirstlane(last);
-        if (!last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        mark(6);
-        for (int vw = 0; vw < 4; vw++)
-            flush_segment<DET>(s_acc, seg_hi - seg_lo, vw, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det, DET ? nullptr : s_ids);
-    }
+    __syncthreads();
+    mark(6);
+    // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request.  (Retiring the waves
+    // that are done and letting the last one flush -- no barrier -- was measured in round 3: 318-321 against 308-312 us.)
+    flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det, DET ? nullptr : s_ids);
     mark(7);
-    if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)(wave_hi > seg_lo ? wave_hi - seg_lo : 0); my_stamp[9] = 1ull; }
+    if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)total; my_stamp[9] = 1ull; }
 }
 
-// ------------------------------------------------------------------------------------------- K7, survivor-column form (round 3)
-// Same grid, same inputs and outputs as composite_bwd_body, different lane mapping.  What bounded the row form (four survivors
-// x 16 pixels per step) was not bandwidth but the price of its cross-lane work on gfx950's vector pipe (tools/valu_rate.hip: a
-// plain v_fma / v_mul / v_add occupies a SIMD for 2.3 cycles, every DPP operation, v_cmp, v_min/max and v_cndmask e64 for 4.2,
-// v_permlane*_swap, v_exp and v_rcp for 8.2): per group of four survivors two all-gathers (6 swaps), two row selects (6 DPP
-// moves) and a 26-DPP-add + 14-select butterfly -- ~250 of ~520 cycles.  Here a step takes SIXTEEN consecutive survivors of the
-// block: lane l holds survivor l & 15 and the four pixels of block row l >> 4, so that
-//   * the front-to-back transmittance and the S sums of a pixel run ALONG a DPP row: a 4-level row_shr scan (+ one shift and one
-//     row_newbcast) per pixel instead of all-gathers + selects per group of four;
-//   * a survivor's nine gradient sums are first summed over the lane's own four pixels (plain adds) and then over the four rows by
-//     the MATRIX pipe: v_mfma_f32_16x16x4_f32 contracts exactly over lane >> 4, D[i][j] += A[i][k] B[k][j] with A = the lane's
-//     partial and B[k][j] = (j == value index) puts the total of value j of survivor i into column j -- nine MFMAs (exact fp32, on a
-//     pipe this kernel otherwise leaves idle) replace the butterfly;
-//   * K7 never tests T against a threshold (activity = list position < n_contrib, alpha from the same expression as K6), so the
-//     scan's association of the products is free to differ from the forward's sequential one (gradients are held to 1e-4).
-// The block's survivors of the 256-entry segment are compacted into an LDS ring once (<= 256 positions), then walked in steps.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-// TILEWISE = false: one workgroup per (256-entry segment, quadrant), restarted from K6's checkpoint (the depth-split form: the
-//   bit-reproducible mode and the per-view path).
-// TILEWISE = true (the default path): one workgroup per (tile, quadrant) walks ALL segments up to the quadrant's largest
-//   n_contrib front to back, T and S simply carried -- no checkpoints, the pixel constants loaded once, two barriers per
-//   segment (double-buffered LDS records), ~17 k waves per step instead of ~300 k whose ~10 k cycles of life were mostly fixed
-//   cost (three dependent scalar loads, the pixel loads, record zeroing, two barriers, the flush).  A step covers 16 survivors,
-//   so the deepest (tile, block) chain of scene_1 -- ~3000 entries -> ~25 steps -- stays short of K6's own.
-template <bool DET, bool TILEWISE>
-__device__ __forceinline__ void composite_bwd16_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
-                                                     const uint32_t *__restrict__ ids_sorted,
-                                                     const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
-                                                     const float4 *__restrict__ recB, const float2 *__restrict__ recC,
-                                                     uint32_t null_rec, const int *__restrict__ seg_offset,
-                                                     const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
-                                                     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                                                     const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
-                                                     float *__restrict__ acc, float *__restrict__ det) {
-    static_assert(!(DET && TILEWISE), "the bit-reproducible mode uses the depth-split form");
-    __shared__ float s_acc[(DET ? 4 : (TILEWISE ? 2 : 1)) * SEG * 9];
-    __shared__ __attribute__((aligned(16))) int s_ring[4][SEG + 16];
-    const int wg = blockIdx.x;
-    const int quad = (wg >> 3) & 3;                                      // the 4 quadrants of a tile / slot share blockIdx % 8
-    int tile, seg_first, slot = 0;
-    if (TILEWISE) {
-        tile = ((wg >> 5) << 3) + (wg & 7);
-        if (tile >= tiles) return;
-        seg_first = 0;
-    } else {
-        slot = ((wg >> 5) << 3) + (wg & 7);
-        if (slot >= seg_offset[tiles]) return;
-        tile = slot_tile[slot];
-        seg_first = slot - seg_offset[tile];
-    }
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, sv = lane & 15, q = lane >> 4;
-    const int blk = (2 * (quad >> 1) + (w >> 1)) * 4 + 2 * (quad & 1) + (w & 1);
-    const int px0 = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4;
-    const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + q;
-    const float fy = (float)py;
-    const int2 range = ranges[tile];
-    const int n = range.y - range.x;
-    const uint32_t rx = (uint32_t)range.x;
-    // which blocks of the quadrant still blend anything: K6 left every block's largest n_contrib.  Workgroups (and, tile-wise, the
-    // segment loop) end on scalar loads instead of behind vector loads, a wave reduction and barriers
-    const uint32_t *blk_hi = reinterpret_cast<const uint32_t *>(seg_offset) + tiles + 1 + tile * 16;
-    const int qb = (2 * (quad >> 1)) * 4 + 2 * (quad & 1);               // first block of the quadrant: blocks qb, qb+1, qb+4, qb+5
-    const int quad_hi = min(n, (int)max(max(blk_hi[qb], blk_hi[qb + 1]), max(blk_hi[qb + 4], blk_hi[qb + 5])));
-    if (quad_hi <= seg_first * SEG) return;                              // (workgroup-uniform)
-    const int block_hi = min(n, (int)blk_hi[blk]);                       // no pixel of the block blends an entry at or behind it
-    const int seg_end = TILEWISE ? (quad_hi + SEG - 1) / SEG : seg_first + 1;
-    // every load that depends only on (tile, pixel) goes out together: the kernel is latency-bound
-    int nc[4], pix[4];
-    bool inside[4];
-    const size_t HW = (size_t)H * W;
-    float dp0[4], dp1[4], dp2[4], OD[4], T[4], S[4], fx[4];
-    uint32_t mk[SEG / 64];
-    auto load_masks = [&](int sg) {
-#pragma unroll
-        for (int c = 0; c < SEG / 64; c++) { const int e = sg * SEG + 64 * c + lane; mk[c] = e < block_hi ? (uint32_t)mask16[rx + e] : 0u; }
-    };
-    load_masks(seg_first);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        inside[j] = px0 + j < W && py < H && block_hi > seg_first * SEG;
-        pix[j] = py * W + px0 + j;
-        nc[j] = inside[j] ? (int)n_contrib[pix[j]] : 0;
-        dp0[j] = inside[j] ? dL_dpix[pix[j]] : 0.f;
-        dp1[j] = inside[j] ? dL_dpix[HW + pix[j]] : 0.f;
-        dp2[j] = inside[j] ? dL_dpix[2 * HW + pix[j]] : 0.f;
-        OD[j] = inside[j] ? out_color[pix[j]] * dp0[j] + out_color[HW + pix[j]] * dp1[j] + out_color[2 * HW + pix[j]] * dp2[j] : 0.f;
-        T[j] = 1.f; S[j] = 0.f;
-        if (!TILEWISE) {
-            const float4 ck = inside[j] ? ckpt[(size_t)slot * 256 + blk * 16 + q * 4 + j] : make_float4(1.f, 0.f, 0.f, 0.f);
-            const bool live = nc[j] > seg_first * SEG;
-            T[j] = live ? ck.x : 1.f;
-            S[j] = live ? ck.y * dp0[j] + ck.z * dp1[j] + ck.w * dp2[j] : 0.f;
-        }
-        fx[j] = (float)(px0 + j);
-    }
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-    // B operands of the reducing MFMAs: column sv of the result takes value index sv
-    float sel[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) sel[t] = sv == t ? 1.f : 0.f;
-    int *ring = s_ring[w];
-    if (TILEWISE) {   // both record buffers start clean; afterwards the flush leaves them clean
-        for (int t = threadIdx.x; t < 2 * SEG * 9; t += 256) s_acc[t] = 0.f;
-        __syncthreads();
-    }
-    for (int sg = seg_first; sg < seg_end; sg++) {
-        const int seg_lo = sg * SEG, seg_hi = min(n, seg_lo + SEG);
-        const int wave_hi = min(seg_hi, block_hi);
-        float *buf = s_acc + ((TILEWISE && (sg & 1)) ? SEG * 9 : 0);     // tile-wise: the records of consecutive segments alternate
-        if (!TILEWISE) {
-            for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) buf[t] = 0.f;
-            __syncthreads();
-        }
-        float *my_acc = buf + (DET ? w * SEG * 9 : 0);
-        int steps = 0;
-        Trip cur, nxt;
-        auto fetch = [&](Trip &t, int s_) {
-            t.pos = ring[16 * s_ + sv];
-            const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
-            t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
-        };
-        if (wave_hi > seg_lo) {
-            // ---- the block's survivors of [seg_lo, wave_hi): list positions, in list order
-            int tail = 0;
-#pragma unroll
-            for (int c = 0; c < SEG / 64; c++) {
-                const int e = seg_lo + 64 * c + lane;
-                const bool hit = e < wave_hi && ((mk[c] >> blk) & 1u);
-                const unsigned long long cur = __ballot(hit);
-                if (hit) ring[tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u))] = e;
-                tail += (int)__popcll(cur);
-            }
-            if (lane < 16) ring[tail + lane] = -1;                       // the last step's padding
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            steps = (tail + 15) >> 4;
-            if (steps > 0) fetch(cur, 0);
-            if (steps > 1) fetch(nxt, 1);
-        }
-        if (TILEWISE) {
-            if (sg + 1 < seg_end) load_masks(sg + 1);                    // the next segment's masks travel under this one's steps
-            // the PREVIOUS segment's records leave now, behind this segment's loads in the memory queue (vmcnt counts in order: a
-            // load issued after the atomics could only be waited for together with them)
-            if (sg > seg_first)
-                flush_segment<false, true>(s_acc + (((sg - 1) & 1) ? SEG * 9 : 0), SEG, w, lane, quad, rx + (uint32_t)(seg_lo - SEG), ids_sorted, acc, det);
-        }
-        if (wave_hi > seg_lo) {
-            for (int s_ = 0; s_ < steps; s_++) {
-                const Trip t = cur;
-                cur = nxt;
-                if (s_ + 2 < steps) fetch(nxt, s_ + 2);                  // the records of two steps travel under this step's arithmetic
-                const float dy = t.a.y - fy;
-                float G[4], al[4], dxs[4];
-                bool act[4];
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float dx = t.a.x - fx[j];
-                    const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
-                    G[j] = __expf(power);
-                    const float a = fminf(0.99f, t.b.y * G[j]);
-                    act[j] = t.pos < nc[j] && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
-                    al[j] = act[j] ? a : 0.f;
-                    dxs[j] = dx;
-                    any = any || act[j];
-                }
-                if (__ballot(any) == 0ull) continue;                     // nobody blends anything of this step: T, S unchanged
-                // (phase by phase over the lane's four pixels: four independent chains for the scans, the exp and the rcp)
-                float inc[4], Tr[4], gdot[4], dch[4], sc[4], Sr[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) inc[j] = 1.f - al[j];
-                float F[4] = {inc[0], inc[1], inc[2], inc[3]};
-                row_scan4_mul(inc);                                      // transmittance factor up to and including every survivor
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    Tr[j] = T[j] * dpp_mov<0x111, 0xF>(inc[j], 1.f);     // in FRONT of it: row_shr:1, lane 0 of the row keeps 1
-                    T[j] *= dpp_mov<0x15F, 0xF>(inc[j], inc[j]);         // row_newbcast:15: behind the step
-                    gdot[j] = t.b.z * dp0[j] + t.b.w * dp1[j] + t.c.x * dp2[j];
-                    dch[j] = al[j] * Tr[j];
-                    sc[j] = gdot[j] * dch[j];
-                }
-                row_scan4_add(sc);
-                float v[9];
-#pragma unroll
-                for (int t9 = 0; t9 < 9; t9++) v[t9] = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    Sr[j] = S[j] + sc[j];
-                    S[j] += dpp_mov<0x15F, 0xF>(sc[j], sc[j]);
-                    const float dL_dalpha = act[j] ? Tr[j] * gdot[j] - (OD[j] - Sr[j]) * __builtin_amdgcn_rcpf(F[j]) : 0.f;
-                    const float dL_dG = t.b.y * dL_dalpha;
-                    const float dx = dxs[j];
-                    const float gdx = G[j] * dx, gdy = G[j] * dy;
-                    const float dG_ddelx = -gdx * t.a.z - gdy * t.a.w;
-                    const float dG_ddely = -gdy * t.b.x - gdx * t.a.w;
-                    v[0] += dL_dG * dG_ddelx * ddelx_dx;
-                    v[1] += dL_dG * dG_ddely * ddely_dy;
-                    v[2] += -0.5f * gdx * dx * dL_dG;
-                    v[3] += -0.5f * gdx * dy * dL_dG;
-                    v[4] += -0.5f * gdy * dy * dL_dG;
-                    v[5] += G[j] * dL_dalpha;
-                    v[6] += dch[j] * dp0[j]; v[7] += dch[j] * dp1[j]; v[8] += dch[j] * dp2[j];
-                }
-                // sums over the four rows on the matrix pipe: lane (q, c) receives, in register r, value c of survivor 4q + r
-                f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
-                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], sel[0], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], sel[1], d1, 0, 0, 0);
-                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], sel[2], d2, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[3], sel[3], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4], sel[4], d1, 0, 0, 0);
-                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[5], sel[5], d2, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[6], sel[6], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[7], sel[7], d1, 0, 0, 0);
-                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[8], sel[8], d2, 0, 0, 0);
-                const int4 pr = *reinterpret_cast<const int4 *>(&ring[16 * s_ + 4 * q]);
-                if (sv < 9) {
-                    const int prr[4] = {pr.x, pr.y, pr.z, pr.w};
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float tot = d0[r] + d1[r] + d2[r];      // (column sv holds ONE value index: two of the three are zero)
-                        if (prr[r] >= 0 && tot != 0.f) {
-                            float *cell = my_acc + (prr[r] - seg_lo) * 9 + sv;
-                            if (DET) *cell = tot;                  // one (entry, block) pair is visited exactly once
-                            else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the quadrant meet here
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();     // tile-wise: the segment's sums are complete AND the buffer of the segment before is clean again
-        // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request
-        if (!TILEWISE) flush_segment<DET>(buf, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
-        else if (sg + 1 == seg_end) flush_segment<false>(buf, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det);
-    }
-}
-
-template <bool DET>
-__global__ __launch_bounds__(256) void k_composite_bwd(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
-                                                        const uint32_t *__restrict__ ids_sorted,
-                                                        const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
-                                                        const float4 *__restrict__ recB, const float2 *__restrict__ recC,
-                                                        uint32_t null_rec, const int *__restrict__ seg_offset,
-                                                        const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
-                                                        const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                                                        const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
-                                                        float *__restrict__ acc, float *__restrict__ det) {
-    composite_bwd16_body<DET, false>(tiles, W, H, gx, ranges, ids_sorted, mask16, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
-                                     n_contrib, out_color, dL_dpix, acc, det);
-}
-// (the row form: four survivors x 16 pixels per step -- the default; k_composite_bwd above is the survivor-column form, behind
-// csplat_debug_flags bit 13: 29 % fewer VALU instructions but 112 VGPRs = 4 waves per SIMD against 7, and slower)
+// (four survivors x 16 pixels per step.  The survivor-column forms of round 3 -- 16 survivors per step, DPP row scans, MFMA reduction:
+// 29 % fewer VALU instructions but 112 VGPRs = 4 waves per SIMD, and slower -- left the library in round 4; they are in the history at
+// commit 809fd4b and described in DESIGN section 6)
 template <bool DET>
 __global__ __launch_bounds__(256) void k_composite_bwd_rows(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
                                                              const uint32_t *__restrict__ ids_sorted,
-                                                             const uint16_t *__restrict__ mask16, const float4 *__restrict__ recA,
+                                                             const unsigned long long *__restrict__ bbits, const float4 *__restrict__ recA,
                                                              const float4 *__restrict__ recB, const float2 *__restrict__ recC,
                                                              uint32_t null_rec, const int *__restrict__ seg_offset,
                                                              const int *__restrict__ slot_tile, const float4 *__restrict__ ckpt,
                                                              const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                              const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
-                                                             float *__restrict__ acc, float *__restrict__ det, int barrier_flush) {
-    composite_bwd_body<DET>(tiles, W, H, gx, ranges, ids_sorted, mask16, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
-                            n_contrib, out_color, dL_dpix, acc, det, nullptr, barrier_flush);
+                                                             float *__restrict__ acc, float *__restrict__ det) {
+    composite_bwd_body<DET>(tiles, W, H, gx, ranges, ids_sorted, bbits, recA, recB, recC, null_rec, seg_offset, slot_tile, ckpt, final_T,
+                            n_contrib, out_color, dL_dpix, acc, det, nullptr);
 }
 
 // K7 for ALL views of a step in one launch (blockIdx.y = view), preceded by one launch that clears every view's records
@@ -2069,7 +1842,7 @@ constexpr int B2_MAX_VIEWS = 8;
 struct B2View {
     const int2 *ranges;
     const uint32_t *ids_sorted;
-    const uint16_t *mask16;
+    const unsigned long long *bbits;
     const float4 *recA, *recB;
     const float2 *recC;
     const int *seg_offset, *slot_tile;
@@ -2080,21 +1853,11 @@ struct B2View {
     float *acc;
     uint32_t R;
 };
-struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; int barrier_flush; };
-__global__ __launch_bounds__(256) void k_composite_bwd_views(int tiles, int W, int H, int gx, B2Table tab) {
-    const B2View &w = tab.v[blockIdx.y];
-    composite_bwd16_body<false, true>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
-                                      w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
-}
-__global__ __launch_bounds__(256) void k_composite_bwd_seg_views(int tiles, int W, int H, int gx, B2Table tab) {
-    const B2View &w = tab.v[blockIdx.y];
-    composite_bwd16_body<false, false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
-                                       w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr);
-}
+struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; };
 __global__ __launch_bounds__(256, 8) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
     const B2View &w = tab.v[blockIdx.y];
-    composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.mask16, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
-                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp, tab.barrier_flush);
+    composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.bbits, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
+                              w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp);
 }
 __global__ __launch_bounds__(256) void k_zero_acc_views(int64_t n4, B2Table tab) {
     float4 *p = reinterpret_cast<float4 *>(tab.v[blockIdx.y].acc);
@@ -2726,7 +2489,8 @@ size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 
 //          4x4 pixel block, written by K6: K7 drops the (segment, quadrant) workgroups behind it on ONE scalar load) | 3 slot_tile i32[slots]
 //          | 4 ckpt float4[slots][16 blocks][16 pixels]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
 //          | 5 mask16 u16[R+1] | 6 recA float4[R+1] | 7 recB float4[R+1] | 8 recC float2[R+1]   (entry R = the null record)
-constexpr int B_NFIELDS = 9;
+//          | 9 bbits u64[slots][16 blocks][4]: per segment and block, which of the segment's 256 entries the block BLENDED (K6 -> K7)
+constexpr int B_NFIELDS = 10;
 size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
     const size_t slots = (size_t)max_slots(R, tiles);
@@ -2739,7 +2503,8 @@ size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     off[6] = off[5] + align256((n + 1) * 2);
     off[7] = off[6] + align256((n + 1) * 16);
     off[8] = off[7] + align256((n + 1) * 16);
-    return off[8] + align256((n + 1) * 8);
+    off[9] = off[8] + align256((n + 1) * 8);
+    return off[9] + align256(slots * 16 * 4 * 8);
 }
 // temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
 size_t temp_offsets(int64_t R, size_t *off) {
@@ -2793,10 +2558,9 @@ bool mail_init() {
 // csplat_debug_flags: bit 0 no culling; bit 1 force the global radix sort; bit 2 no mailbox; bit 4 culling radius x4;
 // bit 5 circle test only; bit 7 per-view K8 launches; bit 8 bit-reproducible backward (ordered sums instead of float atomics);
 // bit 9 per-view launches on per-view streams; bit 10 no speculative second phase; bit 11 tile sort = the LSD radix sort only;
-// bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook); bit 13 K7 in the survivor-column form
-// (16 survivors per step, DPP row scans, MFMA reduction), depth-split; bit 14 the same form, one workgroup per (tile, quadrant);
-// bit 15 K6 in the ROW form (four survivors per step; default: the survivor-column form, 16 per step, DPP row scans); bit 16 K7 (row
-// form) retires the waves that are done and lets the last one flush, instead of the barrier + four-wave flush
+// bit 12 tile sort: a tile with any multi-key bucket takes the radix fallback (test hook);
+// bit 15 K6 in the ROW form (four survivors per step; default: the survivor-column form, 16 per step, DPP row scans).
+// (bits 13, 14, 16-21 selected the shelved kernel forms of round 3; they left the library in round 4 and are ignored)
 unsigned g_debug_flags = 0;
 unsigned long long *g_stamp_buf = nullptr;     // csplat_debug_stamps: 12 u64 per K7 workgroup (rows form, batched launch)
 size_t g_stamp_words = 0;
@@ -3151,6 +2915,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
             k.slot_tile = (int *)((char *)bbase + boff[3]);
             k.ckpt = (float4 *)((char *)bbase + boff[4]);
             k.mask16 = (uint16_t *)((char *)bbase + boff[5]);
+            k.bbits = (unsigned long long *)((char *)bbase + boff[9]);
             k.recA = (float4 *)((char *)bbase + boff[6]); k.recB = (float4 *)((char *)bbase + boff[7]);
             k.recC = (float2 *)((char *)bbase + boff[8]);
             k.bg = t.bg; k.final_T = t.final_T; k.n_contrib = t.n_contrib; k.out_color = v[i].out_color; k.out_depth = v[i].out_depth;
@@ -3171,7 +2936,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         {
             ProfScope ps(PROF_K5, join);
             const int exact = (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1, nbm = cdiv((int64_t)maxR + 1, 256);
-            if ((V == 1 || V == 2 || V == 4 || V == 8) && !(g_debug_flags & (1u << 20)))     // (bit 20: blockIdx.y = view, for A/B)
+            if (V == 1 || V == 2 || V == 4 || V == 8)         // one view per XCD (see k_block_masks_views)
                 k_block_masks_views<<<dim3((unsigned)(((int64_t)nbm * V + 7) / 8 * 8)), 256, 0, join>>>(tab, exact, V);
             else
                 k_block_masks_views<<<dim3(nbm, V), 256, 0, join>>>(tab, exact, 0);
@@ -3186,25 +2951,11 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
             // form by default (sixteen survivors a step: a quarter of the steps, each longer; 96 VGPRs, which no longer matters with two
             // waves per slot to place): 158 -> 137 us for four views, step 0.685 -> 0.665 ms (same box, three alternations).  Bit 15 of
             // csplat_debug_flags selects the row form.
-            if (!(g_debug_flags & 32768u)) {
-                const int total = cdiv(tiles, 8) * 128, bg_ = cdiv((int)Bcap, 8) * 128, busy_grid = bg_ < total ? bg_ : total;
-                if (g_debug_flags & (1u << 21))     // (bit 21: 16 waves for EVERY tile, in tile order, for A/B)
-                    k_composite_fwd_views<false><<<dim3(total, V), 64, 0, join>>>(tiles, W, H, tab, 0, total);
-                else
-                    k_composite_fwd_views<false><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, 1, busy_grid);
-            }
-            else {
-                // (an experiment that did NOT pay, csplat_debug_flags bits 17-19 = n: 1024 * n waves per view walk the items instead of
-                //  one wave per item -- same-box A/B, step of four views: 0.725 ms with one wave per item, 0.81 / 0.767 / 0.755 / 0.73 ms
-                //  for n = 1 / 2 / 4 / 7: K6 is not bound by wave dispatch, and half the waves resident cost only 1.5 x)
-                const int total = cdiv(tiles, 8) * 128, cap = (int)((g_debug_flags >> 17) & 7u) * 1024;
-                if ((g_debug_flags & (1u << 21)) || cap > 0)    // (bit 21: one wave per (tile, block) of EVERY tile, in tile order, for A/B)
-                    k_composite_fwd_views<true><<<dim3(cap > 0 && cap < total ? cap : total, V), 64, 0, join>>>(tiles, W, H, tab, 0, total);
-                else {
-                    const int bg_ = cdiv((int)Bcap, 8) * 128, busy_grid = bg_ < total ? bg_ : total;
-                    k_composite_fwd_views<true><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, 1, busy_grid);
-                }
-            }
+            const int total = cdiv(tiles, 8) * 128, bg_ = cdiv((int)Bcap, 8) * 128, busy_grid = bg_ < total ? bg_ : total;
+            if (!(g_debug_flags & 32768u))
+                k_composite_fwd_views<false><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, busy_grid);
+            else
+                k_composite_fwd_views<true><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, busy_grid);
             LAUNCH_CHECK();
         }
         return 0;
@@ -3330,6 +3081,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     uint16_t *mask16 = (uint16_t *)((char *)bbase + boff[5]);
     float4 *recA = (float4 *)((char *)bbase + boff[6]), *recB = (float4 *)((char *)bbase + boff[7]);
     float2 *recC = (float2 *)((char *)bbase + boff[8]);
+    unsigned long long *bbits = (unsigned long long *)((char *)bbase + boff[9]);
     if (R > 0) {
         void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
         CSPLAT_REQUIRE(tbase, "allocator returned NULL");
@@ -3389,10 +3141,10 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
         ProfScope ps(PROF_K6, s);
         if (g_debug_flags & 32768u)       // (bit 15: the row form, four survivors a step; default: the survivor-column form, 74 -> 67 us alone)
             k_composite_fwd<true><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
-                                                                      final_T, n_contrib, out_color, out_depth);
+                                                                      final_T, n_contrib, out_color, out_depth, bbits);
         else
             k_composite_fwd<false><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
-                                                                       final_T, n_contrib, out_color, out_depth);
+                                                                       final_T, n_contrib, out_color, out_depth, bbits);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
@@ -3440,7 +3192,7 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with
     const int *slot_tile = (const int *)((const char *)binning + boff[3]);
     const float4 *ckpt = (const float4 *)((const char *)binning + boff[4]);
     const uint64_t *keys_sorted = (const uint64_t *)((const char *)binning + boff[0]);
-    const uint16_t *mask16 = (const uint16_t *)((const char *)binning + boff[5]);
+    const unsigned long long *bbits = (const unsigned long long *)((const char *)binning + boff[9]);
     const float4 *recA = (const float4 *)((const char *)binning + boff[6]), *recB = (const float4 *)((const char *)binning + boff[7]);
     const float2 *recC = (const float2 *)((const char *)binning + boff[8]);
     float *acc = (float *)scratch;
@@ -3453,21 +3205,12 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with
         ProfScope ps(PROF_K7, s);
         if (R > 0) {
             const unsigned grid = (unsigned)cdiv(max_slots(R, tiles), 8) * 32u;
-            const bool rows = (g_debug_flags & (8192u | 16384u)) == 0;     // default: the row form; bits 13 / 14: the survivor-column form
-            if (det_mode && rows)
-                k_composite_bwd_rows<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
-                                                                seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det,
-                                                                (g_debug_flags & 65536u) ? 0 : 1);
-            else if (det_mode)
-                k_composite_bwd<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
-                                                           seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
-            else if (rows)
-                k_composite_bwd_rows<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
-                                                                 seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det,
-                                                                 (g_debug_flags & 65536u) ? 0 : 1);
+            if (det_mode)
+                k_composite_bwd_rows<true><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, bbits, recA, recB, recC, (uint32_t)R,
+                                                                seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
             else
-                k_composite_bwd<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, mask16, recA, recB, recC, (uint32_t)R,
-                                                            seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
+                k_composite_bwd_rows<false><<<grid, 256, 0, s>>>(tiles, W, H, cam.gx, ranges, ids_sorted, bbits, recA, recB, recC, (uint32_t)R,
+                                                                 seg_offset, slot_tile, ckpt, final_T, n_contrib, out_color, dL_dpix, acc, det);
             LAUNCH_CHECK();
         }
         if (det_mode) {   // fixed-order sum of every Gaussian's instance records (writes all of acc)
@@ -3750,7 +3493,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 B2View &k = bt.v[i];
                 k.ranges = (const int2 *)(im + ioff[0]); k.n_contrib = (const uint32_t *)(im + ioff[1]); k.final_T = (const float *)(im + ioff[2]);
                 k.ids_sorted = (const uint32_t *)(b + boff[1]); k.seg_offset = (const int *)(b + boff[2]); k.slot_tile = (const int *)(b + boff[3]);
-                k.ckpt = (const float4 *)(b + boff[4]); k.mask16 = (const uint16_t *)(b + boff[5]);
+                k.ckpt = (const float4 *)(b + boff[4]); k.bbits = (const unsigned long long *)(b + boff[9]);
                 k.recA = (const float4 *)(b + boff[6]); k.recB = (const float4 *)(b + boff[7]); k.recC = (const float2 *)(b + boff[8]);
                 k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)Rl;
                 // segments of the view: <= R / SEG + (non-empty tiles) + 1 with the EXACT counts the forward read -- the layout's bound
@@ -3761,18 +3504,12 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             {   // (measurement hook, off unless csplat_debug_stamps handed over a buffer large enough for this launch)
                 const size_t need = (size_t)V * ((size_t)cdiv(slots, 8) * 32u) * 12;
                 bt.stamp = (g_stamp_buf && g_stamp_words >= need) ? g_stamp_buf : nullptr;
-                bt.barrier_flush = (g_debug_flags & 65536u) ? 0 : 1;
             }
             ProfScope ps(PROF_K7, join);
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
             k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
             LAUNCH_CHECK();
-            if (g_debug_flags & 16384u)       // survivor-column form, one workgroup per (tile, quadrant) walking every segment
-                k_composite_bwd_views<<<dim3((unsigned)cdiv(tiles, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
-            else if (g_debug_flags & 8192u)   // survivor-column form, one workgroup per (segment, quadrant)
-                k_composite_bwd_seg_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
-            else                              // row form (default)
-                k_composite_bwd_rows_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            k_composite_bwd_rows_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
             LAUNCH_CHECK();
         }
         for (int i = 0; i < V && !(batch_k7 && one_k8); i++) {

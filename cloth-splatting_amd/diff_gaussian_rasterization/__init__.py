@@ -181,6 +181,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 
 _side_streams = {}
+# how the batched forward's second phase went, per call (bench.py's `speculation` field, tests): "hit" = launched on the previous call's
+# capacities before the counts were read and the counts fitted; "miss" = they did not fit and the phase was repeated with exact sizes;
+# "wait" = no history for this (image size, P) yet (or speculation off): the counts were read first
+SPEC_STATS = {"hit": 0, "miss": 0, "wait": 0}
 
 
 def _view_streams(dev, n, main):
@@ -292,6 +296,8 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             # the GPU is busy with K1..K6 of the views right now: prepare the backward call in its shadow
             ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
+        if not pending.value:
+            SPEC_STATS["wait"] += 1
         if pending.value:
             relaunched = C.c_int(0)
             with _n.on_device(dev):
@@ -300,6 +306,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             for i, v in enumerate(views):
                 v.num_rendered = int(arr[i].num_rendered)
             pending.value = 0
+            SPEC_STATS["miss" if relaunched.value else "hit"] += 1
             if relaunched.value:     # the speculation missed: new binning chunks, new layout -> the plan is rebuilt (rare)
                 for i, v in enumerate(views):
                     v.layout_rendered = int(arr[i].layout_rendered)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CSPLAT_ABI_VERSION 1
+#define CSPLAT_ABI_VERSION 2   /* round 4: csplat_view.busy_tiles, csplat_rows_dot_fwd's extra argument, the binning chunk's layout */
 
 /* scratch chunks requested through the allocator callback */
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
@@ -57,10 +57,12 @@ int csplat_abi_version(void);
  * bit 9: per-view launches on per-view streams instead of one launch per stage for all views of a step;
  * bit 10: csplat_forward_views always waits for a call's counts before launching its second phase (no speculative launch with
  * the previous call's counts as capacities);
- * bits 11-22: A/B switches of kernel forms and experiments (csplat_raster.hip): 11 tile sort by LSD radix only,
- *        12 forced fallback of the bucket sort, 13 / 14 K7 in its survivor-column forms, 15 K6 in the row form (default: survivor
- *        columns), 16 K7 retire-waves flush, 17-19 K6 (row form) items per wave, 20 block masks with blockIdx.y = view, 21 K6 with 16
- *        waves for every tile in tile order (default: the non-empty tiles only, longest list first). */
+ * bit 11: tile sort by LSD radix only; bit 12: forced radix fallback of the bucket sort (both: test hooks of the sort's two paths);
+ * bit 15: K6 in the row form (four survivors per step; default: sixteen per step) -- kept because its transmittance products run in list
+ *         order, which the culling-exactness test holds bit for bit.
+ * Bits 13, 14, 16-21 selected the shelved kernel forms of round 3 (K7 survivor columns, retire-waves flush, K6 items per wave / tile order,
+ * block masks by blockIdx.y); those forms left the library in round 4 (history: commit 809fd4b) and the bits are
+ * ignored.  The word is process-global and meant to be set between calls, not concurrently with them. */
 int csplat_debug_flags(unsigned flags);
 /* measurement hook (not part of the operator interface): a device buffer the batched compositing backward fills with s_memtime stamps,
  * 12 uint64 per workgroup in launch order [view][workgroup] (tools/k7_stamps.py); NULL / 0 switches it off */

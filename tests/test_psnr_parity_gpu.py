@@ -268,10 +268,15 @@ def test_teacher_forced_gradient_parity_along_the_trajectory(flags):
     scene_reconstruction/train_utils.py:240-321), at steps 1, 50, 100, 200, 350 and 500 the real train_step is captured
     (tests/teacher.py) and replayed on the CPU FROM THE HIP STATE of that step -- simulator, mesh transform, losses as fp64 torch, the
     rasterizer = the C oracle with its analytic backward:
-      * every parameter gradient (7 Gaussian groups + the simulator's tensors) <= 1e-4 of its group's scale against the fp64 oracle
-        driven with the step's own dL/dimage; threshold ties counted (<= 1e-3 of the Gaussians), bounded, and required to show in
-        the fp32 build of the oracle too;
-      * dL/dimage of the fused image loss <= 1e-4 against autograd over the fp64 torch formulation at the HIP image;
+      * the rasterizer node on the step's OWN inputs and dL/dimage: image, and the gradient of every rasterizer input (means3D /
+        rotations per camera, opacity, scales, SH) <= 1e-4 against the fp64 oracle; threshold ties counted (<= 1e-3 of the Gaussians),
+        bounded, and required to show in the fp32 build of the oracle too;
+      * every parameter gradient (7 Gaussian groups + the simulator's tensors) <= 1e-4 against fp64 torch over the nodes in front of the
+        rasterizer (simulator, regularisers, mesh transform, activations) driven with the step's own rasterizer-input gradients;
+      * the replay from the parameters through the whole chain: per-Gaussian deviations counted and bounded;
+      * dL/dimage of the fused image loss against autograd over the fp64 torch formulation at the HIP image: <= 1e-4, or -- near
+        convergence, where the SSIM variances cancel -- no further off than 3 x the reference's own fp32 torch formulation is;
+      * simulator groups (sums over all Gaussians that cancel as training converges): <= 1e-4 or 4 x the fp32 ORACLE's own distance;
       * images <= 1e-4, loss <= 1e-4 relative, PSNR <= 1e-3 dB, radii exact.
     The end-to-end fp64 gradient (its own L1 signs) is printed with the number of flipped signs: near convergence the render matches
     the target to 1e-6 at many pixels and sign(render - gt) is decided by rounding -- that, not a kernel, is where fp32 and fp64
@@ -298,17 +303,18 @@ def test_teacher_forced_gradient_parity_along_the_trajectory(flags):
         img = cap.image.cpu().numpy()
         for b in range(img.shape[0]):
             assert image_err(img[b], o64["image"][b].numpy(), outlier_frac=1e-3) < 1e-4
-        d = cap.dimage.cpu().double().reshape(o64["dimage_ref"].shape)
-        e_loss = float((d - o64["dimage_ref"]).abs().max() / o64["dimage_ref"].abs().max())
+        e_loss, e_loss32 = teacher.loss_node_err(cap.dimage, o64)
         gt = torch.stack([c.original_image for c in cams_c])
         flips = int((torch.sign(cap.image.cpu().double() - gt) != torch.sign(e2e["image"] - gt)).sum())
         e2e_rows = [(n, float((g.cpu().double() - r).abs().max() / (r.abs().max() + 1e-30)))
                     for n, g, r in zip(cap.names, cap.grads, e2e["grads"]) if g is not None]
-        print(f"step {it:3d}: PSNR HIP {psnr:.4f} fp64-at-this-state {o64['psnr']:.4f} dB; image loss node {e_loss:.1e}; "
+        print(f"step {it:3d}: PSNR HIP {psnr:.4f} fp64-at-this-state {o64['psnr']:.4f} dB; image loss node {e_loss:.1e} (fp32 torch: {e_loss32:.1e}); "
               f"{flips} L1 signs differ; end-to-end worst {max(e2e_rows, key=lambda r: r[1])[0]} {max(e for _, e in e2e_rows):.1e}")
         assert abs(psnr - o64["psnr"]) <= 1e-3, (it, psnr, o64["psnr"])
-        assert e_loss <= 1e-4, (it, e_loss)
-        res = teacher.compare_chain(cap, o64, o32, P, tol=1e-4, tie_frac=1e-3)
+        assert e_loss <= max(1e-4, 3.0 * e_loss32), (it, e_loss, e_loss32)
+        teacher.raster_stage(cap, cams_c, np.ones(3), tol=1e-4, tie_frac=1e-3)
+        teacher.pre_stage(build_c, cams_c, cap, tol=1e-4)
+        res = teacher.compare_chain(cap, o64, o32, P, tol=1e-4, tie_frac=2e-3)
         seen.append((it, res))
 
     PRE_STEP[:] = [pre]

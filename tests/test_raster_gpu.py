@@ -94,12 +94,12 @@ def _test_forward_image(cfg):
     assert mism.mean() < 2e-4, f"{mism.sum()} n_contrib mismatches"
 
 
-@pytest.mark.parametrize("k7", [0, 8192, 16384], ids=["k7_rows", "k7_columns_depth_split", "k7_columns_tilewise"])
+@pytest.mark.parametrize("k7", [0, 256, 32768], ids=["k7_atomics", "k7_reproducible", "k6_rows_in_front"])
 @pytest.mark.parametrize("cfg", CASES)
 def test_backward_grads(cfg, k7):
-    """(k7: the default row form of the compositing backward, and the survivor-column form -- 16 survivors per step, DPP row scans,
-    MFMA reduction -- depth-split per segment and walking whole tiles; csplat_debug_flags bits 13 / 14.  The batched entry point is
-    covered by test_all_k7_forms_through_the_batched_entry_point.)"""
+    """(k7: the compositing backward with float atomics (default) and in its bit-reproducible mode, csplat_debug_flags bit 8; and behind
+    the ROW form of K6 (bit 15), which writes the "blended" bits K7 walks in its own way.  The batched entry point is covered by
+    test_k6_forms_through_the_batched_entry_point.)"""
     from csplat import native
     native.lib.csplat_debug_flags(k7)
     try:
@@ -861,11 +861,12 @@ def test_config2_full_size_vs_oracle():
         _grad_vs_oracles(k, v.cpu().numpy(), sums32[k], sums[k], P, tie_frac=4e-3)
 
 
-@pytest.mark.parametrize("k7", [8192, 16384, 32768, 32768 | 8192], ids=["k7_columns_depth_split", "k7_columns_tilewise", "k6_rows", "k6_rows_and_k7_columns"])
-def test_all_k7_forms_through_the_batched_entry_point(k7):
-    """rasterize_views (one K7 launch for all views) with the survivor-column forms of K7 (csplat_debug_flags bits 13 / 14) against
-    the default row form: images identical (K7 does not touch them), every gradient equal up to the summation order (1e-5 of scale),
-    on a scene deep enough for several 256-entry segments per tile."""
+@pytest.mark.parametrize("k7", [32768], ids=["k6_rows"])
+def test_k6_forms_through_the_batched_entry_point(k7):
+    """rasterize_views (one launch per stage for all views) with the ROW form of K6 (csplat_debug_flags bit 15) against the default
+    survivor-column form: images equal to rounding (the two forms multiply the transmittance factors in a different order), every
+    gradient equal to 1e-4 of its scale -- K7 walks the "blended" bits either form of K6 leaves -- on a scene deep enough for several
+    256-entry segments per tile."""
     from csplat import native
     from diff_gaussian_rasterization import rasterize_views
     V = 3

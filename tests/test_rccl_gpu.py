@@ -44,7 +44,9 @@ def test_bench_collective_leg_under_rccl_one_rank():
     r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
                         "--no-train-step"], env=_env(), capture_output=True, text=True, timeout=900, cwd=util.ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines and r.stdout.strip().splitlines()[-1] == lines[-1], "the JSON line must be the LAST line of bench.py's output:\n" + r.stdout[-1500:]
+    line = json.loads(lines[-1])
     print("bench.py under RCCL, one rank:", {k: line[k] for k in ("value", "ms_per_step", "collective")})
     c = line["collective"]
     assert c is not None and c["backend"] == "nccl (RCCL)" and c["ranks"] == 1 and c["bytes"] == (62 + 3) * 100_000 * 4
