@@ -41,6 +41,8 @@ EXPORTS = {
     "csplat_forward_views": (_i, [_i, _vp, ALLOC_FN, _vp]),
     "csplat_forward_views_deferred": (_i, [_i, _vp, ALLOC_FN, _vp, _vp]),
     "csplat_forward_views_settle": (_i, [_i, _vp, _vp, _vp]),
+    "csplat_forward_views_faith": (_i, [_i, _vp, ALLOC_FN, _vp, _vp, _vp]),
+    "csplat_image_info_offset": (C.c_size_t, [_i, _i]),
     "csplat_backward_views": (_i, [_i, _vp, _vp]),
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -58,6 +60,7 @@ EXPORTS = {
     "csplat_ssim_fwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_adam_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _i64]),
+    "csplat_adam_step_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "csplat_l1_scratch_bytes": (_sz, []),
     "csplat_mask_to_map_temp_bytes": (_sz, [_i64]),
     "csplat_mask_to_map": (_i, [_vp, _i64, _vp, C.c_int32, _vp, _vp, _vp]),
@@ -229,7 +232,7 @@ class CsplatView(C.Structure):
                 [("num_rendered", _i), ("layout_rendered", _i)] + [(n, _vp) for n in ("geom", "binning", "image", "dL_dpix", "scratch")] +
                 [("accmask", C.c_uint)] +
                 [(n, _vp) for n in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D",
-                                    "dL_dsh", "dL_dscale", "dL_drot")] + [("busy_tiles", _i)])
+                                    "dL_dsh", "dL_dscale", "dL_drot")] + [("busy_tiles", _i), ("valid", _vp)])
 
 
 ACC_OPACITY, ACC_COLOR, ACC_MEAN3D, ACC_COV3D, ACC_SH, ACC_SCALE, ACC_ROT = 1, 2, 4, 8, 16, 32, 64

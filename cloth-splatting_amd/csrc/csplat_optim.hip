@@ -53,6 +53,68 @@ extern "C" int csplat_adam_step(void *stream, int n_tensors, float *const *param
     return 0;
 }
 
+// ---- the same step with its step count, learning rates and go / no-go word ON THE DEVICE: nothing in the launch depends on a value
+// the host would have to compute per step, so the launch can be recorded into a hipGraph and replayed (csplat.train.CapturedStep).
+//   state[0] (int32): steps taken so far; the kernels use state[0] + 1 and k_adam_tick advances it -- unless *valid == 0
+//   lr (double[n_tensors], device): the groups' learning rates (the host rewrites them when a schedule moves them)
+//   valid (device word or NULL): 0 = the step's gradients are not to be applied (a forward launched on faith that did not fit)
+// Arithmetic as csplat_adam_step: the bias corrections are formed in double from the count, per workgroup.
+namespace {
+struct AdamDevDesc { float *p; const float *g; float *m, *v; long long n; };
+struct AdamDevTable { AdamDevDesc d[CSPLAT_ADAM_MAX_TENSORS]; };
+__global__ __launch_bounds__(256) void k_adam_dev(AdamDevTable tab, const double *__restrict__ lr, double beta1, double beta2, float eps,
+                                                  const int *__restrict__ state, const uint32_t *__restrict__ valid) {
+    if (valid && *valid == 0u) return;
+    __shared__ float s_c[2];
+    if (threadIdx.x == 0) {
+        const double step = (double)(state[0] + 1);
+        const double bc1 = 1.0 - pow(beta1, step);
+        s_c[0] = (float)(lr[blockIdx.y] / bc1);
+        s_c[1] = (float)sqrt(1.0 - pow(beta2, step));
+    }
+    __syncthreads();
+    const float step_size = s_c[0], bc2_sqrt = s_c[1];
+    const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2), b2 = (float)beta2;
+    const AdamDevDesc d = tab.d[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)gridDim.x * 256) {
+        const float g = d.g[i];
+        float m = d.m[i], v = d.v[i];
+        m = m + w1 * (g - m);
+        v = v * b2 + (w2 * g) * g;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        d.m[i] = m; d.v[i] = v;
+        d.p[i] = d.p[i] - step_size * (m / denom);
+    }
+}
+__global__ void k_adam_tick(int *state, const uint32_t *__restrict__ valid) {
+    if (threadIdx.x == 0 && !(valid && *valid == 0u)) state[0] += 1;
+}
+}  // namespace
+
+extern "C" int csplat_adam_step_dev(void *stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                                    float *const *exp_avg_sq, const int64_t *numel, const double *lr_dev, double beta1, double beta2,
+                                    double eps, int *state_dev, const uint32_t *valid_dev) {
+    CSPLAT_REQUIRE(n_tensors >= 1 && n_tensors <= CSPLAT_ADAM_MAX_TENSORS && params && grads && exp_avg && exp_avg_sq && numel && lr_dev &&
+                   state_dev, "csplat_adam_step_dev: bad arguments (1..48 tensors)");
+    AdamDevTable tab;
+    memset(&tab, 0, sizeof(tab));
+    int64_t longest = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        CSPLAT_REQUIRE(numel[i] == 0 || (params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i]), "csplat_adam_step_dev: NULL tensor");
+        tab.d[i] = AdamDevDesc{params[i], grads[i], exp_avg[i], exp_avg_sq[i], (long long)numel[i]};
+        longest = numel[i] > longest ? numel[i] : longest;
+    }
+    if (longest > 0) {
+        const int64_t want = (longest + 1023) / 1024;
+        dim3 grid((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want)), (unsigned)n_tensors);
+        k_adam_dev<<<grid, 256, 0, (hipStream_t)stream>>>(tab, lr_dev, beta1, beta2, (float)eps, state_dev, valid_dev);
+        LAUNCH_CHECK();
+    }
+    k_adam_tick<<<1, 64, 0, (hipStream_t)stream>>>(state_dev, valid_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- capacity-based densify / prune (second half).  The reference re-creates every nn.Parameter and both
 // Adam moments of all 7 attribute groups with boolean-mask indexing / torch.cat whenever the number of Gaussians changes
 // (scene_reconstruction/gaussian_model.py:266-341, gaussian_mesh.py:336-431): ~60 allocations and gathers per surgery.  Here

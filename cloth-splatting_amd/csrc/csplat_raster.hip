@@ -605,6 +605,14 @@ struct P2Table { P2View v[P2_MAX_VIEWS]; };
 __device__ __forceinline__ bool p2_live(const P2View &w) { return !w.spec || (w.info[0] - 1u < w.R && w.info[1] <= w.Lcap && w.info[2] <= w.Bcap); }
 __device__ __forceinline__ void seg_plan_body(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
                                               int *__restrict__ slot_tile);
+// the verdict of a launch on faith (csplat_forward_views_faith): every view's counts fitted the capacities its second phase was laid out for
+__global__ void k_p2_valid(P2Table tab, int V, uint32_t *valid) {
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        for (int i = 0; i < V; i++) ok = ok && p2_live(tab.v[i]);
+        *valid = ok ? 1u : 0u;
+    }
+}
 // (the LAST workgroup of every view does not emit: it lays out the view's 256-entry segments -- the former k_seg_plan launch; both only
 // need the tile ranges)
 __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket_views(int P, int tiles, P2Table tab) {
@@ -1160,7 +1168,7 @@ struct BlockStreamT {
 };
 typedef BlockStreamT<4, RING> BlockStream;
 
-struct Trip { float4 a, b; float2 c; int pos; };   // the lane's survivor of a group (row r's), pos = list position or -1
+struct Trip { float4 a, b; float2 c; int pos; uint32_t id; };   // the lane's survivor of a group (row r's), pos = list position or -1
 
 // ---- which entries a block BLENDED (round 4).  K5b's masks say which entries can REACH a 4x4 block (ellipse vs box); K6 finds out which
 // of them any pixel of the block actually blends -- alpha >= 1/255 at some pixel centre that is still open -- and K7 only ever does
@@ -1642,6 +1650,9 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING7];
     __shared__ uint32_t s_ids[DET ? 1 : SEG];   // the segment's Gaussian ids, for the flush
+#ifdef K7_T_LDS
+    __shared__ __attribute__((aligned(16))) float s_gather[4][64];
+#endif
     const int wg = blockIdx.x;
     // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
     unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 : nullptr;
@@ -1703,7 +1714,12 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         ck = ckpt[(size_t)slot * 256 + blk * 16 + l16];
     }
     uint32_t my_id = 0u;
-    if (!DET && seg_lo + (int)threadIdx.x < seg_hi) my_id = ids_sorted[rx + seg_lo + threadIdx.x];
+#ifdef K7_DIRECT
+    constexpr bool LDS_ACC = DET;
+#else
+    constexpr bool LDS_ACC = true;
+#endif
+    if (LDS_ACC && !DET && seg_lo + (int)threadIdx.x < seg_hi) my_id = ids_sorted[rx + seg_lo + threadIdx.x];
     // the wave's survivor list: list positions of the set bits, in order, padded with -1 to a multiple of four (wave-private LDS)
     int *ring = s_ring[w];
     int total = 0;
@@ -1722,9 +1738,11 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         total += pad;
     }
     const int ngroups = total >> 2;
-    for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
-    if (!DET) s_ids[threadIdx.x] = my_id;
-    __syncthreads();
+    if (LDS_ACC) {
+        for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
+        if (!DET) s_ids[threadIdx.x] = my_id;
+        __syncthreads();
+    }
     mark(2);
     float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
     if (live) {
@@ -1741,10 +1759,17 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
         const bool red_active = !lb0 || l16 == 1;
         const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
+#ifdef K7_S_MFMA
+        // A[m = lane & 15][k = lane >> 4] of the prefix-sum MFMA: rows m = 4 j: 1 for k <= j; rows m = 4 j + 1: all ones; other rows unused
+        const float mfma_a = (l16 & 3) == 0 ? (r <= (l16 >> 2) ? 1.f : 0.f) : ((l16 & 3) == 1 ? 1.f : 0.f);
+#endif
         auto fetch = [&](Trip &t, int k) {
             t.pos = ring[4 * k + r];
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
             t.a = recA[ri]; t.b = recB[ri]; t.c.x = reinterpret_cast<const float *>(recC)[2 * (size_t)ri];   // (c.y, the depth, is K6's)
+#ifdef K7_DIRECT
+            t.id = t.pos >= 0 ? ids_sorted[rx + (uint32_t)t.pos] : 0u;
+#endif
         };
         auto process = [&](const Trip &t) {
             const float dx = t.a.x - fx, dy = t.a.y - fy;
@@ -1754,15 +1779,34 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             const bool act = t.pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
             const float al = act ? a : 0.f;
             const float F = 1.f - al;
+#ifdef K7_T_LDS
+            // the pixel's four factors through a wave-private LDS strip: one 4-byte write, one 16-byte read (LDS ops of a wave execute in
+            // order: the next group's write cannot pass this read)
+            s_gather[w][l16 * 4 + r] = F;
+            const float4 gq = *reinterpret_cast<const float4 *>(&s_gather[w][l16 * 4]);
+            const Row4 g = {gq.x, gq.y, gq.z, gq.w};
+#else
             const Row4 g = rows_allgather(F);
+#endif
             const float P1 = T * g.v0, P2 = P1 * g.v1, P3 = P2 * g.v2, P4 = P3 * g.v3;
             const float Tr = rowsel(r, T, P1, P2, P3);
             const float gdot = t.b.z * dp0 + t.b.w * dp1 + t.c.x * dp2;
             const float dchannel_dcolor = al * Tr;
+#ifdef K7_S_MFMA
+            // the running sum S over the group's four survivors on the MATRIX pipe: v_mfma_f32_16x16x4_f32 contracts over lane >> 4 -- the
+            // survivor row -- with the lane's value as B[k = row][n = pixel]; A[m][k] (a per-lane constant) makes output row 4 r the
+            // inclusive prefix over the rows <= r and output row 4 r + 1 the group's total, and a lane's accumulator registers are exactly
+            // D[4 (lane >> 4) + i][lane & 15]: Sr and the new S without an all-gather, four dependent adds and three row selects
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v dS = __builtin_amdgcn_mfma_f32_16x16x4f32(mfma_a, gdot * dchannel_dcolor, (f4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const float Sr = S + dS[0];
+            T = P4; S = S + dS[1];
+#else
             const Row4 gw = rows_allgather(gdot * dchannel_dcolor);
             const float S1 = S + gw.v0, S2 = S1 + gw.v1, S3 = S2 + gw.v2, S4 = S3 + gw.v3;
             const float Sr = rowsel(r, S1, S2, S3, S4);
             T = P4; S = S4;
+#endif
             const float dL_dalpha = act ? Tr * gdot - (OD - Sr) * __builtin_amdgcn_rcpf(F) : 0.f;
             const float dL_dG = t.b.y * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
@@ -1789,14 +1833,37 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             const float tot = lb0 ? l8 : c0;
             // (every survivor of the list was blended at one of the block's pixels: the row always has something to add, padding aside)
             if (red_active && t.pos >= 0) {
+#ifdef K7_DIRECT
+                if (!DET) atomicAdd(acc + (size_t)t.id * ACC_STRIDE + red_t, tot);
+                else
+#endif
+                {
                 float *cell = my_acc + (t.pos - seg_lo) * 9 + red_t;
                 if (DET) *cell = tot;                  // one (entry, block) pair is visited exactly once
                 else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the workgroup meet here
+                }
             }
         };
         // software pipeline, TWO groups in flight: the records of group k+2 are requested when group k has been composited.  (Three in
         // flight -- K6's depth -- cost 11 more registers: 67 VGPRs = 7 waves per SIMD; two = 57 VGPRs = 8 waves: 306 -> 294 us, same-box
         // A/B, three alternations.  Forcing the three-deep form under 64 registers spills 7 of them: 365 us.)
+#ifdef K7_DEPTH3
+        Trip ta, tb, tc;
+        fetch(ta, 0);
+        if (ngroups > 1) fetch(tb, 1);
+        if (ngroups > 2) fetch(tc, 2);
+        mark(4);
+        for (int k = 0; k < ngroups; k += 3) {
+            process(ta);
+            if (k + 3 < ngroups) fetch(ta, k + 3);
+            if (k + 1 >= ngroups) break;
+            process(tb);
+            if (k + 4 < ngroups) fetch(tb, k + 4);
+            if (k + 2 >= ngroups) break;
+            process(tc);
+            if (k + 5 < ngroups) fetch(tc, k + 5);
+        }
+#else
         Trip ta, tb;
         fetch(ta, 0);
         if (ngroups > 1) fetch(tb, 1);
@@ -1809,8 +1876,10 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             process(tb);
             if (k + 3 < ngroups) fetch(tb, k + 3);
         }
+#endif
     }
     mark(5);                                                            // this wave's groups are done
+    if (!LDS_ACC) return;          // (direct form: every row's sums went straight to the per-Gaussian records)
     __syncthreads();
     mark(6);
     // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request.  (Retiring the waves
@@ -1853,8 +1922,9 @@ struct B2View {
     float *acc;
     uint32_t R;
 };
-struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; };
+struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; const uint32_t *valid; };
 __global__ __launch_bounds__(256, 8) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
+    if (tab.valid && *tab.valid == 0u) return;     // (a forward launched on faith whose counts did not fit: its chunks hold nothing)
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.bbits, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
                               w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp);
@@ -2146,6 +2216,7 @@ struct K8View {
 struct K8Table {
     int n;
     unsigned sharedmask;   // CSPLAT_ACC_* bits of the outputs whose buffer is the same in every view
+    const uint32_t *valid; // (csplat_forward_views_faith) 0 there: the forward left the views untouched -- nothing to differentiate
     K8View v[K8_MAX_VIEWS];
 };
 
@@ -2157,6 +2228,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
                                                                const float *__restrict__ scales, float scale_mod,
                                                                int use_precomp_cov, float *__restrict__ dL_dsh, K8Table tab) {
     constexpr bool STAGE = true;
+    if (tab.valid && *tab.valid == 0u) return;
     const unsigned smask = tab.sharedmask;
     // shared output: add to the thread's running sum; per-view output: write (or add, by that view's accmask)
 #define PUTL(local, ptr, idx, val, bit)                                                    \
@@ -2870,30 +2942,13 @@ constexpr int MAX_PENDING = 8;
 static PendingViews g_pending[MAX_PENDING];
 static std::mutex g_pending_mu;
 
-// mode 0: the whole second phase (launch, read the counts, repeat with exact sizes if the speculation missed);
-// mode 1: as 0, but when the speculative launch is possible return right after it with *pend filled (pend->used) -- nothing is read;
-// mode 2: finish a mode-1 call: read the counts, accept or repeat (*relaunched)
-static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done, int mode = 0,
-                                PendingViews *pend = nullptr, int *relaunched = nullptr) {
-    *done = false;
-    if (V < 2 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
+// lays the chunks of every view out for `Rcap[i]` list entries and launches the five stages of the second phase on `join`
+// (valid != nullptr: one more tiny launch leaves 1 there when every view's counts fitted the capacities, else 0 -- csplat_forward_views_faith)
+static int p2_launch(int V, const int *tk, csplat_view *v, hipStream_t join, const uint32_t *Rcap, uint32_t Lcap, int spec, uint32_t Bcap,
+                     uint32_t *valid = nullptr) {
     const FwdTicket &a = g_tickets[tk[0]];
-    for (int i = 0; i < V; i++) {
-        const FwdTicket &t = g_tickets[tk[i]];
-        if (!t.can_bucket || t.P != a.P || t.W != a.W || t.H != a.H || t.P <= 0) return 0;
-    }
     const int P = a.P, W = a.W, H = a.H, tiles = a.tiles, nb = a.nb;
-    const uint32_t cap = tile_sort_cap();
-    uint32_t info[P2_MAX_VIEWS][3];
-    bool have_info = false;
-    auto read_counts = [&]() -> int {   // the one host read of the call: instances and longest tile list of every view
-        for (int i = 0; i < V && !have_info; i++)
-            if (int rc = finish_read(g_tickets[tk[i]], info[i], join)) return rc;
-        have_info = true;
-        return 0;
-    };
-    // lays the chunks of every view out for `Rcap[i]` list entries and launches the five stages
-    auto launch = [&](const uint32_t *Rcap, uint32_t Lcap, int spec, uint32_t Bcap) -> int {
+    {
         P2Table tab;
         uint32_t maxR = 0;
         for (int i = 0; i < V; i++) {
@@ -2958,8 +3013,37 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
                 k_composite_fwd_views<true><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, busy_grid);
             LAUNCH_CHECK();
         }
+        if (valid) {
+            k_p2_valid<<<1, 64, 0, join>>>(tab, V, valid);
+            LAUNCH_CHECK();
+        }
+        return 0;
+    }
+}
+
+// mode 0: the whole second phase (launch, read the counts, repeat with exact sizes if the speculation missed);
+// mode 1: as 0, but when the speculative launch is possible return right after it with *pend filled (pend->used) -- nothing is read;
+// mode 2: finish a mode-1 call: read the counts, accept or repeat (*relaunched)
+static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done, int mode = 0,
+                                PendingViews *pend = nullptr, int *relaunched = nullptr) {
+    *done = false;
+    if (V < 2 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
+    const FwdTicket &a = g_tickets[tk[0]];
+    for (int i = 0; i < V; i++) {
+        const FwdTicket &t = g_tickets[tk[i]];
+        if (!t.can_bucket || t.P != a.P || t.W != a.W || t.H != a.H || t.P <= 0) return 0;
+    }
+    const int P = a.P, W = a.W, H = a.H;
+    const uint32_t cap = tile_sort_cap();
+    uint32_t info[P2_MAX_VIEWS][3];
+    bool have_info = false;
+    auto read_counts = [&]() -> int {   // the one host read of the call: instances and longest tile list of every view
+        for (int i = 0; i < V && !have_info; i++)
+            if (int rc = finish_read(g_tickets[tk[i]], info[i], join)) return rc;
+        have_info = true;
         return 0;
     };
+    auto launch = [&](const uint32_t *Rcap, uint32_t Lcap, int spec, uint32_t Bcap) -> int { return p2_launch(V, tk, v, join, Rcap, Lcap, spec, Bcap); };
     auto remember = [&]() {
         std::lock_guard<std::mutex> lk(g_spec_mu);
         SpecHist &e = g_spec_ring[g_spec_next];
@@ -3361,6 +3445,48 @@ int csplat_forward_views(int V, csplat_view *v, csplat_alloc_fn alloc, void *joi
     return forward_views_impl(V, v, alloc, join_stream, nullptr);
 }
 
+// csplat_forward_views WITHOUT any host read: both phases are launched with the caller's capacities (caps[0] list entries per view,
+// caps[1] longest tile list, caps[2] non-empty tiles) and *valid (device) receives 1 when every view's counts fitted them, else 0 -- in
+// which case the second phase left the views untouched and csplat_backward_views (views[i].valid = valid) does nothing either.  Nothing
+// here waits for the GPU or reads from it: the call can be recorded into a hipGraph (stream capture) and replayed.  The views must
+// qualify for the one-launch-per-stage path (2..8 views sharing P, SH, opacities, scales and the image size), else an error.
+int csplat_forward_views_faith(int V, csplat_view *v, csplat_alloc_fn alloc, void *join_stream, const uint32_t *caps, uint32_t *valid) {
+    CSPLAT_REQUIRE(V >= 2 && V <= P2_MAX_VIEWS && v != nullptr && caps != nullptr && valid != nullptr, "csplat_forward_views_faith: bad arguments");
+    CSPLAT_REQUIRE(caps[0] > 0 && caps[0] <= 0x7FFFFF00u && caps[1] > 0 && caps[1] <= tile_sort_cap() && caps[2] > 0,
+                   "csplat_forward_views_faith: capacities out of range");
+    hipStream_t join = (hipStream_t)join_stream;
+    int tickets[P2_MAX_VIEWS];
+    int rc = 0, begun = 0;
+    for (; begun < V; begun++) {
+        csplat_view &w = v[begun];
+        rc = begin_prepare(w.stream, w.P, w.D, w.M, w.bg, w.W, w.H, w.means3D, w.shs, w.colors_precomp, w.opacities, w.scales,
+                           w.scale_modifier, w.rotations, w.cov3D_precomp, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy,
+                           w.prefiltered, alloc, w.alloc_ctx, w.radii, &tickets[begun]);
+        if (rc) break;
+    }
+    auto release = [&]() {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        for (int i = 0; i < begun; i++) g_tickets[tickets[i]].used = false;
+    };
+    if (rc == 0 && !begin_views_compatible(V, tickets)) {
+        release();
+        CSPLAT_REQUIRE(false, "csplat_forward_views_faith: the views do not qualify for the one-launch-per-stage path");
+    }
+    if (rc == 0) rc = begin_launch_views(V, tickets, join);
+    if (rc == 0) {
+        uint32_t Rcap[P2_MAX_VIEWS];
+        for (int i = 0; i < V; i++) Rcap[i] = caps[0];
+        const uint32_t tiles = (uint32_t)g_tickets[tickets[0]].tiles;
+        rc = p2_launch(V, tickets, v, join, Rcap, caps[1], 1, caps[2] > tiles ? tiles : caps[2], valid);
+    }
+    for (int i = 0; i < V && rc == 0; i++) { v[i].num_rendered = (int)caps[0]; v[i].busy_tiles = 0; v[i].valid = valid; }
+    release();
+    return rc;
+}
+// byte offset, inside the IMAGE chunk, of the three counts a view's first phase leaves (u32: tile instances, longest tile list, non-empty
+// tiles) -- what a caller that launched on faith reads, at a time of its choosing, to size the next launch
+size_t csplat_image_info_offset(int W, int H) { size_t off[5]; image_offsets(W, H, off); return off[3]; }
+
 // csplat_forward_views with the one host read DEFERRED.  When the second phase can be launched speculatively (capacities from the
 // previous call of the same shape) the call returns right behind that launch with *pending = 1: views[i].layout_rendered is the capacity,
 // views[i].num_rendered is -1, and the caller does whatever host work it has (the GPU is busy with K1..K6) before it calls
@@ -3443,6 +3569,7 @@ static bool k8_views_table(int V, const csplat_view *v, K8Table &tab) {
             if (v[i].dL_dmean2D == v[j].dL_dmean2D || v[i].dL_dconic == v[j].dL_dconic || v[i].scratch == v[j].scratch) return false;
     tab.n = V;
     tab.sharedmask = sharedmask;
+    tab.valid = v[0].valid;
     for (int i = 0; i < V; i++) {
         const csplat_view &w = v[i];
         if (!w.geom || !w.scratch || !w.dL_dmean2D || !w.dL_dconic || !w.dL_dopacity || !w.dL_dcolor || !w.dL_dmean3D || !w.dL_dcov3D ||
@@ -3474,6 +3601,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     // one launch per stage for all views: everything runs on the join stream, the views' own streams are not involved and need
     // neither the entry nor the exit fence (six event / wait calls, ~25 us of host time per step)
     const bool side_streams = !(batch_k7 && one_k8);
+    CSPLAT_REQUIRE(!(V > 0 && v[0].valid) || !side_streams, "csplat_backward_views: views launched on faith need the one-launch-per-stage path");
     if (side_streams)
         if (int rc = fence_in(V, v, join)) return rc;
     // from here on side streams may hold work on caller-owned buffers: whatever fails, the exit fence is still issued
@@ -3504,6 +3632,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             {   // (measurement hook, off unless csplat_debug_stamps handed over a buffer large enough for this launch)
                 const size_t need = (size_t)V * ((size_t)cdiv(slots, 8) * 32u) * 12;
                 bt.stamp = (g_stamp_buf && g_stamp_words >= need) ? g_stamp_buf : nullptr;
+                bt.valid = v[0].valid;
             }
             ProfScope ps(PROF_K7, join);
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;

@@ -147,6 +147,8 @@ typedef struct csplat_view {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
     int busy_tiles;                 /* written by the forward (0 = not known): tiles with a non-empty list -- the backward sizes the
                                      * compositing backward's grid with it (segments <= R / 256 + busy_tiles + 1) */
+    const uint32_t *valid;          /* NULL, or (csplat_forward_views_faith) the device word that says whether the forward took place:
+                                     * the backward of views[0..V) does nothing when it is 0 */
 } csplat_view;
 int csplat_forward_views(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream);
 /* The same call with its one host read (the views' counts) DEFERRED.  When the second phase can be launched on the previous call's
@@ -159,6 +161,15 @@ int csplat_forward_views(int V, csplat_view *views, csplat_alloc_fn alloc, void 
 int csplat_forward_views_deferred(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream, int *pending);
 int csplat_forward_views_settle(int V, csplat_view *views, void *join_stream, int *relaunched);
 int csplat_backward_views(int V, csplat_view *views, void *join_stream);
+/* The batched forward WITHOUT a host read, for stream capture (a training step replayed as a hipGraph; the reference times its step
+ * with an event pair around exactly such a loop body, train.py:146,178): both phases are launched with the caller's capacities --
+ * caps[0] list entries per view, caps[1] longest tile list, caps[2] non-empty tiles, normally a previous call's counts plus a margin --
+ * and *valid (device) becomes 1 when every view's counts fitted, else 0 (the second phase then left the views untouched, and
+ * csplat_backward_views, which finds views[i].valid set, does nothing).  num_rendered is NOT the count (it is set to the capacity):
+ * the counts stay on the device, at csplat_image_info_offset(W, H) inside each view's IMAGE chunk (u32 x 3).  The views must qualify
+ * for the one-launch-per-stage path (2..8 views sharing P, SH, opacities, scales, image size); otherwise an error is returned. */
+int csplat_forward_views_faith(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream, const uint32_t *caps, uint32_t *valid);
+size_t csplat_image_info_offset(int W, int H);
 
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
  * out_color is the forward's colour image; dL_dpix[3][H][W] its gradient (the depth image carries no gradient,
@@ -198,6 +209,13 @@ int csplat_blur11(void *stream, int64_t n_images, int H, int W, const float *tap
 int csplat_adam_step(void *stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                      float *const *exp_avg_sq, const int64_t *numel, const double *lr, double beta1, double beta2, double eps,
                      int64_t step);
+/* The same step with NOTHING of the launch depending on a per-step host value (for a training step recorded into a hipGraph):
+ * state_dev[0] (int32, device) = steps taken so far -- the kernel uses state_dev[0] + 1 for its bias corrections and a trailing
+ * one-thread launch advances it; lr_dev = the tensors' learning rates as doubles in device memory; valid_dev (may be NULL) = a device
+ * word: 0 there -> parameters, moments and the step count are left untouched.  At most CSPLAT_ADAM_MAX_TENSORS tensors. */
+int csplat_adam_step_dev(void *stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                         float *const *exp_avg_sq, const int64_t *numel, const double *lr_dev, double beta1, double beta2, double eps,
+                         int *state_dev, const uint32_t *valid_dev);
 
 /* Capacity-based densify / prune: replaces the boolean-mask indexing / torch.cat re-creation of every
  * parameter and Adam moment in /root/reference/scene_reconstruction/gaussian_model.py:266-341 and gaussian_mesh.py:336-431.

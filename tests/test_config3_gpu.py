@@ -102,7 +102,7 @@ def test_config3_full_size_one_step_vs_oracle():
     # ---- the rasterizer node on the step's own inputs: image <= 1e-4, radii exact, every rasterizer-input gradient <= 1e-4 (ties explained)
     teacher.raster_stage(cap, cams_c, np.ones(3), tol=TOL, tie_frac=1e-3, radii=stats["radii"], vsg=stats["viewspace_grad"])
     # ---- every parameter gradient: the nodes in front of the rasterizer, driven with the step's own rasterizer-input gradients
-    teacher.pre_stage(build_c, cams_c, cap, tol=TOL)
+    teacher.pre_stage(build_c, cams_c, cap, tol=TOL, build_cpu32=lambda: build("cpu", torch.float32))
     # ---- ... and through the whole chain from the parameters (deviations counted and bounded)
     teacher.compare_chain(cap, o64, o32, P, tol=TOL, tie_frac=4e-3)
     # ---- end to end (reported; the bar: what the flipped signs can explain)

@@ -269,7 +269,7 @@ def test_teacher_forced_gradient_parity_along_the_trajectory(flags):
     (tests/teacher.py) and replayed on the CPU FROM THE HIP STATE of that step -- simulator, mesh transform, losses as fp64 torch, the
     rasterizer = the C oracle with its analytic backward:
       * the rasterizer node on the step's OWN inputs and dL/dimage: image, and the gradient of every rasterizer input (means3D /
-        rotations per camera, opacity, scales, SH) <= 1e-4 against the fp64 oracle; threshold ties counted (<= 1e-3 of the Gaussians),
+        rotations per camera, opacity, scales, SH) <= 1e-4 against the fp64 oracle; threshold ties counted (<= 2e-3 of the Gaussians),
         bounded, and required to show in the fp32 build of the oracle too;
       * every parameter gradient (7 Gaussian groups + the simulator's tensors) <= 1e-4 against fp64 torch over the nodes in front of the
         rasterizer (simulator, regularisers, mesh transform, activations) driven with the step's own rasterizer-input gradients;
@@ -312,8 +312,8 @@ def test_teacher_forced_gradient_parity_along_the_trajectory(flags):
               f"{flips} L1 signs differ; end-to-end worst {max(e2e_rows, key=lambda r: r[1])[0]} {max(e for _, e in e2e_rows):.1e}")
         assert abs(psnr - o64["psnr"]) <= 1e-3, (it, psnr, o64["psnr"])
         assert e_loss <= max(1e-4, 3.0 * e_loss32), (it, e_loss, e_loss32)
-        teacher.raster_stage(cap, cams_c, np.ones(3), tol=1e-4, tie_frac=1e-3)
-        teacher.pre_stage(build_c, cams_c, cap, tol=1e-4)
+        teacher.raster_stage(cap, cams_c, np.ones(3), tol=1e-4, tie_frac=2e-3)      # (<= 10 of the 5,000 Gaussians: ONE tie pixel moves every Gaussian on it)
+        teacher.pre_stage(build_c, cams_c, cap, tol=1e-4, build_cpu32=lambda: build("cpu", torch.float32))
         res = teacher.compare_chain(cap, o64, o32, P, tol=1e-4, tie_frac=2e-3)
         seen.append((it, res))
 
