@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--P", type=int, default=100_000)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--grid", type=int, default=100)
+    ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying it as a hipGraph")
     print(json.dumps(run(ap.parse_args())), flush=True)
 
 
@@ -72,30 +73,29 @@ def run(args, dev=None):
     from csplat.optim import GroupedAdam
     mopt = GroupedAdam(sim.parameters(), lr=tr.DEFAULT_OPT.meshnet_lr)
     hist = []
+    captured = not getattr(args, "eager", False)      # the step replayed as a hipGraph (csplat.train.CapturedStep); --eager: launch by launch
+    # (warm-up steps never land on a multiple of 1000: the SH-degree bump of train_utils.py:246 is not part of the timed step)
     for it in range(1, args.warmup + 1):
-        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)
+        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg, captured=captured)
         hist.append(float(ps))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     per_step = []
     for it in range(args.warmup + 1, args.warmup + args.steps + 1):
         ts = time.perf_counter()
-        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)
+        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg, captured=captured)
         hist.append(float(ps))   # (.item(): the reference logs PSNR / loss every step too, train.py:182-189)
         per_step.append(time.perf_counter() - ts)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     per_step.sort()
-    # the same loop with the log read ONE STEP LATE (step k's PSNR is read after step k+1 has been issued: same values, one step later) --
-    # to see whether the per-step read is what costs: it is not (1.09-1.38 against 1.09-1.16 ms).  Host (0.9 ms) and GPU (0.94 ms) are
-    # matched per step but not per PHASE: the small kernels of the front and of the backward's tail take 5-15 us each where the host
-    # needs ~25 us per launch, the rasterizer's long kernels the other way round; and a host that runs a step ahead only gets as far
-    # as the forward's read of its counts (behind the previous step's whole backward on the stream), then has the loss and the backward
-    # still to issue when the GPU arrives.
+    # the same number of steps launched EAGERLY (kernel by kernel, ~33 launches, one read of the forward's counts in the middle) with the
+    # log read one step late -- what the step cost before it was recorded (round 3: 1.05-1.16 ms, bound by the host: ~0.9 ms of Python and
+    # launch overhead against 0.94 ms of kernels, matched per step but not per phase)
     pending, t1 = None, time.perf_counter()
     base_it = args.warmup + args.steps
     for it in range(base_it + 1, base_it + args.steps + 1):
-        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)
+        ps, loss, _ = tr.train_step(it, cams, pc, sim, mopt, background=bg)          # (eager: a captured step ends with its own read)
         if pending is not None:
             hist.append(float(pending))
         pending = ps
@@ -108,7 +108,8 @@ def run(args, dev=None):
            # the step is bound by the HOST (Python + launches: ~1.1 ms with a trivial scene): the mean moves with whatever else runs on
            # the box's cores; the median and the fastest decile of the same steps say what the code costs
            "median_ms": round(per_step[len(per_step) // 2] * 1e3, 3), "p10_ms": round(per_step[len(per_step) // 10] * 1e3, 3),
-           "log_one_step_late_ms": round(ms_deferred, 3),
+           "eager_ms": round(ms_deferred, 3), "captured": bool(captured),
+           "captured_stats": dict(pc._captured_step.stats) if getattr(pc, "_captured_step", None) is not None else None,
            "psnr_first": round(hist[0], 3), "psnr_last": round(hist[-1], 3),
            "config": {"workload": f"train_step analogue: V={sc['mesh_pos'].shape[1]} mesh nodes, P={args.P}, 3 cams "
                                   f"{args.res}x{args.res}, ResidualMeshSimulator + Kabsch transform + rasterizer + L1 + "

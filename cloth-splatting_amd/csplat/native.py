@@ -23,6 +23,7 @@ EXPORTS = {
     "csplat_abi_version": (_i, []),
     "csplat_last_error": (C.c_char_p, []),
     "csplat_debug_flags": (_i, [C.c_uint]),
+    "csplat_debug_flags_query": (C.c_uint, []),
     "csplat_debug_stamps": (_i, [_vp, _sz]),
     "csplat_geom_bytes": (_sz, [_i]),
     "csplat_image_bytes": (_sz, [_i, _i]),

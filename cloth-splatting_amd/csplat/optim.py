@@ -59,6 +59,68 @@ class GroupedAdam(torch.optim.Adam):
             return self.step()
         return self._fused_step()
 
+    # ---- the step as a launch that depends on NO per-step host value (csplat_adam_step_dev): for a training step recorded into a hipGraph
+    def captured_setup(self):
+        """(Re-)creates the device-side state a captured step reads: the step count (int32 [1], from the host-side counters, which must
+        agree over all parameters that have state) and the learning rates (double, one per tensor with state, in param_groups order).
+        Call it outside the capture, after at least one ordinary step() (the moments must exist)."""
+        items, counts = [], set()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                st = self.state.get(p, {})
+                if "exp_avg" not in st:
+                    continue
+                items.append((p, st, float(beta1), float(beta2), float(group["eps"]), group))
+                counts.add(int(st["step"].item()))
+        if not items:
+            raise RuntimeError("GroupedAdam.captured_setup: no optimizer state yet (take one ordinary step first)")
+        if len(counts) != 1 or len({it[2:5] for it in items}) != 1:
+            raise RuntimeError("GroupedAdam.captured_setup: the tensors must share one step count and one (beta1, beta2, eps)")
+        dev = items[0][0].device
+        self._cap = {"items": items, "state": torch.tensor([counts.pop()], dtype=torch.int32, device=dev),
+                     "lr": torch.zeros(len(items), dtype=torch.float64, device=dev),
+                     "lr_host": torch.zeros(len(items), dtype=torch.float64).pin_memory(), "lr_seen": None}
+        self.captured_refresh_lr()
+        return self._cap
+
+    def captured_refresh_lr(self):
+        """the groups' current learning rates -> the device table (a schedule edits param_groups[i]['lr'] on the host); no-op when unchanged"""
+        cap = self._cap
+        lrs = tuple(float(it[5]["lr"]) for it in cap["items"])
+        if lrs != cap["lr_seen"]:
+            cap["lr_host"].copy_(torch.tensor(lrs, dtype=torch.float64))
+            cap["lr"].copy_(cap["lr_host"], non_blocking=True)
+            cap["lr_seen"] = lrs
+
+    def step_captured(self, valid):
+        """the launch itself (record it under stream capture): every tensor of captured_setup() that has a gradient NOW; `valid` = a
+        uint32 device word (0 -> nothing is applied, the count does not advance)"""
+        cap = self._cap
+        items = [it for it in cap["items"] if it[0].grad is not None]
+        if len(items) != len(cap["items"]):
+            raise RuntimeError("GroupedAdam.step_captured: a tensor with optimizer state has no gradient in the captured step")
+        n = len(items)
+        ptrs = [(C.c_void_p * n)(*[t.data_ptr() for t in ts]) for ts in ([it[0] for it in items], [it[0].grad for it in items],
+                                                                          [it[1]["exp_avg"] for it in items], [it[1]["exp_avg_sq"] for it in items])]
+        for it in items:
+            g = it[0].grad
+            if not (g.is_contiguous() and g.dtype == torch.float32 and it[0].is_contiguous() and it[0].dtype == torch.float32):
+                raise RuntimeError("GroupedAdam.step_captured: fp32 contiguous parameters and gradients only")
+        numel = (C.c_int64 * n)(*[it[0].numel() for it in items])
+        dev = items[0][0].device
+        with _n.on_device(dev):
+            _n.check(_n.lib.csplat_adam_step_dev(_n.stream_handle(dev), n, C.cast(ptrs[0], C.c_void_p), C.cast(ptrs[1], C.c_void_p),
+                                                 C.cast(ptrs[2], C.c_void_p), C.cast(ptrs[3], C.c_void_p), C.cast(numel, C.c_void_p),
+                                                 _n.ptr(cap["lr"]), items[0][2], items[0][3], items[0][4], _n.ptr(cap["state"]),
+                                                 _n.ptr(valid)), "csplat_adam_step_dev")
+
+    def captured_advance_host(self):
+        """after a replay whose valid word was 1: the host-side step counters follow the device's"""
+        steps = [it[1]["step"] for it in self._cap["items"]]
+        torch._foreach_add_(steps, 1)
+        self.__dict__.pop("_step_cache", None)
+
     def zero_grad_now(self):
         """zero_grad(set_to_none=True) without the wrapper's bookkeeping"""
         for group in self.param_groups:

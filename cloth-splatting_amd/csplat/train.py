@@ -448,15 +448,19 @@ class SimulatorStep(torch.autograd.Function):
         return (None, dW1, db1, dW2, db2, dWo, dbo) + (None,) * 8
 
 
-def simulator_step(simulator, times, gaussians, opt, defer=False):
+def simulator_step(simulator, times, gaussians, opt, defer=False, static=None):
     """(vertices [T,V,3], regulariser loss) through SimulatorStep when the simulator is the time-conditioned residual MLP on the GPU and
     the fused regularisers apply; None otherwise (the caller composes forward_times + regularization).  defer=True: the regularisers'
-    kernel is queued, the caller MUST run launch_deferred() before the loss is consumed."""
+    kernel is queued, the caller MUST run launch_deferred() before the loss is consumed.  static = (code [T,K0], table rows [T,V,3]):
+    the parameter-free inputs of the camera times in buffers of the caller's (CapturedStep refills them between replays)."""
     from meshnet import graph_ops as go
     need = ("times_on_device", "input", "hidden", "output")
     if not all(hasattr(simulator, a) for a in need) or len(times) > 8 or len(times) == 0:
         return None
-    tt, enc, base = simulator.times_on_device(times)
+    if static is not None:
+        enc, base = static
+    else:
+        _tt, enc, base = simulator.times_on_device(times)
     if not go.sim_residual_applies(enc, simulator.input, simulator.hidden, simulator.output, base):
         return None
     ei = gaussians.mesh.edge_index
@@ -605,7 +609,8 @@ def _root_one(loss):
 
 
 def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT,
-               background=None, static=False, view_parallel=False, batched_views=True, densify_opt=None, time_allreduce=False):
+               background=None, static=False, view_parallel=False, batched_views=True, densify_opt=None, time_allreduce=False, captured=False,
+               _cap=None):
     """One optimisation step.  Returns (psnr, loss, stats) where stats holds what densification consumes.
     batched_views=True renders the step's cameras in one rasterizer call (gaussian_renderer.render_views).
     densify_opt: OptimizationParams-like namespace (+ cameras_extent, white_background) -> the reference's densification /
@@ -621,7 +626,13 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         the persistent flat buffer the `.grad` tensors are views of; the radii take one all-reduce(max).
     After the reduction every rank holds exactly the gradients and statistics of the one-rank step (up to summation order)
     and takes the same optimizer / densification decisions, so the replicas stay identical without exchanging parameters."""
-    if iteration % 1000 == 0:
+    if captured and _cap is None:     # the step as a replayed hipGraph (CapturedStep below); falls back to this function when it must
+        cs = gaussians.__dict__.get("_captured_step")
+        if cs is None or not cs.matches(simulator, meshnet_optimizer, pipe, opt, background):
+            cs = gaussians._captured_step = CapturedStep(gaussians, simulator, meshnet_optimizer, pipe, opt, background)
+        if not (static or view_parallel or not batched_views or densify_opt is not None):
+            return cs(iteration, viewpoint_cams)
+    if iteration % 1000 == 0 and _cap is None:
         gaussians.oneupSHdegree()
     _DEFERRED.clear()                 # (a launch queued by a step that raised before issuing it)
     all_cams = list(viewpoint_cams)
@@ -647,7 +658,8 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         # simulator for all cameras at once, and the regularisers recorded BEFORE the rasterizer: autograd runs
         # later-recorded nodes first, so the rasterizer's backward -- the long GPU work of the step -- is launched
         # first and the small launches of everything else are issued under it
-        head = simulator_step(simulator, [cam.time for cam in all_cams], gaussians, opt, defer=True) if gaussians.mesh.pos.is_cuda else None
+        head = simulator_step(simulator, [cam.time for cam in all_cams], gaussians, opt, defer=True,
+                              static=None if _cap is None else _cap["sim_in"]) if gaussians.mesh.pos.is_cuda else None
         if head is not None:      # simulator + regularisers: one autograd node (the regularisers' launch queued, see launch_deferred)
             deforms_all, reg = head
         else:
@@ -678,7 +690,7 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
     psnr_ = None
     if cams:
         image_tensor = stacked if stacked is not None else torch.cat(images, 0)
-        gt_image_tensor = _gt_stack(cams, image_tensor.device)
+        gt_image_tensor = _gt_stack(cams, image_tensor.device) if _cap is None else _cap["gt"]
         mask_tensor = torch.cat(masks, 0) if masks is not None else None
         w_img = 1.0 if len(cams) == n_total else len(cams) / n_total
         if _image_loss_fusable(image_tensor, gt_image_tensor, opt, mask_tensor) and reg.dtype == torch.float32:
@@ -723,12 +735,178 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         if densify_opt is not None and getattr(densify_opt, "bary_cleanup", 0) and iteration % densify_opt.bary_cleanup == 0:
             gaussians.cleanup_barycentric_coordinates()                                  # train_utils.py:306-307
         # (GroupedAdam.step_now / zero_grad_now: the same step without torch.optim's per-call wrapper; any other optimizer: its own)
-        getattr(gaussians.optimizer, "step_now", gaussians.optimizer.step)()
-        if not static:
-            getattr(meshnet_optimizer, "step_now", meshnet_optimizer.step)()
+        if _cap is not None:          # recorded under stream capture: step count, learning rates and the go / no-go word live on the device
+            gaussians.optimizer.step_captured(_cap["valid"])
+            meshnet_optimizer.step_captured(_cap["valid"])
+        else:
+            getattr(gaussians.optimizer, "step_now", gaussians.optimizer.step)()
+            if not static:
+                getattr(meshnet_optimizer, "step_now", meshnet_optimizer.step)()
         zg = getattr(gaussians.optimizer, "zero_grad_now", None)
         zg() if zg is not None else gaussians.optimizer.zero_grad(set_to_none=True)
         zg = getattr(meshnet_optimizer, "zero_grad_now", None)
         zg() if zg is not None else meshnet_optimizer.zero_grad()
     return psnr_, loss_value, dict(viewspace_grad=viewspace_grad, radii=radii, visibility_filter=visibility_filter,
                                    allreduce_ms=fg.last_allreduce_ms if fg is not None else 0.0)
+
+
+class CapturedStep:
+    """train_step recorded ONCE into a hipGraph and replayed (the reference times its step with an event pair around
+    the loop body, train.py:146,178 -- the GPU work of a step, which is what a replayed graph costs).
+
+    The eager step is bound by the host: ~33 launches of 5-300 us, ~25 us of Python and launch overhead each, and one read of the
+    forward's counts in the middle.  Recorded, the launches cost the host nothing -- which needs a step without a single per-step host
+    value in its launches:
+      * the rasterizer's forward is launched ON FAITH (csplat_forward_views_faith): both phases with capacities from the last eager
+        step's counts + 1/8, nothing read back; a device word `valid` says whether the counts fitted, every kernel of the second phase
+        and of the backward leaves an unfitting step alone, and BOTH Adam steps honour the same word (csplat_adam_step_dev: step count
+        and learning rates on the device too) -- a miss changes no parameter, no moment, no count;
+      * camera matrices, the simulator's time inputs and the ground-truth images live in buffers of this object that are refilled
+        between replays (only when the cameras changed);
+      * ONE host read per step, at its end: [valid, PSNR, loss, the views' counts] arrive in pinned memory through a copy node of the
+        graph.  valid == 0 -> the step is repeated eagerly (exact sizes) and the graph is re-recorded with new capacities at the next
+        call; counts within 3 % of a capacity re-record too, before a miss happens.
+    One graph per step SHAPE: (number of cameras, image size, field of view, number of Gaussians, active SH degree, parameter storage).
+    Falls back to the eager train_step for what it does not cover: masks, a static stage, view-parallel runs, densification steps."""
+
+    MARGIN = 8          # capacities = counts + counts / MARGIN (+ a constant)
+
+    def __init__(self, gaussians, simulator, meshnet_optimizer, pipe=DEFAULT_PIPE, opt=DEFAULT_OPT, background=None):
+        self.g, self.sim, self.mopt, self.pipe, self.opt, self.bg = gaussians, simulator, meshnet_optimizer, pipe, opt, background
+        self.graphs = {}
+        self.stats = {"eager": 0, "recorded": 0, "replayed": 0, "missed": 0, "rerecorded_early": 0}
+
+    def matches(self, simulator, meshnet_optimizer, pipe, opt, background):
+        return simulator is self.sim and meshnet_optimizer is self.mopt and pipe is self.pipe and opt is self.opt and background is self.bg
+
+    # ---- shape of a step
+    def _key(self, cams):
+        c0 = cams[0]
+        g = self.g
+        return (len(cams), int(c0.image_height), int(c0.image_width), float(c0.FoVx), float(c0.FoVy), int(g.num_gaussians),
+                int(g.active_sh_degree), tuple(int(p.data_ptr()) for p in g.parameters()),
+                tuple(int(p.data_ptr()) for p in self.sim.parameters()))
+
+    def _coverable(self, cams):
+        from .optim import GroupedAdam
+        return (len(cams) >= 2 and len(cams) <= 8 and all(getattr(c, "mask", None) is None for c in cams) and
+                len({(int(c.image_height), int(c.image_width), float(c.FoVx), float(c.FoVy)) for c in cams}) == 1 and
+                self.g.mesh.pos.is_cuda and isinstance(self.g.optimizer, GroupedAdam) and isinstance(self.mopt, GroupedAdam) and
+                not (int(_n.lib.csplat_debug_flags_query()) & (2 | 128 | 256 | 512)) and      # (global sort, per-view launches, reproducible K7)
+                all(hasattr(self.sim, a) for a in ("times_on_device", "input", "hidden", "output")))
+
+    def _eager(self, iteration, cams):
+        self.stats["eager"] += 1
+        return train_step(iteration, cams, self.g, self.sim, self.mopt, self.pipe, self.opt, self.bg)
+
+    # ---- static inputs
+    def _fill(self, st, cams):
+        """the cameras of this call -> the graph's input buffers (skipped when they are the objects of the previous call)"""
+        if st["cams_seen"] is not None and len(st["cams_seen"]) == len(cams) and all(a is b for a, b in zip(st["cams_seen"], cams)) and \
+                st["times_seen"] == tuple(float(c.time) for c in cams):
+            return
+        dev = st["gt"].device
+        for i, c in enumerate(cams):
+            st["view"][i].copy_(c.world_view_transform.to(dev).reshape(16), non_blocking=True)
+            st["proj"][i].copy_(c.full_proj_transform.to(dev).reshape(16), non_blocking=True)
+            st["campos"][i].copy_(c.camera_center.to(dev).reshape(3), non_blocking=True)
+            st["gt"][i].copy_(c.original_image.to(dev), non_blocking=True)
+        _tt, enc, base = self.sim.times_on_device([c.time for c in cams])
+        st["enc"].copy_(enc)
+        st["base"].copy_(base.reshape(st["base"].shape))
+        st["cams_seen"], st["times_seen"] = list(cams), tuple(float(c.time) for c in cams)
+
+    def _record(self, key, cams, caps):
+        import diff_gaussian_rasterization as dgr
+        g = self.g
+        dev = g.face_bary.device
+        T = len(cams)
+        c0 = cams[0]
+        H, W = int(c0.image_height), int(c0.image_width)
+        _tt, enc, base = self.sim.times_on_device([c.time for c in cams])
+        st = {"view": torch.zeros(T, 16, device=dev), "proj": torch.zeros(T, 16, device=dev), "campos": torch.zeros(T, 3, device=dev),
+              "gt": torch.zeros(T, 3, H, W, device=dev), "enc": torch.zeros_like(enc), "base": torch.zeros_like(base),
+              "valid": torch.zeros(1, dtype=torch.int32, device=dev), "cams_seen": None, "times_seen": None, "caps": tuple(int(c) for c in caps)}
+        scams = [SimpleNamespace(image_height=H, image_width=W, FoVx=c0.FoVx, FoVy=c0.FoVy, world_view_transform=st["view"][i].view(4, 4),
+                                 full_proj_transform=st["proj"][i].view(4, 4), camera_center=st["campos"][i], time=float(cams[i].time),
+                                 original_image=st["gt"][i], mask=None) for i in range(T)]
+        self._fill(st, cams)
+        g.optimizer.captured_setup()
+        self.mopt.captured_setup()
+        st["host"] = torch.zeros(3 + 3 * T, dtype=torch.float32).pin_memory()
+        for p in list(g.parameters()) + list(self.sim.parameters()):
+            p.grad = None
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        faith = {"caps": st["caps"], "valid": st["valid"]}
+        dgr.FAITH = faith
+        try:
+            with torch.cuda.graph(graph):
+                ps, loss, stats = train_step(0, scams, g, self.sim, self.mopt, self.pipe, self.opt, self.bg,
+                                             _cap={"sim_in": (st["enc"], st["base"]), "gt": st["gt"], "valid": st["valid"]})
+                info = torch.stack(faith["info"]).reshape(-1).to(torch.float32)        # (counts < 2^24: exact in fp32)
+                packed = torch.cat([st["valid"].to(torch.float32), ps.reshape(1).to(torch.float32), loss.reshape(1).to(torch.float32), info])
+                st["host"].copy_(packed, non_blocking=True)
+        finally:
+            dgr.FAITH = None
+        st.update(graph=graph, psnr=ps, loss=loss, stats=stats, packed=packed)
+        self.graphs[key] = st
+        self.stats["recorded"] += 1
+        return st
+
+    def _caps_from_counts(self, counts):
+        R = max(int(c[0]) for c in counts)
+        L = max(int(c[1]) for c in counts)
+        B = max(int(c[2]) for c in counts)
+        cap_l = 8192
+        return (R + R // self.MARGIN + 4096, min(L + L // 4 + 64, cap_l), B + B // self.MARGIN + 16)
+
+    def _counts_of_last_eager(self):
+        import diff_gaussian_rasterization as dgr
+        return torch.stack(list(dgr.LAST_INFO)).cpu().tolist() if dgr.LAST_INFO else None
+
+    def __call__(self, iteration, cams):
+        cams = list(cams)
+        # (a step that raises the SH degree, and whatever the graph does not cover, is an ordinary train_step)
+        if iteration % 1000 == 0 or not self._coverable(cams):
+            return self._eager(iteration, cams)
+        key = self._key(cams)
+        st = self.graphs.get(key)
+        if st is None:
+            # first step of a shape: eager -- it creates the optimizer state and leaves the exact counts the capacities are taken from
+            out = self._eager(iteration, cams)
+            counts = self._counts_of_last_eager()
+            if counts is not None:
+                if len(self.graphs) >= 8:
+                    self.graphs.clear()
+                self.graphs[key] = {"graph": None, "pending_caps": self._caps_from_counts(counts)}
+            return out
+        if st.get("graph") is None:
+            st = self._record(key, cams, st["pending_caps"])
+        else:
+            self._fill(st, cams)
+        self.g.optimizer.captured_refresh_lr()
+        self.mopt.captured_refresh_lr()
+        st["graph"].replay()
+        torch.cuda.current_stream(st["gt"].device).synchronize()          # the ONE host wait of the step: its log line is in pinned memory
+        host = st["host"]
+        if float(host[0]) != 1.0:           # the counts outgrew the capacities: nothing was applied -- repeat eagerly, re-record next time
+            self.stats["missed"] += 1
+            self.graphs.pop(key, None)
+            out = self._eager(iteration, cams)
+            counts = self._counts_of_last_eager()
+            if counts is not None:
+                self.graphs[key] = {"graph": None, "pending_caps": self._caps_from_counts(counts)}
+            return out
+        self.stats["replayed"] += 1
+        self.g.optimizer.captured_advance_host()
+        self.mopt.captured_advance_host()
+        T = len(cams)
+        counts = host[3:3 + 3 * T].view(T, 3)
+        caps = st["caps"]
+        if float(counts[:, 0].max()) > 0.97 * caps[0] or float(counts[:, 1].max()) > 0.97 * caps[1] or float(counts[:, 2].max()) > 0.97 * caps[2]:
+            # close to a capacity: re-record with room before a step is lost (the results of this replay are final -- copies are returned)
+            self.graphs[key] = {"graph": None, "pending_caps": self._caps_from_counts(counts.tolist())}
+            self.stats["rerecorded_early"] += 1
+            return host[1].clone(), host[2].clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st["stats"].items()}
+        return host[1], host[2], dict(st["stats"])

@@ -977,7 +977,10 @@ __device__ __forceinline__ bool box_hit(float2 c, float cut2, float4 co, float b
     return qmin - 1e-5f * sabs <= tau * 1.001f + 1e-3f;
 }
 
-constexpr int SEG = 256;   // tile-list entries per backward segment (multiple of 64)
+#ifndef CSPLAT_SEG
+#define CSPLAT_SEG 256
+#endif
+constexpr int SEG = CSPLAT_SEG;   // tile-list entries per backward segment (multiple of 64)
 
 // per-tile segment plan: seg_offset[t] = first segment slot of tile t (exclusive scan of ceil(n_t / SEG)),
 // slot_tile[slot] = owning tile.  One workgroup; tiles are few (2500 at 800x800).
@@ -1182,13 +1185,13 @@ struct Trip { float4 a, b; float2 c; int pos; uint32_t id; };   // the lane's su
 // over a byte strip, four 64-bit selects and their addresses cost the survivor-column K6 22 VGPRs at the flush point, i.e. its fifth wave)
 __device__ __forceinline__ void bbits_mark(uint32_t *s_bits, int pos) { atomicOr(&s_bits[(pos & (SEG - 1)) >> 5], 1u << (pos & 31)); }
 __device__ __forceinline__ void bbits_flush(uint32_t *s_bits, unsigned long long *__restrict__ bbits, size_t slot, int blk, int lane) {
-    if (lane < 8) {
-        reinterpret_cast<uint32_t *>(bbits)[(slot * 16 + (size_t)blk) * 8 + lane] = s_bits[lane];
+    if (lane < SEG / 32) {
+        reinterpret_cast<uint32_t *>(bbits)[(slot * 16 + (size_t)blk) * (SEG / 32) + lane] = s_bits[lane];
         s_bits[lane] = 0u;
     }
 }
 __device__ __forceinline__ void bbits_zero(unsigned long long *__restrict__ bbits, size_t slot, int blk, int lane) {
-    if (lane < 8) reinterpret_cast<uint32_t *>(bbits)[(slot * 16 + (size_t)blk) * 8 + lane] = 0u;
+    if (lane < SEG / 32) reinterpret_cast<uint32_t *>(bbits)[(slot * 16 + (size_t)blk) * (SEG / 32) + lane] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------- K6
@@ -1592,49 +1595,19 @@ __device__ __forceinline__ float bfly(float a, float b, bool s) {
     return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
 }
 
-// the end of K7: the segment's LDS records -> the per-Gaussian records.  The (up to ten) rounds of a wave are independent: all LDS reads
-// and all id loads are issued before the first atomic, so the wave waits for ONE memory round trip instead of one per round
-template <bool DET, bool CLEAR = false>
-__device__ __forceinline__ void flush_segment(float *s_acc, int cnt, int w, int lane, int quad, uint32_t first,
-                                              const uint32_t *__restrict__ ids_sorted, float *__restrict__ acc, float *__restrict__ det,
-                                              const uint32_t *lds_ids = nullptr) {
-    // lds_ids: the segment's ids already staged in LDS by the caller (entry e at lds_ids[e]) -- the flush is then LDS reads -> atomics
-    const int sub = lane / 9, tq = lane - sub * 9;
-    constexpr int ROUNDS = (SEG + 27) / 28;
-    float sv_[ROUNDS];
-    uint32_t id_[ROUNDS];
-#pragma unroll
-    for (int k = 0; k < ROUNDS; k++) {
-        const int e = w * 7 + 28 * k + sub;
-        const bool ok = lane < 63 && e < cnt;
-        if (DET) {
-            sv_[k] = ok ? ((s_acc[e * 9 + tq] + s_acc[SEG * 9 + e * 9 + tq]) + s_acc[2 * SEG * 9 + e * 9 + tq]) + s_acc[3 * SEG * 9 + e * 9 + tq] : 0.f;
-            id_[k] = ok ? 1u : 0u;
-        } else {
-            sv_[k] = ok ? s_acc[e * 9 + tq] : 0.f;
-            if (CLEAR && sv_[k] != 0.f) s_acc[e * 9 + tq] = 0.f;       // (the thread that read a cell leaves it clean for the segment after next)
-            id_[k] = sv_[k] != 0.f ? (lds_ids ? lds_ids[e] : ids_sorted[first + e]) : 0xFFFFFFFFu;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < ROUNDS; k++) {
-        const int e = w * 7 + 28 * k + sub;
-        if (DET) {
-            if (id_[k]) det[((size_t)(first + e) * 4 + quad) * 9 + tq] = sv_[k];
-        } else if (id_[k] != 0xFFFFFFFFu) {
-            atomicAdd(acc + (size_t)id_[k] * ACC_STRIDE + tq, sv_[k]);
-        }
-    }
-}
-
-// grid: one 4-wave workgroup per (segment slot, group of four live blocks); wave w = one 4x4 block.  DET: every wave
-// keeps its own LDS records and the flush stores the four-wave sums (fixed order) per (list entry, quadrant) for
-// k_det_reduce -- the bit-reproducible mode (csplat_debug_flags bit 8); default: one shared LDS record per entry,
-// flushed with float atomics.
-// Round 4: a wave's survivors are the entries of the segment its block BLENDED (bbits, written by K6 -- see bbits_flush), not the
-// entries that reach the block: the four ballot words arrive with one scalar load, the whole segment's survivor list is laid out in the
-// wave's LDS ring before the first group (no mask loads, no ingest inside the loop, a counted loop), and every group of four does
-// arithmetic that lands in a gradient.
+// grid: one 4-wave workgroup per (segment slot, group of four live blocks); wave w = one 4x4 block.  The four waves of a workgroup
+// share nothing but the launch geometry: no LDS records, no barrier.
+// Round 4, first step: a wave's survivors are the entries of the segment its block BLENDED (bbits, written by K6 -- see bbits_flush), not
+// the entries that reach the block: the four ballot words arrive with one scalar load, the whole segment's survivor list is laid out in
+// the wave's LDS ring before the first group (no mask loads, no ingest inside the loop, a counted loop), and every group of four does
+// arithmetic that lands in a gradient: 280 -> 259 us for the four views of a step.
+// Second step: the nine row sums of a survivor go STRAIGHT to the Gaussian's 64-byte record (one global float atomic request per (entry,
+// block): the nine lanes that hold the sums address one record).  Rounds 1-3 added them into an LDS record per list entry first (shared
+// by the workgroup's four blocks, ds_add_f32), zeroed before and flushed behind a barrier -- a quarter of the global requests, but: an
+// LDS float atomic per group on a unit the CU's 32 waves share, 9 KB of zeroing and ten flush rounds per workgroup, and every wave waiting
+// at the barrier for the slowest of its four blocks (8.7 k of a live wave's 46 k cycles, tools/k7_stamps.py).  259 -> 241 us (same-box
+// A/B, three alternations).  DET (csplat_debug_flags bit 8, bit-reproducible): the sums are STORED, one 9-float record per (list entry,
+// block) -- each pair is visited exactly once -- and k_det_reduce adds every Gaussian's records in emission order.
 constexpr int RING7 = SEG;     // a segment's survivors of one block, padded to a multiple of four: at most SEG
 template <bool DET>
 __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -1647,12 +1620,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                                                    const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
                                                    float *__restrict__ acc, float *__restrict__ det,
                                                    unsigned long long *stamp = nullptr) {
-    __shared__ float s_acc[(DET ? 4 : 1) * SEG * 9];
     __shared__ int s_ring[4][RING7];
-    __shared__ uint32_t s_ids[DET ? 1 : SEG];   // the segment's Gaussian ids, for the flush
-#ifdef K7_T_LDS
-    __shared__ __attribute__((aligned(16))) float s_gather[4][64];
-#endif
     const int wg = blockIdx.x;
     // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
     unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 : nullptr;
@@ -1685,9 +1653,11 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const bool has_block = kth < n_live;
     const int blk = has_block ? __builtin_ctz(m_) : 0;
     // the entries of this segment the block blended: four 64-bit words, one scalar load
-    const unsigned long long *bw = bbits + ((size_t)slot * 16 + (size_t)blk) * 4;
-    unsigned long long sw[4] = {0ull, 0ull, 0ull, 0ull};
-    if (has_block) { sw[0] = bw[0]; sw[1] = bw[1]; sw[2] = bw[2]; sw[3] = bw[3]; }
+    constexpr int NW = SEG / 64;
+    const unsigned long long *bw = bbits + ((size_t)slot * 16 + (size_t)blk) * NW;
+    unsigned long long sw[NW];
+#pragma unroll
+    for (int c = 0; c < NW; c++) sw[c] = has_block ? bw[c] : 0ull;
     const int px = (tile % gx) * CSPLAT_TILE + (blk & 3) * 4 + (l16 & 3);
     const int py = (tile / gx) * CSPLAT_TILE + (blk >> 2) * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
@@ -1696,11 +1666,13 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
-    const int seg_hi = min(n, seg_lo + SEG);
     mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi, bbits) has returned
     // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint and (one per
     // thread) the ids the flush will need are requested together, BEFORE the records are zeroed and the barrier
-    const bool live = (sw[0] | sw[1] | sw[2] | sw[3]) != 0ull;
+    unsigned long long any_ = 0ull;
+#pragma unroll
+    for (int c = 0; c < NW; c++) any_ |= sw[c];
+    const bool live = any_ != 0ull;
     const size_t HW = (size_t)H * W;
     int ncontrib = 0;
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, oc0 = 0.f, oc1 = 0.f, oc2 = 0.f;
@@ -1713,19 +1685,12 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         }
         ck = ckpt[(size_t)slot * 256 + blk * 16 + l16];
     }
-    uint32_t my_id = 0u;
-#ifdef K7_DIRECT
-    constexpr bool LDS_ACC = DET;
-#else
-    constexpr bool LDS_ACC = true;
-#endif
-    if (LDS_ACC && !DET && seg_lo + (int)threadIdx.x < seg_hi) my_id = ids_sorted[rx + seg_lo + threadIdx.x];
     // the wave's survivor list: list positions of the set bits, in order, padded with -1 to a multiple of four (wave-private LDS)
     int *ring = s_ring[w];
     int total = 0;
     if (live) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < NW; c++) {
             const unsigned long long cur = sw[c];
             if ((cur >> lane) & 1ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u));
@@ -1738,13 +1703,7 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         total += pad;
     }
     const int ngroups = total >> 2;
-    if (LDS_ACC) {
-        for (int t = threadIdx.x; t < (DET ? 4 : 1) * SEG * 9; t += 256) s_acc[t] = 0.f;
-        if (!DET) s_ids[threadIdx.x] = my_id;
-        __syncthreads();
-    }
     mark(2);
-    float *my_acc = s_acc + (DET ? w * SEG * 9 : 0);
     if (live) {
         const float OD = oc0 * dp0 + oc1 * dp1 + oc2 * dp2;
         float T = 1.f, S = 0.f;
@@ -1759,17 +1718,11 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
         const bool red_active = !lb0 || l16 == 1;
         const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
-#ifdef K7_S_MFMA
-        // A[m = lane & 15][k = lane >> 4] of the prefix-sum MFMA: rows m = 4 j: 1 for k <= j; rows m = 4 j + 1: all ones; other rows unused
-        const float mfma_a = (l16 & 3) == 0 ? (r <= (l16 >> 2) ? 1.f : 0.f) : ((l16 & 3) == 1 ? 1.f : 0.f);
-#endif
         auto fetch = [&](Trip &t, int k) {
             t.pos = ring[4 * k + r];
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
             t.a = recA[ri]; t.b = recB[ri]; t.c.x = reinterpret_cast<const float *>(recC)[2 * (size_t)ri];   // (c.y, the depth, is K6's)
-#ifdef K7_DIRECT
-            t.id = t.pos >= 0 ? ids_sorted[rx + (uint32_t)t.pos] : 0u;
-#endif
+            if (!DET) t.id = t.pos >= 0 ? ids_sorted[rx + (uint32_t)t.pos] : 0u;
         };
         auto process = [&](const Trip &t) {
             const float dx = t.a.x - fx, dy = t.a.y - fy;
@@ -1779,34 +1732,15 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             const bool act = t.pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
             const float al = act ? a : 0.f;
             const float F = 1.f - al;
-#ifdef K7_T_LDS
-            // the pixel's four factors through a wave-private LDS strip: one 4-byte write, one 16-byte read (LDS ops of a wave execute in
-            // order: the next group's write cannot pass this read)
-            s_gather[w][l16 * 4 + r] = F;
-            const float4 gq = *reinterpret_cast<const float4 *>(&s_gather[w][l16 * 4]);
-            const Row4 g = {gq.x, gq.y, gq.z, gq.w};
-#else
             const Row4 g = rows_allgather(F);
-#endif
             const float P1 = T * g.v0, P2 = P1 * g.v1, P3 = P2 * g.v2, P4 = P3 * g.v3;
             const float Tr = rowsel(r, T, P1, P2, P3);
             const float gdot = t.b.z * dp0 + t.b.w * dp1 + t.c.x * dp2;
             const float dchannel_dcolor = al * Tr;
-#ifdef K7_S_MFMA
-            // the running sum S over the group's four survivors on the MATRIX pipe: v_mfma_f32_16x16x4_f32 contracts over lane >> 4 -- the
-            // survivor row -- with the lane's value as B[k = row][n = pixel]; A[m][k] (a per-lane constant) makes output row 4 r the
-            // inclusive prefix over the rows <= r and output row 4 r + 1 the group's total, and a lane's accumulator registers are exactly
-            // D[4 (lane >> 4) + i][lane & 15]: Sr and the new S without an all-gather, four dependent adds and three row selects
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            const f4v dS = __builtin_amdgcn_mfma_f32_16x16x4f32(mfma_a, gdot * dchannel_dcolor, (f4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const float Sr = S + dS[0];
-            T = P4; S = S + dS[1];
-#else
             const Row4 gw = rows_allgather(gdot * dchannel_dcolor);
             const float S1 = S + gw.v0, S2 = S1 + gw.v1, S3 = S2 + gw.v2, S4 = S3 + gw.v3;
             const float Sr = rowsel(r, S1, S2, S3, S4);
             T = P4; S = S4;
-#endif
             const float dL_dalpha = act ? Tr * gdot - (OD - Sr) * __builtin_amdgcn_rcpf(F) : 0.f;
             const float dL_dG = t.b.y * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
@@ -1833,37 +1767,13 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             const float tot = lb0 ? l8 : c0;
             // (every survivor of the list was blended at one of the block's pixels: the row always has something to add, padding aside)
             if (red_active && t.pos >= 0) {
-#ifdef K7_DIRECT
-                if (!DET) atomicAdd(acc + (size_t)t.id * ACC_STRIDE + red_t, tot);
-                else
-#endif
-                {
-                float *cell = my_acc + (t.pos - seg_lo) * 9 + red_t;
-                if (DET) *cell = tot;                  // one (entry, block) pair is visited exactly once
-                else atomicAdd(cell, tot);             // ds_add_f32: the four blocks of the workgroup meet here
-                }
+                if (DET) det[((size_t)(rx + (uint32_t)t.pos) * 16 + (size_t)blk) * 9 + red_t] = tot;      // one (entry, block) pair is visited exactly once
+                else atomicAdd(acc + (size_t)t.id * ACC_STRIDE + red_t, tot);                          // nine lanes, one 64-byte record
             }
         };
         // software pipeline, TWO groups in flight: the records of group k+2 are requested when group k has been composited.  (Three in
         // flight -- K6's depth -- cost 11 more registers: 67 VGPRs = 7 waves per SIMD; two = 57 VGPRs = 8 waves: 306 -> 294 us, same-box
         // A/B, three alternations.  Forcing the three-deep form under 64 registers spills 7 of them: 365 us.)
-#ifdef K7_DEPTH3
-        Trip ta, tb, tc;
-        fetch(ta, 0);
-        if (ngroups > 1) fetch(tb, 1);
-        if (ngroups > 2) fetch(tc, 2);
-        mark(4);
-        for (int k = 0; k < ngroups; k += 3) {
-            process(ta);
-            if (k + 3 < ngroups) fetch(ta, k + 3);
-            if (k + 1 >= ngroups) break;
-            process(tb);
-            if (k + 4 < ngroups) fetch(tb, k + 4);
-            if (k + 2 >= ngroups) break;
-            process(tc);
-            if (k + 5 < ngroups) fetch(tc, k + 5);
-        }
-#else
         Trip ta, tb;
         fetch(ta, 0);
         if (ngroups > 1) fetch(tb, 1);
@@ -1876,15 +1786,9 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             process(tb);
             if (k + 3 < ngroups) fetch(tb, k + 3);
         }
-#endif
     }
     mark(5);                                                            // this wave's groups are done
-    if (!LDS_ACC) return;          // (direct form: every row's sums went straight to the per-Gaussian records)
-    __syncthreads();
     mark(6);
-    // flush: 7 list entries x 9 values per wave-instruction, so that an entry's 36 bytes leave as one atomic request.  (Retiring the waves
-    // that are done and letting the last one flush -- no barrier -- was measured in round 3: 318-321 against 308-312 us.)
-    flush_segment<DET>(s_acc, seg_hi - seg_lo, w, lane, quad, rx + (uint32_t)seg_lo, ids_sorted, acc, det, DET ? nullptr : s_ids);
     mark(7);
     if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)total; my_stamp[9] = 1ull; }
 }
@@ -1961,9 +1865,9 @@ __global__ __launch_bounds__(256) void k_det_reduce(int P, Cam cam, const float2
                     const uint64_t k = ((keys_sorted[mid] & 0xFFFFFFFFull) << 32) | ids_sorted[mid];
                     if (k < want) lo = mid + 1; else hi = mid;
                 }
-                for (int q = 0; q < 4; q++)
+                for (int q = 0; q < 16; q++)
 #pragma unroll
-                    for (int t = 0; t < 9; t++) s[t] += det[((size_t)lo * 4 + q) * 9 + t];
+                    for (int t = 0; t < 9; t++) s[t] += det[((size_t)lo * 16 + q) * 9 + t];
             }
     }
 #pragma unroll
@@ -2561,7 +2465,7 @@ size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 
 //          4x4 pixel block, written by K6: K7 drops the (segment, quadrant) workgroups behind it on ONE scalar load) | 3 slot_tile i32[slots]
 //          | 4 ckpt float4[slots][16 blocks][16 pixels]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
 //          | 5 mask16 u16[R+1] | 6 recA float4[R+1] | 7 recB float4[R+1] | 8 recC float2[R+1]   (entry R = the null record)
-//          | 9 bbits u64[slots][16 blocks][4]: per segment and block, which of the segment's 256 entries the block BLENDED (K6 -> K7)
+//          | 9 bbits u64[slots][16 blocks][SEG / 64]: per segment and block, which of the segment's 256 entries the block BLENDED (K6 -> K7)
 constexpr int B_NFIELDS = 10;
 size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
@@ -2576,7 +2480,7 @@ size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     off[7] = off[6] + align256((n + 1) * 16);
     off[8] = off[7] + align256((n + 1) * 16);
     off[9] = off[8] + align256((n + 1) * 8);
-    return off[9] + align256(slots * 16 * 4 * 8);
+    return off[9] + align256(slots * 16 * (SEG / 8));
 }
 // temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
 size_t temp_offsets(int64_t R, size_t *off) {
@@ -2664,6 +2568,7 @@ extern "C" {
 
 int csplat_abi_version(void) { return CSPLAT_ABI_VERSION; }
 int csplat_debug_flags(unsigned flags) { g_debug_flags = flags; return 0; }
+unsigned csplat_debug_flags_query(void) { return g_debug_flags; }
 // measurement hook: a device buffer that the batched row-form K7 fills with s_memtime stamps (12 u64 per workgroup, launch order
 // [view][workgroup]); NULL switches it off.  Not part of the operator interface.
 int csplat_debug_stamps(void *buf, size_t bytes) { g_stamp_buf = (unsigned long long *)buf; g_stamp_words = bytes / 8; return 0; }
@@ -2675,7 +2580,7 @@ size_t csplat_binning_bytes(int64_t R, int W, int H) { size_t off[B_NFIELDS]; re
 size_t csplat_temp_bytes(int P, int64_t R, int W, int H) { (void)P; (void)W; (void)H; size_t off[5]; return temp_offsets(R, off); }
 // backward scratch: the per-Gaussian records; in the bit-reproducible mode (csplat_debug_flags bit 8) also one 9-float record
 // per (list entry, quadrant)
-static size_t det_bytes(int64_t R) { return align256((size_t)(R > 0 ? R : 1) * 4 * 9 * 4); }
+static size_t det_bytes(int64_t R) { return align256((size_t)(R > 0 ? R : 1) * 16 * 9 * 4); }
 size_t csplat_backward_scratch_bytes(int P, int64_t R) {
     return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4) + ((g_debug_flags & 256u) ? det_bytes(R) : 0);
 }
@@ -3033,7 +2938,7 @@ static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_
         const FwdTicket &t = g_tickets[tk[i]];
         if (!t.can_bucket || t.P != a.P || t.W != a.W || t.H != a.H || t.P <= 0) return 0;
     }
-    const int P = a.P, W = a.W, H = a.H;
+    const int P = a.P, W = a.W, H = a.H, tiles = a.tiles;
     const uint32_t cap = tile_sort_cap();
     uint32_t info[P2_MAX_VIEWS][3];
     bool have_info = false;
@@ -3283,7 +3188,7 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with
     // (with_k7 = false: K7 of all views was launched as one batch by the caller)
     const bool det_mode = (g_debug_flags & 256u) != 0;
     float *det = det_mode ? (float *)((char *)scratch + align256((size_t)P * ACC_STRIDE * 4)) : nullptr;
-    if (with_k7 && det_mode) HIP_TRY(hipMemsetAsync(det, 0, (size_t)(R > 0 ? R : 1) * 4 * 9 * 4, s));
+    if (with_k7 && det_mode) HIP_TRY(hipMemsetAsync(det, 0, (size_t)(R > 0 ? R : 1) * 16 * 9 * 4, s));
     else if (with_k7) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
     if (with_k7) {
         ProfScope ps(PROF_K7, s);

@@ -185,6 +185,14 @@ _side_streams = {}
 # capacities before the counts were read and the counts fitted; "miss" = they did not fit and the phase was repeated with exact sizes;
 # "wait" = no history for this (image size, P) yet (or speculation off): the counts were read first
 SPEC_STATS = {"hit": 0, "miss": 0, "wait": 0}
+# the device words (int32 [3] views into the IMAGE chunks: tile instances, longest tile list, non-empty tiles) of the last batched
+# forward, per view -- what a caller sizes a launch on faith from (one .cpu() read at a moment of its choosing)
+LAST_INFO = []
+# Launch ON FAITH (csplat.train.CapturedStep): when set to a dict {"caps": (R, L, B), "valid": uint32 tensor [1]}, the batched forward
+# launches both phases with those capacities and reads NOTHING back (csplat_forward_views_faith) -- the form a hipGraph capture can
+# record.  The forward leaves in the dict: "info" = per view an int32 [3] VIEW of the device words holding (tile instances, longest tile
+# list, non-empty tiles), to be read whenever the caller syncs anyway.
+FAITH = None
 
 
 def _view_streams(dev, n, main):
@@ -253,9 +261,19 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         # capacities: everything below that does not need the counts -- the output lists, the backward plan -- is host work done
         # while the GPU runs K1..K6, instead of after a ~45 us wait for K1 / K2
         pending = C.c_int(0)
-        with _n.on_device(dev):
-            rc = _n.lib.csplat_forward_views_deferred(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream, C.byref(pending))
-        _n.check(rc, "csplat_forward_views_deferred")
+        faith = FAITH
+        if faith is not None:
+            caps = (C.c_uint32 * 3)(*[int(c) for c in faith["caps"]])
+            with _n.on_device(dev):
+                rc = _n.lib.csplat_forward_views_faith(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream, C.cast(caps, C.c_void_p),
+                                                       _n.ptr(faith["valid"]))
+            _n.check(rc, "csplat_forward_views_faith")
+            off = int(_n.lib.csplat_image_info_offset(views[0].W, views[0].H))
+            faith["info"] = [chunks[i][_n_IMAGE][off:off + 12].view(torch.int32) for i in range(V)]
+        else:
+            with _n.on_device(dev):
+                rc = _n.lib.csplat_forward_views_deferred(V, C.cast(arr, C.c_void_p), cb, main.cuda_stream, C.byref(pending))
+            _n.check(rc, "csplat_forward_views_deferred")
         try:
             return _RasterizeGaussiansBatch._finish_forward(ctx, views, arr, chunks, flat, stacked, colors if stacked else None, dev, main,
                                                             pending, cb)
@@ -296,7 +314,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             # the GPU is busy with K1..K6 of the views right now: prepare the backward call in its shadow
             ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
-        if not pending.value:
+        if not pending.value and FAITH is None:
             SPEC_STATS["wait"] += 1
         if pending.value:
             relaunched = C.c_int(0)
@@ -317,6 +335,9 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 for a, i in enumerate(ctx.plan["active"]):
                     ctx.plan["sub"][a].num_rendered = arr[i].num_rendered
                     ctx.plan["sub"][a].busy_tiles = arr[i].busy_tiles
+        if FAITH is None and len({(v.W, v.H) for v in views}) == 1 and all(_n_IMAGE in c for c in chunks):
+            off = int(_n.lib.csplat_image_info_offset(views[0].W, views[0].H))
+            LAST_INFO[:] = [chunks[i][_n_IMAGE][off:off + 12].view(torch.int32) for i in range(V)]
         return tuple(outs)
 
     @staticmethod

@@ -64,6 +64,7 @@ int csplat_abi_version(void);
  * block masks by blockIdx.y); those forms left the library in round 4 (history: commit 809fd4b) and the bits are
  * ignored.  The word is process-global and meant to be set between calls, not concurrently with them. */
 int csplat_debug_flags(unsigned flags);
+unsigned csplat_debug_flags_query(void);
 /* measurement hook (not part of the operator interface): a device buffer the batched compositing backward fills with s_memtime stamps,
  * 12 uint64 per workgroup in launch order [view][workgroup] (tools/k7_stamps.py); NULL / 0 switches it off */
 int csplat_debug_stamps(void *device_buffer, size_t bytes);

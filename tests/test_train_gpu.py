@@ -633,3 +633,99 @@ def test_fused_gaussian_activations_match_the_properties():
     assert float(c[0].grad.abs().max()) == 0.0 and float(c[3].grad.abs().max()) == 0.0
     assert float((c[1].grad - b[1].grad).abs().max()) <= 1e-6 * float(b[1].grad.abs().max())
 
+
+
+def _captured_fixture(seed=3):
+    import bench_train as bt
+    from csplat import train as tr
+    from csplat.optim import GroupedAdam
+    from gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    sc, pc, sim = bt.build(P=4000, W=160, H=128, grid=16, n_times=6, dev=dev)
+    with torch.no_grad():
+        pc._scaling.add_(0.9)
+        sim.output.weight.copy_(1e-3 * torch.randn_like(sim.output.weight))
+    bg = torch.ones(3, device=dev)
+    times = [0.2, 0.4, 0.6]
+    with torch.no_grad():
+        keep = pc._features_dc.detach().clone()
+        pc._features_dc.add_(0.5 * torch.randn_like(pc._features_dc))
+        targets = [render(c, pc, sim, tr.DEFAULT_PIPE, bg).render.clamp(0, 1).clone() for c in bt.cameras(sc, times, dev)]
+        pc._features_dc.copy_(keep)
+    cams = bt.cameras(sc, times, dev, targets)
+    pc.training_setup(feature_lr=0.01)
+    mopt = GroupedAdam(sim.parameters(), lr=3e-4)
+    return pc, sim, mopt, cams, bg
+
+
+def test_captured_train_step_equals_the_eager_step():
+    """csplat.train.CapturedStep (train_step(captured=True)): the step recorded once into a hipGraph -- forward launched on faith
+    (csplat_forward_views_faith), Adam's step count / learning rates / go word on the device (csplat_adam_step_dev), ONE host read at the
+    end -- against the eager train_step from the same initial state, eight steps: PSNR and loss per step, the densification statistics,
+    every parameter and both Adam moments at the end (only K7's float-atomic order differs between two runs: 1e-5 of scale), the host-side
+    step counters.  Reference step: scene_reconstruction/train_utils.py:240-321, timed as train.py:146,178."""
+    from csplat import train as tr
+    runs = {}
+    for mode in ("eager", "captured"):
+        pc, sim, mopt, cams, bg = _captured_fixture()
+        log = []
+        for it in range(1, 9):
+            ps, loss, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, captured=(mode == "captured"))
+            log.append((float(ps), float(loss), stats["radii"].clone(), stats["viewspace_grad"].clone(), stats["visibility_filter"].clone()))
+        torch.cuda.synchronize()
+        params = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
+        moments = [pc.optimizer.state[p]["exp_avg"].clone() for p in pc.parameters() if p in pc.optimizer.state and pc.optimizer.state[p]]
+        steps = [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if p in pc.optimizer.state and pc.optimizer.state[p]] + \
+                [float(mopt.state[p]["step"]) for p in sim.parameters()]
+        runs[mode] = (log, params, moments, steps, getattr(pc, "_captured_step", None))
+    cs = runs["captured"][4]
+    assert cs is not None and cs.stats["recorded"] == 1 and cs.stats["replayed"] == 7 and cs.stats["eager"] == 1 and cs.stats["missed"] == 0, cs.stats
+    assert runs["eager"][3] == runs["captured"][3] == [8.0] * len(runs["eager"][3])
+    for (pe, le, re_, ve, fe), (pc_, lc, rc, vc, fc) in zip(runs["eager"][0], runs["captured"][0]):
+        assert abs(pe - pc_) < 2e-3 and abs(le - lc) < 1e-5 * max(abs(le), 1e-3), (pe, pc_, le, lc)
+        assert float((re_ != rc).float().mean()) < 1e-3 and torch.equal(fc, rc > 0)
+        assert float((ve - vc).abs().max()) <= 2e-3 * float(ve.abs().max())
+    for a, b in zip(runs["eager"][1] + runs["eager"][2], runs["captured"][1] + runs["captured"][2]):
+        d = (a - b).abs()
+        assert float((d > 1e-6 + 2e-3 * b.abs()).float().mean()) < 0.02, float(d.max())
+
+
+def test_captured_train_step_survives_a_miss():
+    """The counts outgrow the capacities a graph was recorded with (every Gaussian grows by e^0.6 between two steps: R up ~2x): the
+    replay's `valid` word comes back 0 and NOTHING was applied -- parameters, moments and step counts bit-identical to before the
+    replay -- the step is repeated eagerly, the graph re-recorded, and training goes on; the run equals an all-eager run that takes
+    the same jump.  (the forced-miss test.)"""
+    from csplat import train as tr
+    runs = {}
+    for mode in ("eager", "captured"):
+        pc, sim, mopt, cams, bg = _captured_fixture(seed=5)
+        log = []
+        for it in range(1, 9):
+            if it == 5:
+                with torch.no_grad():
+                    pc._scaling.add_(0.6)
+                if mode == "captured":      # what a replay that misses must leave untouched
+                    before = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
+                    cs = pc._captured_step
+                    key = cs._key(cams)
+                    st = cs.graphs[key]
+                    cs._fill(st, cams)
+                    st["graph"].replay()
+                    torch.cuda.synchronize()
+                    assert float(st["host"][0]) == 0.0, "the jump was meant to overflow the recorded capacities"
+                    for a, b in zip(before, list(pc.parameters()) + list(sim.parameters())):
+                        assert torch.equal(a, b)
+                    assert [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if pc.optimizer.state.get(p)] == [4.0] * 6
+                    assert int(pc.optimizer._cap["state"].item()) == 4
+            ps, loss, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, captured=(mode == "captured"))
+            log.append((float(ps), float(loss)))
+        torch.cuda.synchronize()
+        runs[mode] = (log, [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())], getattr(pc, "_captured_step", None))
+    cs = runs["captured"][2]
+    assert cs.stats["missed"] == 1 and cs.stats["recorded"] == 2, cs.stats
+    for (pe, le), (pc_, lc) in zip(runs["eager"][0], runs["captured"][0]):
+        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < 1e-4 * max(abs(le), 1e-3), (pe, pc_, le, lc)
+    for a, b in zip(runs["eager"][1], runs["captured"][1]):
+        d = (a - b).abs()
+        assert float((d > 1e-6 + 5e-3 * b.abs()).float().mean()) < 0.03, float(d.max())
