@@ -61,6 +61,7 @@ EXPORTS = {
     "csplat_ssim_fwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_ssim_bwd": (_i, [_vp, _i64, _i, _i, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_adam_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _i64]),
+    "csplat_gather_words": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "csplat_adam_step_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "csplat_l1_scratch_bytes": (_sz, []),
     "csplat_mask_to_map_temp_bytes": (_sz, [_i64]),
@@ -197,6 +198,19 @@ def stream_handle(device=None):
         idx = device.index if isinstance(device, torch.device) else device
         return _RAW_STREAM(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# While a step is being RECORDED (stream capture) torch's current stream is the capture stream -- but the recording will be replayed on
+# the stream that was current before.  Scratch buffers that are "zeroed once per stream" (their kernels leave the ticket words at zero,
+# and launches on one stream cannot overlap) are therefore keyed on scratch_stream(): the stream the work will RUN on.
+REPLAY_STREAM = {}
+
+
+def scratch_stream(device=None):
+    idx = device.index if isinstance(device, torch.device) else device
+    idx = torch.cuda.current_device() if idx is None else idx
+    alias = REPLAY_STREAM.get(idx)
+    return alias if alias is not None else stream_handle(idx)
 
 
 class _NoSwitch:

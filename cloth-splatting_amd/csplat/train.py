@@ -73,7 +73,7 @@ _L1_SCRATCH = {}
 def _l1_scratch(device):
     """partial sums + ticket counter of csplat_l1 for the CURRENT stream of `device`: zeroed once -- the kernel's last workgroup
     leaves the ticket at zero again, and launches on one stream cannot overlap -- instead of a fill launch per loss"""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (str(device), _n.scratch_stream(device))
     buf = _L1_SCRATCH.get(key)
     if buf is None:
         buf = _L1_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_l1_scratch_bytes()) // 4, dtype=torch.int32, device=device)
@@ -210,7 +210,7 @@ _IMG_SCRATCH = {}
 def _image_loss_scratch(dev, shape):
     """workgroup partials of csplat_image_loss_fwd: one buffer per (device, stream, shape)"""
     B, Cc, H, W = shape
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream, B, Cc, H, W)
+    key = (dev, _n.scratch_stream(dev), B, Cc, H, W)
     buf = _IMG_SCRATCH.get(key)
     if buf is None:
         if len(_IMG_SCRATCH) >= 64:
@@ -361,11 +361,11 @@ class FusedClothRegs(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=D.device)
         grad = torch.empty_like(D)
         ei, rl = edge_index.contiguous(), rest_len.contiguous().float()
-        dev, stream = D.device, _n.stream_handle(D.device)
+        dev, stream, skey = D.device, _n.stream_handle(D.device), _n.scratch_stream(D.device)
 
         def launch():
             with _n.on_device(dev):
-                key = ("regs", dev, stream, T, V, E)
+                key = ("regs", dev, skey, T, V, E)
                 scratch = _IMG_SCRATCH.get(key)          # zeroed once per (device, stream, sizes): the kernel leaves its ticket at zero
                 if scratch is None:
                     if len(_IMG_SCRATCH) >= 64:
@@ -412,11 +412,11 @@ class SimulatorStep(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=D.device)
         grad = torch.empty_like(D)
         ei, rl = edge_index.contiguous(), rest_len.contiguous().float()
-        dev, stream = D.device, _n.stream_handle(D.device)
+        dev, stream, skey = D.device, _n.stream_handle(D.device), _n.scratch_stream(D.device)
 
         def launch():
             with _n.on_device(dev):
-                key = ("regs", dev, stream, T, V, E)
+                key = ("regs", dev, skey, T, V, E)
                 scratch = _IMG_SCRATCH.get(key)
                 if scratch is None:
                     if len(_IMG_SCRATCH) >= 64:
@@ -697,6 +697,8 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
             # image loss + PSNR + the sum with the regularisers: one launch (and one in backward)
             loss, psnr_, _ = FusedImageLoss.apply(image_tensor, gt_image_tensor, opt.lambda_dssim, mask_tensor, reg, w_img,
                                                   1.0 / world if dist_mode else 1.0, 1.0 / max(n_total, 1))
+            if _cap is not None:      # a recorded step: its log line (go word, PSNR, loss, counts) leaves for the host HERE, half a step early
+                _cap["log"](psnr_, loss)
         else:
             psnr_sum = psnr(image_tensor, gt_image_tensor).sum().double()
             image_loss = image_losses(image_tensor, gt_image_tensor, opt, mask_tensor)
@@ -833,23 +835,41 @@ class CapturedStep:
         self._fill(st, cams)
         g.optimizer.captured_setup()
         self.mopt.captured_setup()
-        st["host"] = torch.zeros(3 + 3 * T, dtype=torch.float32).pin_memory()
         for p in list(g.parameters()) + list(self.sim.parameters()):
             p.grad = None
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         faith = {"caps": st["caps"], "valid": st["valid"]}
+        n_log = 4 + 3 * T
+        st["host"] = torch.zeros(n_log, dtype=torch.float32).pin_memory()
+        st["host_seq"] = torch.full((1,), -1.0, dtype=torch.float32).pin_memory()
+        st["packed"] = torch.zeros(n_log, dtype=torch.float32, device=dev)
+        seq_src = g.optimizer._cap["state"]        # steps taken BEFORE this one: the host knows the value it waits for
+
+        def log(psnr_t, loss_t):
+            srcs = [seq_src, st["valid"], psnr_t.reshape(1), loss_t.reshape(1)] + list(faith["info"])
+            kinds = [1, 1, 0, 0] + [1] * T
+            counts = [1, 1, 1, 1] + [3] * T
+            n = len(srcs)
+            keep = [t if t.dtype in (torch.float32, torch.int32) else t.float() for t in srcs]
+            pp = (C.c_void_p * n)(*[t.data_ptr() for t in keep])
+            with _n.on_device(dev):
+                _n.check(_n.lib.csplat_gather_words(_n.stream_handle(dev), n, C.cast(pp, C.c_void_p), C.cast((C.c_int * n)(*kinds), C.c_void_p),
+                                                    C.cast((C.c_int * n)(*counts), C.c_void_p), _n.ptr(st["packed"])), "csplat_gather_words")
+            # two copy nodes: the line, then the word the host spins on -- when the second has landed the first has
+            st["host"].copy_(st["packed"], non_blocking=True)
+            st["host_seq"].copy_(st["packed"][0:1], non_blocking=True)
+            st["_keep"] = keep
         dgr.FAITH = faith
+        _n.REPLAY_STREAM[dev.index if dev.index is not None else torch.cuda.current_device()] = _n.stream_handle(dev)
         try:
             with torch.cuda.graph(graph):
                 ps, loss, stats = train_step(0, scams, g, self.sim, self.mopt, self.pipe, self.opt, self.bg,
-                                             _cap={"sim_in": (st["enc"], st["base"]), "gt": st["gt"], "valid": st["valid"]})
-                info = torch.stack(faith["info"]).reshape(-1).to(torch.float32)        # (counts < 2^24: exact in fp32)
-                packed = torch.cat([st["valid"].to(torch.float32), ps.reshape(1).to(torch.float32), loss.reshape(1).to(torch.float32), info])
-                st["host"].copy_(packed, non_blocking=True)
+                                             _cap={"sim_in": (st["enc"], st["base"]), "gt": st["gt"], "valid": st["valid"], "log": log})
         finally:
             dgr.FAITH = None
-        st.update(graph=graph, psnr=ps, loss=loss, stats=stats, packed=packed)
+            _n.REPLAY_STREAM.clear()
+        st.update(graph=graph, psnr=ps, loss=loss, stats=stats)
         self.graphs[key] = st
         self.stats["recorded"] += 1
         return st
@@ -887,10 +907,21 @@ class CapturedStep:
             self._fill(st, cams)
         self.g.optimizer.captured_refresh_lr()
         self.mopt.captured_refresh_lr()
+        expect = float(int(self.g.optimizer._cap["items"][0][1]["step"].item()))      # (a CPU tensor: the host-side step counter)
+        st["host_seq"][0] = -1.0            # (the previous replay's copies have landed: its line was read)
         st["graph"].replay()
-        torch.cuda.current_stream(st["gt"].device).synchronize()          # the ONE host wait of the step: its log line is in pinned memory
-        host = st["host"]
-        if float(host[0]) != 1.0:           # the counts outgrew the capacities: nothing was applied -- repeat eagerly, re-record next time
+        # the step's log line leaves the GPU right behind the image loss -- half a step before the step ends -- and the host only waits for
+        # THAT: it returns to the caller (and issues the next replay) while the backward and the optimizer steps still run
+        host, seq = st["host"], st["host_seq"]
+        spins = 0
+        while float(seq[0]) != expect:
+            spins += 1
+            if spins > 200000:          # (seconds: something is wrong -- fall back to the stream)
+                torch.cuda.current_stream(st["gt"].device).synchronize()
+                if float(seq[0]) != expect:
+                    raise RuntimeError(f"CapturedStep: the recorded step reported step count {float(seq[0])}, expected {expect}")
+                break
+        if float(host[1]) != 1.0:           # the counts outgrew the capacities: nothing was applied -- repeat eagerly, re-record next time
             self.stats["missed"] += 1
             self.graphs.pop(key, None)
             out = self._eager(iteration, cams)
@@ -902,11 +933,12 @@ class CapturedStep:
         self.g.optimizer.captured_advance_host()
         self.mopt.captured_advance_host()
         T = len(cams)
-        counts = host[3:3 + 3 * T].view(T, 3)
+        counts = host[4:4 + 3 * T].view(T, 3)
         caps = st["caps"]
+        psnr_v, loss_v = host[2].clone(), host[3].clone()        # (the pinned line is overwritten by the next replay)
         if float(counts[:, 0].max()) > 0.97 * caps[0] or float(counts[:, 1].max()) > 0.97 * caps[1] or float(counts[:, 2].max()) > 0.97 * caps[2]:
             # close to a capacity: re-record with room before a step is lost (the results of this replay are final -- copies are returned)
             self.graphs[key] = {"graph": None, "pending_caps": self._caps_from_counts(counts.tolist())}
             self.stats["rerecorded_early"] += 1
-            return host[1].clone(), host[2].clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st["stats"].items()}
-        return host[1], host[2], dict(st["stats"])
+            return psnr_v, loss_v, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st["stats"].items()}
+        return psnr_v, loss_v, dict(st["stats"])

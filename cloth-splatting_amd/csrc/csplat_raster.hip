@@ -601,18 +601,10 @@ struct P2View {
     uint32_t Bcap;              // non-empty tiles the compositing forward's grid was sized for
     int spec;
 };
-struct P2Table { P2View v[P2_MAX_VIEWS]; };
+struct P2Table { P2View v[P2_MAX_VIEWS]; uint32_t *valid; int nviews; };     // valid: see csplat_forward_views_faith (NULL otherwise)
 __device__ __forceinline__ bool p2_live(const P2View &w) { return !w.spec || (w.info[0] - 1u < w.R && w.info[1] <= w.Lcap && w.info[2] <= w.Bcap); }
 __device__ __forceinline__ void seg_plan_body(int tiles, const int2 *__restrict__ ranges, int *__restrict__ seg_offset,
                                               int *__restrict__ slot_tile);
-// the verdict of a launch on faith (csplat_forward_views_faith): every view's counts fitted the capacities its second phase was laid out for
-__global__ void k_p2_valid(P2Table tab, int V, uint32_t *valid) {
-    if (threadIdx.x == 0) {
-        bool ok = true;
-        for (int i = 0; i < V; i++) ok = ok && p2_live(tab.v[i]);
-        *valid = ok ? 1u : 0u;
-    }
-}
 // (the LAST workgroup of every view does not emit: it lays out the view's 256-entry segments -- the former k_seg_plan launch; both only
 // need the tile ranges)
 __global__ __launch_bounds__(BUCKET_G) void k_emit_bucket_views(int P, int tiles, P2Table tab) {
@@ -1567,6 +1559,13 @@ __device__ __forceinline__ void paint_empty_tiles(int tiles, int W, int H, int g
 // 1024 n persistent waves per view walking the items -- DESIGN section 6.)
 template <bool ROWS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_composite_fwd_views(int tiles, int W, int H, P2Table tab, int busy_grid) {
+    if (tab.valid && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        // the verdict of a launch on faith (csplat_forward_views_faith): every view's counts fitted the capacities its second phase was
+        // laid out for -- what the backward's kernels and the optimizer step read before they touch anything
+        bool ok = true;
+        for (int i = 0; i < tab.nviews; i++) ok = ok && p2_live(tab.v[i]);
+        *tab.valid = ok ? 1u : 0u;
+    }
     const P2View &w = tab.v[blockIdx.y];
     if (!p2_live(w)) return;
     const uint32_t *order = w.info + INFO_BUSY + tiles + 4;
@@ -2848,13 +2847,14 @@ static PendingViews g_pending[MAX_PENDING];
 static std::mutex g_pending_mu;
 
 // lays the chunks of every view out for `Rcap[i]` list entries and launches the five stages of the second phase on `join`
-// (valid != nullptr: one more tiny launch leaves 1 there when every view's counts fitted the capacities, else 0 -- csplat_forward_views_faith)
+// (valid != nullptr: K6's first wave leaves 1 there when every view's counts fitted the capacities, else 0 -- csplat_forward_views_faith)
 static int p2_launch(int V, const int *tk, csplat_view *v, hipStream_t join, const uint32_t *Rcap, uint32_t Lcap, int spec, uint32_t Bcap,
                      uint32_t *valid = nullptr) {
     const FwdTicket &a = g_tickets[tk[0]];
     const int P = a.P, W = a.W, H = a.H, tiles = a.tiles, nb = a.nb;
     {
         P2Table tab;
+        tab.valid = valid; tab.nviews = V;
         uint32_t maxR = 0;
         for (int i = 0; i < V; i++) {
             const FwdTicket &t = g_tickets[tk[i]];
@@ -2916,10 +2916,6 @@ static int p2_launch(int V, const int *tk, csplat_view *v, hipStream_t join, con
                 k_composite_fwd_views<false><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, busy_grid);
             else
                 k_composite_fwd_views<true><<<dim3(busy_grid + K6_EXTRA, V), 64, 0, join>>>(tiles, W, H, tab, busy_grid);
-            LAUNCH_CHECK();
-        }
-        if (valid) {
-            k_p2_valid<<<1, 64, 0, join>>>(tab, V, valid);
             LAUNCH_CHECK();
         }
         return 0;

@@ -199,7 +199,7 @@ def _sim_hidden_bwd(e, W2, h1, h2, g):
     dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
     db = torch.empty(2, 256, dtype=torch.float32, device=dev)
     with _n.on_device(dev):
-        key = (str(dev), _n.stream_handle(dev))
+        key = (str(dev), _n.scratch_stream(dev))
         scratch = _SIMH_SCRATCH.get(key)        # zeroed once per stream: the kernel leaves its ticket word at zero
         if scratch is None:
             scratch = _SIMH_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_sim_hidden_scratch_bytes(8)) // 4, dtype=torch.int32, device=dev)

@@ -217,6 +217,10 @@ int csplat_adam_step(void *stream, int n_tensors, float *const *params, const fl
 int csplat_adam_step_dev(void *stream, int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                          float *const *exp_avg_sq, const int64_t *numel, const double *lr_dev, double beta1, double beta2, double eps,
                          int *state_dev, const uint32_t *valid_dev);
+/* dst[...] (float, device) = the concatenation of n <= 32 small device arrays, src[i] holding count[i] values of kind[i] (0 = float,
+ * 1 = int32 / uint32, converted; exact below 2^24): one launch that collects a recorded step's log line -- step count, go / no-go
+ * word, PSNR, loss, the views' instance counts -- for ONE copy to pinned host memory. */
+int csplat_gather_words(void *stream, int n, const void *const *src, const int *kind, const int *count, float *dst);
 
 /* Capacity-based densify / prune: replaces the boolean-mask indexing / torch.cat re-creation of every
  * parameter and Adam moment in /root/reference/scene_reconstruction/gaussian_model.py:266-341 and gaussian_mesh.py:336-431.
