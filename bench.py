@@ -107,7 +107,7 @@ def main():
 
     P, W, H, V = args.P, args.res, args.res, args.views
     from csplat import dist as cd
-    from csplat.train import l1_loss
+    from csplat.train import l1_loss, step_stats
     from diff_gaussian_rasterization import rasterize_views
     T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)  # noqa: E731
 
@@ -160,19 +160,26 @@ def main():
             # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views): the first phase of
             # all views goes out in four launches, then every view's binning / compositing kernels overlap on the chip
             if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
-                colors, _ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
-                                                                 shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
-                                                            for i in range(V)], stacked=True)
+                colors, outs_ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
+                                                                     shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
+                                                                for i in range(V)], stacked=True)
+                self.radii = [o_[1] for o_ in outs_]
                 # one L1 over the [V,3,H,W] batch, as the reference does (train_utils.py:262-285) = the mean of the per-view
                 # means that the camera-by-camera branch below forms
                 loss = l1_loss(colors, self.targets_stacked)
             else:
                 outs = [self.render(i, m2ds[i]) for i in range(V)]
+                self.radii = [o_[1] for o_ in outs]
                 loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).mean()
-            loss.backward(gradient=self.one)   # (a resident 1.0: autograd would launch a fill for the root gradient every step)
+            try:
+                loss.backward(gradient=self.one)   # (a resident 1.0: autograd would launch a fill for the root gradient every step)
+            finally:
+                if self.fg is not None:
+                    self.fg.unbind()
             if self.fg is not None:
-                with torch.no_grad():
-                    torch.sum(torch.stack([m.grad for m in m2ds]), dim=0, out=self.fg.tail.view(P, 3))
+                # the screen-space sum densification consumes, written straight into the flat buffer's tail (one launch; K8 wrote every
+                # parameter gradient into its slice already: no stock add / stack / sum launches in the step)
+                step_stats([m.grad for m in m2ds], self.radii, self.zeros.shape[1], dev, out_vsg=self.fg.tail.view(-1, 3))
                 if not skip_allreduce:
                     self.fg.all_reduce(timed=timed_allreduce)
             return loss
@@ -292,6 +299,58 @@ def main():
         eval_fwd = {"ms_per_call": round(dt_e * 1e3, 4), "views_per_call": V, "fps": round(V / dt_e, 1),
                     "Mpix_per_s": round(V * W * H / 1e6 / dt_e, 1), "what": "rasterizer forward only under no_grad (K1-K6), all views of the batch per call"}
 
+    # ---- what the speculative launch costs when training is NOT static.  In the timed region above every step's
+    # counts equal the previous step's: the second forward phase is launched on the previous call's capacities and never misses.  Real
+    # training changes P at every densification (gaussian_mesh.py:336-431 via train_utils.py:295-304), interleaves evaluation renders of
+    # another size (train.py:286-333) and moves R a little every step.  40 steps: P changes every 10th step (+5 % cloned, then -5 %
+    # pruned, alternating) -> no history for the new shape: the counts are WAITED for; a two-view 400x400 render under no_grad before
+    # every 10th-plus-5 step (its own shape: own history); and at step 20 every Gaussian grows by 35 % for one step -> R up ~1.7x: the
+    # capacities do not fit, the phase is repeated with exact sizes (a MISS).  Per step: which of hit / wait / miss the training-sized
+    # forward took (diff_gaussian_rasterization.SPEC_STATS) and its wall time, device drained before and after.
+    speculation = None
+    if wl is not None and args.view_streams and world == 1 and not scene_mode and V >= 2:
+        try:
+            base = {k: v.detach().clone() for k, v in wl.params.items()}
+            half = [GaussianRasterizationSettings(image_height=H // 2, image_width=W // 2, tanfovx=st_.tanfovx, tanfovy=st_.tanfovy, bg=st_.bg,
+                                                  scale_modifier=1.0, viewmatrix=st_.viewmatrix, projmatrix=st_.projmatrix, sh_degree=3,
+                                                  campos=st_.campos, prefiltered=False, debug=False) for st_ in wl.settings[:2]]
+
+            def set_P(n):
+                idx = torch.arange(n, device=dev) % P
+                wl.params = {k: base[k][idx].clone().requires_grad_(True) for k in wl.names}
+                wl.zeros = torch.zeros(V, n, 3, device=dev)
+            classes = {"hit": [], "wait": [], "miss": []}
+            cur_P = P
+            for it in range(40):
+                if it % 10 == 0 and it > 0:
+                    cur_P = P + P // 20 if (it // 10) % 2 == 1 else P - P // 20
+                    set_P(cur_P)
+                if it % 10 == 5:
+                    with torch.no_grad():
+                        pr = wl.params
+                        rasterize_views(half, [dict(means3D=pr["means3D"], means2D=None, opacities=pr["opacities"], shs=pr["shs"],
+                                                    scales=pr["scales"], rotations=pr["rotations"]) for _ in half], stacked=True)
+                if it in (20, 21):
+                    with torch.no_grad():
+                        wl.params["scales"].mul_(1.35 if it == 20 else 1.0 / 1.35)
+                before = dict(dgr.SPEC_STATS)
+                torch.cuda.synchronize(); t_s = time.perf_counter()
+                wl.step()
+                torch.cuda.synchronize(); t_e = time.perf_counter()
+                kind = next((k for k in ("miss", "wait", "hit") if dgr.SPEC_STATS[k] > before[k]), "hit")
+                classes[kind].append((t_e - t_s) * 1e3)
+            set_P(P)
+            wl.params = {k: base[k].clone().requires_grad_(True) for k in wl.names}
+            mean = lambda a: round(float(np.mean(a)), 4) if a else None  # noqa: E731
+            speculation = {"steps": 40, "hits": len(classes["hit"]), "waits": len(classes["wait"]), "misses": len(classes["miss"]),
+                           "ms_per_hit_step": mean(classes["hit"]), "ms_per_waited_step": mean(classes["wait"]),
+                           "ms_per_missed_step": mean(classes["miss"]),
+                           "what": "40 steps, device drained around each: P +-5 % every 10th step (new shape: counts waited for), a 2-view "
+                                   "400x400 no_grad render before steps 5, 15, 25, 35, every scale x1.35 at step 20 (R up ~1.7x: the second "
+                                   "phase is repeated with exact sizes)"}
+        except Exception as e:      # never let the auxiliary leg take the headline line down
+            speculation = {"error": repr(e)[:200]}
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -391,6 +450,7 @@ def main():
                               "back to back") if args.view_streams and V > 1 else None},
         "kernel_us": breakdown,
         "eval_forward": eval_fwd,
+        "speculation": speculation,
         "collective": collective,
     }
     # the first half of BASELINE.json's metric ("train-step ms"): BASELINE configs[2], measured by bench_train.py (untimed

@@ -44,45 +44,57 @@ def shard_views(views, rank=None, world=None):
 
 
 class FlatGrads:
-    """One flat fp32 buffer whose slices ARE the `.grad` tensors of `params` (+ `extra` trailing floats for whatever else has
-    to be summed over ranks in the same message).  bind() zeroes the buffer and (re-)attaches the views -- call it before
-    backward(), because `optimizer.zero_grad(set_to_none=True)` detaches them; autograd then accumulates in place.
+    """One flat fp32 buffer that ends a step holding the gradient of every one of `params` in its own slice (+ `extra` trailing floats
+    for whatever else has to be summed over ranks in the same message), and the `.grad` tensors are VIEWS of those slices.
+
+    How a gradient gets there (round 4): bind() registers every parameter's slice as its gradient SINK (csplat.native.GRAD_SINK) and
+    clears `.grad`.  The autograd nodes that finish a parameter's gradient -- the rasterizer's K8 for its direct inputs, the activation
+    and mesh-transform adjoints, the simulator's backward -- write it straight into the slice and return a fresh view of it, which
+    autograd ADOPTS as `.grad` (AccumulateGrad steals a gradient nobody else holds): no temporary, no zero fill of the slice, no
+    in-place add.  A gradient that arrives any other way (a node without sink support, a sum of two contributions) is copied into the
+    slice by the post-accumulate hook.  Slices nothing wrote are zero: the first step of a step SHAPE zero-fills the whole buffer and
+    learns which parameters were written in place; afterwards only the other slices and the tail are cleared.
     Rebuilt by the owner when the parameter set changes shape (densification).
 
     `early` = how many LEADING parameters form the early bucket: their gradients are complete long before the backward pass ends
     (the Gaussian parameters: final when the rasterizer's K8 and the activation / mesh-transform adjoints have run, while the
     simulator MLP and the regularisers are still in backward).  The post-accumulate hook of the LAST of them to receive its gradient
     starts the all-reduce of that slice right away (async: RCCL runs it on its own stream behind the kernels queued so far), so the
-    exchange of ~95 % of the bytes overlaps the rest of backward; all_reduce() then sends the remainder (simulator gradients + tail)
-    and waits for both.  The sums are the same sums: results equal the one-shot all-reduce bit for bit."""
+    exchange of ~95 % of the Gaussian bytes overlaps the rest of backward; all_reduce() then sends the remainder (simulator gradients +
+    tail) and waits for both.  The sums are the same sums: results equal the one-shot all-reduce bit for bit."""
 
     def __init__(self, params, extra=0, early=0):
+        import weakref
         self.params = [p for p in params]
         assert self.params, "FlatGrads: no parameters"
         dev = self.params[0].device
         assert all(p.device == dev and p.dtype == self.params[0].dtype for p in self.params), "FlatGrads: mixed devices / dtypes"
         self.shapes = [tuple(p.shape) for p in self.params]
         self.sizes = [p.numel() for p in self.params]
-        self.n_param = sum(self.sizes)
+        # every slice starts on a 256-byte boundary (kernels that write a gradient in place use 16-byte stores); the padding is zero
+        self.offsets, o = [], 0
+        for n in self.sizes:
+            self.offsets.append(o)
+            o += (n + 63) & ~63
+        self.n_param = o
         self.extra = int(extra)
         self.early = int(early)
-        self.n_early = sum(self.sizes[:self.early])
+        self.n_early = self.offsets[self.early] if self.early < len(self.sizes) else self.n_param
         self.flat = torch.zeros(self.n_param + self.extra, dtype=self.params[0].dtype, device=dev)
-        self.views, o = [], 0
-        for p, n in zip(self.params, self.sizes):
-            self.views.append(self.flat[o:o + n].view(p.shape))
-            o += n
+        self.views = [self.flat[o:o + n].view(s) for o, n, s in zip(self.offsets, self.sizes, self.shapes)]
+        self._refs = [weakref.ref(p) for p in self.params]
         self.tail = self.flat[self.n_param:]
         self.last_allreduce_ms = 0.0
         self.early_fired = 0           # how many steps sent their early slice from the backward hook (tests, bench)
-        # which parameters autograd actually wrote during the current backward (bind() hands EVERY parameter a zero-filled view;
-        # a parameter outside the graph -- `face_offset`, a frozen group -- must end the step with grad None exactly as in the
-        # one-rank step, or Adam would create state for it and advance its step count)
+        self.in_place = 0              # gradients adopted in place (written into the slice by their last kernel) since creation
+        self.copied = 0                # ... and gradients that had to be copied into their slice
         self._touched = [False] * len(self.params)
+        self._placed = [False] * len(self.params)
         self._union = {}
-        # which early parameters receive a gradient in a step, per step SHAPE (the `key` of bind(): static / dynamic stage, number of
-        # cameras -- whatever changes the graph); learned on the first step of each shape
+        # per step SHAPE (the `key` of bind(): static / dynamic stage, number of cameras -- whatever changes the graph), learned on the
+        # first step of each shape: which early parameters receive a gradient, and which parameters' slices are written in place
         self._early_expect = {}
+        self._in_place_expect = {}
         self._key = None
         self._early_left = None
         self._early_work = None
@@ -91,8 +103,17 @@ class FlatGrads:
         self._hooks = [p.register_post_accumulate_grad_hook(self._mark(i)) for i, p in enumerate(self.params)]
 
     def _mark(self, i):
-        def hook(_p):
+        def hook(p):
             self._touched[i] = True
+            g = p.grad
+            if g is not None and g.dtype == self.flat.dtype and g.data_ptr() == self.views[i].data_ptr() and g.is_contiguous():
+                self.in_place += 1
+                self._placed[i] = True
+            elif g is not None:            # arrived some other way: into the slice, and `.grad` becomes the slice
+                with torch.no_grad():
+                    self.views[i].copy_(g)
+                p.grad = self.views[i]
+                self.copied += 1
             if i < self.early and self._early_work is not None:
                 self._early_late.append(i)
             if self._early_left is not None and i in self._early_left:
@@ -112,6 +133,7 @@ class FlatGrads:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self.unbind()
 
     def matches(self, params, extra=0, early=0):
         params = list(params)
@@ -119,43 +141,80 @@ class FlatGrads:
             all(a is b and tuple(a.shape) == s for a, b, s in zip(params, self.params, self.shapes))
 
     def bind(self, group=None, key=None):
-        self.flat.zero_()
+        from . import native as _n
         self._touched = [False] * len(self.params)
+        self._placed = [False] * len(self.params)
         self._early_work = None
         self._early_late = []
         self._group = group
         self._key = key
+        known = self._in_place_expect.get(key)
+        if known is None:
+            self.flat.zero_()                      # first step of this shape: everything (and learn who writes in place)
+        else:
+            for i, hit in enumerate(known):        # slices their last kernel overwrites need no clearing; the others and the tail do
+                if not hit:
+                    self.views[i].zero_()
+            if self.extra:
+                self.tail.zero_()
         # the early bucket fires when the same early parameters as in the previous step OF THIS SHAPE have their gradients (the graph
         # of a step shape is static); the first step of a shape learns the set and sends everything at the end
         expect = self._early_expect.get(key)
         self._early_left = set(expect) if (self.early and expect) else None
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        for i, p in enumerate(self.params):
+            p.grad = None
+            if self.flat.is_cuda:
+                _n.GRAD_SINK[id(p)] = (self._refs[i], self.flat, self.offsets[i], self.shapes[i])
+
+    def unbind(self):
+        """the sinks are for ONE step: an ordinary (one-rank) step that follows must not write into this buffer"""
+        from . import native as _n
+        for p in self.params:
+            e = _n.GRAD_SINK.get(id(p))
+            if e is not None and e[1] is self.flat:
+                del _n.GRAD_SINK[id(p)]
 
     def drop_untouched(self, key=None, group=None):
-        """after backward + all_reduce: `p.grad = None` for every parameter that NO rank's backward wrote.  The union over ranks
-        is one tiny all-reduce(max) + host read the first time a step shape `key` is seen (the graph of a step is static: same
-        cameras per rank, same parameters in it) and is served from a cache afterwards."""
+        """after backward + all_reduce: `p.grad` = its slice for every parameter that SOME rank's backward wrote (a rank without a
+        camera got no gradient of its own for the Gaussians, but holds the sum now), None for the others -- a parameter outside the
+        graph (`face_offset`, a frozen group) must end the step with grad None exactly as in the one-rank step, or Adam would create
+        state for it and advance its step count.  The union over ranks is one tiny all-reduce(max) + host read the first time a step
+        shape `key` is seen (the graph of a step is static: same cameras per rank, same parameters in it) and cached afterwards."""
         if key not in self._union:
             t = torch.tensor([int(b) for b in self._touched], dtype=torch.int32, device=self.flat.device)
             if is_dist():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             self._union[key] = [bool(b) for b in t.tolist()]
-        for p, hit in zip(self.params, self._union[key]):
-            if not hit:
-                p.grad = None
+        for i, (p, hit) in enumerate(zip(self.params, self._union[key])):
+            p.grad = self.views[i] if hit else None
 
     def all_reduce(self, group=None, timed=False):
         """sum over ranks, in place: the part of the buffer the early bucket has not already sent, then wait for both.  timed=True
         brackets the call with device synchronisation and records its wall time -- `last_allreduce_ms` = what this call took with
         the device drained first, i.e. the EXPOSED time of the step's exchange when the early bucket was in flight (bench.py reports
         the one-shot time next to it); the default leaves it asynchronous with respect to the host."""
+        self.unbind()
         if self._early_late:
             # the slice that left from the hook did not hold this gradient yet: the sums the other ranks are about to use are wrong.
             # A step whose graph differs from the one its `key` was learned on -- give bind() a key that tells them apart.
             late, self._early_late = self._early_late, []
             raise RuntimeError(f"FlatGrads: early parameter(s) {sorted(set(late))} received a gradient after the early slice had been "
                                f"sent (step shape {self._key!r}): the step's graph changed under one bind() key")
+        known = self._in_place_expect.get(self._key)
+        if known is None:
+            self._in_place_expect[self._key] = list(self._placed)
+        else:
+            # a slice that was left uncleared because its gradient is written in place -- and then was not: it holds the previous
+            # step's sum.  Clear it now (possible unless the early slice is already on its way) and forget the expectation.
+            stale = [i for i, hit in enumerate(known) if hit and not self._placed[i]]
+            if stale:
+                if self._early_work is not None and any(i < self.early for i in stale):
+                    raise RuntimeError(f"FlatGrads: parameter(s) {stale} were expected to be written in place (step shape {self._key!r}) and "
+                                       "were not, after the early slice had been sent")
+                for i in stale:
+                    if not self._touched[i]:
+                        self.views[i].zero_()
+                self._in_place_expect[self._key] = [a and b for a, b in zip(known, self._placed)]
         if self.early and self._key not in self._early_expect:      # learned once per step shape: which early parameters it touches
             self._early_expect[self._key] = [i for i in range(self.early) if self._touched[i]]
         elif self.early and self._early_work is None and self._early_expect[self._key] and \

@@ -21,6 +21,7 @@ class MeshTransform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vertices, bary, rotation, vid, rest, rowptr=None, corners=None):
+        ctx.sinks = (_n.grad_sink(bary), _n.grad_sink(rotation))      # (csplat.dist.FlatGrads: write the parameter gradients in place)
         vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
         batched = vertices.dim() == 3
         T, V = (int(vertices.shape[0]), int(vertices.shape[1])) if batched else (1, int(vertices.shape[0]))
@@ -39,7 +40,9 @@ class MeshTransform(torch.autograd.Function):
     def backward(ctx, g_xyz, g_quat):
         vertices, bary, rotation, vid, rest, rowptr, corners = ctx.saved_tensors
         T, P, V = ctx.dims
-        d_v, d_b, d_r = torch.empty_like(vertices), torch.empty_like(bary), torch.empty_like(rotation)
+        sinks = getattr(ctx, "sinks", (None, None))
+        d_v = torch.empty_like(vertices)
+        d_b, d_r = _n.grad_out(sinks[0], bary.shape, bary.device), _n.grad_out(sinks[1], rotation.shape, rotation.device)
         scratch = None if rowptr is None else torch.empty(max(T * P * 9, 1), dtype=torch.float32, device=vertices.device)
         g_xyz = None if g_xyz is None else g_xyz.contiguous().float()
         g_quat = None if g_quat is None else g_quat.contiguous().float()
@@ -79,6 +82,7 @@ class MeshTransformViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vertices, bary, rotation, vid, rest, rowptr=None, corners=None):
+        ctx.sinks = (_n.grad_sink(bary), _n.grad_sink(rotation))
         vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
         T, V, P = int(vertices.shape[0]), int(vertices.shape[1]), int(vid.shape[0])
         xyz = torch.empty(T, P, 3, dtype=torch.float32, device=vertices.device)
@@ -130,13 +134,13 @@ def _act_fwd(op_raw, sc_raw, f_dc, f_rest):
     return opacity, scales, shs
 
 
-def _act_bwd(opacity, scales, g_op, g_sc, g_shs):
+def _act_bwd(opacity, scales, g_op, g_sc, g_shs, sinks=(None, None, None, None)):
     P, dev = opacity.shape[0], opacity.device
     c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
     g_op, g_sc, g_shs = c(g_op), c(g_sc), c(g_shs)
-    d_op, d_sc = torch.empty_like(opacity), torch.empty_like(scales)
-    d_dc = torch.empty(P, 1, 3, dtype=torch.float32, device=dev)
-    d_rest = torch.empty(P, 15, 3, dtype=torch.float32, device=dev)
+    d_op, d_sc = _n.grad_out(sinks[0], opacity.shape, dev), _n.grad_out(sinks[1], scales.shape, dev)
+    d_dc = _n.grad_out(sinks[2], (P, 1, 3), dev)
+    d_rest = _n.grad_out(sinks[3], (P, 15, 3), dev)
     with _n.on_device(dev):
         _n.check(_n.lib.csplat_gauss_act_bwd(_n.stream_handle(dev), P, _n.ptr(opacity), _n.ptr(scales), _n.ptr(g_op), _n.ptr(g_sc),
                                              _n.ptr(g_shs), _n.ptr(d_op), _n.ptr(d_sc), _n.ptr(d_dc), _n.ptr(d_rest)),
@@ -149,6 +153,7 @@ class _GaussianActivations(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, op_raw, sc_raw, f_dc, f_rest):
+        ctx.sinks = tuple(_n.grad_sink(t) for t in (op_raw, sc_raw, f_dc, f_rest))
         opacity, scales, shs = _act_fwd(op_raw, sc_raw, f_dc, f_rest)
         ctx.save_for_backward(opacity, scales)
         ctx.set_materialize_grads(False)
@@ -156,7 +161,7 @@ class _GaussianActivations(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_op, g_sc, g_shs):
-        return _act_bwd(*ctx.saved_tensors, g_op, g_sc, g_shs)
+        return _act_bwd(*ctx.saved_tensors, g_op, g_sc, g_shs, sinks=ctx.sinks)
 
 
 class GaussianStepInputs(torch.autograd.Function):
@@ -167,6 +172,7 @@ class GaussianStepInputs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vertices, bary, rotation, vid, rest, rowptr, corners, op_raw, sc_raw, f_dc, f_rest):
+        ctx.sinks = tuple(_n.grad_sink(t) for t in (bary, rotation, op_raw, sc_raw, f_dc, f_rest))
         vertices, bary, rotation = vertices.contiguous().float(), bary.contiguous().float(), rotation.contiguous().float()
         T, V, P = int(vertices.shape[0]), int(vertices.shape[1]), int(vid.shape[0])
         xyz = torch.empty(T, P, 3, dtype=torch.float32, device=vertices.device)
@@ -190,18 +196,19 @@ class GaussianStepInputs(torch.autograd.Function):
         g_quat = _join_views(grads[T:2 * T], (P, 4), torch.float32, dev)
         d_mesh = (None, None, None)
         if g_xyz is not None or g_quat is not None:
-            d_mesh = MeshTransform.backward(_Saved(saved[:7], ctx.dims), g_xyz, g_quat)[:3]
+            d_mesh = MeshTransform.backward(_Saved(saved[:7], ctx.dims, ctx.sinks[:2]), g_xyz, g_quat)[:3]
         g_op, g_sc, g_shs = grads[2 * T:]
         d_act = (None,) * 4
         if g_op is not None or g_sc is not None or g_shs is not None:
-            d_act = _act_bwd(saved[7], saved[8], g_op, g_sc, g_shs)
+            d_act = _act_bwd(saved[7], saved[8], g_op, g_sc, g_shs, sinks=ctx.sinks[2:])
         return tuple(d_mesh) + (None, None, None, None) + tuple(d_act)
 
 
 class _Saved:
     """stand-in ctx: hands MeshTransform.backward its saved tensors and dims"""
 
-    def __init__(self, saved, dims):
+    def __init__(self, saved, dims, sinks=(None, None)):
+        self.sinks = sinks
         self.saved_tensors, self.dims = saved, dims
 
 

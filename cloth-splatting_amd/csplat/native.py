@@ -213,6 +213,38 @@ def scratch_stream(device=None):
     return alias if alias is not None else stream_handle(idx)
 
 
+# ---- gradient sinks (csplat.dist.FlatGrads): where the LAST kernel that forms a parameter's gradient should write it.  A
+# view-parallel step all-reduces ONE flat buffer; with a sink registered for a parameter, the node that finishes its gradient (K8, the
+# activation / mesh-transform adjoints, the simulator's backward) writes straight into the parameter's slice of that buffer and returns a
+# fresh view of it, which autograd adopts as `.grad` (no other owner: AccumulateGrad steals it) -- instead of writing a temporary that
+# an in-place add then folds into a zero-filled slice (a second read-modify-write of every gradient byte, one stock launch per tensor).
+GRAD_SINK = {}
+
+
+def grad_sink(t):
+    """the registered sink of parameter `t` as a KEY (flat buffer, offset, shape), or None.  Record it in forward(); grad_out() turns it
+    into a tensor inside backward() -- a view created earlier and kept on the ctx would have a second owner, and AccumulateGrad only
+    adopts a gradient tensor nobody else holds (it clones otherwise)"""
+    e = GRAD_SINK.get(id(t))
+    if e is None or e[0]() is not t:
+        return None
+    return e[1], e[2], e[3]
+
+
+def grad_out(sink, shape, device):
+    """the gradient buffer a backward writes: a FRESH view of the sink when there is one (and it fits), else fresh memory"""
+    if sink is not None:
+        flat, off, shp = sink
+        if tuple(shp) == tuple(shape) and flat.dtype == torch.float32 and flat.device == device:
+            n = 1
+            for d in shp:
+                n *= d
+            v = flat[off:off + n].view(tuple(shp))
+            if v.data_ptr() % 16 == 0:
+                return v
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
 class _NoSwitch:
     def __enter__(self):
         return None

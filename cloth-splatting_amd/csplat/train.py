@@ -404,6 +404,7 @@ class SimulatorStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, W1, b1, W2, b2, Wo, bo, base, edge_index, rest_len, lam_deform, lam_rigid, lam_mom, csr, defer=False):
         from meshnet import graph_ops as go
+        ctx.sinks = tuple(_n.grad_sink(t) for t in (W1, b1, W2, b2, Wo, bo))       # (csplat.dist.FlatGrads: gradients written in place)
         e, W2s, h1, h2 = go._sim_hidden_fwd(e, W1, b1, W2, b2)
         y, Wo = go._rows_dot_fwd(h2, Wo, bo, base)
         T = int(e.shape[0])
@@ -443,8 +444,8 @@ class SimulatorStep(torch.autograd.Function):
             g = grad * g_loss
         else:
             g = g_D.contiguous().float() if g_loss is None else torch.addcmul(g_D, grad, g_loss)
-        dWo, dbo, dh = go._rows_dot_bwd(Wo, h2, g)
-        dW1, db1, dW2, db2 = go._sim_hidden_bwd(e, W2s, h1, h2, dh)
+        dWo, dbo, dh = go._rows_dot_bwd(Wo, h2, g, sinks=ctx.sinks[4:6])
+        dW1, db1, dW2, db2 = go._sim_hidden_bwd(e, W2s, h1, h2, dh, sinks=ctx.sinks[:4])
         return (None, dW1, db1, dW2, db2, dWo, dbo) + (None,) * 8
 
 
@@ -574,9 +575,10 @@ def _gt_stack(cams, device):
 
 
 @torch.no_grad()
-def step_stats(grads, radii_list, P, dev, dtype=torch.float32):
+def step_stats(grads, radii_list, P, dev, dtype=torch.float32, out_vsg=None):
     """train_utils.py:276-285 for the cameras of a step: (sum of the screen-space gradients [P,3], largest radii [P], visible [P] bool).
-    On the GPU one launch (csplat_step_stats) for up to 16 cameras; a camera whose gradient is None counts as zero."""
+    On the GPU one launch (csplat_step_stats) for up to 16 cameras; a camera whose gradient is None counts as zero.  out_vsg: an fp32
+    [P,3] tensor the sum is written into (the tail of the view-parallel step's flat buffer) instead of fresh memory."""
     if not radii_list:
         return (torch.zeros(P, 3, dtype=dtype, device=dev), torch.zeros(P, dtype=torch.int32, device=dev),
                 torch.zeros(P, dtype=torch.bool, device=dev))
@@ -584,7 +586,8 @@ def step_stats(grads, radii_list, P, dev, dtype=torch.float32):
     ok = V <= 16 and all(r.is_cuda and r.dtype == torch.int32 and r.is_contiguous() and r.numel() == P for r in radii_list) and \
         all(g is None or (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == 3 * P) for g in grads)
     if ok:
-        vsg = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        vsg = out_vsg if (out_vsg is not None and out_vsg.is_cuda and out_vsg.dtype == torch.float32 and out_vsg.is_contiguous() and
+                          out_vsg.numel() == 3 * P) else torch.empty(P, 3, dtype=torch.float32, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         vis = torch.empty(P, dtype=torch.bool, device=dev)
         gp = (C.c_void_p * V)(*[None if g is None else g.data_ptr() for g in grads])
@@ -711,13 +714,19 @@ def train_step(iteration, viewpoint_cams, gaussians, simulator, meshnet_optimize
         loss = image_loss + (reg / world if dist_mode else reg)
         psnr_ = psnr_sum / max(n_total, 1)
     if loss.requires_grad:
-        loss.backward(gradient=_root_one(loss))
+        try:
+            loss.backward(gradient=_root_one(loss))
+        finally:
+            if fg is not None:
+                fg.unbind()           # (the gradient sinks are for this backward only)
     viewspace_grad, radii, visibility_filter = step_stats([v.grad for v in vsp_l], [r.reshape(-1) for r in radii_l], P, dev,
-                                                          gaussians.face_bary.dtype)
+                                                          gaussians.face_bary.dtype,
+                                                          out_vsg=fg.tail[:3 * P].view(P, 3) if (fg is not None and radii_l) else None)
     loss_value = loss.detach()
     with torch.no_grad():
         if dist_mode:
-            fg.tail[:3 * P].copy_(viewspace_grad.reshape(-1))
+            if viewspace_grad.data_ptr() != fg.tail.data_ptr():       # (csplat_step_stats wrote the sum into the tail already otherwise)
+                fg.tail[:3 * P].copy_(viewspace_grad.reshape(-1))
             fg.tail[3 * P] = psnr_.to(fg.tail.dtype)
             fg.tail[3 * P + 1] = loss_value.to(fg.tail.dtype)
             slots = fg.tail[3 * P + 2:].view(world, P)

@@ -313,7 +313,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         ctx.plan = None
         if any(ctx.needs_input_grad):
             # the GPU is busy with K1..K6 of the views right now: prepare the backward call in its shadow
-            ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
+            ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat)
         if not pending.value and FAITH is None:
             SPEC_STATS["wait"] += 1
         if pending.value:
@@ -330,7 +330,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     v.layout_rendered = int(arr[i].layout_rendered)
                     v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
                 if ctx.plan is not None:
-                    ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev)
+                    ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat)
             elif ctx.plan is not None:
                 for a, i in enumerate(ctx.plan["active"]):
                     ctx.plan["sub"][a].num_rendered = arr[i].num_rendered
@@ -341,13 +341,16 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
-    def _plan_backward(views, saved, k, arr, first_of, active, dev):
+    def _plan_backward(views, saved, k, arr, first_of, active, dev, inputs=None):
         """Everything of the backward call that does not depend on the incoming gradient values: ONE allocation for every
         gradient, temporary and K7 record of the step (returned gradients are views of it), the csplat_view array with all
         pointers but dL_dpix, the accumulate masks of shared parameters.  Built at the end of forward(), while the
-        compositing kernels run, so that backward() is left with pointer patching and one library call."""
+        compositing kernels run, so that backward() is left with pointer patching and one library call.
+        inputs: the call's input tensors -- one with a registered gradient SINK (csplat.native.GRAD_SINK: a view-parallel step's flat
+        buffer) gets its gradient written there by K8 and handed to autograd as a fresh view of the sink."""
         n = _RasterizeGaussiansBatch.NIN
         plan, owner, total = [], {}, 0
+        sink_of = {}        # (view, slot) -> a fresh view of the input's gradient sink
 
         def reserve(numel):
             nonlocal total
@@ -386,6 +389,14 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     numel = 1
                     for d in shapes[slot]:
                         numel *= d
+                    sk = _n.grad_sink(inputs[i * n + slot]) if (inputs is not None and present[slot] and (i, slot) not in pre and
+                                                                inputs[i * n + slot] is not None) else None
+                    sv = _n.grad_out(sk, inputs[i * n + slot].shape, dev) if sk is not None else None
+                    if sv is not None and sv.numel() == numel and sv.data_ptr() % 16 == 0:
+                        sink_of[(i, slot)] = sv
+                        ent[field] = owner[(i, slot)] = ("sink", i, slot)
+                        ent["ret"][slot] = (ent[field], shapes[slot])
+                        continue
                     ent[field] = owner[(i, slot)] = pre[(i, slot)] if (i, slot) in pre else reserve(numel)
                     if present[slot]:
                         ent["ret"][slot] = (ent[field], shapes[slot])
@@ -402,8 +413,14 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             for field in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh",
                           "dL_dscale", "dL_drot"):
                 off = ent.get(field)
-                setattr(w, field, None if off is None else base + 4 * off)
+                if isinstance(off, tuple):
+                    setattr(w, field, sink_of[off[1:]].data_ptr())
+                else:
+                    setattr(w, field, None if off is None else base + 4 * off)
             for slot, (off, shape) in ent["ret"].items():
+                if isinstance(off, tuple):
+                    out[i * n + slot] = sink_of[off[1:]]
+                    continue
                 numel = 1
                 for d in shape:
                     numel *= d

@@ -191,13 +191,14 @@ def _sim_hidden_fwd(e, W1, b1, W2, b2):
     return e, W2, h1, h2
 
 
-def _sim_hidden_bwd(e, W2, h1, h2, g):
+def _sim_hidden_bwd(e, W2, h1, h2, g, sinks=(None, None, None, None)):
+    """sinks: csplat.native.grad_sink keys of (W1, b1, W2, b2) -- where the gradients are to be written (csplat.dist.FlatGrads)"""
     T, K0 = int(e.shape[0]), int(e.shape[1])
     g = _f32(g)
     dev = g.device
-    dW1 = torch.empty(256, K0, dtype=torch.float32, device=dev)
-    dW2 = torch.empty(256, 256, dtype=torch.float32, device=dev)
-    db = torch.empty(2, 256, dtype=torch.float32, device=dev)
+    dW1 = _n.grad_out(sinks[0], (256, K0), dev)
+    dW2 = _n.grad_out(sinks[2], (256, 256), dev)
+    db = [_n.grad_out(sinks[1], (256,), dev), _n.grad_out(sinks[3], (256,), dev)]
     with _n.on_device(dev):
         key = (str(dev), _n.scratch_stream(dev))
         scratch = _SIMH_SCRATCH.get(key)        # zeroed once per stream: the kernel leaves its ticket word at zero
@@ -234,10 +235,10 @@ def _rows_dot_fwd(h2, Wo, bo, base=None):
     return y, Wo
 
 
-def _rows_dot_bwd(Wo, h2, g):
+def _rows_dot_bwd(Wo, h2, g, sinks=(None, None)):
     g = _f32(g)
     T, R = int(h2.shape[0]), int(Wo.shape[0])
-    dWo, dbo, dh = torch.empty_like(Wo), torch.empty(R, dtype=torch.float32, device=g.device), torch.empty_like(h2)
+    dWo, dbo, dh = _n.grad_out(sinks[0], Wo.shape, g.device), _n.grad_out(sinks[1], (R,), g.device), torch.empty_like(h2)
     scratch = torch.empty(_n.lib.csplat_rows_dot_scratch_bytes(T), dtype=torch.uint8, device=g.device)
     with _n.on_device(g.device):
         _n.check(_n.lib.csplat_rows_dot_bwd(_n.stream_handle(g.device), T, R, 256, _n.ptr(Wo), _n.ptr(h2), _n.ptr(g.reshape(T, R)),

@@ -59,6 +59,9 @@ def _run(view_parallel, steps=2):
         # Adam state must exist for exactly the parameters the one-rank step gives a gradient (a zero-filled
         # flat-buffer view is not "no gradient")
         out["adam_has_state"] = np.array([int(len(pc.optimizer.state.get(p, {})) > 0) for p in pc.parameters()])
+        fg = getattr(pc, "_flat_grads", None)
+        if fg is not None:      # every gradient of the view-parallel step was WRITTEN INTO its slice of the flat buffer by its last kernel
+            assert fg.copied == 0 and fg.in_place >= 12 * steps, (fg.copied, fg.in_place)       # (6 Gaussian + 6 simulator tensors per step)
         torch.cuda.synchronize()
         return out
     finally:

@@ -49,5 +49,5 @@ def test_bench_collective_leg_under_rccl_one_rank():
     line = json.loads(lines[-1])
     print("bench.py under RCCL, one rank:", {k: line[k] for k in ("value", "ms_per_step", "collective")})
     c = line["collective"]
-    assert c is not None and c["backend"] == "nccl (RCCL)" and c["ranks"] == 1 and c["bytes"] == (59 + 3) * 100_000 * 4     # 3 + 1 + 48 + 3 + 4 floats of gradient per Gaussian + the screen-space tail
+    assert c is not None and c["backend"] == "nccl (RCCL)" and c["ranks"] == 1 and 0 <= c["bytes"] - (59 + 3) * 100_000 * 4 <= 5 * 256     # 3 + 1 + 48 + 3 + 4 floats of gradient per Gaussian + the screen-space tail (slices 256-byte aligned)
     assert c["allreduce_ms"] > 0 and line["value"] > 0 and line["n_gpus"] == 1
