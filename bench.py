@@ -304,7 +304,7 @@ def main():
     # training changes P at every densification (gaussian_mesh.py:336-431 via train_utils.py:295-304), interleaves evaluation renders of
     # another size (train.py:286-333) and moves R a little every step.  40 steps: P changes every 10th step (+5 % cloned, then -5 %
     # pruned, alternating) -> no history for the new shape: the counts are WAITED for; a two-view 400x400 render under no_grad before
-    # every 10th-plus-5 step (its own shape: own history); and at step 20 every Gaussian grows by 35 % for one step -> R up ~1.7x: the
+    # every 10th-plus-5 step (its own shape: own history); and at step 23 every Gaussian grows by 30 % for one step -> R up ~1.6x: the
     # capacities do not fit, the phase is repeated with exact sizes (a MISS).  Per step: which of hit / wait / miss the training-sized
     # forward took (diff_gaussian_rasterization.SPEC_STATS) and its wall time, device drained before and after.
     speculation = None
@@ -330,9 +330,9 @@ def main():
                         pr = wl.params
                         rasterize_views(half, [dict(means3D=pr["means3D"], means2D=None, opacities=pr["opacities"], shs=pr["shs"],
                                                     scales=pr["scales"], rotations=pr["rotations"]) for _ in half], stacked=True)
-                if it in (20, 21):
+                if it in (23, 24):
                     with torch.no_grad():
-                        wl.params["scales"].mul_(1.35 if it == 20 else 1.0 / 1.35)
+                        wl.params["scales"].mul_(1.3 if it == 23 else 1.0 / 1.3)
                 before = dict(dgr.SPEC_STATS)
                 torch.cuda.synchronize(); t_s = time.perf_counter()
                 wl.step()
@@ -346,7 +346,7 @@ def main():
                            "ms_per_hit_step": mean(classes["hit"]), "ms_per_waited_step": mean(classes["wait"]),
                            "ms_per_missed_step": mean(classes["miss"]),
                            "what": "40 steps, device drained around each: P +-5 % every 10th step (new shape: counts waited for), a 2-view "
-                                   "400x400 no_grad render before steps 5, 15, 25, 35, every scale x1.35 at step 20 (R up ~1.7x: the second "
+                                   "400x400 no_grad render before steps 5, 15, 25, 35, every scale x1.3 at step 23 (R up ~1.6x: the second "
                                    "phase is repeated with exact sizes)"}
         except Exception as e:      # never let the auxiliary leg take the headline line down
             speculation = {"error": repr(e)[:200]}
