@@ -67,6 +67,7 @@ def main():
                     help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
+    ap.add_argument("--eager", action="store_true", help="launch every step kernel by kernel instead of replaying recorded hipGraphs")
     ap.add_argument("--mode", choices=("views", "scenes"), default="views",
                     help="views: view-parallel weak scaling (default, the BASELINE metric); scenes: 6 scene variants dealt over the ranks")
     args = ap.parse_args()
@@ -184,6 +185,53 @@ def main():
                     self.fg.all_reduce(timed=timed_allreduce)
             return loss
 
+    class GraphedSteps:
+        """The workload's step recorded into G hipGraphs and replayed round-robin (csplat_forward_views_faith: both phases of the forward
+        launched with capacities taken from an eager step's counts, nothing read back; a device word per graph says whether the counts
+        fitted -- checked after the timed region).  Same launches, same work as the eager step(); what is gone is the host: ~35 launches
+        and one read of the counts per step, which on a slow host core (the boxes differ) was what the step waited for.  G graphs, not
+        one: the K7 bracket events of the roofline are external event-record nodes, one pair per graph -- G live samples per read."""
+
+        def __init__(self, w_, G=4):
+            import diff_gaussian_rasterization as dgr_
+            dgr_.KEEP_INFO = True
+            try:
+                w_.step()
+            finally:
+                dgr_.KEEP_INFO = False
+            counts = torch.stack(list(dgr_.LAST_INFO)).cpu().tolist()
+            R_ = max(c[0] for c in counts); L_ = max(c[1] for c in counts); B_ = max(c[2] for c in counts)
+            self.caps = (R_ + R_ // 8 + 4096, min(L_ + L_ // 4 + 64, 8192), B_ + B_ // 8 + 16)
+            self.counts = counts
+            self.graphs, self.valid, self.info = [], [], []
+            self.w, self.G = w_, G
+
+        def record(self):
+            import diff_gaussian_rasterization as dgr_
+            w_, G = self.w, self.G
+            torch.cuda.synchronize()
+            native.REPLAY_STREAM[dev.index] = native.stream_handle(dev)      # (scratch "zeroed once per stream": the stream of the replays)
+            for _ in range(G):
+                valid = torch.zeros(1, dtype=torch.int32, device=dev)
+                faith = {"caps": self.caps, "valid": valid}
+                g_ = torch.cuda.CUDAGraph()
+                dgr_.FAITH = faith
+                try:
+                    with torch.cuda.graph(g_):
+                        w_.step()
+                finally:
+                    dgr_.FAITH = None
+                self.graphs.append(g_); self.valid.append(valid); self.info.append(faith["info"])
+            native.REPLAY_STREAM.clear()
+            self.k = 0
+
+        def step(self):
+            self.graphs[self.k % len(self.graphs)].replay()
+            self.k += 1
+
+        def all_valid(self):
+            return all(int(v.item()) == 1 for v in self.valid)
+
     scene_mode = args.mode == "scenes"
     if scene_mode:      # BASELINE configs[4]: six seeded scene variants, scene s on rank s mod N, no data-path collective
         n_scenes = 6
@@ -214,15 +262,49 @@ def main():
     gc.freeze()
     import diff_gaussian_rasterization as dgr
     sync()
-    if not os.environ.get("CSPLAT_BENCH_NOEVENTS"):
+    # the step as replayed hipGraphs (1 GPU, batched views; --eager / any failure: launch by launch as in rounds 1-3)
+    graphed, launch_mode = None, "eager"
+    want_graph = not dist_on and not scene_mode and args.view_streams and V >= 2 and not args.eager and wl is not None
+    if want_graph:
+        try:
+            graphed = GraphedSteps(wl)              # (an eager step for the counts the capacities are taken from)
+        except Exception as e:
+            graphed, launch_mode = None, "eager (no counts: " + repr(e)[:120] + ")"
+    if graphed is not None:
+        try:
+            graphed.record()
+            for _ in range(2 * len(graphed.graphs)):
+                graphed.step()
+            torch.cuda.synchronize()
+            if not graphed.all_valid():
+                raise RuntimeError("the recorded capacities do not fit the workload's counts")
+            launch_mode = f"hipGraph replay ({len(graphed.graphs)} recordings, round-robin)"
+        except Exception as e:
+            native.REPLAY_STREAM.clear()
+            graphed, launch_mode = None, "eager (recording failed: " + repr(e)[:120] + ")"
+    events_on = not os.environ.get("CSPLAT_BENCH_NOEVENTS")
+    if graphed is None and events_on:
         native.prof_enable(["K7_render_bwd"])
     native.prof_read("K7_render_bwd")
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        graphed.step() if graphed is not None else step()
     sync()
     dt = time.perf_counter() - t0
+    if graphed is not None:
+        if not graphed.all_valid():       # (cannot happen on a static scene; never report a step that did nothing)
+            raise SystemExit("bench.py: a replayed step reported counts beyond its capacities")
+        # K7's HIP-event bracket: a kernel launched by a graph node cannot be bracketed by timeable events on this ROCm (external
+        # event-record nodes: hipEventElapsedTime refuses them), so the SAME K steps run once more launch by launch, straight behind the
+        # timed replays, with the event pair around every K7 launch -- same kernel, same launch geometry, same inputs; the rocprofv3
+        # trace of this command holds both populations under one kernel name
+        if events_on:
+            native.prof_enable(["K7_render_bwd"])
+        native.prof_read("K7_render_bwd")
+        for _ in range(args.steps):
+            step()
+        sync()
     k7_ms, k7_n = native.prof_read("K7_render_bwd")
     native.prof_enable([])
 
@@ -424,7 +506,7 @@ def main():
                                (", + ONE RCCL all-reduce of the flat gradient buffer" if dist_on and not scene_mode else ""),
                    "tile_instances_per_view": R_per_view,
                    "parallelism": (f"scene-parallel x{world} (replicas only)" if scene_mode else f"view-parallel x{world}"),
-                   "streams_per_gpu": V if args.view_streams else 1},
+                   "streams_per_gpu": V if args.view_streams else 1, "launch": launch_mode},
         "roofline": {"bound": "hbm", "kernel": "k_composite_bwd_rows_views (K7 compositing backward, all views of the step in one launch)", "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      # PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of THIS launch (all views of the step), from the committed counter pass of

@@ -807,8 +807,13 @@ class CapturedStep:
                 all(hasattr(self.sim, a) for a in ("times_on_device", "input", "hidden", "output")))
 
     def _eager(self, iteration, cams):
+        import diff_gaussian_rasterization as dgr
         self.stats["eager"] += 1
-        return train_step(iteration, cams, self.g, self.sim, self.mopt, self.pipe, self.opt, self.bg)
+        dgr.KEEP_INFO = True          # (the step's counts stay readable on the device: the next recording's capacities)
+        try:
+            return train_step(iteration, cams, self.g, self.sim, self.mopt, self.pipe, self.opt, self.bg)
+        finally:
+            dgr.KEEP_INFO = False
 
     # ---- static inputs
     def _fill(self, st, cams):

@@ -32,6 +32,10 @@ hipEvent_t prof_event(ProfClass &c) {
 void csplat_prof_mark(int cls, hipStream_t s, bool begin) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfClass &c = g_prof[cls];
+    // (never inside a stream capture: an event recorded by a graph node cannot be timed on this ROCm -- external event-record nodes
+    //  were tried in round 4: hipEventElapsedTime refuses them with "invalid resource handle")
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) return;
     hipEvent_t e = prof_event(c);
     (void)hipEventRecord(e, s);
     (begin ? c.begin : c.end).push_back(e);

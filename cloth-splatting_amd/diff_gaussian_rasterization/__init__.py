@@ -188,6 +188,7 @@ SPEC_STATS = {"hit": 0, "miss": 0, "wait": 0}
 # the device words (int32 [3] views into the IMAGE chunks: tile instances, longest tile list, non-empty tiles) of the last batched
 # forward, per view -- what a caller sizes a launch on faith from (one .cpu() read at a moment of its choosing)
 LAST_INFO = []
+KEEP_INFO = False          # (set by a caller that wants LAST_INFO: the views cost ~10 us of host time per call)
 # Launch ON FAITH (csplat.train.CapturedStep): when set to a dict {"caps": (R, L, B), "valid": uint32 tensor [1]}, the batched forward
 # launches both phases with those capacities and reads NOTHING back (csplat_forward_views_faith) -- the form a hipGraph capture can
 # record.  The forward leaves in the dict: "info" = per view an int32 [3] VIEW of the device words holding (tile instances, longest tile
@@ -313,7 +314,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         ctx.plan = None
         if any(ctx.needs_input_grad):
             # the GPU is busy with K1..K6 of the views right now: prepare the backward call in its shadow
-            ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat)
+            ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat if _n.GRAD_SINK else None)
         if not pending.value and FAITH is None:
             SPEC_STATS["wait"] += 1
         if pending.value:
@@ -330,12 +331,12 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     v.layout_rendered = int(arr[i].layout_rendered)
                     v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
                 if ctx.plan is not None:
-                    ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat)
+                    ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat if _n.GRAD_SINK else None)
             elif ctx.plan is not None:
                 for a, i in enumerate(ctx.plan["active"]):
                     ctx.plan["sub"][a].num_rendered = arr[i].num_rendered
                     ctx.plan["sub"][a].busy_tiles = arr[i].busy_tiles
-        if FAITH is None and len({(v.W, v.H) for v in views}) == 1 and all(_n_IMAGE in c for c in chunks):
+        if KEEP_INFO and FAITH is None and len({(v.W, v.H) for v in views}) == 1 and all(_n_IMAGE in c for c in chunks):
             off = int(_n.lib.csplat_image_info_offset(views[0].W, views[0].H))
             LAST_INFO[:] = [chunks[i][_n_IMAGE][off:off + 12].view(torch.int32) for i in range(V)]
         return tuple(outs)
