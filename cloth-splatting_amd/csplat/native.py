@@ -107,7 +107,6 @@ EXPORTS = {
     "csplat_relu_mask_bias128": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "csplat_linear128_mode": (_i, [C.c_uint]),
     "csplat_linear128_mode_query": (C.c_uint, []),
-    "csplat_linear128_agg": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_gnn_node_update": (_i, [_vp, _i64] + [_vp] * 11 + [_f] + [_vp] * 5),
     "csplat_linear128": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_linear128_ex": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -51,16 +51,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int WB_STRIDE = 136;        // bf16 elements per W row in LDS (272 B: conflict-free 16-byte reads at row stride)
 constexpr size_t L128_LDS_F32 = (size_t)GK * WT_STRIDE * 4, L128_LDS_B3 = (size_t)3 * GN * WB_STRIDE * 2;
 
-template <bool GATHER, bool LN, bool ADD, bool B3, bool AGG = false>
+template <bool GATHER, bool LN, bool ADD, bool B3>
 __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, const float *A, const float *__restrict__ W,
                                                     const float *__restrict__ bias, float alpha, int relu,
                                                     const float *__restrict__ ga, const int64_t *__restrict__ ia,
                                                     const float *__restrict__ gb, const int64_t *__restrict__ ib,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                     const float *add_pre, const float *add_post, float *out,
-                                                    int ldw, int wt, const float *mask, float2 *ln_stats,
-                                                    float *agg = nullptr, const unsigned char *__restrict__ slot_of_row = nullptr,
-                                                    const int *__restrict__ slot_dst = nullptr) {
+                                                    int ldw, int wt, const float *mask, float2 *ln_stats) {
     // W is read as W[j][k] = W[j * ldw + k] (wt = 0: a torch Linear.weight, or a column slice of a wider one) or as
     // W[k * ldw + j] (wt = 1: the TRANSPOSE of such a matrix -- the input-gradient product -- without a transposed copy)
     extern __shared__ float s_wt[];   // fp32 path: [GK][WT_STRIDE], s_wt[k * WT_STRIDE + j] = W[j][k];  B3: bf16 [3][GN][WB_STRIDE]
@@ -363,70 +361,9 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
 #pragma unroll
                 for (int c = 0; c < 4; c++) v[c] = mask[arow * GN + 32 * c + r32] > 0.f ? v[c] : 0.f;
             }
-            if constexpr (AGG) {
-                if (agg) {      // (aggregating epilogue below: the finished rows stay in registers, nothing is stored per row)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) o[r][c] = v[c];
-                    continue;
-                }
-            }
             if (orow < M) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) out[orow * GN + 32 * c + r32] = v[c];
-            }
-        }
-        if constexpr (AGG) {
-            if (agg) {
-                // ---- sum over destination nodes INSIDE the last edge layer (graph_network.py:198-201: aggr='add' over edge_index[1]).
-                // The rows arrive grouped by destination (the caller sorted the edge list once per graph): the 32 rows of a tile belong to
-                // a handful of nodes, numbered 0.. in order of appearance (`slot_of_row`, 255 = no row; `slot_dst` = the node id of each
-                // of the tile's 32 slots, -1 = unused).  agg_tile[slot][col] = sum_row S[slot][row] msg[row][col] is one more MFMA
-                // product per column tile: A = the 0/1 selection matrix (exact in bf16), B = the finished rows -- which this lane holds
-                // as B wants them (lane = column, registers = rows) -- in their three bf16 pieces: exact products, fp32 accumulation.
-                // Each slot's 128 sums then go to agg[node] with float atomics: a node whose edges fit in two tiles receives two
-                // addends on a zeroed row -- commutative, hence bit-reproducible; only a node of more than 33 edges can see three.
-                int *strip = reinterpret_cast<int *>(reinterpret_cast<char *>(s_wt) + L128_LDS_B3) + w * 64;
-                {
-                    const int64_t trow = tile * 32 + r32;
-                    strip[lane] = h == 0 ? (trow < M ? (int)slot_of_row[trow] : 255) : slot_dst[tile * 32 + r32];
-                }
-                bf16x8 S[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const int row = (t & 3) + 8 * (2 * ks + (t >> 2)) + 4 * h;     // the row register 8 ks + t of this lane half holds
-                        S[ks][t] = strip[row] == r32 ? (__bf16)1.0f : (__bf16)0.0f;
-                    }
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    f32x16 sacc;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) sacc[r] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ks++) {
-                        bf16x8 a1, a2, a3;
-#pragma unroll
-                        for (int t = 0; t < 8; t++) {
-                            const float x = o[8 * ks + t][c];
-                            a1[t] = (__bf16)x;
-                            const float r1 = x - (float)a1[t];
-                            a2[t] = (__bf16)r1;
-                            a3[t] = (__bf16)(r1 - (float)a2[t]);
-                        }
-                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S[ks], a3, sacc, 0, 0, 0);
-                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S[ks], a2, sacc, 0, 0, 0);
-                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S[ks], a1, sacc, 0, 0, 0);
-                    }
-                    // D: lane = column 32 c + r32, register r = slot (r & 3) + 8 (r >> 2) + 4 h
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const int dst = strip[32 + slot];
-                        if (dst >= 0) atomicAdd(agg + (size_t)dst * GN + 32 * c + r32, sacc[r]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);     // one column tile at a time: keeps the pieces of the next one out of the registers
-                }
             }
         }
     }
@@ -728,17 +665,18 @@ extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, cons
     CSPLAT_REQUIRE(!ln || ln_beta, "csplat_linear128: LayerNorm needs gamma and beta");
     const bool add = add_pre != nullptr || add_post != nullptr || mask != nullptr;
     CSPLAT_REQUIRE(!(add && gather), "csplat_linear128: row-aligned addends and gathers are not combined (no caller needs it)");
+    CSPLAT_REQUIRE(!(ln && gather), "csplat_linear128: gathers and LayerNorm are not combined (no layer of the network has both)");
     static int s_ok = -1;
     const size_t lds = L128_LDS_F32 + 4 * 64 * sizeof(int);      // W^T + the gather-index strips
     const size_t lds_b3 = L128_LDS_B3 + 8 * 64 * sizeof(int);    // three bf16 pieces of W + strips (one workgroup per CU)
     if (s_ok < 0) {
         s_ok = 1;
-        const void *fns[6] = {(const void *)k_linear128<false, false, false, false>, (const void *)k_linear128<false, true, false, false>,
-                              (const void *)k_linear128<true, false, false, false>,  (const void *)k_linear128<true, true, false, false>,
+        const void *fns[5] = {(const void *)k_linear128<false, false, false, false>, (const void *)k_linear128<false, true, false, false>,
+                              (const void *)k_linear128<true, false, false, false>,
                               (const void *)k_linear128<false, false, true, false>,  (const void *)k_linear128<false, true, true, false>};
         for (const void *f : fns) s_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        const void *fb[6] = {(const void *)k_linear128<false, false, false, true>, (const void *)k_linear128<false, true, false, true>,
-                             (const void *)k_linear128<true, false, false, true>,  (const void *)k_linear128<true, true, false, true>,
+        const void *fb[5] = {(const void *)k_linear128<false, false, false, true>, (const void *)k_linear128<false, true, false, true>,
+                             (const void *)k_linear128<true, false, false, true>,
                              (const void *)k_linear128<false, false, true, true>,  (const void *)k_linear128<false, true, true, true>};
         for (const void *f : fb) s_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b3) == hipSuccess;
         s_ok &= hipFuncSetAttribute((const void *)k_linear128_rows32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
@@ -773,7 +711,6 @@ extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, cons
     } while (0)
     if (add && ln) CSPLAT_L128(false, true, true);
     else if (add) CSPLAT_L128(false, false, true);
-    else if (gather && ln) CSPLAT_L128(true, true, false);
     else if (gather) CSPLAT_L128(true, false, false);
     else if (ln) CSPLAT_L128(false, true, false);
     else CSPLAT_L128(false, false, false);
@@ -782,34 +719,10 @@ extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, cons
     return 0;
 }
 
-// The last Linear + LayerNorm of an InteractionNetwork's edge MLP with the sum over destination nodes in its epilogue (inference):
-//   agg[slot_dst[t][slot_of_row[e]]] += LN(A[e] @ W^T + bias)   for the rows e of tile t = e / 32
-// -- the [M,128] message tensor is neither written nor read back (two of the seven passes over the edge activations of a message-passing
-// step) and the segmented-sum launch is gone.  Rows must arrive grouped by destination; agg must be zero on entry.
-extern "C" int csplat_linear128_agg(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
-                                    const float *ln_gamma, const float *ln_beta, float ln_eps, const unsigned char *slot_of_row,
-                                    const int *slot_dst, float *agg) {
-    CSPLAT_REQUIRE(M > 0 && A && W && ln_gamma && ln_beta && slot_of_row && slot_dst && agg && ldw >= 128, "csplat_linear128_agg: bad arguments");
-    CSPLAT_REQUIRE((((uintptr_t)A | (uintptr_t)W) & 15u) == 0, "csplat_linear128_agg: A / W must be 16-byte aligned");
-    CSPLAT_REQUIRE((g_linear128_mode & 1u) != 0, "csplat_linear128_agg: needs the bf16-split product mode (csplat_linear128_mode(1))");
-    const size_t lds_b3 = L128_LDS_B3 + 8 * 64 * sizeof(int);
-    static int s_ok = -1;
-    if (s_ok < 0) {
-        s_ok = hipFuncSetAttribute((const void *)k_linear128<false, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b3) == hipSuccess;
-        (void)hipGetLastError();
-    }
-    CSPLAT_REQUIRE(s_ok, "csplat_linear128_agg: dynamic LDS refused by the runtime");
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps(PROF_GNN, s);
-    const int64_t ntile = (M + 31) / 32;
-    int grid = (int)((ntile + 7) / 8);
-    if (grid > 256) grid = 256;
-    k_linear128<false, true, false, true, true><<<grid, 512, lds_b3, s>>>(M, A, W, bias, 1.0f, 0, nullptr, nullptr, nullptr, nullptr, ln_gamma, ln_beta,
-                                                                    ln_eps, nullptr, nullptr, nullptr, ldw, w_transposed ? 1 : 0, nullptr, nullptr,
-                                                                    agg, slot_of_row, slot_dst);
-    LAUNCH_CHECK();
-    return 0;
-}
+// (round 3 built a variant of the LayerNorm layer that also summed its rows over the destination nodes in its epilogue -- one more MFMA
+//  product with a 0/1 selection matrix + float atomics, csplat_linear128_agg.  Parity-green and no faster -- the LayerNorm layer is bound
+//  by its epilogue arithmetic, 110 us with or without it -- it spilled 40 VGPRs and stayed opt-in; it left the library in round 4
+//  (history: commit 809fd4b).)
 
 extern "C" int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const float *x, const float *Wa, const float *Wx,
                                       const float *b0, const float *W2, const float *b2, const float *W3, const float *b3,

@@ -19,7 +19,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (linear128_agg, EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows, report_missed_edge_tail,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows, report_missed_edge_tail,
                         linear128, linear_rows, node_update)
 
 
@@ -172,7 +172,7 @@ class InteractionNetwork(nn.Module):
             self._wsplit_key = key
         return self._wsplit
 
-    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None, plan=None):
+    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None):
         """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd.
         Per layer the [E,128] activations make three read+write passes (one per Linear, with gather / bias / ReLU /
         LayerNorm in the epilogues) and one read by the segmented sum; the node level is ONE launch
@@ -183,18 +183,9 @@ class InteractionNetwork(nn.Module):
         if xa is None:
             xa = linear128(x, w_i)                               # contribution of x_i = x[edge_index[1]]
             xb = linear128(x, w_j)                               # contribution of x_j = x[edge_index[0]]
-        if plan is not None:
-            # e0's rows arrive grouped by destination (Processor.forward permuted them once for all layers): the last edge layer sums
-            # its LayerNorm output over the destination nodes in its own epilogue -- the message tensor is never written
-            h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, plan.ei[1], xb, plan.ei[0]))
-            elins = list(self.edge_fn[0].children())[0::2]
-            for lin in elins[1:-1]:
-                h = linear128(h, lin.weight, lin.bias, relu=True, out=h)
-            agg = linear128_agg(h, elins[-1].weight, elins[-1].bias, self.edge_fn[1], plan, x.shape[0])
-        else:
-            h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
-            msg = _fused_tail(self.edge_fn, h)
-            agg = SegmentSum.apply(msg, csr)
+        h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
+        msg = _fused_tail(self.edge_fn, h)
+        agg = SegmentSum.apply(msg, csr)
         lins = list(self.node_fn[0].children())[0::2]
         if len(lins) == 3:
             nw = next_layer._split_weights() if next_layer is not None else (None, None)
@@ -202,23 +193,6 @@ class InteractionNetwork(nn.Module):
         t = linear128(x, w_x, out=xa)
         hn = linear128(agg, w_agg, self.node_fn[0][0].bias, relu=True, add_pre=t, out=t)
         return _fused_tail(self.node_fn, hn, add_post=x), None, None
-
-
-import os as _os
-# rollout: sum over destination nodes inside the last edge layer's epilogue (graph_ops.linear128_agg) instead of a separate segmented sum.
-# Built, parity-green, OFF by default (env CSPLAT_GNN_AGG=1 turns it on): it removes 15 launches and 4.6 GB of HBM traffic per rollout step
-# (the message tensor is never written), but the LayerNorm layer is bound by its epilogue arithmetic, not by its store -- 110 us with or
-# without the aggregation, against 95 + 27 for the layer and the segmented sum -- and the one gather pass that groups e0's rows by
-# destination plus the zero fills cost more than the 12 us saved per layer: 5.54 against 5.35 ms per rollout step (same box, three
-# alternations).  Its float atomics are also order-dependent for nodes of more than 33 incoming edges, where the segmented sum is not.
-AGG_IN_EPILOGUE = _os.environ.get("CSPLAT_GNN_AGG", "0") == "1"
-AGG_MIN_EDGES = 65537       # (the persistent 128-wide kernel serves edge lists of more than 2048 tiles)
-
-
-def _agg_ready(gnn) -> bool:
-    from csplat import native as _n
-    lins = list(gnn.edge_fn[0].children())[0::2]
-    return len(lins) >= 2 and (int(_n.lib.csplat_linear128_mode_query()) & 1) == 1
 
 
 class Processor(nn.Module):
@@ -238,15 +212,9 @@ class Processor(nn.Module):
             # rollout: every layer doubles the edge features (F7), so carry e0 and the scalar 2^l instead of 15 [E,128] passes
             e0, scale = edge_features.contiguous(), 1.0
             xa = xb = None
-            # tall edge lists: group the rows by destination ONCE (one gather pass over e0, shared by all layers) so that every layer's
-            # last edge Linear can aggregate in its epilogue (graph_ops.linear128_agg): 2 of the 7 passes over [E,128] per layer less
-            plan = es = None
-            if AGG_IN_EPILOGUE and e0.shape[0] >= AGG_MIN_EDGES and _agg_ready(self.gnn_stacks[0]):
-                plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
-                es = e0.index_select(0, plan.perm)
             for l, gnn in enumerate(self.gnn_stacks):
                 nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
-                x, xa, xb = gnn.forward_inference(x, edge_index, e0 if plan is None else es, scale, xa, xb, nxt, plan)
+                x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt)
                 scale *= 2.0
             return x, e0 * scale
         if len(self.gnn_stacks) and not torch.is_grad_enabled():

@@ -39,30 +39,6 @@ class GraphCSR:
             self._deg_dst = (rp[1:] - rp[:-1]).to(torch.float32)
         return self._deg_dst
 
-    def agg_plan(self):
-        """What the aggregating edge layer (csplat_linear128_agg) needs, built once per graph: the edge list grouped by destination
-        (`perm`: positions in the caller's order; `ei`: the permuted [2, E] list) and, per 32-row tile of that order, the rank of each
-        row's destination among the tile's distinct destinations (`slot_of_row`, uint8 [E]) and the node id of each of the tile's 32
-        slots (`slot_dst`, int32 [32 * tiles], -1 = unused)."""
-        if getattr(self, "_agg_plan", None) is None:
-            from types import SimpleNamespace
-            E, dev = self.E, self.ei.device
-            perm = self.perm["dst"][:E].long()
-            ei = self.ei.index_select(1, perm).contiguous()
-            dst = ei[1]
-            idx = torch.arange(E, device=dev)
-            new = torch.ones(E, dtype=torch.bool, device=dev)
-            if E > 1:
-                new[1:] = dst[1:] != dst[:-1]
-            new[idx % 32 == 0] = True
-            rank = torch.cumsum(new.long(), 0)
-            slot = rank - rank[(idx // 32) * 32]           # (the tile's first row opens slot 0)
-            ntile = (E + 31) // 32
-            slot_dst = torch.full((ntile * 32,), -1, dtype=torch.int32, device=dev)
-            slot_dst[(idx // 32) * 32 + slot] = dst.to(torch.int32)
-            self._agg_plan = SimpleNamespace(perm=perm, ei=ei, slot_of_row=slot.to(torch.uint8).contiguous(), slot_dst=slot_dst)
-        return self._agg_plan
-
     @classmethod
     def get(cls, edge_index, num_nodes):
         """CSR for this edge_index tensor OBJECT (weakly referenced) at its current in-place version."""
@@ -400,22 +376,6 @@ def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w
                                                float(layer_norm.eps), _n.ptr(nxt[0]), _n.ptr(nxt[1]), _n.ptr(x_new), _n.ptr(xa),
                                                _n.ptr(xb)), "csplat_gnn_node_update")
     return x_new, xa, xb
-
-
-def linear128_agg(A, weight, bias, layer_norm, plan, num_nodes):
-    """sum over destination nodes of LayerNorm(A @ weight^T + bias) -- the last layer of an edge MLP with `aggr='add'` in its epilogue
-    (csplat_linear128_agg; A's rows in the order of plan = GraphCSR.agg_plan()).  Returns agg [num_nodes, 128]; inference only."""
-    _n.require_cuda(A)
-    assert A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == 128 and tuple(weight.shape) == (128, 128)
-    A = A.contiguous()
-    weight, ldw, wt = _weight_layout(weight)
-    agg = torch.zeros(num_nodes, 128, dtype=torch.float32, device=A.device)
-    with _n.on_device(A.device):
-        _n.check(_n.lib.csplat_linear128_agg(_n.stream_handle(A.device), A.shape[0], _n.ptr(A), weight.data_ptr(), ldw, wt,
-                                             None if bias is None else _n.ptr(_f32(bias.detach())), _n.ptr(_f32(layer_norm.weight.detach())),
-                                             _n.ptr(_f32(layer_norm.bias.detach())), float(layer_norm.eps), _n.ptr(plan.slot_of_row),
-                                             _n.ptr(plan.slot_dst), _n.ptr(agg)), "csplat_linear128_agg")
-    return agg
 
 
 def ln128_fwd(x, gamma, beta, eps):

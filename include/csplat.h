@@ -430,15 +430,6 @@ int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const in
  * (both or neither), ln_gamma / ln_beta [128] (both or neither; biased variance, ln_eps), add_pre / add_post [M][128] or
  * NULL (not together with the gathers), out [M][128]; out may alias A (and add_post may then alias both).
  * fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate). A, W and out 16-byte aligned. */
-/* The last Linear(128,128) + LayerNorm of an InteractionNetwork edge MLP WITH the aggregation over destination nodes
- * (/root/reference/meshnet/graph_network.py:178-201: `self.propagate(...)` with aggr='add') in its epilogue -- inference only:
- *   agg[slot_dst[32 t + slot_of_row[e]]][:] += LayerNorm(A[e] @ W^T + bias)      for every row e of tile t = e / 32.
- * Rows must be grouped by destination node (the caller sorts the edge list once per graph); slot_of_row[M] numbers the distinct
- * destinations of a 32-row tile in order of appearance (0..31), slot_dst[32 * ceil(M/32)] holds their node ids (-1 = unused slot);
- * agg [N][128] must be ZERO on entry.  The message tensor is never materialised.  Needs csplat_linear128_mode(1) (the default). */
-int csplat_linear128_agg(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
-                         const float *ln_gamma, const float *ln_beta, float ln_eps, const unsigned char *slot_of_row,
-                         const int *slot_dst, float *agg);
 /* The node update of one InteractionNetwork layer (/root/reference/meshnet/graph_network.py:203-222, two hidden layers of
  * width 128) in one launch, optionally followed by the next layer's node-level products:
  *   h = relu(agg @ Wa^T + x @ Wx^T + b0);  h = relu(h @ W2^T + b2);  x_new = LayerNorm(h @ W3^T + b3) + x;

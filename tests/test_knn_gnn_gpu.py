@@ -407,66 +407,6 @@ def test_splitk_linear_gradients_match_autograd():
     assert rel_err(W2.grad.cpu().numpy(), ((ref > 0).double().t() @ x2.detach().double()).cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("N,deg,seed", [(3000, 30, 0), (2500, 33, 1), (700, 130, 2), (3000, 29, 3)])
-def test_edge_layer_with_aggregation_in_its_epilogue(N, deg, seed):
-    """csplat_linear128_agg (graph_network.py:178-201: the last edge Linear + LayerNorm + aggr='add' over edge_index[1]) against the fp64
-    composition on an edge list in SOURCE order (the plan groups it by destination): nodes of more than 32 incoming edges (several tiles
-    per node), isolated nodes, a ragged last tile; bit-reproducible for degrees that fit two tiles; then the whole Processor with and
-    without the aggregating epilogue."""
-    import torch.nn as nn
-    from meshnet import graph_network as gn
-    from meshnet.graph_ops import GraphCSR, linear128_agg
-    dev = torch.device("cuda")
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    regular = deg <= 33
-    if regular:     # every node but the last 5 receives EXACTLY deg edges (a k-nearest-neighbour graph), listed by source
-        dst = torch.arange(N - 5, device=dev).repeat_interleave(deg)
-        src = torch.randint(0, N, (dst.numel(),), device=dev, generator=g)
-        order = torch.argsort(src * N + dst)
-        ei = torch.stack([src[order], dst[order]])
-    else:           # random destinations: in-degrees spread around deg, some nodes span many tiles
-        src = torch.arange(N, device=dev).repeat_interleave(deg)
-        dst = torch.randint(0, N - 5, (N * deg,), device=dev, generator=g)      # (the last 5 nodes receive nothing)
-        keep = torch.rand(N * deg, device=dev, generator=g) > 0.013
-        ei = torch.stack([src[keep], dst[keep]])
-    E = int(ei.shape[1])
-    assert E > 65536 and (regular or E % 32 != 0)
-    csr = GraphCSR.get(ei, N)
-    plan = csr.agg_plan()
-    assert torch.equal(ei[:, plan.perm], plan.ei) and bool((plan.ei[1][1:] >= plan.ei[1][:-1]).all())
-    A = torch.randn(E, 128, device=dev, generator=g)
-    lin = nn.Linear(128, 128).to(dev)
-    ln = nn.LayerNorm(128).to(dev)
-    with torch.no_grad():
-        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.3, 0.3)
-        As = A.index_select(0, plan.perm)
-        agg = linear128_agg(As, lin.weight, lin.bias, ln, plan, N)
-        msg = torch.nn.functional.layer_norm(A.double() @ lin.weight.double().t() + lin.bias.double(), (128,), ln.weight.double(),
-                                             ln.bias.double(), ln.eps)
-        ref = torch.zeros(N, 128, dtype=torch.float64, device=dev).index_add_(0, ei[1], msg)
-        err = float((agg.double() - ref).abs().max() / ref.abs().max())
-        assert err < 1e-5, err
-        assert float(agg[-5:].abs().max()) == 0.0
-        if regular:     # at most two tiles per node: two addends on a zeroed row commute
-            for _ in range(3):
-                assert torch.equal(agg, linear128_agg(As, lin.weight, lin.bias, ln, plan, N))
-        # ---- the processor: same result with the separate segmented sum
-        torch.manual_seed(seed)
-        proc = gn.Processor(128, 128, 128, 128, nmessage_passing_steps=3, nmlp_layers=2, mlp_hidden_dim=128).to(dev)
-        x = torch.randn(N, 128, device=dev, generator=g)
-        e = 0.3 * torch.randn(E, 128, device=dev, generator=g)
-        keep_flag = gn.AGG_IN_EPILOGUE
-        try:
-            gn.AGG_IN_EPILOGUE = True
-            xa, ea = proc(x, ei, e)
-            gn.AGG_IN_EPILOGUE = False
-            xb, eb = proc(x, ei, e)
-        finally:
-            gn.AGG_IN_EPILOGUE = keep_flag
-        assert torch.equal(ea, eb)
-        assert float((xa - xb).abs().max() / xb.abs().max()) < 2e-5
-
-
 @pytest.mark.parametrize("T,R", [(1, 30000), (3, 30000), (8, 777), (2, 3), (5, 4097)])
 def test_rows_dot_matches_linear_fwd_bwd(T, R):
     """csplat_rows_dot_fwd/_bwd (the simulator's 256 -> 3V output layer for T time rows) against F.linear in fp64."""

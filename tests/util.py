@@ -118,6 +118,7 @@ def gpu_chunks(ctx_chunks, P, W, H, R):
         keys=view(binning, o2[0], np.uint64, R), ids=view(binning, o2[1], np.uint32, R),
         ranges=view(image, o3[0], np.int32, 2 * tiles).reshape(tiles, 2),
         n_contrib=view(image, o3[1], np.uint32, W * H).reshape(H, W), final_T=view(image, o3[2], np.float32, W * H).reshape(H, W))
+    out["_binning_raw"] = ctx_chunks[1]          # (tools/k6_stats.py decodes the masks / "blended" words from it)
     return out
 
 
