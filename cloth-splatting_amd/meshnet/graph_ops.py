@@ -468,7 +468,7 @@ class SplitKLinear(torch.autograd.Function):
     M.  Other shapes / dtypes: plain torch, with the weight gradient as a chunked batched GEMM."""
 
     CHUNK = 3072
-    BIG_ROWS = 16384
+    BIG_ROWS = 16384       # (measured again in round 4 with the node level on csplat_linear128 too -- BIG_ROWS = 64: train step 24.3 against 22.4 ms)
 
     @staticmethod
     def _fast(x, weight):
