@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
     ap.add_argument("--eager", action="store_true", help="launch every step kernel by kernel instead of replaying recorded hipGraphs")
+    ap.add_argument("--no-speculation", action="store_true",
+                    help="skip the auxiliary 40-step pass with changing P / sizes (counter passes: every launch of a kernel then has the same size)")
     ap.add_argument("--mode", choices=("views", "scenes"), default="views",
                     help="views: view-parallel weak scaling (default, the BASELINE metric); scenes: 6 scene variants dealt over the ranks")
     args = ap.parse_args()
@@ -390,7 +392,7 @@ def main():
     # capacities do not fit, the phase is repeated with exact sizes (a MISS).  Per step: which of hit / wait / miss the training-sized
     # forward took (diff_gaussian_rasterization.SPEC_STATS) and its wall time, device drained before and after.
     speculation = None
-    if wl is not None and args.view_streams and world == 1 and not scene_mode and V >= 2:
+    if wl is not None and args.view_streams and world == 1 and not scene_mode and V >= 2 and not args.no_speculation:
         try:
             base = {k: v.detach().clone() for k, v in wl.params.items()}
             half = [GaussianRasterizationSettings(image_height=H // 2, image_width=W // 2, tanfovx=st_.tanfovx, tanfovy=st_.tanfovy, bg=st_.bg,

@@ -36,8 +36,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 sha1sum "$ROOT/cloth-splatting_amd/csrc/csplat_raster.hip" | cut -d" " -f1 > "$OUT/raster_src_sha1.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
   # the DEFAULT command: the launches bench.py times (k_composite_bwd_views = all views of a step in one launch)
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step > "$OUT/pmc_$c.log" 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmcserial_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-view-streams > "$OUT/pmcserial_$c.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-speculation > "$OUT/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmcserial_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-view-streams --no-speculation > "$OUT/pmcserial_$c.log" 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_l128_$c" -o p -- python3 "$ROOT/tools/bench_linear128.py" 300000 2 > /dev/null 2>&1
 done
 cd "$ROOT" && bash tools/collect_issue_counters.sh "$TAG" > /dev/null 2>&1
