@@ -7,7 +7,9 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../csplat/libcsplat.so"
 OBJ="$HERE/build"
 mkdir -p "$OBJ"
-FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -Wall -Wno-unused-function"
+# -fno-slp-vectorize: v_pk_{mul,add,fma}_f32 cost a SIMD what two plain instructions cost (profiles/r04b_valu_rate.txt), but forming their
+# register pairs costs moves -- and copies of just-loaded registers that drag the load's s_waitcnt to the front of a loop (K7, round 4)
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -Wall -Wno-unused-function"
 pids=()
 objs=()
 for src in "$HERE"/*.hip; do

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_knn_search(int P, int nbox, const float
         if (p.z < bx[2] || p.z > bx[5]) ez = fminf(fabsf(p.z - bx[2]), fabsf(p.z - bx[5]));
         const float dist = ex * ex + ey * ey + ez * ez;
         const bool need = live && !(dist > reject || dist > b2);
-        if (__ballot(need) == 0ull) continue;   // the wave skips the box together; lanes that do not need it scan along
+        if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;   // the wave skips the box together; lanes that do not need it scan along
         const int lo = b * KNN_BOX, hi = min(P, lo + KNN_BOX);
 #pragma unroll 4
         for (int j = lo; j < hi; j++) {          // wave-uniform address: one broadcast load per candidate

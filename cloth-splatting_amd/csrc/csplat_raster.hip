@@ -788,10 +788,10 @@ __device__ __forceinline__ void tile_sort_body(const int2 *__restrict__ ranges, 
                 const int idx = wbase + i * 64 + lane;
                 const bool valid = idx < n;
                 const uint32_t d = (uint32_t)(key[i] >> shift) & 0xFF;
-                unsigned long long peers = __ballot(valid);
+                unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const unsigned long long mb = __ballot(valid && ((d >> b) & 1));
+                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(valid && ((d >> b) & 1));
                     peers &= ((d >> b) & 1) ? mb : ~mb;
                 }
                 const uint32_t prev = s_cnt[w * 256 + d];
@@ -1140,7 +1140,7 @@ struct BlockStreamT {
         const uint32_t m = m_next;
         m_next = load(cbase + 64);
         const bool hit = (m >> blk) & 1u;
-        const unsigned long long cur = __ballot(hit);
+        const unsigned long long cur = __builtin_amdgcn_ballot_w64(hit);
         if (hit) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u));
             ring[(tail + rank) & (RN - 1)] = cbase + lane;
@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;   // T: the pixel's (same in its 4 lanes); C*, Dp: this row's share
     uint32_t last = 0;
-    if (n > 0 && __ballot(!done) != 0ull) {
+    if (n > 0 && __builtin_amdgcn_ballot_w64(!done) != 0ull) {
         const int seg0 = seg_offset[tile];
         BlockStream st;
         st.start(mask16 + rx, 0, n, blk, lane, s_ring);
@@ -1255,7 +1255,7 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
             C0 += t.b.z * wgt; C1 += t.b.w * wgt; C2 += t.c.x * wgt; Dp += t.c.y * wgt;
             last = blend ? (uint32_t)(t.pos + 1) : last;
             {   // the row's survivor was blended at one of its 16 pixels: its byte in the segment's strip
-                const unsigned long long bal = __ballot(blend);
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(blend);
                 if (l16 == 0 && ((bal >> (lane & 48)) & 0xFFFFull) != 0ull) bbits_mark(s_hit, t.pos);
             }
             // the products only decrease: the pixel's T after the group is the last one still above the threshold
@@ -1268,15 +1268,15 @@ __device__ __forceinline__ void composite_fwd_body(int tiles, int W, int H, int 
         int k = 3;
         while (va) {
             process(ta);
-            if (__ballot(!done) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
             va = fetch(ta, k++);
             if (!vb) break;
             process(tb);
-            if (__ballot(!done) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
             vb = fetch(tb, k++);
             if (!vc) break;
             process(tc);
-            if (__ballot(!done) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
             vc = fetch(tc, k++);
         }
         if (seg_written >= 0) bbits_flush(s_hit, bbits, (size_t)(seg0 + seg_written), blk, lane);
@@ -1385,7 +1385,7 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
         fx[j] = (float)(px0 + j);
     }
     int seg0 = 0, seg_written = -1;
-    if (n > 0 && __ballot(!(done[0] && done[1] && done[2] && done[3])) != 0ull) {
+    if (n > 0 && __builtin_amdgcn_ballot_w64(!(done[0] && done[1] && done[2] && done[3])) != 0ull) {
         seg0 = seg_offset[tile];
         BlockStreamT<16, RING16> st;
         st.start(mask16 + rx, 0, n, blk, lane, s_ring);
@@ -1445,11 +1445,11 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
                 if (!ends) P[j] = 3.0e38f;
             }
             {   // survivor sv was blended at one of the block's 16 pixels (its four lanes, four pixels each): its byte in the strip
-                const unsigned long long bal = __ballot(blended);
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(blended);
                 const uint32_t any16 = (uint32_t)(bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFu;
                 if (lane < 16 && ((any16 >> lane) & 1u)) bbits_mark(s_hit, t.pos);
             }
-            if (__ballot(fin) != 0ull) {     // rare (once per pixel): the final T of the pixels that ended = the smallest candidate of the row
+            if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {     // rare (once per pixel): the final T of the pixels that ended = the smallest candidate of the row
                 float m[4] = {P[0], P[1], P[2], P[3]};
                 row_scan4_min(m);
 #pragma unroll
@@ -1463,7 +1463,7 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
         Trip ta, tb;
         bool va = fetch(ta, 0), vb = fetch(tb, 1);
         int k = 2;
-        auto all_done = [&]() { return __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull; };
+        auto all_done = [&]() { return __builtin_amdgcn_ballot_w64(!(done[0] && done[1] && done[2] && done[3])) == 0ull; };
         while (va) {
             process(ta);
             if (all_done()) break;
@@ -1618,11 +1618,13 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ out_color, const float *__restrict__ dL_dpix,
                                                    float *__restrict__ acc, float *__restrict__ det,
-                                                   unsigned long long *stamp = nullptr) {
+                                                   unsigned long long *stamp = nullptr, int wg = (int)blockIdx.x) {
     __shared__ int s_ring[4][RING7];
-    const int wg = blockIdx.x;
+    __shared__ float4 s_ra[4][64], s_rb[4][64];                     // one batch of 64 survivors' records per wave (see `stage`)
+    __shared__ float s_rc[4][64];
+    __shared__ uint32_t s_rid[DET ? 1 : 4][DET ? 1 : 64];
     // in-kernel stamps (csplat_debug_stamps; tools/k7_stamps.py): wave 0 of every workgroup leaves s_memtime at the phase boundaries
-    unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 : nullptr;
+    unsigned long long *my_stamp = stamp ? stamp + ((size_t)blockIdx.y * gridDim.x + (size_t)wg) * 12 : nullptr;
     auto mark = [&](int k) {
         if (my_stamp && threadIdx.x == 0) {
             asm volatile("" ::: "memory");
@@ -1701,9 +1703,31 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         if (lane < pad) ring[total + lane] = -1;
         total += pad;
     }
-    const int ngroups = total >> 2;
     mark(2);
     if (live) {
+        // ---- the survivors' RECORDS go through LDS, 64 survivors (16 groups) a batch: lane i requests survivor i's record (x, y, conic,
+        // opacity, colour -- 36 bytes -- and the Gaussian's id) and parks it in the wave's strip; the group loop then contains NO vector
+        // load, only LDS reads (row r reads slot 4k + r: a broadcast) and the atomics.  Why: vmcnt counts loads and atomics together, IN
+        // ORDER -- a record requested behind an atomic cannot be used before that atomic has retired, and under load a float atomic stays
+        // counted for ~3,000 cycles (MI355X_MICROARCH.md, cycle constants).  With the records fetched from global memory two groups
+        // ahead, every group waited for the atomic of the group before the last: 1,670 cycles per group for ~350 of arithmetic
+        // (tools/k7_stamps.py).  The first batch's requests travel with the pixel constants and the checkpoint: one round trip in all
+        // before the first group; later batches (a block that blended more than 64 of the segment's 256 entries) wait once per batch.
+        float4 *ra = s_ra[w], *rb = s_rb[w];
+        float *rc = s_rc[w];
+        uint32_t *rid = s_rid[DET ? 0 : w];
+        auto stage = [&](int b0) {      // survivors b0 .. b0 + 63 -> the strip
+            const int idx = b0 + lane;
+            const int pos = idx < total ? ring[idx] : -1;
+            const uint32_t ri = pos >= 0 ? rx + (uint32_t)pos : null_rec;
+            const float4 A = recA[ri], B = recB[ri];
+            const float C = reinterpret_cast<const float *>(recC)[2 * (size_t)ri];      // (c.y, the depth, is K6's)
+            uint32_t id = 0u;
+            if (!DET) id = ids_sorted[pos >= 0 ? rx + (uint32_t)pos : rx];
+            ra[lane] = A; rb[lane] = B; rc[lane] = C;
+            if (!DET) rid[lane] = id;
+        };
+        stage(0);
         const float OD = oc0 * dp0 + oc1 * dp1 + oc2 * dp2;
         float T = 1.f, S = 0.f;
         if (ncontrib > seg_lo) {
@@ -1711,17 +1735,20 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             S = ck.y * dp0 + ck.z * dp1 + ck.w * dp2;
         }
         if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(S), "v"(T)); }
-        mark(3);                                                        // the pixel constants and the checkpoint have arrived
+        mark(3);                                                        // the pixel constants, the checkpoint and the first batch have arrived
         const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
         const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
         const bool red_active = !lb0 || l16 == 1;
         const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
+        int base = 0;                   // first survivor of the batch in the strip
+        // (every LDS read of the loop is unconditional, with a clamped slot: the compiler's lgkmcnt bookkeeping assumes the path on which
+        //  a conditional read was NOT issued, and then waits for the youngest ones)
         auto fetch = [&](Trip &t, int k) {
-            t.pos = ring[4 * k + r];
-            const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
-            t.a = recA[ri]; t.b = recB[ri]; t.c.x = reinterpret_cast<const float *>(recC)[2 * (size_t)ri];   // (c.y, the depth, is K6's)
-            if (!DET) t.id = t.pos >= 0 ? ids_sorted[rx + (uint32_t)t.pos] : 0u;
+            const int sl = 4 * k + r;
+            t.pos = ring[base + sl];
+            t.a = ra[sl]; t.b = rb[sl]; t.c.x = rc[sl];
+            if (!DET) t.id = rid[sl];
         };
         auto process = [&](const Trip &t) {
             const float dx = t.a.x - fx, dy = t.a.y - fy;
@@ -1770,20 +1797,100 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                 else atomicAdd(acc + (size_t)t.id * ACC_STRIDE + red_t, tot);                          // nine lanes, one 64-byte record
             }
         };
-        // software pipeline, TWO groups in flight: the records of group k+2 are requested when group k has been composited.  (Three in
-        // flight -- K6's depth -- cost 11 more registers: 67 VGPRs = 7 waves per SIMD; two = 57 VGPRs = 8 waves: 306 -> 294 us, same-box
-        // A/B, three alternations.  Forcing the three-deep form under 64 registers spills 7 of them: 365 us.)
-        Trip ta, tb;
-        fetch(ta, 0);
-        if (ngroups > 1) fetch(tb, 1);
-        if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(ta.a.x), "v"(ta.c.x)); }
-        mark(4);                                                        // ring -> the first group's records have arrived
-        for (int k = 0; k < ngroups; k += 2) {
-            process(ta);
-            if (k + 2 < ngroups) fetch(ta, k + 2);
-            if (k + 1 >= ngroups) break;
-            process(tb);
-            if (k + 3 < ngroups) fetch(tb, k + 3);
+        // TWO groups at once, statement by statement: a group is one dependent chain of ~125 vector instructions (~10 cycles from one to
+        // the next: ~1,200 cycles a group for a wave on its own, tools/k7_stamps.py -- and the same with the atomics removed); groups k and
+        // k + 1 only meet where T and S pass from one to the other, so written side by side the two chains fill each other's waits.
+        auto process2 = [&](const Trip &t0, const Trip &t1) {
+            const Trip *t[2] = {&t0, &t1};
+            float dx[2], dy[2], G[2], al[2], F[2], gdot[2], Tr[2], Sr[2], dcc[2];
+            bool act[2];
+            Row4 g[2], gw[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                dx[u] = t[u]->a.x - fx; dy[u] = t[u]->a.y - fy;
+                const float power = -0.5f * (t[u]->a.z * dx[u] * dx[u] + t[u]->b.x * dy[u] * dy[u]) - t[u]->a.w * dx[u] * dy[u];
+                G[u] = __expf(power);
+                const float a = fminf(0.99f, t[u]->b.y * G[u]);
+                act[u] = t[u]->pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;
+                al[u] = act[u] ? a : 0.f;
+                F[u] = 1.f - al[u];
+                gdot[u] = t[u]->b.z * dp0 + t[u]->b.w * dp1 + t[u]->c.x * dp2;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) g[u] = rows_allgather(F[u]);
+            {
+                const float P1 = T * g[0].v0, P2 = P1 * g[0].v1, P3 = P2 * g[0].v2, P4 = P3 * g[0].v3;
+                const float Q1 = P4 * g[1].v0, Q2 = Q1 * g[1].v1, Q3 = Q2 * g[1].v2, Q4 = Q3 * g[1].v3;
+                Tr[0] = rowsel(r, T, P1, P2, P3);
+                Tr[1] = rowsel(r, P4, Q1, Q2, Q3);
+                T = Q4;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) { dcc[u] = al[u] * Tr[u]; gw[u] = rows_allgather(gdot[u] * dcc[u]); }
+            {
+                const float S1 = S + gw[0].v0, S2 = S1 + gw[0].v1, S3 = S2 + gw[0].v2, S4 = S3 + gw[0].v3;
+                const float U1 = S4 + gw[1].v0, U2 = U1 + gw[1].v1, U3 = U2 + gw[1].v2, U4 = U3 + gw[1].v3;
+                Sr[0] = rowsel(r, S1, S2, S3, S4);
+                Sr[1] = rowsel(r, U1, U2, U3, U4);
+                S = U4;
+            }
+            float tot[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const float dL_dalpha = act[u] ? Tr[u] * gdot[u] - (OD - Sr[u]) * __builtin_amdgcn_rcpf(F[u]) : 0.f;
+                const float dL_dG = t[u]->b.y * dL_dalpha;
+                const float gdx = G[u] * dx[u], gdy = G[u] * dy[u];
+                const float dG_ddelx = -gdx * t[u]->a.z - gdy * t[u]->a.w;
+                const float dG_ddely = -gdy * t[u]->b.x - gdx * t[u]->a.w;
+                float v[9];
+                v[0] = dL_dG * dG_ddelx * ddelx_dx;
+                v[1] = dL_dG * dG_ddely * ddely_dy;
+                v[2] = -0.5f * gdx * dx[u] * dL_dG;
+                v[3] = -0.5f * gdx * dy[u] * dL_dG;
+                v[4] = -0.5f * gdy * dy[u] * dL_dG;
+                v[5] = G[u] * dL_dalpha;
+                v[6] = dcc[u] * dp0; v[7] = dcc[u] * dp1; v[8] = dcc[u] * dp2;
+                const float a0 = bfly<0x140>(v[0], v[1], lb3), a1 = bfly<0x140>(v[2], v[3], lb3);
+                const float a2 = bfly<0x140>(v[4], v[5], lb3), a3 = bfly<0x140>(v[6], v[7], lb3);
+                float l8 = dpp_add<0x140>(v[8]);
+                const float b0 = bfly<0x141>(a0, a1, lb2), b1 = bfly<0x141>(a2, a3, lb2);
+                l8 = dpp_add<0x141>(l8);
+                float c0 = bfly<0x4E>(b0, b1, lb1);
+                l8 = dpp_add<0x4E>(l8);
+                c0 = dpp_add<0xB1>(c0);
+                l8 = dpp_add<0xB1>(l8);
+                tot[u] = lb0 ? l8 : c0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (red_active && t[u]->pos >= 0) {
+                    if (DET) det[((size_t)(rx + (uint32_t)t[u]->pos) * 16 + (size_t)blk) * 9 + red_t] = tot[u];
+                    else atomicAdd(acc + (size_t)t[u]->id * ACC_STRIDE + red_t, tot[u]);
+                }
+        };
+        bool first = true;
+#ifndef CSPLAT_K7X
+#define CSPLAT_K7X 0
+#endif
+        for (; base < total && CSPLAT_K7X != 4; base += 64) {
+            if (!first) stage(base);
+            const int ngroups = min(64, total - base) >> 2, last_g = ngroups - 1;
+            // two groups in flight: group k + 2 is read from the strip when group k has been composited
+            Trip ta, tb;
+            fetch(ta, 0);
+            fetch(tb, min(1, last_g));
+            if (first) {
+                if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(ta.a.x), "v"(ta.c.x)); }
+                mark(4);                                                // strip -> the first group's records have arrived
+            }
+            first = false;
+            int k = 0;
+            for (; k + 1 < ngroups; k += 2) {       // (a fetch past the end re-reads the last group: never processed)
+                process2(ta, tb);
+                fetch(ta, min(k + 2, last_g));
+                fetch(tb, min(k + 3, last_g));
+            }
+            if (k < ngroups) process(ta);
         }
     }
     mark(5);                                                            // this wave's groups are done
@@ -3539,7 +3646,8 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
             k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
             LAUNCH_CHECK();
-            k_composite_bwd_rows_views<<<dim3((unsigned)cdiv(slots, 8) * 32u, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            const unsigned items = (unsigned)cdiv(slots, 8) * 32u;
+            k_composite_bwd_rows_views<<<dim3(items, V), 256, 0, join>>>(tiles, W, H, gx, bt);
             LAUNCH_CHECK();
         }
         for (int i = 0; i < V && !(batch_k7 && one_k8); i++) {

@@ -229,10 +229,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint64_t *_
         int64_t idx = wbase + (int64_t)i * 64 + lane;
         bool valid = idx < n;
         uint32_t d = (uint32_t)(key[i] >> shift) & 0xFF;
-        uint64_t peers = __ballot(valid);
+        uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            uint64_t m = __ballot(valid && ((d >> b) & 1));
+            uint64_t m = __builtin_amdgcn_ballot_w64(valid && ((d >> b) & 1));
             peers &= ((d >> b) & 1) ? m : ~m;
         }
         uint32_t prev = cnt[w][d];

@@ -9,7 +9,7 @@ for r in $(seq $ROUNDS); do
   for v in "$@"; do
     name=${v%%:*}; fl=0; [[ "$v" == *:* ]] && fl=${v##*:}
     cp ab/libcsplat_$name.so $LIB
-    CSPLAT_DEBUG_FLAGS=$fl timeout 300 python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-train-step 2>/dev/null | python3 -c "
+    CSPLAT_DEBUG_FLAGS=$fl timeout 300 python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-train-step --no-speculation 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$name', '$fl', d['value'], d['ms_per_step'], 'K7_us', d['roofline']['avg_launch_us'])"

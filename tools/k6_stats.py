@@ -37,7 +37,7 @@ popc16 = np.array([bin(i).count("1") for i in range(65536)], np.int64)
 reach = int(popc16[mask16].sum())
 ranges = st["ranges"]
 # live (slot, block) pairs = those K7 launches a wave for: blk_hi > seg_lo
-live = 0; blended = 0; groups4 = 0; steps16_reach = 0; surv_hist = []
+live = 0; blended = 0; groups4 = 0; steps16_reach = 0; surv_hist = []; wave_steps = []
 for t in range(tiles):
     n_t = int(ranges[t, 1] - ranges[t, 0])
     if n_t == 0:
@@ -46,6 +46,7 @@ for t in range(tiles):
     m = mask16[ranges[t, 0]:ranges[t, 1]]
     for b in range(16):
         bits = (m >> b) & 1
+        wave_steps.append(0)
         for s in range(ns):
             r_ = int(bits[s * SEG:(s + 1) * SEG].sum())
             if s * SEG < blk_hi[t, b]:
@@ -59,8 +60,44 @@ for t in range(tiles):
             if hi > s * SEG:
                 rr = int(bits[s * SEG:hi].sum())
                 steps16_reach += (rr + 15) // 16
+                wave_steps[-1] += (rr + 15) // 16
 sh = np.array(surv_hist)
 print(f"R = {R} entries, {nslots} segments, reach pairs {reach} ({reach / R:.2f} blocks per entry), live (segment, block) pairs {live}")
 print(f"blended pairs {blended} ({blended / max(reach, 1):.2f} of reach); K7 groups of 4 (padded) {groups4} = {4 * groups4} slots, fill {blended / max(4 * groups4, 1):.2f}")
 print(f"blended survivors per live (segment, block): mean {sh.mean():.1f}, median {np.median(sh):.0f}, p90 {np.percentile(sh, 90):.0f}, zero {float((sh == 0).mean()):.2f}")
 print(f"K6 steps of 16 over the reach entries in front of blk_hi: {steps16_reach} = {16 * steps16_reach} slots")
+ws = np.array(wave_steps)
+print(f"K6 waves (non-empty tiles x 16 blocks): {len(ws)}; steps per wave mean {ws.mean():.1f}, median {np.median(ws):.0f}, p90 {np.percentile(ws, 90):.0f}, "
+      f"p99 {np.percentile(ws, 99):.0f}, max {ws.max()}; 5120 wave slots -> {ws.sum() / 5120:.1f} steps per slot if perfectly balanced")
+# how many 64-byte atomic requests K7 would issue if the row sums of an entry were joined over larger pixel areas before leaving the CU
+bbv = bb[:nslots]                                            # [slot][block][4 words]
+def popc(a):
+    a = a.copy(); c = np.zeros(a.shape, np.int64)
+    while a.any():
+        c += (a & np.uint64(1)).astype(np.int64); a >>= np.uint64(1)
+    return c
+per_block = int(popc(bbv).sum())
+pair_h = int(popc(bbv[:, 0::2] | bbv[:, 1::2]).sum())        # blocks (2k, 2k+1): 8x4 pixels
+quad = bbv.reshape(nslots, 2, 2, 2, 2, 4)                    # [by/2][by%2][bx/2][bx%2]
+quad_u = quad[:, :, 0, :, 0] | quad[:, :, 0, :, 1] | quad[:, :, 1, :, 0] | quad[:, :, 1, :, 1]
+tile_u = np.bitwise_or.reduce(bbv, axis=1)
+print(f"atomic requests per view if joined per: block {per_block}, horizontal block pair {pair_h}, 8x8 quadrant {int(popc(quad_u).sum())}, "
+      f"tile {int(popc(tile_u).sum())}  (list entries {R})")
+# K7's workgroups pack a slot's LIVE blocks (blk_hi > seg_lo) four at a time: requests if a workgroup joined its blocks' sums, for two pack orders
+qorder = [0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15]
+def packed(order):
+    tot = 0; wgs = 0
+    for t in range(tiles):
+        n_t = int(ranges[t, 1] - ranges[t, 0])
+        if n_t == 0:
+            continue
+        s0 = int(seg_off[t]); ns = (n_t + SEG - 1) // SEG
+        for s_ in range(ns):
+            livebl = [b for b in order if s_ * SEG < blk_hi[t, b]]
+            for i in range(0, len(livebl), 4):
+                u = np.bitwise_or.reduce(bbv[s0 + s_, livebl[i:i + 4]], axis=0)
+                tot += sum(bin(int(x)).count("1") for x in u); wgs += 1
+    return tot, wgs
+for name, order in (("index order", list(range(16))), ("quadrant-major order", qorder)):
+    tot, wgs = packed(order)
+    print(f"live blocks packed four to a workgroup in {name}: {wgs} workgroups, {tot} requests per view")

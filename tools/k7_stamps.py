@@ -43,16 +43,24 @@ s = buf.cpu().numpy().reshape(-1, 12).astype(np.int64)
 live = s[:, 9] == 1                    # workgroups that reached the end (not the early exits)
 started = s[:, 0] != 0
 print(f"workgroups: launched with a stamp {int(started.sum())}, live to the end {int(live.sum())}")
-L = s[live]
-names = ["scalar chain (slot -> tile -> range, blk_hi)", "n_contrib load issued, LDS zero, barrier", "pixel constants + checkpoint arrive",
-         "masks -> ring -> first records arrive", "the wave's groups", "barrier: the other three waves", "flush (LDS reads, id loads, atomics issued)"]
-d = np.diff(L[:, :8], axis=1)
-tot = L[:, 7] - L[:, 0]
-print(f"wave 0 of a live workgroup: {tot.mean():.0f} cycles from entry to the end of the flush (median {np.median(tot):.0f}); entries in its block's range: {L[:, 8].mean():.0f}")
+L = s[live & (s[:, 8] > 0) & (s[:, 4] != 0)]      # wave 0 had survivors: every stamp was written
+names = ["scalar chain (slot -> tile -> range, blk_hi, bbits)", "pixel loads issued, survivor list -> LDS ring", "pixel constants + checkpoint arrive",
+         "first records arrive", "the wave's groups"]
+d = np.diff(L[:, :6], axis=1)
+tot = L[:, 5] - L[:, 0]
+print(f"wave 0 of a live workgroup: {tot.mean():.0f} cycles from entry to its last group (median {np.median(tot):.0f}); survivors (padded): {L[:, 8].mean():.0f}")
 for k, nme in enumerate(names):
-    print(f"  {nme:52s} mean {d[:, k].mean():8.0f}  median {np.median(d[:, k]):8.0f}  p90 {np.percentile(d[:, k], 90):8.0f}   ({100 * d[:, k].mean() / tot.mean():.0f} %)")
+    print(f"  {nme:60s} mean {d[:, k].mean():8.0f}  median {np.median(d[:, k]):8.0f}  p90 {np.percentile(d[:, k], 90):8.0f}   ({100 * d[:, k].mean() / tot.mean():.0f} %)")
 act = L[L[:, 8] > 0]
-da = np.diff(act[:, :8], axis=1)
-print(f"waves WITH work ({len(act)}): groups phase mean {da[:, 4].mean():.0f} cycles for {act[:, 8].mean():.0f} list entries in range; first-records wait {da[:, 3].mean():.0f}")
-span = s[started][:, 0]
-print(f"launch span by the stamps: {(s[live][:, 7].max() - span.min()) / 2.4e3:.1f} us at 2.4 GHz")
+da = np.diff(act[:, :6], axis=1)
+print(f"waves WITH survivors ({len(act)}): groups phase mean {da[:, 4].mean():.0f} cycles for {act[:, 8].mean() / 4:.1f} groups of four = "
+      f"{da[:, 4].sum() / (act[:, 8].sum() / 4):.0f} cycles per group; first-records wait {da[:, 3].mean():.0f}")
+t0 = s[started][:, 0].min()
+span = s[live][:, 5].max() - t0
+print(f"launch span by the stamps: {span / 2.4e3:.1f} us at 2.4 GHz")
+# waves in flight: every live workgroup holds four waves from its entry to (about) its wave 0's last group
+ev = np.concatenate([np.stack([L[:, 0], np.ones(len(L))], 1), np.stack([L[:, 5], -np.ones(len(L))], 1)])
+ev = ev[np.argsort(ev[:, 0])]
+conc = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0], append=ev[-1, 0])
+print(f"live workgroups in flight, time average: {(conc * dt).sum() / span:.0f} (x 4 waves / 1024 SIMDs = {(conc * dt).sum() / span * 4 / 1024:.2f} live waves per SIMD); "
+      f"in their groups phase: {(L[:, 5] - L[:, 4]).sum() / span * 4 / 1024:.2f} per SIMD")
