@@ -1586,6 +1586,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 //   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..15 pad
 constexpr int ACC_STRIDE = 16;
 
+// ---- K7's chains across the four survivor rows of a group (round 4).  v_permlane16_swap(x, x) hands every lane the two values of its
+// row PAIR (even row's, odd row's); one v_permlane32_swap of the pair's product / sum hands it the totals of both pairs.  The prefix a row
+// needs is then two row-masked DPP operations away -- 2 swaps + 2 masked ops per chain instead of an all-gather of the four values
+// (3 swaps), four dependent operations and three row selects.  The product / sum of a group associates as (f0 f1)(f2 f3) instead of
+// front to back: K7's T and S differ from a sequential walk in the last bit (K7 takes every blend decision from n_contrib, not from T).
+#define CSPLAT_ROWMASK_OP(OP, dst, src0, src1, RM)                                                                                  \
+    asm("s_nop 1\n\tv_" OP "_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:" RM " bank_mask:0xf" : "+v"(dst) : "v"(src0), "v"(src1))
+// Tin: the pixel's transmittance in front of the group (same in the pixel's four lanes) -> in front of the lane's own survivor, behind the group
+__device__ __forceinline__ void rows_scan_mul(float f, float Tin, float &Tr, float &Tout) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(f), __float_as_uint(f), false, false);
+    const float ev = __uint_as_float(s16[0]), od = __uint_as_float(s16[1]);       // the pair's even / odd row
+    const float pr = ev * od;
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pr), __float_as_uint(pr), false, false);
+    const float lo = __uint_as_float(s32[0]), hi = __uint_as_float(s32[1]);       // rows 0-1, rows 2-3
+    float base = Tin;
+    CSPLAT_ROWMASK_OP("mul", base, lo, Tin, "0xc");                               // rows 2, 3: behind the first pair
+    Tr = base;
+    CSPLAT_ROWMASK_OP("mul", Tr, ev, base, "0xa");                                // odd rows: behind the pair's even row
+    Tout = (Tin * lo) * hi;
+}
+// inclusive: Sr = Sin + the addends up to and including the lane's own survivor
+__device__ __forceinline__ void rows_scan_add(float g, float Sin, float &Sr, float &Sout) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(g), __float_as_uint(g), false, false);
+    const float ev = __uint_as_float(s16[0]), od = __uint_as_float(s16[1]);
+    const float pr = ev + od;
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pr), __float_as_uint(pr), false, false);
+    const float lo = __uint_as_float(s32[0]), hi = __uint_as_float(s32[1]);
+    float base = Sin;
+    CSPLAT_ROWMASK_OP("add", base, lo, Sin, "0xc");
+    float incl = ev;
+    CSPLAT_ROWMASK_OP("add", incl, od, ev, "0xa");
+    Sr = base + incl;
+    Sout = (Sin + lo) + hi;
+}
+// the first two butterfly levels keep / send by 4-lane BANKS (lane bits 3 and 2): two bank-masked DPP adds -- lanes of the keep-a banks
+// form a + partner's a, lanes of the keep-b banks b + partner's b -- instead of two selects and a DPP add (bit-identical)
+#define CSPLAT_BFLY_BANK(dst, a, b, CTRL, MA, MB)                                                                                   \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" MA "\n\t"                                            \
+        "v_add_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:" MB : "=&v"(dst) : "v"(a), "v"(b))
 // one level of a butterfly "transpose-reduce": lanes with s == 0 keep a (own + partner's), lanes with s == 1 keep b;
 // the partner permutation CTRL must flip s.  Two values are folded by one DPP add instead of two.
 template <int CTRL>
@@ -1736,7 +1775,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         }
         if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(S), "v"(T)); }
         mark(3);                                                        // the pixel constants, the checkpoint and the first batch have arrived
-        const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
         const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
         // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
         const bool red_active = !lb0 || l16 == 1;
@@ -1750,110 +1788,55 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
             t.a = ra[sl]; t.b = rb[sl]; t.c.x = rc[sl];
             if (!DET) t.id = rid[sl];
         };
-        auto process = [&](const Trip &t) {
-            const float dx = t.a.x - fx, dy = t.a.y - fy;
-            const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
-            const float G = __expf(power);
-            const float a = fminf(0.99f, t.b.y * G);
-            const bool act = t.pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
-            const float al = act ? a : 0.f;
-            const float F = 1.f - al;
-            const Row4 g = rows_allgather(F);
-            const float P1 = T * g.v0, P2 = P1 * g.v1, P3 = P2 * g.v2, P4 = P3 * g.v3;
-            const float Tr = rowsel(r, T, P1, P2, P3);
-            const float gdot = t.b.z * dp0 + t.b.w * dp1 + t.c.x * dp2;
-            const float dchannel_dcolor = al * Tr;
-            const Row4 gw = rows_allgather(gdot * dchannel_dcolor);
-            const float S1 = S + gw.v0, S2 = S1 + gw.v1, S3 = S2 + gw.v2, S4 = S3 + gw.v3;
-            const float Sr = rowsel(r, S1, S2, S3, S4);
-            T = P4; S = S4;
-            const float dL_dalpha = act ? Tr * gdot - (OD - Sr) * __builtin_amdgcn_rcpf(F) : 0.f;
-            const float dL_dG = t.b.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * t.a.z - gdy * t.a.w;
-            const float dG_ddely = -gdy * t.b.x - gdx * t.a.w;
-            float v[9];
-            v[0] = dL_dG * dG_ddelx * ddelx_dx;
-            v[1] = dL_dG * dG_ddely * ddely_dy;
-            v[2] = -0.5f * gdx * dx * dL_dG;
-            v[3] = -0.5f * gdx * dy * dL_dG;
-            v[4] = -0.5f * gdy * dy * dL_dG;
-            v[5] = G * dL_dalpha;
-            v[6] = dchannel_dcolor * dp0; v[7] = dchannel_dcolor * dp1; v[8] = dchannel_dcolor * dp2;
-            // 9 values x 16 lanes -> 9 totals per row: each level folds two values into one register
-            const float a0 = bfly<0x140>(v[0], v[1], lb3), a1 = bfly<0x140>(v[2], v[3], lb3);
-            const float a2 = bfly<0x140>(v[4], v[5], lb3), a3 = bfly<0x140>(v[6], v[7], lb3);
-            float l8 = dpp_add<0x140>(v[8]);
-            const float b0 = bfly<0x141>(a0, a1, lb2), b1 = bfly<0x141>(a2, a3, lb2);
-            l8 = dpp_add<0x141>(l8);
-            float c0 = bfly<0x4E>(b0, b1, lb1);
-            l8 = dpp_add<0x4E>(l8);
-            c0 = dpp_add<0xB1>(c0);
-            l8 = dpp_add<0xB1>(l8);
-            const float tot = lb0 ? l8 : c0;
-            // (every survivor of the list was blended at one of the block's pixels: the row always has something to add, padding aside)
-            if (red_active && t.pos >= 0) {
-                if (DET) det[((size_t)(rx + (uint32_t)t.pos) * 16 + (size_t)blk) * 9 + red_t] = tot;      // one (entry, block) pair is visited exactly once
-                else atomicAdd(acc + (size_t)t.id * ACC_STRIDE + red_t, tot);                          // nine lanes, one 64-byte record
-            }
-        };
-        // TWO groups at once, statement by statement: a group is one dependent chain of ~125 vector instructions (~10 cycles from one to
-        // the next: ~1,200 cycles a group for a wave on its own, tools/k7_stamps.py -- and the same with the atomics removed); groups k and
-        // k + 1 only meet where T and S pass from one to the other, so written side by side the two chains fill each other's waits.
-        auto process2 = [&](const Trip &t0, const Trip &t1) {
-            const Trip *t[2] = {&t0, &t1};
-            float dx[2], dy[2], G[2], al[2], F[2], gdot[2], Tr[2], Sr[2], dcc[2];
-            bool act[2];
-            Row4 g[2], gw[2];
+        // N groups at once, statement by statement: a group is one dependent chain of ~110 vector instructions (~10 cycles from one to the
+        // next: ~1,200 cycles a group for a wave on its own, tools/k7_stamps.py -- the same with the atomics removed); groups k and k + 1
+        // only meet where T and S pass from one to the other, so written side by side the two chains fill each other's waits.
+        auto processN = [&](auto NC, const Trip *const *t) {
+            constexpr int N = decltype(NC)::value;
+            float dx[N], dy[N], G[N], al[N], F[N], gdot[N], Tr[N], Sr[N], dcc[N], tot[N];
+            bool act[N];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < N; u++) {
                 dx[u] = t[u]->a.x - fx; dy[u] = t[u]->a.y - fy;
                 const float power = -0.5f * (t[u]->a.z * dx[u] * dx[u] + t[u]->b.x * dy[u] * dy[u]) - t[u]->a.w * dx[u] * dy[u];
                 G[u] = __expf(power);
                 const float a = fminf(0.99f, t[u]->b.y * G[u]);
-                act[u] = t[u]->pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;
+                act[u] = t[u]->pos < ncontrib && power <= 0.f && a >= ALPHA_MIN;   // (padding: pos = -1, opacity 0 -> a = 0)
                 al[u] = act[u] ? a : 0.f;
                 F[u] = 1.f - al[u];
                 gdot[u] = t[u]->b.z * dp0 + t[u]->b.w * dp1 + t[u]->c.x * dp2;
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) g[u] = rows_allgather(F[u]);
-            {
-                const float P1 = T * g[0].v0, P2 = P1 * g[0].v1, P3 = P2 * g[0].v2, P4 = P3 * g[0].v3;
-                const float Q1 = P4 * g[1].v0, Q2 = Q1 * g[1].v1, Q3 = Q2 * g[1].v2, Q4 = Q3 * g[1].v3;
-                Tr[0] = rowsel(r, T, P1, P2, P3);
-                Tr[1] = rowsel(r, P4, Q1, Q2, Q3);
-                T = Q4;
-            }
+            for (int u = 0; u < N; u++) rows_scan_mul(F[u], T, Tr[u], T);
 #pragma unroll
-            for (int u = 0; u < 2; u++) { dcc[u] = al[u] * Tr[u]; gw[u] = rows_allgather(gdot[u] * dcc[u]); }
-            {
-                const float S1 = S + gw[0].v0, S2 = S1 + gw[0].v1, S3 = S2 + gw[0].v2, S4 = S3 + gw[0].v3;
-                const float U1 = S4 + gw[1].v0, U2 = U1 + gw[1].v1, U3 = U2 + gw[1].v2, U4 = U3 + gw[1].v3;
-                Sr[0] = rowsel(r, S1, S2, S3, S4);
-                Sr[1] = rowsel(r, U1, U2, U3, U4);
-                S = U4;
-            }
-            float tot[2];
+            for (int u = 0; u < N; u++) dcc[u] = al[u] * Tr[u];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < N; u++) rows_scan_add(gdot[u] * dcc[u], S, Sr[u], S);
+#pragma unroll
+            for (int u = 0; u < N; u++) {
                 const float dL_dalpha = act[u] ? Tr[u] * gdot[u] - (OD - Sr[u]) * __builtin_amdgcn_rcpf(F[u]) : 0.f;
-                const float dL_dG = t[u]->b.y * dL_dalpha;
-                const float gdx = G[u] * dx[u], gdy = G[u] * dy[u];
-                const float dG_ddelx = -gdx * t[u]->a.z - gdy * t[u]->a.w;
-                const float dG_ddely = -gdy * t[u]->b.x - gdx * t[u]->a.w;
+                // with h = -0.5 G dL/dG:  dL/dconic = h (dx^2, dx dy, dy^2);  dL/dmean2D = (W, H) * (hx a + hy b, hy c + hx b) -- the
+                // image-size factors 2 * 0.5 W, 2 * 0.5 H are applied ONCE per Gaussian, by K8, to the summed records
+                const float gda = G[u] * dL_dalpha;
+                const float h = -0.5f * t[u]->b.y * gda;
+                const float hx = h * dx[u], hy = h * dy[u];
                 float v[9];
-                v[0] = dL_dG * dG_ddelx * ddelx_dx;
-                v[1] = dL_dG * dG_ddely * ddely_dy;
-                v[2] = -0.5f * gdx * dx[u] * dL_dG;
-                v[3] = -0.5f * gdx * dy[u] * dL_dG;
-                v[4] = -0.5f * gdy * dy[u] * dL_dG;
-                v[5] = G[u] * dL_dalpha;
+                v[0] = hx * t[u]->a.z + hy * t[u]->a.w;
+                v[1] = hy * t[u]->b.x + hx * t[u]->a.w;
+                v[2] = hx * dx[u];
+                v[3] = hx * dy[u];
+                v[4] = hy * dy[u];
+                v[5] = gda;
                 v[6] = dcc[u] * dp0; v[7] = dcc[u] * dp1; v[8] = dcc[u] * dp2;
-                const float a0 = bfly<0x140>(v[0], v[1], lb3), a1 = bfly<0x140>(v[2], v[3], lb3);
-                const float a2 = bfly<0x140>(v[4], v[5], lb3), a3 = bfly<0x140>(v[6], v[7], lb3);
+                // 9 values x 16 lanes -> 9 totals per row: each level folds two values into one register
+                float a0, a1, a2, a3, b0, b1;
+                CSPLAT_BFLY_BANK(a0, v[0], v[1], "row_mirror", "0x3", "0xc");
+                CSPLAT_BFLY_BANK(a1, v[2], v[3], "row_mirror", "0x3", "0xc");
+                CSPLAT_BFLY_BANK(a2, v[4], v[5], "row_mirror", "0x3", "0xc");
+                CSPLAT_BFLY_BANK(a3, v[6], v[7], "row_mirror", "0x3", "0xc");
                 float l8 = dpp_add<0x140>(v[8]);
-                const float b0 = bfly<0x141>(a0, a1, lb2), b1 = bfly<0x141>(a2, a3, lb2);
+                CSPLAT_BFLY_BANK(b0, a0, a1, "row_half_mirror", "0x5", "0xa");
+                CSPLAT_BFLY_BANK(b1, a2, a3, "row_half_mirror", "0x5", "0xa");
                 l8 = dpp_add<0x141>(l8);
                 float c0 = bfly<0x4E>(b0, b1, lb1);
                 l8 = dpp_add<0x4E>(l8);
@@ -1861,13 +1844,16 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
                 l8 = dpp_add<0xB1>(l8);
                 tot[u] = lb0 ? l8 : c0;
             }
+            // (every survivor of the list was blended at one of the block's pixels: the row always has something to add, padding aside)
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < N; u++)
                 if (red_active && t[u]->pos >= 0) {
-                    if (DET) det[((size_t)(rx + (uint32_t)t[u]->pos) * 16 + (size_t)blk) * 9 + red_t] = tot[u];
-                    else atomicAdd(acc + (size_t)t[u]->id * ACC_STRIDE + red_t, tot[u]);
+                    if (DET) det[((size_t)(rx + (uint32_t)t[u]->pos) * 16 + (size_t)blk) * 9 + red_t] = tot[u];   // one (entry, block) pair is visited exactly once
+                    else atomicAdd(acc + (size_t)t[u]->id * ACC_STRIDE + red_t, tot[u]);                      // nine lanes, one 64-byte record
                 }
         };
+        auto process = [&](const Trip &t0) { const Trip *t[1] = {&t0}; processN(std::integral_constant<int, 1>{}, t); };
+        auto process2 = [&](const Trip &t0, const Trip &t1) { const Trip *t[2] = {&t0, &t1}; processN(std::integral_constant<int, 2>{}, t); };
         bool first = true;
 #ifndef CSPLAT_K7X
 #define CSPLAT_K7X 0
@@ -2012,6 +1998,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
     float a9[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
+    a9[0] *= (float)cam.W; a9[1] *= (float)cam.H;      // (K7 leaves dL/dmean2D without the pixel <- NDC factors 2 * 0.5 W, 2 * 0.5 H)
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
     PUT(dL_dopacity, i, a9[5], CSPLAT_ACC_OPACITY);
@@ -2284,6 +2271,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     float a9[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? a9_n[k] : 0.f;
+    a9[0] *= (float)cam.W; a9[1] *= (float)cam.H;      // (see k_preprocess_bwd)
     if (vi + VL < tab.n) {
         const K8View &wn = tab.v[vi + VL];
         vis_n = wn.radii[i] > 0;
