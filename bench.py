@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
+    ap.add_argument("--halves", action="store_true", help="experiment: the step's views as two half-batches on two HIP streams")
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
     ap.add_argument("--eager", action="store_true", help="launch every step kernel by kernel instead of replaying recorded hipGraphs")
@@ -162,7 +163,24 @@ def main():
             m2ds = [self.zeros[i].detach().requires_grad_() for i in range(V)]
             # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views): the first phase of
             # all views goes out in four launches, then every view's binning / compositing kernels overlap on the chip
-            if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
+            if args.view_streams and args.halves and V >= 4 and V % 2 == 0:
+                cur = torch.cuda.current_stream()
+                if not hasattr(self, "_hs"):
+                    self._hs = [torch.cuda.Stream(), torch.cuda.Stream()]
+                losses, self.radii = [], []
+                for h_, st_ in enumerate(self._hs):
+                    st_.wait_stream(cur)
+                    with torch.cuda.stream(st_):
+                        idx = list(range(h_ * V // 2, (h_ + 1) * V // 2))
+                        colors, outs_ = rasterize_views([self.settings[i] for i in idx],
+                                                        [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"], shs=pr["shs"],
+                                                              scales=pr["scales"], rotations=pr["rotations"]) for i in idx], stacked=True)
+                        self.radii += [o_[1] for o_ in outs_]
+                        losses.append(l1_loss(colors, self.targets_stacked[idx[0]:idx[-1] + 1]))
+                for st_ in self._hs:
+                    cur.wait_stream(st_)
+                loss = (losses[0] + losses[1]) * 0.5
+            elif args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
                 colors, outs_ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
                                                                      shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
                                                                 for i in range(V)], stacked=True)
@@ -212,7 +230,8 @@ def main():
             import diff_gaussian_rasterization as dgr_
             w_, G = self.w, self.G
             torch.cuda.synchronize()
-            native.REPLAY_STREAM[dev.index] = native.stream_handle(dev)      # (scratch "zeroed once per stream": the stream of the replays)
+            if not args.halves:
+                native.REPLAY_STREAM[dev.index] = native.stream_handle(dev)      # (scratch "zeroed once per stream": the stream of the replays)
             for _ in range(G):
                 valid = torch.zeros(1, dtype=torch.int32, device=dev)
                 faith = {"caps": self.caps, "valid": valid}

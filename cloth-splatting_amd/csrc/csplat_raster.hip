@@ -586,6 +586,7 @@ struct P2View {
     float4 *ckpt;
     uint16_t *mask16;
     unsigned long long *bbits;  // [slots][16 blocks][4]: which entries of a segment each block blended (K6 -> K7)
+    unsigned long long *bmask;  // [chunks][16 blocks]: which entries of a 64-entry list chunk reach each block (K5b -> K6)
     float4 *recA, *recB;
     float2 *recC;
     const float *bg;
@@ -1065,21 +1066,23 @@ __device__ __forceinline__ float rowsel(int, float a, float b, float c, float d)
 __device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int gx, const uint64_t *__restrict__ keys_sorted,
                                                  const uint32_t *__restrict__ ids_sorted, const float4 *__restrict__ pack,
                                                  uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
-                                                 float4 *__restrict__ recB, float2 *__restrict__ recC, int exact, int64_t block) {
+                                                 float4 *__restrict__ recB, float2 *__restrict__ recC, int exact, int64_t block,
+                                                 unsigned long long *__restrict__ bmask) {
     const int64_t i = block * 256 + threadIdx.x;
-    if (i >= R && i != null_at) return;
+    // (workgroup-uniform: nothing of this workgroup's range is in use -- no list entry, not the list's last chunk, not the null record)
+    if (block * 256 > (R | 63) && !(block * 256 <= null_at && null_at < block * 256 + 256)) return;
     if (i == null_at) {   // the null record behind the list (at the list's CAPACITY): opacity 0, pads incomplete groups of four
         mask16[i] = 0;
         recA[i] = make_float4(0.f, 0.f, 0.f, 0.f); recB[i] = make_float4(0.f, 0.f, 0.f, 0.f); recC[i] = make_float2(0.f, 0.f);
-        return;
     }
+    uint32_t m = 0;
+    if (i < R) {
     const uint32_t tile = (uint32_t)(keys_sorted[i] >> 32), id = ids_sorted[i];
     const float4 pa = pack[3 * (size_t)id], pb = pack[3 * (size_t)id + 1], pc = pack[3 * (size_t)id + 2];
     const float2 c = make_float2(pa.x, pa.y);
     const float4 co = make_float4(pa.z, pa.w, pb.x, pb.y);
     const float cut = pc.z;
     const float x0 = (float)((tile % (uint32_t)gx) * CSPLAT_TILE), y0 = (float)((tile / (uint32_t)gx) * CSPLAT_TILE);
-    uint32_t m = 0;
 #pragma unroll
     for (int by = 0; by < 4; by++)
 #pragma unroll
@@ -1089,12 +1092,33 @@ __device__ __forceinline__ void block_masks_body(int64_t R, int64_t null_at, int
     recA[i] = pa;
     recB[i] = pb;
     recC[i] = make_float2(pc.x, pc.y);
+    }
+    // the wave's 64 entries are list chunk i >> 6: the sixteen ballots ARE the chunk's per-block words; lane b of the wave stores block b's
+    // (entries at or behind the list's end contribute 0; K6 masks its last chunk by the list length anyway)
+    if (bmask && (i >> 6) <= (R >> 6)) {
+        uint32_t lo = 0u, hi = 0u;
+        // (v_writelane_b32 with a literal lane: block b's ballot -- an SGPR pair -- lands in lane b of (lo, hi))
+#define CSPLAT_WORD_TO_LANE(b)                                                                                                      \
+        {                                                                                                                           \
+            const unsigned long long wb_ = __builtin_amdgcn_ballot_w64((m >> b) & 1u);                                              \
+            asm("v_writelane_b32 %0, %2, " #b "\n\tv_writelane_b32 %1, %3, " #b                                                     \
+                : "+v"(lo), "+v"(hi) : "s"((uint32_t)wb_), "s"((uint32_t)(wb_ >> 32)));                                             \
+        }
+        CSPLAT_WORD_TO_LANE(0) CSPLAT_WORD_TO_LANE(1) CSPLAT_WORD_TO_LANE(2) CSPLAT_WORD_TO_LANE(3)
+        CSPLAT_WORD_TO_LANE(4) CSPLAT_WORD_TO_LANE(5) CSPLAT_WORD_TO_LANE(6) CSPLAT_WORD_TO_LANE(7)
+        CSPLAT_WORD_TO_LANE(8) CSPLAT_WORD_TO_LANE(9) CSPLAT_WORD_TO_LANE(10) CSPLAT_WORD_TO_LANE(11)
+        CSPLAT_WORD_TO_LANE(12) CSPLAT_WORD_TO_LANE(13) CSPLAT_WORD_TO_LANE(14) CSPLAT_WORD_TO_LANE(15)
+#undef CSPLAT_WORD_TO_LANE
+        const int lane = threadIdx.x & 63;
+        if (lane < 16) bmask[(size_t)(i >> 6) * 16 + lane] = ((unsigned long long)hi << 32) | lo;
+    }
 }
 __global__ __launch_bounds__(256) void k_block_masks(int64_t R, int gx, const uint64_t *__restrict__ keys_sorted,
                                                       const uint32_t *__restrict__ ids_sorted, const float4 *__restrict__ pack,
                                                       uint16_t *__restrict__ mask16, float4 *__restrict__ recA,
-                                                      float4 *__restrict__ recB, float2 *__restrict__ recC, int exact) {
-    block_masks_body(R, R, gx, keys_sorted, ids_sorted, pack, mask16, recA, recB, recC, exact, blockIdx.x);
+                                                      float4 *__restrict__ recB, float2 *__restrict__ recC, int exact,
+                                                      unsigned long long *__restrict__ bmask) {
+    block_masks_body(R, R, gx, keys_sorted, ids_sorted, pack, mask16, recA, recB, recC, exact, blockIdx.x, bmask);
 }
 // xcd_views = V (1, 2, 4 or 8) on a 1-D grid: a workgroup's XCD is blockIdx.x % 8 and XCD x serves ONLY view x % V.  The list entries of
 // a tile gather their Gaussians' 48-byte records in depth order (random), and a Gaussian recurs in the tiles next to and below it -- one
@@ -1111,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_block_masks_views(P2Table tab, int exac
     const P2View &w = tab.v[view];
     if (!p2_live(w)) return;
     block_masks_body(w.spec ? (int64_t)w.info[0] : (int64_t)w.R, (int64_t)w.R, w.cam.gx, w.keys_sorted, w.ids_sorted, w.g.pack, w.mask16,
-                     w.recA, w.recB, w.recC, exact, block);
+                     w.recA, w.recB, w.recC, exact, block, w.bmask);
 }
 
 // The survivors of block `blk` among list positions [lo, hi) of one tile, as a stream of GROUPS OF FOUR that never cross a
@@ -1162,6 +1186,53 @@ struct BlockStreamT {
     }
 };
 typedef BlockStreamT<4, RING> BlockStream;
+
+// The same stream fed from K5b's TRANSPOSED masks (round 4): bmask[chunk][block] is the ballot a wave of BlockStreamT forms from 64 mask
+// loads -- here it arrives by ONE scalar load per chunk (two chunks ahead), so the stream issues no vector-memory instruction at all and
+// the only loads of K6's loop are the step's records.  Chunks of bmask are aligned to the GLOBAL list index; a tile's list starts at any
+// rx, so tile-relative chunk j is bits o.. of word g0 + j joined with bits ..o-1 of word g0 + j + 1 (o = rx & 63: a funnel shift on the
+// scalar unit) -- segment boundaries (multiples of 256 tile-relative entries) then fall between chunks as before.
+// (the words are read through a CONSTANT-address-space pointer: nothing writes bmask while K6 runs, and only then does the compiler keep
+//  the loads on the scalar unit inside the loop -- behind the loop's stores a plain global pointer gets a vector load + v_readfirstlane
+//  and an s_waitcnt vmcnt(0) on the spot)
+typedef const __attribute__((address_space(4))) unsigned long long *const_u64_ptr;
+template <int G, int RN>
+struct WordStreamT {
+    const_u64_ptr bw;                // word of global chunk g0 for this block; + 16 per chunk
+    int *ring;
+    int cbase, hi, lane, tail, o, j;
+    unsigned long long wa, wb, wc;
+    __device__ __forceinline__ void start(const unsigned long long *bmask, uint32_t rx, int hi_, int blk, int lane_, int *ring_) {
+        bw = (const_u64_ptr)(bmask + ((size_t)(rx >> 6) * 16 + (size_t)blk));
+        o = (int)(rx & 63u); hi = hi_; lane = lane_; ring = ring_; cbase = 0; tail = 0; j = 0;
+        wa = bw[0]; wb = bw[16]; wc = bw[32];
+    }
+    __device__ __forceinline__ void ingest() {   // one tile-relative chunk
+        unsigned long long cur = o ? (wa >> o) | (wb << (64 - o)) : wa;
+        const int rem = hi - cbase;
+        if (rem < 64) cur &= (1ull << rem) - 1ull;
+        wa = wb; wb = wc; j++;
+        wc = bw[(size_t)(j + 2) * 16];
+        if (__builtin_amdgcn_inverse_ballot_w64(cur)) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cur >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cur, 0u));
+            ring[(tail + rank) & (RN - 1)] = cbase + lane;
+        }
+        tail += (int)__popcll(cur);
+        cbase += 64;
+        if ((cbase & (SEG - 1)) == 0 || cbase >= hi) {   // the segment (or the list) ends here: complete the group
+            const int pad = (-tail) & (G - 1);
+            if (lane < pad) ring[(tail + lane) & (RN - 1)] = -1;
+            tail += pad;
+        }
+    }
+    // list position of survivor `slot` of group k (-1 = padding, and -1 with `false` when the stream ends before group k)
+    __device__ __forceinline__ bool group(int k, int slot, int &pos) {
+        while (G * k + G > tail && cbase < hi) ingest();
+        const bool ok = G * k < tail;
+        pos = ok ? ring[(G * k + slot) & (RN - 1)] : -1;
+        return ok;
+    }
+};
 
 struct Trip { float4 a, b; float2 c; int pos; uint32_t id; };   // the lane's survivor of a group (row r's), pos = list position or -1
 
@@ -1359,6 +1430,7 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
                                                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                      float *__restrict__ out_color, float *__restrict__ out_depth,
                                                      unsigned long long *__restrict__ bbits,
+                                                     const unsigned long long *__restrict__ bmask,
                                                      const uint32_t *__restrict__ order = nullptr) {
     __shared__ int s_ring[RING16];
     __shared__ uint32_t s_hit[SEG / 32];
@@ -1373,28 +1445,35 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
     const int2 range = ranges[tile];
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
-    bool inside[4], done[4];
+    // A pixel that is DONE (outside the image, or its walk has ended: T fell below 1e-4) keeps working transmittance 0 -- every weight it
+    // forms is 0 by arithmetic, no select -- and its final T waits in s_Tend; which pixels are done is a LANE MASK per pixel column
+    // (m_done[j], an SGPR pair: the decisions of a step are scalar-unit logic on compare results, selects take the masks directly).
+    __shared__ float s_Tend[16];
+    bool inside[4];
+    unsigned long long m_done[4];
     float T[4], C0[4], C1[4], C2[4], Dp[4], fx[4];
     uint32_t last[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         inside[j] = px0 + j < W && py < H;
-        done[j] = !inside[j];
-        T[j] = 1.f; C0[j] = C1[j] = C2[j] = Dp[j] = 0.f;      // T: the pixel's (same in its 16 lanes); C*, Dp: this lane's survivors' share
+        m_done[j] = __builtin_amdgcn_ballot_w64(!inside[j]);
+        T[j] = inside[j] ? 1.f : 0.f; C0[j] = C1[j] = C2[j] = Dp[j] = 0.f;      // T: the pixel's (same in its 16 lanes); C*, Dp: this lane's survivors' share
         last[j] = 0u;
         fx[j] = (float)(px0 + j);
     }
     int seg0 = 0, seg_written = -1;
-    if (n > 0 && __builtin_amdgcn_ballot_w64(!(done[0] && done[1] && done[2] && done[3])) != 0ull) {
+    if (n > 0 && (m_done[0] & m_done[1] & m_done[2] & m_done[3]) != ~0ull) {
         seg0 = seg_offset[tile];
-        BlockStreamT<16, RING16> st;
-        st.start(mask16 + rx, 0, n, blk, lane, s_ring);
+        WordStreamT<16, RING16> st;
+        st.start(bmask, rx, n, blk, lane, s_ring);
         if (lane < SEG / 32) s_hit[lane] = 0u;
+        // (the three loads are issued whether or not the stream still has a step: s_waitcnt vmcnt counts in order, and a load the
+        //  compiler must assume was NOT issued makes it wait for the youngest ones -- see K7's loop)
         auto fetch = [&](Trip &t, int k) -> bool {
-            if (!st.group(k, sv, t.pos)) return false;
+            const bool ok = st.group(k, sv, t.pos);
             const uint32_t ri = t.pos >= 0 ? rx + (uint32_t)t.pos : null_rec;
             t.a = recA[ri]; t.b = recB[ri]; t.c = recC[ri];
-            return true;
+            return ok;
         };
         auto process = [&](const Trip &t) {
             const int seg = __builtin_amdgcn_readfirstlane(t.pos) / SEG;   // (a group's first entry is never padding)
@@ -1416,54 +1495,84 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
             }
             const float dy = t.a.y - fy;
             float al[4], inc[4];
+            unsigned long long m_live[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float dx = t.a.x - fx[j];
                 const float power = -0.5f * (t.a.z * dx * dx + t.b.x * dy * dy) - t.a.w * dx * dy;
                 const float a = fminf(0.99f, t.b.y * __expf(power));
-                al[j] = (!done[j] && power <= 0.f && a >= ALPHA_MIN) ? a : 0.f;
+                m_live[j] = __builtin_amdgcn_ballot_w64(power <= 0.f) & __builtin_amdgcn_ballot_w64(a >= ALPHA_MIN);
+                al[j] = __builtin_amdgcn_inverse_ballot_w64(m_live[j]) ? a : 0.f;
                 inc[j] = 1.f - al[j];
             }
             row_scan4_mul(inc);                                          // the pixel's factor up to and including every survivor
-            float P[4];
-            bool fin = false, blended = false;
+            float Tr[4], P[4], Pend[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { Tr[j] = T[j]; P[j] = T[j] * inc[j]; }
+            // transmittance in front of the lane's survivor (T x the scan of the lane to the left; survivor 0 of the row keeps T) and
+            // behind the step's last survivor (row_newbcast:15)
+            asm("s_nop 1\n\t"
+                "v_mul_f32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mul_f32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mul_f32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mul_f32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf"
+                : "+v"(Tr[0]), "+v"(Tr[1]), "+v"(Tr[2]), "+v"(Tr[3]) : "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3]));
+            asm("s_nop 1\n\t"
+                "v_mov_b32_dpp %0, %4 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %1, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %2, %6 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %3, %7 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                : "=&v"(Pend[0]), "=&v"(Pend[1]), "=&v"(Pend[2]), "=&v"(Pend[3]) : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]));
+            unsigned long long m_end[4], any_end = 0ull, m_bl = 0ull;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float Tr = T[j] * dpp_mov<0x111, 0xF>(inc[j], 1.f);        // transmittance in front of the lane's survivor
-                P[j] = T[j] * inc[j];                                            // ... and behind it (what the T test looks at)
-                const bool blend = al[j] > 0.f && P[j] >= T_EPS;
-                blended = blended || blend;
-                const float wgt = blend ? al[j] * Tr : 0.f;
-                C0[j] += t.b.z * wgt; C1[j] += t.b.w * wgt; C2[j] += t.c.x * wgt; Dp[j] += t.c.y * wgt;
-                last[j] = blend ? (uint32_t)(t.pos + 1) : last[j];
-                const float Pend = dpp_mov<0x15F, 0xF>(P[j], P[j]);              // row_newbcast:15: behind the step's last survivor
-                const bool ends = !done[j] && !(Pend >= T_EPS);                  // the pixel's walk ends inside this step
-                fin = fin || ends;
-                if (!ends) T[j] = done[j] ? T[j] : Pend;
-                else P[j] = P[j] >= T_EPS ? P[j] : T[j];                         // candidates for the T it keeps: the last product above
-                done[j] = done[j] || ends;                                       //   the threshold (the products only decrease)
-                if (!ends) P[j] = 3.0e38f;
+                m_end[j] = __builtin_amdgcn_ballot_w64(!(Pend[j] >= T_EPS)) & ~m_done[j];       // the pixel's walk ends inside this step
+                any_end |= m_end[j];
             }
-            {   // survivor sv was blended at one of the block's 16 pixels (its four lanes, four pixels each): its byte in the strip
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(blended);
-                const uint32_t any16 = (uint32_t)(bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFu;
-                if (lane < 16 && ((any16 >> lane) & 1u)) bbits_mark(s_hit, t.pos);
-            }
-            if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {     // rare (once per pixel): the final T of the pixels that ended = the smallest candidate of the row
-                float m[4] = {P[0], P[1], P[2], P[3]};
-                row_scan4_min(m);
+            if (any_end == 0ull) {
+                // no pixel of the block ends in this step: every product of an open pixel is above the threshold (they only decrease
+                // along the row), so a survivor is blended exactly where its alpha passed -- and a done pixel's weight is 0 x anything
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float mend = dpp_mov<0x15F, 0xF>(m[j], m[j]);
-                    if (mend < 1.0e38f) T[j] = mend;
+                    const float wgt = al[j] * Tr[j];
+                    C0[j] += t.b.z * wgt; C1[j] += t.b.w * wgt; C2[j] += t.c.x * wgt; Dp[j] += t.c.y * wgt;
+                    const unsigned long long mb = m_live[j] & ~m_done[j];
+                    m_bl |= mb;
+                    last[j] = __builtin_amdgcn_inverse_ballot_w64(mb) ? (uint32_t)(t.pos + 1) : last[j];
+                    T[j] = Pend[j];
                 }
+            } else {
+                float cand[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned long long mb = m_live[j] & ~m_done[j] & __builtin_amdgcn_ballot_w64(P[j] >= T_EPS);
+                    m_bl |= mb;
+                    const float wgt = __builtin_amdgcn_inverse_ballot_w64(mb) ? al[j] * Tr[j] : 0.f;
+                    C0[j] += t.b.z * wgt; C1[j] += t.b.w * wgt; C2[j] += t.c.x * wgt; Dp[j] += t.c.y * wgt;
+                    last[j] = __builtin_amdgcn_inverse_ballot_w64(mb) ? (uint32_t)(t.pos + 1) : last[j];
+                    // the T an ending pixel keeps: the last product above the threshold (the products only decrease) = the row's smallest candidate
+                    cand[j] = __builtin_amdgcn_inverse_ballot_w64(m_end[j]) ? (P[j] >= T_EPS ? P[j] : T[j]) : 3.0e38f;
+                }
+                row_scan4_min(cand);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float mend = dpp_mov<0x15F, 0xF>(cand[j], cand[j]);
+                    const bool ended = __builtin_amdgcn_inverse_ballot_w64(m_end[j]);
+                    if (ended && sv == 0) s_Tend[q * 4 + j] = mend;
+                    m_done[j] |= m_end[j];
+                    T[j] = __builtin_amdgcn_inverse_ballot_w64(m_done[j]) ? 0.f : Pend[j];
+                }
+            }
+            {   // survivor sv was blended at one of the block's 16 pixels (its four lanes, four pixels each): its bit in the strip
+                const uint32_t any16 = (uint32_t)(m_bl | (m_bl >> 16) | (m_bl >> 32) | (m_bl >> 48)) & 0xFFFFu;
+                if (lane < 16 && ((any16 >> lane) & 1u)) bbits_mark(s_hit, t.pos);
             }
         };
         // software pipeline, two steps in flight (a step is ~16 survivors x 4 pixels of arithmetic: one step ahead covers the fetch)
         Trip ta, tb;
         bool va = fetch(ta, 0), vb = fetch(tb, 1);
         int k = 2;
-        auto all_done = [&]() { return __builtin_amdgcn_ballot_w64(!(done[0] && done[1] && done[2] && done[3])) == 0ull; };
+        auto all_done = [&]() { return (m_done[0] & m_done[1] & m_done[2] & m_done[3]) == ~0ull; };
         while (va) {
             process(ta);
             if (all_done()) break;
@@ -1474,6 +1583,9 @@ __device__ __forceinline__ void composite_fwd16_body(int tiles, int W, int H, in
             vb = fetch(tb, k++);
         }
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++)         // the pixels whose walk ended: the transmittance they kept
+        if (inside[j] && __builtin_amdgcn_inverse_ballot_w64(m_done[j])) T[j] = s_Tend[q * 4 + j];
     uint32_t hi_ = 0u;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1518,13 +1630,14 @@ __global__ __launch_bounds__(64) void k_composite_fwd(int tiles, int W, int H, i
                                                        int *seg_offset, float4 *__restrict__ ckpt,
                                                        float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                        float *__restrict__ out_color, float *__restrict__ out_depth,
-                                                       unsigned long long *__restrict__ bbits) {
+                                                       unsigned long long *__restrict__ bbits,
+                                                       const unsigned long long *__restrict__ bmask) {
     if (ROWS)
         composite_fwd_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
                            out_depth, (int)blockIdx.x, bbits);
     else
         composite_fwd16_body(tiles, W, H, gx, ranges, mask16, recA, recB, recC, null_rec, bg, seg_offset, ckpt, final_T, n_contrib, out_color,
-                             out_depth, bbits);
+                             out_depth, bbits, bmask);
 }
 // the waves behind the first busy_grid of a K6 launch: the tiles of the launch-order list that got no waves of their own -- the empty
 // ones -- receive what K6 writes for a tile without a list (background colour, T = 1, no contributor, blk_hi = 0), 256 pixels a pass
@@ -1578,7 +1691,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                            w.n_contrib, w.out_color, w.out_depth, (int)blockIdx.x, w.bbits, order);
     else
         composite_fwd16_body(tiles, W, H, w.cam.gx, w.ranges, w.mask16, w.recA, w.recB, w.recC, w.R, w.bg, w.seg_offset, w.ckpt, w.final_T,
-                             w.n_contrib, w.out_color, w.out_depth, w.bbits, order);
+                             w.n_contrib, w.out_color, w.out_depth, w.bbits, w.bmask, order);
 }
 
 // ------------------------------------------------------------------------------------------- K7
@@ -2560,7 +2673,9 @@ size_t bucket_table_bytes(int P, int tiles) { return align256(((size_t)cdiv(P > 
 //          | 4 ckpt float4[slots][16 blocks][16 pixels]   (slots = R/SEG + tiles + 1 bounds sum_t ceil(n_t/SEG))
 //          | 5 mask16 u16[R+1] | 6 recA float4[R+1] | 7 recB float4[R+1] | 8 recC float2[R+1]   (entry R = the null record)
 //          | 9 bbits u64[slots][16 blocks][SEG / 64]: per segment and block, which of the segment's 256 entries the block BLENDED (K6 -> K7)
-constexpr int B_NFIELDS = 10;
+//          | 10 bmask u64[R / 64 + 4][16 blocks]: mask16 TRANSPOSED -- per 64 list entries (global index >> 6) and block, which entries
+//            reach the block (K5b -> K6, one scalar 8-byte load per chunk instead of 64 mask loads and a ballot)
+constexpr int B_NFIELDS = 11;
 size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     const size_t n = (size_t)(R > 0 ? R : 1);
     const size_t slots = (size_t)max_slots(R, tiles);
@@ -2574,7 +2689,8 @@ size_t binning_offsets(int64_t R, int tiles, size_t *off) {
     off[7] = off[6] + align256((n + 1) * 16);
     off[8] = off[7] + align256((n + 1) * 16);
     off[9] = off[8] + align256((n + 1) * 8);
-    return off[9] + align256(slots * 16 * (SEG / 8));
+    off[10] = off[9] + align256(slots * 16 * (SEG / 8));
+    return off[10] + align256(((n + 63) / 64 + 4) * 16 * 8);
 }
 // temp: 0 keys_unsorted | 1 ids_unsorted | 2 keys_tmp | 3 ids_tmp | 4 sort table
 size_t temp_offsets(int64_t R, size_t *off) {
@@ -2971,6 +3087,7 @@ static int p2_launch(int V, const int *tk, csplat_view *v, hipStream_t join, con
             k.ckpt = (float4 *)((char *)bbase + boff[4]);
             k.mask16 = (uint16_t *)((char *)bbase + boff[5]);
             k.bbits = (unsigned long long *)((char *)bbase + boff[9]);
+            k.bmask = (unsigned long long *)((char *)bbase + boff[10]);
             k.recA = (float4 *)((char *)bbase + boff[6]); k.recB = (float4 *)((char *)bbase + boff[7]);
             k.recC = (float2 *)((char *)bbase + boff[8]);
             k.bg = t.bg; k.final_T = t.final_T; k.n_contrib = t.n_contrib; k.out_color = v[i].out_color; k.out_depth = v[i].out_depth;
@@ -3162,6 +3279,7 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     float4 *recA = (float4 *)((char *)bbase + boff[6]), *recB = (float4 *)((char *)bbase + boff[7]);
     float2 *recC = (float2 *)((char *)bbase + boff[8]);
     unsigned long long *bbits = (unsigned long long *)((char *)bbase + boff[9]);
+    unsigned long long *bmask = (unsigned long long *)((char *)bbase + boff[10]);
     if (R > 0) {
         void *tbase = alloc(alloc_ctx, CSPLAT_CHUNK_TEMP, csplat_temp_bytes(P, R, W, H));
         CSPLAT_REQUIRE(tbase, "allocator returned NULL");
@@ -3214,17 +3332,17 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
     {
         ProfScope ps(PROF_K5, s);
         k_block_masks<<<cdiv((int64_t)R + 1, 256), 256, 0, s>>>((int64_t)R, cam.gx, keys_sorted, ids_sorted, g.pack, mask16, recA, recB, recC,
-                                                                 (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1);
+                                                                 (g_debug_flags & (1u | 16u | 32u)) ? 0 : 1, bmask);
         LAUNCH_CHECK();
     }
     {
         ProfScope ps(PROF_K6, s);
         if (g_debug_flags & 32768u)       // (bit 15: the row form, four survivors a step; default: the survivor-column form, 74 -> 67 us alone)
             k_composite_fwd<true><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
-                                                                      final_T, n_contrib, out_color, out_depth, bbits);
+                                                                      final_T, n_contrib, out_color, out_depth, bbits, bmask);
         else
             k_composite_fwd<false><<<cdiv(tiles, 8) * 128, 64, 0, s>>>(tiles, W, H, cam.gx, ranges, mask16, recA, recB, recC, R, bg, seg_offset, ckpt,
-                                                                       final_T, n_contrib, out_color, out_depth, bbits);
+                                                                       final_T, n_contrib, out_color, out_depth, bbits, bmask);
         LAUNCH_CHECK();
     }
     *geom_out = gbase; *binning_out = bbase; *image_out = ibase;
