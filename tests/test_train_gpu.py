@@ -682,8 +682,11 @@ def test_captured_train_step_equals_the_eager_step():
     cs = runs["captured"][4]
     assert cs is not None and cs.stats["recorded"] == 1 and cs.stats["replayed"] == 7 and cs.stats["eager"] == 1 and cs.stats["missed"] == 0, cs.stats
     assert runs["eager"][3] == runs["captured"][3] == [8.0] * len(runs["eager"][3])
-    for (pe, le, re_, ve, fe), (pc_, lc, rc, vc, fc) in zip(runs["eager"][0], runs["captured"][0]):
-        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < 1e-4 * max(abs(le), 1e-3), (pe, pc_, le, lc)
+    for k_, ((pe, le, re_, ve, fe), (pc_, lc, rc, vc, fc)) in enumerate(zip(runs["eager"][0], runs["captured"][0])):
+        # step 1 starts from identical parameters: the losses agree to rounding.  From step 2 on the two runs' parameters differ by K7's
+        # atomic order, and ONE compositing threshold (alpha against 1/255, T against 1e-4) decided the other way at one pixel moves the
+        # loss by ~1.6e-4 of itself -- seen as a bimodal outcome of this comparison, 2 runs in 8, with either library of round 4
+        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < (1e-5 if k_ == 0 else 5e-4) * max(abs(le), 1e-3), (k_, pe, pc_, le, lc)
         assert float((re_ != rc).float().mean()) < 1e-3 and torch.equal(fc, rc > 0)
         # (from the second step on the two runs' parameters differ by K7's atomic order: rounding-level differences in the gradients)
         assert float((ve - vc).abs().max()) <= 3e-2 * float(ve.abs().max())
