@@ -172,9 +172,8 @@ __device__ __forceinline__ void preprocess_body(int P, int D, int M, const float
                                                 const float *__restrict__ scales, float scale_mod,
                                                 const float *__restrict__ rotations,
                                                 const float *__restrict__ cov3D_precomp, const Cam &cam, const Geom &g,
-                                                int32_t *__restrict__ radii, int nocull, const float *s_shrows) {
+                                                int32_t *__restrict__ radii, int nocull, const float *s_shrows, int i, int srow) {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     float depth = 0.f, px = 0.f, py = 0.f, cut = -1.f;
     float4 co = {0.f, 0.f, 0.f, 0.f};
@@ -224,7 +223,7 @@ __device__ __forceinline__ void preprocess_body(int P, int D, int M, const float
 #pragma unroll
             for (int k = 0; k < 3; k++) rgb[k] = colors_precomp[3 * i + k];
         } else {
-            const float *sh = STAGE ? (const float *)(s_shrows + threadIdx.x * SH_ROW) : shs + (size_t)i * M * 3;
+            const float *sh = STAGE ? (const float *)(s_shrows + srow * SH_ROW) : shs + (size_t)i * M * 3;
             const float d0 = p[0] - cam.campos[0], d1 = p[1] - cam.campos[1], d2 = p[2] - cam.campos[2];
             const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
             const float x = d0 / len, y = d1 / len, z = d2 / len;
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(256) void k_preprocess(int P, int D, int M, const f
         __syncthreads();
     }
     preprocess_body<STAGE>(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_mod, rotations, cov3D_precomp, cam, g, radii,
-                           nocull, s_shrows);
+                           nocull, s_shrows, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)threadIdx.x);
 }
 
 // The first phase of the forward (K1 + the three counting kernels) for ALL views of a step, one launch each (blockIdx.y =
@@ -319,21 +318,26 @@ struct K1View {
 struct K1Table { int n; K1View v[K1_MAX_VIEWS]; };
 
 // (the 192-byte SH row of a Gaussian is staged ONCE per workgroup and evaluated for every view's direction)
+constexpr int K1V_G = 64;
 template <bool STAGE>
 __global__ __launch_bounds__(256) void k_preprocess_views(int P, int D, int M, const float *__restrict__ shs,
                                                            const float *__restrict__ opacities,
                                                            const float *__restrict__ scales, float scale_mod, K1Table tab,
                                                            int nocull) {
-    __shared__ float s_shrows[STAGE ? 256 * SH_ROW : 1];
+    // 64 Gaussians per workgroup, wave w takes the views w, w + 4, ...: the views of a Gaussian run side by side instead of one after the
+    // other in one thread (P / 256 = 391 workgroups of four dependent load -> project -> SH rounds each: 1.2 waves per SIMD, 25 us for
+    // the four views of the bench), the stores of a wave go to ONE view's arrays at consecutive indices
+    __shared__ float s_shrows[STAGE ? K1V_G * SH_ROW : 1];
+    const int base = blockIdx.x * K1V_G;
     if (STAGE) {
-        const int base = blockIdx.x * 256;
-        stage_sh_rows<256>(shs + (size_t)base * 48, min(256, P - base), s_shrows);
+        stage_sh_rows<256>(shs + (size_t)base * 48, min(K1V_G, P - base), s_shrows);
         __syncthreads();
     }
-    for (int vi = 0; vi < tab.n; vi++) {
+    const int lane = threadIdx.x & 63;
+    for (int vi = threadIdx.x >> 6; vi < tab.n; vi += 4) {
         const K1View &w = tab.v[vi];
         preprocess_body<STAGE>(P, D, M, w.means3D, shs, nullptr, opacities, scales, scale_mod, w.rotations, nullptr, w.cam, w.g, w.radii, nocull,
-                               s_shrows);
+                               s_shrows, base + lane, lane);
     }
 }
 
@@ -2956,10 +2960,10 @@ static int begin_launch_views(int V, const int *tk, hipStream_t join) {
         ProfScope ps(PROF_K1, join);
         const bool stage = a.M == 16 && ((uintptr_t)a.shs & 15u) == 0;
         if (stage)
-            k_preprocess_views<true><<<cdiv(P, 256), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
+            k_preprocess_views<true><<<cdiv(P, K1V_G), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
                                                                      nocull_mode());
         else
-            k_preprocess_views<false><<<cdiv(P, 256), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
+            k_preprocess_views<false><<<cdiv(P, K1V_G), 256, 0, join>>>(P, a.D, a.M, a.shs, a.opacities, a.scales, a.scale_modifier, tab,
                                                                       nocull_mode());
         LAUNCH_CHECK();
     }
