@@ -513,9 +513,9 @@ def main():
             counters_from["issue"] = {"error": repr(e)[:120]}
     # what a wave64 VALU instruction costs a SIMD's vector pipe on this part (tools/valu_rate.hip, profiles/r03_valu_rate.txt, >= 2 waves
     # per SIMD): 2.3 cycles for plain v_fma / v_mul / v_add / v_mov, 4.2 for every DPP form, v_cmp, v_min / v_max, v_cndmask_e64, shifts and
-    # conversions, 8.2 for v_exp / v_rcp / v_permlane*_swap.  K7's loop (156 VALU per group of four survivors: 82 / 66 / 8 of the three
-    # classes, from the ISA) averages 3.4 cycles per instruction.
-    SIMDS, CLOCK_GHZ, K7_CYC_PER_VALU = 1024, 2.4, 3.4
+    # conversions, 8.2 for v_exp / v_rcp / v_permlane*_swap.  K7's loop (round 4: 192 VALU per PAIR of groups of four survivors -- 118 / 62
+    # / 12 of the three classes, from the ISA; round 3: 156 per group, 82 / 66 / 8 = 3.4) averages 3.3 cycles per instruction.
+    SIMDS, CLOCK_GHZ, K7_CYC_PER_VALU = 1024, 2.4, 3.3
     issue = lambda us: None if not (valu_insts and us) else round(valu_insts * K7_CYC_PER_VALU / (SIMDS * CLOCK_GHZ * 1e3 * us), 4)  # noqa: E731
     out = {
         "metric": "rasterizer fwd+bwd rendered Mpix/s (scene_1, 800x800)", "value": round(value, 3), "unit": "Mpix/s",
@@ -537,7 +537,7 @@ def main():
                      "launches_timed": int(k7_n),
                      "views_per_launch": views_per_launch,
                      "issue_frac": issue(k7_avg_s * 1e6),
-                     "issue_note": "VALU wave-instructions of this launch (SQ_INSTS_VALU of the committed counter pass) x 3.4 cycles (the "
+                     "issue_note": "VALU wave-instructions of this launch (SQ_INSTS_VALU of the committed counter pass) x 3.3 cycles (the "
                                    "instruction mix of K7's loop priced with tools/valu_rate.hip: 2.3 plain / 4.2 DPP, compare, select, "
                                    "min-max / 8.2 exp, rcp, permlane swap) / (1024 SIMDs x 2.4 GHz x this launch's duration): the share of "
                                    "the vector pipes' cycles the kernel's arithmetic occupies -- the bound that binds it (composite "
