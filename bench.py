@@ -239,7 +239,7 @@ def main():
                 dgr_.FAITH = faith
                 try:
                     with torch.cuda.graph(g_):
-                        w_.step()
+                        w_.step(skip_allreduce=True)      # (N > 1: the all-reduce follows every replay, launched by the host)
                 finally:
                     dgr_.FAITH = None
                 self.graphs.append(g_); self.valid.append(valid); self.info.append(faith["info"])
@@ -249,6 +249,8 @@ def main():
         def step(self):
             self.graphs[self.k % len(self.graphs)].replay()
             self.k += 1
+            if self.w.fg is not None:       # N > 1: ONE all-reduce of the flat gradient buffer the recorded kernels have just filled
+                self.w.fg.all_reduce()
 
         def all_valid(self):
             return all(int(v.item()) == 1 for v in self.valid)
@@ -285,7 +287,7 @@ def main():
     sync()
     # the step as replayed hipGraphs (1 GPU, batched views; --eager / any failure: launch by launch as in rounds 1-3)
     graphed, launch_mode = None, "eager"
-    want_graph = not dist_on and not scene_mode and args.view_streams and V >= 2 and not args.eager and wl is not None
+    want_graph = not scene_mode and args.view_streams and V >= 2 and not args.eager and wl is not None
     if want_graph:
         try:
             graphed = GraphedSteps(wl)              # (an eager step for the counts the capacities are taken from)
@@ -299,7 +301,7 @@ def main():
             torch.cuda.synchronize()
             if not graphed.all_valid():
                 raise RuntimeError("the recorded capacities do not fit the workload's counts")
-            launch_mode = f"hipGraph replay ({len(graphed.graphs)} recordings, round-robin)"
+            launch_mode = f"hipGraph replay ({len(graphed.graphs)} recordings, round-robin)" + (" + one all-reduce per step" if dist_on else "")
         except Exception as e:
             native.REPLAY_STREAM.clear()
             graphed, launch_mode = None, "eager (recording failed: " + repr(e)[:120] + ")"
