@@ -928,3 +928,51 @@ def test_strict_dispatch_rejects_non_fp32_and_strided_inputs():
     rs_t = rs._replace(viewmatrix=rs.viewmatrix.t().contiguous().t(), projmatrix=rs.projmatrix.t().contiguous().t())
     assert not rs_t.viewmatrix.is_contiguous()
     assert torch.equal(GaussianRasterizer(rs_t)(**kw)[0], ref)
+
+
+def test_block_words_are_the_transposed_masks_and_blended_entries_reach_their_block():
+    """Round 4's two bit tables of the binning chunk against the masks they are made from (layout: binning_offsets in csplat_raster.hip):
+      * bmask[chunk][block] (K5b, read by K6 on the scalar unit) == bit `block` of mask16[64 chunk + l], l = 0..63 -- the ballots of the
+        wave that owns the chunk -- for every chunk that holds a list entry;
+      * bbits[slot][block] (K6 -> K7: which entries of a 256-entry segment the block BLENDED) only has bits where the entry REACHES the
+        block (mask16), and no bit at or behind the block's last blended entry (blk_hi)."""
+    case = util.make_case(P=6000, W=160, H=128, grid=40, scale_mul=2.5)
+    _, _, _, st = util.gpu_forward_raw(case)
+    R, W, H = int(st["R"]), case["W"], case["H"]
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    SEG = 256
+    a256 = lambda x: (x + 255) // 256 * 256  # noqa: E731
+    n = max(R, 1)
+    slots = R // SEG + tiles + 1
+    off = [0, a256(n * 8)]
+    off.append(off[1] + a256(n * 4)); off.append(off[2] + a256((tiles + 1) * 4 + tiles * 16 * 4)); off.append(off[3] + a256(slots * 4))
+    off.append(off[4] + a256(slots * 256 * 16)); off.append(off[5] + a256((n + 1) * 2)); off.append(off[6] + a256((n + 1) * 16))
+    off.append(off[7] + a256((n + 1) * 16)); off.append(off[8] + a256((n + 1) * 8)); off.append(off[9] + a256(slots * 16 * (SEG // 8)))
+    raw = st["_binning_raw"].cpu().numpy()
+    mask16 = raw[off[5]:off[5] + 2 * R].view(np.uint16).astype(np.uint64)
+    nch = (R + 63) // 64
+    bm = raw[off[10]:off[10] + nch * 16 * 8].view(np.uint64).reshape(nch, 16)
+    pad = np.zeros(nch * 64, np.uint64); pad[:R] = mask16
+    lanes = np.arange(64, dtype=np.uint64)
+    for b in range(16):
+        want = (((pad.reshape(nch, 64) >> np.uint64(b)) & np.uint64(1)) << lanes).sum(1, dtype=np.uint64)
+        np.testing.assert_array_equal(bm[:, b], want, err_msg=f"block {b}")
+    seg_off = raw[off[2]:off[2] + 4 * (tiles + 1)].view(np.int32)
+    blk_hi = raw[off[2] + 4 * (tiles + 1):off[2] + 4 * (tiles + 1) + tiles * 64].view(np.uint32).reshape(tiles, 16)
+    nslots = int(seg_off[tiles])
+    bb = raw[off[9]:off[9] + nslots * 16 * 32].view(np.uint64).reshape(nslots, 16, 4)
+    ranges = st["ranges"]
+    checked = 0
+    for t in range(tiles):
+        lo, hi = int(ranges[t, 0]), int(ranges[t, 1])
+        for s in range((hi - lo + SEG - 1) // SEG):
+            m = np.zeros(SEG, np.uint64); cnt = min(SEG, hi - lo - s * SEG); m[:cnt] = mask16[lo + s * SEG:lo + s * SEG + cnt]
+            for b in range(16):
+                if s * SEG >= blk_hi[t, b]:
+                    continue                               # (K7 never reads the words of a segment behind the block's last blended entry)
+                bits = np.array([(int(bb[seg_off[t] + s, b, w_]) >> l) & 1 for w_ in range(4) for l in range(64)], np.uint64)
+                assert not np.any(bits & (((m >> np.uint64(b)) & np.uint64(1)) ^ np.uint64(1))), (t, s, b)
+                pos = np.nonzero(bits)[0]
+                assert pos.size == 0 or s * SEG + int(pos.max()) < blk_hi[t, b], (t, s, b)
+                checked += 1
+    assert checked > 50
