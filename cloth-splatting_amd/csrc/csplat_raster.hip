@@ -1034,17 +1034,17 @@ __global__ __launch_bounds__(1024) void k_seg_plan_views(int tiles, P2Table tab)
 //     same association as a one-entry-at-a-time walk, so skipping culled entries (factor 1) cannot change a bit of T;
 //   * which entries reach which block is decided ONCE per view by k_block_masks (exact ellipse-vs-box test, one lane per
 //     tile-list entry, 16 boxes): a 16-bit mask per entry plus a tile-ordered copy of what compositing reads (40 B, so the
-//     walkers read contiguous records instead of gathering five arrays by Gaussian id).  K6 and K7 walk those masks on the
-//     SCALAR unit (ballot of the block's bit over a 64-entry chunk -> s_ff1 / s_andn2 pops): no LDS staging, no per-chunk
-//     re-culling, no 4x re-gather of a tile's entries by its quadrant waves;
+//     walkers read contiguous records instead of gathering five arrays by Gaussian id).  Since round 4 the same masks also leave
+//     TRANSPOSED (bmask[chunk][block]: the sixteen ballots of a wave's 64 entries): K6's wave takes its block's word of a chunk with one
+//     scalar load; K7 no longer looks at the masks at all -- it walks what K6 found BLENDED (bbits);
 //   * K7 runs FORWARD through a 256-entry segment: with S_k = sum_{j<=k} (c_j . dL/dC) alpha_j T_j (restarted from the
 //     forward's checkpoint) the upstream back-to-front recurrence collapses to
 //         dL/dalpha_k = T_k (c_k . dL/dC) - (out_colour . dL/dC - S_k) / (1 - alpha_k),
 //     the same identity the depth-split restart already used once per segment;
-//   * the nine per-pixel partials of a survivor are summed over its 16-lane row by a 4-level butterfly (26 DPP adds for
-//     four survivors at once), added into an LDS record per list entry shared by the four blocks of a quadrant, and
-//     flushed with ONE 36-byte atomic per (entry, quadrant) into 64-byte-aligned per-Gaussian records (global float
-//     atomics are priced per 64-byte request at the memory side, MI355X_MICROARCH.md "Global float atomics").
+//   * the nine per-pixel partials of a survivor are summed over its 16-lane row by a 4-level butterfly (the first two levels bank-masked
+//     DPP adds, 18 DPP adds + 2 selects per survivor row) and go, nine lanes at once, to the Gaussian's 64-byte record as ONE global
+//     float-atomic request per (entry, block) (requests are priced per 64 bytes at the memory side, MI355X_MICROARCH.md "Global
+//     float atomics"; rounds 1-3 joined a workgroup's blocks in an LDS record first -- see composite_bwd_body).
 constexpr float T_EPS = 0.0001f;
 constexpr float ALPHA_MIN = 1.f / 255.f;
 
@@ -1824,8 +1824,8 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
     mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi, bbits) has returned
-    // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint and (one per
-    // thread) the ids the flush will need are requested together, BEFORE the records are zeroed and the barrier
+    // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint and (below, `stage`)
+    // the records + ids of its first 64 survivors are requested together
     unsigned long long any_ = 0ull;
 #pragma unroll
     for (int c = 0; c < NW; c++) any_ |= sw[c];
@@ -1997,8 +1997,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         }
     }
     mark(5);                                                            // this wave's groups are done
-    mark(6);
-    mark(7);
     if (my_stamp && threadIdx.x == 0) { my_stamp[8] = (unsigned long long)total; my_stamp[9] = 1ull; }
 }
 
@@ -3752,10 +3750,10 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 bt.stamp = (g_stamp_buf && g_stamp_words >= need) ? g_stamp_buf : nullptr;
                 bt.valid = v[0].valid;
             }
-            ProfScope ps(PROF_K7, join);
             const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
             k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
             LAUNCH_CHECK();
+            ProfScope ps(PROF_K7, join);       // (the bracket bench.py's roofline reads: K7's launch alone, not the record clearing in front of it)
             const unsigned items = (unsigned)cdiv(slots, 8) * 32u;
             k_composite_bwd_rows_views<<<dim3(items, V), 256, 0, join>>>(tiles, W, H, gx, bt);
             LAUNCH_CHECK();

@@ -55,12 +55,4 @@ act = L[L[:, 8] > 0]
 da = np.diff(act[:, :6], axis=1)
 print(f"waves WITH survivors ({len(act)}): groups phase mean {da[:, 4].mean():.0f} cycles for {act[:, 8].mean() / 4:.1f} groups of four = "
       f"{da[:, 4].sum() / (act[:, 8].sum() / 4):.0f} cycles per group; first-records wait {da[:, 3].mean():.0f}")
-t0 = s[started][:, 0].min()
-span = s[live][:, 5].max() - t0
-print(f"launch span by the stamps: {span / 2.4e3:.1f} us at 2.4 GHz")
-# waves in flight: every live workgroup holds four waves from its entry to (about) its wave 0's last group
-ev = np.concatenate([np.stack([L[:, 0], np.ones(len(L))], 1), np.stack([L[:, 5], -np.ones(len(L))], 1)])
-ev = ev[np.argsort(ev[:, 0])]
-conc = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0], append=ev[-1, 0])
-print(f"live workgroups in flight, time average: {(conc * dt).sum() / span:.0f} (x 4 waves / 1024 SIMDs = {(conc * dt).sum() / span * 4 / 1024:.2f} live waves per SIMD); "
-      f"in their groups phase: {(L[:, 5] - L[:, 4]).sum() / span * 4 / 1024:.2f} per SIMD")
+# (s_memtime counts per XCD: stamps of DIFFERENT workgroups are not comparable -- only the differences inside one wave are used)
