@@ -8,10 +8,10 @@ OUT="$HERE/../csplat/libcsplat.so"
 OBJ="$HERE/build"
 mkdir -p "$OBJ"
 # -fno-slp-vectorize: v_pk_{mul,add,fma}_f32 cost a SIMD what two plain instructions cost (profiles/r04b_valu_rate.txt), but forming their
-# register pairs costs moves -- and copies of just-loaded registers that drag the load's s_waitcnt to the front of a loop (K7, round 4)
-# (the rasterizer only: the GEMM file is 4-5 % slower without its packed bf16 / fp32 forms -- `k_linear128` 75 -> 79 us, rollout 5.54 -> 5.68 ms)
-FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -Wall -Wno-unused-function"
-NOSLP_FILES="csplat_raster.hip"
+# register pairs costs moves -- and copies of just-loaded registers that drag the load's s_waitcnt to the front of a loop (K7, round 4).
+# For every file: same-box A/B of the GNN kernels with and without it -- plain / gather `k_linear128` unchanged (73-74 / 97-99 us), the
+# LayerNorm variant 93.5 -> 88.5 us, rollout 5.37 -> 5.33 ms (figures from different boxes differ by more than that: 75 vs 80 us).
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -Wall -Wno-unused-function"
 pids=()
 objs=()
 for src in "$HERE"/*.hip; do
@@ -21,9 +21,7 @@ for src in "$HERE"/*.hip; do
     if [ -n "$FORCE" ] || [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$0" -nt "$o" ]; then stale=1; fi
     for h in "$HERE"/*.h "$HERE"/../../include/*.h; do [ "$h" -nt "$o" ] && stale=1; done
     if [ $stale = 1 ]; then
-        extra=""
-        case " $NOSLP_FILES " in *" $(basename "$src") "*) extra="-fno-slp-vectorize" ;; esac
-        /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c "$src" -o "$o" &
+        /opt/rocm/bin/hipcc $FLAGS "$@" -c "$src" -o "$o" &
         pids+=($!)
     fi
 done

@@ -1821,7 +1821,6 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
     const int pix = py * W + px;
     const float fx = (float)px, fy = (float)py;
     const int2 range = ranges[tile];
-    const int n = range.y - range.x;
     const uint32_t rx = (uint32_t)range.x;
     mark(1);                                                            // the scalar chain (slot -> tile -> range, blk_hi, bbits) has returned
     // ONE memory round trip for everything a wave needs before its first group: the pixel's constants, its checkpoint and (below, `stage`)
