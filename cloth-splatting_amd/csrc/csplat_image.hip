@@ -265,9 +265,23 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_finish(size_t per_p
                                                             float psnr_scale, const float *__restrict__ partial, float *__restrict__ out) {
     __shared__ float s_red[SSIM_THREADS / 64];
     const size_t nwg = per_plane * planes;
+    // (ONE workgroup pulls ~135 KB of partials: 16-byte loads, four of them in flight per thread -- with 4-byte loads in a dependent
+    //  `t += p[i]` loop the five sums of a 3-camera step took 12.8 us)
     auto block_sum = [&](const float *p, size_t lo, size_t hi) -> float {     // fixed-order sum of p[lo, hi)
         float t = 0.f;
-        for (size_t i = lo + threadIdx.x; i < hi; i += SSIM_THREADS) t += p[i];
+        size_t a0 = lo + (((16u - (unsigned)((uintptr_t)(p + lo) & 15u)) & 15u) >> 2);      // first 16-byte-aligned element of p[lo ..
+        if (a0 > hi) a0 = hi;
+        const size_t n4 = (hi - a0) >> 2;
+        const float4 *p4 = reinterpret_cast<const float4 *>(p + a0);
+        size_t i = threadIdx.x;
+        for (; i + 3 * SSIM_THREADS < n4; i += 4 * SSIM_THREADS) {
+            const float4 u0 = p4[i], u1 = p4[i + SSIM_THREADS], u2 = p4[i + 2 * SSIM_THREADS], u3 = p4[i + 3 * SSIM_THREADS];
+            t += ((u0.x + u0.y) + (u0.z + u0.w)) + ((u1.x + u1.y) + (u1.z + u1.w));
+            t += ((u2.x + u2.y) + (u2.z + u2.w)) + ((u3.x + u3.y) + (u3.z + u3.w));
+        }
+        for (; i < n4; i += SSIM_THREADS) { const float4 u = p4[i]; t += (u.x + u.y) + (u.z + u.w); }
+        for (size_t j = lo + threadIdx.x; j < a0; j += SSIM_THREADS) t += p[j];                    // <= 3 elements in front ...
+        for (size_t j = a0 + (n4 << 2) + threadIdx.x; j < hi; j += SSIM_THREADS) t += p[j];        // ... and behind the float4 body
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
         __syncthreads();

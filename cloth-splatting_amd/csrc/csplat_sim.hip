@@ -339,39 +339,57 @@ int launch_bwd(hipStream_t s, int R, const float *W, const float *h, const float
 //   forward : h1[t][j] = relu(b1[j] + sum_c W1[j][c] e[t][c]),  h2[t][j] = relu(b2[j] + sum_k W2[j][k] h1[t][k])
 //   backward: dz2 = dh2 * (h2 > 0); db2 = sum_t dz2; dW2[j][k] = sum_t dz2[t][j] h1[t][k]; dh1[t][k] = sum_j W2[j][k] dz2[t][j];
 //             dz1 = dh1 * (h1 > 0); db1 = sum_t dz1; dW1[k][c] = sum_t dz1[t][k] e[t][c]          (fixed summation order)
-constexpr int SIM_H = 256, SIM_K0MAX = 16;
+constexpr int SIM_H = 256, SIM_K0MAX = 16, SIM_FWD_WGS = 16;
 template <int T>
 __global__ __launch_bounds__(SIM_H) void k_sim_hidden_fwd(int K0, const float *__restrict__ e, const float *__restrict__ W1,
                                                           const float *__restrict__ b1, const float *__restrict__ W2,
                                                           const float *__restrict__ b2, float *__restrict__ h1, float *__restrict__ h2) {
+    // SIM_FWD_WGS workgroups: every one forms the whole first layer in LDS (13 x 256 multiply-adds, redundantly) and then ITS 16 units of
+    // the second: sixteen lanes per unit read the unit's W2 row as four 16-byte pieces each (coalesced over the row) and meet in a DPP row
+    // sum.  (One workgroup with a thread per unit walked 64 dependent 16-byte loads at a 1 KB stride: 12-13 us.)  The order of every sum is
+    // the same for every T: a T = 1 forward gives the bits of the T = 3 one.
     __shared__ float s_h1[T][SIM_H];
-    const int j = threadIdx.x;
+    const int j = threadIdx.x, g = blockIdx.x;
     float a[T];
 #pragma unroll
     for (int t = 0; t < T; t++) a[t] = b1[j];
     for (int c = 0; c < K0; c++) {
         const float w = W1[j * K0 + c];
 #pragma unroll
-        for (int t = 0; t < T; t++) a[t] = __fmaf_rn(w, e[t * K0 + c], a[t]);    // (explicit fma chains: the same bits for every T)
+        for (int t = 0; t < T; t++) a[t] = __fmaf_rn(w, e[t * K0 + c], a[t]);
     }
 #pragma unroll
-    for (int t = 0; t < T; t++) { a[t] = fmaxf(a[t], 0.f); s_h1[t][j] = a[t]; h1[t * SIM_H + j] = a[t]; }
+    for (int t = 0; t < T; t++) {
+        a[t] = fmaxf(a[t], 0.f);
+        s_h1[t][j] = a[t];
+        if (j / (SIM_H / SIM_FWD_WGS) == g) h1[t * SIM_H + j] = a[t];
+    }
     __syncthreads();
+    const int unit = g * (SIM_H / SIM_FWD_WGS) + (j >> 4), l = j & 15;
     float o[T];
 #pragma unroll
-    for (int t = 0; t < T; t++) o[t] = b2[j];
-    const float4 *row = reinterpret_cast<const float4 *>(W2 + (size_t)j * SIM_H);
-#pragma unroll 4
-    for (int k4 = 0; k4 < SIM_H / 4; k4++) {
-        const float4 w = row[k4];
+    for (int t = 0; t < T; t++) o[t] = 0.f;
+    const float4 *row = reinterpret_cast<const float4 *>(W2 + (size_t)unit * SIM_H);
+    float4 w[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) w[m] = row[l + 16 * m];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            const float4 x = *reinterpret_cast<const float4 *>(&s_h1[t][4 * k4]);    // (same address in every lane: a broadcast)
-            o[t] = __fmaf_rn(w.w, x.w, __fmaf_rn(w.z, x.z, __fmaf_rn(w.y, x.y, __fmaf_rn(w.x, x.x, o[t]))));
+            const float4 x = *reinterpret_cast<const float4 *>(&s_h1[t][4 * (l + 16 * m)]);
+            o[t] = __fmaf_rn(w[m].w, x.w, __fmaf_rn(w[m].z, x.z, __fmaf_rn(w[m].y, x.y, __fmaf_rn(w[m].x, x.x, o[t]))));
         }
     }
 #pragma unroll
-    for (int t = 0; t < T; t++) h2[t * SIM_H + j] = fmaxf(o[t], 0.f);
+    for (int t = 0; t < T; t++) {
+        float v = o[t];
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));   // row_mirror
+        if (l == 0) h2[t * SIM_H + unit] = fmaxf(v + b2[unit], 0.f);
+    }
 }
 
 constexpr int SIM_BWD_WGS = 16;           // workgroups of the backward: 16 rows of W2 / dW2 each
@@ -539,7 +557,7 @@ int csplat_sim_hidden_fwd(void *stream, int T, int K0, const float *e, const flo
     CSPLAT_REQUIRE(T >= 1 && T <= SIM_TMAX && K0 >= 1 && K0 <= SIM_K0MAX, "csplat_sim_hidden_fwd: 1 <= T <= 8 time rows, 1 <= K0 <= 16 inputs");
     CSPLAT_REQUIRE(e && W1 && b1 && W2 && b2 && h1 && h2 && ((uintptr_t)W2 & 15u) == 0, "csplat_sim_hidden_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-#define CSPLAT_SIMH(TT) case TT: k_sim_hidden_fwd<TT><<<1, SIM_H, 0, s>>>(K0, e, W1, b1, W2, b2, h1, h2); break;
+#define CSPLAT_SIMH(TT) case TT: k_sim_hidden_fwd<TT><<<SIM_FWD_WGS, SIM_H, 0, s>>>(K0, e, W1, b1, W2, b2, h1, h2); break;
     switch (T) { CSPLAT_SIMH(1) CSPLAT_SIMH(2) CSPLAT_SIMH(3) CSPLAT_SIMH(4) CSPLAT_SIMH(5) CSPLAT_SIMH(6) CSPLAT_SIMH(7) CSPLAT_SIMH(8) }
 #undef CSPLAT_SIMH
     LAUNCH_CHECK();
