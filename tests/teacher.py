@@ -318,6 +318,29 @@ def pre_stage(build_cpu, cams_cpu, cap, tol=1e-4, opt=None, log=print, build_cpu
         -2 sign w x is added, so that d|x|/dx reads -sign.  probe: a list that receives the fp64 residuals (rigid, momentum) and weights."""
         pc, sim = builder()
         pc.fused = False
+        # the simulator's two ReLU layers (meshnet_network.py:364-366): a hidden unit whose pre-activation is zero to fp32 rounding is on in
+        # one arithmetic and off in the other.  The hooks record the pre-activations of every call (probe) and, for a flip ("relu", (layer,
+        # call, unit), _), hand the ReLU z - 2 z.detach(): the value moves by 2 |z| ~ 1e-8, the gate stands on the other side
+        calls = {"input": 0, "hidden": 0}
+        hooks = []
+        for lname in ("input", "hidden"):
+            lin = getattr(sim, lname, None)
+            if lin is None:
+                continue
+
+            def hook(_m, _inp, out, lname=lname):
+                b_ = calls[lname]
+                calls[lname] += 1
+                if probe is not None:
+                    probe_relu.append((lname, b_, out.detach().reshape(-1).clone()))
+                mine = [idx[2] for kind, idx, _ in flips if kind == "relu" and idx[0] == lname and idx[1] == b_]
+                if mine:
+                    sel = torch.zeros(out.shape[-1], dtype=out.dtype)
+                    sel[mine] = 2.0
+                    return out - sel * out.detach()
+                return None
+            hooks.append(lin.register_forward_hook(hook))
+        probe_relu = []
         ps = list(pc.parameters()) + list(sim.parameters())
         with torch.no_grad():
             for a, b in zip(ps, cap.params):
@@ -351,10 +374,13 @@ def pre_stage(build_cpu, cams_cpu, cap, tol=1e-4, opt=None, log=print, build_cpu
             w_m = opt.lambda_momentum / m.shape[0]
         if probe is not None:
             probe.append((None if x is None else x.detach().clone(), w_r, None if m is None else m.detach().clone(), w_m,
-                          pc.edge_norm.reshape(1, -1).detach().clone(), float(allv.detach().abs().max())))
+                          pc.edge_norm.reshape(1, -1).detach().clone(), float(allv.detach().abs().max()), probe_relu))
         for kind, idx, sgn in flips:
-            reg = reg - 2.0 * sgn * ((w_r * x[idx]) if kind == "rigid" else (w_m * m[idx]))
+            if kind != "relu":
+                reg = reg - 2.0 * sgn * ((w_r * x[idx]) if kind == "rigid" else (w_m * m[idx]))
         torch.autograd.backward(outs + [reg], grads + [torch.ones((), dtype=reg.dtype)])
+        for h_ in hooks:
+            h_.remove()
         return [None if p.grad is None else p.grad.detach().double() for p in ps]
     probe = []
     g64 = run(build_cpu, torch.float64, probe=probe)
@@ -365,7 +391,7 @@ def pre_stage(build_cpu, cams_cpu, cap, tol=1e-4, opt=None, log=print, build_cpu
     # (loss_node_err counts those).  Candidates: residuals below 1e-6 of the edge length / of the coordinates' magnitude.  A candidate is
     # FLIPPED on the fp64 / fp32 side when that moves the fp64 gradient TOWARDS the HIP one by more than half the flip's own length; the
     # flips are counted, reported and bounded.
-    x64, w_r, m64, w_m, enorm, vmax = probe[0]
+    x64, w_r, m64, w_m, enorm, vmax, relu64 = probe[0]
     cands = []
     if x64 is not None:
         for t_, e_ in torch.nonzero(x64.abs() <= 1e-6 * enorm.to(x64.dtype)).tolist():
@@ -373,6 +399,9 @@ def pre_stage(build_cpu, cams_cpu, cap, tol=1e-4, opt=None, log=print, build_cpu
     if m64 is not None:
         for v_, c_ in torch.nonzero(m64.abs() <= 1e-6 * vmax).tolist():
             cands.append(("momentum", (v_, c_), 1.0 if float(m64[v_, c_]) >= 0 else -1.0))
+    for lname, b_, z in relu64:
+        for (u_,) in torch.nonzero(z.abs() <= 1e-6 * float(z.abs().max())).tolist():
+            cands.append(("relu", (lname, b_, u_), 0.0))
     flips = []
     if cands and len(cands) <= 64:
         def flat(gs, ref):
@@ -387,8 +416,8 @@ def pre_stage(build_cpu, cams_cpu, cap, tol=1e-4, opt=None, log=print, build_cpu
             g64 = run(build_cpu, torch.float64, flips=flips)
             if g32 is not None:
                 g32 = run(build_cpu32, torch.float32, flips=flips)
-            log(f"   regulariser L1 ties: {len(flips)} of {len(cands)} near-zero residuals stand on the other side in the HIP step: " +
-                " ".join(f"{k}{i}" for k, i, _ in flips))
+            log(f"   kinks in front of the rasterizer (L1 residuals of the regularisers, ReLU gates of the simulator): {len(flips)} of "
+                f"{len(cands)} near-zero candidates stand on the other side in the HIP step: " + " ".join(f"{k}{i}" for k, i, _ in flips))
     res = {}
     for i, (name, g) in enumerate(zip(cap.names, cap.grads)):
         if g is None or g64[i] is None:
