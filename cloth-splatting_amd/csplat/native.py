@@ -174,8 +174,17 @@ def why_not_f32c(*tensors):
     return None
 
 
+# caches of scratch buffers that are "zeroed once: the kernel leaves its ticket word at zero" (csplat_l1, the image loss, the cloth
+# regularisers, csplat_sim_hidden_bwd ...) register here.  An entry point that FAILS may have left a ticket anywhere -- every later launch
+# would then take the wrong "last workgroup" branch and return wrong sums silently -- so any error drops every cached buffer:
+# the next call allocates and zeroes a fresh one.
+TICKET_CACHES = []
+
+
 def check(rc, what):
     if rc != 0:
+        for c in TICKET_CACHES:
+            c.clear()
         raise CsplatError(f"{what} failed (rc={rc}): {lib.csplat_last_error().decode(errors='replace')}")
 
 

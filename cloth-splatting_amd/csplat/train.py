@@ -68,6 +68,7 @@ def _taps(window_size=11, sigma=1.5):
 
 
 _L1_SCRATCH = {}
+_n.TICKET_CACHES.append(_L1_SCRATCH)
 
 
 def _l1_scratch(device):
@@ -205,6 +206,7 @@ class FusedSSIM(torch.autograd.Function):
 
 
 _IMG_SCRATCH = {}
+_n.TICKET_CACHES.append(_IMG_SCRATCH)
 
 
 def _image_loss_scratch(dev, shape):
@@ -372,8 +374,9 @@ class FusedClothRegs(torch.autograd.Function):
                         _IMG_SCRATCH.clear()
                     scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=dev)
                 _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
-                                                  float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
-                                                  *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])), "csplat_cloth_regs")
+                                                           float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
+                                                           *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])),
+                         "csplat_cloth_regs")
         if defer:       # the kernel writes into `loss` / `grad`, which exist already: WHEN it is launched is the caller's choice
             _DEFERRED.append(launch)                     # (launch_deferred(): e.g. behind the rasterizer's forward, off the step's critical path)
         else:
@@ -424,7 +427,7 @@ class SimulatorStep(torch.autograd.Function):
                         _IMG_SCRATCH.clear()
                     scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=dev)
                 _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
-                                                  float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch), *[_n.ptr(c) for c in csr]),
+                                                           float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch), *[_n.ptr(c) for c in csr]),
                          "csplat_cloth_regs")
         if defer:      # (the caller issues it with launch_deferred(), e.g. behind the rasterizer's forward)
             _DEFERRED.append(launch)

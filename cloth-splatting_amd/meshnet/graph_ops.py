@@ -154,6 +154,7 @@ class RowsDot(torch.autograd.Function):
 
 
 _SIMH_SCRATCH = {}
+_n.TICKET_CACHES.append(_SIMH_SCRATCH)
 
 
 def _sim_hidden_fwd(e, W1, b1, W2, b2):
@@ -181,7 +182,8 @@ def _sim_hidden_bwd(e, W2, h1, h2, g, sinks=(None, None, None, None)):
         if scratch is None:
             scratch = _SIMH_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_sim_hidden_scratch_bytes(8)) // 4, dtype=torch.int32, device=dev)
         _n.check(_n.lib.csplat_sim_hidden_bwd(_n.stream_handle(dev), T, K0, _n.ptr(e), _n.ptr(W2), _n.ptr(h1), _n.ptr(h2), _n.ptr(g),
-                                              _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1]), _n.ptr(scratch)), "csplat_sim_hidden_bwd")
+                                                       _n.ptr(dW1), _n.ptr(db[0]), _n.ptr(dW2), _n.ptr(db[1]), _n.ptr(scratch)),
+                 "csplat_sim_hidden_bwd")
     return dW1, db[0], dW2, db[1]
 
 

@@ -811,3 +811,23 @@ def test_hdf5min_round_trips_through_the_real_h5py(tmp_path):
     for k, v in arrays.items():
         assert back[k].dtype == v.dtype and back[k].shape == v.shape, k
         np.testing.assert_array_equal(back[k], v)
+
+
+def test_a_failed_call_drops_the_ticketed_scratch_caches():
+    """csplat.native.check: an entry point that fails may have left a "zero on entry, left at zero" ticket word anywhere; every cache of
+    such scratch registers in native.TICKET_CACHES and is emptied by ANY error, so the next call zeroes a fresh buffer."""
+    from csplat import native
+    cache = {"k": object()}
+    native.TICKET_CACHES.append(cache)
+    try:
+        native.check(0, "fine")
+        assert cache
+        with pytest.raises(native.CsplatError):
+            native.check(3, "csplat_something")
+        assert not cache
+    finally:
+        native.TICKET_CACHES.remove(cache)
+    import csplat.train as tr
+    from meshnet import graph_ops
+    assert any(c is tr._L1_SCRATCH for c in native.TICKET_CACHES) and any(c is tr._IMG_SCRATCH for c in native.TICKET_CACHES)
+    assert any(c is graph_ops._SIMH_SCRATCH for c in native.TICKET_CACHES)
