@@ -378,8 +378,9 @@ class FusedClothRegs(torch.autograd.Function):
                                                            *([None] * 4 if csr is None else [_n.ptr(c) for c in csr])),
                          "csplat_cloth_regs")
         if defer:       # the kernel writes into `loss` / `grad`, which exist already: WHEN it is launched is the caller's choice
-            _DEFERRED.append(launch)                     # (launch_deferred(): e.g. behind the rasterizer's forward, off the step's critical path)
+            ctx.pending = _defer(launch)                 # (launch_deferred(): e.g. behind the rasterizer's forward, off the step's critical path)
         else:
+            ctx.pending = None
             launch()
         ctx.save_for_backward(grad)
         ctx.tap = bool(tap)
@@ -389,6 +390,7 @@ class FusedClothRegs(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, g_through=None):
+        _issue(ctx.pending)
         (grad,) = ctx.saved_tensors
         if ctx.tap and g_through is not None:
             out = torch.addcmul(g_through, grad, g) if g is not None else g_through
@@ -430,8 +432,9 @@ class SimulatorStep(torch.autograd.Function):
                                                            float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch), *[_n.ptr(c) for c in csr]),
                          "csplat_cloth_regs")
         if defer:      # (the caller issues it with launch_deferred(), e.g. behind the rasterizer's forward)
-            _DEFERRED.append(launch)
+            ctx.pending = _defer(launch)
         else:
+            ctx.pending = None
             launch()
         ctx.save_for_backward(e, W2s, h1, h2, Wo, grad)
         ctx.set_materialize_grads(False)
@@ -440,6 +443,7 @@ class SimulatorStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_D, g_loss):
         from meshnet import graph_ops as go
+        _issue(ctx.pending)
         e, W2s, h1, h2, Wo, grad = ctx.saved_tensors
         if g_D is None and g_loss is None:
             return (None,) * 15
@@ -488,10 +492,27 @@ def simulator_step(simulator, times, gaussians, opt, defer=False, static=None):
 _DEFERRED = []
 
 
+def _defer(launch):
+    """queue a launch for launch_deferred(); returns the queue entry [launch, issued] the node keeps: its backward issues a launch that
+    nobody issued (regularization(..., defer=True) outside train_step -- ADVICE r3: the gradient would be read uninitialised; the LOSS
+    value is only defined once the launch has been issued, which is the caller's contract with defer=True)"""
+    ent = [launch, False]
+    _DEFERRED.append(ent)
+    return ent
+
+
+def _issue(ent):
+    if ent is not None and not ent[1]:
+        ent[1] = True
+        fn, ent[0] = ent[0], None       # (the closure holds the node's tensors: drop it with the launch -- kept on the ctx it is a
+        fn()                            #  reference cycle through the node's own output, and memory of a graph's private pool then
+        _DEFERRED[:] = [e for e in _DEFERRED if e is not ent]        # outlives the capture: a segfault at capture_end, measured)
+
+
 def launch_deferred():
     """launches what FusedClothRegs(defer=True) queued (same stream, in order); a no-op otherwise"""
     while _DEFERRED:
-        _DEFERRED.pop(0)()
+        _issue(_DEFERRED[0])
 
 
 def edge_csr(edge_index, n_nodes):

@@ -826,8 +826,9 @@ def test_a_failed_call_drops_the_ticketed_scratch_caches():
             native.check(3, "csplat_something")
         assert not cache
     finally:
-        native.TICKET_CACHES.remove(cache)
+        native.TICKET_CACHES[:] = [c for c in native.TICKET_CACHES if c is not cache]     # (by identity: an emptied dict equals every empty cache)
     import csplat.train as tr
     from meshnet import graph_ops
-    assert any(c is tr._L1_SCRATCH for c in native.TICKET_CACHES) and any(c is tr._IMG_SCRATCH for c in native.TICKET_CACHES)
-    assert any(c is graph_ops._SIMH_SCRATCH for c in native.TICKET_CACHES)
+    # (the modules' own binding: another test may have imported a second copy of csplat.native)
+    assert any(c is tr._L1_SCRATCH for c in tr._n.TICKET_CACHES) and any(c is tr._IMG_SCRATCH for c in tr._n.TICKET_CACHES)
+    assert any(c is graph_ops._SIMH_SCRATCH for c in graph_ops._n.TICKET_CACHES)
