@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
-    ap.add_argument("--halves", action="store_true", help="experiment: the step's views as two half-batches on two HIP streams")
+    ap.add_argument("--no-gnn", action="store_true", help="skip the auxiliary config-4 MeshNet rollout measurement (bench_gnn.py)")
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
     ap.add_argument("--eager", action="store_true", help="launch every step kernel by kernel instead of replaying recorded hipGraphs")
@@ -151,6 +151,10 @@ def main():
             return GaussianRasterizer(self.settings[i])(means3D=pr["means3D"], means2D=means2D, opacities=pr["opacities"],
                                                         shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
 
+        def grads(self):
+            """the step's gradient tensors: the five parameters' and the per-view screen-space ones"""
+            return {**{k: self.params[k].grad for k in self.names}, **{f"means2D[{i}]": m.grad for i, m in enumerate(self.m2ds)}}
+
         def step(self, timed_allreduce=False, skip_allreduce=False):
             pr = self.params
             if self.fg is not None:
@@ -160,27 +164,10 @@ def main():
                     p_.grad = None
             # the screen-space leaves: V detached views of ONE zero buffer that nothing ever writes into (the rasterizer reads no value
             # of means2D, it returns its gradient) -- resident like every other input, no fill launch per step
-            m2ds = [self.zeros[i].detach().requires_grad_() for i in range(V)]
+            m2ds = self.m2ds = [self.zeros[i].detach().requires_grad_() for i in range(V)]
             # independent views run on separate HIP streams (diff_gaussian_rasterization.rasterize_views): the first phase of
             # all views goes out in four launches, then every view's binning / compositing kernels overlap on the chip
-            if args.view_streams and args.halves and V >= 4 and V % 2 == 0:
-                cur = torch.cuda.current_stream()
-                if not hasattr(self, "_hs"):
-                    self._hs = [torch.cuda.Stream(), torch.cuda.Stream()]
-                losses, self.radii = [], []
-                for h_, st_ in enumerate(self._hs):
-                    st_.wait_stream(cur)
-                    with torch.cuda.stream(st_):
-                        idx = list(range(h_ * V // 2, (h_ + 1) * V // 2))
-                        colors, outs_ = rasterize_views([self.settings[i] for i in idx],
-                                                        [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"], shs=pr["shs"],
-                                                              scales=pr["scales"], rotations=pr["rotations"]) for i in idx], stacked=True)
-                        self.radii += [o_[1] for o_ in outs_]
-                        losses.append(l1_loss(colors, self.targets_stacked[idx[0]:idx[-1] + 1]))
-                for st_ in self._hs:
-                    cur.wait_stream(st_)
-                loss = (losses[0] + losses[1]) * 0.5
-            elif args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
+            if args.view_streams:   # all forwards first (train_step renders every camera, then calls backward once)
                 colors, outs_ = rasterize_views(self.settings, [dict(means3D=pr["means3D"], means2D=m2ds[i], opacities=pr["opacities"],
                                                                      shs=pr["shs"], scales=pr["scales"], rotations=pr["rotations"])
                                                                 for i in range(V)], stacked=True)
@@ -206,54 +193,32 @@ def main():
             return loss
 
     class GraphedSteps:
-        """The workload's step recorded into G hipGraphs and replayed round-robin (csplat_forward_views_faith: both phases of the forward
-        launched with capacities taken from an eager step's counts, nothing read back; a device word per graph says whether the counts
-        fitted -- checked after the timed region).  Same launches, same work as the eager step(); what is gone is the host: ~35 launches
-        and one read of the counts per step, which on a slow host core (the boxes differ) was what the step waited for.  G graphs, not
-        one: the K7 bracket events of the roofline are external event-record nodes, one pair per graph -- G live samples per read."""
+        """The workload's step recorded into G hipGraphs and replayed round-robin: csplat.graphs.ReplayedSteps -- the SAME object
+        tests/test_raster_gpu.py::test_config2_full_size_faith_replay_vs_oracle holds to the oracle (both phases of the forward launched
+        with capacities taken from an eager step's counts, nothing read back; a device word per graph says whether the counts fitted --
+        checked after the timed region, together with the replayed gradients themselves)."""
 
         def __init__(self, w_, G=4):
-            import diff_gaussian_rasterization as dgr_
-            dgr_.KEEP_INFO = True
-            try:
-                w_.step()
-            finally:
-                dgr_.KEEP_INFO = False
-            counts = torch.stack(list(dgr_.LAST_INFO)).cpu().tolist()
-            R_ = max(c[0] for c in counts); L_ = max(c[1] for c in counts); B_ = max(c[2] for c in counts)
-            self.caps = (R_ + R_ // 8 + 4096, min(L_ + L_ // 4 + 64, 8192), B_ + B_ // 8 + 16)
-            self.counts = counts
-            self.graphs, self.valid, self.info = [], [], []
-            self.w, self.G = w_, G
+            from csplat.graphs import ReplayedSteps
+            self.w = w_
+
+            def fn():       # (N > 1: the all-reduce follows every replay, launched by the host)
+                loss = w_.step(skip_allreduce=True)
+                return loss, w_.grads()
+            self.rs = ReplayedSteps(fn, dev, G=G)
+            self.caps, self.counts = self.rs.caps, self.rs.counts
 
         def record(self):
-            import diff_gaussian_rasterization as dgr_
-            w_, G = self.w, self.G
-            torch.cuda.synchronize()
-            if not args.halves:
-                native.REPLAY_STREAM[dev.index] = native.stream_handle(dev)      # (scratch "zeroed once per stream": the stream of the replays)
-            for _ in range(G):
-                valid = torch.zeros(1, dtype=torch.int32, device=dev)
-                faith = {"caps": self.caps, "valid": valid}
-                g_ = torch.cuda.CUDAGraph()
-                dgr_.FAITH = faith
-                try:
-                    with torch.cuda.graph(g_):
-                        w_.step(skip_allreduce=True)      # (N > 1: the all-reduce follows every replay, launched by the host)
-                finally:
-                    dgr_.FAITH = None
-                self.graphs.append(g_); self.valid.append(valid); self.info.append(faith["info"])
-            native.REPLAY_STREAM.clear()
-            self.k = 0
+            self.rs.record()
+            self.graphs = self.rs.graphs
 
         def step(self):
-            self.graphs[self.k % len(self.graphs)].replay()
-            self.k += 1
+            self.rs.step()
             if self.w.fg is not None:       # N > 1: ONE all-reduce of the flat gradient buffer the recorded kernels have just filled
                 self.w.fg.all_reduce()
 
         def all_valid(self):
-            return all(int(v.item()) == 1 for v in self.valid)
+            return self.rs.all_valid()
 
     scene_mode = args.mode == "scenes"
     if scene_mode:      # BASELINE configs[4]: six seeded scene variants, scene s on rank s mod N, no data-path collective
@@ -303,8 +268,13 @@ def main():
                 raise RuntimeError("the recorded capacities do not fit the workload's counts")
             launch_mode = f"hipGraph replay ({len(graphed.graphs)} recordings, round-robin)" + (" + one all-reduce per step" if dist_on else "")
         except Exception as e:
-            native.REPLAY_STREAM.clear()
             graphed, launch_mode = None, "eager (recording failed: " + repr(e)[:120] + ")"
+    if dist_on and want_graph:
+        # all ranks replay or none does: a curve that mixes eager and replayed ranks measures the slowest kind
+        flag = torch.tensor([1 if graphed is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and graphed is not None:
+            graphed, launch_mode = None, "eager (recording failed on another rank)"
     events_on = not os.environ.get("CSPLAT_BENCH_NOEVENTS")
     if graphed is None and events_on:
         native.prof_enable(["K7_render_bwd"])
@@ -315,19 +285,49 @@ def main():
         graphed.step() if graphed is not None else step()
     sync()
     dt = time.perf_counter() - t0
+    replay_check = sustained = None
+    eager_ms_per_step = None
     if graphed is not None:
         if not graphed.all_valid():       # (cannot happen on a static scene; never report a step that did nothing)
             raise SystemExit("bench.py: a replayed step reported counts beyond its capacities")
+        # ---- did the replays do the work?    The LAST replay's loss and gradients against one eager step of the same
+        # workload: the forward is deterministic (loss bit-equal), the gradients differ by the order of K7's float atomics only (1e-5 of
+        # each tensor's scale over 1500 repeats, tools/stress_step.py).  A replay that skipped work, ran on stale buffers or diverged from
+        # the eager path ends the run instead of reporting a number.
+        if wl.fg is None:
+            r_loss, r_grads = graphed.rs.outs[graphed.rs.last()]
+            r_loss = float(r_loss.detach())
+            r_g = {k: v.detach().clone() for k, v in r_grads.items()}
+            e_loss = float(step().detach())
+            e_g = wl.grads()
+            worst = max(float((r_g[k] - e_g[k]).abs().max()) / max(float(e_g[k].abs().max()), 1e-30) for k in e_g)
+            replay_check = {"loss_replayed": r_loss, "loss_eager": e_loss, "grad_max_abs_diff_over_scale": round(worst, 9),
+                            "bar": 1e-4, "what": "last timed replay vs one eager step: loss bit-equal, every gradient tensor (5 parameters + "
+                                                 f"{V} screen-space) within the float-atomic noise of K7"}
+            if r_loss != e_loss or not (worst <= 1e-4):
+                raise SystemExit(f"bench.py: the replayed step differs from the eager step: {replay_check}")
+        # ---- the same step under a sustained load: > 1 s of back-to-back replays (DVFS / power management; the 20-step region is 11 ms)
+        if not dist_on:
+            n_sus = 2000
+            torch.cuda.synchronize(); t_s = time.perf_counter()
+            for _ in range(n_sus):
+                graphed.step()
+            torch.cuda.synchronize()
+            sustained = {"steps": n_sus, "ms_per_step": round((time.perf_counter() - t_s) / n_sus * 1e3, 4),
+                         "what": "back-to-back hipGraph replays of the timed step, untimed by the contract"}
+            graphed.rs.check()
         # K7's HIP-event bracket: a kernel launched by a graph node cannot be bracketed by timeable events on this ROCm (external
         # event-record nodes: hipEventElapsedTime refuses them), so the SAME K steps run once more launch by launch, straight behind the
         # timed replays, with the event pair around every K7 launch -- same kernel, same launch geometry, same inputs; the rocprofv3
-        # trace of this command holds both populations under one kernel name
+        # trace of this command holds both populations under one kernel name.  The pass is timed too: `eager_ms_per_step`.
         if events_on:
             native.prof_enable(["K7_render_bwd"])
         native.prof_read("K7_render_bwd")
+        sync(); t_e = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
+        eager_ms_per_step = (time.perf_counter() - t_e) / args.steps * 1e3
     k7_ms, k7_n = native.prof_read("K7_render_bwd")
     native.prof_enable([])
 
@@ -344,11 +344,18 @@ def main():
     # K7 launched ALONE (views back to back on one stream; untimed, supplementary): the kernel-level reading of the
     # roofline next to the contract's in-step figure, where the views' K7 overlap and each launch lasts longer
     k7_alone_us = None
+    per_camera_ms_per_step = None
     if args.view_streams and V > 1 and wl is not None:
         args.view_streams = False
-        step(); torch.cuda.synchronize()
+        step(); step(); torch.cuda.synchronize()
         native.prof_enable(["K7_render_bwd"]); native.prof_read("K7_render_bwd")
-        step(); torch.cuda.synchronize()
+        # the reference's own call pattern (scene_reconstruction/train_utils.py:259-292): GaussianRasterizer(...) once per camera, one
+        # loss over the images, ONE backward -- timed over the same K steps
+        sync(); t_c = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        per_camera_ms_per_step = (time.perf_counter() - t_c) / args.steps * 1e3
         ms_a, n_a = native.prof_read("K7_render_bwd")
         native.prof_enable([])
         args.view_streams = True
@@ -553,6 +560,12 @@ def main():
                      "note": (f"the K7 work of the step's {V} views is ONE launch (blockIdx.y = view): bytes and instructions of "
                               f"{views_per_launch} view(s) per launch over that launch's duration; 'alone' = one view per launch, views "
                               "back to back") if args.view_streams and V > 1 else None},
+        # the same workload launched three ways: `ms_per_step` = hipGraph replays of the batched step; eager = the batched
+        # step (rasterize_views) launch by launch; per-camera = the reference's call pattern, one GaussianRasterizer call per camera
+        "eager_ms_per_step": None if eager_ms_per_step is None else round(eager_ms_per_step, 4),
+        "per_camera_ms_per_step": None if per_camera_ms_per_step is None else round(per_camera_ms_per_step, 4),
+        "replay_check": replay_check,
+        "sustained": sustained,
         "kernel_us": breakdown,
         "eval_forward": eval_fwd,
         "speculation": speculation,
@@ -573,6 +586,19 @@ def main():
                                  "psnr_first": r["psnr_first"], "psnr_last": r["psnr_last"], "workload": r["config"]["workload"]}
         except Exception as e:      # never let the auxiliary leg take the headline line down
             out["train_step"] = {"error": repr(e)[:200]}
+    # BASELINE configs[3] (MeshNet rollout, N = 10k, E = 300k, L = 128, M = 15): bench_gnn.py's rollout leg, auxiliary like `train_step`
+    if rank == 0 and world == 1 and not scene_mode and not args.no_gnn and (P, W, V) == (100_000, 800, 4):
+        try:
+            import bench_gnn
+            from types import SimpleNamespace as _NS
+            torch.cuda.empty_cache()
+            r = bench_gnn.run(_NS(steps=20, warmup=3, N=10_000, deg=30), dev, train=False)
+            out["gnn"] = {"rollout_ms_per_step": r["rollout_loop_ms_per_step"], "algorithmic_GBps": r["algorithmic_GBps"], "frac": r["frac"],
+                          "predict_velocity_ms": r["rollout_ms"], "kernel_launches_per_step": r["gnn_kernels"]["launches_per_step"],
+                          "algorithmic_bytes_per_step": r["gnn_kernels"]["algorithmic_bytes_per_step"], "peak_GBps": HBM_PEAK_GBS,
+                          "workload": r["config"]["workload"]}
+        except Exception as e:
+            out["gnn"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl.scene, wl.cams, P, W, H)
     elif rank == 0:

@@ -69,8 +69,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--N", type=int, default=10_000)
     ap.add_argument("--deg", type=int, default=30)
-    args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    ap.add_argument("--no-train", action="store_true", help="rollout only (what bench.py embeds as its `gnn` field)")
+    print(json.dumps(run(ap.parse_args())), flush=True)
+
+
+def run(args, dev=None, train=None):
+    """the measurement; returns the JSON record (bench.py embeds the rollout part as its `gnn` field)"""
+    dev = dev or torch.device("cuda:0")
+    train = (not getattr(args, "no_train", False)) if train is None else train
     from csplat import native
     from meshnet.cloth_network import ClothMeshSimulator
     torch.manual_seed(0)
@@ -96,40 +102,49 @@ def main():
     with torch.no_grad():
         ms_loop = timeit(roll, max(args.steps // 10, 2), 1) / nroll          # ms per rollout step, whole loop
         ms_roll = timeit(lambda: sim.predict_velocity(vel, ntype, ei, ef), args.steps, args.warmup)
-        ms_pyg = timeit(lambda: pyg_like_forward(net, feats, ei, ef), args.steps, args.warmup)
-        a = net(feats, ei, ef); b = pyg_like_forward(net, feats, ei, ef)
-        rel = float((a - b).abs().max() / b.abs().max())
+        a = net(feats, ei, ef)
+        ms_pyg = rel = None
+        if train:
+            ms_pyg = timeit(lambda: pyg_like_forward(net, feats, ei, ef), args.steps, args.warmup)
+            b = pyg_like_forward(net, feats, ei, ef)
+            rel = float((a - b).abs().max() / b.abs().max())
         native.prof_enable(["GNN"]); native.prof_read("GNN")
         sim.predict_velocity(vel, ntype, ei, ef); torch.cuda.synchronize()
         gnn_ms, gnn_n = native.prof_read("GNN"); native.prof_enable([])
 
-    sim.train()
-    opt = torch.optim.Adam(sim.parameters(), lr=1e-4)
-    tgt = torch.randn(N, 3, device=dev) * 0.1
+    ms_train = ms_train_pyg = None
+    if train:
+        sim.train()
+        opt = torch.optim.Adam(sim.parameters(), lr=1e-4)
+        tgt = torch.randn(N, 3, device=dev) * 0.1
 
-    def train_step(fwd):
-        opt.zero_grad(set_to_none=True)
-        pred = fwd()
-        loss = ((pred - tgt) ** 2).mean()
-        loss.backward()
-        opt.step()
-    ms_train = timeit(lambda: train_step(lambda: net(feats, ei, ef)), args.steps, args.warmup)
-    ms_train_pyg = timeit(lambda: train_step(lambda: pyg_like_forward(net, feats, ei, ef)), args.steps, args.warmup)
+        def train_step(fwd):
+            opt.zero_grad(set_to_none=True)
+            pred = fwd()
+            loss = ((pred - tgt) ** 2).mean()
+            loss.backward()
+            opt.step()
+        ms_train = timeit(lambda: train_step(lambda: net(feats, ei, ef)), args.steps, args.warmup)
+        ms_train_pyg = timeit(lambda: train_step(lambda: pyg_like_forward(net, feats, ei, ef)), args.steps, args.warmup)
 
     L, M = 128, 15
     alg = (16 * E + 12 * N) * L * M          # bytes of gather/scatter traffic per rollout step
+    r3 = lambda v: None if v is None else round(v, 3)  # noqa: E731
     out = {"metric": "MeshNet rollout step ms (N=10k, E=300k, L=128, M=15)", "value": round(ms_loop, 3), "unit": "ms",
            "higher_is_better": False, "dtype": "f32", "data": "synthetic",
            "rollout_loop_ms_per_step": round(ms_loop, 3), "rollout_loop_steps": nroll,
-           "rollout_ms": round(ms_roll, 3), "pyg_like_torch_rollout_ms": round(ms_pyg, 3),
-           "train_step_ms": round(ms_train, 3), "pyg_like_torch_train_step_ms": round(ms_train_pyg, 3),
+           "rollout_ms": round(ms_roll, 3), "pyg_like_torch_rollout_ms": r3(ms_pyg),
+           "train_step_ms": r3(ms_train), "pyg_like_torch_train_step_ms": r3(ms_train_pyg),
            "hip_vs_pyg_like_rel_diff": rel,
+           # algorithmic gather / scatter bytes of one rollout step over the step's time, against the 8 TB/s HBM peak
+           "algorithmic_GBps": round(alg / (ms_loop * 1e-3) / 1e9, 1), "frac": round(alg / (ms_loop * 1e-3) / 1e9 / 8000.0, 4),
            "gnn_kernels": {"launches_per_step": int(gnn_n), "total_ms_per_step": round(gnn_ms, 3),
                            "algorithmic_GBps": round(alg / (gnn_ms * 1e-3) / 1e9, 1) if gnn_ms > 0 else None,
                            "algorithmic_bytes_per_step": alg},
            "config": {"workload": f"ClothMeshSimulator N={N} E={E} (2-D {args.deg}-nearest-neighbour graph on the cloth grid, coalesced "
-                                  f"edge order) L=128 M=15 hist=2: {nroll}-step rollout loop (value), one predict_velocity call, train step"}}
-    print(json.dumps(out), flush=True)
+                                  f"edge order) L=128 M=15 hist=2: {nroll}-step rollout loop (value), one predict_velocity call" +
+                                  (", train step" if train else "")}}
+    return out
 
 
 if __name__ == "__main__":

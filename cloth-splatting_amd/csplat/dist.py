@@ -164,7 +164,7 @@ class FlatGrads:
         for i, p in enumerate(self.params):
             p.grad = None
             if self.flat.is_cuda:
-                _n.GRAD_SINK[id(p)] = (self._refs[i], self.flat, self.offsets[i], self.shapes[i])
+                _n.GRAD_SINK[id(p)] = (self._refs[i], self.flat, self.offsets[i], self.shapes[i], [False])     # ([used]: one writer per bind)
 
     def unbind(self):
         """the sinks are for ONE step: an ordinary (one-rank) step that follows must not write into this buffer"""

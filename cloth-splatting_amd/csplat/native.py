@@ -179,12 +179,22 @@ def why_not_f32c(*tensors):
 # would then take the wrong "last workgroup" branch and return wrong sums silently -- so any error drops every cached buffer:
 # the next call allocates and zeroes a fresh one.
 TICKET_CACHES = []
+# Recorded hipGraphs (csplat.train.CapturedStep, bench.py's GraphedSteps) hold RAW POINTERS into these buffers: whenever a cache is
+# emptied the freed memory may be handed to another tensor while the graphs stay replayable.  Every eviction therefore bumps
+# this epoch; a holder of recordings notes the epoch it recorded under and re-records (never replays) once it has moved.
+SCRATCH_EPOCH = [0]
+
+
+def evict_scratch(cache=None):
+    """empty one ticketed scratch cache (None: all of them) and invalidate every recording that may point into it"""
+    for c in (TICKET_CACHES if cache is None else [cache]):
+        c.clear()
+    SCRATCH_EPOCH[0] += 1
 
 
 def check(rc, what):
     if rc != 0:
-        for c in TICKET_CACHES:
-            c.clear()
+        evict_scratch()
         raise CsplatError(f"{what} failed (rc={rc}): {lib.csplat_last_error().decode(errors='replace')}")
 
 
@@ -230,27 +240,41 @@ GRAD_SINK = {}
 
 
 def grad_sink(t):
-    """the registered sink of parameter `t` as a KEY (flat buffer, offset, shape), or None.  Record it in forward(); grad_out() turns it
-    into a tensor inside backward() -- a view created earlier and kept on the ctx would have a second owner, and AccumulateGrad only
+    """the registered sink of parameter `t` as a KEY (flat buffer, offset, shape, id), or None.  Record it in forward(); grad_out() turns
+    it into a tensor inside backward() -- a view created earlier and kept on the ctx would have a second owner, and AccumulateGrad only
     adopts a gradient tensor nobody else holds (it clones otherwise)"""
     e = GRAD_SINK.get(id(t))
     if e is None or e[0]() is not t:
         return None
-    return e[1], e[2], e[3]
+    return e[1], e[2], e[3], id(t)
 
 
 def grad_out(sink, shape, device):
-    """the gradient buffer a backward writes: a FRESH view of the sink when there is one (and it fits), else fresh memory"""
+    """the gradient buffer a backward writes: a FRESH view of the sink when there is one (and it fits), else fresh memory.
+    A sink serves ONE writer per bind(): a second node that finishes a gradient of the same parameter inside the same step (per-view
+    transform nodes, a caller's own use between bind and unbind) gets fresh memory -- two aliases of one slice would be summed by
+    autograd as 2x the second contribution, silently; the post-accumulate hook then copies the sum into the slice."""
     if sink is not None:
-        flat, off, shp = sink
-        if tuple(shp) == tuple(shape) and flat.dtype == torch.float32 and flat.device == device:
+        flat, off, shp = sink[:3]
+        ent = GRAD_SINK.get(sink[3]) if len(sink) > 3 else None
+        if ent is not None and ent[1] is flat and not ent[4][0] and tuple(shp) == tuple(shape) and flat.dtype == torch.float32 and \
+                flat.device == device:
             n = 1
             for d in shp:
                 n *= d
             v = flat[off:off + n].view(tuple(shp))
             if v.data_ptr() % 16 == 0:
+                ent[4][0] = True
                 return v
     return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
+def grad_release(sinks):
+    """give back sinks whose views were never handed to autograd (a backward plan that is rebuilt before use)"""
+    for sk in sinks:
+        ent = GRAD_SINK.get(sk[3]) if (sk is not None and len(sk) > 3) else None
+        if ent is not None and ent[1] is sk[0]:
+            ent[4][0] = False
 
 
 class _NoSwitch:

@@ -78,20 +78,38 @@ class GroupedAdam(torch.optim.Adam):
         if len(counts) != 1 or len({it[2:5] for it in items}) != 1:
             raise RuntimeError("GroupedAdam.captured_setup: the tensors must share one step count and one (beta1, beta2, eps)")
         dev = items[0][0].device
-        self._cap = {"items": items, "state": torch.tensor([counts.pop()], dtype=torch.int32, device=dev),
-                     "lr": torch.zeros(len(items), dtype=torch.float64, device=dev),
-                     "lr_host": torch.zeros(len(items), dtype=torch.float64).pin_memory(), "lr_seen": None}
+        count = counts.pop()
+        cap = self.__dict__.get("_cap")
+        if cap is not None and cap["lr"].numel() == len(items) and cap["state"].device == dev:
+            # the device words are allocated ONCE per optimizer and refreshed in place: a hipGraph recorded earlier (another step shape
+            # of csplat.train.CapturedStep) has their addresses baked in and keeps reading live values
+            cap["items"], cap["lr_seen"] = items, None
+            cap["state"].fill_(count)
+            cap["dev_step"] = count
+        else:
+            self._cap = {"items": items, "state": torch.tensor([count], dtype=torch.int32, device=dev),
+                         "lr": torch.zeros(len(items), dtype=torch.float64, device=dev),
+                         "lr_host": torch.zeros(len(items), dtype=torch.float64).pin_memory(), "lr_seen": None, "dev_step": count,
+                         # bumped whenever the device words are RE-allocated: recordings that hold the old addresses are stale
+                         "epoch": (cap["epoch"] + 1) if cap is not None else 0}
         self.captured_refresh_lr()
         return self._cap
 
     def captured_refresh_lr(self):
-        """the groups' current learning rates -> the device table (a schedule edits param_groups[i]['lr'] on the host); no-op when unchanged"""
+        """Before a replay: the groups' current learning rates -> the device table (a schedule edits param_groups[i]['lr'] on the host;
+        no-op when unchanged), and the device-side step count re-synchronised with the host's counters when an ORDINARY step ran in
+        between (csplat.train.CapturedStep runs every 1000th iteration eagerly: the recorded Adam launch would otherwise use a stale
+        count -- wrong bias correction -- and the replay's sequence word would never match)."""
         cap = self._cap
         lrs = tuple(float(it[5]["lr"]) for it in cap["items"])
         if lrs != cap["lr_seen"]:
             cap["lr_host"].copy_(torch.tensor(lrs, dtype=torch.float64))
             cap["lr"].copy_(cap["lr_host"], non_blocking=True)
             cap["lr_seen"] = lrs
+        host_step = int(cap["items"][0][1]["step"].item())          # (a CPU tensor)
+        if host_step != cap["dev_step"]:
+            cap["state"].fill_(host_step)
+            cap["dev_step"] = host_step
 
     def step_captured(self, valid):
         """the launch itself (record it under stream capture): every tensor of captured_setup() that has a gradient NOW; `valid` = a
@@ -119,6 +137,7 @@ class GroupedAdam(torch.optim.Adam):
         """after a replay whose valid word was 1: the host-side step counters follow the device's"""
         steps = [it[1]["step"] for it in self._cap["items"]]
         torch._foreach_add_(steps, 1)
+        self._cap["dev_step"] += 1
         self.__dict__.pop("_step_cache", None)
 
     def zero_grad_now(self):

@@ -216,7 +216,7 @@ def _image_loss_scratch(dev, shape):
     buf = _IMG_SCRATCH.get(key)
     if buf is None:
         if len(_IMG_SCRATCH) >= 64:
-            _IMG_SCRATCH.clear()
+            _n.evict_scratch(_IMG_SCRATCH)
         buf = _IMG_SCRATCH[key] = torch.zeros(int(_n.lib.csplat_image_loss_scratch_bytes(B, Cc, H, W)), dtype=torch.uint8, device=dev)
     return buf
 
@@ -371,7 +371,7 @@ class FusedClothRegs(torch.autograd.Function):
                 scratch = _IMG_SCRATCH.get(key)          # zeroed once per (device, stream, sizes): the kernel leaves its ticket at zero
                 if scratch is None:
                     if len(_IMG_SCRATCH) >= 64:
-                        _IMG_SCRATCH.clear()
+                        _n.evict_scratch(_IMG_SCRATCH)
                     scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=dev)
                 _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
                                                            float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch),
@@ -426,7 +426,7 @@ class SimulatorStep(torch.autograd.Function):
                 scratch = _IMG_SCRATCH.get(key)
                 if scratch is None:
                     if len(_IMG_SCRATCH) >= 64:
-                        _IMG_SCRATCH.clear()
+                        _n.evict_scratch(_IMG_SCRATCH)
                     scratch = _IMG_SCRATCH[key] = torch.zeros(_n.lib.csplat_cloth_regs_scratch_bytes(T, V, E), dtype=torch.uint8, device=dev)
                 _n.check(_n.lib.csplat_cloth_regs(stream, T, V, E, _n.ptr(D), _n.ptr(ei), _n.ptr(rl), float(lam_deform), float(lam_rigid),
                                                            float(lam_mom), _n.ptr(loss), _n.ptr(grad), _n.ptr(scratch), *[_n.ptr(c) for c in csr]),
@@ -502,17 +502,22 @@ def _defer(launch):
 
 
 def _issue(ent):
-    if ent is not None and not ent[1]:
+    if ent is None:
+        return
+    # the entry leaves the queue BEFORE its launch runs: a launch that raises must not stay at the head (launch_deferred would spin on an
+    # entry already marked issued -- ADVICE r4)
+    _DEFERRED[:] = [e for e in _DEFERRED if e is not ent]
+    if not ent[1]:
         ent[1] = True
         fn, ent[0] = ent[0], None       # (the closure holds the node's tensors: drop it with the launch -- kept on the ctx it is a
         fn()                            #  reference cycle through the node's own output, and memory of a graph's private pool then
-        _DEFERRED[:] = [e for e in _DEFERRED if e is not ent]        # outlives the capture: a segfault at capture_end, measured)
+        #                                  outlives the capture: a segfault at capture_end, measured)
 
 
 def launch_deferred():
     """launches what FusedClothRegs(defer=True) queued (same stream, in order); a no-op otherwise"""
     while _DEFERRED:
-        _issue(_DEFERRED[0])
+        _issue(_DEFERRED.pop(0))
 
 
 def edge_csr(edge_index, n_nodes):
@@ -833,11 +838,8 @@ class CapturedStep:
     def _eager(self, iteration, cams):
         import diff_gaussian_rasterization as dgr
         self.stats["eager"] += 1
-        dgr.KEEP_INFO = True          # (the step's counts stay readable on the device: the next recording's capacities)
-        try:
+        with dgr.forward_mode(keep_info=True):      # (the step's counts stay readable on the device: the next recording's capacities)
             return train_step(iteration, cams, self.g, self.sim, self.mopt, self.pipe, self.opt, self.bg)
-        finally:
-            dgr.KEEP_INFO = False
 
     # ---- static inputs
     def _fill(self, st, cams):
@@ -886,7 +888,7 @@ class CapturedStep:
 
         def log(psnr_t, loss_t):
             srcs = [seq_src, st["valid"], psnr_t.reshape(1), loss_t.reshape(1)] + list(faith["info"])
-            kinds = [1, 1, 0, 0] + [1] * T
+            kinds = [1, 1, 0, 0] + [2] * T          # (the views' counts travel as raw int32 bits: exact at any size)
             counts = [1, 1, 1, 1] + [3] * T
             n = len(srcs)
             keep = [t if t.dtype in (torch.float32, torch.int32) else t.float() for t in srcs]
@@ -898,26 +900,22 @@ class CapturedStep:
             st["host"].copy_(st["packed"], non_blocking=True)
             st["host_seq"].copy_(st["packed"][0:1], non_blocking=True)
             st["_keep"] = keep
-        dgr.FAITH = faith
-        _n.REPLAY_STREAM[dev.index if dev.index is not None else torch.cuda.current_device()] = _n.stream_handle(dev)
-        try:
+        with dgr.forward_mode(faith=faith, replay_device=dev):
             with torch.cuda.graph(graph):
                 ps, loss, stats = train_step(0, scams, g, self.sim, self.mopt, self.pipe, self.opt, self.bg,
                                              _cap={"sim_in": (st["enc"], st["base"]), "gt": st["gt"], "valid": st["valid"], "log": log})
-        finally:
-            dgr.FAITH = None
-            _n.REPLAY_STREAM.clear()
-        st.update(graph=graph, psnr=ps, loss=loss, stats=stats)
+        # what the recording's raw pointers depend on: the ticketed scratch caches and both optimizers' device words
+        st.update(graph=graph, psnr=ps, loss=loss, stats=stats, epochs=self._epochs())
         self.graphs[key] = st
         self.stats["recorded"] += 1
         return st
 
     def _caps_from_counts(self, counts):
-        R = max(int(c[0]) for c in counts)
-        L = max(int(c[1]) for c in counts)
-        B = max(int(c[2]) for c in counts)
-        cap_l = 8192
-        return (R + R // self.MARGIN + 4096, min(L + L // 4 + 64, cap_l), B + B // self.MARGIN + 16)
+        from .graphs import caps_from_counts
+        return caps_from_counts(counts, self.MARGIN)
+
+    def _epochs(self):
+        return (_n.SCRATCH_EPOCH[0], self.g.optimizer.__dict__.get("_cap", {}).get("epoch"), self.mopt.__dict__.get("_cap", {}).get("epoch"))
 
     def _counts_of_last_eager(self):
         import diff_gaussian_rasterization as dgr
@@ -939,6 +937,11 @@ class CapturedStep:
                     self.graphs.clear()
                 self.graphs[key] = {"graph": None, "pending_caps": self._caps_from_counts(counts)}
             return out
+        if st.get("graph") is not None and st["epochs"] != self._epochs():
+            # a scratch cache was evicted (an entry point failed, a cache overflowed) or an optimizer's device words were re-allocated since
+            # this graph was recorded: its raw pointers may be dangling -- never replay it; record again with the same capacities
+            self.stats["rerecorded_stale"] = self.stats.get("rerecorded_stale", 0) + 1
+            st = self.graphs[key] = {"graph": None, "pending_caps": st["caps"]}
         if st.get("graph") is None:
             st = self._record(key, cams, st["pending_caps"])
         else:
@@ -971,10 +974,10 @@ class CapturedStep:
         self.g.optimizer.captured_advance_host()
         self.mopt.captured_advance_host()
         T = len(cams)
-        counts = host[4:4 + 3 * T].view(T, 3)
+        counts = host[4:4 + 3 * T].view(torch.int32).view(T, 3)
         caps = st["caps"]
         psnr_v, loss_v = host[2].clone(), host[3].clone()        # (the pinned line is overwritten by the next replay)
-        if float(counts[:, 0].max()) > 0.97 * caps[0] or float(counts[:, 1].max()) > 0.97 * caps[1] or float(counts[:, 2].max()) > 0.97 * caps[2]:
+        if int(counts[:, 0].max()) > 0.97 * caps[0] or int(counts[:, 1].max()) > 0.97 * caps[1] or int(counts[:, 2].max()) > 0.97 * caps[2]:
             # close to a capacity: re-record with room before a step is lost (the results of this replay are final -- copies are returned)
             self.graphs[key] = {"graph": None, "pending_caps": self._caps_from_counts(counts.tolist())}
             self.stats["rerecorded_early"] += 1

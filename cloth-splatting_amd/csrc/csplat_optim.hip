@@ -135,12 +135,12 @@ extern "C" int csplat_adam_step_dev(void *stream, int n_tensors, float *const *p
 // ---- the log line of a recorded step: up to 32 scalars scattered over device tensors (a step count, a go / no-go word, PSNR, loss, the
 // views' instance counts ...) gathered into ONE float array by one launch, so that one copy node carries them to pinned host memory
 namespace {
-struct WordsTable { const void *src[32]; int kind[32]; int count[32]; int n; };      // kind: 0 float, 1 int32 / uint32 (exact below 2^24)
+struct WordsTable { const void *src[32]; int kind[32]; int count[32]; int n; };      // kind: 0 float, 1 int32 -> float (exact below 2^24), 2 int32 bits
 __global__ void k_gather_words(WordsTable tab, float *__restrict__ dst) {
     int o = 0;
     for (int i = 0; i < tab.n; i++) {
         for (int k = threadIdx.x; k < tab.count[i]; k += blockDim.x)
-            dst[o + k] = tab.kind[i] == 0 ? reinterpret_cast<const float *>(tab.src[i])[k] : (float)reinterpret_cast<const int *>(tab.src[i])[k];
+            dst[o + k] = tab.kind[i] == 1 ? (float)reinterpret_cast<const int *>(tab.src[i])[k] : reinterpret_cast<const float *>(tab.src[i])[k];
         o += tab.count[i];
     }
 }
@@ -151,7 +151,7 @@ extern "C" int csplat_gather_words(void *stream, int n, const void *const *src, 
     memset(&tab, 0, sizeof(tab));
     tab.n = n;
     for (int i = 0; i < n; i++) {
-        CSPLAT_REQUIRE(src[i] && count[i] >= 1 && (kind[i] == 0 || kind[i] == 1), "csplat_gather_words: bad source");
+        CSPLAT_REQUIRE(src[i] && count[i] >= 1 && kind[i] >= 0 && kind[i] <= 2, "csplat_gather_words: bad source");
         tab.src[i] = src[i]; tab.kind[i] = kind[i]; tab.count[i] = count[i];
     }
     k_gather_words<<<1, 64, 0, (hipStream_t)stream>>>(tab, dst);

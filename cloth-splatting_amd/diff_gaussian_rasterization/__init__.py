@@ -10,6 +10,7 @@ scene_reconstruction/train_utils.py:290-292), shs, colors_precomp, opacities, sc
 The depth image carries no gradient (as upstream).  All compute is in libcsplat.so (csplat_forward_begin / _finish / csplat_backward).
 `rasterize_views` renders several independent views in one call, one HIP stream per view.
 """
+import contextlib as _contextlib
 import ctypes as C
 from typing import NamedTuple
 
@@ -188,12 +189,49 @@ SPEC_STATS = {"hit": 0, "miss": 0, "wait": 0}
 # the device words (int32 [3] views into the IMAGE chunks: tile instances, longest tile list, non-empty tiles) of the last batched
 # forward, per view -- what a caller sizes a launch on faith from (one .cpu() read at a moment of its choosing)
 LAST_INFO = []
-KEEP_INFO = False          # (set by a caller that wants LAST_INFO: the views cost ~10 us of host time per call)
-# Launch ON FAITH (csplat.train.CapturedStep): when set to a dict {"caps": (R, L, B), "valid": uint32 tensor [1]}, the batched forward
-# launches both phases with those capacities and reads NOTHING back (csplat_forward_views_faith) -- the form a hipGraph capture can
-# record.  The forward leaves in the dict: "info" = per view an int32 [3] VIEW of the device words holding (tile instances, longest tile
-# list, non-empty tiles), to be read whenever the caller syncs anyway.
-FAITH = None
+# ---- launch mode of the batched forward.  Two switches, both PRIVATE and both set only through `forward_mode(...)` below, which restores
+# them on exit whatever happens inside (module globals toggled around a capture leak silently -- one leaked flag and the
+# oracle-tested path and the timed path diverge):
+#   keep_info  the call leaves LAST_INFO (the views cost ~10 us of host time per call)
+#   faith      launch ON FAITH (csplat.train.CapturedStep, csplat.graphs.ReplayedSteps): a dict {"caps": (R, L, B), "valid": uint32 tensor
+#              [1]} -- the batched forward launches both phases with those capacities and reads NOTHING back
+#              (csplat_forward_views_faith): the form a hipGraph capture can record.  The forward leaves in the dict: "info" = per view an
+#              int32 [3] VIEW of the device words holding (tile instances, longest tile list, non-empty tiles), to be read whenever the
+#              caller syncs anyway.
+_KEEP_INFO = False
+_FAITH = None
+
+
+@_contextlib.contextmanager
+def forward_mode(faith=None, keep_info=False, replay_device=None):
+    """Scope in which the batched forward runs in another launch mode: `faith` / `keep_info` as above; `replay_device` = a device whose
+    CURRENT stream is the one the recording made inside this scope will be replayed on (scratch buffers that are "zeroed once per
+    stream" are keyed on it instead of on the capture stream, csplat.native.scratch_stream).  Not re-entrant for `faith` /
+    `replay_device`: nesting two recordings is a bug and raises."""
+    global _FAITH, _KEEP_INFO
+    if faith is not None and _FAITH is not None:
+        raise RuntimeError("diff_gaussian_rasterization.forward_mode: a launch on faith is already in progress")
+    prev = (_FAITH, _KEEP_INFO)
+    idx = None
+    if replay_device is not None:
+        idx = replay_device.index if isinstance(replay_device, torch.device) else int(replay_device)
+        idx = torch.cuda.current_device() if idx is None else idx
+        if idx in _n.REPLAY_STREAM:
+            raise RuntimeError("diff_gaussian_rasterization.forward_mode: a recording for this device is already in progress")
+        _n.REPLAY_STREAM[idx] = _n.stream_handle(idx)
+    _FAITH = faith if faith is not None else prev[0]
+    _KEEP_INFO = bool(keep_info) or prev[1]
+    try:
+        yield faith
+    finally:
+        _FAITH, _KEEP_INFO = prev
+        if idx is not None:
+            _n.REPLAY_STREAM.pop(idx, None)
+
+
+def forward_mode_is_default():
+    """True when no forward_mode scope is open (tests assert it after every recording)"""
+    return _FAITH is None and not _KEEP_INFO and not _n.REPLAY_STREAM
 
 
 def _view_streams(dev, n, main):
@@ -262,7 +300,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         # capacities: everything below that does not need the counts -- the output lists, the backward plan -- is host work done
         # while the GPU runs K1..K6, instead of after a ~45 us wait for K1 / K2
         pending = C.c_int(0)
-        faith = FAITH
+        faith = _FAITH
         if faith is not None:
             caps = (C.c_uint32 * 3)(*[int(c) for c in faith["caps"]])
             with _n.on_device(dev):
@@ -315,7 +353,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             # the GPU is busy with K1..K6 of the views right now: prepare the backward call in its shadow
             ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat if _n.GRAD_SINK else None)
-        if not pending.value and FAITH is None:
+        if not pending.value and _FAITH is None:
             SPEC_STATS["wait"] += 1
         if pending.value:
             relaunched = C.c_int(0)
@@ -331,12 +369,13 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     v.layout_rendered = int(arr[i].layout_rendered)
                     v.chunks = (chunks[i][_n_GEOM], chunks[i][_n_BINNING], chunks[i][_n_IMAGE])
                 if ctx.plan is not None:
+                    _n.grad_release(ctx.plan["sinks"])
                     ctx.plan = _RasterizeGaussiansBatch._plan_backward(views, saved, ctx.nsaved, arr, ctx.first_of, list(range(V)), dev, flat if _n.GRAD_SINK else None)
             elif ctx.plan is not None:
                 for a, i in enumerate(ctx.plan["active"]):
                     ctx.plan["sub"][a].num_rendered = arr[i].num_rendered
                     ctx.plan["sub"][a].busy_tiles = arr[i].busy_tiles
-        if KEEP_INFO and FAITH is None and len({(v.W, v.H) for v in views}) == 1 and all(_n_IMAGE in c for c in chunks):
+        if _KEEP_INFO and _FAITH is None and len({(v.W, v.H) for v in views}) == 1 and all(_n_IMAGE in c for c in chunks):
             off = int(_n.lib.csplat_image_info_offset(views[0].W, views[0].H))
             LAST_INFO[:] = [chunks[i][_n_IMAGE][off:off + 12].view(torch.int32) for i in range(V)]
         return tuple(outs)
@@ -352,6 +391,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         n = _RasterizeGaussiansBatch.NIN
         plan, owner, total = [], {}, 0
         sink_of = {}        # (view, slot) -> a fresh view of the input's gradient sink
+        used_sinks = []
 
         def reserve(numel):
             nonlocal total
@@ -395,6 +435,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     sv = _n.grad_out(sk, inputs[i * n + slot].shape, dev) if sk is not None else None
                     if sv is not None and sv.numel() == numel and sv.data_ptr() % 16 == 0:
                         sink_of[(i, slot)] = sv
+                        used_sinks.append(sk)
                         ent[field] = owner[(i, slot)] = ("sink", i, slot)
                         ent["ret"][slot] = (ent[field], shapes[slot])
                         continue
@@ -426,7 +467,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 for d in shape:
                     numel *= d
                 out[i * n + slot] = big[off:off + numel].view(shape)
-        return {"active": list(active), "big": big, "sub": sub, "out": out}
+        return {"active": list(active), "big": big, "sub": sub, "out": out, "sinks": used_sinks}
 
     @staticmethod
     def backward(ctx, *grads):
@@ -443,6 +484,8 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             return (None, None) + (None,) * (V * _RasterizeGaussiansBatch.NIN)
         plan, ctx.plan = ctx.plan, None                         # (one use: the buffers are handed to autograd)
         if plan is None or plan["active"] != active:            # a view's image went unused, or a second backward pass
+            if plan is not None:
+                _n.grad_release(plan["sinks"])
             plan = _RasterizeGaussiansBatch._plan_backward(views, ctx.saved_tensors, k, arr, ctx.first_of, active, dev)
         gs = [_f32c_grad(gcol[i], dev) for i in active]
         for a, g in enumerate(gs):

@@ -81,8 +81,12 @@ size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-Gaussian accumula
  * geom:    0 depth f32[P] | 1 xy f32[P][2] | 2 conic_opacity f32[P][4] | 3 rgb f32[P][3] | 4 cov3D f32[P][6]
  *          | 5 clamped u32[P] (bit c = channel c clamped) | 6 tiles_touched u32[P]
  *          | 7 offsets u32[P] (inclusive scan; filled only on the global radix-sort path)
- * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)   [then the per-tile segment plan and the forward's
- *          per-segment (T, colour) checkpoints that the depth-split backward restarts from]
+ * binning: 0 keys u64[R] (sorted) | 1 ids u32[R] (sorted)   [ABI 3, behind them and not part of the offsets: the per-tile segment
+ *          plan seg_offset[tiles+1] / slot_tile[slots]; the forward's checkpoints float4[slots][16 blocks][16 px] (T, colour so far
+ *          at the start of every 256-entry list segment); the 16-bit block masks u16[R+1]; the tile-ordered records recA / recB
+ *          float4[R+1], recC float2[R+1] (entry R = the null record); `bbits` u64[slots][16][4] = per (segment, 4x4 block) WHICH of the
+ *          segment's entries the block blended (K6 writes, K7 reads); `bmask` u64[R/64+4][16] = the block masks transposed, per 64
+ *          list entries and block (K5b writes, K6 reads).  R here is the LAYOUT count (csplat_view.layout_rendered >= num_rendered)]
  * image:   0 ranges i32[tiles][2] | 1 n_contrib u32[H*W] | 2 final_T f32[H*W]                               */
 int csplat_geom_layout(int P, size_t *offsets8);
 int csplat_binning_layout(int64_t R, int W, int H, size_t *offsets2);
@@ -175,9 +179,10 @@ size_t csplat_image_info_offset(int W, int H);
 /* Backward: K7 compositing backward, K8 per-Gaussian backward.
  * out_color is the forward's colour image; dL_dpix[3][H][W] its gradient (the depth image carries no gradient,
  * as upstream).
- * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes (one 64-byte-aligned accumulation record per Gaussian:
- * K7 adds one 36-byte partial per (8x8 quadrant, list entry that reached it) with a single atomic request, K8 consumes the
- * records).
+ * scratch: device buffer of csplat_backward_scratch_bytes(P, R) bytes: one 64-byte-aligned accumulation record per Gaussian (9 floats
+ * used).  ABI 3: K7 adds one 36-byte partial per (list entry, 4x4 pixel BLOCK that blended it) -- the nine lanes that hold the row sums
+ * issue one float-atomic request to the Gaussian's record; K8 consumes the records.  In the bit-reproducible mode (csplat_debug_flags
+ * bit 8) the buffer also holds one stored 9-float record per (list entry, block), summed per Gaussian in emission order.
  * Gradient outputs (device, fully overwritten): dL_dmean2D[P][3] (NDC units, .z = 0), dL_dconic[P][4],
  * dL_dopacity[P], dL_dcolor[P][3], dL_dmean3D[P][3], dL_dcov3D[P][6], dL_dsh[P][M][3] (may be NULL when
  * colors_precomp was used), dL_dscale[P][3], dL_drot[P][4] (may be NULL when cov3D_precomp was used). */
@@ -218,7 +223,8 @@ int csplat_adam_step_dev(void *stream, int n_tensors, float *const *params, cons
                          float *const *exp_avg_sq, const int64_t *numel, const double *lr_dev, double beta1, double beta2, double eps,
                          int *state_dev, const uint32_t *valid_dev);
 /* dst[...] (float, device) = the concatenation of n <= 32 small device arrays, src[i] holding count[i] values of kind[i] (0 = float,
- * 1 = int32 / uint32, converted; exact below 2^24): one launch that collects a recorded step's log line -- step count, go / no-go
+ * 1 = int32 / uint32 converted to float, exact below 2^24; 2 = int32 / uint32 copied BIT FOR BIT -- read the slot back as an integer:
+ * instance counts exceed 2^24 on large scenes): one launch that collects a recorded step's log line -- step count, go / no-go
  * word, PSNR, loss, the views' instance counts -- for ONE copy to pinned host memory. */
 int csplat_gather_words(void *stream, int n, const void *const *src, const int *kind, const int *count, float *dst);
 

@@ -350,6 +350,18 @@ def gen_simulator():
     for k, v in emb.state_dict().items():
         out["emb." + k] = npy(v)
     out["emb_out"] = np.stack([npy(emb(torch.tensor(tt, dtype=torch.float32).repeat(V, 1))) for tt in times])
+    # round 5: the reference module's own PARAMETER GRADIENTS (autograd over its three nn.Linear layers) for a fixed cotangent per time --
+    # what csplat_sim_hidden_fwd/_bwd + csplat_rows_dot_fwd/_bwd are held to on the GPU (tests/test_reference_goldens_gpu.py)
+    gw = torch.Generator().manual_seed(61)
+    w = torch.randn(len(times), V, 3, generator=gw)
+    sim.zero_grad()
+    loss = sum((sim(torch.tensor(tt, dtype=torch.float32).repeat(V, 1)) * w[i]).sum() for i, tt in enumerate(times))
+    loss.backward()
+    out["res_grad_w"] = npy(w)
+    out["res_loss"] = npy(loss)
+    for k, prm in sim.named_parameters():
+        if prm.grad is not None:
+            out["res_grad." + k] = npy(prm.grad)
     np.savez(os.path.join(OUT, "simulator.npz"), **out)
 
 
@@ -1014,8 +1026,11 @@ def gen_losses():
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
-    gen_camera(); gen_sh(); gen_misc(); gen_normalizer(); gen_gnn(); gen_simulator(); gen_densify(); gen_scene_io()
-    gen_meshsim(); gen_mesh_transform(); gen_losses(); gen_render_wiring(); gen_gnn128(); gen_vertice_rotation()
+    only = sys.argv[1:]          # e.g. `python make_golden.py simulator`: regenerate the named fixtures only
+    for name in ("camera", "sh", "misc", "normalizer", "gnn", "simulator", "densify", "scene_io", "meshsim", "mesh_transform", "losses",
+                 "render_wiring", "gnn128", "vertice_rotation"):
+        if not only or name in only:
+            globals()["gen_" + name]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

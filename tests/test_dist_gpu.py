@@ -117,3 +117,42 @@ def test_view_parallel_hip_train_step_two_ranks_one_gpu(tmp_path):
         a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
         d = np.abs(a - b)
         assert float((d > 1e-6 + 1e-3 * np.abs(b)).mean()) < 0.02, (k, float(d.max()))
+
+
+def _bench(extra, env_extra, timeout=1500):
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--no-cpu-baseline", "--no-train-step", "--no-gnn",
+                        "--no-speculation"] + extra, env=env, capture_output=True, text=True, timeout=timeout, cwd=util.ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines and r.stdout.strip().splitlines()[-1] == lines[-1], "the JSON line must be the LAST line of bench.py's output"
+    return json.loads(lines[-1])
+
+
+def test_bench_scene_parallel_mode_two_ranks_one_gpu():
+    """BASELINE configs[4]'s own code path in the GPU suite: `bench.py --mode scenes --gpus 2` -- six seeded
+    scene_1 variants dealt over the ranks (scene s on rank s mod 2), no data-path collective, replicas only -- with two gloo ranks that
+    share GPU 0 (RCCL needs one device per rank), started by bench.py's own launcher as fresh children.  Reduced size (P = 20k, 400x400,
+    2 cameras: the full size is the driver's to run); the line must account for all six scenes and say what it is."""
+    line = _bench(["--mode", "scenes", "--gpus", "2", "--steps", "2", "--warmup", "1", "--P", "20000", "--res", "400", "--views", "2"],
+                  {"CSPLAT_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["collective"] is None
+    assert "scene-parallel x2" in line["config"]["parallelism"] and "6 seeded scene_1 variants" in line["config"]["workload"]
+    # value = ALL six scenes' pixels over the slowest rank's time
+    mpix = 6 * 2 * 400 * 400 / 1e6
+    assert abs(line["value"] - mpix / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    assert line["value"] > 0 and line["roofline"]["launches_timed"] > 0
+
+
+def test_bench_view_parallel_two_ranks_one_gpu_all_replay_or_none():
+    """`bench.py --gpus 2` (view-parallel: FlatGrads + one all-reduce per step) with two gloo ranks sharing GPU 0: both ranks replay
+    recorded hipGraphs (or both fall back together -- one all-reduce(min) of a flag), the line carries the
+    `collective` object and the replays are checked against an eager step."""
+    line = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--P", "20000", "--res", "400", "--views", "2"],
+                  {"CSPLAT_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    c = line["collective"]
+    assert c is not None and c["ranks"] == 2 and c["backend"] == "gloo" and c["allreduce_ms"] > 0
+    assert line["config"]["launch"].startswith("hipGraph replay") or line["config"]["launch"].startswith("eager (recording failed"), line["config"]["launch"]

@@ -793,49 +793,43 @@ def _grad_vs_oracles(name, got, g32, g64, P, tie_frac=1e-3, tie_tol=2e-2, exp_ti
     assert np.all((d32[ties] > 0.5 * TOL) | t32[ties]), (name, "a deviation from fp64 that neither the fp32 oracle nor an exp tie explains")
 
 
-def test_config2_full_size_vs_oracle():
-    """BASELINE configs[1] at FULL size through the path bench.py times: P = 100k, 4 cameras 800x800, `rasterize_views`
-    (one launch per stage, blockIdx.y = view), called twice so that the second call takes the SPECULATIVE second phase
-    (chunks laid out for the previous call's counts).  Reference call being matched: gaussian_renderer/__init__.py:156-164
-    (one GaussianRasterizer call per camera, train_utils.py:259-292 sums the cameras' gradients through autograd).
-    Per view: keys / ids / ranges / radii / tiles touched bit-exact vs the fp32 oracle, n_contrib ties < 2e-4, image /
-    depth / final_T <= 1e-4 vs the fp64 oracle; the six gradients (shared parameters: sums over the 4 views; means2D:
-    per view) <= 1e-4 vs the fp64 oracle."""
-    from csplat import synthetic as syn
-    from diff_gaussian_rasterization import rasterize_views
-    P, W, H, V = 100_000, 800, 800, 4
-    sc = syn.scene_1(P=P, W=W, H=H, n_cams=V)
-    g = syn.gaussians_at(sc)
-    cases = [dict(g=g, cam=sc["cameras"][i], W=W, H=H, P=P, bg=sc["bg"], sh_degree=3) for i in range(V)]
-    rng = np.random.default_rng(11)
-    dpix = rng.normal(size=(V, 3, H, W)).astype(np.float32)
-    settings = [util.gpu_settings(c) for c in cases]
-    inp = util.gpu_inputs(cases[0])
-    names = ("means3D", "opacities", "shs", "scales", "rotations")
-    dp = torch.tensor(dpix, device="cuda")
+_CONFIG2 = {}
 
-    def run():
-        for k in names:
-            inp[k].grad = None
-        m2d = [torch.zeros(P, 3, device="cuda", requires_grad=True) for _ in range(V)]
-        kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
-                    rotations=inp["rotations"]) for i in range(V)]
-        colors, outs = rasterize_views(settings, kws, stacked=True)
-        views = colors.grad_fn.views
-        (colors * dp).sum().backward()
-        torch.cuda.synchronize()
-        return colors.detach(), outs, views, m2d
 
-    run()                                   # first call: waits for the counts
-    colors, outs, views, m2d = run()        # second call: speculative layout
-    assert any(v.layout_rendered > v.num_rendered for v in views), "the speculative phase was not taken"
+def _config2():
+    """BASELINE configs[1] at full size, built once per test session: scene, per-view cases, the image gradient, and (lazily, cached) the
+    fp32 / fp64 oracle forwards and backwards of every view -- both full-size tests hold the HIP path to the SAME oracle run"""
+    if not _CONFIG2:
+        from csplat import synthetic as syn
+        P, W, H, V = 100_000, 800, 800, 4
+        sc = syn.scene_1(P=P, W=W, H=H, n_cams=V)
+        g = syn.gaussians_at(sc)
+        cases = [dict(g=g, cam=sc["cameras"][i], W=W, H=H, P=P, bg=sc["bg"], sh_degree=3) for i in range(V)]
+        dpix = np.random.default_rng(11).normal(size=(V, 3, H, W)).astype(np.float32)
+        _CONFIG2.update(P=P, W=W, H=H, V=V, cases=cases, dpix=dpix, oracle={})
+    return _CONFIG2
+
+
+def _config2_oracle(i):
+    c = _config2()
+    if i not in c["oracle"]:
+        o, o64 = oracle_forward(c["cases"][i]), oracle_forward(c["cases"][i], dtype=np.float64)
+        c["oracle"][i] = (o, o64, util.ro.backward(o, c["dpix"][i]), util.ro.backward(o64, c["dpix"][i]))
+    return c["oracle"][i]
+
+
+def _check_config2_against_oracle(colors, outs, chunks, layout_R, counted_R, m2d_grads, param_grads):
+    """Per view: keys / ids / ranges / radii / tiles touched bit-exact vs the fp32 oracle, n_contrib ties < 2e-4, image / depth /
+    final_T <= 1e-4 vs the fp64 oracle; the six gradients (shared parameters: sums over the 4 views; means2D: per view) <= 1e-4 vs
+    the fp64 oracle with _grad_vs_oracles' tie accounting."""
+    c = _config2()
+    P, W, H, V = c["P"], c["W"], c["H"], c["V"]
     sums = {k: 0.0 for k in ("mean3D", "opacity", "sh", "scale", "rot")}
     sums32 = dict(sums)
-    for i, case in enumerate(cases):
-        o = oracle_forward(case)
-        v = views[i]
-        assert v.num_rendered == o.R
-        st = util.gpu_chunks(v.chunks, P, W, H, v.layout_rendered)
+    for i in range(V):
+        o, o64, g32, g64 = _config2_oracle(i)
+        assert counted_R[i] == o.R
+        st = util.gpu_chunks(chunks[i], P, W, H, layout_R[i])
         np.testing.assert_array_equal(outs[i][1].cpu().numpy(), o.radii)
         np.testing.assert_array_equal(st["tiles_touched"], o.tiles_touched)
         np.testing.assert_array_equal(st["keys"][:o.R], o.keys)
@@ -843,22 +837,94 @@ def test_config2_full_size_vs_oracle():
         np.testing.assert_array_equal(st["ranges"], o.ranges)
         mism = st["n_contrib"] != o.n_contrib
         assert mism.mean() < 2e-4, f"view {i}: {mism.sum()} n_contrib mismatches"
-        o64 = oracle_forward(case, dtype=np.float64)
         # images: <= 1e-4 vs the fp32 oracle (threshold-tie pixels: < 1e-4 of the pixels); vs the fp64 oracle the ties of fp32 arithmetic
         # itself add to them (pixels go ~1200 entries deep here): < 1e-3 of the pixels
         assert image_err(colors[i].cpu().numpy(), o.color) < TOL and image_err(colors[i].cpu().numpy(), o64.color, outlier_frac=1e-3) < TOL
         dimg = outs[i][2].detach().cpu().numpy()
         assert image_err(dimg, o.out_depth) < TOL and image_err(dimg, o64.out_depth, outlier_frac=1e-3) < TOL
         assert image_err(st["final_T"], o.final_T) < TOL and image_err(st["final_T"], o64.final_T, outlier_frac=1e-3) < TOL
-        g64, g32 = util.ro.backward(o64, dpix[i]), util.ro.backward(o, dpix[i])
-        _grad_vs_oracles(f"mean2D[{i}]", m2d[i].grad.cpu().numpy(), g32.mean2D, g64.mean2D, P)
+        _grad_vs_oracles(f"mean2D[{i}]", m2d_grads[i].cpu().numpy(), g32.mean2D, g64.mean2D, P)
         for k in sums:
             sums[k] = sums[k] + np.asarray(getattr(g64, k), np.float64)
             sums32[k] = sums32[k] + np.asarray(getattr(g32, k), np.float64)
-    got = dict(mean3D=inp["means3D"].grad, opacity=inp["opacities"].grad.reshape(-1), sh=inp["shs"].grad,
-               scale=inp["scales"].grad, rot=inp["rotations"].grad)
+    got = dict(mean3D=param_grads["means3D"], opacity=param_grads["opacities"].reshape(-1), sh=param_grads["shs"],
+               scale=param_grads["scales"], rot=param_grads["rotations"])
     for k, v in got.items():
         _grad_vs_oracles(k, v.cpu().numpy(), sums32[k], sums[k], P, tie_frac=4e-3)
+
+
+_NAMES = ("means3D", "opacities", "shs", "scales", "rotations")
+
+
+def _config2_step():
+    """the step both full-size tests run: rasterize_views over the 4 cameras, the image gradient `dpix`, one backward"""
+    from diff_gaussian_rasterization import rasterize_views
+    c = _config2()
+    P, V = c["P"], c["V"]
+    settings = [util.gpu_settings(cs) for cs in c["cases"]]
+    inp = util.gpu_inputs(c["cases"][0])
+    dp = torch.tensor(c["dpix"], device="cuda")
+    zeros = torch.zeros(V, P, 3, device="cuda")
+    one = torch.ones((), device="cuda")
+
+    def run():
+        for k in _NAMES:
+            inp[k].grad = None
+        m2d = [zeros[i].detach().requires_grad_() for i in range(V)]
+        kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                    rotations=inp["rotations"]) for i in range(V)]
+        colors, outs = rasterize_views(settings, kws, stacked=True)
+        views = colors.grad_fn.views
+        (colors * dp).sum().backward(gradient=one)
+        return colors.detach(), outs, views, m2d, {k: inp[k].grad for k in _NAMES}
+    return run
+
+
+def test_config2_full_size_vs_oracle():
+    """BASELINE configs[1] at FULL size through the EAGER batched path: P = 100k, 4 cameras 800x800, `rasterize_views`
+    (one launch per stage, blockIdx.y = view), called twice so that the second call takes the SPECULATIVE second phase
+    (chunks laid out for the previous call's counts).  Reference call being matched: gaussian_renderer/__init__.py:156-164
+    (one GaussianRasterizer call per camera, train_utils.py:259-292 sums the cameras' gradients through autograd).
+    Bars: _check_config2_against_oracle."""
+    run = _config2_step()
+    run()                                   # first call: waits for the counts
+    colors, outs, views, m2d, pg = run()        # second call: speculative layout
+    torch.cuda.synchronize()
+    assert any(v.layout_rendered > v.num_rendered for v in views), "the speculative phase was not taken"
+    _check_config2_against_oracle(colors, outs, [v.chunks for v in views], [v.layout_rendered for v in views],
+                                  [v.num_rendered for v in views], [m.grad for m in m2d], pg)
+
+
+def test_config2_full_size_faith_replay_vs_oracle():
+    """The path bench.py TIMES, held to the oracle: the same full-size step recorded by csplat.graphs.ReplayedSteps
+    -- the object bench.py's GraphedSteps wraps: `csplat_forward_views_faith` with capacities from one eager step's counts, nothing read
+    back -- and replayed three times; after the last replay the chunks of THAT recording are decoded and held to the same bars as the
+    eager test: keys / ids / ranges / radii bit-exact, images <= 1e-4, the five parameter gradients and the per-view means2D gradients
+    <= 1e-4 against the C oracle with the tie accounting of _grad_vs_oracles.  Between replays the outputs are poisoned, so a replay
+    that skipped work cannot pass on the previous one's results.  Reference call: gaussian_renderer/__init__.py:156-164."""
+    import diff_gaussian_rasterization as dgr
+    from csplat.graphs import ReplayedSteps
+    c = _config2()
+    rs = ReplayedSteps(_config2_step(), torch.device("cuda", torch.cuda.current_device()), G=2)
+    assert dgr.forward_mode_is_default()
+    rs.record()
+    assert dgr.forward_mode_is_default(), "a launch-mode switch leaked out of the recording"
+    for k in range(3):
+        colors, outs, views, m2d, pg = rs.outs[k % 2]
+        with torch.no_grad():           # poison what the replay must rewrite
+            colors.fill_(float("nan"))
+            for t in list(pg.values()) + [m.grad for m in m2d]:
+                t.fill_(float("nan"))
+        got = rs.step()
+        assert got[0] is colors
+    rs.check()
+    i = rs.last()
+    assert i == 0
+    colors, outs, views, m2d, pg = rs.outs[i]
+    counts = rs.replay_counts(i)
+    assert all(int(v.layout_rendered) == rs.caps[0] for v in views), "the recording was not laid out for the capacities given on faith"
+    _check_config2_against_oracle(colors, outs, [v.chunks for v in views], [int(v.layout_rendered) for v in views],
+                                  [int(cn[0]) for cn in counts], [m.grad for m in m2d], pg)
 
 
 @pytest.mark.parametrize("k7", [32768], ids=["k6_rows"])

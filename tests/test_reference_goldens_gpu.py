@@ -141,3 +141,39 @@ def test_fused_cloth_regularisers_vs_reference_run(Tn):
     loss.backward()
     assert abs(float(loss) - float(g[f"reg{Tn}.loss"])) < 1e-6
     assert rel_err(D.grad.cpu().numpy(), g[f"reg{Tn}.grad"]) < 1e-5
+
+
+def test_residual_mesh_simulator_hip_vs_reference_run():
+    """a6, directly: ResidualMeshSimulator on the GPU -- csplat_sim_hidden_fwd/_bwd (the two hidden layers) and
+    csplat_rows_dot_fwd/_bwd (the 256 -> 3V output layer, table rows added in its launch) -- against the run of the reference's own
+    module (meshnet/meshnet_network.py:327-373, conflict resolved to 9b63d7a; tests/golden/simulator.npz): forward() per time,
+    forward_times() for all five at once, and every PARAMETER GRADIENT for a fixed cotangent (the reference's autograd over its three
+    nn.Linear).  fp32 on both sides: 1e-5 forward, 1e-4 of each gradient tensor's scale."""
+    from meshnet.meshnet_network import ResidualMeshSimulator
+    g = golden("simulator.npz")
+    mesh = T(g["res_mesh"])
+    V = mesh.shape[1]
+    sim = ResidualMeshSimulator(mesh, device="cuda").cuda()
+    sim.load_state_dict({k[4:]: torch.tensor(g[k]) for k in g.files if k.startswith("res.")})
+    for tt, ref in zip(g["res_times"], g["res_out"]):
+        got = sim(torch.tensor(float(tt), device="cuda").repeat(V, 1))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, atol=1e-5)
+    both = sim.forward_times([float(tt) for tt in g["res_times"]])
+    np.testing.assert_allclose(both.detach().cpu().numpy(), g["res_out"], atol=1e-5)
+    w = T(g["res_grad_w"])
+    # (a) the reference's own call pattern: forward() once per time, the losses summed by autograd
+    sim.zero_grad()
+    loss = sum((sim(torch.tensor(float(tt), device="cuda").repeat(V, 1)) * w[i]).sum() for i, tt in enumerate(g["res_times"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["res_loss"])) <= 1e-5 * max(abs(float(g["res_loss"])), 1.0)
+    grads_a = {k: p.grad.detach().clone() for k, p in sim.named_parameters() if p.grad is not None}
+    # (b) the batched form train_step uses: all times through ONE node (T rows per launch)
+    sim.zero_grad()
+    (sim.forward_times([float(tt) for tt in g["res_times"]]) * w).sum().backward()
+    grads_b = {k: p.grad.detach().clone() for k, p in sim.named_parameters() if p.grad is not None}
+    names = [k[len("res_grad."):] for k in g.files if k.startswith("res_grad.") and k != "res_grad_w"]
+    assert sorted(names) == sorted(["input.weight", "input.bias", "hidden.weight", "hidden.bias", "output.weight", "output.bias"])
+    for k in names:
+        ref = g["res_grad." + k]
+        assert rel_err(grads_a[k].cpu().numpy(), ref) < 1e-4, ("per-time calls", k)
+        assert rel_err(grads_b[k].cpu().numpy(), ref) < 1e-4, ("forward_times", k)

@@ -733,3 +733,89 @@ def test_captured_train_step_survives_a_miss():
     for a, b in zip(runs["eager"][1], runs["captured"][1]):
         d = (a - b).abs()
         assert float((d > 1e-6 + 5e-3 * b.abs()).float().mean()) < 0.03, float(d.max())
+
+
+def _captured_run(mode, iterations, cams_of, seed=3, sh_at_max=False, before_step=None):
+    from csplat import train as tr
+    pc, sim, mopt, cams, bg = _captured_fixture(seed=seed)
+    if sh_at_max:
+        pc.active_sh_degree = pc.max_sh_degree
+    log = []
+    for it in iterations:
+        if before_step is not None:
+            before_step(it, pc, sim)
+        ps, loss, stats = tr.train_step(it, cams_of(it, cams), pc, sim, mopt, background=bg, captured=(mode == "captured"))
+        log.append((float(ps), float(loss)))
+    torch.cuda.synchronize()
+    params = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
+    steps = [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if pc.optimizer.state.get(p)] + \
+            [float(mopt.state[p]["step"]) for p in sim.parameters()]
+    dev_steps = None
+    if mode == "captured":
+        dev_steps = (int(pc.optimizer._cap["state"].item()), int(mopt._cap["state"].item()))
+    return log, params, steps, dev_steps, getattr(pc, "_captured_step", None)
+
+
+def _assert_runs_agree(a, b, loss_tol=5e-4):
+    for k_, ((pe, le), (pc_, lc)) in enumerate(zip(a[0], b[0])):
+        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < (1e-5 if k_ == 0 else loss_tol) * max(abs(le), 1e-3), (k_, pe, pc_, le, lc)
+    for x, y in zip(a[1], b[1]):
+        d = (x - y).abs()
+        assert float((d > 1e-6 + 5e-3 * y.abs()).float().mean()) < 0.03, float(d.max())
+
+
+def test_captured_train_step_across_an_eager_iteration():
+    """CapturedStep runs every `iteration % 1000 == 0` step through the eager train_step (the step that may raise the SH
+    degree, train_utils.py:249-251).  With the degree already at its maximum the step shape -- and so the recorded graph -- survives that
+    step; the eager step advances the optimizers' HOST step counters only, and the next replay used to read a stale device count (wrong
+    bias correction, then a sequence mismatch and RuntimeError).  Iterations 997..1004, captured against eager: same losses, same
+    parameters, host and device step counts equal at the end, the graph recorded once."""
+    its = list(range(997, 1005))
+    same = lambda it, cams: cams  # noqa: E731
+    eager = _captured_run("eager", its, same, sh_at_max=True)
+    cap = _captured_run("captured", its, same, sh_at_max=True)
+    cs = cap[4]
+    # 997 eager (first of its shape), 998-999 record + replay, 1000 eager, 1001-1004 replays of the SAME graph
+    assert cs.stats["recorded"] == 1 and cs.stats["eager"] == 2 and cs.stats["replayed"] == 6 and cs.stats["missed"] == 0, cs.stats
+    assert eager[2] == cap[2] == [8.0] * len(eager[2])
+    assert cap[3] == (8, 8)
+    _assert_runs_agree(eager, cap)
+
+
+def test_captured_train_step_alternating_step_shapes():
+    """one graph per step SHAPE.  Recording a second shape used to re-allocate the optimizers' device-side step
+    count and learning-rate table, leaving the first shape's graph with dangling pointers.  Three cameras and two cameras alternate
+    (both shapes recorded, then each replayed after the other was recorded); the learning rate of one group changes mid-run (a
+    schedule editing param_groups, utils/general_utils.py:32-65 as used by gaussian_model.py:162-168): captured == eager."""
+    its = list(range(1, 13))
+    pick = lambda it, cams: cams if (it // 2) % 2 == 0 else cams[:2]  # noqa: E731
+
+    def sched(it, pc, sim):
+        if it == 9:
+            for g in pc.optimizer.param_groups:
+                g["lr"] = g["lr"] * 0.5
+    eager = _captured_run("eager", its, pick, seed=7, before_step=sched)
+    cap = _captured_run("captured", its, pick, seed=7, before_step=sched)
+    cs = cap[4]
+    assert cs.stats["recorded"] == 2 and cs.stats["missed"] == 0 and cs.stats["replayed"] >= 8, cs.stats
+    assert eager[2] == cap[2] == [12.0] * len(eager[2])
+    assert cap[3] == (12, 12)
+    _assert_runs_agree(eager, cap)
+
+
+def test_captured_train_step_rerecords_after_a_scratch_eviction():
+    """a failed entry point (csplat.native.check) or an overflowing cache drops the "zeroed once" scratch buffers the
+    recorded graphs point into.  The eviction bumps csplat.native.SCRATCH_EPOCH; CapturedStep must not replay a graph recorded under an
+    older epoch -- it records again -- and the run still equals the eager run."""
+    from csplat import native
+    its = list(range(1, 9))
+    same = lambda it, cams: cams  # noqa: E731
+
+    def evict(it, pc, sim):
+        if it == 5 and getattr(pc, "_captured_step", None) is not None:
+            native.evict_scratch()
+    eager = _captured_run("eager", its, same, seed=11)
+    cap = _captured_run("captured", its, same, seed=11, before_step=evict)
+    cs = cap[4]
+    assert cs.stats["recorded"] == 2 and cs.stats.get("rerecorded_stale") == 1 and cs.stats["missed"] == 0, cs.stats
+    _assert_runs_agree(eager, cap)

@@ -60,6 +60,19 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def rowwise_rel_err(a, b, rows, floor=1e-2):
+    """ELEMENT-WISE relative error with a floor, per Gaussian (`rel_err` above is max-abs error over the tensor's
+    max -- an error of 1e-4 of the LARGEST gradient could be 100 % of a small one).  For row i (one Gaussian's gradient entries):
+        e_i = max_j |a_ij - b_ij| / max(max_j |b_ij|, floor * max |b|)
+    i.e. relative to the Gaussian's own gradient magnitude, except that Gaussians whose gradient is below `floor` of the tensor's
+    largest are measured against that floor (a gradient that is itself a rounding-level sum has no relative accuracy to speak of).
+    Returns the vector e [rows]."""
+    a = np.asarray(a, np.float64).reshape(rows, -1); b = np.asarray(b, np.float64).reshape(rows, -1)
+    scale = np.abs(b).max() + 1e-30
+    den = np.maximum(np.abs(b).max(1), floor * scale)
+    return np.abs(a - b).max(1) / den
+
+
 def image_err(a, b, outlier_frac=1e-4, outlier_tol=1e-2):
     """Relative max error of an image, robust to THRESHOLD TIES: the compositing rule is discontinuous (a Gaussian is
     dropped at a pixel when alpha < 1/255, a pixel stops when T(1-alpha) < 1e-4), so fp32-vs-fp64 (or v_exp_f32-vs-expf)
