@@ -6,12 +6,33 @@ What replaces a host read.  The reference's rasterizer call reads `num_rendered`
 (/root/reference/gaussian_renderer/__init__.py:156-164 -> upstream `rasterize_points.cu`); a stream capture cannot contain a host read.
 `csplat_forward_views_faith` launches both phases with caller-given capacities and leaves a device word saying whether the counts fitted;
 every later kernel of the step leaves an unfitting view alone.  The caller checks the word whenever it synchronises anyway."""
+import contextlib as _contextlib
+
 import torch
 
 from . import native as _n
 
 MARGIN = 8          # capacities = counts + counts / MARGIN (+ a constant)
 LIST_CAP = 8192     # longest tile list the in-LDS tile sort takes (csplat_raster.hip)
+
+
+@_contextlib.contextmanager
+def capture(graph):
+    """`torch.cuda.graph(graph)` with Python's cyclic collector held off for the duration of the capture.  A collection that starts in the
+    middle of a capture (allocation counts crossing the collector's threshold) frees whatever unreachable tensors it finds -- memory of
+    ANOTHER recording's private pool, events of the previous eager step -- and freeing those is an operation the capturing stream refuses:
+    the process aborts inside the collector (seen in round 5 when a second step shape was recorded while the first shape's graph was
+    alive).  Garbage is collected before the capture starts, the collector resumes after it ends."""
+    import gc
+    was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield graph
+    finally:
+        if was_on:
+            gc.enable()
 
 
 def caps_from_counts(counts, margin=MARGIN):
@@ -61,7 +82,7 @@ class ReplayedSteps:
             faith = {"caps": self.caps, "valid": valid}
             g = torch.cuda.CUDAGraph()
             with dgr.forward_mode(faith=faith, replay_device=self.dev):
-                with torch.cuda.graph(g):
+                with capture(g):
                     out = self.fn()
             self.graphs.append(g); self.valid.append(valid); self.info.append(faith["info"]); self.outs.append(out)
         self.epoch = _n.SCRATCH_EPOCH[0]

@@ -900,8 +900,9 @@ class CapturedStep:
             st["host"].copy_(st["packed"], non_blocking=True)
             st["host_seq"].copy_(st["packed"][0:1], non_blocking=True)
             st["_keep"] = keep
+        from .graphs import capture
         with dgr.forward_mode(faith=faith, replay_device=dev):
-            with torch.cuda.graph(graph):
+            with capture(graph):          # (the cyclic collector is held off during the capture: csplat/graphs.py)
                 ps, loss, stats = train_step(0, scams, g, self.sim, self.mopt, self.pipe, self.opt, self.bg,
                                              _cap={"sim_in": (st["enc"], st["base"]), "gt": st["gt"], "valid": st["valid"], "log": log})
         # what the recording's raw pointers depend on: the ticketed scratch caches and both optimizers' device words
