@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsplat.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -108,6 +108,9 @@ EXPORTS = {
     "csplat_linear128_mode": (_i, [C.c_uint]),
     "csplat_linear128_mode_query": (C.c_uint, []),
     "csplat_gnn_node_update": (_i, [_vp, _i64] + [_vp] * 11 + [_f] + [_vp] * 5),
+    "csplat_gnn_edge_mlp3_image_bytes": (_sz, []),
+    "csplat_gnn_edge_mlp3_pack": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "csplat_linear128": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_linear128_ex": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }

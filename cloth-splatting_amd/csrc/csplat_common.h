@@ -48,6 +48,9 @@ size_t csplat_sort_temp_bytes(int64_t n);
 int csplat_sort_pairs(hipStream_t s, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
                       uint32_t *vals_out, uint64_t *keys_tmp, uint32_t *vals_tmp, int64_t n, int end_bit, void *temp);
 
+// measurement hook (csplat_debug_stamps): the caller-provided device buffer, or nullptr when none of `need_words` u64 words is registered
+unsigned long long *csplat_stamp_buffer(size_t need_words);
+
 // ---- optional event bracketing (csplat_prof_*), implemented in csplat_sort.hip --------------------
 enum { PROF_K1 = 0, PROF_K2, PROF_K3, PROF_K4, PROF_K5, PROF_K6, PROF_K7, PROF_K8, PROF_KNN, PROF_GNN, PROF_NCLASSES };
 extern unsigned g_csplat_prof_mask;

@@ -2783,6 +2783,10 @@ unsigned csplat_debug_flags_query(void) { return g_debug_flags; }
 // measurement hook: a device buffer that the batched row-form K7 fills with s_memtime stamps (12 u64 per workgroup, launch order
 // [view][workgroup]); NULL switches it off.  Not part of the operator interface.
 int csplat_debug_stamps(void *buf, size_t bytes) { g_stamp_buf = (unsigned long long *)buf; g_stamp_words = bytes / 8; return 0; }
+}  // extern "C"
+// (the stamp buffer for the library's other translation units: nullptr unless one of at least `need_words` words was handed over)
+unsigned long long *csplat_stamp_buffer(size_t need_words) { return (g_stamp_buf && g_stamp_words >= need_words) ? g_stamp_buf : nullptr; }
+extern "C" {
 const char *csplat_last_error(void) { return g_csplat_err; }
 
 size_t csplat_geom_bytes(int P) { size_t off[G_NFIELDS]; return geom_offsets(P, off); }

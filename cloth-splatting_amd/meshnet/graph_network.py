@@ -19,8 +19,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_tail_aggregate, edge_tail_ok, layer_norm_rows, report_missed_edge_tail,
-                        linear128, linear_rows, node_update)
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_mlp3, edge_mlp3_pack, edge_tail_aggregate, edge_tail_ok,
+                        layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
 def build_mlp(input_size: int, hidden_layer_sizes: List[int], output_size: int = None,
@@ -99,6 +99,14 @@ def _fused_tail(seq: nn.Sequential, h: torch.Tensor, add_post: torch.Tensor = No
     return h
 
 
+EDGE_MLP_FUSED = True       # rollout: the edge MLP of a layer as one launch (csplat_gnn_edge_mlp3); False = the three csplat_linear128 calls
+
+
+def _is_pow2(v: float) -> bool:
+    import math
+    return v > 0 and math.frexp(v)[0] == 0.5
+
+
 class InteractionNetwork(nn.Module):
     """graph_network.py:114-222 (PyG MessagePassing, aggr='add')."""
 
@@ -172,6 +180,15 @@ class InteractionNetwork(nn.Module):
             self._wsplit_key = key
         return self._wsplit
 
+    def _edge_image(self, w_e, elins):
+        """the packed LDS image of the edge MLP's three weights, re-packed only when a weight changed"""
+        key = (self._wsplit_key, elins[1].weight._version, elins[2].weight._version, elins[1].weight.data_ptr(), elins[2].weight.data_ptr())
+        if getattr(self, "_eimg_key", None) != key:
+            with torch.no_grad():
+                self._eimg = edge_mlp3_pack(w_e, elins[1].weight, elins[2].weight)
+            self._eimg_key = key
+        return self._eimg
+
     def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None):
         """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd.
         Per layer the [E,128] activations make three read+write passes (one per Linear, with gather / bias / ReLU /
@@ -183,8 +200,15 @@ class InteractionNetwork(nn.Module):
         if xa is None:
             xa = linear128(x, w_i)                               # contribution of x_i = x[edge_index[1]]
             xb = linear128(x, w_j)                               # contribution of x_j = x[edge_index[0]]
-        h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
-        msg = _fused_tail(self.edge_fn, h)
+        elins = list(self.edge_fn[0].children())[0::2]
+        if len(elins) == 3 and EDGE_MLP_FUSED and _is_pow2(scale):
+            # the whole message MLP + LayerNorm in ONE launch: the two inner [E,128] activations never leave the registers
+            # (csplat_gnn_edge_mlp3; the weights' LDS image is packed once per weight version)
+            msg = edge_mlp3(e0, scale, xa, csr.ei[1], xb, csr.ei[0], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,
+                            elins[2].bias, self.edge_fn[1])
+        else:
+            h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
+            msg = _fused_tail(self.edge_fn, h)
         agg = SegmentSum.apply(msg, csr)
         lins = list(self.node_fn[0].children())[0::2]
         if len(lins) == 3:

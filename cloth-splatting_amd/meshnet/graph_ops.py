@@ -357,6 +357,44 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
     return out
 
 
+def edge_mlp3_pack(w0, w1, w2):
+    """the three 128 x 128 weights of an edge MLP as the LDS image csplat_gnn_edge_mlp3 stages (three bf16 pieces per weight, the
+    contraction index of layers 2 and 3 permuted to the register layout the previous layer leaves): pack once per weight version"""
+    img = torch.empty(int(_n.lib.csplat_gnn_edge_mlp3_image_bytes()), dtype=torch.uint8, device=w0.device)
+    ws = []
+    for w in (w0, w1, w2):
+        w = w.detach()
+        assert tuple(w.shape) == (128, 128) and w.dtype == torch.float32 and w.is_cuda
+        if not (w.stride(1) == 1 and w.stride(0) >= 128):
+            w = w.contiguous()
+        ws.append(w)
+    with _n.on_device(w0.device):
+        _n.check(_n.lib.csplat_gnn_edge_mlp3_pack(_n.stream_handle(w0.device), ws[0].data_ptr(), int(ws[0].stride(0)), ws[1].data_ptr(),
+                                                  int(ws[1].stride(0)), ws[2].data_ptr(), int(ws[2].stride(0)), _n.ptr(img)),
+                 "csplat_gnn_edge_mlp3_pack")
+    return img
+
+
+def edge_mlp3(e0, alpha, xa, ia, xb, ib, image, b0, b1, b2, layer_norm, out=None):
+    """Inference-only message of one InteractionNetwork layer in ONE launch (csplat_gnn_edge_mlp3, include/csplat.h):
+        out = LN( W2 relu( W1 relu( alpha * W0 e0 + b0 + xa[ia] + xb[ib] ) + b1 ) + b2 )
+    the two inner [E,128] activations stay in registers (graph_network.py:178-199).  image = edge_mlp3_pack(W0, W1, W2)."""
+    _n.require_cuda(e0)
+    e0, xa, xb = _f32(e0), _f32(xa), _f32(xb)
+    E = e0.shape[0]
+    assert e0.shape[1] == 128 and xa.shape[1] == 128 and xb.shape[1] == 128
+    ia, ib = ia.contiguous(), ib.contiguous()
+    assert ia.dtype == torch.int64 and ib.dtype == torch.int64 and ia.numel() == E and ib.numel() == E
+    out = torch.empty_like(e0) if out is None else out
+    c = lambda t: t.detach().contiguous()  # noqa: E731
+    with _n.on_device(e0.device):
+        _n.check(_n.lib.csplat_gnn_edge_mlp3(_n.stream_handle(e0.device), E, _n.ptr(e0), float(alpha), _n.ptr(xa), _n.ptr(ia), _n.ptr(xb),
+                                             _n.ptr(ib), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b1)), _n.ptr(c(b2)),
+                                             _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps), _n.ptr(out)),
+                 "csplat_gnn_edge_mlp3")
+    return out
+
+
 def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w_j_next=None):
     """Inference-only node update of one InteractionNetwork layer in ONE launch (csplat_gnn_node_update, include/csplat.h):
         x_new = LN(W3 relu(W2 relu(Wa agg + Wx x + b0) + b2) + b3) + x,   xa' = x_new Wi'^T,   xb' = x_new Wj'^T

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CSPLAT_ABI_VERSION 3   /* round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask) */
+#define CSPLAT_ABI_VERSION 4   /* round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2, csplat_gnn_edge_mlp3* */
 
 /* scratch chunks requested through the allocator callback */
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
@@ -494,6 +494,20 @@ int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W,
                         float alpha, int relu, const float *gather_a, const int64_t *index_a, const float *gather_b,
                         const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
                         const float *add_pre, const float *add_post, const float *mask, float *ln_stats, float *out);
+
+/* The WHOLE edge MLP of an InteractionNetwork layer in one launch (inference; csplat_edge_mlp.hip) -- replaces the three csplat_linear128
+ * calls of rounds 1-4 for /root/reference/meshnet/graph_network.py:178-199 (`message`: LN(MLP(cat[x_i, x_j, e]))):
+ *     out[e] = LayerNorm( W2 relu( W1 relu( alpha * W0 e0[e] + b0 + xa[index_a[e]] + xb[index_b[e]] ) + b1 ) + b2 ) * gamma + beta
+ * e0 / out [E][128] fp32 (out != e0), xa / xb [N][128] (the node-level x_i / x_j column-block products of the first Linear), index_a /
+ * index_b int64 [E], alpha a power of two (the edge scale 2^l of SURVEY F7).  `image` = the three weight matrices as
+ * csplat_gnn_edge_mlp3_pack lays them out (csplat_gnn_edge_mlp3_image_bytes() bytes of device memory, 16-byte aligned): per layer the
+ * three bf16 pieces of W (fp32-level accuracy on the bf16 matrix cores, as csplat_linear128_mode 1) in the byte order the kernel copies
+ * into LDS.  Pack once per weight version: W_l is read as W_l[j * ld_l + k] (a Linear.weight or a 128-column slice of a wider one). */
+size_t csplat_gnn_edge_mlp3_image_bytes(void);
+int csplat_gnn_edge_mlp3_pack(void *stream, const float *W0, int ld0, const float *W1, int ld1, const float *W2, int ld2, void *image);
+int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, float alpha, const float *xa, const int64_t *index_a, const float *xb,
+                         const int64_t *index_b, const void *image, const float *b0, const float *b1, const float *b2,
+                         const float *ln_gamma, const float *ln_beta, float ln_eps, float *out);
 
 /* The per-step activations of the Gaussian parameters as render() consumes them (/root/reference/scene_reconstruction/
  * gaussian_model.py:96-121 via gaussian_renderer/__init__.py:92-118): opacity[P] = sigmoid(opacity_raw), scales[P][3] = exp(scaling_raw),

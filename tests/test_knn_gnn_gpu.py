@@ -769,3 +769,58 @@ def test_sim_hidden_layers_match_composed_torch_fwd_bwd(T):
     (y1 * wy).sum().backward()
     for a, b in zip([p_.grad for p_ in params] + [base.grad], two):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("E", [1, 31, 257, 4100, 70_001])       # ragged: the last 32-row tile and the last 256-row round are partial
+@pytest.mark.parametrize("alpha", [1.0, 8.0, 16384.0])           # 2^l, l = 0 .. 14 on the 15-layer network
+def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha):
+    """csplat_gnn_edge_mlp3 (the whole message MLP of an InteractionNetwork layer in one launch: gathers + three 128 x 128 layers +
+    LayerNorm, inner activations in registers; /root/reference/meshnet/graph_network.py:178-199) against the fp64 composition
+    (1e-5 of the output scale -- the bar of csplat_linear128) and against the three csplat_linear128 launches it replaces (same
+    products on the same matrix cores in another order: 1e-5).  e0 is scaled so that alpha * e0 stays O(1), as the network's
+    LayerNorm'd edge latents do."""
+    from meshnet.graph_ops import edge_mlp3, edge_mlp3_pack, linear128
+    gen = torch.Generator().manual_seed(E + int(alpha))
+    Nn = 91
+    e0 = (torch.randn(E, 128, generator=gen) / alpha).cuda()
+    W = [(torch.randn(128, 128, generator=gen) * 0.12).cuda() for _ in range(3)]
+    b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+    xa, xb = torch.randn(Nn, 128, generator=gen).cuda(), torch.randn(Nn, 128, generator=gen).cuda()
+    ia, ib = torch.randint(0, Nn, (E,), generator=gen).cuda(), torch.randint(0, Nn, (E,), generator=gen).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    wide = torch.randn(128, 384, generator=gen).cuda() * 0.12         # W0 as a column slice of the wider first-layer weight (ld = 384)
+    W0 = wide[:, 256:]
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(128, generator=gen)); norm.bias.copy_(torch.randn(128, generator=gen))
+        img = edge_mlp3_pack(W0, W[1], W[2])
+        out = edge_mlp3(e0, alpha, xa, ia, xb, ib, img, b[0], b[1], b[2], norm)
+        h = (alpha * (e0.double() @ W0.double().t()) + b[0].double() + xa.double()[ia] + xb.double()[ib]).relu()
+        h = (h @ W[1].double().t() + b[1].double()).relu()
+        h = h @ W[2].double().t() + b[2].double()
+        ref = torch.nn.functional.layer_norm(h, (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+        t = linear128(e0, W0, b[0], alpha=alpha, relu=True, gather=(xa, ia, xb, ib))
+        t = linear128(t, W[1], b[1], relu=True)
+        three = linear128(t, W[2], b[2], layer_norm=norm)
+    assert out.shape == (E, 128) and torch.isfinite(out).all()
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert rel_err(out.cpu().numpy(), three.cpu().numpy()) < 1e-5
+
+
+def test_rollout_with_and_without_the_fused_edge_mlp():
+    """EncodeProcessDecode under no_grad with the one-launch edge MLP (default) and with the three launches of rounds 1-4
+    (graph_network.EDGE_MLP_FUSED = False): the same network output to 1e-5, on a graph whose edge count is not a multiple of 256."""
+    import meshnet.graph_network as gn
+    torch.manual_seed(9)
+    net = gn.EncodeProcessDecode(8, 3, 4, 128, 5, 2, 128).cuda()
+    gen = torch.Generator().manual_seed(12)
+    N, E = 900, 20_011
+    ei = torch.randint(0, N, (2, E), generator=gen).cuda()
+    x, e = torch.randn(N, 8, generator=gen).cuda(), torch.randn(E, 4, generator=gen).cuda()
+    try:
+        with torch.no_grad():
+            y1 = net(x, ei, e)
+            gn.EDGE_MLP_FUSED = False
+            y0 = net(x, ei, e)
+    finally:
+        gn.EDGE_MLP_FUSED = True
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where a wave of csplat_gnn_edge_mlp3 spends a round: s_memtime stamps left by wave 0 of every workgroup at the phase boundaries
+(csplat_debug_stamps).  GPU box: python3 tools/edge_mlp3_stamps.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
+from csplat import native  # noqa: E402
+from meshnet.graph_ops import edge_mlp3, edge_mlp3_pack  # noqa: E402
+
+E, N = 300_000, 10_000
+gen = torch.Generator().manual_seed(0)
+e0 = torch.randn(E, 128, generator=gen).cuda()
+W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(3)]
+b = [torch.randn(128, generator=gen).cuda() for _ in range(3)]
+xa, xb = torch.randn(N, 128, generator=gen).cuda(), torch.randn(N, 128, generator=gen).cuda()
+dst = torch.arange(N).repeat_interleave(E // N)[:E]
+src = (dst + torch.randint(-60, 60, (E,), generator=gen)).clamp(0, N - 1)
+perm = torch.argsort(src * N + dst)
+ia, ib = dst[perm].cuda(), src[perm].cuda()
+norm = torch.nn.LayerNorm(128).cuda()
+img = edge_mlp3_pack(*W)
+out = torch.empty_like(e0)
+buf = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
+with torch.no_grad():
+    for _ in range(3):
+        edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out)
+    torch.cuda.synchronize()
+    native.lib.csplat_debug_stamps(buf.data_ptr(), buf.numel() * 8)
+    edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out)
+    torch.cuda.synchronize()
+    native.lib.csplat_debug_stamps(None, 0)
+s = buf.cpu().numpy().reshape(256, 64).astype(np.int64)
+names = ["gathers (+ first round: rows) via scratch -> registers", "barrier + image-1 DMA -> landed", "layer-1 products + ReLU (wave 0)",
+         "barrier: the other waves' layer-1 products", "image-2 DMA -> landed + barrier", "layer-2 products + ReLU (wave 0)", "barrier: the others",
+         "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)", "LayerNorm + barrier: the others", "rows out via scratch",
+         "(next round's start)"]
+NS = 13       # stamps per round incl. the next round's first
+for r in range(3):
+    seg = s[:, (NS - 1) * r:(NS - 1) * r + NS]
+    ok = (seg > 0).all(1)
+    d = np.diff(seg[ok], axis=1)
+    print(f"round {r}: {int(ok.sum())} workgroups, total {d[:, :NS - 1].sum(1).mean():.0f} cycles")
+    for k in range(NS - 1):
+        print(f"    {names[k]:48s} mean {d[:, k].mean():8.0f}  median {np.median(d[:, k]):8.0f}  p90 {np.percentile(d[:, k], 90):8.0f}")
