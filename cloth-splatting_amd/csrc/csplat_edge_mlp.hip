@@ -21,10 +21,22 @@
 // kernel wants in LDS (rows padded to 272 B: conflict-free 16-byte operand reads), 104,448 B per layer.
 // What sank round 2's attempt at this kernel ("k_edge_mlp3": 349 us against 253-276 for three launches) was
 // re-staging: cutting fp32 weights into bf16 pieces 3 x per round cost 17 k cycles per layer.  With the image pre-cut, re-staging a
-// layer is a straight 102 KiB copy L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 13 wave-instructions per wave, no VGPRs, ~2.5 k
-// cycles) between two barriers; the next round's edge rows are requested under layer 3's MFMAs.
-// Layer 1's gathers and bias are loaded straight into the accumulators (alpha is a power of two: start at (b0 + xa + xb) / alpha and
-// scale the finished sum); LayerNorm statistics cross the lane pair (n, 0) / (n, 1) with one v_permlane32_swap each.
+// layer is a straight 102 KiB copy L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 13 wave-instructions per wave, no VGPRs, ~5 k
+// cycles with its two barriers); the next round's edge rows are fetched into the registers layer 3's steps free.
+// Layout changes (gathered node rows -> lane = edge, finished rows -> whole rows for the stores) are done by the matrix cores
+// themselves (identity / selection B operands), so every global access moves whole rows: no LDS scratch, no per-lane row accesses.
+//
+// MEASURED (round 5, E = 300k, tools/bench_edge_mlp3.py / edge_mlp3_stamps.py / ab_edge_mlp3_rollout.py): parity-green at the first
+// run of every version, and NOT faster than the three launches -- 225-270 us against 235-255 us per layer, rollout 6.07 against 5.68 ms
+// per step -- so graph_network.EDGE_MLP_FUSED is off by default.  Why, from in-kernel stamps: a round (256 rows) takes ~104 k cycles of
+// which the three layers' MFMAs are 37 k: one image in LDS forces the workgroup's 8 waves through the layers in LOCKSTEP (6 barriers
+// per round), at 2 waves per SIMD (220 VGPRs) nothing else is resident to fill the gaps, and so every latency is paid in full -- the
+// image copies (3 x ~5 k), the barrier skew behind the slower wave of each SIMD (3 x ~5 k), the index -> gather -> cut -> MFMA chains
+// of the next round's inputs (~15 k), the LayerNorm / transposition / store issue tail (~25 k).  The three separate launches run 16
+// waves per CU out of phase and hide all of it behind 3 x the HBM traffic.  Starting the workgroups staggered changes nothing (the
+// phases are not chip-wide bursts on a shared resource).  What would change it: ONE wave per SIMD carrying two 32-row tiles through
+// the layers with their memory and MFMA phases interleaved by hand (512 VGPRs: both tiles' rows and accumulators fit, each weight
+// operand read serves two MFMAs), i.e. a software-pipelined rewrite of the schedule, not of the data path.
 #include "csplat_common.h"
 #include <stdlib.h>
 
@@ -40,8 +52,7 @@ constexpr size_t EM_LAYER_BYTES = (size_t)3 * EM_PIECE * 2;      // 104,448 = 10
 constexpr int EM_CHUNKS = (int)(EM_LAYER_BYTES / 1024);          // 1 KiB LDS-DMA pieces per layer
 static_assert(EM_LAYER_BYTES % 1024 == 0, "the layer image is copied in whole 1 KiB wave-instructions");
 constexpr int EM_WAVES = 8, EM_ROWS = 32 * EM_WAVES;             // rows per round
-constexpr int EM_SCR = 32 * EM_N * 4;                            // a wave's transposition scratch: its 32 x 128 fp32 tile
-constexpr size_t EM_LDS_BYTES = (size_t)EM_WAVES * EM_SCR > EM_LAYER_BYTES ? (size_t)EM_WAVES * EM_SCR : EM_LAYER_BYTES;
+constexpr size_t EM_LDS_BYTES = EM_LAYER_BYTES;
 
 // position pos = 64h + 8st + i of an image row (the element lane-half h feeds into step st as operand element i) <-> source column
 __host__ __device__ inline int em_src_col(int layer, int pos) {
@@ -64,14 +75,6 @@ __global__ __launch_bounds__(EM_STRIDE) void k_edge_mlp3_pack(const float *__res
     row[0] = p1; row[EM_PIECE] = p2; row[2 * EM_PIECE] = p3;
 }
 
-// a ^ b formed where it is written: a volatile statement is not hoisted out of the round loop (the compiler otherwise precomputes the ~100
-// round-invariant lane addresses of the transposition scratch and spills them all)
-__device__ __forceinline__ int xor_here(int a, int b) {
-    int r;
-    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 __device__ __forceinline__ float pair_sum(float v) {      // v of lane (n, 0) + v of lane (n, 1), in both lanes
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
     return __int_as_float(sw[0]) + __int_as_float(sw[1]);
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(64 * EM_WAVES) void k_edge_mlp3(int64_t M, const fl
                                                              const float *__restrict__ b1, const float *__restrict__ b2,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                              float *__restrict__ out, int dbg, unsigned long long *__restrict__ stamps) {
-    extern __shared__ char s_img[];       // ONE LDS object: the current layer's image, or (between rounds) the waves' transposition scratch
+    extern __shared__ char s_img[];       // ONE LDS object: the current layer's image
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     const int64_t nround = (M + EM_ROWS - 1) / EM_ROWS;
-    int zs = 0, zv = 0, r32v = r32, lanev = lane, hv = h;      // (opaque zeros and the lane ids formed with them per round, see the round loop)
+    int zs = 0, zv = 0, r32v = r32, hv = h;      // (opaque zeros and the lane ids formed with them per round, see the round loop)
     // (measurement hook, csplat_debug_stamps / tools/edge_mlp3_stamps.py: wave 0 leaves s_memtime at the phase boundaries of its first rounds)
     int stamp_at = 0;
     auto stamp = [&]() {
@@ -176,90 +179,95 @@ __global__ __launch_bounds__(64 * EM_WAVES) void k_edge_mlp3(int64_t M, const fl
             acc[g >> 2][4 * (g & 3)] = t.x; acc[g >> 2][4 * (g & 3) + 1] = t.y; acc[g >> 2][4 * (g & 3) + 2] = t.z; acc[g >> 2][4 * (g & 3) + 3] = t.w;
         }
     };
-    // ---- the wave's 16 KB transposition scratch (its slice of the LDS the images occupy during the layers; used only between a round's
-    // last products and the next round's first image copy).  Global memory is touched in whole rows -- an instruction moves tile rows
-    // 2i and 2i + 1, lane (r32, h) the 16 bytes at granule r32 of row 2i + h: 8 cache lines per instruction -- while the MFMA operands
-    // want lane = row: a lane that reads its own row's 16 bytes touches 64 lines per instruction, and the texture-address unit prices a
-    // memory instruction per line (measured, tools/edge_mlp3_stamps.py: the gathers, row loads and row stores of the first version took
-    // 52 k of a round's 131 k cycles).  Logical granule g (4 floats) of tile row n lives at physical granule g ^ n of the row: both
-    // access patterns are then conflict-free (16 lanes of an LDS lane group = 16 distinct n mod 16, or 16 distinct granules of one row).
-    char *scr = s_img + w * EM_SCR;
-    auto scr_at = [&](int g) { return reinterpret_cast<float4 *>(scr + ((r32v * 32 + xor_here(g, r32v)) << 4)); };      // lane = row view
-    // rows -> scratch by LDS-DMA; grow(i) = the global row this lane's half of instruction i reads (tile row 2i + h)
-    auto dma_rows = [&](const float *__restrict__ base, auto grow) __attribute__((always_inline)) {
+    // ---- layout changes by MFMA.  Global memory wants whole rows per instruction (lanes along a row: 2 cache lines per half-wave load),
+    // the chained layers want lane = edge row (a lane reading its own row's 16 bytes touches 64 lines per instruction, and the
+    // texture-address unit prices a memory instruction per line: the gathers, row loads and row stores of the first version took 52 k of a
+    // round's 131 k cycles; a transposition through LDS took as long -- tools/edge_mlp3_stamps.py).  The matrix core transposes for free:
+    //   gathers   acc[c] (features x edges) += S^T (features x 16 edges, A operand: lane (m, h) element i = S[idx[16kb + 8h + i]][32c + m],
+    //             a coalesced dword load per element) x I (16 edges x 32 edges: B operand = the identity block kb)
+    //   rows out  O[c] (edges x features) = V (edges x 16 features, A operand = the lane's own finished values, registers 8t .. 8t + 7 of
+    //             tile c) x P (16 x 32 selection: feature 32c + j <- the (h, i) that holds it)
+    // each with the fp32 operand cut into three bf16 pieces (times exact ones: no rounding beyond the fp32 accumulation).
+    auto cut3 = [&](const float (&x)[8], bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int trow = 2 * i + hv;
-            const float *src = base + (int64_t)grow(i) * EM_N + 4 * xor_here(trow, r32v);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(scr + i * 1024), 16, 0, 0);
+        for (int j = 0; j < 8; j++) {
+            a1[j] = (__bf16)x[j];
+            const float r1 = x[j] - (float)a1[j];
+            a2[j] = (__bf16)r1;
+            a3[j] = (__bf16)(r1 - (float)a2[j]);
         }
+    };
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto ones_where = [&](auto pred) __attribute__((always_inline)) {      // bf16x8 with 1.0 where pred(i)
+        s16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = pred(i) ? (short)0x3F80 : (short)0;
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto gather_add = [&](const float *__restrict__ S, int idx, f32x16 (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            const bf16x8 eye = ones_where([&](int i) { return r32v == 16 * kb + 8 * hv + i; });
+            float v[4][8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int lo = __builtin_amdgcn_readlane(idx, 16 * kb + i), hi = __builtin_amdgcn_readlane(idx, 16 * kb + 8 + i);
+                const float *p = S + (size_t)(hv ? hi : lo) * EM_N + r32v;
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c][i] = p[32 * c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = v[c][i] * inv_alpha;
+                bf16x8 a1, a2, a3;
+                cut3(x, a1, a2, a3);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, eye, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, eye, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, eye, acc[c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // a round's layer-1 accumulators: (b0 + xa[dst] + xb[src]) / alpha
+    auto load_inputs = [&](int64_t round, f32x16 (&acc)[4]) __attribute__((always_inline)) {
+        const int64_t row = (round * EM_WAVES + w) * 32 + r32v;
+        const int64_t crow = row < M ? row : M - 1;                             // rows past M: clamped loads, masked stores
+        const int ja = (int)ia[crow], jb = (int)ib[crow];
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const float4 t = *reinterpret_cast<const float4 *>(b0 + zs + col_of(g));
+            const int c = g >> 2, r = 4 * (g & 3);
+            acc[c][r] = t.x * inv_alpha; acc[c][r + 1] = t.y * inv_alpha; acc[c][r + 2] = t.z * inv_alpha; acc[c][r + 3] = t.w * inv_alpha;
+        }
+        gather_add(xa, ja, acc);
+        gather_add(xb, jb, acc);
     };
 
     float X[64];                              // the lane's contraction values of the coming layer
-    bool have_x = false;
     f32x16 acc[4];
-    // a round's inputs: the 32 edge rows of the wave (-> X), and the layer-1 accumulators' start (b0 + xa[dst] + xb[src]) / alpha
-    auto load_inputs = [&](int64_t round) __attribute__((always_inline)) {
-        const int64_t base_row = (round * EM_WAVES + w) * 32;
-        const int64_t row = base_row + r32 < M ? base_row + r32 : M - 1;       // rows past M: clamped loads, masked stores
-        const int ja = (int)ia[row], jb = (int)ib[row];
-        if (!have_x) {                        // (first round of the workgroup; later rounds find X prefetched under the previous round's layer 3)
-            dma_rows(e0, [&](int i) { const int64_t r = base_row + 2 * i + hv; return r < M ? r : M - 1; });
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // the workgroup's first round: its rows straight into registers (lane = row: 64 lines per instruction, once), its gathers
+        const int64_t row = ((int64_t)blockIdx.x * EM_WAVES + w) * 32 + r32;
+        const float4 *ap = reinterpret_cast<const float4 *>(e0 + (row < M ? row : M - 1) * EM_N + 64 * h);
 #pragma unroll
-            for (int q = 0; q < 16; q++) { const float4 t = *scr_at(16 * hv + q); X[4 * q] = t.x; X[4 * q + 1] = t.y; X[4 * q + 2] = t.z; X[4 * q + 3] = t.w; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        // the x_i block's rows: destination nodes, scattered -> through the scratch as whole rows
-        dma_rows(xa, [&](int i) { const int lo = __builtin_amdgcn_readlane(ja, 2 * i), hi = __builtin_amdgcn_readlane(ja, 2 * i + 1); return hv ? hi : lo; });
-        // bias + the x_j block's rows, straight into registers: with the edge list in PyG's coalesced (source-major) order the 32 rows of a
-        // tile share 1-3 source nodes, i.e. 1-3 cache lines per instruction (any other order is as correct and slower)
-        {   // (four batches of four column groups: 8 float4 in flight each -- all 32 at once would cost 128 registers beside X and acc)
-            const float *pb = xb + (size_t)jb * EM_N;
-#pragma unroll
-            for (int bq = 0; bq < 4; bq++) {
-                float4 tb[4], tc[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    tb[u] = *reinterpret_cast<const float4 *>(b0 + zs + col_of(4 * bq + u));
-                    tc[u] = *reinterpret_cast<const float4 *>(pb + col_of(4 * bq + u));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    acc[bq][4 * u] = (tb[u].x + tc[u].x) * inv_alpha; acc[bq][4 * u + 1] = (tb[u].y + tc[u].y) * inv_alpha;
-                    acc[bq][4 * u + 2] = (tb[u].z + tc[u].z) * inv_alpha; acc[bq][4 * u + 3] = (tb[u].w + tc[u].w) * inv_alpha;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const float4 t = *scr_at(8 * (g >> 2) + 2 * (g & 3) + hv);
-            const int c = g >> 2, r = 4 * (g & 3);
-            acc[c][r] += t.x * inv_alpha; acc[c][r + 1] += t.y * inv_alpha; acc[c][r + 2] += t.z * inv_alpha; acc[c][r + 3] += t.w * inv_alpha;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-
+        for (int q = 0; q < 16; q++) { const float4 t = ap[q]; X[4 * q] = t.x; X[4 * q + 1] = t.y; X[4 * q + 2] = t.z; X[4 * q + 3] = t.w; }
+        stage(0);                             // (before the gathers: their waits then cover it -- vmcnt counts in order)
+        if (blockIdx.x < nround) load_inputs(blockIdx.x, acc);
+    }
     for (int64_t round = blockIdx.x; round < nround; round += gridDim.x) {
         // opaque zeros, renewed per round: everything addressed through them stays INSIDE the loop.  Left alone, the compiler hoists the
-        // round-invariant loads (bias, gamma, beta: 80 float4) and the ~100 per-lane addresses out of the loop and spills them all
+        // round-invariant loads (bias, gamma, beta) and per-lane addresses out of the loop and spills them all
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
-        r32v = r32 + zv; lanev = lane + zv; hv = h + zv;
-        stamp();                              // 0: round start
-        load_inputs(round);                   // (the scratch is free: first round, or the previous round's stores have read it back)
-        stamp();                              // 1: inputs in registers
+        r32v = r32 + zv; hv = h + zv;
+        stamp();                              // 0: round start -- X, the layer-1 accumulators' start and the image-1 DMA are under way
         // ---------------- layer 1: alpha * We e0 + b0 + xa[dst] + xb[src], ReLU
-        __syncthreads();                      // (every wave is done with its scratch: the image may land)
-        stage(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(63)" ::: "memory");      // (everything but the previous round's 64 row stores, the youngest, has landed)
         __syncthreads();                      // (every wave's share of the image has landed)
-        stamp();                              // 2: layer-1 image in
+        stamp();                              // 1: layer-1 image in
         products(X, acc, nullptr);
-        stamp();                              // (layer-1 products done)
+        stamp();                              // 2: layer-1 products done (this wave)
 #pragma unroll
         for (int k = 0; k < 64; k++) X[k] = fmaxf(alpha * acc[k >> 4][k & 15], 0.f);
         // ---------------- layer 2
@@ -291,7 +299,6 @@ __global__ __launch_bounds__(64 * EM_WAVES) void k_edge_mlp3(int64_t M, const fl
             products(X, acc, ap);             // (the last round re-reads a clamped row for nothing: no second copy of the loop)
         }
         stamp();                              // 8
-        have_x = more;
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < 64; k++) sum += acc[k >> 4][k & 15];
@@ -300,27 +307,46 @@ __global__ __launch_bounds__(64 * EM_WAVES) void k_edge_mlp3(int64_t M, const fl
 #pragma unroll
         for (int k = 0; k < 64; k++) { const float d = acc[k >> 4][k & 15] - mean; acc[k >> 4][k & 15] = d; sq += d * d; }
         const float rstd = rsqrtf(pair_sum(sq) * (1.f / EM_N) + eps);
-        __syncthreads();                      // (every wave is done with the layer-3 image: the scratch may be written)
-        stamp();                              // 9: every wave's layer-3 products + LayerNorm sums done
+        // edges x features: O[c][r] = the normalised value of edge (r & 3) + 8 (r >> 2) + 4h, feature 32c + r32
+        f32x16 O[4];
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int col = col_of(g);
-            const float4 ga = *reinterpret_cast<const float4 *>(gamma + zs + col), be = *reinterpret_cast<const float4 *>(beta + zs + col);
-            const int c = g >> 2, r = 4 * (g & 3);
-            *scr_at(8 * c + 2 * (g & 3) + hv) = make_float4(acc[c][r] * rstd * ga.x + be.x, acc[c][r + 1] * rstd * ga.y + be.y,
-                                                           acc[c][r + 2] * rstd * ga.z + be.z, acc[c][r + 3] * rstd * ga.w + be.w);
-        }
-        {   // whole rows back out: instruction i stores tile rows 2i, 2i + 1
-            const int64_t base_row = (round * EM_WAVES + w) * 32;
+        for (int c = 0; c < 4; c++) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int trow = 2 * i + hv;
-                const float4 v = *reinterpret_cast<const float4 *>(scr + i * 1024 + lanev * 16);
-                if (base_row + trow < M) *reinterpret_cast<float4 *>(out + (base_row + trow) * EM_N + 4 * xor_here(trow, r32v)) = v;
+            for (int r = 0; r < 16; r++) O[c][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const bf16x8 pick = ones_where([&](int i) { return r32v == 16 * t + 8 * (i >> 2) + 4 * hv + (i & 3); });
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = acc[c][8 * t + i] * rstd;
+                bf16x8 a1, a2, a3;
+                cut3(x, a1, a2, a3);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, pick, O[c], 0, 0, 0);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, pick, O[c], 0, 0, 0);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pick, O[c], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp();                              // 10: rows out issued
+        __syncthreads();                      // (every wave is done with the layer-3 image: the next round's first image may land)
+        stamp();                              // 9
+        if (more) {
+            stage(0);
+            load_inputs(round + gridDim.x, acc);
+        }
+        stamp();                              // 10: next round's inputs requested and in
+        {   // whole rows out, LAST: the stores are the youngest memory operations of the wave, so nothing the next round waits for queues
+            // behind their drain to HBM (vmcnt counts in order)
+            const int64_t base_row = (round * EM_WAVES + w) * 32;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float ga = gamma[zs + 32 * c + r32v], be = beta[zs + 32 * c + r32v];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int64_t orow = base_row + (r & 3) + 8 * (r >> 2) + 4 * hv;
+                    if (orow < M) out[orow * EM_N + 32 * c + r32v] = O[c][r] * ga + be;
+                }
+            }
+        }
+        stamp();                              // 11: rows out issued
     }
 }
 
@@ -354,7 +380,7 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
         s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EM_LDS_BYTES) == hipSuccess;
         (void)hipGetLastError();
     }
-    CSPLAT_REQUIRE(s_ok, "csplat_gnn_edge_mlp3: 128 KB of dynamic LDS refused by the runtime");
+    CSPLAT_REQUIRE(s_ok, "csplat_gnn_edge_mlp3: 102 KB of dynamic LDS refused by the runtime");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_GNN, s);
     const int64_t nround = (E + EM_ROWS - 1) / EM_ROWS;

@@ -14,6 +14,7 @@ adds them (+ReLU) in one HBM pass.  The scatter-add is csplat_gnn_segment_sum ov
 (deterministic).  The node MLP's cat[agg, x] is likewise split.  Node-level y and dx GEMMs stay on rocBLAS; every 128 x 128
 weight gradient (edge AND node level) is csplat_dw128.
 """
+import os
 from typing import List
 
 import torch
@@ -99,7 +100,9 @@ def _fused_tail(seq: nn.Sequential, h: torch.Tensor, add_post: torch.Tensor = No
     return h
 
 
-EDGE_MLP_FUSED = True       # rollout: the edge MLP of a layer as one launch (csplat_gnn_edge_mlp3); False = the three csplat_linear128 calls
+# rollout: the edge MLP of a layer as ONE launch (csplat_gnn_edge_mlp3) instead of three csplat_linear128 calls.  Off by default: parity-green and
+# measured SLOWER in round 5 (6.07 against 5.68 ms per rollout step; why: header of csrc/csplat_edge_mlp.hip).  env CSPLAT_GNN_EDGE_FUSED=1 turns it on.
+EDGE_MLP_FUSED = os.environ.get("CSPLAT_GNN_EDGE_FUSED", "0") not in ("", "0")
 
 
 def _is_pow2(v: float) -> bool:

@@ -807,8 +807,9 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha):
 
 
 def test_rollout_with_and_without_the_fused_edge_mlp():
-    """EncodeProcessDecode under no_grad with the one-launch edge MLP (default) and with the three launches of rounds 1-4
-    (graph_network.EDGE_MLP_FUSED = False): the same network output to 1e-5, on a graph whose edge count is not a multiple of 256."""
+    """EncodeProcessDecode under no_grad with the one-launch edge MLP (graph_network.EDGE_MLP_FUSED = True; opt-in, it is not faster) and
+    with the three launches of rounds 1-4 (the default): the same network output to 1e-5, on a graph whose edge count is not a multiple
+    of 256."""
     import meshnet.graph_network as gn
     torch.manual_seed(9)
     net = gn.EncodeProcessDecode(8, 3, 4, 128, 5, 2, 128).cuda()
@@ -816,11 +817,13 @@ def test_rollout_with_and_without_the_fused_edge_mlp():
     N, E = 900, 20_011
     ei = torch.randint(0, N, (2, E), generator=gen).cuda()
     x, e = torch.randn(N, 8, generator=gen).cuda(), torch.randn(E, 4, generator=gen).cuda()
+    was = gn.EDGE_MLP_FUSED
     try:
         with torch.no_grad():
+            gn.EDGE_MLP_FUSED = True
             y1 = net(x, ei, e)
             gn.EDGE_MLP_FUSED = False
             y0 = net(x, ei, e)
     finally:
-        gn.EDGE_MLP_FUSED = True
+        gn.EDGE_MLP_FUSED = was
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5

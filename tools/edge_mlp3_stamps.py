@@ -35,10 +35,9 @@ with torch.no_grad():
     torch.cuda.synchronize()
     native.lib.csplat_debug_stamps(None, 0)
 s = buf.cpu().numpy().reshape(256, 64).astype(np.int64)
-names = ["gathers (+ first round: rows) via scratch -> registers", "barrier + image-1 DMA -> landed", "layer-1 products + ReLU (wave 0)",
-         "barrier: the other waves' layer-1 products", "image-2 DMA -> landed + barrier", "layer-2 products + ReLU (wave 0)", "barrier: the others",
-         "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)", "LayerNorm + barrier: the others", "rows out via scratch",
-         "(next round's start)"]
+names = ["wait: image-1 + barrier", "layer-1 products (wave 0)", "ReLU + barrier: the other waves", "image-2 DMA -> landed + barrier",
+         "layer-2 products (wave 0)", "ReLU + barrier: the others", "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)",
+         "LayerNorm, rows x features by MFMA, barrier", "image-1 DMA issued, next round's gathers by MFMA", "rows out issued", "(next round's start)"]
 NS = 13       # stamps per round incl. the next round's first
 for r in range(3):
     seg = s[:, (NS - 1) * r:(NS - 1) * r + NS]
