@@ -319,15 +319,19 @@ def main():
         # K7's HIP-event bracket: a kernel launched by a graph node cannot be bracketed by timeable events on this ROCm (external
         # event-record nodes: hipEventElapsedTime refuses them), so the SAME K steps run once more launch by launch, straight behind the
         # timed replays, with the event pair around every K7 launch -- same kernel, same launch geometry, same inputs; the rocprofv3
-        # trace of this command holds both populations under one kernel name.  The pass is timed too: `eager_ms_per_step`.
-        if events_on:
-            native.prof_enable(["K7_render_bwd"])
-        native.prof_read("K7_render_bwd")
+        # trace of this command holds both populations under one kernel name.  Before it, the same K steps launched eagerly WITHOUT brackets are
+        # timed: `eager_ms_per_step`.
         sync(); t_e = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
         eager_ms_per_step = (time.perf_counter() - t_e) / args.steps * 1e3
+        if events_on:
+            native.prof_enable(["K7_render_bwd"])
+        native.prof_read("K7_render_bwd")
+        for _ in range(args.steps):
+            step()
+        sync()
     k7_ms, k7_n = native.prof_read("K7_render_bwd")
     native.prof_enable([])
 
@@ -348,14 +352,15 @@ def main():
     if args.view_streams and V > 1 and wl is not None:
         args.view_streams = False
         step(); step(); torch.cuda.synchronize()
-        native.prof_enable(["K7_render_bwd"]); native.prof_read("K7_render_bwd")
         # the reference's own call pattern (scene_reconstruction/train_utils.py:259-292): GaussianRasterizer(...) once per camera, one
-        # loss over the images, ONE backward -- timed over the same K steps
+        # loss over the images, ONE backward -- timed over the same K steps, no event brackets inside (they cost host time per launch)
         sync(); t_c = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
         per_camera_ms_per_step = (time.perf_counter() - t_c) / args.steps * 1e3
+        native.prof_enable(["K7_render_bwd"]); native.prof_read("K7_render_bwd")
+        step(); step(); torch.cuda.synchronize()
         ms_a, n_a = native.prof_read("K7_render_bwd")
         native.prof_enable([])
         args.view_streams = True

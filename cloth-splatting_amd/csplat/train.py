@@ -72,8 +72,9 @@ _n.TICKET_CACHES.append(_L1_SCRATCH)
 
 
 def _l1_scratch(device):
-    """partial sums + ticket counter of csplat_l1 for the CURRENT stream of `device`: zeroed once -- the kernel's last workgroup
-    leaves the ticket at zero again, and launches on one stream cannot overlap -- instead of a fill launch per loss"""
+    """workgroup partial sums of csplat_l1 for the CURRENT stream of `device` (launches on one stream cannot overlap): one buffer per
+    stream instead of an allocation per loss.  (Rounds 1-4 kept a ticket counter here too; since round 5 a second one-workgroup launch sums
+    the partials -- the ticket's device-scope release cost ~10 us of L2 write-back per call, csrc/csplat_image.hip.)"""
     key = (str(device), _n.scratch_stream(device))
     buf = _L1_SCRATCH.get(key)
     if buf is None:

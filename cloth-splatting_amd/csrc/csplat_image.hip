@@ -365,14 +365,12 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_bwd(int H, int W, T
 // ---- fused L1 loss: mean |a - b| and its gradient sign(a - b) / n in ONE pass (utils/loss_utils.py:20-23 is three
 // elementwise launches forward and three backward).  Deterministic: workgroup partials are summed in index order by
 // whichever workgroup finishes last (ticket counter), not with float atomics.
-constexpr int L1_BLOCKS = 256, L1_THREADS = 1024;  // few, fat workgroups: the ticket atomics serialise at one L2 address (~30 ns each; 1024 x 256 measured 2x slower)
+constexpr int L1_BLOCKS = 256, L1_THREADS = 1024;  // one fat workgroup per CU; their partials are summed by k_l1_finish
 __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
-                                                    float inv_n, float *__restrict__ partial, unsigned *__restrict__ ticket,
-                                                    float *__restrict__ loss, float *__restrict__ grad,
+                                                    float inv_n, float *__restrict__ partial, float *__restrict__ grad,
                                                     const float *__restrict__ mask, int64_t hw, int channels, int mask_channels,
                                                     signed char *__restrict__ sign8) {
     __shared__ float s_red[L1_THREADS / 64];
-    __shared__ bool s_last;
     float acc = 0.f;
     auto sg = [&](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
     auto s8 = [&](float d) { return (signed char)(d > 0.f ? 1 : (d < 0.f ? -1 : 0)); };   // the backward's input when the caller asks for 1 byte per element
@@ -427,22 +425,24 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(int64_t n, const float *__res
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        { float t_ = 0.f; for (int k_ = 0; k_ < L1_THREADS / 64; k_++) t_ += s_red[k_]; partial[blockIdx.x] = t_; }
-        __threadfence();
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
+    // one partial per workgroup; k_l1_finish (a second, one-workgroup launch) sums them in index order.  Rounds 1-4 had the LAST workgroup
+    // to arrive do that behind a ticket: a device-scope release per workgroup, and on gfx950 a release writes the XCD's dirty L2 lines back
+    // -- here the sign bytes this kernel has just stored and the image the compositing kernel wrote in front of it -- which made ~10 us of
+    // fixed cost on a kernel that streams its 69 MB in ~14 us (24.8 us for four views, 15 us for ONE view: profiles/r04g, r05g).
+    if (threadIdx.x == 0) { float t_ = 0.f; for (int k_ = 0; k_ < L1_THREADS / 64; k_++) t_ += s_red[k_]; partial[blockIdx.x] = t_; }
+}
+__global__ __launch_bounds__(L1_BLOCKS) void k_l1_finish(int nparts, const float *__restrict__ partial, float inv_n, float *__restrict__ loss) {
+    __shared__ float s[L1_BLOCKS];
+    s[threadIdx.x] = (int)threadIdx.x < nparts ? partial[threadIdx.x] : 0.f;
     __syncthreads();
-    if (s_last) {
-        __threadfence();
-        float t = 0.f;
-        for (int i2 = threadIdx.x; i2 < (int)gridDim.x; i2 += L1_THREADS) t += __builtin_nontemporal_load(partial + i2);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) { float t_ = 0.f; for (int k_ = 0; k_ < L1_THREADS / 64; k_++) t_ += s_red[k_]; *loss = t_ * inv_n; *ticket = 0u; }
+    if (threadIdx.x == 0) {       // groups of 16 in index order, then the group sums in index order: a fixed tree
+        float tt = 0.f;
+        for (int g = 0; g < L1_BLOCKS / 16; g++) {
+            float t = 0.f;
+            for (int k = 0; k < 16; k++) t += s[16 * g + k];
+            tt += t;
+        }
+        *loss = tt * inv_n;
     }
 }
 // ---- PSNR per image (utils/image_utils.py psnr: mse over all channels and pixels of an image, 20 log10(1 / sqrt(mse))).
@@ -505,7 +505,7 @@ extern "C" int csplat_blur11(void *stream, int64_t n_images, int H, int W, const
     return 0;
 }
 
-extern "C" size_t csplat_l1_scratch_bytes(void) { return (size_t)(L1_BLOCKS + 1) * 4; }
+extern "C" size_t csplat_l1_scratch_bytes(void) { return (size_t)(L1_BLOCKS + 1) * 4; }   // the workgroup partials
 
 // backward of the fused L1 when the forward kept one BYTE per element (csplat_l1_signs): out[i] = g[0] * sign[i] * m[i] / n -- the
 // upstream gradient g is a device scalar, so the reference's three elementwise backward launches (and the multiply by the incoming
@@ -538,13 +538,13 @@ static int l1_launch(void *stream, int64_t n, const float *a, const float *b, vo
     CSPLAT_REQUIRE(n > 0 && a && b && scratch && loss, "csplat_l1: bad arguments");
     CSPLAT_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad | (uintptr_t)mask) & 15u) == 0, "csplat_l1: operands must be 16-byte aligned");
     float *partial = (float *)scratch;
-    unsigned *ticket = (unsigned *)scratch + L1_BLOCKS;     // zero on entry; the kernel leaves it zero
     const int64_t units = (mask && (hw & 3)) ? n : n / 4;
     const int64_t work = (units + L1_THREADS - 1) / L1_THREADS;
     const int grid = (int)(work < 1 ? 1 : (work > L1_BLOCKS ? L1_BLOCKS : work));
     CSPLAT_REQUIRE(((uintptr_t)sign8 & 3u) == 0, "csplat_l1: the sign buffer must be 4-byte aligned");
-    k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, ticket, loss, grad, mask, hw, channels,
-                                                        mask_channels, sign8);
+    k_l1<<<grid, L1_THREADS, 0, (hipStream_t)stream>>>(n, a, b, 1.0f / (float)n, partial, grad, mask, hw, channels, mask_channels, sign8);
+    LAUNCH_CHECK();
+    k_l1_finish<<<1, L1_BLOCKS, 0, (hipStream_t)stream>>>(grid, partial, 1.0f / (float)n, loss);
     LAUNCH_CHECK();
     (void)who;
     return 0;

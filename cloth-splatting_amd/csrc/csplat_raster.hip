@@ -2081,6 +2081,12 @@ __global__ __launch_bounds__(256) void k_det_reduce(int P, Cam cam, const float2
 }
 
 // ------------------------------------------------------------------------------------------- K8
+// CSPLAT_SCRATCH_ZEROED: the record K8 has just read goes back to zero (12 of its 16 floats: the 9 in use, as three 16-byte stores)
+__device__ __forceinline__ void clear_record(const float *acc, int i) {
+    float4 *p = reinterpret_cast<float4 *>(const_cast<float *>(acc) + (size_t)i * ACC_STRIDE);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    p[0] = z; p[1] = z; p[2] = z;
+}
 template <bool STAGE, int NT>
 __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, const float *__restrict__ means3D,
                                                          const float *__restrict__ shs, const float *__restrict__ scales,
@@ -2112,6 +2118,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
     float a9[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
+    if (vis && (accmask & CSPLAT_SCRATCH_ZEROED)) clear_record(acc, i);      // (consumed: the caller's buffer is all zero again for its next step)
     a9[0] *= (float)cam.W; a9[1] *= (float)cam.H;      // (K7 leaves dL/dmean2D without the pixel <- NDC factors 2 * 0.5 W, 2 * 0.5 H)
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
@@ -2370,6 +2377,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
         vis_n = tab.v[vl].radii[i] > 0;
 #pragma unroll
         for (int k = 0; k < 9; k++) a9_n[k] = tab.v[vl].acc[(size_t)i * ACC_STRIDE + k];
+        if (vis_n && (tab.v[vl].accmask & CSPLAT_SCRATCH_ZEROED)) clear_record(tab.v[vl].acc, i);
     }
     for (int vi = vl; vi < tab.n; vi += VL) {
     const K8View &w = tab.v[vi];
@@ -2391,6 +2399,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
         vis_n = wn.radii[i] > 0;
 #pragma unroll
         for (int k = 0; k < 9; k++) a9_n[k] = wn.acc[(size_t)i * ACC_STRIDE + k];
+        if (vis_n && (wn.accmask & CSPLAT_SCRATCH_ZEROED)) clear_record(wn.acc, i);
     }
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
@@ -2934,7 +2943,9 @@ static int begin_launch(const FwdTicket &t) {
 // the same for V views that share the Gaussians (P, SH, opacities, scales; own means / rotations / cameras): four launches on
 // `join` in all, then every view's stream waits for them.  false = the views do not qualify (the caller launches per view).
 static bool begin_views_compatible(int V, const int *tk) {
-    if (V < 2 || V > K1_MAX_VIEWS || (g_debug_flags & 512u)) return false;
+    // (V == 1 qualifies too since round 5: a camera-by-camera caller -- the reference's own loop, train_utils.py:259-272 -- then gets the
+    //  speculative second phase as well instead of a blocking read of its counts per camera)
+    if (V < 1 || V > K1_MAX_VIEWS || (g_debug_flags & 512u)) return false;
     const FwdTicket &a = g_tickets[tk[0]];
     if (a.P <= 0 || !a.can_bucket || !a.shs || a.colors_precomp || a.cov3D_precomp || !a.scales || !a.rotations) return false;
     for (int i = 1; i < V; i++) {
@@ -3145,7 +3156,7 @@ static int p2_launch(int V, const int *tk, csplat_view *v, hipStream_t join, con
 static int finish_views_batched(int V, const int *tk, csplat_view *v, hipStream_t join, bool *done, int mode = 0,
                                 PendingViews *pend = nullptr, int *relaunched = nullptr) {
     *done = false;
-    if (V < 2 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
+    if (V < 1 || V > P2_MAX_VIEWS || (g_debug_flags & 512u)) return 0;
     const FwdTicket &a = g_tickets[tk[0]];
     for (int i = 0; i < V; i++) {
         const FwdTicket &t = g_tickets[tk[i]];
@@ -3403,7 +3414,7 @@ static int backward_impl(hipStream_t s, hipStream_t k8s, bool with_k7, bool with
     const bool det_mode = (g_debug_flags & 256u) != 0;
     float *det = det_mode ? (float *)((char *)scratch + align256((size_t)P * ACC_STRIDE * 4)) : nullptr;
     if (with_k7 && det_mode) HIP_TRY(hipMemsetAsync(det, 0, (size_t)(R > 0 ? R : 1) * 16 * 9 * 4, s));
-    else if (with_k7) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
+    else if (with_k7 && !(accmask & CSPLAT_SCRATCH_ZEROED)) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * ACC_STRIDE * 4, s));
     if (with_k7) {
         ProfScope ps(PROF_K7, s);
         if (R > 0) {
@@ -3709,7 +3720,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     CSPLAT_REQUIRE(V >= 0 && (V == 0 || v != nullptr), "csplat_backward_views: bad view count");
     hipStream_t join = (hipStream_t)join_stream;
     bool shared = false;   // any view adding into another view's buffers: all K8 run on the join stream, in view order
-    for (int i = 0; i < V; i++) shared |= v[i].accmask != 0u;
+    for (int i = 0; i < V; i++) shared |= (v[i].accmask & ~(unsigned)CSPLAT_SCRATCH_ZEROED) != 0u;
     K8Table tab;
     const bool one_k8 = shared && k8_views_table(V, v, tab);
     // K7 of all views in ONE launch on the join stream (plus one launch clearing the records) when the views are alike
@@ -3719,7 +3730,8 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                    v[i].binning && v[i].image && v[i].out_color && v[i].scratch && v[i].dL_dpix;
     // one launch per stage for all views: everything runs on the join stream, the views' own streams are not involved and need
     // neither the entry nor the exit fence (six event / wait calls, ~25 us of host time per step)
-    const bool side_streams = !(batch_k7 && one_k8);
+    const bool lone = V == 1 && (hipStream_t)v[0].stream == join;      // one view on the caller's stream: nothing to fence
+    const bool side_streams = !(batch_k7 && one_k8) && !lone;
     CSPLAT_REQUIRE(!(V > 0 && v[0].valid) || !side_streams, "csplat_backward_views: views launched on faith need the one-launch-per-stage path");
     if (side_streams)
         if (int rc = fence_in(V, v, join)) return rc;
@@ -3753,9 +3765,13 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 bt.stamp = (g_stamp_buf && g_stamp_words >= need) ? g_stamp_buf : nullptr;
                 bt.valid = v[0].valid;
             }
-            const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
-            k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
-            LAUNCH_CHECK();
+            bool zeroed = true;      // every view's records are zero already (CSPLAT_SCRATCH_ZEROED) and K8 will leave them so: no clearing launch
+            for (int i = 0; i < V; i++) zeroed = zeroed && (v[i].accmask & CSPLAT_SCRATCH_ZEROED);
+            if (!zeroed) {
+                const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
+                k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
+                LAUNCH_CHECK();
+            }
             ProfScope ps(PROF_K7, join);       // (the bracket bench.py's roofline reads: K7's launch alone, not the record clearing in front of it)
             const unsigned items = (unsigned)cdiv(slots, 8) * 32u;
             k_composite_bwd_rows_views<<<dim3(items, V), 256, 0, join>>>(tiles, W, H, gx, bt);

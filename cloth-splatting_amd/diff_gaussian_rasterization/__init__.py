@@ -65,8 +65,19 @@ def _f32c_grad(t, device):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    """One camera (what GaussianRasterizer.forward calls, gaussian_renderer/__init__.py:156-164).  Since round 5 a single view goes
+    through the same library entry as a batch of views (csplat_forward_views_deferred with V = 1): from the second call of an image size
+    on, the second forward phase is launched on the previous call's capacities and the counts are read AFTER the host has prepared the
+    backward -- a camera-by-camera loop (the reference's train_utils.py:259-272) no longer leaves the GPU idle for a host round trip per
+    camera.  Images, radii, depth and gradients are those of _RasterizeGaussians (tests: test_batched_views_equal_single_view_calls)."""
+    if PER_CALL_SPECULATION and means3D.is_cuda:
+        return _RasterizeGaussiansBatch.apply((raster_settings,), False, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                              cov3Ds_precomp)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
+
+
+PER_CALL_SPECULATION = True      # False: every call waits for its own counts (csplat_forward_begin / _finish, the path of rounds 1-4)
 
 
 class _View:
@@ -182,6 +193,26 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 
 _side_streams = {}
+# K7's per-Gaussian accumulation records, kept from step to step (round 5): zeroed ONCE per (device, stream the work runs on, P, view slot);
+# K8 clears every record it consumes (csplat.h: CSPLAT_SCRATCH_ZEROED), so the next step finds them zero again -- no clearing launch and
+# no 25.6 MB of zero fill per step.  Launches on one stream cannot overlap, so two backward passes that share a slot are ordered.  A failed
+# entry point may leave records behind: the cache is a ticket cache (csplat.native.check drops it, recordings are invalidated).
+_ACC_SCRATCH = {}
+_n.TICKET_CACHES.append(_ACC_SCRATCH)
+SCRATCH_ZEROED = 256       # csplat.h: CSPLAT_SCRATCH_ZEROED
+
+
+def _acc_scratch(dev, P, slot):
+    """(tensor, True) = the persistent zeroed records of `slot`; (None, False) in the bit-reproducible mode (its scratch is laid out per call)"""
+    if int(_n.lib.csplat_debug_flags_query()) & 256:
+        return None, False
+    key = (dev.index, _n.scratch_stream(dev), int(P), int(slot))
+    buf = _ACC_SCRATCH.get(key)
+    if buf is None:
+        if len(_ACC_SCRATCH) >= 32:
+            _n.evict_scratch(_ACC_SCRATCH)
+        buf = _ACC_SCRATCH[key] = torch.zeros(max(int(_n.lib.csplat_backward_scratch_bytes(int(P), 0)), 256), dtype=torch.uint8, device=dev)
+    return buf, True
 # how the batched forward's second phase went, per call (bench.py's `speculation` field, tests): "hit" = launched on the previous call's
 # capacities before the counts were read and the counts fitted; "miss" = they did not fit and the phase was repeated with exact sizes;
 # "wait" = no history for this (image size, P) yet (or speculation off): the counts were read first
@@ -411,8 +442,9 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             v = views[i]
             means3D, sh, colors_precomp, scales, rotations, cov3Ds, radii = saved[i * k:i * k + 7]
             P, M = v.P, v.M
-            ent = {"scratch": reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.layout_rendered)) // 4 + 64),
-                   "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": 0, "ret": {}}
+            acc_buf, zeroed = _acc_scratch(dev, P, len(plan))
+            ent = {"scratch": acc_buf if zeroed else reserve(int(_n.lib.csplat_backward_scratch_bytes(P, v.layout_rendered)) // 4 + 64),
+                   "dL_dmean2D": reserve(3 * P), "dL_dconic": reserve(4 * P), "mask": SCRATCH_ZEROED if zeroed else 0, "ret": {}}
             ent["ret"][1] = (ent["dL_dmean2D"], (P, 3))
             shapes = {0: (P, 3), 2: (P, M, 3) if sh is not None else None, 3: (P, 3), 4: (P, 1),
                       5: (P, 3) if scales is not None else None, 6: (P, 4) if rotations is not None else None, 7: (P, 6)}
@@ -451,7 +483,8 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             ent = plan[a]
             C.memmove(C.byref(sub[a]), C.byref(arr[i]), C.sizeof(_n.CsplatView))
             w = sub[a]
-            w.scratch, w.accmask = base + 4 * ent["scratch"], ent["mask"]
+            w.scratch = ent["scratch"].data_ptr() if torch.is_tensor(ent["scratch"]) else base + 4 * ent["scratch"]
+            w.accmask = ent["mask"]
             for field in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh",
                           "dL_dscale", "dL_drot"):
                 off = ent.get(field)
@@ -467,7 +500,8 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 for d in shape:
                     numel *= d
                 out[i * n + slot] = big[off:off + numel].view(shape)
-        return {"active": list(active), "big": big, "sub": sub, "out": out, "sinks": used_sinks}
+        return {"active": list(active), "big": big, "sub": sub, "out": out, "sinks": used_sinks,
+                "acc": [e["scratch"] for e in plan if torch.is_tensor(e["scratch"])]}      # (kept alive with the plan)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -483,6 +517,9 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         if not active:
             return (None, None) + (None,) * (V * _RasterizeGaussiansBatch.NIN)
         plan, ctx.plan = ctx.plan, None                         # (one use: the buffers are handed to autograd)
+        if plan is not None and plan["acc"] and (int(_n.lib.csplat_debug_flags_query()) & 256):
+            _n.grad_release(plan["sinks"])                      # (the bit-reproducible mode was switched on after the forward: its scratch
+            plan = None                                         #  has another layout -- plan again)
         if plan is None or plan["active"] != active:            # a view's image went unused, or a second backward pass
             if plan is not None:
                 _n.grad_release(plan["sinks"])

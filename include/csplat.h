@@ -132,7 +132,11 @@ int csplat_forward_finish(int ticket, float *out_color, float *out_depth, int *n
  * needs no per-view temporaries and no summation launches); when any view accumulates, K8 of all views runs on the join
  * stream in view order.  dL_dmean2D / dL_dconic are always written.  Field meanings as in csplat_forward / csplat_backward. */
 enum { CSPLAT_ACC_OPACITY = 1, CSPLAT_ACC_COLOR = 2, CSPLAT_ACC_MEAN3D = 4, CSPLAT_ACC_COV3D = 8, CSPLAT_ACC_SH = 16,
-       CSPLAT_ACC_SCALE = 32, CSPLAT_ACC_ROT = 64 };
+       CSPLAT_ACC_SCALE = 32, CSPLAT_ACC_ROT = 64,
+       /* not an accumulate bit: the view's `scratch` records are ALL ZERO on entry and the call leaves them all zero again (K8 clears
+        * every record it has consumed) -- a caller that keeps the buffer from step to step on one stream then needs no clearing launch per
+        * step (25.6 MB of zero fill for four views of 100k Gaussians).  Without the bit the library clears the records itself. */
+       CSPLAT_SCRATCH_ZEROED = 256 };
 typedef struct csplat_view {
     void *stream;
     int P, D, M, W, H, prefiltered;

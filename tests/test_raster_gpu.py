@@ -1050,3 +1050,41 @@ def test_block_words_are_the_transposed_masks_and_blended_entries_reach_their_bl
                 assert pos.size == 0 or s * SEG + int(pos.max()) < blk_hi[t, b], (t, s, b)
                 checked += 1
     assert checked > 50
+
+
+def test_accumulation_records_are_left_zero_by_the_backward():
+    """Round 5: K7's per-Gaussian accumulation records are kept from step to step, zeroed once, and K8 clears every record it consumes
+    (csplat.h CSPLAT_SCRATCH_ZEROED) -- no clearing launch per step.  Two different steps in a row (other image gradients, other
+    camera: other Gaussians visible) must each give the gradients of a run that starts from freshly zeroed records, and the records
+    must read all zero after every backward."""
+    import diff_gaussian_rasterization as dgr
+    from csplat import native
+    from diff_gaussian_rasterization import rasterize_views
+    V, P = 2, 5000
+    cases = [util.make_case(P=P, W=96, H=80, seed=17, grid=12, scale_mul=4.0, theta=-40.0 + 80.0 * i, radius=3.0) for i in range(V + 1)]
+    inp = util.gpu_inputs(cases[0])
+    gen = torch.Generator(device="cuda").manual_seed(5)
+
+    def run(case_ids, dp):
+        for k in _NAMES:
+            inp[k].grad = None
+        m2d = [torch.zeros(P, 3, device="cuda", requires_grad=True) for _ in case_ids]
+        kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                    rotations=inp["rotations"]) for i in range(len(case_ids))]
+        colors, _ = rasterize_views([util.gpu_settings(cases[c]) for c in case_ids], kws, stacked=True)
+        (colors * dp).sum().backward()
+        torch.cuda.synchronize()
+        return [inp[k].grad.clone() for k in _NAMES] + [m.grad.clone() for m in m2d]
+    dpA = torch.randn(V, 3, 80, 96, device="cuda", generator=gen)
+    dpB = torch.randn(V, 3, 80, 96, device="cuda", generator=gen)
+    run([0, 1], dpA)
+    assert dgr._ACC_SCRATCH, "the persistent records were not used"
+    for buf in dgr._ACC_SCRATCH.values():
+        assert int(buf.view(torch.int32).abs().max()) == 0, "a backward left accumulation records behind"
+    gB = run([1, 2], dpB)                    # straight behind step A, on its records
+    for buf in dgr._ACC_SCRATCH.values():
+        assert int(buf.view(torch.int32).abs().max()) == 0
+    native.evict_scratch(dgr._ACC_SCRATCH)   # fresh records
+    gB_fresh = run([1, 2], dpB)
+    for a, b in zip(gB, gB_fresh):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
