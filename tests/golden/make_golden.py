@@ -291,6 +291,85 @@ def gen_gnn128():
     np.savez_compressed(os.path.join(OUT, "gnn128.npz"), **out)
 
 
+def gen_sim128():
+    """The two simulator wrappers of SURVEY a9 at the config-4 WIDTH (latent 128, hidden 128: the width at which the build's HIP kernels
+    -- csplat_linear128 / csplat_gnn_node_update under no_grad, the fused autograd nodes in training -- take over; the reference-run
+    fixtures meshsim.npz / gnn.npz are at latent 32 and exercise the generic path only): the reference's own
+    ClothMeshSimulator (meshnet/cloth_network.py:13-254, normalize=True) and MeshSimulator (meshnet/meshnet_network.py:14-191, its text
+    exec'd with the merge conflict resolved to 9b63d7a) under the PyG shim, weights in closed form (not stored), on a graph of E = 17,400
+    edges (>= the row count from which the build's training path runs its fused nodes): train-mode call with noise (online normaliser
+    statistics), a decoder / encoder weight gradient, eval-mode prediction."""
+    install_pyg_shim()
+    from meshnet.cloth_network import ClothMeshSimulator
+    viz = types.ModuleType("meshnet.viz")
+    viz.plot_mesh = viz.plot_pcd_list = None
+    sys.modules["meshnet.viz"] = viz
+    src = open(os.path.join(REF, "meshnet/meshnet_network.py")).read()
+    src = re.sub(r"<<<<<<< HEAD\n.*?=======\n(.*?)>>>>>>> [^\n]*\n", r"\1", src, flags=re.S)
+    ns = {"__name__": "meshnet.meshnet_network"}
+    exec(compile(src, "<meshnet_network>", "exec"), ns)
+    MeshSimulator = ns["MeshSimulator"]
+    g = torch.Generator().manual_seed(1280)
+    N, deg = 580, 30
+    E = N * deg
+    dst = torch.arange(N).repeat_interleave(deg)
+    src_ = (dst + torch.randint(1, 45, (E,), generator=g)) % N
+    perm = torch.randperm(E, generator=g)
+    ei = torch.stack([src_, dst])[:, perm].contiguous()
+    ef = torch.randn(E, 4, generator=g)
+    out = dict(edge_index=npy(ei).astype(np.int32), edge_features=npy(ef))
+    # ---- ClothMeshSimulator
+    sim = closed_form_weights(ClothMeshSimulator(simulation_dimensions=3, nnode_in=8, nedge_in=4, latent_dim=128, nmessage_passing_steps=3,
+                                                 nmlp_layers=2, mlp_hidden_dim=128, nnode_types=2, node_type_embedding_size=2,
+                                                 normalize=True, device="cpu"), salt=3)
+    vel = torch.randn(N, 6, generator=g) * 0.1
+    ntype = torch.randint(0, 2, (N, 1), generator=g)
+    tgt = torch.randn(N, 3, generator=g) * 0.1
+    noise = torch.randn(N, 6, generator=g) * 0.01
+    w = torch.randn(N, 3, generator=g)
+    sim.train()
+    pa, ta = sim.predict_acceleration(vel, ntype, ei, ef, target_velocities=tgt, velocity_noise=noise)
+    sim.zero_grad()
+    pa2, _ = sim.predict_acceleration(vel, ntype, ei, ef, target_velocities=tgt, velocity_noise=noise)
+    (pa2 * w).sum().backward()
+    epd = sim._encode_process_decode
+    out.update(c_vel=npy(vel), c_type=npy(ntype), c_tgt=npy(tgt), c_noise=npy(noise), c_w=npy(w), c_pred_acc=npy(pa), c_tgt_acc=npy(ta),
+               c_pred_acc2=npy(pa2), c_dW_dec=npy(epd._decoder.node_fn[0].weight.grad),
+               c_dW_edge_hidden1=npy(epd._processor.gnn_stacks[1].edge_fn[0][2].weight.grad),
+               c_w_probe=npy(epd._processor.gnn_stacks[0].edge_fn[0][2].weight[:2, :5]))
+    for nm in ("_output_normalizer", "_node_normalizer"):
+        for k, v in getattr(sim, nm).get_variable().items():
+            if torch.is_tensor(v):
+                out[f"c{nm}.{k}"] = npy(v)
+    sim.eval()
+    out["c_pred_vel"] = npy(sim.predict_velocity(vel, ntype, ei, ef))
+    # ---- MeshSimulator
+    ms = closed_form_weights(MeshSimulator(simulation_dimensions=3, nnode_in=6, nedge_in=4, latent_dim=128, nmessage_passing_steps=3,
+                                           nmlp_layers=2, mlp_hidden_dim=128, nnode_types=2, node_type_embedding_size=2, device="cpu"), salt=5)
+    pos = torch.randn(N, 3, generator=g)
+    # (a per-node time: with ONE time value for all 580 nodes the reference's Normalizer takes sqrt(E[t^2] - E[t]^2) of a column whose
+    #  variance is zero up to fp32 rounding -- it came out negative in the reference's own run and the prediction was NaN)
+    tvec = 0.35 + 0.1 * torch.rand(N, generator=g)
+    mtgt = pos + torch.randn(N, 3, generator=g) * 0.05
+    mnoise = torch.randn(N, 3, generator=g) * 0.01
+    ms.train()
+    pd1, td1 = ms.predict_dx(pos, tvec, ntype, ei, ef, target_positions=mtgt, position_noise=mnoise)
+    ms.zero_grad()
+    pd2, _ = ms.predict_dx(pos, tvec, ntype, ei, ef, target_positions=mtgt, position_noise=mnoise)
+    (pd2 * w).sum().backward()
+    mepd = ms._encode_process_decode
+    out.update(m_pos=npy(pos), m_time=npy(tvec), m_tgt=npy(mtgt), m_noise=npy(mnoise), m_dx1_pred=npy(pd1), m_dx1_target=npy(td1),
+               m_dx2_pred=npy(pd2), m_dW_dec=npy(mepd._decoder.node_fn[0].weight.grad),
+               m_dW_enc=npy(mepd._encoder.node_fn[0][0].weight.grad))
+    for nm in ("_output_normalizer", "_node_normalizer"):
+        for k, v in getattr(ms, nm).get_variable().items():
+            if torch.is_tensor(v):
+                out[f"m{nm}.{k}"] = npy(v)
+    ms.eval()
+    out["m_position"] = npy(ms.predict_position(pos, tvec[:, None], ntype, ei, ef))
+    np.savez_compressed(os.path.join(OUT, "sim128.npz"), **out)
+
+
 def gen_normalizer():
     install_pyg_shim()
     from meshnet.model_utils import Normalizer
@@ -1028,7 +1107,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
     only = sys.argv[1:]          # e.g. `python make_golden.py simulator`: regenerate the named fixtures only
     for name in ("camera", "sh", "misc", "normalizer", "gnn", "simulator", "densify", "scene_io", "meshsim", "mesh_transform", "losses",
-                 "render_wiring", "gnn128", "vertice_rotation"):
+                 "render_wiring", "gnn128", "vertice_rotation", "sim128"):
         if not only or name in only:
             globals()["gen_" + name]()
     for f in sorted(os.listdir(OUT)):

@@ -177,3 +177,60 @@ def test_residual_mesh_simulator_hip_vs_reference_run():
         ref = g["res_grad." + k]
         assert rel_err(grads_a[k].cpu().numpy(), ref) < 1e-4, ("per-time calls", k)
         assert rel_err(grads_b[k].cpu().numpy(), ref) < 1e-4, ("forward_times", k)
+
+
+def test_simulators_at_latent_128_hip_path_vs_reference_run():
+    """a9 on the HIP path: ClothMeshSimulator.predict_acceleration / predict_velocity and MeshSimulator.predict_dx /
+    predict_position at latent 128 -- the width at which csplat_linear128 / csplat_gnn_node_update (no_grad) and the fused autograd nodes
+    (training; E = 17,400 >= their row threshold) run, under STRICT dispatch with NO fallback allowed -- against a run of the reference's
+    own classes (tests/golden/sim128.npz, make_golden.py:gen_sim128; PyG-shim-derived; weights regenerated in closed form on both
+    sides).  fp32 vs the reference's fp32: outputs 1e-4, online normaliser statistics 1e-5, weight gradients 1e-4 of their scale or
+    -- ReLU ties at this size, see test_encode_process_decode_latent128_tall_graph_vs_reference -- 2e-3."""
+    from meshnet.cloth_network import ClothMeshSimulator
+    from meshnet.meshnet_network import MeshSimulator
+    from csplat import native
+    g = golden("sim128.npz")
+    ei, ef = T(g["edge_index"]).long(), T(g["edge_features"])
+    before = dict(native.FALLBACK_COUNTS)
+    # ---- ClothMeshSimulator
+    sim = util.closed_form_weights(ClothMeshSimulator(3, 8, 4, 128, 3, 2, 128, 2, 2, normalize=True, device="cuda").cuda(), salt=3)
+    epd = sim._encode_process_decode
+    np.testing.assert_allclose(epd._processor.gnn_stacks[0].edge_fn[0][2].weight[:2, :5].detach().cpu().numpy(), g["c_w_probe"], rtol=0, atol=0)
+    vel, ntype, tgt, noise, w = T(g["c_vel"]), T(g["c_type"]), T(g["c_tgt"]), T(g["c_noise"]), T(g["c_w"])
+    sim.train()
+    pa, ta = sim.predict_acceleration(vel, ntype, ei, ef, target_velocities=tgt, velocity_noise=noise)
+    assert rel_err(pa.detach().cpu().numpy(), g["c_pred_acc"]) < 1e-4 and rel_err(ta.cpu().numpy(), g["c_tgt_acc"]) < 1e-4
+    sim.zero_grad()
+    pa2, _ = sim.predict_acceleration(vel, ntype, ei, ef, target_velocities=tgt, velocity_noise=noise)
+    assert rel_err(pa2.detach().cpu().numpy(), g["c_pred_acc2"]) < 1e-4
+    (pa2 * w).sum().backward()
+    assert rel_err(epd._decoder.node_fn[0].weight.grad.cpu().numpy(), g["c_dW_dec"]) < 2e-3
+    assert rel_err(epd._processor.gnn_stacks[1].edge_fn[0][2].weight.grad.cpu().numpy(), g["c_dW_edge_hidden1"]) < 2e-3
+    for nm in ("_output_normalizer", "_node_normalizer"):
+        for k in ("_acc_sum", "_acc_sum_squared", "_acc_count", "_num_accumulations"):
+            np.testing.assert_allclose(getattr(getattr(sim, nm), k).cpu().numpy(), g[f"c{nm}.{k}"], rtol=1e-5, atol=1e-6)
+    sim.eval()
+    with torch.no_grad():
+        pv = sim.predict_velocity(vel, ntype, ei, ef)
+    assert rel_err(pv.cpu().numpy(), g["c_pred_vel"]) < 1e-4
+    # ---- MeshSimulator
+    ms = util.closed_form_weights(MeshSimulator(3, 6, 4, 128, 3, 2, 128, 2, 2, device="cuda").cuda(), salt=5)
+    pos, tvec, mtgt, mnoise = T(g["m_pos"]), T(g["m_time"]), T(g["m_tgt"]), T(g["m_noise"])
+    ms.train()
+    p1, t1 = ms.predict_dx(pos, tvec, ntype, ei, ef, target_positions=mtgt, position_noise=mnoise)
+    assert rel_err(p1.detach().cpu().numpy(), g["m_dx1_pred"]) < 1e-4 and rel_err(t1.cpu().numpy(), g["m_dx1_target"]) < 1e-4
+    ms.zero_grad()
+    p2, _ = ms.predict_dx(pos, tvec, ntype, ei, ef, target_positions=mtgt, position_noise=mnoise)
+    assert rel_err(p2.detach().cpu().numpy(), g["m_dx2_pred"]) < 1e-4
+    (p2 * w).sum().backward()
+    mepd = ms._encode_process_decode
+    assert rel_err(mepd._decoder.node_fn[0].weight.grad.cpu().numpy(), g["m_dW_dec"]) < 2e-3
+    assert rel_err(mepd._encoder.node_fn[0][0].weight.grad.cpu().numpy(), g["m_dW_enc"]) < 2e-3
+    for nm in ("_output_normalizer", "_node_normalizer"):
+        for k in ("_acc_sum", "_acc_sum_squared", "_acc_count", "_num_accumulations"):
+            np.testing.assert_allclose(getattr(getattr(ms, nm), k).cpu().numpy(), g[f"m{nm}.{k}"], rtol=1e-5, atol=1e-6)
+    ms.eval()
+    with torch.no_grad():
+        pp = ms.predict_position(pos, tvec[:, None], ntype, ei, ef)
+    assert rel_err(pp.cpu().numpy(), g["m_position"]) < 1e-4
+    assert dict(native.FALLBACK_COUNTS) == before, "a composed-torch fallback was taken at latent 128"
