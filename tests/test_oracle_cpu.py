@@ -832,3 +832,109 @@ def test_a_failed_call_drops_the_ticketed_scratch_caches():
     # (the modules' own binding: another test may have imported a second copy of csplat.native)
     assert any(c is tr._L1_SCRATCH for c in tr._n.TICKET_CACHES) and any(c is tr._IMG_SCRATCH for c in tr._n.TICKET_CACHES)
     assert any(c is graph_ops._SIMH_SCRATCH for c in graph_ops._n.TICKET_CACHES)
+
+
+_FULL = {}
+
+
+def _full_size_case():
+    if not _FULL:
+        P, W, H = 100_000, 800, 800
+        sc = syn.scene_1(P=P, W=W, H=H, n_cams=4)
+        case = dict(g=syn.gaussians_at(sc), cam=sc["cameras"][1], W=W, H=H, P=P, bg=sc["bg"], sh_degree=3)
+        _FULL.update(case=case, o=oracle_forward(case))
+    return _FULL["case"], _FULL["o"]
+
+
+def test_preprocess_full_size_against_a_numpy_fp64_restatement():
+    """K1 at BASELINE configs[1] size against a restatement written here in numpy float64 from the published algorithm (SURVEY Appendix
+    A.1) -- view transform, near cull at 0.2, homogeneous divide with the 1e-7 guard, Sigma = (S R)^T (S R) from the UN-normalised
+    quaternion, the 1.3 tan(fov) frustum clamp, J W Sigma W^T J^T + 0.3 I, conic, radius = ceil(3 sqrt(lambda_max)) with the
+    max(0.1, mid^2 - det) guard, ndc2pix -- sharing no line with oracle/raster_ref.c or csplat_raster.hip.  The fp32 oracle must agree
+    with it: depth / centre / conic to fp32 rounding, the cull decision everywhere, the integer radius everywhere except where
+    3 sqrt(lambda_max) lies within fp32 rounding of an integer (counted: < 1e-4 of the Gaussians, off by exactly one)."""
+    case, o = _full_size_case()
+    g, cam, W, H = case["g"], case["cam"], case["W"], case["H"]
+    f8 = lambda a: np.asarray(a, np.float64)  # noqa: E731
+    p, s, q = f8(g["means3D"]), f8(g["scales"]), f8(g["rotations"])
+    V, Pm = f8(cam["world_view_transform"]).reshape(4, 4), f8(cam["full_proj_transform"]).reshape(4, 4)
+    ph = np.concatenate([p, np.ones((len(p), 1))], 1)
+    pv, hom = ph @ V, ph @ Pm                                  # row-vector convention (scene_reconstruction/cameras.py:63-67)
+    seen = pv[:, 2] > 0.2
+    w_ = 1.0 / (hom[:, 3] + 1e-7)
+    ndc = hom[:, :2] * w_[:, None]
+    px, py = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]           # (r, x, y, z), NOT normalised in the kernel
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                  2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                  2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    A = R * s[:, None, :]                                      # R diag(s)
+    Sig = A @ A.transpose(0, 2, 1)
+    tanx, tany = float(cam["tanfovx"]), float(cam["tanfovy"])
+    fx, fy = W / (2 * tanx), H / (2 * tany)
+    tz = np.where(seen, pv[:, 2], 1.0)
+    tx = np.clip(pv[:, 0] / tz, -1.3 * tanx, 1.3 * tanx) * tz
+    ty = np.clip(pv[:, 1] / tz, -1.3 * tany, 1.3 * tany) * tz
+    zero = np.zeros_like(tz)
+    J = np.stack([fx / tz, zero, -fx * tx / (tz * tz), zero, fy / tz, -fy * ty / (tz * tz)], 1).reshape(-1, 2, 3)
+    T = J @ V[:3, :3].T
+    cov = T @ Sig @ T.transpose(0, 2, 1)
+    a, b, c = cov[:, 0, 0] + 0.3, cov[:, 0, 1], cov[:, 1, 1] + 0.3
+    det = a * c - b * b
+    mid = 0.5 * (a + c)
+    lam = mid + np.sqrt(np.maximum(0.1, mid * mid - det))
+    rad = np.ceil(3.0 * np.sqrt(lam))
+    on = o.radii > 0
+    # a Gaussian the oracle kept is seen here (the oracle may drop more: zero-area rectangles)
+    assert not np.any(on & ~seen)
+    k = np.nonzero(on)[0]
+    assert np.abs(o.depth[k] - pv[k, 2]).max() <= 2e-6 * np.abs(pv[k, 2]).max()
+    assert np.abs(o.xy[k, 0] - px[k]).max() <= 2e-3 and np.abs(o.xy[k, 1] - py[k]).max() <= 2e-3          # pixels, fp32 at |x| ~ 800
+    con = np.stack([c / det, -b / det, a / det], 1)
+    assert np.abs(o.conic_opacity[k, :3] - con[k]).max() <= 2e-5 * np.abs(con[k]).max()
+    dr = o.radii[k].astype(np.int64) - rad[k].astype(np.int64)
+    assert np.abs(dr).max() <= 1 and (dr != 0).mean() < 1e-4, (int(np.abs(dr).max()), float((dr != 0).mean()))
+    near_int = np.abs(3.0 * np.sqrt(lam[k][dr != 0]) - np.round(3.0 * np.sqrt(lam[k][dr != 0])))
+    assert np.all(near_int < 1e-3)                             # every disagreement is a rounding tie at an integer radius
+
+
+def test_binning_full_size_against_a_vectorised_numpy_restatement():
+    """The independent binning restatement at BASELINE configs[1] size (the bit-exact index tests compare two
+    compilations of one formula, and the independent restatement above runs on 600 Gaussians): P = 100,000, one 800 x 800 camera,
+    R ~ 536k instances.  Rectangle from (centre, radius) by C-style truncation in float32, instances emitted tile-row-major per
+    Gaussian in index order, key = tile << 32 | depth bits, numpy's STABLE argsort, ranges by run boundaries -- written with array
+    operations, no line shared with oracle/raster_ref.c or the HIP kernels.  Keys, sorted ids, tiles touched and ranges identical.
+    (The HIP path is held bit-exact to the same oracle output at this size by tests/test_raster_gpu.py::test_config2_full_size_*.)"""
+    case, o = _full_size_case()
+    P, W, H = case["P"], case["W"], case["H"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    vis = np.nonzero(o.radii > 0)[0]
+    x, y, r = o.xy[vis, 0].astype(np.float32), o.xy[vis, 1].astype(np.float32), o.radii[vis].astype(np.float32)
+    s16, s15 = np.float32(16), np.float32(15)
+    trunc = lambda v: v.astype(np.int64)                       # C (int) cast of a float32: truncation towards zero  # noqa: E731
+    minx = np.clip(trunc((x - r) / s16), 0, gx); maxx = np.clip(trunc((x + r + s15) / s16), 0, gx)
+    miny = np.clip(trunc((y - r) / s16), 0, gy); maxy = np.clip(trunc((y + r + s15) / s16), 0, gy)
+    nx, ny = maxx - minx, maxy - miny
+    touched = nx * ny
+    full = np.zeros(P, np.int64); full[vis] = touched
+    np.testing.assert_array_equal(full, o.tiles_touched.astype(np.int64))
+    keep = touched > 0
+    vis, minx, miny, nx, touched = vis[keep], minx[keep], miny[keep], nx[keep], touched[keep]
+    owner = np.repeat(np.arange(len(vis)), touched)             # instance -> its Gaussian (position in `vis`)
+    local = np.arange(int(touched.sum())) - np.repeat(np.cumsum(touched) - touched, touched)
+    ty = miny[owner] + local // nx[owner]                       # tile rows outer, columns inner
+    tx = minx[owner] + local % nx[owner]
+    dbits = o.depth[vis].astype(np.float32).view(np.uint32).astype(np.uint64)
+    keys = ((ty * gx + tx).astype(np.uint64) << np.uint64(32)) | dbits[owner]
+    ids = vis[owner].astype(np.uint32)
+    assert len(keys) == o.R
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(keys[order], o.keys)
+    np.testing.assert_array_equal(ids[order], o.ids)
+    tiles = (keys[order] >> np.uint64(32)).astype(np.int64)
+    first = np.r_[True, tiles[1:] != tiles[:-1]]
+    starts = np.nonzero(first)[0]
+    ends = np.r_[starts[1:], len(tiles)]
+    ranges = np.zeros((gx * gy, 2), np.int32)
+    ranges[tiles[starts], 0] = starts; ranges[tiles[starts], 1] = ends
+    np.testing.assert_array_equal(ranges, o.ranges)
