@@ -7,6 +7,7 @@
 // backward of blur is the same kernel applied to the incoming gradient.
 #include "csplat_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 constexpr int BW = 64, BH = 16, R5 = 5;
@@ -177,17 +178,58 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_ssim_bwd(int H, int W, Taps ta
 // tile already holds x and y: the L1 term, the sign byte of its gradient and the squared error ride on the third phase.  Workgroup
 // partials (3 floats) are summed in index order by k_image_loss_finish: bit-reproducible, no float atomics.
 // Replaces k_l1 + k_psnr + k_ssim_fwd and eight stock reductions / elementwise launches.
-__global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
-                                                         float *__restrict__ P1, float *__restrict__ P2, float *__restrict__ P3,
-                                                         signed char *__restrict__ sign8, const float *__restrict__ mask, int mask_channels,
-                                                         int channels, float *__restrict__ partial) {
-    __shared__ float s_x[(BH + 2 * R5)][BW + 2 * R5 + 1];
-    __shared__ float s_y[(BH + 2 * R5)][BW + 2 * R5 + 1];
-    __shared__ float s_h[5][(BH + 2 * R5)][BW + 1];
-    __shared__ float s_red[3][SSIM_THREADS / 64];
+// k_image_loss_fwd / _bwd, REGISTER-BLOCKED since round 5.  The round-4 forms (one output per thread and pass: every output re-read its
+// eleven taps from LDS, re-formed x^2 / y^2 / xy per tap; counters: 428 lane-instructions and 79 LDS instructions per pixel, vector pipe
+// ~45 % busy, 53 % of the wave-cycles waiting) measured 80.2 / 54.9 us at [3,3,800,800].  Here a thread owns a strip: the horizontal pass
+// makes 4 consecutive outputs of a row from 14 loaded values per map (products formed once per loaded value), the vertical pass 2
+// consecutive rows of a column from 12 values per map -- half the instructions -- for 76.1 / 48.1 us (same box, rocprofv3).  Not more,
+// because what the kernel waits for is a tile's LIFE (load, barrier, pass, barrier, pass, stores) with three tiles resident per CU (51 KB of
+// LDS each): the same scheme on 256 threads per tile (8 x 1 / 1 x 4 strips) was SLOWER than the round-4 kernels (97.6 / 61.3 us), and at 84
+// VGPRs (5 waves per SIMD: two tiles per CU) the forward took 92.6 us -- hence __launch_bounds__(512, 6).  Same tile (64 x 16), same
+// partial-sum layout, same arithmetic per output (tap order k = 0 .. 10): the finish kernel and the parity tests are unchanged.
+constexpr int IL_T = 512, IL_HR = BH + 2 * R5, IL_XP = BW + 2 * R5 + 2, IL_HP = BW + 4;      // 26 halo rows; pitches 76 / 68 floats
+constexpr int IL_HS = 4, IL_VS = 2;            // outputs per horizontal / vertical strip: 26 x 16 = 416 and 64 x 8 = 512 strips for 512 threads
+static_assert((BW / IL_HS) * IL_HR <= IL_T && BW * (BH / IL_VS) == IL_T, "one strip per thread");
+static_assert(BW == 64 && BH == 16, "the strip assignment below is written for 64 x 16 tiles");
+
+// horizontal 11-tap pass of one row strip: out[o] = sum_k w[k] v[o + k], o = 0 .. IL_HS - 1
+__device__ __forceinline__ void il_hrow(const Taps &taps, const float (&v)[IL_HS + 10], float *dst) {
+    float a[IL_HS];
+#pragma unroll
+    for (int o = 0; o < IL_HS; o++) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) t += taps.w[k] * v[o + k];
+        a[o] = t;
+    }
+    static_assert(IL_HS == 4, "one 16-byte store per strip");
+    reinterpret_cast<float4 *>(dst)[0] = make_float4(a[0], a[1], a[2], a[3]);
+}
+// vertical 11-tap pass of one column strip: out[r] = sum_k w[k] s[(row0 + r + k) * IL_HP], r = 0 .. IL_VS - 1
+__device__ __forceinline__ void il_vcol(const Taps &taps, const float *s, float (&out)[IL_VS]) {
+    float v[IL_VS + 10];
+#pragma unroll
+    for (int j = 0; j < IL_VS + 10; j++) v[j] = s[j * IL_HP];
+#pragma unroll
+    for (int r = 0; r < IL_VS; r++) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) t += taps.w[k] * v[r + k];
+        out[r] = t;
+    }
+}
+
+__global__ __launch_bounds__(IL_T, 6) void k_image_loss_fwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
+                                                           float *__restrict__ P1, float *__restrict__ P2, float *__restrict__ P3,
+                                                           signed char *__restrict__ sign8, const float *__restrict__ mask, int mask_channels,
+                                                           int channels, float *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float s_x[IL_HR][IL_XP];
+    __shared__ __attribute__((aligned(16))) float s_y[IL_HR][IL_XP];
+    __shared__ __attribute__((aligned(16))) float s_h[5][IL_HR][IL_HP];
+    __shared__ float s_red[3][IL_T / 64];
     const size_t img = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += SSIM_THREADS) {
+    for (int t = threadIdx.x; t < IL_HR * (BW + 2 * R5); t += IL_T) {
         const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
         const int y = y0 + ry - R5, x = x0 + rx - R5;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
@@ -195,50 +237,62 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_fwd(int H, int W, T
         s_y[ry][rx] = in ? Y[img + (size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    constexpr int NS = BW / IL_HS, NV = IL_HS + 10;
+    if (threadIdx.x < IL_HR * NS) {                    // strip = (halo row, IL_HS columns)
+        const int ry = threadIdx.x / NS, c0 = (threadIdx.x % NS) * IL_HS;
+        float xv[NV], yv[NV], v[NV];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = taps.w[k], xv = s_x[ry][rx + k], yv = s_y[ry][rx + k];
-            a0 += w * xv; a1 += w * yv; a2 += w * (xv * xv); a3 += w * (yv * yv); a4 += w * (xv * yv);
-        }
-        s_h[0][ry][rx] = a0; s_h[1][ry][rx] = a1; s_h[2][ry][rx] = a2; s_h[3][ry][rx] = a3; s_h[4][ry][rx] = a4;
+        for (int k = 0; k < NV; k++) { xv[k] = s_x[ry][c0 + k]; yv[k] = s_y[ry][c0 + k]; }
+        il_hrow(taps, xv, &s_h[0][ry][c0]);
+        il_hrow(taps, yv, &s_h[1][ry][c0]);
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = xv[k] * xv[k];
+        il_hrow(taps, v, &s_h[2][ry][c0]);
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = yv[k] * yv[k];
+        il_hrow(taps, v, &s_h[3][ry][c0]);
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = xv[k] * yv[k];
+        il_hrow(taps, v, &s_h[4][ry][c0]);
     }
     __syncthreads();
     float acc_s = 0.f, acc_l = 0.f, acc_q = 0.f;
-    for (int t = threadIdx.x; t < BH * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        const int y = y0 + ry, x = x0 + rx;
-        if (y < H && x < W) {
-            float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    {                                                   // strip = (column, IL_VS rows)
+        const int rx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * IL_VS;
+        float m1[IL_VS], m2[IL_VS], q11[IL_VS], q22[IL_VS], q12[IL_VS];
+        il_vcol(taps, &s_h[0][r0][rx], m1);
+        il_vcol(taps, &s_h[1][r0][rx], m2);
+        il_vcol(taps, &s_h[2][r0][rx], q11);
+        il_vcol(taps, &s_h[3][r0][rx], q22);
+        il_vcol(taps, &s_h[4][r0][rx], q12);
+        const int x = x0 + rx;
+        const size_t plane = mask ? (mask_channels == 1 ? blockIdx.z / channels : blockIdx.z) : 0;
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float w = taps.w[k];
-                mu1 += w * s_h[0][ry + k][rx]; mu2 += w * s_h[1][ry + k][rx]; s11 += w * s_h[2][ry + k][rx];
-                s22 += w * s_h[3][ry + k][rx]; s12 += w * s_h[4][ry + k][rx];
-            }
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * (s12 - mu12) + SSIM_C2;
-            const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = (s11 - mu1_sq) + (s22 - mu2_sq) + SSIM_C2;
-            const float inv = 1.f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            const size_t o = img + (size_t)y * W + x;
-            float m = 1.f;
-            if (mask) {
-                const size_t plane = mask_channels == 1 ? blockIdx.z / channels : blockIdx.z;
-                m = mask[(plane * H + y) * W + x];
-                acc_s += (1.f - S) * m;
-            } else acc_s += S;
-            const float d0 = s_x[ry + R5][rx + R5] - s_y[ry + R5][rx + R5];
-            const float d = d0 * m;                               // (utils/loss_utils.py:21-22: |(x - y) m|; the PSNR is unmasked)
-            acc_l += fabsf(d);
-            acc_q += d0 * d0;
-            if (sign8) sign8[o] = (signed char)(d > 0.f ? 1 : (d < 0.f ? -1 : 0));
-            if (P1) {
-                P1[o] = m * (2.f * mu2 * (A2 - A1) * inv - S * 2.f * mu1 * (B2 - B1) * inv);
-                P2[o] = m * (-S / B2);
-                P3[o] = m * (2.f * A1 * inv);
+        for (int r = 0; r < IL_VS; r++) {
+            const int y = y0 + r0 + r;
+            if (y < H && x < W) {
+                const float mu1 = m1[r], mu2 = m2[r], s11 = q11[r], s22 = q22[r], s12 = q12[r];
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * (s12 - mu12) + SSIM_C2;
+                const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = (s11 - mu1_sq) + (s22 - mu2_sq) + SSIM_C2;
+                const float inv = 1.f / (B1 * B2);
+                const float S = A1 * A2 * inv;
+                const size_t o = img + (size_t)y * W + x;
+                float m = 1.f;
+                if (mask) {
+                    m = mask[(plane * H + y) * W + x];
+                    acc_s += (1.f - S) * m;
+                } else acc_s += S;
+                const float d0 = s_x[r0 + r + R5][rx + R5] - s_y[r0 + r + R5][rx + R5];
+                const float d = d0 * m;                               // (utils/loss_utils.py:21-22: |(x - y) m|; the PSNR is unmasked)
+                acc_l += fabsf(d);
+                acc_q += d0 * d0;
+                if (sign8) sign8[o] = (signed char)(d > 0.f ? 1 : (d < 0.f ? -1 : 0));
+                if (P1) {
+                    P1[o] = m * (2.f * mu2 * (A2 - A1) * inv - S * 2.f * mu1 * (B2 - B1) * inv);
+                    P2[o] = m * (-S / B2);
+                    P3[o] = m * (2.f * A1 * inv);
+                }
             }
         }
     }
@@ -251,8 +305,56 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_fwd(int H, int W, T
         const size_t me = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         for (int q = 0; q < 3; q++) {
             float t_ = 0.f;
-            for (int k = 0; k < SSIM_THREADS / 64; k++) t_ += s_red[q][k];
+            for (int k = 0; k < IL_T / 64; k++) t_ += s_red[q][k];
             partial[q * nwg + me] = t_;
+        }
+    }
+}
+
+__global__ __launch_bounds__(IL_T, 6) void k_image_loss_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
+                                                           const float *__restrict__ P1, const float *__restrict__ P2,
+                                                           const float *__restrict__ P3, const signed char *__restrict__ sign8,
+                                                           const float *__restrict__ mask, int mask_channels, int channels,
+                                                           const float *__restrict__ gscalar, float g_l1, float g_ssim, float *__restrict__ dX) {
+    __shared__ __attribute__((aligned(16))) float s_p[3][IL_HR][IL_XP];
+    __shared__ __attribute__((aligned(16))) float s_h[3][IL_HR][IL_HP];
+    const size_t img = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
+    for (int t = threadIdx.x; t < IL_HR * (BW + 2 * R5); t += IL_T) {
+        const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
+        const int y = y0 + ry - R5, x = x0 + rx - R5;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const size_t o = img + (size_t)y * W + x;
+        s_p[0][ry][rx] = in ? P1[o] : 0.f; s_p[1][ry][rx] = in ? P2[o] : 0.f; s_p[2][ry][rx] = in ? P3[o] : 0.f;
+    }
+    __syncthreads();
+    constexpr int NS = BW / IL_HS, NV = IL_HS + 10;
+    if (threadIdx.x < IL_HR * NS) {
+        const int ry = threadIdx.x / NS, c0 = (threadIdx.x % NS) * IL_HS;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) v[k] = s_p[q][ry][c0 + k];
+            il_hrow(taps, v, &s_h[q][ry][c0]);
+        }
+    }
+    __syncthreads();
+    const float gs = gscalar[0] * g_ssim, gl = gscalar[0] * g_l1;
+    const int rx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * IL_VS;
+    float b1[IL_VS], b2[IL_VS], b3[IL_VS];
+    il_vcol(taps, &s_h[0][r0][rx], b1);
+    il_vcol(taps, &s_h[1][r0][rx], b2);
+    il_vcol(taps, &s_h[2][r0][rx], b3);
+    const int x = x0 + rx;
+    const size_t plane = mask ? (mask_channels == 1 ? blockIdx.z / channels : blockIdx.z) : 0;
+#pragma unroll
+    for (int r = 0; r < IL_VS; r++) {
+        const int y = y0 + r0 + r;
+        if (y < H && x < W) {
+            const size_t o = img + (size_t)y * W + x;
+            const float m = mask ? mask[(plane * H + y) * W + x] : 1.f;
+            dX[o] = gs * (b1[r] + 2.f * X[o] * b2[r] + Y[o] * b3[r]) + gl * (float)sign8[o] * m;
         }
     }
 }
@@ -308,57 +410,6 @@ __global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_finish(size_t per_p
         out[1] = psnr_scale * psnr_sum;
         out[2] = image_loss;
         out[3] = l1;
-    }
-}
-
-// backward of k_image_loss_fwd: dX = g w / n * (sign m - lambda (blur(P1) + 2 x blur(P2) + y blur(P3)))   (P* carry the mask already)
-__global__ __launch_bounds__(SSIM_THREADS) void k_image_loss_bwd(int H, int W, Taps taps, const float *__restrict__ X, const float *__restrict__ Y,
-                                                         const float *__restrict__ P1, const float *__restrict__ P2,
-                                                         const float *__restrict__ P3, const signed char *__restrict__ sign8,
-                                                         const float *__restrict__ mask, int mask_channels, int channels,
-                                                         const float *__restrict__ gscalar, float g_l1, float g_ssim, float *__restrict__ dX) {
-    __shared__ float s_p[3][(BH + 2 * R5)][BW + 2 * R5 + 1];
-    __shared__ float s_h[3][(BH + 2 * R5)][BW + 1];
-    const size_t img = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * (BW + 2 * R5); t += SSIM_THREADS) {
-        const int ry = t / (BW + 2 * R5), rx = t - ry * (BW + 2 * R5);
-        const int y = y0 + ry - R5, x = x0 + rx - R5;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const size_t o = img + (size_t)y * W + x;
-        s_p[0][ry][rx] = in ? P1[o] : 0.f; s_p[1][ry][rx] = in ? P2[o] : 0.f; s_p[2][ry][rx] = in ? P3[o] : 0.f;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < (BH + 2 * R5) * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = taps.w[k];
-            a0 += w * s_p[0][ry][rx + k]; a1 += w * s_p[1][ry][rx + k]; a2 += w * s_p[2][ry][rx + k];
-        }
-        s_h[0][ry][rx] = a0; s_h[1][ry][rx] = a1; s_h[2][ry][rx] = a2;
-    }
-    __syncthreads();
-    const float gs = gscalar[0] * g_ssim, gl = gscalar[0] * g_l1;
-    for (int t = threadIdx.x; t < BH * BW; t += SSIM_THREADS) {
-        const int ry = t / BW, rx = t - ry * BW;
-        const int y = y0 + ry, x = x0 + rx;
-        if (y < H && x < W) {
-            float b1 = 0.f, b2 = 0.f, b3 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float w = taps.w[k];
-                b1 += w * s_h[0][ry + k][rx]; b2 += w * s_h[1][ry + k][rx]; b3 += w * s_h[2][ry + k][rx];
-            }
-            const size_t o = img + (size_t)y * W + x;
-            float m = 1.f;
-            if (mask) {
-                const size_t plane = mask_channels == 1 ? blockIdx.z / channels : blockIdx.z;
-                m = mask[(plane * H + y) * W + x];
-            }
-            dX[o] = gs * (b1 + 2.f * X[o] * b2 + Y[o] * b3) + gl * (float)sign8[o] * m;
-        }
     }
 }
 
@@ -645,7 +696,7 @@ extern "C" int csplat_image_loss_fwd(void *stream, int64_t n_batch, int channels
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)(n_batch * channels));
     float *partial = (float *)scratch;
-    k_image_loss_fwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, sign8, mask, mask ? mask_channels : 1, channels, partial);
+    k_image_loss_fwd<<<grid, IL_T, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, sign8, mask, mask ? mask_channels : 1, channels, partial);
     LAUNCH_CHECK();
     k_image_loss_finish<<<1, SSIM_THREADS, 0, (hipStream_t)stream>>>((size_t)grid.x * grid.y, (int)grid.z, channels, H, W, mask ? 1 : 0, lam, img_weight,
                                                                      add, add_weight, psnr_scale, partial, out);
@@ -661,8 +712,8 @@ extern "C" int csplat_image_loss_bwd(void *stream, int64_t n_batch, int channels
     memcpy(t.w, taps11, sizeof(t.w));
     dim3 grid(cdiv(W, BW), cdiv(H, BH), (unsigned)(n_batch * channels));
     const float inv_n = 1.0f / ((float)(n_batch * channels) * (float)H * (float)W);
-    k_image_loss_bwd<<<grid, SSIM_THREADS, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, sign8, mask, mask ? mask_channels : 1, channels, g_scalar,
-                                                                      img_weight * inv_n, -lam * img_weight * inv_n, dx);
+    k_image_loss_bwd<<<grid, IL_T, 0, (hipStream_t)stream>>>(H, W, t, x, y, p1, p2, p3, sign8, mask, mask ? mask_channels : 1, channels, g_scalar,
+                                                             img_weight * inv_n, -lam * img_weight * inv_n, dx);
     LAUNCH_CHECK();
     return 0;
 }
