@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the auxiliary config-3 train-step measurement (bench_train.py) appended on 1 GPU")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the auxiliary 2000-replay sustained-clock pass (profiler runs)")
     ap.add_argument("--no-gnn", action="store_true", help="skip the auxiliary config-4 MeshNet rollout measurement (bench_gnn.py)")
     ap.add_argument("--no-view-streams", dest="view_streams", action="store_false",
                     help="run the views of a step back to back on one stream instead of one HIP stream per view")
@@ -307,7 +308,7 @@ def main():
             if r_loss != e_loss or not (worst <= 1e-4):
                 raise SystemExit(f"bench.py: the replayed step differs from the eager step: {replay_check}")
         # ---- the same step under a sustained load: > 1 s of back-to-back replays (DVFS / power management; the 20-step region is 11 ms)
-        if not dist_on:
+        if not dist_on and not args.no_sustained:
             n_sus = 2000
             torch.cuda.synchronize(); t_s = time.perf_counter()
             for _ in range(n_sus):
@@ -321,6 +322,8 @@ def main():
         # timed replays, with the event pair around every K7 launch -- same kernel, same launch geometry, same inputs; the rocprofv3
         # trace of this command holds both populations under one kernel name.  Before it, the same K steps launched eagerly WITHOUT brackets are
         # timed: `eager_ms_per_step`.
+        for _ in range(3):      # (stream capture emptied torch's allocator cache: the first eager steps behind it re-grow the pools)
+            step()
         sync(); t_e = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -351,7 +354,9 @@ def main():
     per_camera_ms_per_step = None
     if args.view_streams and V > 1 and wl is not None:
         args.view_streams = False
-        step(); step(); torch.cuda.synchronize()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
         # the reference's own call pattern (scene_reconstruction/train_utils.py:259-292): GaussianRasterizer(...) once per camera, one
         # loss over the images, ONE backward -- timed over the same K steps, no event brackets inside (they cost host time per launch)
         sync(); t_c = time.perf_counter()

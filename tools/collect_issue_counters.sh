@@ -10,7 +10,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-speculation"
+CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-gnn --no-sustained --no-speculation"
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SMEM"
 P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"
 P3="SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INSTS_BRANCH GRBM_GUI_ACTIVE"

@@ -18,7 +18,8 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+src, dst = os.path.join(root, "gpurun_out", tag), os.environ.get("CSPLAT_PROFILES_DST") or os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
 VALU_CYC = 2.0
 SIMDS, GHZ = 1024, 2.4
 

@@ -13,7 +13,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+src, dst = os.path.join(root, "gpurun_out", tag), os.environ.get("CSPLAT_PROFILES_DST") or os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
@@ -23,7 +23,7 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-for f in ("bench.json", "bench_2rank_gloo.json", "bench_2rank_scenes.json", "valu_rate.txt", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "linear128_train.txt", "dw128.txt", "mfma_rate.txt", "gnn_train.txt"):
+for f in ("bench.json", "bench_2rank_gloo.json", "bench_2rank_scenes.json", "valu_rate.txt", "bench_serial.json", "bench_gnn.json", "bench_train.json", "linear128.txt", "linear128_train.txt", "dw128.txt", "mfma_rate.txt", "gnn_train.txt", "edge_mlp3.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         if f.endswith(".json"):      # keep the JSON line only (the gloo transport prints its own lines on stdout)
