@@ -44,6 +44,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int EM_N = 128;                 // layer width
 constexpr int EM_STRIDE = 136;            // bf16 elements per image row (272 B)
@@ -350,14 +351,346 @@ __global__ __launch_bounds__(64 * EM_WAVES) void k_edge_mlp3(int64_t M, const fl
     }
 }
 
+
+// =====================================================================================================================================
+// k_edge_mlp3r -- the same message MLP with the WEIGHTS RESIDENT IN REGISTERS (round 5, second design).
+//
+// What the stamps of k_edge_mlp3 above said: with one weight image in LDS the workgroup re-stages 102 KiB three times per 256 rows and
+// walks the layers in lockstep.  Here nothing is re-staged.  One 4-wave workgroup per CU, one wave per SIMD (up to 512 registers each);
+// wave j owns output features 32j .. 32j + 31 of ALL THREE layers: 3 layers x 3 bf16 pieces x 8 steps = 72 MFMA A operands = 288
+// registers, loaded once per launch.  What moves through LDS is the ACTIVATIONS, already cut into bf16 pieces by whoever produced them:
+// a 64-row super-tile (two 32-row tiles = two independent accumulator chains per wave) is [tile][piece][32 rows][128 + 8] bf16, 51 KiB,
+// in two buffers the layers ping-pong between.  Per layer a wave issues 2 x 48 MFMAs with B operands read from LDS (one 16-byte read
+// per piece and step), turns its 32 x 32 result into the next layer's pieces (ReLU, cut, two 16-byte LDS writes per piece), barrier.
+// Global memory is touched in whole rows only: the next super-tile's edge rows and gathered node rows are fetched half-wave-per-row
+// into registers while a layer's products run, cut / summed, and parked in LDS (pieces; G = (b0 + xa[dst] + xb[src]) / alpha, which
+// layer 1's accumulators START from, as the other layers' start from their bias); LayerNorm's statistics cross the four waves through
+// LDS ((sum, M2) per wave, combined by the parallel-variance formula).
+// Contraction order: position pos = 64h + 8st + i of an activation row is what lane-half h feeds into step st as element i.  Layer 1:
+// pos = column of e0.  Layers 2, 3: the producing wave j' writes its lane's 16 accumulator registers of row n contiguously, pos = 32j'
+// + 16h' + r <-> feature 32j' + 8(r >> 2) + 4h' + (r & 3); the permutation is applied to the packed weights (er_src_col).
+constexpr int ER_TILE_P = 32 * EM_STRIDE;                 // bf16 elements of one piece of one 32-row tile
+constexpr int ER_XBUF = 2 * 3 * ER_TILE_P;                // one activation buffer: [tile 2][piece 3][32][EM_STRIDE]
+constexpr int ER_GSTRIDE = 132;                           // floats per G row (528 B: conflict-free 16-byte accesses, lane = row)
+constexpr size_t ER_X_BYTES = (size_t)2 * ER_XBUF * 2;    // 104,448
+constexpr size_t ER_G_BYTES = (size_t)64 * ER_GSTRIDE * 4;        // 33,792
+constexpr size_t ER_S_BYTES = (size_t)2 * 64 * 4 * 8;     // LayerNorm partials [parity][row 64][wave 4] (sum, M2)
+constexpr size_t ER_T_BYTES = (size_t)4 * EM_N * 4;       // b1, b2, gamma, beta
+constexpr size_t ER_LDS_BYTES = ER_X_BYTES + ER_G_BYTES + ER_S_BYTES + ER_T_BYTES;
+constexpr size_t ER_IMAGE_BYTES = (size_t)3 * 4 * 3 * 8 * 64 * 16;      // [layer][wave][piece][step][lane] x 16 B = 294,912
+
+__host__ __device__ inline int er_src_col(int layer, int pos) {
+    if (layer == 0) return pos;
+    const int j = pos >> 5, h = (pos >> 4) & 1, r = pos & 15;
+    return 32 * j + 8 * (r >> 2) + 4 * h + (r & 3);
+}
+
+__global__ __launch_bounds__(64) void k_edge_mlp3r_pack(const float *__restrict__ W0, int ld0, const float *__restrict__ W1, int ld1,
+                                                        const float *__restrict__ W2, int ld2, bf16x8 *__restrict__ img) {
+    // block = (layer l, wave j, step st); lane (m, h): the 8 contraction elements of output feature 32j + m it feeds into step st
+    const int st = blockIdx.x & 7, j = (blockIdx.x >> 3) & 3, l = blockIdx.x >> 5;
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const float *W = l == 0 ? W0 : (l == 1 ? W1 : W2);
+    const int ld = l == 0 ? ld0 : (l == 1 ? ld1 : ld2);
+    bf16x8 p1, p2, p3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float x = W[(size_t)(32 * j + m) * ld + er_src_col(l, 64 * h + 8 * st + i)];
+        p1[i] = (__bf16)x;
+        const float r1 = x - (float)p1[i];
+        p2[i] = (__bf16)r1;
+        p3[i] = (__bf16)(r1 - (float)p2[i]);
+    }
+    bf16x8 *dst = img + ((size_t)((l * 4 + j) * 3) * 8 + st) * 64 + lane;
+    dst[0] = p1; dst[8 * 64] = p2; dst[2 * 8 * 64] = p3;
+}
+
+__global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__restrict__ e0, float alpha, float inv_alpha,
+                                                    const float *__restrict__ xa, const int64_t *__restrict__ ia,
+                                                    const float *__restrict__ xb, const int64_t *__restrict__ ib,
+                                                    const bf16x8 *__restrict__ wimg, const float *__restrict__ b0,
+                                                    const float *__restrict__ b1, const float *__restrict__ b2,
+                                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                    float *__restrict__ out, unsigned long long *__restrict__ stamps) {
+    extern __shared__ char s_mem[];
+    __bf16 *const sX = reinterpret_cast<__bf16 *>(s_mem);
+    float *const sG = reinterpret_cast<float *>(s_mem + ER_X_BYTES);
+    float2 *const sS = reinterpret_cast<float2 *>(s_mem + ER_X_BYTES + ER_G_BYTES);
+    float *const sT = reinterpret_cast<float *>(s_mem + ER_X_BYTES + ER_G_BYTES + ER_S_BYTES);
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const int64_t nst = (M + 63) / 64;
+
+    int stamp_at = 0;                         // (measurement hook, csplat_debug_stamps / tools/edge_mlp3_stamps.py)
+    auto stamp = [&]() {
+        if (stamps && w == 0 && stamp_at < 64) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (lane == 0) stamps[(size_t)blockIdx.x * 64 + stamp_at] = t;
+            stamp_at++;
+        }
+    };
+    // this wave's 32 output features of the three layers: 72 operands = 288 registers, for the whole launch.  The first 64 operands are
+    // PINNED to the accumulation registers (values that only ever meet "a" constraints: the allocator cannot put them anywhere else) and
+    // copied next to their use; left to itself the allocator fills the 256 architectural registers with weights first and the loop's own
+    // values fight over what is left (operand reads from LDS serialised with their MFMAs: 41 cycles per MFMA instead of 32)
+    int Wa[64][4];
+    bf16x8 Wv[8];
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int st = 0; st < 8; st++) {
+                const int id = (l * 3 + p) * 8 + st;
+                const bf16x8 v = wimg[((size_t)((l * 4 + w) * 3 + p) * 8 + st) * 64 + lane];
+                if (id < 64) {
+                    const i32x4 q = __builtin_bit_cast(i32x4, v);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) asm("v_accvgpr_write_b32 %0, %1" : "=a"(Wa[id][c]) : "v"(q[c]));
+                } else Wv[id - 64] = v;
+            }
+    int tick = 0;                             // (renewed per layer: an operand copy depends on it, so it stays next to its use)
+    auto wop = [&](int l, int p, int st) __attribute__((always_inline)) -> bf16x8 {
+        const int id = (l * 3 + p) * 8 + st;
+        if (id >= 64) return Wv[id - 64];
+        i32x4 q;
+#pragma unroll
+        for (int c = 0; c < 4; c++) asm("v_accvgpr_read_b32 %0, %1" : "=v"(q[c]) : "a"(Wa[id][c]), "v"(tick));
+        return __builtin_bit_cast(bf16x8, q);
+    };
+    for (int t = threadIdx.x; t < 4 * EM_N; t += 256)
+        sT[t] = t < EM_N ? b1[t] : (t < 2 * EM_N ? b2[t - EM_N] : (t < 3 * EM_N ? gamma[t - 2 * EM_N] : beta[t - 3 * EM_N]));
+    float4 b0v = *reinterpret_cast<const float4 *>(b0 + 4 * n);       // (loader layout: half-wave per row, lane n <-> columns 4n .. 4n + 3)
+    b0v.x *= inv_alpha; b0v.y *= inv_alpha; b0v.z *= inv_alpha; b0v.w *= inv_alpha;
+
+    // ---- loaders.  A wave brings in rows 16w .. 16w + 15 of a super-tile, two rows per instruction (half-wave per row, 16 bytes per lane)
+    int iva = 0, ivb = 0;                     // lanes 0 .. 15: the gather indices of the wave's 16 rows
+    auto load_idx = [&](int64_t s) {
+        int64_t row = s * 64 + 16 * w + (lane & 15);
+        row = row < M ? row : M - 1;          // (rows past M: clamped loads, masked stores)
+        iva = (int)ia[row]; ivb = (int)ib[row];
+    };
+    float4 E[8];
+    auto issue_e0 = [&](int64_t s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int64_t row = s * 64 + 16 * w + 2 * k + h;
+            row = row < M ? row : M - 1;
+            E[k] = *reinterpret_cast<const float4 *>(e0 + row * EM_N + 4 * n);
+        }
+    };
+    auto cut4 = [&](const float4 &v, uint2 &q1, uint2 &q2, uint2 &q3) __attribute__((always_inline)) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        __bf16 p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            p1[t] = (__bf16)x[t];
+            const float r1 = x[t] - (float)p1[t];
+            p2[t] = (__bf16)r1;
+            p3[t] = (__bf16)(r1 - (float)p2[t]);
+        }
+        q1 = *reinterpret_cast<uint2 *>(p1); q2 = *reinterpret_cast<uint2 *>(p2); q3 = *reinterpret_cast<uint2 *>(p3);
+    };
+    auto commit_e0 = [&](__bf16 *Xb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int lr = 16 * w + 2 * k + h;                        // row of the super-tile
+            __bf16 *dst = Xb + (size_t)(lr >> 5) * 3 * ER_TILE_P + (size_t)(lr & 31) * EM_STRIDE + 4 * n;
+            uint2 q1, q2, q3;
+            cut4(E[k], q1, q2, q3);
+            *reinterpret_cast<uint2 *>(dst) = q1;
+            *reinterpret_cast<uint2 *>(dst + ER_TILE_P) = q2;
+            *reinterpret_cast<uint2 *>(dst + 2 * ER_TILE_P) = q3;
+        }
+    };
+    float4 GA[4], GB[4];
+    auto issue_g = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int kk = 4 * half + k;
+            const int a0 = __builtin_amdgcn_readlane(iva, 2 * kk), a1 = __builtin_amdgcn_readlane(iva, 2 * kk + 1);
+            const int c0 = __builtin_amdgcn_readlane(ivb, 2 * kk), c1 = __builtin_amdgcn_readlane(ivb, 2 * kk + 1);
+            GA[k] = *reinterpret_cast<const float4 *>(xa + (size_t)(h ? a1 : a0) * EM_N + 4 * n);
+            GB[k] = *reinterpret_cast<const float4 *>(xb + (size_t)(h ? c1 : c0) * EM_N + 4 * n);
+        }
+    };
+    auto commit_g = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int lr = 16 * w + 2 * (4 * half + k) + h;
+            float4 v;
+            v.x = (GA[k].x + GB[k].x) * inv_alpha + b0v.x; v.y = (GA[k].y + GB[k].y) * inv_alpha + b0v.y;
+            v.z = (GA[k].z + GB[k].z) * inv_alpha + b0v.z; v.w = (GA[k].w + GB[k].w) * inv_alpha + b0v.w;
+            *reinterpret_cast<float4 *>(sG + (size_t)lr * ER_GSTRIDE + 4 * n) = v;
+        }
+    };
+
+    // ---- a layer of both tiles: acc_t += W_l (registers) x X_t (pieces in LDS); the six products that matter, small terms first
+    auto products = [&](int l, const __bf16 *Xin, f32x16 &acc0, f32x16 &acc1) __attribute__((always_inline)) {
+        const __bf16 *row = Xin + (size_t)n * EM_STRIDE + 64 * h;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tick));
+        bf16x8 b[6], bn[6];
+#pragma unroll
+        for (int p = 0; p < 6; p++) b[p] = *reinterpret_cast<const bf16x8 *>(row + p * ER_TILE_P);
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            if (st < 7) {
+#pragma unroll
+                for (int p = 0; p < 6; p++) bn[p] = *reinterpret_cast<const bf16x8 *>(row + p * ER_TILE_P + 8 * (st + 1));
+            }
+            const bf16x8 w0 = wop(l, 0, st), w1 = wop(l, 1, st), w2 = wop(l, 2, st);
+            __builtin_amdgcn_sched_barrier(0);      // (the next step's operands are requested BEFORE this step's 12 MFMAs, not next to their use)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[5], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b[3], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[4], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[4], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[3], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[3], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 6; p++) b[p] = bn[p];
+        }
+    };
+    // the accumulators' start: 16 floats of this lane's features (register r <-> feature 32w + 8(r >> 2) + 4h + (r & 3)) from an LDS row
+    auto start_from = [&](const float *base, f32x16 &acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 t = *reinterpret_cast<const float4 *>(base + 32 * w + 8 * q + 4 * h);
+            acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
+        }
+    };
+    // ReLU(scale * acc) cut into the next layer's pieces: 16 contiguous positions 32w + 16h .. + 15 of row n
+    auto relu_to_pieces = [&](const f32x16 &acc, float scale, __bf16 *Xtile) __attribute__((always_inline)) {
+        __bf16 p1[16], p2[16], p3[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float x = fmaxf(scale * acc[r], 0.f);
+            p1[r] = (__bf16)x;
+            const float r1 = x - (float)p1[r];
+            p2[r] = (__bf16)r1;
+            p3[r] = (__bf16)(r1 - (float)p2[r]);
+        }
+        __bf16 *dst = Xtile + (size_t)n * EM_STRIDE + 32 * w + 16 * h;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            *reinterpret_cast<uint4 *>(dst + 8 * k) = *reinterpret_cast<uint4 *>(p1 + 8 * k);
+            *reinterpret_cast<uint4 *>(dst + ER_TILE_P + 8 * k) = *reinterpret_cast<uint4 *>(p2 + 8 * k);
+            *reinterpret_cast<uint4 *>(dst + 2 * ER_TILE_P + 8 * k) = *reinterpret_cast<uint4 *>(p3 + 8 * k);
+        }
+    };
+    // LayerNorm, first half: this wave's (sum, M2 about its own mean) of the row's 32 features it holds
+    auto ln_partials = [&](const f32x16 &acc, float2 *srow) __attribute__((always_inline)) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += acc[r];
+        s = pair_sum(s);
+        const float mj = s * (1.f / 32.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float d = acc[r] - mj; m2 += d * d; }
+        m2 = pair_sum(m2);
+        if (h == 0) srow[w] = make_float2(s, m2);
+    };
+    // second half: combine the four waves' partials, normalise, scale / shift, this lane's 4 x 16 bytes of the row out
+    auto ln_store = [&](const f32x16 &acc, const float2 *srow, int64_t grow) __attribute__((always_inline)) {
+        const float4 u0 = *reinterpret_cast<const float4 *>(srow), u1 = *reinterpret_cast<const float4 *>(srow + 2);
+        const float mean = (u0.x + u0.z + u1.x + u1.z) * (1.f / EM_N);
+        const float d0 = u0.x * (1.f / 32.f) - mean, d1 = u0.z * (1.f / 32.f) - mean, d2 = u1.x * (1.f / 32.f) - mean, d3 = u1.z * (1.f / 32.f) - mean;
+        const float m2 = (u0.y + u0.w + u1.y + u1.w) + 32.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+        const float rstd = rsqrtf(m2 * (1.f / EM_N) + eps);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int f = 32 * w + 8 * q + 4 * h;
+            const float4 ga = *reinterpret_cast<const float4 *>(sT + 2 * EM_N + f), be = *reinterpret_cast<const float4 *>(sT + 3 * EM_N + f);
+            float4 y;
+            y.x = (acc[4 * q] - mean) * rstd * ga.x + be.x; y.y = (acc[4 * q + 1] - mean) * rstd * ga.y + be.y;
+            y.z = (acc[4 * q + 2] - mean) * rstd * ga.z + be.z; y.w = (acc[4 * q + 3] - mean) * rstd * ga.w + be.w;
+            if (grow < M) *reinterpret_cast<float4 *>(out + grow * EM_N + f) = y;
+        }
+    };
+
+    int64_t s = blockIdx.x;
+    const int64_t stride = gridDim.x;
+    // the first super-tile, synchronously
+    load_idx(s);
+    issue_e0(s);
+    issue_g(0); commit_g(0);
+    issue_g(1); commit_g(1);
+    commit_e0(sX);
+    load_idx(s + stride);
+    __syncthreads();
+    int par = 0;
+    for (; s < nst; s += stride, par ^= 1) {
+        __bf16 *Xa = sX + (size_t)par * ER_XBUF, *Xb = sX + (size_t)(par ^ 1) * ER_XBUF;
+        const int64_t sn = s + stride;
+        f32x16 acc0, acc1;
+        // ---------------- layer 1: alpha * (We e0 + (b0 + xa[dst] + xb[src]) / alpha), ReLU
+        stamp();                              // 0
+        start_from(sG + (size_t)n * ER_GSTRIDE, acc0);
+        start_from(sG + (size_t)(32 + n) * ER_GSTRIDE, acc1);
+        products(0, Xa, acc0, acc1);
+        stamp();                              // 1: layer-1 products
+        relu_to_pieces(acc0, alpha, Xb);
+        relu_to_pieces(acc1, alpha, Xb + 3 * ER_TILE_P);
+        stamp();                              // 2: pieces written
+        __syncthreads();                      // (X1 complete; every wave has taken its start values out of G)
+        stamp();                              // 3: barrier
+        // ---------------- layer 2 (the next super-tile's rows and the first half of its gathers travel under it)
+        issue_e0(sn);
+        issue_g(0);
+        start_from(sT, acc0);
+        start_from(sT, acc1);
+        products(1, Xb, acc0, acc1);
+        stamp();                              // 4: loads issued, layer-2 products
+        relu_to_pieces(acc0, 1.f, Xa);
+        relu_to_pieces(acc1, 1.f, Xa + 3 * ER_TILE_P);
+        commit_g(0);
+        stamp();                              // 5: pieces + G half written
+        __syncthreads();                      // (X2 complete; Xb free)
+        stamp();                              // 6: barrier
+        // ---------------- layer 3 + LayerNorm
+        commit_e0(Xb);
+        issue_g(1);
+        stamp();                              // 7: next rows cut and parked
+        start_from(sT + EM_N, acc0);
+        start_from(sT + EM_N, acc1);
+        products(2, Xa, acc0, acc1);
+        stamp();                              // 8: layer-3 products
+        float2 *srow = sS + (size_t)par * 64 * 4;
+        ln_partials(acc0, srow + (size_t)n * 4);
+        ln_partials(acc1, srow + (size_t)(32 + n) * 4);
+        commit_g(1);
+        load_idx(sn + stride);
+        stamp();                              // 9: partials, G half
+        __syncthreads();                      // (partials, next pieces and next G complete)
+        stamp();                              // 10: barrier
+        ln_store(acc0, srow + (size_t)n * 4, s * 64 + n);
+        ln_store(acc1, srow + (size_t)(32 + n) * 4, s * 64 + 32 + n);
+    }
+}
+
 }  // namespace
 
-extern "C" size_t csplat_gnn_edge_mlp3_image_bytes(void) { return 3 * EM_LAYER_BYTES; }
+// which of the two kernels serves the entry points (development switch, read once): CSPLAT_EM_KERNEL=lds -> k_edge_mlp3 (weights staged
+// through LDS), anything else -> k_edge_mlp3r (weights in registers).  The image is laid out for the kernel that will read it.
+static bool em_use_regs() {
+    static const int v = [] { const char *e = getenv("CSPLAT_EM_KERNEL"); return (e && e[0] == 'l') ? 0 : 1; }();
+    return v != 0;
+}
+
+extern "C" size_t csplat_gnn_edge_mlp3_image_bytes(void) { return 3 * EM_LAYER_BYTES > ER_IMAGE_BYTES ? 3 * EM_LAYER_BYTES : ER_IMAGE_BYTES; }
 
 extern "C" int csplat_gnn_edge_mlp3_pack(void *stream, const float *W0, int ld0, const float *W1, int ld1, const float *W2, int ld2, void *image) {
     CSPLAT_REQUIRE(W0 && W1 && W2 && image && ld0 >= EM_N && ld1 >= EM_N && ld2 >= EM_N, "csplat_gnn_edge_mlp3_pack: bad arguments");
     CSPLAT_REQUIRE(((uintptr_t)image & 15u) == 0, "csplat_gnn_edge_mlp3_pack: the image must be 16-byte aligned");
-    k_edge_mlp3_pack<<<dim3(EM_N, 3), EM_STRIDE, 0, (hipStream_t)stream>>>(W0, ld0, W1, ld1, W2, ld2, (__bf16 *)image);
+    if (em_use_regs()) k_edge_mlp3r_pack<<<3 * 4 * 8, 64, 0, (hipStream_t)stream>>>(W0, ld0, W1, ld1, W2, ld2, (bf16x8 *)image);
+    else k_edge_mlp3_pack<<<dim3(EM_N, 3), EM_STRIDE, 0, (hipStream_t)stream>>>(W0, ld0, W1, ld1, W2, ld2, (__bf16 *)image);
     LAUNCH_CHECK();
     return 0;
 }
@@ -375,13 +708,28 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
     int ex = 0;
     const float m = frexpf(alpha, &ex);
     CSPLAT_REQUIRE(alpha > 0.f && m == 0.5f, "csplat_gnn_edge_mlp3: alpha must be a power of two (the edge scale 2^l)");
+    hipStream_t s = (hipStream_t)stream;
+    if (em_use_regs()) {
+        static int r_ok = -1;
+        if (r_ok < 0) {
+            r_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ER_LDS_BYTES) == hipSuccess;
+            (void)hipGetLastError();
+        }
+        CSPLAT_REQUIRE(r_ok, "csplat_gnn_edge_mlp3: 141 KB of dynamic LDS refused by the runtime");
+        ProfScope ps(PROF_GNN, s);
+        const int64_t nst = (E + 63) / 64;
+        k_edge_mlp3r<<<(int)(nst < 256 ? nst : 256), 256, ER_LDS_BYTES, s>>>(E, e0, alpha, 1.0f / alpha, xa, index_a, xb, index_b,
+                                                                             (const bf16x8 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, out,
+                                                                             csplat_stamp_buffer((size_t)256 * 64));
+        LAUNCH_CHECK();
+        return 0;
+    }
     static int s_ok = -1;
     if (s_ok < 0) {
         s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EM_LDS_BYTES) == hipSuccess;
         (void)hipGetLastError();
     }
     CSPLAT_REQUIRE(s_ok, "csplat_gnn_edge_mlp3: 102 KB of dynamic LDS refused by the runtime");
-    hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_GNN, s);
     const int64_t nround = (E + EM_ROWS - 1) / EM_ROWS;
     const int grid = (int)(nround < 256 ? nround : 256);      // persistent: one 8-wave workgroup per CU

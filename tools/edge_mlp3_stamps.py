@@ -35,14 +35,21 @@ with torch.no_grad():
     torch.cuda.synchronize()
     native.lib.csplat_debug_stamps(None, 0)
 s = buf.cpu().numpy().reshape(256, 64).astype(np.int64)
-names = ["wait: image-1 + barrier", "layer-1 products (wave 0)", "ReLU + barrier: the other waves", "image-2 DMA -> landed + barrier",
-         "layer-2 products (wave 0)", "ReLU + barrier: the others", "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)",
-         "LayerNorm, rows x features by MFMA, barrier", "image-1 DMA issued, next round's gathers by MFMA", "rows out issued", "(next round's start)"]
-NS = 13       # stamps per round incl. the next round's first
-for r in range(3):
+if os.environ.get("CSPLAT_EM_KERNEL", "")[:1] == "l":
+    names = ["wait: image-1 + barrier", "layer-1 products (wave 0)", "ReLU + barrier: the other waves", "image-2 DMA -> landed + barrier",
+             "layer-2 products (wave 0)", "ReLU + barrier: the others", "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)",
+             "LayerNorm, rows x features by MFMA, barrier", "image-1 DMA issued, next round's gathers by MFMA", "rows out issued", "(next round's start)"]
+    unit = "256-row round"
+else:       # k_edge_mlp3r (weights in registers): 64-row super-tiles
+    names = ["start values + layer-1 products", "ReLU, cut, pieces -> LDS", "barrier", "next rows / gathers issued, layer-2 products",
+             "pieces -> LDS, G half", "barrier", "next rows cut -> LDS, gathers issued", "layer-3 products", "LayerNorm partials, G half, indices",
+             "barrier", "normalise, rows out"]
+    unit = "64-row super-tile"
+NS = len(names) + 1       # stamps per round incl. the next round's first
+for r in range(4 if NS < 13 else 3):
     seg = s[:, (NS - 1) * r:(NS - 1) * r + NS]
     ok = (seg > 0).all(1)
     d = np.diff(seg[ok], axis=1)
-    print(f"round {r}: {int(ok.sum())} workgroups, total {d[:, :NS - 1].sum(1).mean():.0f} cycles")
+    print(f"{unit} {r}: {int(ok.sum())} workgroups, total {d[:, :NS - 1].sum(1).mean():.0f} cycles")
     for k in range(NS - 1):
         print(f"    {names[k]:48s} mean {d[:, k].mean():8.0f}  median {np.median(d[:, k]):8.0f}  p90 {np.percentile(d[:, k], 90):8.0f}")
