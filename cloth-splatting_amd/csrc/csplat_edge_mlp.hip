@@ -413,13 +413,12 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                     float *__restrict__ out, unsigned long long *__restrict__ stamps) {
     extern __shared__ char s_mem[];
-    __bf16 *const sX = reinterpret_cast<__bf16 *>(s_mem);
-    float *const sG = reinterpret_cast<float *>(s_mem + ER_X_BYTES);
-    float2 *const sS = reinterpret_cast<float2 *>(s_mem + ER_X_BYTES + ER_G_BYTES);
-    float *const sT = reinterpret_cast<float *>(s_mem + ER_X_BYTES + ER_G_BYTES + ER_S_BYTES);
+    __bf16 *const sX = reinterpret_cast<__bf16 *>(s_mem);                                     // [slot 2][buffer 2] tiles of three pieces
+    float *const sG = reinterpret_cast<float *>(s_mem + ER_X_BYTES);                          // [slot 2][32][ER_GSTRIDE]
+    float2 *const sS = reinterpret_cast<float2 *>(s_mem + ER_X_BYTES + ER_G_BYTES);           // [slot 2][32][wave 4] (sum, M2)
+    float *const sT = reinterpret_cast<float *>(s_mem + ER_X_BYTES + ER_G_BYTES + ER_S_BYTES);      // b1, b2, gamma, beta
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
-    const int64_t nst = (M + 63) / 64;
 
     int stamp_at = 0;                         // (measurement hook, csplat_debug_stamps / tools/edge_mlp3_stamps.py)
     auto stamp = [&]() {
@@ -429,250 +428,320 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
             stamp_at++;
         }
     };
-    // this wave's 32 output features of the three layers: 72 operands = 288 registers, for the whole launch.  The first 64 operands are
-    // PINNED to the accumulation registers (values that only ever meet "a" constraints: the allocator cannot put them anywhere else) and
-    // copied next to their use; left to itself the allocator fills the 256 architectural registers with weights first and the loop's own
-    // values fight over what is left (operand reads from LDS serialised with their MFMAs: 41 cycles per MFMA instead of 32)
-    int Wa[64][4];
+
+    // ---- this wave's 32 output features of the three layers: 72 MFMA A operands = 288 registers, for the whole launch.  64 of them
+    // are OWNED through "a" constraints (loaded straight into accumulation registers, read there by the MFMAs: the allocator never sees
+    // them as something to move), the last 8 live with the loop's own values in the architectural half.
+    i32x4 Wa[64];
     bf16x8 Wv[8];
 #pragma unroll
-    for (int l = 0; l < 3; l++)
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int st = 0; st < 8; st++) {
-                const int id = (l * 3 + p) * 8 + st;
-                const bf16x8 v = wimg[((size_t)((l * 4 + w) * 3 + p) * 8 + st) * 64 + lane];
-                if (id < 64) {
-                    const i32x4 q = __builtin_bit_cast(i32x4, v);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) asm("v_accvgpr_write_b32 %0, %1" : "=a"(Wa[id][c]) : "v"(q[c]));
-                } else Wv[id - 64] = v;
-            }
-    int tick = 0;                             // (renewed per layer: an operand copy depends on it, so it stays next to its use)
-    auto wop = [&](int l, int p, int st) __attribute__((always_inline)) -> bf16x8 {
-        const int id = (l * 3 + p) * 8 + st;
-        if (id >= 64) return Wv[id - 64];
-        i32x4 q;
-#pragma unroll
-        for (int c = 0; c < 4; c++) asm("v_accvgpr_read_b32 %0, %1" : "=v"(q[c]) : "a"(Wa[id][c]), "v"(tick));
-        return __builtin_bit_cast(bf16x8, q);
-    };
+    for (int id = 0; id < 72; id++) {
+        const int l = id / 24, p = (id / 8) % 3, st = id & 7;
+        const bf16x8 *src = wimg + ((size_t)((l * 4 + w) * 3 + p) * 8 + st) * 64 + lane;
+        if (id < 64) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(Wa[id]) : "v"(src) : "memory");
+        else Wv[id - 64] = *src;
+    }
     for (int t = threadIdx.x; t < 4 * EM_N; t += 256)
-        sT[t] = t < EM_N ? b1[t] : (t < 2 * EM_N ? b2[t - EM_N] : (t < 3 * EM_N ? gamma[t - 2 * EM_N] : beta[t - 3 * EM_N]));
+        sT[t] = t < EM_N ? b1[t] * inv_alpha : (t < 2 * EM_N ? b2[t - EM_N] * inv_alpha : (t < 3 * EM_N ? gamma[t - 2 * EM_N] : beta[t - 3 * EM_N]));
+    eps *= inv_alpha * inv_alpha;             // (everything runs divided by alpha: see the side work)
     float4 b0v = *reinterpret_cast<const float4 *>(b0 + 4 * n);       // (loader layout: half-wave per row, lane n <-> columns 4n .. 4n + 3)
     b0v.x *= inv_alpha; b0v.y *= inv_alpha; b0v.z *= inv_alpha; b0v.w *= inv_alpha;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the asm loads are not in the compiler's books)
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- loaders.  A wave brings in rows 16w .. 16w + 15 of a super-tile, two rows per instruction (half-wave per row, 16 bytes per lane)
-    int iva = 0, ivb = 0;                     // lanes 0 .. 15: the gather indices of the wave's 16 rows
-    auto load_idx = [&](int64_t s) {
-        int64_t row = s * 64 + 16 * w + (lane & 15);
-        row = row < M ? row : M - 1;          // (rows past M: clamped loads, masked stores)
-        iva = (int)ia[row]; ivb = (int)ib[row];
+    // one product: acc += W[id] x b.  Accumulate chain: an MFMA's D taken whole as the next one's C needs no wait states; B comes from
+    // LDS reads (counted by the compiler); the chain's readers run a barrier later
+    auto mfma = [&](int id, const bf16x8 &b, f32x16 &acc) __attribute__((always_inline)) {
+        if (id < 64) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(Wa[id & 63]), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(Wv[id & 7]), "v"(b));
     };
-    float4 E[8];
-    auto issue_e0 = [&](int64_t s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int64_t row = s * 64 + 16 * w + 2 * k + h;
-            row = row < M ? row : M - 1;
-            E[k] = *reinterpret_cast<const float4 *>(e0 + row * EM_N + 4 * n);
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto pk = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+        bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+        return __builtin_bit_cast(unsigned, v);
+    };
+    auto lo_f = [&](unsigned q) { return __uint_as_float(q << 16); };
+    auto hi_f = [&](unsigned q) { return __uint_as_float(q & 0xffff0000u); };
+
+    // =================== side work, cut into operations of 1-4 instructions that ride in the gaps between MFMAs.  One wave per SIMD: a gap
+    // hides ~5 single-issue instructions, the sixth costs its full price -- so every task is a numbered list of small operations and
+    // spread() deals a task's list evenly over a range of a phase's 48 gaps.
+    // Everything below works on values scaled by 1 / alpha (a power of two: exact): layer 1 accumulates We e0 + (b0 + xa + xb) / alpha,
+    // the biases of layers 2 and 3 are parked divided by alpha, and LayerNorm runs with eps / alpha^2 -- (az - am) / sqrt(a^2 v + eps) =
+    // (z - m) / sqrt(v + eps / a^2) -- so no ReLU carries a multiplication.
+    // (a macro: the per-gap trip count must be a literal for the loop to unroll before the gap index is known)
+#define ER_SPREAD(k, S0, S1, N, OP)                                                                                   \
+    do {                                                                                                              \
+        if ((k) >= (S0) && (k) < (S1)) {                                                                              \
+            const int a_ = ((k) - (S0)) * (N) / ((S1) - (S0)), b_ = ((k) + 1 - (S0)) * (N) / ((S1) - (S0));           \
+            _Pragma("unroll") for (int d_ = 0; d_ < ((N) + (S1) - (S0) - 1) / ((S1) - (S0)); d_++) {                  \
+                const int m = a_ + d_;                                                                                \
+                if (m < b_) { OP; }                                                                                   \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    auto opaque = [&](unsigned &q) __attribute__((always_inline)) { asm volatile("" : "+v"(q)); };      // (keeps a packed pair ONE conversion: see pk)
+    // ---- ReLU(acc) -> the next layer's three bf16 pieces, positions 32w + 16h .. + 15 of row n.  62 operations: per value pair
+    // (max, max, pack) (low -) (high -) (pack) (low -) (high -) (pack); 3 x 16-byte writes after pairs 0-3 and after pairs 4-7
+    constexpr int RELU_OPS = 62;
+    float rx0 = 0.f, rx1 = 0.f;
+    unsigned P[3][4], rq = 0;
+    auto relu_op = [&](int m, const f32x16 &acc, __bf16 *Xtile) __attribute__((always_inline)) {
+        const int half = m / 31, mm = m % 31;
+        if (mm < 28) {
+            const int jj = mm / 7, j = 4 * half + jj, o = mm % 7;
+            if (o == 0) { rx0 = fmaxf(acc[2 * j], 0.f); rx1 = fmaxf(acc[2 * j + 1], 0.f); rq = pk(rx0, rx1); opaque(rq); P[0][jj] = rq; }
+            else if (o == 1 || o == 4) rx0 -= lo_f(rq);
+            else if (o == 2 || o == 5) rx1 -= hi_f(rq);
+            else if (o == 3) { rq = pk(rx0, rx1); opaque(rq); P[1][jj] = rq; }
+            else P[2][jj] = pk(rx0, rx1);
+        } else {
+            const int p = mm - 28;
+            __bf16 *dst = Xtile + (size_t)p * ER_TILE_P + (size_t)n * EM_STRIDE + 32 * w + 16 * h + 8 * half;
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(P[p][0], P[p][1], P[p][2], P[p][3]);
         }
     };
-    auto cut4 = [&](const float4 &v, uint2 &q1, uint2 &q2, uint2 &q3) __attribute__((always_inline)) {
-        const float x[4] = {v.x, v.y, v.z, v.w};
-        __bf16 p1[4], p2[4], p3[4];
+    // ---- LayerNorm, first half: this wave's (sum, M2 about its own mean) of the 32 features it holds of row n: 14 operations
+    constexpr int LNP_OPS = 14;
+    float ln_s = 0.f, ln_mj = 0.f, ln_m2 = 0.f;
+    auto lnp_op = [&](int m, const f32x16 &acc, float2 *srow) __attribute__((always_inline)) {
+        if (m < 4) {
+            const float t = (acc[4 * m] + acc[4 * m + 1]) + (acc[4 * m + 2] + acc[4 * m + 3]);
+            ln_s = m == 0 ? t : ln_s + t;
+        } else if (m == 4) {
+            ln_s = pair_sum(ln_s);
+            ln_mj = ln_s * (1.f / 32.f);
+        } else if (m < 13) {
+            const int q = m - 5;              // two values each
+            float t = q == 0 ? 0.f : ln_m2;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            p1[t] = (__bf16)x[t];
-            const float r1 = x[t] - (float)p1[t];
-            p2[t] = (__bf16)r1;
-            p3[t] = (__bf16)(r1 - (float)p2[t]);
+            for (int r = 2 * q; r < 2 * q + 2; r++) { const float d = acc[r] - ln_mj; t = fmaf(d, d, t); }
+            ln_m2 = t;
+        } else {
+            ln_m2 = pair_sum(ln_m2);
+            srow[w] = make_float2(ln_s, ln_m2);      // (both half-waves write the same pair)
         }
-        q1 = *reinterpret_cast<uint2 *>(p1); q2 = *reinterpret_cast<uint2 *>(p2); q3 = *reinterpret_cast<uint2 *>(p3);
     };
-    auto commit_e0 = [&](__bf16 *Xb) __attribute__((always_inline)) {
+    // ---- second half: the four waves' partials combined (parallel-variance formula), normalise, scale / shift, 4 x 16 bytes out: 18 operations
+    constexpr int LNF_OPS = 18;
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(M * 512), 0x00020000);      // (rows past M: dropped)
+    const int st_lane = n * 512 + (32 * w + 4 * h) * 4;
+    float4 lf_u0, lf_u1, lf_ga, lf_be;
+    float lf_mean = 0.f, lf_m2 = 0.f, lf_rstd = 0.f, lf_nm = 0.f, lf_y[4];
+    auto lnf_op = [&](int m, const f32x16 &acc, const float2 *srow, unsigned tile_off) __attribute__((always_inline)) {
+        if (m == 0) {
+            lf_u0 = *reinterpret_cast<const float4 *>(srow); lf_u1 = *reinterpret_cast<const float4 *>(srow + 2);
+        } else if (m == 1) {
+            lf_mean = ((lf_u0.x + lf_u0.z) + (lf_u1.x + lf_u1.z)) * (1.f / EM_N);
+        } else if (m == 2) {
+            lf_m2 = (lf_u0.y + lf_u0.w) + (lf_u1.y + lf_u1.w);
+            const int f = 32 * w + 4 * h;
+            lf_ga = *reinterpret_cast<const float4 *>(sT + 2 * EM_N + f); lf_be = *reinterpret_cast<const float4 *>(sT + 3 * EM_N + f);
+        } else if (m == 3) {
+            const float d0 = fmaf(lf_u0.x, 1.f / 32.f, -lf_mean), d1 = fmaf(lf_u0.z, 1.f / 32.f, -lf_mean);
+            lf_y[0] = d0 * d0; lf_y[0] = fmaf(d1, d1, lf_y[0]);
+        } else if (m == 4) {
+            const float d2 = fmaf(lf_u1.x, 1.f / 32.f, -lf_mean), d3 = fmaf(lf_u1.z, 1.f / 32.f, -lf_mean);
+            lf_y[0] = fmaf(d2, d2, lf_y[0]); lf_y[0] = fmaf(d3, d3, lf_y[0]);
+        } else if (m == 5) {
+            lf_m2 = fmaf(32.f, lf_y[0], lf_m2);
+            lf_rstd = __builtin_amdgcn_rsqf(fmaf(lf_m2, 1.f / EM_N, eps));
+            lf_nm = -lf_mean * lf_rstd;
+        } else {
+            const int q = (m - 6) / 3, part = (m - 6) % 3;
+            if (part == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int lr = 16 * w + 2 * k + h;                        // row of the super-tile
-            __bf16 *dst = Xb + (size_t)(lr >> 5) * 3 * ER_TILE_P + (size_t)(lr & 31) * EM_STRIDE + 4 * n;
-            uint2 q1, q2, q3;
-            cut4(E[k], q1, q2, q3);
-            *reinterpret_cast<uint2 *>(dst) = q1;
-            *reinterpret_cast<uint2 *>(dst + ER_TILE_P) = q2;
-            *reinterpret_cast<uint2 *>(dst + 2 * ER_TILE_P) = q3;
+                for (int i = 0; i < 4; i++) lf_y[i] = fmaf(acc[4 * q + i], lf_rstd, lf_nm);
+            } else if (part == 1) {
+                lf_y[0] = fmaf(lf_y[0], lf_ga.x, lf_be.x); lf_y[1] = fmaf(lf_y[1], lf_ga.y, lf_be.y);
+                lf_y[2] = fmaf(lf_y[2], lf_ga.z, lf_be.z); lf_y[3] = fmaf(lf_y[3], lf_ga.w, lf_be.w);
+                if (q < 3) {
+                    const int f = 32 * w + 8 * (q + 1) + 4 * h;
+                    lf_ga = *reinterpret_cast<const float4 *>(sT + 2 * EM_N + f); lf_be = *reinterpret_cast<const float4 *>(sT + 3 * EM_N + f);
+                }
+            } else {
+                i32x4 v;
+                v[0] = __float_as_int(lf_y[0]); v[1] = __float_as_int(lf_y[1]); v[2] = __float_as_int(lf_y[2]); v[3] = __float_as_int(lf_y[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, r_out, st_lane + tile_off + 32 * q, 0, 0);
+            }
         }
+    };
+    // ---- loaders.  A wave brings in rows 8w .. 8w + 7 of a tile, two rows per instruction (half-wave per row, 16 bytes per lane): global
+    // memory only ever sees whole rows.  Buffer loads: what lies past the last row reads as zero (edge rows) / index 0 (gathers)
+    const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc((void *)e0, 0, (int)(M * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ia = __builtin_amdgcn_make_buffer_rsrc((void *)ia, 0, (int)(M * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ib = __builtin_amdgcn_make_buffer_rsrc((void *)ib, 0, (int)(M * 8), 0x00020000);
+    const int ld_lane = (8 * w + h) * 512 + 16 * n, ix_lane = (8 * w + h) * 8;
+    // the gather indices of the wave's rows, already where the gathers want them: lane (n, h), k <-> row 8w + 2k + h (8 operations)
+    auto idx_op = [&](int m, unsigned tile_rows, int (&ja)[4], int (&jb)[4]) __attribute__((always_inline)) {
+        const int k = m >> 1;
+        if (m & 1) jb[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ib, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
+        else ja[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ia, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
     };
     float4 GA[4], GB[4];
-    auto issue_g = [&](int half) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int kk = 4 * half + k;
-            const int a0 = __builtin_amdgcn_readlane(iva, 2 * kk), a1 = __builtin_amdgcn_readlane(iva, 2 * kk + 1);
-            const int c0 = __builtin_amdgcn_readlane(ivb, 2 * kk), c1 = __builtin_amdgcn_readlane(ivb, 2 * kk + 1);
-            GA[k] = *reinterpret_cast<const float4 *>(xa + (size_t)(h ? a1 : a0) * EM_N + 4 * n);
-            GB[k] = *reinterpret_cast<const float4 *>(xb + (size_t)(h ? c1 : c0) * EM_N + 4 * n);
-        }
+    auto g_issue_op = [&](int m, const int (&ja)[4], const int (&jb)[4]) __attribute__((always_inline)) {      // 8 operations
+        const int k = m >> 1;
+        if (m & 1) GB[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xb) + (size_t)((unsigned)jb[k] * 512u + 16u * n));
+        else GA[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xa) + (size_t)((unsigned)ja[k] * 512u + 16u * n));
     };
-    auto commit_g = [&](int half) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int lr = 16 * w + 2 * (4 * half + k) + h;
-            float4 v;
-            v.x = (GA[k].x + GB[k].x) * inv_alpha + b0v.x; v.y = (GA[k].y + GB[k].y) * inv_alpha + b0v.y;
-            v.z = (GA[k].z + GB[k].z) * inv_alpha + b0v.z; v.w = (GA[k].w + GB[k].w) * inv_alpha + b0v.w;
-            *reinterpret_cast<float4 *>(sG + (size_t)lr * ER_GSTRIDE + 4 * n) = v;
-        }
+    // G = (xa[dst] + xb[src] + b0) / alpha, what layer 1's accumulators start from: 12 operations
+    auto g_commit_op = [&](int m, float *Gt) __attribute__((always_inline)) {
+        const int k = m / 3, part = m % 3;
+        if (part == 0) { GA[k].x += GB[k].x; GA[k].y += GB[k].y; GA[k].z += GB[k].z; GA[k].w += GB[k].w; }
+        else if (part == 1) {
+            GA[k].x = fmaf(GA[k].x, inv_alpha, b0v.x); GA[k].y = fmaf(GA[k].y, inv_alpha, b0v.y);
+            GA[k].z = fmaf(GA[k].z, inv_alpha, b0v.z); GA[k].w = fmaf(GA[k].w, inv_alpha, b0v.w);
+        } else *reinterpret_cast<float4 *>(Gt + (size_t)(8 * w + 2 * k + h) * ER_GSTRIDE + 4 * n) = GA[k];
+    };
+    auto e_issue_op = [&](int k, float4 (&E)[4], unsigned tile_off) __attribute__((always_inline)) {      // 4 operations
+        E[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_e0, ld_lane + tile_off + 1024 * k, 0, 0));
+    };
+    // an edge row's 16 bytes cut into the three pieces, parked as layer 1's B operand: 4 x 11 operations
+    constexpr int EC_OPS = 44;
+    unsigned eq0 = 0, eq1 = 0;
+    auto e_commit_op = [&](int m, float4 (&E)[4], __bf16 *Xtile) __attribute__((always_inline)) {
+        const int k = m / 11, o = m % 11;
+        __bf16 *dst = Xtile + (size_t)(8 * w + 2 * k + h) * EM_STRIDE + 4 * n;
+        auto pack_out = [&](int p) __attribute__((always_inline)) {
+            eq0 = pk(E[k].x, E[k].y); eq1 = pk(E[k].z, E[k].w);
+            if (p < 2) { opaque(eq0); opaque(eq1); }
+            *reinterpret_cast<uint2 *>(dst + (size_t)p * ER_TILE_P) = make_uint2(eq0, eq1);
+        };
+        if (o == 0) pack_out(0);
+        else if (o == 5) pack_out(1);
+        else if (o == 10) pack_out(2);
+        else if (o == 1 || o == 6) E[k].x -= lo_f(eq0);
+        else if (o == 2 || o == 7) E[k].y -= hi_f(eq0);
+        else if (o == 3 || o == 8) E[k].z -= lo_f(eq1);
+        else if (o == 4 || o == 9) E[k].w -= hi_f(eq1);
     };
 
-    // ---- a layer of both tiles: acc_t += W_l (registers) x X_t (pieces in LDS); the six products that matter, small terms first
-    auto products = [&](int l, const __bf16 *Xin, f32x16 &acc0, f32x16 &acc1) __attribute__((always_inline)) {
-        const __bf16 *row = Xin + (size_t)n * EM_STRIDE + 64 * h;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(tick));
-        bf16x8 b[6], bn[6];
-#pragma unroll
-        for (int p = 0; p < 6; p++) b[p] = *reinterpret_cast<const bf16x8 *>(row + p * ER_TILE_P);
-#pragma unroll
-        for (int st = 0; st < 8; st++) {
-            if (st < 7) {
-#pragma unroll
-                for (int p = 0; p < 6; p++) bn[p] = *reinterpret_cast<const bf16x8 *>(row + p * ER_TILE_P + 8 * (st + 1));
-            }
-            const bf16x8 w0 = wop(l, 0, st), w1 = wop(l, 1, st), w2 = wop(l, 2, st);
-            __builtin_amdgcn_sched_barrier(0);      // (the next step's operands are requested BEFORE this step's 12 MFMAs, not next to their use)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[5], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b[3], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[4], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[4], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[3], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[3], acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < 6; p++) b[p] = bn[p];
-        }
-    };
-    // the accumulators' start: 16 floats of this lane's features (register r <-> feature 32w + 8(r >> 2) + 4h + (r & 3)) from an LDS row
-    auto start_from = [&](const float *base, f32x16 &acc) __attribute__((always_inline)) {
+    // =================== a phase: one layer of one tile, 48 MFMAs on one accumulation chain, with side(k) riding behind MFMA k.
+    // acc starts from 16 floats of an LDS row (register r <-> feature 32w + 8(r >> 2) + 4h + (r & 3)); the step's three B operands are
+    // read one step ahead, the piece the next step needs first first
+    auto phase = [&](int l, const __bf16 *Xtile, const float *init, f32x16 &acc, auto &&side) __attribute__((always_inline)) {
+        const __bf16 *row = Xtile + (size_t)n * EM_STRIDE + 64 * h;
+        bf16x8 bc[3], bn[3];
+        bc[2] = *reinterpret_cast<const bf16x8 *>(row + 2 * ER_TILE_P);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float4 t = *reinterpret_cast<const float4 *>(base + 32 * w + 8 * q + 4 * h);
+            const float4 t = *reinterpret_cast<const float4 *>(init + 32 * w + 8 * q + 4 * h);
             acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
         }
-    };
-    // ReLU(scale * acc) cut into the next layer's pieces: 16 contiguous positions 32w + 16h .. + 15 of row n
-    auto relu_to_pieces = [&](const f32x16 &acc, float scale, __bf16 *Xtile) __attribute__((always_inline)) {
-        __bf16 p1[16], p2[16], p3[16];
+        bc[0] = *reinterpret_cast<const bf16x8 *>(row);
+        bc[1] = *reinterpret_cast<const bf16x8 *>(row + ER_TILE_P);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float x = fmaxf(scale * acc[r], 0.f);
-            p1[r] = (__bf16)x;
-            const float r1 = x - (float)p1[r];
-            p2[r] = (__bf16)r1;
-            p3[r] = (__bf16)(r1 - (float)p2[r]);
-        }
-        __bf16 *dst = Xtile + (size_t)n * EM_STRIDE + 32 * w + 16 * h;
+        for (int st = 0; st < 8; st++) {
+            // (weight piece, activation piece): the six products that matter, small terms first
+            constexpr int WP[6] = {0, 2, 1, 0, 1, 0}, XP[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int RD[6] = {-1, 2, -1, 0, -1, 1};      // the next step's piece requested behind MFMA i
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            *reinterpret_cast<uint4 *>(dst + 8 * k) = *reinterpret_cast<uint4 *>(p1 + 8 * k);
-            *reinterpret_cast<uint4 *>(dst + ER_TILE_P + 8 * k) = *reinterpret_cast<uint4 *>(p2 + 8 * k);
-            *reinterpret_cast<uint4 *>(dst + 2 * ER_TILE_P + 8 * k) = *reinterpret_cast<uint4 *>(p3 + 8 * k);
-        }
-    };
-    // LayerNorm, first half: this wave's (sum, M2 about its own mean) of the row's 32 features it holds
-    auto ln_partials = [&](const f32x16 &acc, float2 *srow) __attribute__((always_inline)) {
-        float s = 0.f;
+            for (int i = 0; i < 6; i++) {
+                mfma((l * 3 + WP[i]) * 8 + st, bc[XP[i]], acc);
+                if (RD[i] >= 0 && st < 7) bn[RD[i]] = *reinterpret_cast<const bf16x8 *>(row + RD[i] * ER_TILE_P + 8 * (st + 1));
+#ifndef EM_NOSIDE      // (timing experiment: the bare MFMA pipeline -- results wrong)
+                side(6 * st + i);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-        for (int r = 0; r < 16; r++) s += acc[r];
-        s = pair_sum(s);
-        const float mj = s * (1.f / 32.f);
-        float m2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const float d = acc[r] - mj; m2 += d * d; }
-        m2 = pair_sum(m2);
-        if (h == 0) srow[w] = make_float2(s, m2);
-    };
-    // second half: combine the four waves' partials, normalise, scale / shift, this lane's 4 x 16 bytes of the row out
-    auto ln_store = [&](const f32x16 &acc, const float2 *srow, int64_t grow) __attribute__((always_inline)) {
-        const float4 u0 = *reinterpret_cast<const float4 *>(srow), u1 = *reinterpret_cast<const float4 *>(srow + 2);
-        const float mean = (u0.x + u0.z + u1.x + u1.z) * (1.f / EM_N);
-        const float d0 = u0.x * (1.f / 32.f) - mean, d1 = u0.z * (1.f / 32.f) - mean, d2 = u1.x * (1.f / 32.f) - mean, d3 = u1.z * (1.f / 32.f) - mean;
-        const float m2 = (u0.y + u0.w + u1.y + u1.w) + 32.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-        const float rstd = rsqrtf(m2 * (1.f / EM_N) + eps);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int f = 32 * w + 8 * q + 4 * h;
-            const float4 ga = *reinterpret_cast<const float4 *>(sT + 2 * EM_N + f), be = *reinterpret_cast<const float4 *>(sT + 3 * EM_N + f);
-            float4 y;
-            y.x = (acc[4 * q] - mean) * rstd * ga.x + be.x; y.y = (acc[4 * q + 1] - mean) * rstd * ga.y + be.y;
-            y.z = (acc[4 * q + 2] - mean) * rstd * ga.z + be.z; y.w = (acc[4 * q + 3] - mean) * rstd * ga.w + be.w;
-            if (grow < M) *reinterpret_cast<float4 *>(out + grow * EM_N + f) = y;
+            for (int p = 0; p < 3; p++) bc[p] = bn[p];
         }
     };
 
-    int64_t s = blockIdx.x;
-    const int64_t stride = gridDim.x;
-    // the first super-tile, synchronously
-    load_idx(s);
-    issue_e0(s);
-    issue_g(0); commit_g(0);
-    issue_g(1); commit_g(1);
-    commit_e0(sX);
-    load_idx(s + stride);
-    __syncthreads();
-    int par = 0;
-    for (; s < nst; s += stride, par ^= 1) {
-        __bf16 *Xa = sX + (size_t)par * ER_XBUF, *Xb = sX + (size_t)(par ^ 1) * ER_XBUF;
-        const int64_t sn = s + stride;
-        f32x16 acc0, acc1;
-        // ---------------- layer 1: alpha * (We e0 + (b0 + xa[dst] + xb[src]) / alpha), ReLU
-        stamp();                              // 0
-        start_from(sG + (size_t)n * ER_GSTRIDE, acc0);
-        start_from(sG + (size_t)(32 + n) * ER_GSTRIDE, acc1);
-        products(0, Xa, acc0, acc1);
-        stamp();                              // 1: layer-1 products
-        relu_to_pieces(acc0, alpha, Xb);
-        relu_to_pieces(acc1, alpha, Xb + 3 * ER_TILE_P);
-        stamp();                              // 2: pieces written
-        __syncthreads();                      // (X1 complete; every wave has taken its start values out of G)
-        stamp();                              // 3: barrier
-        // ---------------- layer 2 (the next super-tile's rows and the first half of its gathers travel under it)
-        issue_e0(sn);
-        issue_g(0);
-        start_from(sT, acc0);
-        start_from(sT, acc1);
-        products(1, Xb, acc0, acc1);
-        stamp();                              // 4: loads issued, layer-2 products
-        relu_to_pieces(acc0, 1.f, Xa);
-        relu_to_pieces(acc1, 1.f, Xa + 3 * ER_TILE_P);
-        commit_g(0);
-        stamp();                              // 5: pieces + G half written
-        __syncthreads();                      // (X2 complete; Xb free)
-        stamp();                              // 6: barrier
-        // ---------------- layer 3 + LayerNorm
-        commit_e0(Xb);
-        issue_g(1);
-        stamp();                              // 7: next rows cut and parked
-        start_from(sT + EM_N, acc0);
-        start_from(sT + EM_N, acc1);
-        products(2, Xa, acc0, acc1);
-        stamp();                              // 8: layer-3 products
-        float2 *srow = sS + (size_t)par * 64 * 4;
-        ln_partials(acc0, srow + (size_t)n * 4);
-        ln_partials(acc1, srow + (size_t)(32 + n) * 4);
-        commit_g(1);
-        load_idx(sn + stride);
-        stamp();                              // 9: partials, G half
-        __syncthreads();                      // (partials, next pieces and next G complete)
-        stamp();                              // 10: barrier
-        ln_store(acc0, srow + (size_t)n * 4, s * 64 + n);
-        ln_store(acc1, srow + (size_t)(32 + n) * 4, s * 64 + 32 + n);
+    const int T0 = blockIdx.x, stride = gridDim.x, ntiles = (int)((M + 31) / 32);
+    __bf16 *const XA = sX, *const XB = sX + 2 * (3 * ER_TILE_P);       // slot s, buffer b: sX + (2s + b) * 3 * ER_TILE_P
+    float *const GtA = sG, *const GtB = sG + 32 * ER_GSTRIDE;
+    float2 *const SrA = sS + (size_t)n * 4, *const SrB = sS + (size_t)(32 + n) * 4;
+    constexpr int XT = 3 * ER_TILE_P;
+    int jaA[4], jbA[4], jaB[4], jbB[4];
+    float4 EA[4], EB[4];
+    {   // the first two tiles' inputs, synchronously
+#pragma unroll
+        for (int m = 0; m < 8; m++) { idx_op(m, (unsigned)T0 * 32u, jaA, jbA); idx_op(m, (unsigned)(T0 + stride) * 32u, jaB, jbB); }
+#pragma unroll
+        for (int m = 0; m < 8; m++) g_issue_op(m, jaA, jbA);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { e_issue_op(k, EA, (unsigned)T0 * 16384u); e_issue_op(k, EB, (unsigned)(T0 + stride) * 16384u); }
+#pragma unroll
+        for (int m = 0; m < 12; m++) g_commit_op(m, GtA);
+#pragma unroll
+        for (int m = 0; m < 8; m++) g_issue_op(m, jaB, jbB);
+#pragma unroll
+        for (int m = 0; m < EC_OPS; m++) e_commit_op(m, EA, XA);      // (one list at a time: the operations of a list share their temporaries)
+#pragma unroll
+        for (int m = 0; m < EC_OPS; m++) e_commit_op(m, EB, XB);
+#pragma unroll
+        for (int m = 0; m < 12; m++) g_commit_op(m, GtB);
     }
+    f32x16 accA, accB, accLA, accLB;
+#pragma unroll
+    for (int r = 0; r < 16; r++) accLA[r] = accLB[r] = 0.f;
+    unsigned offA_prev = 0xfff00000u, offB_prev = 0xfff00000u;       // (no rows to write yet: past the end of any buffer this kernel takes)
+    __syncthreads();
+    int x = 0;
+    for (int tA = T0; tA < ntiles; tA += 2 * stride, x ^= 1) {
+        const int tB = tA + stride, tA2 = tA + 2 * stride, tB2 = tB + 2 * stride;
+        __bf16 *const XA0 = XA + x * XT, *const XA1 = XA + (x ^ 1) * XT, *const XB0 = XB + x * XT, *const XB1 = XB + (x ^ 1) * XT;
+        stamp();
+        // 0: layer 1 of A | LayerNorm partials of the previous B, LayerNorm's end + rows out of the previous A, the next A's indices
+        phase(0, XA0, GtA + (size_t)n * ER_GSTRIDE, accA, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, 0, 18, LNP_OPS, lnp_op(m, accLB, SrB));
+            ER_SPREAD(k, 14, 44, LNF_OPS, lnf_op(m, accLA, SrA, offA_prev));
+            ER_SPREAD(k, 44, 48, 8, idx_op(m, (unsigned)tA2 * 32u, jaA, jbA));
+        });
+        __syncthreads();
+        stamp();
+        // 1: layer 1 of B | A's ReLU + pieces, LayerNorm's end + rows out of the previous B, the next B's indices
+        phase(0, XB0, GtB + (size_t)n * ER_GSTRIDE, accB, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, 0, 32, LNF_OPS, lnf_op(m, accLB, SrB, offB_prev));
+            ER_SPREAD(k, 0, 48, RELU_OPS, relu_op(m, accA, XA1));
+            ER_SPREAD(k, 44, 48, 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
+        });
+        __syncthreads();
+        stamp();
+        // 2: layer 2 of A | B's ReLU + pieces, the next A's gathers
+        phase(1, XA1, sT, accA, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, 0, 8, 8, g_issue_op(m, jaA, jbA));
+            ER_SPREAD(k, 0, 48, RELU_OPS, relu_op(m, accB, XB1));
+            ER_SPREAD(k, 32, 48, 12, g_commit_op(m, GtA));
+        });
+        __syncthreads();
+        stamp();
+        // 3: layer 2 of B | A's ReLU + pieces, the next B's gathers, the next A's edge rows requested
+        phase(1, XB1, sT, accB, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, 0, 8, 8, g_issue_op(m, jaB, jbB));
+            ER_SPREAD(k, 8, 12, 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
+            ER_SPREAD(k, 0, 48, RELU_OPS, relu_op(m, accA, XA0));
+            ER_SPREAD(k, 32, 48, 12, g_commit_op(m, GtB));
+        });
+        __syncthreads();
+        stamp();
+        // 4: layer 3 of A | B's ReLU + pieces, the next A's edge rows cut and parked, the next B's requested
+        phase(2, XA0, sT + EM_N, accLA, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, 0, 4, 4, e_issue_op(m, EB, (unsigned)tB2 * 16384u));
+            ER_SPREAD(k, 0, 48, RELU_OPS, relu_op(m, accB, XB0));
+            ER_SPREAD(k, 4, 48, EC_OPS, e_commit_op(m, EA, XA1));
+        });
+        __syncthreads();
+        stamp();
+        // 5: layer 3 of B | A's LayerNorm partials, the next B's edge rows cut and parked
+        phase(2, XB0, sT + EM_N, accLB, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, 0, 20, LNP_OPS, lnp_op(m, accLA, SrA));
+            ER_SPREAD(k, 4, 48, EC_OPS, e_commit_op(m, EB, XB1));
+        });
+        offA_prev = (unsigned)tA * 16384u; offB_prev = (unsigned)tB * 16384u;
+        __syncthreads();
+    }
+    // the pipeline's tail: the last B's partials, both tiles' LayerNorm ends
+#pragma unroll
+    for (int m = 0; m < LNP_OPS; m++) lnp_op(m, accLB, SrB);
+#pragma unroll
+    for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLA, SrA, offA_prev);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLB, SrB, offB_prev);
 }
 
 }  // namespace

@@ -40,13 +40,12 @@ if os.environ.get("CSPLAT_EM_KERNEL", "")[:1] == "l":
              "layer-2 products (wave 0)", "ReLU + barrier: the others", "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)",
              "LayerNorm, rows x features by MFMA, barrier", "image-1 DMA issued, next round's gathers by MFMA", "rows out issued", "(next round's start)"]
     unit = "256-row round"
-else:       # k_edge_mlp3r (weights in registers): 64-row super-tiles
-    names = ["start values + layer-1 products", "ReLU, cut, pieces -> LDS", "barrier", "next rows / gathers issued, layer-2 products",
-             "pieces -> LDS, G half", "barrier", "next rows cut -> LDS, gathers issued", "layer-3 products", "LayerNorm partials, G half, indices",
-             "barrier", "normalise, rows out"]
-    unit = "64-row super-tile"
+else:       # k_edge_mlp3r (weights in registers): a pair of 32-row tiles, one phase = 48 MFMAs of one tile's layer + the side work in its gaps + barrier
+    names = ["0: A layer 1 | LN partials B', LN end + rows out A'", "1: B layer 1 | ReLU A, LN end + rows out B'", "2: A layer 2 | ReLU B, gathers A+",
+             "3: B layer 2 | ReLU A, gathers B+", "4: A layer 3 | ReLU B, edge rows A+", "5: B layer 3 | LN partials A, edge rows B+"]
+    unit = "pair of 32-row tiles"
 NS = len(names) + 1       # stamps per round incl. the next round's first
-for r in range(4 if NS < 13 else 3):
+for r in range(3 if NS == 13 else 8):
     seg = s[:, (NS - 1) * r:(NS - 1) * r + NS]
     ok = (seg > 0).all(1)
     d = np.diff(seg[ok], axis=1)
