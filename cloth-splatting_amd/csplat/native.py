@@ -108,6 +108,7 @@ EXPORTS = {
     "csplat_linear128_mode": (_i, [C.c_uint]),
     "csplat_linear128_mode_query": (C.c_uint, []),
     "csplat_gnn_node_update": (_i, [_vp, _i64] + [_vp] * 11 + [_f] + [_vp] * 5),
+    "csplat_linear_narrow128": (_i, [_vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_edge_mlp3_image_bytes": (_sz, []),
     "csplat_gnn_edge_mlp3_pack": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),

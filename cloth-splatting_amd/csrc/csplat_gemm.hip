@@ -651,6 +651,56 @@ extern "C" int csplat_linear128(void *stream, int64_t M, const float *A, const f
                                add_pre, add_post, nullptr, nullptr, out);
 }
 
+// ---- a narrow first layer: out[M,128] = (ReLU)(x[M,K] W^T + b), K <= 32 (the encoders' first Linear: 4 edge features / 8 node features
+// -> 128, /root/reference/meshnet/graph_network.py:48-111).  Paced by the 512 bytes it writes per row; W^T sits in LDS, a thread makes
+// 4 adjacent outputs of a row, the 32 threads of a row read the same K inputs (one broadcast line).
+namespace {
+constexpr int SK_ROWS = 64;               // rows per workgroup pass (8 rows x 8 passes)
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_linear_narrow(int64_t M, int K, const float *__restrict__ x, int ldx, const float *__restrict__ W,
+                                                        int ldw, const float *__restrict__ bias, float *__restrict__ out) {
+    __shared__ float4 sWt[32 * 32];       // [k][column group]: W[4g .. 4g + 3][k]
+    for (int t = threadIdx.x; t < K * 32; t += 256) {
+        const int k = t >> 5, g = t & 31;
+        sWt[t] = make_float4(W[(size_t)(4 * g) * ldw + k], W[(size_t)(4 * g + 1) * ldw + k], W[(size_t)(4 * g + 2) * ldw + k], W[(size_t)(4 * g + 3) * ldw + k]);
+    }
+    __syncthreads();
+    const int g = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t base = (int64_t)blockIdx.x * SK_ROWS; base < M; base += (int64_t)gridDim.x * SK_ROWS) {
+#pragma unroll
+        for (int p = 0; p < SK_ROWS / 8; p++) {
+            const int64_t row = base + 8 * p + r;
+            if (row >= M) break;
+            const float *xr = x + row * ldx;
+            float4 a = b;
+            for (int k = 0; k < K; k++) {
+                const float v = xr[k];
+                const float4 w = sWt[k * 32 + g];
+                a.x = fmaf(v, w.x, a.x); a.y = fmaf(v, w.y, a.y); a.z = fmaf(v, w.z, a.z); a.w = fmaf(v, w.w, a.w);
+            }
+            if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            *reinterpret_cast<float4 *>(out + row * 128 + 4 * g) = a;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int csplat_linear_narrow128(void *stream, int64_t M, int K, const float *x, int ldx, const float *W, int ldw, const float *bias,
+                                       int relu, float *out) {
+    CSPLAT_REQUIRE(M >= 0 && K >= 1 && K <= 32 && ldx >= K && ldw >= K && (M == 0 || (x && W && out)), "csplat_linear_narrow128: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)out | (uintptr_t)bias) & 15u) == 0, "csplat_linear_narrow128: out / bias must be 16-byte aligned");
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    const int64_t nb = (M + SK_ROWS - 1) / SK_ROWS;
+    const int grid = (int)(nb < 2048 ? nb : 2048);
+    if (relu) k_linear_narrow<true><<<grid, 256, 0, s>>>(M, K, x, ldx, W, ldw, bias, out);
+    else k_linear_narrow<false><<<grid, 256, 0, s>>>(M, K, x, ldx, W, ldw, bias, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W, int ldw, int w_transposed, const float *bias,
                                    float alpha, int relu, const float *gather_a, const int64_t *index_a, const float *gather_b,
                                    const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,

@@ -20,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_mlp3, edge_mlp3_pack, edge_tail_aggregate, edge_tail_ok,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_mlp3, edge_mlp3_pack, edge_tail_aggregate, edge_tail_ok, linear_narrow128,
                         layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
@@ -52,6 +52,12 @@ class Encoder(nn.Module):
                                                  nedge_out_features), nn.LayerNorm(nedge_out_features)])
 
     def forward(self, x: torch.Tensor, edge_features: torch.Tensor):
+        if not torch.is_grad_enabled():
+            # rollout: both MLPs on the HIP kernels -- the narrow first Linear in one write-paced launch, the 128-wide layers and the
+            # LayerNorm as csplat_linear128 epilogues (stock kernels took 0.86 of the 4.2 ms rollout step here: profiles/r05b)
+            xe, ee = _encode_inference(self.node_fn, x), _encode_inference(self.edge_fn, edge_features)
+            if xe is not None and ee is not None:
+                return xe, ee
         e = _tail(self.edge_fn[0], edge_features, first_has_act=False, skip_first=False)
         return self.node_fn(x), layer_norm_rows(e, self.edge_fn[1])
 
@@ -100,9 +106,20 @@ def _fused_tail(seq: nn.Sequential, h: torch.Tensor, add_post: torch.Tensor = No
     return h
 
 
-# rollout: the edge MLP of a layer as ONE launch (csplat_gnn_edge_mlp3) instead of three csplat_linear128 calls.  Off by default: parity-green and
-# measured SLOWER in round 5 (6.07 against 5.68 ms per rollout step; why: header of csrc/csplat_edge_mlp.hip).  env CSPLAT_GNN_EDGE_FUSED=1 turns it on.
-EDGE_MLP_FUSED = os.environ.get("CSPLAT_GNN_EDGE_FUSED", "0") not in ("", "0")
+def _encode_inference(seq: nn.Sequential, x: torch.Tensor):
+    """[build_mlp(K -> 128 -> ... -> 128), LayerNorm(128)] of an encoder under no_grad, or None when the shapes are not these"""
+    lins = list(seq[0].children())[0::2]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[1] <= 32 and len(lins) >= 2 and _fusable(seq)
+            and tuple(lins[0].weight.shape) == (128, x.shape[1]) and lins[0].weight.dtype == torch.float32):
+        return None
+    h = linear_narrow128(x, lins[0].weight, lins[0].bias, relu=True)
+    return _fused_tail(seq, h)
+
+
+# rollout: the edge MLP of a layer as ONE launch (csplat_gnn_edge_mlp3: weights resident in registers, the two inner [E,128] activations never in
+# HBM) instead of three csplat_linear128 calls: 150-167 us against 235-245 per layer at E = 300k, rollout step 4.16 against 5.56 ms
+# (tools/ab_edge_mlp3_rollout.py).  env CSPLAT_GNN_EDGE_FUSED=0 goes back to the three launches.
+EDGE_MLP_FUSED = os.environ.get("CSPLAT_GNN_EDGE_FUSED", "1") not in ("", "0")
 
 
 def _is_pow2(v: float) -> bool:

@@ -357,6 +357,23 @@ def linear128(A, weight, bias=None, alpha=1.0, relu=False, gather=None, layer_no
     return out
 
 
+def linear_narrow128(x, weight, bias=None, relu=False):
+    """(ReLU)(x @ weight^T + bias) for a narrow input (1 <= K <= 32 columns) and 128 outputs: the first Linear of the encoders' MLPs
+    (csplat_linear_narrow128, include/csplat.h).  No autograd graph is recorded."""
+    _n.require_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[1] <= 32 and tuple(weight.shape) == (128, x.shape[1])
+    x = x if x.stride(1) == 1 else x.contiguous()
+    w = weight.detach()
+    w = w if w.stride(1) == 1 else w.contiguous()
+    bias = None if bias is None else bias.detach().contiguous()
+    out = torch.empty(x.shape[0], 128, dtype=torch.float32, device=x.device)
+    with _n.on_device(x.device):
+        _n.check(_n.lib.csplat_linear_narrow128(_n.stream_handle(x.device), x.shape[0], x.shape[1], _n.ptr(x), int(x.stride(0)) if x.shape[0] > 1 else x.shape[1],
+                                                w.data_ptr(), int(w.stride(0)), _n.ptr(bias), int(relu), _n.ptr(out)),
+                 "csplat_linear_narrow128")
+    return out
+
+
 def edge_mlp3_pack(w0, w1, w2):
     """the three 128 x 128 weights of an edge MLP as the LDS image csplat_gnn_edge_mlp3 stages (three bf16 pieces per weight, the
     contraction index of layers 2 and 3 permuted to the register layout the previous layer leaves): pack once per weight version"""

@@ -499,6 +499,12 @@ int csplat_linear128_ex(void *stream, int64_t M, const float *A, const float *W,
                         const int64_t *index_b, const float *ln_gamma, const float *ln_beta, float ln_eps,
                         const float *add_pre, const float *add_post, const float *mask, float *ln_stats, float *out);
 
+/* out[M,128] = (ReLU)(x[M,K] W^T + bias) for a narrow input, 1 <= K <= 32: the first Linear of the encoders' MLPs
+ * (/root/reference/meshnet/graph_network.py:48-111, build_mlp's NN-0 on 4 edge / 8 node features).  W is [128][ldw >= K] row-major as
+ * nn.Linear stores it, x is [M][ldx >= K]; bias may be NULL; out is dense [M][128], 16-byte aligned. */
+int csplat_linear_narrow128(void *stream, int64_t M, int K, const float *x, int ldx, const float *W, int ldw, const float *bias, int relu,
+                            float *out);
+
 /* The WHOLE edge MLP of an InteractionNetwork layer in one launch (inference; csplat_edge_mlp.hip) -- replaces the three csplat_linear128
  * calls of rounds 1-4 for /root/reference/meshnet/graph_network.py:178-199 (`message`: LN(MLP(cat[x_i, x_j, e]))):
  *     out[e] = LayerNorm( W2 relu( W1 relu( alpha * W0 e0[e] + b0 + xa[index_a[e]] + xb[index_b[e]] ) + b1 ) + b2 ) * gamma + beta

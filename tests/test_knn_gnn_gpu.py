@@ -806,10 +806,53 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha):
     assert rel_err(out.cpu().numpy(), three.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M", [1, 63, 70_001])
+@pytest.mark.parametrize("K", [1, 4, 8, 32])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_narrow128_vs_fp64(M, K, relu):
+    """csplat_linear_narrow128 (the encoders' first Linear, K features -> 128; /root/reference/meshnet/graph_network.py:48-111) against the
+    fp64 product: plain fp32 FMAs in another order than the library's, 1e-6 of the output scale.  The weight is read with its own
+    row stride (a column slice of a wider matrix)."""
+    from meshnet.graph_ops import linear_narrow128
+    gen = torch.Generator().manual_seed(100 * K + M % 97)
+    x = torch.randn(M, K, generator=gen).cuda()
+    wide = torch.randn(128, K + 3, generator=gen).cuda()
+    W, b = wide[:, 1:K + 1], torch.randn(128, generator=gen).cuda()
+    with torch.no_grad():
+        out = linear_narrow128(x, W, b, relu=relu)
+        ref = x.double() @ W.double().t() + b.double()
+        ref = ref.relu() if relu else ref
+    assert out.shape == (M, 128) and rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+def test_encoder_rollout_path_vs_module_path():
+    """Encoder.forward under no_grad (csplat_linear_narrow128 + csplat_linear128 with ReLU / LayerNorm epilogues, no stock kernel) against the
+    same module with autograd on (the training path: library GEMMs + LayerNorm128) and against the fp64 composition."""
+    import meshnet.graph_network as gn
+    from csplat import native
+    torch.manual_seed(4)
+    enc = gn.Encoder(8, 128, 4, 128, 2, 128).cuda()
+    gen = torch.Generator().manual_seed(5)
+    x, e = torch.randn(1201, 8, generator=gen).cuda(), torch.randn(30_011, 4, generator=gen).cuda()
+    with torch.no_grad():
+        native.prof_enable(["GNN"]); native.prof_read("GNN")
+        xn, en = enc(x, e)
+        torch.cuda.synchronize()
+        _ms, launches = native.prof_read("GNN"); native.prof_enable([])
+    assert launches == 6, launches            # 3 per MLP: narrow first layer, 128 x 128 + ReLU, 128 x 128 + LayerNorm
+    xg, eg = enc(x, e)
+    enc64 = gn.Encoder(8, 128, 4, 128, 2, 128).double().cuda()
+    enc64.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
+    with torch.no_grad():
+        x64 = enc64.node_fn(x.double()); e64 = enc64.edge_fn(e.double())
+    for a, g, r in ((xn, xg, x64), (en, eg, e64)):
+        assert rel_err(a.cpu().numpy(), r.cpu().numpy()) < 1e-5
+        assert rel_err(a.cpu().numpy(), g.detach().cpu().numpy()) < 1e-5
+
+
 def test_rollout_with_and_without_the_fused_edge_mlp():
-    """EncodeProcessDecode under no_grad with the one-launch edge MLP (graph_network.EDGE_MLP_FUSED = True; opt-in, it is not faster) and
-    with the three launches of rounds 1-4 (the default): the same network output to 1e-5, on a graph whose edge count is not a multiple
-    of 256."""
+    """EncodeProcessDecode under no_grad with the one-launch edge MLP (graph_network.EDGE_MLP_FUSED = True, the default) and with the
+    three launches of rounds 1-4: the same network output to 1e-5, on a graph whose edge count is not a multiple of 64."""
     import meshnet.graph_network as gn
     torch.manual_seed(9)
     net = gn.EncodeProcessDecode(8, 3, 4, 128, 5, 2, 128).cuda()
