@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsplat.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -111,7 +111,9 @@ EXPORTS = {
     "csplat_linear_narrow128": (_i, [_vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_edge_mlp3_image_bytes": (_sz, []),
     "csplat_gnn_edge_mlp3_pack": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
-    "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "csplat_gnn_edge_mlp3_mode": (_i, [_i]),
+    "csplat_absmax": (_i, [_vp, _i64, _vp, _vp]),
     "csplat_linear128": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_linear128_ex": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -20,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, edge_latent_linear, edge_mlp3, edge_mlp3_pack, edge_tail_aggregate, edge_tail_ok, linear_narrow128,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, edge_tail_ok, linear_narrow128,
                         layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
@@ -202,14 +202,15 @@ class InteractionNetwork(nn.Module):
 
     def _edge_image(self, w_e, elins):
         """the packed LDS image of the edge MLP's three weights, re-packed only when a weight changed"""
-        key = (self._wsplit_key, elins[1].weight._version, elins[2].weight._version, elins[1].weight.data_ptr(), elins[2].weight.data_ptr())
+        key = (self._wsplit_key, elins[1].weight._version, elins[2].weight._version, elins[1].weight.data_ptr(), elins[2].weight.data_ptr(),
+               edge_mlp3_mode())
         if getattr(self, "_eimg_key", None) != key:
             with torch.no_grad():
                 self._eimg = edge_mlp3_pack(w_e, elins[1].weight, elins[2].weight)
             self._eimg_key = key
         return self._eimg
 
-    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None):
+    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None, e0_absmax=None):
         """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd.
         Per layer the [E,128] activations make three read+write passes (one per Linear, with gather / bias / ReLU /
         LayerNorm in the epilogues) and one read by the segmented sum; the node level is ONE launch
@@ -225,7 +226,7 @@ class InteractionNetwork(nn.Module):
             # the whole message MLP + LayerNorm in ONE launch: the two inner [E,128] activations never leave the registers
             # (csplat_gnn_edge_mlp3; the weights' LDS image is packed once per weight version)
             msg = edge_mlp3(e0, scale, xa, csr.ei[1], xb, csr.ei[0], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,
-                            elins[2].bias, self.edge_fn[1])
+                            elins[2].bias, self.edge_fn[1], e0_absmax=e0_absmax)
         else:
             h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
             msg = _fused_tail(self.edge_fn, h)
@@ -251,16 +252,20 @@ class Processor(nn.Module):
                                nmlp_layers=nmlp_layers, mlp_hidden_dim=mlp_hidden_dim)
             for _ in range(nmessage_passing_steps)])
 
-    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor, edges_out: bool = True):
+        """edges_out=False (EncodeProcessDecode, which drops them): the rollout path returns None for the edge latents instead of spending
+        a pass over [E,128] on 2^M * e0"""
         if len(self.gnn_stacks) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks):
             # rollout: every layer doubles the edge features (F7), so carry e0 and the scalar 2^l instead of 15 [E,128] passes
             e0, scale = edge_features.contiguous(), 1.0
             xa = xb = None
+            # (the fp16 pieces of the one-launch edge MLP take their scale from max |e0|: one pass for all the layers)
+            amax = absmax(e0) if EDGE_MLP_FUSED and edge_mlp3_mode() == 0 and e0.numel() else None
             for l, gnn in enumerate(self.gnn_stacks):
                 nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
-                x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt)
+                x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt, e0_absmax=amax)
                 scale *= 2.0
-            return x, e0 * scale
+            return x, (e0 * scale if edges_out else None)
         if len(self.gnn_stacks) and not torch.is_grad_enabled():
             # inference on a form the one-pass rollout kernels do not cover (they are built for the 128-wide fp32 network of config 4)
             from csplat import native as _n
@@ -301,6 +306,6 @@ class EncodeProcessDecode(nn.Module):
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
         x, edge_features = self._encoder(x, edge_features)
-        x, edge_features = self._processor(x, edge_index, edge_features)
+        x, _edges = self._processor(x, edge_index, edge_features, edges_out=False)
         x = self._decoder(x)
         return x

@@ -374,9 +374,27 @@ def linear_narrow128(x, weight, bias=None, relu=False):
     return out
 
 
+def edge_mlp3_mode(mode=None):
+    """the arithmetic of csplat_gnn_edge_mlp3 (include/csplat.h): 0 = two fp16 pieces per operand (default), 1 = three bf16 pieces (fp32's
+    exponent range).  Returns the mode that was set before; None only queries.  An image is packed FOR a mode."""
+    return int(_n.lib.csplat_gnn_edge_mlp3_mode(-1 if mode is None else int(mode)))
+
+
+def absmax(x):
+    """max |x| as a one-element device tensor (csplat_absmax: one pass, no host read) -- what edge_mlp3 takes its fp16 scale from"""
+    _n.require_cuda(x)
+    x = _f32(x)
+    assert x.numel() % 4 == 0
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    with _n.on_device(x.device):
+        _n.check(_n.lib.csplat_absmax(_n.stream_handle(x.device), x.numel(), _n.ptr(x), _n.ptr(out)), "csplat_absmax")
+    return out
+
+
 def edge_mlp3_pack(w0, w1, w2):
-    """the three 128 x 128 weights of an edge MLP as the LDS image csplat_gnn_edge_mlp3 stages (three bf16 pieces per weight, the
-    contraction index of layers 2 and 3 permuted to the register layout the previous layer leaves): pack once per weight version"""
+    """the three 128 x 128 weights of an edge MLP as the register image csplat_gnn_edge_mlp3 loads (the 16-bit pieces of every wave's 32
+    output rows as MFMA A operands, the contraction index of layers 2 and 3 permuted to the order the previous layer leaves its
+    activations in): pack once per weight version and per edge_mlp3_mode"""
     img = torch.empty(int(_n.lib.csplat_gnn_edge_mlp3_image_bytes()), dtype=torch.uint8, device=w0.device)
     ws = []
     for w in (w0, w1, w2):
@@ -392,10 +410,11 @@ def edge_mlp3_pack(w0, w1, w2):
     return img
 
 
-def edge_mlp3(e0, alpha, xa, ia, xb, ib, image, b0, b1, b2, layer_norm, out=None):
+def edge_mlp3(e0, alpha, xa, ia, xb, ib, image, b0, b1, b2, layer_norm, out=None, e0_absmax=None):
     """Inference-only message of one InteractionNetwork layer in ONE launch (csplat_gnn_edge_mlp3, include/csplat.h):
         out = LN( W2 relu( W1 relu( alpha * W0 e0 + b0 + xa[ia] + xb[ib] ) + b1 ) + b2 )
-    the two inner [E,128] activations stay in registers (graph_network.py:178-199).  image = edge_mlp3_pack(W0, W1, W2)."""
+    the two inner [E,128] activations never leave the chip (graph_network.py:178-199).  image = edge_mlp3_pack(W0, W1, W2) under the
+    current edge_mlp3_mode; e0_absmax = absmax(e0) (or of a tensor e0 is a slice of), computed here when not handed in (mode 0 only)."""
     _n.require_cuda(e0)
     e0, xa, xb = _f32(e0), _f32(xa), _f32(xb)
     E = e0.shape[0]
@@ -403,10 +422,12 @@ def edge_mlp3(e0, alpha, xa, ia, xb, ib, image, b0, b1, b2, layer_norm, out=None
     ia, ib = ia.contiguous(), ib.contiguous()
     assert ia.dtype == torch.int64 and ib.dtype == torch.int64 and ia.numel() == E and ib.numel() == E
     out = torch.empty_like(e0) if out is None else out
+    if e0_absmax is None and E > 0 and edge_mlp3_mode() == 0:
+        e0_absmax = absmax(e0)
     c = lambda t: t.detach().contiguous()  # noqa: E731
     with _n.on_device(e0.device):
-        _n.check(_n.lib.csplat_gnn_edge_mlp3(_n.stream_handle(e0.device), E, _n.ptr(e0), float(alpha), _n.ptr(xa), _n.ptr(ia), _n.ptr(xb),
-                                             _n.ptr(ib), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b1)), _n.ptr(c(b2)),
+        _n.check(_n.lib.csplat_gnn_edge_mlp3(_n.stream_handle(e0.device), E, _n.ptr(e0), float(alpha), _n.ptr(e0_absmax), _n.ptr(xa), _n.ptr(ia),
+                                             _n.ptr(xb), _n.ptr(ib), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b1)), _n.ptr(c(b2)),
                                              _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps), _n.ptr(out)),
                  "csplat_gnn_edge_mlp3")
     return out

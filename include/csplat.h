@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CSPLAT_ABI_VERSION 4   /* round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2, csplat_gnn_edge_mlp3* */
+#define CSPLAT_ABI_VERSION 5   /* round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
 
 /* scratch chunks requested through the allocator callback */
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
@@ -508,16 +508,24 @@ int csplat_linear_narrow128(void *stream, int64_t M, int K, const float *x, int 
 /* The WHOLE edge MLP of an InteractionNetwork layer in one launch (inference; csplat_edge_mlp.hip) -- replaces the three csplat_linear128
  * calls of rounds 1-4 for /root/reference/meshnet/graph_network.py:178-199 (`message`: LN(MLP(cat[x_i, x_j, e]))):
  *     out[e] = LayerNorm( W2 relu( W1 relu( alpha * W0 e0[e] + b0 + xa[index_a[e]] + xb[index_b[e]] ) + b1 ) + b2 ) * gamma + beta
- * e0 / out [E][128] fp32 (out != e0), xa / xb [N][128] (the node-level x_i / x_j column-block products of the first Linear), index_a /
- * index_b int64 [E], alpha a power of two (the edge scale 2^l of SURVEY F7).  `image` = the three weight matrices as
- * csplat_gnn_edge_mlp3_pack lays them out (csplat_gnn_edge_mlp3_image_bytes() bytes of device memory, 16-byte aligned): per layer the
- * three bf16 pieces of W (fp32-level accuracy on the bf16 matrix cores, as csplat_linear128_mode 1) in the byte order the kernel copies
- * into LDS.  Pack once per weight version: W_l is read as W_l[j * ld_l + k] (a Linear.weight or a 128-column slice of a wider one). */
+ * e0 / out [E][128] fp32 (out != e0), xa / xb [N][128] (the node-level x_i / x_j column-block products of the first Linear; N < 2^23),
+ * index_a / index_b int64 [E], alpha a power of two (the edge scale 2^l of SURVEY F7).  `image` = the three weight matrices as
+ * csplat_gnn_edge_mlp3_pack lays them out (csplat_gnn_edge_mlp3_image_bytes() bytes of device memory, 16-byte aligned): per wave of the
+ * kernel the 16-bit pieces of its 32 output rows of the three W as MFMA A operands, in the order the kernel loads them into registers.
+ * Pack once per weight version AND mode: W_l is read as W_l[j * ld_l + k] (a Linear.weight or a 128-column slice of a wider one).
+ * csplat_gnn_edge_mlp3_mode(mode) selects the arithmetic and returns the previous mode (any other value only queries):
+ *   0 (default)  two fp16 pieces per operand, three products: 3e-7 of the output scale against fp64 inside its domain -- the values are
+ *                brought into fp16's range by a power of two taken from e0_absmax = the device word csplat_absmax leaves (max |e0| over
+ *                the launch's rows or over a superset of them; NULL = 1.0).  Domain and failure mode: header of csplat_edge_mlp.hip.
+ *   1            three bf16 pieces per operand, six products: fp32's exponent range, 7e-7 against fp64; e0_absmax is not read.
+ * csplat_absmax(n, x, out): *out = max |x[i]| (n a multiple of 4, x 16-byte aligned; one pass, asynchronous on `stream`). */
+int csplat_gnn_edge_mlp3_mode(int mode);
 size_t csplat_gnn_edge_mlp3_image_bytes(void);
 int csplat_gnn_edge_mlp3_pack(void *stream, const float *W0, int ld0, const float *W1, int ld1, const float *W2, int ld2, void *image);
-int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, float alpha, const float *xa, const int64_t *index_a, const float *xb,
-                         const int64_t *index_b, const void *image, const float *b0, const float *b1, const float *b2,
-                         const float *ln_gamma, const float *ln_beta, float ln_eps, float *out);
+int csplat_absmax(void *stream, int64_t n, const float *x, float *out);
+int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, float alpha, const float *e0_absmax, const float *xa,
+                         const int64_t *index_a, const float *xb, const int64_t *index_b, const void *image, const float *b0,
+                         const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out);
 
 /* The per-step activations of the Gaussian parameters as render() consumes them (/root/reference/scene_reconstruction/
  * gaussian_model.py:96-121 via gaussian_renderer/__init__.py:92-118): opacity[P] = sigmoid(opacity_raw), scales[P][3] = exp(scaling_raw),

@@ -771,15 +771,16 @@ def test_sim_hidden_layers_match_composed_torch_fwd_bwd(T):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("E", [1, 31, 257, 4100, 70_001])       # ragged: the last 32-row tile and the last 256-row round are partial
+@pytest.mark.parametrize("E", [1, 31, 257, 4100, 70_001])       # ragged: the last 32-row tile is partial, odd and even tile counts per workgroup
 @pytest.mark.parametrize("alpha", [1.0, 8.0, 16384.0])           # 2^l, l = 0 .. 14 on the 15-layer network
-def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha):
+@pytest.mark.parametrize("mode", [0, 1])                         # two fp16 pieces (default) / three bf16 pieces per operand
+def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha, mode):
     """csplat_gnn_edge_mlp3 (the whole message MLP of an InteractionNetwork layer in one launch: gathers + three 128 x 128 layers +
     LayerNorm, inner activations in registers; /root/reference/meshnet/graph_network.py:178-199) against the fp64 composition
     (1e-5 of the output scale -- the bar of csplat_linear128) and against the three csplat_linear128 launches it replaces (same
     products on the same matrix cores in another order: 1e-5).  e0 is scaled so that alpha * e0 stays O(1), as the network's
     LayerNorm'd edge latents do."""
-    from meshnet.graph_ops import edge_mlp3, edge_mlp3_pack, linear128
+    from meshnet.graph_ops import edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, linear128
     gen = torch.Generator().manual_seed(E + int(alpha))
     Nn = 91
     e0 = (torch.randn(E, 128, generator=gen) / alpha).cuda()
@@ -792,8 +793,12 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha):
     W0 = wide[:, 256:]
     with torch.no_grad():
         norm.weight.copy_(torch.randn(128, generator=gen)); norm.bias.copy_(torch.randn(128, generator=gen))
-        img = edge_mlp3_pack(W0, W[1], W[2])
-        out = edge_mlp3(e0, alpha, xa, ia, xb, ib, img, b[0], b[1], b[2], norm)
+        was = edge_mlp3_mode(mode)
+        try:
+            img = edge_mlp3_pack(W0, W[1], W[2])
+            out = edge_mlp3(e0, alpha, xa, ia, xb, ib, img, b[0], b[1], b[2], norm)
+        finally:
+            edge_mlp3_mode(was)
         h = (alpha * (e0.double() @ W0.double().t()) + b[0].double() + xa.double()[ia] + xb.double()[ib]).relu()
         h = (h @ W[1].double().t() + b[1].double()).relu()
         h = h @ W[2].double().t() + b[2].double()
@@ -804,6 +809,38 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha):
     assert out.shape == (E, 128) and torch.isfinite(out).all()
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
     assert rel_err(out.cpu().numpy(), three.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("scale", [1.0, 1e-3, 300.0])
+def test_edge_mlp3_network_magnitudes(mode, scale):
+    """What the rollout really feeds csplat_gnn_edge_mlp3: LayerNorm'd edge latents of O(1) -- here also 1e-3 and 300 times that -- under
+    alpha = 2^l up to 16384, so that layer 1's pre-activations reach 1e4-1e6 before the final LayerNorm brings them back.  Mode 0 keeps its
+    fp16 pieces in range by the power of two it takes from max |e0| (csplat_absmax); both modes hold 1e-5 of the output scale against
+    the fp64 composition."""
+    from meshnet.graph_ops import absmax, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack
+    E, Nn = 20_001, 700
+    for alpha in (1.0, 64.0, 16384.0):
+        gen = torch.Generator().manual_seed(int(alpha) + mode)
+        e0 = (torch.randn(E, 128, generator=gen) * scale).cuda()
+        W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(3)]
+        b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+        xa, xb = torch.randn(Nn, 128, generator=gen).cuda() * 2, torch.randn(Nn, 128, generator=gen).cuda() * 2
+        ia, ib = torch.randint(0, Nn, (E,), generator=gen).cuda(), torch.randint(0, Nn, (E,), generator=gen).cuda()
+        norm = torch.nn.LayerNorm(128).cuda()
+        with torch.no_grad():
+            am = absmax(e0)
+            assert float(am) == float(e0.abs().max())
+            was = edge_mlp3_mode(mode)
+            try:
+                out = edge_mlp3(e0, alpha, xa, ia, xb, ib, edge_mlp3_pack(*W), b[0], b[1], b[2], norm, e0_absmax=am)
+            finally:
+                edge_mlp3_mode(was)
+            h = (alpha * (e0.double() @ W[0].double().t()) + b[0].double() + xa.double()[ia] + xb.double()[ib]).relu()
+            h = (h @ W[1].double().t() + b[1].double()).relu()
+            ref = torch.nn.functional.layer_norm(h @ W[2].double().t() + b[2].double(), (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+        assert torch.isfinite(out).all()
+        assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5, (alpha, scale)
 
 
 @pytest.mark.parametrize("M", [1, 63, 70_001])

@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
-from meshnet.graph_ops import edge_mlp3, edge_mlp3_pack, linear128  # noqa: E402
+from meshnet.graph_ops import absmax, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, linear128  # noqa: E402
 
 E, N = int(os.environ.get("E", 300_000)), 10_000
 gen = torch.Generator().manual_seed(0)
@@ -22,13 +22,15 @@ src = (dst + torch.randint(-60, 60, (E,), generator=gen)).clamp(0, N - 1)
 perm = torch.argsort(src * N + dst)
 ia, ib = dst[perm].cuda(), src[perm].cuda()
 norm = torch.nn.LayerNorm(128).cuda()
+edge_mlp3_mode(int(os.environ.get("EM_MODE", "0")))      # 0: two fp16 pieces, 1: three bf16 pieces
 img = edge_mlp3_pack(*W)
+amax = absmax(e0)
 out = torch.empty_like(e0)
 t1, t2 = torch.empty_like(e0), torch.empty_like(e0)
 
 
 def fused():
-    edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out)
+    edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax)
 
 
 def three():

@@ -10,7 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cloth-splatting_amd"))
 from csplat import native  # noqa: E402
-from meshnet.graph_ops import edge_mlp3, edge_mlp3_pack  # noqa: E402
+from meshnet.graph_ops import absmax, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack  # noqa: E402
 
 E, N = 300_000, 10_000
 gen = torch.Generator().manual_seed(0)
@@ -23,24 +23,23 @@ src = (dst + torch.randint(-60, 60, (E,), generator=gen)).clamp(0, N - 1)
 perm = torch.argsort(src * N + dst)
 ia, ib = dst[perm].cuda(), src[perm].cuda()
 norm = torch.nn.LayerNorm(128).cuda()
+edge_mlp3_mode(int(os.environ.get("EM_MODE", "0")))      # 0: two fp16 pieces, 1: three bf16 pieces
 img = edge_mlp3_pack(*W)
+amax = absmax(e0)
 out = torch.empty_like(e0)
 buf = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
 with torch.no_grad():
     for _ in range(3):
-        edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out)
+        edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax)
     torch.cuda.synchronize()
     native.lib.csplat_debug_stamps(buf.data_ptr(), buf.numel() * 8)
-    edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out)
+    edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax)
     torch.cuda.synchronize()
     native.lib.csplat_debug_stamps(None, 0)
 s = buf.cpu().numpy().reshape(256, 64).astype(np.int64)
-if os.environ.get("CSPLAT_EM_KERNEL", "")[:1] == "l":
-    names = ["wait: image-1 + barrier", "layer-1 products (wave 0)", "ReLU + barrier: the other waves", "image-2 DMA -> landed + barrier",
-             "layer-2 products (wave 0)", "ReLU + barrier: the others", "image-3 DMA -> landed + barrier", "layer-3 products (wave 0; next rows fetched)",
-             "LayerNorm, rows x features by MFMA, barrier", "image-1 DMA issued, next round's gathers by MFMA", "rows out issued", "(next round's start)"]
-    unit = "256-row round"
-else:       # k_edge_mlp3r (weights in registers): a pair of 32-row tiles, one phase = 48 MFMAs of one tile's layer + the side work in its gaps + barrier
+if False:
+    pass
+else:       # k_edge_mlp3r (weights in registers): a pair of 32-row tiles, one phase = the 24 (fp16 pieces) / 48 (bf16 pieces) MFMAs of one tile's layer + the side work in its gaps + barrier
     names = ["0: A layer 1 | LN partials B', LN end + rows out A'", "1: B layer 1 | ReLU A, LN end + rows out B'", "2: A layer 2 | ReLU B, gathers A+",
              "3: B layer 2 | ReLU A, gathers B+", "4: A layer 3 | ReLU B, edge rows A+", "5: B layer 3 | LN partials A, edge rows B+"]
     unit = "pair of 32-row tiles"
