@@ -73,7 +73,9 @@ template <bool F16> struct ErCfg {
     static constexpr int NW = 3 * NP * 8;                 // A operands per wave
     static constexpr int XT = NP * ER_TILE_P;             // elements of one tile buffer
     static constexpr size_t X_BYTES = (size_t)4 * XT * 2; // [slot 2][buffer 2]: 104,448 / 69,632
-    static constexpr size_t LDS_BYTES = X_BYTES + ER_G_BYTES + ER_S_BYTES + ER_T_BYTES;
+    static constexpr bool ROWS_VIA_LDS = F16;             // finished rows cross LDS and leave as whole rows (room for it with two pieces only)
+    static constexpr size_t Y_BYTES = ROWS_VIA_LDS ? ER_G_BYTES : 0;      // [slot 2][32][ER_GSTRIDE] floats
+    static constexpr size_t LDS_BYTES = X_BYTES + ER_G_BYTES + ER_S_BYTES + ER_T_BYTES + Y_BYTES;
     static constexpr size_t IMAGE_BYTES = (size_t)4 * NW * 64 * 16;      // [wave][layer][piece][step][lane] x 16 B: 294,912 / 196,608
 };
 
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     float *const sG = reinterpret_cast<float *>(s_mem + C::X_BYTES);                          // [slot 2][32][ER_GSTRIDE]
     float2 *const sS = reinterpret_cast<float2 *>(s_mem + C::X_BYTES + ER_G_BYTES);           // [slot 2][32][wave 4] (sum, M2)
     float *const sT = reinterpret_cast<float *>(s_mem + C::X_BYTES + ER_G_BYTES + ER_S_BYTES);      // b1, b2, gamma, beta
+    float *const sY = reinterpret_cast<float *>(s_mem + C::X_BYTES + ER_G_BYTES + ER_S_BYTES + ER_T_BYTES);      // finished rows [slot 2][32][ER_GSTRIDE]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
 
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     const int st_lane = n * 512 + (32 * w + 4 * h) * 4;
     float4 lf_u0, lf_u1, lf_ga, lf_be;
     float lf_mean = 0.f, lf_m2 = 0.f, lf_rstd = 0.f, lf_nm = 0.f, lf_y[4];
-    auto lnf_op = [&](int m, const f32x16 &acc, const float2 *srow, unsigned tile_off) __attribute__((always_inline)) {
+    auto lnf_op = [&](int m, const f32x16 &acc, const float2 *srow, unsigned tile_off, float *Yt) __attribute__((always_inline)) {
         if (m == 0) {
             lf_u0 = *reinterpret_cast<const float4 *>(srow); lf_u1 = *reinterpret_cast<const float4 *>(srow + 2);
         } else if (m == 1) {
@@ -306,28 +309,45 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
                     lf_ga = *reinterpret_cast<const float4 *>(sT + 2 * EM_N + f); lf_be = *reinterpret_cast<const float4 *>(sT + 3 * EM_N + f);
                 }
             } else {
-                i32x4 v;
-                v[0] = __float_as_int(lf_y[0]); v[1] = __float_as_int(lf_y[1]); v[2] = __float_as_int(lf_y[2]); v[3] = __float_as_int(lf_y[3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, r_out, st_lane + tile_off + 32 * q, 0, 0);
+                if (C::ROWS_VIA_LDS) {
+                    *reinterpret_cast<float4 *>(Yt + (size_t)n * ER_GSTRIDE + 32 * w + 8 * q + 4 * h) = make_float4(lf_y[0], lf_y[1], lf_y[2], lf_y[3]);
+                } else {      // 16 bytes of the lane's own row: 32 lines per instruction
+                    i32x4 v;
+                    v[0] = __float_as_int(lf_y[0]); v[1] = __float_as_int(lf_y[1]); v[2] = __float_as_int(lf_y[2]); v[3] = __float_as_int(lf_y[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, r_out, st_lane + tile_off + 32 * q, 0, 0);
+                }
             }
         }
+    };
+    // ---- (ROWS_VIA_LDS) the finished tile leaves as WHOLE rows, a phase after LayerNorm parked it: a wave takes rows 8w .. 8w + 7, two per
+    // instruction -- 8 cache lines per store instead of the 32 a lane-owns-its-row store touches (the L1 / address unit prices a memory
+    // instruction by its lines, and the rows out were the dearest thing in the kernel: tools/edge_mlp3_skip_ab.sh).  8 operations
+    const int ld_lane = (8 * w + h) * 512 + 16 * n;       // (loader / whole-row layout: half-wave per row, 16 bytes per lane)
+    float4 ro[2];
+    auto rows_out_op = [&](int m, const float *Yt, unsigned tile_off) __attribute__((always_inline)) {
+        constexpr int RDK[8] = {0, 1, -1, 2, -1, 3, -1, -1}, STK[8] = {-1, -1, 0, -1, 1, -1, 2, 3};
+        if (RDK[m] >= 0) ro[RDK[m] & 1] = *reinterpret_cast<const float4 *>(Yt + (size_t)(8 * w + 2 * RDK[m] + h) * ER_GSTRIDE + 4 * n);
+        if (STK[m] >= 0 && !(EM_SKIP & 64))
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ro[STK[m] & 1]), r_out, ld_lane + tile_off + 1024 * STK[m], 0, 0);
     };
     // ---- loaders.  A wave brings in rows 8w .. 8w + 7 of a tile, two rows per instruction (half-wave per row, 16 bytes per lane): global
     // memory only ever sees whole rows.  Buffer loads: what lies past the last row reads as zero (edge rows) / index 0 (gathers)
     const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc((void *)e0, 0, (int)(M * 512), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_ia = __builtin_amdgcn_make_buffer_rsrc((void *)ia, 0, (int)(M * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_ib = __builtin_amdgcn_make_buffer_rsrc((void *)ib, 0, (int)(M * 8), 0x00020000);
-    const int ld_lane = (8 * w + h) * 512 + 16 * n, ix_lane = (8 * w + h) * 8;
+    const int ix_lane = (8 * w + h) * 8;
     // the gather indices of the wave's rows, already where the gathers want them: lane (n, h), k <-> row 8w + 2k + h (8 operations; one
     // 8-lane load per array + a lane exchange measured 2 % slower, tools/edge_mlp3_lib_ab.sh)
     auto idx_op = [&](int m, unsigned tile_rows, int (&ja)[4], int (&jb)[4]) __attribute__((always_inline)) {
         const int k = m >> 1;
+        if (EM_SKIP & 512) return;
         if (m & 1) jb[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ib, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
         else ja[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ia, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
     };
     float4 GA[4], GB[4];
     auto g_issue_op = [&](int m, const int (&ja)[4], const int (&jb)[4]) __attribute__((always_inline)) {      // 8 operations
         const int k = m >> 1;
+        if (EM_SKIP & 256) return;
         if (m & 1) GB[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xb) + (size_t)((unsigned)jb[k] * 512u + 16u * n));
         else GA[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xa) + (size_t)((unsigned)ja[k] * 512u + 16u * n));
     };
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         } else *reinterpret_cast<float4 *>(Gt + (size_t)(8 * w + 2 * k + h) * ER_GSTRIDE + 4 * n) = GA[k];
     };
     auto e_issue_op = [&](int k, float4 (&E)[4], unsigned tile_off) __attribute__((always_inline)) {      // 4 operations
-        E[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_e0, ld_lane + tile_off + 1024 * k, 0, 0));
+        if (!(EM_SKIP & 128)) E[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_e0, ld_lane + tile_off + 1024 * k, 0, 0));
     };
     // an edge row's 16 bytes (times cs) cut into the NP pieces, parked as layer 1's B operand: per 16 bytes (scale) (pack, write), then per
     // further piece 4 x (-) and (pack, write)
@@ -406,7 +426,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     const int T0 = blockIdx.x, stride = gridDim.x, ntiles = (int)((M + 31) / 32);
     constexpr int XT = C::XT;
     el16 *const XA = sX, *const XB = sX + 2 * XT;       // slot s, buffer b: sX + (2s + b) * XT
-    float *const GtA = sG, *const GtB = sG + 32 * ER_GSTRIDE;
+    float *const GtA = sG, *const GtB = sG + 32 * ER_GSTRIDE, *const YtA = sY, *const YtB = sY + 32 * ER_GSTRIDE;
     float2 *const SrA = sS + (size_t)n * 4, *const SrB = sS + (size_t)(32 + n) * 4;
     // Memory schedule of a pair cycle.  By elimination (tools/edge_mlp3_skip_ab.sh, fp16 pieces, 115 us: without the rows out 91, without the
     // edge rows 96, without the gathers 101, without the index loads 108, without the ReLU + cut's ~290 vector instructions 113, bare MFMA
@@ -448,14 +468,15 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         // 0: layer 1 of A | LayerNorm partials of the previous B, LayerNorm's end + rows out of the previous A, the next A's indices
         phase(0, XA0, GtA + (size_t)n * ER_GSTRIDE, accA, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 2)) ER_SPREAD(k, SL(0), SL(18), LNP_OPS, lnp_op(m, accLB, SrB));
-            if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(14), SL(44), LNF_OPS, lnf_op(m, accLA, SrA, offA_prev));
+            if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(14), SL(44), LNF_OPS, lnf_op(m, accLA, SrA, offA_prev, YtA));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(44), SL(48), 8, idx_op(m, (unsigned)tA2 * 32u, jaA, jbA));
         });
         __syncthreads();
         stamp();
         // 1: layer 1 of B | A's ReLU + pieces, LayerNorm's end + rows out of the previous B, the next B's indices
         phase(0, XB0, GtB + (size_t)n * ER_GSTRIDE, accB, [&](int k) __attribute__((always_inline)) {
-            if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(0), SL(32), LNF_OPS, lnf_op(m, accLB, SrB, offB_prev));
+            if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(0), SL(32), LNF_OPS, lnf_op(m, accLB, SrB, offB_prev, YtB));
+            if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(40), 8, rows_out_op(m, YtA, offA_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA1));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(44), SL(48), 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
         });
@@ -464,6 +485,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         // 2: layer 2 of A | B's ReLU + pieces, the next A's gathers
         phase(1, XA1, sT, accA, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(0), SL(8), 8, g_issue_op(m, jaA, jbA));
+            if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
+            if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(32), 8, rows_out_op(m, YtB, offB_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB1));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 12, g_commit_op(m, GtA));
         });
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         // 3: layer 2 of B | A's ReLU + pieces, the next B's gathers, the next A's edge rows requested
         phase(1, XB1, sT, accB, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(0), SL(8), 8, g_issue_op(m, jaB, jbB));
-            if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(8), SL(12), 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
+            if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EB, (unsigned)tB2 * 16384u));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA0));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 12, g_commit_op(m, GtB));
         });
@@ -480,7 +503,6 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         stamp();
         // 4: layer 3 of A | B's ReLU + pieces, the next A's edge rows cut and parked, the next B's requested
         phase(2, XA0, sT + EM_N, accLA, [&](int k) __attribute__((always_inline)) {
-            if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(0), SL(4), 4, e_issue_op(m, EB, (unsigned)tB2 * 16384u));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB0));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(4), SL(48), EC_OPS, e_commit_op(m, EA, XA1));
         });
@@ -494,14 +516,21 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         offA_prev = (unsigned)tA * 16384u; offB_prev = (unsigned)tB * 16384u;
         __syncthreads();
     }
-    // the pipeline's tail: the last B's partials, both tiles' LayerNorm ends
+    // the pipeline's tail: the last B's partials, both tiles' LayerNorm ends, their rows out
 #pragma unroll
     for (int m = 0; m < LNP_OPS; m++) lnp_op(m, accLB, SrB);
 #pragma unroll
-    for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLA, SrA, offA_prev);
+    for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLA, SrA, offA_prev, YtA);
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLB, SrB, offB_prev);
+    for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLB, SrB, offB_prev, YtB);
+    if (C::ROWS_VIA_LDS) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) rows_out_op(m, YtA, offA_prev);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; m++) rows_out_op(m, YtB, offB_prev);
+    }
 #undef SL
 }
 }  // namespace
