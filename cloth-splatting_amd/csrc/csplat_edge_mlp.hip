@@ -129,14 +129,16 @@ __global__ __launch_bounds__(256) void k_absmax(int64_t n4, const float4 *__rest
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
 }
 
-template <bool F16>
+template <bool F16, bool AGG>
 __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__restrict__ e0, float alpha, const float *__restrict__ e0_absmax,
                                                     const float *__restrict__ xa, const int64_t *__restrict__ ia,
                                                     const float *__restrict__ xb, const int64_t *__restrict__ ib,
                                                     const i32x4 *__restrict__ wimg, const float *__restrict__ b0,
                                                     const float *__restrict__ b1, const float *__restrict__ b2,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                    float *__restrict__ out, unsigned long long *__restrict__ stamps) {
+                                                    float *__restrict__ out, const int *__restrict__ group_piece0, float *__restrict__ pieces,
+                                                    unsigned long long *__restrict__ stamps) {
+    static_assert(!AGG || ErCfg<F16>::ROWS_VIA_LDS, "the fused aggregation reads the finished tile from LDS");
     typedef ErCfg<F16> C;
     constexpr int NP = C::NP, NS = C::NS;
     extern __shared__ char s_mem[];
@@ -330,6 +332,42 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         if (STK[m] >= 0 && !(EM_SKIP & 64))
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ro[STK[m] & 1]), r_out, ld_lane + tile_off + 1024 * STK[m], 0, 0);
     };
+    // ---- (AGG) ... or does not leave at all: the tile's rows are in DESTINATION order (the caller permuted the edge list), so what the
+    // network needs of them -- their sum per destination node, /root/reference/meshnet/graph_network.py:201-222 (aggr = 'add') -- is a sum
+    // over runs of consecutive rows.  A wave sums ITS 8 rows (lane <-> two columns) run by run and writes one 512-byte "piece" per run:
+    // pieces are cut where the destination changes and every 8 rows, numbered in row order (group_piece0[g] = first piece of rows 8g ..
+    // 8g + 7, prepared once per graph), so each piece has exactly one writer and the caller adds a node's few consecutive pieces in a
+    // fixed order: deterministic, no atomics, and ~E / 8 + N rows of traffic instead of E written here and E read by the segmented sum.
+    // The run structure is wave-uniform: destinations and piece base arrive by scalar loads.  9 operations
+    const __amdgpu_buffer_rsrc_t r_pc = __builtin_amdgcn_make_buffer_rsrc(pieces, 0, -1, 0x00020000);
+    int ag_d[8], ag_nv = 0, ag_p = 0;
+    float2 ag_acc = make_float2(0.f, 0.f);
+    auto agg_op = [&](int m, const float *Yt, int tile) __attribute__((always_inline)) {
+        if (m == 0) {
+            const int64_t row0 = (int64_t)tile * 32 + 8 * w, left = M - row0;
+            ag_nv = left < 0 ? 0 : (left > 8 ? 8 : (int)left);
+            ag_acc = make_float2(0.f, 0.f);
+            if (ag_nv > 0) {
+                const int64_t *ip = ia + row0;
+#pragma unroll
+                for (int r = 0; r < 8; r++) ag_d[r] = (int)ip[r < ag_nv ? r : ag_nv - 1];
+                ag_p = group_piece0[row0 >> 3];
+            }
+            return;
+        }
+        const int r = m - 1;
+        if (r < ag_nv) {
+            const float2 y = *reinterpret_cast<const float2 *>(Yt + (size_t)(8 * w + r) * ER_GSTRIDE + 2 * lane);
+            ag_acc.x += y.x; ag_acc.y += y.y;
+            if (r == ag_nv - 1 || ag_d[(r + 1) & 7] != ag_d[r]) {
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                i32x2 v; v[0] = __float_as_int(ag_acc.x); v[1] = __float_as_int(ag_acc.y);
+                __builtin_amdgcn_raw_buffer_store_b64(v, r_pc, ag_p * 512 + lane * 8, 0, 0);
+                ag_p++;
+                ag_acc = make_float2(0.f, 0.f);
+            }
+        }
+    };
     // ---- loaders.  A wave brings in rows 8w .. 8w + 7 of a tile, two rows per instruction (half-wave per row, 16 bytes per lane): global
     // memory only ever sees whole rows.  Buffer loads: what lies past the last row reads as zero (edge rows) / index 0 (gathers)
     const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc((void *)e0, 0, (int)(M * 512), 0x00020000);
@@ -458,6 +496,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
 #pragma unroll
     for (int r = 0; r < 16; r++) accLA[r] = accLB[r] = 0.f;
     unsigned offA_prev = 0xfff00000u, offB_prev = 0xfff00000u;       // (no rows to write yet: past the end of any buffer this kernel takes)
+    int tA_prev = 0x3fffffff, tB_prev = 0x3fffffff;                  // (AGG: a tile past the last row has no rows to sum)
     __syncthreads();
 #define SL(a) ((a) * NS / 48)      /* gap ranges below are written for 48 gaps per phase */
     int x = 0;
@@ -476,7 +515,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         // 1: layer 1 of B | A's ReLU + pieces, LayerNorm's end + rows out of the previous B, the next B's indices
         phase(0, XB0, GtB + (size_t)n * ER_GSTRIDE, accB, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(0), SL(32), LNF_OPS, lnf_op(m, accLB, SrB, offB_prev, YtB));
-            if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(40), 8, rows_out_op(m, YtA, offA_prev));
+            if (AGG) ER_SPREAD(k, SL(6), SL(42), 9, agg_op(m, YtA, tA_prev));
+            else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(40), 8, rows_out_op(m, YtA, offA_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA1));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(44), SL(48), 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
         });
@@ -486,7 +526,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         phase(1, XA1, sT, accA, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(0), SL(8), 8, g_issue_op(m, jaA, jbA));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
-            if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(32), 8, rows_out_op(m, YtB, offB_prev));
+            if (AGG) ER_SPREAD(k, SL(8), SL(44), 9, agg_op(m, YtB, tB_prev));
+            else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(32), 8, rows_out_op(m, YtB, offB_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB1));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 12, g_commit_op(m, GtA));
         });
@@ -514,6 +555,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(4), SL(48), EC_OPS, e_commit_op(m, EB, XB1));
         });
         offA_prev = (unsigned)tA * 16384u; offB_prev = (unsigned)tB * 16384u;
+        tA_prev = tA; tB_prev = tB;
         __syncthreads();
     }
     // the pipeline's tail: the last B's partials, both tiles' LayerNorm ends, their rows out
@@ -524,7 +566,13 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLB, SrB, offB_prev, YtB);
-    if (C::ROWS_VIA_LDS) {
+    if (AGG) {
+#pragma unroll
+        for (int m = 0; m < 9; m++) agg_op(m, YtA, tA_prev);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 9; m++) agg_op(m, YtB, tB_prev);
+    } else if (C::ROWS_VIA_LDS) {
 #pragma unroll
         for (int m = 0; m < 8; m++) rows_out_op(m, YtA, offA_prev);
         __syncthreads();
@@ -568,22 +616,26 @@ extern "C" int csplat_absmax(void *stream, int64_t n, const float *x, float *out
 
 extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, float alpha, const float *e0_absmax, const float *xa,
                                     const int64_t *index_a, const float *xb, const int64_t *index_b, const void *image, const float *b0,
-                                    const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out) {
-    CSPLAT_REQUIRE(E >= 0 && (E == 0 || (e0 && xa && index_a && xb && index_b && image && b0 && b1 && b2 && ln_gamma && ln_beta && out)),
+                                    const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out,
+                                    const int32_t *group_piece0, float *pieces) {
+    const bool agg = pieces != nullptr;
+    CSPLAT_REQUIRE(E >= 0 && (E == 0 || (e0 && xa && index_a && xb && index_b && image && b0 && b1 && b2 && ln_gamma && ln_beta && (out || agg))),
                    "csplat_gnn_edge_mlp3: bad arguments");
+    CSPLAT_REQUIRE(!agg || (group_piece0 && g_em_mode == 0), "csplat_gnn_edge_mlp3: the fused aggregation needs group_piece0 and mode 0");
     if (E == 0) return 0;
     const uintptr_t al = (uintptr_t)e0 | (uintptr_t)xa | (uintptr_t)xb | (uintptr_t)image | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2 |
-                         (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)out;
+                         (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)out | (uintptr_t)pieces;
     CSPLAT_REQUIRE((al & 15u) == 0, "csplat_gnn_edge_mlp3: operands must be 16-byte aligned");
-    CSPLAT_REQUIRE(out != e0, "csplat_gnn_edge_mlp3: out must not alias e0 (rows are read ahead of the rows being written)");
+    CSPLAT_REQUIRE(out != e0 && pieces != e0, "csplat_gnn_edge_mlp3: out must not alias e0 (rows are read ahead of the rows being written)");
     int ex = 0;
     const float m = frexpf(alpha, &ex);
     CSPLAT_REQUIRE(alpha > 0.f && m == 0.5f, "csplat_gnn_edge_mlp3: alpha must be a power of two (the edge scale 2^l)");
     hipStream_t s = (hipStream_t)stream;
     static int s_ok = -1;
     if (s_ok < 0) {
-        s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
-        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<false>::LDS_BYTES) == hipSuccess;
+        s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<false>::LDS_BYTES) == hipSuccess;
         (void)hipGetLastError();
     }
     CSPLAT_REQUIRE(s_ok, "csplat_gnn_edge_mlp3: 141 KB of dynamic LDS refused by the runtime");
@@ -596,12 +648,17 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
         const int64_t nst = (rows + 63) / 64;
         const int grid = (int)(nst < 256 ? nst : 256);      // persistent: one 4-wave workgroup per CU, two 32-row tiles in flight each
         unsigned long long *stamps = csplat_stamp_buffer((size_t)256 * 64);
-        if (g_em_mode == 0)
-            k_edge_mlp3r<true><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
-                                                                          (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, out + r0 * EM_N, stamps);
+        float *o = out ? out + r0 * EM_N : nullptr;
+        const int *gp = group_piece0 ? group_piece0 + r0 / 8 : nullptr;
+        if (agg)
+            k_edge_mlp3r<true, true><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
+                                                                                (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
+        else if (g_em_mode == 0)
+            k_edge_mlp3r<true, false><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
+                                                                                 (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
         else
-            k_edge_mlp3r<false><<<grid, 256, ErCfg<false>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
-                                                                            (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, out + r0 * EM_N, stamps);
+            k_edge_mlp3r<false, false><<<grid, 256, ErCfg<false>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
+                                                                                   (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
         LAUNCH_CHECK();
     }
     return 0;

@@ -20,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, edge_tail_ok, linear_narrow128,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, segment_sum_rows, edge_tail_ok, linear_narrow128,
                         layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
@@ -120,6 +120,9 @@ def _encode_inference(seq: nn.Sequential, x: torch.Tensor):
 # HBM) instead of three csplat_linear128 calls: 150-167 us against 235-245 per layer at E = 300k, rollout step 4.16 against 5.56 ms
 # (tools/ab_edge_mlp3_rollout.py).  env CSPLAT_GNN_EDGE_FUSED=0 goes back to the three launches.
 EDGE_MLP_FUSED = os.environ.get("CSPLAT_GNN_EDGE_FUSED", "1") not in ("", "0")
+# ... and that launch sums its messages per destination node itself (edges taken in destination order, per-run "pieces" instead of E message
+# rows: include/csplat.h), the segmented sum then runs over ~E / 8 + N piece rows.  env CSPLAT_GNN_EDGE_AGG=0: messages out, segmented sum over E.
+EDGE_AGG_FUSED = os.environ.get("CSPLAT_GNN_EDGE_AGG", "1") not in ("", "0")
 
 
 def _is_pow2(v: float) -> bool:
@@ -210,7 +213,7 @@ class InteractionNetwork(nn.Module):
             self._eimg_key = key
         return self._eimg
 
-    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None, e0_absmax=None):
+    def forward_inference(self, x, edge_index, e0, scale: float, xa=None, xb=None, next_layer=None, e0_absmax=None, plan=None):
         """Same arithmetic as forward() for edge features scale * e0 (scale = 2^l after l layers), no autograd.
         Per layer the [E,128] activations make three read+write passes (one per Linear, with gather / bias / ReLU /
         LayerNorm in the epilogues) and one read by the segmented sum; the node level is ONE launch
@@ -225,12 +228,21 @@ class InteractionNetwork(nn.Module):
         if len(elins) == 3 and EDGE_MLP_FUSED and _is_pow2(scale):
             # the whole message MLP + LayerNorm in ONE launch: the two inner [E,128] activations never leave the registers
             # (csplat_gnn_edge_mlp3; the weights' LDS image is packed once per weight version)
-            msg = edge_mlp3(e0, scale, xa, csr.ei[1], xb, csr.ei[0], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,
-                            elins[2].bias, self.edge_fn[1], e0_absmax=e0_absmax)
+            if plan is not None:
+                # e0 and the index arrays are in destination order: the launch leaves per-run sums, a node's aggregate = its few pieces
+                pieces = torch.empty(max(plan["npieces"], 1), 128, dtype=torch.float32, device=x.device)
+                edge_mlp3(e0, scale, xa, plan["dst"], xb, plan["src"], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,
+                          elins[2].bias, self.edge_fn[1], e0_absmax=e0_absmax, agg=(plan["gp0"], pieces))
+                msg = None
+                agg = segment_sum_rows(pieces[:plan["npieces"]], plan["pp"], plan["iota"], x.shape[0])
+            else:
+                msg = edge_mlp3(e0, scale, xa, csr.ei[1], xb, csr.ei[0], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,
+                                elins[2].bias, self.edge_fn[1], e0_absmax=e0_absmax)
         else:
             h = linear128(e0, w_e, self.edge_fn[0][0].bias, alpha=scale, relu=True, gather=(xa, csr.ei[1], xb, csr.ei[0]))
             msg = _fused_tail(self.edge_fn, h)
-        agg = SegmentSum.apply(msg, csr)
+        if msg is not None:
+            agg = SegmentSum.apply(msg, csr)
         lins = list(self.node_fn[0].children())[0::2]
         if len(lins) == 3:
             nw = next_layer._split_weights() if next_layer is not None else (None, None)
@@ -260,10 +272,15 @@ class Processor(nn.Module):
             e0, scale = edge_features.contiguous(), 1.0
             xa = xb = None
             # (the fp16 pieces of the one-launch edge MLP take their scale from max |e0|: one pass for all the layers)
-            amax = absmax(e0) if EDGE_MLP_FUSED and edge_mlp3_mode() == 0 and e0.numel() else None
+            fp16 = EDGE_MLP_FUSED and edge_mlp3_mode() == 0 and e0.numel() > 0
+            amax = absmax(e0) if fp16 else None
+            plan = e0_run = None
+            if fp16 and EDGE_AGG_FUSED and all(len(list(g.edge_fn[0].children())[0::2]) == 3 for g in self.gnn_stacks):
+                plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
+                e0_run = gather_rows(e0, plan["perm"])          # the edge latents in destination order, once for all the layers
             for l, gnn in enumerate(self.gnn_stacks):
                 nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
-                x, xa, xb = gnn.forward_inference(x, edge_index, e0, scale, xa, xb, nxt, e0_absmax=amax)
+                x, xa, xb = gnn.forward_inference(x, edge_index, e0 if plan is None else e0_run, scale, xa, xb, nxt, e0_absmax=amax, plan=plan)
                 scale *= 2.0
             return x, (e0 * scale if edges_out else None)
         if len(self.gnn_stacks) and not torch.is_grad_enabled():

@@ -39,6 +39,28 @@ class GraphCSR:
             self._deg_dst = (rp[1:] - rp[:-1]).to(torch.float32)
         return self._deg_dst
 
+    def agg_plan(self):
+        """What the one-launch edge MLP needs to sum its messages per destination itself (csplat_gnn_edge_mlp3 with `pieces`, include/csplat.h):
+        the edge list in destination order -- perm (int64, position -> edge id), dst / src in that order -- and the numbering of the
+        pieces: runs of equal destination, cut additionally every 8 rows.  gp0[g] = first piece of rows 8g .. 8g + 7; node v's pieces are
+        pp[v] .. pp[v + 1] - 1.  Built once per graph with stock tensor operations."""
+        if getattr(self, "_agg_plan", None) is None:
+            dev = self.ei.device
+            perm = self.perm["dst"][:self.E].long()
+            dst_s, src_s = self.ei[1][perm].contiguous(), self.ei[0][perm].contiguous()
+            r = torch.arange(self.E, device=dev)
+            new = (r % 8 == 0)
+            if self.E > 1:
+                new[1:] |= dst_s[1:] != dst_s[:-1]
+            pidx = torch.cumsum(new.to(torch.int32), 0, dtype=torch.int32) - 1
+            npieces = int(pidx[-1].item()) + 1 if self.E else 0
+            gp0 = pidx[0::8].contiguous() if self.E else torch.zeros(0, dtype=torch.int32, device=dev)
+            pidx_ext = torch.cat([pidx, torch.tensor([npieces], dtype=torch.int32, device=dev)])
+            pp = pidx_ext[self.rowptr["dst"].long()].contiguous()
+            self._agg_plan = {"perm": perm, "dst": dst_s, "src": src_s, "gp0": gp0, "pp": pp, "npieces": npieces,
+                              "iota": torch.arange(max(npieces, 1), dtype=torch.int32, device=dev)}
+        return self._agg_plan
+
     @classmethod
     def get(cls, edge_index, num_nodes):
         """CSR for this edge_index tensor OBJECT (weakly referenced) at its current in-place version."""
@@ -374,6 +396,28 @@ def linear_narrow128(x, weight, bias=None, relu=False):
     return out
 
 
+def gather_rows(rows, keys):
+    """rows[keys] for [.,L] fp32 rows and int64 keys (csplat_gnn_gather_rows), no autograd"""
+    _n.require_cuda(rows)
+    rows, keys = _f32(rows), keys.contiguous()
+    assert keys.dtype == torch.int64
+    out = torch.empty(keys.numel(), rows.shape[1], dtype=torch.float32, device=rows.device)
+    with _n.on_device(rows.device):
+        _n.check(_n.lib.csplat_gnn_gather_rows(_n.stream_handle(rows.device), keys.numel(), rows.shape[1], _n.ptr(rows), _n.ptr(keys), _n.ptr(out)),
+                 "csplat_gnn_gather_rows")
+    return out
+
+
+def segment_sum_rows(rows, rowptr, perm, N):
+    """out[v] = sum of rows[perm[rowptr[v] .. rowptr[v + 1] - 1]] in that order (csplat_gnn_segment_sum), no autograd"""
+    rows = _f32(rows)
+    out = torch.empty(N, rows.shape[1], dtype=torch.float32, device=rows.device)
+    with _n.on_device(rows.device):
+        _n.check(_n.lib.csplat_gnn_segment_sum(_n.stream_handle(rows.device), N, rows.shape[0], rows.shape[1], _n.ptr(rows), _n.ptr(rowptr), _n.ptr(perm),
+                                               _n.ptr(out)), "csplat_gnn_segment_sum")
+    return out
+
+
 def edge_mlp3_mode(mode=None):
     """the arithmetic of csplat_gnn_edge_mlp3 (include/csplat.h): 0 = two fp16 pieces per operand (default), 1 = three bf16 pieces (fp32's
     exponent range).  Returns the mode that was set before; None only queries.  An image is packed FOR a mode."""
@@ -410,27 +454,35 @@ def edge_mlp3_pack(w0, w1, w2):
     return img
 
 
-def edge_mlp3(e0, alpha, xa, ia, xb, ib, image, b0, b1, b2, layer_norm, out=None, e0_absmax=None):
+def edge_mlp3(e0, alpha, xa, ia, xb, ib, image, b0, b1, b2, layer_norm, out=None, e0_absmax=None, agg=None):
     """Inference-only message of one InteractionNetwork layer in ONE launch (csplat_gnn_edge_mlp3, include/csplat.h):
         out = LN( W2 relu( W1 relu( alpha * W0 e0 + b0 + xa[ia] + xb[ib] ) + b1 ) + b2 )
     the two inner [E,128] activations never leave the chip (graph_network.py:178-199).  image = edge_mlp3_pack(W0, W1, W2) under the
-    current edge_mlp3_mode; e0_absmax = absmax(e0) (or of a tensor e0 is a slice of), computed here when not handed in (mode 0 only)."""
+    current edge_mlp3_mode; e0_absmax = absmax(e0) (or of a tensor e0 is a slice of), computed here when not handed in (mode 0 only).
+    agg = (gp0, pieces) -- rows in destination order (GraphCSR.agg_plan): the messages are not written, their per-run sums land in
+    `pieces` [npieces,128] (returned); mode 0 only."""
     _n.require_cuda(e0)
     e0, xa, xb = _f32(e0), _f32(xa), _f32(xb)
     E = e0.shape[0]
     assert e0.shape[1] == 128 and xa.shape[1] == 128 and xb.shape[1] == 128
     ia, ib = ia.contiguous(), ib.contiguous()
     assert ia.dtype == torch.int64 and ib.dtype == torch.int64 and ia.numel() == E and ib.numel() == E
-    out = torch.empty_like(e0) if out is None else out
+    gp0 = pieces = None
+    if agg is not None:
+        gp0, pieces = agg
+        assert gp0.dtype == torch.int32 and gp0.numel() == (E + 7) // 8 and pieces.dtype == torch.float32 and pieces.shape[1] == 128
+    else:
+        out = torch.empty_like(e0) if out is None else out
     if e0_absmax is None and E > 0 and edge_mlp3_mode() == 0:
         e0_absmax = absmax(e0)
     c = lambda t: t.detach().contiguous()  # noqa: E731
     with _n.on_device(e0.device):
         _n.check(_n.lib.csplat_gnn_edge_mlp3(_n.stream_handle(e0.device), E, _n.ptr(e0), float(alpha), _n.ptr(e0_absmax), _n.ptr(xa), _n.ptr(ia),
                                              _n.ptr(xb), _n.ptr(ib), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b1)), _n.ptr(c(b2)),
-                                             _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps), _n.ptr(out)),
+                                             _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps), _n.ptr(out),
+                                             _n.ptr(gp0), _n.ptr(pieces)),
                  "csplat_gnn_edge_mlp3")
-    return out
+    return out if agg is None else pieces
 
 
 def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w_j_next=None):

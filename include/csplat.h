@@ -518,14 +518,21 @@ int csplat_linear_narrow128(void *stream, int64_t M, int K, const float *x, int 
  *                brought into fp16's range by a power of two taken from e0_absmax = the device word csplat_absmax leaves (max |e0| over
  *                the launch's rows or over a superset of them; NULL = 1.0).  Domain and failure mode: header of csplat_edge_mlp.hip.
  *   1            three bf16 pieces per operand, six products: fp32's exponent range, 7e-7 against fp64; e0_absmax is not read.
- * csplat_absmax(n, x, out): *out = max |x[i]| (n a multiple of 4, x 16-byte aligned; one pass, asynchronous on `stream`). */
+ * csplat_absmax(n, x, out): *out = max |x[i]| (n a multiple of 4, x 16-byte aligned; one pass, asynchronous on `stream`).
+ * Fused aggregation (mode 0; pieces != NULL, out may be NULL and is not written): the rows are in DESTINATION order (index_a
+ * non-decreasing: the caller permuted e0 / index_a / index_b by the CSR order), and instead of E message rows the launch writes their sums
+ * over runs of equal index_a, cut additionally every 8 rows: piece p = sum of the rows of run p, [npieces][128] fp32, numbered in row
+ * order; group_piece0[g] = number of the first piece of rows 8g .. 8g + 7 (int32 [ceil(E / 8)]).  A node's aggregate (graph_network.py:
+ * 201-222, aggr = 'add') is the sum of its consecutive pieces -- csplat_gnn_segment_sum over the piece rows; one writer per piece, fixed
+ * order of addition: deterministic.  Replaces the E x 128 write here and the E x 128 read of the segmented sum by ~(E / 8 + N) x 128. */
 int csplat_gnn_edge_mlp3_mode(int mode);
 size_t csplat_gnn_edge_mlp3_image_bytes(void);
 int csplat_gnn_edge_mlp3_pack(void *stream, const float *W0, int ld0, const float *W1, int ld1, const float *W2, int ld2, void *image);
 int csplat_absmax(void *stream, int64_t n, const float *x, float *out);
 int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, float alpha, const float *e0_absmax, const float *xa,
                          const int64_t *index_a, const float *xb, const int64_t *index_b, const void *image, const float *b0,
-                         const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out);
+                         const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out,
+                         const int32_t *group_piece0, float *pieces);
 
 /* The per-step activations of the Gaussian parameters as render() consumes them (/root/reference/scene_reconstruction/
  * gaussian_model.py:96-121 via gaussian_renderer/__init__.py:92-118): opacity[P] = sigmoid(opacity_raw), scales[P][3] = exp(scaling_raw),

@@ -811,6 +811,44 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha, mode):
     assert rel_err(out.cpu().numpy(), three.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("E,N", [(5, 3), (1000, 7), (20_011, 900), (70_001, 40_000)])
+def test_edge_mlp3_fused_aggregation_vs_messages_and_segment_sum(E, N):
+    """csplat_gnn_edge_mlp3 with `pieces` (the launch sums its messages over runs of equal destination, cut every 8 rows; a node's
+    aggregate = csplat_gnn_segment_sum over its consecutive pieces) against the same launch writing the E message rows + the segmented
+    sum over them: the same per-node sums (/root/reference/meshnet/graph_network.py:201-222, aggr = 'add') to fp32 rounding of another
+    order of addition, zero rows for nodes without edges, deterministic.  Graphs: a hub with hundreds of edges (runs across many 8-row
+    groups and tiles), many nodes without edges, E not a multiple of 8 or 32."""
+    from meshnet.graph_ops import GraphCSR, SegmentSum, absmax, edge_mlp3, edge_mlp3_pack, gather_rows, segment_sum_rows
+    gen = torch.Generator().manual_seed(E)
+    dst = torch.randint(0, N, (E,), generator=gen)
+    dst[: E // 3] = N // 2                                   # a hub
+    src = torch.randint(0, N, (E,), generator=gen)
+    ei = torch.stack([src, dst]).cuda()
+    e0 = torch.randn(E, 128, generator=gen).cuda()
+    W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(3)]
+    b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+    xa, xb = torch.randn(N, 128, generator=gen).cuda(), torch.randn(N, 128, generator=gen).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        csr = GraphCSR(ei, N)
+        plan = csr.agg_plan()
+        assert plan["npieces"] <= E // 8 + 1 + N and int(plan["pp"][-1]) == plan["npieces"]
+        img, am = edge_mlp3_pack(*W), absmax(e0)
+        msg = edge_mlp3(e0, 2.0, xa, ei[1], xb, ei[0], img, b[0], b[1], b[2], norm, e0_absmax=am)
+        ref = SegmentSum.apply(msg, csr)
+        runs = []
+        for _ in range(2):
+            pieces = torch.full((plan["npieces"], 128), float("nan"), device="cuda")
+            edge_mlp3(gather_rows(e0, plan["perm"]), 2.0, xa, plan["dst"], xb, plan["src"], img, b[0], b[1], b[2], norm, e0_absmax=am,
+                      agg=(plan["gp0"], pieces))
+            assert torch.isfinite(pieces).all()              # every piece has a writer
+            runs.append(segment_sum_rows(pieces, plan["pp"], plan["iota"], N))
+    assert torch.equal(runs[0], runs[1])
+    assert rel_err(runs[0].cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    empty = torch.bincount(dst, minlength=N) == 0
+    assert float(runs[0][empty.cuda()].abs().max() if empty.any() else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("scale", [1.0, 1e-3, 300.0])
 def test_edge_mlp3_network_magnitudes(mode, scale):
