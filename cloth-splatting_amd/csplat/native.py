@@ -97,6 +97,7 @@ EXPORTS = {
     "csplat_gnn_edge_combine_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_gnn_segment_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "csplat_gnn_gather_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "csplat_gnn_gather_rows_absmax": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "csplat_gnn_edge_features": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "csplat_dw128_workspace_bytes": (_sz, [_i64]),
     "csplat_dw128": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -109,6 +110,9 @@ EXPORTS = {
     "csplat_linear128_mode_query": (C.c_uint, []),
     "csplat_gnn_node_update": (_i, [_vp, _i64] + [_vp] * 11 + [_f] + [_vp] * 5),
     "csplat_linear_narrow128": (_i, [_vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "csplat_gnn_node_update_image_bytes": (_sz, []),
+    "csplat_gnn_node_update_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_gnn_node_update_packed": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "csplat_gnn_edge_mlp3_image_bytes": (_sz, []),
     "csplat_gnn_edge_mlp3_pack": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),

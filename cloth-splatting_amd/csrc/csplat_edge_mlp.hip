@@ -58,6 +58,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short el16;              // a 16-bit piece in LDS (bf16 or fp16 by mode)
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 
 constexpr int EM_N = 128;                 // layer width
 constexpr int EM_STRIDE = 136;            // 16-bit elements per activation row in LDS (272 B: conflict-free 16-byte operand reads)
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(256) void k_absmax(int64_t n4, const float4 *__rest
     __shared__ float sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
+    if (threadIdx.x == 0) {
+        const unsigned b = __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
+        if (b > *reinterpret_cast<volatile unsigned *>(out)) atomicMax(out, b);      // (a stale read costs an extra atomic, never the result)
+    }
 }
 
 template <bool F16, bool AGG>
@@ -581,6 +585,224 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     }
 #undef SL
 }
+
+// =====================================================================================================================================
+// k_node_update_b3 -- the node update of an InteractionNetwork layer (+ the next layer's node-level products) on the same machinery:
+//   h = relu(agg Wa^T + x Wx^T + b0);  h = relu(h W2^T + b2);  x' = LayerNorm(h W3^T + b3) + x;  xa' = x' Wi^T;  xb' = x' Wj^T
+// (/root/reference/meshnet/graph_network.py:203-222).  Rounds 2-5 ran it on the exact-fp32 MFMA with the weights transposed through LDS
+// by scalar writes (k_node_update, csplat_gemm.hip: 44 us at N = 1e4, 0.66 of the 3.0 ms rollout step).  Here: three bf16 pieces per
+// operand, six products (fp32's exponent range: no scaling question for node latents and aggregates), weights PRE-PACKED as MFMA A
+// operands (csplat_gnn_node_update_pack: [matrix 6][wave 4][piece 3][step 8][lane] x 16 bytes) and streamed from L2 into registers half
+// a product ahead; one 32-row tile per 4-wave workgroup, wave j = output features 32j .. 32j + 31, activations between the layers as
+// piece tiles in LDS.  ~160 registers and 80 KB of LDS: two workgroups per CU, which is what fills the gaps (the layers of a tile are
+// a dependent chain).
+constexpr int NB_MATS = 6;                                         // Wa, Wx, W2, W3, Wi', Wj'
+constexpr size_t NB_IMAGE_BYTES = (size_t)NB_MATS * 4 * 3 * 8 * 64 * 16;      // 589,824
+constexpr int NB_XT = 3 * ER_TILE_P;
+constexpr size_t NB_LDS_BYTES = (size_t)3 * NB_XT * 2 + 32 * 4 * 8;           // three piece tiles + LayerNorm partials
+
+__global__ __launch_bounds__(64) void k_node_pack(const float *__restrict__ W0, const float *__restrict__ W1, const float *__restrict__ W2,
+                                                  const float *__restrict__ W3, const float *__restrict__ W4, const float *__restrict__ W5,
+                                                  i32x4 *__restrict__ img) {
+    // block = (matrix, wave j, step st); lane (m, h): the 8 contraction elements of output feature 32j + m it feeds into step st.
+    // Matrices 0, 1 contract over rows as they lie in memory; 2 .. 5 over what the previous layer's waves left in LDS (er_src_col)
+    const int st = blockIdx.x & 7, j = (blockIdx.x >> 3) & 3, mat = blockIdx.x >> 5;
+    const float *W = mat == 0 ? W0 : mat == 1 ? W1 : mat == 2 ? W2 : mat == 3 ? W3 : mat == 4 ? W4 : W5;
+    if (!W) return;
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    el16 p[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float x = W[(size_t)(32 * j + m) * EM_N + er_src_col(mat < 2 ? 0 : 1, 64 * h + 8 * st + i)];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { const __bf16 v = (__bf16)x; p[q][i] = __builtin_bit_cast(el16, v); x -= (float)v; }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) img[((size_t)((mat * 4 + j) * 3 + q) * 8 + st) * 64 + lane] = *reinterpret_cast<const i32x4 *>(p[q]);
+}
+
+__global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const float *__restrict__ agg, const float *__restrict__ x,
+                                                           const i32x4 *__restrict__ img, const float *__restrict__ b0,
+                                                           const float *__restrict__ b2, const float *__restrict__ b3,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                           int has_next, float *__restrict__ x_new, float *__restrict__ xa,
+                                                           float *__restrict__ xb) {
+    extern __shared__ char s_mem[];
+    el16 *const sB = reinterpret_cast<el16 *>(s_mem);                                         // three tiles of three pieces
+    float2 *const sS = reinterpret_cast<float2 *>(s_mem + (size_t)3 * NB_XT * 2);             // [32][wave 4] (sum, M2)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+    auto pk = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+        b16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+        return __builtin_bit_cast(unsigned, v);
+    };
+    auto lo_f = [&](unsigned q) { return __uint_as_float(q << 16); };
+    auto hi_f = [&](unsigned q) { return __uint_as_float(q & 0xffff0000u); };
+
+    // weights: the 24 A operands of a product in two halves (steps 0-3, 4-7), each requested half a product ahead
+    i32x4 wq[2][12];
+    auto fetch = [&](int mat, int half) __attribute__((always_inline)) {
+        const i32x4 *src = img + ((size_t)(mat * 4 + w) * 3 * 8) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) wq[half][p * 4 + s4] = src[(size_t)(p * 8 + 4 * half + s4) * 64];
+    };
+    fetch(0, 0);
+    fetch(0, 1);
+    // ---- the tile's rows of agg and x, whole rows per instruction (half-wave per row), cut into pieces -> tiles 0 and 1
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const float *src = a == 0 ? agg : x;
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int64_t row = row0 + 8 * w + 2 * k + h;
+            row = row < N ? row : N - 1;
+            v[k] = *reinterpret_cast<const float4 *>(src + row * EM_N + 4 * n);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            el16 *dst = sB + (size_t)a * NB_XT + (size_t)(8 * w + 2 * k + h) * EM_STRIDE + 4 * n;
+            float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const unsigned q0 = pk(e[0], e[1]), q1 = pk(e[2], e[3]);
+                *reinterpret_cast<uint2 *>(dst + (size_t)p * ER_TILE_P) = make_uint2(q0, q1);
+                e[0] -= lo_f(q0); e[1] -= hi_f(q0); e[2] -= lo_f(q1); e[3] -= hi_f(q1);
+            }
+        }
+    }
+    // the residual's x in the accumulators' layout (register r <-> feature 32w + 8(r >> 2) + 4h + (r & 3) of row n)
+    float4 xres[4];
+    {
+        int64_t row = row0 + n;
+        row = row < N ? row : N - 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) xres[q] = *reinterpret_cast<const float4 *>(x + row * EM_N + 32 * w + 8 * q + 4 * h);
+    }
+    __syncthreads();
+
+    // one product: acc += W_mat (registers) x tile (pieces in LDS); the next weights are requested as the halves free up
+    auto product = [&](const el16 *Bt, f32x16 &acc, int next_mat) __attribute__((always_inline)) {
+        constexpr int WP[6] = {0, 2, 1, 0, 1, 0}, XP[6] = {2, 0, 1, 1, 0, 0};
+        const el16 *row = Bt + (size_t)n * EM_STRIDE + 64 * h;
+        i32x4 bc[3], bn[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) bc[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P);
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            if (st < 7) {
+#pragma unroll
+                for (int p = 0; p < 3; p++) bn[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P + 8 * (st + 1));
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, wq[st >> 2][WP[i] * 4 + (st & 3)]),
+                                                              __builtin_bit_cast(bf16x8v, bc[XP[i]]), acc, 0, 0, 0);
+            if (st == 3 && next_mat >= 0) fetch(next_mat, 0);
+#pragma unroll
+            for (int p = 0; p < 3; p++) bc[p] = bn[p];
+        }
+        if (next_mat >= 0) fetch(next_mat, 1);
+    };
+    auto start_from = [&](const float *b, f32x16 &acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 t = b ? *reinterpret_cast<const float4 *>(b + 32 * w + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
+        }
+    };
+    // 16 values of row n -> the next product's pieces, positions 32w + 16h .. + 15
+    auto to_pieces = [&](const float (&v)[16], el16 *Bt) __attribute__((always_inline)) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) e[r] = v[r];
+        el16 *dst = Bt + (size_t)n * EM_STRIDE + 32 * w + 16 * h;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            unsigned q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { q[j] = pk(e[2 * j], e[2 * j + 1]); e[2 * j] -= lo_f(q[j]); e[2 * j + 1] -= hi_f(q[j]); }
+            *reinterpret_cast<uint4 *>(dst + (size_t)p * ER_TILE_P) = make_uint4(q[0], q[1], q[2], q[3]);
+            *reinterpret_cast<uint4 *>(dst + (size_t)p * ER_TILE_P + 8) = make_uint4(q[4], q[5], q[6], q[7]);
+        }
+    };
+    const int64_t grow = row0 + n;
+    auto store_rows = [&](const float (&v)[16], float *dst) __attribute__((always_inline)) {
+        if (grow < N) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<float4 *>(dst + grow * EM_N + 32 * w + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+    };
+    el16 *const B0 = sB, *const B1 = sB + NB_XT, *const B2 = sB + 2 * NB_XT;
+    f32x16 acc;
+    float v[16];
+    // ---- layer 1 (K = 256: agg and x)
+    start_from(b0, acc);
+    product(B0, acc, 1);
+    product(B1, acc, 2);
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[r], 0.f);
+    to_pieces(v, B2);
+    __syncthreads();
+    // ---- layer 2
+    start_from(b2, acc);
+    product(B2, acc, 3);
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[r], 0.f);
+    to_pieces(v, B0);
+    __syncthreads();
+    // ---- layer 3, LayerNorm (the four waves' partials combined by the parallel-variance formula), residual
+    start_from(b3, acc);
+    product(B0, acc, has_next ? 4 : -1);
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += acc[r];
+        s = pair_sum(s);
+        const float mj = s * (1.f / 32.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float d = acc[r] - mj; m2 = fmaf(d, d, m2); }
+        m2 = pair_sum(m2);
+        sS[n * 4 + w] = make_float2(s, m2);
+    }
+    __syncthreads();
+    {
+        const float4 u0 = *reinterpret_cast<const float4 *>(sS + n * 4), u1 = *reinterpret_cast<const float4 *>(sS + n * 4 + 2);
+        const float mean = ((u0.x + u0.z) + (u1.x + u1.z)) * (1.f / EM_N);
+        const float d0 = u0.x * (1.f / 32.f) - mean, d1 = u0.z * (1.f / 32.f) - mean, d2 = u1.x * (1.f / 32.f) - mean, d3 = u1.z * (1.f / 32.f) - mean;
+        const float m2 = ((u0.y + u0.w) + (u1.y + u1.w)) + 32.f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = rsqrtf(m2 * (1.f / EM_N) + eps);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int f = 32 * w + 8 * q + 4 * h;
+            const float4 ga = *reinterpret_cast<const float4 *>(gamma + f), be = *reinterpret_cast<const float4 *>(beta + f);
+            v[4 * q] = (acc[4 * q] - mean) * rstd * ga.x + be.x + xres[q].x; v[4 * q + 1] = (acc[4 * q + 1] - mean) * rstd * ga.y + be.y + xres[q].y;
+            v[4 * q + 2] = (acc[4 * q + 2] - mean) * rstd * ga.z + be.z + xres[q].z; v[4 * q + 3] = (acc[4 * q + 3] - mean) * rstd * ga.w + be.w + xres[q].w;
+        }
+    }
+    store_rows(v, x_new);
+    if (!has_next) return;
+    // ---- the next layer's node-level products of the updated latents
+    to_pieces(v, B1);
+    __syncthreads();
+    start_from(nullptr, acc);
+    product(B1, acc, 5);
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = acc[r];
+    store_rows(v, xa);
+    start_from(nullptr, acc);
+    product(B1, acc, -1);
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = acc[r];
+    store_rows(v, xb);
+}
+
 }  // namespace
 
 // 0: two fp16 pieces (default), 1: three bf16 pieces (header).  The image is laid out for the mode it is packed under; callers re-pack when
@@ -661,5 +883,40 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
                                                                                    (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
         LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" size_t csplat_gnn_node_update_image_bytes(void) { return NB_IMAGE_BYTES; }
+
+extern "C" int csplat_gnn_node_update_pack(void *stream, const float *Wa, const float *Wx, const float *W2, const float *W3, const float *Wi_next,
+                                           const float *Wj_next, void *image) {
+    CSPLAT_REQUIRE(Wa && Wx && W2 && W3 && image && (Wi_next == nullptr) == (Wj_next == nullptr), "csplat_gnn_node_update_pack: bad arguments");
+    CSPLAT_REQUIRE(((uintptr_t)image & 15u) == 0, "csplat_gnn_node_update_pack: the image must be 16-byte aligned");
+    k_node_pack<<<NB_MATS * 4 * 8, 64, 0, (hipStream_t)stream>>>(Wa, Wx, W2, W3, Wi_next, Wj_next, (i32x4 *)image);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int csplat_gnn_node_update_packed(void *stream, int64_t N, const float *agg, const float *x, const void *image, const float *b0,
+                                             const float *b2, const float *b3, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                                             int has_next, float *x_new, float *xa_next, float *xb_next) {
+    CSPLAT_REQUIRE(N >= 0 && (N == 0 || (agg && x && image && b0 && b2 && b3 && ln_gamma && ln_beta && x_new)), "csplat_gnn_node_update_packed: bad arguments");
+    CSPLAT_REQUIRE(!has_next || (xa_next && xb_next), "csplat_gnn_node_update_packed: next-layer outputs missing");
+    CSPLAT_REQUIRE(x_new != x && x_new != agg, "csplat_gnn_node_update_packed: x_new must not alias an input (the residual reads x)");
+    const uintptr_t al = (uintptr_t)agg | (uintptr_t)x | (uintptr_t)image | (uintptr_t)b0 | (uintptr_t)b2 | (uintptr_t)b3 | (uintptr_t)ln_gamma |
+                         (uintptr_t)ln_beta | (uintptr_t)x_new | (uintptr_t)xa_next | (uintptr_t)xb_next;
+    CSPLAT_REQUIRE((al & 15u) == 0, "csplat_gnn_node_update_packed: operands must be 16-byte aligned");
+    if (N == 0) return 0;
+    static int s_ok = -1;
+    if (s_ok < 0) {
+        s_ok = hipFuncSetAttribute((const void *)k_node_update_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    CSPLAT_REQUIRE(s_ok, "csplat_gnn_node_update_packed: 78 KB of dynamic LDS refused by the runtime");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    k_node_update_b3<<<(unsigned)((N + 31) / 32), 256, NB_LDS_BYTES, s>>>(N, agg, x, (const i32x4 *)image, b0, b2, b3, ln_gamma, ln_beta, ln_eps,
+                                                                          has_next ? 1 : 0, x_new, xa_next, xb_next);
+    LAUNCH_CHECK();
     return 0;
 }

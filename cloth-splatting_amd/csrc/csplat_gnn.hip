@@ -131,6 +131,24 @@ __global__ __launch_bounds__(256) void k_gather_rows(int64_t E, int LV, const VT
     out[t] = rows[keys[e] * LV + c];
 }
 
+// the same pass also leaves max |value| (bits of a non-negative float order as integers; *amax zeroed by the caller).  Grid-stride: a
+// wave carries its maximum through all its elements and touches the one shared word once, and only if it beats what is there (a stale
+// read costs an extra atomic, never the result) -- one atomic per 256 elements on one address took 1.7 ms at E = 3e5
+__global__ __launch_bounds__(256) void k_gather_rows_absmax(int64_t E, int LV, const float4 *__restrict__ rows, const int64_t *__restrict__ keys,
+                                                             float4 *__restrict__ out, unsigned *__restrict__ amax) {
+    float m = 0.f;
+    const int64_t total = E * LV;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = t / LV;
+        const float4 v = rows[keys[e] * LV + (int)(t - e * LV)];
+        out[t] = v;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned *>(amax)) atomicMax(amax, __float_as_uint(m));
+}
+
 }  // namespace
 
 extern "C" {
@@ -234,6 +252,19 @@ int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, co
         k_gather_rows<float4><<<cdiv(E * (L / 4), 256), 256, 0, s>>>(E, L / 4, (const float4 *)rows, keys, (float4 *)out);
     else
         k_gather_rows<float><<<cdiv(E * L, 256), 256, 0, s>>>(E, L, rows, keys, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int csplat_gnn_gather_rows_absmax(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out, float *absmax) {
+    CSPLAT_REQUIRE(E >= 0 && L > 0 && L % 4 == 0 && absmax && (E == 0 || (rows && keys && out)), "csplat_gnn_gather_rows_absmax: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)rows | (uintptr_t)out) & 15u) == 0, "csplat_gnn_gather_rows_absmax: rows / out must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(absmax, 0, sizeof(float), s));
+    if (E == 0) return 0;
+    ProfScope ps(PROF_GNN, s);
+    const int64_t nb = cdiv(E * (L / 4), 256);
+    k_gather_rows_absmax<<<(int)(nb < 4096 ? nb : 4096), 256, 0, s>>>(E, L / 4, (const float4 *)rows, keys, (float4 *)out, (unsigned *)absmax);
     LAUNCH_CHECK();
     return 0;
 }

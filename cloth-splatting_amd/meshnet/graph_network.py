@@ -20,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, segment_sum_rows, edge_tail_ok, linear_narrow128,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, node_update_pack, node_update_packed, segment_sum_rows, edge_tail_ok, linear_narrow128,
                         layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
@@ -123,6 +123,9 @@ EDGE_MLP_FUSED = os.environ.get("CSPLAT_GNN_EDGE_FUSED", "1") not in ("", "0")
 # ... and that launch sums its messages per destination node itself (edges taken in destination order, per-run "pieces" instead of E message
 # rows: include/csplat.h), the segmented sum then runs over ~E / 8 + N piece rows.  env CSPLAT_GNN_EDGE_AGG=0: messages out, segmented sum over E.
 EDGE_AGG_FUSED = os.environ.get("CSPLAT_GNN_EDGE_AGG", "1") not in ("", "0")
+# the node update on pre-packed bf16-piece weights (csplat_gnn_node_update_packed) instead of the exact-fp32 MFMA kernel of rounds 2-5; env
+# CSPLAT_GNN_NODE_PACKED=0 goes back
+NODE_UPDATE_PACKED = os.environ.get("CSPLAT_GNN_NODE_PACKED", "1") not in ("", "0")
 
 
 def _is_pow2(v: float) -> bool:
@@ -203,6 +206,16 @@ class InteractionNetwork(nn.Module):
             self._wsplit_key = key
         return self._wsplit
 
+    def _node_image(self, w_agg, w_x, lins, next_layer, nw):
+        """the packed register image of the node update's weights (+ the next layer's x_i / x_j blocks), re-packed only when one changed"""
+        key = (self._wsplit_key, lins[1].weight._version, lins[2].weight._version, lins[1].weight.data_ptr(), lins[2].weight.data_ptr(),
+               None if next_layer is None else next_layer._wsplit_key)
+        if getattr(self, "_nimg_key", None) != key:
+            with torch.no_grad():
+                self._nimg = node_update_pack(w_agg, w_x, lins[1].weight, lins[2].weight, nw[0], nw[1])
+            self._nimg_key = key
+        return self._nimg
+
     def _edge_image(self, w_e, elins):
         """the packed LDS image of the edge MLP's three weights, re-packed only when a weight changed"""
         key = (self._wsplit_key, elins[1].weight._version, elins[2].weight._version, elins[1].weight.data_ptr(), elins[2].weight.data_ptr(),
@@ -246,6 +259,9 @@ class InteractionNetwork(nn.Module):
         lins = list(self.node_fn[0].children())[0::2]
         if len(lins) == 3:
             nw = next_layer._split_weights() if next_layer is not None else (None, None)
+            if NODE_UPDATE_PACKED:
+                return node_update_packed(agg, x, self._node_image(w_agg, w_x, lins, next_layer, nw), lins[0].bias, lins[1].bias, lins[2].bias,
+                                          self.node_fn[1], next_layer is not None)
             return node_update(agg, x, w_agg, w_x, lins[0].bias, lins[1], lins[2], self.node_fn[1], nw[0], nw[1])
         t = linear128(x, w_x, out=xa)
         hn = linear128(agg, w_agg, self.node_fn[0][0].bias, relu=True, add_pre=t, out=t)
@@ -273,11 +289,13 @@ class Processor(nn.Module):
             xa = xb = None
             # (the fp16 pieces of the one-launch edge MLP take their scale from max |e0|: one pass for all the layers)
             fp16 = EDGE_MLP_FUSED and edge_mlp3_mode() == 0 and e0.numel() > 0
-            amax = absmax(e0) if fp16 else None
-            plan = e0_run = None
+            plan = e0_run = amax = None
             if fp16 and EDGE_AGG_FUSED and all(len(list(g.edge_fn[0].children())[0::2]) == 3 for g in self.gnn_stacks):
                 plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
-                e0_run = gather_rows(e0, plan["perm"])          # the edge latents in destination order, once for all the layers
+                # the edge latents in destination order, once for all the layers (and max |e0| from the same pass)
+                e0_run, amax = gather_rows(e0, plan["perm"], with_absmax=True)
+            elif fp16:
+                amax = absmax(e0)
             for l, gnn in enumerate(self.gnn_stacks):
                 nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
                 x, xa, xb = gnn.forward_inference(x, edge_index, e0 if plan is None else e0_run, scale, xa, xb, nxt, e0_absmax=amax, plan=plan)

@@ -396,13 +396,19 @@ def linear_narrow128(x, weight, bias=None, relu=False):
     return out
 
 
-def gather_rows(rows, keys):
-    """rows[keys] for [.,L] fp32 rows and int64 keys (csplat_gnn_gather_rows), no autograd"""
+def gather_rows(rows, keys, with_absmax=False):
+    """rows[keys] for [.,L] fp32 rows and int64 keys (csplat_gnn_gather_rows), no autograd; with_absmax: also max |value| of the result as a
+    one-element device tensor, from the same pass (csplat_gnn_gather_rows_absmax)"""
     _n.require_cuda(rows)
     rows, keys = _f32(rows), keys.contiguous()
     assert keys.dtype == torch.int64
     out = torch.empty(keys.numel(), rows.shape[1], dtype=torch.float32, device=rows.device)
     with _n.on_device(rows.device):
+        if with_absmax:
+            am = torch.empty(1, dtype=torch.float32, device=rows.device)
+            _n.check(_n.lib.csplat_gnn_gather_rows_absmax(_n.stream_handle(rows.device), keys.numel(), rows.shape[1], _n.ptr(rows), _n.ptr(keys),
+                                                          _n.ptr(out), _n.ptr(am)), "csplat_gnn_gather_rows_absmax")
+            return out, am
         _n.check(_n.lib.csplat_gnn_gather_rows(_n.stream_handle(rows.device), keys.numel(), rows.shape[1], _n.ptr(rows), _n.ptr(keys), _n.ptr(out)),
                  "csplat_gnn_gather_rows")
     return out
@@ -505,6 +511,36 @@ def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w
         _n.check(_n.lib.csplat_gnn_node_update(_n.stream_handle(x.device), N, _n.ptr(agg), _n.ptr(x), *[_n.ptr(t) for t in ops],
                                                float(layer_norm.eps), _n.ptr(nxt[0]), _n.ptr(nxt[1]), _n.ptr(x_new), _n.ptr(xa),
                                                _n.ptr(xb)), "csplat_gnn_node_update")
+    return x_new, xa, xb
+
+
+def node_update_pack(w_agg, w_x, w2, w3, w_i_next=None, w_j_next=None):
+    """the node update's weights (+ the next layer's x_i / x_j blocks) as the register image csplat_gnn_node_update_packed streams: three bf16
+    pieces per matrix as MFMA A operands (csplat_gnn_node_update_pack); pack once per weight version"""
+    img = torch.empty(int(_n.lib.csplat_gnn_node_update_image_bytes()), dtype=torch.uint8, device=w_agg.device)
+    c = lambda t: None if t is None else t.detach().contiguous()  # noqa: E731
+    ws = [c(t) for t in (w_agg, w_x, w2, w3, w_i_next, w_j_next)]
+    for t in ws[:4]:
+        assert tuple(t.shape) == (128, 128) and t.dtype == torch.float32 and t.is_cuda
+    with _n.on_device(w_agg.device):
+        _n.check(_n.lib.csplat_gnn_node_update_pack(_n.stream_handle(w_agg.device), *[_n.ptr(t) for t in ws], _n.ptr(img)), "csplat_gnn_node_update_pack")
+    return img
+
+
+def node_update_packed(agg, x, image, b0, b2, b3, layer_norm, has_next):
+    """node_update() on the pre-packed weights (csplat_gnn_node_update_packed, include/csplat.h): returns (x_new, xa', xb')"""
+    _n.require_cuda(x)
+    agg, x = _f32(agg), _f32(x)
+    N = x.shape[0]
+    assert tuple(agg.shape) == (N, 128) and x.shape[1] == 128
+    c = lambda t: t.detach().contiguous()  # noqa: E731
+    x_new = torch.empty_like(x)
+    xa = torch.empty_like(x) if has_next else None
+    xb = torch.empty_like(x) if has_next else None
+    with _n.on_device(x.device):
+        _n.check(_n.lib.csplat_gnn_node_update_packed(_n.stream_handle(x.device), N, _n.ptr(agg), _n.ptr(x), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b2)),
+                                                      _n.ptr(c(b3)), _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps),
+                                                      int(bool(has_next)), _n.ptr(x_new), _n.ptr(xa), _n.ptr(xb)), "csplat_gnn_node_update_packed")
     return x_new, xa, xb
 
 

@@ -426,6 +426,8 @@ int csplat_gnn_segment_sum(void *stream, int N, int64_t E, int L, const float *m
                            const int32_t *perm, float *agg);
 /* its backward: dmsg[e][:] = dagg[key[e]][:]   (row gather) */
 int csplat_gnn_gather_rows(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out);
+/* the same pass also leaves *absmax = max |value| over the gathered rows (L a multiple of 4; what csplat_gnn_edge_mlp3's mode 0 scales by) */
+int csplat_gnn_gather_rows_absmax(void *stream, int64_t E, int L, const float *rows, const int64_t *keys, float *out, float *absmax);
 /* Edge features of one rollout step (PyG Cartesian(norm=False) + Distance(norm=False), the `transformer(graph)` of
  * /root/reference/train_meshnet_sim.py:152 and dataloader_sim.py): out[e] = (pos[row] - pos[col], |pos[row] - pos[col]|) with
  * row = edge_index[0][e], col = edge_index[1][e]; pos [N][3], out [E][4] (16-byte aligned). */
@@ -450,6 +452,18 @@ int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const floa
                            const float *b0, const float *W2, const float *b2, const float *W3, const float *b3,
                            const float *ln_gamma, const float *ln_beta, float ln_eps, const float *Wi_next,
                            const float *Wj_next, float *x_new, float *xa_next, float *xb_next);
+
+/* The same node update on three bf16 pieces per operand (six products on the bf16 matrix cores: fp32's exponent range, ~7e-7 of the output
+ * scale against fp64) with the six weight matrices PRE-PACKED as MFMA A operands: csplat_gnn_node_update_pack lays Wa, Wx, W2, W3 and the
+ * next layer's Wi, Wj (both NULL: none; all [128][128] row-major, contiguous) out in `image` (csplat_gnn_node_update_image_bytes() bytes
+ * of device memory, 16-byte aligned) -- once per weight version; csplat_gnn_node_update_packed is the launch (has_next = the image holds
+ * Wi / Wj and xa_next / xb_next are written).  18 us against 44 for csplat_gnn_node_update at N = 1e4 (csplat_edge_mlp.hip). */
+size_t csplat_gnn_node_update_image_bytes(void);
+int csplat_gnn_node_update_pack(void *stream, const float *Wa, const float *Wx, const float *W2, const float *W3, const float *Wi_next,
+                                const float *Wj_next, void *image);
+int csplat_gnn_node_update_packed(void *stream, int64_t N, const float *agg, const float *x, const void *image, const float *b0,
+                                  const float *b2, const float *b3, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                                  int has_next, float *x_new, float *xa_next, float *xb_next);
 
 /* LayerNorm(128) of the MeshNet MLPs under autograd (/root/reference/meshnet/graph_network.py:86-97,139-150: every edge / node
  * MLP ends in nn.LayerNorm), single HBM passes over [M][128] rows:

@@ -811,6 +811,37 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha, mode):
     assert rel_err(out.cpu().numpy(), three.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("N", [1, 33, 10_000])
+@pytest.mark.parametrize("has_next", [False, True])
+def test_node_update_packed_vs_fp64_and_vs_exact_kernel(N, has_next):
+    """csplat_gnn_node_update_packed (three bf16 pieces per operand, pre-packed weights; /root/reference/meshnet/graph_network.py:203-222)
+    against the fp64 composition and against csplat_gnn_node_update (exact fp32 MFMA): 1e-5 of each output's scale; aggregates of O(30)
+    and latents of O(5) as the rollout has them."""
+    from meshnet.graph_ops import node_update, node_update_pack, node_update_packed
+    gen = torch.Generator().manual_seed(N + has_next)
+    agg, x = (torch.randn(N, 128, generator=gen) * 30).cuda(), (torch.randn(N, 128, generator=gen) * 5).cuda()
+    W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(6)]
+    b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+    l2, l3 = torch.nn.Linear(128, 128).cuda(), torch.nn.Linear(128, 128).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        l2.weight.copy_(W[2]); l2.bias.copy_(b[1]); l3.weight.copy_(W[3]); l3.bias.copy_(b[2])
+        norm.weight.copy_(torch.randn(128, generator=gen)); norm.bias.copy_(torch.randn(128, generator=gen))
+        wi, wj = (W[4], W[5]) if has_next else (None, None)
+        img = node_update_pack(W[0], W[1], W[2], W[3], wi, wj)
+        got = node_update_packed(agg, x, img, b[0], b[1], b[2], norm, has_next)
+        exact = node_update(agg, x, W[0], W[1], b[0], l2, l3, norm, wi, wj)
+        h = (agg.double() @ W[0].double().t() + x.double() @ W[1].double().t() + b[0].double()).relu()
+        h = (h @ W[2].double().t() + b[1].double()).relu()
+        xn = torch.nn.functional.layer_norm(h @ W[3].double().t() + b[2].double(), (128,), norm.weight.double(), norm.bias.double(), norm.eps) + x.double()
+        ref = [xn, xn @ W[4].double().t(), xn @ W[5].double().t()] if has_next else [xn, None, None]
+    for g, e, r in zip(got, exact, ref):
+        if r is None:
+            assert g is None
+            continue
+        assert rel_err(g.cpu().numpy(), r.cpu().numpy()) < 1e-5 and rel_err(g.cpu().numpy(), e.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("E,N", [(5, 3), (1000, 7), (20_011, 900), (70_001, 40_000)])
 def test_edge_mlp3_fused_aggregation_vs_messages_and_segment_sum(E, N):
     """csplat_gnn_edge_mlp3 with `pieces` (the launch sums its messages over runs of equal destination, cut every 8 rows; a node's
