@@ -406,11 +406,18 @@ def pre_stage(build_cpu, cams_cpu, cap, tol=1e-4, opt=None, log=print, build_cpu
     if cands and len(cands) <= 64:
         def flat(gs, ref):
             return torch.cat([(torch.zeros_like(r) if g_ is None else g_.detach().cpu().double()).reshape(-1) for g_, r in zip(gs, ref) if r is not None])
-        resid = flat(cap.grads, g64) - flat(g64, g64)
-        for cnd in cands:
-            delta = flat(run(build_cpu, torch.float64, flips=[cnd]), g64) - flat(g64, g64)
-            if float(resid @ delta) > 0.5 * float(delta @ delta) > 0.0:
-                flips.append(cnd)
+        # (a flip's effect on the gradient does not depend on the other flips -- the L1 terms are separable -- but the effects overlap where
+        #  edges share vertices: greedy over the candidates with the residual UPDATED after every accepted flip, twice over the list)
+        base = flat(g64, g64)
+        resid = flat(cap.grads, g64) - base
+        deltas = [flat(run(build_cpu, torch.float64, flips=[cnd]), g64) - base for cnd in cands]
+        taken = [False] * len(cands)
+        for _sweep in range(2):
+            for ci, (cnd, delta) in enumerate(zip(cands, deltas)):
+                if not taken[ci] and float(resid @ delta) > 0.5 * float(delta @ delta) > 0.0:
+                    taken[ci] = True
+                    flips.append(cnd)
+                    resid = resid - delta
         assert len(flips) <= 8, ("regulariser L1 ties", len(flips), len(cands))
         if flips:
             g64 = run(build_cpu, torch.float64, flips=flips)
