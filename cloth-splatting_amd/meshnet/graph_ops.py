@@ -48,15 +48,7 @@ class GraphCSR:
             dev = self.ei.device
             perm = self.perm["dst"][:self.E].long()
             dst_s, src_s = self.ei[1][perm].contiguous(), self.ei[0][perm].contiguous()
-            r = torch.arange(self.E, device=dev)
-            new = (r % 8 == 0)
-            if self.E > 1:
-                new[1:] |= dst_s[1:] != dst_s[:-1]
-            pidx = torch.cumsum(new.to(torch.int32), 0, dtype=torch.int32) - 1
-            npieces = int(pidx[-1].item()) + 1 if self.E else 0
-            gp0 = pidx[0::8].contiguous() if self.E else torch.zeros(0, dtype=torch.int32, device=dev)
-            pidx_ext = torch.cat([pidx, torch.tensor([npieces], dtype=torch.int32, device=dev)])
-            pp = pidx_ext[self.rowptr["dst"].long()].contiguous()
+            gp0, pp, npieces = piece_numbering(dst_s, self.rowptr["dst"])
             self._agg_plan = {"perm": perm, "dst": dst_s, "src": src_s, "gp0": gp0, "pp": pp, "npieces": npieces,
                               "iota": torch.arange(max(npieces, 1), dtype=torch.int32, device=dev)}
         return self._agg_plan
@@ -79,6 +71,25 @@ class GraphCSR:
 
 def _f32(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def piece_numbering(dst_sorted, rowptr, group=8):
+    """The numbering of the "pieces" the one-launch edge MLP leaves instead of messages (csplat_gnn_edge_mlp3 with `pieces`): rows are edges in
+    destination order; a piece = a maximal run of rows with one destination, cut additionally at every multiple of `group` rows (a wave
+    of the kernel sums its own 8 rows); pieces are numbered in row order.  Returns (gp0 [ceil(E / group)] int32: first piece of each
+    group of rows, pp [N + 1] int32: node v's pieces are pp[v] .. pp[v + 1] - 1, npieces).  Plain tensor operations: any device."""
+    E = int(dst_sorted.numel())
+    dev = dst_sorted.device
+    if E == 0:
+        return torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(rowptr.numel(), dtype=torch.int32, device=dev), 0
+    new = (torch.arange(E, device=dev) % group == 0)
+    if E > 1:
+        new[1:] |= dst_sorted[1:] != dst_sorted[:-1]
+    pidx = torch.cumsum(new.to(torch.int32), 0, dtype=torch.int32) - 1
+    npieces = int(pidx[-1].item()) + 1
+    gp0 = pidx[0::group].contiguous()
+    pidx_ext = torch.cat([pidx, torch.tensor([npieces], dtype=torch.int32, device=dev)])
+    return gp0, pidx_ext[rowptr.long()].contiguous(), npieces
 
 
 class EdgeCombine(torch.autograd.Function):

@@ -938,3 +938,32 @@ def test_binning_full_size_against_a_vectorised_numpy_restatement():
     ranges = np.zeros((gx * gy, 2), np.int32)
     ranges[tiles[starts], 0] = starts; ranges[tiles[starts], 1] = ends
     np.testing.assert_array_equal(ranges, o.ranges)
+
+
+@pytest.mark.parametrize("E,N", [(0, 3), (1, 1), (5, 3), (64, 2), (1000, 37), (4099, 5000)])
+def test_piece_numbering_of_the_fused_aggregation(E, N):
+    """meshnet.graph_ops.piece_numbering (host side of csplat_gnn_edge_mlp3's fused aggregation, /root/reference/meshnet/graph_network.py:
+    201-222 aggr = 'add'): against a plain loop -- a piece per maximal run of equal destination, cut every 8 rows, numbered in row order --
+    and the property the node side relies on: summing rows by piece, then a node's pieces pp[v] .. pp[v + 1] - 1, gives the per-node sums
+    of the rows (nodes without edges: empty ranges)."""
+    import torch
+    from meshnet.graph_ops import piece_numbering
+    gen = torch.Generator().manual_seed(E + N)
+    dst = torch.sort(torch.randint(0, N, (E,), generator=gen)).values
+    if E > 40:
+        dst[3:40] = dst[3]                     # a run across several groups of 8
+        dst = torch.sort(dst).values
+    rowptr = torch.zeros(N + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=N), 0).to(torch.int32)
+    gp0, pp, npieces = piece_numbering(dst, rowptr)
+    piece_of_row, p = [], -1
+    for r in range(E):
+        if r % 8 == 0 or dst[r] != dst[r - 1]:
+            p += 1
+        piece_of_row.append(p)
+    assert npieces == p + 1 and gp0.tolist() == piece_of_row[0::8] and pp.shape == (N + 1,) and int(pp[-1]) == npieces
+    vals = torch.randn(E, 3, generator=gen, dtype=torch.float64)
+    pieces = torch.zeros(max(npieces, 1), 3, dtype=torch.float64).index_add_(0, torch.tensor(piece_of_row, dtype=torch.long), vals)
+    per_node = torch.stack([pieces[int(pp[v]):int(pp[v + 1])].sum(0) for v in range(N)])
+    ref = torch.zeros(N, 3, dtype=torch.float64).index_add_(0, dst, vals)
+    assert torch.allclose(per_node, ref, atol=1e-12)
