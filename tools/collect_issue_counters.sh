@@ -9,6 +9,7 @@ TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
+sha1sum "$ROOT/cloth-splatting_amd/csrc/csplat_raster.hip" | cut -d" " -f1 > "$OUT/raster_src_sha1.txt"
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-gnn --no-sustained --no-speculation"
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SMEM"
@@ -25,5 +26,14 @@ for P in "$P1" "$P2"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/issue_serial_$i" -o p -- $CMD --no-view-streams > "$OUT/issue_serial_$i.log" 2>&1
 done
-find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
-ls "$OUT"
+# SUMMARIZE=1: form the summary HERE, on the box, under gpurun_out/<tag>_profiles/ (copy it into profiles/), and drop the raw per-dispatch files
+# (gpurun merges at most 64 MiB back)
+if [ -n "${SUMMARIZE:-}" ]; then
+  cd "$ROOT" && CSPLAT_PROFILES_DST="$ROOT/gpurun_out/${TAG}_profiles" python3 tools/summarize_issue_counters.py "$TAG" > "$OUT/summarize_issue.log" 2>&1
+  find "$OUT" -name "*kernel_trace.csv" -delete
+  find "$OUT" -name "*counter_collection.csv" -delete
+  ls "$ROOT/gpurun_out/${TAG}_profiles"
+else
+  find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
+  ls "$OUT"
+fi
