@@ -864,7 +864,11 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
     ProfScope ps(PROF_GNN, s);
     // the kernel addresses its rows through 32-bit buffer offsets (rows past the end dropped by the hardware's bounds check): 2^22 rows =
     // 2 GiB of [.,128] floats per launch
-    constexpr int64_t CHUNK = (int64_t)1 << 22;
+    static const int64_t CHUNK = [] {      // (CSPLAT_EM_CHUNK_ROWS: a smaller chunk, a multiple of 64, so that tests reach the loop)
+        const char *e = getenv("CSPLAT_EM_CHUNK_ROWS");
+        const int64_t v = e ? atoll(e) : 0;
+        return (v >= 64 && v % 64 == 0 && v <= ((int64_t)1 << 22)) ? v : (int64_t)1 << 22;
+    }();
     for (int64_t r0 = 0; r0 < E; r0 += CHUNK) {
         const int64_t rows = E - r0 < CHUNK ? E - r0 : CHUNK;
         const int64_t nst = (rows + 63) / 64;

@@ -1,6 +1,8 @@
 """GPU parity of distCUDA2 and of the MeshNet message-passing path (through the C-ABI) against the oracle and the
 shim-derived golden vectors of the reference modules."""
 import numpy as np
+import os
+
 import pytest
 
 import util
@@ -878,6 +880,46 @@ def test_edge_mlp3_fused_aggregation_vs_messages_and_segment_sum(E, N):
     assert rel_err(runs[0].cpu().numpy(), ref.cpu().numpy()) < 2e-6
     empty = torch.bincount(dst, minlength=N) == 0
     assert float(runs[0][empty.cuda()].abs().max() if empty.any() else 0.0) == 0.0
+
+
+def test_edge_mlp3_row_chunks():
+    """csplat_gnn_edge_mlp3 addresses its rows through 32-bit buffer offsets and therefore walks edge lists longer than 2^22 rows in chunks
+    (index arrays, piece numbering and outputs offset per chunk).  With CSPLAT_EM_CHUNK_ROWS=4096 in a fresh process, E = 10,005 takes
+    three launches: messages and fused aggregation bit-equal to the one-launch results."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "cloth-splatting_amd"))
+from meshnet.graph_ops import GraphCSR, absmax, edge_mlp3, edge_mlp3_pack, gather_rows
+gen = torch.Generator().manual_seed(3)
+E, N = 10_005, 300
+ei = torch.stack([torch.randint(0, N, (E,), generator=gen), torch.randint(0, N, (E,), generator=gen)]).cuda()
+e0 = torch.randn(E, 128, generator=gen).cuda()
+W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(3)]
+b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+xa, xb = torch.randn(N, 128, generator=gen).cuda(), torch.randn(N, 128, generator=gen).cuda()
+norm = torch.nn.LayerNorm(128).cuda()
+with torch.no_grad():
+    plan = GraphCSR(ei, N).agg_plan()
+    img, am = edge_mlp3_pack(*W), absmax(e0)
+    msg = edge_mlp3(e0, 4.0, xa, ei[1], xb, ei[0], img, b[0], b[1], b[2], norm, e0_absmax=am)
+    pieces = torch.zeros(plan["npieces"], 128, device="cuda")
+    edge_mlp3(gather_rows(e0, plan["perm"]), 4.0, xa, plan["dst"], xb, plan["src"], img, b[0], b[1], b[2], norm, e0_absmax=am, agg=(plan["gp0"], pieces))
+torch.save({"msg": msg.cpu(), "pieces": pieces.cpu()}, sys.argv[1])
+"""
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for chunk in ("", "4096"):
+            path = os.path.join(td, f"o{chunk}.pt")
+            env = dict(os.environ)
+            env.pop("CSPLAT_EM_CHUNK_ROWS", None)
+            if chunk:
+                env["CSPLAT_EM_CHUNK_ROWS"] = chunk
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs.append(torch.load(path))
+    assert torch.equal(outs[0]["msg"], outs[1]["msg"]) and torch.equal(outs[0]["pieces"], outs[1]["pieces"])
 
 
 @pytest.mark.parametrize("mode", [0, 1])
