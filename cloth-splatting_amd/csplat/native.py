@@ -112,7 +112,7 @@ EXPORTS = {
     "csplat_linear_narrow128": (_i, [_vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_node_update_image_bytes": (_sz, []),
     "csplat_gnn_node_update_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "csplat_gnn_node_update_packed": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "csplat_gnn_node_update_packed": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "csplat_gnn_edge_mlp3_image_bytes": (_sz, []),
     "csplat_gnn_edge_mlp3_pack": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
                                                            const float *__restrict__ b2, const float *__restrict__ b3,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                            int has_next, float *__restrict__ x_new, float *__restrict__ xa,
-                                                           float *__restrict__ xb) {
+                                                           float *__restrict__ xb, const int *__restrict__ piece_ptr) {
     extern __shared__ char s_mem[];
     el16 *const sB = reinterpret_cast<el16 *>(s_mem);                                         // three tiles of three pieces
     float2 *const sS = reinterpret_cast<float2 *>(s_mem + (size_t)3 * NB_XT * 2);             // [32][wave 4] (sum, M2)
@@ -661,7 +661,17 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
         for (int k = 0; k < 4; k++) {
             int64_t row = row0 + 8 * w + 2 * k + h;
             row = row < N ? row : N - 1;
-            v[k] = *reinterpret_cast<const float4 *>(src + row * EM_N + 4 * n);
+            if (a == 0 && piece_ptr) {
+                // the aggregate arrives as the edge launch's "pieces" (csplat_gnn_edge_mlp3): node `row` owns pieces piece_ptr[row] ..
+                // piece_ptr[row + 1] - 1, summed here in that order -- what csplat_gnn_segment_sum over the pieces would have written
+                const int p0 = piece_ptr[row], p1 = piece_ptr[row + 1];
+                float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int p = p0; p < p1; p++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)p * EM_N + 4 * n);
+                    acc4.x += t.x; acc4.y += t.y; acc4.z += t.z; acc4.w += t.w;
+                }
+                v[k] = acc4;
+            } else v[k] = *reinterpret_cast<const float4 *>(src + row * EM_N + 4 * n);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -903,7 +913,7 @@ extern "C" int csplat_gnn_node_update_pack(void *stream, const float *Wa, const 
 
 extern "C" int csplat_gnn_node_update_packed(void *stream, int64_t N, const float *agg, const float *x, const void *image, const float *b0,
                                              const float *b2, const float *b3, const float *ln_gamma, const float *ln_beta, float ln_eps,
-                                             int has_next, float *x_new, float *xa_next, float *xb_next) {
+                                             int has_next, float *x_new, float *xa_next, float *xb_next, const int32_t *piece_ptr) {
     CSPLAT_REQUIRE(N >= 0 && (N == 0 || (agg && x && image && b0 && b2 && b3 && ln_gamma && ln_beta && x_new)), "csplat_gnn_node_update_packed: bad arguments");
     CSPLAT_REQUIRE(!has_next || (xa_next && xb_next), "csplat_gnn_node_update_packed: next-layer outputs missing");
     CSPLAT_REQUIRE(x_new != x && x_new != agg, "csplat_gnn_node_update_packed: x_new must not alias an input (the residual reads x)");
@@ -920,7 +930,7 @@ extern "C" int csplat_gnn_node_update_packed(void *stream, int64_t N, const floa
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_GNN, s);
     k_node_update_b3<<<(unsigned)((N + 31) / 32), 256, NB_LDS_BYTES, s>>>(N, agg, x, (const i32x4 *)image, b0, b2, b3, ln_gamma, ln_beta, ln_eps,
-                                                                          has_next ? 1 : 0, x_new, xa_next, xb_next);
+                                                                          has_next ? 1 : 0, x_new, xa_next, xb_next, piece_ptr);
     LAUNCH_CHECK();
     return 0;
 }

@@ -247,6 +247,12 @@ class InteractionNetwork(nn.Module):
                 edge_mlp3(e0, scale, xa, plan["dst"], xb, plan["src"], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,
                           elins[2].bias, self.edge_fn[1], e0_absmax=e0_absmax, agg=(plan["gp0"], pieces))
                 msg = None
+                lins_n = list(self.node_fn[0].children())[0::2]
+                if NODE_UPDATE_PACKED and len(lins_n) == 3:
+                    # ... added up by the node update's own row loader
+                    nw = next_layer._split_weights() if next_layer is not None else (None, None)
+                    return node_update_packed(pieces, x, self._node_image(w_agg, w_x, lins_n, next_layer, nw), lins_n[0].bias, lins_n[1].bias,
+                                              lins_n[2].bias, self.node_fn[1], next_layer is not None, piece_ptr=plan["pp"])
                 agg = segment_sum_rows(pieces[:plan["npieces"]], plan["pp"], plan["iota"], x.shape[0])
             else:
                 msg = edge_mlp3(e0, scale, xa, csr.ei[1], xb, csr.ei[0], self._edge_image(w_e, elins), elins[0].bias, elins[1].bias,

@@ -538,12 +538,14 @@ def node_update_pack(w_agg, w_x, w2, w3, w_i_next=None, w_j_next=None):
     return img
 
 
-def node_update_packed(agg, x, image, b0, b2, b3, layer_norm, has_next):
-    """node_update() on the pre-packed weights (csplat_gnn_node_update_packed, include/csplat.h): returns (x_new, xa', xb')"""
+def node_update_packed(agg, x, image, b0, b2, b3, layer_norm, has_next, piece_ptr=None):
+    """node_update() on the pre-packed weights (csplat_gnn_node_update_packed, include/csplat.h): returns (x_new, xa', xb').  piece_ptr
+    (int32 [N + 1]): `agg` is the pieces array of edge_mlp3's fused aggregation, a node's aggregate = the sum of its pieces"""
     _n.require_cuda(x)
     agg, x = _f32(agg), _f32(x)
     N = x.shape[0]
-    assert tuple(agg.shape) == (N, 128) and x.shape[1] == 128
+    assert agg.shape[1] == 128 and x.shape[1] == 128 and (piece_ptr is not None or agg.shape[0] == N)
+    assert piece_ptr is None or (piece_ptr.dtype == torch.int32 and piece_ptr.numel() == N + 1)
     c = lambda t: t.detach().contiguous()  # noqa: E731
     x_new = torch.empty_like(x)
     xa = torch.empty_like(x) if has_next else None
@@ -551,7 +553,7 @@ def node_update_packed(agg, x, image, b0, b2, b3, layer_norm, has_next):
     with _n.on_device(x.device):
         _n.check(_n.lib.csplat_gnn_node_update_packed(_n.stream_handle(x.device), N, _n.ptr(agg), _n.ptr(x), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b2)),
                                                       _n.ptr(c(b3)), _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps),
-                                                      int(bool(has_next)), _n.ptr(x_new), _n.ptr(xa), _n.ptr(xb)), "csplat_gnn_node_update_packed")
+                                                      int(bool(has_next)), _n.ptr(x_new), _n.ptr(xa), _n.ptr(xb), _n.ptr(piece_ptr)), "csplat_gnn_node_update_packed")
     return x_new, xa, xb
 
 

@@ -457,13 +457,15 @@ int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const floa
  * scale against fp64) with the six weight matrices PRE-PACKED as MFMA A operands: csplat_gnn_node_update_pack lays Wa, Wx, W2, W3 and the
  * next layer's Wi, Wj (both NULL: none; all [128][128] row-major, contiguous) out in `image` (csplat_gnn_node_update_image_bytes() bytes
  * of device memory, 16-byte aligned) -- once per weight version; csplat_gnn_node_update_packed is the launch (has_next = the image holds
- * Wi / Wj and xa_next / xb_next are written).  18 us against 44 for csplat_gnn_node_update at N = 1e4 (csplat_edge_mlp.hip). */
+ * Wi / Wj and xa_next / xb_next are written).  26 us against 44 for csplat_gnn_node_update at N = 1e4 (csplat_edge_mlp.hip).
+ * piece_ptr != NULL: `agg` holds the PIECES csplat_gnn_edge_mlp3's fused aggregation left, node v's aggregate = the sum of pieces
+ * piece_ptr[v] .. piece_ptr[v + 1] - 1 in that order (int32 [N + 1]) -- formed while the rows are loaded, no csplat_gnn_segment_sum launch. */
 size_t csplat_gnn_node_update_image_bytes(void);
 int csplat_gnn_node_update_pack(void *stream, const float *Wa, const float *Wx, const float *W2, const float *W3, const float *Wi_next,
                                 const float *Wj_next, void *image);
 int csplat_gnn_node_update_packed(void *stream, int64_t N, const float *agg, const float *x, const void *image, const float *b0,
                                   const float *b2, const float *b3, const float *ln_gamma, const float *ln_beta, float ln_eps,
-                                  int has_next, float *x_new, float *xa_next, float *xb_next);
+                                  int has_next, float *x_new, float *xa_next, float *xb_next, const int32_t *piece_ptr);
 
 /* LayerNorm(128) of the MeshNet MLPs under autograd (/root/reference/meshnet/graph_network.py:86-97,139-150: every edge / node
  * MLP ends in nn.LayerNorm), single HBM passes over [M][128] rows:

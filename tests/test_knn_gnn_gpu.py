@@ -842,6 +842,19 @@ def test_node_update_packed_vs_fp64_and_vs_exact_kernel(N, has_next):
             assert g is None
             continue
         assert rel_err(g.cpu().numpy(), r.cpu().numpy()) < 1e-5 and rel_err(g.cpu().numpy(), e.cpu().numpy()) < 1e-5
+    # the aggregate handed over as pieces (0 .. 4 per node, in order): bit-equal to the same launch on their sums
+    cnt = torch.randint(0, 5, (N,), generator=gen)
+    pp = torch.zeros(N + 1, dtype=torch.int32); pp[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    pieces = (torch.randn(int(pp[-1]) + 1, 128, generator=gen) * 10).cuda()
+    agg2 = torch.zeros(N, 128, device="cuda")
+    for j in range(4):                                           # the same order of addition as the kernel's loop
+        sel = (cnt > j).cuda()
+        agg2[sel] = agg2[sel] + pieces[(pp[:-1].long() + j).cuda()[sel]]
+    with torch.no_grad():
+        a = node_update_packed(pieces, x, img, b[0], b[1], b[2], norm, has_next, piece_ptr=pp.cuda())
+        c = node_update_packed(agg2, x, img, b[0], b[1], b[2], norm, has_next)
+    for u, v_ in zip(a, c):
+        assert (u is None and v_ is None) or torch.equal(u, v_)
 
 
 @pytest.mark.parametrize("E,N", [(5, 3), (1000, 7), (20_011, 900), (70_001, 40_000)])
