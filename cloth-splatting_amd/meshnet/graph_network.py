@@ -286,9 +286,26 @@ class Processor(nn.Module):
                                nmlp_layers=nmlp_layers, mlp_hidden_dim=mlp_hidden_dim)
             for _ in range(nmessage_passing_steps)])
 
-    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor, edges_out: bool = True):
+    def takes_destination_order(self, x: torch.Tensor, edge_features: torch.Tensor) -> bool:
+        """whether forward() will run the one-launch edge MLP with its fused aggregation on these inputs -- the path that wants the edge
+        latents in destination order (GraphCSR.agg_plan) and can be handed them that way (dst_order=)"""
+        return bool(len(self.gnn_stacks)) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks) and EDGE_MLP_FUSED and \
+            EDGE_AGG_FUSED and edge_mlp3_mode() == 0 and edge_features.numel() > 0 and \
+            all(len(list(g.edge_fn[0].children())[0::2]) == 3 for g in self.gnn_stacks)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor, edges_out: bool = True, dst_order=None):
         """edges_out=False (EncodeProcessDecode, which drops them): the rollout path returns None for the edge latents instead of spending
-        a pass over [E,128] on 2^M * e0"""
+        a pass over [E,128] on 2^M * e0.  dst_order=(plan, bound): edge_features ALREADY are in the destination order of `plan`
+        (GraphCSR.agg_plan of this edge_index) and `bound` is a device scalar >= max |edge_features| (only when takes_destination_order())"""
+        if dst_order is not None:
+            assert self.takes_destination_order(x, edge_features) and not edges_out
+            plan, amax = dst_order
+            e0_run, scale, xa, xb = edge_features.contiguous(), 1.0, None, None
+            for l, gnn in enumerate(self.gnn_stacks):
+                nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
+                x, xa, xb = gnn.forward_inference(x, edge_index, e0_run, scale, xa, xb, nxt, e0_absmax=amax, plan=plan)
+                scale *= 2.0
+            return x, None
         if len(self.gnn_stacks) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks):
             # rollout: every layer doubles the edge features (F7), so carry e0 and the scalar 2^l instead of 15 [E,128] passes
             e0, scale = edge_features.contiguous(), 1.0
@@ -296,7 +313,7 @@ class Processor(nn.Module):
             # (the fp16 pieces of the one-launch edge MLP take their scale from max |e0|: one pass for all the layers)
             fp16 = EDGE_MLP_FUSED and edge_mlp3_mode() == 0 and e0.numel() > 0
             plan = e0_run = amax = None
-            if fp16 and EDGE_AGG_FUSED and all(len(list(g.edge_fn[0].children())[0::2]) == 3 for g in self.gnn_stacks):
+            if self.takes_destination_order(x, edge_features):
                 plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
                 # the edge latents in destination order, once for all the layers (and max |e0| from the same pass)
                 e0_run, amax = gather_rows(e0, plan["perm"], with_absmax=True)
@@ -345,8 +362,32 @@ class EncodeProcessDecode(nn.Module):
         self._decoder = Decoder(nnode_in=latent_dim, nnode_out=nnode_out_features, nmlp_layers=nmlp_layers,
                                 mlp_hidden_dim=mlp_hidden_dim)
 
+    def _edge_latent_bound(self):
+        """a device scalar >= |any edge latent the encoder can produce|: its MLP ends in LayerNorm(128), whose normalised values are at most
+        sqrt(127) in magnitude, so max|gamma| * sqrt(127) + max|beta| bounds them -- what the one-launch edge MLP takes its fp16 scale from
+        without a pass over the [E,128] latents (re-derived when the LayerNorm's parameters change)"""
+        ln = self._encoder.edge_fn[1]
+        key = (ln.weight._version, ln.bias._version, ln.weight.data_ptr(), ln.weight.device)
+        if getattr(self, "_elb_key", None) != key:
+            with torch.no_grad():
+                self._elb = (ln.weight.abs().max() * (127.0 ** 0.5) + ln.bias.abs().max()).reshape(1).float().contiguous()
+            self._elb_key = key
+        return self._elb
+
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
-        x, edge_features = self._encoder(x, edge_features)
+        if not torch.is_grad_enabled() and EDGE_MLP_FUSED and EDGE_AGG_FUSED and edge_mlp3_mode() == 0 and edge_features.is_cuda and \
+                edge_features.dim() == 2 and edge_features.shape[0] > 0 and edge_features.dtype == torch.float32 and x.dtype == torch.float32 and \
+                isinstance(self._encoder.edge_fn[1], nn.LayerNorm) and self._encoder.edge_fn[1].elementwise_affine:
+            # rollout: the processor's edge launch wants the edges in destination order -- so ENCODE them in that order (a gather of the
+            # [E,4] inputs instead of one of the [E,128] latents)
+            plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
+            xe, ee = self._encoder(x, edge_features[plan["perm"]])
+            if self._processor.takes_destination_order(xe, ee):
+                xp, _edges = self._processor(xe, edge_index, ee, edges_out=False, dst_order=(plan, self._edge_latent_bound()))
+                return self._decoder(xp)
+            x, edge_features = xe, torch.empty_like(ee).index_copy_(0, plan["perm"], ee)      # (not that path after all: back to edge order)
+        else:
+            x, edge_features = self._encoder(x, edge_features)
         x, _edges = self._processor(x, edge_index, edge_features, edges_out=False)
         x = self._decoder(x)
         return x
