@@ -386,15 +386,14 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         if (m & 1) jb[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ib, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
         else ja[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ia, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
     };
-    float4 GA[4], GB[4];
-    auto g_issue_op = [&](int m, const int (&ja)[4], const int (&jb)[4]) __attribute__((always_inline)) {      // 8 operations
+    auto g_issue_op = [&](int m, float4 (&GA)[4], float4 (&GB)[4], const int (&ja)[4], const int (&jb)[4]) __attribute__((always_inline)) {      // 8 operations
         const int k = m >> 1;
         if (EM_SKIP & 256) return;
         if (m & 1) GB[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xb) + (size_t)((unsigned)jb[k] * 512u + 16u * n));
         else GA[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xa) + (size_t)((unsigned)ja[k] * 512u + 16u * n));
     };
     // G = (xa[dst] + xb[src] + b0) / alpha, what layer 1's accumulators start from: 12 operations
-    auto g_commit_op = [&](int m, float *Gt) __attribute__((always_inline)) {
+    auto g_commit_op = [&](int m, float4 (&GA)[4], float4 (&GB)[4], float *Gt) __attribute__((always_inline)) {
         const int k = m / 3, part = m % 3;
         if (part == 0) { GA[k].x += GB[k].x; GA[k].y += GB[k].y; GA[k].z += GB[k].z; GA[k].w += GB[k].w; }
         else if (part == 1) {
@@ -477,24 +476,24 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     // phase, a phase earlier (so that no wait stands behind the rows out: vmcnt counts stores too, in order), measured 5 % SLOWER: what
     // is below spreads the requests over the phases.
     int jaA[4], jbA[4], jaB[4], jbB[4];
-    float4 EA[4], EB[4];
+    float4 EA[4], EB[4], GAa[4], GBa[4], GAb[4], GBb[4];
     {   // the first two tiles' inputs, synchronously
 #pragma unroll
         for (int m = 0; m < 8; m++) { idx_op(m, (unsigned)T0 * 32u, jaA, jbA); idx_op(m, (unsigned)(T0 + stride) * 32u, jaB, jbB); }
 #pragma unroll
-        for (int m = 0; m < 8; m++) g_issue_op(m, jaA, jbA);
+        for (int m = 0; m < 8; m++) g_issue_op(m, GAa, GBa, jaA, jbA);
 #pragma unroll
         for (int k = 0; k < 4; k++) { e_issue_op(k, EA, (unsigned)T0 * 16384u); e_issue_op(k, EB, (unsigned)(T0 + stride) * 16384u); }
 #pragma unroll
-        for (int m = 0; m < 12; m++) g_commit_op(m, GtA);
+        for (int m = 0; m < 12; m++) g_commit_op(m, GAa, GBa, GtA);
 #pragma unroll
-        for (int m = 0; m < 8; m++) g_issue_op(m, jaB, jbB);
+        for (int m = 0; m < 8; m++) g_issue_op(m, GAb, GBb, jaB, jbB);
 #pragma unroll
         for (int m = 0; m < EC_OPS; m++) e_commit_op(m, EA, XA);      // (one list at a time: the operations of a list share their temporaries)
 #pragma unroll
         for (int m = 0; m < EC_OPS; m++) e_commit_op(m, EB, XB);
 #pragma unroll
-        for (int m = 0; m < 12; m++) g_commit_op(m, GtB);
+        for (int m = 0; m < 12; m++) g_commit_op(m, GAb, GBb, GtB);
     }
     f32x16 accA, accB, accLA, accLB;
 #pragma unroll
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         phase(0, XA0, GtA + (size_t)n * ER_GSTRIDE, accA, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 2)) ER_SPREAD(k, SL(0), SL(18), LNP_OPS, lnp_op(m, accLB, SrB));
             if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(14), SL(44), LNF_OPS, lnf_op(m, accLA, SrA, offA_prev, YtA));
-            if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(44), SL(48), 8, idx_op(m, (unsigned)tA2 * 32u, jaA, jbA));
+            if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(40), SL(48), 8, idx_op(m, (unsigned)tA2 * 32u, jaA, jbA));
         });
         __syncthreads();
         stamp();
@@ -522,27 +521,27 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
             if (AGG) ER_SPREAD(k, SL(6), SL(42), 9, agg_op(m, YtA, tA_prev));
             else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(40), 8, rows_out_op(m, YtA, offA_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA1));
-            if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(44), SL(48), 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
+            if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(40), SL(48), 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
+            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 8, g_issue_op(m, GAa, GBa, jaA, jbA));
         });
         __syncthreads();
         stamp();
         // 2: layer 2 of A | B's ReLU + pieces, the next A's gathers
         phase(1, XA1, sT, accA, [&](int k) __attribute__((always_inline)) {
-            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(0), SL(8), 8, g_issue_op(m, jaA, jbA));
+            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 8, g_issue_op(m, GAb, GBb, jaB, jbB));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
             if (AGG) ER_SPREAD(k, SL(8), SL(44), 9, agg_op(m, YtB, tB_prev));
             else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(32), 8, rows_out_op(m, YtB, offB_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB1));
-            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 12, g_commit_op(m, GtA));
+            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(20), SL(44), 12, g_commit_op(m, GAa, GBa, GtA));
         });
         __syncthreads();
         stamp();
         // 3: layer 2 of B | A's ReLU + pieces, the next B's gathers, the next A's edge rows requested
         phase(1, XB1, sT, accB, [&](int k) __attribute__((always_inline)) {
-            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(0), SL(8), 8, g_issue_op(m, jaB, jbB));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EB, (unsigned)tB2 * 16384u));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA0));
-            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 12, g_commit_op(m, GtB));
+            if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(20), SL(44), 12, g_commit_op(m, GAb, GBb, GtB));
         });
         __syncthreads();
         stamp();

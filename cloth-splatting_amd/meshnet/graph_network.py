@@ -381,7 +381,7 @@ class EncodeProcessDecode(nn.Module):
             # rollout: the processor's edge launch wants the edges in destination order -- so ENCODE them in that order (a gather of the
             # [E,4] inputs instead of one of the [E,128] latents)
             plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
-            xe, ee = self._encoder(x, edge_features[plan["perm"]])
+            xe, ee = self._encoder(x, gather_rows(edge_features, plan["perm"]))
             if self._processor.takes_destination_order(xe, ee):
                 xp, _edges = self._processor(xe, edge_index, ee, edges_out=False, dst_order=(plan, self._edge_latent_bound()))
                 return self._decoder(xp)
