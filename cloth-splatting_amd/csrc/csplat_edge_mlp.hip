@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
 // operands (csplat_gnn_node_update_pack: [matrix 6][wave 4][piece 3][step 8][lane] x 16 bytes) and streamed from L2 into registers half
 // a product ahead; one 32-row tile per 4-wave workgroup, wave j = output features 32j .. 32j + 31, activations between the layers as
 // piece tiles in LDS.  ~160 registers and 80 KB of LDS: two workgroups per CU, which is what fills the gaps (the layers of a tile are
-// a dependent chain).
+// a dependent chain).  (Two tiles per workgroup sharing each weight operand -- half the 576 KB of packed weights per row through the L1 --
+// measured SLOWER, 36.9 against 30.3 us: the chain of six products per tile, not the weight traffic, is what a workgroup waits for.)
 constexpr int NB_MATS = 6;                                         // Wa, Wx, W2, W3, Wi', Wj'
 constexpr size_t NB_IMAGE_BYTES = (size_t)NB_MATS * 4 * 3 * 8 * 64 * 16;      // 589,824
 constexpr int NB_XT = 3 * ER_TILE_P;
