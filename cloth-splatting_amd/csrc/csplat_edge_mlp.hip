@@ -59,6 +59,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short el16;              // a 16-bit piece in LDS (bf16 or fp16 by mode)
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 
 constexpr int EM_N = 128;                 // layer width
 constexpr int EM_STRIDE = 136;            // 16-bit elements per activation row in LDS (272 B: conflict-free 16-byte operand reads)
@@ -601,6 +602,7 @@ constexpr size_t NB_IMAGE_BYTES = (size_t)NB_MATS * 4 * 3 * 8 * 64 * 16;      //
 constexpr int NB_XT = 3 * ER_TILE_P;
 constexpr size_t NB_LDS_BYTES = (size_t)3 * NB_XT * 2 + 32 * 4 * 8;           // three piece tiles + LayerNorm partials
 
+template <bool F16>
 __global__ __launch_bounds__(64) void k_node_pack(const float *__restrict__ W0, const float *__restrict__ W1, const float *__restrict__ W2,
                                                   const float *__restrict__ W3, const float *__restrict__ W4, const float *__restrict__ W5,
                                                   i32x4 *__restrict__ img) {
@@ -610,17 +612,22 @@ __global__ __launch_bounds__(64) void k_node_pack(const float *__restrict__ W0, 
     const float *W = mat == 0 ? W0 : mat == 1 ? W1 : mat == 2 ? W2 : mat == 3 ? W3 : mat == 4 ? W4 : W5;
     if (!W) return;
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    constexpr int NP = F16 ? 2 : 3;
     el16 p[3][8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float x = W[(size_t)(32 * j + m) * EM_N + er_src_col(mat < 2 ? 0 : 1, 64 * h + 8 * st + i)];
 #pragma unroll
-        for (int q = 0; q < 3; q++) { const __bf16 v = (__bf16)x; p[q][i] = __builtin_bit_cast(el16, v); x -= (float)v; }
+        for (int q = 0; q < NP; q++) {
+            if (F16) { const _Float16 v = (_Float16)x; p[q][i] = __builtin_bit_cast(el16, v); x -= (float)v; }
+            else { const __bf16 v = (__bf16)x; p[q][i] = __builtin_bit_cast(el16, v); x -= (float)v; }
+        }
     }
 #pragma unroll
-    for (int q = 0; q < 3; q++) img[((size_t)((mat * 4 + j) * 3 + q) * 8 + st) * 64 + lane] = *reinterpret_cast<const i32x4 *>(p[q]);
+    for (int q = 0; q < NP; q++) img[((size_t)((mat * 4 + j) * NP + q) * 8 + st) * 64 + lane] = *reinterpret_cast<const i32x4 *>(p[q]);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const float *__restrict__ agg, const float *__restrict__ x,
                                                            const i32x4 *__restrict__ img, const float *__restrict__ b0,
                                                            const float *__restrict__ b2, const float *__restrict__ b3,
@@ -633,20 +640,33 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 32;
-    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+    // F16: two fp16 pieces per operand, three products per step -- half the MFMAs of the layers' dependent chain.  fp16's range is kept by
+    // running everything multiplied by SC = 2^-4 (exact: ReLU is homogeneous, LayerNorm takes SC^2 eps, the next layer's products are
+    // multiplied back): aggregates and latents up to ~1e6 in magnitude fit, and an element below 2 of the original units keeps an absolute
+    // error of 5e-7 -- node latents and aggregates of LayerNorm'd messages are O(1 .. 100).
+    constexpr int NP = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
+    constexpr float SC = F16 ? 0.0625f : 1.f, ISC = F16 ? 16.f : 1.f;
     auto pk = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
-        b16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+        if (F16) { h16x2 v; v[0] = (_Float16)lo; v[1] = (_Float16)hi; return __builtin_bit_cast(unsigned, v); }
+        bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
         return __builtin_bit_cast(unsigned, v);
     };
-    auto lo_f = [&](unsigned q) { return __uint_as_float(q << 16); };
-    auto hi_f = [&](unsigned q) { return __uint_as_float(q & 0xffff0000u); };
+    auto lo_f = [&](unsigned q) __attribute__((always_inline)) -> float {
+        if (F16) return (float)__builtin_bit_cast(h16x2, q)[0];
+        return __uint_as_float(q << 16);
+    };
+    auto hi_f = [&](unsigned q) __attribute__((always_inline)) -> float {
+        if (F16) return (float)__builtin_bit_cast(h16x2, q)[1];
+        return __uint_as_float(q & 0xffff0000u);
+    };
+    eps *= SC * SC;
 
     // weights: the 24 A operands of a product in two halves (steps 0-3, 4-7), each requested half a product ahead
-    i32x4 wq[2][12];
+    i32x4 wq[2][4 * NP];
     auto fetch = [&](int mat, int half) __attribute__((always_inline)) {
-        const i32x4 *src = img + ((size_t)(mat * 4 + w) * 3 * 8) * 64 + lane;
+        const i32x4 *src = img + ((size_t)(mat * 4 + w) * NP * 8) * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < 3; p++)
+        for (int p = 0; p < NP; p++)
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) wq[half][p * 4 + s4] = src[(size_t)(p * 8 + 4 * half + s4) * 64];
     };
@@ -676,9 +696,9 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             el16 *dst = sB + (size_t)a * NB_XT + (size_t)(8 * w + 2 * k + h) * EM_STRIDE + 4 * n;
-            float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            float e[4] = {v[k].x * SC, v[k].y * SC, v[k].z * SC, v[k].w * SC};
 #pragma unroll
-            for (int p = 0; p < 3; p++) {
+            for (int p = 0; p < NP; p++) {
                 const unsigned q0 = pk(e[0], e[1]), q1 = pk(e[2], e[3]);
                 *reinterpret_cast<uint2 *>(dst + (size_t)p * ER_TILE_P) = make_uint2(q0, q1);
                 e[0] -= lo_f(q0); e[1] -= hi_f(q0); e[2] -= lo_f(q1); e[3] -= hi_f(q1);
@@ -697,24 +717,27 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
 
     // one product: acc += W_mat (registers) x tile (pieces in LDS); the next weights are requested as the halves free up
     auto product = [&](const el16 *Bt, f32x16 &acc, int next_mat) __attribute__((always_inline)) {
-        constexpr int WP[6] = {0, 2, 1, 0, 1, 0}, XP[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int WP[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0}, XP[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};
         const el16 *row = Bt + (size_t)n * EM_STRIDE + 64 * h;
-        i32x4 bc[3], bn[3];
+        i32x4 bc[NP], bn[NP];
 #pragma unroll
-        for (int p = 0; p < 3; p++) bc[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P);
+        for (int p = 0; p < NP; p++) bc[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P);
 #pragma unroll
         for (int st = 0; st < 8; st++) {
             if (st < 7) {
 #pragma unroll
-                for (int p = 0; p < 3; p++) bn[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P + 8 * (st + 1));
+                for (int p = 0; p < NP; p++) bn[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P + 8 * (st + 1));
             }
 #pragma unroll
-            for (int i = 0; i < 6; i++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, wq[st >> 2][WP[i] * 4 + (st & 3)]),
-                                                              __builtin_bit_cast(bf16x8v, bc[XP[i]]), acc, 0, 0, 0);
+            for (int i = 0; i < NPROD; i++) {
+                if (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, wq[st >> 2][WP[i] * 4 + (st & 3)]),
+                                                                      __builtin_bit_cast(f16x8v, bc[XP[i]]), acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, wq[st >> 2][WP[i] * 4 + (st & 3)]),
+                                                                   __builtin_bit_cast(bf16x8v, bc[XP[i]]), acc, 0, 0, 0);
+            }
             if (st == 3 && next_mat >= 0) fetch(next_mat, 0);
 #pragma unroll
-            for (int p = 0; p < 3; p++) bc[p] = bn[p];
+            for (int p = 0; p < NP; p++) bc[p] = bn[p];
         }
         if (next_mat >= 0) fetch(next_mat, 1);
     };
@@ -722,17 +745,17 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float4 t = b ? *reinterpret_cast<const float4 *>(b + 32 * w + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-            acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
+            acc[4 * q] = t.x * SC; acc[4 * q + 1] = t.y * SC; acc[4 * q + 2] = t.z * SC; acc[4 * q + 3] = t.w * SC;
         }
     };
     // 16 values of row n -> the next product's pieces, positions 32w + 16h .. + 15
-    auto to_pieces = [&](const float (&v)[16], el16 *Bt) __attribute__((always_inline)) {
+    auto to_pieces = [&](const float (&v)[16], el16 *Bt, float scale) __attribute__((always_inline)) {
         float e[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) e[r] = v[r];
+        for (int r = 0; r < 16; r++) e[r] = F16 ? v[r] * scale : v[r];
         el16 *dst = Bt + (size_t)n * EM_STRIDE + 32 * w + 16 * h;
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < NP; p++) {
             unsigned q[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) { q[j] = pk(e[2 * j], e[2 * j + 1]); e[2 * j] -= lo_f(q[j]); e[2 * j + 1] -= hi_f(q[j]); }
@@ -757,14 +780,14 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
     product(B1, acc, 2);
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[r], 0.f);
-    to_pieces(v, B2);
+    to_pieces(v, B2, 1.f);
     __syncthreads();
     // ---- layer 2
     start_from(b2, acc);
     product(B2, acc, 3);
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[r], 0.f);
-    to_pieces(v, B0);
+    to_pieces(v, B0, 1.f);
     __syncthreads();
     // ---- layer 3, LayerNorm (the four waves' partials combined by the parallel-variance formula), residual
     start_from(b3, acc);
@@ -799,17 +822,17 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
     store_rows(v, x_new);
     if (!has_next) return;
     // ---- the next layer's node-level products of the updated latents
-    to_pieces(v, B1);
+    to_pieces(v, B1, SC);
     __syncthreads();
     start_from(nullptr, acc);
     product(B1, acc, 5);
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = acc[r];
+    for (int r = 0; r < 16; r++) v[r] = acc[r] * ISC;
     store_rows(v, xa);
     start_from(nullptr, acc);
     product(B1, acc, -1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = acc[r];
+    for (int r = 0; r < 16; r++) v[r] = acc[r] * ISC;
     store_rows(v, xb);
 }
 
@@ -906,7 +929,8 @@ extern "C" int csplat_gnn_node_update_pack(void *stream, const float *Wa, const 
                                            const float *Wj_next, void *image) {
     CSPLAT_REQUIRE(Wa && Wx && W2 && W3 && image && (Wi_next == nullptr) == (Wj_next == nullptr), "csplat_gnn_node_update_pack: bad arguments");
     CSPLAT_REQUIRE(((uintptr_t)image & 15u) == 0, "csplat_gnn_node_update_pack: the image must be 16-byte aligned");
-    k_node_pack<<<NB_MATS * 4 * 8, 64, 0, (hipStream_t)stream>>>(Wa, Wx, W2, W3, Wi_next, Wj_next, (i32x4 *)image);
+    if (g_em_mode == 0) k_node_pack<true><<<NB_MATS * 4 * 8, 64, 0, (hipStream_t)stream>>>(Wa, Wx, W2, W3, Wi_next, Wj_next, (i32x4 *)image);
+    else k_node_pack<false><<<NB_MATS * 4 * 8, 64, 0, (hipStream_t)stream>>>(Wa, Wx, W2, W3, Wi_next, Wj_next, (i32x4 *)image);
     LAUNCH_CHECK();
     return 0;
 }
@@ -923,13 +947,18 @@ extern "C" int csplat_gnn_node_update_packed(void *stream, int64_t N, const floa
     if (N == 0) return 0;
     static int s_ok = -1;
     if (s_ok < 0) {
-        s_ok = hipFuncSetAttribute((const void *)k_node_update_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        s_ok = hipFuncSetAttribute((const void *)k_node_update_b3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_node_update_b3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
         (void)hipGetLastError();
     }
     CSPLAT_REQUIRE(s_ok, "csplat_gnn_node_update_packed: 78 KB of dynamic LDS refused by the runtime");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_GNN, s);
-    k_node_update_b3<<<(unsigned)((N + 31) / 32), 256, NB_LDS_BYTES, s>>>(N, agg, x, (const i32x4 *)image, b0, b2, b3, ln_gamma, ln_beta, ln_eps,
+    if (g_em_mode == 0)
+        k_node_update_b3<true><<<(unsigned)((N + 31) / 32), 256, NB_LDS_BYTES, s>>>(N, agg, x, (const i32x4 *)image, b0, b2, b3, ln_gamma, ln_beta, ln_eps,
+                                                                          has_next ? 1 : 0, x_new, xa_next, xb_next, piece_ptr);
+    else
+        k_node_update_b3<false><<<(unsigned)((N + 31) / 32), 256, NB_LDS_BYTES, s>>>(N, agg, x, (const i32x4 *)image, b0, b2, b3, ln_gamma, ln_beta, ln_eps,
                                                                           has_next ? 1 : 0, x_new, xa_next, xb_next, piece_ptr);
     LAUNCH_CHECK();
     return 0;

@@ -209,7 +209,7 @@ class InteractionNetwork(nn.Module):
     def _node_image(self, w_agg, w_x, lins, next_layer, nw):
         """the packed register image of the node update's weights (+ the next layer's x_i / x_j blocks), re-packed only when one changed"""
         key = (self._wsplit_key, lins[1].weight._version, lins[2].weight._version, lins[1].weight.data_ptr(), lins[2].weight.data_ptr(),
-               None if next_layer is None else next_layer._wsplit_key)
+               None if next_layer is None else next_layer._wsplit_key, edge_mlp3_mode())
         if getattr(self, "_nimg_key", None) != key:
             with torch.no_grad():
                 self._nimg = node_update_pack(w_agg, w_x, lins[1].weight, lins[2].weight, nw[0], nw[1])

@@ -815,13 +815,16 @@ def test_edge_mlp3_one_launch_vs_fp64_and_vs_three_launches(E, alpha, mode):
 
 @pytest.mark.parametrize("N", [1, 33, 10_000])
 @pytest.mark.parametrize("has_next", [False, True])
-def test_node_update_packed_vs_fp64_and_vs_exact_kernel(N, has_next):
-    """csplat_gnn_node_update_packed (three bf16 pieces per operand, pre-packed weights; /root/reference/meshnet/graph_network.py:203-222)
-    against the fp64 composition and against csplat_gnn_node_update (exact fp32 MFMA): 1e-5 of each output's scale; aggregates of O(30)
-    and latents of O(5) as the rollout has them."""
-    from meshnet.graph_ops import node_update, node_update_pack, node_update_packed
+@pytest.mark.parametrize("mode,mag", [(0, 1.0), (0, 1e-2), (0, 300.0), (1, 1.0)])
+def test_node_update_packed_vs_fp64_and_vs_exact_kernel(N, has_next, mode, mag):
+    """csplat_gnn_node_update_packed (pre-packed weights, two fp16 pieces per operand at a fixed 2^-4 scale -- mode 0 -- or three bf16 pieces
+    -- mode 1; /root/reference/meshnet/graph_network.py:203-222) against the fp64 composition and against csplat_gnn_node_update (exact
+    fp32 MFMA): 1e-5 of each output's scale; aggregates of O(30) and latents of O(5) as the rollout has them, and 100 times less / 300
+    times more for the fp16 mode's range."""
+    from meshnet.graph_ops import edge_mlp3_mode, node_update, node_update_pack, node_update_packed
     gen = torch.Generator().manual_seed(N + has_next)
-    agg, x = (torch.randn(N, 128, generator=gen) * 30).cuda(), (torch.randn(N, 128, generator=gen) * 5).cuda()
+    agg, x = (torch.randn(N, 128, generator=gen) * 30 * mag).cuda(), (torch.randn(N, 128, generator=gen) * 5 * mag).cuda()
+    was = edge_mlp3_mode(mode)
     W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(6)]
     b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
     l2, l3 = torch.nn.Linear(128, 128).cuda(), torch.nn.Linear(128, 128).cuda()
@@ -853,6 +856,7 @@ def test_node_update_packed_vs_fp64_and_vs_exact_kernel(N, has_next):
     with torch.no_grad():
         a = node_update_packed(pieces, x, img, b[0], b[1], b[2], norm, has_next, piece_ptr=pp.cuda())
         c = node_update_packed(agg2, x, img, b[0], b[1], b[2], norm, has_next)
+    edge_mlp3_mode(was)
     for u, v_ in zip(a, c):
         assert (u is None and v_ is None) or torch.equal(u, v_)
 
