@@ -590,8 +590,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
 // k_node_update_b3 -- the node update of an InteractionNetwork layer (+ the next layer's node-level products) on the same machinery:
 //   h = relu(agg Wa^T + x Wx^T + b0);  h = relu(h W2^T + b2);  x' = LayerNorm(h W3^T + b3) + x;  xa' = x' Wi^T;  xb' = x' Wj^T
 // (/root/reference/meshnet/graph_network.py:203-222).  Rounds 2-5 ran it on the exact-fp32 MFMA with the weights transposed through LDS
-// by scalar writes (k_node_update, csplat_gemm.hip: 44 us at N = 1e4, 0.66 of the 3.0 ms rollout step).  Here: three bf16 pieces per
-// operand, six products (fp32's exponent range: no scaling question for node latents and aggregates), weights PRE-PACKED as MFMA A
+// by scalar writes (k_node_update, csplat_gemm.hip: 44 us at N = 1e4, 0.66 of the 3.0 ms rollout step).  Here: 16-bit pieces as in the edge
+// kernel (F16: two fp16 pieces, three products, a fixed 2^-4 scale; else three bf16 pieces, six products), weights PRE-PACKED as MFMA A
 // operands (csplat_gnn_node_update_pack: [matrix 6][wave 4][piece 3][step 8][lane] x 16 bytes) and streamed from L2 into registers half
 // a product ahead; one 32-row tile per 4-wave workgroup, wave j = output features 32j .. 32j + 31, activations between the layers as
 // piece tiles in LDS.  ~160 registers and 80 KB of LDS: two workgroups per CU, which is what fills the gaps (the layers of a tile are

@@ -453,11 +453,13 @@ int csplat_gnn_node_update(void *stream, int64_t N, const float *agg, const floa
                            const float *ln_gamma, const float *ln_beta, float ln_eps, const float *Wi_next,
                            const float *Wj_next, float *x_new, float *xa_next, float *xb_next);
 
-/* The same node update on three bf16 pieces per operand (six products on the bf16 matrix cores: fp32's exponent range, ~7e-7 of the output
- * scale against fp64) with the six weight matrices PRE-PACKED as MFMA A operands: csplat_gnn_node_update_pack lays Wa, Wx, W2, W3 and the
+/* The same node update on 16-bit pieces -- by csplat_gnn_edge_mlp3_mode: 0 (default) two fp16 pieces per operand, three products, everything run
+ * at a fixed 2^-4 scale (values up to ~1e6 in magnitude fit; 1e-5 of the output scale against fp64 held from 1e-2 to 300 times the rollout's
+ * magnitudes in tests/test_knn_gnn_gpu.py); 1 three bf16 pieces, six products (fp32's exponent range) -- with the six weight matrices
+ * PRE-PACKED as MFMA A operands (pack under the mode the launch will run in): csplat_gnn_node_update_pack lays Wa, Wx, W2, W3 and the
  * next layer's Wi, Wj (both NULL: none; all [128][128] row-major, contiguous) out in `image` (csplat_gnn_node_update_image_bytes() bytes
  * of device memory, 16-byte aligned) -- once per weight version; csplat_gnn_node_update_packed is the launch (has_next = the image holds
- * Wi / Wj and xa_next / xb_next are written).  26 us against 44 for csplat_gnn_node_update at N = 1e4 (csplat_edge_mlp.hip).
+ * Wi / Wj and xa_next / xb_next are written).  23 us (mode 0) / 30 us (mode 1) against 44 for csplat_gnn_node_update at N = 1e4.
  * piece_ptr != NULL: `agg` holds the PIECES csplat_gnn_edge_mlp3's fused aggregation left, node v's aggregate = the sum of pieces
  * piece_ptr[v] .. piece_ptr[v + 1] - 1 in that order (int32 [N + 1]) -- formed while the rows are loaded, no csplat_gnn_segment_sum launch. */
 size_t csplat_gnn_node_update_image_bytes(void);
