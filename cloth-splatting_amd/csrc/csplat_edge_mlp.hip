@@ -343,24 +343,29 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     // pieces are cut where the destination changes and every 8 rows, numbered in row order (group_piece0[g] = first piece of rows 8g ..
     // 8g + 7, prepared once per graph), so each piece has exactly one writer and the caller adds a node's few consecutive pieces in a
     // fixed order: deterministic, no atomics, and ~E / 8 + N rows of traffic instead of E written here and E read by the segmented sum.
-    // The run structure is wave-uniform: destinations and piece base arrive by scalar loads.  9 operations
+    // The run structure is wave-uniform: the 8 destinations and the piece base are fetched by two small vector loads and spread with
+    // v_readlane (SCALAR loads -- out-of-order returns, one counter with LDS -- make every LDS wait a wait for them too: measured +17 % on
+    // the kernel when the gather indices went that way).  9 operations
     const __amdgpu_buffer_rsrc_t r_pc = __builtin_amdgcn_make_buffer_rsrc(pieces, 0, -1, 0x00020000);
-    int ag_d[8], ag_nv = 0, ag_p = 0;
+    const __amdgpu_buffer_rsrc_t r_gp = __builtin_amdgcn_make_buffer_rsrc((void *)group_piece0, 0, AGG ? (int)(((M + 7) / 8) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc((void *)ia, 0, (int)(M * 8), 0x00020000);
+    int ag_d[8], ag_nv = 0, ag_p = 0, ag_vd = 0, ag_vp = 0;
     float2 ag_acc = make_float2(0.f, 0.f);
     auto agg_op = [&](int m, const float *Yt, int tile) __attribute__((always_inline)) {
         if (m == 0) {
             const int64_t row0 = (int64_t)tile * 32 + 8 * w, left = M - row0;
             ag_nv = left < 0 ? 0 : (left > 8 ? 8 : (int)left);
             ag_acc = make_float2(0.f, 0.f);
-            if (ag_nv > 0) {
-                const int64_t *ip = ia + row0;
-#pragma unroll
-                for (int r = 0; r < 8; r++) ag_d[r] = (int)ip[r < ag_nv ? r : ag_nv - 1];
-                ag_p = group_piece0[row0 >> 3];
-            }
+            ag_vd = __builtin_amdgcn_raw_buffer_load_b32(r_dst, (int)(row0 * 8) + (lane & 7) * 8, 0, 0);      // (past the end: 0, unused)
+            ag_vp = __builtin_amdgcn_raw_buffer_load_b32(r_gp, (int)(row0 >> 3) * 4, 0, 0);
             return;
         }
         const int r = m - 1;
+        if (r == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) ag_d[q] = __builtin_amdgcn_readlane(ag_vd, q);
+            ag_p = __builtin_amdgcn_readfirstlane(ag_vp);
+        }
         if (r < ag_nv) {
             const float2 y = *reinterpret_cast<const float2 *>(Yt + (size_t)(8 * w + r) * ER_GSTRIDE + 2 * lane);
             ag_acc.x += y.x; ag_acc.y += y.y;
