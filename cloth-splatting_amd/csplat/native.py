@@ -117,6 +117,7 @@ EXPORTS = {
     "csplat_gnn_edge_mlp3_pack": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "csplat_gnn_edge_mlp3": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_gnn_edge_mlp3_mode": (_i, [_i]),
+    "csplat_gnn_mlp3_rows": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "csplat_absmax": (_i, [_vp, _i64, _vp, _vp]),
     "csplat_linear128": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "csplat_linear128_ex": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_absmax(int64_t n4, const float4 *__rest
     }
 }
 
-template <bool F16, bool AGG>
+template <bool F16, int MODE>      // MODE 0: message rows out; 1: messages summed per destination, pieces out; 2: narrow input rows, no gathers
 __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__restrict__ e0, float alpha, const float *__restrict__ e0_absmax,
                                                     const float *__restrict__ xa, const int64_t *__restrict__ ia,
                                                     const float *__restrict__ xb, const int64_t *__restrict__ ib,
@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
                                                     const float *__restrict__ b1, const float *__restrict__ b2,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                     float *__restrict__ out, const int *__restrict__ group_piece0, float *__restrict__ pieces,
-                                                    unsigned long long *__restrict__ stamps) {
+                                                    int in_cols, unsigned long long *__restrict__ stamps) {
+    constexpr bool AGG = MODE == 1, NARROW = MODE == 2;
     static_assert(!AGG || ErCfg<F16>::ROWS_VIA_LDS, "the fused aggregation reads the finished tile from LDS");
     typedef ErCfg<F16> C;
     constexpr int NP = C::NP, NS = C::NS;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     };
     // ---- loaders.  A wave brings in rows 8w .. 8w + 7 of a tile, two rows per instruction (half-wave per row, 16 bytes per lane): global
     // memory only ever sees whole rows.  Buffer loads: what lies past the last row reads as zero (edge rows) / index 0 (gathers)
-    const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc((void *)e0, 0, (int)(M * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc((void *)e0, 0, NARROW ? (int)(M * in_cols * 4) : (int)(M * 512), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_ia = __builtin_amdgcn_make_buffer_rsrc((void *)ia, 0, (int)(M * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_ib = __builtin_amdgcn_make_buffer_rsrc((void *)ib, 0, (int)(M * 8), 0x00020000);
     const int ix_lane = (8 * w + h) * 8;
@@ -388,19 +389,23 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     // 8-lane load per array + a lane exchange measured 2 % slower, tools/edge_mlp3_lib_ab.sh)
     auto idx_op = [&](int m, unsigned tile_rows, int (&ja)[4], int (&jb)[4]) __attribute__((always_inline)) {
         const int k = m >> 1;
-        if (EM_SKIP & 512) return;
+        if (NARROW || (EM_SKIP & 512)) return;
         if (m & 1) jb[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ib, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
         else ja[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ia, ix_lane + tile_rows * 8 + 16 * k, 0, 0);
     };
     auto g_issue_op = [&](int m, float4 (&GA)[4], float4 (&GB)[4], const int (&ja)[4], const int (&jb)[4]) __attribute__((always_inline)) {      // 8 operations
         const int k = m >> 1;
-        if (EM_SKIP & 256) return;
+        if (NARROW || (EM_SKIP & 256)) return;
         if (m & 1) GB[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xb) + (size_t)((unsigned)jb[k] * 512u + 16u * n));
         else GA[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xa) + (size_t)((unsigned)ja[k] * 512u + 16u * n));
     };
     // G = (xa[dst] + xb[src] + b0) / alpha, what layer 1's accumulators start from: 12 operations
     auto g_commit_op = [&](int m, float4 (&GA)[4], float4 (&GB)[4], float *Gt) __attribute__((always_inline)) {
         const int k = m / 3, part = m % 3;
+        if (NARROW) {      // (no gathers: layer 1 starts from its bias)
+            if (part == 2) *reinterpret_cast<float4 *>(Gt + (size_t)(8 * w + 2 * k + h) * ER_GSTRIDE + 4 * n) = b0v;
+            return;
+        }
         if (part == 0) { GA[k].x += GB[k].x; GA[k].y += GB[k].y; GA[k].z += GB[k].z; GA[k].w += GB[k].w; }
         else if (part == 1) {
             GA[k].x = fmaf(GA[k].x, inv_alpha, b0v.x); GA[k].y = fmaf(GA[k].y, inv_alpha, b0v.y);
@@ -408,6 +413,14 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         } else *reinterpret_cast<float4 *>(Gt + (size_t)(8 * w + 2 * k + h) * ER_GSTRIDE + 4 * n) = GA[k];
     };
     auto e_issue_op = [&](int k, float4 (&E)[4], unsigned tile_off) __attribute__((always_inline)) {      // 4 operations
+        if (NARROW) {
+            // (MODE 2) the rows are [M][in_cols] floats, in_cols a multiple of 4 up to 128: the lanes that stand for columns past in_cols hold
+            // zeros (layer 1's packed weight is zero there too), a row's real columns are one or a few 16-byte reads
+            const unsigned rowb = ((tile_off >> 9) + 8 * w + 2 * k + h) * (unsigned)(in_cols * 4);
+            const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_e0, rowb + 16 * n, 0, 0));
+            E[k] = 4 * n < in_cols ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
         if (!(EM_SKIP & 128)) E[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_e0, ld_lane + tile_off + 1024 * k, 0, 0));
     };
     // an edge row's 16 bytes (times cs) cut into the NP pieces, parked as layer 1's B operand: per 16 bytes (scale) (pack, write), then per
@@ -893,9 +906,10 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
     hipStream_t s = (hipStream_t)stream;
     static int s_ok = -1;
     if (s_ok < 0) {
-        s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
-        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
-        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<false>::LDS_BYTES) == hipSuccess;
+        s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_edge_mlp3r<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<false>::LDS_BYTES) == hipSuccess;
         (void)hipGetLastError();
     }
     CSPLAT_REQUIRE(s_ok, "csplat_gnn_edge_mlp3: 141 KB of dynamic LDS refused by the runtime");
@@ -915,14 +929,14 @@ extern "C" int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, fl
         float *o = out ? out + r0 * EM_N : nullptr;
         const int *gp = group_piece0 ? group_piece0 + r0 / 8 : nullptr;
         if (agg)
-            k_edge_mlp3r<true, true><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
-                                                                                (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
+            k_edge_mlp3r<true, 1><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
+                                                                                (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, 0, stamps);
         else if (g_em_mode == 0)
-            k_edge_mlp3r<true, false><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
-                                                                                 (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
+            k_edge_mlp3r<true, 0><<<grid, 256, ErCfg<true>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
+                                                                                 (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, 0, stamps);
         else
-            k_edge_mlp3r<false, false><<<grid, 256, ErCfg<false>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
-                                                                                   (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, stamps);
+            k_edge_mlp3r<false, 0><<<grid, 256, ErCfg<false>::LDS_BYTES, s>>>(rows, e0 + r0 * EM_N, alpha, e0_absmax, xa, index_a + r0, xb, index_b + r0,
+                                                                                   (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps, o, gp, pieces, 0, stamps);
         LAUNCH_CHECK();
     }
     return 0;
@@ -965,6 +979,34 @@ extern "C" int csplat_gnn_node_update_packed(void *stream, int64_t N, const floa
     else
         k_node_update_b3<false><<<(unsigned)((N + 31) / 32), 256, NB_LDS_BYTES, s>>>(N, agg, x, (const i32x4 *)image, b0, b2, b3, ln_gamma, ln_beta, ln_eps,
                                                                           has_next ? 1 : 0, x_new, xa_next, xb_next, piece_ptr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// MODE 2 of the same kernel as a stand-alone operator: out[m] = LayerNorm( W2 relu( W1 relu( W0 x[m] + b0 ) + b1 ) + b2 ) for NARROW input rows
+// x [M][K] (K a multiple of 4, <= 128): the encoders' MLPs (/root/reference/meshnet/graph_network.py:48-111) in one launch.  `image` =
+// csplat_gnn_edge_mlp3_pack of (W0 padded with zero columns to [128][128], W1, W2) under mode 0; x_absmax as e0_absmax there.
+extern "C" int csplat_gnn_mlp3_rows(void *stream, int64_t M, const float *x, int K, const float *x_absmax, const void *image, const float *b0,
+                                    const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out) {
+    CSPLAT_REQUIRE(M >= 0 && K >= 4 && K <= 128 && K % 4 == 0 && (M == 0 || (x && image && b0 && b1 && b2 && ln_gamma && ln_beta && out)),
+                   "csplat_gnn_mlp3_rows: bad arguments (K a multiple of 4, 4 .. 128)");
+    CSPLAT_REQUIRE(g_em_mode == 0, "csplat_gnn_mlp3_rows: mode 0 (fp16 pieces) only");
+    if (M == 0) return 0;
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)image | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)out;
+    CSPLAT_REQUIRE((al & 15u) == 0, "csplat_gnn_mlp3_rows: operands must be 16-byte aligned");
+    CSPLAT_REQUIRE(M <= ((int64_t)1 << 22), "csplat_gnn_mlp3_rows: at most 2^22 rows per call");
+    static int s_ok = -1;
+    if (s_ok < 0) {
+        s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    CSPLAT_REQUIRE(s_ok, "csplat_gnn_mlp3_rows: 141 KB of dynamic LDS refused by the runtime");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    const int64_t nst = (M + 63) / 64;
+    k_edge_mlp3r<true, 2><<<(int)(nst < 256 ? nst : 256), 256, ErCfg<true>::LDS_BYTES, s>>>(M, x, 1.0f, x_absmax, nullptr, nullptr, nullptr, nullptr, (const i32x4 *)image,
+                                                                                           b0, b1, b2, ln_gamma, ln_beta, ln_eps, out, nullptr, nullptr, K,
+                                                                                           csplat_stamp_buffer((size_t)256 * 64));
     LAUNCH_CHECK();
     return 0;
 }

@@ -20,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, node_update_pack, node_update_packed, segment_sum_rows, edge_tail_ok, linear_narrow128,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, mlp3_rows, node_update_pack, node_update_packed, segment_sum_rows, edge_tail_ok, linear_narrow128,
                         layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
@@ -112,10 +112,23 @@ def _encode_inference(seq: nn.Sequential, x: torch.Tensor):
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[1] <= 32 and len(lins) >= 2 and _fusable(seq)
             and tuple(lins[0].weight.shape) == (128, x.shape[1]) and lins[0].weight.dtype == torch.float32):
         return None
+    if ENCODER_FUSED and len(lins) == 3 and x.shape[1] % 4 == 0 and x.shape[0] > 0 and edge_mlp3_mode() == 0:
+        # the whole MLP + LayerNorm in ONE launch (csplat_gnn_mlp3_rows: the one-launch edge MLP's kernel on narrow rows, no gathers); the
+        # first weight zero-padded to 128 columns, image packed once per weight version
+        key = tuple((l.weight._version, l.weight.data_ptr()) for l in lins)
+        if getattr(seq, "_mlp3_key", None) != key:
+            with torch.no_grad():
+                w0 = torch.zeros(128, 128, dtype=torch.float32, device=x.device)
+                w0[:, :x.shape[1]] = lins[0].weight
+                seq._mlp3_img = edge_mlp3_pack(w0, lins[1].weight, lins[2].weight)
+            seq._mlp3_key = key
+        return mlp3_rows(x, seq._mlp3_img, lins[0].bias, lins[1].bias, lins[2].bias, seq[1])
     h = linear_narrow128(x, lins[0].weight, lins[0].bias, relu=True)
     return _fused_tail(seq, h)
 
 
+# rollout: an encoder's MLP + LayerNorm as ONE launch (csplat_gnn_mlp3_rows) instead of three; env CSPLAT_GNN_ENCODER_FUSED=0 goes back
+ENCODER_FUSED = os.environ.get("CSPLAT_GNN_ENCODER_FUSED", "1") not in ("", "0")
 # rollout: the edge MLP of a layer as ONE launch (csplat_gnn_edge_mlp3: weights resident in registers, the two inner [E,128] activations never in
 # HBM) instead of three csplat_linear128 calls: 150-167 us against 235-245 per layer at E = 300k, rollout step 4.16 against 5.56 ms
 # (tools/ab_edge_mlp3_rollout.py).  env CSPLAT_GNN_EDGE_FUSED=0 goes back to the three launches.

@@ -525,6 +525,25 @@ def node_update(agg, x, w_agg, w_x, b0, lin2, lin3, layer_norm, w_i_next=None, w
     return x_new, xa, xb
 
 
+def mlp3_rows(x, image, b0, b1, b2, layer_norm, x_absmax=None):
+    """LayerNorm(W2 relu(W1 relu(W0 x + b0) + b1) + b2) for narrow rows x [M, K] (K a multiple of 4, <= 128) in ONE launch
+    (csplat_gnn_mlp3_rows: the one-launch edge MLP's kernel without gathers).  image = edge_mlp3_pack(W0 zero-padded to [128,128], W1, W2)
+    under edge_mlp3_mode 0; x_absmax = absmax(x), computed here when not handed in."""
+    _n.require_cuda(x)
+    x = _f32(x)
+    M, K = x.shape
+    assert K % 4 == 0 and 4 <= K <= 128 and edge_mlp3_mode() == 0
+    out = torch.empty(M, 128, dtype=torch.float32, device=x.device)
+    if x_absmax is None and M > 0:
+        x_absmax = absmax(x)
+    c = lambda t: t.detach().contiguous()  # noqa: E731
+    with _n.on_device(x.device):
+        _n.check(_n.lib.csplat_gnn_mlp3_rows(_n.stream_handle(x.device), M, _n.ptr(x), K, _n.ptr(x_absmax), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b1)),
+                                             _n.ptr(c(b2)), _n.ptr(c(layer_norm.weight)), _n.ptr(c(layer_norm.bias)), float(layer_norm.eps), _n.ptr(out)),
+                 "csplat_gnn_mlp3_rows")
+    return out
+
+
 def node_update_pack(w_agg, w_x, w2, w3, w_i_next=None, w_j_next=None):
     """the node update's weights (+ the next layer's x_i / x_j blocks) as the register image csplat_gnn_node_update_packed streams: three bf16
     pieces per matrix as MFMA A operands (csplat_gnn_node_update_pack); pack once per weight version"""

@@ -552,6 +552,14 @@ int csplat_gnn_edge_mlp3(void *stream, int64_t E, const float *e0, float alpha, 
                          const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out,
                          const int32_t *group_piece0, float *pieces);
 
+/* The same kernel as a stand-alone operator on NARROW input rows -- the encoders' MLPs (/root/reference/meshnet/graph_network.py:48-111:
+ * build_mlp(K -> 128 -> 128 -> 128) + LayerNorm) in ONE launch:
+ *     out[m] = LayerNorm( W2 relu( W1 relu( W0 x[m] + b0 ) + b1 ) + b2 ) * gamma + beta
+ * x [M][K] fp32 (K a multiple of 4, 4 .. 128; M <= 2^22), out [M][128].  `image` = csplat_gnn_edge_mlp3_pack(W0 PADDED with zero columns
+ * to [128][128], W1, W2) under mode 0; x_absmax = csplat_absmax of x (or of a superset; NULL = 1.0).  Mode 0 (fp16 pieces) only. */
+int csplat_gnn_mlp3_rows(void *stream, int64_t M, const float *x, int K, const float *x_absmax, const void *image, const float *b0,
+                         const float *b1, const float *b2, const float *ln_gamma, const float *ln_beta, float ln_eps, float *out);
+
 /* The per-step activations of the Gaussian parameters as render() consumes them (/root/reference/scene_reconstruction/
  * gaussian_model.py:96-121 via gaussian_renderer/__init__.py:92-118): opacity[P] = sigmoid(opacity_raw), scales[P][3] = exp(scaling_raw),
  * shs[P][16][3] = cat(features_dc[P][1][3], features_rest[P][15][3]) in one launch, and their backward in one launch (any incoming

@@ -990,6 +990,29 @@ def test_linear_narrow128_vs_fp64(M, K, relu):
     assert out.shape == (M, 128) and rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("M,K", [(1, 4), (63, 8), (30_011, 4), (5000, 128)])
+def test_mlp3_rows_vs_fp64(M, K):
+    """csplat_gnn_mlp3_rows (an encoder's whole MLP + LayerNorm on narrow rows in one launch; /root/reference/meshnet/graph_network.py:48-111)
+    against the fp64 composition, inputs of the size of the rollout's edge features (1e-2) and of O(1)."""
+    from meshnet.graph_ops import edge_mlp3_pack, mlp3_rows
+    for mag in (1e-2, 1.0):
+        gen = torch.Generator().manual_seed(M + K)
+        x = (torch.randn(M, K, generator=gen) * mag).cuda()
+        W0 = (torch.randn(128, K, generator=gen) * (0.5 if K < 128 else 0.1)).cuda()
+        W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(2)]
+        b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+        norm = torch.nn.LayerNorm(128).cuda()
+        with torch.no_grad():
+            norm.weight.copy_(torch.randn(128, generator=gen)); norm.bias.copy_(torch.randn(128, generator=gen))
+            w0 = torch.zeros(128, 128, device="cuda"); w0[:, :K] = W0
+            out = mlp3_rows(x, edge_mlp3_pack(w0, W[0], W[1]), b[0], b[1], b[2], norm)
+            h = (x.double() @ W0.double().t() + b[0].double()).relu()
+            h = (h @ W[0].double().t() + b[1].double()).relu()
+            ref = torch.nn.functional.layer_norm(h @ W[1].double().t() + b[2].double(), (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+        assert out.shape == (M, 128) and torch.isfinite(out).all()
+        assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5, mag
+
+
 def test_encoder_rollout_path_vs_module_path():
     """Encoder.forward under no_grad (csplat_linear_narrow128 + csplat_linear128 with ReLU / LayerNorm epilogues, no stock kernel) against the
     same module with autograd on (the training path: library GEMMs + LayerNorm128) and against the fp64 composition."""
@@ -1004,7 +1027,7 @@ def test_encoder_rollout_path_vs_module_path():
         xn, en = enc(x, e)
         torch.cuda.synchronize()
         _ms, launches = native.prof_read("GNN"); native.prof_enable([])
-    assert launches == 6, launches            # 3 per MLP: narrow first layer, 128 x 128 + ReLU, 128 x 128 + LayerNorm
+    assert launches == 2, launches            # one per MLP: csplat_gnn_mlp3_rows (the max |x| pass before it is not a GNN-class launch)
     xg, eg = enc(x, e)
     enc64 = gn.Encoder(8, 128, 4, 128, 2, 128).double().cuda()
     enc64.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
