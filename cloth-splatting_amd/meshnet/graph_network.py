@@ -130,14 +130,14 @@ def _encode_inference(seq: nn.Sequential, x: torch.Tensor):
 # rollout: an encoder's MLP + LayerNorm as ONE launch (csplat_gnn_mlp3_rows) instead of three; env CSPLAT_GNN_ENCODER_FUSED=0 goes back
 ENCODER_FUSED = os.environ.get("CSPLAT_GNN_ENCODER_FUSED", "1") not in ("", "0")
 # rollout: the edge MLP of a layer as ONE launch (csplat_gnn_edge_mlp3: weights resident in registers, the two inner [E,128] activations never in
-# HBM) instead of three csplat_linear128 calls: 150-167 us against 235-245 per layer at E = 300k, rollout step 4.16 against 5.56 ms
-# (tools/ab_edge_mlp3_rollout.py).  env CSPLAT_GNN_EDGE_FUSED=0 goes back to the three launches.
+# HBM) instead of three csplat_linear128 calls: 112-118 us against 235-245 per layer at E = 300k, rollout step 2.24 against 4.4-5.0 ms with
+# everything below on (tools/ab_edge_mlp3_rollout.py).  env CSPLAT_GNN_EDGE_FUSED=0 goes back to the three launches.
 EDGE_MLP_FUSED = os.environ.get("CSPLAT_GNN_EDGE_FUSED", "1") not in ("", "0")
 # ... and that launch sums its messages per destination node itself (edges taken in destination order, per-run "pieces" instead of E message
 # rows: include/csplat.h), the segmented sum then runs over ~E / 8 + N piece rows.  env CSPLAT_GNN_EDGE_AGG=0: messages out, segmented sum over E.
 EDGE_AGG_FUSED = os.environ.get("CSPLAT_GNN_EDGE_AGG", "1") not in ("", "0")
-# the node update on pre-packed bf16-piece weights (csplat_gnn_node_update_packed) instead of the exact-fp32 MFMA kernel of rounds 2-5; env
-# CSPLAT_GNN_NODE_PACKED=0 goes back
+# the node update on pre-packed 16-bit-piece weights (csplat_gnn_node_update_packed; fp16 or bf16 pieces by edge_mlp3_mode) instead of the
+# exact-fp32 MFMA kernel of rounds 2-5; env CSPLAT_GNN_NODE_PACKED=0 goes back
 NODE_UPDATE_PACKED = os.environ.get("CSPLAT_GNN_NODE_PACKED", "1") not in ("", "0")
 
 
