@@ -18,7 +18,7 @@ CSPLAT_BENCH_BACKEND=gloo timeout 600 python3 -m torch.distributed.run --nnodes=
 python3 bench_gnn.py                 > "$OUT/bench_gnn.json"   2> /dev/null
 python3 tools/gnn_train_trace.py 10  > "$OUT/gnn_train.txt"    2> /dev/null
 python3 bench_train.py --steps 40 --warmup 5 > "$OUT/bench_train.json" 2> /dev/null
-# the one-launch edge MLP (opt-in) against the three launches: kernel time, in-kernel phase stamps, same-box rollout A/B
+# the one-launch edge MLP against the three launches: kernel time, in-kernel phase stamps, same-box rollout A/B
 { python3 tools/bench_edge_mlp3.py; python3 tools/edge_mlp3_stamps.py; python3 tools/ab_edge_mlp3_rollout.py; } > "$OUT/edge_mlp3.txt" 2> /dev/null
 # LIGHT=1: skip the micro-probes of kernels that did not change since the last full collection (GEMM / dW / rate probes, the scenes-mode 2-rank run)
 if [ -z "${LIGHT:-}" ]; then
