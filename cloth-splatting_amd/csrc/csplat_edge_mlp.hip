@@ -350,25 +350,34 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     const __amdgpu_buffer_rsrc_t r_pc = __builtin_amdgcn_make_buffer_rsrc(pieces, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_gp = __builtin_amdgcn_make_buffer_rsrc((void *)group_piece0, 0, AGG ? (int)(((M + 7) / 8) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc((void *)ia, 0, (int)(M * 8), 0x00020000);
-    int ag_d[8], ag_nv = 0, ag_p = 0, ag_vd = 0, ag_vp = 0;
-    float2 ag_acc = make_float2(0.f, 0.f);
-    auto agg_op = [&](int m, const float *Yt, int tile) __attribute__((always_inline)) {
+    int ag_d[8], ag_nv = 0, ag_p = 0;
+    int2 ag_lA = make_int2(0, 0), ag_lB = make_int2(0, 0);      // per slot: (the 8 destinations in lanes 0-7, the piece base), requested a phase ahead
+    float2 ag_acc = make_float2(0.f, 0.f), ag_y = make_float2(0.f, 0.f);
+    auto agg_load_op = [&](int tile, int2 &l) __attribute__((always_inline)) {
+        const int64_t row0 = (int64_t)tile * 32 + 8 * w;
+        l.x = __builtin_amdgcn_raw_buffer_load_b32(r_dst, (int)(row0 * 8) + (lane & 7) * 8, 0, 0);      // (past the end: 0, unused)
+        l.y = __builtin_amdgcn_raw_buffer_load_b32(r_gp, (int)(row0 >> 3) * 4, 0, 0);
+    };
+    // operation 0: the run structure to the scalar side, the first row requested; operation r + 1: row r added (the next one requested
+    // first: a row's LDS read is a whole operation ahead of its use), its run closed -- one 512-byte store -- when the destination changes.
+    // (Branch-free, every row storing and the stores that close no run aimed out of bounds: slower, 122-127 against 118 us -- a dropped
+    // store is still a memory instruction.)
+    auto agg_op = [&](int m, const float *Yt, int tile, const int2 &l) __attribute__((always_inline)) {
+        const float *yrow = Yt + (size_t)(8 * w) * ER_GSTRIDE + 2 * lane;
         if (m == 0) {
             const int64_t row0 = (int64_t)tile * 32 + 8 * w, left = M - row0;
             ag_nv = left < 0 ? 0 : (left > 8 ? 8 : (int)left);
             ag_acc = make_float2(0.f, 0.f);
-            ag_vd = __builtin_amdgcn_raw_buffer_load_b32(r_dst, (int)(row0 * 8) + (lane & 7) * 8, 0, 0);      // (past the end: 0, unused)
-            ag_vp = __builtin_amdgcn_raw_buffer_load_b32(r_gp, (int)(row0 >> 3) * 4, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) ag_d[q] = __builtin_amdgcn_readlane(l.x, q);
+            ag_p = __builtin_amdgcn_readfirstlane(l.y);
+            ag_y = *reinterpret_cast<const float2 *>(yrow);
             return;
         }
         const int r = m - 1;
-        if (r == 0) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) ag_d[q] = __builtin_amdgcn_readlane(ag_vd, q);
-            ag_p = __builtin_amdgcn_readfirstlane(ag_vp);
-        }
+        const float2 y = ag_y;
+        if (r < 7) ag_y = *reinterpret_cast<const float2 *>(yrow + (size_t)(r + 1) * ER_GSTRIDE);
         if (r < ag_nv) {
-            const float2 y = *reinterpret_cast<const float2 *>(Yt + (size_t)(8 * w + r) * ER_GSTRIDE + 2 * lane);
             ag_acc.x += y.x; ag_acc.y += y.y;
             if (r == ag_nv - 1 || ag_d[(r + 1) & 7] != ag_d[r]) {
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -531,13 +540,15 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
             if (!(EM_SKIP & 2)) ER_SPREAD(k, SL(0), SL(18), LNP_OPS, lnp_op(m, accLB, SrB));
             if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(14), SL(44), LNF_OPS, lnf_op(m, accLA, SrA, offA_prev, YtA));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(40), SL(48), 8, idx_op(m, (unsigned)tA2 * 32u, jaA, jbA));
+            if (AGG) ER_SPREAD(k, SL(44), SL(46), 1, agg_load_op(tA_prev, ag_lA));
         });
         __syncthreads();
         stamp();
         // 1: layer 1 of B | A's ReLU + pieces, LayerNorm's end + rows out of the previous B, the next B's indices
         phase(0, XB0, GtB + (size_t)n * ER_GSTRIDE, accB, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(0), SL(32), LNF_OPS, lnf_op(m, accLB, SrB, offB_prev, YtB));
-            if (AGG) ER_SPREAD(k, SL(6), SL(42), 9, agg_op(m, YtA, tA_prev));
+            if (AGG) ER_SPREAD(k, SL(6), SL(42), 9, agg_op(m, YtA, tA_prev, ag_lA));
+            if (AGG) ER_SPREAD(k, SL(44), SL(46), 1, agg_load_op(tB_prev, ag_lB));
             else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(40), 8, rows_out_op(m, YtA, offA_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA1));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(40), SL(48), 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         phase(1, XA1, sT, accA, [&](int k) __attribute__((always_inline)) {
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 8, g_issue_op(m, GAb, GBb, jaB, jbB));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
-            if (AGG) ER_SPREAD(k, SL(8), SL(44), 9, agg_op(m, YtB, tB_prev));
+            if (AGG) ER_SPREAD(k, SL(8), SL(44), 9, agg_op(m, YtB, tB_prev, ag_lB));
             else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(32), 8, rows_out_op(m, YtB, offB_prev));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB1));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(20), SL(44), 12, g_commit_op(m, GAa, GBa, GtA));
@@ -589,11 +600,13 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
 #pragma unroll
     for (int m = 0; m < LNF_OPS; m++) lnf_op(m, accLB, SrB, offB_prev, YtB);
     if (AGG) {
+        agg_load_op(tA_prev, ag_lA);
+        agg_load_op(tB_prev, ag_lB);
 #pragma unroll
-        for (int m = 0; m < 9; m++) agg_op(m, YtA, tA_prev);
+        for (int m = 0; m < 9; m++) agg_op(m, YtA, tA_prev, ag_lA);
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 9; m++) agg_op(m, YtB, tB_prev);
+        for (int m = 0; m < 9; m++) agg_op(m, YtB, tB_prev, ag_lB);
     } else if (C::ROWS_VIA_LDS) {
 #pragma unroll
         for (int m = 0; m < 8; m++) rows_out_op(m, YtA, offA_prev);

@@ -27,13 +27,21 @@ edge_mlp3_mode(int(os.environ.get("EM_MODE", "0")))      # 0: two fp16 pieces, 1
 img = edge_mlp3_pack(*W)
 amax = absmax(e0)
 out = torch.empty_like(e0)
+AGG = bool(int(os.environ.get("EM_AGG", "0")))      # 1: the launch sums its messages per destination (what the rollout runs)
+if AGG:
+    from meshnet.graph_ops import GraphCSR, gather_rows
+    plan = GraphCSR(torch.stack([ib, ia]), N).agg_plan()
+    e0p = gather_rows(e0, plan["perm"])
+    pieces = torch.empty(plan["npieces"], 128, device="cuda")
 buf = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
 with torch.no_grad():
     for _ in range(3):
-        edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax)
+        (edge_mlp3(e0p, 4.0, xa, plan["dst"], xb, plan["src"], img, b[0], b[1], b[2], norm, e0_absmax=amax, agg=(plan["gp0"], pieces)) if AGG else
+         edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax))
     torch.cuda.synchronize()
     native.lib.csplat_debug_stamps(buf.data_ptr(), buf.numel() * 8)
-    edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax)
+    (edge_mlp3(e0p, 4.0, xa, plan["dst"], xb, plan["src"], img, b[0], b[1], b[2], norm, e0_absmax=amax, agg=(plan["gp0"], pieces)) if AGG else
+         edge_mlp3(e0, 4.0, xa, ia, xb, ib, img, b[0], b[1], b[2], norm, out=out, e0_absmax=amax))
     torch.cuda.synchronize()
     native.lib.csplat_debug_stamps(None, 0)
 s = buf.cpu().numpy().reshape(256, 64).astype(np.int64)
