@@ -390,7 +390,8 @@ class EncodeProcessDecode(nn.Module):
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
         if not torch.is_grad_enabled() and EDGE_MLP_FUSED and EDGE_AGG_FUSED and edge_mlp3_mode() == 0 and edge_features.is_cuda and \
                 edge_features.dim() == 2 and edge_features.shape[0] > 0 and edge_features.dtype == torch.float32 and x.dtype == torch.float32 and \
-                isinstance(self._encoder.edge_fn[1], nn.LayerNorm) and self._encoder.edge_fn[1].elementwise_affine:
+                isinstance(self._encoder.edge_fn[1], nn.LayerNorm) and self._encoder.edge_fn[1].elementwise_affine and \
+                len(self._processor.gnn_stacks) > 0 and all(g._nnode_in == 128 and g._nedge_in == 128 for g in self._processor.gnn_stacks):
             # rollout: the processor's edge launch wants the edges in destination order -- so ENCODE them in that order (a gather of the
             # [E,4] inputs instead of one of the [E,128] latents)
             plan = GraphCSR.get(edge_index, x.shape[0]).agg_plan()
