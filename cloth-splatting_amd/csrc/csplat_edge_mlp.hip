@@ -111,6 +111,11 @@ __global__ __launch_bounds__(64) void k_edge_mlp3r_pack(const float *__restrict_
         img[((size_t)j * ErCfg<F16>::NW + (l * NP + q) * 8 + st) * 64 + lane] = *reinterpret_cast<const i32x4 *>(p[q]);
 }
 
+// ReLU that lets a NaN through.  fmaxf(x, 0) (v_max_f32) returns 0 for a NaN -- and a value that left fp16's range turns into NaN one layer
+// later (pieces Inf and -Inf), which the NEXT ReLU would then launder into finite garbage: measured, a first-layer weight of 3e4 gave
+// finite rows with a relative error of 1.2.  With this form an overflow anywhere reaches the output as NaN rows: visible, never silent.
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 __device__ __forceinline__ float pair_sum(float v) {      // v of lane (n, 0) + v of lane (n, 1), in both lanes
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
     return __int_as_float(sw[0]) + __int_as_float(sw[1]);
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         const int half = m / RELU_HALF, mm = m % RELU_HALF;
         if (mm < 4 * RELU_PAIR) {
             const int jj = mm / RELU_PAIR, j = 4 * half + jj, o = mm % RELU_PAIR;
-            if (o == 0) { rx0 = fmaxf(acc[2 * j], 0.f); rx1 = fmaxf(acc[2 * j + 1], 0.f); rq = pk(rx0, rx1); opaque(rq); P[0][jj] = rq; }
+            if (o == 0) { rx0 = relu_nan(acc[2 * j]); rx1 = relu_nan(acc[2 * j + 1]); rq = pk(rx0, rx1); opaque(rq); P[0][jj] = rq; }
             else if (o % 3 == 1) rx0 -= lo_f(rq);
             else if (o % 3 == 2) rx1 -= hi_f(rq);
             else { rq = pk(rx0, rx1); if (o != RELU_PAIR - 1) opaque(rq); P[o / 3][jj] = rq; }
@@ -810,14 +815,14 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
     product(B0, acc, 1);
     product(B1, acc, 2);
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; r++) v[r] = relu_nan(acc[r]);
     to_pieces(v, B2, 1.f);
     __syncthreads();
     // ---- layer 2
     start_from(b2, acc);
     product(B2, acc, 3);
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; r++) v[r] = relu_nan(acc[r]);
     to_pieces(v, B0, 1.f);
     __syncthreads();
     // ---- layer 3, LayerNorm (the four waves' partials combined by the parallel-variance formula), residual

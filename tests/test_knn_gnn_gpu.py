@@ -899,6 +899,38 @@ def test_edge_mlp3_fused_aggregation_vs_messages_and_segment_sum(E, N):
     assert float(runs[0][empty.cuda()].abs().max() if empty.any() else 0.0) == 0.0
 
 
+def test_edge_mlp3_fp16_overflow_is_visible_and_bf16_mode_is_not_affected():
+    """The documented failure mode of the fp16-piece arithmetic (include/csplat.h): inner activations far above the
+    edge rows' scale (here a first-layer weight of 3e4: ~1e6 times the inputs) leave fp16's range and the rows come out non-finite --
+    visible, never a silently wrong finite row -- while mode 1 (three bf16 pieces, fp32's exponent range) still matches fp64."""
+    from meshnet.graph_ops import edge_mlp3, edge_mlp3_mode, edge_mlp3_pack
+    gen = torch.Generator().manual_seed(11)
+    E, Nn = 4100, 50
+    e0 = torch.randn(E, 128, generator=gen).cuda()
+    W = [(torch.randn(128, 128, generator=gen) * s_).cuda() for s_ in (3e4, 0.1, 0.1)]
+    b = [torch.randn(128, generator=gen).cuda() * 0.3 for _ in range(3)]
+    xa, xb = torch.randn(Nn, 128, generator=gen).cuda(), torch.randn(Nn, 128, generator=gen).cuda()
+    ia, ib = torch.randint(0, Nn, (E,), generator=gen).cuda(), torch.randint(0, Nn, (E,), generator=gen).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        h = (e0.double() @ W[0].double().t() + b[0].double() + xa.double()[ia] + xb.double()[ib]).relu()
+        h = (h @ W[1].double().t() + b[1].double()).relu()
+        ref = torch.nn.functional.layer_norm(h @ W[2].double().t() + b[2].double(), (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+        outs = {}
+        for mode in (0, 1):
+            was = edge_mlp3_mode(mode)
+            try:
+                outs[mode] = edge_mlp3(e0, 1.0, xa, ia, xb, ib, edge_mlp3_pack(*W), b[0], b[1], b[2], norm)
+            finally:
+                edge_mlp3_mode(was)
+    assert not torch.isfinite(outs[0]).all()
+    bad = ~torch.isfinite(outs[0]).all(1)
+    good = ~bad
+    if good.any():                                  # whatever row stayed in range is right
+        assert rel_err(outs[0][good].cpu().numpy(), ref[good].cpu().numpy()) < 1e-4
+    assert torch.isfinite(outs[1]).all() and rel_err(outs[1].cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
 def test_edge_mlp3_row_chunks():
     """csplat_gnn_edge_mlp3 addresses its rows through 32-bit buffer offsets and therefore walks edge lists longer than 2^22 rows in chunks
     (index arrays, piece numbering and outputs offset per chunk).  With CSPLAT_EM_CHUNK_ROWS=4096 in a fresh process, E = 10,005 takes
