@@ -465,6 +465,16 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     // acc starts from 16 floats of an LDS row (register r <-> feature 32w + 8(r >> 2) + 4h + (r & 3)); the step's NP B operands are
     // read one step ahead, the piece the next step needs first first.  (weight piece, activation piece) of a step's products, small
     // terms first -- bf16: the six that matter of nine; fp16: three of four
+    // the accumulators' start (G row of the tile for layer 1, the bias table for layers 2 and 3): 4 LDS reads.  What they read does not
+    // depend on the phase's barrier, so the phase BEFORE requests them in its last gaps, once the accumulator's previous content has been
+    // consumed: the first MFMA behind a barrier then waits for its B operand only
+    auto start_op = [&](const float *init, f32x16 &acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 t = *reinterpret_cast<const float4 *>(init + 32 * w + 8 * q + 4 * h);
+            acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
+        }
+    };
     auto phase = [&](int l, const el16 *Xtile, const float *init, f32x16 &acc, auto &&side) __attribute__((always_inline)) {
         constexpr int NPROD = C::NPROD;
         constexpr int WP[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0}, XP[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};
@@ -472,11 +482,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         const el16 *row = Xtile + (size_t)n * EM_STRIDE + 64 * h;
         i32x4 bc[NP], bn[NP];
         bc[XP[0]] = *reinterpret_cast<const i32x4 *>(row + XP[0] * ER_TILE_P);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 t = *reinterpret_cast<const float4 *>(init + 32 * w + 8 * q + 4 * h);
-            acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
-        }
+        if (init) start_op(init, acc);      // (else: requested by the previous phase's last gaps -- nothing of it waits for this phase's barrier)
 #pragma unroll
         for (int p = 0; p < NP; p++)
             if (p != XP[0]) bc[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P);
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     unsigned offA_prev = 0xfff00000u, offB_prev = 0xfff00000u;       // (no rows to write yet: past the end of any buffer this kernel takes)
     int tA_prev = 0x3fffffff, tB_prev = 0x3fffffff;                  // (AGG: a tile past the last row has no rows to sum)
     __syncthreads();
+    start_op(GtA + (size_t)n * ER_GSTRIDE, accA);
 #define SL(a) ((a) * NS / 48)      /* gap ranges below are written for 48 gaps per phase */
     int x = 0;
     for (int tA = T0; tA < ntiles; tA += 2 * stride, x ^= 1) {
@@ -541,7 +548,8 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         el16 *const XA0 = XA + x * XT, *const XA1 = XA + (x ^ 1) * XT, *const XB0 = XB + x * XT, *const XB1 = XB + (x ^ 1) * XT;
         stamp();
         // 0: layer 1 of A | LayerNorm partials of the previous B, LayerNorm's end + rows out of the previous A, the next A's indices
-        phase(0, XA0, GtA + (size_t)n * ER_GSTRIDE, accA, [&](int k) __attribute__((always_inline)) {
+        phase(0, XA0, nullptr, accA, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, SL(46), SL(48), 1, start_op(GtB + (size_t)n * ER_GSTRIDE, accB));
             if (!(EM_SKIP & 2)) ER_SPREAD(k, SL(0), SL(18), LNP_OPS, lnp_op(m, accLB, SrB));
             if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(14), SL(44), LNF_OPS, lnf_op(m, accLA, SrA, offA_prev, YtA));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(40), SL(48), 8, idx_op(m, (unsigned)tA2 * 32u, jaA, jbA));
@@ -550,30 +558,33 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         __syncthreads();
         stamp();
         // 1: layer 1 of B | A's ReLU + pieces, LayerNorm's end + rows out of the previous B, the next B's indices
-        phase(0, XB0, GtB + (size_t)n * ER_GSTRIDE, accB, [&](int k) __attribute__((always_inline)) {
+        phase(0, XB0, nullptr, accB, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, SL(46), SL(48), 1, start_op(sT, accA));
             if (!(EM_SKIP & 4)) ER_SPREAD(k, SL(0), SL(32), LNF_OPS, lnf_op(m, accLB, SrB, offB_prev, YtB));
             if (AGG) ER_SPREAD(k, SL(6), SL(42), 9, agg_op(m, YtA, tA_prev, ag_lA));
             if (AGG) ER_SPREAD(k, SL(44), SL(46), 1, agg_load_op(tB_prev, ag_lB));
             else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(40), 8, rows_out_op(m, YtA, offA_prev));
-            if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA1));
+            if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(44), RELU_OPS, relu_op(m, accA, XA1));
             if (!(EM_SKIP & 32)) ER_SPREAD(k, SL(40), SL(48), 8, idx_op(m, (unsigned)tB2 * 32u, jaB, jbB));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 8, g_issue_op(m, GAa, GBa, jaA, jbA));
         });
         __syncthreads();
         stamp();
         // 2: layer 2 of A | B's ReLU + pieces, the next A's gathers
-        phase(1, XA1, sT, accA, [&](int k) __attribute__((always_inline)) {
+        phase(1, XA1, nullptr, accA, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, SL(46), SL(48), 1, start_op(sT, accB));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(32), SL(48), 8, g_issue_op(m, GAb, GBb, jaB, jbB));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EA, (unsigned)tA2 * 16384u));
             if (AGG) ER_SPREAD(k, SL(8), SL(44), 9, agg_op(m, YtB, tB_prev, ag_lB));
             else if (C::ROWS_VIA_LDS && !(EM_SKIP & 4)) ER_SPREAD(k, SL(8), SL(32), 8, rows_out_op(m, YtB, offB_prev));
-            if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB1));
+            if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(44), RELU_OPS, relu_op(m, accB, XB1));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(20), SL(44), 12, g_commit_op(m, GAa, GBa, GtA));
         });
         __syncthreads();
         stamp();
         // 3: layer 2 of B | A's ReLU + pieces, the next B's gathers, the next A's edge rows requested
-        phase(1, XB1, sT, accB, [&](int k) __attribute__((always_inline)) {
+        phase(1, XB1, nullptr, accB, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, SL(46), SL(48), 1, start_op(sT + EM_N, accLA));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(32), SL(40), 4, e_issue_op(m, EB, (unsigned)tB2 * 16384u));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accA, XA0));
             if (!(EM_SKIP & 8)) ER_SPREAD(k, SL(20), SL(44), 12, g_commit_op(m, GAb, GBb, GtB));
@@ -581,14 +592,16 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         __syncthreads();
         stamp();
         // 4: layer 3 of A | B's ReLU + pieces, the next A's edge rows cut and parked, the next B's requested
-        phase(2, XA0, sT + EM_N, accLA, [&](int k) __attribute__((always_inline)) {
+        phase(2, XA0, nullptr, accLA, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, SL(46), SL(48), 1, start_op(sT + EM_N, accLB));
             if (!(EM_SKIP & 1)) ER_SPREAD(k, SL(0), SL(48), RELU_OPS, relu_op(m, accB, XB0));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(4), SL(48), EC_OPS, e_commit_op(m, EA, XA1));
         });
         __syncthreads();
         stamp();
         // 5: layer 3 of B | A's LayerNorm partials, the next B's edge rows cut and parked
-        phase(2, XB0, sT + EM_N, accLB, [&](int k) __attribute__((always_inline)) {
+        phase(2, XB0, nullptr, accLB, [&](int k) __attribute__((always_inline)) {
+            ER_SPREAD(k, SL(46), SL(48), 1, start_op(GtA + (size_t)n * ER_GSTRIDE, accA));
             if (!(EM_SKIP & 2)) ER_SPREAD(k, SL(0), SL(20), LNP_OPS, lnp_op(m, accLA, SrA));
             if (!(EM_SKIP & 16)) ER_SPREAD(k, SL(4), SL(48), EC_OPS, e_commit_op(m, EB, XB1));
         });
