@@ -503,7 +503,14 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         }
     };
 
-    const int T0 = blockIdx.x, stride = gridDim.x, ntiles = (int)((M + 31) / 32);
+    // Which tiles a workgroup takes.  Workgroup b runs on XCD b % 8, and every XCD has its own L2: with the tiles dealt round-robin each L2
+    // would have to hold the gathered node rows of the WHOLE graph (10 MB at N = 1e4 against 4 MB: ~55 MB of the launch's 209 MB of
+    // reads were gathers missing it).  So the tile sequence is cut into 8 contiguous eighths, one per XCD, and each eighth into contiguous
+    // ranges of pairs, one per workgroup of that XCD: edges are in destination order, so an XCD's workgroups gather from one region of
+    // the node tables.  (Grids that are not a multiple of 8: plain contiguous ranges.)
+    const int ntiles = (int)((M + 31) / 32), npairs = (ntiles + 1) / 2, G = (int)gridDim.x;
+    const int wg = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int T0 = 2 * (int)((int64_t)wg * npairs / G), Tend = 2 * (int)((int64_t)(wg + 1) * npairs / G), stride = 1;
     constexpr int XT = C::XT;
     el16 *const XA = sX, *const XB = sX + 2 * XT;       // slot s, buffer b: sX + (2s + b) * XT
     float *const GtA = sG, *const GtB = sG + 32 * ER_GSTRIDE, *const YtA = sY, *const YtB = sY + 32 * ER_GSTRIDE;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
     start_op(GtA + (size_t)n * ER_GSTRIDE, accA);
 #define SL(a) ((a) * NS / 48)      /* gap ranges below are written for 48 gaps per phase */
     int x = 0;
-    for (int tA = T0; tA < ntiles; tA += 2 * stride, x ^= 1) {
+    for (int tA = T0; tA < Tend; tA += 2 * stride, x ^= 1) {
         const int tB = tA + stride, tA2 = tA + 2 * stride, tB2 = tB + 2 * stride;
         el16 *const XA0 = XA + x * XT, *const XA1 = XA + (x ^ 1) * XT, *const XB0 = XB + x * XT, *const XB1 = XB + (x ^ 1) * XT;
         stamp();
