@@ -833,7 +833,7 @@ class CapturedStep:
         return (len(cams) >= 2 and len(cams) <= 8 and all(getattr(c, "mask", None) is None for c in cams) and
                 len({(int(c.image_height), int(c.image_width), float(c.FoVx), float(c.FoVy)) for c in cams}) == 1 and
                 self.g.mesh.pos.is_cuda and isinstance(self.g.optimizer, GroupedAdam) and isinstance(self.mopt, GroupedAdam) and
-                not (int(_n.lib.csplat_debug_flags_query()) & (2 | 128 | 256 | 512)) and      # (global sort, per-view launches, reproducible K7)
+                not (int(_n.lib.csplat_debug_flags_query()) & (2 | 128 | 512)) and      # (global sort, per-view launches; the bit-reproducible K7, bit 8, is served by the batched path since round 6)
                 all(hasattr(self.sim, a) for a in ("times_on_device", "input", "hidden", "output")))
 
     def _eager(self, iteration, cams):

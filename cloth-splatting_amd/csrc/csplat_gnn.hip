@@ -149,6 +149,54 @@ __global__ __launch_bounds__(256) void k_gather_rows_absmax(int64_t E, int LV, c
     if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned *>(amax)) atomicMax(amax, __float_as_uint(m));
 }
 
+// ---- the rollout's `real_world` refinement (/root/reference/train_meshnet_sim.py:211-250): per rollout step ten Adam iterations on the
+// predicted velocities v, loss = sum_e w_e (|(x + v)[row_e] - (x + v)[col_e]| - L0_e)^2 (w_e = 0 for the entry the reference zeroes with
+// `length_deviation[grasped_particle] *= 0`).  ONE launch per iteration, node-centric over the graph's two CSR orderings: thread i forms
+// dL/dv_i from its out- and in-edges (every edge length is evaluated from either end -- cheaper than six float atomics per edge, and
+// bit-reproducible) and takes the Adam step of its own three coordinates in the same pass (torch.optim.Adam's arithmetic order, as
+// csplat_optim.hip).  v is double-buffered by the caller: neighbours are read from v_in, v_out is written.
+__global__ __launch_bounds__(256) void k_edge_len_adam(int N, long long E, const float *__restrict__ pos, const float *__restrict__ v_in,
+                                                       float *__restrict__ v_out, float *__restrict__ m, float *__restrict__ sq,
+                                                       const int64_t *__restrict__ ei, const float *__restrict__ rest_len,
+                                                       const float *__restrict__ edge_w, const int *__restrict__ dst_rowptr,
+                                                       const int *__restrict__ dst_perm, const int *__restrict__ src_rowptr,
+                                                       const int *__restrict__ src_perm, float w1, float w2, float b2, float eps,
+                                                       float bc2_sqrt, float step_size) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t i3 = 3 * (size_t)i;
+    const float vx = v_in[i3], vy = v_in[i3 + 1], vz = v_in[i3 + 2];
+    const float px = pos[i3] + vx, py = pos[i3 + 1] + vy, pz = pos[i3 + 2] + vz;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int e = src_rowptr[i], end = src_rowptr[i + 1]; e < end; e++) {     // edges with row == i: d = p_i - p_col, dL/dp_i = +2 dev d / len
+        const int id = src_perm[e];
+        const size_t b = 3 * (size_t)ei[E + id];
+        const float dx = px - (pos[b] + v_in[b]), dy = py - (pos[b + 1] + v_in[b + 1]), dz = pz - (pos[b + 2] + v_in[b + 2]);
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float dev = (len - rest_len[id]) * (edge_w ? edge_w[id] : 1.f);
+        const float k = len > 0.f ? 2.f * dev / len : 0.f;                    // (torch.norm's backward: zero at a zero-length edge)
+        gx += k * dx; gy += k * dy; gz += k * dz;
+    }
+    for (int e = dst_rowptr[i], end = dst_rowptr[i + 1]; e < end; e++) {     // edges with col == i: d = p_row - p_i, dL/dp_i = -2 dev d / len
+        const int id = dst_perm[e];
+        const size_t a = 3 * (size_t)ei[id];
+        const float dx = (pos[a] + v_in[a]) - px, dy = (pos[a + 1] + v_in[a + 1]) - py, dz = (pos[a + 2] + v_in[a + 2]) - pz;
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float dev = (len - rest_len[id]) * (edge_w ? edge_w[id] : 1.f);
+        const float k = len > 0.f ? 2.f * dev / len : 0.f;
+        gx -= k * dx; gy -= k * dy; gz -= k * dz;
+    }
+    const float g[3] = {gx, gy, gz}, v0[3] = {vx, vy, vz};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float mm = m[i3 + c], ss = sq[i3 + c];
+        mm = mm + (g[c] - mm) * w1;                         // exp_avg.lerp_(grad, 1 - beta1)
+        ss = ss * b2 + w2 * g[c] * g[c];                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(ss) / bc2_sqrt + eps;
+        v_out[i3 + c] = v0[c] - step_size * (mm / denom);
+        m[i3 + c] = mm; sq[i3 + c] = ss;
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -159,6 +207,35 @@ int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const in
     if (E == 0) return 0;
     k_edge_features<<<cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, (float4 *)out);
     LAUNCH_CHECK();
+    return 0;
+}
+
+// The `real_world` refinement of one rollout step (/root/reference/train_meshnet_sim.py:211-250): `iters` Adam iterations (a fresh
+// torch.optim.Adam(lr): zero moments, step counts 1..iters) on v [N][3] against the squared deviation of the edge lengths of pos + v from
+// rest_len [E]; edge_w [E] or NULL weights the deviations (0 for the entry the reference zeroes).  v is updated IN PLACE; scratch =
+// 9 N floats (the other half of the double buffer and both moments; contents irrelevant on entry).  edge_index [2][E] int64; the two
+// CSR orderings as csplat_gnn_build_csr leaves them.  Nothing is read back: recordable into a hipGraph.
+int csplat_gnn_edge_length_refine(void *stream, int N, int64_t E, const float *pos, float *v, const int64_t *edge_index, const float *rest_len,
+                                  const float *edge_w, const int32_t *dst_rowptr, const int32_t *dst_perm, const int32_t *src_rowptr,
+                                  const int32_t *src_perm, int iters, double lr, double beta1, double beta2, double eps, float *scratch) {
+    CSPLAT_REQUIRE(N >= 0 && E >= 0 && iters >= 0 && iters <= 1000, "csplat_gnn_edge_length_refine: bad sizes");
+    if (N == 0 || iters == 0) return 0;
+    CSPLAT_REQUIRE(pos && v && scratch && dst_rowptr && src_rowptr && (E == 0 || (edge_index && rest_len && dst_perm && src_perm)),
+                   "csplat_gnn_edge_length_refine: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    float *v2 = scratch, *m = scratch + 3 * (size_t)N, *sq = scratch + 6 * (size_t)N;
+    HIP_TRY(hipMemsetAsync(m, 0, 6 * (size_t)N * sizeof(float), s));
+    float *cur = v, *nxt = v2;
+    for (int t = 1; t <= iters; t++) {
+        const double bc1 = 1.0 - pow(beta1, (double)t);
+        const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+        k_edge_len_adam<<<cdiv(N, 256), 256, 0, s>>>(N, (long long)E, pos, cur, nxt, m, sq, edge_index, rest_len, edge_w, dst_rowptr, dst_perm,
+                                                     src_rowptr, src_perm, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)beta2, (float)eps,
+                                                     bc2_sqrt, (float)(lr / bc1));
+        LAUNCH_CHECK();
+        float *t_ = cur; cur = nxt; nxt = t_;
+    }
+    if (cur != v) HIP_TRY(hipMemcpyAsync(v, cur, 3 * (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 

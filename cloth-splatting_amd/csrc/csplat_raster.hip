@@ -2031,6 +2031,7 @@ struct B2View {
     const float *out_color, *dL_dpix;
     float *acc;
     uint32_t R;
+    float *det;        // bit-reproducible mode: the (entry, block) records behind the per-Gaussian ones, else NULL
 };
 struct B2Table { B2View v[B2_MAX_VIEWS]; unsigned long long *stamp; const uint32_t *valid; };
 __global__ __launch_bounds__(256, 8) void k_composite_bwd_rows_views(int tiles, int W, int H, int gx, B2Table tab) {
@@ -2038,6 +2039,21 @@ __global__ __launch_bounds__(256, 8) void k_composite_bwd_rows_views(int tiles, 
     const B2View &w = tab.v[blockIdx.y];
     composite_bwd_body<false>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.bbits, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
                               w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, nullptr, tab.stamp);
+}
+// the same launch in the bit-reproducible mode (round 6: the batched and the recorded step take the mode too, so that an eager and a
+// replayed step can be compared bit for bit)
+__global__ __launch_bounds__(256) void k_composite_bwd_rows_views_det(int tiles, int W, int H, int gx, B2Table tab) {
+    if (tab.valid && *tab.valid == 0u) return;
+    const B2View &w = tab.v[blockIdx.y];
+    composite_bwd_body<true>(tiles, W, H, gx, w.ranges, w.ids_sorted, w.bbits, w.recA, w.recB, w.recC, w.R, w.seg_offset, w.slot_tile, w.ckpt,
+                             w.final_T, w.n_contrib, w.out_color, w.dL_dpix, w.acc, w.det, nullptr);
+}
+__global__ __launch_bounds__(256) void k_zero_det_views(B2Table tab) {
+    if (tab.valid && *tab.valid == 0u) return;
+    const B2View &w = tab.v[blockIdx.y];
+    float4 *p = reinterpret_cast<float4 *>(w.det);
+    const int64_t n4 = ((int64_t)(w.R > 0 ? w.R : 1) * 16 * 9 + 3) / 4;        // (det_bytes() is a multiple of 256: the tail is ours)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __global__ __launch_bounds__(256) void k_zero_acc_views(int64_t n4, B2Table tab) {
     float4 *p = reinterpret_cast<float4 *>(tab.v[blockIdx.y].acc);
@@ -2078,6 +2094,41 @@ __global__ __launch_bounds__(256) void k_det_reduce(int P, Cam cam, const float2
     }
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[(size_t)i * ACC_STRIDE + t] = s[t];
+}
+
+struct DetView { Cam cam; const float2 *xy; const float *depth; const int32_t *radii; const int2 *ranges; const uint64_t *keys_sorted;
+                 const uint32_t *ids_sorted; const float *det; float *acc; };
+struct DetTable { DetView v[B2_MAX_VIEWS]; const uint32_t *valid; };
+__global__ __launch_bounds__(256) void k_det_reduce_views(int P, DetTable tab) {
+    if (tab.valid && *tab.valid == 0u) return;
+    const DetView &w = tab.v[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) s[t] = 0.f;
+    const int rad = w.radii[i];
+    if (rad > 0) {
+        const float2 p = w.xy[i];
+        int minx, miny, maxx, maxy;
+        tile_rect(p.x, p.y, rad, w.cam, minx, miny, maxx, maxy);
+        const uint64_t want = ((uint64_t)__float_as_uint(w.depth[i]) << 32) | (uint32_t)i;
+        for (int y = miny; y < maxy; y++)
+            for (int x = minx; x < maxx; x++) {
+                const int2 rg = w.ranges[y * w.cam.gx + x];
+                int lo = rg.x, hi = rg.y;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint64_t k = ((w.keys_sorted[mid] & 0xFFFFFFFFull) << 32) | w.ids_sorted[mid];
+                    if (k < want) lo = mid + 1; else hi = mid;
+                }
+                for (int q = 0; q < 16; q++)
+#pragma unroll
+                    for (int t = 0; t < 9; t++) s[t] += w.det[((size_t)lo * 16 + q) * 9 + t];
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) w.acc[(size_t)i * ACC_STRIDE + t] = s[t];
 }
 
 // ------------------------------------------------------------------------------------------- K8
@@ -3724,7 +3775,8 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     K8Table tab;
     const bool one_k8 = shared && k8_views_table(V, v, tab);
     // K7 of all views in ONE launch on the join stream (plus one launch clearing the records) when the views are alike
-    bool batch_k7 = V >= 2 && V <= B2_MAX_VIEWS && !(g_debug_flags & (256u | 512u));
+    const bool det_mode = (g_debug_flags & 256u) != 0;
+    bool batch_k7 = V >= 2 && V <= B2_MAX_VIEWS && !(g_debug_flags & 512u);
     for (int i = 0; i < V && batch_k7; i++)
         batch_k7 = v[i].P == v[0].P && v[i].P > 0 && v[i].W == v[0].W && v[i].H == v[0].H && v[i].num_rendered > 0 && v[i].geom &&
                    v[i].binning && v[i].image && v[i].out_color && v[i].scratch && v[i].dL_dpix;
@@ -3740,6 +3792,8 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
         if (batch_k7) {
             const int W = v[0].W, H = v[0].H, P = v[0].P, gx = cdiv(W, CSPLAT_TILE), tiles = gx * cdiv(H, CSPLAT_TILE);
             B2Table bt;
+            DetTable dt;
+            dt.valid = v[0].valid;
             int64_t slots = 0;
             size_t ioff[5];
             image_offsets(W, H, ioff);
@@ -3755,6 +3809,14 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                 k.ckpt = (const float4 *)(b + boff[4]); k.bbits = (const unsigned long long *)(b + boff[9]);
                 k.recA = (const float4 *)(b + boff[6]); k.recB = (const float4 *)(b + boff[7]); k.recC = (const float2 *)(b + boff[8]);
                 k.out_color = w.out_color; k.dL_dpix = w.dL_dpix; k.acc = (float *)w.scratch; k.R = (uint32_t)Rl;
+                k.det = det_mode ? (float *)((char *)w.scratch + align256((size_t)P * ACC_STRIDE * 4)) : nullptr;
+                if (det_mode) {
+                    DetView &d = dt.v[i];
+                    make_cam(d.cam, w.view, w.proj, w.campos, w.tanfovx, w.tanfovy, w.W, w.H);
+                    const Geom g = geom_view((void *)w.geom, P);
+                    d.xy = g.xy; d.depth = g.depth; d.radii = w.radii; d.ranges = k.ranges; d.keys_sorted = (const uint64_t *)(b + boff[0]);
+                    d.ids_sorted = k.ids_sorted; d.det = k.det; d.acc = k.acc;
+                }
                 // segments of the view: <= R / SEG + (non-empty tiles) + 1 with the EXACT counts the forward read -- the layout's bound
                 // (capacity / SEG + all tiles + 1) launches twice as many workgroups that find no segment
                 const int64_t sl = (w.busy_tiles > 0 && w.num_rendered > 0) ? (int64_t)w.num_rendered / SEG + w.busy_tiles + 1 : max_slots(Rl, tiles);
@@ -3767,14 +3829,22 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             }
             bool zeroed = true;      // every view's records are zero already (CSPLAT_SCRATCH_ZEROED) and K8 will leave them so: no clearing launch
             for (int i = 0; i < V; i++) zeroed = zeroed && (v[i].accmask & CSPLAT_SCRATCH_ZEROED);
-            if (!zeroed) {
+            if (det_mode) {          // (k_det_reduce_views writes every record: nothing to clear but the (entry, block) records)
+                k_zero_det_views<<<dim3(1024, V), 256, 0, join>>>(bt);
+                LAUNCH_CHECK();
+            } else if (!zeroed) {
                 const int64_t n4 = (int64_t)P * ACC_STRIDE / 4;
                 k_zero_acc_views<<<dim3((unsigned)(cdiv(n4, 256) > 1024 ? 1024 : cdiv(n4, 256)), V), 256, 0, join>>>(n4, bt);
                 LAUNCH_CHECK();
             }
             ProfScope ps(PROF_K7, join);       // (the bracket bench.py's roofline reads: K7's launch alone, not the record clearing in front of it)
             const unsigned items = (unsigned)cdiv(slots, 8) * 32u;
-            k_composite_bwd_rows_views<<<dim3(items, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+            if (det_mode) {
+                k_composite_bwd_rows_views_det<<<dim3(items, V), 256, 0, join>>>(tiles, W, H, gx, bt);
+                LAUNCH_CHECK();
+                k_det_reduce_views<<<dim3((unsigned)cdiv(P, 256), V), 256, 0, join>>>(P, dt);
+            } else
+                k_composite_bwd_rows_views<<<dim3(items, V), 256, 0, join>>>(tiles, W, H, gx, bt);
             LAUNCH_CHECK();
         }
         for (int i = 0; i < V && !(batch_k7 && one_k8); i++) {

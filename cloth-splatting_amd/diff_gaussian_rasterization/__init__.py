@@ -467,7 +467,10 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     sv = _n.grad_out(sk, inputs[i * n + slot].shape, dev) if sk is not None else None
                     if sv is not None and sv.numel() == numel and sv.data_ptr() % 16 == 0:
                         sink_of[(i, slot)] = sv
-                        used_sinks.append(sk)
+                        # (only a sink this plan really CLAIMED is given back when the plan is rebuilt: grad_out() hands out fresh memory
+                        # when another node holds the slice, and releasing that node's claim would let a third writer alias it -- ADVICE r5)
+                        if sv.data_ptr() == sk[0].data_ptr() + 4 * int(sk[1]):
+                            used_sinks.append(sk)
                         ent[field] = owner[(i, slot)] = ("sink", i, slot)
                         ent["ret"][slot] = (ent[field], shapes[slot])
                         continue

@@ -432,6 +432,15 @@ int csplat_gnn_gather_rows_absmax(void *stream, int64_t E, int L, const float *r
  * /root/reference/train_meshnet_sim.py:152 and dataloader_sim.py): out[e] = (pos[row] - pos[col], |pos[row] - pos[col]|) with
  * row = edge_index[0][e], col = edge_index[1][e]; pos [N][3], out [E][4] (16-byte aligned). */
 int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const int64_t *edge_index, float *out);
+/* The `real_world` branch of the rollout (/root/reference/train_meshnet_sim.py:211-250: per rollout step, ten iterations of a fresh
+ * torch.optim.Adam(lr = 1e-3) on the predicted velocities against sum_e w_e (|(pos + v)[row_e] - (pos + v)[col_e]| - rest_len_e)^2).
+ * v [N][3] is updated in place; edge_w [E] or NULL (the reference zeroes ONE deviation: `length_deviation[grasped_particle] *= 0`);
+ * the CSR orderings by destination (edge_index[1]) and by source (edge_index[0]) as csplat_gnn_build_csr leaves them; scratch = 9 N
+ * floats.  One launch per iteration (gradient gathered per node over both orderings -- no atomics -- and the Adam step of the node's own
+ * coordinates in the same pass), nothing read back. */
+int csplat_gnn_edge_length_refine(void *stream, int N, int64_t E, const float *pos, float *v, const int64_t *edge_index, const float *rest_len,
+                                  const float *edge_w, const int32_t *dst_rowptr, const int32_t *dst_perm, const int32_t *src_rowptr,
+                                  const int32_t *src_perm, int iters, double lr, double beta1, double beta2, double eps, float *scratch);
 
 /* The 128-wide Linear layers of the MeshNet MLPs for inference (replaces the cuBLAS sgemm behind nn.Linear at
  * /root/reference/meshnet/graph_network.py:198,221 when no autograd graph is recorded), with everything that follows the

@@ -22,6 +22,8 @@ STEP_HOOK = [None]              # tools/psnr_shadow.py: called after every HIP s
 PRE_STEP = [None]               # (it, pc, sim) -> context manager entered around the HIP step (tests/teacher.py: capture), or None
 HIP_FLAGS = [256]               # csplat_debug_flags of the HIP run (bit 8: bit-reproducible K7)
 TORCH_DTYPE = [None]            # (None = torch.float64; the probe also runs the whole CPU side in float32, like the reference's own arithmetic)
+PERTURB = [None]                # ensemble member k: the initial colours scaled by (1 + 1e-7 * seeded noise) -- a DETERMINISTIC sample of the chaos
+ATOMIC_STEPS = [()]             # steps whose CAPTURED run uses K7's float atomics while the trajectory itself stays reproducible (see hip_run)
 ORACLE_DTYPE = [np.float64]     # (tools/psnr_probe.py also runs the fp32 build of the oracle: how far fp32 ARITHMETIC alone moves a trajectory)
 
 
@@ -77,8 +79,8 @@ def test_psnr_parity_hip_vs_oracle_training(masked):
         tools/psnr_shadow.py: every gradient along the trajectory agrees with the fp64 oracle to 1e-5 until ~step 420 and differs
         afterwards exactly at steps where the two IMAGES differ by 1e-6 (sign flips), while tools/psnr_debug.py shows the raw rasterizer
         backward on the same dL/dimage agreeing with the fp32 oracle to 2e-6 in every K7 mode.  A single pair of trajectories therefore
-        says nothing at step 500: the fp64 CPU result is held against an ENSEMBLE of HIP runs (the reproducible one + six with
-        atomics): its PSNR over the last 40 steps must lie inside the ensemble's range (+- 0.05 dB) and within max(0.05 dB, 2.5 standard
+        says nothing at step 500: the fp64 CPU result is held against an ENSEMBLE of HIP runs (the reproducible one + six reproducible
+        runs from initial colours perturbed by 1e-7 relative, seeded; until round 5: six runs with float atomics): its PSNR over the last 40 steps must lie inside the ensemble's range (+- 0.05 dB) and within max(0.05 dB, 2.5 standard
         errors) of the ensemble's median."""
     psnr_g, psnr_c = _parity(masked)
     n = min(len(psnr_g), 200)
@@ -87,13 +89,14 @@ def test_psnr_parity_hip_vs_oracle_training(masked):
     late = lambda tr_, end: float(np.mean(tr_[end - 40:end]))    # noqa: E731   (PSNR over 40 steps: a run caught in a dip at the very last
     runs = [psnr_g]                                               #  step says little about where it trains to)
     STEP_HOOK[0] = lambda *a: None            # (one HIP run per call, no bit-equality replay)
-    real = native.lib.csplat_debug_flags
     try:
-        native.lib.csplat_debug_flags = lambda f: real(0)      # default mode: K7 sums with float atomics
-        for _ in range(ENSEMBLE):
+        # round 6: the ensemble members are REPRODUCIBLE runs whose initial colours differ by 1e-7 relative (seeded), not runs that differ
+        # in the order of K7's float atomics: the same sample of the chaos on every run of the suite -- the test cannot pass or fail by luck
+        for k in range(ENSEMBLE):
+            PERTURB[0] = k
             runs.append(_parity(masked, len(psnr_g), hip_only=True)[0])
     finally:
-        native.lib.csplat_debug_flags = real
+        PERTURB[0] = None
         STEP_HOOK[0] = None
     # the north_star's "within 0.05 dB": held at step 200 and at the protocol's step 500, each time against the ensemble
     for end in sorted({n, len(psnr_g)}):
@@ -171,8 +174,35 @@ def _parity(masked, steps=None, hip_only=False):
             c.mask = m.to(dev)
 
     # ---- (a) HIP training, bit-reproducible mode
+    def snapshot(pc, sim, mopt):
+        ps = list(pc.parameters()) + list(sim.parameters())
+        st = []
+        for opt in (pc.optimizer, mopt):
+            for p in ps:
+                e = opt.state.get(p)
+                st.append((opt, p, None if not e else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in e.items()}))
+        return [p.detach().clone() for p in ps], st
+
+    def restore(pc, sim, mopt, snap):
+        with torch.no_grad():
+            for p, q in zip(list(pc.parameters()) + list(sim.parameters()), snap[0]):
+                p.copy_(q)
+            for opt, p, e in snap[1]:
+                if e is None:
+                    opt.state.pop(p, None)
+                else:
+                    for k, v in e.items():
+                        opt.state[p][k].copy_(v) if torch.is_tensor(v) else opt.state[p].__setitem__(k, v)
+                opt.__dict__.pop("_step_cache", None)
+        for p in list(pc.parameters()) + list(sim.parameters()):
+            p.grad = None
+
     def hip_run():
         pc, sim = build(dev, torch.float32)
+        if PERTURB[0] is not None:
+            g = torch.Generator().manual_seed(4242 + int(PERTURB[0]))
+            with torch.no_grad():
+                pc._features_dc.mul_(1.0 + 1e-7 * torch.randn(pc._features_dc.shape, generator=g).to(dev))
         pc.training_setup(**LRS)
         mopt = torch.optim.Adam(sim.parameters(), lr=3e-4)
         ps = []
@@ -180,6 +210,24 @@ def _parity(masked, steps=None, hip_only=False):
             ctx = PRE_STEP[0](it, pc, sim) if PRE_STEP[0] is not None else None
             if ctx is None:
                 ps.append(float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0]))
+            elif it in ATOMIC_STEPS[0]:
+                # the step under test runs with float atomics FROM THE REPRODUCIBLE TRAJECTORY'S STATE; what it did to the parameters is
+                # then undone and the trajectory advances by the same step in the reproducible mode -- every run of the test visits the
+                # same states, whatever order the atomics took (bars must not be tuned to run-to-run noise)
+                snap = snapshot(pc, sim, mopt)
+                native.lib.csplat_debug_flags(0)
+                try:
+                    with ctx as cap:
+                        ps.append(float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0]))
+                finally:
+                    native.lib.csplat_debug_flags(HIP_FLAGS[0])
+                PRE_STEP[1:] = [cap]
+                if STEP_HOOK[0] is not None:
+                    STEP_HOOK[0](it, pc, sim, cams_g, bg, build, ps[-1])
+                restore(pc, sim, mopt, snap)
+                again = float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0])
+                assert again == ps[-1], (it, again, ps[-1])          # (the forward does not depend on K7's mode)
+                continue
             else:
                 with ctx as cap:
                     ps.append(float(tr.train_step(it, cams_g, pc, sim, mopt, background=bg)[0]))
@@ -326,11 +374,16 @@ def test_teacher_forced_gradient_parity_along_the_trajectory(flags):
 
     PRE_STEP[:] = [pre]
     STEP_HOOK[0] = post
-    HIP_FLAGS[0] = flags
+    # flags == 0: the six checkpoint steps run with K7's float atomics, from the states of the REPRODUCIBLE trajectory (hip_run: the atomic
+    # step is undone and repeated in the reproducible mode) -- the atomic kernels are held to the oracle at the same six states on every
+    # run of the suite, instead of at the states of a trajectory that differs from run to run (round 5: tie counts of a chaotic sample)
+    HIP_FLAGS[0] = 256
+    ATOMIC_STEPS[0] = tuple(CHECKPOINTS) if flags == 0 else ()
     try:
         _parity(False, max(CHECKPOINTS), hip_only=True)
     finally:
         PRE_STEP[:] = [None]
         STEP_HOOK[0] = None
         HIP_FLAGS[0] = 256
+        ATOMIC_STEPS[0] = ()
     assert [it for it, _ in seen] == list(CHECKPOINTS)

@@ -1088,3 +1088,56 @@ def test_accumulation_records_are_left_zero_by_the_backward():
     gB_fresh = run([1, 2], dpB)
     for a, b in zip(gB, gB_fresh):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_gradient_sink_keeps_one_writer_when_a_second_node_rebuilds_its_plan():
+    """a view-parallel step binds every parameter's slice of the flat gradient buffer as its gradient SINK
+    (csplat.dist.FlatGrads.bind), one writer per bind.  Two rasterizer nodes of one step share the bound parameters; the second node's
+    forward MISSES its speculation (its scene grew 4x: the backward plan is rebuilt).  The rebuilt plan used to give back a sink the
+    FIRST node holds and then claim the same slice: two kernels writing aliased memory, autograd summing the alias twice.  The
+    gradients must be the plain sum of the two nodes' gradients (here: what the same two calls give without any sink)."""
+    from csplat.dist import FlatGrads
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import rasterize_views
+    V, P = 2, 2900          # (a shape no other test of the suite uses: the library's speculation history is per process and shape)
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+
+    def run(bound):
+        res = None
+        base = util.make_case(P=P, W=176, H=128, seed=9, theta=-40.0, scale_mul=2.0)
+        inp = util.gpu_inputs(base)
+        params = [inp[k] for k in names]
+        fg = FlatGrads(params) if bound else None
+        try:
+            for rnd in range(2):                       # round 0 leaves the capacities the second node of round 1 will miss
+                for p in params:
+                    p.grad = None
+                if fg is not None:
+                    fg.bind()
+                before = dict(dgr.SPEC_STATS)
+                loss = 0.0
+                for node, mul in enumerate((1.0, 1.0 if rnd == 0 else 2.0)):
+                    cases = [util.make_case(P=P, W=176, H=128, seed=9, theta=-40.0 + 25.0 * i, scale_mul=2.0) for i in range(V)]
+                    settings = [util.gpu_settings(c, scale_mod=mul) for c in cases]
+                    m2d = [torch.zeros(P, 3, device="cuda", requires_grad=True) for _ in range(V)]
+                    kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                                rotations=inp["rotations"]) for i in range(V)]
+                    outs = rasterize_views(settings, kws)
+                    gen = torch.Generator(device="cuda").manual_seed(10 * rnd + node)
+                    tgt = torch.rand(V, 3, 128, 176, device="cuda", generator=gen)
+                    loss = loss + (1 + node) * sum(((o[0] - tgt[i]) ** 2).mean() for i, o in enumerate(outs))
+                missed = dgr.SPEC_STATS["miss"] - before["miss"]
+                loss.backward()
+                torch.cuda.synchronize()
+                if fg is not None:
+                    fg.unbind()
+                res = ([p.grad.detach().clone() for p in params], missed)
+        finally:
+            if fg is not None:
+                fg.close()
+        return res
+    plain, _m0 = run(False)
+    sunk, missed = run(True)
+    assert missed >= 1, "the second node of the last round was meant to miss its speculation"
+    for name, a, b in zip(names, sunk, plain):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, name

@@ -1,5 +1,7 @@
 """train_step analogue on a small scene: the whole hot path under autograd + two Adam
 optimisers must fit a perturbed target: PSNR rises, loss falls, statistics have the reference's shapes."""
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -659,163 +661,237 @@ def _captured_fixture(seed=3):
     return pc, sim, mopt, cams, bg
 
 
-def test_captured_train_step_equals_the_eager_step():
-    """csplat.train.CapturedStep (train_step(captured=True)): the step recorded once into a hipGraph -- forward launched on faith
-    (csplat_forward_views_faith), Adam's step count / learning rates / go word on the device (csplat_adam_step_dev), ONE host read at the
-    end -- against the eager train_step from the same initial state, eight steps: PSNR and loss per step, the densification statistics,
-    every parameter and both Adam moments at the end (only K7's float-atomic order differs between two runs: 1e-5 of scale), the host-side
-    step counters.  Reference step: scene_reconstruction/train_utils.py:240-321, timed as train.py:146,178."""
+DET = 256       # csplat_debug_flags bit 8: bit-reproducible K7 (per-(entry, block) records summed in emission order instead of float atomics)
+
+
+@contextlib.contextmanager
+def _reproducible_k7(on=True):
+    """Both arms of an eager-against-recorded comparison run with the bit-reproducible K7: every kernel of the step then sums in a fixed
+    order, and a recorded step that does the eager step's work must reproduce it BIT FOR BIT -- a statement no tolerance can water down and
+    no threshold tie can flake.  The flag is set before any scratch of the step is sized and reset whatever happens."""
+    from csplat import native
+    native.lib.csplat_debug_flags(DET if on else 0)
+    try:
+        yield
+    finally:
+        native.lib.csplat_debug_flags(0)
+
+
+def _adam_state(opt, params):
+    out = []
+    for p in params:
+        st = opt.state.get(p)
+        if st:
+            out += [st["exp_avg"].clone(), st["exp_avg_sq"].clone()]
+    return out
+
+
+def _captured_run(mode, iterations, cams_of, seed=3, sh_at_max=False, before_step=None, det=True):
+    """one training run from `_captured_fixture(seed)`: per step (PSNR, loss, radii, viewspace gradient sum, visibility), then every
+    parameter, both Adam moments of both optimizers, the host and device step counts and the CapturedStep object"""
     from csplat import train as tr
-    runs = {}
-    for mode in ("eager", "captured"):
-        pc, sim, mopt, cams, bg = _captured_fixture()
+    with _reproducible_k7(det):
+        pc, sim, mopt, cams, bg = _captured_fixture(seed=seed)
+        if sh_at_max:
+            pc.active_sh_degree = pc.max_sh_degree
         log = []
-        for it in range(1, 9):
-            ps, loss, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, captured=(mode == "captured"))
+        for it in iterations:
+            if before_step is not None:
+                before_step(it, pc, sim, cams, mode)
+            ps, loss, stats = tr.train_step(it, cams_of(it, cams), pc, sim, mopt, background=bg, captured=(mode == "captured"))
             log.append((float(ps), float(loss), stats["radii"].clone(), stats["viewspace_grad"].clone(), stats["visibility_filter"].clone()))
         torch.cuda.synchronize()
         params = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
-        moments = [pc.optimizer.state[p]["exp_avg"].clone() for p in pc.parameters() if p in pc.optimizer.state and pc.optimizer.state[p]]
-        steps = [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if p in pc.optimizer.state and pc.optimizer.state[p]] + \
+        moments = _adam_state(pc.optimizer, pc.parameters()) + _adam_state(mopt, sim.parameters())
+        steps = [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if pc.optimizer.state.get(p)] + \
                 [float(mopt.state[p]["step"]) for p in sim.parameters()]
-        runs[mode] = (log, params, moments, steps, getattr(pc, "_captured_step", None))
-    cs = runs["captured"][4]
+        dev_steps = None
+        if mode == "captured":
+            dev_steps = (int(pc.optimizer._cap["state"].item()), int(mopt._cap["state"].item()))
+    return {"log": log, "params": params, "moments": moments, "steps": steps, "dev_steps": dev_steps,
+            "cs": getattr(pc, "_captured_step", None)}
+
+
+def _assert_runs_bit_equal(a, b):
+    """two runs in the bit-reproducible mode: PSNR, loss, radii, visibility and the summed screen-space gradient of EVERY step, every
+    parameter, both Adam moments and the step counts -- equal bit for bit"""
+    assert len(a["log"]) == len(b["log"])
+    for k_, ((pa, la, ra, va, fa), (pb, lb, rb, vb, fb)) in enumerate(zip(a["log"], b["log"])):
+        assert pa == pb and la == lb, (k_, pa, pb, la, lb)
+        assert torch.equal(ra, rb) and torch.equal(fa, fb), k_
+        assert torch.equal(va, vb), (k_, float((va - vb).abs().max()))
+    assert len(a["params"]) == len(b["params"]) and len(a["moments"]) == len(b["moments"]) and len(a["moments"]) > 0
+    for i, (x, y) in enumerate(zip(a["params"], b["params"])):
+        assert torch.equal(x, y), ("parameter", i, tuple(x.shape), float((x - y).abs().max()))
+    for i, (x, y) in enumerate(zip(a["moments"], b["moments"])):
+        assert torch.equal(x, y), ("moment", i, tuple(x.shape), float((x - y).abs().max()))
+    assert a["steps"] == b["steps"]
+
+
+def test_captured_train_step_equals_the_eager_step():
+    """csplat.train.CapturedStep (train_step(captured=True)): the step recorded once into a hipGraph -- forward launched on faith
+    (csplat_forward_views_faith), Adam's step count / learning rates / go word on the device (csplat_adam_step_dev), ONE host read at the
+    end -- against the eager train_step from the same initial state, eight steps, BOTH in the bit-reproducible mode: PSNR, loss, the
+    densification statistics of every step, every parameter, both Adam moments and the step counters equal BIT FOR BIT.
+    Reference step: scene_reconstruction/train_utils.py:240-321, timed as train.py:146,178."""
+    same = lambda it, cams: cams  # noqa: E731
+    its = list(range(1, 9))
+    eager = _captured_run("eager", its, same)
+    cap = _captured_run("captured", its, same)
+    cs = cap["cs"]
     assert cs is not None and cs.stats["recorded"] == 1 and cs.stats["replayed"] == 7 and cs.stats["eager"] == 1 and cs.stats["missed"] == 0, cs.stats
-    assert runs["eager"][3] == runs["captured"][3] == [8.0] * len(runs["eager"][3])
-    for k_, ((pe, le, re_, ve, fe), (pc_, lc, rc, vc, fc)) in enumerate(zip(runs["eager"][0], runs["captured"][0])):
-        # step 1 starts from identical parameters: the losses agree to rounding.  From step 2 on the two runs' parameters differ by K7's
-        # atomic order, and ONE compositing threshold (alpha against 1/255, T against 1e-4) decided the other way at one pixel moves the
-        # loss by ~1.6e-4 of itself -- seen as a bimodal outcome of this comparison, 2 runs in 8, with either library of round 4
-        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < (1e-5 if k_ == 0 else 5e-4) * max(abs(le), 1e-3), (k_, pe, pc_, le, lc)
-        assert float((re_ != rc).float().mean()) < 1e-3 and torch.equal(fc, rc > 0)
-        # (from the second step on the two runs' parameters differ by K7's atomic order: rounding-level differences in the gradients)
-        assert float((ve - vc).abs().max()) <= 3e-2 * float(ve.abs().max())
-    for a, b in zip(runs["eager"][1] + runs["eager"][2], runs["captured"][1] + runs["captured"][2]):
-        d = (a - b).abs()
-        assert float((d > 1e-6 + 2e-3 * b.abs()).float().mean()) < 0.02, float(d.max())
+    assert eager["steps"] == cap["steps"] == [8.0] * len(eager["steps"])
+    assert cap["dev_steps"] == (8, 8)
+    _assert_runs_bit_equal(eager, cap)
+    # and the reproducible mode is reproducible: a second eager run equals the first
+    _assert_runs_bit_equal(eager, _captured_run("eager", its, same))
+
+
+def _calibration():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "captured_atomic_calibration.json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def captured_atomic_metrics(eager, cap):
+    """How far two runs in the DEFAULT mode (K7 sums with float atomics: the order of the additions differs from run to run) are apart.
+    tools/calibrate_captured_atomic.py measures these over many pairs of runs; the test's bars are twice the largest values it saw."""
+    m = {"psnr": 0.0, "loss_rel_first": 0.0, "loss_rel": 0.0, "radii_frac": 0.0, "vgrad_rel": 0.0, "param_frac": 0.0}
+    for k_, ((pa, la, ra, va, fa), (pb, lb, rb, vb, fb)) in enumerate(zip(eager["log"], cap["log"])):
+        m["psnr"] = max(m["psnr"], abs(pa - pb))
+        rel = abs(la - lb) / max(abs(la), 1e-3)
+        if k_ == 0:
+            m["loss_rel_first"] = rel
+        m["loss_rel"] = max(m["loss_rel"], rel)
+        m["radii_frac"] = max(m["radii_frac"], float((ra != rb).float().mean()))
+        m["vgrad_rel"] = max(m["vgrad_rel"], float((va - vb).abs().max()) / max(float(va.abs().max()), 1e-20))
+    for x, y in zip(eager["params"] + eager["moments"], cap["params"] + cap["moments"]):
+        d = (x - y).abs()
+        m["param_frac"] = max(m["param_frac"], float((d > 1e-6 + 2e-3 * y.abs()).float().mean()))
+    return m
+
+
+def test_captured_train_step_default_mode_within_calibrated_atomic_noise():
+    """The same comparison in the DEFAULT mode, where K7 adds with float atomics and two runs are two samples of a chaotic trajectory (one
+    compositing threshold decided the other way at one pixel moves a loss by ~1e-4 of itself).  The bars are not tuned by hand: they are
+    twice the largest deviation over the committed calibration (tests/golden/captured_atomic_calibration.json, made by
+    tools/calibrate_captured_atomic.py from >= 32 pairs of runs, eager against eager AND eager against captured; distribution in
+    profiles/r06_captured_atomic_calibration.txt)."""
+    cal = _calibration()
+    assert cal["pairs"] >= 32
+    same = lambda it, cams: cams  # noqa: E731
+    its = list(range(1, 9))
+    eager = _captured_run("eager", its, same, det=False)
+    cap = _captured_run("captured", its, same, det=False)
+    cs = cap["cs"]
+    assert cs.stats["recorded"] == 1 and cs.stats["replayed"] == 7 and cs.stats["missed"] == 0, cs.stats
+    assert eager["steps"] == cap["steps"] == [8.0] * len(eager["steps"])
+    m = captured_atomic_metrics(eager, cap)
+    for k, v in m.items():
+        assert v <= cal["bars"][k], (k, v, cal["bars"][k], m)
+    for (_p, _l, _r, _v, fc), (_p2, _l2, rc, _v2, _f2) in zip(cap["log"], cap["log"]):
+        assert torch.equal(fc, rc > 0)
 
 
 def test_captured_train_step_survives_a_miss():
     """The counts outgrow the capacities a graph was recorded with (every Gaussian grows by e^0.6 between two steps: R up ~2x): the
     replay's `valid` word comes back 0 and NOTHING was applied -- parameters, moments and step counts bit-identical to before the
-    replay -- the step is repeated eagerly, the graph re-recorded, and training goes on; the run equals an all-eager run that takes
-    the same jump.  (the forced-miss test.)"""
-    from csplat import train as tr
-    runs = {}
-    for mode in ("eager", "captured"):
-        pc, sim, mopt, cams, bg = _captured_fixture(seed=5)
-        log = []
-        for it in range(1, 9):
-            if it == 5:
-                with torch.no_grad():
-                    pc._scaling.add_(0.6)
-                if mode == "captured":      # what a replay that misses must leave untouched
-                    before = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
-                    cs = pc._captured_step
-                    key = cs._key(cams)
-                    st = cs.graphs[key]
-                    cs._fill(st, cams)
-                    st["graph"].replay()
-                    torch.cuda.synchronize()
-                    assert float(st["host"][1]) == 0.0, "the jump was meant to overflow the recorded capacities"
-                    for a, b in zip(before, list(pc.parameters()) + list(sim.parameters())):
-                        assert torch.equal(a, b)
-                    assert [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if pc.optimizer.state.get(p)] == [4.0] * 6
-                    assert int(pc.optimizer._cap["state"].item()) == 4
-            ps, loss, stats = tr.train_step(it, cams, pc, sim, mopt, background=bg, captured=(mode == "captured"))
-            log.append((float(ps), float(loss)))
-        torch.cuda.synchronize()
-        runs[mode] = (log, [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())], getattr(pc, "_captured_step", None))
-    cs = runs["captured"][2]
+    replay -- the step is repeated eagerly, the graph re-recorded, and training goes on; the run equals, bit for bit (reproducible mode), an
+    all-eager run that takes the same jump.  (the forced-miss test.)"""
+    def jump(it, pc, sim, cams, mode):
+        if it != 5:
+            return
+        with torch.no_grad():
+            pc._scaling.add_(0.6)
+        if mode == "captured":      # what a replay that misses must leave untouched
+            before = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
+            mom = _adam_state(pc.optimizer, pc.parameters())
+            cs = pc._captured_step
+            key = cs._key(cams)
+            st = cs.graphs[key]
+            cs._fill(st, cams)
+            st["graph"].replay()
+            torch.cuda.synchronize()
+            assert float(st["host"][1]) == 0.0, "the jump was meant to overflow the recorded capacities"
+            for a, b in zip(before, list(pc.parameters()) + list(sim.parameters())):
+                assert torch.equal(a, b)
+            for a, b in zip(mom, _adam_state(pc.optimizer, pc.parameters())):
+                assert torch.equal(a, b)
+            assert [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if pc.optimizer.state.get(p)] == [4.0] * 6
+            assert int(pc.optimizer._cap["state"].item()) == 4
+    same = lambda it, cams: cams  # noqa: E731
+    its = list(range(1, 9))
+    eager = _captured_run("eager", its, same, seed=5, before_step=jump)
+    cap = _captured_run("captured", its, same, seed=5, before_step=jump)
+    cs = cap["cs"]
     assert cs.stats["missed"] == 1 and cs.stats["recorded"] == 2, cs.stats
-    for (pe, le), (pc_, lc) in zip(runs["eager"][0], runs["captured"][0]):
-        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < 1e-4 * max(abs(le), 1e-3), (pe, pc_, le, lc)
-    for a, b in zip(runs["eager"][1], runs["captured"][1]):
-        d = (a - b).abs()
-        assert float((d > 1e-6 + 5e-3 * b.abs()).float().mean()) < 0.03, float(d.max())
-
-
-def _captured_run(mode, iterations, cams_of, seed=3, sh_at_max=False, before_step=None):
-    from csplat import train as tr
-    pc, sim, mopt, cams, bg = _captured_fixture(seed=seed)
-    if sh_at_max:
-        pc.active_sh_degree = pc.max_sh_degree
-    log = []
-    for it in iterations:
-        if before_step is not None:
-            before_step(it, pc, sim)
-        ps, loss, stats = tr.train_step(it, cams_of(it, cams), pc, sim, mopt, background=bg, captured=(mode == "captured"))
-        log.append((float(ps), float(loss)))
-    torch.cuda.synchronize()
-    params = [p.detach().clone() for p in list(pc.parameters()) + list(sim.parameters())]
-    steps = [float(pc.optimizer.state[p]["step"]) for p in pc.parameters() if pc.optimizer.state.get(p)] + \
-            [float(mopt.state[p]["step"]) for p in sim.parameters()]
-    dev_steps = None
-    if mode == "captured":
-        dev_steps = (int(pc.optimizer._cap["state"].item()), int(mopt._cap["state"].item()))
-    return log, params, steps, dev_steps, getattr(pc, "_captured_step", None)
-
-
-def _assert_runs_agree(a, b, loss_tol=5e-4):
-    for k_, ((pe, le), (pc_, lc)) in enumerate(zip(a[0], b[0])):
-        assert abs(pe - pc_) < 5e-3 and abs(le - lc) < (1e-5 if k_ == 0 else loss_tol) * max(abs(le), 1e-3), (k_, pe, pc_, le, lc)
-    for x, y in zip(a[1], b[1]):
-        d = (x - y).abs()
-        assert float((d > 1e-6 + 5e-3 * y.abs()).float().mean()) < 0.03, float(d.max())
+    _assert_runs_bit_equal(eager, cap)
 
 
 def test_captured_train_step_across_an_eager_iteration():
     """CapturedStep runs every `iteration % 1000 == 0` step through the eager train_step (the step that may raise the SH
     degree, train_utils.py:249-251).  With the degree already at its maximum the step shape -- and so the recorded graph -- survives that
     step; the eager step advances the optimizers' HOST step counters only, and the next replay used to read a stale device count (wrong
-    bias correction, then a sequence mismatch and RuntimeError).  Iterations 997..1004, captured against eager: same losses, same
-    parameters, host and device step counts equal at the end, the graph recorded once."""
+    bias correction, then a sequence mismatch and RuntimeError).  Iterations 997..1004, captured against eager in the reproducible mode:
+    bit-equal losses, parameters and moments, host and device step counts equal at the end, the graph recorded once."""
     its = list(range(997, 1005))
     same = lambda it, cams: cams  # noqa: E731
     eager = _captured_run("eager", its, same, sh_at_max=True)
     cap = _captured_run("captured", its, same, sh_at_max=True)
-    cs = cap[4]
+    cs = cap["cs"]
     # 997 eager (first of its shape), 998-999 record + replay, 1000 eager, 1001-1004 replays of the SAME graph
     assert cs.stats["recorded"] == 1 and cs.stats["eager"] == 2 and cs.stats["replayed"] == 6 and cs.stats["missed"] == 0, cs.stats
-    assert eager[2] == cap[2] == [8.0] * len(eager[2])
-    assert cap[3] == (8, 8)
-    _assert_runs_agree(eager, cap)
+    assert eager["steps"] == cap["steps"] == [8.0] * len(eager["steps"])
+    assert cap["dev_steps"] == (8, 8)
+    _assert_runs_bit_equal(eager, cap)
 
 
 def test_captured_train_step_alternating_step_shapes():
     """one graph per step SHAPE.  Recording a second shape used to re-allocate the optimizers' device-side step
     count and learning-rate table, leaving the first shape's graph with dangling pointers.  Three cameras and two cameras alternate
     (both shapes recorded, then each replayed after the other was recorded); the learning rate of one group changes mid-run (a
-    schedule editing param_groups, utils/general_utils.py:32-65 as used by gaussian_model.py:162-168): captured == eager."""
+    schedule editing param_groups, utils/general_utils.py:32-65 as used by gaussian_model.py:162-168): captured == eager, bit for bit."""
     its = list(range(1, 13))
     pick = lambda it, cams: cams if (it // 2) % 2 == 0 else cams[:2]  # noqa: E731
 
-    def sched(it, pc, sim):
+    def sched(it, pc, sim, cams, mode):
         if it == 9:
             for g in pc.optimizer.param_groups:
                 g["lr"] = g["lr"] * 0.5
     eager = _captured_run("eager", its, pick, seed=7, before_step=sched)
     cap = _captured_run("captured", its, pick, seed=7, before_step=sched)
-    cs = cap[4]
+    cs = cap["cs"]
     assert cs.stats["recorded"] == 2 and cs.stats["missed"] == 0 and cs.stats["replayed"] >= 8, cs.stats
-    assert eager[2] == cap[2] == [12.0] * len(eager[2])
-    assert cap[3] == (12, 12)
-    _assert_runs_agree(eager, cap)
+    assert eager["steps"] == cap["steps"] == [12.0] * len(eager["steps"])
+    assert cap["dev_steps"] == (12, 12)
+    _assert_runs_bit_equal(eager, cap)
 
 
 def test_captured_train_step_rerecords_after_a_scratch_eviction():
     """a failed entry point (csplat.native.check) or an overflowing cache drops the "zeroed once" scratch buffers the
     recorded graphs point into.  The eviction bumps csplat.native.SCRATCH_EPOCH; CapturedStep must not replay a graph recorded under an
-    older epoch -- it records again -- and the run still equals the eager run."""
+    older epoch -- it records again -- and the run still equals the eager run.  Run in the DEFAULT mode as well as the reproducible one: the
+    persistent zeroed records (the cache the eviction drops) exist only in the default mode."""
     from csplat import native
     its = list(range(1, 9))
     same = lambda it, cams: cams  # noqa: E731
 
-    def evict(it, pc, sim):
+    def evict(it, pc, sim, cams, mode):
         if it == 5 and getattr(pc, "_captured_step", None) is not None:
             native.evict_scratch()
     eager = _captured_run("eager", its, same, seed=11)
     cap = _captured_run("captured", its, same, seed=11, before_step=evict)
-    cs = cap[4]
+    cs = cap["cs"]
     assert cs.stats["recorded"] == 2 and cs.stats.get("rerecorded_stale") == 1 and cs.stats["missed"] == 0, cs.stats
-    _assert_runs_agree(eager, cap)
+    _assert_runs_bit_equal(eager, cap)
+    # default mode: the recording really points into the evicted cache; bars from the committed calibration
+    cal = _calibration()
+    eager = _captured_run("eager", its, same, seed=11, det=False)
+    cap = _captured_run("captured", its, same, seed=11, before_step=evict, det=False)
+    cs = cap["cs"]
+    assert cs.stats["recorded"] == 2 and cs.stats.get("rerecorded_stale") == 1 and cs.stats["missed"] == 0, cs.stats
+    m = captured_atomic_metrics(eager, cap)
+    for k, v in m.items():
+        assert v <= cal["bars"][k], (k, v, cal["bars"][k], m)
