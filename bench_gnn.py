@@ -99,9 +99,17 @@ def run(args, dev=None, train=None):
 
     def roll():
         return rollout(sim, pos0, hist, ntype, ei, actions, 0, nroll)
+    from meshnet import rollout as ro
+    from meshnet.graph_network import deferred_overflow_check
     with torch.no_grad():
-        ms_loop = timeit(roll, max(args.steps // 10, 2), 1) / nroll          # ms per rollout step, whole loop
-        ms_roll = timeit(lambda: sim.predict_velocity(vel, ntype, ei, ef), args.steps, args.warmup)
+        ms_loop = timeit(roll, max(args.steps // 10, 2), 1) / nroll          # ms per rollout step, whole loop (step 1 recorded, 18 replays)
+        roll_stats = dict(ro.ROLLOUT_STATS)
+        ms_loop_eager = timeit(lambda: rollout(sim, pos0, hist, ntype, ei, actions, 0, nroll, graph=False), 2, 1) / nroll
+        # (predict_velocity reads its overflow word per call -- one host synchronisation; a loop of calls defers the reads, as rollout() does)
+        with deferred_overflow_check() as chk:
+            ms_roll = timeit(lambda: sim.predict_velocity(vel, ntype, ei, ef), args.steps, args.warmup)
+            overflowed = chk.overflowed()
+        ms_roll_sync = timeit(lambda: sim.predict_velocity(vel, ntype, ei, ef), args.steps, args.warmup)
         a = net(feats, ei, ef)
         ms_pyg = rel = None
         if train:
@@ -128,16 +136,31 @@ def run(args, dev=None, train=None):
         ms_train_pyg = timeit(lambda: train_step(lambda: pyg_like_forward(net, feats, ei, ef)), args.steps, args.warmup)
 
     L, M = 128, 15
-    alg = (16 * E + 12 * N) * L * M          # bytes of gather/scatter traffic per rollout step
+    alg = (16 * E + 12 * N) * L * M          # bytes of gather/scatter traffic per rollout step (the UNFUSED formulation's traffic)
+    # what binds the fused layer kernels is the matrix pipe, not HBM: per layer the edge launch multiplies 3 Linears x
+    # 2*128*128 x E in three fp16 piece-products, the node launch 6 matrices x 2*128*128 x N likewise
+    piece_flop = M * 3 * 2 * 128 * 128 * (3 * E + 6 * N)
+    MFMA_F16_DENSE = 2.5e15                  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
+    # measured HBM bytes of the two layer launches (profiles/r05b_edge_mlp3_traffic.txt: FETCH_SIZE / WRITE_SIZE per edge launch at this
+    # size, XCD-aware tile ranges: 182.0 MB read + 22.9 MB written; node launch: pieces in, three [N,128] out + x in = ~50 MB)
+    hbm_bytes_step = M * (182.0e6 + 22.9e6 + 50.0e6) if (N, E) == (10_000, 300_000) else None
     r3 = lambda v: None if v is None else round(v, 3)  # noqa: E731
     out = {"metric": "MeshNet rollout step ms (N=10k, E=300k, L=128, M=15)", "value": round(ms_loop, 3), "unit": "ms",
            "higher_is_better": False, "dtype": "f32", "data": "synthetic",
            "rollout_loop_ms_per_step": round(ms_loop, 3), "rollout_loop_steps": nroll,
-           "rollout_ms": round(ms_roll, 3), "pyg_like_torch_rollout_ms": r3(ms_pyg),
+           "rollout_loop_eager_ms_per_step": round(ms_loop_eager, 3), "rollout_recording": roll_stats,
+           "rollout_ms": round(ms_roll, 3), "rollout_ms_with_per_call_overflow_read": round(ms_roll_sync, 3), "overflowed": bool(overflowed),
+           "pyg_like_torch_rollout_ms": r3(ms_pyg),
            "train_step_ms": r3(ms_train), "pyg_like_torch_train_step_ms": r3(ms_train_pyg),
            "hip_vs_pyg_like_rel_diff": rel,
            # algorithmic gather / scatter bytes of one rollout step over the step's time, against the 8 TB/s HBM peak
-           "algorithmic_GBps": round(alg / (ms_loop * 1e-3) / 1e9, 1), "frac": round(alg / (ms_loop * 1e-3) / 1e9 / 8000.0, 4),
+           "algorithmic_GBps": round(alg / (ms_loop * 1e-3) / 1e9, 1),
+           # (NOT a utilisation: the unfused formulation's bytes over the fused kernels' time -- kept for continuity with rounds 1-5)
+           "unfused_bytes_frac": round(alg / (ms_loop * 1e-3) / 1e9 / 8000.0, 4),
+           "mfma_frac": round(piece_flop / (ms_loop * 1e-3) / MFMA_F16_DENSE, 4), "piece_product_flop_per_step": piece_flop,
+           "hbm_GBps": None if hbm_bytes_step is None else round(hbm_bytes_step / (ms_loop * 1e-3) / 1e9, 1),
+           "hbm_frac": None if hbm_bytes_step is None else round(hbm_bytes_step / (ms_loop * 1e-3) / 1e9 / 8000.0, 4),
+           "hbm_bytes_per_step_from": "profiles/r05b_edge_mlp3_traffic.txt (PMC FETCH_SIZE / WRITE_SIZE of the edge launch) + the node launch's rows",
            "gnn_kernels": {"launches_per_step": int(gnn_n), "total_ms_per_step": round(gnn_ms, 3),
                            "algorithmic_GBps": round(alg / (gnn_ms * 1e-3) / 1e9, 1) if gnn_ms > 0 else None,
                            "algorithmic_bytes_per_step": alg},

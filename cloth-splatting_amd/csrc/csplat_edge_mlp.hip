@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void k_edge_mlp3r(int64_t M, const float *__re
         const float m = e0_absmax ? *e0_absmax : 1.f;
         int ex = 0;
         if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);      // m = f 2^ex, f in [0.5, 1)
+        // (a tiny or denormal max |e0| would make 2^(4 - ex) overflow to Inf and the whole launch NaN -- ADVICE r5; below 2^-96 the rows
+        //  are left smaller than [8, 16): what they contribute next to the node-level terms is below fp32 rounding anyway)
+        ex = ex < -96 ? -96 : (ex > 100 ? 100 : ex);
         cs = ldexpf(1.f, 4 - ex);
     }
     const float inv_alpha = cs / alpha;       // (a power of two: every product with it is exact)
@@ -1032,7 +1035,6 @@ extern "C" int csplat_gnn_mlp3_rows(void *stream, int64_t M, const float *x, int
     if (M == 0) return 0;
     const uintptr_t al = (uintptr_t)x | (uintptr_t)image | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)out;
     CSPLAT_REQUIRE((al & 15u) == 0, "csplat_gnn_mlp3_rows: operands must be 16-byte aligned");
-    CSPLAT_REQUIRE(M <= ((int64_t)1 << 22), "csplat_gnn_mlp3_rows: at most 2^22 rows per call");
     static int s_ok = -1;
     if (s_ok < 0) {
         s_ok = hipFuncSetAttribute((const void *)k_edge_mlp3r<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ErCfg<true>::LDS_BYTES) == hipSuccess;
@@ -1041,10 +1043,16 @@ extern "C" int csplat_gnn_mlp3_rows(void *stream, int64_t M, const float *x, int
     CSPLAT_REQUIRE(s_ok, "csplat_gnn_mlp3_rows: 141 KB of dynamic LDS refused by the runtime");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_GNN, s);
-    const int64_t nst = (M + 63) / 64;
-    k_edge_mlp3r<true, 2><<<(int)(nst < 256 ? nst : 256), 256, ErCfg<true>::LDS_BYTES, s>>>(M, x, 1.0f, x_absmax, nullptr, nullptr, nullptr, nullptr, (const i32x4 *)image,
-                                                                                           b0, b1, b2, ln_gamma, ln_beta, ln_eps, out, nullptr, nullptr, K,
-                                                                                           csplat_stamp_buffer((size_t)256 * 64));
-    LAUNCH_CHECK();
+    // (32-bit buffer offsets inside the kernel: 2^22 rows of 128 floats per launch, as csplat_gnn_edge_mlp3 -- longer inputs go out in chunks)
+    const int64_t CHUNK = (int64_t)1 << 22;
+    for (int64_t r0 = 0; r0 < M; r0 += CHUNK) {
+        const int64_t rows = M - r0 < CHUNK ? M - r0 : CHUNK;
+        const int64_t nst = (rows + 63) / 64;
+        k_edge_mlp3r<true, 2><<<(int)(nst < 256 ? nst : 256), 256, ErCfg<true>::LDS_BYTES, s>>>(rows, x + r0 * K, 1.0f, x_absmax, nullptr, nullptr, nullptr, nullptr,
+                                                                                               (const i32x4 *)image, b0, b1, b2, ln_gamma, ln_beta, ln_eps,
+                                                                                               out + r0 * EM_N, nullptr, nullptr, K,
+                                                                                               csplat_stamp_buffer((size_t)256 * 64));
+        LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -141,6 +141,34 @@ EDGE_AGG_FUSED = os.environ.get("CSPLAT_GNN_EDGE_AGG", "1") not in ("", "0")
 NODE_UPDATE_PACKED = os.environ.get("CSPLAT_GNN_NODE_PACKED", "1") not in ("", "0")
 
 
+# deferred_overflow_check(): a stack of lists collecting (module, device flag) per EncodeProcessDecode call instead of reading the flag
+_OVERFLOW_COLLECT = []
+
+
+class deferred_overflow_check:
+    """`with deferred_overflow_check() as chk:` -- EncodeProcessDecode calls inside the scope do not read their overflow word (no host
+    read per call); `chk.overflowed()` reads them all at once (ONE synchronisation) and latches the modules concerned to bf16 pieces."""
+
+    def __enter__(self):
+        self.items = []
+        _OVERFLOW_COLLECT.append(self.items)
+        return self
+
+    def __exit__(self, *exc):
+        _OVERFLOW_COLLECT.remove(self.items)
+        return False
+
+    def overflowed(self) -> bool:
+        if not self.items:
+            return False
+        fine = torch.stack([b for _m, b in self.items]).cpu().tolist()
+        mods = {id(m): m for (m, _b), f in zip(self.items, fine) if not f}
+        for m in mods.values():
+            m.latch_bf16()
+        self.items.clear()
+        return bool(mods)
+
+
 def _is_pow2(v: float) -> bool:
     import math
     return v > 0 and math.frexp(v)[0] == 0.5
@@ -204,8 +232,10 @@ class InteractionNetwork(nn.Module):
 
     def inference_ok(self, x, edge_features) -> bool:
         n = self._nnode_in
+        # (the one-launch kernels gather node rows through 32-bit byte offsets: index * 512 < 2^32 -- graphs beyond 2^23 nodes take the
+        #  composed path)
         return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and \
-            edge_features.dtype == torch.float32 and n == 128 and self._nedge_in == 128 and \
+            edge_features.dtype == torch.float32 and n == 128 and self._nedge_in == 128 and x.shape[0] < (1 << 23) and \
             _fusable(self.edge_fn) and _fusable(self.node_fn)
 
     def _split_weights(self):
@@ -302,8 +332,10 @@ class Processor(nn.Module):
     def takes_destination_order(self, x: torch.Tensor, edge_features: torch.Tensor) -> bool:
         """whether forward() will run the one-launch edge MLP with its fused aggregation on these inputs -- the path that wants the edge
         latents in destination order (GraphCSR.agg_plan) and can be handed them that way (dst_order=)"""
+        # (piece rows are addressed as index * 512 in 32 bits: E / 8 + N pieces must stay below 2^22 -- larger graphs write message rows)
         return bool(len(self.gnn_stacks)) and all(g.inference_ok(x, edge_features) for g in self.gnn_stacks) and EDGE_MLP_FUSED and \
             EDGE_AGG_FUSED and edge_mlp3_mode() == 0 and edge_features.numel() > 0 and \
+            edge_features.shape[0] // 8 + x.shape[0] + 8 < (1 << 22) and \
             all(len(list(g.edge_fn[0].children())[0::2]) == 3 for g in self.gnn_stacks)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor, edges_out: bool = True, dst_order=None):
@@ -388,6 +420,48 @@ class EncodeProcessDecode(nn.Module):
         return self._elb
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
+        """The rollout's default arithmetic multiplies with two fp16 pieces per operand (edge_mlp3_mode 0), whose exponent range a trained
+        checkpoint with large hidden activations can leave; every ReLU of those kernels lets a NaN through, so an overflow ANYWHERE reaches
+        the decoder's output as non-finite rows -- never as finite garbage (csplat_edge_mlp.hip: relu_nan).  Round 6: that is detected
+        (one device word per call) and the call is repeated with three bf16 pieces (fp32's exponent range), which this module then keeps
+        (`_bf16_latched`, logged once): the reference's fp32 path has no such failure, and neither has the drop-in.  Inside
+        `deferred_overflow_check()` (meshnet.rollout.rollout) the word is collected instead of read, so that the loop stays free of
+        host reads; the rollout is repeated from its start when a step overflowed."""
+        if torch.is_grad_enabled() or not x.is_cuda:
+            return self._forward(x, edge_index, edge_features)
+        if getattr(self, "_bf16_latched", False) and edge_mlp3_mode() == 0:
+            was = edge_mlp3_mode(1)
+            try:
+                return self._forward(x, edge_index, edge_features)
+            finally:
+                edge_mlp3_mode(was)
+        out = self._forward(x, edge_index, edge_features)
+        if edge_mlp3_mode() != 0 or not (EDGE_MLP_FUSED or NODE_UPDATE_PACKED or ENCODER_FUSED):
+            return out
+        ok = torch.isfinite(out).all()              # (two small launches on [N, out]; read here, or collected and read once per rollout)
+        if _OVERFLOW_COLLECT:
+            _OVERFLOW_COLLECT[-1].append((self, ok))
+            return out
+        if not bool(ok):
+            was = edge_mlp3_mode(1)
+            try:
+                again = self._forward(x, edge_index, edge_features)
+            finally:
+                edge_mlp3_mode(was)
+            if bool(torch.isfinite(again).all()):      # (non-finite under fp32's exponent range too: the INPUT was -- nothing to latch)
+                self.latch_bf16()
+            return again
+        return out
+
+    def latch_bf16(self):
+        """from now on this module's inference runs with three bf16 pieces (csplat_gnn_edge_mlp3_mode 1)"""
+        if not getattr(self, "_bf16_latched", False):
+            import warnings
+            warnings.warn("meshnet.graph_network.EncodeProcessDecode: an activation left fp16's range under the two-piece fp16 arithmetic "
+                          "(non-finite output rows); this module now runs with three bf16 pieces (csplat_gnn_edge_mlp3_mode 1)")
+        self._bf16_latched = True
+
+    def _forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor):
         if not torch.is_grad_enabled() and EDGE_MLP_FUSED and EDGE_AGG_FUSED and edge_mlp3_mode() == 0 and edge_features.is_cuda and \
                 edge_features.dim() == 2 and edge_features.shape[0] > 0 and edge_features.dtype == torch.float32 and x.dtype == torch.float32 and \
                 isinstance(self._encoder.edge_fn[1], nn.LayerNorm) and self._encoder.edge_fn[1].elementwise_affine and \

@@ -1103,11 +1103,47 @@ def gen_losses():
     np.savez_compressed(os.path.join(OUT, "losses.npz"), **{k: npy(v) for k, v in out.items()})
 
 
+def gen_refine():
+    """The `real_world` branch of the reference's rollout (train_meshnet_sim.py:212-250): the text of the branch's body is exec'd as it
+    stands (ten iterations of a fresh Adam on the predicted velocities against the squared edge-length deviation, the
+    `length_deviation[grasped_particle] *= 0` line included) on a small triangulated patch.  Stored: inputs and the refined velocities."""
+    import torch.optim as optim
+    lines = open(os.path.join(REF, "train_meshnet_sim.py")).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.strip() == "if real_world:")
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("predictions.append(predicted_next_velocity)"))
+    body = "if True:\n" + "\n".join(lines[start + 1:end])        # (the branch's body as it stands, under a stand-in for `if real_world:`)
+    g = torch.Generator().manual_seed(2125)
+    out = {}
+    for name, (gx, gy, amp) in {"a": (9, 7, 0.02), "b": (14, 11, 0.05)}.items():
+        ys, xs = torch.meshgrid(torch.arange(gy, dtype=torch.float32), torch.arange(gx, dtype=torch.float32), indexing="ij")
+        rest = torch.stack([xs.reshape(-1) * 0.05, ys.reshape(-1) * 0.05, torch.zeros(gx * gy)], 1)
+        idx = lambda x, y: y * gx + x  # noqa: E731
+        e = []
+        for y in range(gy):
+            for x in range(gx):
+                for dx, dy in ((1, 0), (0, 1), (1, 1)):
+                    if x + dx < gx and y + dy < gy:
+                        e += [(idx(x, y), idx(x + dx, y + dy)), (idx(x + dx, y + dy), idx(x, y))]
+        edge_index = torch.tensor(e, dtype=torch.long).t().contiguous()
+        edge_index = edge_index[:, torch.randperm(edge_index.shape[1], generator=g)]
+        original_edge_lengths = torch.norm(rest[edge_index.T[:, 1]] - rest[edge_index.T[:, 0]], dim=1)       # (:114-116)
+        current_node_coords = rest + amp * torch.randn(rest.shape, generator=g)
+        v = amp * torch.randn(rest.shape, generator=g)
+        grasped = 5 if name == "a" else 37
+        action = torch.tensor([[0.01, -0.02, 0.03]])
+        ns = dict(torch=torch, optim=optim, predicted_next_velocity=v.clone(), current_node_coords=current_node_coords.clone(),
+                  edge_index=edge_index, original_edge_lengths=original_edge_lengths, grasped_particle=grasped, current_action=action)
+        exec(compile(body, "<train_meshnet_sim.real_world>", "exec"), ns)
+        out.update({f"{name}.pos": current_node_coords, f"{name}.v": v, f"{name}.edge_index": edge_index, f"{name}.rest_len": original_edge_lengths,
+                    f"{name}.grasped": torch.tensor(grasped), f"{name}.action": action, f"{name}.v_refined": ns["predicted_next_velocity"]})
+    np.savez_compressed(os.path.join(OUT, "refine.npz"), **{k: npy(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be generated where /root/reference exists"
     only = sys.argv[1:]          # e.g. `python make_golden.py simulator`: regenerate the named fixtures only
     for name in ("camera", "sh", "misc", "normalizer", "gnn", "simulator", "densify", "scene_io", "meshsim", "mesh_transform", "losses",
-                 "render_wiring", "gnn128", "vertice_rotation", "sim128"):
+                 "render_wiring", "gnn128", "vertice_rotation", "sim128", "refine"):
         if not only or name in only:
             globals()["gen_" + name]()
     for f in sorted(os.listdir(OUT)):

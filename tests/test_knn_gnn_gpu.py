@@ -629,6 +629,64 @@ def test_edge_features_kernel_and_rollout_loop():
     assert torch.equal(preds[:, 7], actions)
 
 
+def test_real_world_edge_length_refinement_kernel_and_rollout():
+    """csplat_gnn_edge_length_refine (one launch per Adam iteration, node-centric, no autograd) against the reference's own `real_world`
+    branch (train_meshnet_sim.py:212-250, its text exec'd by tests/golden/make_golden.py: refine.npz) and against the same optimisation in
+    fp64; then meshnet.rollout.rollout(real_world=True) against the loop written out in plain torch with the host form of the refinement
+    (which tests/test_oracle_cpu.py holds to the same fixture).  Degenerate inputs: a zero-length edge, a self loop, an isolated node."""
+    from meshnet.cloth_network import ClothMeshSimulator
+    from meshnet.rollout import refine_edge_lengths, rollout
+    dev = "cuda"
+    d = util.golden("refine.npz")
+    for name in ("a", "b"):
+        t = lambda k: torch.from_numpy(d[f"{name}.{k}"])  # noqa: E731
+        grasped = int(d[f"{name}.grasped"])
+        v = refine_edge_lengths(t("pos").to(dev), t("v").to(dev), t("edge_index").to(dev), t("rest_len").to(dev), grasped)
+        again = refine_edge_lengths(t("pos").to(dev), t("v").to(dev), t("edge_index").to(dev), t("rest_len").to(dev), grasped)
+        assert torch.equal(v, again)                                  # no atomics: the same bits
+        v[grasped] = t("action").to(dev)
+        ref = t("v_refined")
+        assert float((v.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), name
+        v64 = refine_edge_lengths(t("pos").double(), t("v").double(), t("edge_index"), t("rest_len").double(), grasped)
+        v64[grasped] = t("action").double()
+        assert float((v.cpu().double() - v64).abs().max()) <= 2e-6 * float(v64.abs().max()), name
+    # degenerate edges: (3 -> 3) self loop, an edge whose ends coincide (len 0: torch.norm's backward is 0 there), node 9 isolated
+    g = torch.Generator().manual_seed(5)
+    N = 10
+    pos = torch.randn(N, 3, generator=g) * 0.1
+    pos[6] = pos[5]
+    v0 = torch.zeros(N, 3)
+    ei = torch.tensor([[0, 1, 3, 5, 2, 4, 7, 8], [1, 2, 3, 6, 0, 7, 8, 4]])
+    rl = torch.rand(ei.shape[1], generator=g) * 0.1
+    out = refine_edge_lengths(pos.to(dev), v0.to(dev), ei.to(dev), rl.to(dev), None)
+    ref = refine_edge_lengths(pos.double(), v0.double(), ei, rl.double(), None)
+    assert torch.isfinite(out).all() and float((out.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(out[9].abs().max()) == 0.0
+    # the rollout loop with real_world=True
+    N, E = 300, 2100
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+    torch.manual_seed(3)
+    sim = ClothMeshSimulator(3, 8, 4, 128, 2, 2, 128, 2, 2, normalize=False, device=dev).eval()
+    hist = (torch.randn(2, N, 3, generator=g) * 0.01).to(dev)
+    ntype = torch.randint(0, 2, (N, 1), generator=g).to(dev)
+    actions = (torch.randn(3, 3, generator=g) * 0.01).to(dev)
+    preds, pos_end = rollout(sim, pos, hist, ntype, ei, actions, 7, 3, real_world=True)
+    L0 = torch.norm(pos[ei[1]] - pos[ei[0]], dim=1)
+    with torch.no_grad():
+        p, h, outs = pos.clone(), hist.clone(), []
+        for step in range(3):
+            dd = p[ei[0]] - p[ei[1]]
+            feats = torch.cat([dd, dd.norm(dim=1, keepdim=True)], 1)
+            v = sim.predict_velocity(torch.cat([h[0], h[1]], 1), ntype, ei, feats)
+            v = refine_edge_lengths(p.cpu().double(), v.cpu().double(), ei.cpu(), L0.cpu().double(), 7).float().to(dev)
+            v[7] = actions[step]
+            outs.append(v); p = p + v
+            h = torch.stack([h[1], v])
+    assert rel_err(preds.cpu().numpy(), torch.stack(outs).cpu().numpy()) < 1e-4
+    assert rel_err(pos_end.cpu().numpy(), p.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_linear128_wide_dynamic_range_rows(mode):
     """the 3-way bf16 split (default) reconstructs fp32 operands to 24 bits, but its three pieces share ONE exponent range per
@@ -1090,3 +1148,120 @@ def test_rollout_with_and_without_the_fused_edge_mlp():
     finally:
         gn.EDGE_MLP_FUSED = was
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
+
+
+def test_fp16_piece_overflow_is_detected_and_the_call_repeated_with_bf16_pieces():
+    """VERDICT r5 item 7 / ADVICE r5: a network whose hidden activations leave fp16's range (a processor edge weight scaled by 1e6) used to
+    return NaN rows from the default rollout arithmetic where the reference's fp32 path returns numbers.  EncodeProcessDecode now notices
+    (one device word per call), repeats the call with three bf16 pieces and keeps that mode for the module; meshnet.rollout.rollout
+    collects the words, reads them once behind its loop and repeats the rollout.  Results against the fp64 oracle of the same network."""
+    import warnings
+    from meshnet.graph_network import EncodeProcessDecode
+    from meshnet.graph_ops import edge_mlp3_mode
+    from oracle import gnn_ref
+    gen = torch.Generator().manual_seed(21)
+    N, E = 500, 6000
+    torch.manual_seed(8)
+    net = EncodeProcessDecode(8, 3, 4, 128, 2, 2, 128).cuda().eval()
+    with torch.no_grad():
+        net._processor.gnn_stacks[0].edge_fn[0][0].weight.mul_(1e6)
+    x = torch.randn(N, 8, generator=gen).cuda()
+    ei = torch.stack([torch.randint(0, N, (E,), generator=gen), torch.randint(0, N, (E,), generator=gen)]).cuda()
+    ef = torch.randn(E, 4, generator=gen).cuda()
+    assert edge_mlp3_mode() == 0
+    with torch.no_grad():
+        raw = net._forward(x, ei, ef)                                  # the plain fp16-piece path: the overflow is visible
+        assert not torch.isfinite(raw).all()
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            out = net(x, ei, ef)
+        assert any("bf16" in str(w.message) for w in wlist)
+        assert net._bf16_latched and edge_mlp3_mode() == 0             # the library-wide mode is restored, the MODULE keeps bf16
+        out2 = net(x, ei, ef)
+    p_ = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    ref = gnn_ref.encode_process_decode(p_, x.cpu().numpy(), ei.cpu().numpy(), ef.cpu().numpy())
+    assert torch.isfinite(out).all() and rel_err(out.cpu().numpy(), ref) < 1e-4
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("real_world", [False, True])
+def test_recorded_rollout_equals_the_launch_by_launch_loop(real_world):
+    """meshnet.rollout.rollout with its step recorded into a hipGraph (step 0 eager, step 1 recorded, the rest replays) against the same
+    loop launched kernel by kernel (graph=False): predictions and final positions BIT-equal -- a replay is the same launches on the same
+    buffers.  Latent 128 (the one-launch edge MLP / node update kernels) on a 2,000-node graph, with and without the real_world
+    refinement.  Reference loop: train_meshnet_sim.py:126-265."""
+    from meshnet import rollout as ro
+    from meshnet.cloth_network import ClothMeshSimulator
+    dev = "cuda"
+    g = torch.Generator().manual_seed(31)
+    N, E = 2000, 24_000
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)]).to(dev)
+    torch.manual_seed(4)
+    sim = ClothMeshSimulator(3, 8, 4, 128, 3, 2, 128, 2, 2, normalize=False, device=dev).eval()
+    hist = (torch.randn(2, N, 3, generator=g) * 0.01).to(dev)
+    ntype = torch.randint(0, 2, (N, 1), generator=g).to(dev)
+    actions = (torch.randn(7, 3, generator=g) * 0.01).to(dev)
+    before = dict(ro.ROLLOUT_STATS)
+    a_pred, a_pos = ro.rollout(sim, pos, hist, ntype, ei, actions, 11, 7, real_world=real_world, graph=True)
+    after = dict(ro.ROLLOUT_STATS)
+    assert after["recorded"] == before["recorded"] + 1 and after["replayed_steps"] == before["replayed_steps"] + 6 and \
+        after["record_failed"] == before["record_failed"], (before, after)
+    b_pred, b_pos = ro.rollout(sim, pos, hist, ntype, ei, actions, 11, 7, real_world=real_world, graph=False)
+    assert torch.isfinite(a_pred).all()
+    assert torch.equal(a_pred, b_pred) and torch.equal(a_pos, b_pos)
+    assert torch.equal(a_pred[:, 11], actions)
+    # a second rollout of the same combination, from another state: all seven steps are replays of the kept recording
+    pos2, hist2 = pos + 0.01, hist * 0.5
+    c_pred, c_pos = ro.rollout(sim, pos2, hist2, ntype, ei, actions, 11, 7, real_world=real_world, graph=True)
+    again = dict(ro.ROLLOUT_STATS)
+    assert again["recorded"] == after["recorded"] and again["replayed_steps"] == after["replayed_steps"] + 7
+    d_pred, d_pos = ro.rollout(sim, pos2, hist2, ntype, ei, actions, 11, 7, real_world=real_world, graph=False)
+    assert torch.equal(c_pred, d_pred) and torch.equal(c_pos, d_pos)
+    # a weight changes: the recording is not replayed (its packed weight images are stale) -- recorded again
+    with torch.no_grad():
+        sim._encode_process_decode._decoder.node_fn[0].weight.mul_(1.01)
+    e_pred, _ = ro.rollout(sim, pos, hist, ntype, ei, actions, 11, 7, real_world=real_world, graph=True)
+    assert ro.ROLLOUT_STATS["recorded"] == again["recorded"] + 1
+    f_pred, _ = ro.rollout(sim, pos, hist, ntype, ei, actions, 11, 7, real_world=real_world, graph=False)
+    assert torch.equal(e_pred, f_pred) and not torch.equal(e_pred, a_pred)
+
+
+def test_rollout_repeats_with_bf16_pieces_after_an_overflow():
+    """a rollout whose network leaves fp16's range at some step: the per-call overflow words are collected without a host read, read once
+    behind the loop, and the rollout is repeated from its start with three bf16 pieces -- finite results equal to the launch-by-launch
+    loop under csplat_gnn_edge_mlp3_mode(1)."""
+    import warnings
+    from meshnet import rollout as ro
+    from meshnet.cloth_network import ClothMeshSimulator
+    from meshnet.graph_ops import edge_mlp3_mode
+    dev = "cuda"
+    g = torch.Generator().manual_seed(33)
+    N, E = 1500, 18_000
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)]).to(dev)
+    hist = (torch.randn(2, N, 3, generator=g) * 0.01).to(dev)
+    ntype = torch.randint(0, 2, (N, 1), generator=g).to(dev)
+    actions = (torch.randn(5, 3, generator=g) * 0.01).to(dev)
+
+    def build():
+        torch.manual_seed(6)
+        sim = ClothMeshSimulator(3, 8, 4, 128, 2, 2, 128, 2, 2, normalize=False, device=dev).eval()
+        with torch.no_grad():
+            sim._encode_process_decode._processor.gnn_stacks[1].edge_fn[0][0].weight.mul_(1e6)
+            sim._encode_process_decode._decoder.node_fn[-2].weight.mul_(1e-3)      # (keep the velocities small: the state must stay finite)
+        return sim
+    sim = build()
+    before = dict(ro.ROLLOUT_STATS)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        pred, pos_end = ro.rollout(sim, pos, hist, ntype, ei, actions, 3, 5)
+    assert ro.ROLLOUT_STATS["repeated_bf16"] == before["repeated_bf16"] + 1
+    assert torch.isfinite(pred).all() and torch.isfinite(pos_end).all() and sim._encode_process_decode._bf16_latched
+    ref_sim = build()
+    was = edge_mlp3_mode(1)
+    try:
+        ref_pred, ref_pos = ro.rollout(ref_sim, pos, hist, ntype, ei, actions, 3, 5, graph=False)
+    finally:
+        edge_mlp3_mode(was)
+    assert torch.equal(pred, ref_pred) and torch.equal(pos_end, ref_pos)

@@ -967,3 +967,19 @@ def test_piece_numbering_of_the_fused_aggregation(E, N):
     per_node = torch.stack([pieces[int(pp[v]):int(pp[v + 1])].sum(0) for v in range(N)])
     ref = torch.zeros(N, 3, dtype=torch.float64).index_add_(0, dst, vals)
     assert torch.allclose(per_node, ref, atol=1e-12)
+
+
+def test_rollout_real_world_refinement_host_form_replays_the_reference():
+    """meshnet.rollout.refine_edge_lengths on CPU tensors (the host form: torch autograd + a fresh Adam, ten iterations) against the
+    reference's own `real_world` branch (train_meshnet_sim.py:212-250, its text exec'd by tests/golden/make_golden.py: refine.npz),
+    including the `length_deviation[grasped_particle] *= 0` entry; the grasped node is pinned afterwards as the rollout does."""
+    import torch
+    from meshnet.rollout import refine_edge_lengths
+    d = util.golden("refine.npz")
+    for name in ("a", "b"):
+        t = lambda k: torch.from_numpy(d[f"{name}.{k}"])  # noqa: E731
+        grasped = int(d[f"{name}.grasped"])
+        v = refine_edge_lengths(t("pos"), t("v"), t("edge_index"), t("rest_len"), grasped)
+        v[grasped] = t("action")
+        ref = t("v_refined")
+        assert float((v - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), name
