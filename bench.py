@@ -72,6 +72,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every step kernel by kernel instead of replaying recorded hipGraphs")
     ap.add_argument("--no-speculation", action="store_true",
                     help="skip the auxiliary 40-step pass with changing P / sizes (counter passes: every launch of a kernel then has the same size)")
+    ap.add_argument("--exchange", choices=("auto", "oneshot", "direct", "sliced"), default="auto",
+                    help="N > 1: how the step's gradients are summed over the ranks -- oneshot: one RCCL all-reduce of the flat buffer behind "
+                         "the step; direct: the same message as all-to-all reduce-scatter + all-gather (full-mesh xGMI); sliced: K8 cut into "
+                         "--slices Gaussian ranges, each range's rows leave while the next computes; auto (default): all are timed on this "
+                         "node before the timed region and the fastest is used")
+    ap.add_argument("--slices", type=int, default=4)
     ap.add_argument("--mode", choices=("views", "scenes"), default="views",
                     help="views: view-parallel weak scaling (default, the BASELINE metric); scenes: 6 scene variants dealt over the ranks")
     args = ap.parse_args()
@@ -114,6 +120,7 @@ def main():
     from csplat import dist as cd
     from csplat.train import l1_loss, step_stats
     from diff_gaussian_rasterization import rasterize_views
+    import diff_gaussian_rasterization as dgr_
     T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)  # noqa: E731
 
     class Workload:
@@ -156,7 +163,9 @@ def main():
             """the step's gradient tensors: the five parameters' and the per-view screen-space ones"""
             return {**{k: self.params[k].grad for k in self.names}, **{f"means2D[{i}]": m.grad for i, m in enumerate(self.m2ds)}}
 
-        def step(self, timed_allreduce=False, skip_allreduce=False):
+        def step(self, timed_allreduce=False, skip_allreduce=False, defer=None):
+            """defer: a diff_gaussian_rasterization.DeferredK8 -- the backward launches K7 only; finish_sliced() launches the K8 slices, each
+            followed by the exchange of its gradient rows, then the statistics"""
             pr = self.params
             if self.fg is not None:
                 self.fg.bind()
@@ -181,10 +190,17 @@ def main():
                 self.radii = [o_[1] for o_ in outs]
                 loss = torch.stack([l1_loss(outs[i][0], self.targets[i]) for i in range(V)]).mean()
             try:
-                loss.backward(gradient=self.one)   # (a resident 1.0: autograd would launch a fill for the root gradient every step)
+                if defer is not None:
+                    with dgr_.deferred_k8(defer):
+                        loss.backward(gradient=self.one)
+                else:
+                    loss.backward(gradient=self.one)   # (a resident 1.0: autograd would launch a fill for the root gradient every step)
             finally:
                 if self.fg is not None:
                     self.fg.unbind()
+            if defer is not None:
+                self.m2d_grads = [m.grad for m in m2ds]         # (filled by the K8 slices)
+                return loss
             if self.fg is not None:
                 # the screen-space sum densification consumes, written straight into the flat buffer's tail (one launch; K8 wrote every
                 # parameter gradient into its slice already: no stock add / stack / sum launches in the step)
@@ -193,20 +209,48 @@ def main():
                     self.fg.all_reduce(timed=timed_allreduce)
             return loss
 
+        def finish_sliced(self, holder, m2d_grads, radii, G, exchange=True):
+            """the tail of a step whose backward was launched with `defer`: K8 slice by slice, the rows of slice g on their way while
+            slice g + 1 computes; then the statistics into the buffer's tail and the rest of the exchange"""
+            for g_ in range(G):
+                holder.launch(g_, G)
+                if exchange and self.fg is not None:
+                    lo, hi = holder.rows(g_, G)
+                    self.fg.start_ranges(self.fg.slice_ranges(P, lo, hi))
+            if self.fg is not None:
+                step_stats(m2d_grads, radii, self.zeros.shape[1], dev, out_vsg=self.fg.tail.view(-1, 3))
+                if exchange:
+                    self.fg.finish_sliced(P)
+
     class GraphedSteps:
         """The workload's step recorded into G hipGraphs and replayed round-robin: csplat.graphs.ReplayedSteps -- the SAME object
         tests/test_raster_gpu.py::test_config2_full_size_faith_replay_vs_oracle holds to the oracle (both phases of the forward launched
         with capacities taken from an eager step's counts, nothing read back; a device word per graph says whether the counts fitted --
         checked after the timed region, together with the replayed gradients themselves)."""
 
-        def __init__(self, w_, G=4):
+        def __init__(self, w_, G=4, sliced=0):
+            """sliced = S > 0 (N > 1): the recordings end behind K7; the host launches the S K8 slices behind every replay, each followed
+            by the exchange of its gradient rows (Workload.finish_sliced)"""
             from csplat.graphs import ReplayedSteps
-            self.w = w_
+            self.w, self.sliced, self.exchange = w_, int(sliced), True
 
             def fn():       # (N > 1: the all-reduce follows every replay, launched by the host)
+                if self.sliced:
+                    holder = dgr_.DeferredK8()
+                    loss = w_.step(defer=holder)
+                    return loss, w_.grads(), holder, w_.m2d_grads, w_.radii
                 loss = w_.step(skip_allreduce=True)
                 return loss, w_.grads()
-            self.rs = ReplayedSteps(fn, dev, G=G)
+            self.fn = fn
+            if self.sliced:     # (the count pass runs fn() eagerly: its deferred K8 must be launched too, or the scratch records stay dirty)
+                def counted():
+                    out_ = fn()
+                    w_.finish_sliced(out_[2], out_[3], out_[4], self.sliced, exchange=False)
+                    return out_
+                self.rs = ReplayedSteps(counted, dev, G=G)
+                self.rs.fn = fn
+            else:
+                self.rs = ReplayedSteps(fn, dev, G=G)
             self.caps, self.counts = self.rs.caps, self.rs.counts
 
         def record(self):
@@ -214,8 +258,10 @@ def main():
             self.graphs = self.rs.graphs
 
         def step(self):
-            self.rs.step()
-            if self.w.fg is not None:       # N > 1: ONE all-reduce of the flat gradient buffer the recorded kernels have just filled
+            out_ = self.rs.step()
+            if self.sliced:
+                self.w.finish_sliced(out_[2], out_[3], out_[4], self.sliced, exchange=self.exchange)
+            elif self.w.fg is not None and self.exchange:       # N > 1: ONE all-reduce of the flat gradient buffer the recorded kernels have just filled
                 self.w.fg.all_reduce()
 
         def all_valid(self):
@@ -276,6 +322,58 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and graphed is not None:
             graphed, launch_mode = None, "eager (recording failed on another rank)"
+    # ---- N > 1: HOW the step's gradients are summed over the ranks is measured on this node, not assumed (round 6).  Candidates: one RCCL
+    # all-reduce of the flat buffer behind the step ("oneshot"); the same message as an all-to-all reduce-scatter + local sum + all-gather
+    # ("direct": xGMI is a full mesh, an all-to-all drives all seven links of every GPU at once); K8 cut into S Gaussian ranges whose rows
+    # leave while the next range computes ("sliced").  Each is timed over the same replayed steps (max over ranks), next to the steps
+    # WITHOUT any exchange; the fastest is used for the timed region and the line says which, with every candidate's time.
+    exchange_info = None
+    if dist_on and graphed is not None and wl.fg is not None:
+        def time_steps(g_, n=10):
+            for _ in range(3):
+                g_.step()
+            sync(); t_x = time.perf_counter()
+            for _ in range(n):
+                g_.step()
+            sync()
+            t_ = torch.tensor([(time.perf_counter() - t_x) / n * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        cand = {}
+        graphed.exchange = False
+        cand["no_exchange"] = time_steps(graphed)
+        graphed.exchange = True
+        want = [args.exchange] if args.exchange != "auto" else ["oneshot", "direct", "sliced"]
+        sliced_g = None
+        for name in want:
+            try:
+                if name == "sliced":
+                    sliced_g = GraphedSteps(wl, sliced=max(1, args.slices))
+                    sliced_g.record()
+                    wl.fg.algo = "rccl"
+                    cand[name] = time_steps(sliced_g)
+                    if not sliced_g.all_valid():
+                        raise RuntimeError("capacities")
+                else:
+                    wl.fg.algo = "direct" if name == "direct" else "rccl"
+                    cand[name] = time_steps(graphed)
+                    if name == "direct" and wl.fg.algo != "direct":
+                        cand[name] = None           # (the backend has no all-to-all on device tensors: fell back)
+            except Exception as e:
+                cand[name] = None
+                cand[name + "_error"] = repr(e)[:120]
+        ok_ = torch.tensor([0.0 if cand.get(n_) is None else 1.0 for n_ in want], dtype=torch.float64, device=dev)
+        dist.all_reduce(ok_, op=dist.ReduceOp.MIN)          # a candidate counts only if it worked on every rank
+        live = [n_ for n_, o_ in zip(want, ok_.tolist()) if o_ > 0]
+        chosen = min(live, key=lambda n_: cand[n_]) if live else "oneshot"
+        wl.fg.algo = "direct" if chosen == "direct" else "rccl"
+        if chosen == "sliced":
+            graphed = sliced_g
+        exchange_info = {"chosen": chosen, "slices": max(1, args.slices) if chosen == "sliced" else 1,
+                         "step_ms": {k_: (None if v_ is None else round(v_, 4)) for k_, v_ in cand.items() if not k_.endswith("_error")},
+                         "errors": {k_: v_ for k_, v_ in cand.items() if k_.endswith("_error")} or None,
+                         "exposed_allreduce_ms": None if cand.get(chosen) is None else round(cand[chosen] - cand["no_exchange"], 4)}
+        launch_mode = f"hipGraph replay ({len(graphed.graphs)} recordings, round-robin) + exchange '{chosen}'"
     events_on = not os.environ.get("CSPLAT_BENCH_NOEVENTS")
     # ---- the step under a sustained load, FIRST (round 6: the driver's gpu_busy sampler saw 0 % twice in a 6.9 s run whose timed region
     # lasts 11 ms): > 1 s of back-to-back replays of the step that is timed next -- an extended warm-up by the contract's terms (untimed),
@@ -394,7 +492,10 @@ def main():
         sync(); ms_ar = (time.perf_counter() - t_n) / 5 * 1e3
         collective = {"backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
                       "bytes": int(wl.fg.flat.numel() * 4), "allreduce_ms": round(float(np.median(ar)), 4),
-                      "exposed_allreduce_ms": round(ms_ar - ms_noar, 4), "step_ms_without_allreduce": round(ms_noar, 4),
+                      # the exchange the TIMED region used, chosen by measurement before it (all candidates' step times, max over ranks)
+                      "exchange": exchange_info, "slices": (exchange_info or {}).get("slices", 1),
+                      "exposed_allreduce_ms": (exchange_info or {}).get("exposed_allreduce_ms", round(ms_ar - ms_noar, 4)),
+                      "eager_exposed_allreduce_ms": round(ms_ar - ms_noar, 4), "step_ms_without_allreduce": round(ms_noar, 4),
                       "what": "one all-reduce(sum) per step over the flat gradient buffer (62 floats per Gaussian + 3 for the "
                               "screen-space gradient); timed alone, after the step's kernels have drained"}
     R_per_view = [0] * V

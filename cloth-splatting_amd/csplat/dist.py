@@ -80,11 +80,18 @@ class FlatGrads:
         self.extra = int(extra)
         self.early = int(early)
         self.n_early = self.offsets[self.early] if self.early < len(self.sizes) else self.n_param
-        self.flat = torch.zeros(self.n_param + self.extra, dtype=self.params[0].dtype, device=dev)
+        # (padded to a multiple of 64 floats per rank: the direct exchange cuts the buffer into one chunk per rank; the padding is zero)
+        w_ = world_rank()[0]
+        self.n_used = self.n_param + self.extra
+        self.flat_all = torch.zeros(-(-self.n_used // (64 * w_)) * 64 * w_, dtype=self.params[0].dtype, device=dev)
+        self.flat = self.flat_all[:self.n_used]
         self.views = [self.flat[o:o + n].view(s) for o, n, s in zip(self.offsets, self.sizes, self.shapes)]
         self._refs = [weakref.ref(p) for p in self.params]
         self.tail = self.flat[self.n_param:]
         self.last_allreduce_ms = 0.0
+        self.algo = os.environ.get("CSPLAT_ALLREDUCE", "rccl") if os.environ.get("CSPLAT_ALLREDUCE", "rccl") in ("rccl", "direct") else "rccl"
+        self.algo_note = None
+        self._slice_work, self._sliced = [], []
         self.early_fired = 0           # how many steps sent their early slice from the backward hook (tests, bench)
         self.in_place = 0              # gradients adopted in place (written into the slice by their last kernel) since creation
         self.copied = 0                # ... and gradients that had to be copied into their slice
@@ -236,13 +243,137 @@ class FlatGrads:
         else:
             rest = self.flat
         if rest.numel():
-            dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=group)
+            if rest.data_ptr() == self.flat.data_ptr() and rest.numel() == self.flat.numel():
+                self._exchange(group)           # (the whole buffer in one message: the tuned algorithm)
+            else:
+                dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=group)
         if self._early_work is not None:
             self._early_work.wait()
             self._early_work = None
         if timed and self.flat.is_cuda:
             torch.cuda.synchronize(self.flat.device)
             self.last_allreduce_ms = (time.perf_counter() - t0) * 1e3
+        return self.flat
+
+
+    # ---- the exchange itself.  ALGO: "rccl" = one all-reduce of the buffer (the library's ring / tree); "direct" = reduce-scatter by
+    # all-to-all + local sum + all-gather: xGMI is a full mesh of point-to-point links (7 x ~153 GB/s per GPU,
+    # /opt/skills/guides/MI355X_MICROARCH.md), and an all-to-all drives all seven links of every GPU at once with 1/world of the buffer
+    # each way, where a ring pushes 2 (w - 1) / w of the buffer through per-link hops; every chunk is summed by ONE rank in rank order and
+    # broadcast, so the replicas stay bit-identical.  Which one is faster on a given node is MEASURED, not guessed: `tune_exchange()`
+    # times both on this buffer and keeps the faster (the ranks agree through a MAX all-reduce of the timings).
+    def _exchange(self, group=None):
+        if self.algo == "direct":
+            try:
+                self._direct(group)
+                return
+            except (RuntimeError, NotImplementedError, ValueError) as e:      # (a backend without all-to-all: gloo on device tensors)
+                self.algo, self.algo_note = "rccl", "direct exchange unavailable: " + repr(e)[:100]
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+    def _direct(self, group=None):
+        w, r = dist.get_world_size(group), dist.get_rank(group)
+        chunk = self.flat_all.numel() // w
+        send = self.flat_all.view(w, chunk)
+        if getattr(self, "_recv", None) is None or self._recv.shape != send.shape:
+            self._recv = torch.empty_like(send)
+        dist.all_to_all_single(self._recv.view(-1), self.flat_all, group=group)          # row j = rank j's copy of MY chunk
+        torch.sum(self._recv, dim=0, out=send[r])                                      # fixed order over ranks
+        dist.all_gather_into_tensor(self.flat_all, send[r], group=group)                 # (in place: input = output chunk r)
+
+    def tune_exchange(self, group=None, reps=5):
+        """time both exchange algorithms on this buffer (contents are summed `reps` times each: call it on a buffer whose contents do not
+        matter -- before the first step) and keep the faster; returns {"rccl_ms", "direct_ms", "chosen"}"""
+        if not is_dist() or not self.flat.is_cuda:
+            return {"rccl_ms": None, "direct_ms": None, "chosen": self.algo}
+        res = {}
+        for algo in ("rccl", "direct"):
+            self.algo = algo
+            try:
+                self._exchange(group)
+                torch.cuda.synchronize(self.flat.device)
+                if self.algo != algo:
+                    res[algo] = float("inf")
+                    continue
+                dist.barrier(group)
+                torch.cuda.synchronize(self.flat.device)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    self._exchange(group)
+                torch.cuda.synchronize(self.flat.device)
+                res[algo] = (time.perf_counter() - t0) / reps * 1e3
+            except Exception:
+                res[algo] = float("inf")
+        t = torch.tensor([res["rccl"], res["direct"]], dtype=torch.float64, device=self.flat.device)
+        t = torch.nan_to_num(t, posinf=1e9)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        rc, dr = float(t[0]), float(t[1])
+        self.algo = "direct" if dr < rc else "rccl"
+        self.flat_all.zero_()
+        return {"rccl_ms": None if rc >= 1e9 else round(rc, 4), "direct_ms": None if dr >= 1e9 else round(dr, 4), "chosen": self.algo}
+
+    # ---- the exchange in SLICES of Gaussian rows (round 6): K8 finishes the gradient rows of a range of Gaussians per launch
+    # (csplat_backward_views_parts); the rows of slice g travel while slice g + 1 computes
+    def per_gaussian(self, P):
+        """indices of the parameters whose leading dimension is the Gaussian count P (their gradients are finished row range by row range)"""
+        return [i for i, s_ in enumerate(self.shapes) if len(s_) >= 1 and s_[0] == P and self.sizes[i] % max(P, 1) == 0]
+
+    def slice_ranges(self, P, row_lo, row_hi, which=None):
+        """the flat sub-ranges holding rows [row_lo, row_hi) of every per-Gaussian parameter"""
+        out = []
+        for i in (self.per_gaussian(P) if which is None else which):
+            wdt = self.sizes[i] // P
+            if row_hi > row_lo:
+                out.append(self.flat[self.offsets[i] + row_lo * wdt:self.offsets[i] + row_hi * wdt])
+        return out
+
+    def start_ranges(self, ranges, group=None):
+        """all-reduce(sum) of a list of flat sub-ranges, asynchronous: queued on the collective's stream behind the kernels launched so
+        far; the handles are waited for in finish_sliced().  One grouped launch where the backend coalesces (RCCL), else one per range."""
+        if not is_dist() or not ranges:
+            return
+        self.unbind()
+        if dist.get_backend(group) == "nccl" and len(ranges) > 1 and hasattr(dist, "_coalescing_manager"):
+            # (decided up front, never as a fallback: a manager that failed half way would have issued some of the sums already)
+            with dist._coalescing_manager(group=group, device=self.flat.device, async_ops=True) as cm:
+                for t in ranges:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            self._slice_work.append(cm)
+        else:
+            for t in ranges:
+                self._slice_work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        self._sliced.extend((int(t.data_ptr()), int(t.numel())) for t in ranges)
+
+    def finish_sliced(self, P, group=None):
+        """everything the slices did not carry (parameters that are not per-Gaussian, the tail) in one more collective, then wait for all.
+        The slices must have covered every row of every per-Gaussian parameter (checked): the sums equal the one-shot all-reduce's."""
+        self.unbind()
+        if not is_dist():
+            self._slice_work, self._sliced = [], []
+            return self.flat
+        covered = {}
+        base = int(self.flat.data_ptr())
+        for ptr, n in self._sliced:
+            covered[(ptr - base) // 4] = n
+        pg = set(self.per_gaussian(P))
+        rest = []
+        for i in range(len(self.params)):
+            if i in pg:
+                o, end = self.offsets[i], self.offsets[i] + self.sizes[i]
+                while o < end:
+                    n = covered.get(o)
+                    if not n:
+                        raise RuntimeError(f"FlatGrads.finish_sliced: rows of parameter {i} at flat offset {o} were sent by no slice")
+                    o += n
+            else:
+                rest.append(self.flat[self.offsets[i]:self.offsets[i] + self.sizes[i]])
+        if self.extra:
+            rest.append(self.tail)
+        if rest:
+            self.start_ranges(rest, group)
+        for wk in self._slice_work:
+            wk.wait()
+        self._slice_work, self._sliced = [], []
         return self.flat
 
 

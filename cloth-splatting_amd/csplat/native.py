@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsplat.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -45,6 +45,8 @@ EXPORTS = {
     "csplat_forward_views_faith": (_i, [_i, _vp, ALLOC_FN, _vp, _vp, _vp]),
     "csplat_image_info_offset": (C.c_size_t, [_i, _i]),
     "csplat_backward_views": (_i, [_i, _vp, _vp]),
+    "csplat_backward_views_parts": (_i, [_i, _vp, _vp, C.c_uint, _i, _i]),
+    "csplat_backward_slice_rows": (_i, [_i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "csplat_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_dist2": (_i, [_vp, _i, _vp, _vp]),

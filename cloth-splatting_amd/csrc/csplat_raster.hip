@@ -2395,9 +2395,12 @@ struct K8Table {
 template <int NT, int VL>
 __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M, const float *__restrict__ shs,
                                                                const float *__restrict__ scales, float scale_mod,
-                                                               int use_precomp_cov, float *__restrict__ dL_dsh, K8Table tab) {
+                                                               int use_precomp_cov, float *__restrict__ dL_dsh, K8Table tab, int block0) {
     constexpr bool STAGE = true;
     if (tab.valid && *tab.valid == 0u) return;
+    // (block0: first workgroup of a Gaussian-range SLICE of the launch -- csplat_backward_views_parts: the gradient rows of a finished slice
+    //  can leave for the other ranks while the next slice computes)
+    const int bx = (int)blockIdx.x + block0;
     const unsigned smask = tab.sharedmask;
     // shared output: add to the thread's running sum; per-view output: write (or add, by that view's accmask)
 #define PUTL(local, ptr, idx, val, bit)                                                    \
@@ -2410,10 +2413,10 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     __shared__ float s_in[STAGE ? NG * SH_ROW : 1];
     __shared__ float s_out[STAGE ? NT * SH_ROW : 1];
     const int gi = threadIdx.x / VL, vl = threadIdx.x % VL;
-    const int i = blockIdx.x * NG + gi;
-    const int rows = min(NG, P - blockIdx.x * NG);
+    const int i = bx * NG + gi;
+    const int rows = min(NG, P - bx * NG);
     if (STAGE) {
-        stage_sh_rows<NT>(shs + (size_t)blockIdx.x * NG * 48, rows, s_in);
+        stage_sh_rows<NT>(shs + (size_t)bx * NG * 48, rows, s_in);
         for (int k = 0; k < 48; k++) s_out[threadIdx.x * SH_ROW + k] = 0.f;
         __syncthreads();
     }
@@ -2673,7 +2676,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     }   // i < P
     if (STAGE) {   // coalesced 16-byte stores of the workgroup's SH gradients
         __syncthreads();
-        float4 *dst4 = reinterpret_cast<float4 *>(dL_dsh + (size_t)blockIdx.x * NG * 48);
+        float4 *dst4 = reinterpret_cast<float4 *>(dL_dsh + (size_t)bx * NG * 48);
         for (int t = threadIdx.x; t < rows * 12; t += NT) {
             const int row = t / 12, c = (t - row * 12) * 4;
             const float *sp = s_out + row * VL * SH_ROW + c;
@@ -3767,8 +3770,16 @@ static bool k8_views_table(int V, const csplat_view *v, K8Table &tab) {
     return true;
 }
 
-int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
+// csplat_backward_views cut into parts (round 6: the gradient exchange of a view-parallel step starts before the backward has ended).
+// parts bit 0: the compositing backward (K7) of all views; bit 1: the per-Gaussian backward (K8) for SLICE `slice` of `nslices` equal
+// ranges of Gaussians (boundaries at multiples of 32: csplat_backward_slice_rows) -- a caller launches K7 once, then the K8 slices one by
+// one, and may hand the gradient rows of slice g to its collective while slice g + 1 computes.  Only the one-launch-per-stage path can be
+// cut (the views share P, SH, scales and the image size, as csplat_forward_views_faith requires); parts == 3 with one slice is
+// csplat_backward_views.  The sum of the parts is the whole call bit for bit: every Gaussian's arithmetic is the same in any slicing.
+static int backward_views_impl(int V, csplat_view *v, void *join_stream, unsigned parts, int slice, int nslices) {
     CSPLAT_REQUIRE(V >= 0 && (V == 0 || v != nullptr), "csplat_backward_views: bad view count");
+    CSPLAT_REQUIRE(parts >= 1 && parts <= 3 && nslices >= 1 && slice >= 0 && slice < nslices, "csplat_backward_views_parts: bad parts / slice");
+    const bool want_k7 = (parts & 1u) != 0, want_k8 = (parts & 2u) != 0, whole = parts == 3u && nslices == 1;
     hipStream_t join = (hipStream_t)join_stream;
     bool shared = false;   // any view adding into another view's buffers: all K8 run on the join stream, in view order
     for (int i = 0; i < V; i++) shared |= (v[i].accmask & ~(unsigned)CSPLAT_SCRATCH_ZEROED) != 0u;
@@ -3784,12 +3795,13 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
     // neither the entry nor the exit fence (six event / wait calls, ~25 us of host time per step)
     const bool lone = V == 1 && (hipStream_t)v[0].stream == join;      // one view on the caller's stream: nothing to fence
     const bool side_streams = !(batch_k7 && one_k8) && !lone;
+    CSPLAT_REQUIRE(whole || (batch_k7 && one_k8), "csplat_backward_views_parts: only the one-launch-per-stage path can be cut into parts");
     CSPLAT_REQUIRE(!(V > 0 && v[0].valid) || !side_streams, "csplat_backward_views: views launched on faith need the one-launch-per-stage path");
     if (side_streams)
         if (int rc = fence_in(V, v, join)) return rc;
     // from here on side streams may hold work on caller-owned buffers: whatever fails, the exit fence is still issued
     auto body = [&]() -> int {
-        if (batch_k7) {
+        if (batch_k7 && want_k7) {
             const int W = v[0].W, H = v[0].H, P = v[0].P, gx = cdiv(W, CSPLAT_TILE), tiles = gx * cdiv(H, CSPLAT_TILE);
             B2Table bt;
             DetTable dt;
@@ -3857,7 +3869,7 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
                                        w.dL_dcolor, w.dL_dmean3D, w.dL_dcov3D, w.dL_dsh, w.dL_dscale, w.dL_drot))
                 return rc;
         }
-        if (one_k8) {   // every view's K7 is queued on its own stream: the join stream waits for all of them, then ONE K8
+        if (one_k8 && want_k8) {   // every view's K7 is queued on its own stream: the join stream waits for all of them, then ONE K8
             for (int i = 0; i < V && !batch_k7; i++) {
                 if ((hipStream_t)v[i].stream == join) continue;
                 hipEvent_t ev = pooled_event();
@@ -3867,14 +3879,30 @@ int csplat_backward_views(int V, csplat_view *v, void *join_stream) {
             }
             ProfScope ps(PROF_K8, join);
             const csplat_view &a = v[0];
-            k_preprocess_bwd_views<128, 4><<<cdiv(a.P, 32), 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab);
-            LAUNCH_CHECK();
+            const int nb = cdiv(a.P, 32);
+            const int b_lo = (int)((int64_t)nb * slice / nslices), b_hi = (int)((int64_t)nb * (slice + 1) / nslices);
+            if (b_hi > b_lo) {
+                k_preprocess_bwd_views<128, 4><<<b_hi - b_lo, 128, 0, join>>>(a.P, a.D, a.M, a.shs, a.scales, a.scale_modifier, 0, a.dL_dsh, tab, b_lo);
+                LAUNCH_CHECK();
+            }
         }
         return 0;
     };
     const int rc = body();
     const int r2 = side_streams ? fence_out(V, v, join) : 0;
     return rc ? rc : r2;
+}
+int csplat_backward_views(int V, csplat_view *v, void *join_stream) { return backward_views_impl(V, v, join_stream, 3u, 0, 1); }
+int csplat_backward_views_parts(int V, csplat_view *v, void *join_stream, unsigned parts, int slice, int nslices) {
+    return backward_views_impl(V, v, join_stream, parts, slice, nslices);
+}
+// rows [*row_lo, *row_hi) of the P Gaussians that K8 slice `slice` of `nslices` finishes
+int csplat_backward_slice_rows(int P, int slice, int nslices, int64_t *row_lo, int64_t *row_hi) {
+    CSPLAT_REQUIRE(P >= 0 && nslices >= 1 && slice >= 0 && slice < nslices && row_lo && row_hi, "csplat_backward_slice_rows: bad arguments");
+    const int64_t nb = cdiv(P, 32);
+    const int64_t lo = nb * slice / nslices * 32, hi = nb * (slice + 1) / nslices * 32;
+    *row_lo = lo < P ? lo : P; *row_hi = hi < P ? hi : P;
+    return 0;
 }
 
 }  // extern "C"

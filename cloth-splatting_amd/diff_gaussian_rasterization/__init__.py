@@ -260,6 +260,49 @@ def forward_mode(faith=None, keep_info=False, replay_device=None):
             _n.REPLAY_STREAM.pop(idx, None)
 
 
+class DeferredK8:
+    """Filled by `deferred_k8()`: the batched backward passes inside the scope launched their K7 only; `launch(slice, nslices)` launches
+    the per-Gaussian backward (K8) of one Gaussian range for all of them, `rows(slice, nslices)` says which gradient rows that finishes
+    (csplat_backward_views_parts / csplat_backward_slice_rows).  A view-parallel step hands the finished rows to its collective while
+    the next slice computes (csplat.dist.FlatGrads.start_ranges).  The entries hold raw pointers of the pass that made them: valid as
+    long as its gradient tensors are (for a recorded step: as long as the recording)."""
+
+    def __init__(self):
+        self.entries = []           # (csplat_view array, number of views, device, P, keep-alive)
+
+    def launch(self, slice_, nslices):
+        for sub, n, dev, _P, _keep in self.entries:
+            with _n.on_device(dev):
+                rc = _n.lib.csplat_backward_views_parts(n, C.cast(sub, C.c_void_p), torch.cuda.current_stream(dev).cuda_stream, 2, int(slice_),
+                                                        int(nslices))
+            _n.check(rc, "csplat_backward_views_parts")
+
+    def rows(self, slice_, nslices):
+        P = self.entries[0][3]
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        _n.check(_n.lib.csplat_backward_slice_rows(int(P), int(slice_), int(nslices), C.byref(lo), C.byref(hi)), "csplat_backward_slice_rows")
+        return int(lo.value), int(hi.value)
+
+
+_K8_DEFER = None
+
+
+@_contextlib.contextmanager
+def deferred_k8(holder=None):
+    """Scope in which `_RasterizeGaussiansBatch.backward` launches the compositing backward (K7) only and leaves the per-Gaussian backward
+    (K8) to the caller: `with deferred_k8() as h: loss.backward()`, then `h.launch(g, G)` for g = 0 .. G-1.  The gradient tensors autograd
+    has been handed are filled by those launches -- nothing may read them in between: every input of the node must be a LEAF (or feed
+    leaves through nodes that do not read values, like views), each receiving its gradient from this node alone."""
+    global _K8_DEFER
+    if _K8_DEFER is not None:
+        raise RuntimeError("diff_gaussian_rasterization.deferred_k8: already inside a deferred_k8 scope")
+    _K8_DEFER = holder if holder is not None else DeferredK8()
+    try:
+        yield _K8_DEFER
+    finally:
+        _K8_DEFER = None
+
+
 def forward_mode_is_default():
     """True when no forward_mode scope is open (tests assert it after every recording)"""
     return _FAITH is None and not _KEEP_INFO and not _n.REPLAY_STREAM
@@ -530,6 +573,16 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         gs = [_f32c_grad(gcol[i], dev) for i in active]
         for a, g in enumerate(gs):
             plan["sub"][a].dL_dpix = _n.ptr(g)
+        if _K8_DEFER is not None:
+            # K7 now, K8 in slices later (DeferredK8.launch): the plan -- the view array and every buffer it points into -- stays alive
+            with _n.on_device(dev):
+                rc = _n.lib.csplat_backward_views_parts(len(active), C.cast(plan["sub"], C.c_void_p), main.cuda_stream, 1, 0, 1)
+            _n.check(rc, "csplat_backward_views_parts")
+            # (kept alive: the MEMORY the K8 slices write -- never the gradient tensor objects themselves: AccumulateGrad adopts a
+            #  gradient only when nobody else holds it, and would otherwise snapshot the still unwritten buffer into a copy)
+            outs, plan["out"] = tuple(plan["out"]), None
+            _K8_DEFER.entries.append((plan["sub"], len(active), dev, views[active[0]].P, (plan["big"], plan["acc"], gs, ctx.saved_tensors)))
+            return (None, None) + outs
         with _n.on_device(dev):
             rc = _n.lib.csplat_backward_views(len(active), C.cast(plan["sub"], C.c_void_p), main.cuda_stream)
         _n.check(rc, "csplat_backward_views")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CSPLAT_ABI_VERSION 5   /* round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
+#define CSPLAT_ABI_VERSION 6   /* 6 (round 6): csplat_backward_views_parts / _slice_rows, csplat_gnn_edge_length_refine; round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
 
 /* scratch chunks requested through the allocator callback */
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
@@ -170,6 +170,15 @@ int csplat_forward_views(int V, csplat_view *views, csplat_alloc_fn alloc, void 
 int csplat_forward_views_deferred(int V, csplat_view *views, csplat_alloc_fn alloc, void *join_stream, int *pending);
 int csplat_forward_views_settle(int V, csplat_view *views, void *join_stream, int *relaunched);
 int csplat_backward_views(int V, csplat_view *views, void *join_stream);
+/* csplat_backward_views cut into parts (round 6; no counterpart upstream -- the reference is single-GPU): parts bit 0 = the compositing
+ * backward (K7) of all views, bit 1 = the per-Gaussian backward (K8) for slice `slice` of `nslices` equal ranges of Gaussians (boundaries
+ * at multiples of 32; csplat_backward_slice_rows).  A view-parallel step launches K7 once, then the K8 slices one by one, and hands the
+ * finished gradient rows of slice g to its collective while slice g + 1 computes.  Only the one-launch-per-stage path can be cut (views
+ * sharing P, SH, scales and the image size); parts = 3, one slice = csplat_backward_views.  The parts together equal the whole call bit for
+ * bit. */
+int csplat_backward_views_parts(int n_views, csplat_view *views, void *join_stream, unsigned parts, int slice, int nslices);
+/* rows [*row_lo, *row_hi) of the P Gaussians whose gradients K8 slice `slice` of `nslices` finishes */
+int csplat_backward_slice_rows(int P, int slice, int nslices, int64_t *row_lo, int64_t *row_hi);
 /* The batched forward WITHOUT a host read, for stream capture (a training step replayed as a hipGraph; the reference times its step
  * with an event pair around exactly such a loop body, train.py:146,178): both phases are launched with the caller's capacities --
  * caps[0] list entries per view, caps[1] longest tile list, caps[2] non-empty tiles, normally a previous call's counts plus a margin --

@@ -152,3 +152,71 @@ def test_view_parallel_train_step_equals_single_process_step(tmp_path, n_cams, w
             continue
         a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
         assert np.abs(a - b).max() <= 1e-9 * (np.abs(b).max() + 1e-30) + 1e-12, (k, np.abs(a - b).max())
+
+
+def _worker_sliced(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(util.ROOT, "cloth-splatting_amd"))
+    from csplat import dist as cd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = 203                                             # (not a multiple of 32: the last slice is ragged)
+        gen = torch.Generator().manual_seed(7)
+        shapes = [(P, 3), (P, 1), (P, 16, 3), (P, 3), (P, 4), (17, 5)]          # five per-Gaussian parameters + one that is not
+        params = [torch.nn.Parameter(torch.randn(*s, generator=gen)) for s in shapes]
+        res = {}
+        for mode in ("oneshot", "sliced", "direct"):
+            fg = cd.FlatGrads(params, extra=3 * P)
+            g2 = torch.Generator().manual_seed(100 + rank)                      # every rank its own gradients
+            fg.flat.copy_(torch.randn(fg.flat.numel(), generator=g2))
+            # (the padding between slices is never exchanged by the sliced form: keep it zero, as bind() does)
+            for i in range(len(params)):
+                end = fg.offsets[i] + fg.sizes[i]
+                nxt = fg.offsets[i + 1] if i + 1 < len(params) else fg.n_param
+                fg.flat[end:nxt] = 0
+            if mode == "oneshot":
+                fg.all_reduce()
+            elif mode == "direct":
+                fg.algo = "direct"
+                fg.all_reduce()
+                res["direct_algo_after"] = np.array([fg.algo == "direct"])
+            else:
+                G = 4
+                nb = -(-P // 32)
+                for g_ in range(G):
+                    lo, hi = min(nb * g_ // G * 32, P), min(nb * (g_ + 1) // G * 32, P)
+                    fg.start_ranges(fg.slice_ranges(P, lo, hi))
+                fg.finish_sliced(P)
+            res[mode] = fg.flat.clone().numpy()
+            fg.close()
+        # a slice that was never sent must be noticed
+        fg = cd.FlatGrads(params, extra=3 * P)
+        fg.start_ranges(fg.slice_ranges(P, 0, 64))
+        try:
+            fg.finish_sliced(P)
+            res["missing_noticed"] = np.array([False])
+        except RuntimeError:
+            res["missing_noticed"] = np.array([True])
+            for wk in fg._slice_work:
+                wk.wait()
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sliced_and_direct_exchange_equal_the_one_shot_all_reduce_gloo(tmp_path):
+    """FlatGrads on two gloo ranks: the exchange in four slices of Gaussian rows (start_ranges per slice, finish_sliced
+    for the rest -- what bench.py --gpus N issues behind the K8 slices of csplat_backward_views_parts) and the direct exchange
+    (all-to-all reduce-scatter + local sum + all-gather) give the one-shot all-reduce's sums -- with two ranks bit for bit (a + b in
+    either order) -- the replicas stay identical, and a row range no slice sent is noticed."""
+    import torch.multiprocessing as mp
+    port = 29500 + ((os.getpid() * 7 + 3) % 2000)
+    mp.spawn(_worker_sliced, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
+    for k in ("oneshot", "sliced", "direct"):
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)               # replicas identical
+    np.testing.assert_array_equal(r0["oneshot"], r0["sliced"])
+    np.testing.assert_array_equal(r0["oneshot"], r0["direct"])
+    assert bool(r0["direct_algo_after"][0]), "gloo on CPU tensors serves all_to_all_single: the direct exchange must have run"
+    assert bool(r0["missing_noticed"][0]) and bool(r1["missing_noticed"][0])

@@ -1141,3 +1141,55 @@ def test_gradient_sink_keeps_one_writer_when_a_second_node_rebuilds_its_plan():
     assert missed >= 1, "the second node of the last round was meant to miss its speculation"
     for name, a, b in zip(names, sunk, plain):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, name
+
+
+@pytest.mark.parametrize("G", [1, 3, 4])
+def test_backward_in_parts_equals_the_whole_backward(G):
+    """csplat_backward_views_parts (round 6: the view-parallel step's gradient rows leave for the other ranks slice by slice): K7 once, then
+    K8 for G ranges of Gaussians -- every gradient of every input BIT-equal to the one-call backward (bit-reproducible K7 mode, so that
+    K7's own sums are the same in both runs), the row ranges tile [0, P) at multiples of 32, and a slice leaves the rows of the others
+    untouched until its own launch."""
+    from csplat import native
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import rasterize_views
+    V, P = 3, 2901
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    native.lib.csplat_debug_flags(256)
+    try:
+        def run(parts):
+            base = util.make_case(P=P, W=144, H=112, seed=4, theta=-30.0, scale_mul=2.0)
+            inp = util.gpu_inputs(base)
+            cases = [util.make_case(P=P, W=144, H=112, seed=4, theta=-30.0 + 30.0 * i, scale_mul=2.0) for i in range(V)]
+            settings = [util.gpu_settings(c) for c in cases]
+            m2d = [torch.zeros(P, 3, device="cuda", requires_grad=True) for _ in range(V)]
+            kws = [dict(means3D=inp["means3D"], means2D=m2d[i], opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                        rotations=inp["rotations"]) for i in range(V)]
+            colors, _outs = rasterize_views(settings, kws, stacked=True)
+            gen = torch.Generator(device="cuda").manual_seed(3)
+            loss = ((colors - torch.rand(V, 3, 112, 144, device="cuda", generator=gen)) ** 2).mean()
+            rows = []
+            if parts:
+                with dgr.deferred_k8() as h:
+                    loss.backward()
+                assert len(h.entries) == 1
+                # (the gradients autograd holds are the buffers the slices write: poison them first -- a gradient that had been copied
+                #  out before its slice ran would keep whatever the allocator's recycled memory held, e.g. the other run's values)
+                for t in [inp[k].grad for k in names] + [m.grad for m in m2d]:
+                    t.fill_(float("nan"))
+                for g_ in range(G):
+                    rows.append(h.rows(g_, G))
+                    h.launch(g_, G)
+                    if g_ + 1 < G:      # rows of later slices are still untouched
+                        assert torch.isnan(inp["scales"].grad[rows[-1][1]:]).all() and torch.isfinite(inp["scales"].grad[:rows[-1][1]]).all()
+            else:
+                loss.backward()
+            torch.cuda.synchronize()
+            return [inp[k].grad.clone() for k in names] + [m.grad.clone() for m in m2d], rows
+        whole, _ = run(False)
+        cut, rows = run(True)
+    finally:
+        native.lib.csplat_debug_flags(0)
+    assert rows[0][0] == 0 and rows[-1][1] == P and all(a[1] == b[0] for a, b in zip(rows, rows[1:])) and \
+        all(lo % 32 == 0 for lo, _hi in rows)
+    for a, b in zip(whole, cut):
+        assert torch.equal(a, b)

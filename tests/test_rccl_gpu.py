@@ -51,3 +51,24 @@ def test_bench_collective_leg_under_rccl_one_rank():
     c = line["collective"]
     assert c is not None and c["backend"] == "nccl (RCCL)" and c["ranks"] == 1 and 0 <= c["bytes"] - (59 + 3) * 100_000 * 4 <= 5 * 256     # 3 + 1 + 48 + 3 + 4 floats of gradient per Gaussian + the screen-space tail (slices 256-byte aligned)
     assert c["allreduce_ms"] > 0 and line["value"] > 0 and line["n_gpus"] == 1
+    # round 6: the exchange of the timed region is CHOSEN BY MEASUREMENT among the one-shot all-reduce, the direct (all-to-all) exchange
+    # and the sliced one (K8 in four Gaussian ranges, csplat_backward_views_parts); all three must have run under RCCL
+    ex = c["exchange"]
+    assert ex is not None and ex["chosen"] in ("oneshot", "direct", "sliced") and not ex["errors"], ex
+    for k in ("no_exchange", "oneshot", "direct", "sliced"):
+        assert ex["step_ms"].get(k) and ex["step_ms"][k] > 0, ex
+    assert c["slices"] == (4 if ex["chosen"] == "sliced" else 1)
+
+
+@pytest.mark.parametrize("exchange", ["sliced", "direct"])
+def test_bench_forced_exchange_under_rccl_one_rank(exchange):
+    """the same run with the exchange forced: the timed region really goes through the sliced K8 + per-slice collectives (or the direct
+    exchange), and the step it times is the full step (the line's replayed work is checked by bench.py itself; here: it ran, it is valid)"""
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-train-step", "--no-gnn", "--no-speculation", "--exchange", exchange], env=_env(), capture_output=True, text=True,
+                       timeout=900, cwd=util.ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    ex = line["collective"]["exchange"]
+    assert ex["chosen"] == exchange and not ex["errors"] and ex["step_ms"][exchange] > 0, ex
+    assert exchange in line["config"]["launch"] and line["value"] > 0

@@ -1,3 +1,10 @@
 mkdir -p gpurun_out/r06
-python -m pytest tests/test_knn_gnn_gpu.py tests/test_raster_gpu.py -q -p no:cacheprovider -k "refinement or overflow or sink or rollout or encoder" > gpurun_out/r06/new_4.log 2>&1; tail -30 gpurun_out/r06/new_4.log
-python bench_gnn.py --no-train > gpurun_out/r06/bench_gnn_4.json 2> gpurun_out/r06/bench_gnn_4.err; tail -3 gpurun_out/r06/bench_gnn_4.json; tail -5 gpurun_out/r06/bench_gnn_4.err
+python -m pytest tests/test_raster_gpu.py -q -p no:cacheprovider -k "parts or sink" > gpurun_out/r06/new_6.log 2>&1; tail -15 gpurun_out/r06/new_6.log
+python -m pytest tests/test_rccl_gpu.py -q -p no:cacheprovider > gpurun_out/r06/dist_6.log 2>&1; tail -10 gpurun_out/r06/dist_6.log
+python bench.py --no-train-step --no-gnn --no-cpu-baseline > gpurun_out/r06/bench_6.json 2> gpurun_out/r06/bench_6.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r06/bench_6.json'))
+for k in ("value","ms_per_step","eager_ms_per_step","per_camera_ms_per_step","sustained","speculation"):
+    print(k, d[k])
+PY
