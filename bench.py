@@ -416,7 +416,8 @@ def main():
             replay_check = {"loss_replayed": r_loss, "loss_eager": e_loss, "grad_max_abs_diff_over_scale": round(worst, 9),
                             "bar": 1e-4, "what": "last timed replay vs one eager step: loss bit-equal, every gradient tensor (5 parameters + "
                                                  f"{V} screen-space) within the float-atomic noise of K7"}
-            if r_loss != e_loss or not (worst <= 1e-4):
+            if (r_loss != e_loss or not (worst <= 1e-4)) and not os.environ.get("CSPLAT_BENCH_ELIMINATION_BUILD"):
+                # (CSPLAT_BENCH_ELIMINATION_BUILD=1: tools/ab_libs.sh timing a build with work compiled OUT on purpose -- its line is scratch)
                 raise SystemExit(f"bench.py: the replayed step differs from the eager step: {replay_check}")
         # K7's HIP-event bracket: a kernel launched by a graph node cannot be bracketed by timeable events on this ROCm (external
         # event-record nodes: hipEventElapsedTime refuses them), so the SAME K steps run once more launch by launch, straight behind the

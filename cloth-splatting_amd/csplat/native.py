@@ -6,7 +6,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsplat.so")
+# CSPLAT_LIB=<path>: load another build of the library (same-box A/B of kernel variants: tools/ab_libs.sh) -- the shipped file is never
+# overwritten by an experiment
+LIB_PATH = os.environ.get("CSPLAT_LIB") or os.path.join(_HERE, "libcsplat.so")
 ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):

@@ -1700,7 +1700,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 
 // ------------------------------------------------------------------------------------------- K7
 // per-Gaussian gradient accumulator filled by K7 and consumed by K8 (one 64-byte record per Gaussian):
-//   0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..15 pad
+//   rounds 1-5: 0 dmean2D.x  1 dmean2D.y  2 dconic.a  3 dconic.b  4 dconic.c  5 dopacity  6..8 dcolour  9..15 pad
+//   round 6:    0 Mx  1 My  2 Mxx  3 Mxy  4 Myy  5 M0 (= dopacity)  6..8 dcolour -- moments of G dL/dalpha (moments_to_gradients, K8)
 constexpr int ACC_STRIDE = 16;
 
 // ---- K7's chains across the four survivor rows of a group (round 4).  v_permlane16_swap(x, x) hands every lane the two values of its
@@ -1763,6 +1764,9 @@ __device__ __forceinline__ float bfly(float a, float b, bool s) {
 // at the barrier for the slowest of its four blocks (8.7 k of a live wave's 46 k cycles, tools/k7_stamps.py).  259 -> 241 us (same-box
 // A/B, three alternations).  DET (csplat_debug_flags bit 8, bit-reproducible): the sums are STORED, one 9-float record per (list entry,
 // block) -- each pair is visited exactly once -- and k_det_reduce adds every Gaussian's records in emission order.
+#ifndef CSPLAT_K7X
+#define CSPLAT_K7X 0
+#endif
 constexpr int RING7 = SEG;     // a segment's survivors of one block, padded to a multiple of four: at most SEG
 template <bool DET>
 __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -1891,10 +1895,15 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
         }
         if (my_stamp && threadIdx.x == 0) { asm volatile("" :: "v"(S), "v"(T)); }
         mark(3);                                                        // the pixel constants, the checkpoint and the first batch have arrived
-        const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
-        // after the row butterfly an even lane of a row holds the total of value 4*bit1 + 2*bit2 + bit3, lane 1 value 8
-        const bool red_active = !lb0 || l16 == 1;
-        const int red_t = lb0 ? 8 : 4 * (int)lb1 + 2 * (int)lb2 + (int)lb3;
+        // after the moment reduction (processN) nine lanes of a row hold a record entry each: lane 4 j + t of the row = block pixel
+        // (column t, row j).  Record: 0 Mx  1 My  2 Mxx  3 Mxy  4 Myy  5 M0  6..8 colour (K8: moments -> dL/dmean2D, dL/dconic)
+        const bool lq0 = (l16 & 3) == 0, lq1 = (l16 & 3) == 1, lq2 = (l16 & 3) == 2;
+        constexpr int RED_T[16] = {5, 0, 2, 7, 4, -1, -1, -1, 1, 3, -1, 8, 6, -1, -1, -1};
+        int red_t_ = -1;
+#pragma unroll
+        for (int q = 0; q < 16; q++) red_t_ = l16 == q ? RED_T[q] : red_t_;
+        const bool red_active = red_t_ >= 0;
+        const int red_t = red_active ? red_t_ : 0;
         int base = 0;                   // first survivor of the batch in the strip
         // (every LDS read of the loop is unconditional, with a clamped slot: the compiler's lgkmcnt bookkeeping assumes the path on which
         //  a conditional read was NOT issued, and then waits for the youngest ones)
@@ -1931,49 +1940,58 @@ __device__ __forceinline__ void composite_bwd_body(int tiles, int W, int H, int 
 #pragma unroll
             for (int u = 0; u < N; u++) {
                 const float dL_dalpha = act[u] ? Tr[u] * gdot[u] - (OD - Sr[u]) * __builtin_amdgcn_rcpf(F[u]) : 0.f;
-                // with h = -0.5 G dL/dG:  dL/dconic = h (dx^2, dx dy, dy^2);  dL/dmean2D = (W, H) * (hx a + hy b, hy c + hx b) -- the
-                // image-size factors 2 * 0.5 W, 2 * 0.5 H are applied ONCE per Gaussian, by K8, to the summed records
+                // Round 6: the row's lanes no longer form the nine GRADIENT values and reduce each over the 16 pixels (14 multiplications + a
+                // 4-level butterfly of ~24 DPP operations); they reduce the MOMENTS of m = G dL/dalpha about the Gaussian's centre,
+                //   M0 = sum m, Mx = sum m dx, My = sum m dy, Mxx = sum m dx^2, Mxy = sum m dx dy, Myy = sum m dy^2,
+                // which factor over the 4 x 4 block (dx depends on the pixel column only, dy on the row only): first over the rows j at a
+                // fixed column (values m, m dy, m dy^2 and colour 0 -- a two-level transposing fold on the 4-lane banks), then over the
+                // columns with the weights 1, dx, dx^2 (two quad_perm levels); colours 1 and 2 take a five-step reduction of their own.
+                // 7 multiplications + 19 DPP adds + 3 selects; K8 turns the summed moments into dL/dmean2D and dL/dconic once per
+                // Gaussian: dL/dmean2D = -0.5 o (a Mx + b My, c My + b Mx), dL/dconic = -0.5 o (Mxx, Mxy, Myy), dL/dopacity = M0.
                 const float gda = G[u] * dL_dalpha;
-                const float h = -0.5f * t[u]->b.y * gda;
-                const float hx = h * dx[u], hy = h * dy[u];
-                float v[9];
-                v[0] = hx * t[u]->a.z + hy * t[u]->a.w;
-                v[1] = hy * t[u]->b.x + hx * t[u]->a.w;
-                v[2] = hx * dx[u];
-                v[3] = hx * dy[u];
-                v[4] = hy * dy[u];
-                v[5] = gda;
-                v[6] = dcc[u] * dp0; v[7] = dcc[u] * dp1; v[8] = dcc[u] * dp2;
-                // 9 values x 16 lanes -> 9 totals per row: each level folds two values into one register
-                float a0, a1, a2, a3, b0, b1;
-                CSPLAT_BFLY_BANK(a0, v[0], v[1], "row_mirror", "0x3", "0xc");
-                CSPLAT_BFLY_BANK(a1, v[2], v[3], "row_mirror", "0x3", "0xc");
-                CSPLAT_BFLY_BANK(a2, v[4], v[5], "row_mirror", "0x3", "0xc");
-                CSPLAT_BFLY_BANK(a3, v[6], v[7], "row_mirror", "0x3", "0xc");
-                float l8 = dpp_add<0x140>(v[8]);
-                CSPLAT_BFLY_BANK(b0, a0, a1, "row_half_mirror", "0x5", "0xa");
-                CSPLAT_BFLY_BANK(b1, a2, a3, "row_half_mirror", "0x5", "0xa");
-                l8 = dpp_add<0x141>(l8);
-                float c0 = bfly<0x4E>(b0, b1, lb1);
-                l8 = dpp_add<0x4E>(l8);
-                c0 = dpp_add<0xB1>(c0);
-                l8 = dpp_add<0xB1>(l8);
-                tot[u] = lb0 ? l8 : c0;
+                const float c0v = dcc[u] * dp0, c1v = dcc[u] * dp1, c2v = dcc[u] * dp2;
+                float a1, a2, P, Q, R, X, b1, b2;
+                asm("v_mul_f32 %0, %8, %10\n\t"                                                               // a1 = m dy
+                    "v_mul_f32 %1, %0, %10\n\t"                                                               // a2 = m dy^2
+                    "v_add_f32_dpp %2, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                       // P (rows 0, 1) = m      + partner row's
+                    "v_add_f32_dpp %5, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                     // X (rows 0, 1) = colour 1
+                    "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                     // X (rows 2, 3) = colour 2
+                    "v_add_f32_dpp %2, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                       // P (rows 2, 3) = m dy
+                    "v_add_f32_dpp %3, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                       // Q (rows 0, 1) = m dy^2
+                    "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                     // Q (rows 2, 3) = colour 0
+                    "v_add_f32_dpp %4, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"                      // R (rows 0, 2) = P over all four rows
+                    "v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                 // X: the half's pairs
+                    "v_add_f32_dpp %4, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"                       // R (rows 1, 3) = Q over all four rows
+                    "v_mul_f32 %6, %4, %9\n\t"                                                                // b1 = R dx
+                    "v_mul_f32 %7, %6, %9\n\t"                                                                // b2 = R dx^2
+                    "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                    : "=&v"(a1), "=&v"(a2), "=&v"(P), "=&v"(Q), "=&v"(R), "=&v"(X), "=&v"(b1), "=&v"(b2)
+                    : "v"(gda), "v"(dx[u]), "v"(dy[u]), "v"(c0v), "v"(c1v), "v"(c2v));
+                // column t of the block's lane grid keeps: t = 0 the plain sums, t = 1 the dx-weighted, t = 2 the dx^2-weighted, t = 3 colours 1 / 2
+                tot[u] = lq0 ? R : (lq1 ? b1 : (lq2 ? b2 : X));
             }
             // (every survivor of the list was blended at one of the block's pixels: the row always has something to add, padding aside)
 #pragma unroll
             for (int u = 0; u < N; u++)
                 if (red_active && t[u]->pos >= 0) {
                     if (DET) det[((size_t)(rx + (uint32_t)t[u]->pos) * 16 + (size_t)blk) * 9 + red_t] = tot[u];   // one (entry, block) pair is visited exactly once
-                    else atomicAdd(acc + (size_t)t[u]->id * ACC_STRIDE + red_t, tot[u]);                      // nine lanes, one 64-byte record
+                    else if (CSPLAT_K7X != 1) atomicAdd(acc + (size_t)t[u]->id * ACC_STRIDE + red_t, tot[u]);                      // nine lanes, one 64-byte record
+                    else asm volatile("" :: "v"(tot[u]));        // (elimination build CSPLAT_K7X=1: the sums are formed, nothing is sent)
                 }
         };
         auto process = [&](const Trip &t0) { const Trip *t[1] = {&t0}; processN(std::integral_constant<int, 1>{}, t); };
         auto process2 = [&](const Trip &t0, const Trip &t1) { const Trip *t[2] = {&t0, &t1}; processN(std::integral_constant<int, 2>{}, t); };
         bool first = true;
-#ifndef CSPLAT_K7X
-#define CSPLAT_K7X 0
-#endif
+        // (round 6, tried and dropped: requesting the NEXT batch's records before this batch's atomics are issued -- vmcnt retires in order and
+        //  a load queued behind a float atomic waits for it -- costs ten registers across the batch (44 bytes of scratch at the 64-register
+        //  bound) and changed nothing: 214-215 against 210-217 us, profiles/r06_k7_elimination.txt)
         for (; base < total && CSPLAT_K7X != 4; base += 64) {
             if (!first) stage(base);
             const int ngroups = min(64, total - base) >> 2, last_g = ngroups - 1;
@@ -2132,6 +2150,17 @@ __global__ __launch_bounds__(256) void k_det_reduce_views(int P, DetTable tab) {
 }
 
 // ------------------------------------------------------------------------------------------- K8
+// K7's per-Gaussian record (round 6) holds the MOMENTS of m = G dL/dalpha over the pixels the Gaussian was blended at, about its centre:
+// 0 Mx  1 My  2 Mxx  3 Mxy  4 Myy  5 M0  6..8 dL/dcolour.  With conic (a, b, c) and opacity o the pixel-level gradients upstream sums
+// pixel by pixel are linear in them:  dL/dmean2D = -0.5 o (a Mx + b My, c My + b Mx)  (pixel units),  dL/dconic = -0.5 o (Mxx, Mxy, Myy),
+// dL/dopacity = M0.  In place: a9[0..4] become (dmean2D.x, dmean2D.y, dconic.a, dconic.b, dconic.c), a9[5..8] stay.
+__device__ __forceinline__ void moments_to_gradients(float (&a9)[9], const float4 co) {
+    const float h = -0.5f * co.w;
+    const float mx = a9[0], my = a9[1];
+    a9[0] = h * (co.x * mx + co.y * my);
+    a9[1] = h * (co.z * my + co.y * mx);
+    a9[2] *= h; a9[3] *= h; a9[4] *= h;
+}
 // CSPLAT_SCRATCH_ZEROED: the record K8 has just read goes back to zero (12 of its 16 floats: the 9 in use, as three 16-byte stores)
 __device__ __forceinline__ void clear_record(const float *acc, int i) {
     float4 *p = reinterpret_cast<float4 *>(const_cast<float *>(acc) + (size_t)i * ACC_STRIDE);
@@ -2170,6 +2199,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd(int P, int D, int M, cons
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? acc[(size_t)i * ACC_STRIDE + k] : 0.f;
     if (vis && (accmask & CSPLAT_SCRATCH_ZEROED)) clear_record(acc, i);      // (consumed: the caller's buffer is all zero again for its next step)
+    moments_to_gradients(a9, vis ? g.conic_opacity[i] : make_float4(0.f, 0.f, 0.f, 0.f));
     a9[0] *= (float)cam.W; a9[1] *= (float)cam.H;      // (K7 leaves dL/dmean2D without the pixel <- NDC factors 2 * 0.5 W, 2 * 0.5 H)
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
     dL_dconic[4 * i] = a9[2]; dL_dconic[4 * i + 1] = a9[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = a9[4];
@@ -2447,6 +2477,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     float a9[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? a9_n[k] : 0.f;
+    moments_to_gradients(a9, vis ? g.conic_opacity[i] : make_float4(0.f, 0.f, 0.f, 0.f));
     a9[0] *= (float)cam.W; a9[1] *= (float)cam.H;      // (see k_preprocess_bwd)
     if (vi + VL < tab.n) {
         const K8View &wn = tab.v[vi + VL];
