@@ -500,6 +500,7 @@ def main():
                       "what": "one all-reduce(sum) per step over the flat gradient buffer (62 floats per Gaussian + 3 for the "
                               "screen-space gradient); timed alone, after the step's kernels have drained"}
     R_per_view = [0] * V
+    pairs_per_view = []
     if wl is not None:
         with torch.no_grad():
             for i in range(V):
@@ -507,6 +508,24 @@ def main():
                 dgr._RasterizeGaussians.forward(ctx, wl.params["means3D"], None, wl.params["shs"], None, wl.params["opacities"],
                                                 wl.params["scales"], wl.params["rotations"], None, wl.settings[i])
                 R_per_view[i] = ctx.view_state.num_rendered
+                try:        # the (list entry, 4x4 block) pairs K6 marked as blended = the float-atomic requests K7 issues for this view
+                    import ctypes as _C
+                    o11 = (_C.c_size_t * 11)()
+                    native.lib.csplat_binning_fields(int(R_per_view[i]), W, H, o11)
+                    raw = ctx.view_state.chunks[1]
+                    tiles_ = ((W + 15) // 16) * ((H + 15) // 16)
+                    seg_off_ = raw[o11[2]:o11[2] + 4 * (tiles_ + 1)].view(torch.int32).cpu().numpy()
+                    nslots = int(seg_off_[tiles_])
+                    blk_hi_ = raw[o11[2] + 4 * (tiles_ + 1):o11[2] + 4 * (tiles_ + 1) + tiles_ * 64].view(torch.int32).cpu().numpy().reshape(tiles_, 16)
+                    slot_tile_ = raw[o11[3]:o11[3] + 4 * nslots].view(torch.int32).cpu().numpy()
+                    bb = raw[o11[9]:o11[9] + nslots * 16 * 32].cpu().numpy().reshape(nslots, 16, 32)
+                    # (K7 visits the (segment, block) words whose block still blends at or behind the segment -- blk_hi > segment start;
+                    #  the others were never written)
+                    seg_lo_ = (np.arange(nslots) - seg_off_[slot_tile_]) * 256
+                    live_ = blk_hi_[slot_tile_] > seg_lo_[:, None]
+                    pairs_per_view.append(int(np.unpackbits(bb, axis=2).sum(axis=2)[live_].sum()))
+                except Exception:
+                    pairs_per_view.append(None)
 
     # forward-only (evaluation) rate, auxiliary: what the reference's render.py prints as FPS (render.py:195,301: render() under no_grad,
     # camera by camera) -- here the V cameras of the batch per call, K1-K6 only
@@ -660,6 +679,16 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(k7_avg_s * 1e6, 2),
                      "launches_timed": int(k7_n),
                      "views_per_launch": views_per_launch,
+                     # what BINDS K7 (round 6, profiles/r06_k7_elimination.txt): its float atomics execute at the memory side at one
+                     # chip-wide rate, ~1.3 TB/s priced per 64-byte request (MI355X_MICROARCH.md, Global float atomics); K7 issues ONE
+                     # request per (list entry, 4x4 block) pair that blended (counted here from K6's bbits words of this workload)
+                     "atomics": None if (not pairs_per_view or any(p_ is None for p_ in pairs_per_view) or k7_avg_s <= 0) else {
+                         "requests_per_launch": int(sum(pairs_per_view) * views_per_launch / max(len(pairs_per_view), 1)),
+                         "bytes_per_request_priced": 64, "peak_GBps": 1300.0,
+                         "achieved_GBps": round(sum(pairs_per_view) * views_per_launch / max(len(pairs_per_view), 1) * 64 / k7_avg_s / 1e9, 1),
+                         "frac": round(sum(pairs_per_view) * views_per_launch / max(len(pairs_per_view), 1) * 64 / k7_avg_s / 1e9 / 1300.0, 4),
+                         "what": "the resource that binds K7: memory-side float-atomic requests against the measured chip-wide rate; the "
+                                 "kernel takes 161 us with the atomics compiled out (elimination build), 211 with them"},
                      "issue_frac": issue(k7_avg_s * 1e6),
                      "issue_note": "VALU wave-instructions of this launch (SQ_INSTS_VALU of the committed counter pass) x 3.3 cycles (the "
                                    "instruction mix of K7's loop priced with tools/valu_rate.hip: 2.3 plain / 4.2 DPP, compare, select, "

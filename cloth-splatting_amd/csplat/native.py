@@ -34,6 +34,7 @@ EXPORTS = {
     "csplat_backward_scratch_bytes": (_sz, [_i, _i64]),
     "csplat_geom_layout": (_i, [_i, C.POINTER(_sz)]),
     "csplat_binning_layout": (_i, [_i64, _i, _i, C.POINTER(_sz)]),
+    "csplat_binning_fields": (_i, [_i64, _i, _i, C.POINTER(_sz)]),
     "csplat_image_layout": (_i, [_i, _i, C.POINTER(_sz)]),
     "csplat_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                             _i, ALLOC_FN, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp),

@@ -2457,8 +2457,10 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     // processed: otherwise the thread walks V dependent load -> compute rounds
     bool vis_n = false;
     float a9_n[9];
+    float4 co_n = make_float4(0.f, 0.f, 0.f, 0.f);       // (the view's conic + opacity travel with its record: moments_to_gradients)
     if (vl < tab.n) {
         vis_n = tab.v[vl].radii[i] > 0;
+        co_n = tab.v[vl].g.conic_opacity[i];
 #pragma unroll
         for (int k = 0; k < 9; k++) a9_n[k] = tab.v[vl].acc[(size_t)i * ACC_STRIDE + k];
         if (vis_n && (tab.v[vl].accmask & CSPLAT_SCRATCH_ZEROED)) clear_record(tab.v[vl].acc, i);
@@ -2477,13 +2479,14 @@ __global__ __launch_bounds__(NT) void k_preprocess_bwd_views(int P, int D, int M
     float a9[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) a9[k] = vis ? a9_n[k] : 0.f;
-    moments_to_gradients(a9, vis ? g.conic_opacity[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+    moments_to_gradients(a9, vis ? co_n : make_float4(0.f, 0.f, 0.f, 0.f));
     a9[0] *= (float)cam.W; a9[1] *= (float)cam.H;      // (see k_preprocess_bwd)
     if (vi + VL < tab.n) {
         const K8View &wn = tab.v[vi + VL];
         vis_n = wn.radii[i] > 0;
 #pragma unroll
         for (int k = 0; k < 9; k++) a9_n[k] = wn.acc[(size_t)i * ACC_STRIDE + k];
+        co_n = wn.g.conic_opacity[i];
         if (vis_n && (wn.accmask & CSPLAT_SCRATCH_ZEROED)) clear_record(wn.acc, i);
     }
     dL_dmean2D[3 * i] = a9[0]; dL_dmean2D[3 * i + 1] = a9[1]; dL_dmean2D[3 * i + 2] = 0.f;
@@ -2894,6 +2897,10 @@ size_t csplat_backward_scratch_bytes(int P, int64_t R) {
     return align256((size_t)(P > 0 ? P : 1) * ACC_STRIDE * 4) + ((g_debug_flags & 256u) ? det_bytes(R) : 0);
 }
 int csplat_geom_layout(int P, size_t *o8) { size_t off[G_NFIELDS]; geom_offsets(P, off); for (int k = 0; k < 8; k++) o8[k] = off[k]; return 0; }
+// every sub-buffer of the BINNING chunk (csplat.h: csplat_binning_fields): 0 keys 1 ids 2 seg_offset + blk_hi 3 slot_tile 4 checkpoints
+// 5 masks 6-8 records A / B / C 9 bbits 10 bmask; o11[11] = byte offsets for a chunk laid out for R list entries (diagnostics: tools/,
+// bench.py's count of K7's atomic requests)
+int csplat_binning_fields(int64_t R, int W, int H, size_t *o11) { binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), o11); return 0; }
 int csplat_binning_layout(int64_t R, int W, int H, size_t *o2) { size_t off[B_NFIELDS]; binning_offsets(R, cdiv(W, CSPLAT_TILE) * cdiv(H, CSPLAT_TILE), off); o2[0] = off[0]; o2[1] = off[1]; return 0; }
 int csplat_image_layout(int W, int H, size_t *o3) { size_t off[5]; image_offsets(W, H, off); o3[0] = off[0]; o3[1] = off[1]; o3[2] = off[2]; return 0; }
 

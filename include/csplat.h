@@ -90,6 +90,11 @@ size_t csplat_backward_scratch_bytes(int P, int64_t R); /* per-Gaussian accumula
  * image:   0 ranges i32[tiles][2] | 1 n_contrib u32[H*W] | 2 final_T f32[H*W]                               */
 int csplat_geom_layout(int P, size_t *offsets8);
 int csplat_binning_layout(int64_t R, int W, int H, size_t *offsets2);
+/* byte offsets of ALL eleven sub-buffers of a BINNING chunk laid out for R list entries: 0 sorted keys, 1 sorted ids, 2 seg_offset[tiles + 1]
+ * followed by blk_hi[tiles][16], 3 slot_tile, 4 checkpoints, 5 block masks, 6-8 the tile-ordered records, 9 bbits u64[slots][16][4] (which
+ * entries of a 256-entry segment a 4x4 block blended), 10 bmask.  Diagnostics only (tools/k6_stats.py, bench.py's count of the (entry,
+ * block) pairs = K7's float-atomic requests). */
+int csplat_binning_fields(int64_t R, int W, int H, size_t *o11);
 int csplat_image_layout(int W, int H, size_t *offsets3);
 
 /* Forward: K1 preprocess (+ per-tile counts), K2 tile scan, K3 instance emission into tile buckets, K4 per-tile LDS sort
