@@ -60,3 +60,8 @@ struct ProfScope {
     ProfScope(int c, hipStream_t st) : cls(c), s(st), on((g_csplat_prof_mask >> c) & 1u) { if (on) csplat_prof_mark(cls, s, true); }
     ~ProfScope() { if (on) csplat_prof_mark(cls, s, false); }
 };
+
+// ReLU as torch applies it: a NaN stays a NaN.  fmaxf(x, 0) (v_max_f32) returns 0 for a NaN -- and an overflow of the fp16-piece kernels
+// upstream (csplat_edge_mlp.hip) would be laundered into finite garbage by the next layer's ReLU; round 6: every ReLU of the library lets
+// it through, so that it reaches the output where it is detected (meshnet/graph_network.py, meshnet/rollout.py).
+__device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }

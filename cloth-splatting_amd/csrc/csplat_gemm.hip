@@ -271,7 +271,7 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
                 each([&](float a, int, int, int) { return alpha * a; });
             }
             if (add_pre) { float4 t[16]; row4(add_pre, t); each([&](float a, int i, int j, int) { return a + comp(t[i], j); }); }
-            if (relu) each([&](float a, int, int, int) { return fmaxf(a, 0.f); });
+            if (relu) each([&](float a, int, int, int) { return relu_keep_nan(a); });
             if (add_post) { float4 t[16]; row4(add_post, t); each([&](float a, int i, int j, int) { return a + comp(t[i], j); }); }
             if (mask) { float4 t[16]; row4(mask, t); each([&](float a, int i, int j, int) { return comp(t[i], j) > 0.f ? a : 0.f; }); }
             if (live) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(B3 ? 512 : 256, 2) void k_linear128(int64_t M, cons
             }
             if (relu) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = fmaxf(v[c], 0.f);
+                for (int c = 0; c < 4; c++) v[c] = relu_keep_nan(v[c]);
             }
             if (LN) {
                 float sum = (v[0] + v[1]) + (v[2] + v[3]);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_linear128_rows32(int64_t M, const float
         orow = orow < M ? orow : M - 1;
         v[r] = alpha * acc[r] + bcol;
         if (add_pre) v[r] += add_pre[orow * GN + col];
-        if (relu) v[r] = fmaxf(v[r], 0.f);
+        if (relu) v[r] = relu_keep_nan(v[r]);
     }
     if (LN) {
         float mean[16];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_node_update(int64_t N, const float *__r
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             float v = acc[r] + bv;
-            s_act[(r & 3) + 8 * (r >> 2) + 4 * h][col] = relu ? fmaxf(v, 0.f) : v;
+            s_act[(r & 3) + 8 * (r >> 2) + 4 * h][col] = relu ? relu_keep_nan(v) : v;
         }
     };
     float4 X[16], X2[16];
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_linear_narrow(int64_t M, int K, const f
                 const float4 w = sWt[k * 32 + g];
                 a.x = fmaf(v, w.x, a.x); a.y = fmaf(v, w.y, a.y); a.z = fmaf(v, w.z, a.z); a.w = fmaf(v, w.w, a.w);
             }
-            if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (RELU) { a.x = relu_keep_nan(a.x); a.y = relu_keep_nan(a.y); a.z = relu_keep_nan(a.z); a.w = relu_keep_nan(a.w); }
             *reinterpret_cast<float4 *>(out + row * 128 + 4 * g) = a;
         }
     }
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256, 1) void k_dw128(int64_t M, const float4 *__res
             float b[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
             if (XRELU) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) b[j] = fmaxf(b[j], 0.f);
+                for (int j = 0; j < 4; j++) b[j] = relu_keep_nan(b[j]);
             }
             if (BIAS) { gsum.x += a[0]; gsum.y += a[1]; gsum.z += a[2]; gsum.w += a[3]; }
 #pragma unroll

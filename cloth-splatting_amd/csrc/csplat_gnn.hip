@@ -53,11 +53,95 @@ __global__ __launch_bounds__(256) void k_edge_features(int64_t E, const float *_
     out[e] = make_float4(dx, dy, dz, sqrtf(dx * dx + dy * dy + dz * dz));
 }
 
+// (the same features for the edges in ANOTHER order: row r of `out` = edge order[r] -- the rollout encodes its edges in destination order)
+__global__ __launch_bounds__(256) void k_edge_features_ordered(int64_t E, const float *__restrict__ pos, const int64_t *__restrict__ ei,
+                                                                const int64_t *__restrict__ order, float4 *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= E) return;
+    const int64_t e = order[q];
+    const int64_t r = ei[e], c = ei[E + e];
+    const float dx = pos[3 * r] - pos[3 * c], dy = pos[3 * r + 1] - pos[3 * c + 1], dz = pos[3 * r + 2] - pos[3 * c + 2];
+    out[q] = make_float4(dx, dy, dz, sqrtf(dx * dx + dy * dy + dz * dz));
+}
+
+// ---- the rollout step's head and tail (round 6: no stock launch is left in a recorded rollout step).  Reference: the feature assembly of
+// /root/reference/meshnet/cloth_network.py:72-110 (cat(velocity history, one_hot(node type)) -> node normaliser), the de-normalisation and
+// v_next = v[:, -3:] + acc of :163-193, and the loop's pinning / integration / history shift, train_meshnet_sim.py:176,256-262.
+// Elementwise arithmetic in the order torch's own ops apply it ((x - mean) / std; y * std + mean; then + v): no contraction.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_rollout_head(int N, int H, int T, const float *__restrict__ hist, const int *__restrict__ node_type,
+                                                       const float *__restrict__ mean, const float *__restrict__ stdv,
+                                                       float *__restrict__ feats, int *__restrict__ counter) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n == 0 && counter) *counter += 1;            // (the step's number + 1: k_rollout_integrate reads it behind this launch)
+    if (n >= N) return;
+    const int F = 3 * H + T;
+    float *o = feats + (size_t)n * F;
+    for (int h = 0; h < H; h++)
+        for (int c = 0; c < 3; c++) {
+            const int j = 3 * h + c;
+            const float x = hist[((size_t)h * N + n) * 3 + c];
+            o[j] = mean ? (x - mean[j]) / stdv[j] : x;
+        }
+    const int ty = node_type[n];
+    for (int t = 0; t < T; t++) {
+        const int j = 3 * H + t;
+        const float x = ty == t ? 1.f : 0.f;
+        o[j] = mean ? (x - mean[j]) / stdv[j] : x;
+    }
+}
+// decoder's last Linear (128 -> D <= 4) + de-normalisation + v_next = last velocity + acceleration; *fine is cleared by a non-finite row
+__global__ __launch_bounds__(256) void k_rollout_decode(int N, int D, const float *__restrict__ h, const float *__restrict__ W,
+                                                         const float *__restrict__ b, const float *__restrict__ omean,
+                                                         const float *__restrict__ ostd, const float *__restrict__ last_v,
+                                                         float *__restrict__ v, int *__restrict__ fine) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float4 *row = reinterpret_cast<const float4 *>(h + (size_t)n * 128);
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k4 = 0; k4 < 32; k4++) {
+        const float4 a = row[k4];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (d < D) {
+                const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)d * 128 + 4 * k4);
+                y[d] = y[d] + a.x * w.x; y[d] = y[d] + a.y * w.y; y[d] = y[d] + a.z * w.z; y[d] = y[d] + a.w * w.w;
+            }
+    }
+    bool ok = true;
+    for (int d = 0; d < D; d++) {
+        float a = y[d] + b[d];
+        if (omean) a = a * ostd[d] + omean[d];
+        const float r = last_v[(size_t)n * D + d] + a;
+        v[(size_t)n * D + d] = r;
+        ok = ok && (r - r == 0.f);
+    }
+    if (!ok) *fine = 0;
+}
+// pin the grasped node to the step's action, leave the step's row of the predictions, integrate, shift the velocity history
+__global__ __launch_bounds__(256) void k_rollout_integrate(int N, int H, int D, float *__restrict__ v, const float *__restrict__ actions,
+                                                            const int *__restrict__ counter, long long grasped, float *__restrict__ pos,
+                                                            float *__restrict__ hist, float *__restrict__ preds) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int k = *counter - 1;
+    for (int d = 0; d < D; d++) {
+        const size_t j = (size_t)n * D + d;
+        const float val = (long long)n == grasped ? actions[(size_t)k * D + d] : v[j];
+        v[j] = val;
+        preds[(size_t)k * N * D + j] = val;
+        pos[j] = pos[j] + val;
+        for (int h = 0; h + 1 < H; h++) hist[(size_t)h * N * D + j] = hist[(size_t)(h + 1) * N * D + j];
+        hist[(size_t)(H - 1) * N * D + j] = val;
+    }
+}
+#pragma clang fp contract(fast)
+
 // row movers are templated on the per-lane vector: float4 (16 B/lane) when L % 4 == 0, float otherwise
 __device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float vadd(float a, float b) { return a + b; }
-__device__ __forceinline__ float4 vrelu(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
-__device__ __forceinline__ float vrelu(float a) { return fmaxf(a, 0.f); }
+__device__ __forceinline__ float4 vrelu(float4 a) { return make_float4(relu_keep_nan(a.x), relu_keep_nan(a.y), relu_keep_nan(a.z), relu_keep_nan(a.w)); }
+__device__ __forceinline__ float vrelu(float a) { return relu_keep_nan(a); }
 __device__ __forceinline__ float4 vmask(float4 g, float4 o) {
     return make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
 }
@@ -206,6 +290,40 @@ int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const in
     CSPLAT_REQUIRE(((uintptr_t)out & 15u) == 0, "csplat_gnn_edge_features: out must be 16-byte aligned");
     if (E == 0) return 0;
     k_edge_features<<<cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, (float4 *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, const int64_t *edge_index, const int64_t *order, float *out) {
+    CSPLAT_REQUIRE(E >= 0 && (E == 0 || (pos && edge_index && order && out)), "csplat_gnn_edge_features_ordered: bad arguments");
+    CSPLAT_REQUIRE(((uintptr_t)out & 15u) == 0, "csplat_gnn_edge_features_ordered: out must be 16-byte aligned");
+    if (E == 0) return 0;
+    k_edge_features_ordered<<<cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, order, (float4 *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+int csplat_rollout_head(void *stream, int N, int H, int T, const float *hist, const int32_t *node_type, const float *mean, const float *stdv,
+                        float *feats, int32_t *counter) {
+    CSPLAT_REQUIRE(N >= 0 && H >= 1 && H <= 16 && T >= 0 && T <= 16 && (N == 0 || (hist && node_type && feats)) && ((mean == nullptr) == (stdv == nullptr)),
+                   "csplat_rollout_head: bad arguments");
+    k_rollout_head<<<cdiv(N > 0 ? N : 1, 256), 256, 0, (hipStream_t)stream>>>(N, H, T, hist, node_type, mean, stdv, feats, counter);
+    LAUNCH_CHECK();
+    return 0;
+}
+int csplat_rollout_decode(void *stream, int N, int D, const float *h, const float *W, const float *b, const float *omean, const float *ostd,
+                          const float *last_v, float *v, int32_t *fine) {
+    CSPLAT_REQUIRE(N >= 0 && D >= 1 && D <= 4 && (N == 0 || (h && W && b && last_v && v && fine)) && ((omean == nullptr) == (ostd == nullptr)),
+                   "csplat_rollout_decode: bad arguments");
+    CSPLAT_REQUIRE((((uintptr_t)h | (uintptr_t)W) & 15u) == 0, "csplat_rollout_decode: h and W must be 16-byte aligned");
+    if (N == 0) return 0;
+    k_rollout_decode<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, D, h, W, b, omean, ostd, last_v, v, fine);
+    LAUNCH_CHECK();
+    return 0;
+}
+int csplat_rollout_integrate(void *stream, int N, int H, int D, float *v, const float *actions, const int32_t *counter, int64_t grasped,
+                             float *pos, float *hist, float *preds) {
+    CSPLAT_REQUIRE(N >= 0 && H >= 1 && D >= 1 && D <= 4 && (N == 0 || (v && actions && counter && pos && hist && preds)), "csplat_rollout_integrate: bad arguments");
+    if (N == 0) return 0;
+    k_rollout_integrate<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, H, D, v, actions, counter, (long long)grasped, pos, hist, preds);
     LAUNCH_CHECK();
     return 0;
 }

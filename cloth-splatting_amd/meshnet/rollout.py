@@ -29,7 +29,7 @@ def edge_features(pos, edge_index):
     return torch.cat([d, d.norm(dim=1, keepdim=True)], 1)
 
 
-def refine_edge_lengths(pos, v, edge_index, rest_len, grasped_particle=None, iters=10, lr=1e-3, edge_w=None):
+def refine_edge_lengths(pos, v, edge_index, rest_len, grasped_particle=None, iters=10, lr=1e-3, edge_w=None, in_place=False):
     """The `real_world` branch of the reference's rollout (/root/reference/train_meshnet_sim.py:211-250), per rollout step: `iters`
     iterations of a FRESH torch.optim.Adam(lr) on the predicted velocities v [N,3] against
         sum_e (|(pos + v)[edge_index[0][e]] - (pos + v)[edge_index[1][e]]| - rest_len[e])^2
@@ -42,7 +42,7 @@ def refine_edge_lengths(pos, v, edge_index, rest_len, grasped_particle=None, ite
         dev = v.device
         N = int(v.shape[0])
         csr = GraphCSR.get(edge_index, N)
-        out = v.detach().clone().contiguous()
+        out = v if (in_place and v.is_contiguous()) else v.detach().clone().contiguous()      # (in_place: the kernel updates v itself)
         w = edge_w          # (a rollout builds the weights once for all its steps)
         if w is None and grasped_particle is not None and E > 0:
             w = torch.ones(E, dtype=torch.float32, device=dev)
@@ -79,6 +79,8 @@ import os as _os
 # the rollout loop recorded: one eager step (weight images packed, caches filled), one step recorded into a hipGraph, the rest replays.
 # CSPLAT_ROLLOUT_GRAPH=0 keeps the launch-by-launch loop.
 ROLLOUT_GRAPH = _os.environ.get("CSPLAT_ROLLOUT_GRAPH", "1") not in ("", "0")
+# a ClothMeshSimulator at latent 128 in eval mode: the step as library launches only (_FusedClothStep); CSPLAT_ROLLOUT_FUSED=0: the generic step
+FUSED_STEP = _os.environ.get("CSPLAT_ROLLOUT_FUSED", "1") not in ("", "0")
 ROLLOUT_STATS = {"eager_steps": 0, "replayed_steps": 0, "recorded": 0, "record_failed": 0, "repeated_bf16": 0}
 
 
@@ -97,6 +99,166 @@ def _step_body(simulator, pos, hist, act, node_type, edge_index, grasped_particl
     if H > 1:
         hist[:H - 1] = hist[1:].clone()
     hist[-1] = v_next
+
+
+class _FusedClothStep:
+    """One rollout step of a ClothMeshSimulator (latent 128, the fused inference kernels) as LIBRARY LAUNCHES ONLY (round 6): head
+    (history + node type -> normalised node features), edge features in destination order, the two encoder launches, the processor's
+    30 launches, the decoder's two hidden layers (csplat_linear128), decode (last Linear + de-normalisation + last velocity + finite
+    check), [edge-length refinement], integrate (pin, predictions row, positions, history shift).  The step number lives on the device
+    (the head launch counts it up; integrate reads the step's action and writes the step's row of the predictions by it), so a recorded
+    step needs NOTHING from the host per step.  State buffers belong to this object."""
+
+    @staticmethod
+    def applicable(sim, positions, velocity_history, node_type, edge_index, actions, grasped_particle):
+        from .cloth_network import ClothMeshSimulator
+        from .graph_network import ENCODER_FUSED
+        from .graph_ops import edge_mlp3_mode
+        if not (isinstance(sim, ClothMeshSimulator) and not sim.training and isinstance(grasped_particle, int) and positions.is_cuda):
+            return False
+        epd = sim._encode_process_decode
+        if getattr(epd, "_bf16_latched", False) or edge_mlp3_mode() != 0 or not ENCODER_FUSED:
+            return False
+        if not (positions.dtype == torch.float32 and velocity_history.dtype == torch.float32 and actions.dtype == torch.float32 and
+                positions.dim() == 2 and positions.shape[1] == 3 and velocity_history.dim() == 3 and velocity_history.shape[2] == 3 and
+                actions.dim() == 2 and actions.shape[1] == 3 and edge_index.dtype == torch.int64 and int(edge_index.shape[1]) > 0):
+            return False
+        N, H, T = int(positions.shape[0]), int(velocity_history.shape[0]), int(sim._node_type_embedding_size)
+        F = 3 * H + T
+        lins_n = list(epd._encoder.node_fn[0].children())[0::2]
+        lins_e = list(epd._encoder.edge_fn[0].children())[0::2]
+        dec = list(epd._decoder.node_fn.children())[0::2]
+        if not (F % 4 == 0 and F <= 32 and len(lins_n) == 3 and len(lins_e) == 3 and tuple(lins_n[0].weight.shape) == (128, F) and
+                tuple(lins_e[0].weight.shape) == (128, 4) and len(dec) == 3 and tuple(dec[0].weight.shape) == (128, 128) and
+                tuple(dec[1].weight.shape) == (128, 128) and tuple(dec[2].weight.shape) == (3, 128) and dec[2].weight.is_contiguous() and
+                all(isinstance(a, torch.nn.ReLU) for a in list(epd._decoder.node_fn.children())[1:4:2]) and node_type.numel() == N):
+            return False
+        # (the processor's one-launch kernels in destination order: asked on tensors of the right shape)
+        probe_x = torch.empty(N, 128, dtype=torch.float32, device=positions.device)
+        probe_e = torch.empty(int(edge_index.shape[1]), 128, dtype=torch.float32, device=positions.device)
+        with torch.no_grad():
+            return epd._processor.takes_destination_order(probe_x, probe_e)
+
+    def __init__(self, sim, positions, velocity_history, node_type, edge_index, cap, grasped_particle, real_world):
+        from .graph_ops import GraphCSR
+        dev = positions.device
+        self.sim, self.epd = sim, sim._encode_process_decode
+        self.N, self.H, self.T = int(positions.shape[0]), int(velocity_history.shape[0]), int(sim._node_type_embedding_size)
+        self.F, self.E, self.cap = 3 * self.H + self.T, int(edge_index.shape[1]), int(cap)
+        self.edge_index, self.grasped, self.real_world = edge_index, int(grasped_particle), bool(real_world)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.pos = torch.empty(self.N, 3, **f32)
+        self.hist = torch.empty(self.H, self.N, 3, **f32)
+        self.v = torch.empty(self.N, 3, **f32)
+        self.feats = torch.empty(self.N, self.F, **f32)
+        self.ef = torch.empty(self.E, 4, **f32)
+        self.actions = torch.zeros(self.cap, 3, **f32)
+        self.preds = torch.empty(self.cap, self.N, 3, **f32)
+        self.nt = node_type.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.fine = torch.ones(1, dtype=torch.int32, device=dev)
+        self.norm = {k: torch.empty(n_, **f32) for k, n_ in (("nm", self.F), ("ns", self.F), ("om", 3), ("os", 3))}
+        self.has_node_norm = self.has_out_norm = False
+        self.csr = GraphCSR.get(edge_index, self.N)
+        self.plan = self.csr.agg_plan()
+        self.L0 = torch.empty(self.E, **f32) if real_world else None
+        self.edge_w = None
+        if real_world:
+            self.edge_w = torch.ones(self.E, **f32)
+            self.edge_w[self.grasped] = 0.0          # (`length_deviation[grasped_particle] *= 0`, train_meshnet_sim.py:234)
+        self.graph = None
+
+    def begin(self, positions, velocity_history, actions, original_edge_lengths):
+        """the state of a new rollout -> the buffers (stock copies, once per rollout); the normalisers' statistics as plain vectors"""
+        from .model_utils import Normalizer
+        self.pos.copy_(positions); self.hist.copy_(velocity_history)
+        self.actions[:actions.shape[0]].copy_(actions)
+        self.counter.zero_(); self.fine.fill_(1)
+        if self.L0 is not None:
+            self.L0.copy_(original_edge_lengths)
+        nn_, on_ = self.sim._node_normalizer, self.sim._output_normalizer
+        self.has_node_norm, self.has_out_norm = isinstance(nn_, Normalizer), isinstance(on_, Normalizer)
+        if self.has_node_norm:
+            self.norm["nm"].copy_(nn_._mean().reshape(-1)); self.norm["ns"].copy_(nn_._std_with_epsilon().reshape(-1))
+        if self.has_out_norm:
+            self.norm["om"].copy_(on_._mean().reshape(-1)); self.norm["os"].copy_(on_._std_with_epsilon().reshape(-1))
+
+    def step(self):
+        from .graph_ops import linear128
+        dev = self.pos.device
+        st = _n.stream_handle(dev)
+        epd, N, H, T = self.epd, self.N, self.H, self.T
+        nm, ns = (self.norm["nm"], self.norm["ns"]) if self.has_node_norm else (None, None)
+        om, os_ = (self.norm["om"], self.norm["os"]) if self.has_out_norm else (None, None)
+        with _n.on_device(dev):
+            _n.check(_n.lib.csplat_rollout_head(st, N, H, T, _n.ptr(self.hist), _n.ptr(self.nt), _n.ptr(nm), _n.ptr(ns), _n.ptr(self.feats),
+                                                _n.ptr(self.counter)), "csplat_rollout_head")
+            _n.check(_n.lib.csplat_gnn_edge_features_ordered(st, self.E, _n.ptr(self.pos), _n.ptr(self.csr.ei), _n.ptr(self.plan["perm"]),
+                                                             _n.ptr(self.ef)), "csplat_gnn_edge_features_ordered")
+        xe, ee = epd._encoder(self.feats, self.ef)
+        xp, _e = epd._processor(xe, self.edge_index, ee, edges_out=False, dst_order=(self.plan, epd._edge_latent_bound()))
+        dec = list(epd._decoder.node_fn.children())[0::2]
+        h = linear128(xp, dec[0].weight, dec[0].bias, relu=True)
+        h = linear128(h, dec[1].weight, dec[1].bias, relu=True, out=h)
+        last = self.hist[H - 1]
+        with _n.on_device(dev):
+            _n.check(_n.lib.csplat_rollout_decode(st, N, 3, _n.ptr(h), _n.ptr(dec[2].weight.detach()), _n.ptr(dec[2].bias.detach().contiguous()),
+                                                  _n.ptr(om), _n.ptr(os_), _n.ptr(last), _n.ptr(self.v), _n.ptr(self.fine)), "csplat_rollout_decode")
+        if self.real_world:
+            refine_edge_lengths(self.pos, self.v, self.edge_index, self.L0, self.grasped, edge_w=self.edge_w, in_place=True)
+        with _n.on_device(dev):
+            _n.check(_n.lib.csplat_rollout_integrate(st, N, H, 3, _n.ptr(self.v), _n.ptr(self.actions), _n.ptr(self.counter), self.grasped,
+                                                     _n.ptr(self.pos), _n.ptr(self.hist), _n.ptr(self.preds)), "csplat_rollout_integrate")
+
+
+def _rollout_fused(simulator, positions, velocity_history, node_type, edge_index, actions, grasped_particle, nsteps, real_world,
+                   original_edge_lengths, use_graph):
+    """rollout() on _FusedClothStep: every step a replay of ONE recorded step that holds library kernels only (the first rollout of a
+    combination runs its step 0 launch by launch and records its step 1); None when an overflow made the module switch arithmetic"""
+    dev = positions.device
+    cap = max(64, 1 << max(int(nsteps) - 1, 0).bit_length())
+    base = _rollout_key(simulator, positions, velocity_history, node_type, edge_index, actions, grasped_particle, real_world)
+    key = None if base is None else base + ("fused", cap)
+    ent = _ROLLOUT_CACHE.get(key) if key is not None else None
+    if ent is None:
+        fs = _FusedClothStep(simulator, positions, velocity_history, node_type, edge_index, cap, grasped_particle, real_world)
+        ent = {"fused": fs, "keep": (simulator, edge_index, node_type)}
+        if key is not None:
+            while len(_ROLLOUT_CACHE) >= _ROLLOUT_CACHE_MAX:
+                _ROLLOUT_CACHE.pop(next(iter(_ROLLOUT_CACHE)))
+            _ROLLOUT_CACHE[key] = ent
+    fs = ent["fused"]
+    fs.begin(positions, velocity_history, actions, original_edge_lengths)
+    for step in range(nsteps):
+        if use_graph and fs.graph is not None:
+            fs.graph.replay()
+            ROLLOUT_STATS["replayed_steps"] += 1
+        elif use_graph and key is not None and step == 1:
+            try:
+                from csplat.graphs import capture
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with capture(g):
+                    fs.step()
+                fs.graph = g
+                ROLLOUT_STATS["recorded"] += 1
+                g.replay()
+                ROLLOUT_STATS["replayed_steps"] += 1
+            except Exception:
+                fs.graph, use_graph = None, False
+                ROLLOUT_STATS["record_failed"] += 1
+                torch.cuda.synchronize(dev)
+                fs.step()
+                ROLLOUT_STATS["eager_steps"] += 1
+        else:
+            fs.step()
+            ROLLOUT_STATS["eager_steps"] += 1
+    preds, pos = fs.preds[:nsteps].clone(), fs.pos.clone()
+    if int(fs.fine.item()) == 0:          # (the one host read of the rollout)
+        simulator._encode_process_decode.latch_bf16()
+        _ROLLOUT_CACHE.pop(key, None)
+        return None
+    return preds, pos
 
 
 # recorded steps are kept across rollout() calls (recording costs ~40 ms: a collection pass, the capture, the instantiation -- two steps'
@@ -145,6 +307,12 @@ def rollout(simulator, positions, velocity_history, node_type, edge_index, actio
     dev = positions.device
     use_graph = (ROLLOUT_GRAPH if graph is None else bool(graph)) and positions.is_cuda and nsteps >= 4
     N = positions.shape[0]
+    if nsteps > 0 and FUSED_STEP and _FusedClothStep.applicable(simulator, positions, velocity_history, node_type, edge_index, actions, grasped_particle):
+        res = _rollout_fused(simulator, positions, velocity_history, node_type, edge_index, actions, grasped_particle, nsteps, real_world,
+                             original_edge_lengths, use_graph)
+        if res is not None:
+            return res
+        ROLLOUT_STATS["repeated_bf16"] += 1          # (a step left fp16's range: the module now runs bf16 pieces -- the generic loop below)
     for attempt in range(2):
         key = _rollout_key(simulator, positions, velocity_history, node_type, edge_index, actions, grasped_particle, real_world) if use_graph else None
         ent = _ROLLOUT_CACHE.get(key) if key is not None else None

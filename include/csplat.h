@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CSPLAT_ABI_VERSION 6   /* 6 (round 6): csplat_backward_views_parts / _slice_rows, csplat_gnn_edge_length_refine; round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
+#define CSPLAT_ABI_VERSION 6   /* 6 (round 6): csplat_backward_views_parts / _slice_rows, csplat_gnn_edge_length_refine, csplat_rollout_head / _decode / _integrate, csplat_gnn_edge_features_ordered, csplat_binning_fields; round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
 
 /* scratch chunks requested through the allocator callback */
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
@@ -446,6 +446,22 @@ int csplat_gnn_gather_rows_absmax(void *stream, int64_t E, int L, const float *r
  * /root/reference/train_meshnet_sim.py:152 and dataloader_sim.py): out[e] = (pos[row] - pos[col], |pos[row] - pos[col]|) with
  * row = edge_index[0][e], col = edge_index[1][e]; pos [N][3], out [E][4] (16-byte aligned). */
 int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const int64_t *edge_index, float *out);
+/* csplat_gnn_edge_features for the edges in another order: row r of out = the features of edge order[r] (the rollout encodes its edges in the
+ * destination order of GraphCSR.agg_plan: a permuted read of the [E] index pairs instead of a gather of [E][4] rows afterwards). */
+int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, const int64_t *edge_index, const int64_t *order, float *out);
+/* Head and tail of ONE rollout step of ClothMeshSimulator around the network's launches (round 6: a recorded step holds library kernels only).
+ *   head:      feats[n] = normalise(cat(hist[0][n], .., hist[H-1][n], one_hot(node_type[n], T)))   (/root/reference/meshnet/cloth_network.py:72-110;
+ *              mean / std [3H + T] or both NULL = IdentityNormalizer); also *counter += 1 (the step's number + 1, device side)
+ *   decode:    v[n] = last_v[n] + denormalise(W h[n] + b)   (the decoder's last Linear 128 -> D <= 4 and cloth_network.py:163-193); *fine = 0
+ *              when a row is not finite (the fp16-piece arithmetic's overflow signal, meshnet/graph_network.py)
+ *   integrate: v[grasped] = actions[*counter - 1]; preds[*counter - 1] = v; pos += v; hist <- (hist[1:], v)
+ *              (/root/reference/train_meshnet_sim.py:176,256-262).  hist [H][N][D], pos / v [N][D], actions / preds [steps][..]. */
+int csplat_rollout_head(void *stream, int N, int H, int T, const float *hist, const int32_t *node_type, const float *mean, const float *stdv,
+                        float *feats, int32_t *counter);
+int csplat_rollout_decode(void *stream, int N, int D, const float *h, const float *W, const float *b, const float *omean, const float *ostd,
+                          const float *last_v, float *v, int32_t *fine);
+int csplat_rollout_integrate(void *stream, int N, int H, int D, float *v, const float *actions, const int32_t *counter, int64_t grasped,
+                             float *pos, float *hist, float *preds);
 /* The `real_world` branch of the rollout (/root/reference/train_meshnet_sim.py:211-250: per rollout step, ten iterations of a fresh
  * torch.optim.Adam(lr = 1e-3) on the predicted velocities against sum_e w_e (|(pos + v)[row_e] - (pos + v)[col_e]| - rest_len_e)^2).
  * v [N][3] is updated in place; edge_w [E] or NULL (the reference zeroes ONE deviation: `length_deviation[grasped_particle] *= 0`);

@@ -1265,3 +1265,43 @@ def test_rollout_repeats_with_bf16_pieces_after_an_overflow():
     finally:
         edge_mlp3_mode(was)
     assert torch.equal(pred, ref_pred) and torch.equal(pos_end, ref_pos)
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_fused_rollout_step_equals_the_module_path(normalize):
+    """meshnet.rollout._FusedClothStep (round 6: the rollout step as library launches only -- head, ordered edge features, encoders,
+    processor, decoder layers, decode, integrate; the step number on the device) against the generic step that calls
+    ClothMeshSimulator.predict_velocity and stock tensor operations (CSPLAT_ROLLOUT_FUSED=0's path), with and without trained-like
+    normaliser statistics: predictions and final positions to 1e-5 of their scale (the decoder's last Linear and the 128-wide layers sum
+    in another order than the library GEMMs), the grasped node pinned exactly.  Reference: cloth_network.py:72-193,
+    train_meshnet_sim.py:126-265."""
+    from meshnet import rollout as ro
+    from meshnet.cloth_network import ClothMeshSimulator
+    dev = "cuda"
+    g = torch.Generator().manual_seed(41)
+    N, E = 1200, 15_000
+    pos = torch.randn(N, 3, generator=g).to(dev)
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)]).to(dev)
+    torch.manual_seed(9)
+    sim = ClothMeshSimulator(3, 8, 4, 128, 3, 2, 128, 2, 2, normalize=normalize, device=dev)
+    if normalize:            # statistics as a few training batches would leave them
+        sim.train()
+        with torch.no_grad():
+            for _ in range(3):
+                sim._node_normalizer(torch.randn(N, 8, generator=g).to(dev) * 0.3 + 0.1, True)
+                sim._output_normalizer(torch.randn(N, 3, generator=g).to(dev) * 0.02, True)
+    sim.eval()
+    hist = (torch.randn(2, N, 3, generator=g) * 0.01).to(dev)
+    ntype = torch.randint(0, 2, (N, 1), generator=g).to(dev)
+    actions = (torch.randn(6, 3, generator=g) * 0.01).to(dev)
+    assert ro._FusedClothStep.applicable(sim, pos, hist, ntype, ei, actions, 5)
+    a_pred, a_pos = ro.rollout(sim, pos, hist, ntype, ei, actions, 5, 6)
+    was = ro.FUSED_STEP
+    ro.FUSED_STEP = False
+    try:
+        b_pred, b_pos = ro.rollout(sim, pos, hist, ntype, ei, actions, 5, 6, graph=False)
+    finally:
+        ro.FUSED_STEP = was
+    assert torch.isfinite(a_pred).all()
+    assert rel_err(a_pred.cpu().numpy(), b_pred.cpu().numpy()) < 1e-5 and rel_err(a_pos.cpu().numpy(), b_pos.cpu().numpy()) < 1e-5
+    assert torch.equal(a_pred[:, 5], actions)
