@@ -1,3 +1,4 @@
 mkdir -p gpurun_out/r06
-python -m pytest tests/test_knn_gnn_gpu.py tests/test_reference_goldens_gpu.py -q -p no:cacheprovider > gpurun_out/r06/new_16.log 2>&1; tail -30 gpurun_out/r06/new_16.log
-python bench_gnn.py --no-train > gpurun_out/r06/bench_gnn_16.json 2> gpurun_out/r06/bench_gnn_16.err; tail -2 gpurun_out/r06/bench_gnn_16.json | cut -c1-700
+bash tools/ab_libs.sh 2 cur k8x > gpurun_out/r06/ab_k8_1.txt 2>&1; cat gpurun_out/r06/ab_k8_1.txt
+python -m pytest tests/test_knn_gnn_gpu.py -q -p no:cacheprovider -k "rollout or refinement or overflow" > gpurun_out/r06/new_19.log 2>&1; tail -3 gpurun_out/r06/new_19.log
+bash tools/gnn_kernel_table.sh r06_gnnprof2 2>&1 | grep -i "rollout_decode\|rows32\|absmax" | cut -c1-150
