@@ -104,10 +104,12 @@ EXPORTS = {
     "csplat_gnn_gather_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "csplat_gnn_gather_rows_absmax": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "csplat_gnn_edge_features": (_i, [_vp, _i64, _vp, _vp, _vp]),
-    "csplat_gnn_edge_features_ordered": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "csplat_rollout_head": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_gnn_rows_chain_pack": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "csplat_gnn_rows_chain": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_gnn_edge_features_ordered": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "csplat_rollout_head": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csplat_rollout_decode": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "csplat_rollout_integrate": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "csplat_rollout_integrate": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "csplat_gnn_edge_length_refine": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double,
                                            C.c_double, _vp]),
     "csplat_dw128_workspace_bytes": (_sz, [_i64]),

@@ -895,6 +895,164 @@ __global__ __launch_bounds__(256, 2) void k_node_update_b3(int64_t N, const floa
     store_rows(v, xb);
 }
 
+// A CHAIN of 128-wide Linears on node rows with the node update's machinery (pre-packed 16-bit-piece weights streamed into registers half a
+// product ahead, one 32-row tile per workgroup), round 6 -- what the rollout step still ran as four launches of the exact-fp32
+// k_linear128_rows32 (16 us each at N = 10^4: latency-sized):
+//   MODE 0: out_a = x Wa^T, out_b = x Wb^T                 (the first processor layer's x_i / x_j products, graph_network.py:178-199)
+//   MODE 1: out_a = relu(W1 relu(W0 x + b0) + b1)          (the decoder's two hidden layers, graph_network.py:295-332)
+// image = csplat_gnn_rows_chain_pack: matrix slots 0 / 1 (MODE 0: Wa, Wb -- both contract over the rows as they lie in memory) or
+// 0 / 2 (MODE 1: W0 over the rows, W1 over what the first layer's waves left in LDS).
+template <bool F16, int MODE>
+__global__ __launch_bounds__(256, 2) void k_rows_chain(int64_t N, const float *__restrict__ x, const i32x4 *__restrict__ img,
+                                                       const float *__restrict__ b0, const float *__restrict__ b1,
+                                                       float *__restrict__ out_a, float *__restrict__ out_b) {
+
+    extern __shared__ char s_mem[];
+    el16 *const sB = reinterpret_cast<el16 *>(s_mem);                                         // three tiles of three pieces
+    float2 *const sS = reinterpret_cast<float2 *>(s_mem + (size_t)3 * NB_XT * 2);             // [32][wave 4] (sum, M2)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    // F16: two fp16 pieces per operand, three products per step -- half the MFMAs of the layers' dependent chain.  fp16's range is kept by
+    // running everything multiplied by SC = 2^-4 (exact: ReLU is homogeneous, LayerNorm takes SC^2 eps, the next layer's products are
+    // multiplied back): aggregates and latents up to ~1e6 in magnitude fit, and an element below 2 of the original units keeps an absolute
+    // error of 5e-7 -- node latents and aggregates of LayerNorm'd messages are O(1 .. 100).
+    constexpr int NP = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
+    constexpr float SC = F16 ? 0.0625f : 1.f, ISC = F16 ? 16.f : 1.f;
+    auto pk = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+        if (F16) { h16x2 v; v[0] = (_Float16)lo; v[1] = (_Float16)hi; return __builtin_bit_cast(unsigned, v); }
+        bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+        return __builtin_bit_cast(unsigned, v);
+    };
+    auto lo_f = [&](unsigned q) __attribute__((always_inline)) -> float {
+        if (F16) return (float)__builtin_bit_cast(h16x2, q)[0];
+        return __uint_as_float(q << 16);
+    };
+    auto hi_f = [&](unsigned q) __attribute__((always_inline)) -> float {
+        if (F16) return (float)__builtin_bit_cast(h16x2, q)[1];
+        return __uint_as_float(q & 0xffff0000u);
+    };
+
+    // weights: the 24 A operands of a product in two halves (steps 0-3, 4-7), each requested half a product ahead
+    i32x4 wq[2][4 * NP];
+    auto fetch = [&](int mat, int half) __attribute__((always_inline)) {
+        const i32x4 *src = img + ((size_t)(mat * 4 + w) * NP * 8) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) wq[half][p * 4 + s4] = src[(size_t)(p * 8 + 4 * half + s4) * 64];
+    };
+    fetch(0, 0);
+    fetch(0, 1);
+    // ---- the tile's rows of x, whole rows per instruction (half-wave per row), cut into pieces -> tile 0
+    {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int64_t row = row0 + 8 * w + 2 * k + h;
+            row = row < N ? row : N - 1;
+            v[k] = *reinterpret_cast<const float4 *>(x + row * EM_N + 4 * n);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            el16 *dst = sB + (size_t)(8 * w + 2 * k + h) * EM_STRIDE + 4 * n;
+            float e[4] = {v[k].x * SC, v[k].y * SC, v[k].z * SC, v[k].w * SC};
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const unsigned q0 = pk(e[0], e[1]), q1 = pk(e[2], e[3]);
+                *reinterpret_cast<uint2 *>(dst + (size_t)p * ER_TILE_P) = make_uint2(q0, q1);
+                e[0] -= lo_f(q0); e[1] -= hi_f(q0); e[2] -= lo_f(q1); e[3] -= hi_f(q1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // one product: acc += W_mat (registers) x tile (pieces in LDS); the next weights are requested as the halves free up
+    auto product = [&](const el16 *Bt, f32x16 &acc, int next_mat) __attribute__((always_inline)) {
+        constexpr int WP[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0}, XP[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};
+        const el16 *row = Bt + (size_t)n * EM_STRIDE + 64 * h;
+        i32x4 bc[NP], bn[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) bc[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P);
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            if (st < 7) {
+#pragma unroll
+                for (int p = 0; p < NP; p++) bn[p] = *reinterpret_cast<const i32x4 *>(row + p * ER_TILE_P + 8 * (st + 1));
+            }
+#pragma unroll
+            for (int i = 0; i < NPROD; i++) {
+                if (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, wq[st >> 2][WP[i] * 4 + (st & 3)]),
+                                                                      __builtin_bit_cast(f16x8v, bc[XP[i]]), acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, wq[st >> 2][WP[i] * 4 + (st & 3)]),
+                                                                   __builtin_bit_cast(bf16x8v, bc[XP[i]]), acc, 0, 0, 0);
+            }
+            if (st == 3 && next_mat >= 0) fetch(next_mat, 0);
+#pragma unroll
+            for (int p = 0; p < NP; p++) bc[p] = bn[p];
+        }
+        if (next_mat >= 0) fetch(next_mat, 1);
+    };
+    auto start_from = [&](const float *b, f32x16 &acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 t = b ? *reinterpret_cast<const float4 *>(b + 32 * w + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[4 * q] = t.x * SC; acc[4 * q + 1] = t.y * SC; acc[4 * q + 2] = t.z * SC; acc[4 * q + 3] = t.w * SC;
+        }
+    };
+    // 16 values of row n -> the next product's pieces, positions 32w + 16h .. + 15
+    auto to_pieces = [&](const float (&v)[16], el16 *Bt, float scale) __attribute__((always_inline)) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) e[r] = F16 ? v[r] * scale : v[r];
+        el16 *dst = Bt + (size_t)n * EM_STRIDE + 32 * w + 16 * h;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            unsigned q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { q[j] = pk(e[2 * j], e[2 * j + 1]); e[2 * j] -= lo_f(q[j]); e[2 * j + 1] -= hi_f(q[j]); }
+            *reinterpret_cast<uint4 *>(dst + (size_t)p * ER_TILE_P) = make_uint4(q[0], q[1], q[2], q[3]);
+            *reinterpret_cast<uint4 *>(dst + (size_t)p * ER_TILE_P + 8) = make_uint4(q[4], q[5], q[6], q[7]);
+        }
+    };
+    const int64_t grow = row0 + n;
+    auto store_rows = [&](const float (&v)[16], float *dst) __attribute__((always_inline)) {
+        if (grow < N) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<float4 *>(dst + grow * EM_N + 32 * w + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+    };
+    el16 *const B0 = sB, *const B1 = sB + NB_XT, *const B2 = sB + 2 * NB_XT;
+    f32x16 acc;
+    float v[16];
+    if (MODE == 0) {
+        start_from(nullptr, acc);
+        product(B0, acc, 1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = acc[r] * ISC;
+        store_rows(v, out_a);
+        start_from(nullptr, acc);
+        product(B0, acc, -1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = acc[r] * ISC;
+        store_rows(v, out_b);
+    } else {
+        start_from(b0, acc);
+        product(B0, acc, 2);
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = relu_nan(acc[r]);
+        to_pieces(v, B1, 1.f);
+        __syncthreads();
+        start_from(b1, acc);
+        product(B1, acc, -1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = relu_nan(acc[r]) * ISC;
+        store_rows(v, out_a);
+    }
+    (void)B2; (void)sS;
+}
+
 }  // namespace
 
 // 0: two fp16 pieces (default), 1: three bf16 pieces (header).  The image is laid out for the mode it is packed under; callers re-pack when
@@ -1054,5 +1212,47 @@ extern "C" int csplat_gnn_mlp3_rows(void *stream, int64_t M, const float *x, int
                                                                                                csplat_stamp_buffer((size_t)256 * 64));
         LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ---- csplat_gnn_rows_chain: k_rows_chain (above).  mode 0: out_a = x Wa^T, out_b = x Wb^T; mode 1: out_a = relu(W1 relu(W0 x + b0) + b1).
+// The image (csplat_gnn_node_update_image_bytes bytes) is packed under the current csplat_gnn_edge_mlp3_mode and must be used under it.
+extern "C" int csplat_gnn_rows_chain_pack(void *stream, int mode, const float *Wfirst, const float *Wsecond, void *image) {
+    CSPLAT_REQUIRE((mode == 0 || mode == 1) && Wfirst && Wsecond && image && ((uintptr_t)image & 15u) == 0, "csplat_gnn_rows_chain_pack: bad arguments");
+    const float *W1 = mode == 0 ? Wsecond : nullptr, *W2 = mode == 1 ? Wsecond : nullptr;
+    if (g_em_mode == 0) k_node_pack<true><<<NB_MATS * 4 * 8, 64, 0, (hipStream_t)stream>>>(Wfirst, W1, W2, nullptr, nullptr, nullptr, (i32x4 *)image);
+    else k_node_pack<false><<<NB_MATS * 4 * 8, 64, 0, (hipStream_t)stream>>>(Wfirst, W1, W2, nullptr, nullptr, nullptr, (i32x4 *)image);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int csplat_gnn_rows_chain(void *stream, int64_t N, int mode, const float *x, const void *image, const float *b0, const float *b1,
+                                     float *out_a, float *out_b) {
+    CSPLAT_REQUIRE(N >= 0 && (mode == 0 || mode == 1) && (N == 0 || (x && image && out_a)) && (mode == 1 || out_b || N == 0),
+                   "csplat_gnn_rows_chain: bad arguments");
+    CSPLAT_REQUIRE(out_a != x && out_b != x, "csplat_gnn_rows_chain: the outputs must not alias x");
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)image | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)out_a | (uintptr_t)out_b;
+    CSPLAT_REQUIRE((al & 15u) == 0, "csplat_gnn_rows_chain: operands must be 16-byte aligned");
+    if (N == 0) return 0;
+    static int s_ok = -1;
+    if (s_ok < 0) {
+        s_ok = hipFuncSetAttribute((const void *)k_rows_chain<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_rows_chain<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_rows_chain<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        s_ok &= hipFuncSetAttribute((const void *)k_rows_chain<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NB_LDS_BYTES) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    CSPLAT_REQUIRE(s_ok, "csplat_gnn_rows_chain: 78 KB of dynamic LDS refused by the runtime");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_GNN, s);
+    const unsigned grid = (unsigned)((N + 31) / 32);
+    const i32x4 *im = (const i32x4 *)image;
+    if (g_em_mode == 0) {
+        if (mode == 0) k_rows_chain<true, 0><<<grid, 256, NB_LDS_BYTES, s>>>(N, x, im, b0, b1, out_a, out_b);
+        else k_rows_chain<true, 1><<<grid, 256, NB_LDS_BYTES, s>>>(N, x, im, b0, b1, out_a, out_b);
+    } else {
+        if (mode == 0) k_rows_chain<false, 0><<<grid, 256, NB_LDS_BYTES, s>>>(N, x, im, b0, b1, out_a, out_b);
+        else k_rows_chain<false, 1><<<grid, 256, NB_LDS_BYTES, s>>>(N, x, im, b0, b1, out_a, out_b);
+    }
+    LAUNCH_CHECK();
     return 0;
 }

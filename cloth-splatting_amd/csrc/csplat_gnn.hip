@@ -54,14 +54,31 @@ __global__ __launch_bounds__(256) void k_edge_features(int64_t E, const float *_
 }
 
 // (the same features for the edges in ANOTHER order: row r of `out` = edge order[r] -- the rollout encodes its edges in destination order)
+// (absmax, or NULL: max |value| of the rows as float bits, by atomicMax -- bits of non-negative floats order as integers; the caller zeroes it)
 __global__ __launch_bounds__(256) void k_edge_features_ordered(int64_t E, const float *__restrict__ pos, const int64_t *__restrict__ ei,
-                                                                const int64_t *__restrict__ order, float4 *__restrict__ out) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= E) return;
-    const int64_t e = order[q];
-    const int64_t r = ei[e], c = ei[E + e];
-    const float dx = pos[3 * r] - pos[3 * c], dy = pos[3 * r + 1] - pos[3 * c + 1], dz = pos[3 * r + 2] - pos[3 * c + 2];
-    out[q] = make_float4(dx, dy, dz, sqrtf(dx * dx + dy * dy + dz * dz));
+                                                                const int64_t *__restrict__ order, float4 *__restrict__ out,
+                                                                unsigned *__restrict__ absmax) {
+    // (grid-stride over at most 512 workgroups, ONE atomic per workgroup: thousands of atomics on one word serialise at the memory side --
+    //  one per wave cost 58 us at E = 300k against 6 us for the features themselves)
+    __shared__ float s_m[4];
+    float m = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < E; q += (int64_t)gridDim.x * 256) {
+        const int64_t e = order[q];
+        const int64_t r = ei[e], c = ei[E + e];
+        const float dx = pos[3 * r] - pos[3 * c], dy = pos[3 * r + 1] - pos[3 * c + 1], dz = pos[3 * r + 2] - pos[3 * c + 2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        out[q] = make_float4(dx, dy, dz, len);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fmaxf(fabsf(dz), len)));
+    }
+    if (absmax) {
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+            if (m > 0.f) atomicMax(absmax, __float_as_uint(m));
+        }
+    }
 }
 
 // ---- the rollout step's head and tail (round 6: no stock launch is left in a recorded rollout step).  Reference: the feature assembly of
@@ -71,23 +88,39 @@ __global__ __launch_bounds__(256) void k_edge_features_ordered(int64_t E, const 
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void k_rollout_head(int N, int H, int T, const float *__restrict__ hist, const int *__restrict__ node_type,
                                                        const float *__restrict__ mean, const float *__restrict__ stdv,
-                                                       float *__restrict__ feats, int *__restrict__ counter) {
+                                                       float *__restrict__ feats, int *__restrict__ counter, unsigned *__restrict__ absmax) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n == 0 && counter) *counter += 1;            // (the step's number + 1: k_rollout_integrate reads it behind this launch)
-    if (n >= N) return;
-    const int F = 3 * H + T;
-    float *o = feats + (size_t)n * F;
-    for (int h = 0; h < H; h++)
-        for (int c = 0; c < 3; c++) {
-            const int j = 3 * h + c;
-            const float x = hist[((size_t)h * N + n) * 3 + c];
-            o[j] = mean ? (x - mean[j]) / stdv[j] : x;
+    float m = 0.f;
+    if (n < N) {
+        const int F = 3 * H + T;
+        float *o = feats + (size_t)n * F;
+        for (int h = 0; h < H; h++)
+            for (int c = 0; c < 3; c++) {
+                const int j = 3 * h + c;
+                const float x = hist[((size_t)h * N + n) * 3 + c];
+                const float y = mean ? (x - mean[j]) / stdv[j] : x;
+                o[j] = y;
+                m = fmaxf(m, fabsf(y));
+            }
+        const int ty = node_type[n];
+        for (int t = 0; t < T; t++) {
+            const int j = 3 * H + t;
+            const float x = ty == t ? 1.f : 0.f;
+            const float y = mean ? (x - mean[j]) / stdv[j] : x;
+            o[j] = y;
+            m = fmaxf(m, fabsf(y));
         }
-    const int ty = node_type[n];
-    for (int t = 0; t < T; t++) {
-        const int j = 3 * H + t;
-        const float x = ty == t ? 1.f : 0.f;
-        o[j] = mean ? (x - mean[j]) / stdv[j] : x;
+    }
+    if (absmax) {       // (max |feature| as float bits: what the encoder's fp16 pieces are scaled by; zeroed by k_rollout_integrate / the caller)
+        __shared__ float s_m[4];
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+            if (m > 0.f) atomicMax(absmax, __float_as_uint(m));
+        }
     }
 }
 // decoder's last Linear (128 -> D <= 4) + de-normalisation + v_next = last velocity + acceleration; *fine is cleared by a non-finite row.
@@ -123,8 +156,9 @@ __global__ __launch_bounds__(256) void k_rollout_decode(int N, int D, const floa
 // pin the grasped node to the step's action, leave the step's row of the predictions, integrate, shift the velocity history
 __global__ __launch_bounds__(256) void k_rollout_integrate(int N, int H, int D, float *__restrict__ v, const float *__restrict__ actions,
                                                             const int *__restrict__ counter, long long grasped, float *__restrict__ pos,
-                                                            float *__restrict__ hist, float *__restrict__ preds) {
+                                                            float *__restrict__ hist, float *__restrict__ preds, unsigned *__restrict__ absmax2) {
     const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n == 0 && absmax2) { absmax2[0] = 0u; absmax2[1] = 0u; }      // (the step's two absmax words, consumed by its encoders: zero for the next step)
     if (n >= N) return;
     const int k = *counter - 1;
     for (int d = 0; d < D; d++) {
@@ -295,19 +329,21 @@ int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const in
     LAUNCH_CHECK();
     return 0;
 }
-int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, const int64_t *edge_index, const int64_t *order, float *out) {
+int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, const int64_t *edge_index, const int64_t *order, float *out,
+                                     float *absmax) {
     CSPLAT_REQUIRE(E >= 0 && (E == 0 || (pos && edge_index && order && out)), "csplat_gnn_edge_features_ordered: bad arguments");
     CSPLAT_REQUIRE(((uintptr_t)out & 15u) == 0, "csplat_gnn_edge_features_ordered: out must be 16-byte aligned");
     if (E == 0) return 0;
-    k_edge_features_ordered<<<cdiv(E, 256), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, order, (float4 *)out);
+    const int64_t nb = cdiv(E, 256);
+    k_edge_features_ordered<<<(int)(nb < 512 ? nb : 512), 256, 0, (hipStream_t)stream>>>(E, pos, edge_index, order, (float4 *)out, (unsigned *)absmax);
     LAUNCH_CHECK();
     return 0;
 }
 int csplat_rollout_head(void *stream, int N, int H, int T, const float *hist, const int32_t *node_type, const float *mean, const float *stdv,
-                        float *feats, int32_t *counter) {
+                        float *feats, int32_t *counter, float *absmax) {
     CSPLAT_REQUIRE(N >= 0 && H >= 1 && H <= 16 && T >= 0 && T <= 16 && (N == 0 || (hist && node_type && feats)) && ((mean == nullptr) == (stdv == nullptr)),
                    "csplat_rollout_head: bad arguments");
-    k_rollout_head<<<cdiv(N > 0 ? N : 1, 256), 256, 0, (hipStream_t)stream>>>(N, H, T, hist, node_type, mean, stdv, feats, counter);
+    k_rollout_head<<<cdiv(N > 0 ? N : 1, 256), 256, 0, (hipStream_t)stream>>>(N, H, T, hist, node_type, mean, stdv, feats, counter, (unsigned *)absmax);
     LAUNCH_CHECK();
     return 0;
 }
@@ -322,10 +358,10 @@ int csplat_rollout_decode(void *stream, int N, int D, const float *h, const floa
     return 0;
 }
 int csplat_rollout_integrate(void *stream, int N, int H, int D, float *v, const float *actions, const int32_t *counter, int64_t grasped,
-                             float *pos, float *hist, float *preds) {
+                             float *pos, float *hist, float *preds, float *absmax2) {
     CSPLAT_REQUIRE(N >= 0 && H >= 1 && D >= 1 && D <= 4 && (N == 0 || (v && actions && counter && pos && hist && preds)), "csplat_rollout_integrate: bad arguments");
     if (N == 0) return 0;
-    k_rollout_integrate<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, H, D, v, actions, counter, (long long)grasped, pos, hist, preds);
+    k_rollout_integrate<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(N, H, D, v, actions, counter, (long long)grasped, pos, hist, preds, (unsigned *)absmax2);
     LAUNCH_CHECK();
     return 0;
 }

@@ -106,7 +106,7 @@ def _fused_tail(seq: nn.Sequential, h: torch.Tensor, add_post: torch.Tensor = No
     return h
 
 
-def _encode_inference(seq: nn.Sequential, x: torch.Tensor):
+def _encode_inference(seq: nn.Sequential, x: torch.Tensor, x_absmax=None):
     """[build_mlp(K -> 128 -> ... -> 128), LayerNorm(128)] of an encoder under no_grad, or None when the shapes are not these"""
     lins = list(seq[0].children())[0::2]
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[1] <= 32 and len(lins) >= 2 and _fusable(seq)
@@ -122,7 +122,7 @@ def _encode_inference(seq: nn.Sequential, x: torch.Tensor):
                 w0[:, :x.shape[1]] = lins[0].weight
                 seq._mlp3_img = edge_mlp3_pack(w0, lins[1].weight, lins[2].weight)
             seq._mlp3_key = key
-        return mlp3_rows(x, seq._mlp3_img, lins[0].bias, lins[1].bias, lins[2].bias, seq[1])
+        return mlp3_rows(x, seq._mlp3_img, lins[0].bias, lins[1].bias, lins[2].bias, seq[1], x_absmax=x_absmax)
     h = linear_narrow128(x, lins[0].weight, lins[0].bias, relu=True)
     return _fused_tail(seq, h)
 
@@ -338,7 +338,8 @@ class Processor(nn.Module):
             edge_features.shape[0] // 8 + x.shape[0] + 8 < (1 << 22) and \
             all(len(list(g.edge_fn[0].children())[0::2]) == 3 for g in self.gnn_stacks)
 
-    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor, edges_out: bool = True, dst_order=None):
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_features: torch.Tensor, edges_out: bool = True, dst_order=None,
+                first_products=None):
         """edges_out=False (EncodeProcessDecode, which drops them): the rollout path returns None for the edge latents instead of spending
         a pass over [E,128] on 2^M * e0.  dst_order=(plan, bound): edge_features ALREADY are in the destination order of `plan`
         (GraphCSR.agg_plan of this edge_index) and `bound` is a device scalar >= max |edge_features| (only when takes_destination_order())"""
@@ -346,6 +347,8 @@ class Processor(nn.Module):
             assert self.takes_destination_order(x, edge_features) and not edges_out
             plan, amax = dst_order
             e0_run, scale, xa, xb = edge_features.contiguous(), 1.0, None, None
+            if first_products is not None:      # (the first layer's x_i / x_j products, already formed: meshnet.rollout's csplat_gnn_rows_chain)
+                xa, xb = first_products
             for l, gnn in enumerate(self.gnn_stacks):
                 nxt = self.gnn_stacks[l + 1] if l + 1 < len(self.gnn_stacks) else None
                 x, xa, xb = gnn.forward_inference(x, edge_index, e0_run, scale, xa, xb, nxt, e0_absmax=amax, plan=plan)

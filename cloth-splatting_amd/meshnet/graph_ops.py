@@ -557,6 +557,32 @@ def node_update_pack(w_agg, w_x, w2, w3, w_i_next=None, w_j_next=None):
     return img
 
 
+def rows_chain_pack(mode, w_first, w_second):
+    """the register image of csplat_gnn_rows_chain (mode 0: the pair (Wa, Wb); mode 1: the two layers (W0, W1)); pack once per weight version,
+    under the edge_mlp3_mode it will be used with"""
+    img = torch.empty(int(_n.lib.csplat_gnn_node_update_image_bytes()), dtype=torch.uint8, device=w_first.device)
+    a, b = w_first.detach().contiguous(), w_second.detach().contiguous()
+    assert tuple(a.shape) == (128, 128) and tuple(b.shape) == (128, 128) and a.dtype == torch.float32 and a.is_cuda
+    with _n.on_device(a.device):
+        _n.check(_n.lib.csplat_gnn_rows_chain_pack(_n.stream_handle(a.device), int(mode), _n.ptr(a), _n.ptr(b), _n.ptr(img)), "csplat_gnn_rows_chain_pack")
+    return img
+
+
+def rows_chain(x, image, mode, b0=None, b1=None):
+    """csplat_gnn_rows_chain (include/csplat.h), no autograd: mode 0 -> (x Wa^T, x Wb^T); mode 1 -> relu(W1 relu(W0 x + b0) + b1)"""
+    _n.require_cuda(x)
+    x = _f32(x)
+    N = x.shape[0]
+    assert x.shape[1] == 128
+    out_a = torch.empty_like(x)
+    out_b = torch.empty_like(x) if mode == 0 else None
+    c = lambda t: None if t is None else t.detach().contiguous()  # noqa: E731
+    with _n.on_device(x.device):
+        _n.check(_n.lib.csplat_gnn_rows_chain(_n.stream_handle(x.device), N, int(mode), _n.ptr(x), _n.ptr(image), _n.ptr(c(b0)), _n.ptr(c(b1)),
+                                              _n.ptr(out_a), _n.ptr(out_b)), "csplat_gnn_rows_chain")
+    return (out_a, out_b) if mode == 0 else out_a
+
+
 def node_update_packed(agg, x, image, b0, b2, b3, layer_norm, has_next, piece_ptr=None):
     """node_update() on the pre-packed weights (csplat_gnn_node_update_packed, include/csplat.h): returns (x_new, xa', xb').  piece_ptr
     (int32 [N + 1]): `agg` is the pieces array of edge_mlp3's fused aggregation, a node's aggregate = the sum of its pieces"""

@@ -157,6 +157,7 @@ class _FusedClothStep:
         self.nt = node_type.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fine = torch.ones(1, dtype=torch.int32, device=dev)
+        self.am = torch.zeros(2, **f32)             # max |node feature|, max |edge feature| of the step (float bits by atomicMax)
         self.norm = {k: torch.empty(n_, **f32) for k, n_ in (("nm", self.F), ("ns", self.F), ("om", 3), ("os", 3))}
         self.has_node_norm = self.has_out_norm = False
         self.csr = GraphCSR.get(edge_index, self.N)
@@ -167,13 +168,14 @@ class _FusedClothStep:
             self.edge_w = torch.ones(self.E, **f32)
             self.edge_w[self.grasped] = 0.0          # (`length_deviation[grasped_particle] *= 0`, train_meshnet_sim.py:234)
         self.graph = None
+        self.chain = None
 
     def begin(self, positions, velocity_history, actions, original_edge_lengths):
         """the state of a new rollout -> the buffers (stock copies, once per rollout); the normalisers' statistics as plain vectors"""
         from .model_utils import Normalizer
         self.pos.copy_(positions); self.hist.copy_(velocity_history)
         self.actions[:actions.shape[0]].copy_(actions)
-        self.counter.zero_(); self.fine.fill_(1)
+        self.counter.zero_(); self.fine.fill_(1); self.am.zero_()
         if self.L0 is not None:
             self.L0.copy_(original_edge_lengths)
         nn_, on_ = self.sim._node_normalizer, self.sim._output_normalizer
@@ -184,7 +186,8 @@ class _FusedClothStep:
             self.norm["om"].copy_(on_._mean().reshape(-1)); self.norm["os"].copy_(on_._std_with_epsilon().reshape(-1))
 
     def step(self):
-        from .graph_ops import linear128
+        from .graph_network import _encode_inference
+        from .graph_ops import rows_chain, rows_chain_pack
         dev = self.pos.device
         st = _n.stream_handle(dev)
         epd, N, H, T = self.epd, self.N, self.H, self.T
@@ -192,14 +195,23 @@ class _FusedClothStep:
         om, os_ = (self.norm["om"], self.norm["os"]) if self.has_out_norm else (None, None)
         with _n.on_device(dev):
             _n.check(_n.lib.csplat_rollout_head(st, N, H, T, _n.ptr(self.hist), _n.ptr(self.nt), _n.ptr(nm), _n.ptr(ns), _n.ptr(self.feats),
-                                                _n.ptr(self.counter)), "csplat_rollout_head")
+                                                _n.ptr(self.counter), self.am.data_ptr()), "csplat_rollout_head")
             _n.check(_n.lib.csplat_gnn_edge_features_ordered(st, self.E, _n.ptr(self.pos), _n.ptr(self.csr.ei), _n.ptr(self.plan["perm"]),
-                                                             _n.ptr(self.ef)), "csplat_gnn_edge_features_ordered")
-        xe, ee = epd._encoder(self.feats, self.ef)
-        xp, _e = epd._processor(xe, self.edge_index, ee, edges_out=False, dst_order=(self.plan, epd._edge_latent_bound()))
+                                                             _n.ptr(self.ef), self.am.data_ptr() + 4), "csplat_gnn_edge_features_ordered")
+        # the encoders (one launch each) with the absmax words the two launches above left: no absmax pass of their own
+        xe = _encode_inference(epd._encoder.node_fn, self.feats, self.am[0:1])
+        ee = _encode_inference(epd._encoder.edge_fn, self.ef, self.am[1:2])
+        if xe is None or ee is None:         # (an encoder the one-launch form does not cover: the module's own path)
+            xe, ee = epd._encoder(self.feats, self.ef)
         dec = list(epd._decoder.node_fn.children())[0::2]
-        h = linear128(xp, dec[0].weight, dec[0].bias, relu=True)
-        h = linear128(h, dec[1].weight, dec[1].bias, relu=True, out=h)
+        if self.chain is None:          # (packed once per object: the object is keyed on the weights' versions)
+            w_i, w_j = epd._processor.gnn_stacks[0]._split_weights()[:2]
+            self.chain = (rows_chain_pack(0, w_i, w_j), rows_chain_pack(1, dec[0].weight, dec[1].weight))
+        # the first layer's x_i / x_j products and the decoder's two hidden layers: ONE launch each on pre-packed 16-bit pieces
+        # (csplat_gnn_rows_chain) instead of four exact-fp32 launches of 16 us
+        xp, _e = epd._processor(xe, self.edge_index, ee, edges_out=False, dst_order=(self.plan, epd._edge_latent_bound()),
+                                first_products=rows_chain(xe, self.chain[0], 0))
+        h = rows_chain(xp, self.chain[1], 1, dec[0].bias, dec[1].bias)
         last = self.hist[H - 1]
         with _n.on_device(dev):
             _n.check(_n.lib.csplat_rollout_decode(st, N, 3, _n.ptr(h), _n.ptr(dec[2].weight.detach()), _n.ptr(dec[2].bias.detach().contiguous()),
@@ -208,7 +220,7 @@ class _FusedClothStep:
             refine_edge_lengths(self.pos, self.v, self.edge_index, self.L0, self.grasped, edge_w=self.edge_w, in_place=True)
         with _n.on_device(dev):
             _n.check(_n.lib.csplat_rollout_integrate(st, N, H, 3, _n.ptr(self.v), _n.ptr(self.actions), _n.ptr(self.counter), self.grasped,
-                                                     _n.ptr(self.pos), _n.ptr(self.hist), _n.ptr(self.preds)), "csplat_rollout_integrate")
+                                                     _n.ptr(self.pos), _n.ptr(self.hist), _n.ptr(self.preds), _n.ptr(self.am)), "csplat_rollout_integrate")
 
 
 def _rollout_fused(simulator, positions, velocity_history, node_type, edge_index, actions, grasped_particle, nsteps, real_world,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CSPLAT_ABI_VERSION 6   /* 6 (round 6): csplat_backward_views_parts / _slice_rows, csplat_gnn_edge_length_refine, csplat_rollout_head / _decode / _integrate, csplat_gnn_edge_features_ordered, csplat_binning_fields; round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
+#define CSPLAT_ABI_VERSION 6   /* 6 (round 6): csplat_backward_views_parts / _slice_rows, csplat_gnn_edge_length_refine, csplat_rollout_head / _decode / _integrate, csplat_gnn_edge_features_ordered, csplat_gnn_rows_chain(_pack), csplat_binning_fields; round 4: csplat_view.busy_tiles / .valid, csplat_rows_dot_fwd's extra argument; 3: the binning chunk's layout (bbits, bmask); 4 (round 5): csplat_gather_words kind 2; 5: csplat_gnn_edge_mlp3* (e0_absmax, modes), csplat_absmax, csplat_linear_narrow128 */
 
 /* scratch chunks requested through the allocator callback */
 #define CSPLAT_CHUNK_GEOM 0    /* per-Gaussian state, kept for backward */
@@ -446,9 +446,18 @@ int csplat_gnn_gather_rows_absmax(void *stream, int64_t E, int L, const float *r
  * /root/reference/train_meshnet_sim.py:152 and dataloader_sim.py): out[e] = (pos[row] - pos[col], |pos[row] - pos[col]|) with
  * row = edge_index[0][e], col = edge_index[1][e]; pos [N][3], out [E][4] (16-byte aligned). */
 int csplat_gnn_edge_features(void *stream, int64_t E, const float *pos, const int64_t *edge_index, float *out);
+/* A chain of 128-wide Linears on node rows with pre-packed 16-bit-piece weights (the node update's machinery; round 6):
+ *   mode 0: out_a = x Wa^T, out_b = x Wb^T           -- the first processor layer's x_i / x_j products (graph_network.py:178-199)
+ *   mode 1: out_a = relu(W1 relu(W0 x + b0) + b1)    -- the decoder's two hidden layers (graph_network.py:295-332); out_b unused
+ * x, out_* [N][128] fp32, 16-byte aligned, outputs not aliasing x; image = csplat_gnn_rows_chain_pack(mode, first, second) of
+ * csplat_gnn_node_update_image_bytes() bytes, packed and used under one csplat_gnn_edge_mlp3_mode. */
+int csplat_gnn_rows_chain_pack(void *stream, int mode, const float *Wfirst, const float *Wsecond, void *image);
+int csplat_gnn_rows_chain(void *stream, int64_t N, int mode, const float *x, const void *image, const float *b0, const float *b1,
+                          float *out_a, float *out_b);
 /* csplat_gnn_edge_features for the edges in another order: row r of out = the features of edge order[r] (the rollout encodes its edges in the
  * destination order of GraphCSR.agg_plan: a permuted read of the [E] index pairs instead of a gather of [E][4] rows afterwards). */
-int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, const int64_t *edge_index, const int64_t *order, float *out);
+int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, const int64_t *edge_index, const int64_t *order, float *out,
+                                     float *absmax /* or NULL: receives max |value| (as csplat_absmax: atomicMax on the bits; zeroed by the caller) */);
 /* Head and tail of ONE rollout step of ClothMeshSimulator around the network's launches (round 6: a recorded step holds library kernels only).
  *   head:      feats[n] = normalise(cat(hist[0][n], .., hist[H-1][n], one_hot(node_type[n], T)))   (/root/reference/meshnet/cloth_network.py:72-110;
  *              mean / std [3H + T] or both NULL = IdentityNormalizer); also *counter += 1 (the step's number + 1, device side)
@@ -457,11 +466,11 @@ int csplat_gnn_edge_features_ordered(void *stream, int64_t E, const float *pos, 
  *   integrate: v[grasped] = actions[*counter - 1]; preds[*counter - 1] = v; pos += v; hist <- (hist[1:], v)
  *              (/root/reference/train_meshnet_sim.py:176,256-262).  hist [H][N][D], pos / v [N][D], actions / preds [steps][..]. */
 int csplat_rollout_head(void *stream, int N, int H, int T, const float *hist, const int32_t *node_type, const float *mean, const float *stdv,
-                        float *feats, int32_t *counter);
+                        float *feats, int32_t *counter, float *absmax /* or NULL: max |feature|, as csplat_absmax */);
 int csplat_rollout_decode(void *stream, int N, int D, const float *h, const float *W, const float *b, const float *omean, const float *ostd,
                           const float *last_v, float *v, int32_t *fine);
 int csplat_rollout_integrate(void *stream, int N, int H, int D, float *v, const float *actions, const int32_t *counter, int64_t grasped,
-                             float *pos, float *hist, float *preds);
+                             float *pos, float *hist, float *preds, float *absmax2 /* or NULL: two words set to zero for the next step's head / edge features */);
 /* The `real_world` branch of the rollout (/root/reference/train_meshnet_sim.py:211-250: per rollout step, ten iterations of a fresh
  * torch.optim.Adam(lr = 1e-3) on the predicted velocities against sum_e w_e (|(pos + v)[row_e] - (pos + v)[col_e]| - rest_len_e)^2).
  * v [N][3] is updated in place; edge_w [E] or NULL (the reference zeroes ONE deviation: `length_deviation[grasped_particle] *= 0`);

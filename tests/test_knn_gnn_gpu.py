@@ -1305,3 +1305,30 @@ def test_fused_rollout_step_equals_the_module_path(normalize):
     assert torch.isfinite(a_pred).all()
     assert rel_err(a_pred.cpu().numpy(), b_pred.cpu().numpy()) < 1e-5 and rel_err(a_pos.cpu().numpy(), b_pos.cpu().numpy()) < 1e-5
     assert torch.equal(a_pred[:, 5], actions)
+
+
+@pytest.mark.parametrize("em_mode", [0, 1])
+@pytest.mark.parametrize("N", [1, 31, 1000, 10_007])
+def test_rows_chain_matches_fp64(N, em_mode):
+    """csplat_gnn_rows_chain (round 6: the first processor layer's x_i / x_j products and the decoder's two hidden layers on pre-packed
+    16-bit pieces, one launch each): both modes against the fp64 composition, 1e-5 of each output's scale, node latents of O(1) and of
+    O(100); rows past a multiple of 32; both arithmetic modes (two fp16 pieces / three bf16 pieces).  Reference: graph_network.py:178-199,
+    :295-332."""
+    from meshnet.graph_ops import edge_mlp3_mode, rows_chain, rows_chain_pack
+    gen = torch.Generator().manual_seed(100 + N)
+    was = edge_mlp3_mode(em_mode)
+    try:
+        for scale in (1.0, 100.0):
+            x = (torch.randn(N, 128, generator=gen) * scale).cuda()
+            W = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(2)]
+            b = [(torch.randn(128, generator=gen) * 0.3).cuda() for _ in range(2)]
+            with torch.no_grad():
+                a, c = rows_chain(x, rows_chain_pack(0, W[0], W[1]), 0)
+                h = rows_chain(x, rows_chain_pack(1, W[0], W[1]), 1, b[0], b[1])
+            xd = x.double()
+            ra, rc = xd @ W[0].double().t(), xd @ W[1].double().t()
+            rh = ((xd @ W[0].double().t() + b[0].double()).relu() @ W[1].double().t() + b[1].double()).relu()
+            for got, ref in ((a, ra), (c, rc), (h, rh)):
+                assert got.shape == ref.shape and rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    finally:
+        edge_mlp3_mode(was)
