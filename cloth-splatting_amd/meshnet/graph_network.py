@@ -20,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, mlp3_rows, node_update_pack, node_update_packed, segment_sum_rows, edge_tail_ok, linear_narrow128,
+from .graph_ops import (EdgeCombine, EdgeFirstLayer, GraphCSR, SegmentSum, absmax, rows_chain, rows_chain_pack, edge_latent_linear, edge_mlp3, edge_mlp3_mode, edge_mlp3_pack, edge_tail_aggregate, gather_rows, mlp3_rows, node_update_pack, node_update_packed, segment_sum_rows, edge_tail_ok, linear_narrow128,
                         layer_norm_rows, report_missed_edge_tail, linear128, linear_rows, node_update)
 
 
@@ -277,7 +277,16 @@ class InteractionNetwork(nn.Module):
         Linear.  Returns (x_new, xa_next, xb_next); xa / xb for this layer are computed here when not handed in."""
         csr = GraphCSR.get(edge_index, x.shape[0])
         w_i, w_j, w_e, w_agg, w_x = self._split_weights()
-        if xa is None:
+        if xa is None and NODE_UPDATE_PACKED and x.shape[0] > 0:
+            # both node-level products of the first layer in ONE launch on pre-packed 16-bit pieces (csplat_gnn_rows_chain, round 6: 8 us
+            # against two exact-fp32 launches of 16 us at N = 10^4); later layers get theirs from the previous layer's node update
+            key = (self._wsplit_key, edge_mlp3_mode())
+            if getattr(self, "_pair_key", None) != key:
+                with torch.no_grad():
+                    self._pair_img = rows_chain_pack(0, w_i, w_j)
+                self._pair_key = key
+            xa, xb = rows_chain(x, self._pair_img, 0)
+        elif xa is None:
             xa = linear128(x, w_i)                               # contribution of x_i = x[edge_index[1]]
             xb = linear128(x, w_j)                               # contribution of x_j = x[edge_index[0]]
         elins = list(self.edge_fn[0].children())[0::2]
@@ -392,6 +401,22 @@ class Decoder(nn.Module):
         self.node_fn = build_mlp(nnode_in, [mlp_hidden_dim for _ in range(nmlp_layers)], nnode_out)
 
     def forward(self, x: torch.Tensor):
+        lins = list(self.node_fn.children())[0::2]
+        acts = list(self.node_fn.children())[1::2]
+        if (not torch.is_grad_enabled()) and NODE_UPDATE_PACKED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and \
+                x.shape[0] > 0 and x.shape[1] == 128 and len(lins) == 3 and tuple(lins[0].weight.shape) == (128, 128) and \
+                tuple(lins[1].weight.shape) == (128, 128) and lins[2].in_features == 128 and \
+                isinstance(acts[0], nn.ReLU) and isinstance(acts[1], nn.ReLU) and isinstance(acts[2], nn.Identity) and \
+                lins[0].weight.dtype == torch.float32:
+            # rollout: the two hidden layers in ONE launch on pre-packed 16-bit pieces (csplat_gnn_rows_chain, round 6) instead of two
+            # library GEMMs + two ReLU launches; the narrow last Linear stays the library's
+            key = tuple((l.weight._version, l.weight.data_ptr()) for l in lins[:2]) + (edge_mlp3_mode(),)
+            if getattr(self, "_chain_key", None) != key:
+                with torch.no_grad():
+                    self._chain_img = rows_chain_pack(1, lins[0].weight, lins[1].weight)
+                self._chain_key = key
+            h = rows_chain(x, self._chain_img, 1, lins[0].bias, lins[1].bias)
+            return torch.nn.functional.linear(h, lins[2].weight, lins[2].bias)
         return self.node_fn(x)
 
 
