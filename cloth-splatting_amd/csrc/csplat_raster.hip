@@ -10,7 +10,7 @@
 //   K5 k_tile_ranges       [first,last) per tile; k_seg_plan (256-entry segments of every tile list);
 //      k_block_masks       per list entry: which of the tile's sixteen 4x4 pixel blocks it can reach + tile-ordered records
 //   K6 k_composite_fwd     front-to-back compositing of RGB + depth: one wavefront per 4x4 block, four survivors per step
-//   K7 k_composite_bwd     per (segment, quadrant) workgroup, forward-ordered replay from the checkpoints, row butterfly
+//   K7 k_composite_bwd     per (segment, quadrant) workgroup, forward-ordered replay from the checkpoints, factored moment reduction
 //                          reduction, LDS records, one atomic per (entry, quadrant)
 //   K8 k_preprocess_bwd    conic->cov2D->cov3D/mean, mean2D(NDC)->mean3D, colour->SH, cov3D->(scale,quat)
 //
@@ -1041,10 +1041,11 @@ __global__ __launch_bounds__(1024) void k_seg_plan_views(int tiles, P2Table tab)
 //     forward's checkpoint) the upstream back-to-front recurrence collapses to
 //         dL/dalpha_k = T_k (c_k . dL/dC) - (out_colour . dL/dC - S_k) / (1 - alpha_k),
 //     the same identity the depth-split restart already used once per segment;
-//   * the nine per-pixel partials of a survivor are summed over its 16-lane row by a 4-level butterfly (the first two levels bank-masked
-//     DPP adds, 18 DPP adds + 2 selects per survivor row) and go, nine lanes at once, to the Gaussian's 64-byte record as ONE global
-//     float-atomic request per (entry, block) (requests are priced per 64 bytes at the memory side, MI355X_MICROARCH.md "Global
-//     float atomics"; rounds 1-3 joined a workgroup's blocks in an LDS record first -- see composite_bwd_body).
+//   * what a survivor's 16-lane row sums over its pixels are the MOMENTS of m = G dL/dalpha about the Gaussian's centre + three colour
+//     sums (round 6; rounds 2-5: the nine gradient values, by a 4-level butterfly): they factor over the 4 x 4 block, 19 DPP adds + 3
+//     selects per survivor row (processN), and go, nine lanes at once, to the Gaussian's 64-byte record as ONE global float-atomic
+//     request per (entry, block) -- requests are priced per 64 bytes at the memory side (MI355X_MICROARCH.md "Global float atomics"),
+//     and their rate is what binds the kernel (profiles/r06_k7_elimination.txt); K8 turns the moments into gradients.
 constexpr float T_EPS = 0.0001f;
 constexpr float ALPHA_MIN = 1.f / 255.f;
 
@@ -1738,19 +1739,6 @@ __device__ __forceinline__ void rows_scan_add(float g, float Sin, float &Sr, flo
     Sr = base + incl;
     Sout = (Sin + lo) + hi;
 }
-// the first two butterfly levels keep / send by 4-lane BANKS (lane bits 3 and 2): two bank-masked DPP adds -- lanes of the keep-a banks
-// form a + partner's a, lanes of the keep-b banks b + partner's b -- instead of two selects and a DPP add (bit-identical)
-#define CSPLAT_BFLY_BANK(dst, a, b, CTRL, MA, MB)                                                                                   \
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" MA "\n\t"                                            \
-        "v_add_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:" MB : "=&v"(dst) : "v"(a), "v"(b))
-// one level of a butterfly "transpose-reduce": lanes with s == 0 keep a (own + partner's), lanes with s == 1 keep b;
-// the partner permutation CTRL must flip s.  Two values are folded by one DPP add instead of two.
-template <int CTRL>
-__device__ __forceinline__ float bfly(float a, float b, bool s) {
-    const float send = s ? a : b, keep = s ? b : a;
-    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
-}
-
 // grid: one 4-wave workgroup per (segment slot, group of four live blocks); wave w = one 4x4 block.  The four waves of a workgroup
 // share nothing but the launch geometry: no LDS records, no barrier.
 // Round 4, first step: a wave's survivors are the entries of the segment its block BLENDED (bbits, written by K6 -- see bbits_flush), not
